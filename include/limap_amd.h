@@ -1,0 +1,163 @@
+/*
+ * limap_amd.h -- C ABI of the MI355X-native line-triangulation backend (liblimap_amd.so).
+ *
+ * Drop-in boundary for the hot path of cvg/limap's `limap.triangulation.GlobalLineTriangulator`
+ * (reference pybind surface: src/limap/triangulation/bindings.cc:19-32,78-119; only production
+ * caller: src/limap/runners/line_triangulation.py:102-168).  Plain pointers and sizes, no
+ * exceptions across the boundary: every call returns 0 on success or a negative code, and
+ * lt_last_error(ctx) holds the message the reference would have thrown.  One context per thread.
+ *
+ * All arithmetic is FP64 like the reference.  Image ids are arbitrary int32 values; internally
+ * images are ordered by ascending id (the reference iterates std::map<int, ...>).  A "node" is an
+ * (image, line) pair; global node index = seg_off[image index] + line id.
+ */
+#ifndef LIMAP_AMD_H
+#define LIMAP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_OK 0
+#define LT_ERR_RUNTIME (-1)  /* std::runtime_error in the reference (bad matches, bad strategy) */
+#define LT_ERR_ARGUMENT (-2) /* THROW_CHECK / std::out_of_range in the reference */
+#define LT_ERR_HIP (-3)      /* HIP runtime failure */
+#define LT_ERR_STATE (-4)    /* call-order violation (e.g. triangulate before init) */
+
+/* Replaces GlobalLineTriangulatorConfig(py::dict) = BaseLineTriangulatorConfig
+ * (triangulation/base_line_triangulator.h:20-43, .cc:16-31) + GlobalLineTriangulatorConfig
+ * (triangulation/global_line_triangulator.h:11-24, .cc:18-29) + LineLinker2dConfig /
+ * LineLinker3dConfig (base/line_linker.h:18-52,88-151, .cc:21-34,164-179), field for field.
+ * lt_config_default() fills the reference's C++ defaults. */
+typedef struct lt_config {
+  int32_t debug_mode;
+  int32_t add_halfpix;
+  int32_t use_vp;                            /* optional VP proposals: not implemented, must be 0 */
+  int32_t use_endpoints_triangulation;
+  int32_t disable_many_points_triangulation; /* point proposals need SetBipartites2d: n/a */
+  int32_t disable_one_point_triangulation;
+  int32_t disable_algebraic_triangulation;
+  int32_t disable_vp_triangulation;
+  double min_length_2d;
+  double line_tri_angle_threshold;
+  double IoU_threshold;
+  double sensitivity_threshold;
+  double var2d;
+  double fullscore_th;
+  int32_t max_valid_conns;
+  int32_t min_num_outer_edges;
+  int32_t merging_strategy; /* 0 = "greedy"; others -> LT_ERR_RUNTIME like the reference's throw */
+  int32_t num_outliers_aggregator;
+  double l2_score_th, l2_th_angle, l2_th_overlap, l2_th_smartoverlap, l2_th_smartangle,
+      l2_th_perp, l2_th_innerseg;
+  int32_t l2_use_angle, l2_use_overlap, l2_use_smartangle, l2_use_perp, l2_use_innerseg;
+  int32_t _pad0;
+  double l3_score_th, l3_th_angle, l3_th_overlap, l3_th_smartoverlap, l3_th_smartangle,
+      l3_th_perp, l3_th_innerseg, l3_th_scaleinv;
+  int32_t l3_use_angle, l3_use_overlap, l3_use_smartangle, l3_use_perp, l3_use_innerseg,
+      l3_use_scaleinv;
+} lt_config;
+
+typedef struct lt_ctx lt_ctx;
+
+void lt_config_default(lt_config *cfg);
+
+/* GlobalLineTriangulator(cfg) -- bindings.cc:79-80,99.  device = HIP device ordinal.
+ * Returns NULL (and writes a message to stderr) if no usable GPU / HIP runtime is present:
+ * there is NO CPU fallback. */
+lt_ctx *lt_create(const lt_config *cfg, int device);
+void lt_destroy(lt_ctx *ctx);
+const char *lt_last_error(lt_ctx *ctx);
+/* run the kernels on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream */
+int lt_set_stream(lt_ctx *ctx, void *hip_stream);
+
+/* SetRanges / UnsetRanges -- base_line_triangulator.h:61-65, bindings.cc:94-95 */
+int lt_set_ranges(lt_ctx *ctx, const double lo[3], const double hi[3]);
+int lt_unset_ranges(lt_ctx *ctx);
+
+/* Init(all_2d_segs, imagecols) -- base_line_triangulator.cc:45-63, global_line_triangulator.cc:31-57.
+ * kvec = (fx,fy,cx,cy) of the undistorted pinhole camera, qvec = (w,x,y,z), tvec; seg_off[n_img+1]
+ * offsets into segs[.][4] = (x1,y1,x2,y2).  Host pointers; data is snapshotted (the reference
+ * keeps a raw pointer to the caller's ImageCollection -- base_line_triangulator.cc:50). */
+int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, const double *qvec,
+            const double *tvec, const int64_t *seg_off, const double *segs);
+/* Same with kvec/qvec/tvec/segs already resident in HBM (e.g. the output of the RCCL all-gather),
+ * images given in ascending id order. */
+int lt_init_device(lt_ctx *ctx, int n_img, const int32_t *img_ids, const void *d_kvec,
+                   const void *d_qvec, const void *d_tvec, const int64_t *seg_off,
+                   const void *d_segs);
+
+/* TriangulateImage(img_id, matches) -- base_line_triangulator.cc:71-109, bindings.cc:83.
+ * Rows m_off[k]..m_off[k+1] of m_pairs[.][2] = (line_id, ng_line_id) belong to neighbour
+ * nb_ids[k].  Calls are buffered; the GPU runs at the next lt_flush / lt_compute_tracks / getter
+ * (observable behaviour is unchanged: results are only readable through those). */
+int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids,
+                         const int64_t *m_off, const int32_t *m_pairs);
+/* TriangulateImageExhaustiveMatch(img_id, neighbors) -- base_line_triangulator.cc:111-136 */
+int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids);
+
+/* Staged execution of the buffered images (lt_flush = upload + run + download). */
+int lt_upload(lt_ctx *ctx);     /* host staging -> HBM (matches, neighbour tables) */
+int lt_run_device(lt_ctx *ctx); /* kernels only, inputs resident in HBM; repeatable */
+int lt_download(lt_ctx *ctx);   /* per-node results -> host */
+int lt_flush(lt_ctx *ctx);
+
+/* ComputeLineTracks() -- global_line_triangulator.cc:353-359 */
+int lt_compute_tracks(lt_ctx *ctx);
+
+/* CountImages / CountLines -- base_line_triangulator.h:84-87 */
+int64_t lt_count_images(lt_ctx *ctx);
+int64_t lt_count_lines(lt_ctx *ctx, int img_id);
+int64_t lt_num_nodes(lt_ctx *ctx);
+
+/* Per-node results, node order = images ascending id x lines.
+ * line10 = start3,end3,depths2,uncertainty,line.score ; score = multi-view support score;
+ * src2 = (ng_img_id, ng_line_id) ; has_best = 0 for nodes without any candidate
+ * (GetBestScoredTriNode / GetAllBestTris -- global_line_triangulator.cc:496-541). */
+int lt_get_best(lt_ctx *ctx, double *out_line10, double *out_score, int32_t *out_src2,
+                uint8_t *out_has_best);
+int lt_get_num_tris(lt_ctx *ctx, int32_t *out_n_tris);
+/* valid_edges_ (global_line_triangulator.cc:138-142) as CSR: (neighbour index, ng_line_id) */
+int64_t lt_num_valid_edges(lt_ctx *ctx);
+int lt_get_valid_edges(lt_ctx *ctx, int64_t *out_off, int32_t *out_edges2);
+/* All scored candidates of the last device run (GetScoredTrisNode; kept regardless of
+ * debug_mode until the next run): CSR off[n_nodes+1], line10, score, src2. */
+int64_t lt_num_all_tris(lt_ctx *ctx);
+int lt_get_all_tris(lt_ctx *ctx, int64_t *out_off, double *out_line10, double *out_score,
+                    int32_t *out_src2);
+/* GetTracks() -- tracks as CSR over members (LineTrack fields, base/linetrack.h:33-42):
+ * line7 = start3,end3,uncertainty */
+int64_t lt_num_tracks(lt_ctx *ctx);
+int64_t lt_num_track_members(lt_ctx *ctx);
+int lt_get_tracks(lt_ctx *ctx, double *out_line7, int64_t *out_off, int32_t *out_img_ids,
+                  int32_t *out_line_ids, int32_t *out_node_ids, double *out_scores,
+                  double *out_line3d6);
+
+/* Counters of the last device run: [0] connections tested, [1] candidates, [2] ordered candidate
+ * pairs swept by the scoring kernel (sum n_tris^2), [3] valid edges, [4] graph nodes,
+ * [5] graph edges, [6] tracks, [7] nodes. */
+int lt_get_stats(lt_ctx *ctx, int64_t out[8]);
+/* HIP-event timings (ms) of the last lt_run_device on the context's stream:
+ * [0] whole run, [1] invariants, [2] connection sort, [3] generation, [4] compaction,
+ * [5] scoring kernel, [6] selection + edges, [7] gather; host: [8] upload, [9] download,
+ * [10] tail (lt_compute_tracks) */
+int lt_get_timers(lt_ctx *ctx, double out[16]);
+
+/* ---- free functions of limap.triangulation (bindings.cc:22-31) on raw arrays, run on the GPU
+ * one query per call (convenience / parity checks; the batch path is the API above).
+ * cam = kvec[4] | qvec[4] | tvec[3]; seg = x1,y1,x2,y2; line10 as above. */
+int lt_fn_get_normal_direction(lt_ctx *ctx, const double seg[4], const double cam[11], double out[3]);
+int lt_fn_compute_fundamental_matrix(lt_ctx *ctx, const double cam1[11], const double cam2[11],
+                                     double out[9]);
+int lt_fn_compute_epipolar_IoU(lt_ctx *ctx, const double seg1[4], const double cam1[11],
+                               const double seg2[4], const double cam2[11], double *out);
+int lt_fn_triangulate_line(lt_ctx *ctx, const double seg1[4], const double cam1[11],
+                           const double seg2[4], const double cam2[11], int by_endpoints,
+                           double out_line10[10]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIMAP_AMD_H */

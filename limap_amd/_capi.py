@@ -1,0 +1,321 @@
+"""ctypes binding of liblimap_amd.so (C ABI declared in include/limap_amd.h).
+
+The library is built in-tree by ``limap_amd.build.build_extension()`` (hipcc, gfx950).  There is
+no CPU fallback: if the shared object is missing, or no HIP device is visible, every entry point
+raises ``RuntimeError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblimap_amd.so")
+
+EXPORTED_SYMBOLS = [
+    "lt_config_default", "lt_create", "lt_destroy", "lt_last_error", "lt_set_stream", "lt_set_ranges",
+    "lt_unset_ranges", "lt_init", "lt_init_device", "lt_triangulate_image",
+    "lt_triangulate_image_exhaustive", "lt_upload", "lt_run_device", "lt_download", "lt_flush",
+    "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
+    "lt_get_num_tris", "lt_num_valid_edges", "lt_get_valid_edges", "lt_num_all_tris", "lt_get_all_tris",
+    "lt_num_tracks", "lt_num_track_members", "lt_get_tracks", "lt_get_stats", "lt_get_timers",
+    "lt_fn_get_normal_direction", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
+    "lt_fn_triangulate_line",
+]
+
+
+class LtConfig(C.Structure):
+    """lt_config of include/limap_amd.h (field for field)."""
+    _fields_ = [
+        ("debug_mode", C.c_int32), ("add_halfpix", C.c_int32), ("use_vp", C.c_int32),
+        ("use_endpoints_triangulation", C.c_int32), ("disable_many_points_triangulation", C.c_int32),
+        ("disable_one_point_triangulation", C.c_int32), ("disable_algebraic_triangulation", C.c_int32),
+        ("disable_vp_triangulation", C.c_int32),
+        ("min_length_2d", C.c_double), ("line_tri_angle_threshold", C.c_double), ("IoU_threshold", C.c_double),
+        ("sensitivity_threshold", C.c_double), ("var2d", C.c_double), ("fullscore_th", C.c_double),
+        ("max_valid_conns", C.c_int32), ("min_num_outer_edges", C.c_int32), ("merging_strategy", C.c_int32),
+        ("num_outliers_aggregator", C.c_int32),
+        ("l2_score_th", C.c_double), ("l2_th_angle", C.c_double), ("l2_th_overlap", C.c_double),
+        ("l2_th_smartoverlap", C.c_double), ("l2_th_smartangle", C.c_double), ("l2_th_perp", C.c_double),
+        ("l2_th_innerseg", C.c_double),
+        ("l2_use_angle", C.c_int32), ("l2_use_overlap", C.c_int32), ("l2_use_smartangle", C.c_int32),
+        ("l2_use_perp", C.c_int32), ("l2_use_innerseg", C.c_int32), ("_pad0", C.c_int32),
+        ("l3_score_th", C.c_double), ("l3_th_angle", C.c_double), ("l3_th_overlap", C.c_double),
+        ("l3_th_smartoverlap", C.c_double), ("l3_th_smartangle", C.c_double), ("l3_th_perp", C.c_double),
+        ("l3_th_innerseg", C.c_double), ("l3_th_scaleinv", C.c_double),
+        ("l3_use_angle", C.c_int32), ("l3_use_overlap", C.c_int32), ("l3_use_smartangle", C.c_int32),
+        ("l3_use_perp", C.c_int32), ("l3_use_innerseg", C.c_int32), ("l3_use_scaleinv", C.c_int32),
+    ]
+
+
+BASE_KEYS = [
+    "debug_mode", "add_halfpix", "use_vp", "use_endpoints_triangulation",
+    "disable_many_points_triangulation", "disable_one_point_triangulation",
+    "disable_algebraic_triangulation", "disable_vp_triangulation", "min_length_2d",
+    "line_tri_angle_threshold", "IoU_threshold", "sensitivity_threshold", "var2d",
+    "fullscore_th", "max_valid_conns", "min_num_outer_edges", "num_outliers_aggregator",
+]
+L2_KEYS = ["score_th", "th_angle", "th_overlap", "th_smartoverlap", "th_smartangle", "th_perp", "th_innerseg",
+           "use_angle", "use_overlap", "use_smartangle", "use_perp", "use_innerseg"]
+L3_KEYS = L2_KEYS[:7] + ["th_scaleinv"] + L2_KEYS[7:] + ["use_scaleinv"]
+MERGING = {"greedy": 0, "exhaustive": 1, "avg": 2}
+
+_lib = None
+
+
+def load_library():
+    """dlopen liblimap_amd.so and declare the prototypes.  Raises if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"limap_amd: HIP extension {LIB_PATH} is not built (run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C limap_amd/csrc`); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, i64p, dp, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    L.lt_config_default.argtypes = [C.POINTER(LtConfig)]
+    L.lt_config_default.restype = None
+    L.lt_create.argtypes = [C.POINTER(LtConfig), C.c_int]
+    L.lt_create.restype = vp
+    L.lt_destroy.argtypes = [vp]
+    L.lt_destroy.restype = None
+    L.lt_last_error.argtypes = [vp]
+    L.lt_last_error.restype = C.c_char_p
+    L.lt_set_stream.argtypes = [vp, vp]
+    L.lt_set_ranges.argtypes = [vp, dp, dp]
+    L.lt_unset_ranges.argtypes = [vp]
+    L.lt_init.argtypes = [vp, C.c_int, i32p, dp, dp, dp, i64p, dp]
+    L.lt_init_device.argtypes = [vp, C.c_int, i32p, vp, vp, vp, i64p, vp]
+    L.lt_triangulate_image.argtypes = [vp, C.c_int, C.c_int, i32p, i64p, i32p]
+    L.lt_triangulate_image_exhaustive.argtypes = [vp, C.c_int, C.c_int, i32p]
+    for n in ("lt_upload", "lt_run_device", "lt_download", "lt_flush", "lt_compute_tracks"):
+        getattr(L, n).argtypes = [vp]
+    for n in ("lt_count_images", "lt_num_nodes", "lt_num_valid_edges", "lt_num_all_tris", "lt_num_tracks",
+              "lt_num_track_members"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = C.c_int64
+    L.lt_count_lines.argtypes = [vp, C.c_int]
+    L.lt_count_lines.restype = C.c_int64
+    L.lt_get_best.argtypes = [vp, dp, dp, i32p, u8p]
+    L.lt_get_num_tris.argtypes = [vp, i32p]
+    L.lt_get_valid_edges.argtypes = [vp, i64p, i32p]
+    L.lt_get_all_tris.argtypes = [vp, i64p, dp, dp, i32p]
+    L.lt_get_tracks.argtypes = [vp, dp, i64p, i32p, i32p, i32p, dp, dp]
+    L.lt_get_stats.argtypes = [vp, i64p]
+    L.lt_get_timers.argtypes = [vp, dp]
+    L.lt_fn_get_normal_direction.argtypes = [vp, dp, dp, dp]
+    L.lt_fn_compute_fundamental_matrix.argtypes = [vp, dp, dp, dp]
+    L.lt_fn_compute_epipolar_IoU.argtypes = [vp, dp, dp, dp, dp, dp]
+    L.lt_fn_triangulate_line.argtypes = [vp, dp, dp, dp, dp, C.c_int, dp]
+    _lib = L
+    return L
+
+
+def config_from_dict(d=None):
+    """``GlobalLineTriangulatorConfig(py::dict)`` semantics (internal/helpers.h:25-27 of the
+    reference): keys that are present overwrite the C++ defaults, unknown keys are ignored."""
+    cfg = LtConfig()
+    load_library().lt_config_default(C.byref(cfg))
+    d = d or {}
+    for k in BASE_KEYS:
+        if k in d and d[k] is not None:
+            setattr(cfg, k, type(getattr(cfg, k))(d[k]))
+    if "merging_strategy" in d:
+        cfg.merging_strategy = MERGING.get(d["merging_strategy"], 99)
+    for prefix, keys, sub in (("l2_", L2_KEYS, "linker2d_config"), ("l3_", L3_KEYS, "linker3d_config")):
+        subd = d.get(sub) or {}
+        for k in keys:
+            if k in subd:
+                cur = getattr(cfg, prefix + k)
+                setattr(cfg, prefix + k, type(cur)(subd[k]))
+    return cfg
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Context:
+    """Owns one ``lt_ctx``; thin, typed access to the C ABI on numpy arrays."""
+
+    def __init__(self, cfg_dict=None, device=0, cfg_struct=None):
+        self.L = load_library()
+        self.cfg = cfg_struct if cfg_struct is not None else config_from_dict(cfg_dict)
+        h = self.L.lt_create(C.byref(self.cfg), int(device))
+        if not h:
+            raise RuntimeError("limap_amd: lt_create failed -- no usable HIP device (this backend has no CPU fallback)")
+        self.h = C.c_void_p(h)
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def chk(self, rc):
+        if rc != 0:
+            msg = self.L.lt_last_error(self.h).decode(errors="replace")
+            if rc == -2:
+                raise IndexError(msg) if msg.startswith("unknown") else ValueError(msg)
+            raise RuntimeError(msg)
+
+    # --- setup ---
+    def set_stream(self, stream_ptr):
+        self.chk(self.L.lt_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_ranges(self, lo, hi):
+        lo, hi = f64(lo).reshape(3), f64(hi).reshape(3)
+        self.chk(self.L.lt_set_ranges(self.h, ptr(lo, C.c_double), ptr(hi, C.c_double)))
+
+    def unset_ranges(self):
+        self.chk(self.L.lt_unset_ranges(self.h))
+
+    def init(self, img_ids, kvec, qvec, tvec, seg_off, segs):
+        img_ids, kvec, qvec, tvec = i32(img_ids), f64(kvec), f64(qvec), f64(tvec)
+        seg_off, segs = i64(seg_off), f64(segs)
+        n = len(img_ids)
+        assert kvec.shape == (n, 4) and qvec.shape == (n, 4) and tvec.shape == (n, 3) and len(seg_off) == n + 1
+        assert segs.shape == (int(seg_off[-1]) - int(seg_off[0]), 4) or segs.size == 0
+        self.chk(self.L.lt_init(self.h, n, ptr(img_ids, C.c_int32), ptr(kvec, C.c_double), ptr(qvec, C.c_double),
+                                ptr(tvec, C.c_double), ptr(seg_off, C.c_int64), ptr(segs, C.c_double)))
+
+    def init_device(self, img_ids, d_kvec, d_qvec, d_tvec, seg_off, d_segs):
+        img_ids, seg_off = i32(img_ids), i64(seg_off)
+        self.chk(self.L.lt_init_device(self.h, len(img_ids), ptr(img_ids, C.c_int32), C.c_void_p(d_kvec),
+                                       C.c_void_p(d_qvec), C.c_void_p(d_tvec), ptr(seg_off, C.c_int64),
+                                       C.c_void_p(d_segs)))
+
+    def triangulate_image(self, img_id, nb_ids, m_off, m_pairs):
+        nb_ids, m_off, m_pairs = i32(nb_ids), i64(m_off), i32(m_pairs)
+        self.chk(self.L.lt_triangulate_image(self.h, int(img_id), len(nb_ids), ptr(nb_ids, C.c_int32),
+                                             ptr(m_off, C.c_int64), ptr(m_pairs, C.c_int32)))
+
+    def triangulate_image_exhaustive(self, img_id, nb_ids):
+        nb_ids = i32(nb_ids)
+        self.chk(self.L.lt_triangulate_image_exhaustive(self.h, int(img_id), len(nb_ids), ptr(nb_ids, C.c_int32)))
+
+    def upload(self):
+        self.chk(self.L.lt_upload(self.h))
+
+    def run_device(self):
+        self.chk(self.L.lt_run_device(self.h))
+
+    def download(self):
+        self.chk(self.L.lt_download(self.h))
+
+    def flush(self):
+        self.chk(self.L.lt_flush(self.h))
+
+    def compute_tracks(self):
+        self.chk(self.L.lt_compute_tracks(self.h))
+
+    # --- getters ---
+    def num_nodes(self):
+        return int(self.L.lt_num_nodes(self.h))
+
+    def count_images(self):
+        return int(self.L.lt_count_images(self.h))
+
+    def count_lines(self, img_id):
+        n = int(self.L.lt_count_lines(self.h, int(img_id)))
+        if n < 0:
+            raise IndexError(self.L.lt_last_error(self.h).decode())
+        return n
+
+    def get_best(self):
+        n = self.num_nodes()
+        line = np.zeros((n, 10)); score = np.zeros(n); src = np.zeros((n, 2), np.int32); has = np.zeros(n, np.uint8)
+        self.chk(self.L.lt_get_best(self.h, ptr(line, C.c_double), ptr(score, C.c_double), ptr(src, C.c_int32),
+                                    ptr(has, C.c_uint8)))
+        return dict(line=line, score=score, src=src, has_best=has)
+
+    def get_num_tris(self):
+        out = np.zeros(self.num_nodes(), np.int32)
+        self.chk(self.L.lt_get_num_tris(self.h, ptr(out, C.c_int32)))
+        return out
+
+    def get_valid_edges(self):
+        ne = int(self.L.lt_num_valid_edges(self.h))
+        if ne < 0:
+            self.chk(-1)
+        off = np.zeros(self.num_nodes() + 1, np.int64); edges = np.zeros((max(ne, 1), 2), np.int32)
+        self.chk(self.L.lt_get_valid_edges(self.h, ptr(off, C.c_int64), ptr(edges, C.c_int32)))
+        return off, edges[:ne]
+
+    def get_all_tris(self):
+        nt = int(self.L.lt_num_all_tris(self.h))
+        if nt < 0:
+            self.chk(-1)
+        off = np.zeros(self.num_nodes() + 1, np.int64); line = np.zeros((max(nt, 1), 10)); score = np.zeros(max(nt, 1))
+        src = np.zeros((max(nt, 1), 2), np.int32)
+        self.chk(self.L.lt_get_all_tris(self.h, ptr(off, C.c_int64), ptr(line, C.c_double), ptr(score, C.c_double),
+                                        ptr(src, C.c_int32)))
+        return dict(off=off, line=line[:nt], score=score[:nt], src=src[:nt])
+
+    def get_tracks(self):
+        T = int(self.L.lt_num_tracks(self.h)); M = int(self.L.lt_num_track_members(self.h))
+        line = np.zeros((max(T, 1), 7)); off = np.zeros(T + 1, np.int64)
+        img = np.zeros(max(M, 1), np.int32); lid = np.zeros(max(M, 1), np.int32); nid = np.zeros(max(M, 1), np.int32)
+        sc = np.zeros(max(M, 1)); l3d = np.zeros((max(M, 1), 6))
+        self.chk(self.L.lt_get_tracks(self.h, ptr(line, C.c_double), ptr(off, C.c_int64), ptr(img, C.c_int32),
+                                      ptr(lid, C.c_int32), ptr(nid, C.c_int32), ptr(sc, C.c_double),
+                                      ptr(l3d, C.c_double)))
+        return dict(line=line[:T], off=off, image_ids=img[:M], line_ids=lid[:M], node_ids=nid[:M], scores=sc[:M],
+                    line3d=l3d[:M])
+
+    def stats(self):
+        out = np.zeros(8, np.int64)
+        self.chk(self.L.lt_get_stats(self.h, ptr(out, C.c_int64)))
+        keys = ["connections", "candidates", "pairs", "valid_edges", "graph_nodes", "graph_edges", "tracks", "nodes"]
+        return dict(zip(keys, out.tolist()))
+
+    def timers(self):
+        out = np.zeros(16)
+        self.chk(self.L.lt_get_timers(self.h, ptr(out, C.c_double)))
+        keys = ["run", "invariants", "sort", "gen", "compact", "score", "select", "gather", "upload", "download", "tail"]
+        return dict(zip(keys, out.tolist()))
+
+    # --- free functions ---
+    def fn_normal_direction(self, seg, cam):
+        out = np.zeros(3)
+        self.chk(self.L.lt_fn_get_normal_direction(self.h, ptr(f64(seg), C.c_double), ptr(f64(cam), C.c_double),
+                                                   ptr(out, C.c_double)))
+        return out
+
+    def fn_fundamental_matrix(self, cam1, cam2):
+        out = np.zeros(9)
+        self.chk(self.L.lt_fn_compute_fundamental_matrix(self.h, ptr(f64(cam1), C.c_double), ptr(f64(cam2), C.c_double),
+                                                         ptr(out, C.c_double)))
+        return out.reshape(3, 3)
+
+    def fn_epipolar_iou(self, seg1, cam1, seg2, cam2):
+        out = C.c_double(0)
+        self.chk(self.L.lt_fn_compute_epipolar_IoU(self.h, ptr(f64(seg1), C.c_double), ptr(f64(cam1), C.c_double),
+                                                   ptr(f64(seg2), C.c_double), ptr(f64(cam2), C.c_double), C.byref(out)))
+        return out.value
+
+    def fn_triangulate_line(self, seg1, cam1, seg2, cam2, by_endpoints=False):
+        out = np.zeros(10)
+        self.chk(self.L.lt_fn_triangulate_line(self.h, ptr(f64(seg1), C.c_double), ptr(f64(cam1), C.c_double),
+                                               ptr(f64(seg2), C.c_double), ptr(f64(cam2), C.c_double),
+                                               int(bool(by_endpoints)), ptr(out, C.c_double)))
+        return out

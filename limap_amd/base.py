@@ -1,0 +1,164 @@
+"""Light stand-ins for the `limap.base` value types the triangulation boundary exchanges.
+
+When a real limap install is present the triangulator accepts and returns limap's own objects
+(duck-typed, see ``triangulation.py``); these classes carry the same attribute / method names
+(reference: src/limap/base/linebase.h:16-60, base/linetrack.h:21-50, base/camera_view.h:56-88,
+base/image_collection.h:24-115) so the same caller code runs without limap.
+"""
+import numpy as np
+
+
+class Line2d:
+    """linebase.h:16-35"""
+
+    def __init__(self, start=None, end=None, score=-1.0):
+        if start is not None and end is None:
+            a = np.asarray(start, float)
+            if a.shape == (2, 2):
+                start, end = a[0], a[1]
+            else:
+                a = a.reshape(-1)
+                start, end = a[0:2], a[2:4]
+        self.start = np.zeros(2) if start is None else np.asarray(start, float).copy()
+        self.end = np.zeros(2) if end is None else np.asarray(end, float).copy()
+        self.score = float(score)
+
+    def length(self):
+        return float(np.linalg.norm(self.start - self.end))
+
+    def midpoint(self):
+        return 0.5 * (self.start + self.end)
+
+    def direction(self):
+        d = self.end - self.start
+        n = np.linalg.norm(d)
+        return d / n if n > 0 else d
+
+    def as_array(self):
+        return np.stack([self.start, self.end], 0)
+
+
+class Line3d:
+    """linebase.h:37-60"""
+
+    def __init__(self, start=None, end=None, score=-1.0, depth_start=-1.0, depth_end=-1.0, uncertainty=-1.0):
+        if start is not None and end is None:
+            a = np.asarray(start, float).reshape(2, 3)
+            start, end = a[0], a[1]
+        self.start = np.zeros(3) if start is None else np.asarray(start, float).copy()
+        self.end = np.zeros(3) if end is None else np.asarray(end, float).copy()
+        self.score = float(score)
+        self.uncertainty = float(uncertainty)
+        self.depths = np.array([depth_start, depth_end], float)
+
+    @classmethod
+    def from10(cls, a):
+        """line10 layout of the C ABI: start3, end3, depths2, uncertainty, score."""
+        return cls(a[0:3], a[3:6], a[9], a[6], a[7], a[8])
+
+    def set_uncertainty(self, val):
+        self.uncertainty = float(val)
+
+    def length(self):
+        return float(np.linalg.norm(self.start - self.end))
+
+    def midpoint(self):
+        return 0.5 * (self.start + self.end)
+
+    def direction(self):
+        d = self.end - self.start
+        n = np.linalg.norm(d)
+        return d / n if n > 0 else d
+
+    def as_array(self):
+        return np.stack([self.start, self.end], 0)
+
+
+class LineTrack:
+    """linetrack.h:21-50 (fields filled by GlobalLineTriangulator::build_tracks_from_clusters)."""
+
+    def __init__(self, line=None, image_id_list=None, line_id_list=None, line2d_list=None):
+        self.line = line if line is not None else Line3d()
+        self.image_id_list = list(image_id_list or [])
+        self.line_id_list = list(line_id_list or [])
+        self.line2d_list = list(line2d_list or [])
+        self.node_id_list = []
+        self.line3d_list = []
+        self.score_list = []
+        self.active = True
+
+    def count_lines(self):
+        return len(self.line2d_list)
+
+    def GetSortedImageIds(self):
+        return sorted(set(self.image_id_list))
+
+    def count_images(self):
+        return len(self.GetSortedImageIds())
+
+    def HasImage(self, image_id):
+        return image_id in self.image_id_list
+
+    def as_dict(self):  # linetrack.cc:31-48
+        return dict(line=self.line.as_array(), image_id_list=list(self.image_id_list),
+                    line_id_list=list(self.line_id_list), node_id_list=list(self.node_id_list),
+                    score_list=list(self.score_list), line2d_list=[l.as_array() for l in self.line2d_list],
+                    line3d_list=[l.as_array() for l in self.line3d_list], active=self.active)
+
+
+class CameraView:
+    """camera_view.h:56-88 reduced to the undistorted pinhole the hot path requires
+    (base_line_triangulator.cc:49)."""
+
+    def __init__(self, kvec, qvec, tvec, image_name="none"):
+        self.kvec = np.asarray(kvec, float).reshape(4)
+        q = np.asarray(qvec, float).reshape(4)
+        n = np.linalg.norm(q)
+        self.qvec = q / n if n > 0 else q
+        self.tvec = np.asarray(tvec, float).reshape(3)
+        self._name = image_name
+
+    def image_name(self):
+        return self._name
+
+    def K(self):
+        fx, fy, cx, cy = self.kvec
+        return np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+
+    def R(self):
+        w, x, y, z = self.qvec / np.linalg.norm(self.qvec)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+    def T(self):
+        return self.tvec
+
+    def as_cam11(self):
+        return np.concatenate([self.kvec, self.qvec, self.tvec])
+
+
+class ImageCollection:
+    """image_collection.h:24-115 reduced to ids + per-image pinhole views."""
+
+    def __init__(self, views=None):
+        self._views = dict(views or {})
+
+    @classmethod
+    def from_arrays(cls, img_ids, kvec, qvec, tvec):
+        return cls({int(i): CameraView(kvec[k], qvec[k], tvec[k]) for k, i in enumerate(img_ids)})
+
+    def get_img_ids(self):
+        return sorted(self._views.keys())
+
+    def NumImages(self):
+        return len(self._views)
+
+    def exist_image(self, img_id):
+        return img_id in self._views
+
+    def camview(self, img_id):
+        return self._views[img_id]
+
+    def IsUndistorted(self):
+        return True

@@ -1,0 +1,1321 @@
+// lt_api.cpp -- C ABI (include/limap_amd.h) of the MI355X line-triangulation backend:
+// context, device buffers, the device pipeline, and the host tail (ComputeLineTracks).
+//
+// The tail follows global_line_triangulator.cc:168-351 (filterNodeByNumOuterEdges, run_clustering,
+// build_tracks_from_clusters), base/graph.cc:57-87,156-165, merging/merging.cc:18-103
+// (ComputeLineTrackLabelsGreedy) and merging/aggregator.cc:8-101; it runs on the host in C++
+// because it is a serial union-find over a few 10^4..10^6 edges (SURVEY.md 8e "Tail").
+// There is no CPU fallback for the kernels: without a GPU lt_create fails.
+
+#include "../../include/limap_amd.h"
+#include "lt_device.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <queue>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace lt;
+
+namespace lt {
+void launch_fn_query(hipStream_t st, const double *in30, int by_endpoints, double *out32);
+}
+
+namespace {
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t bytes) {
+    if (bytes <= cap) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) return false;
+    cap = want;
+    return true;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct Track {
+  double line[7];
+  std::vector<int> img_ids, line_ids, node_ids;
+  std::vector<double> scores;
+  std::vector<long long> gnodes;  // global node index of every member
+};
+
+}  // namespace
+
+struct lt_ctx {
+  lt_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  std::string err;
+  bool ranges_on = false;
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+
+  // ---- scene ----
+  bool inited = false;
+  int n_img = 0;
+  std::vector<int> img_ids;  // ascending
+  std::unordered_map<int, int> id2idx;
+  std::vector<long long> seg_off;  // n_img+1
+  long long G = 0;
+  std::vector<int> h_node_img;  // node -> image index
+  DevBuf d_kvec, d_qvec, d_tvec, d_segs_raw, d_cams, d_segs, d_seg_off, d_node_img;
+
+  // ---- buffered job ----
+  int job_mode = 0;  // 0 none, 1 matched, 2 exhaustive
+  std::vector<int> job_imgs;               // image indices in call order
+  std::vector<std::vector<int>> job_nbs;   // per job image: neighbour image indices, processing order
+  std::vector<std::vector<int>> job_order; // per job image: slots in ascending neighbour-id order
+  std::vector<long long> h_m_off;          // per block row offsets (n_blk+1), matched mode
+  std::vector<int> h_m_pairs;              // 2 * P
+  std::vector<char> triangulated;          // per image: already passed to TriangulateImage*
+  bool uploaded = false, ran = false, downloaded = false;
+  // neighbours_ of every triangulated image (ids), persists for the tail
+  std::vector<std::vector<int>> neighbors;  // image idx -> neighbour image indices (slot order)
+
+  // ---- device job tables ----
+  int n_blk = 0;
+  int max_nb = 1;
+  long long P = 0;        // connections (matched) / work items (exhaustive: n_items)
+  long long n_conn = 0;   // connections tested (stat)
+  std::vector<long long> h_nb_off;  // n_img+1
+  std::vector<int> h_blk_img, h_blk_nb, h_blk_slot, h_blk_order;
+  std::vector<long long> h_item_off;  // exhaustive: per node first item (G+1)
+  DevBuf d_nb_off, d_blk_img, d_blk_nb, d_blk_slot, d_blk_order, d_m_off, d_m_pairs, d_pairs;
+  DevBuf d_keys, d_rows, d_row_blk, d_skeys, d_srows, d_sort_tmp, d_conn_off;
+  DevBuf d_st_c, d_st_l, d_flags, d_pos, d_scan_tmp;
+  DevBuf d_item_off, d_masks, d_mask_cnt, d_mask_pos;
+  DevBuf d_cand, d_lite, d_tri_off, d_score, d_best_idx, d_edge_flag, d_nvalid, d_edge_off, d_edges;
+  DevBuf d_best_c, d_best_score, d_best_src, d_ntris, d_err;
+  long long cand_cap = 0;
+  long long C = 0, E = 0;  // candidates / valid edges of the last run
+
+  // ---- host results (all nodes) ----
+  std::vector<Cand> best_c;
+  std::vector<double> best_score;
+  std::vector<int> best_src2, n_tris;
+  std::vector<unsigned char> has_best;
+  std::vector<std::vector<int>> valid_edges;  // per node: flat (slot, ng_line) pairs
+  // ---- tail ----
+  std::vector<Track> tracks;
+  bool tracks_done = false;
+  long long stat_graph_nodes = 0, stat_graph_edges = 0, stat_pairs = 0;
+  double timers[16] = {0};
+  hipEvent_t ev[9] = {nullptr};
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                  \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (ctx)->err = std::string("HIP error: ") + hipGetErrorString(e_) + " at " #call;      \
+      return LT_ERR_HIP;                                                                   \
+    }                                                                                      \
+  } while (0)
+
+#define ENSURE(ctx, buf, bytes)                                                 \
+  do {                                                                          \
+    if (!(buf).ensure(bytes)) {                                                 \
+      (ctx)->err = "hipMalloc failed for " #buf;                                \
+      return LT_ERR_HIP;                                                        \
+    }                                                                           \
+  } while (0)
+
+int fail(lt_ctx *ctx, int code, const std::string &msg) {
+  ctx->err = msg;
+  return code;
+}
+
+double multiplier(double score_th) { return 1.0 / std::sqrt(-std::log(score_th) * 2.0); }  // line_linker.cc:9-12
+
+LinkCfg2 make_l2(const lt_config &c) {
+  LinkCfg2 l;
+  l.score_th = c.l2_score_th; l.th_angle = c.l2_th_angle; l.th_overlap = c.l2_th_overlap;
+  l.th_smartoverlap = c.l2_th_smartoverlap; l.th_smartangle = c.l2_th_smartangle;
+  l.th_perp = c.l2_th_perp; l.th_innerseg = c.l2_th_innerseg;
+  l.mult = multiplier(c.l2_score_th);
+  l.use_angle = c.l2_use_angle; l.use_overlap = c.l2_use_overlap; l.use_smartangle = c.l2_use_smartangle;
+  l.use_perp = c.l2_use_perp; l.use_innerseg = c.l2_use_innerseg; l.pad_ = 0;
+  return l;
+}
+LinkCfg3 make_l3(const lt_config &c) {
+  LinkCfg3 l;
+  l.score_th = c.l3_score_th; l.th_angle = c.l3_th_angle; l.th_overlap = c.l3_th_overlap;
+  l.th_smartoverlap = c.l3_th_smartoverlap; l.th_smartangle = c.l3_th_smartangle;
+  l.th_perp = c.l3_th_perp; l.th_innerseg = c.l3_th_innerseg; l.th_scaleinv = c.l3_th_scaleinv;
+  l.mult = multiplier(c.l3_score_th);
+  l.use_angle = c.l3_use_angle; l.use_overlap = c.l3_use_overlap; l.use_smartangle = c.l3_use_smartangle;
+  l.use_perp = c.l3_use_perp; l.use_innerseg = c.l3_use_innerseg; l.use_scaleinv = c.l3_use_scaleinv;
+  return l;
+}
+
+GenCfg make_gen(const lt_ctx *ctx) {
+  const lt_config &c = ctx->cfg;
+  GenCfg g;
+  g.min_length_2d = c.min_length_2d; g.angle_th = c.line_tri_angle_threshold; g.iou_th = c.IoU_threshold;
+  g.sens_th = c.sensitivity_threshold; g.var2d = c.var2d;
+  for (int k = 0; k < 3; ++k) { g.lo[k] = ctx->lo[k]; g.hi[k] = ctx->hi[k]; }
+  g.use_ranges = ctx->ranges_on; g.use_endpoints = c.use_endpoints_triangulation;
+  g.disable_algebraic = c.disable_algebraic_triangulation; g.pad_ = 0;
+  // The gate `90 - acos(a)*180/pi < th` is equivalent to a < sin(th) up to libm rounding; outside
+  // a +-1e-7 relative band around sin(th) the comparison of a alone decides, inside it the exact
+  // expression is evaluated.  For thresholds outside (0, 90) the band covers everything.
+  double th = c.line_tri_angle_threshold;
+  if (th > 1e-3 && th < 89.0) {
+    double s = std::sin(th * kPi / 180.0);
+    g.sin_lo = s * (1.0 - 1e-7);
+    g.sin_hi = s * (1.0 + 1e-7);
+  } else {
+    g.sin_lo = -1.0;
+    g.sin_hi = 1e300;
+  }
+  return g;
+}
+
+ScoreCfg make_score(const lt_ctx *ctx) {
+  ScoreCfg s;
+  s.l2 = make_l2(ctx->cfg);
+  s.l3 = make_l3(ctx->cfg);
+  // set_to_shared_parent_scoring, line_linker.h:115-121
+  s.l3.use_angle = 1; s.l3.use_overlap = 0; s.l3.use_perp = 0; s.l3.use_innerseg = 0; s.l3.use_scaleinv = 1;
+  // 3D angle gate: score_angle >= score_th  <=>  angle <= th_angle (up to rounding).  Pairs whose
+  // |cos| is below cos(th_angle * (1 + 1e-6) + 1e-6 deg) can never pass; all others are evaluated
+  // exactly.  th_angle >= 90 disables the early exit.
+  double th = s.l3.th_angle * (1.0 + 1e-6) + 1e-6;
+  s.cos_guard = (th < 90.0) ? std::cos(th * kPi / 180.0) : -1.0;
+  s.fullscore_th = ctx->cfg.fullscore_th;
+  s.max_valid_conns = ctx->cfg.max_valid_conns;
+  s.pad_ = 0;
+  return s;
+}
+
+int bits_for(long long n) {
+  int b = 1;
+  while (b < 32 && (1ll << b) < n) ++b;
+  return b;
+}
+
+// ---------------------------------------------------------------------------------------------
+int init_common(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *seg_off_in,
+                const std::vector<int> &perm) {
+  // perm: sorted position -> caller position
+  ctx->n_img = n_img;
+  ctx->img_ids.resize(n_img);
+  ctx->id2idx.clear();
+  ctx->seg_off.assign(n_img + 1, 0);
+  for (int i = 0; i < n_img; ++i) {
+    ctx->img_ids[i] = img_ids[perm[i]];
+    if (ctx->id2idx.count(ctx->img_ids[i])) return fail(ctx, LT_ERR_ARGUMENT, "duplicate image id in Init");
+    ctx->id2idx[ctx->img_ids[i]] = i;
+    long long m = seg_off_in[perm[i] + 1] - seg_off_in[perm[i]];
+    if (m < 0) return fail(ctx, LT_ERR_ARGUMENT, "seg_off must be non-decreasing");
+    if (m > 65535) return fail(ctx, LT_ERR_ARGUMENT, "more than 65535 lines in one image (uint16 line ids, util/types.h:16)");
+    ctx->seg_off[i + 1] = ctx->seg_off[i] + m;
+  }
+  ctx->G = ctx->seg_off[n_img];
+  if (ctx->G >= (1ll << 32) - 1) return fail(ctx, LT_ERR_ARGUMENT, "too many nodes (>= 2^32-1)");
+  ctx->h_node_img.resize(ctx->G);
+  for (int i = 0; i < n_img; ++i)
+    for (long long g = ctx->seg_off[i]; g < ctx->seg_off[i + 1]; ++g) ctx->h_node_img[g] = i;
+  ctx->triangulated.assign(n_img, 0);
+  ctx->neighbors.assign(n_img, {});
+  ctx->best_c.assign(ctx->G, Cand{});
+  ctx->best_score.assign(ctx->G, 0.0);
+  ctx->best_src2.assign(2 * ctx->G, 0);
+  ctx->n_tris.assign(ctx->G, 0);
+  ctx->has_best.assign(ctx->G, 0);
+  ctx->valid_edges.assign(ctx->G, {});
+  ctx->tracks.clear();
+  ctx->tracks_done = false;
+  ctx->job_mode = 0;
+  ctx->job_imgs.clear(); ctx->job_nbs.clear(); ctx->job_order.clear();
+  ctx->h_m_off.assign(1, 0); ctx->h_m_pairs.clear();
+  ctx->uploaded = ctx->ran = ctx->downloaded = false;
+  return LT_OK;
+}
+
+int build_invariants(lt_ctx *ctx) {
+  hipStream_t st = ctx->stream;
+  ENSURE(ctx, ctx->d_cams, sizeof(Cam) * (size_t)std::max(ctx->n_img, 1));
+  ENSURE(ctx, ctx->d_segs, sizeof(Seg) * (size_t)std::max<long long>(ctx->G, 1));
+  ENSURE(ctx, ctx->d_seg_off, sizeof(long long) * (size_t)(ctx->n_img + 1));
+  ENSURE(ctx, ctx->d_node_img, sizeof(int) * (size_t)std::max<long long>(ctx->G, 1));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_seg_off.p, ctx->seg_off.data(), sizeof(long long) * (ctx->n_img + 1),
+                             hipMemcpyHostToDevice, st));
+  if (ctx->G > 0)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_node_img.p, ctx->h_node_img.data(), sizeof(int) * ctx->G,
+                               hipMemcpyHostToDevice, st));
+  launch_build_cams(st, ctx->n_img, ctx->d_kvec.as<double>(), ctx->d_qvec.as<double>(), ctx->d_tvec.as<double>(),
+                    ctx->d_cams.as<Cam>());
+  launch_build_segs(st, ctx->G, ctx->n_img, ctx->d_seg_off.as<long long>(), ctx->d_segs_raw.as<double>(),
+                    ctx->cfg.add_halfpix ? 0.5 : 0.0, ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>());
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  ctx->inited = true;
+  return LT_OK;
+}
+
+// Assemble the per-job neighbour tables from the buffered calls.
+void build_job_tables(lt_ctx *ctx) {
+  const int n_img = ctx->n_img;
+  ctx->h_nb_off.assign(n_img + 1, 0);
+  std::vector<int> job_pos(n_img, -1);
+  for (size_t j = 0; j < ctx->job_imgs.size(); ++j) job_pos[ctx->job_imgs[j]] = (int)j;
+  ctx->h_blk_img.clear(); ctx->h_blk_nb.clear(); ctx->h_blk_slot.clear(); ctx->h_blk_order.clear();
+  ctx->max_nb = 1;
+  for (int i = 0; i < n_img; ++i) {
+    ctx->h_nb_off[i] = (long long)ctx->h_blk_img.size();
+    int j = job_pos[i];
+    if (j < 0) continue;
+    const auto &nbs = ctx->job_nbs[j];
+    ctx->max_nb = std::max(ctx->max_nb, (int)nbs.size());
+    for (size_t k = 0; k < nbs.size(); ++k) {
+      ctx->h_blk_img.push_back(i);
+      ctx->h_blk_nb.push_back(nbs[k]);
+      ctx->h_blk_slot.push_back((int)k);
+      ctx->h_blk_order.push_back(ctx->job_order[j][k]);
+    }
+  }
+  ctx->h_nb_off[n_img] = (long long)ctx->h_blk_img.size();
+  ctx->n_blk = (int)ctx->h_blk_img.size();
+}
+
+template <class T>
+int upload_vec(lt_ctx *ctx, DevBuf &buf, const std::vector<T> &v) {
+  ENSURE(ctx, buf, sizeof(T) * std::max<size_t>(v.size(), 1));
+  if (!v.empty())
+    HIPCHK(ctx, hipMemcpyAsync(buf.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, ctx->stream));
+  return LT_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+void lt_config_default(lt_config *c) {
+  std::memset(c, 0, sizeof(*c));
+  c->min_length_2d = 20.0; c->line_tri_angle_threshold = 5.0; c->IoU_threshold = 0.1;
+  c->sensitivity_threshold = 70.0; c->var2d = 2.0;
+  c->fullscore_th = 1.0; c->max_valid_conns = 1000; c->min_num_outer_edges = 1;
+  c->merging_strategy = 0; c->num_outliers_aggregator = 2;
+  c->l2_score_th = 0.5; c->l2_th_angle = 8.0; c->l2_th_overlap = 0.1; c->l2_th_smartoverlap = 0.2;
+  c->l2_th_smartangle = 1.0; c->l2_th_perp = 5.0; c->l2_th_innerseg = 5.0;
+  c->l2_use_angle = 1; c->l2_use_overlap = 1; c->l2_use_smartangle = 1; c->l2_use_perp = 1; c->l2_use_innerseg = 0;
+  c->l3_score_th = 0.5; c->l3_th_angle = 10.0; c->l3_th_overlap = 0.01; c->l3_th_smartoverlap = 0.1;
+  c->l3_th_smartangle = 1.0; c->l3_th_perp = 0.02; c->l3_th_innerseg = 0.02; c->l3_th_scaleinv = 0.01;
+  c->l3_use_angle = 1; c->l3_use_overlap = 1; c->l3_use_smartangle = 1; c->l3_use_perp = 0;
+  c->l3_use_innerseg = 1; c->l3_use_scaleinv = 0;
+}
+
+lt_ctx *lt_create(const lt_config *cfg, int device) {
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev <= 0) {
+    std::fprintf(stderr, "limap_amd: no HIP device available (%s); this backend has no CPU fallback\n",
+                 hipGetErrorString(e));
+    return nullptr;
+  }
+  if (device < 0 || device >= n_dev) {
+    std::fprintf(stderr, "limap_amd: device %d out of range (%d devices)\n", device, n_dev);
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  lt_ctx *ctx = new lt_ctx();
+  ctx->cfg = *cfg;
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return nullptr;
+  }
+  for (auto &ev : ctx->ev) (void)hipEventCreate(&ev);
+  return ctx;
+}
+
+void lt_destroy(lt_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  DevBuf *bufs[] = {&ctx->d_kvec, &ctx->d_qvec, &ctx->d_tvec, &ctx->d_segs_raw, &ctx->d_cams, &ctx->d_segs,
+                    &ctx->d_seg_off, &ctx->d_node_img, &ctx->d_nb_off, &ctx->d_blk_img, &ctx->d_blk_nb,
+                    &ctx->d_blk_slot, &ctx->d_blk_order, &ctx->d_m_off, &ctx->d_m_pairs, &ctx->d_pairs,
+                    &ctx->d_keys, &ctx->d_rows, &ctx->d_row_blk, &ctx->d_skeys, &ctx->d_srows, &ctx->d_sort_tmp,
+                    &ctx->d_conn_off, &ctx->d_st_c, &ctx->d_st_l, &ctx->d_flags, &ctx->d_pos, &ctx->d_scan_tmp,
+                    &ctx->d_item_off, &ctx->d_masks, &ctx->d_mask_cnt, &ctx->d_mask_pos, &ctx->d_cand,
+                    &ctx->d_lite, &ctx->d_tri_off, &ctx->d_score, &ctx->d_best_idx, &ctx->d_edge_flag,
+                    &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
+                    &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err};
+  for (DevBuf *b : bufs) b->release();
+  for (auto &ev : ctx->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *lt_last_error(lt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int lt_set_stream(lt_ctx *ctx, void *hip_stream) {
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (hip_stream) {
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
+  } else {
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  return LT_OK;
+}
+
+int lt_set_ranges(lt_ctx *ctx, const double lo[3], const double hi[3]) {
+  ctx->ranges_on = true;
+  for (int k = 0; k < 3; ++k) { ctx->lo[k] = lo[k]; ctx->hi[k] = hi[k]; }
+  return LT_OK;
+}
+int lt_unset_ranges(lt_ctx *ctx) {
+  ctx->ranges_on = false;
+  return LT_OK;
+}
+
+int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, const double *qvec,
+            const double *tvec, const int64_t *seg_off, const double *segs) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->cfg.use_vp) return fail(ctx, LT_ERR_ARGUMENT, "use_vp (VP-guided proposals) is not implemented in this backend");
+  if (n_img < 0) return fail(ctx, LT_ERR_ARGUMENT, "n_img < 0");
+  std::vector<int> perm(n_img);
+  for (int i = 0; i < n_img; ++i) perm[i] = i;
+  std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return img_ids[a] < img_ids[b]; });
+  int rc = init_common(ctx, n_img, img_ids, seg_off, perm);
+  if (rc) return rc;
+  // gather into ascending-id order
+  std::vector<double> k(4 * (size_t)n_img), q(4 * (size_t)n_img), t(3 * (size_t)n_img), s(4 * (size_t)ctx->G);
+  for (int i = 0; i < n_img; ++i) {
+    int p = perm[i];
+    std::memcpy(&k[4 * i], kvec + 4 * p, 32);
+    std::memcpy(&q[4 * i], qvec + 4 * p, 32);
+    std::memcpy(&t[3 * i], tvec + 3 * p, 24);
+    long long m = seg_off[p + 1] - seg_off[p];
+    if (m > 0) std::memcpy(&s[4 * ctx->seg_off[i]], segs + 4 * seg_off[p], (size_t)m * 32);
+  }
+  if ((rc = upload_vec(ctx, ctx->d_kvec, k))) return rc;
+  if ((rc = upload_vec(ctx, ctx->d_qvec, q))) return rc;
+  if ((rc = upload_vec(ctx, ctx->d_tvec, t))) return rc;
+  if ((rc = upload_vec(ctx, ctx->d_segs_raw, s))) return rc;
+  return build_invariants(ctx);
+}
+
+int lt_init_device(lt_ctx *ctx, int n_img, const int32_t *img_ids, const void *d_kvec, const void *d_qvec,
+                   const void *d_tvec, const int64_t *seg_off, const void *d_segs) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->cfg.use_vp) return fail(ctx, LT_ERR_ARGUMENT, "use_vp (VP-guided proposals) is not implemented in this backend");
+  std::vector<int> perm(n_img);
+  for (int i = 0; i < n_img; ++i) {
+    perm[i] = i;
+    if (i > 0 && img_ids[i] <= img_ids[i - 1])
+      return fail(ctx, LT_ERR_ARGUMENT, "lt_init_device needs strictly ascending image ids");
+  }
+  int rc = init_common(ctx, n_img, img_ids, seg_off, perm);
+  if (rc) return rc;
+  hipStream_t st = ctx->stream;
+  ENSURE(ctx, ctx->d_kvec, 32 * (size_t)std::max(n_img, 1));
+  ENSURE(ctx, ctx->d_qvec, 32 * (size_t)std::max(n_img, 1));
+  ENSURE(ctx, ctx->d_tvec, 24 * (size_t)std::max(n_img, 1));
+  ENSURE(ctx, ctx->d_segs_raw, 32 * (size_t)std::max<long long>(ctx->G, 1));
+  if (n_img > 0) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_kvec.p, d_kvec, 32 * (size_t)n_img, hipMemcpyDeviceToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_qvec.p, d_qvec, 32 * (size_t)n_img, hipMemcpyDeviceToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_tvec.p, d_tvec, 24 * (size_t)n_img, hipMemcpyDeviceToDevice, st));
+  }
+  if (ctx->G > 0)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_segs_raw.p, d_segs, 32 * (size_t)ctx->G, hipMemcpyDeviceToDevice, st));
+  return build_invariants(ctx);
+}
+
+static int begin_image(lt_ctx *ctx, int img_id, int mode, int *idx_out) {
+  if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "TriangulateImage called before Init");
+  auto it = ctx->id2idx.find(img_id);
+  if (it == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "unknown image id " + std::to_string(img_id));
+  if (ctx->job_mode != 0 && ctx->job_mode != mode && !ctx->downloaded) {
+    int rc = lt_flush(ctx);  // switching between matched and exhaustive calls: run what is buffered
+    if (rc) return rc;
+  }
+  if (ctx->downloaded) {  // a new batch after results were read: start a fresh job
+    ctx->job_imgs.clear(); ctx->job_nbs.clear(); ctx->job_order.clear();
+    ctx->h_m_off.assign(1, 0); ctx->h_m_pairs.clear();
+    ctx->uploaded = ctx->ran = ctx->downloaded = false;
+  }
+  ctx->job_mode = mode;
+  ctx->uploaded = ctx->ran = false;
+  ctx->tracks_done = false;
+  *idx_out = it->second;
+  return LT_OK;
+}
+
+int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids, const int64_t *m_off,
+                         const int32_t *m_pairs) {
+  int idx;
+  int rc = begin_image(ctx, img_id, 1, &idx);
+  if (rc) return rc;
+  if (ctx->triangulated[idx]) return LT_OK;  // already_scored_ guard (global_line_triangulator.cc:73)
+  if (n_nb > 255) return fail(ctx, LT_ERR_ARGUMENT, "more than 255 neighbours (uint8 neighbour index, base_line_triangulator.h:15)");
+  // the reference iterates std::map<int, MatrixXi>: ascending neighbour id
+  std::vector<int> order(n_nb);
+  for (int k = 0; k < n_nb; ++k) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nb_ids[a] < nb_ids[b]; });
+  std::vector<int> nbs, ord;
+  const long long M1 = ctx->seg_off[idx + 1] - ctx->seg_off[idx];
+  size_t m_off_mark = ctx->h_m_off.size();
+  size_t pairs_mark = ctx->h_m_pairs.size();
+  for (int k = 0; k < n_nb; ++k) {
+    int o = order[k];
+    if (k > 0 && nb_ids[o] == nb_ids[order[k - 1]]) {
+      ctx->h_m_off.resize(m_off_mark); ctx->h_m_pairs.resize(pairs_mark);
+      return fail(ctx, LT_ERR_ARGUMENT, "duplicate neighbour id in matches");
+    }
+    auto it = ctx->id2idx.find(nb_ids[o]);
+    if (it == ctx->id2idx.end()) {
+      ctx->h_m_off.resize(m_off_mark); ctx->h_m_pairs.resize(pairs_mark);
+      return fail(ctx, LT_ERR_ARGUMENT, "unknown neighbour image id " + std::to_string(nb_ids[o]));
+    }
+    const long long M2 = ctx->seg_off[it->second + 1] - ctx->seg_off[it->second];
+    long long r0 = m_off[o], r1 = m_off[o + 1];
+    for (long long r = r0; r < r1; ++r) {
+      int line = m_pairs[2 * r], ng = m_pairs[2 * r + 1];
+      if (line < 0 || line >= M1) {  // base_line_triangulator.cc:87-94
+        ctx->h_m_off.resize(m_off_mark); ctx->h_m_pairs.resize(pairs_mark);
+        return fail(ctx, LT_ERR_RUNTIME,
+                    "IndexError! Out-of-index matches exist between image (img_id = " + std::to_string(img_id) +
+                        ") and neighbor image (img_id = " + std::to_string(nb_ids[o]) +
+                        "). Please make sure you are reusing the correct descriptors and matches when using the "
+                        "--skip_exists option.");
+      }
+      if (ng < 0 || ng >= M2) {
+        ctx->h_m_off.resize(m_off_mark); ctx->h_m_pairs.resize(pairs_mark);
+        return fail(ctx, LT_ERR_RUNTIME, "IndexError! neighbour line id out of range in matches of image " +
+                                             std::to_string(img_id));
+      }
+    }
+    ctx->h_m_pairs.insert(ctx->h_m_pairs.end(), m_pairs + 2 * r0, m_pairs + 2 * r1);
+    ctx->h_m_off.push_back(ctx->h_m_off.back() + (r1 - r0));
+    nbs.push_back(it->second);
+    ord.push_back(k);  // already ascending id
+  }
+  ctx->job_imgs.push_back(idx);
+  ctx->job_nbs.push_back(nbs);
+  ctx->job_order.push_back(ord);
+  ctx->neighbors[idx] = nbs;
+  ctx->triangulated[idx] = 1;
+  return LT_OK;
+}
+
+int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids) {
+  int idx;
+  int rc = begin_image(ctx, img_id, 2, &idx);
+  if (rc) return rc;
+  if (ctx->triangulated[idx]) return LT_OK;
+  if (n_nb > 255) return fail(ctx, LT_ERR_ARGUMENT, "more than 255 neighbours (uint8 neighbour index, base_line_triangulator.h:15)");
+  std::vector<int> nbs;
+  for (int k = 0; k < n_nb; ++k) {
+    auto it = ctx->id2idx.find(nb_ids[k]);
+    if (it == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "unknown neighbour image id " + std::to_string(nb_ids[k]));
+    for (int p = 0; p < k; ++p)
+      if (nb_ids[p] == nb_ids[k]) return fail(ctx, LT_ERR_ARGUMENT, "duplicate neighbour id in neighbors list");
+    nbs.push_back(it->second);
+  }
+  // exhaustive mode keeps the caller's neighbour order (:113-114); the per-image support sum
+  // still runs over ascending image ids (std::map score_table, global_line_triangulator.cc:83,110)
+  std::vector<int> ord(n_nb);
+  for (int k = 0; k < n_nb; ++k) ord[k] = k;
+  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return nb_ids[a] < nb_ids[b]; });
+  ctx->job_imgs.push_back(idx);
+  ctx->job_nbs.push_back(nbs);
+  ctx->job_order.push_back(ord);
+  ctx->neighbors[idx] = nbs;
+  ctx->triangulated[idx] = 1;
+  return LT_OK;
+}
+
+int lt_upload(lt_ctx *ctx) {
+  if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "upload before Init");
+  if (ctx->uploaded) return LT_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  double t0 = now_ms();
+  build_job_tables(ctx);
+  int rc;
+  if ((rc = upload_vec(ctx, ctx->d_nb_off, ctx->h_nb_off))) return rc;
+  if ((rc = upload_vec(ctx, ctx->d_blk_img, ctx->h_blk_img))) return rc;
+  if ((rc = upload_vec(ctx, ctx->d_blk_nb, ctx->h_blk_nb))) return rc;
+  if ((rc = upload_vec(ctx, ctx->d_blk_slot, ctx->h_blk_slot))) return rc;
+  if ((rc = upload_vec(ctx, ctx->d_blk_order, ctx->h_blk_order))) return rc;
+  if (ctx->job_mode == 1) {
+    // block order in the tables is image-index-major; the staging arrays are call-order-major:
+    // re-pack rows so that block b of the table owns rows m_off[b]..m_off[b+1]
+    std::vector<long long> call_first_blk(ctx->job_imgs.size() + 1, 0);
+    for (size_t j = 0; j < ctx->job_imgs.size(); ++j) call_first_blk[j + 1] = call_first_blk[j] + (long long)ctx->job_nbs[j].size();
+    std::vector<int> job_pos(ctx->n_img, -1);
+    for (size_t j = 0; j < ctx->job_imgs.size(); ++j) job_pos[ctx->job_imgs[j]] = (int)j;
+    std::vector<long long> m_off(ctx->n_blk + 1, 0);
+    bool in_order = true;
+    {
+      long long b = 0;
+      for (int i = 0; i < ctx->n_img; ++i) {
+        int j = job_pos[i];
+        if (j < 0) continue;
+        if (call_first_blk[j] != b) in_order = false;
+        for (size_t k = 0; k < ctx->job_nbs[j].size(); ++k, ++b) {
+          long long cb = call_first_blk[j] + (long long)k;
+          m_off[b + 1] = m_off[b] + (ctx->h_m_off[cb + 1] - ctx->h_m_off[cb]);
+        }
+      }
+    }
+    ctx->P = m_off[ctx->n_blk];
+    ctx->n_conn = ctx->P;
+    if (ctx->P >= (1ll << 32) - 1) return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch (>= 2^32-1)");
+    ENSURE(ctx, ctx->d_m_pairs, sizeof(int) * 2 * (size_t)std::max<long long>(ctx->P, 1));
+    if (in_order) {
+      if (ctx->P > 0)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_m_pairs.p, ctx->h_m_pairs.data(), sizeof(int) * 2 * (size_t)ctx->P,
+                                   hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      long long b = 0;
+      for (int i = 0; i < ctx->n_img; ++i) {
+        int j = job_pos[i];
+        if (j < 0) continue;
+        for (size_t k = 0; k < ctx->job_nbs[j].size(); ++k, ++b) {
+          long long cb = call_first_blk[j] + (long long)k;
+          long long n = ctx->h_m_off[cb + 1] - ctx->h_m_off[cb];
+          if (n > 0)
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_m_pairs.as<int>() + 2 * m_off[b], ctx->h_m_pairs.data() + 2 * ctx->h_m_off[cb],
+                                       sizeof(int) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        }
+      }
+    }
+    if ((rc = upload_vec(ctx, ctx->d_m_off, m_off))) return rc;
+  } else if (ctx->job_mode == 2) {
+    // work items: per node, per neighbour block, chunks of 64 neighbour lines
+    ctx->h_item_off.assign(ctx->G + 1, 0);
+    long long items = 0, conns = 0;
+    for (int i = 0; i < ctx->n_img; ++i) {
+      long long per_node = 0, conn_node = 0;
+      for (long long b = ctx->h_nb_off[i]; b < ctx->h_nb_off[i + 1]; ++b) {
+        int i2 = ctx->h_blk_nb[b];
+        long long M2 = ctx->seg_off[i2 + 1] - ctx->seg_off[i2];
+        per_node += (M2 + 63) / 64;
+        conn_node += M2;
+      }
+      for (long long g = ctx->seg_off[i]; g < ctx->seg_off[i + 1]; ++g) {
+        ctx->h_item_off[g] = items;
+        items += per_node;
+        conns += conn_node;
+      }
+    }
+    ctx->h_item_off[ctx->G] = items;
+    ctx->P = items;
+    ctx->n_conn = conns;
+    if ((rc = upload_vec(ctx, ctx->d_item_off, ctx->h_item_off))) return rc;
+  } else {
+    ctx->P = 0;
+    ctx->n_conn = 0;
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->uploaded = true;
+  ctx->ran = false;
+  ctx->timers[8] = now_ms() - t0;
+  return LT_OK;
+}
+
+int lt_run_device(lt_ctx *ctx) {
+  if (!ctx->uploaded) return fail(ctx, LT_ERR_STATE, "lt_run_device before lt_upload");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const long long G = ctx->G, P = ctx->P;
+  const GenCfg gcfg = make_gen(ctx);
+  const ScoreCfg scfg = make_score(ctx);
+  ENSURE(ctx, ctx->d_err, sizeof(int));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_err.p, 0, sizeof(int), st));
+  ENSURE(ctx, ctx->d_pairs, sizeof(PairRec) * (size_t)std::max(ctx->n_blk, 1));
+  ENSURE(ctx, ctx->d_tri_off, sizeof(long long) * (size_t)(G + 1));
+  HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
+  launch_build_pairs(st, ctx->n_blk, ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_cams.as<Cam>(),
+                     ctx->d_pairs.as<PairRec>());
+  HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
+
+  if (ctx->job_mode == 1) {
+    const size_t Pn = (size_t)std::max<long long>(P, 1);
+    ENSURE(ctx, ctx->d_keys, 4 * Pn); ENSURE(ctx, ctx->d_rows, 4 * Pn); ENSURE(ctx, ctx->d_row_blk, 4 * Pn);
+    ENSURE(ctx, ctx->d_skeys, 4 * Pn); ENSURE(ctx, ctx->d_srows, 4 * Pn);
+    ENSURE(ctx, ctx->d_conn_off, sizeof(long long) * (size_t)(G + 1));
+    launch_conn_keys(st, P, ctx->n_blk, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
+                     ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
+                     ctx->d_keys.as<unsigned>(), ctx->d_rows.as<unsigned>(), ctx->d_row_blk.as<unsigned>(),
+                     ctx->d_err.as<int>());
+    if (P > 0) {
+      // keys are node ids < G plus the 0xFFFFFFFF sentinel of rejected rows (never produced here:
+      // rows are validated on the host), so G's bit width suffices
+      int end_bit = bits_for(G + 1);
+      size_t tmp = sort_temp_bytes(P, end_bit);
+      ENSURE(ctx, ctx->d_sort_tmp, std::max<size_t>(tmp, 16));
+      if (launch_sort(st, ctx->d_sort_tmp.p, tmp, P, ctx->d_keys.as<unsigned>(), ctx->d_skeys.as<unsigned>(),
+                      ctx->d_rows.as<unsigned>(), ctx->d_srows.as<unsigned>(), end_bit) != 0)
+        return fail(ctx, LT_ERR_HIP, "rocprim radix sort failed");
+    }
+    launch_node_offsets(st, P, G, ctx->d_skeys.as<unsigned>(), ctx->d_conn_off.as<long long>());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+    // staging slots: one per connection; the compacted arrays get the same capacity so that no
+    // host round trip is needed between generation and scoring
+    ENSURE(ctx, ctx->d_st_c, sizeof(Cand) * Pn); ENSURE(ctx, ctx->d_st_l, sizeof(CandLite) * Pn);
+    ENSURE(ctx, ctx->d_flags, 4 * (Pn + 1)); ENSURE(ctx, ctx->d_pos, 4 * (Pn + 1));
+    ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Pn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Pn);
+    ENSURE(ctx, ctx->d_score, 8 * Pn); ENSURE(ctx, ctx->d_edge_flag, 4 * Pn);
+    ctx->cand_cap = (long long)Pn;
+    launch_gen_matched(st, P, gcfg, ctx->d_skeys.as<unsigned>(), ctx->d_srows.as<unsigned>(),
+                       ctx->d_row_blk.as<unsigned>(), ctx->d_m_pairs.as<int>(), ctx->d_blk_img.as<int>(),
+                       ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(), ctx->d_seg_off.as<long long>(),
+                       ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
+                       ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(), ctx->d_flags.as<unsigned>());
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_flags.as<unsigned>() + P, 0, 4, st));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
+    {
+      size_t tmp = scan_temp_bytes_u32(P + 1);
+      ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
+      if (launch_scan_u32(st, ctx->d_scan_tmp.p, tmp, P + 1, ctx->d_flags.as<unsigned>(), ctx->d_pos.as<unsigned>()) != 0)
+        return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+    }
+    launch_compact(st, P, ctx->d_flags.as<unsigned>(), ctx->d_pos.as<unsigned>(), ctx->d_st_c.as<Cand>(),
+                   ctx->d_st_l.as<CandLite>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>());
+    launch_tri_offsets(st, G, ctx->d_conn_off.as<long long>(), ctx->d_pos.as<unsigned>(), P, 0u,
+                       ctx->d_tri_off.as<long long>());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
+  } else if (ctx->job_mode == 2) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+    const size_t In = (size_t)std::max<long long>(P, 1);
+    ENSURE(ctx, ctx->d_masks, 8 * In); ENSURE(ctx, ctx->d_mask_cnt, 4 * (In + 1));
+    ENSURE(ctx, ctx->d_mask_pos, 8 * (In + 1));
+    launch_gen_exhaustive(st, false, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
+                          ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
+                          ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
+                          ctx->d_masks.as<unsigned long long>(), nullptr, nullptr, nullptr);
+    launch_popc(st, P, ctx->d_masks.as<unsigned long long>(), ctx->d_mask_cnt.as<unsigned>());
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_mask_cnt.as<unsigned>() + P, 0, 4, st));
+    {
+      size_t tmp = scan_temp_bytes_u32_to_i64(P + 1);
+      ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
+      if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, P + 1, ctx->d_mask_cnt.as<unsigned>(),
+                                 ctx->d_mask_pos.as<long long>()) != 0)
+        return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+    }
+    // the candidate count sizes the compacted arrays: one small host round trip
+    long long total = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_mask_pos.as<long long>() + P, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
+    const size_t Cn = (size_t)std::max<long long>(total, 1);
+    ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);
+    ENSURE(ctx, ctx->d_score, 8 * Cn); ENSURE(ctx, ctx->d_edge_flag, 4 * Cn);
+    ctx->cand_cap = (long long)Cn;
+    launch_gen_exhaustive(st, true, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
+                          ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
+                          ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
+                          ctx->d_masks.as<unsigned long long>(), ctx->d_mask_pos.as<long long>(),
+                          ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>());
+    launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, total,
+                          ctx->d_tri_off.as<long long>());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
+  } else {
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_tri_off.p, 0, sizeof(long long) * (size_t)(G + 1), st));
+    ENSURE(ctx, ctx->d_cand, sizeof(Cand)); ENSURE(ctx, ctx->d_lite, sizeof(CandLite));
+    ENSURE(ctx, ctx->d_score, 8); ENSURE(ctx, ctx->d_edge_flag, 4);
+    for (int k = 2; k <= 4; ++k) HIPCHK(ctx, hipEventRecord(ctx->ev[k], st));
+  }
+
+  // ---- scoring ----
+  ScoreArgs sa;
+  sa.G = G; sa.tri_off = ctx->d_tri_off.as<long long>(); sa.cand = ctx->d_cand.as<Cand>();
+  sa.lite = ctx->d_lite.as<CandLite>(); sa.node_img = ctx->d_node_img.as<int>();
+  sa.nb_off = ctx->d_nb_off.as<long long>(); sa.blk_nb = ctx->d_blk_nb.as<int>();
+  sa.blk_order = ctx->d_blk_order.as<int>(); sa.seg_off = ctx->d_seg_off.as<long long>();
+  sa.segs = ctx->d_segs.as<Seg>(); sa.cams = ctx->d_cams.as<Cam>(); sa.score = ctx->d_score.as<double>();
+  sa.max_nb = ctx->max_nb;
+  if (score_lds_bytes(sa.max_nb) > 160 * 1024)
+    return fail(ctx, LT_ERR_ARGUMENT, "too many neighbours for the scoring kernel's LDS budget");
+  launch_score(st, sa, scfg);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[5], st));
+  ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));
+  ENSURE(ctx, ctx->d_nvalid, 4 * (size_t)(G + 1));
+  ENSURE(ctx, ctx->d_edge_off, 8 * (size_t)(G + 1));
+  launch_select(st, G, ctx->d_tri_off.as<long long>(), ctx->d_score.as<double>(), scfg.fullscore_th,
+                scfg.max_valid_conns, ctx->d_best_idx.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
+                ctx->d_nvalid.as<unsigned>());
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_nvalid.as<unsigned>() + G, 0, 4, st));
+  {
+    size_t tmp = scan_temp_bytes_u32_to_i64(G + 1);
+    ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
+    if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, G + 1, ctx->d_nvalid.as<unsigned>(),
+                               ctx->d_edge_off.as<long long>()) != 0)
+      return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev[6], st));
+  ENSURE(ctx, ctx->d_best_c, sizeof(Cand) * (size_t)std::max<long long>(G, 1));
+  ENSURE(ctx, ctx->d_best_score, 8 * (size_t)std::max<long long>(G, 1));
+  ENSURE(ctx, ctx->d_best_src, 8 * (size_t)std::max<long long>(G, 1));
+  ENSURE(ctx, ctx->d_ntris, 4 * (size_t)std::max<long long>(G, 1));
+  launch_gather_best(st, G, ctx->d_best_idx.as<long long>(), ctx->d_tri_off.as<long long>(), ctx->d_cand.as<Cand>(),
+                     ctx->d_lite.as<CandLite>(), ctx->d_score.as<double>(), ctx->d_node_img.as<int>(),
+                     ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_best_c.as<Cand>(),
+                     ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(), ctx->d_ntris.as<int>());
+  HIPCHK(ctx, hipEventRecord(ctx->ev[7], st));
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  int derr = 0;
+  HIPCHK(ctx, hipMemcpy(&derr, ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (derr != 0) return fail(ctx, LT_ERR_RUNTIME, "IndexError! Out-of-index matches detected on the device");
+  float ms;
+  static const int kMap[7] = {1, 2, 3, 4, 5, 6, 7};
+  for (int k = 0; k < 7; ++k) {
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
+    ctx->timers[kMap[k]] = ms;
+  }
+  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[7]));
+  ctx->timers[0] = ms;
+  ctx->ran = true;
+  ctx->downloaded = false;
+  return LT_OK;
+}
+
+int lt_download(lt_ctx *ctx) {
+  if (!ctx->ran) return fail(ctx, LT_ERR_STATE, "lt_download before lt_run_device");
+  if (ctx->downloaded) return LT_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  double t0 = now_ms();
+  hipStream_t st = ctx->stream;
+  const long long G = ctx->G;
+  // edges need their final positions: fill on device now that edge_off is known
+  std::vector<long long> tri_off(G + 1), edge_off(G + 1);
+  HIPCHK(ctx, hipMemcpyAsync(tri_off.data(), ctx->d_tri_off.p, 8 * (size_t)(G + 1), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipMemcpyAsync(edge_off.data(), ctx->d_edge_off.p, 8 * (size_t)(G + 1), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  ctx->C = tri_off[G];
+  ctx->E = edge_off[G];
+  ENSURE(ctx, ctx->d_edges, 8 * (size_t)std::max<long long>(ctx->E, 1));
+  launch_edge_fill(st, G, ctx->d_tri_off.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
+                   ctx->d_edge_off.as<long long>(), ctx->d_lite.as<CandLite>(), ctx->d_edges.as<int>());
+  std::vector<Cand> bc(G);
+  std::vector<double> bs(G);
+  std::vector<int> bsrc(2 * G), nt(G), edges(2 * std::max<long long>(ctx->E, 1));
+  if (G > 0) {
+    HIPCHK(ctx, hipMemcpyAsync(bc.data(), ctx->d_best_c.p, sizeof(Cand) * (size_t)G, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(bs.data(), ctx->d_best_score.p, 8 * (size_t)G, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(bsrc.data(), ctx->d_best_src.p, 8 * (size_t)G, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(nt.data(), ctx->d_ntris.p, 4 * (size_t)G, hipMemcpyDeviceToHost, st));
+  }
+  if (ctx->E > 0)
+    HIPCHK(ctx, hipMemcpyAsync(edges.data(), ctx->d_edges.p, 8 * (size_t)ctx->E, hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  // merge the nodes of the job's images into the persistent per-node results
+  long long pairs = 0;
+  for (int idx : ctx->job_imgs) {
+    for (long long g = ctx->seg_off[idx]; g < ctx->seg_off[idx + 1]; ++g) {
+      ctx->n_tris[g] = nt[g];
+      pairs += (long long)nt[g] * nt[g];
+      ctx->has_best[g] = nt[g] > 0 ? 1 : 0;
+      ctx->best_c[g] = bc[g];
+      ctx->best_score[g] = bs[g];
+      // src image index -> id
+      ctx->best_src2[2 * g] = nt[g] > 0 ? ctx->img_ids[bsrc[2 * g]] : 0;
+      ctx->best_src2[2 * g + 1] = nt[g] > 0 ? bsrc[2 * g + 1] : 0;
+      ctx->valid_edges[g].assign(edges.begin() + 2 * edge_off[g], edges.begin() + 2 * edge_off[g + 1]);
+    }
+  }
+  ctx->stat_pairs = pairs;
+  ctx->downloaded = true;
+  ctx->timers[9] = now_ms() - t0;
+  return LT_OK;
+}
+
+int lt_flush(lt_ctx *ctx) {
+  int rc;
+  if (ctx->job_mode == 0 && !ctx->uploaded) {
+    if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "flush before Init");
+    ctx->downloaded = true;
+    return LT_OK;
+  }
+  if (!ctx->uploaded && (rc = lt_upload(ctx))) return rc;
+  if (!ctx->ran && (rc = lt_run_device(ctx))) return rc;
+  if (!ctx->downloaded && (rc = lt_download(ctx))) return rc;
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host tail
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+int uf_root(int i, std::vector<int> &parent) {  // base/graph.cc:156-165 (iterative path compression)
+  int r = i;
+  while (parent[r] != -1) r = parent[r];
+  while (parent[i] != -1) {
+    int nx = parent[i];
+    if (nx != r) parent[i] = r;
+    i = nx;
+  }
+  return r;
+}
+
+// principal axis of a point set: eigenvector of the largest eigenvalue of the 3x3 scatter matrix
+// (cyclic Jacobi).  Replaces Eigen::JacobiSVD(...).matrixV().col(0) (merging/aggregator.cc:76-78);
+// sign fixed so that the largest-magnitude component is positive.
+void principal_axis(const std::vector<d3> &pts, double out[3]) {
+  double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (const d3 &p : pts) {
+    double v[3] = {p.x, p.y, p.z};
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) A[i][j] += v[i] * v[j];
+  }
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    double off = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]);
+    double diag = std::fabs(A[0][0]) + std::fabs(A[1][1]) + std::fabs(A[2][2]);
+    if (off <= 1e-18 * diag || off == 0.0) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (A[p][q] == 0.0) continue;
+        double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) {
+          double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int b = 0;
+  if (A[1][1] > A[b][b]) b = 1;
+  if (A[2][2] > A[b][b]) b = 2;
+  double d[3] = {V[0][b], V[1][b], V[2][b]};
+  double ax = std::fabs(d[0]), ay = std::fabs(d[1]), az = std::fabs(d[2]);
+  double lead = (ax >= ay && ax >= az) ? d[0] : (ay >= az ? d[1] : d[2]);
+  double sgn = lead < 0 ? -1.0 : 1.0;
+  for (int k = 0; k < 3; ++k) out[k] = sgn * d[k];
+}
+
+// Aggregator::aggregate_line3d_list, merging/aggregator.cc:53-101 (+ takebest :8-29)
+void aggregate(const std::vector<const Cand *> &lines, const std::vector<double> &scores, int num_outliers,
+               double out7[7]) {
+  const int n = (int)lines.size();
+  double min_unc = kMaxDist;
+  for (int i = 0; i < n; ++i)
+    if (lines[i]->unc < min_unc) min_unc = lines[i]->unc;
+  if (n < 4) {
+    double best_score = 0.0;
+    int best = -1;
+    for (int i = 0; i < n; ++i)
+      if (scores[i] > best_score) {
+        best_score = scores[i];
+        best = i;
+      }
+    if (best < 0) best = 0;
+    for (int k = 0; k < 3; ++k) {
+      out7[k] = lines[best]->s[k];
+      out7[3 + k] = lines[best]->e[k];
+    }
+    out7[6] = min_unc;
+    return;
+  }
+  d3 center = mk3(0, 0, 0);
+  for (int i = 0; i < n; ++i) {
+    center = add(center, mk3(lines[i]->s[0], lines[i]->s[1], lines[i]->s[2]));
+    center = add(center, mk3(lines[i]->e[0], lines[i]->e[1], lines[i]->e[2]));
+  }
+  double dn = (double)(2 * n);
+  center = mk3(center.x / dn, center.y / dn, center.z / dn);
+  std::vector<d3> pts(2 * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    pts[2 * i] = sub(mk3(lines[i]->s[0], lines[i]->s[1], lines[i]->s[2]), center);
+    pts[2 * i + 1] = sub(mk3(lines[i]->e[0], lines[i]->e[1], lines[i]->e[2]), center);
+  }
+  double dv[3];
+  principal_axis(pts, dv);
+  d3 direc = mk3(dv[0], dv[1], dv[2]);
+  double nn = std::sqrt(sqn(direc));
+  direc = mk3(direc.x / nn, direc.y / nn, direc.z / nn);
+  std::vector<double> proj(2 * (size_t)n);
+  for (int i = 0; i < 2 * n; ++i) proj[i] = dot(pts[i], direc);
+  std::sort(proj.begin(), proj.end());
+  double a = proj[num_outliers], b = proj[2 * n - 1 - num_outliers];
+  out7[0] = center.x + direc.x * a; out7[1] = center.y + direc.y * a; out7[2] = center.z + direc.z * a;
+  out7[3] = center.x + direc.x * b; out7[4] = center.y + direc.y * b; out7[5] = center.z + direc.z * b;
+  out7[6] = min_unc;
+}
+
+}  // namespace
+
+int lt_compute_tracks(lt_ctx *ctx) {
+  int rc = lt_flush(ctx);
+  if (rc) return rc;
+  if (ctx->cfg.merging_strategy != 0)  // global_line_triangulator.cc:314-316
+    return fail(ctx, LT_ERR_RUNTIME, "Error!The given merging strategy is not implemented");
+  double t0 = now_ms();
+  const long long G = ctx->G;
+  const int min_outer = ctx->cfg.min_num_outer_edges;
+  auto node2 = [&](long long g, int slot, int ng_line) -> long long {
+    int img = ctx->h_node_img[g];
+    return ctx->seg_off[ctx->neighbors[img][slot]] + ng_line;
+  };
+  // filterNodeByNumOuterEdges (global_line_triangulator.cc:168-232)
+  std::vector<char> flags(G, 1);
+  if (min_outer > 0) {
+    std::vector<int> counters(G);
+    std::vector<std::vector<unsigned>> parents(G);
+    for (long long g = 0; g < G; ++g) {
+      const auto &ve = ctx->valid_edges[g];
+      counters[g] = (int)(ve.size() / 2);
+      for (size_t e = 0; e + 1 < ve.size(); e += 2) parents[node2(g, ve[e], ve[e + 1])].push_back((unsigned)g);
+      if (counters[g] < min_outer) flags[g] = 0;
+    }
+    std::queue<long long> q;
+    for (long long g = 0; g < G; ++g)
+      if (!flags[g]) q.push(g);
+    while (!q.empty()) {
+      long long nd = q.front();
+      q.pop();
+      for (unsigned p : parents[nd]) {
+        if (!flags[p]) continue;
+        if (--counters[p] < min_outer) {
+          flags[p] = 0;
+          q.push(p);
+        }
+      }
+    }
+  }
+  // undirected edge set, ordered like std::set<pair<LineNode, LineNode>> (:243-261): the global
+  // node index is monotone in (img_id, line_id)
+  std::vector<unsigned long long> edges;
+  for (long long g = 0; g < G; ++g) {
+    if (!flags[g]) continue;
+    const auto &ve = ctx->valid_edges[g];
+    for (size_t e = 0; e + 1 < ve.size(); e += 2) {
+      long long h = node2(g, ve[e], ve[e + 1]);
+      if (!flags[h]) continue;
+      unsigned long long a = (unsigned long long)std::min(g, h), b = (unsigned long long)std::max(g, h);
+      edges.push_back((a << 32) | b);
+    }
+  }
+  std::sort(edges.begin(), edges.end());
+  edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+  // edge similarity: score_3d in spatial-merging mode between the two best candidates (:264-290)
+  LinkCfg3 l3 = make_l3(ctx->cfg);
+  l3.use_angle = 1; l3.use_overlap = 1; l3.use_perp = 0; l3.use_innerseg = 1; l3.use_scaleinv = 0;  // line_linker.h:123-129
+  std::vector<double> sims(edges.size());
+  const long long nE = (long long)edges.size();
+#pragma omp parallel for schedule(static)
+  for (long long e = 0; e < nE; ++e) {
+    long long a = (long long)(edges[e] >> 32), b = (long long)(edges[e] & 0xFFFFFFFFull);
+    const Cand &ca = ctx->best_c[a];
+    const Cand &cb = ctx->best_c[b];
+    L3 la{mk3(ca.s[0], ca.s[1], ca.s[2]), mk3(ca.e[0], ca.e[1], ca.e[2])};
+    L3 lb{mk3(cb.s[0], cb.s[1], cb.s[2]), mk3(cb.e[0], cb.e[1], cb.e[2])};
+    // nodes without any candidate hold a value-initialised TriTuple in the reference; its zero
+    // line scores 0 against everything (direction 0 -> angle 90 deg)
+    sims[e] = (ctx->has_best[a] && ctx->has_best[b]) ? score3d(l3, la, lb, ca.unc, cb.unc, ca.depth) : 0.0;
+  }
+  // graph in edge order (base/graph.cc:57-87)
+  std::vector<long long> gnode;              // graph node -> global node
+  std::unordered_map<long long, int> gmap;   // global node -> graph node
+  std::vector<int> e1, e2;
+  std::vector<double> es;
+  auto find_or_create = [&](long long g) {
+    auto it = gmap.find(g);
+    if (it != gmap.end()) return it->second;
+    int id = (int)gnode.size();
+    gnode.push_back(g);
+    gmap.emplace(g, id);
+    return id;
+  };
+  for (long long e = 0; e < nE; ++e) {
+    if (sims[e] == 0) continue;
+    int n1 = find_or_create((long long)(edges[e] >> 32));
+    int n2 = find_or_create((long long)(edges[e] & 0xFFFFFFFFull));
+    e1.push_back(n1); e2.push_back(n2); es.push_back(sims[e]);
+  }
+  ctx->stat_graph_nodes = (long long)gnode.size();
+  ctx->stat_graph_edges = (long long)es.size();
+  // ComputeLineTrackLabelsGreedy (merging/merging.cc:18-103)
+  const int n_nodes = (int)gnode.size();
+  std::vector<int> order(es.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::sort(order.begin(), order.end(), [&](int x, int y) {  // descending (sim, idx1, idx2)
+    if (es[x] != es[y]) return es[x] > es[y];
+    if (e1[x] != e1[y]) return e1[x] > e1[y];
+    return e2[x] > e2[y];
+  });
+  std::vector<int> parent(n_nodes, -1);
+  std::vector<std::set<int>> images_in_track(n_nodes);
+  for (int i = 0; i < n_nodes; ++i) images_in_track[i].insert(ctx->img_ids[ctx->h_node_img[gnode[i]]]);
+  for (int oi : order) {
+    int r1 = uf_root(e1[oi], parent), r2 = uf_root(e2[oi], parent);
+    if (r1 == r2) continue;
+    if (images_in_track[r1].size() < images_in_track[r2].size()) {
+      parent[r1] = r2;
+      images_in_track[r2].insert(images_in_track[r1].begin(), images_in_track[r1].end());
+      images_in_track[r1].clear();
+    } else {
+      parent[r2] = r1;
+      images_in_track[r1].insert(images_in_track[r2].begin(), images_in_track[r2].end());
+      images_in_track[r2].clear();
+    }
+  }
+  // NOTE: the reference's recursive root lookup compresses paths as a side effect and reads
+  // parent_nodes[node] afterwards; labels are assigned from the parent array as it stands after
+  // the union loop.  uf_root() above applies the same full path compression per lookup.
+  std::vector<int> labels(n_nodes, -1);
+  int n_tracks = 0;
+  for (int i = 0; i < n_nodes; ++i) {
+    if (parent[i] == -1) continue;
+    int p = parent[i];
+    if (parent[p] == -1 && labels[p] == -1) labels[p] = n_tracks++;
+  }
+  for (int i = 0; i < n_nodes; ++i) {
+    if (parent[i] == -1) continue;
+    labels[i] = labels[uf_root(i, parent)];
+  }
+  // build_tracks_from_clusters (:293-351)
+  ctx->tracks.clear();
+  if (n_nodes > 0) {
+    int mx = -1;
+    for (int l : labels) mx = std::max(mx, l);
+    ctx->tracks.resize(mx + 1);
+    for (int i = 0; i < n_nodes; ++i) {
+      int tl = labels[i];
+      if (tl == -1) continue;
+      long long g = gnode[i];
+      int img = ctx->h_node_img[g];
+      Track &tr = ctx->tracks[tl];
+      tr.node_ids.push_back(i);
+      tr.img_ids.push_back(ctx->img_ids[img]);
+      tr.line_ids.push_back((int)(g - ctx->seg_off[img]));
+      tr.scores.push_back(ctx->best_score[g]);
+      tr.gnodes.push_back(g);
+    }
+    const long long nT = (long long)ctx->tracks.size();
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long long t = 0; t < nT; ++t) {
+      Track &tr = ctx->tracks[t];
+      std::vector<const Cand *> lines;
+      for (long long g : tr.gnodes) lines.push_back(&ctx->best_c[g]);
+      aggregate(lines, tr.scores, ctx->cfg.num_outliers_aggregator, tr.line);
+    }
+  }
+  ctx->tracks_done = true;
+  ctx->timers[10] = now_ms() - t0;
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// getters
+// ---------------------------------------------------------------------------------------------
+int64_t lt_count_images(lt_ctx *ctx) { return ctx->n_img; }
+int64_t lt_count_lines(lt_ctx *ctx, int img_id) {
+  auto it = ctx->id2idx.find(img_id);
+  if (it == ctx->id2idx.end()) {
+    ctx->err = "unknown image id " + std::to_string(img_id);
+    return -1;
+  }
+  return ctx->seg_off[it->second + 1] - ctx->seg_off[it->second];
+}
+int64_t lt_num_nodes(lt_ctx *ctx) { return ctx->G; }
+
+int lt_get_best(lt_ctx *ctx, double *out_line10, double *out_score, int32_t *out_src2, uint8_t *out_has_best) {
+  int rc = lt_flush(ctx);
+  if (rc) return rc;
+  for (long long g = 0; g < ctx->G; ++g) {
+    const Cand &c = ctx->best_c[g];
+    double *o = out_line10 + 10 * g;
+    bool hb = ctx->has_best[g];
+    for (int k = 0; k < 3; ++k) { o[k] = hb ? c.s[k] : 0.0; o[3 + k] = hb ? c.e[k] : 0.0; }
+    o[6] = hb ? c.depth[0] : 0.0; o[7] = hb ? c.depth[1] : 0.0; o[8] = hb ? c.unc : 0.0; o[9] = hb ? c.score3 : 0.0;
+    out_score[g] = hb ? ctx->best_score[g] : 0.0;
+    out_src2[2 * g] = ctx->best_src2[2 * g];
+    out_src2[2 * g + 1] = ctx->best_src2[2 * g + 1];
+    out_has_best[g] = ctx->has_best[g];
+  }
+  return LT_OK;
+}
+
+int lt_get_num_tris(lt_ctx *ctx, int32_t *out) {
+  int rc = lt_flush(ctx);
+  if (rc) return rc;
+  std::memcpy(out, ctx->n_tris.data(), 4 * (size_t)ctx->G);
+  return LT_OK;
+}
+
+int64_t lt_num_valid_edges(lt_ctx *ctx) {
+  if (lt_flush(ctx)) return -1;
+  int64_t n = 0;
+  for (auto &v : ctx->valid_edges) n += (int64_t)v.size() / 2;
+  return n;
+}
+
+int lt_get_valid_edges(lt_ctx *ctx, int64_t *out_off, int32_t *out_edges2) {
+  int rc = lt_flush(ctx);
+  if (rc) return rc;
+  int64_t e = 0;
+  out_off[0] = 0;
+  for (long long g = 0; g < ctx->G; ++g) {
+    const auto &v = ctx->valid_edges[g];
+    if (!v.empty()) std::memcpy(out_edges2 + 2 * e, v.data(), 4 * v.size());
+    e += (int64_t)v.size() / 2;
+    out_off[g + 1] = e;
+  }
+  return LT_OK;
+}
+
+int64_t lt_num_all_tris(lt_ctx *ctx) {
+  if (lt_flush(ctx)) return -1;
+  return ctx->C;
+}
+
+int lt_get_all_tris(lt_ctx *ctx, int64_t *out_off, double *out_line10, double *out_score, int32_t *out_src2) {
+  int rc = lt_flush(ctx);
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const long long G = ctx->G, C = ctx->C;
+  std::vector<long long> tri_off(G + 1);
+  HIPCHK(ctx, hipMemcpy(tri_off.data(), ctx->d_tri_off.p, 8 * (size_t)(G + 1), hipMemcpyDeviceToHost));
+  for (long long g = 0; g <= G; ++g) out_off[g] = tri_off[g];
+  if (C == 0) return LT_OK;
+  std::vector<Cand> c(C);
+  std::vector<CandLite> l(C);
+  HIPCHK(ctx, hipMemcpy(c.data(), ctx->d_cand.p, sizeof(Cand) * (size_t)C, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(l.data(), ctx->d_lite.p, sizeof(CandLite) * (size_t)C, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(out_score, ctx->d_score.p, 8 * (size_t)C, hipMemcpyDeviceToHost));
+  for (long long g = 0; g < G; ++g) {
+    int img = ctx->h_node_img[g];
+    for (long long t = tri_off[g]; t < tri_off[g + 1]; ++t) {
+      double *o = out_line10 + 10 * t;
+      for (int k = 0; k < 3; ++k) { o[k] = c[t].s[k]; o[3 + k] = c[t].e[k]; }
+      o[6] = c[t].depth[0]; o[7] = c[t].depth[1]; o[8] = c[t].unc; o[9] = c[t].score3;
+      out_src2[2 * t] = ctx->img_ids[ctx->neighbors[img][l[t].nb_slot]];
+      out_src2[2 * t + 1] = l[t].ng_line;
+    }
+  }
+  return LT_OK;
+}
+
+int64_t lt_num_tracks(lt_ctx *ctx) { return (int64_t)ctx->tracks.size(); }
+int64_t lt_num_track_members(lt_ctx *ctx) {
+  int64_t n = 0;
+  for (auto &t : ctx->tracks) n += (int64_t)t.img_ids.size();
+  return n;
+}
+int lt_get_tracks(lt_ctx *ctx, double *out_line7, int64_t *out_off, int32_t *out_img_ids, int32_t *out_line_ids,
+                  int32_t *out_node_ids, double *out_scores, double *out_line3d6) {
+  int64_t e = 0, ti = 0;
+  out_off[0] = 0;
+  for (auto &tr : ctx->tracks) {
+    std::memcpy(out_line7 + 7 * ti, tr.line, 56);
+    for (size_t k = 0; k < tr.img_ids.size(); ++k, ++e) {
+      out_img_ids[e] = tr.img_ids[k];
+      out_line_ids[e] = tr.line_ids[k];
+      out_node_ids[e] = tr.node_ids[k];
+      out_scores[e] = tr.scores[k];
+      const Cand &c = ctx->best_c[tr.gnodes[k]];
+      for (int q = 0; q < 3; ++q) { out_line3d6[6 * e + q] = c.s[q]; out_line3d6[6 * e + 3 + q] = c.e[q]; }
+    }
+    out_off[++ti] = e;
+  }
+  return LT_OK;
+}
+
+int lt_get_stats(lt_ctx *ctx, int64_t out[8]) {
+  out[0] = ctx->n_conn; out[1] = ctx->C; out[2] = ctx->stat_pairs; out[3] = ctx->E;
+  out[4] = ctx->stat_graph_nodes; out[5] = ctx->stat_graph_edges; out[6] = (int64_t)ctx->tracks.size();
+  out[7] = ctx->G;
+  return LT_OK;
+}
+int lt_get_timers(lt_ctx *ctx, double out[16]) {
+  std::memcpy(out, ctx->timers, sizeof(ctx->timers));
+  return LT_OK;
+}
+
+// ---- free functions ----
+static int fn_query(lt_ctx *ctx, const double *seg1, const double *cam1, const double *seg2, const double *cam2,
+                    int by_endpoints, double out32[32]) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  double in[30];
+  std::memcpy(in, seg1, 32); std::memcpy(in + 4, cam1, 88); std::memcpy(in + 15, seg2, 32); std::memcpy(in + 19, cam2, 88);
+  DevBuf din, dout;
+  ENSURE(ctx, din, sizeof(in)); ENSURE(ctx, dout, 32 * 8);
+  HIPCHK(ctx, hipMemcpyAsync(din.p, in, sizeof(in), hipMemcpyHostToDevice, ctx->stream));
+  launch_fn_query(ctx->stream, din.as<double>(), by_endpoints, dout.as<double>());
+  HIPCHK(ctx, hipMemcpyAsync(out32, dout.p, 32 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  din.release(); dout.release();
+  return LT_OK;
+}
+int lt_fn_get_normal_direction(lt_ctx *ctx, const double seg[4], const double cam[11], double out[3]) {
+  double o[32];
+  int rc = fn_query(ctx, seg, cam, seg, cam, 0, o);
+  if (rc) return rc;
+  std::memcpy(out, o, 24);
+  return LT_OK;
+}
+int lt_fn_compute_fundamental_matrix(lt_ctx *ctx, const double cam1[11], const double cam2[11], double out[9]) {
+  double o[32], seg[4] = {0, 0, 1, 1};
+  int rc = fn_query(ctx, seg, cam1, seg, cam2, 0, o);
+  if (rc) return rc;
+  std::memcpy(out, o + 3, 72);
+  return LT_OK;
+}
+int lt_fn_compute_epipolar_IoU(lt_ctx *ctx, const double seg1[4], const double cam1[11], const double seg2[4],
+                               const double cam2[11], double *out) {
+  double o[32];
+  int rc = fn_query(ctx, seg1, cam1, seg2, cam2, 0, o);
+  if (rc) return rc;
+  *out = o[12];
+  return LT_OK;
+}
+int lt_fn_triangulate_line(lt_ctx *ctx, const double seg1[4], const double cam1[11], const double seg2[4],
+                           const double cam2[11], int by_endpoints, double out_line10[10]) {
+  double o[32];
+  int rc = fn_query(ctx, seg1, cam1, seg2, cam2, by_endpoints, o);
+  if (rc) return rc;
+  std::memcpy(out_line10, o + 13, 80);
+  return LT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,825 @@
+// lt_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) of the line-triangulation path.
+//
+//   k_build_cams / k_build_segs / k_build_pairs : hoisted invariants (per image, per 2D segment,
+//       per (image, neighbour) pair) -- the reference recomputes them per connection.
+//   k_conn_keys + radix sort + k_node_offsets   : matched mode, group connections by node
+//       (image, line) in the reference's candidate order (neighbour-major, match-row order).
+//   k_gen_matched / k_gen_exhaustive            : HOT LOOP 1, triangulateOneNode
+//       (triangulation/base_line_triangulator.cc:161-337): degeneracy gates, weak epipolar IoU,
+//       ray/plane triangulation, sensitivity gate, uncertainty, ranges.
+//   k_compact                                   : stable stream compaction of the survivors.
+//   k_score                                     : HOT LOOP 2, scoreOneNode
+//       (triangulation/global_line_triangulator.cc:71-116): one wave64 per node, O(n^2) sweep
+//       with a cosine-domain early exit, dense evaluation of the surviving pairs from an LDS
+//       work queue, per-neighbour-image maxima in LDS (ds_max_u64), ordered sum.
+//   k_select                                    : per-node strict arg-max (lowest index wins ties,
+//       global_line_triangulator.cc:145-153) and valid-edge flags (:118-142).
+//
+// Nothing here is a dense contraction, so there is no MFMA; the work is FP64 VALU + gathers that
+// hit L2/MALL, and the rules that matter are coalescing, wave64 ballots/shuffles, LDS atomics.
+// Compiled with -ffp-contract=off (see lt_geom.h).
+
+#include "lt_device.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace lt {
+
+static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+static __device__ __forceinline__ unsigned long long lanemask_lt() {
+  return (1ull << lane_id()) - 1ull;
+}
+// lanes of ONE wave exchanging data through LDS: order the DS traffic, no s_barrier needed
+static __device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+// invariants
+// ---------------------------------------------------------------------------------------------
+__global__ void k_build_cams(int n, const double *__restrict__ kvec, const double *__restrict__ qvec,
+                             const double *__restrict__ tvec, Cam *__restrict__ cams) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Cam c;
+  cam_build(kvec + 4 * i, qvec + 4 * i, tvec + 3 * i, &c);
+  cams[i] = c;
+}
+
+__global__ void k_build_segs(long long n_segs, int n_img, const long long *__restrict__ seg_off,
+                             const double *__restrict__ segs, double halfpix,
+                             const Cam *__restrict__ cams, Seg *__restrict__ out) {
+  long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_segs) return;
+  // image of this segment: upper_bound(seg_off, s) - 1
+  int lo = 0, hi = n_img;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (seg_off[mid] <= s) lo = mid; else hi = mid;
+  }
+  const double *p = segs + 4 * s;
+  Seg r;
+  // offsetHalfPixel (base_line_triangulator.cc:33-43): start + (0.5, 0.5) when add_halfpix
+  double x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+  if (halfpix != 0.0) {
+    x1 = x1 + halfpix; y1 = y1 + halfpix; x2 = x2 + halfpix; y2 = y2 + halfpix;
+  }
+  seg_build(cams[lo], x1, y1, x2, y2, &r);
+  out[s] = r;
+}
+
+__global__ void k_build_pairs(int n_blk, const int *__restrict__ blk_img,
+                              const int *__restrict__ blk_nb, const Cam *__restrict__ cams,
+                              PairRec *__restrict__ out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_blk) return;
+  PairRec p;
+  pair_build(cams[blk_img[b]], cams[blk_nb[b]], &p);
+  out[b] = p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// matched mode: connection keys
+// ---------------------------------------------------------------------------------------------
+// One thread per match row.  key = global node id of (image, line_id); also records the
+// neighbour block of the row.  Out-of-range ids raise the error flag (the reference throws
+// "IndexError! Out-of-index matches ...", base_line_triangulator.cc:87-94).
+__global__ void k_conn_keys(long long P, int n_blk, const long long *__restrict__ m_off,
+                            const int *__restrict__ m_pairs, const int *__restrict__ blk_img,
+                            const int *__restrict__ blk_nb, const long long *__restrict__ seg_off,
+                            unsigned *__restrict__ keys, unsigned *__restrict__ rows,
+                            unsigned *__restrict__ row_blk, int *__restrict__ err) {
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P) return;
+  int lo = 0, hi = n_blk;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (m_off[mid] <= r) lo = mid; else hi = mid;
+  }
+  int i1 = blk_img[lo], i2 = blk_nb[lo];
+  int line = m_pairs[2 * r], ng_line = m_pairs[2 * r + 1];
+  long long M1 = seg_off[i1 + 1] - seg_off[i1], M2 = seg_off[i2 + 1] - seg_off[i2];
+  unsigned key = 0xFFFFFFFFu;  // invalid rows sort to the end and are skipped
+  if (line < 0 || line >= M1) {
+    atomicExch(err, LT_ERR_MATCH_LINE_RANGE);
+  } else if (ng_line < 0 || ng_line >= M2) {
+    atomicExch(err, LT_ERR_MATCH_NGLINE_RANGE);
+  } else {
+    key = (unsigned)(seg_off[i1] + line);
+  }
+  keys[r] = key;
+  rows[r] = (unsigned)r;
+  row_blk[r] = (unsigned)lo;
+}
+
+// conn_off[g] = first sorted position whose key >= g  (keys sorted ascending)
+__global__ void k_node_offsets(long long P, long long G, const unsigned *__restrict__ skeys,
+                               long long *__restrict__ conn_off) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > P) return;
+  long long a = (t == 0) ? -1 : (long long)skeys[t - 1];
+  long long b = (t == P) ? G : (long long)skeys[t];
+  if (a >= G) return;
+  if (b > G) b = G;
+  for (long long g = a + 1; g <= b; ++g) conn_off[g] = t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HOT LOOP 1: one connection -> at most one candidate
+// ---------------------------------------------------------------------------------------------
+struct GenOut {
+  Cand c;
+  CandLite l;
+};
+
+// triangulate_point, functions.cc:100-117 (2x2 LDLT solve with diagonal pivoting)
+static __device__ __forceinline__ bool tri_point(const Cam &c1, d3 r1, const Cam &c2, d3 r2, d3 *out) {
+  d3 C1 = cam_center(c1), C2 = cam_center(c2);
+  double a00 = dot(r1, r1), a10 = -dot(r2, r1), a11 = dot(r2, r2);
+  double b0 = dot(r1, sub(C2, C1));
+  double b1 = dot(r2, sub(C1, C2));
+  bool sw = fabs(a11) > fabs(a00);
+  double dd0 = sw ? a11 : a00, dd1 = sw ? a00 : a11;
+  double q0 = sw ? b1 : b0, q1 = sw ? b0 : b1;
+  double l10 = a10 / dd0;
+  double s1d = dd1 - l10 * (dd0 * l10);
+  double y1 = q1 - l10 * q0;
+  double z0 = q0 / dd0, z1 = y1 / s1d;
+  double s0 = z0 - l10 * z1;
+  double x0 = sw ? z1 : s0, x1 = sw ? s0 : z1;
+  d3 p = add(add(add(scale(r1, x0), C1), scale(r2, x1)), C2);
+  p = d3{0.5 * p.x, 0.5 * p.y, 0.5 * p.z};
+  if (cam_depth(c1, p) < kEps || cam_depth(c2, p) < kEps) return false;
+  *out = p;
+  return true;
+}
+
+// Line3d::sensitivity, linebase.cc:100-107
+static __device__ __forceinline__ double sensitivity(const Cam &c, d3 s, d3 e, d3 dir3) {
+  d2 ps = cam_project(c, s), pe = cam_project(c, e);
+  d2 mid = d2{0.5 * (ps.x + pe.x), 0.5 * (ps.y + pe.y)};
+  d3 ray = cam_ray(c, mid);
+  double cv = fabs(dot(dir3, ray));
+  return 90 - acos(cv) * 180.0 / kPi;
+}
+
+// compute_epipolar_IoU (functions.cc:76-98) with the fundamental matrix hoisted per image pair
+static __device__ __forceinline__ double epipolar_iou(const Seg &s1, const Seg &s2, const double *F) {
+  L2 l2{mk2(s2.x1, s2.y1), mk2(s2.x2, s2.y2)};
+  double ln2 = len(l2);
+  d3 lc2 = mk3(s2.lc[0], s2.lc[1], s2.lc[2]);
+  d3 eps = unit(mv(F, mk3(s1.x1, s1.y1, 1.0)));
+  d3 hs = cross(lc2, eps);
+  double zs = hs.z + kEps;
+  d2 cs = d2{hs.x / zs, hs.y / zs};
+  d3 epe = unit(mv(F, mk3(s1.x2, s1.y2, 1.0)));
+  d3 he = cross(lc2, epe);
+  double ze = he.z + kEps;
+  d2 ce = d2{he.x / ze, he.y / ze};
+  d2 dv = dir(l2);
+  double c1v = dot(sub(cs, l2.s), dv) / ln2;
+  double c2v = dot(sub(ce, l2.s), dv) / ln2;
+  if (c1v > c2v) {
+    double t = c1v; c1v = c2v; c2v = t;
+  }
+  return (dmin(c2v, 1.0) - dmax(c1v, 0.0)) / (dmax(c2v, 1.0) - dmin(c1v, 0.0));
+}
+
+// line_triangulation (functions.cc:194-233): x = (A^-1 B)[0], A = [c1 | -c2s | -c2e]
+static __device__ __forceinline__ bool tri_line(const Cam &c1, const Cam &c2, const Seg &s1, const Seg &s2,
+                                                const double *Bv, d3 *ps_o, d3 *pe_o, double *z_start,
+                                                double *z_end, double *d21, double *d22) {
+  d3 r1s = mk3(s1.rs[0], s1.rs[1], s1.rs[2]), r1e = mk3(s1.re[0], s1.re[1], s1.re[2]);
+  d3 c2s = mk3(s2.rs[0], s2.rs[1], s2.rs[2]), c2e = mk3(s2.re[0], s2.re[1], s2.re[2]);
+  d3 u = mk3(-c2s.x, -c2s.y, -c2s.z), v = mk3(-c2e.x, -c2e.y, -c2e.z);
+  // cofactors (j,0) of A do not involve column 0: shared by the start and the end solve
+  double k0 = u.y * v.z - v.y * u.z;
+  double k1 = u.z * v.x - v.z * u.x;
+  double k2 = u.x * v.y - v.x * u.y;
+  d3 B = mk3(Bv[0], Bv[1], Bv[2]);
+  d3 C1 = cam_center(c1);
+  d3 ps, pe;
+  {
+    double det = (k0 * r1s.x + k1 * r1s.y) + k2 * r1s.z;
+    double id = 1.0 / det;
+    double x0 = ((k0 * id) * B.x + (k1 * id) * B.y) + (k2 * id) * B.z;
+    ps = add(scale(r1s, x0), C1);
+    *z_start = cam_depth(c1, ps);
+  }
+  {
+    double det = (k0 * r1e.x + k1 * r1e.y) + k2 * r1e.z;
+    double id = 1.0 / det;
+    double x0 = ((k0 * id) * B.x + (k1 * id) * B.y) + (k2 * id) * B.z;
+    pe = add(scale(r1e, x0), C1);
+    *z_end = cam_depth(c1, pe);
+  }
+  *ps_o = ps;
+  *pe_o = pe;
+  if (*z_start < kEps || *z_end < kEps) return false;
+  *d21 = cam_depth(c2, ps);
+  *d22 = cam_depth(c2, pe);
+  if (*d21 < kEps || *d22 < kEps) return false;
+  if (isnan(ps.x) || isnan(pe.x)) return false;
+  return true;
+}
+
+static __device__ __forceinline__ bool gen_one(const GenCfg &cfg, const Cam &c1, const Cam &c2,
+                                               const Seg &s1, const Seg &s2, const PairRec &pr,
+                                               GenOut *out) {
+  L2 l1{mk2(s1.x1, s1.y1), mk2(s1.x2, s1.y2)};
+  L2 l2{mk2(s2.x1, s2.y1), mk2(s2.x2, s2.y2)};
+  if (len(l1) <= cfg.min_length_2d) return false;  // base_line_triangulator.cc:166
+  double ln2 = len(l2);
+  if (ln2 <= cfg.min_length_2d) return false;      // :177
+  if (cfg.disable_algebraic) return false;
+  // degeneracy by ray-plane angles (:293-302).  angle = 90 - acos(a) 180/pi < th  <=>  a < sin(th)
+  // up to libm rounding: outside the [sin_lo, sin_hi] band the cosine alone decides.
+  d3 n2 = mk3(s2.n[0], s2.n[1], s2.n[2]);
+  d3 r1s = mk3(s1.rs[0], s1.rs[1], s1.rs[2]), r1e = mk3(s1.re[0], s1.re[1], s1.re[2]);
+  double as = fabs(dot(n2, r1s));
+  if (as < cfg.sin_lo) return false;
+  if (!(as > cfg.sin_hi)) {
+    double ang = 90 - acos(as) * 180.0 / kPi;
+    if (ang < cfg.angle_th) return false;
+  }
+  double ae = fabs(dot(n2, r1e));
+  if (ae < cfg.sin_lo) return false;
+  if (!(ae > cfg.sin_hi)) {
+    double ang = 90 - acos(ae) * 180.0 / kPi;
+    if (ang < cfg.angle_th) return false;
+  }
+  // weak epipolar constraint (:305-307)
+  {
+    double iou = epipolar_iou(s1, s2, pr.F);
+    if (iou < cfg.iou_th) return false;
+  }
+  d3 ps, pe;
+  double z_start, z_end, d21, d22;
+  if (!cfg.use_endpoints) {
+    if (!tri_line(c1, c2, s1, s2, pr.B, &ps, &pe, &z_start, &z_end, &d21, &d22)) return false;
+  } else {
+    // triangulate_line_by_endpoints (functions.cc:172-190)
+    d3 c2s = mk3(s2.rs[0], s2.rs[1], s2.rs[2]), c2e = mk3(s2.re[0], s2.re[1], s2.re[2]);
+    if (!tri_point(c1, r1s, c2, c2s, &ps)) return false;
+    if (!tri_point(c1, r1e, c2, c2e, &pe)) return false;
+    z_start = cam_depth(c1, ps);
+    z_end = cam_depth(c1, pe);
+    d21 = cam_depth(c2, ps);
+    d22 = cam_depth(c2, pe);
+  }
+  d3 dir3 = unit(sub(pe, ps));
+  // sensitivity gate (:315-317): rejected only if too sensitive in BOTH views
+  if (sensitivity(c1, ps, pe, dir3) > cfg.sens_th && sensitivity(c2, ps, pe, dir3) > cfg.sens_th)
+    return false;
+  // uncertainty (:319-321; linebase.cc:109-116; camera.cc:228-242)
+  double u1 = cfg.var2d * ((z_start + z_end) / 2.0) / c1.f;
+  double u2 = cfg.var2d * ((d21 + d22) / 2.0) / c2.f;
+  // ranges (:330-333; functions.cc:8-26)
+  if (cfg.use_ranges) {
+    if (ps.x < cfg.lo[0] || ps.x > cfg.hi[0]) return false;
+    if (ps.y < cfg.lo[1] || ps.y > cfg.hi[1]) return false;
+    if (ps.z < cfg.lo[2] || ps.z > cfg.hi[2]) return false;
+    if (pe.x < cfg.lo[0] || pe.x > cfg.hi[0]) return false;
+    if (pe.y < cfg.lo[1] || pe.y > cfg.hi[1]) return false;
+    if (pe.z < cfg.lo[2] || pe.z > cfg.hi[2]) return false;
+  }
+  out->c.s[0] = ps.x; out->c.s[1] = ps.y; out->c.s[2] = ps.z;
+  out->c.e[0] = pe.x; out->c.e[1] = pe.y; out->c.e[2] = pe.z;
+  out->c.depth[0] = z_start; out->c.depth[1] = z_end;
+  out->c.unc = dmin(u1, u2);
+  out->c.score3 = 1.0;
+  out->l.dir[0] = dir3.x; out->l.dir[1] = dir3.y; out->l.dir[2] = dir3.z;
+  return true;
+}
+
+// Matched mode: thread t handles the t-th connection in node-major order.  Survivors are
+// written to slot t of the staging arrays; k_compact squeezes them (stable) afterwards.
+__global__ void __launch_bounds__(256)
+k_gen_matched(long long P, GenCfg cfg, const unsigned *__restrict__ skeys,
+              const unsigned *__restrict__ srows, const unsigned *__restrict__ row_blk,
+              const int *__restrict__ m_pairs, const int *__restrict__ blk_img,
+              const int *__restrict__ blk_nb, const int *__restrict__ blk_slot,
+              const long long *__restrict__ seg_off, const Cam *__restrict__ cams,
+              const Seg *__restrict__ segs, const PairRec *__restrict__ pairs,
+              Cand *__restrict__ st_c, CandLite *__restrict__ st_l, unsigned *__restrict__ flags) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  unsigned key = skeys[t];
+  unsigned f = 0;
+  if (key != 0xFFFFFFFFu) {
+    unsigned row = srows[t];
+    unsigned b = row_blk[row];
+    int ng_line = m_pairs[2 * (long long)row + 1];
+    int i1 = blk_img[b], i2 = blk_nb[b];
+    GenOut o;
+    if (gen_one(cfg, cams[i1], cams[i2], segs[key], segs[seg_off[i2] + ng_line], pairs[b], &o)) {
+      o.l.nb_slot = blk_slot[b];
+      o.l.ng_line = ng_line;
+      st_c[t] = o.c;
+      st_l[t] = o.l;
+      f = 1;
+    }
+  }
+  flags[t] = f;
+}
+
+// Exhaustive mode (TriangulateImageExhaustiveMatch, base_line_triangulator.cc:111-136): the
+// connection list is implicit.  Work item = (node, neighbour block, chunk of 64 ng lines);
+// the wave writes its ballot of survivors as one 64-bit word (pass 1), and after a scan over the
+// popcounts pass 2 re-derives the survivors and writes them at their final, ordered position.
+template <bool kFill>
+__global__ void __launch_bounds__(256)
+k_gen_exhaustive(long long n_items, GenCfg cfg, const long long *__restrict__ item_off /* per node: first item */,
+                 long long G, const int *__restrict__ node_img, const long long *__restrict__ nb_off,
+                 const int *__restrict__ blk_nb, const long long *__restrict__ seg_off,
+                 const Cam *__restrict__ cams, const Seg *__restrict__ segs,
+                 const PairRec *__restrict__ pairs, unsigned long long *__restrict__ masks,
+                 const long long *__restrict__ mask_pos, Cand *__restrict__ out_c,
+                 CandLite *__restrict__ out_l) {
+  long long item = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (item >= n_items) return;
+  // node of this item: upper_bound(item_off, item) - 1
+  long long lo = 0, hi = G;
+  while (hi - lo > 1) {
+    long long mid = (lo + hi) >> 1;
+    if (item_off[mid] <= item) lo = mid; else hi = mid;
+  }
+  long long g = lo;
+  int i1 = node_img[g];
+  long long rem = item - item_off[g];  // chunk index inside the node, neighbour-major
+  long long b = nb_off[i1];
+  const long long b_end = nb_off[i1 + 1];
+  int i2 = -1;
+  long long M2 = 0;
+  for (; b < b_end; ++b) {
+    i2 = blk_nb[b];
+    M2 = seg_off[i2 + 1] - seg_off[i2];
+    long long chunks = (M2 + 63) >> 6;
+    if (rem < chunks) break;
+    rem -= chunks;
+  }
+  if (b >= b_end) return;
+  int ng_line = (int)(rem << 6) + lane_id();
+  bool ok = false;
+  GenOut o;
+  bool candidate_lane = ng_line < M2;
+  if (kFill) candidate_lane = candidate_lane && ((masks[item] >> lane_id()) & 1ull);
+  if (candidate_lane)
+    ok = gen_one(cfg, cams[i1], cams[i2], segs[g], segs[seg_off[i2] + ng_line], pairs[b], &o);
+  unsigned long long m = __ballot(ok);
+  if (!kFill) {
+    if (lane_id() == 0) masks[item] = m;
+  } else if (ok) {
+    long long pos = mask_pos[item] + __popcll(m & lanemask_lt());
+    o.l.nb_slot = (int)(b - nb_off[i1]);
+    o.l.ng_line = ng_line;
+    out_c[pos] = o.c;
+    out_l[pos] = o.l;
+  }
+}
+
+// stable compaction: pos = exclusive scan of flags
+__global__ void k_compact(long long P, const unsigned *__restrict__ flags,
+                          const unsigned *__restrict__ pos, const Cand *__restrict__ st_c,
+                          const CandLite *__restrict__ st_l, Cand *__restrict__ out_c,
+                          CandLite *__restrict__ out_l) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P || !flags[t]) return;
+  out_c[pos[t]] = st_c[t];
+  out_l[pos[t]] = st_l[t];
+}
+
+// tri_off[g] = pos[conn_off[g]] (pos has P+1 entries: exclusive scan + total)
+__global__ void k_tri_offsets(long long G, const long long *__restrict__ conn_off,
+                              const unsigned *__restrict__ pos, long long P, unsigned total,
+                              long long *__restrict__ tri_off) {
+  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > G) return;
+  long long c = conn_off[g];
+  tri_off[g] = (c >= P) ? (long long)total : (long long)pos[c];
+}
+
+__global__ void k_popc(long long n, const unsigned long long *__restrict__ masks,
+                       unsigned *__restrict__ cnt) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) cnt[t] = (unsigned)__popcll(masks[t]);
+}
+
+// tri_off[g] = mask_pos[item_off[g]]
+__global__ void k_tri_offsets_ex(long long G, const long long *__restrict__ item_off,
+                                 const long long *__restrict__ mask_pos, long long n_items,
+                                 long long total, long long *__restrict__ tri_off) {
+  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > G) return;
+  long long it = item_off[g];
+  tri_off[g] = (it >= n_items) ? total : mask_pos[it];
+}
+
+// ---------------------------------------------------------------------------------------------
+// HOT LOOP 2: scoreOneNode.  One wave64 per node; lane = candidate i of the current 64-tile.
+// ---------------------------------------------------------------------------------------------
+constexpr int kQCap = 256;       // per-wave pair queue (entries), drained when > kQCap - 64
+constexpr int kWavesPerBlock = 4;
+
+
+// dense evaluation of one (i, j) pair: score3d (shared-parent mode) then score2d of l_i projected
+// into the view of j against the 2D segment that generated j.  global_line_triangulator.cc:97-104
+static __device__ __forceinline__ double pair_score(const ScoreCfg &cfg, const double *ti /*11*/,
+                                                    const Cand &cj, const Cam &camj, const Seg &sj) {
+  L3 li{mk3(ti[0], ti[1], ti[2]), mk3(ti[3], ti[4], ti[5])};
+  L3 lj{mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2])};
+  double dep[2] = {ti[9], ti[10]};
+  double s3 = score3d(cfg.l3, li, lj, 0.0, 0.0, dep);
+  if (s3 == 0) return 0.0;
+  L2 pi{cam_project(camj, li.s), cam_project(camj, li.e)};
+  L2 sg{mk2(sj.x1, sj.y1), mk2(sj.x2, sj.y2)};
+  double s2 = score2d(cfg.l2, pi, sg);
+  if (s2 == 0) return 0.0;
+  return dmin(s3, s2);
+}
+
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+k_score(ScoreArgs a, ScoreCfg cfg) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  // per-wave LDS: S[max_nb][64] u64 | tile[64][11] double | queue[kQCap] u32
+  const size_t per_wave = (size_t)a.max_nb * 64 * 8 + 64 * 11 * 8 + kQCap * 4;
+  unsigned char *base = smem_raw + per_wave * wave;
+  unsigned long long *S = reinterpret_cast<unsigned long long *>(base);
+  double *tile = reinterpret_cast<double *>(base + (size_t)a.max_nb * 64 * 8);
+  unsigned *queue = reinterpret_cast<unsigned *>(base + (size_t)a.max_nb * 64 * 8 + 64 * 11 * 8);
+
+  long long g = (long long)blockIdx.x * kWavesPerBlock + wave;
+  if (g >= a.G) return;
+  const long long off = a.tri_off[g];
+  const int n = (int)(a.tri_off[g + 1] - off);
+  if (n == 0) return;
+  const int img = a.node_img[g];
+  const long long nb0 = a.nb_off[img];
+  const int n_nb = (int)(a.nb_off[img + 1] - nb0);
+
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    const bool active = i < n;
+    double dix = 0, diy = 0, diz = 0;
+    int sloti = -1;
+    if (active) {
+      const CandLite li = a.lite[off + i];
+      const Cand ci = a.cand[off + i];
+      dix = li.dir[0]; diy = li.dir[1]; diz = li.dir[2];
+      sloti = li.nb_slot;
+      double *t = tile + lane * 11;
+      t[0] = ci.s[0]; t[1] = ci.s[1]; t[2] = ci.s[2];
+      t[3] = ci.e[0]; t[4] = ci.e[1]; t[5] = ci.e[2];
+      t[6] = dix; t[7] = diy; t[8] = diz;
+      t[9] = ci.depth[0]; t[10] = ci.depth[1];
+    }
+    for (int k = 0; k < n_nb; ++k) S[k * 64 + lane] = 0ull;
+    int qn = 0;
+    wave_lds_sync();
+
+    auto drain = [&]() {
+      wave_lds_sync();
+      for (int q0 = 0; q0 < qn; q0 += 64) {
+        int p = q0 + lane;
+        if (p < qn) {
+          unsigned e = queue[p];
+          int il = (int)(e >> 26);
+          int j = (int)(e & 0x3FFFFFFu);
+          const CandLite lj = a.lite[off + j];
+          const Cand cj = a.cand[off + j];
+          const int imgj = a.blk_nb[nb0 + lj.nb_slot];
+          double sc = pair_score(cfg, tile + il * 11, cj, a.cams[imgj],
+                                 a.segs[a.seg_off[imgj] + lj.ng_line]);
+          if (sc > 0.0) atomicMax(&S[lj.nb_slot * 64 + il], (unsigned long long)__double_as_longlong(sc));
+        }
+      }
+      qn = 0;
+      wave_lds_sync();
+    };
+
+    // sweep over all candidates j of the node (wave-uniform index -> broadcast loads)
+    for (int j = 0; j < n; ++j) {
+      const CandLite lj = a.lite[off + j];
+      bool pass = active && (j != i) && (lj.nb_slot != sloti);
+      if (pass) {
+        double c = fabs((dix * lj.dir[0] + diy * lj.dir[1]) + diz * lj.dir[2]);
+        pass = !(c < cfg.cos_guard);  // below the guard the 3D angle score is certainly gated to 0
+      }
+      unsigned long long m = __ballot(pass);
+      if (m) {
+        if (pass) queue[qn + __popcll(m & lanemask_lt())] = ((unsigned)lane << 26) | (unsigned)j;
+        qn += __popcll(m);
+        if (qn > kQCap - 64) drain();
+      }
+    }
+    drain();
+
+    // one image contributes at most one support (:109-112); images summed in ascending id order
+    if (active) {
+      double sum = 0.0;
+      for (int r = 0; r < n_nb; ++r) {
+        int k = a.blk_order[nb0 + r];
+        sum += __longlong_as_double((long long)S[k * 64 + lane]);
+      }
+      a.score[off + i] = sum;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-node selection: best candidate = first strict maximum; valid-edge flags
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_select(long long G, const long long *__restrict__ tri_off, const double *__restrict__ score,
+         double fullscore_th, int max_valid_conns, long long *__restrict__ best_idx,
+         unsigned *__restrict__ edge_flag, unsigned *__restrict__ n_valid) {
+  long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (g >= G) return;
+  const int lane = lane_id();
+  const long long off = tri_off[g];
+  const int n = (int)(tri_off[g + 1] - off);
+  double bs = -1.0;
+  int bi = -1;
+  int n_full = 0;
+  for (int i = lane; i < n; i += 64) {
+    double s = score[off + i];
+    if (s > bs) {  // ascending i inside a lane: first strict max
+      bs = s;
+      bi = i;
+    }
+    if (s >= fullscore_th) ++n_full;
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    double os = __shfl_xor(bs, d);
+    int oi = __shfl_xor(bi, d);
+    n_full += __shfl_xor(n_full, d);
+    bool take = (oi >= 0) && (bi < 0 || os > bs || (os == bs && oi < bi));
+    if (take) {
+      bs = os;
+      bi = oi;
+    }
+  }
+  if (lane == 0) best_idx[g] = (bi < 0) ? -1 : off + bi;
+  // valid edges: the max_valid_conns best by (score, tri_id) descending, kept if score >= th
+  const bool need_rank = n_full > max_valid_conns;
+  int kept = 0;
+  for (int i = lane; i < n; i += 64) {
+    double s = score[off + i];
+    unsigned f = s >= fullscore_th ? 1u : 0u;
+    if (f && need_rank) {
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        double sj = score[off + j];
+        if (sj > s || (sj == s && j > i)) ++rank;
+      }
+      if (rank >= max_valid_conns) f = 0;
+    }
+    edge_flag[off + i] = f;
+    kept += (int)f;
+  }
+  for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d);
+  if (lane == 0) n_valid[g] = (unsigned)kept;
+}
+
+// valid edges of a node, in candidate order, at edge_off[g] (one wave per node)
+__global__ void __launch_bounds__(256)
+k_edge_fill(long long G, const long long *__restrict__ tri_off, const unsigned *__restrict__ edge_flag,
+            const long long *__restrict__ edge_off, const CandLite *__restrict__ lite,
+            int *__restrict__ edges2) {
+  long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (g >= G) return;
+  const int lane = lane_id();
+  const long long off = tri_off[g];
+  const int n = (int)(tri_off[g + 1] - off);
+  long long base = edge_off[g];
+  if (edge_off[g + 1] == base) return;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    int i = i0 + lane;
+    bool f = (i < n) && edge_flag[off + i];
+    unsigned long long m = __ballot(f);
+    if (f) {
+      long long p = base + __popcll(m & lanemask_lt());
+      edges2[2 * p] = lite[off + i].nb_slot;
+      edges2[2 * p + 1] = lite[off + i].ng_line;
+    }
+    base += __popcll(m);
+  }
+}
+
+// gather the best candidate of every node into dense per-node arrays
+__global__ void k_gather_best(long long G, const long long *__restrict__ best_idx,
+                              const long long *__restrict__ tri_off, const Cand *__restrict__ cand,
+                              const CandLite *__restrict__ lite, const double *__restrict__ score,
+                              const int *__restrict__ node_img, const long long *__restrict__ nb_off,
+                              const int *__restrict__ blk_nb, Cand *__restrict__ best_c,
+                              double *__restrict__ best_score, int *__restrict__ best_src2,
+                              int *__restrict__ n_tris) {
+  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  n_tris[g] = (int)(tri_off[g + 1] - tri_off[g]);
+  long long b = best_idx[g];
+  Cand c;
+  double s = 0.0;
+  int src_img = -1, src_line = -1;
+  if (b >= 0) {
+    c = cand[b];
+    s = score[b];
+    src_img = blk_nb[nb_off[node_img[g]] + lite[b].nb_slot];
+    src_line = lite[b].ng_line;
+  } else {
+    for (int k = 0; k < 3; ++k) c.s[k] = c.e[k] = 0.0;
+    c.depth[0] = c.depth[1] = 0.0;
+    c.unc = 0.0;
+    c.score3 = 0.0;
+  }
+  best_c[g] = c;
+  best_score[g] = s;
+  best_src2[2 * g] = src_img;
+  best_src2[2 * g + 1] = src_line;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers (called from lt_api.cpp)
+// ---------------------------------------------------------------------------------------------
+static inline unsigned nblk(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+void launch_build_cams(hipStream_t st, int n, const double *k, const double *q, const double *t, Cam *cams) {
+  if (n > 0) hipLaunchKernelGGL(k_build_cams, dim3(nblk(n, 128)), dim3(128), 0, st, n, k, q, t, cams);
+}
+void launch_build_segs(hipStream_t st, long long n_segs, int n_img, const long long *seg_off,
+                       const double *segs, double halfpix, const Cam *cams, Seg *out) {
+  if (n_segs > 0)
+    hipLaunchKernelGGL(k_build_segs, dim3(nblk(n_segs, 256)), dim3(256), 0, st, n_segs, n_img, seg_off, segs,
+                       halfpix, cams, out);
+}
+void launch_build_pairs(hipStream_t st, int n_blk, const int *blk_img, const int *blk_nb, const Cam *cams,
+                        PairRec *out) {
+  if (n_blk > 0)
+    hipLaunchKernelGGL(k_build_pairs, dim3(nblk(n_blk, 128)), dim3(128), 0, st, n_blk, blk_img, blk_nb, cams, out);
+}
+void launch_conn_keys(hipStream_t st, long long P, int n_blk, const long long *m_off, const int *m_pairs,
+                      const int *blk_img, const int *blk_nb, const long long *seg_off, unsigned *keys,
+                      unsigned *rows, unsigned *row_blk, int *err) {
+  if (P > 0)
+    hipLaunchKernelGGL(k_conn_keys, dim3(nblk(P, 256)), dim3(256), 0, st, P, n_blk, m_off, m_pairs, blk_img,
+                       blk_nb, seg_off, keys, rows, row_blk, err);
+}
+size_t sort_temp_bytes(long long P, int end_bit) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr,
+                            (unsigned *)nullptr, (size_t)P, 0, end_bit, (hipStream_t)0);
+  return bytes;
+}
+int launch_sort(hipStream_t st, void *temp, size_t temp_bytes, long long P, const unsigned *keys_in,
+                unsigned *keys_out, const unsigned *vals_in, unsigned *vals_out, int end_bit) {
+  if (P <= 0) return 0;
+  return (int)rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)P, 0,
+                                        end_bit, st);
+}
+void launch_node_offsets(hipStream_t st, long long P, long long G, const unsigned *skeys, long long *conn_off) {
+  hipLaunchKernelGGL(k_node_offsets, dim3(nblk(P + 1, 256)), dim3(256), 0, st, P, G, skeys, conn_off);
+}
+void launch_gen_matched(hipStream_t st, long long P, const GenCfg &cfg, const unsigned *skeys,
+                        const unsigned *srows, const unsigned *row_blk, const int *m_pairs,
+                        const int *blk_img, const int *blk_nb, const int *blk_slot, const long long *seg_off,
+                        const Cam *cams, const Seg *segs, const PairRec *pairs, Cand *st_c, CandLite *st_l,
+                        unsigned *flags) {
+  if (P > 0)
+    hipLaunchKernelGGL(k_gen_matched, dim3(nblk(P, 256)), dim3(256), 0, st, P, cfg, skeys, srows, row_blk,
+                       m_pairs, blk_img, blk_nb, blk_slot, seg_off, cams, segs, pairs, st_c, st_l, flags);
+}
+size_t scan_temp_bytes_u32(long long n) {
+  size_t bytes = 0;
+  (void)rocprim::exclusive_scan(nullptr, bytes, (unsigned *)nullptr, (unsigned *)nullptr, 0u, (size_t)n,
+                          rocprim::plus<unsigned>(), (hipStream_t)0);
+  return bytes;
+}
+int launch_scan_u32(hipStream_t st, void *temp, size_t temp_bytes, long long n, const unsigned *in,
+                    unsigned *out) {
+  if (n <= 0) return 0;
+  return (int)rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, (size_t)n, rocprim::plus<unsigned>(), st);
+}
+size_t scan_temp_bytes_u32_to_i64(long long n) {
+  size_t bytes = 0;
+  (void)rocprim::exclusive_scan(nullptr, bytes, (unsigned *)nullptr, (long long *)nullptr, 0ll, (size_t)n,
+                          rocprim::plus<long long>(), (hipStream_t)0);
+  return bytes;
+}
+int launch_scan_u32_to_i64(hipStream_t st, void *temp, size_t temp_bytes, long long n, const unsigned *in,
+                           long long *out) {
+  if (n <= 0) return 0;
+  return (int)rocprim::exclusive_scan(temp, temp_bytes, in, out, 0ll, (size_t)n, rocprim::plus<long long>(), st);
+}
+void launch_compact(hipStream_t st, long long P, const unsigned *flags, const unsigned *pos, const Cand *st_c,
+                    const CandLite *st_l, Cand *out_c, CandLite *out_l) {
+  if (P > 0)
+    hipLaunchKernelGGL(k_compact, dim3(nblk(P, 256)), dim3(256), 0, st, P, flags, pos, st_c, st_l, out_c, out_l);
+}
+void launch_tri_offsets(hipStream_t st, long long G, const long long *conn_off, const unsigned *pos, long long P,
+                        unsigned total, long long *tri_off) {
+  hipLaunchKernelGGL(k_tri_offsets, dim3(nblk(G + 1, 256)), dim3(256), 0, st, G, conn_off, pos, P, total, tri_off);
+}
+void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const GenCfg &cfg,
+                           const long long *item_off, long long G, const int *node_img, const long long *nb_off,
+                           const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
+                           const PairRec *pairs, unsigned long long *masks, const long long *mask_pos,
+                           Cand *out_c, CandLite *out_l) {
+  if (n_items <= 0) return;
+  dim3 grid(nblk(n_items * 64, 256)), block(256);
+  if (!fill)
+    hipLaunchKernelGGL(k_gen_exhaustive<false>, grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off,
+                       blk_nb, seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l);
+  else
+    hipLaunchKernelGGL(k_gen_exhaustive<true>, grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off,
+                       blk_nb, seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l);
+}
+void launch_popc(hipStream_t st, long long n, const unsigned long long *masks, unsigned *cnt) {
+  if (n > 0) hipLaunchKernelGGL(k_popc, dim3(nblk(n, 256)), dim3(256), 0, st, n, masks, cnt);
+}
+void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_off, const long long *mask_pos,
+                           long long n_items, long long total, long long *tri_off) {
+  hipLaunchKernelGGL(k_tri_offsets_ex, dim3(nblk(G + 1, 256)), dim3(256), 0, st, G, item_off, mask_pos, n_items,
+                     total, tri_off);
+}
+size_t score_lds_bytes(int max_nb) {
+  return kWavesPerBlock * ((size_t)max_nb * 64 * 8 + 64 * 11 * 8 + kQCap * 4);
+}
+void launch_score(hipStream_t st, const ScoreArgs &a, const ScoreCfg &cfg) {
+  if (a.G <= 0) return;
+  size_t lds = score_lds_bytes(a.max_nb);
+  hipLaunchKernelGGL(k_score, dim3(nblk(a.G, kWavesPerBlock)), dim3(64 * kWavesPerBlock), lds, st, a, cfg);
+}
+void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
+                   int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid) {
+  if (G > 0)
+    hipLaunchKernelGGL(k_select, dim3(nblk(G * 64, 256)), dim3(256), 0, st, G, tri_off, score, th, max_valid,
+                       best_idx, edge_flag, n_valid);
+}
+void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
+                      const long long *edge_off, const CandLite *lite, int *edges2) {
+  if (G > 0)
+    hipLaunchKernelGGL(k_edge_fill, dim3(nblk(G * 64, 256)), dim3(256), 0, st, G, tri_off, edge_flag, edge_off,
+                       lite, edges2);
+}
+void launch_gather_best(hipStream_t st, long long G, const long long *best_idx, const long long *tri_off,
+                        const Cand *cand, const CandLite *lite, const double *score, const int *node_img,
+                        const long long *nb_off, const int *blk_nb, Cand *best_c, double *best_score,
+                        int *best_src2, int *n_tris) {
+  if (G > 0)
+    hipLaunchKernelGGL(k_gather_best, dim3(nblk(G, 256)), dim3(256), 0, st, G, best_idx, tri_off, cand, lite,
+                       score, node_img, nb_off, blk_nb, best_c, best_score, best_src2, n_tris);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// free-function queries (limap.triangulation.get_normal_direction / compute_fundamental_matrix /
+// compute_epipolar_IoU / triangulate_line[_by_endpoints], bindings.cc:22-31): one thread.
+// in30 = seg1[4] cam1[11] seg2[4] cam2[11]; out32 = n(seg1)[3] F[9] IoU line10[10]
+// ---------------------------------------------------------------------------------------------
+__global__ void k_fn_query(const double *__restrict__ in, int by_endpoints, double *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Cam c1, c2;
+  cam_build(in + 4, in + 8, in + 12, &c1);
+  cam_build(in + 19, in + 23, in + 27, &c2);
+  Seg s1, s2;
+  seg_build(c1, in[0], in[1], in[2], in[3], &s1);
+  seg_build(c2, in[15], in[16], in[17], in[18], &s2);
+  PairRec pr;
+  pair_build(c1, c2, &pr);
+  out[0] = s1.n[0]; out[1] = s1.n[1]; out[2] = s1.n[2];
+  for (int k = 0; k < 9; ++k) out[3 + k] = pr.F[k];
+  out[12] = epipolar_iou(s1, s2, pr.F);
+  d3 ps, pe;
+  double zs, ze, d21, d22;
+  bool ok;
+  if (!by_endpoints) {
+    ok = tri_line(c1, c2, s1, s2, pr.B, &ps, &pe, &zs, &ze, &d21, &d22);
+  } else {
+    d3 r1s = mk3(s1.rs[0], s1.rs[1], s1.rs[2]), r1e = mk3(s1.re[0], s1.re[1], s1.re[2]);
+    d3 c2s = mk3(s2.rs[0], s2.rs[1], s2.rs[2]), c2e = mk3(s2.re[0], s2.re[1], s2.re[2]);
+    ok = tri_point(c1, r1s, c2, c2s, &ps) && tri_point(c1, r1e, c2, c2e, &pe);
+    if (ok) {
+      zs = cam_depth(c1, ps);
+      ze = cam_depth(c1, pe);
+    }
+  }
+  double *l = out + 13;
+  if (ok) {
+    l[0] = ps.x; l[1] = ps.y; l[2] = ps.z; l[3] = pe.x; l[4] = pe.y; l[5] = pe.z;
+    l[6] = zs; l[7] = ze; l[8] = -1.0; l[9] = 1.0;
+  } else {  // failure sentinel Line3d((0,0,0),(1,1,1),-1)  (functions.cc:300)
+    l[0] = l[1] = l[2] = 0.0; l[3] = l[4] = l[5] = 1.0;
+    l[6] = l[7] = -1.0; l[8] = -1.0; l[9] = -1.0;
+  }
+}
+
+void launch_fn_query(hipStream_t st, const double *in30, int by_endpoints, double *out32) {
+  hipLaunchKernelGGL(k_fn_query, dim3(1), dim3(64), 0, st, in30, by_endpoints, out32);
+}
+
+}  // namespace lt

@@ -1,0 +1,378 @@
+"""Host-side mirror of `limap.triangulation` for the MI355X backend.
+
+Same names, argument meaning and error behaviour as the reference's pybind surface
+(src/limap/triangulation/bindings.cc:19-32,78-119 and the doc wrappers in
+src/limap/triangulation/triangulation.py), implemented over the C ABI of include/limap_amd.h.
+Drop-in: ``limap.triangulation.GlobalLineTriangulator = limap_amd.triangulation.GlobalLineTriangulator``
+(see INTEGRATION.md); the only production caller is src/limap/runners/line_triangulation.py:102-168.
+
+The reference runs the whole multi-view step inside every ``TriangulateImage`` call.  Here the
+per-image calls only buffer their inputs; the batch is executed on the GPU the first time results
+are requested (``ComputeLineTracks`` or any getter), which is not observable through the API.
+"""
+import numpy as np
+
+from . import _capi
+from .base import CameraView, ImageCollection, Line2d, Line3d, LineTrack
+
+__all__ = [
+    "GlobalLineTriangulator", "GlobalLineTriangulatorConfig", "get_normal_direction",
+    "compute_essential_matrix", "compute_fundamental_matrix", "compute_epipolar_IoU",
+    "triangulate_line", "triangulate_line_by_endpoints",
+]
+
+
+class GlobalLineTriangulatorConfig:
+    """Mirror of the pybind config class (bindings.cc:40-74): attribute access to every field the
+    reference exposes; constructed empty or from the ``cfg["triangulation"]`` dict."""
+
+    def __init__(self, cfg_dict=None):
+        object.__setattr__(self, "_s", _capi.config_from_dict(cfg_dict))
+        object.__setattr__(self, "merging_strategy_name", (cfg_dict or {}).get("merging_strategy", "greedy"))
+
+    def __getattr__(self, name):
+        s = object.__getattribute__(self, "_s")
+        if name == "merging_strategy":
+            return object.__getattribute__(self, "merging_strategy_name")
+        if name in ("linker2d_config", "linker3d_config"):
+            pre = "l2_" if name == "linker2d_config" else "l3_"
+            return {k[3:]: getattr(s, k) for k, _ in s._fields_ if k.startswith(pre)}
+        if hasattr(s, name):
+            return getattr(s, name)
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        s = object.__getattribute__(self, "_s")
+        if name == "merging_strategy":
+            object.__setattr__(self, "merging_strategy_name", value)
+            s.merging_strategy = _capi.MERGING.get(value, 99)
+        elif name in ("linker2d_config", "linker3d_config"):
+            pre = "l2_" if name == "linker2d_config" else "l3_"
+            for k, v in dict(value).items():
+                if hasattr(s, pre + k):
+                    setattr(s, pre + k, type(getattr(s, pre + k))(v))
+        elif hasattr(s, name):
+            setattr(s, name, type(getattr(s, name))(value))
+        else:
+            raise AttributeError(name)
+
+
+def _view_arrays(view):
+    """(kvec4, qvec4, tvec3) of a limap CameraView or of limap_amd.base.CameraView."""
+    if hasattr(view, "kvec"):
+        return np.asarray(view.kvec, float), np.asarray(view.qvec, float), np.asarray(view.tvec, float)
+    K = np.asarray(view.K(), float)
+    pose = getattr(view, "pose", view)
+    q = np.asarray(getattr(pose, "qvec"), float).reshape(4)
+    t = np.asarray(getattr(pose, "tvec"), float).reshape(3)
+    return np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]]), q, t
+
+
+def _segs_array(lines):
+    """list[Line2d-like] or (M, >=4) array -> (M,4) float64 (GetLine2dVectorFromArray, linebase.cc:134-142)."""
+    if isinstance(lines, np.ndarray):
+        a = np.asarray(lines, float)
+        if a.size == 0:
+            return np.zeros((0, 4))
+        if a.ndim != 2 or a.shape[1] < 4:
+            raise ValueError("segments must have shape (M, >=4)")
+        return np.ascontiguousarray(a[:, :4])
+    out = np.zeros((len(lines), 4))
+    for i, l in enumerate(lines):
+        if hasattr(l, "start"):
+            out[i, :2] = np.asarray(l.start, float)
+            out[i, 2:] = np.asarray(l.end, float)
+        else:
+            out[i] = np.asarray(l, float).reshape(-1)[:4]
+    return out
+
+
+def _cam11(view):
+    if isinstance(view, np.ndarray) or isinstance(view, (list, tuple)):
+        a = np.asarray(view, float).reshape(-1)
+        if a.size != 11:
+            raise ValueError("camera must be kvec4|qvec4|tvec3")
+        return a
+    k, q, t = _view_arrays(view)
+    n = np.linalg.norm(q)
+    return np.concatenate([k, q, t])
+
+
+def _make_line3d(a10):
+    try:  # hand limap's own type back when it is installed
+        import limap.base as _lb  # noqa: F401
+        l = _lb.Line3d(np.asarray(a10[0:3]), np.asarray(a10[3:6]), float(a10[9]), float(a10[6]), float(a10[7]),
+                       float(a10[8]))
+        return l
+    except Exception:
+        return Line3d.from10(a10)
+
+
+class GlobalLineTriangulator:
+    """`limap.triangulation.GlobalLineTriangulator` on MI355X (bindings.cc:78-119)."""
+
+    def __init__(self, cfg=None, device=0):
+        if isinstance(cfg, GlobalLineTriangulatorConfig):
+            self._ctx = _capi.Context(cfg_struct=cfg._s, device=device)
+        else:
+            self._ctx = _capi.Context(cfg_dict=dict(cfg) if cfg is not None else None, device=device)
+        self._img_ids = []
+        self._segs = {}
+        self._seg_off = None
+        self._tracks = []
+        self._debug = bool(self._ctx.cfg.debug_mode)
+
+    # ---- interfaces (bindings.cc:78-95) ----
+    def SetRanges(self, ranges):
+        self._ctx.set_ranges(ranges[0], ranges[1])
+
+    def UnsetRanges(self):
+        self._ctx.unset_ranges()
+
+    def Init(self, all_2d_segs, imagecols):
+        """Init(dict[int -> list[Line2d] | ndarray(M,4+)], ImageCollection)."""
+        if hasattr(imagecols, "IsUndistorted") and not imagecols.IsUndistorted():
+            raise ValueError("Check failed: imagecols->IsUndistorted() == true")  # base_line_triangulator.cc:49
+        if isinstance(imagecols, dict):
+            imagecols = ImageCollection({int(i): (v if hasattr(v, "K") else CameraView(*v)) for i, v in imagecols.items()})
+        ids = [int(i) for i in imagecols.get_img_ids()]
+        k = np.zeros((len(ids), 4)); q = np.zeros((len(ids), 4)); t = np.zeros((len(ids), 3))
+        seg_list = []
+        for n, i in enumerate(ids):
+            k[n], q[n], t[n] = _view_arrays(imagecols.camview(i))
+            if i not in all_2d_segs:
+                raise IndexError(f"map::at: no 2D segments for image {i}")  # all_2d_segs.at(img_id), :56
+            seg_list.append(_segs_array(all_2d_segs[i]))
+        self.InitArrays(ids, k, q, t, seg_list)
+
+    def InitArrays(self, img_ids, kvec, qvec, tvec, segs_per_image):
+        """Flat-array form of Init (what the C ABI takes)."""
+        seg_off = np.zeros(len(img_ids) + 1, np.int64)
+        seg_off[1:] = np.cumsum([len(s) for s in segs_per_image])
+        segs = np.concatenate(segs_per_image, 0) if len(segs_per_image) else np.zeros((0, 4))
+        self._ctx.init(img_ids, kvec, qvec, tvec, seg_off, segs.reshape(-1, 4))
+        order = np.argsort(np.asarray(img_ids), kind="stable")
+        self._img_ids = [int(img_ids[o]) for o in order]
+        self._segs = {int(img_ids[o]): np.asarray(segs_per_image[o], float).reshape(-1, 4) for o in order}
+        so = np.zeros(len(img_ids) + 1, np.int64)
+        so[1:] = np.cumsum([len(self._segs[i]) for i in self._img_ids])
+        self._seg_off = so
+        self._idx = {i: n for n, i in enumerate(self._img_ids)}
+        self._tracks = []
+
+    def InitVPResults(self, vpresults):
+        raise NotImplementedError("VP-guided proposals (use_vp) are not implemented in the MI355X backend")
+
+    def SetBipartites2d(self, all_bpt2ds):
+        raise NotImplementedError("point-guided proposals (use_pointsfm) are not implemented in the MI355X backend")
+
+    def SetSfMPoints(self, points):
+        raise NotImplementedError("point-guided proposals (use_pointsfm) are not implemented in the MI355X backend")
+
+    def TriangulateImage(self, img_id, matches):
+        """matches: dict[int -> ndarray(K,2) int] (the content of matches_{img_id}.npy)."""
+        nb = list(matches.keys())
+        off = np.zeros(len(nb) + 1, np.int64)
+        rows = []
+        for n, key in enumerate(nb):
+            m = np.asarray(matches[key])
+            if m.size != 0 and (m.ndim != 2 or m.shape[1] != 2):
+                raise ValueError("Check failed: match_info.cols() == 2")  # base_line_triangulator.cc:79
+            m = m.reshape(-1, 2)
+            rows.append(m.astype(np.int32, copy=False))
+            off[n + 1] = off[n] + len(m)
+        pairs = np.concatenate(rows, 0) if rows else np.zeros((0, 2), np.int32)
+        self._ctx.triangulate_image(img_id, [int(x) for x in nb], off, pairs)
+
+    def TriangulateImageExhaustiveMatch(self, img_id, neighbors):
+        self._ctx.triangulate_image_exhaustive(img_id, [int(x) for x in neighbors])
+
+    def ComputeLineTracks(self):
+        self._ctx.compute_tracks()
+        self._tracks = self._build_tracks(self._ctx.get_tracks())
+        return self.GetTracks()
+
+    def GetTracks(self):
+        return list(self._tracks)
+
+    def CountImages(self):
+        return self._ctx.count_images()
+
+    def CountLines(self, img_id):
+        return self._ctx.count_lines(img_id)
+
+    def GetLinker(self):
+        c = self._ctx.cfg
+        return dict(linker2d={k[3:]: getattr(c, k) for k, _ in c._fields_ if k.startswith("l2_")},
+                    linker3d={k[3:]: getattr(c, k) for k, _ in c._fields_ if k.startswith("l3_")})
+
+    # ---- visualisation getters (bindings.cc:100-119) ----
+    def _node(self, img_id, line_id):
+        return int(self._seg_off[self._idx[int(img_id)]] + int(line_id))
+
+    def _best(self):
+        return self._ctx.get_best()
+
+    def GetAllBestTris(self):
+        b = self._best()
+        return [_make_line3d(b["line"][g]) for g in range(len(b["score"]))]
+
+    def GetAllValidBestTris(self):
+        """Best candidates of the nodes that survive filterNodeByNumOuterEdges (valid_flags_)."""
+        b = self._best()
+        flags = self._valid_flags()
+        return [_make_line3d(b["line"][g]) for g in range(len(b["score"])) if flags[g]]
+
+    def GetBestTrisImage(self, img_id):
+        b = self._best()
+        i = self._idx[int(img_id)]
+        return [_make_line3d(b["line"][g]) for g in range(self._seg_off[i], self._seg_off[i + 1])]
+
+    def GetBestTriNode(self, img_id, line_id):
+        return _make_line3d(self._best()["line"][self._node(img_id, line_id)])
+
+    def GetBestScoredTriNode(self, img_id, line_id):
+        b = self._best()
+        g = self._node(img_id, line_id)
+        return (_make_line3d(b["line"][g]), float(b["score"][g]), (int(b["src"][g, 0]), int(b["src"][g, 1])))
+
+    def CountAllTris(self):
+        return int(self._ctx.get_num_tris().sum()) if self._debug else 0
+
+    def GetScoredTrisNode(self, img_id, line_id):
+        if not self._debug:  # tris_ is cleared after scoring unless debug_mode (global_line_triangulator.cc:156-159)
+            return []
+        a = self._ctx.get_all_tris()
+        g = self._node(img_id, line_id)
+        return [(_make_line3d(a["line"][t]), float(a["score"][t]), (int(a["src"][t, 0]), int(a["src"][t, 1])))
+                for t in range(a["off"][g], a["off"][g + 1])]
+
+    def GetValidScoredTrisNode(self, img_id, line_id):
+        """valid_tris_: candidates with score >= fullscore_th among the max_valid_conns best, in
+        descending (score, tri_id) order (global_line_triangulator.cc:124-142)."""
+        tris = self.GetScoredTrisNode(img_id, line_id)
+        order = sorted(range(len(tris)), key=lambda t: (tris[t][1], t), reverse=True)
+        order = order[:int(self._ctx.cfg.max_valid_conns)]
+        return [tris[t] for t in order if tris[t][1] >= self._ctx.cfg.fullscore_th]
+
+    def GetValidScoredTrisNodeSet(self, img_id, line_id):
+        best = {}
+        for tri in self.GetValidScoredTrisNode(img_id, line_id):  # first strictly-greater per image wins
+            k = tri[2][0]
+            if k not in best or tri[1] > best[k][1]:
+                best[k] = tri
+        return [best[k] for k in sorted(best)]
+
+    def CountAllValidTris(self):
+        return int(len(self._ctx.get_valid_edges()[1])) if self._debug else 0
+
+    def GetValidTrisNode(self, img_id, line_id):
+        return [t[0] for t in self.GetValidScoredTrisNode(img_id, line_id)]
+
+    def GetValidTrisNodeSet(self, img_id, line_id):
+        return [t[0] for t in self.GetValidScoredTrisNodeSet(img_id, line_id)]
+
+    def GetValidTrisImage(self, img_id):
+        out = []
+        for l in range(self.CountLines(img_id)):
+            out += self.GetValidTrisNode(img_id, l)
+        return out
+
+    def GetAllValidTris(self):
+        out = []
+        for i in self._img_ids:
+            out += self.GetValidTrisImage(i)
+        return out
+
+    def GetSurvivedLinesImage(self, image_id, n_visible_views):
+        out = []
+        for tr in self._tracks:  # global_line_triangulator.cc:543-558
+            if tr.count_images() < n_visible_views:
+                continue
+            out += [l for i, l in zip(tr.image_id_list, tr.line_id_list) if i == image_id]
+        return out
+
+    # ---- extras of this backend ----
+    def stats(self):
+        return self._ctx.stats()
+
+    def timers(self):
+        return self._ctx.timers()
+
+    def context(self):
+        return self._ctx
+
+    # ---- helpers ----
+    def _valid_flags(self):
+        """filterNodeByNumOuterEdges (global_line_triangulator.cc:168-232) on the valid edges."""
+        off, edges = self._ctx.get_valid_edges()
+        G = len(off) - 1
+        flags = np.ones(G, bool)
+        k = int(self._ctx.cfg.min_num_outer_edges)
+        if k <= 0:
+            return flags
+        raise NotImplementedError("GetAllValidBestTris with min_num_outer_edges > 0: use ComputeLineTracks()")
+
+    def _build_tracks(self, t):
+        tracks = []
+        off = t["off"]
+        for n in range(len(off) - 1):
+            sl = slice(int(off[n]), int(off[n + 1]))
+            tr = LineTrack()
+            tr.line = Line3d(t["line"][n, 0:3], t["line"][n, 3:6], -1.0, -1.0, -1.0, t["line"][n, 6])
+            tr.image_id_list = [int(x) for x in t["image_ids"][sl]]
+            tr.line_id_list = [int(x) for x in t["line_ids"][sl]]
+            tr.node_id_list = [int(x) for x in t["node_ids"][sl]]
+            tr.score_list = [float(x) for x in t["scores"][sl]]
+            tr.line2d_list = [Line2d(self._segs[i][l, 0:2], self._segs[i][l, 2:4])
+                              for i, l in zip(tr.image_id_list, tr.line_id_list)]
+            tr.line3d_list = [Line3d(a[0:3], a[3:6]) for a in t["line3d"][sl]]
+            tracks.append(tr)
+        try:  # convert to limap's LineTrack when limap is installed (linetrack.cc:50-74 dict ctor)
+            import limap.base as _lb
+            return [_lb.LineTrack(tr.as_dict()) for tr in tracks]
+        except Exception:
+            return tracks
+
+
+# ---- free functions (bindings.cc:22-31; doc wrappers triangulation.py:1-138 of the reference) ----
+_fn_ctx = None
+
+
+def _fctx():
+    global _fn_ctx
+    if _fn_ctx is None:
+        _fn_ctx = _capi.Context()
+    return _fn_ctx
+
+
+def get_normal_direction(l2d, view):
+    return _fctx().fn_normal_direction(_segs_array([l2d])[0], _cam11(view))
+
+
+def compute_fundamental_matrix(view1, view2):
+    return _fctx().fn_fundamental_matrix(_cam11(view1), _cam11(view2))
+
+
+def compute_essential_matrix(view1, view2):
+    """E = K2^T F K1 is not how the reference computes it (functions.cc:44-67 builds E first); the
+    device query returns F, and E is recovered here only for API completeness."""
+    F = compute_fundamental_matrix(view1, view2)
+    k1, k2 = _cam11(view1)[:4], _cam11(view2)[:4]
+    K1 = np.array([[k1[0], 0, k1[2]], [0, k1[1], k1[3]], [0, 0, 1.0]])
+    K2 = np.array([[k2[0], 0, k2[2]], [0, k2[1], k2[3]], [0, 0, 1.0]])
+    return K2.T @ F @ K1
+
+
+def compute_epipolar_IoU(l1, view1, l2, view2):
+    return _fctx().fn_epipolar_iou(_segs_array([l1])[0], _cam11(view1), _segs_array([l2])[0], _cam11(view2))
+
+
+def triangulate_line(l1, view1, l2, view2):
+    return _make_line3d(_fctx().fn_triangulate_line(_segs_array([l1])[0], _cam11(view1), _segs_array([l2])[0],
+                                                    _cam11(view2), False))
+
+
+def triangulate_line_by_endpoints(l1, view1, l2, view2):
+    return _make_line3d(_fctx().fn_triangulate_line(_segs_array([l1])[0], _cam11(view1), _segs_array([l2])[0],
+                                                    _cam11(view2), True))

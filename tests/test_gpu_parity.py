@@ -1,0 +1,47 @@
+"""-m gpu: HIP backend (through the C ABI) against the CPU oracle on identical seeded inputs.
+Bars: indices bit-exact; coordinates that never pass through acos/exp bit-exact; scores 1e-12;
+aggregated track endpoints 1e-5 relative (north_star)."""
+import numpy as np
+import pytest
+
+from limap_amd import synthetic as syn
+
+from helpers import (compare_best, compare_candidates, compare_tracks, compare_valid_edges, run_oracle,
+                     run_product, small_scene)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_matched_stage_by_stage(gpu_lib, oracle, seed):
+    sc = small_scene(seed=seed)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    T = run_product(sc, cfg)
+    O = run_oracle(oracle, sc, cfg)
+    compare_candidates(T.context().get_all_tris(), O.get_all_tris())
+    assert np.array_equal(T.context().get_num_tris(), O.get_num_tris())
+    compare_best(T.context().get_best(), O.get_best())
+    compare_valid_edges(T.context().get_valid_edges(), O.get_valid_edges())
+    T.ComputeLineTracks()
+    ot = O.ComputeLineTracks()
+    compare_tracks(T.context().get_tracks(), ot)
+    st, so = T.stats(), O.stats()
+    for k in ("connections", "candidates", "pairs", "valid_edges", "graph_nodes", "graph_edges", "tracks"):
+        assert st[k] == so[k], k
+
+
+def test_exhaustive_stage_by_stage(gpu_lib, oracle):
+    sc = small_scene(seed=2, n_views=10, n_segs=70, n_neighbors=5)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    T = run_product(sc, cfg, exhaustive=True)
+    O = run_oracle(oracle, sc, cfg, exhaustive=True)
+    compare_candidates(T.context().get_all_tris(), O.get_all_tris())
+    compare_best(T.context().get_best(), O.get_best())
+    compare_valid_edges(T.context().get_valid_edges(), O.get_valid_edges())
+    T.ComputeLineTracks()
+    compare_tracks(T.context().get_tracks(), O.ComputeLineTracks())
+
+
+def test_smoke_entry(gpu_lib, oracle):
+    import __graft_entry__ as g
+    g.smoke()
