@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""bench.py -- line-triangulation hot path on N MI355X GPUs (one process per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic 100 views x 500 segments/view PER GPU, 20
+neighbours, matched mode topk = 10 (10^7 connections per GPU), cfgs/triangulation/default.yaml
+parameters, var2d = 2.0 (LSD).  At N > 1 the scene is N connected rooms with 100 views each
+(weak scaling); every rank owns the 2D segments + poses of its 100 images, and one RCCL
+all-gather over xGMI gives every rank the whole scene before it triangulates its own images.
+
+One step = [all-gather of the per-image payload (N > 1)] + rebuild of the per-camera / per-segment
+invariants + the whole device pipeline (pair invariants, connection sort, candidate generation,
+compaction, multi-view scoring, per-node arg-max + valid edges) with the match lists already
+resident in HBM.  metric value = 3D line candidates scored per second, whole job.
+The JSON line also carries the end-to-end wall-clock of the reference's API sequence
+(ctor + Init + TriangulateImage x views + ComputeLineTracks, incl. PCIe and the host tail), the
+roofline of the dominant kernel (HIP-event timed on the kernels' stream), and the CPU oracle
+timed on the host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(stats, n_img_active, nn):
+    """bytes_score = 136 C + 104 nodes + 4 E ;
+    bytes_gen = 8 P + 32 (nodes + N nn M) + 88 N (1 + nn) + 96 C."""
+    C, E, P, G = stats["candidates"], stats["valid_edges"], stats["connections"], stats["active_nodes"]
+    score = 136 * C + 104 * G + 4 * E
+    gen = 8 * P + 32 * (G + nn * G) + 88 * n_img_active * (1 + nn) + 96 * C
+    return score, gen
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views", type=int, default=100, help="views per GPU")
+    ap.add_argument("--segs", type=int, default=500)
+    ap.add_argument("--neighbors", type=int, default=20)
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--mode", default="matched", choices=["matched", "exhaustive"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from limap_amd import _capi
+    from limap_amd import synthetic as syn
+    from limap_amd import dist as ltdist
+
+    n_total = args.views * world
+    scene = syn.make_scene(n_views=n_total, n_segs=args.segs, n_neighbors=args.neighbors, n_rooms=world, seed=0,
+                           topk=args.topk)
+    cfg = syn.default_triangulation_cfg()
+    my_imgs = ltdist.shard_images(scene.img_ids, rank, world)
+
+    ctx = _capi.Context(cfg_dict=cfg, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.set_ranges(*scene.ranges)
+
+    # ---- scene payload: this rank uploads only its own images, the rest arrives by all-gather ----
+    gather = ltdist.SceneGather(scene.img_ids, scene.seg_off, rank, world, dev)
+    gather.load_local(scene.kvec, scene.qvec, scene.tvec, scene.segs)
+    d_k, d_q, d_t, d_s = gather.all_gather()
+    ctx.init_device(scene.img_ids, d_k.data_ptr(), d_q.data_ptr(), d_t.data_ptr(), scene.seg_off, d_s.data_ptr())
+
+    # ---- this rank's images: buffer + upload the match lists (resident before the timed region) ----
+    t_up0 = time.perf_counter()
+    for i in my_imgs:
+        if args.mode == "matched":
+            m = scene.matches_of(int(i), args.topk)
+            nb = list(m.keys())
+            off = np.zeros(len(nb) + 1, np.int64)
+            off[1:] = np.cumsum([len(m[k]) for k in nb])
+            pairs = np.concatenate([m[k] for k in nb], 0) if nb else np.zeros((0, 2), np.int32)
+            ctx.triangulate_image(int(i), nb, off, pairs)
+        else:
+            ctx.triangulate_image_exhaustive(int(i), scene.neighbors[int(i)])
+    ctx.upload()
+    t_upload = time.perf_counter() - t_up0
+
+    def step():
+        k, q, t, s = gather.all_gather()
+        ctx.refresh_scene_device(k.data_ptr(), q.data_ptr(), t.data_ptr(), s.data_ptr())
+        ctx.run_device()
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    acc = {}
+    for _ in range(args.steps):
+        step()
+        for k, v in ctx.timers().items():
+            acc[k] = acc.get(k, 0.0) + v
+    sync()
+    elapsed = time.perf_counter() - t0
+    kt = {k: v / max(args.steps, 1) for k, v in acc.items()}  # average HIP-event ms per launch
+
+    # results of the last step -> host, then the tail (not part of the timed step)
+    ctx.download()
+    st = ctx.stats()
+    st["active_nodes"] = int(sum(scene.seg_off[j + 1] - scene.seg_off[j] for j in
+                                 np.searchsorted(scene.img_ids, my_imgs)))
+    t_tail0 = time.perf_counter()
+    ctx.compute_tracks()
+    t_tail = time.perf_counter() - t_tail0
+    st_after = ctx.stats()
+
+    if world > 1:
+        t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        elapsed = float(t_el.item())
+        tot = torch.tensor([st["candidates"], st["connections"], st["pairs"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        cand_total, conn_total, pairs_total = [float(x) for x in tot.tolist()]
+    else:
+        cand_total, conn_total, pairs_total = float(st["candidates"]), float(st["connections"]), float(st["pairs"])
+
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    value = cand_total * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        b_score, b_gen = algorithmic_bytes(st, len(my_imgs), args.neighbors)
+        kernels = {"score": (b_score, kt.get("score", 0.0)), "gen": (b_gen, kt.get("gen", 0.0))}
+        dom = max(kernels, key=lambda k: kernels[k][1])
+        roof = {}
+        for name, (nbytes, ms) in kernels.items():
+            gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            roof[name] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": ms, "algorithmic_bytes": nbytes}
+        out = {
+            "metric": "3D line candidates scored/sec (100 views x 500 segs per GPU, matched topk=10)"
+                      if args.mode == "matched" else "3D line candidates scored/sec (exhaustive)",
+            "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.views} views x {args.segs} segs/view per GPU, "
+                                   f"{args.neighbors} neighbours, {args.mode}"
+                                   + (f" topk={args.topk}" if args.mode == "matched" else "")
+                                   + ", cfgs/triangulation/default.yaml params, var2d=2.0",
+                       "views_total": n_total, "segs_per_view": args.segs, "n_neighbors": args.neighbors,
+                       "mode": args.mode, "topk": args.topk, "parallelism": f"shard-by-image x{world}"},
+            "counts": {"connections": conn_total, "candidates": cand_total, "scoring_pairs": pairs_total,
+                       "valid_edges_rank0": st["valid_edges"], "tracks_rank0": st_after["tracks"]},
+            "kernel_ms": kt,
+            "connections_per_s": conn_total * args.steps / elapsed,
+            "roofline": dict(roof[dom], kernel=("k_score" if dom == "score" else "k_gen_" + args.mode)),
+            "roofline_all": roof,
+            "host_ms": {"upload_matches": 1e3 * t_upload, "tail_compute_tracks": 1e3 * t_tail},
+        }
+
+    # ---- end-to-end wall-clock through the reference's API sequence, rank 0 / N = 1 ----
+    if rank == 0 and world == 1:
+        from limap_amd import triangulation as tri
+        matches = {int(i): scene.matches_of(int(i), args.topk) for i in scene.img_ids} if args.mode == "matched" else None
+        segs_list = [scene.segs_of(j) for j in range(scene.n_images)]
+        e2e = []
+        for rep in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            T = tri.GlobalLineTriangulator(cfg, device=local_rank)
+            T.SetRanges(scene.ranges)
+            T.InitArrays(scene.img_ids, scene.kvec, scene.qvec, scene.tvec, segs_list)
+            for i in scene.img_ids:
+                if args.mode == "matched":
+                    T.TriangulateImage(int(i), matches[int(i)])
+                else:
+                    T.TriangulateImageExhaustiveMatch(int(i), scene.neighbors[int(i)])
+            T.context().compute_tracks()
+            e2e.append(time.perf_counter() - t0)
+            tm = T.timers()
+            del T
+        out["e2e_wall_ms"] = 1e3 * float(np.median(e2e))
+        out["e2e_breakdown_ms"] = {k: tm[k] for k in ("upload", "run", "download", "tail")}
+
+        if not args.no_cpu_baseline:
+            from oracle import oracle as ora
+            ora.build()
+            nthreads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            ora.set_num_threads(nthreads)
+            # bounded sample: the same scene, first `n_s` images triangulated (all images as neighbours)
+            n_s = min(len(scene.img_ids), 100 if args.mode == "matched" else 4)
+            O = ora.OracleTriangulator(cfg, faithful=True)
+            t0 = time.perf_counter()
+            O.SetRanges(scene.ranges)
+            O.Init(scene.img_ids, scene.kvec, scene.qvec, scene.tvec, scene.seg_off, scene.segs)
+            for i in scene.img_ids[:n_s]:
+                if args.mode == "matched":
+                    O.TriangulateImage(int(i), matches[int(i)])
+                else:
+                    O.TriangulateImageExhaustiveMatch(int(i), scene.neighbors[int(i)])
+            O.ComputeLineTracks()
+            cpu_s = time.perf_counter() - t0
+            so = O.stats()
+            out["cpu_baseline"] = {
+                "value": so["candidates"] / cpu_s, "unit": "candidates/s", "cores": nthreads, "kind": "port",
+                "sample": f"oracle (reference-faithful mode, g++ -O2 -fopenmp, {nthreads} OpenMP threads): "
+                          f"Init + TriangulateImage on {n_s} of {len(scene.img_ids)} images + ComputeLineTracks, "
+                          f"{so['connections']} connections, {so['candidates']} candidates",
+                "wall_s": cpu_s, "timers_s": O.timers(),
+            }
+            if n_s == len(scene.img_ids):
+                out["e2e_speedup_vs_cpu"] = cpu_s / (out["e2e_wall_ms"] * 1e-3)
+                out["cpu_parity"] = {"tracks_cpu": so["tracks"], "tracks_gpu": st_after["tracks"],
+                                     "candidates_cpu": so["candidates"], "candidates_gpu": st["candidates"]}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

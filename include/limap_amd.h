@@ -89,6 +89,12 @@ int lt_init_device(lt_ctx *ctx, int n_img, const int32_t *img_ids, const void *d
                    const void *d_qvec, const void *d_tvec, const int64_t *seg_off,
                    const void *d_segs);
 
+/* Re-read the scene arrays from HBM (same image set and segment counts as the last init) and
+ * rebuild the per-camera / per-segment invariants on the context's stream, keeping the buffered
+ * or uploaded images: the per-step entry of the multi-GPU path, called after the all-gather. */
+int lt_refresh_scene_device(lt_ctx *ctx, const void *d_kvec, const void *d_qvec, const void *d_tvec,
+                            const void *d_segs);
+
 /* TriangulateImage(img_id, matches) -- base_line_triangulator.cc:71-109, bindings.cc:83.
  * Rows m_off[k]..m_off[k+1] of m_pairs[.][2] = (line_id, ng_line_id) belong to neighbour
  * nb_ids[k].  Calls are buffered; the GPU runs at the next lt_flush / lt_compute_tracks / getter

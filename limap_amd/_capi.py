@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "liblimap_amd.so")
 
 EXPORTED_SYMBOLS = [
     "lt_config_default", "lt_create", "lt_destroy", "lt_last_error", "lt_set_stream", "lt_set_ranges",
-    "lt_unset_ranges", "lt_init", "lt_init_device", "lt_triangulate_image",
+    "lt_unset_ranges", "lt_init", "lt_init_device", "lt_refresh_scene_device", "lt_triangulate_image",
     "lt_triangulate_image_exhaustive", "lt_upload", "lt_run_device", "lt_download", "lt_flush",
     "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
     "lt_get_num_tris", "lt_num_valid_edges", "lt_get_valid_edges", "lt_num_all_tris", "lt_get_all_tris",
@@ -87,6 +87,7 @@ def load_library():
     L.lt_unset_ranges.argtypes = [vp]
     L.lt_init.argtypes = [vp, C.c_int, i32p, dp, dp, dp, i64p, dp]
     L.lt_init_device.argtypes = [vp, C.c_int, i32p, vp, vp, vp, i64p, vp]
+    L.lt_refresh_scene_device.argtypes = [vp, vp, vp, vp, vp]
     L.lt_triangulate_image.argtypes = [vp, C.c_int, C.c_int, i32p, i64p, i32p]
     L.lt_triangulate_image_exhaustive.argtypes = [vp, C.c_int, C.c_int, i32p]
     for n in ("lt_upload", "lt_run_device", "lt_download", "lt_flush", "lt_compute_tracks"):
@@ -203,6 +204,10 @@ class Context:
         self.chk(self.L.lt_init_device(self.h, len(img_ids), ptr(img_ids, C.c_int32), C.c_void_p(d_kvec),
                                        C.c_void_p(d_qvec), C.c_void_p(d_tvec), ptr(seg_off, C.c_int64),
                                        C.c_void_p(d_segs)))
+
+    def refresh_scene_device(self, d_kvec, d_qvec, d_tvec, d_segs):
+        self.chk(self.L.lt_refresh_scene_device(self.h, C.c_void_p(d_kvec), C.c_void_p(d_qvec), C.c_void_p(d_tvec),
+                                                C.c_void_p(d_segs)))
 
     def triangulate_image(self, img_id, nb_ids, m_off, m_pairs):
         nb_ids, m_off, m_pairs = i32(nb_ids), i64(m_off), i32(m_pairs)

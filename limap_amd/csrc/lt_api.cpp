@@ -455,6 +455,28 @@ int lt_init_device(lt_ctx *ctx, int n_img, const int32_t *img_ids, const void *d
   return build_invariants(ctx);
 }
 
+int lt_refresh_scene_device(lt_ctx *ctx, const void *d_kvec, const void *d_qvec, const void *d_tvec,
+                            const void *d_segs) {
+  if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "lt_refresh_scene_device before Init");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int n_img = ctx->n_img;
+  if (n_img > 0) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_kvec.p, d_kvec, 32 * (size_t)n_img, hipMemcpyDeviceToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_qvec.p, d_qvec, 32 * (size_t)n_img, hipMemcpyDeviceToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_tvec.p, d_tvec, 24 * (size_t)n_img, hipMemcpyDeviceToDevice, st));
+  }
+  if (ctx->G > 0)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_segs_raw.p, d_segs, 32 * (size_t)ctx->G, hipMemcpyDeviceToDevice, st));
+  launch_build_cams(st, n_img, ctx->d_kvec.as<double>(), ctx->d_qvec.as<double>(), ctx->d_tvec.as<double>(),
+                    ctx->d_cams.as<Cam>());
+  launch_build_segs(st, ctx->G, n_img, ctx->d_seg_off.as<long long>(), ctx->d_segs_raw.as<double>(),
+                    ctx->cfg.add_halfpix ? 0.5 : 0.0, ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>());
+  HIPCHK(ctx, hipGetLastError());
+  ctx->ran = false;
+  return LT_OK;
+}
+
 static int begin_image(lt_ctx *ctx, int img_id, int mode, int *idx_out) {
   if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "TriangulateImage called before Init");
   auto it = ctx->id2idx.find(img_id);

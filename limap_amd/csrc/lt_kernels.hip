@@ -398,8 +398,8 @@ __global__ void k_tri_offsets(long long G, const long long *__restrict__ conn_of
                               long long *__restrict__ tri_off) {
   long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g > G) return;
-  long long c = conn_off[g];
-  tri_off[g] = (c >= P) ? (long long)total : (long long)pos[c];
+  (void)total;
+  tri_off[g] = (long long)pos[conn_off[g]];  // pos has P+1 entries, pos[P] = number of survivors
 }
 
 __global__ void k_popc(long long n, const unsigned long long *__restrict__ masks,

@@ -1,0 +1,110 @@
+"""Multi-GPU sharding of the triangulation path: one process per GPU, images sharded by rank,
+ONE all-gather (RCCL over xGMI; gloo on CPU for tests) of the per-image payload before scoring.
+
+`TriangulateImage(img)` reads only replicated data (all 2D segments, all poses, the neighbours and
+matches of `img`) and writes only the results of `img`'s own nodes
+(global_line_triangulator.cc:138-151 of the reference), so after the exchange every rank runs
+generation + scoring for its shard with no further communication; the serial tail
+(`ComputeLineTracks`) runs once on rank 0 over the gathered per-node results.
+
+What travels: kvec[4] | qvec[4] | tvec[3] | segs[M,4] (FP64) of each rank's own images.  What is
+replicated on the host beforehand: the image ids and the per-image segment counts (the layout).
+"""
+import numpy as np
+
+
+def shard_bounds(n_items, world, weights=None):
+    """Contiguous blocks [b[r], b[r+1]) of the id-ordered image list, balanced by `weights`
+    (e.g. connections per image) -- contiguity keeps the gathered arrays a plain concatenation."""
+    if weights is None:
+        weights = np.ones(n_items)
+    w = np.asarray(weights, float)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    total = cum[-1]
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        b = int(np.searchsorted(cum, target, side="left"))
+        b = min(max(b, bounds[-1]), n_items)
+        bounds.append(b)
+    bounds.append(n_items)
+    return bounds
+
+
+def shard_images(img_ids, rank, world, weights=None):
+    ids = np.sort(np.asarray(img_ids))
+    b = shard_bounds(len(ids), world, weights)
+    return ids[b[rank]:b[rank + 1]]
+
+
+class SceneGather:
+    """Packs this rank's images into one buffer, all-gathers once, unpacks into the global
+    kvec / qvec / tvec / segs arrays (ascending image id) on the device."""
+
+    def __init__(self, img_ids, seg_off, rank, world, device, weights=None):
+        import torch
+        self.torch = torch
+        self.rank, self.world, self.device = rank, world, device
+        ids = np.asarray(img_ids)
+        assert np.all(np.diff(ids) > 0), "image ids must be ascending"
+        self.n_img = len(ids)
+        self.seg_off = np.asarray(seg_off, np.int64)
+        self.bounds = shard_bounds(self.n_img, world, weights)
+        # per-rank payload sizes in doubles
+        self.sizes = []
+        for r in range(world):
+            a, b = self.bounds[r], self.bounds[r + 1]
+            self.sizes.append(11 * (b - a) + 4 * int(self.seg_off[b] - self.seg_off[a]))
+        self.max_size = max(self.sizes) if self.sizes else 0
+        G = int(self.seg_off[-1])
+        self.local = torch.zeros(max(self.max_size, 1), dtype=torch.float64, device=device)
+        self.recv = torch.zeros(max(self.max_size, 1) * world, dtype=torch.float64, device=device)
+        self.kvec = torch.zeros((self.n_img, 4), dtype=torch.float64, device=device)
+        self.qvec = torch.zeros((self.n_img, 4), dtype=torch.float64, device=device)
+        self.tvec = torch.zeros((self.n_img, 3), dtype=torch.float64, device=device)
+        self.segs = torch.zeros((max(G, 1), 4), dtype=torch.float64, device=device)
+
+    def load_local(self, kvec, qvec, tvec, segs):
+        """Host arrays of the WHOLE scene are accepted for convenience; only this rank's slice is
+        copied to the device."""
+        torch = self.torch
+        a, b = self.bounds[self.rank], self.bounds[self.rank + 1]
+        s0, s1 = int(self.seg_off[a]), int(self.seg_off[b])
+        buf = np.concatenate([np.asarray(kvec, np.float64)[a:b].reshape(-1), np.asarray(qvec, np.float64)[a:b].reshape(-1),
+                              np.asarray(tvec, np.float64)[a:b].reshape(-1), np.asarray(segs, np.float64)[s0:s1].reshape(-1)])
+        assert len(buf) == self.sizes[self.rank]
+        self.local[:len(buf)].copy_(torch.from_numpy(buf))
+
+    def all_gather(self):
+        """One collective; returns (kvec, qvec, tvec, segs) device tensors of the whole scene."""
+        torch = self.torch
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.recv, self.local)
+            recv = self.recv
+        else:
+            recv = self.local
+        for r in range(self.world):
+            a, b = self.bounds[r], self.bounds[r + 1]
+            n = b - a
+            s0, s1 = int(self.seg_off[a]), int(self.seg_off[b])
+            base = r * max(self.max_size, 1)
+            if n == 0:
+                continue
+            self.kvec[a:b].copy_(recv[base:base + 4 * n].view(n, 4))
+            self.qvec[a:b].copy_(recv[base + 4 * n:base + 8 * n].view(n, 4))
+            self.tvec[a:b].copy_(recv[base + 8 * n:base + 11 * n].view(n, 3))
+            if s1 > s0:
+                self.segs[s0:s1].copy_(recv[base + 11 * n:base + 11 * n + 4 * (s1 - s0)].view(s1 - s0, 4))
+        return self.kvec, self.qvec, self.tvec, self.segs
+
+
+def gather_results_to_rank0(ctx_results, rank, world):
+    """Gather per-node results (dict of numpy arrays restricted to this rank's nodes) on rank 0
+    with one object gather; used before the host tail."""
+    if world == 1:
+        return [ctx_results]
+    import torch.distributed as dist
+    out = [None] * world if rank == 0 else None
+    dist.gather_object(ctx_results, out, dst=0)
+    return out

@@ -18,6 +18,8 @@
 
 #include "lt_oracle.h"
 
+#include <omp.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -1299,6 +1301,8 @@ ora_ctx *ora_create(const ora_config *cfg, int faithful) {
   return ctx;
 }
 void ora_destroy(ora_ctx *ctx) { delete ctx; }
+void ora_set_num_threads(int n) { omp_set_num_threads(n); }
+int ora_get_max_threads(void) { return omp_get_max_threads(); }
 const char *ora_last_error(ora_ctx *ctx) { return ctx->t.err.c_str(); }
 
 int ora_set_ranges(ora_ctx *ctx, const double lo[3], const double hi[3]) {

@@ -68,6 +68,10 @@ void ora_config_default(ora_config *cfg);
 ora_ctx *ora_create(const ora_config *cfg, int faithful);
 void ora_destroy(ora_ctx *ctx);
 const char *ora_last_error(ora_ctx *ctx);
+/* OpenMP threads used by the two parallel loops (default: min(host cores, 16) set by oracle.py;
+ * the reference uses OMP's default = all cores) */
+void ora_set_num_threads(int n);
+int ora_get_max_threads(void);
 
 int ora_set_ranges(ora_ctx *ctx, const double lo[3], const double hi[3]);
 int ora_unset_ranges(ora_ctx *ctx);

@@ -109,7 +109,18 @@ def lib():
                      "ora_line3d_uncertainty", "ora_linker2d_score", "ora_linker3d_score"):
             getattr(L, name).restype = C.c_double
         _lib = L
+        # tiny parallel regions (<= topk iterations each) on a 256-core host spend all their time in
+        # fork/join; the checker runs with a bounded team.  bench.py sets the count it reports.
+        L.ora_set_num_threads(min(os.cpu_count() or 1, 16))
     return _lib
+
+
+def set_num_threads(n):
+    lib().ora_set_num_threads(int(n))
+
+
+def get_max_threads():
+    return int(lib().ora_get_max_threads())
 
 
 def config_from_dict(d=None):

@@ -1,5 +1,6 @@
 # quick on-GPU diagnosis script: prints mismatch summaries instead of asserting
-import sys, time
+import sys, time, functools
+print = functools.partial(print, flush=True)
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 from limap_amd import synthetic as syn
@@ -10,8 +11,13 @@ for mode in ("matched", "exhaustive"):
     ex = mode == "exhaustive"
     sc = syn.make_scene(n_views=16 if not ex else 10, n_segs=120 if not ex else 70, n_neighbors=8 if not ex else 5, seed=0)
     cfg = syn.default_triangulation_cfg(debug_mode=True)
-    t0 = time.time(); T = run_product(sc, cfg, exhaustive=ex); ga = T.context().get_all_tris(); t1 = time.time()
-    O = run_oracle(ora, sc, cfg, exhaustive=ex); oa = O.get_all_tris()
+    print(mode, "scene ready")
+    t0 = time.time(); T = run_product(sc, cfg, exhaustive=ex); print("  buffered", time.time() - t0)
+    T.context().upload(); print("  uploaded", time.time() - t0)
+    T.context().run_device(); print("  ran", time.time() - t0, T.timers())
+    T.context().download(); print("  downloaded", time.time() - t0)
+    ga = T.context().get_all_tris(); t1 = time.time()
+    O = run_oracle(ora, sc, cfg, exhaustive=ex); oa = O.get_all_tris(); print('  oracle done', time.time() - t1)
     print(mode, "product %.3fs" % (t1 - t0), "stats", T.stats(), "timers", {k: round(v, 3) for k, v in T.timers().items()})
     print("  oracle stats", O.stats())
     same_off = np.array_equal(ga["off"], oa["off"])
