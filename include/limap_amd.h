@@ -63,6 +63,8 @@ typedef struct lt_config {
 typedef struct lt_ctx lt_ctx;
 
 void lt_config_default(lt_config *cfg);
+int lt_abi_version(void);          /* bumped on any incompatible change of this header */
+uint64_t lt_sizeof_config(void);   /* sizeof(lt_config) the library was built with */
 
 /* GlobalLineTriangulator(cfg) -- bindings.cc:79-80,99.  device = HIP device ordinal.
  * Returns NULL (and writes a message to stderr) if no usable GPU / HIP runtime is present:

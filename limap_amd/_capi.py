@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblimap_amd.so")
 
 EXPORTED_SYMBOLS = [
-    "lt_config_default", "lt_create", "lt_destroy", "lt_last_error", "lt_set_stream", "lt_set_ranges",
+    "lt_config_default", "lt_abi_version", "lt_sizeof_config", "lt_create", "lt_destroy", "lt_last_error", "lt_set_stream", "lt_set_ranges",
     "lt_unset_ranges", "lt_init", "lt_init_device", "lt_refresh_scene_device", "lt_triangulate_image",
     "lt_triangulate_image_exhaustive", "lt_upload", "lt_run_device", "lt_download", "lt_flush",
     "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
@@ -76,6 +76,9 @@ def load_library():
     vp, i32p, i64p, dp, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
     L.lt_config_default.argtypes = [C.POINTER(LtConfig)]
     L.lt_config_default.restype = None
+    L.lt_sizeof_config.restype = C.c_uint64
+    if L.lt_sizeof_config() != C.sizeof(LtConfig):
+        raise RuntimeError("limap_amd: lt_config layout mismatch between liblimap_amd.so and the Python binding")
     L.lt_create.argtypes = [C.POINTER(LtConfig), C.c_int]
     L.lt_create.restype = vp
     L.lt_destroy.argtypes = [vp]

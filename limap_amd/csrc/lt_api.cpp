@@ -333,6 +333,9 @@ void lt_config_default(lt_config *c) {
   c->l3_use_innerseg = 1; c->l3_use_scaleinv = 0;
 }
 
+int lt_abi_version(void) { return 1; }
+uint64_t lt_sizeof_config(void) { return (uint64_t)sizeof(lt_config); }
+
 lt_ctx *lt_create(const lt_config *cfg, int device) {
   int n_dev = 0;
   hipError_t e = hipGetDeviceCount(&n_dev);

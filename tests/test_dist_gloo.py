@@ -1,0 +1,61 @@
+"""world_size-2 `gloo` test of the N > 1 path on CPU: the single all-gather of the per-image
+payload reproduces the whole scene on every rank, and the shards partition the images."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from limap_amd import dist as ltdist, synthetic as syn
+        # ragged segment counts per image exercise the padding of the gathered buffer
+        sc = syn.make_scene(n_views=7, n_segs=30, n_neighbors=3, seed=2)
+        keep = [slice(sc.seg_off[i], sc.seg_off[i] + 30 - 3 * i) for i in range(7)]
+        segs = np.concatenate([sc.segs[s] for s in keep], 0)
+        seg_off = np.zeros(8, np.int64)
+        seg_off[1:] = np.cumsum([30 - 3 * i for i in range(7)])
+        g = ltdist.SceneGather(sc.img_ids, seg_off, rank, world, torch.device("cpu"))
+        # poison everything that is not this rank's so that only the collective can fill it in
+        a, b = g.bounds[rank], g.bounds[rank + 1]
+        kv, qv, tv, sg = sc.kvec.copy(), sc.qvec.copy(), sc.tvec.copy(), segs.copy()
+        mask = np.ones(7, bool); mask[a:b] = False
+        kv[mask] = np.nan; qv[mask] = np.nan; tv[mask] = np.nan
+        smask = np.ones(len(sg), bool); smask[seg_off[a]:seg_off[b]] = False
+        sg[smask] = np.nan
+        g.load_local(kv, qv, tv, sg)
+        k, q_, t, s = g.all_gather()
+        ok = (np.array_equal(k.numpy(), sc.kvec) and np.array_equal(q_.numpy(), sc.qvec)
+              and np.array_equal(t.numpy(), sc.tvec) and np.array_equal(s.numpy()[:len(segs)], segs))
+        mine = ltdist.shard_images(sc.img_ids, rank, world).tolist()
+        parts = ltdist.gather_results_to_rank0({"rank": rank, "imgs": mine}, rank, world)
+        if rank == 0:
+            allimgs = sorted(sum((p["imgs"] for p in parts), []))
+            ok = ok and allimgs == sc.img_ids.tolist() and [p["rank"] for p in parts] == [0, 1]
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]

@@ -1,0 +1,85 @@
+"""Host-side logic that needs no GPU: the synthetic generator, the value types, the sharding
+helpers, the config mirror."""
+import numpy as np
+import pytest
+
+from limap_amd import base, dist as ltdist, synthetic as syn
+
+
+def test_scene_is_deterministic_and_well_formed():
+    a = syn.make_scene(n_views=12, n_segs=50, n_neighbors=5, seed=4)
+    b = syn.make_scene(n_views=12, n_segs=50, n_neighbors=5, seed=4)
+    assert np.array_equal(a.segs, b.segs) and np.array_equal(a.qvec, b.qvec)
+    assert a.segs.shape == (12 * 50, 4) and a.seg_off[-1] == 600
+    # endpoints slide +-15 % along the line after clipping, so they may poke slightly outside the image
+    assert np.all(a.segs[:, [0, 2]] >= -0.3 * syn.W_IMG) and np.all(a.segs[:, [0, 2]] <= 1.3 * syn.W_IMG)
+    lens = np.linalg.norm(a.segs[:, 2:] - a.segs[:, :2], axis=1).reshape(12, 50)
+    assert np.all(np.diff(lens, axis=1) <= 1e-9), "segments are sorted by length (take_longest_k)"
+    np.testing.assert_allclose(np.linalg.norm(a.qvec, axis=1), 1.0, atol=1e-12)
+    for i, nbs in a.neighbors.items():
+        assert i not in nbs and len(nbs) <= 5 and len(set(nbs)) == len(nbs)
+    m = a.matches_of(3)
+    m2 = a.matches_of(3)
+    assert sorted(m.keys()) == sorted(a.neighbors[3])
+    for k in m:
+        assert m[k].dtype == np.int32 and m[k].shape[1] == 2 and np.array_equal(m[k], m2[k])
+        assert m[k][:, 0].max() < 50 and m[k][:, 1].max() < 50
+        assert np.all(np.diff(m[k][:, 0]) >= 0), "rows grouped by line id"
+    c = syn.make_scene(n_views=12, n_segs=50, n_neighbors=5, seed=5)
+    assert not np.array_equal(a.segs, c.segs)
+
+
+def test_true_matches_are_geometrically_consistent():
+    sc = syn.make_scene(n_views=10, n_segs=60, n_neighbors=4, seed=1)
+    i, nb = 2, sc.neighbors[2][0]
+    g1, g2 = sc.gt_ids[sc.seg_off[i]:sc.seg_off[i + 1]], sc.gt_ids[sc.seg_off[nb]:sc.seg_off[nb + 1]]
+    m = sc.matches_of(i)[nb]
+    same = (g1[m[:, 0]] >= 0) & (g1[m[:, 0]] == g2[m[:, 1]])
+    vis_both = np.isin(g1[g1 >= 0], g2[g2 >= 0]).sum()
+    # (a random distractor may coincide with the true match, hence count lines, not rows)
+    assert len(np.unique(m[same, 0])) == vis_both > 0
+
+
+def test_value_types():
+    l = base.Line2d([0, 0], [3, 4])
+    assert l.length() == 5 and np.allclose(l.direction(), [0.6, 0.8]) and l.as_array().shape == (2, 2)
+    l3 = base.Line3d.from10(np.array([0, 0, 0, 0, 0, 2, 5, 6, 0.1, 1.0]))
+    assert l3.length() == 2 and l3.uncertainty == 0.1 and np.allclose(l3.depths, [5, 6]) and l3.score == 1.0
+    tr = base.LineTrack()
+    tr.image_id_list, tr.line_id_list = [3, 1, 3], [0, 2, 5]
+    tr.line2d_list = [l, l, l]
+    assert tr.count_lines() == 3 and tr.count_images() == 2 and tr.GetSortedImageIds() == [1, 3]
+    d = tr.as_dict()
+    assert set(d) >= {"line", "image_id_list", "line_id_list", "node_id_list", "score_list", "line2d_list", "line3d_list", "active"}
+    ic = base.ImageCollection.from_arrays([5, 2], np.tile([700.0, 700, 400, 300], (2, 1)),
+                                          np.tile([1.0, 0, 0, 0], (2, 1)), np.zeros((2, 3)))
+    assert ic.get_img_ids() == [2, 5] and ic.NumImages() == 2 and np.allclose(ic.camview(5).R(), np.eye(3))
+
+
+@pytest.mark.parametrize("n,world", [(100, 1), (100, 8), (7, 3), (3, 8)])
+def test_shard_bounds_cover_everything_once(n, world):
+    b = ltdist.shard_bounds(n, world)
+    assert b[0] == 0 and b[-1] == n and len(b) == world + 1 and all(x <= y for x, y in zip(b, b[1:]))
+    ids = np.arange(n) * 3 + 1
+    got = np.concatenate([ltdist.shard_images(ids, r, world) for r in range(world)])
+    assert np.array_equal(got, ids)
+
+
+def test_shard_bounds_balance_by_weight():
+    w = np.array([1] * 10 + [10] * 10)
+    b = ltdist.shard_bounds(20, 2, w)
+    loads = [w[b[r]:b[r + 1]].sum() for r in range(2)]
+    assert abs(loads[0] - loads[1]) <= 10
+
+
+def test_config_mirror_class():
+    pytest.importorskip("ctypes")
+    from limap_amd import triangulation as tri
+    c = tri.GlobalLineTriangulatorConfig(syn.default_triangulation_cfg())
+    assert c.fullscore_th == 1.0 and c.merging_strategy == "greedy" and c.linker3d_config["th_scaleinv"] == 0.015
+    c.var2d = 4.0
+    c.linker2d_config = {"th_perp": 3.0}
+    c.merging_strategy = "avg"
+    assert c.var2d == 4.0 and c.linker2d_config["th_perp"] == 3.0 and c._s.merging_strategy == 2
+    with pytest.raises(AttributeError):
+        c.sensitivity_threshold_typo = 1  # like the pybind class: unknown attributes are rejected

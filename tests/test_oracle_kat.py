@@ -1,0 +1,277 @@
+"""Known-answer tests that pin the CPU oracle: the reference's own tests hold no
+golden vectors for this path, so the restatement is checked against closed-form geometry computed
+independently here with numpy.  Runs on CPU (-m "not gpu")."""
+import numpy as np
+import pytest
+
+from limap_amd import synthetic as syn
+
+
+def K_of(k4):
+    return np.array([[k4[0], 0, k4[2]], [0, k4[1], k4[3]], [0, 0, 1.0]])
+
+
+def project(cam, X):
+    R = syn.quat_to_rot(cam[4:8])
+    x = K_of(cam[:4]) @ (R @ X + cam[8:11])
+    return x[:2] / x[2]
+
+
+def depth(cam, X):
+    return (syn.quat_to_rot(cam[4:8]) @ X + cam[8:11])[2]
+
+
+def look_at_cam(C, target, f=700.0, roll=0.0):
+    fwd = (target - C) / np.linalg.norm(target - C)
+    up = np.array([0, 0, 1.0])
+    right = np.cross(fwd, up); right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    r2 = np.cos(roll) * right + np.sin(roll) * down
+    R = np.stack([r2, np.cross(fwd, r2), fwd], 0)
+    q = syn._rot_to_quat(R)
+    t = -syn.quat_to_rot(q) @ C
+    return np.concatenate([[f, f, 400.0, 300.0], q, t])
+
+
+@pytest.fixture(scope="module")
+def two_views():
+    rng = np.random.default_rng(5)
+    P, Q = np.array([1.0, 4.0, 1.2]), np.array([2.5, 4.3, 1.9])
+    c1 = look_at_cam(np.array([0.5, 0.0, 1.0]), 0.5 * (P + Q) + rng.normal(0, 0.2, 3), roll=0.05)
+    c2 = look_at_cam(np.array([3.0, 0.5, 1.6]), 0.5 * (P + Q) + rng.normal(0, 0.2, 3), roll=-0.08)
+    return P, Q, c1, c2
+
+
+def test_camera_primitives(oracle, two_views):
+    P, Q, c1, c2 = two_views
+    np.testing.assert_allclose(oracle.cam_R(c1), syn.quat_to_rot(c1[4:8]), atol=1e-15)
+    C = -syn.quat_to_rot(c1[4:8]).T @ c1[8:11]
+    np.testing.assert_allclose(oracle.cam_center(c1), C, atol=1e-14)
+    np.testing.assert_allclose(oracle.cam_project(c1, P), project(c1, P), rtol=1e-12)
+    assert abs(oracle.cam_projdepth(c1, P) - depth(c1, P)) < 1e-13
+    ray = oracle.cam_ray_direction(c1, project(c1, P))
+    np.testing.assert_allclose(ray, (P - C) / np.linalg.norm(P - C), atol=1e-12)
+
+
+def test_kat_i_exact_projection(oracle, two_views):
+    """(i) a GT segment projected exactly into two views: IoU == 1, triangulate_line recovers the
+    endpoints, depths equal projdepth."""
+    P, Q, c1, c2 = two_views
+    s1 = np.concatenate([project(c1, P), project(c1, Q)])
+    s2 = np.concatenate([project(c2, P), project(c2, Q)])
+    # dehomogeneous() divides by (z + 1e-12) (util/types.h:40-45) and z of the crossed, normalised
+    # line coordinates is ~1e-6 here, so the reference's IoU is only exact to ~1e-6
+    assert abs(oracle.compute_epipolar_IoU(s1, c1, s2, c2) - 1.0) < 1e-5
+    l = oracle.triangulate_line(s1, c1, s2, c2)
+    np.testing.assert_allclose(l[0:3], P, atol=1e-9)
+    np.testing.assert_allclose(l[3:6], Q, atol=1e-9)
+    assert abs(l[6] - depth(c1, P)) < 1e-9 and abs(l[7] - depth(c1, Q)) < 1e-9
+    assert l[9] == 1.0
+    le = oracle.triangulate_line_by_endpoints(s1, c1, s2, c2)
+    np.testing.assert_allclose(le[0:6], np.concatenate([P, Q]), atol=1e-9)
+    # F from the oracle satisfies the epipolar constraint x2^T F x1 = 0
+    F = oracle.compute_fundamental_matrix(c1, c2)
+    x1, x2 = np.append(project(c1, P), 1), np.append(project(c2, P), 1)
+    assert abs(x2 @ F @ x1) / np.linalg.norm(F) < 1e-9
+    # plane normal of the back-projected segment is orthogonal to both viewing rays
+    n = oracle.get_normal_direction(s1, c1)
+    C1 = oracle.cam_center(c1)
+    assert abs(n @ (P - C1)) < 1e-9 and abs(n @ (Q - C1)) < 1e-9 and abs(np.linalg.norm(n) - 1) < 1e-12
+
+
+def test_kat_ii_partial_overlap(oracle, two_views):
+    """(ii) view 2 observes only a sub-interval: IoU equals the analytic interval ratio."""
+    P, Q, c1, c2 = two_views
+    X = lambda t: P + t * (Q - P)
+    s1 = np.concatenate([project(c1, X(0.0)), project(c1, X(1.0))])
+    a, b = 0.3, 1.4
+    l2s, l2e = project(c2, X(a)), project(c2, X(b))
+    s2 = np.concatenate([l2s, l2e])
+    d = (l2e - l2s) / np.linalg.norm(l2e - l2s)
+    L = np.linalg.norm(l2e - l2s)
+    c_lo = (project(c2, X(0.0)) - l2s) @ d / L
+    c_hi = (project(c2, X(1.0)) - l2s) @ d / L
+    c_lo, c_hi = min(c_lo, c_hi), max(c_lo, c_hi)
+    expect = (min(c_hi, 1) - max(c_lo, 0)) / (max(c_hi, 1) - min(c_lo, 0))
+    assert abs(oracle.compute_epipolar_IoU(s1, c1, s2, c2) - expect) < 1e-5
+    assert 0.2 < expect < 0.9
+
+
+def _two_image_run(oracle, c1, c2, s1, s2, **cfg_over):
+    cfg = syn.default_triangulation_cfg(debug_mode=True, **cfg_over)
+    O = oracle.OracleTriangulator(cfg, faithful=True)
+    O.Init([0, 1], np.stack([c1[:4], c2[:4]]), np.stack([c1[4:8], c2[4:8]]), np.stack([c1[8:], c2[8:]]), [0, 1, 2],
+           np.stack([s1, s2]))
+    O.TriangulateImage(0, {1: np.array([[0, 0]], np.int32)})
+    return O
+
+
+def test_kat_iii_degenerate_plane(oracle, two_views):
+    """(iii) camera 1 inside the back-projected plane of l2: ray/plane angle 0 -> no proposal."""
+    P, Q, c1, c2 = two_views
+    C2 = oracle.cam_center(c2)
+    C1_deg = C2 + 0.7 * (P - C2) * 0.2 + 0.5 * (Q - P)  # in the plane spanned by C2 and the line
+    c1d = look_at_cam(C1_deg, 0.5 * (P + Q))
+    s1 = np.concatenate([project(c1d, P), project(c1d, Q)])
+    s2 = np.concatenate([project(c2, P), project(c2, Q)])
+    assert _two_image_run(oracle, c1d, c2, s1, s2).get_num_tris()[0] == 0
+    s1ok = np.concatenate([project(c1, P), project(c1, Q)])
+    O = _two_image_run(oracle, c1, c2, s1ok, s2)
+    assert O.get_num_tris()[0] == 1
+    tri = O.get_all_tris()
+    np.testing.assert_allclose(tri["line"][0, :6], np.concatenate([P, Q]), atol=1e-8)
+    # uncertainty = min over both views of var2d * mean depth / f  (linebase.cc:109-116)
+    u = min(2.0 * 0.5 * (depth(c, P) + depth(c, Q)) / 700.0 for c in (c1, c2))
+    assert abs(tri["line"][0, 8] - u) < 1e-12
+
+
+def test_kat_iv_behind_camera(oracle, two_views):
+    """(iv) a segment behind both cameras triangulates to negative depths -> sentinel score -1."""
+    P, Q, c1, c2 = two_views
+    C1 = oracle.cam_center(c1)
+    back = lambda X: C1 - (X - C1)  # mirrored through C1: projects to a valid pixel, depth < 0 in view 1
+    s1 = np.concatenate([project(c1, back(P)), project(c1, back(Q))])
+    s2 = np.concatenate([project(c2, back(P)), project(c2, back(Q))])
+    l = oracle.triangulate_line(s1, c1, s2, c2)
+    assert l[9] == -1.0 and np.allclose(l[:6], [0, 0, 0, 1, 1, 1])
+    assert _two_image_run(oracle, c1, c2, s1, s2, line_tri_angle_threshold=0.0, IoU_threshold=-1e9).get_num_tris()[0] == 0
+
+
+def test_kat_v_linker_scores(oracle):
+    """(v) exp-scored gates: s = exp(-(x/(th m))^2/2), m = 1/sqrt(-2 ln score_th); exactly 0 above
+    the threshold, == score_th at the threshold."""
+    cfg = syn.default_triangulation_cfg()
+    m = 1.0 / np.sqrt(-2.0 * np.log(0.5))
+    base = np.array([100.0, 100.0, 300.0, 100.0])
+    for theta in (0.5, 2.0, 4.9):
+        rot = np.deg2rad(theta)
+        seg = np.array([100.0, 100.0, 100 + 200 * np.cos(rot), 100 + 200 * np.sin(rot)])
+        s = oracle.linker2d_score(cfg, seg, base)
+        # angle, overlap (=1), smart-angle (no shrink: overlap 1), perpendicular (endpoint offset)
+        perp = 200 * np.sin(rot)
+        expect = min(np.exp(-(theta / (5.0 * m)) ** 2 / 2), np.exp(-(perp / (2.0 * m)) ** 2 / 2))
+        expect = 0.0 if expect < 0.5 else expect
+        assert abs(s - expect) < 1e-9, theta
+    seg = np.array([100.0, 100.0, 100 + 200 * np.cos(np.deg2rad(5.2)), 100 + 200 * np.sin(np.deg2rad(5.2))])
+    assert oracle.linker2d_score(cfg, seg, base) == 0.0
+    # pure perpendicular offset d: parallel segments
+    for d, want0 in ((0.5, False), (1.99, False), (2.01, True)):
+        s = oracle.linker2d_score(cfg, base + np.array([0, d, 0, d]), base)
+        e = np.exp(-(d / (2.0 * m)) ** 2 / 2)
+        assert (s == 0.0) if want0 else abs(s - e) < 1e-12
+    # score at the threshold equals score_th
+    assert abs(np.exp(-(2.0 / (2.0 * m)) ** 2 / 2) - 0.5) < 1e-15
+    # 3D shared-parent mode: angle + one-way scale-invariant endpoint distance using l1's depths
+    l1 = np.array([0, 0, 5, 1, 0, 5, 5.0, 5.0, 0.01, 1.0])
+    l2 = l1.copy(); l2[2] += 0.05; l2[5] += 0.05  # shift both endpoints by 0.05 at depth 5 -> d = 0.01
+    s = oracle.linker3d_score(cfg, 1, l1, l2)
+    assert abs(s - np.exp(-(0.01 / (0.015 * m)) ** 2 / 2)) < 1e-9
+    l2[2] += 0.05; l2[5] += 0.05  # d = 0.02 > th_scaleinv 0.015
+    assert oracle.linker3d_score(cfg, 1, l1, l2) == 0.0
+    # spatial-merging mode needs overlap: disjoint collinear segments score 0
+    l3 = l1.copy(); l3[0] += 5; l3[3] += 5
+    assert oracle.linker3d_score(cfg, 2, l1, l3) == 0.0
+    assert oracle.linker3d_score(cfg, 2, l1, l1) == 1.0
+
+
+def test_kat_vi_multiview_support(oracle):
+    """(vi) scoreOneNode: one GT line seen exactly in 5 views + 1 outlier match.  Every true
+    candidate is supported once per OTHER neighbour image (score 1 each), the outlier gets 0;
+    best = first strict maximum; valid edges = candidates with score >= fullscore_th."""
+    P, Q = np.array([1.0, 4.0, 1.2]), np.array([2.2, 4.2, 1.7])
+    centers = [np.array([0.0, 0, 0.3]), np.array([1.0, -0.5, 2.6]), np.array([2.0, 0.2, 0.1]),
+               np.array([3.0, -0.3, 2.8]), np.array([3.8, 0.4, 0.2])]
+    cams = [look_at_cam(c, 0.5 * (P + Q)) for c in centers]
+    segs, off = [], [0]
+    for n, c in enumerate(cams):
+        segs.append(np.concatenate([project(c, P), project(c, Q)]))
+        if n == 2:  # an unrelated segment in image 2, matched as an outlier
+            segs.append(np.array([50.0, 60.0, 300.0, 400.0]))
+        off.append(len(segs))
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    O = oracle.OracleTriangulator(cfg)
+    arr = np.stack(cams)
+    O.Init(list(range(5)), arr[:, :4], arr[:, 4:8], arr[:, 8:], off, np.stack(segs))
+    matches = {1: np.array([[0, 0]]), 2: np.array([[0, 0], [0, 1]]), 3: np.array([[0, 0]]), 4: np.array([[0, 0]])}
+    O.TriangulateImage(0, matches)
+    tri = O.get_all_tris()
+    n0 = tri["off"][1]
+    src = tri["src"][:n0]
+    sc = tri["score"][:n0]
+    true = ~((src[:, 0] == 2) & (src[:, 1] == 1))
+    assert true.sum() == 4
+    np.testing.assert_allclose(sc[true], 3.0, atol=1e-6)  # three other neighbour images each
+    assert np.all(sc[~true] == 0.0)
+    b = O.get_best()
+    assert tuple(b["src"][0]) == tuple(src[int(np.argmax(sc))])  # first strict maximum in candidate order
+    assert b["score"][0] == sc.max()
+    eoff, edges = O.get_valid_edges()
+    assert eoff[1] == 4 and set(map(tuple, edges[:4])) == {(0, 0), (1, 0), (2, 0), (3, 0)}
+
+
+def test_kat_vii_union_find_labels(oracle):
+    """(vii) ComputeLineTrackLabelsGreedy on a toy graph: edges sorted by (sim, n1, n2) descending,
+    every edge unions, smaller image set hangs under the larger (ties: root2 under root1), labels in
+    order of the first node whose direct parent is a final root."""
+    node_img = [0, 1, 2, 0, 1, 5, 7]
+    edges = [(0.9, 0, 1), (0.8, 1, 2), (0.95, 3, 4), (0.6, 4, 5)]
+    lab = oracle.track_labels_greedy(node_img, [e[0] for e in edges], [[e[1], e[2]] for e in edges])
+    # order: (3,4) -> parent[4]=3 ; (0,1) -> parent[1]=0 ; (1,2) -> root(1)=0 has 2 imgs > 1 -> parent[2]=0 ;
+    # (4,5) -> parent[5]=3.  node 6 isolated.  first labelled root: node 1's parent 0 -> track 0 ; then 3 -> 1
+    assert lab.tolist() == [0, 0, 0, 1, 1, 1, -1]
+    # tie on sim falls back to the node indices (descending tuple order)
+    lab = oracle.track_labels_greedy([0, 1, 0, 1], [0.7, 0.7], [[0, 1], [2, 3]])
+    assert lab.tolist() == [0, 0, 1, 1]
+    # smaller image set attaches under the larger one: {2 imgs} absorbs {1 img} regardless of edge direction
+    lab = oracle.track_labels_greedy([0, 1, 2], [0.9, 0.5], [[1, 2], [0, 1]])
+    assert lab.tolist() == [0, 0, 0]
+
+
+def test_kat_viii_aggregator(oracle):
+    """(viii) collinear supports: endpoints at sorted projections [k] and [2n-1-k]; < 4 supports
+    returns the best-scored line with the minimum uncertainty."""
+    d = np.array([1.0, 2.0, 2.0]) / 3.0
+    o = np.array([0.5, -1.0, 2.0])
+    spans = [(0.0, 1.0), (0.2, 1.5), (-0.3, 0.9), (0.1, 1.2), (0.4, 2.0)]
+    lines = np.array([np.concatenate([o + a * d, o + b * d, [1, 1, 0.01 * (i + 1), 1]]) for i, (a, b) in enumerate(spans)])
+    out = oracle.aggregate_line3d_list(lines, np.ones(5), 2)
+    ts = sorted([v for ab in spans for v in ab])
+    lo, hi = o + ts[2] * d, o + ts[-3] * d
+    got = (out[:3], out[3:6])
+    ok = (np.allclose(got[0], lo, atol=1e-10) and np.allclose(got[1], hi, atol=1e-10)) or \
+         (np.allclose(got[0], hi, atol=1e-10) and np.allclose(got[1], lo, atol=1e-10))
+    assert ok and abs(out[6] - 0.01) < 1e-15
+    out3 = oracle.aggregate_line3d_list(lines[:3], np.array([0.5, 2.0, 1.0]), 2)
+    np.testing.assert_array_equal(out3[:6], lines[1, :6])
+    assert out3[6] == 0.01
+
+
+def test_sensitivity_and_ranges(oracle, two_views):
+    P, Q, c1, c2 = two_views
+    C1 = oracle.cam_center(c1)
+    l = np.concatenate([P, Q, [1, 1, -1, 1]])
+    mid2d = 0.5 * (project(c1, P) + project(c1, Q))
+    ray = oracle.cam_ray_direction(c1, mid2d)
+    dirv = (Q - P) / np.linalg.norm(Q - P)
+    expect = 90 - np.degrees(np.arccos(abs(dirv @ ray)))
+    assert abs(oracle.line3d_sensitivity(l, c1) - expect) < 1e-9
+    # ranges filter drops candidates outside the box (functions.cc:8-26)
+    s1 = np.concatenate([project(c1, P), project(c1, Q)]); s2 = np.concatenate([project(c2, P), project(c2, Q)])
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    for rng_, n in (((np.zeros(3), np.full(3, 10.0)), 1), ((np.zeros(3), np.array([10, 10, 1.5])), 0)):
+        O = oracle.OracleTriangulator(cfg)
+        O.SetRanges(rng_)
+        O.Init([0, 1], np.stack([c1[:4], c2[:4]]), np.stack([c1[4:8], c2[4:8]]), np.stack([c1[8:], c2[8:]]), [0, 1, 2],
+               np.stack([s1, s2]))
+        O.TriangulateImage(0, {1: np.array([[0, 0]], np.int32)})
+        assert O.get_num_tris()[0] == n
+
+
+def test_out_of_index_match_raises(oracle, two_views):
+    P, Q, c1, c2 = two_views
+    s = np.array([10.0, 10.0, 200.0, 50.0])
+    O = oracle.OracleTriangulator(syn.default_triangulation_cfg())
+    O.Init([0, 1], np.stack([c1[:4], c2[:4]]), np.stack([c1[4:8], c2[4:8]]), np.stack([c1[8:], c2[8:]]), [0, 1, 2],
+           np.stack([s, s]))
+    with pytest.raises(RuntimeError, match="IndexError"):
+        O.TriangulateImage(0, {1: np.array([[3, 0]], np.int32)})
