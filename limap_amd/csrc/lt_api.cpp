@@ -26,6 +26,28 @@ using namespace lt;
 
 namespace lt {
 void launch_fn_query(hipStream_t st, const double *in30, int by_endpoints, double *out32);
+// lt_kernels_v2.hip
+void launch_line_off(hipStream_t st, long long P, int n_blk, long long n_entries, const long long *m_off,
+                     const int *m_pairs, const long long *blk_line_base, unsigned *line_off, int *unsorted_flag);
+void launch_node_conn_count(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
+                            const long long *nb_off, const long long *blk_line_base, const unsigned *line_off,
+                            unsigned *conn_cnt);
+void launch_build_rowlist(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
+                          const long long *nb_off, const long long *blk_line_base, const unsigned *line_off,
+                          const long long *conn_off, unsigned *srows);
+void launch_gen_rows(hipStream_t st, long long P, int n_blk, const GenCfg &cfg, const long long *m_off,
+                     const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
+                     const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs, Cand *st_c,
+                     CandLite *st_l, unsigned char *flag8, unsigned *n_tris);
+void launch_node_fill(hipStream_t st, long long G, const long long *conn_off, const unsigned *srows,
+                      const unsigned char *flag8, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
+                      Cand *cand, CandLite *lite, unsigned *cand_node);
+void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, unsigned *cand_node);
+size_t score2_lds_bytes(int max_nb);
+void launch_score2(hipStream_t st, long long C_cap, long long G, const long long *tri_off, const unsigned *cand_node,
+                   const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
+                   const int *blk_nb, const int *blk_order, const long long *seg_off, const Seg *segs,
+                   const Cam *cams, double *score, int max_nb, const ScoreCfg &cfg, double scaleinv_guard2);
 }
 
 namespace {
@@ -110,6 +132,10 @@ struct lt_ctx {
   DevBuf d_item_off, d_masks, d_mask_cnt, d_mask_pos;
   DevBuf d_cand, d_lite, d_tri_off, d_score, d_best_idx, d_edge_flag, d_nvalid, d_edge_off, d_edges;
   DevBuf d_best_c, d_best_score, d_best_src, d_ntris, d_err;
+  DevBuf d_blk_line_base, d_line_off, d_conn_cnt, d_flag8, d_ntris_u, d_cand_node;
+  std::vector<long long> h_blk_line_base;
+  bool rows_sorted = true;   // every (image, neighbour) block lists its rows in non-decreasing line id
+  long long *h_pinned = nullptr;  // pinned scratch for small device->host scalars
   long long cand_cap = 0;
   long long C = 0, E = 0;  // candidates / valid edges of the last run
 
@@ -255,6 +281,7 @@ int init_common(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *s
   ctx->job_mode = 0;
   ctx->job_imgs.clear(); ctx->job_nbs.clear(); ctx->job_order.clear();
   ctx->h_m_off.assign(1, 0); ctx->h_m_pairs.clear();
+  ctx->rows_sorted = true;
   ctx->uploaded = ctx->ran = ctx->downloaded = false;
   return LT_OK;
 }
@@ -303,6 +330,11 @@ void build_job_tables(lt_ctx *ctx) {
   }
   ctx->h_nb_off[n_img] = (long long)ctx->h_blk_img.size();
   ctx->n_blk = (int)ctx->h_blk_img.size();
+  ctx->h_blk_line_base.assign(ctx->n_blk + 1, 0);
+  for (int b = 0; b < ctx->n_blk; ++b) {
+    int i1 = ctx->h_blk_img[b];
+    ctx->h_blk_line_base[b + 1] = ctx->h_blk_line_base[b] + (ctx->seg_off[i1 + 1] - ctx->seg_off[i1]) + 1;
+  }
 }
 
 template <class T>
@@ -357,6 +389,7 @@ lt_ctx *lt_create(const lt_config *cfg, int device) {
     return nullptr;
   }
   for (auto &ev : ctx->ev) (void)hipEventCreate(&ev);
+  if (hipHostMalloc((void **)&ctx->h_pinned, 64, hipHostMallocDefault) != hipSuccess) ctx->h_pinned = nullptr;
   return ctx;
 }
 
@@ -372,7 +405,9 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_item_off, &ctx->d_masks, &ctx->d_mask_cnt, &ctx->d_mask_pos, &ctx->d_cand,
                     &ctx->d_lite, &ctx->d_tri_off, &ctx->d_score, &ctx->d_best_idx, &ctx->d_edge_flag,
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
-                    &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err};
+                    &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_line_off,
+                    &ctx->d_conn_cnt, &ctx->d_flag8, &ctx->d_ntris_u, &ctx->d_cand_node};
+  if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   for (DevBuf *b : bufs) b->release();
   for (auto &ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -491,6 +526,7 @@ static int begin_image(lt_ctx *ctx, int img_id, int mode, int *idx_out) {
   if (ctx->downloaded) {  // a new batch after results were read: start a fresh job
     ctx->job_imgs.clear(); ctx->job_nbs.clear(); ctx->job_order.clear();
     ctx->h_m_off.assign(1, 0); ctx->h_m_pairs.clear();
+    ctx->rows_sorted = true;
     ctx->uploaded = ctx->ran = ctx->downloaded = false;
   }
   ctx->job_mode = mode;
@@ -528,8 +564,11 @@ int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_id
     }
     const long long M2 = ctx->seg_off[it->second + 1] - ctx->seg_off[it->second];
     long long r0 = m_off[o], r1 = m_off[o + 1];
+    int prev_line = -1;
     for (long long r = r0; r < r1; ++r) {
       int line = m_pairs[2 * r], ng = m_pairs[2 * r + 1];
+      if (line < prev_line) ctx->rows_sorted = false;
+      prev_line = line;
       if (line < 0 || line >= M1) {  // base_line_triangulator.cc:87-94
         ctx->h_m_off.resize(m_off_mark); ctx->h_m_pairs.resize(pairs_mark);
         return fail(ctx, LT_ERR_RUNTIME,
@@ -596,6 +635,7 @@ int lt_upload(lt_ctx *ctx) {
   if ((rc = upload_vec(ctx, ctx->d_blk_nb, ctx->h_blk_nb))) return rc;
   if ((rc = upload_vec(ctx, ctx->d_blk_slot, ctx->h_blk_slot))) return rc;
   if ((rc = upload_vec(ctx, ctx->d_blk_order, ctx->h_blk_order))) return rc;
+  if ((rc = upload_vec(ctx, ctx->d_blk_line_base, ctx->h_blk_line_base))) return rc;
   if (ctx->job_mode == 1) {
     // block order in the tables is image-index-major; the staging arrays are call-order-major:
     // re-pack rows so that block b of the table owns rows m_off[b]..m_off[b+1]
@@ -689,51 +729,84 @@ int lt_run_device(lt_ctx *ctx) {
                      ctx->d_pairs.as<PairRec>());
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
 
+  long long C_known = -1;  // candidate count once it is known on the host
   if (ctx->job_mode == 1) {
     const size_t Pn = (size_t)std::max<long long>(P, 1);
-    ENSURE(ctx, ctx->d_keys, 4 * Pn); ENSURE(ctx, ctx->d_rows, 4 * Pn); ENSURE(ctx, ctx->d_row_blk, 4 * Pn);
-    ENSURE(ctx, ctx->d_skeys, 4 * Pn); ENSURE(ctx, ctx->d_srows, 4 * Pn);
+    ENSURE(ctx, ctx->d_srows, 4 * Pn);
     ENSURE(ctx, ctx->d_conn_off, sizeof(long long) * (size_t)(G + 1));
-    launch_conn_keys(st, P, ctx->n_blk, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
-                     ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
-                     ctx->d_keys.as<unsigned>(), ctx->d_rows.as<unsigned>(), ctx->d_row_blk.as<unsigned>(),
-                     ctx->d_err.as<int>());
-    if (P > 0) {
-      // keys are node ids < G plus the 0xFFFFFFFF sentinel of rejected rows (never produced here:
-      // rows are validated on the host), so G's bit width suffices
-      int end_bit = bits_for(G + 1);
-      size_t tmp = sort_temp_bytes(P, end_bit);
-      ENSURE(ctx, ctx->d_sort_tmp, std::max<size_t>(tmp, 16));
-      if (launch_sort(st, ctx->d_sort_tmp.p, tmp, P, ctx->d_keys.as<unsigned>(), ctx->d_skeys.as<unsigned>(),
-                      ctx->d_rows.as<unsigned>(), ctx->d_srows.as<unsigned>(), end_bit) != 0)
-        return fail(ctx, LT_ERR_HIP, "rocprim radix sort failed");
+    // ---- group the match rows by node, in the reference's candidate order ----
+    if (ctx->rows_sorted) {
+      // every block lists its rows by non-decreasing line id: offsets instead of a sort
+      const long long n_entries = ctx->h_blk_line_base[ctx->n_blk];
+      ENSURE(ctx, ctx->d_line_off, 4 * (size_t)std::max<long long>(n_entries, 1));
+      ENSURE(ctx, ctx->d_conn_cnt, 4 * (size_t)(G + 1));
+      launch_line_off(st, P, ctx->n_blk, n_entries, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
+                      ctx->d_blk_line_base.as<long long>(), ctx->d_line_off.as<unsigned>(), ctx->d_err.as<int>());
+      launch_node_conn_count(st, G, ctx->d_node_img.as<int>(), ctx->d_seg_off.as<long long>(),
+                             ctx->d_nb_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
+                             ctx->d_line_off.as<unsigned>(), ctx->d_conn_cnt.as<unsigned>());
+      size_t tmp = scan_temp_bytes_u32_to_i64(G + 1);
+      ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
+      if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, G + 1, ctx->d_conn_cnt.as<unsigned>(),
+                                 ctx->d_conn_off.as<long long>()) != 0)
+        return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+      launch_build_rowlist(st, G, ctx->d_node_img.as<int>(), ctx->d_seg_off.as<long long>(),
+                           ctx->d_nb_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
+                           ctx->d_line_off.as<unsigned>(), ctx->d_conn_off.as<long long>(),
+                           ctx->d_srows.as<unsigned>());
+    } else {
+      // generic input: stable radix sort of the rows by node id
+      ENSURE(ctx, ctx->d_keys, 4 * Pn); ENSURE(ctx, ctx->d_rows, 4 * Pn); ENSURE(ctx, ctx->d_row_blk, 4 * Pn);
+      ENSURE(ctx, ctx->d_skeys, 4 * Pn);
+      launch_conn_keys(st, P, ctx->n_blk, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
+                       ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
+                       ctx->d_keys.as<unsigned>(), ctx->d_rows.as<unsigned>(), ctx->d_row_blk.as<unsigned>(),
+                       ctx->d_err.as<int>());
+      if (P > 0) {
+        int end_bit = bits_for(G + 1);
+        size_t tmp = sort_temp_bytes(P, end_bit);
+        ENSURE(ctx, ctx->d_sort_tmp, std::max<size_t>(tmp, 16));
+        if (launch_sort(st, ctx->d_sort_tmp.p, tmp, P, ctx->d_keys.as<unsigned>(), ctx->d_skeys.as<unsigned>(),
+                        ctx->d_rows.as<unsigned>(), ctx->d_srows.as<unsigned>(), end_bit) != 0)
+          return fail(ctx, LT_ERR_HIP, "rocprim radix sort failed");
+      }
+      launch_node_offsets(st, P, G, ctx->d_skeys.as<unsigned>(), ctx->d_conn_off.as<long long>());
     }
-    launch_node_offsets(st, P, G, ctx->d_skeys.as<unsigned>(), ctx->d_conn_off.as<long long>());
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
-    // staging slots: one per connection; the compacted arrays get the same capacity so that no
-    // host round trip is needed between generation and scoring
+    // ---- generation in row order; survivors staged at their row index ----
     ENSURE(ctx, ctx->d_st_c, sizeof(Cand) * Pn); ENSURE(ctx, ctx->d_st_l, sizeof(CandLite) * Pn);
-    ENSURE(ctx, ctx->d_flags, 4 * (Pn + 1)); ENSURE(ctx, ctx->d_pos, 4 * (Pn + 1));
-    ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Pn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Pn);
-    ENSURE(ctx, ctx->d_score, 8 * Pn); ENSURE(ctx, ctx->d_edge_flag, 4 * Pn);
-    ctx->cand_cap = (long long)Pn;
-    launch_gen_matched(st, P, gcfg, ctx->d_skeys.as<unsigned>(), ctx->d_srows.as<unsigned>(),
-                       ctx->d_row_blk.as<unsigned>(), ctx->d_m_pairs.as<int>(), ctx->d_blk_img.as<int>(),
-                       ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(), ctx->d_seg_off.as<long long>(),
-                       ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
-                       ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(), ctx->d_flags.as<unsigned>());
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_flags.as<unsigned>() + P, 0, 4, st));
+    ENSURE(ctx, ctx->d_flag8, Pn); ENSURE(ctx, ctx->d_ntris_u, 4 * (size_t)(G + 1));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_flag8.p, 0, Pn, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_ntris_u.p, 0, 4 * (size_t)(G + 1), st));
+    launch_gen_rows(st, P, ctx->n_blk, gcfg, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
+                    ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(),
+                    ctx->d_seg_off.as<long long>(), ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(),
+                    ctx->d_pairs.as<PairRec>(), ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(),
+                    ctx->d_flag8.as<unsigned char>(), ctx->d_ntris_u.as<unsigned>());
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
     {
-      size_t tmp = scan_temp_bytes_u32(P + 1);
+      size_t tmp = scan_temp_bytes_u32_to_i64(G + 1);
       ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
-      if (launch_scan_u32(st, ctx->d_scan_tmp.p, tmp, P + 1, ctx->d_flags.as<unsigned>(), ctx->d_pos.as<unsigned>()) != 0)
+      if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, G + 1, ctx->d_ntris_u.as<unsigned>(),
+                                 ctx->d_tri_off.as<long long>()) != 0)
         return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
     }
-    launch_compact(st, P, ctx->d_flags.as<unsigned>(), ctx->d_pos.as<unsigned>(), ctx->d_st_c.as<Cand>(),
-                   ctx->d_st_l.as<CandLite>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>());
-    launch_tri_offsets(st, G, ctx->d_conn_off.as<long long>(), ctx->d_pos.as<unsigned>(), P, 0u,
-                       ctx->d_tri_off.as<long long>());
+    // the candidate count sizes the compact arrays and the scoring grid: an 8-byte async copy
+    // whose wait overlaps with nothing heavier than the scan
+    long long *hC = ctx->h_pinned ? ctx->h_pinned : nullptr;
+    long long hC_fallback = 0;
+    if (!hC) hC = &hC_fallback;
+    HIPCHK(ctx, hipMemcpyAsync(hC, ctx->d_tri_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    C_known = *hC;
+    const size_t Cn = (size_t)std::max<long long>(C_known, 1);
+    ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);
+    ENSURE(ctx, ctx->d_score, 8 * Cn); ENSURE(ctx, ctx->d_edge_flag, 4 * Cn); ENSURE(ctx, ctx->d_cand_node, 4 * Cn);
+    ctx->cand_cap = (long long)Cn;
+    launch_node_fill(st, G, ctx->d_conn_off.as<long long>(), ctx->d_srows.as<unsigned>(),
+                     ctx->d_flag8.as<unsigned char>(), ctx->d_tri_off.as<long long>(), ctx->d_st_c.as<Cand>(),
+                     ctx->d_st_l.as<CandLite>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
+                     ctx->d_cand_node.as<unsigned>());
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
   } else if (ctx->job_mode == 2) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
@@ -769,25 +842,31 @@ int lt_run_device(lt_ctx *ctx) {
                           ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>());
     launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, total,
                           ctx->d_tri_off.as<long long>());
+    ENSURE(ctx, ctx->d_cand_node, 4 * Cn);
+    launch_cand_node(st, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>());
+    C_known = total;
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
   } else {
     HIPCHK(ctx, hipMemsetAsync(ctx->d_tri_off.p, 0, sizeof(long long) * (size_t)(G + 1), st));
     ENSURE(ctx, ctx->d_cand, sizeof(Cand)); ENSURE(ctx, ctx->d_lite, sizeof(CandLite));
-    ENSURE(ctx, ctx->d_score, 8); ENSURE(ctx, ctx->d_edge_flag, 4);
+    ENSURE(ctx, ctx->d_score, 8); ENSURE(ctx, ctx->d_edge_flag, 4); ENSURE(ctx, ctx->d_cand_node, 4);
+    C_known = 0;
     for (int k = 2; k <= 4; ++k) HIPCHK(ctx, hipEventRecord(ctx->ev[k], st));
   }
 
   // ---- scoring ----
-  ScoreArgs sa;
-  sa.G = G; sa.tri_off = ctx->d_tri_off.as<long long>(); sa.cand = ctx->d_cand.as<Cand>();
-  sa.lite = ctx->d_lite.as<CandLite>(); sa.node_img = ctx->d_node_img.as<int>();
-  sa.nb_off = ctx->d_nb_off.as<long long>(); sa.blk_nb = ctx->d_blk_nb.as<int>();
-  sa.blk_order = ctx->d_blk_order.as<int>(); sa.seg_off = ctx->d_seg_off.as<long long>();
-  sa.segs = ctx->d_segs.as<Seg>(); sa.cams = ctx->d_cams.as<Cam>(); sa.score = ctx->d_score.as<double>();
-  sa.max_nb = ctx->max_nb;
-  if (score_lds_bytes(sa.max_nb) > 160 * 1024)
+  if (score2_lds_bytes(ctx->max_nb) > 160 * 1024)
     return fail(ctx, LT_ERR_ARGUMENT, "too many neighbours for the scoring kernel's LDS budget");
-  launch_score(st, sa, scfg);
+  {
+    // conservative square of the scale-invariant endpoint gate (see k_score2)
+    double th = scfg.l3.th_scaleinv * (1.0 + 1e-6);
+    double guard2 = (scfg.l3.th_scaleinv > 0.0 && scfg.l3.score_th > 0.0 && scfg.l3.score_th < 1.0) ? th * th : 1e300;
+    launch_score2(st, C_known, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(),
+                  ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_node_img.as<int>(),
+                  ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_blk_order.as<int>(),
+                  ctx->d_seg_off.as<long long>(), ctx->d_segs.as<Seg>(), ctx->d_cams.as<Cam>(),
+                  ctx->d_score.as<double>(), ctx->max_nb, scfg, guard2);
+  }
   HIPCHK(ctx, hipEventRecord(ctx->ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));
   ENSURE(ctx, ctx->d_nvalid, 4 * (size_t)(G + 1));

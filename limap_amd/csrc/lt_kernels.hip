@@ -19,23 +19,13 @@
 // hit L2/MALL, and the rules that matter are coalescing, wave64 ballots/shuffles, LDS atomics.
 // Compiled with -ffp-contract=off (see lt_geom.h).
 
-#include "lt_device.h"
+#include "lt_devfn.h"
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 namespace lt {
-
-static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-static __device__ __forceinline__ unsigned long long lanemask_lt() {
-  return (1ull << lane_id()) - 1ull;
-}
-// lanes of ONE wave exchanging data through LDS: order the DS traffic, no s_barrier needed
-static __device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 // ---------------------------------------------------------------------------------------------
 // invariants
@@ -130,171 +120,6 @@ __global__ void k_node_offsets(long long P, long long G, const unsigned *__restr
 // ---------------------------------------------------------------------------------------------
 // HOT LOOP 1: one connection -> at most one candidate
 // ---------------------------------------------------------------------------------------------
-struct GenOut {
-  Cand c;
-  CandLite l;
-};
-
-// triangulate_point, functions.cc:100-117 (2x2 LDLT solve with diagonal pivoting)
-static __device__ __forceinline__ bool tri_point(const Cam &c1, d3 r1, const Cam &c2, d3 r2, d3 *out) {
-  d3 C1 = cam_center(c1), C2 = cam_center(c2);
-  double a00 = dot(r1, r1), a10 = -dot(r2, r1), a11 = dot(r2, r2);
-  double b0 = dot(r1, sub(C2, C1));
-  double b1 = dot(r2, sub(C1, C2));
-  bool sw = fabs(a11) > fabs(a00);
-  double dd0 = sw ? a11 : a00, dd1 = sw ? a00 : a11;
-  double q0 = sw ? b1 : b0, q1 = sw ? b0 : b1;
-  double l10 = a10 / dd0;
-  double s1d = dd1 - l10 * (dd0 * l10);
-  double y1 = q1 - l10 * q0;
-  double z0 = q0 / dd0, z1 = y1 / s1d;
-  double s0 = z0 - l10 * z1;
-  double x0 = sw ? z1 : s0, x1 = sw ? s0 : z1;
-  d3 p = add(add(add(scale(r1, x0), C1), scale(r2, x1)), C2);
-  p = d3{0.5 * p.x, 0.5 * p.y, 0.5 * p.z};
-  if (cam_depth(c1, p) < kEps || cam_depth(c2, p) < kEps) return false;
-  *out = p;
-  return true;
-}
-
-// Line3d::sensitivity, linebase.cc:100-107
-static __device__ __forceinline__ double sensitivity(const Cam &c, d3 s, d3 e, d3 dir3) {
-  d2 ps = cam_project(c, s), pe = cam_project(c, e);
-  d2 mid = d2{0.5 * (ps.x + pe.x), 0.5 * (ps.y + pe.y)};
-  d3 ray = cam_ray(c, mid);
-  double cv = fabs(dot(dir3, ray));
-  return 90 - acos(cv) * 180.0 / kPi;
-}
-
-// compute_epipolar_IoU (functions.cc:76-98) with the fundamental matrix hoisted per image pair
-static __device__ __forceinline__ double epipolar_iou(const Seg &s1, const Seg &s2, const double *F) {
-  L2 l2{mk2(s2.x1, s2.y1), mk2(s2.x2, s2.y2)};
-  double ln2 = len(l2);
-  d3 lc2 = mk3(s2.lc[0], s2.lc[1], s2.lc[2]);
-  d3 eps = unit(mv(F, mk3(s1.x1, s1.y1, 1.0)));
-  d3 hs = cross(lc2, eps);
-  double zs = hs.z + kEps;
-  d2 cs = d2{hs.x / zs, hs.y / zs};
-  d3 epe = unit(mv(F, mk3(s1.x2, s1.y2, 1.0)));
-  d3 he = cross(lc2, epe);
-  double ze = he.z + kEps;
-  d2 ce = d2{he.x / ze, he.y / ze};
-  d2 dv = dir(l2);
-  double c1v = dot(sub(cs, l2.s), dv) / ln2;
-  double c2v = dot(sub(ce, l2.s), dv) / ln2;
-  if (c1v > c2v) {
-    double t = c1v; c1v = c2v; c2v = t;
-  }
-  return (dmin(c2v, 1.0) - dmax(c1v, 0.0)) / (dmax(c2v, 1.0) - dmin(c1v, 0.0));
-}
-
-// line_triangulation (functions.cc:194-233): x = (A^-1 B)[0], A = [c1 | -c2s | -c2e]
-static __device__ __forceinline__ bool tri_line(const Cam &c1, const Cam &c2, const Seg &s1, const Seg &s2,
-                                                const double *Bv, d3 *ps_o, d3 *pe_o, double *z_start,
-                                                double *z_end, double *d21, double *d22) {
-  d3 r1s = mk3(s1.rs[0], s1.rs[1], s1.rs[2]), r1e = mk3(s1.re[0], s1.re[1], s1.re[2]);
-  d3 c2s = mk3(s2.rs[0], s2.rs[1], s2.rs[2]), c2e = mk3(s2.re[0], s2.re[1], s2.re[2]);
-  d3 u = mk3(-c2s.x, -c2s.y, -c2s.z), v = mk3(-c2e.x, -c2e.y, -c2e.z);
-  // cofactors (j,0) of A do not involve column 0: shared by the start and the end solve
-  double k0 = u.y * v.z - v.y * u.z;
-  double k1 = u.z * v.x - v.z * u.x;
-  double k2 = u.x * v.y - v.x * u.y;
-  d3 B = mk3(Bv[0], Bv[1], Bv[2]);
-  d3 C1 = cam_center(c1);
-  d3 ps, pe;
-  {
-    double det = (k0 * r1s.x + k1 * r1s.y) + k2 * r1s.z;
-    double id = 1.0 / det;
-    double x0 = ((k0 * id) * B.x + (k1 * id) * B.y) + (k2 * id) * B.z;
-    ps = add(scale(r1s, x0), C1);
-    *z_start = cam_depth(c1, ps);
-  }
-  {
-    double det = (k0 * r1e.x + k1 * r1e.y) + k2 * r1e.z;
-    double id = 1.0 / det;
-    double x0 = ((k0 * id) * B.x + (k1 * id) * B.y) + (k2 * id) * B.z;
-    pe = add(scale(r1e, x0), C1);
-    *z_end = cam_depth(c1, pe);
-  }
-  *ps_o = ps;
-  *pe_o = pe;
-  if (*z_start < kEps || *z_end < kEps) return false;
-  *d21 = cam_depth(c2, ps);
-  *d22 = cam_depth(c2, pe);
-  if (*d21 < kEps || *d22 < kEps) return false;
-  if (isnan(ps.x) || isnan(pe.x)) return false;
-  return true;
-}
-
-static __device__ __forceinline__ bool gen_one(const GenCfg &cfg, const Cam &c1, const Cam &c2,
-                                               const Seg &s1, const Seg &s2, const PairRec &pr,
-                                               GenOut *out) {
-  L2 l1{mk2(s1.x1, s1.y1), mk2(s1.x2, s1.y2)};
-  L2 l2{mk2(s2.x1, s2.y1), mk2(s2.x2, s2.y2)};
-  if (len(l1) <= cfg.min_length_2d) return false;  // base_line_triangulator.cc:166
-  double ln2 = len(l2);
-  if (ln2 <= cfg.min_length_2d) return false;      // :177
-  if (cfg.disable_algebraic) return false;
-  // degeneracy by ray-plane angles (:293-302).  angle = 90 - acos(a) 180/pi < th  <=>  a < sin(th)
-  // up to libm rounding: outside the [sin_lo, sin_hi] band the cosine alone decides.
-  d3 n2 = mk3(s2.n[0], s2.n[1], s2.n[2]);
-  d3 r1s = mk3(s1.rs[0], s1.rs[1], s1.rs[2]), r1e = mk3(s1.re[0], s1.re[1], s1.re[2]);
-  double as = fabs(dot(n2, r1s));
-  if (as < cfg.sin_lo) return false;
-  if (!(as > cfg.sin_hi)) {
-    double ang = 90 - acos(as) * 180.0 / kPi;
-    if (ang < cfg.angle_th) return false;
-  }
-  double ae = fabs(dot(n2, r1e));
-  if (ae < cfg.sin_lo) return false;
-  if (!(ae > cfg.sin_hi)) {
-    double ang = 90 - acos(ae) * 180.0 / kPi;
-    if (ang < cfg.angle_th) return false;
-  }
-  // weak epipolar constraint (:305-307)
-  {
-    double iou = epipolar_iou(s1, s2, pr.F);
-    if (iou < cfg.iou_th) return false;
-  }
-  d3 ps, pe;
-  double z_start, z_end, d21, d22;
-  if (!cfg.use_endpoints) {
-    if (!tri_line(c1, c2, s1, s2, pr.B, &ps, &pe, &z_start, &z_end, &d21, &d22)) return false;
-  } else {
-    // triangulate_line_by_endpoints (functions.cc:172-190)
-    d3 c2s = mk3(s2.rs[0], s2.rs[1], s2.rs[2]), c2e = mk3(s2.re[0], s2.re[1], s2.re[2]);
-    if (!tri_point(c1, r1s, c2, c2s, &ps)) return false;
-    if (!tri_point(c1, r1e, c2, c2e, &pe)) return false;
-    z_start = cam_depth(c1, ps);
-    z_end = cam_depth(c1, pe);
-    d21 = cam_depth(c2, ps);
-    d22 = cam_depth(c2, pe);
-  }
-  d3 dir3 = unit(sub(pe, ps));
-  // sensitivity gate (:315-317): rejected only if too sensitive in BOTH views
-  if (sensitivity(c1, ps, pe, dir3) > cfg.sens_th && sensitivity(c2, ps, pe, dir3) > cfg.sens_th)
-    return false;
-  // uncertainty (:319-321; linebase.cc:109-116; camera.cc:228-242)
-  double u1 = cfg.var2d * ((z_start + z_end) / 2.0) / c1.f;
-  double u2 = cfg.var2d * ((d21 + d22) / 2.0) / c2.f;
-  // ranges (:330-333; functions.cc:8-26)
-  if (cfg.use_ranges) {
-    if (ps.x < cfg.lo[0] || ps.x > cfg.hi[0]) return false;
-    if (ps.y < cfg.lo[1] || ps.y > cfg.hi[1]) return false;
-    if (ps.z < cfg.lo[2] || ps.z > cfg.hi[2]) return false;
-    if (pe.x < cfg.lo[0] || pe.x > cfg.hi[0]) return false;
-    if (pe.y < cfg.lo[1] || pe.y > cfg.hi[1]) return false;
-    if (pe.z < cfg.lo[2] || pe.z > cfg.hi[2]) return false;
-  }
-  out->c.s[0] = ps.x; out->c.s[1] = ps.y; out->c.s[2] = ps.z;
-  out->c.e[0] = pe.x; out->c.e[1] = pe.y; out->c.e[2] = pe.z;
-  out->c.depth[0] = z_start; out->c.depth[1] = z_end;
-  out->c.unc = dmin(u1, u2);
-  out->c.score3 = 1.0;
-  out->l.dir[0] = dir3.x; out->l.dir[1] = dir3.y; out->l.dir[2] = dir3.z;
-  return true;
-}
-
 // Matched mode: thread t handles the t-th connection in node-major order.  Survivors are
 // written to slot t of the staging arrays; k_compact squeezes them (stable) afterwards.
 __global__ void __launch_bounds__(256)
@@ -424,22 +249,6 @@ __global__ void k_tri_offsets_ex(long long G, const long long *__restrict__ item
 constexpr int kQCap = 256;       // per-wave pair queue (entries), drained when > kQCap - 64
 constexpr int kWavesPerBlock = 4;
 
-
-// dense evaluation of one (i, j) pair: score3d (shared-parent mode) then score2d of l_i projected
-// into the view of j against the 2D segment that generated j.  global_line_triangulator.cc:97-104
-static __device__ __forceinline__ double pair_score(const ScoreCfg &cfg, const double *ti /*11*/,
-                                                    const Cand &cj, const Cam &camj, const Seg &sj) {
-  L3 li{mk3(ti[0], ti[1], ti[2]), mk3(ti[3], ti[4], ti[5])};
-  L3 lj{mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2])};
-  double dep[2] = {ti[9], ti[10]};
-  double s3 = score3d(cfg.l3, li, lj, 0.0, 0.0, dep);
-  if (s3 == 0) return 0.0;
-  L2 pi{cam_project(camj, li.s), cam_project(camj, li.e)};
-  L2 sg{mk2(sj.x1, sj.y1), mk2(sj.x2, sj.y2)};
-  double s2 = score2d(cfg.l2, pi, sg);
-  if (s2 == 0) return 0.0;
-  return dmin(s3, s2);
-}
 
 __global__ void __launch_bounds__(64 * kWavesPerBlock)
 k_score(ScoreArgs a, ScoreCfg cfg) {

@@ -45,3 +45,30 @@ def test_exhaustive_stage_by_stage(gpu_lib, oracle):
 def test_smoke_entry(gpu_lib, oracle):
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_matched_unsorted_rows_generic_grouping(gpu_lib, oracle):
+    """Rows of a block in arbitrary order (not grouped by line id): the backend falls back to the
+    stable radix sort by node; the candidate order must still follow the match-row order."""
+    sc = small_scene(seed=4, n_views=12, n_segs=90, n_neighbors=6)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    from limap_amd import triangulation as tri
+    T = tri.GlobalLineTriangulator(cfg)
+    O = oracle.OracleTriangulator(cfg, faithful=False)
+    T.SetRanges(sc.ranges); O.SetRanges(sc.ranges)
+    T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+    O.Init(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, sc.seg_off, sc.segs)
+    rng = np.random.default_rng(0)
+    for i in sc.img_ids:
+        m = sc.matches_of(int(i))
+        m = {k: v[rng.permutation(len(v))] for k, v in m.items()}
+        # dict order scrambled too: the reference iterates a std::map (ascending neighbour id)
+        keys = list(m.keys()); rng.shuffle(keys)
+        m = {k: m[k] for k in keys}
+        T.TriangulateImage(int(i), m)
+        O.TriangulateImage(int(i), m)
+    compare_candidates(T.context().get_all_tris(), O.get_all_tris())
+    compare_best(T.context().get_best(), O.get_best())
+    compare_valid_edges(T.context().get_valid_edges(), O.get_valid_edges())
+    T.ComputeLineTracks()
+    compare_tracks(T.context().get_tracks(), O.ComputeLineTracks())
