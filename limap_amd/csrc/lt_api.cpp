@@ -27,18 +27,19 @@ using namespace lt;
 namespace lt {
 void launch_fn_query(hipStream_t st, const double *in30, int by_endpoints, double *out32);
 // lt_kernels_v2.hip
-void launch_line_off(hipStream_t st, long long P, int n_blk, long long n_entries, const long long *m_off,
-                     const int *m_pairs, const long long *blk_line_base, unsigned *line_off, int *unsorted_flag);
+void launch_line_off(hipStream_t st, long long P, int n_blk, long long n_entries, long long max_rows,
+                     const long long *m_off, const int *m_pairs, const long long *blk_line_base,
+                     unsigned *line_off, int *unsorted_flag);
 void launch_node_conn_count(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                             const long long *nb_off, const long long *blk_line_base, const unsigned *line_off,
                             unsigned *conn_cnt);
 void launch_build_rowlist(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                           const long long *nb_off, const long long *blk_line_base, const unsigned *line_off,
                           const long long *conn_off, unsigned *srows);
-void launch_gen_rows(hipStream_t st, long long P, int n_blk, const GenCfg &cfg, const long long *m_off,
-                     const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
-                     const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs, Cand *st_c,
-                     CandLite *st_l, unsigned char *flag8, unsigned *n_tris);
+void launch_gen_rows(hipStream_t st, long long P, int n_blk, long long max_rows, const GenCfg &cfg,
+                     const long long *m_off, const int *m_pairs, const int *blk_img, const int *blk_nb,
+                     const int *blk_slot, const long long *seg_off, const Cam *cams, const Seg *segs,
+                     const PairRec *pairs, Cand *st_c, CandLite *st_l, unsigned char *flag8, unsigned *n_tris);
 void launch_node_fill(hipStream_t st, long long G, const long long *conn_off, const unsigned *srows,
                       const unsigned char *flag8, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
                       Cand *cand, CandLite *lite, unsigned *cand_node);
@@ -122,6 +123,7 @@ struct lt_ctx {
   int n_blk = 0;
   int max_nb = 1;
   long long P = 0;        // connections (matched) / work items (exhaustive: n_items)
+  long long max_rows = 0; // matched: most rows of any (image, neighbour) block
   long long n_conn = 0;   // connections tested (stat)
   std::vector<long long> h_nb_off;  // n_img+1
   std::vector<int> h_blk_img, h_blk_nb, h_blk_slot, h_blk_order;
@@ -659,6 +661,8 @@ int lt_upload(lt_ctx *ctx) {
     }
     ctx->P = m_off[ctx->n_blk];
     ctx->n_conn = ctx->P;
+    ctx->max_rows = 0;
+    for (int bq = 0; bq < ctx->n_blk; ++bq) ctx->max_rows = std::max(ctx->max_rows, m_off[bq + 1] - m_off[bq]);
     if (ctx->P >= (1ll << 32) - 1) return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch (>= 2^32-1)");
     ENSURE(ctx, ctx->d_m_pairs, sizeof(int) * 2 * (size_t)std::max<long long>(ctx->P, 1));
     if (in_order) {
@@ -740,7 +744,7 @@ int lt_run_device(lt_ctx *ctx) {
       const long long n_entries = ctx->h_blk_line_base[ctx->n_blk];
       ENSURE(ctx, ctx->d_line_off, 4 * (size_t)std::max<long long>(n_entries, 1));
       ENSURE(ctx, ctx->d_conn_cnt, 4 * (size_t)(G + 1));
-      launch_line_off(st, P, ctx->n_blk, n_entries, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
+      launch_line_off(st, P, ctx->n_blk, n_entries, ctx->max_rows, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
                       ctx->d_blk_line_base.as<long long>(), ctx->d_line_off.as<unsigned>(), ctx->d_err.as<int>());
       launch_node_conn_count(st, G, ctx->d_node_img.as<int>(), ctx->d_seg_off.as<long long>(),
                              ctx->d_nb_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
@@ -778,7 +782,7 @@ int lt_run_device(lt_ctx *ctx) {
     ENSURE(ctx, ctx->d_flag8, Pn); ENSURE(ctx, ctx->d_ntris_u, 4 * (size_t)(G + 1));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_flag8.p, 0, Pn, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ntris_u.p, 0, 4 * (size_t)(G + 1), st));
-    launch_gen_rows(st, P, ctx->n_blk, gcfg, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
+    launch_gen_rows(st, P, ctx->n_blk, ctx->max_rows, gcfg, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
                     ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(),
                     ctx->d_seg_off.as<long long>(), ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(),
                     ctx->d_pairs.as<PairRec>(), ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(),

@@ -144,6 +144,73 @@ static __device__ __forceinline__ bool gen_gates(const GenCfg &cfg, const Seg &s
   return true;
 }
 
+// Stage A with a cheap, conservative form of the weak-epipolar gate.  The reference computes
+// IoU = (min(c2,1) - max(c1,0)) / (max(c2,1) - min(c1,0)) from two normalised epipolar lines and
+// rejects IoU < th.  Only the DECISION is needed here, and the denominator is >= 1, so the test is
+// num - th * den < 0.  c1, c2 are evaluated without the intermediate normalisations (same algebra:
+// c = (N.xy . v - D s2 . v) / (D |v|^2) with N = lc2 x (F x~), D = N.z + eps |F x~|), which costs two
+// square roots and two divisions instead of five and fifteen.  The cheap form decides only when it is
+// far (1e-7) from the threshold and well conditioned; otherwise the exact expression is evaluated, so
+// the outcome is always the reference's.
+static __device__ __forceinline__ bool gen_gates_fast(const GenCfg &cfg, const Seg &s1, const Seg &s2,
+                                                      const double *F) {
+  const double d1x = s1.x1 - s1.x2, d1y = s1.y1 - s1.y2;
+  const double d2x = s2.x1 - s2.x2, d2y = s2.y1 - s2.y2;
+  const double q1 = d1x * d1x + d1y * d1y, q2 = d2x * d2x + d2y * d2y;
+  if (cfg.min_length_2d > 0.0) {  // base_line_triangulator.cc:166,177
+    if (sqrt(q1) <= cfg.min_length_2d) return false;
+    if (sqrt(q2) <= cfg.min_length_2d) return false;
+  } else if (cfg.min_length_2d == 0.0) {  // length <= 0  <=>  squared length == 0
+    if (q1 == 0.0 || q2 == 0.0) return false;
+  }
+  if (cfg.disable_algebraic) return false;
+  d3 n2 = mk3(s2.n[0], s2.n[1], s2.n[2]);
+  d3 r1s = mk3(s1.rs[0], s1.rs[1], s1.rs[2]), r1e = mk3(s1.re[0], s1.re[1], s1.re[2]);
+  double as = fabs(dot(n2, r1s));
+  if (as < cfg.sin_lo) return false;
+  if (!(as > cfg.sin_hi)) {
+    double ang = 90 - acos(as) * 180.0 / kPi;
+    if (ang < cfg.angle_th) return false;
+  }
+  double ae = fabs(dot(n2, r1e));
+  if (ae < cfg.sin_lo) return false;
+  if (!(ae > cfg.sin_hi)) {
+    double ang = 90 - acos(ae) * 180.0 / kPi;
+    if (ang < cfg.angle_th) return false;
+  }
+  // cheap weak-epipolar decision
+  {
+    const double vx = -d2x, vy = -d2y;  // e2 - s2
+    const double sv = s2.x1 * vx + s2.y1 * vy;
+    double cv[2];
+    bool well = q2 > 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double px = k == 0 ? s1.x1 : s1.x2, py = k == 0 ? s1.y1 : s1.y2;
+      const double ax = F[0] * px + F[1] * py + F[2];
+      const double ay = F[3] * px + F[4] * py + F[5];
+      const double az = F[6] * px + F[7] * py + F[8];
+      const double na = sqrt(ax * ax + ay * ay + az * az);
+      const double nx = s2.lc[1] * az - s2.lc[2] * ay;
+      const double ny = s2.lc[2] * ax - s2.lc[0] * az;
+      const double t1 = s2.lc[0] * ay, t2 = s2.lc[1] * ax;
+      const double D = (t1 - t2) + kEps * na;
+      well = well && (fabs(D) > 1e-4 * (fabs(t1) + fabs(t2))) && (na > 0.0);
+      cv[k] = ((nx * vx + ny * vy) - D * sv) / (D * q2);
+    }
+    double c1v = cv[0] < cv[1] ? cv[0] : cv[1], c2v = cv[0] < cv[1] ? cv[1] : cv[0];
+    double num = dmin(c2v, 1.0) - dmax(c1v, 0.0);
+    double den = dmax(c2v, 1.0) - dmin(c1v, 0.0);
+    double delta = num - cfg.iou_th * den;
+    double margin = 1e-7 * (1.0 + fabs(c1v) + fabs(c2v)) * (1.0 + fabs(cfg.iou_th));
+    if (well && delta < -margin) return false;
+    if (well && delta > margin) return true;
+  }
+  double iou = epipolar_iou(s1, s2, F);  // exact path (rare)
+  if (iou < cfg.iou_th) return false;
+  return true;
+}
+
 // Stage B: triangulation, cheirality, sensitivity gate, uncertainty, ranges (:309-333).
 static __device__ __forceinline__ bool gen_finish(const GenCfg &cfg, const Cam &c1, const Cam &c2,
                                                   const Seg &s1, const Seg &s2, const double *Bv,

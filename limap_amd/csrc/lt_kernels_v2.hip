@@ -40,29 +40,17 @@ __global__ void k_line_off_init(int n_blk, const long long *__restrict__ blk_lin
   line_off[e] = (unsigned)m_off[lo + 1];
 }
 
-// block of a row: wave-uniform binary search for the wave's first row, then a short walk
-static __device__ __forceinline__ int block_of_row(long long r, long long r_first, int n_blk,
-                                                   const long long *__restrict__ m_off) {
-  int lo = 0, hi = n_blk;
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if (m_off[mid] <= r_first) lo = mid; else hi = mid;
-  }
-  int b = lo;
-  while (b + 1 < n_blk && r >= m_off[b + 1]) ++b;
-  return b;
-}
-
+// grid.y = neighbour block, grid.x = 256-row chunk of the block: no search for the block of a row
 __global__ void __launch_bounds__(256)
-k_line_off(long long P, int n_blk, const long long *__restrict__ m_off, const int *__restrict__ m_pairs,
+k_line_off(const long long *__restrict__ m_off, const int *__restrict__ m_pairs,
            const long long *__restrict__ blk_line_base, unsigned *__restrict__ line_off,
            int *__restrict__ unsorted_flag) {
-  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= P) return;
-  long long r_first = r - (threadIdx.x & 63);
-  int b = block_of_row(r, r_first, n_blk, m_off);
+  const int b = blockIdx.y;
+  const long long rb = m_off[b], re = m_off[b + 1];
+  long long r = rb + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= re) return;
   int line = m_pairs[2 * r];
-  int prev = (r == m_off[b]) ? -1 : m_pairs[2 * (r - 1)];
+  int prev = (r == rb) ? -1 : m_pairs[2 * (r - 1)];
   if (line < prev) {
     *unsorted_flag = 1;  // the host checked this already; never expected
     return;
@@ -131,78 +119,62 @@ constexpr int kGenChunks = 8;   // 64-row chunks per wave
 constexpr int kGenQCap = 192;   // LDS queue entries per wave (drained at >= 64 + ... see below)
 
 __global__ void __launch_bounds__(256)
-k_gen_rows(long long P, int n_blk, GenCfg cfg, const long long *__restrict__ m_off,
-           const int *__restrict__ m_pairs, const int *__restrict__ blk_img, const int *__restrict__ blk_nb,
-           const int *__restrict__ blk_slot, const long long *__restrict__ seg_off,
-           const Cam *__restrict__ cams, const Seg *__restrict__ segs, const PairRec *__restrict__ pairs,
-           Cand *__restrict__ st_c, CandLite *__restrict__ st_l, unsigned char *__restrict__ flag8,
-           unsigned *__restrict__ n_tris) {
+k_gen_rows(GenCfg cfg, const long long *__restrict__ m_off, const int *__restrict__ m_pairs,
+           const int *__restrict__ blk_img, const int *__restrict__ blk_nb, const int *__restrict__ blk_slot,
+           const long long *__restrict__ seg_off, const Cam *__restrict__ cams, const Seg *__restrict__ segs,
+           const PairRec *__restrict__ pairs, Cand *__restrict__ st_c, CandLite *__restrict__ st_l,
+           unsigned char *__restrict__ flag8, unsigned *__restrict__ n_tris) {
   __shared__ unsigned q_row[4][kGenQCap];
-  __shared__ unsigned q_blk[4][kGenQCap];
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
-  const long long wave_id = (long long)blockIdx.x * 4 + wave;
-  const long long r0 = wave_id * (64ll * kGenChunks);
-  if (r0 >= P) return;
-  unsigned *qr = q_row[wave], *qb = q_blk[wave];
+  // grid.y = neighbour block (uniform: image pair, F, cameras live in scalar registers),
+  // grid.x * 4 waves * kGenChunks * 64 rows cover the block's rows
+  const int b = blockIdx.y;
+  const long long rb = m_off[b], re = m_off[b + 1];
+  const long long r0 = rb + ((long long)blockIdx.x * 4 + wave) * (64ll * kGenChunks);
+  if (r0 >= re) return;
+  const int i1 = blk_img[b], i2 = blk_nb[b], slot = blk_slot[b];
+  const long long g1 = seg_off[i1], g2 = seg_off[i2];
+  const PairRec *pr = pairs + b;
+  unsigned *qr = q_row[wave];
   int qn = 0;
-
-  // wave-uniform block of the first row
-  int b_first;
-  {
-    int lo = 0, hi = n_blk;
-    while (hi - lo > 1) {
-      int mid = (lo + hi) >> 1;
-      if (m_off[mid] <= r0) lo = mid; else hi = mid;
-    }
-    b_first = lo;
-  }
 
   auto stage_b = [&](int count) {  // dense: lanes 0..count-1 finish one surviving connection each
     if (lane < count) {
-      unsigned r = qr[lane], b = qb[lane];
+      unsigned r = qr[lane];
       int line = m_pairs[2 * (long long)r], ng = m_pairs[2 * (long long)r + 1];
-      int i1 = blk_img[b], i2 = blk_nb[b];
-      long long g = seg_off[i1] + line;
       GenOut o;
-      if (gen_finish(cfg, cams[i1], cams[i2], segs[g], segs[seg_off[i2] + ng], pairs[b].B, &o)) {
-        o.l.nb_slot = blk_slot[b];
+      if (gen_finish(cfg, cams[i1], cams[i2], segs[g1 + line], segs[g2 + ng], pr->B, &o)) {
+        o.l.nb_slot = slot;
         o.l.ng_line = ng;
         st_c[r] = o.c;
         st_l[r] = o.l;
         flag8[r] = 1;
-        atomicAdd(&n_tris[g], 1u);
+        atomicAdd(&n_tris[g1 + line], 1u);
       }
     }
   };
 
-  int b = b_first;
   for (int c = 0; c < kGenChunks; ++c) {
     long long r = r0 + 64ll * c + lane;
     bool pass = false;
-    if (r < P) {
-      while (b + 1 < n_blk && r >= m_off[b + 1]) ++b;
+    if (r < re) {
       int line = m_pairs[2 * r], ng = m_pairs[2 * r + 1];
-      int i1 = blk_img[b], i2 = blk_nb[b];
-      pass = gen_gates(cfg, segs[seg_off[i1] + line], segs[seg_off[i2] + ng], pairs[b].F);
+      pass = gen_gates_fast(cfg, segs[g1 + line], segs[g2 + ng], pr->F);
     }
     unsigned long long m = __ballot(pass);
     if (m) {
-      if (pass) {
-        int p = qn + __popcll(m & lanemask_lt());
-        qr[p] = (unsigned)r;
-        qb[p] = (unsigned)b;
-      }
+      if (pass) qr[qn + __popcll(m & lanemask_lt())] = (unsigned)r;
       qn += __popcll(m);
       wave_lds_sync();
-      while (qn >= 64) {  // keep the oldest 64 in front: process the first 64, shift the rest down
+      while (qn >= 64) {  // process the oldest 64, shift the rest down
         stage_b(64);
         wave_lds_sync();
         int rest = qn - 64;
-        unsigned tr = 0, tb = 0;
-        if (lane < rest) { tr = qr[64 + lane]; tb = qb[64 + lane]; }
+        unsigned tr = 0;
+        if (lane < rest) tr = qr[64 + lane];
         wave_lds_sync();
-        if (lane < rest) { qr[lane] = tr; qb[lane] = tb; }
+        if (lane < rest) qr[lane] = tr;
         wave_lds_sync();
         qn = rest;
       }
@@ -223,22 +195,30 @@ k_node_fill(long long G, const long long *__restrict__ conn_off, const unsigned 
   long long out = tri_off[g];
   if (tri_off[g + 1] == out) return;
   const long long c0 = conn_off[g], c1 = conn_off[g + 1];
-  for (long long t0 = c0; t0 < c1; t0 += 64) {
-    long long t = t0 + lane;
-    unsigned r = 0;
-    bool f = false;
-    if (t < c1) {
-      r = srows[t];
-      f = flag8[r] != 0;
+  for (long long t0 = c0; t0 < c1; t0 += 256) {  // four independent 64-connection chunks in flight
+    unsigned r[4];
+    bool f[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      long long t = t0 + 64 * k + lane;
+      r[k] = (t < c1) ? srows[t] : 0u;
     }
-    unsigned long long m = __ballot(f);
-    if (f) {
-      long long p = out + __popcll(m & lanemask_lt());
-      cand[p] = st_c[r];
-      lite[p] = st_l[r];
-      cand_node[p] = (unsigned)g;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      long long t = t0 + 64 * k + lane;
+      f[k] = (t < c1) && flag8[r[k]] != 0;
     }
-    out += __popcll(m);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned long long m = __ballot(f[k]);
+      if (f[k]) {
+        long long p = out + __popcll(m & lanemask_lt());
+        cand[p] = st_c[r[k]];
+        lite[p] = st_l[r[k]];
+        cand_node[p] = (unsigned)g;
+      }
+      out += __popcll(m);
+    }
   }
 }
 
@@ -392,14 +372,15 @@ k_score2(Score2Args a, ScoreCfg cfg, double scaleinv_guard2) {
 // ---------------------------------------------------------------------------------------------
 static inline unsigned nblk2(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
-void launch_line_off(hipStream_t st, long long P, int n_blk, long long n_entries, const long long *m_off,
-                     const int *m_pairs, const long long *blk_line_base, unsigned *line_off, int *unsorted_flag) {
+void launch_line_off(hipStream_t st, long long P, int n_blk, long long n_entries, long long max_rows,
+                     const long long *m_off, const int *m_pairs, const long long *blk_line_base,
+                     unsigned *line_off, int *unsorted_flag) {
   if (n_entries > 0)
     hipLaunchKernelGGL(k_line_off_init, dim3(nblk2(n_entries, 256)), dim3(256), 0, st, n_blk, blk_line_base, m_off,
                        line_off);
-  if (P > 0)
-    hipLaunchKernelGGL(k_line_off, dim3(nblk2(P, 256)), dim3(256), 0, st, P, n_blk, m_off, m_pairs, blk_line_base,
-                       line_off, unsorted_flag);
+  if (P > 0 && n_blk > 0 && max_rows > 0)
+    hipLaunchKernelGGL(k_line_off, dim3(nblk2(max_rows, 256), n_blk), dim3(256), 0, st, m_off, m_pairs,
+                       blk_line_base, line_off, unsorted_flag);
 }
 void launch_node_conn_count(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                             const long long *nb_off, const long long *blk_line_base, const unsigned *line_off,
@@ -414,14 +395,14 @@ void launch_build_rowlist(hipStream_t st, long long G, const int *node_img, cons
     hipLaunchKernelGGL(k_build_rowlist, dim3(nblk2(G * 64, 256)), dim3(256), 0, st, G, node_img, seg_off, nb_off,
                        blk_line_base, line_off, conn_off, srows);
 }
-void launch_gen_rows(hipStream_t st, long long P, int n_blk, const GenCfg &cfg, const long long *m_off,
-                     const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
-                     const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs, Cand *st_c,
-                     CandLite *st_l, unsigned char *flag8, unsigned *n_tris) {
-  if (P <= 0) return;
-  long long waves = (P + 64ll * kGenChunks - 1) / (64ll * kGenChunks);
-  hipLaunchKernelGGL(k_gen_rows, dim3(nblk2(waves, 4)), dim3(256), 0, st, P, n_blk, cfg, m_off, m_pairs, blk_img,
-                     blk_nb, blk_slot, seg_off, cams, segs, pairs, st_c, st_l, flag8, n_tris);
+void launch_gen_rows(hipStream_t st, long long P, int n_blk, long long max_rows, const GenCfg &cfg,
+                     const long long *m_off, const int *m_pairs, const int *blk_img, const int *blk_nb,
+                     const int *blk_slot, const long long *seg_off, const Cam *cams, const Seg *segs,
+                     const PairRec *pairs, Cand *st_c, CandLite *st_l, unsigned char *flag8, unsigned *n_tris) {
+  if (P <= 0 || n_blk <= 0 || max_rows <= 0) return;
+  const long long rows_per_wg = 4ll * 64 * kGenChunks;
+  hipLaunchKernelGGL(k_gen_rows, dim3(nblk2(max_rows, (int)rows_per_wg), n_blk), dim3(256), 0, st, cfg, m_off,
+                     m_pairs, blk_img, blk_nb, blk_slot, seg_off, cams, segs, pairs, st_c, st_l, flag8, n_tris);
 }
 void launch_node_fill(hipStream_t st, long long G, const long long *conn_off, const unsigned *srows,
                       const unsigned char *flag8, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
