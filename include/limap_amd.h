@@ -150,7 +150,7 @@ int lt_get_stats(lt_ctx *ctx, int64_t out[8]);
 /* HIP-event timings (ms) of the last lt_run_device on the context's stream:
  * [0] whole run, [1] invariants, [2] connection sort, [3] generation, [4] compaction,
  * [5] scoring kernel, [6] selection + edges, [7] gather; host: [8] upload, [9] download,
- * [10] tail (lt_compute_tracks) */
+ * [10] tail (lt_compute_tracks); [11] candidate pairs that reached the dense evaluation in k_score3 */
 int lt_get_timers(lt_ctx *ctx, double out[16]);
 
 /* ---- free functions of limap.triangulation (bindings.cc:22-31) on raw arrays, run on the GPU

@@ -299,7 +299,8 @@ class Context:
     def timers(self):
         out = np.zeros(16)
         self.chk(self.L.lt_get_timers(self.h, ptr(out, C.c_double)))
-        keys = ["run", "invariants", "sort", "gen", "compact", "score", "select", "gather", "upload", "download", "tail"]
+        keys = ["run", "invariants", "sort", "gen", "compact", "score", "select", "gather", "upload", "download", "tail",
+                "pairs_eval"]
         return dict(zip(keys, out.tolist()))
 
     # --- free functions ---

@@ -44,11 +44,11 @@ void launch_node_fill(hipStream_t st, long long G, const long long *conn_off, co
                       const unsigned char *flag8, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
                       Cand *cand, CandLite *lite, unsigned *cand_node);
 void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, unsigned *cand_node);
-size_t score2_lds_bytes(int max_nb);
-void launch_score2(hipStream_t st, long long C_cap, long long G, const long long *tri_off, const unsigned *cand_node,
+size_t score3_lds_bytes(int max_nb);
+void launch_score3(hipStream_t st, long long C, long long G, const long long *tri_off, const unsigned *cand_node,
                    const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
-                   const int *blk_nb, const int *blk_order, const long long *seg_off, const Seg *segs,
-                   const Cam *cams, double *score, int max_nb, const ScoreCfg &cfg, double scaleinv_guard2);
+                   const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
+                   int max_nb, const ScoreCfg &cfg, double scaleinv_guard2);
 }
 
 namespace {
@@ -134,7 +134,8 @@ struct lt_ctx {
   DevBuf d_item_off, d_masks, d_mask_cnt, d_mask_pos;
   DevBuf d_cand, d_lite, d_tri_off, d_score, d_best_idx, d_edge_flag, d_nvalid, d_edge_off, d_edges;
   DevBuf d_best_c, d_best_score, d_best_src, d_ntris, d_err;
-  DevBuf d_blk_line_base, d_line_off, d_conn_cnt, d_flag8, d_ntris_u, d_cand_node;
+  DevBuf d_blk_line_base, d_line_off, d_conn_cnt, d_flag8, d_ntris_u, d_cand_node, d_pair_counter;
+  long long stat_pairs_eval = 0;
   std::vector<long long> h_blk_line_base;
   bool rows_sorted = true;   // every (image, neighbour) block lists its rows in non-decreasing line id
   long long *h_pinned = nullptr;  // pinned scratch for small device->host scalars
@@ -408,7 +409,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_lite, &ctx->d_tri_off, &ctx->d_score, &ctx->d_best_idx, &ctx->d_edge_flag,
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_line_off,
-                    &ctx->d_conn_cnt, &ctx->d_flag8, &ctx->d_ntris_u, &ctx->d_cand_node};
+                    &ctx->d_conn_cnt, &ctx->d_flag8, &ctx->d_ntris_u, &ctx->d_cand_node, &ctx->d_pair_counter};
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   for (DevBuf *b : bufs) b->release();
   for (auto &ev : ctx->ev)
@@ -859,17 +860,19 @@ int lt_run_device(lt_ctx *ctx) {
   }
 
   // ---- scoring ----
-  if (score2_lds_bytes(ctx->max_nb) > 160 * 1024)
+  if (score3_lds_bytes(ctx->max_nb) > 160 * 1024)
     return fail(ctx, LT_ERR_ARGUMENT, "too many neighbours for the scoring kernel's LDS budget");
   {
     // conservative square of the scale-invariant endpoint gate (see k_score2)
     double th = scfg.l3.th_scaleinv * (1.0 + 1e-6);
     double guard2 = (scfg.l3.th_scaleinv > 0.0 && scfg.l3.score_th > 0.0 && scfg.l3.score_th < 1.0) ? th * th : 1e300;
-    launch_score2(st, C_known, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(),
+    ENSURE(ctx, ctx->d_pair_counter, 8);
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_pair_counter.p, 0, 8, st));
+    launch_score3(st, C_known, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(),
                   ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_node_img.as<int>(),
-                  ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_blk_order.as<int>(),
-                  ctx->d_seg_off.as<long long>(), ctx->d_segs.as<Seg>(), ctx->d_cams.as<Cam>(),
-                  ctx->d_score.as<double>(), ctx->max_nb, scfg, guard2);
+                  ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
+                  ctx->d_score.as<double>(), ctx->d_pair_counter.as<unsigned long long>(), ctx->max_nb, scfg,
+                  guard2);
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));
@@ -900,6 +903,11 @@ int lt_run_device(lt_ctx *ctx) {
   HIPCHK(ctx, hipStreamSynchronize(st));
   int derr = 0;
   HIPCHK(ctx, hipMemcpy(&derr, ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost));
+  {
+    unsigned long long pe = 0;
+    HIPCHK(ctx, hipMemcpy(&pe, ctx->d_pair_counter.p, 8, hipMemcpyDeviceToHost));
+    ctx->stat_pairs_eval = (long long)pe;
+  }
   if (derr != 0) return fail(ctx, LT_ERR_RUNTIME, "IndexError! Out-of-index matches detected on the device");
   float ms;
   static const int kMap[7] = {1, 2, 3, 4, 5, 6, 7};
@@ -1332,12 +1340,11 @@ int lt_get_all_tris(lt_ctx *ctx, int64_t *out_off, double *out_line10, double *o
   HIPCHK(ctx, hipMemcpy(l.data(), ctx->d_lite.p, sizeof(CandLite) * (size_t)C, hipMemcpyDeviceToHost));
   HIPCHK(ctx, hipMemcpy(out_score, ctx->d_score.p, 8 * (size_t)C, hipMemcpyDeviceToHost));
   for (long long g = 0; g < G; ++g) {
-    int img = ctx->h_node_img[g];
     for (long long t = tri_off[g]; t < tri_off[g + 1]; ++t) {
       double *o = out_line10 + 10 * t;
       for (int k = 0; k < 3; ++k) { o[k] = c[t].s[k]; o[3 + k] = c[t].e[k]; }
       o[6] = c[t].depth[0]; o[7] = c[t].depth[1]; o[8] = c[t].unc; o[9] = c[t].score3;
-      out_src2[2 * t] = ctx->img_ids[ctx->neighbors[img][l[t].nb_slot]];
+      out_src2[2 * t] = ctx->img_ids[lite_img(l[t])];
       out_src2[2 * t + 1] = l[t].ng_line;
     }
   }
@@ -1376,6 +1383,7 @@ int lt_get_stats(lt_ctx *ctx, int64_t out[8]) {
   return LT_OK;
 }
 int lt_get_timers(lt_ctx *ctx, double out[16]) {
+  ctx->timers[11] = (double)ctx->stat_pairs_eval;
   std::memcpy(out, ctx->timers, sizeof(ctx->timers));
   return LT_OK;
 }

@@ -251,6 +251,7 @@ static __device__ __forceinline__ bool gen_finish(const GenCfg &cfg, const Cam &
   out->c.depth[0] = z_start; out->c.depth[1] = z_end;
   out->c.unc = dmin(u1, u2);
   out->c.score3 = 1.0;
+  out->c.seg[0] = s2.x1; out->c.seg[1] = s2.y1; out->c.seg[2] = s2.x2; out->c.seg[3] = s2.y2;
   out->l.dir[0] = dir3.x; out->l.dir[1] = dir3.y; out->l.dir[2] = dir3.z;
   return true;
 }
@@ -262,21 +263,34 @@ static __device__ __forceinline__ bool gen_one(const GenCfg &cfg, const Cam &c1,
   return gen_finish(cfg, c1, c2, s1, s2, pr.B, out);
 }
 
-// dense evaluation of one (i, j) pair: score3d (shared-parent mode) then score2d of l_i projected
-// into the view of j against the 2D segment that generated j.  global_line_triangulator.cc:97-104
-static __device__ __forceinline__ double pair_score(const ScoreCfg &cfg, const double *ti /*11*/,
-                                                    const Cand &cj, const Cam &camj, const Seg &sj) {
-  L3 li{mk3(ti[0], ti[1], ti[2]), mk3(ti[3], ti[4], ti[5])};
-  L3 lj{mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2])};
-  double dep[2] = {ti[9], ti[10]};
-  double s3 = score3d(cfg.l3, li, lj, 0.0, 0.0, dep);
+// Dense evaluation of one (i, j) pair (global_line_triangulator.cc:97-104): LineLinker3d score in
+// shared-parent mode (3D angle + one-way scale-invariant endpoint distance with l_i's depths,
+// line_linker.cc:306-331 with the flags of line_linker.h:115-121), then LineLinker2d score of l_i
+// projected into the view of j against the 2D segment that generated j.  The unit directions are
+// the ones stored with the candidates: Line3d::direction() is a pure function of the endpoints, so
+// the stored value is bit-identical to the reference's recomputation.
+static __device__ __forceinline__ double pair_score(const ScoreCfg &cfg, d3 si, d3 ei, d3 diri, double dep0,
+                                                    double dep1, d3 sj, d3 ej, d3 dirj, const double *segj,
+                                                    const Cam &camj) {
+  const LinkCfg3 &c3 = cfg.l3;
+  double s3 = 1.0;
+  {  // score_angle
+    double ang = angle_deg_from_cos(fabs(dot(diri, dirj)));
+    s3 = dmin(s3, gate(expscore(ang, c3.th_angle * c3.mult), c3.score_th));
+  }
+  if (s3 < c3.score_th) return 0.0;
+  {  // score_scaleinv
+    double ds = sqrt(sqn(sub(si, sj)));
+    double de = sqrt(sqn(sub(ei, ej)));
+    double d = dmax(ds / (dep0 + kEps), de / (dep1 + kEps));
+    s3 = dmin(s3, gate(expscore(d, c3.th_scaleinv * c3.mult), c3.score_th));
+  }
   if (s3 == 0) return 0.0;
-  L2 pi{cam_project(camj, li.s), cam_project(camj, li.e)};
-  L2 sg{mk2(sj.x1, sj.y1), mk2(sj.x2, sj.y2)};
+  L2 pi{cam_project(camj, si), cam_project(camj, ei)};
+  L2 sg{mk2(segj[0], segj[1]), mk2(segj[2], segj[3])};
   double s2 = score2d(cfg.l2, pi, sg);
   if (s2 == 0) return 0.0;
   return dmin(s3, s2);
 }
-
 
 }  // namespace lt

@@ -12,8 +12,6 @@
 
 namespace lt {
 
-struct ScoreArgs;
-
 void launch_build_cams(hipStream_t st, int n, const double *k, const double *q, const double *t, Cam *cams);
 void launch_build_segs(hipStream_t st, long long n_segs, int n_img, const long long *seg_off,
                        const double *segs, double halfpix, const Cam *cams, Seg *out);
@@ -26,21 +24,9 @@ size_t sort_temp_bytes(long long P, int end_bit);
 int launch_sort(hipStream_t st, void *temp, size_t temp_bytes, long long P, const unsigned *keys_in,
                 unsigned *keys_out, const unsigned *vals_in, unsigned *vals_out, int end_bit);
 void launch_node_offsets(hipStream_t st, long long P, long long G, const unsigned *skeys, long long *conn_off);
-void launch_gen_matched(hipStream_t st, long long P, const GenCfg &cfg, const unsigned *skeys,
-                        const unsigned *srows, const unsigned *row_blk, const int *m_pairs,
-                        const int *blk_img, const int *blk_nb, const int *blk_slot, const long long *seg_off,
-                        const Cam *cams, const Seg *segs, const PairRec *pairs, Cand *st_c, CandLite *st_l,
-                        unsigned *flags);
-size_t scan_temp_bytes_u32(long long n);
-int launch_scan_u32(hipStream_t st, void *temp, size_t temp_bytes, long long n, const unsigned *in,
-                    unsigned *out);
 size_t scan_temp_bytes_u32_to_i64(long long n);
 int launch_scan_u32_to_i64(hipStream_t st, void *temp, size_t temp_bytes, long long n, const unsigned *in,
                            long long *out);
-void launch_compact(hipStream_t st, long long P, const unsigned *flags, const unsigned *pos, const Cand *st_c,
-                    const CandLite *st_l, Cand *out_c, CandLite *out_l);
-void launch_tri_offsets(hipStream_t st, long long G, const long long *conn_off, const unsigned *pos, long long P,
-                        unsigned total, long long *tri_off);
 void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const GenCfg &cfg,
                            const long long *item_off, long long G, const int *node_img, const long long *nb_off,
                            const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
@@ -50,23 +36,6 @@ void launch_popc(hipStream_t st, long long n, const unsigned long long *masks, u
 void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_off, const long long *mask_pos,
                            long long n_items, long long total, long long *tri_off);
 
-struct ScoreArgs {
-  long long G;
-  const long long *tri_off;
-  const Cand *cand;
-  const CandLite *lite;
-  const int *node_img;
-  const long long *nb_off;
-  const int *blk_nb;
-  const int *blk_order;
-  const long long *seg_off;
-  const Seg *segs;
-  const Cam *cams;
-  double *score;
-  int max_nb;
-};
-size_t score_lds_bytes(int max_nb);
-void launch_score(hipStream_t st, const ScoreArgs &a, const ScoreCfg &cfg);
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
                    int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid);
 void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,

@@ -213,18 +213,23 @@ LT_HD void pair_build(const Cam &c1, const Cam &c2, PairRec *p) {
 // 3D candidate ("TriTuple", base_line_triangulator.h:17-18) split into a heavy and a light
 // record: the O(n^2) scoring sweep only streams the 32 B light record.
 // ---------------------------------------------------------------------------------------------
-struct Cand {  // 80 B
+struct Cand {  // 112 B
   double s[3], e[3];
   double depth[2];  // depths in the source view (view1)
   double unc;
   double score3;    // Line3d::score (1.0 for a valid proposal)
+  double seg[4];    // the neighbour's 2D segment that generated the candidate (scoring compares
+                    // reprojections against exactly this segment, global_line_triangulator.cc:100-101)
 };
 struct CandLite {  // 32 B
   double dir[3];   // Line3d::direction()
-  int nb_slot;     // index of the neighbour image in neighbors_[img]
+  int nb_slot;     // (neighbour image index << 8) | index of that image in neighbors_[img]
   int ng_line;     // line id in that neighbour image
 };
-static_assert(sizeof(Cand) == 80 && sizeof(CandLite) == 32, "candidate layout");
+static_assert(sizeof(Cand) == 112 && sizeof(CandLite) == 32, "candidate layout");
+LT_HD int lite_pack(int slot, int img) { return (img << 8) | (slot & 0xFF); }
+LT_HD int lite_slot(const CandLite &l) { return l.nb_slot & 0xFF; }
+LT_HD int lite_img(const CandLite &l) { return (int)((unsigned)l.nb_slot >> 8); }
 
 // ---------------------------------------------------------------------------------------------
 // Configuration in device-friendly form (constants folded on the host with glibc, like the

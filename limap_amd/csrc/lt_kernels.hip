@@ -2,16 +2,13 @@
 //
 //   k_build_cams / k_build_segs / k_build_pairs : hoisted invariants (per image, per 2D segment,
 //       per (image, neighbour) pair) -- the reference recomputes them per connection.
-//   k_conn_keys + radix sort + k_node_offsets   : matched mode, group connections by node
-//       (image, line) in the reference's candidate order (neighbour-major, match-row order).
-//   k_gen_matched / k_gen_exhaustive            : HOT LOOP 1, triangulateOneNode
-//       (triangulation/base_line_triangulator.cc:161-337): degeneracy gates, weak epipolar IoU,
-//       ray/plane triangulation, sensitivity gate, uncertainty, ranges.
-//   k_compact                                   : stable stream compaction of the survivors.
-//   k_score                                     : HOT LOOP 2, scoreOneNode
-//       (triangulation/global_line_triangulator.cc:71-116): one wave64 per node, O(n^2) sweep
-//       with a cosine-domain early exit, dense evaluation of the surviving pairs from an LDS
-//       work queue, per-neighbour-image maxima in LDS (ds_max_u64), ordered sum.
+//   k_conn_keys + radix sort + k_node_offsets   : matched mode, generic grouping of the connections
+//       by node (image, line) in the reference's candidate order (neighbour-major, match-row order)
+//       when the rows of a block are not sorted by line id.
+//   k_gen_exhaustive                            : HOT LOOP 1, triangulateOneNode
+//       (triangulation/base_line_triangulator.cc:161-337) for TriangulateImageExhaustiveMatch:
+//       degeneracy gates, weak epipolar IoU, ray/plane triangulation, sensitivity gate,
+//       uncertainty, ranges.  (Matched mode: k_gen_rows in lt_kernels_v2.hip; scoring: k_score3.)
 //   k_select                                    : per-node strict arg-max (lowest index wins ties,
 //       global_line_triangulator.cc:145-153) and valid-edge flags (:118-142).
 //
@@ -120,37 +117,6 @@ __global__ void k_node_offsets(long long P, long long G, const unsigned *__restr
 // ---------------------------------------------------------------------------------------------
 // HOT LOOP 1: one connection -> at most one candidate
 // ---------------------------------------------------------------------------------------------
-// Matched mode: thread t handles the t-th connection in node-major order.  Survivors are
-// written to slot t of the staging arrays; k_compact squeezes them (stable) afterwards.
-__global__ void __launch_bounds__(256)
-k_gen_matched(long long P, GenCfg cfg, const unsigned *__restrict__ skeys,
-              const unsigned *__restrict__ srows, const unsigned *__restrict__ row_blk,
-              const int *__restrict__ m_pairs, const int *__restrict__ blk_img,
-              const int *__restrict__ blk_nb, const int *__restrict__ blk_slot,
-              const long long *__restrict__ seg_off, const Cam *__restrict__ cams,
-              const Seg *__restrict__ segs, const PairRec *__restrict__ pairs,
-              Cand *__restrict__ st_c, CandLite *__restrict__ st_l, unsigned *__restrict__ flags) {
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= P) return;
-  unsigned key = skeys[t];
-  unsigned f = 0;
-  if (key != 0xFFFFFFFFu) {
-    unsigned row = srows[t];
-    unsigned b = row_blk[row];
-    int ng_line = m_pairs[2 * (long long)row + 1];
-    int i1 = blk_img[b], i2 = blk_nb[b];
-    GenOut o;
-    if (gen_one(cfg, cams[i1], cams[i2], segs[key], segs[seg_off[i2] + ng_line], pairs[b], &o)) {
-      o.l.nb_slot = blk_slot[b];
-      o.l.ng_line = ng_line;
-      st_c[t] = o.c;
-      st_l[t] = o.l;
-      f = 1;
-    }
-  }
-  flags[t] = f;
-}
-
 // Exhaustive mode (TriangulateImageExhaustiveMatch, base_line_triangulator.cc:111-136): the
 // connection list is implicit.  Work item = (node, neighbour block, chunk of 64 ng lines);
 // the wave writes its ballot of survivors as one 64-bit word (pass 1), and after a scan over the
@@ -199,32 +165,11 @@ k_gen_exhaustive(long long n_items, GenCfg cfg, const long long *__restrict__ it
     if (lane_id() == 0) masks[item] = m;
   } else if (ok) {
     long long pos = mask_pos[item] + __popcll(m & lanemask_lt());
-    o.l.nb_slot = (int)(b - nb_off[i1]);
+    o.l.nb_slot = lite_pack((int)(b - nb_off[i1]), i2);
     o.l.ng_line = ng_line;
     out_c[pos] = o.c;
     out_l[pos] = o.l;
   }
-}
-
-// stable compaction: pos = exclusive scan of flags
-__global__ void k_compact(long long P, const unsigned *__restrict__ flags,
-                          const unsigned *__restrict__ pos, const Cand *__restrict__ st_c,
-                          const CandLite *__restrict__ st_l, Cand *__restrict__ out_c,
-                          CandLite *__restrict__ out_l) {
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= P || !flags[t]) return;
-  out_c[pos[t]] = st_c[t];
-  out_l[pos[t]] = st_l[t];
-}
-
-// tri_off[g] = pos[conn_off[g]] (pos has P+1 entries: exclusive scan + total)
-__global__ void k_tri_offsets(long long G, const long long *__restrict__ conn_off,
-                              const unsigned *__restrict__ pos, long long P, unsigned total,
-                              long long *__restrict__ tri_off) {
-  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g > G) return;
-  (void)total;
-  tri_off[g] = (long long)pos[conn_off[g]];  // pos has P+1 entries, pos[P] = number of survivors
 }
 
 __global__ void k_popc(long long n, const unsigned long long *__restrict__ masks,
@@ -241,103 +186,6 @@ __global__ void k_tri_offsets_ex(long long G, const long long *__restrict__ item
   if (g > G) return;
   long long it = item_off[g];
   tri_off[g] = (it >= n_items) ? total : mask_pos[it];
-}
-
-// ---------------------------------------------------------------------------------------------
-// HOT LOOP 2: scoreOneNode.  One wave64 per node; lane = candidate i of the current 64-tile.
-// ---------------------------------------------------------------------------------------------
-constexpr int kQCap = 256;       // per-wave pair queue (entries), drained when > kQCap - 64
-constexpr int kWavesPerBlock = 4;
-
-
-__global__ void __launch_bounds__(64 * kWavesPerBlock)
-k_score(ScoreArgs a, ScoreCfg cfg) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int wave = threadIdx.x >> 6;
-  const int lane = lane_id();
-  // per-wave LDS: S[max_nb][64] u64 | tile[64][11] double | queue[kQCap] u32
-  const size_t per_wave = (size_t)a.max_nb * 64 * 8 + 64 * 11 * 8 + kQCap * 4;
-  unsigned char *base = smem_raw + per_wave * wave;
-  unsigned long long *S = reinterpret_cast<unsigned long long *>(base);
-  double *tile = reinterpret_cast<double *>(base + (size_t)a.max_nb * 64 * 8);
-  unsigned *queue = reinterpret_cast<unsigned *>(base + (size_t)a.max_nb * 64 * 8 + 64 * 11 * 8);
-
-  long long g = (long long)blockIdx.x * kWavesPerBlock + wave;
-  if (g >= a.G) return;
-  const long long off = a.tri_off[g];
-  const int n = (int)(a.tri_off[g + 1] - off);
-  if (n == 0) return;
-  const int img = a.node_img[g];
-  const long long nb0 = a.nb_off[img];
-  const int n_nb = (int)(a.nb_off[img + 1] - nb0);
-
-  for (int i0 = 0; i0 < n; i0 += 64) {
-    const int i = i0 + lane;
-    const bool active = i < n;
-    double dix = 0, diy = 0, diz = 0;
-    int sloti = -1;
-    if (active) {
-      const CandLite li = a.lite[off + i];
-      const Cand ci = a.cand[off + i];
-      dix = li.dir[0]; diy = li.dir[1]; diz = li.dir[2];
-      sloti = li.nb_slot;
-      double *t = tile + lane * 11;
-      t[0] = ci.s[0]; t[1] = ci.s[1]; t[2] = ci.s[2];
-      t[3] = ci.e[0]; t[4] = ci.e[1]; t[5] = ci.e[2];
-      t[6] = dix; t[7] = diy; t[8] = diz;
-      t[9] = ci.depth[0]; t[10] = ci.depth[1];
-    }
-    for (int k = 0; k < n_nb; ++k) S[k * 64 + lane] = 0ull;
-    int qn = 0;
-    wave_lds_sync();
-
-    auto drain = [&]() {
-      wave_lds_sync();
-      for (int q0 = 0; q0 < qn; q0 += 64) {
-        int p = q0 + lane;
-        if (p < qn) {
-          unsigned e = queue[p];
-          int il = (int)(e >> 26);
-          int j = (int)(e & 0x3FFFFFFu);
-          const CandLite lj = a.lite[off + j];
-          const Cand cj = a.cand[off + j];
-          const int imgj = a.blk_nb[nb0 + lj.nb_slot];
-          double sc = pair_score(cfg, tile + il * 11, cj, a.cams[imgj],
-                                 a.segs[a.seg_off[imgj] + lj.ng_line]);
-          if (sc > 0.0) atomicMax(&S[lj.nb_slot * 64 + il], (unsigned long long)__double_as_longlong(sc));
-        }
-      }
-      qn = 0;
-      wave_lds_sync();
-    };
-
-    // sweep over all candidates j of the node (wave-uniform index -> broadcast loads)
-    for (int j = 0; j < n; ++j) {
-      const CandLite lj = a.lite[off + j];
-      bool pass = active && (j != i) && (lj.nb_slot != sloti);
-      if (pass) {
-        double c = fabs((dix * lj.dir[0] + diy * lj.dir[1]) + diz * lj.dir[2]);
-        pass = !(c < cfg.cos_guard);  // below the guard the 3D angle score is certainly gated to 0
-      }
-      unsigned long long m = __ballot(pass);
-      if (m) {
-        if (pass) queue[qn + __popcll(m & lanemask_lt())] = ((unsigned)lane << 26) | (unsigned)j;
-        qn += __popcll(m);
-        if (qn > kQCap - 64) drain();
-      }
-    }
-    drain();
-
-    // one image contributes at most one support (:109-112); images summed in ascending id order
-    if (active) {
-      double sum = 0.0;
-      for (int r = 0; r < n_nb; ++r) {
-        int k = a.blk_order[nb0 + r];
-        sum += __longlong_as_double((long long)S[k * 64 + lane]);
-      }
-      a.score[off + i] = sum;
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -413,7 +261,7 @@ k_edge_fill(long long G, const long long *__restrict__ tri_off, const unsigned *
     unsigned long long m = __ballot(f);
     if (f) {
       long long p = base + __popcll(m & lanemask_lt());
-      edges2[2 * p] = lite[off + i].nb_slot;
+      edges2[2 * p] = lite_slot(lite[off + i]);
       edges2[2 * p + 1] = lite[off + i].ng_line;
     }
     base += __popcll(m);
@@ -438,7 +286,7 @@ __global__ void k_gather_best(long long G, const long long *__restrict__ best_id
   if (b >= 0) {
     c = cand[b];
     s = score[b];
-    src_img = blk_nb[nb_off[node_img[g]] + lite[b].nb_slot];
+    src_img = lite_img(lite[b]);
     src_line = lite[b].ng_line;
   } else {
     for (int k = 0; k < 3; ++k) c.s[k] = c.e[k] = 0.0;
@@ -493,26 +341,6 @@ int launch_sort(hipStream_t st, void *temp, size_t temp_bytes, long long P, cons
 void launch_node_offsets(hipStream_t st, long long P, long long G, const unsigned *skeys, long long *conn_off) {
   hipLaunchKernelGGL(k_node_offsets, dim3(nblk(P + 1, 256)), dim3(256), 0, st, P, G, skeys, conn_off);
 }
-void launch_gen_matched(hipStream_t st, long long P, const GenCfg &cfg, const unsigned *skeys,
-                        const unsigned *srows, const unsigned *row_blk, const int *m_pairs,
-                        const int *blk_img, const int *blk_nb, const int *blk_slot, const long long *seg_off,
-                        const Cam *cams, const Seg *segs, const PairRec *pairs, Cand *st_c, CandLite *st_l,
-                        unsigned *flags) {
-  if (P > 0)
-    hipLaunchKernelGGL(k_gen_matched, dim3(nblk(P, 256)), dim3(256), 0, st, P, cfg, skeys, srows, row_blk,
-                       m_pairs, blk_img, blk_nb, blk_slot, seg_off, cams, segs, pairs, st_c, st_l, flags);
-}
-size_t scan_temp_bytes_u32(long long n) {
-  size_t bytes = 0;
-  (void)rocprim::exclusive_scan(nullptr, bytes, (unsigned *)nullptr, (unsigned *)nullptr, 0u, (size_t)n,
-                          rocprim::plus<unsigned>(), (hipStream_t)0);
-  return bytes;
-}
-int launch_scan_u32(hipStream_t st, void *temp, size_t temp_bytes, long long n, const unsigned *in,
-                    unsigned *out) {
-  if (n <= 0) return 0;
-  return (int)rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, (size_t)n, rocprim::plus<unsigned>(), st);
-}
 size_t scan_temp_bytes_u32_to_i64(long long n) {
   size_t bytes = 0;
   (void)rocprim::exclusive_scan(nullptr, bytes, (unsigned *)nullptr, (long long *)nullptr, 0ll, (size_t)n,
@@ -523,15 +351,6 @@ int launch_scan_u32_to_i64(hipStream_t st, void *temp, size_t temp_bytes, long l
                            long long *out) {
   if (n <= 0) return 0;
   return (int)rocprim::exclusive_scan(temp, temp_bytes, in, out, 0ll, (size_t)n, rocprim::plus<long long>(), st);
-}
-void launch_compact(hipStream_t st, long long P, const unsigned *flags, const unsigned *pos, const Cand *st_c,
-                    const CandLite *st_l, Cand *out_c, CandLite *out_l) {
-  if (P > 0)
-    hipLaunchKernelGGL(k_compact, dim3(nblk(P, 256)), dim3(256), 0, st, P, flags, pos, st_c, st_l, out_c, out_l);
-}
-void launch_tri_offsets(hipStream_t st, long long G, const long long *conn_off, const unsigned *pos, long long P,
-                        unsigned total, long long *tri_off) {
-  hipLaunchKernelGGL(k_tri_offsets, dim3(nblk(G + 1, 256)), dim3(256), 0, st, G, conn_off, pos, P, total, tri_off);
 }
 void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const GenCfg &cfg,
                            const long long *item_off, long long G, const int *node_img, const long long *nb_off,
@@ -554,14 +373,6 @@ void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_of
                            long long n_items, long long total, long long *tri_off) {
   hipLaunchKernelGGL(k_tri_offsets_ex, dim3(nblk(G + 1, 256)), dim3(256), 0, st, G, item_off, mask_pos, n_items,
                      total, tri_off);
-}
-size_t score_lds_bytes(int max_nb) {
-  return kWavesPerBlock * ((size_t)max_nb * 64 * 8 + 64 * 11 * 8 + kQCap * 4);
-}
-void launch_score(hipStream_t st, const ScoreArgs &a, const ScoreCfg &cfg) {
-  if (a.G <= 0) return;
-  size_t lds = score_lds_bytes(a.max_nb);
-  hipLaunchKernelGGL(k_score, dim3(nblk(a.G, kWavesPerBlock)), dim3(64 * kWavesPerBlock), lds, st, a, cfg);
 }
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
                    int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid) {

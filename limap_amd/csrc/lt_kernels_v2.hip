@@ -14,10 +14,11 @@
 //       the expensive path runs on full wave64s instead of a few stray lanes.
 //   k_node_fill
 //       Ordered per-node compaction of the survivors (wave per node, ballot prefix).
-//   k_score2
-//       HOT LOOP 2, candidate-major: lane = candidate (nodes packed densely into waves), sweep over
-//       the candidates of the lane's own node with a two-level conservative early exit (cosine, then
-//       squared scale-invariant endpoint distance), survivors evaluated densely from an LDS queue.
+//   k_score3
+//       HOT LOOP 2, candidate-major: lane = candidate (nodes packed densely into waves), LDS-staged
+//       sweep over the candidates of the lane's own node with a two-level conservative early exit
+//       (cosine, then squared scale-invariant endpoint distance), survivors evaluated densely from
+//       an LDS queue.
 // Compiled with -ffp-contract=off (see lt_geom.h).
 
 #include "lt_devfn.h"
@@ -145,7 +146,7 @@ k_gen_rows(GenCfg cfg, const long long *__restrict__ m_off, const int *__restric
       int line = m_pairs[2 * (long long)r], ng = m_pairs[2 * (long long)r + 1];
       GenOut o;
       if (gen_finish(cfg, cams[i1], cams[i2], segs[g1 + line], segs[g2 + ng], pr->B, &o)) {
-        o.l.nb_slot = slot;
+        o.l.nb_slot = lite_pack(slot, i2);
         o.l.ng_line = ng;
         st_c[r] = o.c;
         st_l[r] = o.l;
@@ -231,44 +232,49 @@ k_cand_node(long long G, const long long *__restrict__ tri_off, unsigned *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// HOT LOOP 2, candidate-major
+// HOT LOOP 2, candidate-major (scoreOneNode, global_line_triangulator.cc:71-116)
 // ---------------------------------------------------------------------------------------------
+// One wave64 per 64 consecutive candidates (lane = candidate i; small nodes are packed densely into
+// the wave).  The candidates of all nodes the wave touches are staged through an LDS window (SoA:
+// direction, endpoints, neighbour slot), so the O(n^2) sweep runs out of LDS: every lane walks the
+// candidates j of ITS OWN node and applies a two-level conservative early exit (cosine of the 3D
+// angle gate, then the squared one-way scale-invariant endpoint gate with l_i's depths).  Survivors
+// are pushed (ballot + popcount) into an LDS queue and evaluated densely, one pair per lane; the
+// per-neighbour-image maxima live in LDS (ds_max_u64 on the bit pattern of the non-negative scores)
+// and are summed per lane in ascending image-id order (std::map order, :110-112).
 constexpr int kSQCap = 192;
+constexpr int kWin = 128;
 
-struct Score2Args {
-  long long C_cap;                 // launch covers candidates [0, C_cap); C = *c_total
-  const long long *tri_off;        // tri_off[G] = C
+struct Score3Args {
   long long G;
+  const long long *tri_off;  // tri_off[G] = C
   const unsigned *cand_node;
   const Cand *cand;
   const CandLite *lite;
   const int *node_img;
   const long long *nb_off;
-  const int *blk_nb;
   const int *blk_order;
-  const long long *seg_off;
-  const Seg *segs;
   const Cam *cams;
   double *score;
+  unsigned long long *pair_counter;  // stats: pairs that reached the dense evaluation
   int max_nb;
 };
 
-__global__ void __launch_bounds__(256)
-k_score2(Score2Args a, ScoreCfg cfg, double scaleinv_guard2) {
+__global__ void __launch_bounds__(64)
+k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int wave = threadIdx.x >> 6;
-  const int lane = lane_id();
-  // per-wave LDS: S[max_nb][64] u64 | q[kSQCap] u32 | woff[64] i64
-  const size_t per_wave = (size_t)a.max_nb * 64 * 8 + kSQCap * 4 + 64 * 8;
-  unsigned char *base = smem_raw + per_wave * wave;
-  unsigned long long *S = reinterpret_cast<unsigned long long *>(base);
-  unsigned *queue = reinterpret_cast<unsigned *>(base + (size_t)a.max_nb * 64 * 8);
-  long long *woff = reinterpret_cast<long long *>(base + (size_t)a.max_nb * 64 * 8 + kSQCap * 4);
+  const int lane = threadIdx.x;
+  // LDS: W[9][kWin] f64 | S[max_nb][64] u64 | woff[64] i64 | wslot[kWin] i32 | queue[kSQCap] u32
+  double *W = reinterpret_cast<double *>(smem_raw);
+  unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_raw + 9 * kWin * 8);
+  long long *woff = reinterpret_cast<long long *>(smem_raw + 9 * kWin * 8 + (size_t)a.max_nb * 64 * 8);
+  int *wslot = reinterpret_cast<int *>(smem_raw + 9 * kWin * 8 + (size_t)a.max_nb * 64 * 8 + 64 * 8);
+  unsigned *queue = reinterpret_cast<unsigned *>(smem_raw + 9 * kWin * 8 + (size_t)a.max_nb * 64 * 8 + 64 * 8 + kWin * 4);
 
   const long long C = a.tri_off[a.G];
-  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x);
-  const long long wave_first = i - lane;
-  if (wave_first >= C) return;
+  const long long i0 = (long long)blockIdx.x * 64;
+  if (i0 >= C) return;
+  const long long i = i0 + lane;
   const bool active = i < C;
 
   long long off = 0, nb0 = 0;
@@ -285,23 +291,25 @@ k_score2(Score2Args a, ScoreCfg cfg, double scaleinv_guard2) {
     const CandLite li = a.lite[i];
     const Cand ci = a.cand[i];
     dix = li.dir[0]; diy = li.dir[1]; diz = li.dir[2];
-    sloti = li.nb_slot;
+    sloti = lite_slot(li);
     six = ci.s[0]; siy = ci.s[1]; siz = ci.s[2];
     eix = ci.e[0]; eiy = ci.e[1]; eiz = ci.e[2];
-    // conservative bound of the one-way scale-invariant endpoint gate (line_dists.cc:55-60):
-    // dist / (depth + eps) > th_scaleinv (1 + 1e-6)  can never score >= score_th
+    // dist / (depth + eps) > th_scaleinv (1 + 1e-6) can never score >= score_th (line_dists.cc:55-60)
     double zs = ci.depth[0] + kEps, ze = ci.depth[1] + kEps;
-    gs2 = scaleinv_guard2 * zs * zs;
-    ge2 = scaleinv_guard2 * ze * ze;
-    if (!(zs > 0.0)) gs2 = 1e300;  // non-positive depth: leave the decision to the exact path
-    if (!(ze > 0.0)) ge2 = 1e300;
+    gs2 = (zs > 0.0) ? scaleinv_guard2 * zs * zs : 1e300;  // odd depths: leave it to the exact path
+    ge2 = (ze > 0.0) ? scaleinv_guard2 * ze * ze : 1e300;
   }
   woff[lane] = off;
   for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
-  int nmax = n;
-  for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+  // candidate range of all nodes this wave touches (lane 0 is always active)
+  const long long lo = __shfl(off, 0);
+  long long hi = active ? off + n : 0;
+  for (int d = 32; d >= 1; d >>= 1) {
+    long long o = __shfl_xor(hi, d);
+    hi = o > hi ? o : hi;
+  }
   int qn = 0;
-  wave_lds_sync();
+  unsigned long long n_eval = 0;
 
   auto drain = [&]() {
     wave_lds_sync();
@@ -310,49 +318,66 @@ k_score2(Score2Args a, ScoreCfg cfg, double scaleinv_guard2) {
       if (p < qn) {
         unsigned e = queue[p];
         int il = (int)(e >> 26);
-        long long oi = woff[il];
-        long long j = oi + (long long)(e & 0x3FFFFFFu);
-        long long ii = wave_first + il;
+        long long j = woff[il] + (long long)(e & 0x3FFFFFFu);
+        long long ii = i0 + il;
         const Cand ci = a.cand[ii];
         const CandLite li = a.lite[ii];
-        double ti[11] = {ci.s[0], ci.s[1], ci.s[2], ci.e[0], ci.e[1], ci.e[2], li.dir[0], li.dir[1], li.dir[2],
-                         ci.depth[0], ci.depth[1]};
         const CandLite lj = a.lite[j];
         const Cand cj = a.cand[j];
-        const unsigned gi = a.cand_node[ii];
-        const long long nbi = a.nb_off[a.node_img[gi]];
-        const int imgj = a.blk_nb[nbi + lj.nb_slot];
-        double sc = pair_score(cfg, ti, cj, a.cams[imgj], a.segs[a.seg_off[imgj] + lj.ng_line]);
-        if (sc > 0.0) atomicMax(&S[lj.nb_slot * 64 + il], (unsigned long long)__double_as_longlong(sc));
+        double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
+                               mk3(li.dir[0], li.dir[1], li.dir[2]), ci.depth[0], ci.depth[1],
+                               mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
+                               mk3(lj.dir[0], lj.dir[1], lj.dir[2]), cj.seg, a.cams[lite_img(lj)]);
+        if (sc > 0.0) atomicMax(&S[lite_slot(lj) * 64 + il], (unsigned long long)__double_as_longlong(sc));
       }
     }
+    n_eval += (unsigned long long)qn;
     qn = 0;
     wave_lds_sync();
   };
 
-  for (int jj = 0; jj < nmax; ++jj) {
-    bool pass = active && (jj < n);
-    if (pass) {
-      const long long j = off + jj;
-      const CandLite lj = a.lite[j];
-      pass = (j != i) && (lj.nb_slot != sloti);
+  for (long long wb = lo; wb < hi; wb += kWin) {
+    wave_lds_sync();
+    const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
+    for (int e = lane; e < wn; e += 64) {
+      const CandLite l = a.lite[wb + e];
+      const Cand c = a.cand[wb + e];
+      W[0 * kWin + e] = l.dir[0]; W[1 * kWin + e] = l.dir[1]; W[2 * kWin + e] = l.dir[2];
+      W[3 * kWin + e] = c.s[0]; W[4 * kWin + e] = c.s[1]; W[5 * kWin + e] = c.s[2];
+      W[6 * kWin + e] = c.e[0]; W[7 * kWin + e] = c.e[1]; W[8 * kWin + e] = c.e[2];
+      wslot[e] = lite_slot(l);
+    }
+    wave_lds_sync();
+    // this lane's sub-range of the window
+    long long jlo = off > wb ? off : wb;
+    long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
+    int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
+    int cmax = cnt;
+    for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d));
+    const int w0 = (int)(jlo - wb);
+    const int jj0 = (int)(jlo - off);
+    for (int t = 0; t < cmax; ++t) {
+      bool pass = t < cnt;
       if (pass) {
-        double c = fabs((dix * lj.dir[0] + diy * lj.dir[1]) + diz * lj.dir[2]);
-        pass = !(c < cfg.cos_guard);
+        const int w = w0 + t;
+        pass = (jlo + t != i) && (wslot[w] != sloti);
         if (pass) {
-          const Cand cj = a.cand[j];
-          double ax = six - cj.s[0], ay = siy - cj.s[1], az = siz - cj.s[2];
-          double bx = eix - cj.e[0], by = eiy - cj.e[1], bz = eiz - cj.e[2];
-          double ds2 = ax * ax + ay * ay + az * az, de2 = bx * bx + by * by + bz * bz;
-          pass = !(ds2 > gs2) && !(de2 > ge2);
+          double c = fabs((dix * W[0 * kWin + w] + diy * W[1 * kWin + w]) + diz * W[2 * kWin + w]);
+          pass = !(c < cfg.cos_guard);  // below the guard the 3D angle score is certainly gated to 0
+          if (pass) {
+            double ax = six - W[3 * kWin + w], ay = siy - W[4 * kWin + w], az = siz - W[5 * kWin + w];
+            double bx = eix - W[6 * kWin + w], by = eiy - W[7 * kWin + w], bz = eiz - W[8 * kWin + w];
+            double ds2 = ax * ax + ay * ay + az * az, de2 = bx * bx + by * by + bz * bz;
+            pass = !(ds2 > gs2) && !(de2 > ge2);
+          }
         }
       }
-    }
-    unsigned long long m = __ballot(pass);
-    if (m) {
-      if (pass) queue[qn + __popcll(m & lanemask_lt())] = ((unsigned)lane << 26) | (unsigned)jj;
-      qn += __popcll(m);
-      if (qn > kSQCap - 64) drain();
+      unsigned long long m = __ballot(pass);
+      if (m) {
+        if (pass) queue[qn + __popcll(m & lanemask_lt())] = ((unsigned)lane << 26) | (unsigned)(jj0 + t);
+        qn += __popcll(m);
+        if (qn > kSQCap - 64) drain();
+      }
     }
   }
   drain();
@@ -365,6 +390,7 @@ k_score2(Score2Args a, ScoreCfg cfg, double scaleinv_guard2) {
     }
     a.score[i] = sum;
   }
+  if (lane == 0 && a.pair_counter) atomicAdd(a.pair_counter, n_eval);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -415,18 +441,19 @@ void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, uns
   if (G > 0)
     hipLaunchKernelGGL(k_cand_node, dim3(nblk2(G * 64, 256)), dim3(256), 0, st, G, tri_off, cand_node);
 }
-size_t score2_lds_bytes(int max_nb) { return 4 * ((size_t)max_nb * 64 * 8 + kSQCap * 4 + 64 * 8); }
-void launch_score2(hipStream_t st, long long C_cap, long long G, const long long *tri_off, const unsigned *cand_node,
+size_t score3_lds_bytes(int max_nb) {
+  return 9 * kWin * 8 + (size_t)max_nb * 64 * 8 + 64 * 8 + kWin * 4 + kSQCap * 4;
+}
+void launch_score3(hipStream_t st, long long C, long long G, const long long *tri_off, const unsigned *cand_node,
                    const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
-                   const int *blk_nb, const int *blk_order, const long long *seg_off, const Seg *segs,
-                   const Cam *cams, double *score, int max_nb, const ScoreCfg &cfg, double scaleinv_guard2) {
-  if (C_cap <= 0) return;
-  Score2Args a;
-  a.C_cap = C_cap; a.tri_off = tri_off; a.G = G; a.cand_node = cand_node; a.cand = cand; a.lite = lite;
-  a.node_img = node_img; a.nb_off = nb_off; a.blk_nb = blk_nb; a.blk_order = blk_order; a.seg_off = seg_off;
-  a.segs = segs; a.cams = cams; a.score = score; a.max_nb = max_nb;
-  hipLaunchKernelGGL(k_score2, dim3(nblk2(C_cap, 256)), dim3(256), score2_lds_bytes(max_nb), st, a, cfg,
-                     scaleinv_guard2);
+                   const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
+                   int max_nb, const ScoreCfg &cfg, double scaleinv_guard2) {
+  if (C <= 0) return;
+  Score3Args a;
+  a.G = G; a.tri_off = tri_off; a.cand_node = cand_node; a.cand = cand; a.lite = lite; a.node_img = node_img;
+  a.nb_off = nb_off; a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
+  a.max_nb = max_nb;
+  hipLaunchKernelGGL(k_score3, dim3(nblk2(C, 64)), dim3(64), score3_lds_bytes(max_nb), st, a, cfg, scaleinv_guard2);
 }
 
 }  // namespace lt
