@@ -27,22 +27,25 @@ using namespace lt;
 namespace lt {
 void launch_fn_query(hipStream_t st, const double *in30, int by_endpoints, double *out32);
 // lt_kernels_v2.hip
-void launch_line_off(hipStream_t st, long long P, int n_blk, long long n_entries, long long max_rows,
-                     const long long *m_off, const int *m_pairs, const long long *blk_line_base,
-                     unsigned *line_off, int *unsorted_flag);
-void launch_node_conn_count(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
-                            const long long *nb_off, const long long *blk_line_base, const unsigned *line_off,
-                            unsigned *conn_cnt);
-void launch_build_rowlist(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
-                          const long long *nb_off, const long long *blk_line_base, const unsigned *line_off,
-                          const long long *conn_off, unsigned *srows);
-void launch_gen_rows(hipStream_t st, long long P, int n_blk, long long max_rows, const GenCfg &cfg,
-                     const long long *m_off, const int *m_pairs, const int *blk_img, const int *blk_nb,
-                     const int *blk_slot, const long long *seg_off, const Cam *cams, const Seg *segs,
-                     const PairRec *pairs, Cand *st_c, CandLite *st_l, unsigned char *flag8, unsigned *n_tris);
-void launch_node_fill(hipStream_t st, long long G, const long long *conn_off, const unsigned *srows,
-                      const unsigned char *flag8, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
-                      Cand *cand, CandLite *lite, unsigned *cand_node);
+unsigned gen_grid_x(long long max_rows);
+size_t gen_lds_bytes(int lds_segs);
+void launch_gen_rows(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
+                     const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
+                     const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
+                     const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
+                     unsigned *wave_count, unsigned *cnt_bl, int lds_segs);
+void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
+                        const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
+                        unsigned *n_tris);
+void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
+                  const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
+                  const unsigned *wave_count, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
+                  const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node);
+void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
+                      const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
+                      unsigned *keys_c, unsigned *src_c);
+void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const Cand *st_c,
+                    const CandLite *st_l, Cand *cand, CandLite *lite, unsigned *cand_node);
 void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, unsigned *cand_node);
 size_t score3_lds_bytes(int max_nb);
 void launch_score3(hipStream_t st, long long C, long long G, const long long *tri_off, const unsigned *cand_node,
@@ -134,7 +137,8 @@ struct lt_ctx {
   DevBuf d_item_off, d_masks, d_mask_cnt, d_mask_pos;
   DevBuf d_cand, d_lite, d_tri_off, d_score, d_best_idx, d_edge_flag, d_nvalid, d_edge_off, d_edges;
   DevBuf d_best_c, d_best_score, d_best_src, d_ntris, d_err;
-  DevBuf d_blk_line_base, d_line_off, d_conn_cnt, d_flag8, d_ntris_u, d_cand_node, d_pair_counter;
+  DevBuf d_blk_line_base, d_cnt_bl, d_st_key, d_wave_count, d_wave_pos, d_ntris_u, d_cand_node, d_pair_counter;
+  int max_nb_segs = 0;   // most segments of any neighbour image in the job (LDS table sizing)
   long long stat_pairs_eval = 0;
   std::vector<long long> h_blk_line_base;
   bool rows_sorted = true;   // every (image, neighbour) block lists its rows in non-decreasing line id
@@ -334,8 +338,11 @@ void build_job_tables(lt_ctx *ctx) {
   ctx->h_nb_off[n_img] = (long long)ctx->h_blk_img.size();
   ctx->n_blk = (int)ctx->h_blk_img.size();
   ctx->h_blk_line_base.assign(ctx->n_blk + 1, 0);
+  ctx->max_nb_segs = 0;
   for (int b = 0; b < ctx->n_blk; ++b) {
     int i1 = ctx->h_blk_img[b];
+    int i2 = ctx->h_blk_nb[b];
+    ctx->max_nb_segs = std::max(ctx->max_nb_segs, (int)(ctx->seg_off[i2 + 1] - ctx->seg_off[i2]));
     ctx->h_blk_line_base[b + 1] = ctx->h_blk_line_base[b] + (ctx->seg_off[i1 + 1] - ctx->seg_off[i1]) + 1;
   }
 }
@@ -408,8 +415,9 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_item_off, &ctx->d_masks, &ctx->d_mask_cnt, &ctx->d_mask_pos, &ctx->d_cand,
                     &ctx->d_lite, &ctx->d_tri_off, &ctx->d_score, &ctx->d_best_idx, &ctx->d_edge_flag,
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
-                    &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_line_off,
-                    &ctx->d_conn_cnt, &ctx->d_flag8, &ctx->d_ntris_u, &ctx->d_cand_node, &ctx->d_pair_counter};
+                    &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
+                    &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
+                    &ctx->d_pair_counter};
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   for (DevBuf *b : bufs) b->release();
   for (auto &ev : ctx->ev)
@@ -737,81 +745,86 @@ int lt_run_device(lt_ctx *ctx) {
   long long C_known = -1;  // candidate count once it is known on the host
   if (ctx->job_mode == 1) {
     const size_t Pn = (size_t)std::max<long long>(P, 1);
-    ENSURE(ctx, ctx->d_srows, 4 * Pn);
-    ENSURE(ctx, ctx->d_conn_off, sizeof(long long) * (size_t)(G + 1));
-    // ---- group the match rows by node, in the reference's candidate order ----
-    if (ctx->rows_sorted) {
-      // every block lists its rows by non-decreasing line id: offsets instead of a sort
-      const long long n_entries = ctx->h_blk_line_base[ctx->n_blk];
-      ENSURE(ctx, ctx->d_line_off, 4 * (size_t)std::max<long long>(n_entries, 1));
-      ENSURE(ctx, ctx->d_conn_cnt, 4 * (size_t)(G + 1));
-      launch_line_off(st, P, ctx->n_blk, n_entries, ctx->max_rows, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
-                      ctx->d_blk_line_base.as<long long>(), ctx->d_line_off.as<unsigned>(), ctx->d_err.as<int>());
-      launch_node_conn_count(st, G, ctx->d_node_img.as<int>(), ctx->d_seg_off.as<long long>(),
-                             ctx->d_nb_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
-                             ctx->d_line_off.as<unsigned>(), ctx->d_conn_cnt.as<unsigned>());
-      size_t tmp = scan_temp_bytes_u32_to_i64(G + 1);
-      ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
-      if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, G + 1, ctx->d_conn_cnt.as<unsigned>(),
-                                 ctx->d_conn_off.as<long long>()) != 0)
-        return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
-      launch_build_rowlist(st, G, ctx->d_node_img.as<int>(), ctx->d_seg_off.as<long long>(),
-                           ctx->d_nb_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
-                           ctx->d_line_off.as<unsigned>(), ctx->d_conn_off.as<long long>(),
-                           ctx->d_srows.as<unsigned>());
-    } else {
-      // generic input: stable radix sort of the rows by node id
-      ENSURE(ctx, ctx->d_keys, 4 * Pn); ENSURE(ctx, ctx->d_rows, 4 * Pn); ENSURE(ctx, ctx->d_row_blk, 4 * Pn);
-      ENSURE(ctx, ctx->d_skeys, 4 * Pn);
-      launch_conn_keys(st, P, ctx->n_blk, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
-                       ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
-                       ctx->d_keys.as<unsigned>(), ctx->d_rows.as<unsigned>(), ctx->d_row_blk.as<unsigned>(),
-                       ctx->d_err.as<int>());
-      if (P > 0) {
-        int end_bit = bits_for(G + 1);
-        size_t tmp = sort_temp_bytes(P, end_bit);
-        ENSURE(ctx, ctx->d_sort_tmp, std::max<size_t>(tmp, 16));
-        if (launch_sort(st, ctx->d_sort_tmp.p, tmp, P, ctx->d_keys.as<unsigned>(), ctx->d_skeys.as<unsigned>(),
-                        ctx->d_rows.as<unsigned>(), ctx->d_srows.as<unsigned>(), end_bit) != 0)
-          return fail(ctx, LT_ERR_HIP, "rocprim radix sort failed");
-      }
-      launch_node_offsets(st, P, G, ctx->d_skeys.as<unsigned>(), ctx->d_conn_off.as<long long>());
-    }
+    const bool fast = ctx->rows_sorted;
+    const long long n_waves = (long long)ctx->n_blk * gen_grid_x(ctx->max_rows) * 4;
+    const long long n_entries = ctx->h_blk_line_base[ctx->n_blk];
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
-    // ---- generation in row order; survivors staged at their row index ----
+    // ---- generation in row order; valid candidates appended in row order to per-wave lists ----
     ENSURE(ctx, ctx->d_st_c, sizeof(Cand) * Pn); ENSURE(ctx, ctx->d_st_l, sizeof(CandLite) * Pn);
-    ENSURE(ctx, ctx->d_flag8, Pn); ENSURE(ctx, ctx->d_ntris_u, 4 * (size_t)(G + 1));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_flag8.p, 0, Pn, st));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_ntris_u.p, 0, 4 * (size_t)(G + 1), st));
-    launch_gen_rows(st, P, ctx->n_blk, ctx->max_rows, gcfg, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
+    ENSURE(ctx, ctx->d_st_key, 4 * Pn);
+    ENSURE(ctx, ctx->d_wave_count, 4 * (size_t)(n_waves + 1));
+    ENSURE(ctx, ctx->d_ntris_u, 4 * (size_t)(G + 1));
+    if (fast) {
+      ENSURE(ctx, ctx->d_cnt_bl, 4 * (size_t)std::max<long long>(n_entries, 1));
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt_bl.p, 0, 4 * (size_t)std::max<long long>(n_entries, 1), st));
+    }
+    const int lds_segs = (ctx->max_nb_segs <= 768) ? ctx->max_nb_segs : 0;
+    launch_gen_rows(st, ctx->n_blk, ctx->max_rows, gcfg, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
                     ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(),
                     ctx->d_seg_off.as<long long>(), ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(),
-                    ctx->d_pairs.as<PairRec>(), ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(),
-                    ctx->d_flag8.as<unsigned char>(), ctx->d_ntris_u.as<unsigned>());
+                    ctx->d_pairs.as<PairRec>(), ctx->d_blk_line_base.as<long long>(), ctx->d_st_c.as<Cand>(),
+                    ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(), ctx->d_wave_count.as<unsigned>(),
+                    fast ? ctx->d_cnt_bl.as<unsigned>() : nullptr, lds_segs);
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
-    {
+    long long *hC = ctx->h_pinned;
+    long long hC_fallback = 0;
+    if (!hC) hC = &hC_fallback;
+    if (fast) {
+      // rows of every block are sorted by line id: sort-free placement
+      launch_node_prefix(st, G, ctx->d_node_img.as<int>(), ctx->d_seg_off.as<long long>(),
+                         ctx->d_nb_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
+                         ctx->d_cnt_bl.as<unsigned>(), ctx->d_ntris_u.as<unsigned>());
       size_t tmp = scan_temp_bytes_u32_to_i64(G + 1);
       ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
       if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, G + 1, ctx->d_ntris_u.as<unsigned>(),
                                  ctx->d_tri_off.as<long long>()) != 0)
         return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+      // the candidate count sizes the compact arrays and the scoring grid (8-byte async copy)
+      HIPCHK(ctx, hipMemcpyAsync(hC, ctx->d_tri_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      C_known = *hC;
+    } else {
+      // generic rows: stable radix sort of the candidates by node (input is in row order)
+      ENSURE(ctx, ctx->d_wave_pos, 8 * (size_t)(n_waves + 1));
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_wave_count.as<unsigned>() + n_waves, 0, 4, st));
+      size_t tmp = scan_temp_bytes_u32_to_i64(n_waves + 1);
+      ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
+      if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, n_waves + 1, ctx->d_wave_count.as<unsigned>(),
+                                 ctx->d_wave_pos.as<long long>()) != 0)
+        return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+      HIPCHK(ctx, hipMemcpyAsync(hC, ctx->d_wave_pos.as<long long>() + n_waves, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      C_known = *hC;
     }
-    // the candidate count sizes the compact arrays and the scoring grid: an 8-byte async copy
-    // whose wait overlaps with nothing heavier than the scan
-    long long *hC = ctx->h_pinned ? ctx->h_pinned : nullptr;
-    long long hC_fallback = 0;
-    if (!hC) hC = &hC_fallback;
-    HIPCHK(ctx, hipMemcpyAsync(hC, ctx->d_tri_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    C_known = *hC;
     const size_t Cn = (size_t)std::max<long long>(C_known, 1);
     ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);
     ENSURE(ctx, ctx->d_score, 8 * Cn); ENSURE(ctx, ctx->d_edge_flag, 4 * Cn); ENSURE(ctx, ctx->d_cand_node, 4 * Cn);
     ctx->cand_cap = (long long)Cn;
-    launch_node_fill(st, G, ctx->d_conn_off.as<long long>(), ctx->d_srows.as<unsigned>(),
-                     ctx->d_flag8.as<unsigned char>(), ctx->d_tri_off.as<long long>(), ctx->d_st_c.as<Cand>(),
+    if (fast) {
+      launch_place(st, ctx->n_blk, ctx->max_rows, ctx->d_m_off.as<long long>(), ctx->d_blk_img.as<int>(),
+                   ctx->d_seg_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
+                   ctx->d_cnt_bl.as<unsigned>(), ctx->d_wave_count.as<unsigned>(), ctx->d_tri_off.as<long long>(),
+                   ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(),
+                   ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_cand_node.as<unsigned>());
+    } else {
+      ENSURE(ctx, ctx->d_keys, 4 * Cn); ENSURE(ctx, ctx->d_rows, 4 * Cn);
+      ENSURE(ctx, ctx->d_skeys, 4 * Cn); ENSURE(ctx, ctx->d_srows, 4 * Cn);
+      launch_pack_keys(st, ctx->n_blk, ctx->max_rows, ctx->d_m_off.as<long long>(),
+                       ctx->d_wave_count.as<unsigned>(), ctx->d_wave_pos.as<long long>(),
+                       ctx->d_st_key.as<unsigned>(), ctx->d_keys.as<unsigned>(), ctx->d_rows.as<unsigned>());
+      if (C_known > 0) {
+        int end_bit = bits_for(G + 1);
+        size_t tmp = sort_temp_bytes(C_known, end_bit);
+        ENSURE(ctx, ctx->d_sort_tmp, std::max<size_t>(tmp, 16));
+        if (launch_sort(st, ctx->d_sort_tmp.p, tmp, C_known, ctx->d_keys.as<unsigned>(), ctx->d_skeys.as<unsigned>(),
+                        ctx->d_rows.as<unsigned>(), ctx->d_srows.as<unsigned>(), end_bit) != 0)
+          return fail(ctx, LT_ERR_HIP, "rocprim radix sort failed");
+      }
+      launch_node_offsets(st, C_known, G, ctx->d_skeys.as<unsigned>(), ctx->d_tri_off.as<long long>());
+      launch_permute(st, C_known, ctx->d_skeys.as<unsigned>(), ctx->d_srows.as<unsigned>(), ctx->d_st_c.as<Cand>(),
                      ctx->d_st_l.as<CandLite>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
                      ctx->d_cand_node.as<unsigned>());
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
   } else if (ctx->job_mode == 2) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));

@@ -152,10 +152,14 @@ static __device__ __forceinline__ bool gen_gates(const GenCfg &cfg, const Seg &s
 // square roots and two divisions instead of five and fifteen.  The cheap form decides only when it is
 // far (1e-7) from the threshold and well conditioned; otherwise the exact expression is evaluated, so
 // the outcome is always the reference's.
-static __device__ __forceinline__ bool gen_gates_fast(const GenCfg &cfg, const Seg &s1, const Seg &s2,
-                                                      const double *F) {
-  const double d1x = s1.x1 - s1.x2, d1y = s1.y1 - s1.y2;
-  const double d2x = s2.x1 - s2.x2, d2y = s2.y1 - s2.y2;
+static __device__ __forceinline__ bool gen_gates_fast(const GenCfg &cfg, double a1x, double a1y, double b1x,
+                                                      double b1y, const double *rs1, const double *re1,
+                                                      double n2x, double n2y, double n2z, double lcx, double lcy,
+                                                      double lcz, double a2x, double a2y, double b2x, double b2y,
+                                                      const double *F, const Seg &s2_exact) {
+  // (a1,b1) = endpoints of l1, (a2,b2) = endpoints of l2, n2 = plane normal of l2, lc = coords of l2
+  const double d1x = a1x - b1x, d1y = a1y - b1y;
+  const double d2x = a2x - b2x, d2y = a2y - b2y;
   const double q1 = d1x * d1x + d1y * d1y, q2 = d2x * d2x + d2y * d2y;
   if (cfg.min_length_2d > 0.0) {  // base_line_triangulator.cc:166,177
     if (sqrt(q1) <= cfg.min_length_2d) return false;
@@ -164,8 +168,8 @@ static __device__ __forceinline__ bool gen_gates_fast(const GenCfg &cfg, const S
     if (q1 == 0.0 || q2 == 0.0) return false;
   }
   if (cfg.disable_algebraic) return false;
-  d3 n2 = mk3(s2.n[0], s2.n[1], s2.n[2]);
-  d3 r1s = mk3(s1.rs[0], s1.rs[1], s1.rs[2]), r1e = mk3(s1.re[0], s1.re[1], s1.re[2]);
+  d3 n2 = mk3(n2x, n2y, n2z);
+  d3 r1s = mk3(rs1[0], rs1[1], rs1[2]), r1e = mk3(re1[0], re1[1], re1[2]);
   double as = fabs(dot(n2, r1s));
   if (as < cfg.sin_lo) return false;
   if (!(as > cfg.sin_hi)) {
@@ -181,19 +185,19 @@ static __device__ __forceinline__ bool gen_gates_fast(const GenCfg &cfg, const S
   // cheap weak-epipolar decision
   {
     const double vx = -d2x, vy = -d2y;  // e2 - s2
-    const double sv = s2.x1 * vx + s2.y1 * vy;
+    const double sv = a2x * vx + a2y * vy;
     double cv[2];
     bool well = q2 > 0.0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const double px = k == 0 ? s1.x1 : s1.x2, py = k == 0 ? s1.y1 : s1.y2;
+      const double px = k == 0 ? a1x : b1x, py = k == 0 ? a1y : b1y;
       const double ax = F[0] * px + F[1] * py + F[2];
       const double ay = F[3] * px + F[4] * py + F[5];
       const double az = F[6] * px + F[7] * py + F[8];
       const double na = sqrt(ax * ax + ay * ay + az * az);
-      const double nx = s2.lc[1] * az - s2.lc[2] * ay;
-      const double ny = s2.lc[2] * ax - s2.lc[0] * az;
-      const double t1 = s2.lc[0] * ay, t2 = s2.lc[1] * ax;
+      const double nx = lcy * az - lcz * ay;
+      const double ny = lcz * ax - lcx * az;
+      const double t1 = lcx * ay, t2 = lcy * ax;
       const double D = (t1 - t2) + kEps * na;
       well = well && (fabs(D) > 1e-4 * (fabs(t1) + fabs(t2))) && (na > 0.0);
       cv[k] = ((nx * vx + ny * vy) - D * sv) / (D * q2);
@@ -206,7 +210,10 @@ static __device__ __forceinline__ bool gen_gates_fast(const GenCfg &cfg, const S
     if (well && delta < -margin) return false;
     if (well && delta > margin) return true;
   }
-  double iou = epipolar_iou(s1, s2, F);  // exact path (rare)
+  // exact path (rare): the reference's expression on the full records
+  Seg s1x;
+  s1x.x1 = a1x; s1x.y1 = a1y; s1x.x2 = b1x; s1x.y2 = b1y;
+  double iou = epipolar_iou(s1x, s2_exact, F);
   if (iou < cfg.iou_th) return false;
   return true;
 }

@@ -2,9 +2,8 @@
 //
 //   k_build_cams / k_build_segs / k_build_pairs : hoisted invariants (per image, per 2D segment,
 //       per (image, neighbour) pair) -- the reference recomputes them per connection.
-//   k_conn_keys + radix sort + k_node_offsets   : matched mode, generic grouping of the connections
-//       by node (image, line) in the reference's candidate order (neighbour-major, match-row order)
-//       when the rows of a block are not sorted by line id.
+//   radix sort + k_node_offsets                 : matched mode, generic (stable) grouping of the
+//       candidates by node when the rows of a block are not sorted by line id.
 //   k_gen_exhaustive                            : HOT LOOP 1, triangulateOneNode
 //       (triangulation/base_line_triangulator.cc:161-337) for TriangulateImageExhaustiveMatch:
 //       degeneracy gates, weak epipolar IoU, ray/plane triangulation, sensitivity gate,
@@ -66,40 +65,6 @@ __global__ void k_build_pairs(int n_blk, const int *__restrict__ blk_img,
   PairRec p;
   pair_build(cams[blk_img[b]], cams[blk_nb[b]], &p);
   out[b] = p;
-}
-
-// ---------------------------------------------------------------------------------------------
-// matched mode: connection keys
-// ---------------------------------------------------------------------------------------------
-// One thread per match row.  key = global node id of (image, line_id); also records the
-// neighbour block of the row.  Out-of-range ids raise the error flag (the reference throws
-// "IndexError! Out-of-index matches ...", base_line_triangulator.cc:87-94).
-__global__ void k_conn_keys(long long P, int n_blk, const long long *__restrict__ m_off,
-                            const int *__restrict__ m_pairs, const int *__restrict__ blk_img,
-                            const int *__restrict__ blk_nb, const long long *__restrict__ seg_off,
-                            unsigned *__restrict__ keys, unsigned *__restrict__ rows,
-                            unsigned *__restrict__ row_blk, int *__restrict__ err) {
-  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= P) return;
-  int lo = 0, hi = n_blk;
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if (m_off[mid] <= r) lo = mid; else hi = mid;
-  }
-  int i1 = blk_img[lo], i2 = blk_nb[lo];
-  int line = m_pairs[2 * r], ng_line = m_pairs[2 * r + 1];
-  long long M1 = seg_off[i1 + 1] - seg_off[i1], M2 = seg_off[i2 + 1] - seg_off[i2];
-  unsigned key = 0xFFFFFFFFu;  // invalid rows sort to the end and are skipped
-  if (line < 0 || line >= M1) {
-    atomicExch(err, LT_ERR_MATCH_LINE_RANGE);
-  } else if (ng_line < 0 || ng_line >= M2) {
-    atomicExch(err, LT_ERR_MATCH_NGLINE_RANGE);
-  } else {
-    key = (unsigned)(seg_off[i1] + line);
-  }
-  keys[r] = key;
-  rows[r] = (unsigned)r;
-  row_blk[r] = (unsigned)lo;
 }
 
 // conn_off[g] = first sorted position whose key >= g  (keys sorted ascending)
@@ -318,13 +283,6 @@ void launch_build_pairs(hipStream_t st, int n_blk, const int *blk_img, const int
                         PairRec *out) {
   if (n_blk > 0)
     hipLaunchKernelGGL(k_build_pairs, dim3(nblk(n_blk, 128)), dim3(128), 0, st, n_blk, blk_img, blk_nb, cams, out);
-}
-void launch_conn_keys(hipStream_t st, long long P, int n_blk, const long long *m_off, const int *m_pairs,
-                      const int *blk_img, const int *blk_nb, const long long *seg_off, unsigned *keys,
-                      unsigned *rows, unsigned *row_blk, int *err) {
-  if (P > 0)
-    hipLaunchKernelGGL(k_conn_keys, dim3(nblk(P, 256)), dim3(256), 0, st, P, n_blk, m_off, m_pairs, blk_img,
-                       blk_nb, seg_off, keys, rows, row_blk, err);
 }
 size_t sort_temp_bytes(long long P, int end_bit) {
   size_t bytes = 0;

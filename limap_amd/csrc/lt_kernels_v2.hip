@@ -2,18 +2,16 @@
 // stage (see DESIGN.md section 3 for the map; lt_kernels.hip keeps the invariant builders, the
 // generic radix-sort grouping, the exhaustive generation and the selection kernels).
 //
-//   k_line_off_init / k_line_off / k_node_conn_count / k_build_rowlist
-//       Fast grouping of the match rows by node when every (image, neighbour) block lists its rows
-//       in non-decreasing line id (what limap's matchers write): per-(block, line) row offsets are
-//       read off the row stream, so no sort is needed to obtain the reference's candidate order
-//       (neighbour-ascending, then match-row order -- base_line_triangulator.cc:71-103).
 //   k_gen_rows
-//       HOT LOOP 1 in row (block) order: coalesced match rows, the neighbour's segment table is
-//       shared by all rows of a block (L1/L2 locality), stage A = cheap gates on every row, stage B =
-//       triangulation etc. only for the survivors, which are first gathered in an LDS queue so that
-//       the expensive path runs on full wave64s instead of a few stray lanes.
-//   k_node_fill
-//       Ordered per-node compaction of the survivors (wave per node, ballot prefix).
+//       HOT LOOP 1 in row (block) order: coalesced match rows, the neighbour's segment table staged
+//       in LDS, stage A = cheap gates on every row, stage B = triangulation etc. only for the
+//       survivors, which are first gathered in an LDS queue so that the expensive path runs on full
+//       wave64s.  Valid candidates are appended in row order to per-wave lists.
+//   k_node_prefix + k_place (rows of every block sorted by line id -- what limap's matchers write)
+//       Sort-free placement into the reference's candidate order (neighbour-ascending, then
+//       match-row order -- base_line_triangulator.cc:71-103): per-(block, line) counts -> per-node
+//       prefix over the neighbour blocks -> final position of every candidate.
+//   k_pack_keys + radix sort + k_permute (generic rows): stable sort of the candidates by node.
 //   k_score3
 //       HOT LOOP 2, candidate-major: lane = candidate (nodes packed densely into waves), LDS-staged
 //       sweep over the candidates of the lane's own node with a two-level conservative early exit
@@ -26,201 +24,249 @@
 namespace lt {
 
 // ---------------------------------------------------------------------------------------------
-// fast grouping
+// HOT LOOP 1, row order (triangulateOneNode, base_line_triangulator.cc:161-337)
 // ---------------------------------------------------------------------------------------------
-// entry (b, l) of line_off lives at blk_line_base[b] + l, l in [0, M_img(b)]
-__global__ void k_line_off_init(int n_blk, const long long *__restrict__ blk_line_base,
-                                const long long *__restrict__ m_off, unsigned *__restrict__ line_off) {
-  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= blk_line_base[n_blk]) return;
-  int lo = 0, hi = n_blk;
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if (blk_line_base[mid] <= e) lo = mid; else hi = mid;
-  }
-  line_off[e] = (unsigned)m_off[lo + 1];
-}
+// grid.y = neighbour block b = (image, neighbour): the image pair, F, baseline and both cameras are
+// wave-uniform (scalar registers).  grid.x * 4 waves * kGenChunks * 64 rows cover the block's rows.
+// The gate fields of the neighbour's 2D segments (plane normal, line coordinates, endpoints: 80 B)
+// are staged once per workgroup in LDS (SoA), since every row of the block indexes that one table.
+//   stage A: cheap gates on every row (gen_gates_fast); survivors are queued (ballot + popcount).
+//   stage B: triangulation / cheirality / sensitivity / uncertainty / ranges on full wave64s.
+// Valid candidates are appended IN ROW ORDER to the wave's own list st_*[r0 ...] (r0 = first row of
+// the wave, capacity = rows per wave); wave_count[] holds the list lengths.  In the fast path the
+// number of valid candidates per (block, line) run is counted in cnt_bl for the placement pass.
+constexpr int kGenChunks = 8;   // 64-row chunks per wave
+constexpr int kGenQCap = 128;   // queue entries per wave (drained whenever >= 64)
+constexpr int kRowsPerWave = 64 * kGenChunks;
+constexpr int kRowsPerWG = 4 * kRowsPerWave;
 
-// grid.y = neighbour block, grid.x = 256-row chunk of the block: no search for the block of a row
+struct GenArgs {
+  const long long *m_off;
+  const int *m_pairs;
+  const int *blk_img, *blk_nb, *blk_slot;
+  const long long *seg_off;
+  const Cam *cams;
+  const Seg *segs;
+  const PairRec *pairs;
+  const long long *blk_line_base;
+  Cand *st_c;
+  CandLite *st_l;
+  unsigned *st_key;       // node id of every staged candidate
+  unsigned *wave_count;   // [n_blk * gridDim.x * 4]
+  unsigned *cnt_bl;       // valid candidates per (block, line) or nullptr (generic path)
+  int lds_segs;           // capacity (in segments) of the LDS table; 0 = read the gate fields from HBM/L2
+};
+
 __global__ void __launch_bounds__(256)
-k_line_off(const long long *__restrict__ m_off, const int *__restrict__ m_pairs,
-           const long long *__restrict__ blk_line_base, unsigned *__restrict__ line_off,
-           int *__restrict__ unsorted_flag) {
+k_gen_rows(GenArgs a, GenCfg cfg) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  unsigned *q_all = reinterpret_cast<unsigned *>(smem_raw);          // [4][kGenQCap]
+  double *T = reinterpret_cast<double *>(smem_raw + 4 * kGenQCap * 4);  // [10][lds_segs]
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
   const int b = blockIdx.y;
-  const long long rb = m_off[b], re = m_off[b + 1];
-  long long r = rb + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= re) return;
-  int line = m_pairs[2 * r];
-  int prev = (r == rb) ? -1 : m_pairs[2 * (r - 1)];
-  if (line < prev) {
-    *unsorted_flag = 1;  // the host checked this already; never expected
+  const long long rb = a.m_off[b], re = a.m_off[b + 1];
+  const int i1 = a.blk_img[b], i2 = a.blk_nb[b], slot = a.blk_slot[b];
+  const long long g1 = a.seg_off[i1], g2 = a.seg_off[i2];
+  const int M2 = (int)(a.seg_off[i2 + 1] - g2);
+  const long long wg_r0 = rb + (long long)blockIdx.x * kRowsPerWG;
+  const unsigned lin = ((unsigned)b * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
+  if (wg_r0 >= re) {  // nothing for this workgroup (grid.x is sized by the largest block)
+    if (lane == 0) a.wave_count[lin] = 0;
     return;
   }
-  long long base = blk_line_base[b];
-  for (int l = prev + 1; l <= line; ++l) line_off[base + l] = (unsigned)r;
+  const bool use_lds = a.lds_segs >= M2;
+  const int ts = a.lds_segs;  // table stride
+  if (use_lds) {
+    for (int s = threadIdx.x; s < M2; s += blockDim.x) {
+      const Seg &sg = a.segs[g2 + s];
+      T[0 * ts + s] = sg.n[0]; T[1 * ts + s] = sg.n[1]; T[2 * ts + s] = sg.n[2];
+      T[3 * ts + s] = sg.lc[0]; T[4 * ts + s] = sg.lc[1]; T[5 * ts + s] = sg.lc[2];
+      T[6 * ts + s] = sg.x1; T[7 * ts + s] = sg.y1; T[8 * ts + s] = sg.x2; T[9 * ts + s] = sg.y2;
+    }
+    __syncthreads();
+  }
+  const long long r0 = wg_r0 + (long long)wave * kRowsPerWave;
+  unsigned wcount = 0;
+  if (r0 < re) {
+    const PairRec *pr = a.pairs + b;
+    const long long lbase = a.cnt_bl ? a.blk_line_base[b] : 0;
+    unsigned *qr = q_all + wave * kGenQCap;
+    int qn = 0;
+
+    auto stage_b = [&](int count) {  // lanes 0..count-1 finish one surviving connection each
+      bool ok = false;
+      GenOut o;
+      int line = 0;
+      if (lane < count) {
+        unsigned r = qr[lane];
+        line = a.m_pairs[2 * (long long)r];
+        int ng = a.m_pairs[2 * (long long)r + 1];
+        ok = gen_finish(cfg, a.cams[i1], a.cams[i2], a.segs[g1 + line], a.segs[g2 + ng], pr->B, &o);
+        o.l.nb_slot = lite_pack(slot, i2);
+        o.l.ng_line = ng;
+      }
+      unsigned long long m = __ballot(ok);
+      if (ok) {
+        long long p = r0 + wcount + __popcll(m & lanemask_lt());
+        a.st_c[p] = o.c;
+        a.st_l[p] = o.l;
+        a.st_key[p] = (unsigned)(g1 + line);
+        if (a.cnt_bl) atomicAdd(&a.cnt_bl[lbase + line], 1u);
+      }
+      wcount += (unsigned)__popcll(m);
+    };
+
+    for (int c = 0; c < kGenChunks; ++c) {
+      long long r = r0 + 64ll * c + lane;
+      bool pass = false;
+      if (r < re) {
+        int line = a.m_pairs[2 * r], ng = a.m_pairs[2 * r + 1];
+        const Seg &s1 = a.segs[g1 + line];
+        if (use_lds) {
+          pass = gen_gates_fast(cfg, s1.x1, s1.y1, s1.x2, s1.y2, s1.rs, s1.re, T[0 * ts + ng], T[1 * ts + ng],
+                                T[2 * ts + ng], T[3 * ts + ng], T[4 * ts + ng], T[5 * ts + ng], T[6 * ts + ng],
+                                T[7 * ts + ng], T[8 * ts + ng], T[9 * ts + ng], pr->F, a.segs[g2 + ng]);
+        } else {
+          const Seg &s2 = a.segs[g2 + ng];
+          pass = gen_gates_fast(cfg, s1.x1, s1.y1, s1.x2, s1.y2, s1.rs, s1.re, s2.n[0], s2.n[1], s2.n[2],
+                                s2.lc[0], s2.lc[1], s2.lc[2], s2.x1, s2.y1, s2.x2, s2.y2, pr->F, s2);
+        }
+      }
+      unsigned long long m = __ballot(pass);
+      if (m) {
+        if (pass) qr[qn + __popcll(m & lanemask_lt())] = (unsigned)r;
+        qn += __popcll(m);
+        wave_lds_sync();
+        while (qn >= 64) {  // process the oldest 64, shift the rest down
+          stage_b(64);
+          wave_lds_sync();
+          int rest = qn - 64;
+          unsigned tr = 0;
+          if (lane < rest) tr = qr[64 + lane];
+          wave_lds_sync();
+          if (lane < rest) qr[lane] = tr;
+          wave_lds_sync();
+          qn = rest;
+        }
+      }
+    }
+    if (qn > 0) stage_b(qn);
+  }
+  if (lane == 0) a.wave_count[lin] = wcount;
 }
 
-// connections of node g = sum over the image's neighbour blocks of the rows with this line id
-__global__ void k_node_conn_count(long long G, const int *__restrict__ node_img,
-                                  const long long *__restrict__ seg_off, const long long *__restrict__ nb_off,
-                                  const long long *__restrict__ blk_line_base,
-                                  const unsigned *__restrict__ line_off, unsigned *__restrict__ conn_cnt) {
+// Fast path: exclusive prefix of cnt_bl over the neighbour blocks of every node (in place) and the
+// node's candidate count.
+__global__ void k_node_prefix(long long G, const int *__restrict__ node_img,
+                              const long long *__restrict__ seg_off, const long long *__restrict__ nb_off,
+                              const long long *__restrict__ blk_line_base, unsigned *__restrict__ cnt_bl,
+                              unsigned *__restrict__ n_tris) {
   long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g > G) return;
-  unsigned c = 0;
+  unsigned run = 0;
   if (g < G) {
     int img = node_img[g];
     int line = (int)(g - seg_off[img]);
     for (long long b = nb_off[img]; b < nb_off[img + 1]; ++b) {
       long long e = blk_line_base[b] + line;
-      c += line_off[e + 1] - line_off[e];
+      unsigned c = cnt_bl[e];
+      cnt_bl[e] = run;
+      run += c;
     }
   }
-  conn_cnt[g] = c;
+  n_tris[g] = run;
 }
 
-// srows[conn_off[g] ...] = the node's rows, neighbour-major (one wave per node, lane = block)
+// Fast path: move every staged candidate to its final, reference-ordered position
+//   pos = tri_off[node] + (valid candidates of the node in earlier neighbour blocks) + rank in its run.
+// Same 2D grid as k_gen_rows; one wave per generation wave.  Rows of a block are sorted by line id,
+// so the candidates of one (block, line) run are adjacent in the row-ordered lists; the rank is
+// found by looking back over equal keys (crossing into the previous wave's list if the run does).
 __global__ void __launch_bounds__(256)
-k_build_rowlist(long long G, const int *__restrict__ node_img, const long long *__restrict__ seg_off,
-                const long long *__restrict__ nb_off, const long long *__restrict__ blk_line_base,
-                const unsigned *__restrict__ line_off, const long long *__restrict__ conn_off,
-                unsigned *__restrict__ srows) {
-  long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (g >= G) return;
-  const int lane = lane_id();
-  long long out = conn_off[g];
-  if (conn_off[g + 1] == out) return;
-  int img = node_img[g];
-  int line = (int)(g - seg_off[img]);
-  long long b0 = nb_off[img], b1 = nb_off[img + 1];
-  for (long long bb = b0; bb < b1; bb += 64) {
-    long long b = bb + lane;
-    unsigned lo = 0, cnt = 0;
-    if (b < b1) {
-      long long e = blk_line_base[b] + line;
-      lo = line_off[e];
-      cnt = line_off[e + 1] - lo;
-    }
-    unsigned pre = cnt;  // inclusive wave scan
-    for (int d = 1; d < 64; d <<= 1) {
-      unsigned v = __shfl_up(pre, d);
-      if (lane >= d) pre += v;
-    }
-    unsigned total = __shfl(pre, 63);
-    long long w = out + (pre - cnt);
-    for (unsigned t = 0; t < cnt; ++t) srows[w + t] = lo + t;
-    out += total;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// HOT LOOP 1, row order
-// ---------------------------------------------------------------------------------------------
-constexpr int kGenChunks = 8;   // 64-row chunks per wave
-constexpr int kGenQCap = 192;   // LDS queue entries per wave (drained at >= 64 + ... see below)
-
-__global__ void __launch_bounds__(256)
-k_gen_rows(GenCfg cfg, const long long *__restrict__ m_off, const int *__restrict__ m_pairs,
-           const int *__restrict__ blk_img, const int *__restrict__ blk_nb, const int *__restrict__ blk_slot,
-           const long long *__restrict__ seg_off, const Cam *__restrict__ cams, const Seg *__restrict__ segs,
-           const PairRec *__restrict__ pairs, Cand *__restrict__ st_c, CandLite *__restrict__ st_l,
-           unsigned char *__restrict__ flag8, unsigned *__restrict__ n_tris) {
-  __shared__ unsigned q_row[4][kGenQCap];
+k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
+        const long long *__restrict__ seg_off, const long long *__restrict__ blk_line_base,
+        const unsigned *__restrict__ base_bl, const unsigned *__restrict__ wave_count,
+        const long long *__restrict__ tri_off, const Cand *__restrict__ st_c,
+        const CandLite *__restrict__ st_l, const unsigned *__restrict__ st_key, Cand *__restrict__ cand,
+        CandLite *__restrict__ lite, unsigned *__restrict__ cand_node) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
-  // grid.y = neighbour block (uniform: image pair, F, cameras live in scalar registers),
-  // grid.x * 4 waves * kGenChunks * 64 rows cover the block's rows
   const int b = blockIdx.y;
   const long long rb = m_off[b], re = m_off[b + 1];
-  const long long r0 = rb + ((long long)blockIdx.x * 4 + wave) * (64ll * kGenChunks);
+  const long long r0 = rb + (long long)blockIdx.x * kRowsPerWG + (long long)wave * kRowsPerWave;
   if (r0 >= re) return;
-  const int i1 = blk_img[b], i2 = blk_nb[b], slot = blk_slot[b];
-  const long long g1 = seg_off[i1], g2 = seg_off[i2];
-  const PairRec *pr = pairs + b;
-  unsigned *qr = q_row[wave];
-  int qn = 0;
-
-  auto stage_b = [&](int count) {  // dense: lanes 0..count-1 finish one surviving connection each
-    if (lane < count) {
-      unsigned r = qr[lane];
-      int line = m_pairs[2 * (long long)r], ng = m_pairs[2 * (long long)r + 1];
-      GenOut o;
-      if (gen_finish(cfg, cams[i1], cams[i2], segs[g1 + line], segs[g2 + ng], pr->B, &o)) {
-        o.l.nb_slot = lite_pack(slot, i2);
-        o.l.ng_line = ng;
-        st_c[r] = o.c;
-        st_l[r] = o.l;
-        flag8[r] = 1;
-        atomicAdd(&n_tris[g1 + line], 1u);
+  const unsigned lin = ((unsigned)b * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
+  const unsigned count = wave_count[lin];
+  if (count == 0) return;
+  const long long g1 = seg_off[blk_img[b]];
+  const long long lbase = blk_line_base[b];
+  for (unsigned e0 = 0; e0 < count; e0 += 64) {
+    unsigned e = e0 + lane;
+    if (e >= count) break;
+    const unsigned key = st_key[r0 + e];
+    // rank within the (block, line) run
+    unsigned rank = 0;
+    {
+      long long cur_r0 = r0;
+      long long idx = (long long)e - 1;
+      unsigned cur_lin = lin;
+      while (true) {
+        while (idx >= 0 && st_key[cur_r0 + idx] == key) {
+          ++rank;
+          --idx;
+        }
+        if (idx >= 0) break;                 // a different key precedes: run starts inside this list
+        if (cur_r0 - kRowsPerWave < rb) break;  // first wave of the block
+        cur_r0 -= kRowsPerWave;
+        cur_lin -= 1;
+        unsigned pc = wave_count[cur_lin];
+        if (pc == 0) {
+          // an empty list: the run can only continue further back if that whole wave range belongs
+          // to the same line, which an empty list cannot tell -- keep walking (bounded by the block)
+          idx = -1;
+          continue;
+        }
+        idx = (long long)pc - 1;
       }
     }
-  };
-
-  for (int c = 0; c < kGenChunks; ++c) {
-    long long r = r0 + 64ll * c + lane;
-    bool pass = false;
-    if (r < re) {
-      int line = m_pairs[2 * r], ng = m_pairs[2 * r + 1];
-      pass = gen_gates_fast(cfg, segs[g1 + line], segs[g2 + ng], pr->F);
-    }
-    unsigned long long m = __ballot(pass);
-    if (m) {
-      if (pass) qr[qn + __popcll(m & lanemask_lt())] = (unsigned)r;
-      qn += __popcll(m);
-      wave_lds_sync();
-      while (qn >= 64) {  // process the oldest 64, shift the rest down
-        stage_b(64);
-        wave_lds_sync();
-        int rest = qn - 64;
-        unsigned tr = 0;
-        if (lane < rest) tr = qr[64 + lane];
-        wave_lds_sync();
-        if (lane < rest) qr[lane] = tr;
-        wave_lds_sync();
-        qn = rest;
-      }
-    }
+    const long long pos = tri_off[key] + base_bl[lbase + (long long)(key - g1)] + rank;
+    cand[pos] = st_c[r0 + e];
+    lite[pos] = st_l[r0 + e];
+    cand_node[pos] = key;
   }
-  if (qn > 0) stage_b(qn);
 }
 
-// ordered per-node compaction of the staged survivors (one wave per node)
+// Generic path: pack the row-ordered wave lists into dense (key, source index) arrays for the sort
 __global__ void __launch_bounds__(256)
-k_node_fill(long long G, const long long *__restrict__ conn_off, const unsigned *__restrict__ srows,
-            const unsigned char *__restrict__ flag8, const long long *__restrict__ tri_off,
-            const Cand *__restrict__ st_c, const CandLite *__restrict__ st_l, Cand *__restrict__ cand,
-            CandLite *__restrict__ lite, unsigned *__restrict__ cand_node) {
-  long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (g >= G) return;
+k_pack_keys(const long long *__restrict__ m_off, const unsigned *__restrict__ wave_count,
+            const long long *__restrict__ wave_pos, const unsigned *__restrict__ st_key,
+            unsigned *__restrict__ keys_c, unsigned *__restrict__ src_c) {
+  const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
-  long long out = tri_off[g];
-  if (tri_off[g + 1] == out) return;
-  const long long c0 = conn_off[g], c1 = conn_off[g + 1];
-  for (long long t0 = c0; t0 < c1; t0 += 256) {  // four independent 64-connection chunks in flight
-    unsigned r[4];
-    bool f[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      long long t = t0 + 64 * k + lane;
-      r[k] = (t < c1) ? srows[t] : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      long long t = t0 + 64 * k + lane;
-      f[k] = (t < c1) && flag8[r[k]] != 0;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      unsigned long long m = __ballot(f[k]);
-      if (f[k]) {
-        long long p = out + __popcll(m & lanemask_lt());
-        cand[p] = st_c[r[k]];
-        lite[p] = st_l[r[k]];
-        cand_node[p] = (unsigned)g;
-      }
-      out += __popcll(m);
-    }
+  const int b = blockIdx.y;
+  const long long rb = m_off[b], re = m_off[b + 1];
+  const long long r0 = rb + (long long)blockIdx.x * kRowsPerWG + (long long)wave * kRowsPerWave;
+  if (r0 >= re) return;
+  const unsigned lin = ((unsigned)b * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
+  const unsigned count = wave_count[lin];
+  const long long base = wave_pos[lin];
+  for (unsigned e = lane; e < count; e += 64) {
+    keys_c[base + e] = st_key[r0 + e];
+    src_c[base + e] = (unsigned)(r0 + e);
   }
+}
+
+// Generic path: gather the candidates into sorted (node-major, stable) order
+__global__ void k_permute(long long C, const unsigned *__restrict__ skeys, const unsigned *__restrict__ ssrc,
+                          const Cand *__restrict__ st_c, const CandLite *__restrict__ st_l,
+                          Cand *__restrict__ cand, CandLite *__restrict__ lite, unsigned *__restrict__ cand_node) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= C) return;
+  unsigned src = ssrc[t];
+  cand[t] = st_c[src];
+  lite[t] = st_l[src];
+  cand_node[t] = skeys[t];
 }
 
 // cand_node for pipelines that produce the compact arrays directly (exhaustive mode)
@@ -398,44 +444,47 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
 // ---------------------------------------------------------------------------------------------
 static inline unsigned nblk2(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
-void launch_line_off(hipStream_t st, long long P, int n_blk, long long n_entries, long long max_rows,
-                     const long long *m_off, const int *m_pairs, const long long *blk_line_base,
-                     unsigned *line_off, int *unsorted_flag) {
-  if (n_entries > 0)
-    hipLaunchKernelGGL(k_line_off_init, dim3(nblk2(n_entries, 256)), dim3(256), 0, st, n_blk, blk_line_base, m_off,
-                       line_off);
-  if (P > 0 && n_blk > 0 && max_rows > 0)
-    hipLaunchKernelGGL(k_line_off, dim3(nblk2(max_rows, 256), n_blk), dim3(256), 0, st, m_off, m_pairs,
-                       blk_line_base, line_off, unsorted_flag);
+unsigned gen_grid_x(long long max_rows) { return nblk2(max_rows, kRowsPerWG); }
+size_t gen_lds_bytes(int lds_segs) { return 4 * kGenQCap * 4 + (size_t)lds_segs * 80; }
+void launch_gen_rows(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
+                     const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
+                     const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
+                     const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
+                     unsigned *wave_count, unsigned *cnt_bl, int lds_segs) {
+  if (n_blk <= 0 || max_rows <= 0) return;
+  GenArgs a;
+  a.m_off = m_off; a.m_pairs = m_pairs; a.blk_img = blk_img; a.blk_nb = blk_nb; a.blk_slot = blk_slot;
+  a.seg_off = seg_off; a.cams = cams; a.segs = segs; a.pairs = pairs; a.blk_line_base = blk_line_base;
+  a.st_c = st_c; a.st_l = st_l; a.st_key = st_key; a.wave_count = wave_count; a.cnt_bl = cnt_bl;
+  a.lds_segs = lds_segs;
+  hipLaunchKernelGGL(k_gen_rows, dim3(gen_grid_x(max_rows), n_blk), dim3(256), gen_lds_bytes(lds_segs), st, a, cfg);
 }
-void launch_node_conn_count(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
-                            const long long *nb_off, const long long *blk_line_base, const unsigned *line_off,
-                            unsigned *conn_cnt) {
-  hipLaunchKernelGGL(k_node_conn_count, dim3(nblk2(G + 1, 256)), dim3(256), 0, st, G, node_img, seg_off, nb_off,
-                     blk_line_base, line_off, conn_cnt);
+void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
+                        const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
+                        unsigned *n_tris) {
+  hipLaunchKernelGGL(k_node_prefix, dim3(nblk2(G + 1, 256)), dim3(256), 0, st, G, node_img, seg_off, nb_off,
+                     blk_line_base, cnt_bl, n_tris);
 }
-void launch_build_rowlist(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
-                          const long long *nb_off, const long long *blk_line_base, const unsigned *line_off,
-                          const long long *conn_off, unsigned *srows) {
-  if (G > 0)
-    hipLaunchKernelGGL(k_build_rowlist, dim3(nblk2(G * 64, 256)), dim3(256), 0, st, G, node_img, seg_off, nb_off,
-                       blk_line_base, line_off, conn_off, srows);
+void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
+                  const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
+                  const unsigned *wave_count, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
+                  const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node) {
+  if (n_blk <= 0 || max_rows <= 0) return;
+  hipLaunchKernelGGL(k_place, dim3(gen_grid_x(max_rows), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
+                     blk_line_base, base_bl, wave_count, tri_off, st_c, st_l, st_key, cand, lite, cand_node);
 }
-void launch_gen_rows(hipStream_t st, long long P, int n_blk, long long max_rows, const GenCfg &cfg,
-                     const long long *m_off, const int *m_pairs, const int *blk_img, const int *blk_nb,
-                     const int *blk_slot, const long long *seg_off, const Cam *cams, const Seg *segs,
-                     const PairRec *pairs, Cand *st_c, CandLite *st_l, unsigned char *flag8, unsigned *n_tris) {
-  if (P <= 0 || n_blk <= 0 || max_rows <= 0) return;
-  const long long rows_per_wg = 4ll * 64 * kGenChunks;
-  hipLaunchKernelGGL(k_gen_rows, dim3(nblk2(max_rows, (int)rows_per_wg), n_blk), dim3(256), 0, st, cfg, m_off,
-                     m_pairs, blk_img, blk_nb, blk_slot, seg_off, cams, segs, pairs, st_c, st_l, flag8, n_tris);
+void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
+                      const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
+                      unsigned *keys_c, unsigned *src_c) {
+  if (n_blk <= 0 || max_rows <= 0) return;
+  hipLaunchKernelGGL(k_pack_keys, dim3(gen_grid_x(max_rows), n_blk), dim3(256), 0, st, m_off, wave_count, wave_pos,
+                     st_key, keys_c, src_c);
 }
-void launch_node_fill(hipStream_t st, long long G, const long long *conn_off, const unsigned *srows,
-                      const unsigned char *flag8, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
-                      Cand *cand, CandLite *lite, unsigned *cand_node) {
-  if (G > 0)
-    hipLaunchKernelGGL(k_node_fill, dim3(nblk2(G * 64, 256)), dim3(256), 0, st, G, conn_off, srows, flag8, tri_off,
-                       st_c, st_l, cand, lite, cand_node);
+void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const Cand *st_c,
+                    const CandLite *st_l, Cand *cand, CandLite *lite, unsigned *cand_node) {
+  if (C > 0)
+    hipLaunchKernelGGL(k_permute, dim3(nblk2(C, 256)), dim3(256), 0, st, C, skeys, ssrc, st_c, st_l, cand, lite,
+                       cand_node);
 }
 void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, unsigned *cand_node) {
   if (G > 0)
