@@ -162,10 +162,19 @@ def main():
         kernels = {"score": (b_score, kt.get("score", 0.0)), "gen": (b_gen, kt.get("gen", 0.0))}
         dom = max(kernels, key=lambda k: kernels[k][1])
         roof = {}
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs, gfx950 FETCH_SIZE x2 correction) -- valid for the default workload only
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        default_wl = (args.views, args.segs, args.neighbors, args.topk, args.mode, world) == (100, 500, 20, 10, "matched", 1)
+        if default_wl and os.path.exists(tpath):
+            tk = json.load(open(tpath))["kernels"]
+            traffic = {"score": tk.get("k_score3", {}).get("hbm_bytes"), "gen": tk.get("k_gen_rows", {}).get("hbm_bytes")}
         for name, (nbytes, ms) in kernels.items():
             gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             roof[name] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": ms, "algorithmic_bytes": nbytes}
+                          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(name), "kernel_ms": ms,
+                          "algorithmic_bytes": nbytes}
         out = {
             "metric": "3D line candidates scored/sec (100 views x 500 segs per GPU, matched topk=10)"
                       if args.mode == "matched" else "3D line candidates scored/sec (exhaustive)",
@@ -182,7 +191,8 @@ def main():
                        "valid_edges_rank0": st["valid_edges"], "tracks_rank0": st_after["tracks"]},
             "kernel_ms": kt,
             "connections_per_s": conn_total * args.steps / elapsed,
-            "roofline": dict(roof[dom], kernel=("k_score" if dom == "score" else "k_gen_" + args.mode)),
+            "roofline": dict(roof[dom], kernel=("k_score3" if dom == "score" else
+                                                 ("k_gen_rows" if args.mode == "matched" else "k_gen_exhaustive"))),
             "roofline_all": roof,
             "host_ms": {"upload_matches": 1e3 * t_upload, "tail_compute_tracks": 1e3 * t_tail},
         }
