@@ -109,9 +109,12 @@ def main():
     ctx.upload()
     t_upload = time.perf_counter() - t_up0
 
+    # per-step path: the invariants are rebuilt straight from the all-gather's receive buffer
+    ctx.set_scene_chunks(*gather.chunk_pointers())
+
     def step():
-        k, q, t, s = gather.all_gather()
-        ctx.refresh_scene_device(k.data_ptr(), q.data_ptr(), t.data_ptr(), s.data_ptr())
+        gather.gather_only()
+        ctx.refresh_scene_chunks()
         ctx.run_device()
 
     def sync():

@@ -97,6 +97,15 @@ int lt_init_device(lt_ctx *ctx, int n_img, const int32_t *img_ids, const void *d
 int lt_refresh_scene_device(lt_ctx *ctx, const void *d_kvec, const void *d_qvec, const void *d_tvec,
                             const void *d_segs);
 
+/* Multi-GPU per-step path without unpack copies: describe the scene as n_chunks chunks (one per
+ * rank of the all-gather), chunk c holding images [img_begin[c], img_begin[c+1]) (indices in
+ * ascending-id order) as four device arrays kvec | qvec | tvec | segs.  lt_set_scene_chunks records
+ * the (persistent) buffer addresses once; lt_refresh_scene_chunks rebuilds the invariants from them
+ * on the context's stream after every all-gather. */
+int lt_set_scene_chunks(lt_ctx *ctx, int n_chunks, const int32_t *img_begin, const void *const *d_kvec,
+                        const void *const *d_qvec, const void *const *d_tvec, const void *const *d_segs);
+int lt_refresh_scene_chunks(lt_ctx *ctx);
+
 /* TriangulateImage(img_id, matches) -- base_line_triangulator.cc:71-109, bindings.cc:83.
  * Rows m_off[k]..m_off[k+1] of m_pairs[.][2] = (line_id, ng_line_id) belong to neighbour
  * nb_ids[k].  Calls are buffered; the GPU runs at the next lt_flush / lt_compute_tracks / getter

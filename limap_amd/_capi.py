@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "liblimap_amd.so")
 
 EXPORTED_SYMBOLS = [
     "lt_config_default", "lt_abi_version", "lt_sizeof_config", "lt_create", "lt_destroy", "lt_last_error", "lt_set_stream", "lt_set_ranges",
-    "lt_unset_ranges", "lt_init", "lt_init_device", "lt_refresh_scene_device", "lt_triangulate_image",
+    "lt_unset_ranges", "lt_init", "lt_init_device", "lt_refresh_scene_device", "lt_set_scene_chunks",
+    "lt_refresh_scene_chunks", "lt_triangulate_image",
     "lt_triangulate_image_exhaustive", "lt_upload", "lt_run_device", "lt_download", "lt_flush",
     "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
     "lt_get_num_tris", "lt_num_valid_edges", "lt_get_valid_edges", "lt_num_all_tris", "lt_get_all_tris",
@@ -91,6 +92,9 @@ def load_library():
     L.lt_init.argtypes = [vp, C.c_int, i32p, dp, dp, dp, i64p, dp]
     L.lt_init_device.argtypes = [vp, C.c_int, i32p, vp, vp, vp, i64p, vp]
     L.lt_refresh_scene_device.argtypes = [vp, vp, vp, vp, vp]
+    vpp = C.POINTER(C.c_void_p)
+    L.lt_set_scene_chunks.argtypes = [vp, C.c_int, i32p, vpp, vpp, vpp, vpp]
+    L.lt_refresh_scene_chunks.argtypes = [vp]
     L.lt_triangulate_image.argtypes = [vp, C.c_int, C.c_int, i32p, i64p, i32p]
     L.lt_triangulate_image_exhaustive.argtypes = [vp, C.c_int, C.c_int, i32p]
     for n in ("lt_upload", "lt_run_device", "lt_download", "lt_flush", "lt_compute_tracks"):
@@ -211,6 +215,15 @@ class Context:
     def refresh_scene_device(self, d_kvec, d_qvec, d_tvec, d_segs):
         self.chk(self.L.lt_refresh_scene_device(self.h, C.c_void_p(d_kvec), C.c_void_p(d_qvec), C.c_void_p(d_tvec),
                                                 C.c_void_p(d_segs)))
+
+    def set_scene_chunks(self, img_begin, d_k, d_q, d_t, d_s):
+        n = len(img_begin)
+        ib = i32(img_begin)
+        arr = lambda ps: (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in ps])
+        self.chk(self.L.lt_set_scene_chunks(self.h, n, ptr(ib, C.c_int32), arr(d_k), arr(d_q), arr(d_t), arr(d_s)))
+
+    def refresh_scene_chunks(self):
+        self.chk(self.L.lt_refresh_scene_chunks(self.h))
 
     def triangulate_image(self, img_id, nb_ids, m_off, m_pairs):
         nb_ids, m_off, m_pairs = i32(nb_ids), i64(m_off), i32(m_pairs)

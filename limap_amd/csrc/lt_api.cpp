@@ -143,6 +143,8 @@ struct lt_ctx {
   std::vector<long long> h_blk_line_base;
   bool rows_sorted = true;   // every (image, neighbour) block lists its rows in non-decreasing line id
   long long *h_pinned = nullptr;  // pinned scratch for small device->host scalars
+  DevBuf d_chunks;
+  int n_chunks = 0;
   long long cand_cap = 0;
   long long C = 0, E = 0;  // candidates / valid edges of the last run
 
@@ -417,7 +419,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
-                    &ctx->d_pair_counter};
+                    &ctx->d_pair_counter, &ctx->d_chunks};
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   for (DevBuf *b : bufs) b->release();
   for (auto &ev : ctx->ev)
@@ -521,6 +523,38 @@ int lt_refresh_scene_device(lt_ctx *ctx, const void *d_kvec, const void *d_qvec,
                     ctx->d_cams.as<Cam>());
   launch_build_segs(st, ctx->G, n_img, ctx->d_seg_off.as<long long>(), ctx->d_segs_raw.as<double>(),
                     ctx->cfg.add_halfpix ? 0.5 : 0.0, ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>());
+  HIPCHK(ctx, hipGetLastError());
+  ctx->ran = false;
+  return LT_OK;
+}
+
+int lt_set_scene_chunks(lt_ctx *ctx, int n_chunks, const int32_t *img_begin, const void *const *d_kvec,
+                        const void *const *d_qvec, const void *const *d_tvec, const void *const *d_segs) {
+  if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "lt_set_scene_chunks before Init");
+  if (n_chunks <= 0 || img_begin[0] != 0) return fail(ctx, LT_ERR_ARGUMENT, "chunks must start at image 0");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<SceneChunk> ch(n_chunks);
+  for (int c = 0; c < n_chunks; ++c) {
+    if (img_begin[c] < 0 || img_begin[c] > ctx->n_img || (c > 0 && img_begin[c] < img_begin[c - 1]))
+      return fail(ctx, LT_ERR_ARGUMENT, "chunk image ranges must be ascending and inside the scene");
+    ch[c].k = (const double *)d_kvec[c]; ch[c].q = (const double *)d_qvec[c]; ch[c].t = (const double *)d_tvec[c];
+    ch[c].s = (const double *)d_segs[c];
+    ch[c].img_begin = img_begin[c];
+    ch[c].seg_begin = ctx->seg_off[img_begin[c]];
+    ch[c].pad_ = 0;
+  }
+  ENSURE(ctx, ctx->d_chunks, sizeof(SceneChunk) * (size_t)n_chunks);
+  HIPCHK(ctx, hipMemcpy(ctx->d_chunks.p, ch.data(), sizeof(SceneChunk) * (size_t)n_chunks, hipMemcpyHostToDevice));
+  ctx->n_chunks = n_chunks;
+  return LT_OK;
+}
+
+int lt_refresh_scene_chunks(lt_ctx *ctx) {
+  if (!ctx->inited || ctx->n_chunks <= 0) return fail(ctx, LT_ERR_STATE, "lt_refresh_scene_chunks before lt_set_scene_chunks");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  launch_build_scene_chunked(ctx->stream, ctx->n_img, ctx->G, ctx->n_chunks, ctx->d_chunks.as<SceneChunk>(),
+                             ctx->d_seg_off.as<long long>(), ctx->cfg.add_halfpix ? 0.5 : 0.0, ctx->d_cams.as<Cam>(),
+                             ctx->d_segs.as<Seg>());
   HIPCHK(ctx, hipGetLastError());
   ctx->ran = false;
   return LT_OK;

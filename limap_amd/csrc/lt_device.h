@@ -12,6 +12,14 @@
 
 namespace lt {
 
+struct SceneChunk {  // images [img_begin, next chunk's img_begin) live in these buffers
+  const double *k, *q, *t, *s;
+  long long seg_begin;  // global index of the chunk's first segment
+  int img_begin, pad_;
+};
+void launch_build_scene_chunked(hipStream_t st, int n_img, long long n_segs, int n_chunks, const SceneChunk *ch,
+                                const long long *seg_off, double halfpix, Cam *cams, Seg *segs);
+
 void launch_build_cams(hipStream_t st, int n, const double *k, const double *q, const double *t, Cam *cams);
 void launch_build_segs(hipStream_t st, long long n_segs, int n_img, const long long *seg_off,
                        const double *segs, double halfpix, const Cam *cams, Seg *out);

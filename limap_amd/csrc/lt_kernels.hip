@@ -57,6 +57,42 @@ __global__ void k_build_segs(long long n_segs, int n_img, const long long *__res
   out[s] = r;
 }
 
+// Scene given as chunks (one per rank of the all-gather): chunk c holds images [img_begin[c],
+// img_begin[c+1]) as kvec | qvec | tvec | segs in its own buffers.  Reads the gathered receive buffer
+// in place -- no unpack copies on the per-step path of the multi-GPU job.
+__global__ void k_build_cams_chunked(int n, int n_chunks, const SceneChunk *__restrict__ ch, Cam *__restrict__ cams) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int c = 0;
+  while (c + 1 < n_chunks && i >= ch[c + 1].img_begin) ++c;
+  int li = i - ch[c].img_begin;
+  Cam cm;
+  cam_build(ch[c].k + 4 * li, ch[c].q + 4 * li, ch[c].t + 3 * li, &cm);
+  cams[i] = cm;
+}
+
+__global__ void k_build_segs_chunked(long long n_segs, int n_img, int n_chunks, const SceneChunk *__restrict__ ch,
+                                     const long long *__restrict__ seg_off, double halfpix,
+                                     const Cam *__restrict__ cams, Seg *__restrict__ out) {
+  long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_segs) return;
+  int lo = 0, hi = n_img;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (seg_off[mid] <= s) lo = mid; else hi = mid;
+  }
+  int c = 0;
+  while (c + 1 < n_chunks && lo >= ch[c + 1].img_begin) ++c;
+  const double *p = ch[c].s + 4 * (s - ch[c].seg_begin);
+  double x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+  if (halfpix != 0.0) {
+    x1 = x1 + halfpix; y1 = y1 + halfpix; x2 = x2 + halfpix; y2 = y2 + halfpix;
+  }
+  Seg r;
+  seg_build(cams[lo], x1, y1, x2, y2, &r);
+  out[s] = r;
+}
+
 __global__ void k_build_pairs(int n_blk, const int *__restrict__ blk_img,
                               const int *__restrict__ blk_nb, const Cam *__restrict__ cams,
                               PairRec *__restrict__ out) {
@@ -278,6 +314,14 @@ void launch_build_segs(hipStream_t st, long long n_segs, int n_img, const long l
   if (n_segs > 0)
     hipLaunchKernelGGL(k_build_segs, dim3(nblk(n_segs, 256)), dim3(256), 0, st, n_segs, n_img, seg_off, segs,
                        halfpix, cams, out);
+}
+void launch_build_scene_chunked(hipStream_t st, int n_img, long long n_segs, int n_chunks, const SceneChunk *ch,
+                                const long long *seg_off, double halfpix, Cam *cams, Seg *segs) {
+  if (n_img > 0)
+    hipLaunchKernelGGL(k_build_cams_chunked, dim3(nblk(n_img, 128)), dim3(128), 0, st, n_img, n_chunks, ch, cams);
+  if (n_segs > 0)
+    hipLaunchKernelGGL(k_build_segs_chunked, dim3(nblk(n_segs, 256)), dim3(256), 0, st, n_segs, n_img, n_chunks, ch,
+                       seg_off, halfpix, cams, segs);
 }
 void launch_build_pairs(hipStream_t st, int n_blk, const int *blk_img, const int *blk_nb, const Cam *cams,
                         PairRec *out) {

@@ -75,6 +75,27 @@ class SceneGather:
         assert len(buf) == self.sizes[self.rank]
         self.local[:len(buf)].copy_(torch.from_numpy(buf))
 
+    def gather_only(self):
+        """The collective alone: afterwards `chunk_pointers()` describe the scene in place."""
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.recv, self.local)
+
+    def chunk_pointers(self):
+        """(img_begin, k_ptrs, q_ptrs, t_ptrs, s_ptrs): per-rank views into the receive buffer
+        (the local buffer for world == 1), for lt_set_scene_chunks.  Empty shards are skipped."""
+        buf = self.recv if self.world > 1 else self.local
+        base = buf.data_ptr()
+        ib, pk, pq, pt, ps = [], [], [], [], []
+        for r in range(self.world):
+            a, b = self.bounds[r], self.bounds[r + 1]
+            n = b - a
+            if n == 0 and r > 0:
+                continue
+            o = base + 8 * r * max(self.max_size, 1)
+            ib.append(a); pk.append(o); pq.append(o + 8 * 4 * n); pt.append(o + 8 * 8 * n); ps.append(o + 8 * 11 * n)
+        return ib, pk, pq, pt, ps
+
     def all_gather(self):
         """One collective; returns (kvec, qvec, tvec, segs) device tensors of the whole scene."""
         torch = self.torch

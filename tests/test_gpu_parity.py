@@ -72,3 +72,45 @@ def test_matched_unsorted_rows_generic_grouping(gpu_lib, oracle):
     compare_valid_edges(T.context().get_valid_edges(), O.get_valid_edges())
     T.ComputeLineTracks()
     compare_tracks(T.context().get_tracks(), O.ComputeLineTracks())
+
+
+def test_device_resident_scene_and_chunked_refresh(gpu_lib, oracle):
+    """lt_init_device + lt_set_scene_chunks / lt_refresh_scene_chunks (the per-step path of the
+    multi-GPU job, here with the scene cut into 3 artificial chunks) give the results of a plain
+    host Init; kernels run on torch's current stream."""
+    import torch
+    from limap_amd import _capi
+    sc = small_scene(seed=5, n_views=9, n_segs=70, n_neighbors=5)
+    cfg = syn.default_triangulation_cfg()
+    ref = run_product(sc, cfg).context().get_best()
+
+    dev = torch.device("cuda", 0)
+    ctx = _capi.Context(cfg_dict=cfg, device=0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.set_ranges(*sc.ranges)
+    bounds = [0, 2, 6, 9]
+    chunks = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        s0, s1 = int(sc.seg_off[a]), int(sc.seg_off[b])
+        buf = np.concatenate([sc.kvec[a:b].ravel(), sc.qvec[a:b].ravel(), sc.tvec[a:b].ravel(), sc.segs[s0:s1].ravel()])
+        chunks.append((a, b, torch.from_numpy(buf).to(dev)))
+    dk = torch.from_numpy(sc.kvec).to(dev); dq = torch.from_numpy(sc.qvec).to(dev)
+    dt = torch.from_numpy(sc.tvec).to(dev); ds = torch.from_numpy(sc.segs).to(dev)
+    torch.cuda.synchronize()
+    ctx.init_device(sc.img_ids, dk.data_ptr(), dq.data_ptr(), dt.data_ptr(), sc.seg_off, ds.data_ptr())
+    # now poison the invariants' sources and rebuild from the chunks
+    dk.fill_(float("nan")); ds.fill_(float("nan"))
+    ib = [a for a, _, _ in chunks]
+    n = [b - a for a, b, _ in chunks]
+    base = [t.data_ptr() for _, _, t in chunks]
+    ctx.set_scene_chunks(ib, base, [p + 32 * k for p, k in zip(base, n)], [p + 64 * k for p, k in zip(base, n)],
+                         [p + 88 * k for p, k in zip(base, n)])
+    ctx.refresh_scene_chunks()
+    for i in sc.img_ids:
+        m = sc.matches_of(int(i))
+        nb = list(m.keys())
+        off = np.zeros(len(nb) + 1, np.int64); off[1:] = np.cumsum([len(m[k]) for k in nb])
+        ctx.triangulate_image(int(i), nb, off, np.concatenate([m[k] for k in nb], 0))
+    got = ctx.get_best()
+    compare_best(got, ref)
+    assert np.array_equal(got["line"], ref["line"])
