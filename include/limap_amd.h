@@ -152,6 +152,18 @@ int lt_get_tracks(lt_ctx *ctx, double *out_line7, int64_t *out_off, int32_t *out
                   int32_t *out_line_ids, int32_t *out_node_ids, double *out_scores,
                   double *out_line3d6);
 
+/* Multi-GPU tail: the rank that triangulated an image exports its per-node results (neighbour list,
+ * best candidate per line, valid edges); the rank that runs ComputeLineTracks imports them for the
+ * images it did not triangulate itself.  lt_image_results_size returns the image's line count and
+ * its number of valid edges (array sizes for the export). */
+int64_t lt_image_results_size(lt_ctx *ctx, int img_id, int64_t *n_edges);
+int lt_export_image_results(lt_ctx *ctx, int img_id, int32_t *out_nb_ids /*[255]*/, int32_t *out_n_nb,
+                            double *out_line10, double *out_score, int32_t *out_src2, int32_t *out_n_tris,
+                            int64_t *out_edge_off, int32_t *out_edges2);
+int lt_import_image_results(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids, const double *line10,
+                            const double *score, const int32_t *src2, const int32_t *n_tris,
+                            const int64_t *edge_off, const int32_t *edges2);
+
 /* Counters of the last device run: [0] connections tested, [1] candidates, [2] ordered candidate
  * pairs swept by the scoring kernel (sum n_tris^2), [3] valid edges, [4] graph nodes,
  * [5] graph edges, [6] tracks, [7] nodes. */

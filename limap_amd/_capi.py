@@ -19,7 +19,8 @@ EXPORTED_SYMBOLS = [
     "lt_triangulate_image_exhaustive", "lt_upload", "lt_run_device", "lt_download", "lt_flush",
     "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
     "lt_get_num_tris", "lt_num_valid_edges", "lt_get_valid_edges", "lt_num_all_tris", "lt_get_all_tris",
-    "lt_num_tracks", "lt_num_track_members", "lt_get_tracks", "lt_get_stats", "lt_get_timers",
+    "lt_num_tracks", "lt_num_track_members", "lt_get_tracks", "lt_image_results_size",
+    "lt_export_image_results", "lt_import_image_results", "lt_get_stats", "lt_get_timers",
     "lt_fn_get_normal_direction", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
     "lt_fn_triangulate_line",
 ]
@@ -110,6 +111,10 @@ def load_library():
     L.lt_get_valid_edges.argtypes = [vp, i64p, i32p]
     L.lt_get_all_tris.argtypes = [vp, i64p, dp, dp, i32p]
     L.lt_get_tracks.argtypes = [vp, dp, i64p, i32p, i32p, i32p, dp, dp]
+    L.lt_image_results_size.argtypes = [vp, C.c_int, i64p]
+    L.lt_image_results_size.restype = C.c_int64
+    L.lt_export_image_results.argtypes = [vp, C.c_int, i32p, i32p, dp, dp, i32p, i32p, i64p, i32p]
+    L.lt_import_image_results.argtypes = [vp, C.c_int, C.c_int, i32p, dp, dp, i32p, i32p, i64p, i32p]
     L.lt_get_stats.argtypes = [vp, i64p]
     L.lt_get_timers.argtypes = [vp, dp]
     L.lt_fn_get_normal_direction.argtypes = [vp, dp, dp, dp]
@@ -302,6 +307,32 @@ class Context:
                                       ptr(l3d, C.c_double)))
         return dict(line=line[:T], off=off, image_ids=img[:M], line_ids=lid[:M], node_ids=nid[:M], scores=sc[:M],
                     line3d=l3d[:M])
+
+    def export_image_results(self, img_id):
+        """Per-node results of one image this context triangulated (dict of numpy arrays)."""
+        ne = C.c_int64(0)
+        m = int(self.L.lt_image_results_size(self.h, int(img_id), C.byref(ne)))
+        if m < 0:
+            self.chk(-1)
+        nb = np.zeros(255, np.int32); n_nb = C.c_int32(0)
+        line = np.zeros((max(m, 1), 10)); score = np.zeros(max(m, 1)); src = np.zeros((max(m, 1), 2), np.int32)
+        nt = np.zeros(max(m, 1), np.int32); eoff = np.zeros(m + 1, np.int64); edges = np.zeros((max(ne.value, 1), 2), np.int32)
+        self.chk(self.L.lt_export_image_results(self.h, int(img_id), ptr(nb, C.c_int32), C.byref(n_nb), ptr(line, C.c_double),
+                                                ptr(score, C.c_double), ptr(src, C.c_int32), ptr(nt, C.c_int32),
+                                                ptr(eoff, C.c_int64), ptr(edges, C.c_int32)))
+        return dict(img_id=int(img_id), nb_ids=nb[:n_nb.value].copy(), line=line[:m], score=score[:m], src=src[:m],
+                    n_tris=nt[:m], edge_off=eoff, edges=edges[:ne.value])
+
+    def import_image_results(self, r):
+        nb = i32(r["nb_ids"]); line = f64(r["line"]).reshape(-1, 10); score = f64(r["score"]); src = i32(r["src"]).reshape(-1, 2)
+        nt = i32(r["n_tris"]); eoff = i64(r["edge_off"]); edges = i32(r["edges"]).reshape(-1, 2)
+        if edges.size == 0:
+            edges = np.zeros((1, 2), np.int32)
+        if line.size == 0:
+            line = np.zeros((1, 10)); score = np.zeros(1); src = np.zeros((1, 2), np.int32); nt = np.zeros(1, np.int32)
+        self.chk(self.L.lt_import_image_results(self.h, int(r["img_id"]), len(nb), ptr(nb, C.c_int32), ptr(line, C.c_double),
+                                                ptr(score, C.c_double), ptr(src, C.c_int32), ptr(nt, C.c_int32),
+                                                ptr(eoff, C.c_int64), ptr(edges, C.c_int32)))
 
     def stats(self):
         out = np.zeros(8, np.int64)

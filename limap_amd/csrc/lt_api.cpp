@@ -1423,6 +1423,88 @@ int lt_get_tracks(lt_ctx *ctx, double *out_line7, int64_t *out_off, int32_t *out
   return LT_OK;
 }
 
+// ---- per-image results: export on the rank that triangulated the image, import on the rank that
+// runs the tail (multi-GPU: SURVEY.md 8e "Tail") ----
+int64_t lt_image_results_size(lt_ctx *ctx, int img_id, int64_t *n_edges) {
+  if (lt_flush(ctx)) return -1;
+  auto it = ctx->id2idx.find(img_id);
+  if (it == ctx->id2idx.end()) {
+    ctx->err = "unknown image id " + std::to_string(img_id);
+    return -1;
+  }
+  int idx = it->second;
+  int64_t e = 0;
+  for (long long g = ctx->seg_off[idx]; g < ctx->seg_off[idx + 1]; ++g) e += (int64_t)ctx->valid_edges[g].size() / 2;
+  if (n_edges) *n_edges = e;
+  return ctx->seg_off[idx + 1] - ctx->seg_off[idx];
+}
+
+int lt_export_image_results(lt_ctx *ctx, int img_id, int32_t *out_nb_ids, int32_t *out_n_nb, double *out_line10,
+                            double *out_score, int32_t *out_src2, int32_t *out_n_tris, int64_t *out_edge_off,
+                            int32_t *out_edges2) {
+  int rc = lt_flush(ctx);
+  if (rc) return rc;
+  auto it = ctx->id2idx.find(img_id);
+  if (it == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "unknown image id " + std::to_string(img_id));
+  int idx = it->second;
+  if (!ctx->triangulated[idx]) return fail(ctx, LT_ERR_STATE, "image was not triangulated on this context");
+  const auto &nb = ctx->neighbors[idx];
+  *out_n_nb = (int32_t)nb.size();
+  for (size_t k = 0; k < nb.size(); ++k) out_nb_ids[k] = ctx->img_ids[nb[k]];
+  int64_t e = 0;
+  long long g0 = ctx->seg_off[idx];
+  out_edge_off[0] = 0;
+  for (long long g = g0; g < ctx->seg_off[idx + 1]; ++g) {
+    long long l = g - g0;
+    const Cand &c = ctx->best_c[g];
+    double *o = out_line10 + 10 * l;
+    for (int k = 0; k < 3; ++k) { o[k] = c.s[k]; o[3 + k] = c.e[k]; }
+    o[6] = c.depth[0]; o[7] = c.depth[1]; o[8] = c.unc; o[9] = c.score3;
+    out_score[l] = ctx->best_score[g];
+    out_src2[2 * l] = ctx->best_src2[2 * g];
+    out_src2[2 * l + 1] = ctx->best_src2[2 * g + 1];
+    out_n_tris[l] = ctx->n_tris[g];
+    const auto &v = ctx->valid_edges[g];
+    if (!v.empty()) std::memcpy(out_edges2 + 2 * e, v.data(), 4 * v.size());
+    e += (int64_t)v.size() / 2;
+    out_edge_off[l + 1] = e;
+  }
+  return LT_OK;
+}
+
+int lt_import_image_results(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids, const double *line10,
+                            const double *score, const int32_t *src2, const int32_t *n_tris,
+                            const int64_t *edge_off, const int32_t *edges2) {
+  if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "import before Init");
+  auto it = ctx->id2idx.find(img_id);
+  if (it == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "unknown image id " + std::to_string(img_id));
+  int idx = it->second;
+  std::vector<int> nb;
+  for (int k = 0; k < n_nb; ++k) {
+    auto jt = ctx->id2idx.find(nb_ids[k]);
+    if (jt == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "unknown neighbour image id " + std::to_string(nb_ids[k]));
+    nb.push_back(jt->second);
+  }
+  ctx->neighbors[idx] = nb;
+  ctx->triangulated[idx] = 1;
+  long long g0 = ctx->seg_off[idx];
+  for (long long g = g0; g < ctx->seg_off[idx + 1]; ++g) {
+    long long l = g - g0;
+    Cand &c = ctx->best_c[g];
+    const double *o = line10 + 10 * l;
+    for (int k = 0; k < 3; ++k) { c.s[k] = o[k]; c.e[k] = o[3 + k]; }
+    c.depth[0] = o[6]; c.depth[1] = o[7]; c.unc = o[8]; c.score3 = o[9];
+    ctx->best_score[g] = score[l];
+    ctx->best_src2[2 * g] = src2[2 * l];
+    ctx->best_src2[2 * g + 1] = src2[2 * l + 1];
+    ctx->n_tris[g] = n_tris[l];
+    ctx->has_best[g] = n_tris[l] > 0 ? 1 : 0;
+    ctx->valid_edges[g].assign(edges2 + 2 * edge_off[l], edges2 + 2 * edge_off[l + 1]);
+  }
+  ctx->tracks_done = false;
+  return LT_OK;
+}
+
 int lt_get_stats(lt_ctx *ctx, int64_t out[8]) {
   out[0] = ctx->n_conn; out[1] = ctx->C; out[2] = ctx->stat_pairs; out[3] = ctx->E;
   out[4] = ctx->stat_graph_nodes; out[5] = ctx->stat_graph_edges; out[6] = (int64_t)ctx->tracks.size();

@@ -114,3 +114,51 @@ def test_device_resident_scene_and_chunked_refresh(gpu_lib, oracle):
     got = ctx.get_best()
     compare_best(got, ref)
     assert np.array_equal(got["line"], ref["line"])
+
+
+def test_incremental_batches(gpu_lib, oracle):
+    """Images triangulated in several batches with result reads in between (streamed use, config 5):
+    every flush merges into the persistent per-node results; the final tracks equal a one-batch run."""
+    sc = small_scene(seed=6, n_views=14, n_segs=90, n_neighbors=7)
+    cfg = syn.default_triangulation_cfg()
+    from limap_amd import triangulation as tri
+    T = tri.GlobalLineTriangulator(cfg)
+    T.SetRanges(sc.ranges)
+    T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+    ids = [int(i) for i in sc.img_ids]
+    for chunk in (ids[:5], ids[5:6], ids[6:]):
+        for i in chunk:
+            T.TriangulateImage(i, sc.matches_of(i))
+        assert T.context().get_best()["has_best"].shape[0] == sc.seg_off[-1]  # forces a flush
+    O = run_oracle(oracle, sc, cfg)
+    compare_best(T.context().get_best(), O.get_best())
+    compare_valid_edges(T.context().get_valid_edges(), O.get_valid_edges())
+    T.ComputeLineTracks()
+    compare_tracks(T.context().get_tracks(), O.ComputeLineTracks())
+
+
+def test_two_rank_shards_merge_on_rank0(gpu_lib, oracle):
+    """The multi-GPU flow on one GPU: two contexts ("ranks") share the scene, each triangulates its
+    shard of the images, rank 1 exports its per-image results, rank 0 imports them and runs the tail.
+    Tracks must equal the single-process run."""
+    from limap_amd import _capi, dist as ltdist
+    sc = small_scene(seed=7, n_views=12, n_segs=100, n_neighbors=6)
+    cfg = syn.default_triangulation_cfg()
+    ranks = []
+    for r in range(2):
+        ctx = _capi.Context(cfg_dict=cfg, device=0)
+        ctx.set_ranges(*sc.ranges)
+        ctx.init(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, sc.seg_off, sc.segs)
+        for i in ltdist.shard_images(sc.img_ids, r, 2):
+            m = sc.matches_of(int(i))
+            nb = list(m.keys())
+            off = np.zeros(len(nb) + 1, np.int64); off[1:] = np.cumsum([len(m[k]) for k in nb])
+            ctx.triangulate_image(int(i), nb, off, np.concatenate([m[k] for k in nb], 0))
+        ranks.append(ctx)
+    for i in ltdist.shard_images(sc.img_ids, 1, 2):
+        ranks[0].import_image_results(ranks[1].export_image_results(int(i)))
+    ranks[0].compute_tracks()
+    O = run_oracle(oracle, sc, cfg)
+    compare_best(ranks[0].get_best(), O.get_best())
+    compare_valid_edges(ranks[0].get_valid_edges(), O.get_valid_edges())
+    compare_tracks(ranks[0].get_tracks(), O.ComputeLineTracks())
