@@ -141,6 +141,13 @@ def main():
     st = ctx.stats()
     st["active_nodes"] = int(sum(scene.seg_off[j + 1] - scene.seg_off[j] for j in
                                  np.searchsorted(scene.img_ids, my_imgs)))
+    # N > 1: rank 0 imports the other shards' per-node results and runs the tail for the whole scene
+    merge_note = None
+    if world > 1:
+        try:
+            ltdist.merge_shards_on_rank0(ctx, my_imgs, rank, world)
+        except Exception as e:  # never lose the throughput line over the (untimed) merge
+            merge_note = f"merge failed: {type(e).__name__}: {e}"
     t_tail0 = time.perf_counter()
     ctx.compute_tracks()
     t_tail = time.perf_counter() - t_tail0
@@ -198,6 +205,7 @@ def main():
                                                  ("k_gen_rows" if args.mode == "matched" else "k_gen_exhaustive"))),
             "roofline_all": roof,
             "host_ms": {"upload_matches": 1e3 * t_upload, "tail_compute_tracks": 1e3 * t_tail},
+            "tracks_whole_scene": st_after["tracks"], "merge_note": merge_note,
         }
 
     # ---- end-to-end wall-clock through the reference's API sequence, rank 0 / N = 1 ----

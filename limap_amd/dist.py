@@ -120,6 +120,25 @@ class SceneGather:
         return self.kvec, self.qvec, self.tvec, self.segs
 
 
+def merge_shards_on_rank0(ctx, my_imgs, rank, world):
+    """After every rank has triangulated its shard: ship the per-image results to rank 0 (one object
+    collective) and import them into rank 0's context, which can then run `compute_tracks()` for the
+    whole scene.  Returns the number of images imported (0 on the other ranks)."""
+    if world == 1:
+        return 0
+    import torch.distributed as dist
+    mine = [ctx.export_image_results(int(i)) for i in my_imgs]
+    parts = [None] * world
+    dist.all_gather_object(parts, mine if rank != 0 else [])
+    n = 0
+    if rank == 0:
+        for r in range(1, world):
+            for res in parts[r]:
+                ctx.import_image_results(res)
+                n += 1
+    return n
+
+
 def gather_results_to_rank0(ctx_results, rank, world):
     """Gather per-node results (dict of numpy arrays restricted to this rank's nodes) on rank 0
     with one object gather; used before the host tail."""
