@@ -164,6 +164,33 @@ int lt_import_image_results(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb
                             const double *score, const int32_t *src2, const int32_t *n_tris,
                             const int64_t *edge_off, const int32_t *edges2);
 
+/* ---- post-triangulation steps of limap.runners.line_triangulation (:171-200), SURVEY 8(f) rank 2:
+ * limap.merging.filter_tracks_by_reprojection / remerge / filter_tracks_by_sensitivity /
+ * filter_tracks_by_overlap (merging/merging_utils.cc:27-155, merging/merging.cc:513-644).
+ * A track set is a host container of LineTracks (base/linetrack.h:21-50); cameras are those of the
+ * context's Init.  member arrays: img/lid/nid int32, score f64, line2d4 = x1 y1 x2 y2,
+ * line3d10 = start3 end3 depths2 uncertainty score; line7 = start3 end3 uncertainty. ---- */
+typedef struct lt_trackset lt_trackset;
+lt_trackset *lt_ts_from_ctx(lt_ctx *ctx); /* copy of GetTracks() with the auxiliary lists filled */
+lt_trackset *lt_ts_create(int64_t n_tracks, const double *line7, const uint8_t *active, const int64_t *off,
+                          const int32_t *img, const int32_t *lid, const int32_t *nid, const double *score,
+                          const double *line2d4, const double *line3d10);
+void lt_ts_destroy(lt_trackset *ts);
+int64_t lt_ts_num_tracks(lt_trackset *ts);
+int64_t lt_ts_num_members(lt_trackset *ts);
+int lt_ts_get(lt_trackset *ts, double *line7, uint8_t *active, int64_t *off, int32_t *img, int32_t *lid,
+              int32_t *nid, double *score, double *line2d4, double *line3d10);
+/* _FilterSupportLines (merging_utils.cc:51-83) */
+int lt_ts_filter_by_reprojection(lt_ctx *ctx, lt_trackset *ts, double th_angular2d, double th_perp2d,
+                                 int num_outliers);
+/* _FilterTracksBySensitivity (merging_utils.cc:105-128) */
+int lt_ts_filter_by_sensitivity(lt_ctx *ctx, lt_trackset *ts, double th_angular3d, int min_supports);
+/* _FilterTracksByOverlap (merging_utils.cc:130-155) */
+int lt_ts_filter_by_overlap(lt_ctx *ctx, lt_trackset *ts, double th_overlap, int min_supports);
+/* one pass of _RemergeLineTracks (merging/merging.cc:513-644); the LineLinker3d is read from the
+ * l3_* fields of linker_cfg; the all-pairs connection test runs on the GPU */
+int lt_ts_remerge_once(lt_ctx *ctx, lt_trackset *ts, const lt_config *linker_cfg, int num_outliers);
+
 /* Counters of the last device run: [0] connections tested, [1] candidates, [2] ordered candidate
  * pairs swept by the scoring kernel (sum n_tris^2), [3] valid edges, [4] graph nodes,
  * [5] graph edges, [6] tracks, [7] nodes. */

@@ -20,7 +20,9 @@ EXPORTED_SYMBOLS = [
     "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
     "lt_get_num_tris", "lt_num_valid_edges", "lt_get_valid_edges", "lt_num_all_tris", "lt_get_all_tris",
     "lt_num_tracks", "lt_num_track_members", "lt_get_tracks", "lt_image_results_size",
-    "lt_export_image_results", "lt_import_image_results", "lt_get_stats", "lt_get_timers",
+    "lt_export_image_results", "lt_import_image_results", "lt_ts_from_ctx", "lt_ts_create", "lt_ts_destroy",
+    "lt_ts_num_tracks", "lt_ts_num_members", "lt_ts_get", "lt_ts_filter_by_reprojection",
+    "lt_ts_filter_by_sensitivity", "lt_ts_filter_by_overlap", "lt_ts_remerge_once", "lt_get_stats", "lt_get_timers",
     "lt_fn_get_normal_direction", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
     "lt_fn_triangulate_line",
 ]
@@ -115,6 +117,20 @@ def load_library():
     L.lt_image_results_size.restype = C.c_int64
     L.lt_export_image_results.argtypes = [vp, C.c_int, i32p, i32p, dp, dp, i32p, i32p, i64p, i32p]
     L.lt_import_image_results.argtypes = [vp, C.c_int, C.c_int, i32p, dp, dp, i32p, i32p, i64p, i32p]
+    L.lt_ts_from_ctx.argtypes = [vp]
+    L.lt_ts_from_ctx.restype = vp
+    L.lt_ts_create.argtypes = [C.c_int64, dp, u8p, i64p, i32p, i32p, i32p, dp, dp, dp]
+    L.lt_ts_create.restype = vp
+    L.lt_ts_destroy.argtypes = [vp]
+    L.lt_ts_destroy.restype = None
+    for n in ("lt_ts_num_tracks", "lt_ts_num_members"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = C.c_int64
+    L.lt_ts_get.argtypes = [vp, dp, u8p, i64p, i32p, i32p, i32p, dp, dp, dp]
+    L.lt_ts_filter_by_reprojection.argtypes = [vp, vp, C.c_double, C.c_double, C.c_int]
+    L.lt_ts_filter_by_sensitivity.argtypes = [vp, vp, C.c_double, C.c_int]
+    L.lt_ts_filter_by_overlap.argtypes = [vp, vp, C.c_double, C.c_int]
+    L.lt_ts_remerge_once.argtypes = [vp, vp, C.POINTER(LtConfig), C.c_int]
     L.lt_get_stats.argtypes = [vp, i64p]
     L.lt_get_timers.argtypes = [vp, dp]
     L.lt_fn_get_normal_direction.argtypes = [vp, dp, dp, dp]

@@ -7,8 +7,8 @@
 // because it is a serial union-find over a few 10^4..10^6 edges (SURVEY.md 8e "Tail").
 // There is no CPU fallback for the kernels: without a GPU lt_create fails.
 
-#include "../../include/limap_amd.h"
-#include "lt_device.h"
+#include "lt_ctx.h"
+#include "lt_tail.h"
 
 #include <algorithm>
 #include <chrono>
@@ -60,131 +60,9 @@ double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-struct DevBuf {
-  void *p = nullptr;
-  size_t cap = 0;
-  bool ensure(size_t bytes) {
-    if (bytes <= cap) return true;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = bytes + bytes / 8 + 256;
-    if (hipMalloc(&p, want) != hipSuccess) return false;
-    cap = want;
-    return true;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-  template <class T>
-  T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-struct Track {
-  double line[7];
-  std::vector<int> img_ids, line_ids, node_ids;
-  std::vector<double> scores;
-  std::vector<long long> gnodes;  // global node index of every member
-};
-
 }  // namespace
 
-struct lt_ctx {
-  lt_config cfg;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = true;
-  std::string err;
-  bool ranges_on = false;
-  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-
-  // ---- scene ----
-  bool inited = false;
-  int n_img = 0;
-  std::vector<int> img_ids;  // ascending
-  std::unordered_map<int, int> id2idx;
-  std::vector<long long> seg_off;  // n_img+1
-  long long G = 0;
-  std::vector<int> h_node_img;  // node -> image index
-  DevBuf d_kvec, d_qvec, d_tvec, d_segs_raw, d_cams, d_segs, d_seg_off, d_node_img;
-
-  // ---- buffered job ----
-  int job_mode = 0;  // 0 none, 1 matched, 2 exhaustive
-  std::vector<int> job_imgs;               // image indices in call order
-  std::vector<std::vector<int>> job_nbs;   // per job image: neighbour image indices, processing order
-  std::vector<std::vector<int>> job_order; // per job image: slots in ascending neighbour-id order
-  std::vector<long long> h_m_off;          // per block row offsets (n_blk+1), matched mode
-  std::vector<int> h_m_pairs;              // 2 * P
-  std::vector<char> triangulated;          // per image: already passed to TriangulateImage*
-  bool uploaded = false, ran = false, downloaded = false;
-  // neighbours_ of every triangulated image (ids), persists for the tail
-  std::vector<std::vector<int>> neighbors;  // image idx -> neighbour image indices (slot order)
-
-  // ---- device job tables ----
-  int n_blk = 0;
-  int max_nb = 1;
-  long long P = 0;        // connections (matched) / work items (exhaustive: n_items)
-  long long max_rows = 0; // matched: most rows of any (image, neighbour) block
-  long long n_conn = 0;   // connections tested (stat)
-  std::vector<long long> h_nb_off;  // n_img+1
-  std::vector<int> h_blk_img, h_blk_nb, h_blk_slot, h_blk_order;
-  std::vector<long long> h_item_off;  // exhaustive: per node first item (G+1)
-  DevBuf d_nb_off, d_blk_img, d_blk_nb, d_blk_slot, d_blk_order, d_m_off, d_m_pairs, d_pairs;
-  DevBuf d_keys, d_rows, d_row_blk, d_skeys, d_srows, d_sort_tmp, d_conn_off;
-  DevBuf d_st_c, d_st_l, d_flags, d_pos, d_scan_tmp;
-  DevBuf d_item_off, d_masks, d_mask_cnt, d_mask_pos;
-  DevBuf d_cand, d_lite, d_tri_off, d_score, d_best_idx, d_edge_flag, d_nvalid, d_edge_off, d_edges;
-  DevBuf d_best_c, d_best_score, d_best_src, d_ntris, d_err;
-  DevBuf d_blk_line_base, d_cnt_bl, d_st_key, d_wave_count, d_wave_pos, d_ntris_u, d_cand_node, d_pair_counter;
-  int max_nb_segs = 0;   // most segments of any neighbour image in the job (LDS table sizing)
-  long long stat_pairs_eval = 0;
-  std::vector<long long> h_blk_line_base;
-  bool rows_sorted = true;   // every (image, neighbour) block lists its rows in non-decreasing line id
-  long long *h_pinned = nullptr;  // pinned scratch for small device->host scalars
-  DevBuf d_chunks;
-  int n_chunks = 0;
-  long long cand_cap = 0;
-  long long C = 0, E = 0;  // candidates / valid edges of the last run
-
-  // ---- host results (all nodes) ----
-  std::vector<Cand> best_c;
-  std::vector<double> best_score;
-  std::vector<int> best_src2, n_tris;
-  std::vector<unsigned char> has_best;
-  std::vector<std::vector<int>> valid_edges;  // per node: flat (slot, ng_line) pairs
-  // ---- tail ----
-  std::vector<Track> tracks;
-  bool tracks_done = false;
-  long long stat_graph_nodes = 0, stat_graph_edges = 0, stat_pairs = 0;
-  double timers[16] = {0};
-  hipEvent_t ev[9] = {nullptr};
-};
-
 namespace {
-
-#define HIPCHK(ctx, call)                                                                  \
-  do {                                                                                     \
-    hipError_t e_ = (call);                                                                \
-    if (e_ != hipSuccess) {                                                                \
-      (ctx)->err = std::string("HIP error: ") + hipGetErrorString(e_) + " at " #call;      \
-      return LT_ERR_HIP;                                                                   \
-    }                                                                                      \
-  } while (0)
-
-#define ENSURE(ctx, buf, bytes)                                                 \
-  do {                                                                          \
-    if (!(buf).ensure(bytes)) {                                                 \
-      (ctx)->err = "hipMalloc failed for " #buf;                                \
-      return LT_ERR_HIP;                                                        \
-    }                                                                           \
-  } while (0)
-
-int fail(lt_ctx *ctx, int code, const std::string &msg) {
-  ctx->err = msg;
-  return code;
-}
 
 double multiplier(double score_th) { return 1.0 / std::sqrt(-std::log(score_th) * 2.0); }  // line_linker.cc:9-12
 
@@ -312,6 +190,22 @@ int build_invariants(lt_ctx *ctx) {
                     ctx->cfg.add_halfpix ? 0.5 : 0.0, ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>());
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(st));
+  {  // host copies for the tail-side filters (small: 88 B per image + 32 B per segment)
+    const int n = ctx->n_img;
+    std::vector<double> k(4 * (size_t)n), q(4 * (size_t)n), t(3 * (size_t)n);
+    ctx->h_segs.assign(4 * (size_t)ctx->G, 0.0);
+    if (n > 0) {
+      HIPCHK(ctx, hipMemcpy(k.data(), ctx->d_kvec.p, 32 * (size_t)n, hipMemcpyDeviceToHost));
+      HIPCHK(ctx, hipMemcpy(q.data(), ctx->d_qvec.p, 32 * (size_t)n, hipMemcpyDeviceToHost));
+      HIPCHK(ctx, hipMemcpy(t.data(), ctx->d_tvec.p, 24 * (size_t)n, hipMemcpyDeviceToHost));
+    }
+    if (ctx->G > 0)
+      HIPCHK(ctx, hipMemcpy(ctx->h_segs.data(), ctx->d_segs_raw.p, 32 * (size_t)ctx->G, hipMemcpyDeviceToHost));
+    if (ctx->cfg.add_halfpix)
+      for (double &v : ctx->h_segs) v = v + 0.5;
+    ctx->h_cams.resize(n);
+    for (int i = 0; i < n; ++i) cam_build(&k[4 * i], &q[4 * i], &t[3 * i], &ctx->h_cams[i]);
+  }
   ctx->inited = true;
   return LT_OK;
 }
@@ -1035,118 +929,6 @@ int lt_flush(lt_ctx *ctx) {
 // ---------------------------------------------------------------------------------------------
 // host tail
 // ---------------------------------------------------------------------------------------------
-namespace {
-
-int uf_root(int i, std::vector<int> &parent) {  // base/graph.cc:156-165 (iterative path compression)
-  int r = i;
-  while (parent[r] != -1) r = parent[r];
-  while (parent[i] != -1) {
-    int nx = parent[i];
-    if (nx != r) parent[i] = r;
-    i = nx;
-  }
-  return r;
-}
-
-// principal axis of a point set: eigenvector of the largest eigenvalue of the 3x3 scatter matrix
-// (cyclic Jacobi).  Replaces Eigen::JacobiSVD(...).matrixV().col(0) (merging/aggregator.cc:76-78);
-// sign fixed so that the largest-magnitude component is positive.
-void principal_axis(const std::vector<d3> &pts, double out[3]) {
-  double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  for (const d3 &p : pts) {
-    double v[3] = {p.x, p.y, p.z};
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) A[i][j] += v[i] * v[j];
-  }
-  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  for (int sweep = 0; sweep < 64; ++sweep) {
-    double off = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]);
-    double diag = std::fabs(A[0][0]) + std::fabs(A[1][1]) + std::fabs(A[2][2]);
-    if (off <= 1e-18 * diag || off == 0.0) break;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        if (A[p][q] == 0.0) continue;
-        double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 3; ++k) {
-          double akp = A[k][p], akq = A[k][q];
-          A[k][p] = c * akp - s * akq;
-          A[k][q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < 3; ++k) {
-          double apk = A[p][k], aqk = A[q][k];
-          A[p][k] = c * apk - s * aqk;
-          A[q][k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < 3; ++k) {
-          double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - s * vkq;
-          V[k][q] = s * vkp + c * vkq;
-        }
-      }
-  }
-  int b = 0;
-  if (A[1][1] > A[b][b]) b = 1;
-  if (A[2][2] > A[b][b]) b = 2;
-  double d[3] = {V[0][b], V[1][b], V[2][b]};
-  double ax = std::fabs(d[0]), ay = std::fabs(d[1]), az = std::fabs(d[2]);
-  double lead = (ax >= ay && ax >= az) ? d[0] : (ay >= az ? d[1] : d[2]);
-  double sgn = lead < 0 ? -1.0 : 1.0;
-  for (int k = 0; k < 3; ++k) out[k] = sgn * d[k];
-}
-
-// Aggregator::aggregate_line3d_list, merging/aggregator.cc:53-101 (+ takebest :8-29)
-void aggregate(const std::vector<const Cand *> &lines, const std::vector<double> &scores, int num_outliers,
-               double out7[7]) {
-  const int n = (int)lines.size();
-  double min_unc = kMaxDist;
-  for (int i = 0; i < n; ++i)
-    if (lines[i]->unc < min_unc) min_unc = lines[i]->unc;
-  if (n < 4) {
-    double best_score = 0.0;
-    int best = -1;
-    for (int i = 0; i < n; ++i)
-      if (scores[i] > best_score) {
-        best_score = scores[i];
-        best = i;
-      }
-    if (best < 0) best = 0;
-    for (int k = 0; k < 3; ++k) {
-      out7[k] = lines[best]->s[k];
-      out7[3 + k] = lines[best]->e[k];
-    }
-    out7[6] = min_unc;
-    return;
-  }
-  d3 center = mk3(0, 0, 0);
-  for (int i = 0; i < n; ++i) {
-    center = add(center, mk3(lines[i]->s[0], lines[i]->s[1], lines[i]->s[2]));
-    center = add(center, mk3(lines[i]->e[0], lines[i]->e[1], lines[i]->e[2]));
-  }
-  double dn = (double)(2 * n);
-  center = mk3(center.x / dn, center.y / dn, center.z / dn);
-  std::vector<d3> pts(2 * (size_t)n);
-  for (int i = 0; i < n; ++i) {
-    pts[2 * i] = sub(mk3(lines[i]->s[0], lines[i]->s[1], lines[i]->s[2]), center);
-    pts[2 * i + 1] = sub(mk3(lines[i]->e[0], lines[i]->e[1], lines[i]->e[2]), center);
-  }
-  double dv[3];
-  principal_axis(pts, dv);
-  d3 direc = mk3(dv[0], dv[1], dv[2]);
-  double nn = std::sqrt(sqn(direc));
-  direc = mk3(direc.x / nn, direc.y / nn, direc.z / nn);
-  std::vector<double> proj(2 * (size_t)n);
-  for (int i = 0; i < 2 * n; ++i) proj[i] = dot(pts[i], direc);
-  std::sort(proj.begin(), proj.end());
-  double a = proj[num_outliers], b = proj[2 * n - 1 - num_outliers];
-  out7[0] = center.x + direc.x * a; out7[1] = center.y + direc.y * a; out7[2] = center.z + direc.z * a;
-  out7[3] = center.x + direc.x * b; out7[4] = center.y + direc.y * b; out7[5] = center.z + direc.z * b;
-  out7[6] = min_unc;
-}
-
-}  // namespace
-
 int lt_compute_tracks(lt_ctx *ctx) {
   int rc = lt_flush(ctx);
   if (rc) return rc;

@@ -1,0 +1,144 @@
+// lt_ctx.h -- context of the C ABI, shared by lt_api.cpp (pipeline, tail) and lt_tracks.cpp
+// (post-triangulation filters and remerge).
+#pragma once
+
+#include "../../include/limap_amd.h"
+#include "lt_device.h"
+
+#include <string>
+#include <hip/hip_runtime.h>
+#include <unordered_map>
+#include <vector>
+
+namespace lt_host {
+using namespace lt;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t bytes) {
+    if (bytes <= cap) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) return false;
+    cap = want;
+    return true;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct Track {
+  double line[7];
+  std::vector<int> img_ids, line_ids, node_ids;
+  std::vector<double> scores;
+  std::vector<long long> gnodes;  // global node index of every member
+};
+
+}  // namespace lt_host
+
+using lt_host::DevBuf;
+using lt_host::Track;
+
+struct lt_ctx {
+  using Cand = lt::Cand;
+  lt_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  std::string err;
+  bool ranges_on = false;
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+
+  // ---- scene ----
+  bool inited = false;
+  int n_img = 0;
+  std::vector<int> img_ids;  // ascending
+  std::unordered_map<int, int> id2idx;
+  std::vector<long long> seg_off;  // n_img+1
+  long long G = 0;
+  std::vector<int> h_node_img;  // node -> image index
+  std::vector<lt::Cam> h_cams;     // host copy of the camera table (post-triangulation filters)
+  std::vector<double> h_segs;     // host copy of the 2D segments, x1 y1 x2 y2 (after add_halfpix)
+  DevBuf d_kvec, d_qvec, d_tvec, d_segs_raw, d_cams, d_segs, d_seg_off, d_node_img;
+
+  // ---- buffered job ----
+  int job_mode = 0;  // 0 none, 1 matched, 2 exhaustive
+  std::vector<int> job_imgs;               // image indices in call order
+  std::vector<std::vector<int>> job_nbs;   // per job image: neighbour image indices, processing order
+  std::vector<std::vector<int>> job_order; // per job image: slots in ascending neighbour-id order
+  std::vector<long long> h_m_off;          // per block row offsets (n_blk+1), matched mode
+  std::vector<int> h_m_pairs;              // 2 * P
+  std::vector<char> triangulated;          // per image: already passed to TriangulateImage*
+  bool uploaded = false, ran = false, downloaded = false;
+  // neighbours_ of every triangulated image (ids), persists for the tail
+  std::vector<std::vector<int>> neighbors;  // image idx -> neighbour image indices (slot order)
+
+  // ---- device job tables ----
+  int n_blk = 0;
+  int max_nb = 1;
+  long long P = 0;        // connections (matched) / work items (exhaustive: n_items)
+  long long max_rows = 0; // matched: most rows of any (image, neighbour) block
+  long long n_conn = 0;   // connections tested (stat)
+  std::vector<long long> h_nb_off;  // n_img+1
+  std::vector<int> h_blk_img, h_blk_nb, h_blk_slot, h_blk_order;
+  std::vector<long long> h_item_off;  // exhaustive: per node first item (G+1)
+  DevBuf d_nb_off, d_blk_img, d_blk_nb, d_blk_slot, d_blk_order, d_m_off, d_m_pairs, d_pairs;
+  DevBuf d_keys, d_rows, d_row_blk, d_skeys, d_srows, d_sort_tmp, d_conn_off;
+  DevBuf d_st_c, d_st_l, d_flags, d_pos, d_scan_tmp;
+  DevBuf d_item_off, d_masks, d_mask_cnt, d_mask_pos;
+  DevBuf d_cand, d_lite, d_tri_off, d_score, d_best_idx, d_edge_flag, d_nvalid, d_edge_off, d_edges;
+  DevBuf d_best_c, d_best_score, d_best_src, d_ntris, d_err;
+  DevBuf d_blk_line_base, d_cnt_bl, d_st_key, d_wave_count, d_wave_pos, d_ntris_u, d_cand_node, d_pair_counter;
+  int max_nb_segs = 0;   // most segments of any neighbour image in the job (LDS table sizing)
+  long long stat_pairs_eval = 0;
+  std::vector<long long> h_blk_line_base;
+  bool rows_sorted = true;   // every (image, neighbour) block lists its rows in non-decreasing line id
+  long long *h_pinned = nullptr;  // pinned scratch for small device->host scalars
+  DevBuf d_chunks;
+  int n_chunks = 0;
+  long long cand_cap = 0;
+  long long C = 0, E = 0;  // candidates / valid edges of the last run
+
+  // ---- host results (all nodes) ----
+  std::vector<Cand> best_c;
+  std::vector<double> best_score;
+  std::vector<int> best_src2, n_tris;
+  std::vector<unsigned char> has_best;
+  std::vector<std::vector<int>> valid_edges;  // per node: flat (slot, ng_line) pairs
+  // ---- tail ----
+  std::vector<Track> tracks;
+  bool tracks_done = false;
+  long long stat_graph_nodes = 0, stat_graph_edges = 0, stat_pairs = 0;
+  double timers[16] = {0};
+  hipEvent_t ev[9] = {nullptr};
+};
+
+#define HIPCHK(ctx, call)                                                                  \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (ctx)->err = std::string("HIP error: ") + hipGetErrorString(e_) + " at " #call;      \
+      return LT_ERR_HIP;                                                                   \
+    }                                                                                      \
+  } while (0)
+
+#define ENSURE(ctx, buf, bytes)                                                 \
+  do {                                                                          \
+    if (!(buf).ensure(bytes)) {                                                 \
+      (ctx)->err = "hipMalloc failed for " #buf;                                \
+      return LT_ERR_HIP;                                                        \
+    }                                                                           \
+  } while (0)
+
+static inline int fail(lt_ctx *ctx, int code, const std::string &msg) {
+  ctx->err = msg;
+  return code;
+}

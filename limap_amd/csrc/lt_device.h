@@ -50,4 +50,8 @@ void launch_gather_best(hipStream_t st, long long G, const long long *best_idx, 
                         const long long *nb_off, const int *blk_nb, Cand *best_c, double *best_score,
                         int *best_src2, int *n_tris);
 
+void launch_track_connect(hipStream_t st, int T, const double *line7, const unsigned char *active, int all_active,
+                          const LinkCfg3 &cfg, double cos_guard, unsigned long long *edges,
+                          unsigned long long capacity, unsigned long long *n_edges);
+
 }  // namespace lt

@@ -438,4 +438,50 @@ LT_HD double score3d(const LinkCfg3 &c, const L3 &l1, const L3 &l2, double unc1,
   return score;
 }
 
+// LineLinker3d::check_connection, line_linker.cc:285-304 (boolean form used by RemergeLineTracks,
+// merging/merging.cc:523-556): angle <= th_angle directly, the other gates through their scores.
+LT_HD bool check3d(const LinkCfg3 &c, const L3 &l1, const L3 &l2, double unc1, double unc2,
+                   const double *dep1) {
+  double ang = 0.0;
+  bool have_ang = false;
+  if (c.use_angle) {  // :212-216
+    ang = angle_between(l1, l2);
+    have_ang = true;
+    if (!(ang <= c.th_angle)) return false;
+  }
+  double ov = 0.0;
+  bool have_ov = false;
+  if (c.use_overlap) {  // :232-235
+    ov = bioverlap(l1, l2);
+    have_ov = true;
+    if (!(ov > c.th_overlap)) return false;
+  }
+  if (c.use_angle && c.use_overlap && c.use_smartangle) {  // :218-221
+    if (!have_ang) ang = angle_between(l1, l2);
+    if (!have_ov) ov = bioverlap(l1, l2);
+    double th = c.th_angle;
+    if (ov < c.th_smartoverlap) {
+      double ratio = (c.th_smartoverlap - ov) / (c.th_smartoverlap - c.th_overlap);
+      ratio = dmin(ratio, 1.0);
+      th = c.th_angle - ratio * (c.th_angle - c.th_smartangle);
+    }
+    if (!(gate(expscore(ang, th * c.mult), c.score_th) >= c.score_th)) return false;
+  }
+  if (c.use_perp) {  // :248-251
+    double u = dmin(unc1, unc2);
+    if (!(gate(expscore(perp_dist(l1, l2), c.th_perp * u * c.mult), c.score_th) >= c.score_th)) return false;
+  }
+  if (c.use_innerseg) {  // :264-267
+    double u = dmin(unc1, unc2);
+    if (!(gate(expscore(innerseg_dist(l1, l2), c.th_innerseg * u * c.mult), c.score_th) >= c.score_th)) return false;
+  }
+  if (c.use_scaleinv) {  // :279-282
+    double ds = sqrt(sqn(sub(l1.s, l2.s)));
+    double de = sqrt(sqn(sub(l1.e, l2.e)));
+    double d = dmax(ds / (dep1[0] + kEps), de / (dep1[1] + kEps));
+    if (!(gate(expscore(d, c.th_scaleinv * c.mult), c.score_th) >= c.score_th)) return false;
+  }
+  return true;
+}
+
 }  // namespace lt

@@ -399,6 +399,62 @@ void launch_gather_best(hipStream_t st, long long G, const long long *best_idx, 
 
 
 // ---------------------------------------------------------------------------------------------
+// RemergeLineTracks (merging/merging.cc:523-556): all-pairs LineLinker3d::check_connection between
+// the track lines.  lane = track i (active only), wave-uniform sweep over a chunk of tracks j;
+// conservative cosine early exit (angle <= th_angle can only hold if |cos| >= cos(th (1+1e-6))),
+// exact check for the rest; edges (min << 32 | max) appended through a device counter.
+// When every track is active the reference tests each unordered pair once, from the side given by
+// the parity of i + j (:535-540); that orientation is kept because l1/l2 are not interchangeable
+// bit for bit.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_track_connect(int T, const double *__restrict__ line7, const unsigned char *__restrict__ active, int all_active,
+                LinkCfg3 cfg, double cos_guard, unsigned long long *__restrict__ edges,
+                unsigned long long capacity, unsigned long long *__restrict__ n_edges) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j0 = blockIdx.y * 256;
+  const int j1 = min(T, j0 + 256);
+  const bool live = (i < T) && active[i];
+  L3 li{mk3(0, 0, 0), mk3(0, 0, 0)};
+  d3 di = mk3(0, 0, 0);
+  double ui = 0.0;
+  if (live) {
+    const double *p = line7 + 7 * (long long)i;
+    li.s = mk3(p[0], p[1], p[2]);
+    li.e = mk3(p[3], p[4], p[5]);
+    ui = p[6];
+    di = dir(li);
+  }
+  const double dep[2] = {0.0, 0.0};
+  for (int j = j0; j < j1; ++j) {
+    bool test = live && (j != i);
+    if (test && all_active) {
+      if (i < j && ((i + j) & 1) == 0) test = false;
+      if (i > j && ((i + j) & 1) == 1) test = false;
+    }
+    if (!test) continue;
+    const double *q = line7 + 7 * (long long)j;
+    L3 lj{mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5])};
+    if (cfg.use_angle) {
+      double c = fabs(dot(di, dir(lj)));
+      if (c < cos_guard) continue;
+    }
+    if (!check3d(cfg, li, lj, ui, q[6], dep)) continue;
+    unsigned long long slot = atomicAdd(n_edges, 1ull);
+    unsigned long long a = (unsigned long long)min(i, j), b = (unsigned long long)max(i, j);
+    if (slot < capacity) edges[slot] = (a << 32) | b;
+  }
+}
+
+void launch_track_connect(hipStream_t st, int T, const double *line7, const unsigned char *active, int all_active,
+                          const LinkCfg3 &cfg, double cos_guard, unsigned long long *edges,
+                          unsigned long long capacity, unsigned long long *n_edges) {
+  if (T <= 0) return;
+  hipLaunchKernelGGL(k_track_connect, dim3(nblk(T, 256), nblk(T, 256)), dim3(256), 0, st, T, line7, active,
+                     all_active, cfg, cos_guard, edges, capacity, n_edges);
+}
+
+// ---------------------------------------------------------------------------------------------
 // free-function queries (limap.triangulation.get_normal_direction / compute_fundamental_matrix /
 // compute_epipolar_IoU / triangulate_line[_by_endpoints], bindings.cc:22-31): one thread.
 // in30 = seg1[4] cam1[11] seg2[4] cam2[11]; out32 = n(seg1)[3] F[9] IoU line10[10]

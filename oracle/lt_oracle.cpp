@@ -449,6 +449,21 @@ struct Linker3d {
     if (s < config.score_th) s = 0.0;
     return s;
   }
+  bool check_connection(const Line3d &l1, const Line3d &l2) const {  // line_linker.cc:285-304
+    if (config.use_angle)  // check_connection_angle, :212-216: plain angle <= th_angle
+      if (!(compute_angle(l1, l2) <= config.th_angle)) return false;
+    if (config.use_overlap)  // :232-235
+      if (!(score_overlap(l1, l2) == 1.0)) return false;
+    if (config.use_angle && config.use_overlap && config.use_smartangle)  // :218-221
+      if (!(score_smartangle(l1, l2) >= config.score_th)) return false;
+    if (config.use_perp)  // :248-251
+      if (!(score_perp(l1, l2) >= config.score_th)) return false;
+    if (config.use_innerseg)  // :264-267
+      if (!(score_innerseg(l1, l2) >= config.score_th)) return false;
+    if (config.use_scaleinv)  // :279-282
+      if (!(score_scaleinv(l1, l2) >= config.score_th)) return false;
+    return true;
+  }
   double compute_score(const Line3d &l1, const Line3d &l2) const {  // line_linker.cc:306-331
     double score = 1.0;
     if (config.use_angle) score = std::min(score, score_angle(l1, l2));
@@ -792,7 +807,166 @@ struct LineTrack {  // base/linetrack.h:21-50 (fields the path fills)
   std::vector<Line2d> line2d_list;
   std::vector<Line3d> line3d_list;
   std::vector<double> score_list;
+  bool active = true;
+  size_t count_lines() const { return line2d_list.size(); }
 };
+
+// ---------------------------------------------------------------------------------------------
+// merging/merging_utils.cc:27-155, merging/merging.cc:513-644 -- the steps that follow
+// ComputeLineTracks in runners/line_triangulation.py:171-200
+// ---------------------------------------------------------------------------------------------
+template <class L>
+static double dist_endpoints_perpendicular_oneway(const L &l1, const L &l2) {  // line_dists.h:113-120
+  auto d = dists_endpoints_perpendicular_oneway(l1, l2);
+  return std::max(d.first, d.second);
+}
+
+static void CheckReprojection(std::vector<bool> &results, const LineTrack &tr,
+                              const std::map<int, CameraView> &views, double th_angular2d,
+                              double th_perp2d) {  // merging_utils.cc:27-49
+  results.clear();
+  for (size_t i = 0; i < tr.count_lines(); ++i) {
+    const Line2d &line2d = tr.line2d_list[i];
+    Line2d proj = tr.line.projection(views.at(tr.image_id_list[i]));
+    double angle = compute_angle(line2d, proj);
+    if (angle > th_angular2d) {
+      results.push_back(false);
+      continue;
+    }
+    double d = dist_endpoints_perpendicular_oneway(line2d, proj);
+    if (d > th_perp2d) {
+      results.push_back(false);
+      continue;
+    }
+    results.push_back(true);
+  }
+}
+
+static std::vector<LineTrack> FilterSupportingLines(const std::vector<LineTrack> &tracks,
+                                                    const std::map<int, CameraView> &views,
+                                                    double th_angular2d, double th_perp2d,
+                                                    int num_outliers) {  // merging_utils.cc:51-83
+  std::vector<LineTrack> out;
+  for (const auto &tr : tracks) {
+    std::vector<bool> res;
+    CheckReprojection(res, tr, views, th_angular2d, th_perp2d);
+    LineTrack nt;
+    for (size_t k = 0; k < tr.count_lines(); ++k) {
+      if (!res[k]) continue;
+      nt.node_id_list.push_back(tr.node_id_list[k]);
+      nt.image_id_list.push_back(tr.image_id_list[k]);
+      nt.line_id_list.push_back(tr.line_id_list[k]);
+      nt.line2d_list.push_back(tr.line2d_list[k]);
+      nt.line3d_list.push_back(tr.line3d_list[k]);
+      nt.score_list.push_back(tr.score_list[k]);
+    }
+    if (nt.count_lines() == 0) continue;
+    nt.line = aggregate_line3d_list(nt.line3d_list, nt.score_list, num_outliers);
+    out.push_back(nt);
+  }
+  return out;
+}
+
+static std::vector<LineTrack> FilterTracksBySensitivity(const std::vector<LineTrack> &tracks,
+                                                        const std::map<int, CameraView> &views,
+                                                        double th_angular3d,
+                                                        int min_support_ns) {  // merging_utils.cc:85-128
+  std::vector<LineTrack> out;
+  for (const auto &tr : tracks) {
+    std::set<int> support_images;
+    for (size_t i = 0; i < tr.count_lines(); ++i) {
+      double sens = tr.line.sensitivity(views.at(tr.image_id_list[i]));
+      if (!(sens > th_angular3d)) support_images.insert(tr.image_id_list[i]);
+    }
+    if (int(support_images.size()) >= min_support_ns) out.push_back(tr);
+  }
+  return out;
+}
+
+static std::vector<LineTrack> FilterTracksByOverlap(const std::vector<LineTrack> &tracks,
+                                                    const std::map<int, CameraView> &views,
+                                                    double th_overlap,
+                                                    int min_support_ns) {  // merging_utils.cc:130-155
+  std::vector<LineTrack> out;
+  for (const auto &tr : tracks) {
+    std::set<int> support_images;
+    for (size_t i = 0; i < tr.count_lines(); ++i) {
+      Line2d proj = tr.line.projection(views.at(tr.image_id_list[i]));
+      double overlap = compute_overlap(proj, tr.line2d_list[i]);
+      if (overlap >= th_overlap) support_images.insert(tr.image_id_list[i]);
+    }
+    if (int(support_images.size()) >= min_support_ns) out.push_back(tr);
+  }
+  return out;
+}
+
+static std::vector<LineTrack> RemergeLineTracks(const std::vector<LineTrack> &tracks, Linker3d linker3d,
+                                                int num_outliers) {  // merging/merging.cc:513-644
+  linker3d.config.set_to_spatial_merging();
+  const size_t n_tracks = tracks.size();
+  std::set<std::pair<size_t, size_t>> edges;
+  std::vector<std::set<std::pair<size_t, size_t>>> edges_per_track(n_tracks);
+  std::vector<int> active_ids;
+  for (size_t i = 0; i < n_tracks; ++i)
+    if (tracks[i].active) active_ids.push_back(int(i));
+  const size_t n_active = active_ids.size();
+#pragma omp parallel for
+  for (size_t k = 0; k < n_active; ++k) {
+    size_t i = size_t(active_ids[k]);
+    const Line3d &l1 = tracks[i].line;
+    for (size_t j = 0; j < n_tracks; ++j) {
+      if (i == j) continue;
+      if (n_active == n_tracks) {
+        if (i < j && (i + j) % 2 == 0) continue;
+        if (i > j && (i + j) % 2 == 1) continue;
+      }
+      if (!linker3d.check_connection(l1, tracks[j].line)) continue;
+      if (i < j) edges_per_track[i].insert({i, j});
+      else edges_per_track[i].insert({j, i});
+    }
+  }
+  for (size_t i = 0; i < n_tracks; ++i) edges.insert(edges_per_track[i].begin(), edges_per_track[i].end());
+  std::vector<int> parent(n_tracks, -1);
+  std::vector<size_t> group_size(n_tracks, 1);  // |tracks_in_group|
+  for (const auto &e : edges) {
+    size_t r1 = size_t(union_find_get_root(int(e.first), parent));
+    size_t r2 = size_t(union_find_get_root(int(e.second), parent));
+    if (r1 == r2) continue;
+    if (group_size[r1] < group_size[r2]) {
+      parent[r1] = int(r2);
+      group_size[r2] += group_size[r1];
+      group_size[r1] = 0;
+    } else {
+      parent[r2] = int(r1);
+      group_size[r1] += group_size[r2];
+      group_size[r2] = 0;
+    }
+  }
+  std::vector<long> labels(n_tracks, -1);
+  size_t n_groups = 0;
+  for (size_t t = 0; t < n_tracks; ++t)
+    if (parent[t] == -1) labels[t] = long(n_groups++);
+  for (size_t t = 0; t < n_tracks; ++t)
+    if (labels[t] == -1) labels[t] = labels[size_t(union_find_get_root(int(t), parent))];
+  std::vector<LineTrack> out(n_groups);
+  std::vector<int> counter(n_groups, 0);
+  for (size_t t = 0; t < n_tracks; ++t) {
+    const LineTrack &tr = tracks[t];
+    LineTrack &g = out[size_t(labels[t])];
+    counter[size_t(labels[t])]++;
+    g.node_id_list.insert(g.node_id_list.end(), tr.node_id_list.begin(), tr.node_id_list.end());
+    g.image_id_list.insert(g.image_id_list.end(), tr.image_id_list.begin(), tr.image_id_list.end());
+    g.line_id_list.insert(g.line_id_list.end(), tr.line_id_list.begin(), tr.line_id_list.end());
+    g.line2d_list.insert(g.line2d_list.end(), tr.line2d_list.begin(), tr.line2d_list.end());
+    g.line3d_list.insert(g.line3d_list.end(), tr.line3d_list.begin(), tr.line3d_list.end());
+    g.score_list.insert(g.score_list.end(), tr.score_list.begin(), tr.score_list.end());
+  }
+  for (size_t gidx = 0; gidx < n_groups; ++gidx) {
+    out[gidx].line = aggregate_line3d_list(out[gidx].line3d_list, out[gidx].score_list, num_outliers);
+    if (counter[gidx] == 1) out[gidx].active = false;
+  }
+  return out;
+}
 
 // ---------------------------------------------------------------------------------------------
 // triangulation/base_line_triangulator.{h,cc} + global_line_triangulator.{h,cc}
@@ -1491,6 +1665,64 @@ int ora_get_timers(ora_ctx *ctx, double out[4]) {
   out[2] = ctx->t.t_tail;
   out[3] = 0;
   return 0;
+}
+
+// ---- track sets: post-triangulation filters and remerge on flat arrays ----
+struct ora_trackset {
+  std::vector<ora::LineTrack> tracks;
+};
+
+ora_trackset *ora_ts_from_ctx(ora_ctx *ctx) {
+  auto *ts = new ora_trackset();
+  ts->tracks = ctx->t.tracks_;
+  return ts;
+}
+void ora_ts_destroy(ora_trackset *ts) { delete ts; }
+int64_t ora_ts_num_tracks(ora_trackset *ts) { return int64_t(ts->tracks.size()); }
+int64_t ora_ts_num_members(ora_trackset *ts) {
+  int64_t n = 0;
+  for (auto &t : ts->tracks) n += int64_t(t.count_lines());
+  return n;
+}
+int ora_ts_get(ora_trackset *ts, double *line7, uint8_t *active, int64_t *off, int32_t *img, int32_t *lid,
+               int32_t *nid, double *score, double *line2d4, double *line3d10) {
+  int64_t e = 0, ti = 0;
+  off[0] = 0;
+  for (auto &tr : ts->tracks) {
+    double *o = line7 + 7 * ti;
+    o[0] = tr.line.start.x; o[1] = tr.line.start.y; o[2] = tr.line.start.z;
+    o[3] = tr.line.end.x;   o[4] = tr.line.end.y;   o[5] = tr.line.end.z;
+    o[6] = tr.line.uncertainty;
+    active[ti] = tr.active ? 1 : 0;
+    for (size_t k = 0; k < tr.count_lines(); ++k, ++e) {
+      img[e] = tr.image_id_list[k]; lid[e] = tr.line_id_list[k]; nid[e] = tr.node_id_list[k];
+      score[e] = tr.score_list[k];
+      line2d4[4 * e] = tr.line2d_list[k].start.x; line2d4[4 * e + 1] = tr.line2d_list[k].start.y;
+      line2d4[4 * e + 2] = tr.line2d_list[k].end.x; line2d4[4 * e + 3] = tr.line2d_list[k].end.y;
+      ora::line_to10(tr.line3d_list[k], line3d10 + 10 * e);
+    }
+    off[++ti] = e;
+  }
+  return 0;
+}
+int ora_ts_filter_by_reprojection(ora_ctx *ctx, ora_trackset *ts, double th_angular2d, double th_perp2d,
+                                  int num_outliers) {
+  ORA_TRY(ctx, { ts->tracks = ora::FilterSupportingLines(ts->tracks, ctx->t.views, th_angular2d, th_perp2d, num_outliers); })
+}
+int ora_ts_filter_by_sensitivity(ora_ctx *ctx, ora_trackset *ts, double th_angular3d, int min_supports) {
+  ORA_TRY(ctx, { ts->tracks = ora::FilterTracksBySensitivity(ts->tracks, ctx->t.views, th_angular3d, min_supports); })
+}
+int ora_ts_filter_by_overlap(ora_ctx *ctx, ora_trackset *ts, double th_overlap, int min_supports) {
+  ORA_TRY(ctx, { ts->tracks = ora::FilterTracksByOverlap(ts->tracks, ctx->t.views, th_overlap, min_supports); })
+}
+/* one pass of RemergeLineTracks; the linker is taken from cfg's l3_* fields */
+int ora_ts_remerge_once(ora_ctx *ctx, ora_trackset *ts, const ora_config *linker_cfg, int num_outliers) {
+  ORA_TRY(ctx, {
+    ora::Linker2d l2;
+    ora::Linker3d l3;
+    ora::set_linkers(*linker_cfg, l2, l3);
+    ts->tracks = ora::RemergeLineTracks(ts->tracks, l3, num_outliers);
+  })
 }
 
 // ---- free functions ----

@@ -115,6 +115,22 @@ int ora_get_stats(ora_ctx *ctx, int64_t out[8]);
 /* wall-clock split of the last run in seconds: [0] generation, [1] scoring, [2] tail */
 int ora_get_timers(ora_ctx *ctx, double out[4]);
 
+/* ---- post-triangulation filters + remerge (merging/merging_utils.cc:27-155,
+ * merging/merging.cc:513-644; called from runners/line_triangulation.py:171-200) on a copy of the
+ * context's tracks.  Cameras are the ones given to ora_init. ---- */
+typedef struct ora_trackset ora_trackset;
+ora_trackset *ora_ts_from_ctx(ora_ctx *ctx);
+void ora_ts_destroy(ora_trackset *ts);
+int64_t ora_ts_num_tracks(ora_trackset *ts);
+int64_t ora_ts_num_members(ora_trackset *ts);
+int ora_ts_get(ora_trackset *ts, double *line7, uint8_t *active, int64_t *off, int32_t *img, int32_t *lid,
+               int32_t *nid, double *score, double *line2d4, double *line3d10);
+int ora_ts_filter_by_reprojection(ora_ctx *ctx, ora_trackset *ts, double th_angular2d, double th_perp2d,
+                                  int num_outliers);
+int ora_ts_filter_by_sensitivity(ora_ctx *ctx, ora_trackset *ts, double th_angular3d, int min_supports);
+int ora_ts_filter_by_overlap(ora_ctx *ctx, ora_trackset *ts, double th_overlap, int min_supports);
+int ora_ts_remerge_once(ora_ctx *ctx, ora_trackset *ts, const ora_config *linker_cfg, int num_outliers);
+
 /* ---- free functions (mirror triangulation/bindings.cc:22-31) on raw arrays ----
  * cam = kvec[4] | qvec[4] | tvec[3]  (11 doubles), seg = x1,y1,x2,y2 */
 void ora_get_normal_direction(const double seg[4], const double cam[11], double out[3]);

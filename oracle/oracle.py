@@ -365,3 +365,61 @@ def aggregate_line3d_list(lines10, scores, num_outliers=2):
     out = np.zeros(7)
     lib().ora_aggregate_line3d_list(len(scores), _d(lines10), _d(scores), int(num_outliers), _d(out))
     return out
+
+
+class OracleTrackSet:
+    """Copy of an OracleTriangulator's tracks for the post-triangulation steps
+    (limap.merging.filter_tracks_by_reprojection / remerge / filter_tracks_by_sensitivity /
+    filter_tracks_by_overlap; runners/line_triangulation.py:171-200)."""
+
+    def __init__(self, tri):
+        self.L = lib()
+        self.tri = tri
+        self.L.ora_ts_from_ctx.restype = C.c_void_p
+        self.L.ora_ts_num_tracks.restype = C.c_int64
+        self.L.ora_ts_num_members.restype = C.c_int64
+        self.L.ora_ts_filter_by_reprojection.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int]
+        self.L.ora_ts_filter_by_sensitivity.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int]
+        self.L.ora_ts_filter_by_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int]
+        self.L.ora_ts_remerge_once.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OraConfig), C.c_int]
+        self.h = C.c_void_p(self.L.ora_ts_from_ctx(tri.ctx))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ora_ts_destroy(self.h)
+            self.h = None
+
+    def num_tracks(self):
+        return int(self.L.ora_ts_num_tracks(self.h))
+
+    def filter_by_reprojection(self, th_angular2d, th_perp2d, num_outliers=2):
+        self.tri._chk(self.L.ora_ts_filter_by_reprojection(self.tri.ctx, self.h, th_angular2d, th_perp2d, num_outliers))
+
+    def filter_by_sensitivity(self, th_angular3d, min_supports):
+        self.tri._chk(self.L.ora_ts_filter_by_sensitivity(self.tri.ctx, self.h, th_angular3d, min_supports))
+
+    def filter_by_overlap(self, th_overlap, min_supports):
+        self.tri._chk(self.L.ora_ts_filter_by_overlap(self.tri.ctx, self.h, th_overlap, min_supports))
+
+    def remerge(self, linker3d_dict, num_outliers=2):
+        """merging.remerge (merging/merging.py:24-42): repeat until the track count stops changing."""
+        cfg = config_from_dict({"linker3d_config": dict(linker3d_dict)})
+        if self.num_tracks() == 0:
+            return
+        n = self.num_tracks()
+        while True:
+            self.tri._chk(self.L.ora_ts_remerge_once(self.tri.ctx, self.h, C.byref(cfg), num_outliers))
+            n_new = self.num_tracks()
+            if n_new == n:
+                break
+            n = n_new
+
+    def get(self):
+        T = self.num_tracks(); M = int(self.L.ora_ts_num_members(self.h))
+        line = np.zeros((max(T, 1), 7)); active = np.zeros(max(T, 1), np.uint8); off = np.zeros(T + 1, np.int64)
+        img = np.zeros(max(M, 1), np.int32); lid = np.zeros(max(M, 1), np.int32); nid = np.zeros(max(M, 1), np.int32)
+        sc = np.zeros(max(M, 1)); l2 = np.zeros((max(M, 1), 4)); l3 = np.zeros((max(M, 1), 10))
+        self.L.ora_ts_get(self.h, _p(line, C.c_double), _p(active, C.c_uint8), _p(off, C.c_int64), _p(img, C.c_int32),
+                          _p(lid, C.c_int32), _p(nid, C.c_int32), _p(sc, C.c_double), _p(l2, C.c_double), _p(l3, C.c_double))
+        return dict(line=line[:T], active=active[:T], off=off, image_ids=img[:M], line_ids=lid[:M], node_ids=nid[:M],
+                    scores=sc[:M], line2d=l2[:M], line3d=l3[:M])
