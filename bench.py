@@ -32,6 +32,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# cfgs/triangulation/default.yaml:102-110 (remerging.linker3d)
+REMERGE_LINKER = dict(score_th=0.5, th_angle=5.0, th_overlap=0.001, th_smartoverlap=0.1, th_smartangle=1.0,
+                      th_perp=1.0, th_innerseg=1.0)
 
 
 def algorithmic_bytes(stats, n_img_active, nn):
@@ -228,9 +231,20 @@ def main():
             T.context().compute_tracks()
             e2e.append(time.perf_counter() - t0)
             tm = T.timers()
+            if rep == 2:  # the steps that follow in line_triangulation(): filters + remerge (cfg defaults)
+                from limap_amd import merging
+                tp0 = time.perf_counter()
+                ts = merging.TrackSet.from_triangulator(T)
+                ts.filter_by_reprojection(8.0, 5.0).remerge(REMERGE_LINKER).filter_by_reprojection(8.0, 5.0)
+                ts.filter_by_sensitivity(75.0, 3).filter_by_overlap(0.5, 3)
+                post_ms, post_tracks = 1e3 * (time.perf_counter() - tp0), len(ts)
+                del ts
             del T
         out["e2e_wall_ms"] = 1e3 * float(np.median(e2e))
         out["e2e_breakdown_ms"] = {k: tm[k] for k in ("upload", "run", "download", "tail")}
+        out["postprocess"] = {"ms": post_ms, "tracks_after": post_tracks,
+                              "steps": "filter_by_reprojection, remerge (to fixed point), filter_by_reprojection, "
+                                       "filter_by_sensitivity, filter_by_overlap (cfgs/triangulation/default.yaml:102-115)"}
 
         if not args.no_cpu_baseline:
             from oracle import oracle as ora
@@ -251,12 +265,18 @@ def main():
             O.ComputeLineTracks()
             cpu_s = time.perf_counter() - t0
             so = O.stats()
+            tp0 = time.perf_counter()
+            ots = ora.OracleTrackSet(O)
+            ots.filter_by_reprojection(8.0, 5.0); ots.remerge(REMERGE_LINKER); ots.filter_by_reprojection(8.0, 5.0)
+            ots.filter_by_sensitivity(75.0, 3); ots.filter_by_overlap(0.5, 3)
+            cpu_post_s, cpu_post_tracks = time.perf_counter() - tp0, ots.num_tracks()
             out["cpu_baseline"] = {
                 "value": so["candidates"] / cpu_s, "unit": "candidates/s", "cores": nthreads, "kind": "port",
                 "sample": f"oracle (reference-faithful mode, g++ -O2 -fopenmp, {nthreads} OpenMP threads): "
                           f"Init + TriangulateImage on {n_s} of {len(scene.img_ids)} images + ComputeLineTracks, "
                           f"{so['connections']} connections, {so['candidates']} candidates",
                 "wall_s": cpu_s, "timers_s": O.timers(),
+                "postprocess_s": cpu_post_s, "postprocess_tracks_after": cpu_post_tracks,
             }
             if n_s == len(scene.img_ids):
                 out["e2e_speedup_vs_cpu"] = cpu_s / (out["e2e_wall_ms"] * 1e-3)
