@@ -112,6 +112,10 @@ int lt_refresh_scene_chunks(lt_ctx *ctx);
  * (observable behaviour is unchanged: results are only readable through those). */
 int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids,
                          const int64_t *m_off, const int32_t *m_pairs);
+/* Same, with the (K,2) int32 row array of every neighbour given by its own pointer -- the natural
+ * form of the std::map<int, Eigen::MatrixXi> argument; saves the caller a concatenation. */
+int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids,
+                              const int32_t *const *rows, const int64_t *n_rows);
 /* TriangulateImageExhaustiveMatch(img_id, neighbors) -- base_line_triangulator.cc:111-136 */
 int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids);
 

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "liblimap_amd.so")
 EXPORTED_SYMBOLS = [
     "lt_config_default", "lt_abi_version", "lt_sizeof_config", "lt_create", "lt_destroy", "lt_last_error", "lt_set_stream", "lt_set_ranges",
     "lt_unset_ranges", "lt_init", "lt_init_device", "lt_refresh_scene_device", "lt_set_scene_chunks",
-    "lt_refresh_scene_chunks", "lt_triangulate_image",
+    "lt_refresh_scene_chunks", "lt_triangulate_image", "lt_triangulate_image_rows",
     "lt_triangulate_image_exhaustive", "lt_upload", "lt_run_device", "lt_download", "lt_flush",
     "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
     "lt_get_num_tris", "lt_num_valid_edges", "lt_get_valid_edges", "lt_num_all_tris", "lt_get_all_tris",
@@ -99,6 +99,7 @@ def load_library():
     L.lt_set_scene_chunks.argtypes = [vp, C.c_int, i32p, vpp, vpp, vpp, vpp]
     L.lt_refresh_scene_chunks.argtypes = [vp]
     L.lt_triangulate_image.argtypes = [vp, C.c_int, C.c_int, i32p, i64p, i32p]
+    L.lt_triangulate_image_rows.argtypes = [vp, C.c_int, C.c_int, i32p, C.POINTER(C.c_void_p), i64p]
     L.lt_triangulate_image_exhaustive.argtypes = [vp, C.c_int, C.c_int, i32p]
     for n in ("lt_upload", "lt_run_device", "lt_download", "lt_flush", "lt_compute_tracks"):
         getattr(L, n).argtypes = [vp]
@@ -250,6 +251,14 @@ class Context:
         nb_ids, m_off, m_pairs = i32(nb_ids), i64(m_off), i32(m_pairs)
         self.chk(self.L.lt_triangulate_image(self.h, int(img_id), len(nb_ids), ptr(nb_ids, C.c_int32),
                                              ptr(m_off, C.c_int64), ptr(m_pairs, C.c_int32)))
+
+    def triangulate_image_rows(self, img_id, nb_ids, arrays):
+        """arrays[k]: C-contiguous int32 (K,2) rows of neighbour nb_ids[k] (kept alive for the call)."""
+        n = len(arrays)
+        nb = i32(nb_ids)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrays])
+        cnt = np.fromiter((a.shape[0] for a in arrays), np.int64, n) if n else np.zeros(1, np.int64)
+        self.chk(self.L.lt_triangulate_image_rows(self.h, int(img_id), n, ptr(nb, C.c_int32), ptrs, ptr(cnt, C.c_int64)))
 
     def triangulate_image_exhaustive(self, img_id, nb_ids):
         nb_ids = i32(nb_ids)

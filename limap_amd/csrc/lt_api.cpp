@@ -475,8 +475,11 @@ static int begin_image(lt_ctx *ctx, int img_id, int mode, int *idx_out) {
   return LT_OK;
 }
 
-int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids, const int64_t *m_off,
-                         const int32_t *m_pairs) {
+// TriangulateImage with the rows of every neighbour given by its own pointer (no concatenation on the
+// caller's side).  Validation (base_line_triangulator.cc:79,87-94), the sortedness probe for the
+// sort-free placement and the single copy into the staging buffer run in one parallel pass.
+int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids,
+                              const int32_t *const *rows, const int64_t *n_rows) {
   int idx;
   int rc = begin_image(ctx, img_id, 1, &idx);
   if (rc) return rc;
@@ -486,53 +489,76 @@ int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_id
   std::vector<int> order(n_nb);
   for (int k = 0; k < n_nb; ++k) order[k] = k;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nb_ids[a] < nb_ids[b]; });
-  std::vector<int> nbs, ord;
+  std::vector<int> nbs(n_nb), ord(n_nb);
+  std::vector<long long> M2(n_nb), dst(n_nb + 1, 0);
   const long long M1 = ctx->seg_off[idx + 1] - ctx->seg_off[idx];
-  size_t m_off_mark = ctx->h_m_off.size();
-  size_t pairs_mark = ctx->h_m_pairs.size();
   for (int k = 0; k < n_nb; ++k) {
     int o = order[k];
-    if (k > 0 && nb_ids[o] == nb_ids[order[k - 1]]) {
-      ctx->h_m_off.resize(m_off_mark); ctx->h_m_pairs.resize(pairs_mark);
-      return fail(ctx, LT_ERR_ARGUMENT, "duplicate neighbour id in matches");
-    }
+    if (k > 0 && nb_ids[o] == nb_ids[order[k - 1]]) return fail(ctx, LT_ERR_ARGUMENT, "duplicate neighbour id in matches");
     auto it = ctx->id2idx.find(nb_ids[o]);
-    if (it == ctx->id2idx.end()) {
-      ctx->h_m_off.resize(m_off_mark); ctx->h_m_pairs.resize(pairs_mark);
-      return fail(ctx, LT_ERR_ARGUMENT, "unknown neighbour image id " + std::to_string(nb_ids[o]));
-    }
-    const long long M2 = ctx->seg_off[it->second + 1] - ctx->seg_off[it->second];
-    long long r0 = m_off[o], r1 = m_off[o + 1];
-    int prev_line = -1;
-    for (long long r = r0; r < r1; ++r) {
-      int line = m_pairs[2 * r], ng = m_pairs[2 * r + 1];
-      if (line < prev_line) ctx->rows_sorted = false;
-      prev_line = line;
-      if (line < 0 || line >= M1) {  // base_line_triangulator.cc:87-94
-        ctx->h_m_off.resize(m_off_mark); ctx->h_m_pairs.resize(pairs_mark);
-        return fail(ctx, LT_ERR_RUNTIME,
-                    "IndexError! Out-of-index matches exist between image (img_id = " + std::to_string(img_id) +
-                        ") and neighbor image (img_id = " + std::to_string(nb_ids[o]) +
-                        "). Please make sure you are reusing the correct descriptors and matches when using the "
-                        "--skip_exists option.");
-      }
-      if (ng < 0 || ng >= M2) {
-        ctx->h_m_off.resize(m_off_mark); ctx->h_m_pairs.resize(pairs_mark);
-        return fail(ctx, LT_ERR_RUNTIME, "IndexError! neighbour line id out of range in matches of image " +
-                                             std::to_string(img_id));
-      }
-    }
-    ctx->h_m_pairs.insert(ctx->h_m_pairs.end(), m_pairs + 2 * r0, m_pairs + 2 * r1);
-    ctx->h_m_off.push_back(ctx->h_m_off.back() + (r1 - r0));
-    nbs.push_back(it->second);
-    ord.push_back(k);  // already ascending id
+    if (it == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "unknown neighbour image id " + std::to_string(nb_ids[o]));
+    if (n_rows[o] < 0) return fail(ctx, LT_ERR_ARGUMENT, "negative row count");
+    nbs[k] = it->second;
+    ord[k] = k;  // already ascending id
+    M2[k] = ctx->seg_off[it->second + 1] - ctx->seg_off[it->second];
+    dst[k + 1] = dst[k] + n_rows[o];
   }
+  const size_t base = ctx->h_m_pairs.size();
+  if (ctx->job_imgs.empty() && dst[n_nb] > 0)  // first image of a batch: one allocation for the usual case
+    ctx->h_m_pairs.reserve(2 * (size_t)dst[n_nb] * (size_t)std::max(1, ctx->n_img) + 1024);
+  if (!ctx->h_m_pairs.grow_to(base + 2 * (size_t)dst[n_nb])) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the match rows");
+  int *out = ctx->h_m_pairs.data() + base;
+  std::vector<int> bad(n_nb, 0);
+  int unsorted = 0;
+#pragma omp parallel for num_threads(std::min(lt::host_threads(), 8)) schedule(dynamic, 1) reduction(| : unsorted)
+  for (int k = 0; k < n_nb; ++k) {
+    const int32_t *src = rows[order[k]];
+    const long long n = n_rows[order[k]];
+    int *o = out + 2 * dst[k];
+    int prev_line = -1, err = 0, uns = 0;
+    const long long m2 = M2[k];
+    for (long long r = 0; r < n; ++r) {
+      const int line = src[2 * r], ng = src[2 * r + 1];
+      uns |= line < prev_line;
+      prev_line = line;
+      if ((unsigned)line >= (unsigned long long)M1) err |= 1;
+      if ((unsigned)ng >= (unsigned long long)m2) err |= 2;
+      o[2 * r] = line;
+      o[2 * r + 1] = ng;
+    }
+    bad[k] = err;
+    unsorted |= uns;
+  }
+  for (int k = 0; k < n_nb; ++k) {
+    if (!bad[k]) continue;
+    ctx->h_m_pairs.grow_to(base);
+    if (bad[k] & 1)  // base_line_triangulator.cc:87-94
+      return fail(ctx, LT_ERR_RUNTIME,
+                  "IndexError! Out-of-index matches exist between image (img_id = " + std::to_string(img_id) +
+                      ") and neighbor image (img_id = " + std::to_string(nb_ids[order[k]]) +
+                      "). Please make sure you are reusing the correct descriptors and matches when using the "
+                      "--skip_exists option.");
+    return fail(ctx, LT_ERR_RUNTIME, "IndexError! neighbour line id out of range in matches of image " + std::to_string(img_id));
+  }
+  if (unsorted) ctx->rows_sorted = false;
+  for (int k = 0; k < n_nb; ++k) ctx->h_m_off.push_back(ctx->h_m_off.back() + n_rows[order[k]]);
   ctx->job_imgs.push_back(idx);
   ctx->job_nbs.push_back(nbs);
   ctx->job_order.push_back(ord);
   ctx->neighbors[idx] = nbs;
   ctx->triangulated[idx] = 1;
   return LT_OK;
+}
+
+int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids, const int64_t *m_off,
+                         const int32_t *m_pairs) {
+  std::vector<const int32_t *> rows(std::max(n_nb, 1));
+  std::vector<int64_t> n_rows(std::max(n_nb, 1));
+  for (int k = 0; k < n_nb; ++k) {
+    rows[k] = m_pairs + 2 * m_off[k];
+    n_rows[k] = m_off[k + 1] - m_off[k];
+  }
+  return lt_triangulate_image_rows(ctx, img_id, n_nb, nb_ids, rows.data(), n_rows.data());
 }
 
 int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids) {
@@ -987,7 +1013,7 @@ int lt_compute_tracks(lt_ctx *ctx) {
   l3.use_angle = 1; l3.use_overlap = 1; l3.use_perp = 0; l3.use_innerseg = 1; l3.use_scaleinv = 0;  // line_linker.h:123-129
   std::vector<double> sims(edges.size());
   const long long nE = (long long)edges.size();
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(static)
   for (long long e = 0; e < nE; ++e) {
     long long a = (long long)(edges[e] >> 32), b = (long long)(edges[e] & 0xFFFFFFFFull);
     const Cand &ca = ctx->best_c[a];
@@ -1077,7 +1103,7 @@ int lt_compute_tracks(lt_ctx *ctx) {
       tr.gnodes.push_back(g);
     }
     const long long nT = (long long)ctx->tracks.size();
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 16)
     for (long long t = 0; t < nT; ++t) {
       Track &tr = ctx->tracks[t];
       std::vector<const Cand *> lines;

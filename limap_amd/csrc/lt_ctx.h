@@ -5,6 +5,8 @@
 #include "../../include/limap_amd.h"
 #include "lt_device.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <hip/hip_runtime.h>
 #include <unordered_map>
@@ -33,6 +35,37 @@ struct DevBuf {
   }
   template <class T>
   T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// growable int buffer without value-initialisation (the match rows are overwritten right away)
+struct RawInts {
+  int *p = nullptr;
+  size_t n = 0, cap = 0;
+  ~RawInts() { std::free(p); }
+  RawInts() = default;
+  RawInts(const RawInts &) = delete;
+  RawInts &operator=(const RawInts &) = delete;
+  size_t size() const { return n; }
+  int *data() { return p; }
+  const int *data() const { return p; }
+  void clear() { n = 0; }
+  bool grow_to(size_t want) {  // size := want, contents beyond the old size are uninitialised
+    if (want > cap) {
+      size_t nc = std::max(want, cap + cap / 2 + 1024);
+      int *q = (int *)std::realloc(p, nc * sizeof(int));
+      if (!q) return false;
+      p = q;
+      cap = nc;
+    }
+    n = want;
+    return true;
+  }
+  bool reserve(size_t want) {
+    size_t keep = n;
+    if (!grow_to(std::max(want, n))) return false;
+    n = keep;
+    return true;
+  }
 };
 
 struct Track {
@@ -75,7 +108,7 @@ struct lt_ctx {
   std::vector<std::vector<int>> job_nbs;   // per job image: neighbour image indices, processing order
   std::vector<std::vector<int>> job_order; // per job image: slots in ascending neighbour-id order
   std::vector<long long> h_m_off;          // per block row offsets (n_blk+1), matched mode
-  std::vector<int> h_m_pairs;              // 2 * P
+  lt_host::RawInts h_m_pairs;              // 2 * P
   std::vector<char> triangulated;          // per image: already passed to TriangulateImage*
   bool uploaded = false, ran = false, downloaded = false;
   // neighbours_ of every triangulated image (ids), persists for the tail

@@ -5,11 +5,20 @@
 
 #include "lt_geom.h"
 
+#include <omp.h>
+
 #include <algorithm>
 #include <cmath>
 #include <vector>
 
 namespace lt {
+
+// The host loops here are short (10^3..10^6 cheap items): a bounded team avoids the fork/join cost of a
+// 256-thread default on big hosts.
+inline int host_threads() {
+  int n = omp_get_max_threads();
+  return n > 16 ? 16 : (n < 1 ? 1 : n);
+}
 
 inline int uf_root(int i, std::vector<int> &parent) {  // base/graph.cc:156-165 (iterative path compression)
   int r = i;

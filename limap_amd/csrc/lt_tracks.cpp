@@ -148,7 +148,7 @@ int lt_ts_filter_by_reprojection(lt_ctx *ctx, lt_trackset *ts, double th_angular
     }
   std::vector<TrackFull> out((size_t)nT);
   std::vector<char> keep((size_t)nT, 0);
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 8)
   for (long long ti = 0; ti < nT; ++ti) {
     const TrackFull &t = ts->tracks[ti];
     TrackFull nt;
@@ -182,7 +182,7 @@ int lt_ts_filter_by_sensitivity(lt_ctx *ctx, lt_trackset *ts, double th_angular3
   const long long nT = (long long)ts->tracks.size();
   std::vector<char> keep((size_t)nT, 0);
   int bad = 0;
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 8)
   for (long long ti = 0; ti < nT; ++ti) {
     const TrackFull &t = ts->tracks[ti];
     d3 s = mk3(t.line[0], t.line[1], t.line[2]), e = mk3(t.line[3], t.line[4], t.line[5]);
@@ -216,7 +216,7 @@ int lt_ts_filter_by_overlap(lt_ctx *ctx, lt_trackset *ts, double th_overlap, int
   const long long nT = (long long)ts->tracks.size();
   std::vector<char> keep((size_t)nT, 0);
   int bad = 0;
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 8)
   for (long long ti = 0; ti < nT; ++ti) {
     const TrackFull &t = ts->tracks[ti];
     std::set<int> imgs;
@@ -331,7 +331,7 @@ int lt_ts_remerge_once(lt_ctx *ctx, lt_trackset *ts, const lt_config *linker_cfg
     counter[labels[t]]++;
     g.m.insert(g.m.end(), ts->tracks[t].m.begin(), ts->tracks[t].m.end());
   }
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 8)
   for (long gi = 0; gi < n_groups; ++gi) {
     reaggregate(out[gi], num_outliers);
     out[gi].active = counter[gi] != 1;

@@ -171,18 +171,16 @@ class GlobalLineTriangulator:
 
     def TriangulateImage(self, img_id, matches):
         """matches: dict[int -> ndarray(K,2) int] (the content of matches_{img_id}.npy)."""
-        nb = list(matches.keys())
-        off = np.zeros(len(nb) + 1, np.int64)
-        rows = []
-        for n, key in enumerate(nb):
-            m = np.asarray(matches[key])
+        nb, rows = [], []
+        for key, m in matches.items():
+            m = np.asarray(m)
             if m.size != 0 and (m.ndim != 2 or m.shape[1] != 2):
                 raise ValueError("Check failed: match_info.cols() == 2")  # base_line_triangulator.cc:79
-            m = m.reshape(-1, 2)
-            rows.append(m.astype(np.int32, copy=False))
-            off[n + 1] = off[n] + len(m)
-        pairs = np.concatenate(rows, 0) if rows else np.zeros((0, 2), np.int32)
-        self._ctx.triangulate_image(img_id, [int(x) for x in nb], off, pairs)
+            if m.dtype != np.int32 or not m.flags.c_contiguous or m.ndim != 2:
+                m = np.ascontiguousarray(m.reshape(-1, 2), dtype=np.int32)  # Eigen::MatrixXi caster: converted by copy
+            nb.append(int(key))
+            rows.append(m)
+        self._ctx.triangulate_image_rows(img_id, nb, rows)
 
     def TriangulateImageExhaustiveMatch(self, img_id, neighbors):
         self._ctx.triangulate_image_exhaustive(img_id, [int(x) for x in neighbors])
