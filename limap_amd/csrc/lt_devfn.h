@@ -10,9 +10,12 @@ static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 static __device__ __forceinline__ unsigned long long lanemask_lt() {
   return (1ull << lane_id()) - 1ull;
 }
-// lanes of ONE wave exchanging data through LDS: order the DS traffic, no s_barrier needed
+// Lanes of ONE wave exchanging data through LDS.  DS operations of a wave execute in order, so all
+// that is needed is (a) the compiler must not move LDS accesses across this point (asm memory clobber)
+// and (b) earlier DS results must have landed (lgkmcnt(0)).  Deliberately NOT a fence: an acq_rel
+// fence also drains vmcnt, i.e. waits for every outstanding global store of the wave.
 static __device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 

@@ -117,22 +117,53 @@ k_gen_rows(GenArgs a, GenCfg cfg) {
       wcount += (unsigned)__popcll(m);
     };
 
-    for (int c = 0; c < kGenChunks; ++c) {
+    // Software pipeline over the 64-row chunks: the match rows are fetched two chunks ahead and the
+    // image's own segment (gather by line id) one chunk ahead, so that neither global round trip sits
+    // on the critical path of the gate arithmetic.
+    auto load_rows = [&](int c, int *line, int *ng) {
       long long r = r0 + 64ll * c + lane;
+      *line = -1;
+      *ng = 0;
+      if (c < kGenChunks && r < re) {
+        const int2 v = *reinterpret_cast<const int2 *>(a.m_pairs + 2 * r);
+        *line = v.x;
+        *ng = v.y;
+      }
+    };
+    struct S1 { double x1, y1, x2, y2, rs[3], re[3]; };
+    auto load_s1 = [&](int line, S1 *o) {
+      if (line >= 0) {
+        const Seg &s = a.segs[g1 + line];
+        o->x1 = s.x1; o->y1 = s.y1; o->x2 = s.x2; o->y2 = s.y2;
+        o->rs[0] = s.rs[0]; o->rs[1] = s.rs[1]; o->rs[2] = s.rs[2];
+        o->re[0] = s.re[0]; o->re[1] = s.re[1]; o->re[2] = s.re[2];
+      }
+    };
+    int line_c, ng_c, line_n, ng_n, line_nn = -1, ng_nn = 0;
+    S1 cur, nxt;
+    load_rows(0, &line_c, &ng_c);
+    load_rows(1, &line_n, &ng_n);
+    load_s1(line_c, &cur);
+    for (int c = 0; c < kGenChunks; ++c) {
+      load_rows(c + 2, &line_nn, &ng_nn);
+      load_s1(line_n, &nxt);
+      const long long r = r0 + 64ll * c + lane;
       bool pass = false;
-      if (r < re) {
-        int line = a.m_pairs[2 * r], ng = a.m_pairs[2 * r + 1];
-        const Seg &s1 = a.segs[g1 + line];
+      if (line_c >= 0) {
+        const int ng = ng_c;
         if (use_lds) {
-          pass = gen_gates_fast(cfg, s1.x1, s1.y1, s1.x2, s1.y2, s1.rs, s1.re, T[0 * ts + ng], T[1 * ts + ng],
+          pass = gen_gates_fast(cfg, cur.x1, cur.y1, cur.x2, cur.y2, cur.rs, cur.re, T[0 * ts + ng], T[1 * ts + ng],
                                 T[2 * ts + ng], T[3 * ts + ng], T[4 * ts + ng], T[5 * ts + ng], T[6 * ts + ng],
                                 T[7 * ts + ng], T[8 * ts + ng], T[9 * ts + ng], pr->F, a.segs[g2 + ng]);
         } else {
           const Seg &s2 = a.segs[g2 + ng];
-          pass = gen_gates_fast(cfg, s1.x1, s1.y1, s1.x2, s1.y2, s1.rs, s1.re, s2.n[0], s2.n[1], s2.n[2],
+          pass = gen_gates_fast(cfg, cur.x1, cur.y1, cur.x2, cur.y2, cur.rs, cur.re, s2.n[0], s2.n[1], s2.n[2],
                                 s2.lc[0], s2.lc[1], s2.lc[2], s2.x1, s2.y1, s2.x2, s2.y2, pr->F, s2);
         }
       }
+      cur = nxt;
+      line_c = line_n; ng_c = ng_n;
+      line_n = line_nn; ng_n = ng_nn;
       unsigned long long m = __ballot(pass);
       if (m) {
         if (pass) qr[qn + __popcll(m & lanemask_lt())] = (unsigned)r;
