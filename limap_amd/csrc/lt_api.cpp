@@ -48,8 +48,9 @@ void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const un
                     const CandLite *st_l, Cand *cand, CandLite *lite, unsigned *cand_node);
 void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, unsigned *cand_node);
 size_t score3_lds_bytes(int max_nb);
+size_t cand_meta_bytes();
 void launch_score3(hipStream_t st, long long C, long long G, const long long *tri_off, const unsigned *cand_node,
-                   const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
+                   void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2);
 }
@@ -313,7 +314,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
-                    &ctx->d_pair_counter, &ctx->d_chunks};
+                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta};
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   for (DevBuf *b : bufs) b->release();
   for (auto &ev : ctx->ev)
@@ -835,7 +836,10 @@ int lt_run_device(lt_ctx *ctx) {
     double guard2 = (scfg.l3.th_scaleinv > 0.0 && scfg.l3.score_th > 0.0 && scfg.l3.score_th < 1.0) ? th * th : 1e300;
     ENSURE(ctx, ctx->d_pair_counter, 8);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_pair_counter.p, 0, 8, st));
-    launch_score3(st, C_known, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(),
+    if (ctx->h_nb_off[ctx->n_img] >= (1ll << 24))
+      return fail(ctx, LT_ERR_ARGUMENT, "too many (image, neighbour) blocks in one batch (>= 2^24)");
+    ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_known, 1));
+    launch_score3(st, C_known, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
                   ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_node_img.as<int>(),
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
                   ctx->d_score.as<double>(), ctx->d_pair_counter.as<unsigned long long>(), ctx->max_nb, scfg,

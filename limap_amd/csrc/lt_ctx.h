@@ -135,7 +135,7 @@ struct lt_ctx {
   std::vector<long long> h_blk_line_base;
   bool rows_sorted = true;   // every (image, neighbour) block lists its rows in non-decreasing line id
   long long *h_pinned = nullptr;  // pinned scratch for small device->host scalars
-  DevBuf d_chunks;
+  DevBuf d_chunks, d_cand_meta;
   int n_chunks = 0;
   long long cand_cap = 0;
   long long C = 0, E = 0;  // candidates / valid edges of the last run

@@ -300,6 +300,31 @@ __global__ void k_permute(long long C, const unsigned *__restrict__ skeys, const
   cand_node[t] = skeys[t];
 }
 
+// Per-candidate record for the scoring kernel: where its node's candidates start, how many there
+// are, and the neighbour table of its image -- so that the scoring prologue is ONE load level
+// instead of the chain cand_node -> tri_off / node_img -> nb_off.
+struct CandMeta {
+  unsigned off_lo, off_hi;  // tri_off[node] (64-bit split)
+  unsigned n;               // candidates of the node
+  unsigned nb;              // (nb_off[img] << 8) | number of neighbours  (nb_off < 2^24)
+};
+__global__ void k_cand_meta(long long C, const unsigned *__restrict__ cand_node,
+                            const long long *__restrict__ tri_off, const int *__restrict__ node_img,
+                            const long long *__restrict__ nb_off, CandMeta *__restrict__ meta) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  const unsigned g = cand_node[i];
+  const long long off = tri_off[g];
+  const int img = node_img[g];
+  const long long nb0 = nb_off[img];
+  CandMeta m;
+  m.off_lo = (unsigned)(off & 0xFFFFFFFFll);
+  m.off_hi = (unsigned)(off >> 32);
+  m.n = (unsigned)(tri_off[g + 1] - off);
+  m.nb = ((unsigned)nb0 << 8) | (unsigned)(nb_off[img + 1] - nb0);
+  meta[i] = m;
+}
+
 // cand_node for pipelines that produce the compact arrays directly (exhaustive mode)
 __global__ void __launch_bounds__(256)
 k_cand_node(long long G, const long long *__restrict__ tri_off, unsigned *__restrict__ cand_node) {
@@ -325,11 +350,9 @@ constexpr int kWin = 128;
 struct Score3Args {
   long long G;
   const long long *tri_off;  // tri_off[G] = C
-  const unsigned *cand_node;
+  const CandMeta *meta;
   const Cand *cand;
   const CandLite *lite;
-  const int *node_img;
-  const long long *nb_off;
   const int *blk_order;
   const Cam *cams;
   double *score;
@@ -341,12 +364,13 @@ __global__ void __launch_bounds__(64)
 k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x;
-  // LDS: W[9][kWin] f64 | S[max_nb][64] u64 | woff[64] i64 | wslot[kWin] i32 | queue[kSQCap] u32
+  // LDS: W[9][kWin] f64 | S[max_nb][64] u64 | woff[64] i64 | wslot[kWin] i32 | queue[kSQCap] u32 | ord[max_nb] i32
   double *W = reinterpret_cast<double *>(smem_raw);
   unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_raw + 9 * kWin * 8);
   long long *woff = reinterpret_cast<long long *>(smem_raw + 9 * kWin * 8 + (size_t)a.max_nb * 64 * 8);
   int *wslot = reinterpret_cast<int *>(smem_raw + 9 * kWin * 8 + (size_t)a.max_nb * 64 * 8 + 64 * 8);
   unsigned *queue = reinterpret_cast<unsigned *>(smem_raw + 9 * kWin * 8 + (size_t)a.max_nb * 64 * 8 + 64 * 8 + kWin * 4);
+  int *ordl = reinterpret_cast<int *>(smem_raw + 9 * kWin * 8 + (size_t)a.max_nb * 64 * 8 + 64 * 8 + kWin * 4 + kSQCap * 4);
 
   const long long C = a.tri_off[a.G];
   const long long i0 = (long long)blockIdx.x * 64;
@@ -359,12 +383,11 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   double dix = 0, diy = 0, diz = 0;
   double six = 0, siy = 0, siz = 0, eix = 0, eiy = 0, eiz = 0, gs2 = 0, ge2 = 0;
   if (active) {
-    const unsigned g = a.cand_node[i];
-    off = a.tri_off[g];
-    n = (int)(a.tri_off[g + 1] - off);
-    const int img = a.node_img[g];
-    nb0 = a.nb_off[img];
-    n_nb = (int)(a.nb_off[img + 1] - nb0);
+    const CandMeta mt = a.meta[i];
+    off = ((long long)mt.off_hi << 32) | (long long)mt.off_lo;
+    n = (int)mt.n;
+    nb0 = (long long)(mt.nb >> 8);
+    n_nb = (int)(mt.nb & 0xFFu);
     const CandLite li = a.lite[i];
     const Cand ci = a.cand[i];
     dix = li.dir[0]; diy = li.dir[1]; diz = li.dir[2];
@@ -377,6 +400,9 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     ge2 = (ze > 0.0) ? scaleinv_guard2 * ze * ze : 1e300;
   }
   woff[lane] = off;
+  // summation order of the first lane's image, staged once (lanes of another image read it from HBM)
+  const long long wave_nb0 = __shfl(nb0, 0);
+  if (lane < __shfl(n_nb, 0)) ordl[lane] = a.blk_order[wave_nb0 + lane];
   for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
   // candidate range of all nodes this wave touches (lane 0 is always active)
   const long long lo = __shfl(off, 0);
@@ -436,18 +462,19 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     for (int t = 0; t < cmax; ++t) {
       bool pass = t < cnt;
       if (pass) {
+        // one LDS round trip per iteration: fetch every field up front, then test
         const int w = w0 + t;
-        pass = (jlo + t != i) && (wslot[w] != sloti);
-        if (pass) {
-          double c = fabs((dix * W[0 * kWin + w] + diy * W[1 * kWin + w]) + diz * W[2 * kWin + w]);
-          pass = !(c < cfg.cos_guard);  // below the guard the 3D angle score is certainly gated to 0
-          if (pass) {
-            double ax = six - W[3 * kWin + w], ay = siy - W[4 * kWin + w], az = siz - W[5 * kWin + w];
-            double bx = eix - W[6 * kWin + w], by = eiy - W[7 * kWin + w], bz = eiz - W[8 * kWin + w];
-            double ds2 = ax * ax + ay * ay + az * az, de2 = bx * bx + by * by + bz * bz;
-            pass = !(ds2 > gs2) && !(de2 > ge2);
-          }
-        }
+        const int sl = wslot[w];
+        const double jx = W[0 * kWin + w], jy = W[1 * kWin + w], jz = W[2 * kWin + w];
+        const double sx = W[3 * kWin + w], sy = W[4 * kWin + w], sz = W[5 * kWin + w];
+        const double ex = W[6 * kWin + w], ey = W[7 * kWin + w], ez = W[8 * kWin + w];
+        const double c = fabs((dix * jx + diy * jy) + diz * jz);
+        const double ax = six - sx, ay = siy - sy, az = siz - sz;
+        const double bx = eix - ex, by = eiy - ey, bz = eiz - ez;
+        const double ds2 = ax * ax + ay * ay + az * az, de2 = bx * bx + by * by + bz * bz;
+        // below the cosine guard the 3D angle score is certainly gated to 0; beyond the squared
+        // distance guards the scale-invariant endpoint score is
+        pass = (jlo + t != i) && (sl != sloti) && !(c < cfg.cos_guard) && !(ds2 > gs2) && !(de2 > ge2);
       }
       unsigned long long m = __ballot(pass);
       if (m) {
@@ -461,8 +488,9 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
 
   if (active) {
     double sum = 0.0;
+    const bool own = nb0 == wave_nb0;
     for (int r = 0; r < n_nb; ++r) {
-      int k = a.blk_order[nb0 + r];
+      int k = own ? ordl[r] : a.blk_order[nb0 + r];
       sum += __longlong_as_double((long long)S[k * 64 + lane]);
     }
     a.score[i] = sum;
@@ -522,16 +550,19 @@ void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, uns
     hipLaunchKernelGGL(k_cand_node, dim3(nblk2(G * 64, 256)), dim3(256), 0, st, G, tri_off, cand_node);
 }
 size_t score3_lds_bytes(int max_nb) {
-  return 9 * kWin * 8 + (size_t)max_nb * 64 * 8 + 64 * 8 + kWin * 4 + kSQCap * 4;
+  return 9 * kWin * 8 + (size_t)max_nb * 64 * 8 + 64 * 8 + kWin * 4 + kSQCap * 4 + (size_t)max_nb * 4;
 }
+size_t cand_meta_bytes() { return sizeof(CandMeta); }
 void launch_score3(hipStream_t st, long long C, long long G, const long long *tri_off, const unsigned *cand_node,
-                   const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
+                   void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2) {
   if (C <= 0) return;
+  hipLaunchKernelGGL(k_cand_meta, dim3(nblk2(C, 256)), dim3(256), 0, st, C, cand_node, tri_off, node_img, nb_off,
+                     reinterpret_cast<CandMeta *>(meta));
   Score3Args a;
-  a.G = G; a.tri_off = tri_off; a.cand_node = cand_node; a.cand = cand; a.lite = lite; a.node_img = node_img;
-  a.nb_off = nb_off; a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
+  a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand; a.lite = lite;
+  a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
   a.max_nb = max_nb;
   hipLaunchKernelGGL(k_score3, dim3(nblk2(C, 64)), dim3(64), score3_lds_bytes(max_nb), st, a, cfg, scaleinv_guard2);
 }
