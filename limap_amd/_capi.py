@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblimap_amd.so")
+# LIMAP_AMD_LIB: developer override (A/B builds of the extension); the default is the in-tree library
+LIB_PATH = os.environ.get("LIMAP_AMD_LIB") or os.path.join(_HERE, "liblimap_amd.so")
 
 EXPORTED_SYMBOLS = [
     "lt_config_default", "lt_abi_version", "lt_sizeof_config", "lt_create", "lt_destroy", "lt_last_error", "lt_set_stream", "lt_set_ranges",

@@ -27,13 +27,15 @@ using namespace lt;
 namespace lt {
 void launch_fn_query(hipStream_t st, const double *in30, int by_endpoints, double *out32);
 // lt_kernels_v2.hip
-unsigned gen_grid_x(long long max_rows);
-size_t gen_lds_bytes(int lds_segs);
-void launch_gen_rows(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
-                     const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
-                     const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
-                     const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
-                     unsigned *wave_count, unsigned *cnt_bl, int lds_segs);
+int gen_slots(long long max_rows);
+size_t seg_gate_bytes();
+size_t blk_rec_bytes();
+void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
+                      const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
+                      const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
+                      const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
+                      unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, unsigned *st_row,
+                      unsigned *surv_count, long long n_segs, void *gates, void *blkrec);
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
                         unsigned *n_tris);
@@ -107,6 +109,16 @@ GenCfg make_gen(const lt_ctx *ctx) {
   } else {
     g.sin_lo = -1.0;
     g.sin_hi = 1e300;
+  }
+  // `length <= min_length` skips the connection (base_line_triangulator.cc:166,177); length = sqrt(q)
+  const double L = c.min_length_2d;
+  if (L > 0.0) {
+    g.len_lo2 = L * L * (1.0 - 1e-12);
+    g.len_hi2 = L * L * (1.0 + 1e-12);
+  } else if (L == 0.0) {
+    g.len_lo2 = g.len_hi2 = 0.0;  // only q == 0 has length <= 0
+  } else {
+    g.len_lo2 = g.len_hi2 = -1.0;  // nothing has a negative length
   }
   return g;
 }
@@ -236,10 +248,12 @@ void build_job_tables(lt_ctx *ctx) {
   ctx->n_blk = (int)ctx->h_blk_img.size();
   ctx->h_blk_line_base.assign(ctx->n_blk + 1, 0);
   ctx->max_nb_segs = 0;
+  ctx->max_own_segs = 0;
   for (int b = 0; b < ctx->n_blk; ++b) {
     int i1 = ctx->h_blk_img[b];
     int i2 = ctx->h_blk_nb[b];
     ctx->max_nb_segs = std::max(ctx->max_nb_segs, (int)(ctx->seg_off[i2 + 1] - ctx->seg_off[i2]));
+    ctx->max_own_segs = std::max(ctx->max_own_segs, (int)(ctx->seg_off[i1 + 1] - ctx->seg_off[i1]));
     ctx->h_blk_line_base[b + 1] = ctx->h_blk_line_base[b] + (ctx->seg_off[i1 + 1] - ctx->seg_off[i1]) + 1;
   }
 }
@@ -314,7 +328,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
-                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta};
+                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec};
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   for (DevBuf *b : bufs) b->release();
   for (auto &ev : ctx->ev)
@@ -701,7 +715,7 @@ int lt_run_device(lt_ctx *ctx) {
   if (ctx->job_mode == 1) {
     const size_t Pn = (size_t)std::max<long long>(P, 1);
     const bool fast = ctx->rows_sorted;
-    const long long n_waves = (long long)ctx->n_blk * gen_grid_x(ctx->max_rows) * 4;
+    const long long n_waves = (long long)ctx->n_blk * gen_slots(ctx->max_rows);
     const long long n_entries = ctx->h_blk_line_base[ctx->n_blk];
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
     // ---- generation in row order; valid candidates appended in row order to per-wave lists ----
@@ -713,13 +727,25 @@ int lt_run_device(lt_ctx *ctx) {
       ENSURE(ctx, ctx->d_cnt_bl, 4 * (size_t)std::max<long long>(n_entries, 1));
       HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt_bl.p, 0, 4 * (size_t)std::max<long long>(n_entries, 1), st));
     }
-    const int lds_segs = (ctx->max_nb_segs <= 768) ? ctx->max_nb_segs : 0;
-    launch_gen_rows(st, ctx->n_blk, ctx->max_rows, gcfg, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
-                    ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(),
-                    ctx->d_seg_off.as<long long>(), ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(),
-                    ctx->d_pairs.as<PairRec>(), ctx->d_blk_line_base.as<long long>(), ctx->d_st_c.as<Cand>(),
-                    ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(), ctx->d_wave_count.as<unsigned>(),
-                    fast ? ctx->d_cnt_bl.as<unsigned>() : nullptr, lds_segs);
+    static const bool no_lds_table = getenv("LT_GEN_NO_LDS_TABLE") != nullptr;  // developer A/B switch
+    // LDS tables of k_gates: the neighbour's gate records (T2) and the image's own segments (T1), 80 B
+    // per segment each; two workgroups per CU need both within 80 KB, one workgroup within 160 KB
+    int lds_segs = (!no_lds_table && ctx->max_nb_segs <= 1024) ? ctx->max_nb_segs : 0;
+    int lds_segs1 = (!no_lds_table && ctx->max_own_segs <= 1024) ? ctx->max_own_segs : 0;
+    if (lds_segs + lds_segs1 > 2048) lds_segs1 = 0;
+    {
+      ENSURE(ctx, ctx->d_st_row, 4 * Pn);
+      ENSURE(ctx, ctx->d_surv_count, 4 * (size_t)(n_waves + 1));
+      ENSURE(ctx, ctx->d_seg_gates, seg_gate_bytes() * (size_t)std::max<long long>(G, 1));
+      ENSURE(ctx, ctx->d_blkrec, blk_rec_bytes() * (size_t)std::max(ctx->n_blk, 1));
+      launch_gen_split(st, ctx->n_blk, ctx->max_rows, gcfg, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
+                       ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(),
+                       ctx->d_seg_off.as<long long>(), ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(),
+                       ctx->d_pairs.as<PairRec>(), ctx->d_blk_line_base.as<long long>(), ctx->d_st_c.as<Cand>(),
+                       ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(), ctx->d_wave_count.as<unsigned>(),
+                       fast ? ctx->d_cnt_bl.as<unsigned>() : nullptr, lds_segs, lds_segs1, ctx->d_st_row.as<unsigned>(),
+                       ctx->d_surv_count.as<unsigned>(), G, ctx->d_seg_gates.p, ctx->d_blkrec.p);
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
     long long *hC = ctx->h_pinned;
     long long hC_fallback = 0;

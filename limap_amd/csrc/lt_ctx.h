@@ -130,12 +130,13 @@ struct lt_ctx {
   DevBuf d_cand, d_lite, d_tri_off, d_score, d_best_idx, d_edge_flag, d_nvalid, d_edge_off, d_edges;
   DevBuf d_best_c, d_best_score, d_best_src, d_ntris, d_err;
   DevBuf d_blk_line_base, d_cnt_bl, d_st_key, d_wave_count, d_wave_pos, d_ntris_u, d_cand_node, d_pair_counter;
+  int max_own_segs = 0;  // most segments of any image with a job (LDS table sizing)
   int max_nb_segs = 0;   // most segments of any neighbour image in the job (LDS table sizing)
   long long stat_pairs_eval = 0;
   std::vector<long long> h_blk_line_base;
   bool rows_sorted = true;   // every (image, neighbour) block lists its rows in non-decreasing line id
   long long *h_pinned = nullptr;  // pinned scratch for small device->host scalars
-  DevBuf d_chunks, d_cand_meta;
+  DevBuf d_chunks, d_cand_meta, d_st_row, d_surv_count, d_seg_gates, d_blkrec;
   int n_chunks = 0;
   long long cand_cap = 0;
   long long C = 0, E = 0;  // candidates / valid edges of the last run

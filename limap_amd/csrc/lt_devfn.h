@@ -147,78 +147,97 @@ static __device__ __forceinline__ bool gen_gates(const GenCfg &cfg, const Seg &s
   return true;
 }
 
-// Stage A with a cheap, conservative form of the weak-epipolar gate.  The reference computes
-// IoU = (min(c2,1) - max(c1,0)) / (max(c2,1) - min(c1,0)) from two normalised epipolar lines and
-// rejects IoU < th.  Only the DECISION is needed here, and the denominator is >= 1, so the test is
-// num - th * den < 0.  c1, c2 are evaluated without the intermediate normalisations (same algebra:
-// c = (N.xy . v - D s2 . v) / (D |v|^2) with N = lc2 x (F x~), D = N.z + eps |F x~|), which costs two
-// square roots and two divisions instead of five and fifteen.  The cheap form decides only when it is
-// far (1e-7) from the threshold and well conditioned; otherwise the exact expression is evaluated, so
-// the outcome is always the reference's.
-static __device__ __forceinline__ bool gen_gates_fast(const GenCfg &cfg, double a1x, double a1y, double b1x,
-                                                      double b1y, const double *rs1, const double *re1,
-                                                      double n2x, double n2y, double n2z, double lcx, double lcy,
-                                                      double lcz, double a2x, double a2y, double b2x, double b2y,
-                                                      const double *F, const Seg &s2_exact) {
-  // (a1,b1) = endpoints of l1, (a2,b2) = endpoints of l2, n2 = plane normal of l2, lc = coords of l2
+// 1 / x to full double precision without the IEEE division sequence (v_rcp_f64 + two Newton steps).
+// Only used inside conservative decisions that carry their own error margin.
+static __device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// Three-way form of stage A for the split pipeline (k_gates + k_tri_rows): 0 = the reference
+// certainly skips this connection, 1 = it certainly passes every gate, 2 = too close to a threshold
+// (or badly conditioned) for the cheap arithmetic -- the exact gates (gen_gates) then decide in the
+// triangulation kernel.  The reference computes IoU = (min(c2,1) - max(c1,0)) / (max(c2,1) - min(c1,0))
+// from two normalised epipolar lines and rejects IoU < th; only the DECISION is needed here and the
+// denominator is >= 1, so the test is num - th * den < 0.  Nothing transcendental or exact is
+// evaluated: no acos, no normalisations, sqrt only in float (it enters D at the 1e-12 level), a
+// reciprocal instead of the divisions, FMAs, no branches.  This is NOT reference arithmetic -- it
+// only ever returns 0/1 when the reference's outcome is certain, with these error budgets:
+//   * lengths: q vs min_length^2 (1 +- 1e-12)                  [exact test: sqrt(q) <= min_length]
+//   * ray/plane angles: |cos| vs sin(th) (1 +- 1e-7)           [exact: 90 - acos(.) 180/pi < th]
+//   * IoU: delta = num - th den vs a margin of 1e-7 (1 + |c1| + |c2|)(1 + |th|) plus 1e-12 x the
+//     cancellation bound of the numerators, and only if D has no cancellation beyond 1e4 (`well`).
+// The neighbour-side operands come from the per-segment SegGate record (segment-only invariants of
+// the algebra c = (N.xy . v - D s2 . v) / (D |v|^2), N = lc2 x (F x~), D = N.z + eps |F x~|):
+//   N.xy . v = az w1 + ax P + ay Q   with  w1 = lcy vx - lcx vy, P = lcz vy, Q = -lcz vx, v = e2 - s2.
+struct SegGate {
+  double n[3];      // plane normal of the segment's back-projection (Seg::n)
+  double lcx, lcy;  // first two line coordinates (Seg::lc)
+  double P, Q, w1;  // see above
+  double sv;        // s2 . v
+  double q2;        // |v|^2
+};
+static_assert(sizeof(SegGate) == 80, "SegGate layout");
+
+static __device__ __forceinline__ void seg_gate_build(const Seg &s, SegGate *g) {
+  const double vx = s.x2 - s.x1, vy = s.y2 - s.y1;
+  g->n[0] = s.n[0]; g->n[1] = s.n[1]; g->n[2] = s.n[2];
+  g->lcx = s.lc[0]; g->lcy = s.lc[1];
+  g->P = s.lc[2] * vy;
+  g->Q = -(s.lc[2] * vx);
+  g->w1 = s.lc[1] * vx - s.lc[0] * vy;
+  g->sv = s.x1 * vx + s.y1 * vy;
+  g->q2 = vx * vx + vy * vy;  // == (x1-x2)^2 + (y1-y2)^2 bit for bit (negation is exact)
+}
+
+static __device__ __forceinline__ int gate3(const GenCfg &cfg, double a1x, double a1y, double b1x, double b1y,
+                                            double rs1x, double rs1y, double rs1z, double re1x, double re1y,
+                                            double re1z, double n2x, double n2y, double n2z, double lcx,
+                                            double lcy, double P, double Q, double w1, double sv, double q2,
+                                            const double *F) {
   const double d1x = a1x - b1x, d1y = a1y - b1y;
-  const double d2x = a2x - b2x, d2y = a2y - b2y;
-  const double q1 = d1x * d1x + d1y * d1y, q2 = d2x * d2x + d2y * d2y;
-  if (cfg.min_length_2d > 0.0) {  // base_line_triangulator.cc:166,177
-    if (sqrt(q1) <= cfg.min_length_2d) return false;
-    if (sqrt(q2) <= cfg.min_length_2d) return false;
-  } else if (cfg.min_length_2d == 0.0) {  // length <= 0  <=>  squared length == 0
-    if (q1 == 0.0 || q2 == 0.0) return false;
-  }
-  if (cfg.disable_algebraic) return false;
-  d3 n2 = mk3(n2x, n2y, n2z);
-  d3 r1s = mk3(rs1[0], rs1[1], rs1[2]), r1e = mk3(re1[0], re1[1], re1[2]);
-  double as = fabs(dot(n2, r1s));
-  if (as < cfg.sin_lo) return false;
-  if (!(as > cfg.sin_hi)) {
-    double ang = 90 - acos(as) * 180.0 / kPi;
-    if (ang < cfg.angle_th) return false;
-  }
-  double ae = fabs(dot(n2, r1e));
-  if (ae < cfg.sin_lo) return false;
-  if (!(ae > cfg.sin_hi)) {
-    double ang = 90 - acos(ae) * 180.0 / kPi;
-    if (ang < cfg.angle_th) return false;
-  }
-  // cheap weak-epipolar decision
-  {
-    const double vx = -d2x, vy = -d2y;  // e2 - s2
-    const double sv = a2x * vx + a2y * vy;
-    double cv[2];
-    bool well = q2 > 0.0;
+  const double q1 = __builtin_fma(d1x, d1x, d1y * d1y);
+  bool rej = (q1 <= cfg.len_lo2) | (q2 <= cfg.len_lo2) | (cfg.disable_algebraic != 0);
+  bool und = !(q1 > cfg.len_hi2) | !(q2 > cfg.len_hi2);
+  const double as = fabs(__builtin_fma(n2x, rs1x, __builtin_fma(n2y, rs1y, n2z * rs1z)));
+  const double ae = fabs(__builtin_fma(n2x, re1x, __builtin_fma(n2y, re1y, n2z * re1z)));
+  rej |= (as < cfg.sin_lo) | (ae < cfg.sin_lo);
+  und |= !(as > cfg.sin_hi) | !(ae > cfg.sin_hi);
+  double cv[2], cerr = 0.0;
+  bool well = q2 > 0.0;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const double px = k == 0 ? a1x : b1x, py = k == 0 ? a1y : b1y;
-      const double ax = F[0] * px + F[1] * py + F[2];
-      const double ay = F[3] * px + F[4] * py + F[5];
-      const double az = F[6] * px + F[7] * py + F[8];
-      const double na = sqrt(ax * ax + ay * ay + az * az);
-      const double nx = lcy * az - lcz * ay;
-      const double ny = lcz * ax - lcx * az;
-      const double t1 = lcx * ay, t2 = lcy * ax;
-      const double D = (t1 - t2) + kEps * na;
-      well = well && (fabs(D) > 1e-4 * (fabs(t1) + fabs(t2))) && (na > 0.0);
-      cv[k] = ((nx * vx + ny * vy) - D * sv) / (D * q2);
-    }
-    double c1v = cv[0] < cv[1] ? cv[0] : cv[1], c2v = cv[0] < cv[1] ? cv[1] : cv[0];
-    double num = dmin(c2v, 1.0) - dmax(c1v, 0.0);
-    double den = dmax(c2v, 1.0) - dmin(c1v, 0.0);
-    double delta = num - cfg.iou_th * den;
-    double margin = 1e-7 * (1.0 + fabs(c1v) + fabs(c2v)) * (1.0 + fabs(cfg.iou_th));
-    if (well && delta < -margin) return false;
-    if (well && delta > margin) return true;
+  for (int k = 0; k < 2; ++k) {
+    const double px = k == 0 ? a1x : b1x, py = k == 0 ? a1y : b1y;
+    const double ax = __builtin_fma(F[0], px, __builtin_fma(F[1], py, F[2]));
+    const double ay = __builtin_fma(F[3], px, __builtin_fma(F[4], py, F[5]));
+    const double az = __builtin_fma(F[6], px, __builtin_fma(F[7], py, F[8]));
+    const double n2a = __builtin_fma(ax, ax, __builtin_fma(ay, ay, az * az));
+    const double na = (double)__builtin_amdgcn_sqrtf((float)n2a);
+    const double t1 = lcx * ay, t2 = lcy * ax;
+    const double D = __builtin_fma(kEps, na, t1 - t2);
+    const double m0 = az * w1, m1 = ax * P, m2 = ay * Q, m3 = D * sv;
+    const double numer = ((m0 + m1) + m2) - m3;
+    const double Dq = D * q2;
+    const double r = fast_rcp(Dq);
+    // conditioning: no cancellation in D beyond 1e4, the float sqrt stays far below the margin, no
+    // overflow / underflow games
+    well = well & (fabs(D) > 1e-4 * (fabs(t1) + fabs(t2))) & (fabs(D) > 1e-9 * na) & (n2a > 1e-30) &
+           (n2a < 1e30) & (fabs(Dq) > 1e-280) & (fabs(Dq) < 1e280);
+    cv[k] = numer * r;
+    cerr += (((fabs(m0) + fabs(m1)) + fabs(m2)) + fabs(m3)) * fabs(r);
   }
-  // exact path (rare): the reference's expression on the full records
-  Seg s1x;
-  s1x.x1 = a1x; s1x.y1 = a1y; s1x.x2 = b1x; s1x.y2 = b1y;
-  double iou = epipolar_iou(s1x, s2_exact, F);
-  if (iou < cfg.iou_th) return false;
-  return true;
+  // v_min/v_max drop NaN operands: harmless here, a NaN can only come from an infinite term of
+  // `numer`, which makes cerr (hence the margin) infinite or NaN and the outcome "undecided"
+  const double c1v = __builtin_fmin(cv[0], cv[1]), c2v = __builtin_fmax(cv[0], cv[1]);
+  const double num = __builtin_fmin(c2v, 1.0) - __builtin_fmax(c1v, 0.0);
+  const double den = __builtin_fmax(c2v, 1.0) - __builtin_fmin(c1v, 0.0);
+  const double delta = num - cfg.iou_th * den;
+  const double margin = __builtin_fma(1e-12, cerr, 1e-7 * (1.0 + fabs(c1v) + fabs(c2v)) * (1.0 + fabs(cfg.iou_th)));
+  rej |= well & (delta < -margin);
+  und |= !(well & (delta > margin));
+  return rej ? 0 : (und ? 2 : 1);
 }
 
 // Stage B: triangulation, cheirality, sensitivity gate, uncertainty, ranges (:309-333).

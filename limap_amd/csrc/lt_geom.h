@@ -252,6 +252,9 @@ struct GenCfg {
   int use_ranges, use_endpoints, disable_algebraic, pad_;
   // conservative cosine-domain guards for the 1-degree ray/plane gate (see gen kernel)
   double sin_lo, sin_hi;
+  // squared-length guards of the min_length_2d test: q <= len_lo2 certainly fails `sqrt(q) > min_length`,
+  // q > len_hi2 certainly passes it, in between the exact expression decides
+  double len_lo2, len_hi2;
 };
 struct ScoreCfg {
   LinkCfg2 l2;

@@ -2,11 +2,11 @@
 // stage (see DESIGN.md section 3 for the map; lt_kernels.hip keeps the invariant builders, the
 // generic radix-sort grouping, the exhaustive generation and the selection kernels).
 //
-//   k_gen_rows
-//       HOT LOOP 1 in row (block) order: coalesced match rows, the neighbour's segment table staged
-//       in LDS, stage A = cheap gates on every row, stage B = triangulation etc. only for the
-//       survivors, which are first gathered in an LDS queue so that the expensive path runs on full
-//       wave64s.  Valid candidates are appended in row order to per-wave lists.
+//   k_gates + k_tri_rows
+//       HOT LOOP 1 in row (block) order.  k_gates: coalesced match rows, the neighbour's gate table
+//       staged in LDS, cheap three-way gates on every row -> ordered survivor lists.  k_tri_rows:
+//       triangulation etc. for the survivors on dense wave64s -> valid candidates appended in row
+//       order to per-slot lists.
 //   k_node_prefix + k_place (rows of every block sorted by line id -- what limap's matchers write)
 //       Sort-free placement into the reference's candidate order (neighbour-ascending, then
 //       match-row order -- base_line_triangulator.cc:71-103): per-(block, line) counts -> per-node
@@ -21,24 +21,57 @@
 
 #include "lt_devfn.h"
 
+#include <algorithm>
+
 namespace lt {
 
 // ---------------------------------------------------------------------------------------------
 // HOT LOOP 1, row order (triangulateOneNode, base_line_triangulator.cc:161-337)
 // ---------------------------------------------------------------------------------------------
-// grid.y = neighbour block b = (image, neighbour): the image pair, F, baseline and both cameras are
-// wave-uniform (scalar registers).  grid.x * 4 waves * kGenChunks * 64 rows cover the block's rows.
-// The gate fields of the neighbour's 2D segments (plane normal, line coordinates, endpoints: 80 B)
-// are staged once per workgroup in LDS (SoA), since every row of the block indexes that one table.
-//   stage A: cheap gates on every row (gen_gates_fast); survivors are queued (ballot + popcount).
-//   stage B: triangulation / cheirality / sensitivity / uncertainty / ranges on full wave64s.
-// Valid candidates are appended IN ROW ORDER to the wave's own list st_*[r0 ...] (r0 = first row of
-// the wave, capacity = rows per wave); wave_count[] holds the list lengths.  In the fast path the
-// number of valid candidates per (block, line) run is counted in cnt_bl for the placement pass.
-constexpr int kGenChunks = 8;   // 64-row chunks per wave
-constexpr int kGenQCap = 128;   // queue entries per wave (drained whenever >= 64)
+// The rows of neighbour block b = (image, neighbour) are cut into SLOTS of kRowsPerWave rows; one
+// wave owns one slot in every kernel of this stage (slot s of block b: rows m_off[b] + s * kRowsPerWave
+// ..., list index lin = b * n_slots + s).  grid.y = block, so the image pair, F, the baseline and
+// both cameras are wave-uniform (scalar registers).
+//   k_gates     stage A on every row with the three-way cheap gates (gate3): lean, high occupancy.
+//               The neighbour's gate table (SegGate, 80 B per segment) is staged once per workgroup
+//               in LDS.  Per slot an ordered list of surviving rows:
+//               st_row[r0 + k] = (row - r0) | undecided << 31.
+//   k_tri_rows  stage B (triangulation / cheirality / sensitivity / uncertainty / ranges) from those
+//               lists on dense wave64s; rows flagged undecided first go through the exact gates
+//               (gen_gates).  Valid candidates are appended IN ROW ORDER to the slot's list
+//               st_*[r0 ...]; wave_count[] holds the list lengths.  In the fast path the number of
+//               valid candidates per (block, line) run is counted in cnt_bl for the placement pass.
+// Tuning knobs (compile-time; Makefile EXTRA=-D...)
+#ifndef LT_GEN_CHUNKS
+#define LT_GEN_CHUNKS 5
+#endif
+#ifndef LT_GATE_WAVES
+#define LT_GATE_WAVES 8
+#endif
+#ifndef LT_GATE_WAVES_PER_EU
+#define LT_GATE_WAVES_PER_EU 4  // two 8-wave workgroups per CU: the register budget is 128
+#endif
+#define LT_GATE_OCC __attribute__((amdgpu_waves_per_eu(LT_GATE_WAVES_PER_EU, LT_GATE_WAVES_PER_EU)))
+#ifdef LT_SCORE_WAVES_PER_EU
+#define LT_SCORE_OCC __attribute__((amdgpu_waves_per_eu(LT_SCORE_WAVES_PER_EU, LT_SCORE_WAVES_PER_EU)))
+#else
+#define LT_SCORE_OCC
+#endif
+#ifndef LT_SCORE_WIN
+#define LT_SCORE_WIN 128
+#endif
+constexpr int kGenChunks = LT_GEN_CHUNKS;  // 64-row chunks per slot
 constexpr int kRowsPerWave = 64 * kGenChunks;
-constexpr int kRowsPerWG = 4 * kRowsPerWave;
+constexpr int kGateWaves = LT_GATE_WAVES;  // waves (= slots) per k_gates workgroup
+
+#ifdef LT_TRACE
+// developer build: per-wave timestamps (100 MHz wall clock), read back by lt_debug_read_trace
+__device__ unsigned long long g_trace[4 * 4 * 65536];
+#define LT_TRACE_MARK(kern, id, slot) \
+  if (lane_id() == 0 && (id) < 65536u) g_trace[(kern) * 4 * 65536 + 4 * (id) + (slot)] = wall_clock64()
+#else
+#define LT_TRACE_MARK(kern, id, slot)
+#endif
 
 struct GenArgs {
   const long long *m_off;
@@ -47,143 +80,249 @@ struct GenArgs {
   const long long *seg_off;
   const Cam *cams;
   const Seg *segs;
+  const SegGate *gates;
   const PairRec *pairs;
   const long long *blk_line_base;
-  Cand *st_c;
+  unsigned *st_row;       // [P] surviving rows of stage A, per-slot lists at the slot's first row
+  unsigned *surv_count;   // [n_blk * n_slots]
+  Cand *st_c;             // [P] valid candidates, per-slot lists at the slot's first row
   CandLite *st_l;
   unsigned *st_key;       // node id of every staged candidate
-  unsigned *wave_count;   // [n_blk * gridDim.x * 4]
+  unsigned *wave_count;   // [n_blk * n_slots]
   unsigned *cnt_bl;       // valid candidates per (block, line) or nullptr (generic path)
-  int lds_segs;           // capacity (in segments) of the LDS table; 0 = read the gate fields from HBM/L2
+  const struct BlkRec *blk;  // [n_blk]
+  int n_blk;
+  int n_slots;            // slots per block (multiple of kGateWaves)
+  int lds_segs;           // capacity (in segments) of the LDS table T2; 0 = read the gate records from HBM/L2
+  int lds_segs1;          // capacity of T1 (the image's own segments); 0 = gather them from HBM/L2
 };
 
-__global__ void __launch_bounds__(256)
-k_gen_rows(GenArgs a, GenCfg cfg) {
+__global__ void k_build_gates(long long n_segs, const Seg *__restrict__ segs, SegGate *__restrict__ gates) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_segs) seg_gate_build(segs[i], &gates[i]);
+}
+
+// Per-block record: everything the row kernels need to know about neighbour block b in ONE scalar
+// load (instead of the chain m_off[b] / blk_img[b] / blk_nb[b] -> seg_off[...]).
+struct BlkRec {
+  long long rb, re;   // rows of the block
+  long long g1, g2;   // first segment (= node id) of the image / of the neighbour
+  long long lbase;    // first (block, line) counter
+  int M2;             // segments of the neighbour
+  int i1, i2, nbslot; // image, neighbour, position of the neighbour in the image's list
+  int pad_[2];
+};
+static_assert(sizeof(BlkRec) == 64, "BlkRec layout");
+
+__global__ void k_build_blk(int n_blk, const long long *__restrict__ m_off, const int *__restrict__ blk_img,
+                            const int *__restrict__ blk_nb, const int *__restrict__ blk_slot,
+                            const long long *__restrict__ seg_off, const long long *__restrict__ blk_line_base,
+                            BlkRec *__restrict__ out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_blk) return;
+  BlkRec r;
+  r.rb = m_off[b]; r.re = m_off[b + 1];
+  r.i1 = blk_img[b]; r.i2 = blk_nb[b]; r.nbslot = blk_slot[b];
+  r.g1 = seg_off[r.i1]; r.g2 = seg_off[r.i2];
+  r.M2 = (int)(seg_off[r.i2 + 1] - r.g2);
+  r.lbase = blk_line_base[b];
+  r.pad_[0] = r.pad_[1] = 0;
+  out[b] = r;
+}
+
+// Persistent workgroups: workgroup w takes a contiguous range of items, where item = (block, part) and
+// a part is kGateWaves slots.  Both operand tables of an item live in LDS: T1 = the first 80 bytes
+// (endpoints, start / end rays) of the image's own Seg records, reloaded only when the image changes
+// (blocks of one image are consecutive), and T2 = the neighbour's SegGate records.  While an item is
+// being processed the T2 units of the NEXT item are already in flight (held in registers until the
+// table is free), so the chunk loop sees no global latency beyond the (prefetched) match rows.
+// kLds1 / kLds2: compile-time choice of the operand source (LDS table or HBM/L2 gather) -- a run-time
+// choice would merge the two pointers and turn every operand read into a FLAT load.
+template <bool kLds1, bool kLds2>
+__global__ void __launch_bounds__(64 * kGateWaves) LT_GATE_OCC
+k_gates(GenArgs a, GenCfg cfg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  unsigned *q_all = reinterpret_cast<unsigned *>(smem_raw);          // [4][kGenQCap]
-  double *T = reinterpret_cast<double *>(smem_raw + 4 * kGenQCap * 4);  // [10][lds_segs]
+  double2 *T2 = reinterpret_cast<double2 *>(smem_raw);   // [lds_segs][5] : SegGate records of the neighbour
+  double2 *T1 = T2 + (size_t)a.lds_segs * 5;             // [lds_segs1][5]: own segments (x1 y1 x2 y2 rs re)
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  const int n_parts = a.n_slots / kGateWaves;
+  const int n_items = a.n_blk * n_parts;
+  constexpr int kRowsPerPart = kGateWaves * kRowsPerWave;
+  constexpr int kTab = 5;  // 16-byte units of T2 per thread held in flight (5 * 512 threads * 16 B = 40 KB)
+  constexpr int nth = 64 * kGateWaves;
+  const int per_wg = (n_items + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int item_end = min(n_items, ((int)blockIdx.x + 1) * per_wg);
+
+  // next item: record fields (wave-uniform) and table units (in flight)
+  long long n_rb = 0, n_re = 0, n_g1 = 0, n_g2 = 0;
+  int n_M2 = 0, n_i1 = -1;
+  bool n_live = false;
+  double2 tv0, tv1, tv2, tv3, tv4;
+  tv0 = tv1 = tv2 = tv3 = tv4 = double2{0.0, 0.0};
+#define LT_GATES_FETCH(IT)                                                                          \
+  {                                                                                                 \
+    const int it_ = (IT);                                                                           \
+    const int itc_ = it_ < item_end ? it_ : item_end - 1;                                           \
+    const int bb_ = itc_ / n_parts, pp_ = itc_ - bb_ * n_parts;                                     \
+    const BlkRec *rp_ = a.blk + bb_;                                                                \
+    n_rb = rp_->rb; n_re = rp_->re; n_g1 = rp_->g1; n_g2 = rp_->g2; n_M2 = rp_->M2; n_i1 = rp_->i1; \
+    n_live = it_ < item_end && n_rb + (long long)pp_ * kRowsPerPart < n_re;                         \
+    if (kLds2 && n_live) {                                                                          \
+      const double2 *src_ = reinterpret_cast<const double2 *>(a.gates + n_g2);                      \
+      const int units_ = n_M2 * 5;                                                                  \
+      if ((int)threadIdx.x + 0 * nth < units_) tv0 = src_[threadIdx.x + 0 * nth];                   \
+      if ((int)threadIdx.x + 1 * nth < units_) tv1 = src_[threadIdx.x + 1 * nth];                   \
+      if ((int)threadIdx.x + 2 * nth < units_) tv2 = src_[threadIdx.x + 2 * nth];                   \
+      if ((int)threadIdx.x + 3 * nth < units_) tv3 = src_[threadIdx.x + 3 * nth];                   \
+      if ((int)threadIdx.x + 4 * nth < units_) tv4 = src_[threadIdx.x + 4 * nth];                   \
+    }                                                                                               \
+  }
+  int item = (int)blockIdx.x * per_wg;
+  if (item >= item_end) return;
+  int cur_i1 = -1;       // image whose segments are in T1
+  LT_GATES_FETCH(item);
+  for (; item < item_end; ++item) {
+    const long long rb = n_rb, re = n_re, g1 = n_g1, g2 = n_g2;
+    const int M2 = n_M2, i1 = n_i1;
+    const bool live = n_live;
+    const int b = item / n_parts, part = item - b * n_parts;
+    const int slot = part * kGateWaves + wave;
+    const unsigned lin = (unsigned)b * (unsigned)a.n_slots + (unsigned)slot;
+    LT_TRACE_MARK(0, lin, 0);
+    if (live) {
+      const bool new_img = kLds1 && i1 != cur_i1;
+      if (kLds2 || new_img) __syncthreads();  // the previous item's readers are done with the tables
+      if (kLds2) {
+        const int units = M2 * 5;
+        if ((int)threadIdx.x + 0 * nth < units) T2[threadIdx.x + 0 * nth] = tv0;
+        if ((int)threadIdx.x + 1 * nth < units) T2[threadIdx.x + 1 * nth] = tv1;
+        if ((int)threadIdx.x + 2 * nth < units) T2[threadIdx.x + 2 * nth] = tv2;
+        if ((int)threadIdx.x + 3 * nth < units) T2[threadIdx.x + 3 * nth] = tv3;
+        if ((int)threadIdx.x + 4 * nth < units) T2[threadIdx.x + 4 * nth] = tv4;
+        for (int u = threadIdx.x + kTab * nth; u < units; u += nth)  // tables beyond one pass (rare)
+          T2[u] = reinterpret_cast<const double2 *>(a.gates + g2)[u];
+      }
+      if (new_img) {
+        cur_i1 = i1;
+        const int M1 = (int)(a.seg_off[i1 + 1] - g1);
+        for (int u = threadIdx.x; u < M1 * 5; u += nth) {
+          const int sidx = u / 5, k = u - sidx * 5;
+          T1[u] = reinterpret_cast<const double2 *>(a.segs + g1 + sidx)[k];
+        }
+      }
+      if (kLds2 || new_img) __syncthreads();
+    }
+    LT_GATES_FETCH(item + 1);
+    LT_TRACE_MARK(0, lin, 1);
+    const long long r0 = rb + (long long)slot * kRowsPerWave;
+    unsigned wcount = 0;
+    if (live && r0 < re) {
+      const double *F = (a.pairs + b)->F;
+      int line_n = -1, ng_n = 0;
+      {
+        long long r = r0 + lane;
+        if (r < re) {
+          const int2 v = *reinterpret_cast<const int2 *>(a.m_pairs + 2 * r);
+          line_n = v.x; ng_n = v.y;
+        }
+      }
+      for (int c = 0; c < kGenChunks; ++c) {
+        const int line = line_n, ng = ng_n;
+        line_n = -1;
+        {  // next chunk's rows
+          long long r = r0 + 64ll * (c + 1) + lane;
+          if (c + 1 < kGenChunks && r < re) {
+            const int2 v = *reinterpret_cast<const int2 *>(a.m_pairs + 2 * r);
+            line_n = v.x; ng_n = v.y;
+          }
+        }
+        int res = 0;
+        if (line >= 0) {
+          // separate LDS / global code paths: a selected pointer would turn these into FLAT loads
+          double2 e0, e1, e2, e3, e4, h0, h1, h2, h3, h4;
+          if (kLds1) {
+            const double2 *p1 = T1 + line * 5;
+            e0 = p1[0]; e1 = p1[1]; e2 = p1[2]; e3 = p1[3]; e4 = p1[4];
+          } else {
+            const double2 *p1 = reinterpret_cast<const double2 *>(a.segs + g1 + line);
+            e0 = p1[0]; e1 = p1[1]; e2 = p1[2]; e3 = p1[3]; e4 = p1[4];
+          }
+          if (kLds2) {
+            const double2 *p2 = T2 + ng * 5;
+            h0 = p2[0]; h1 = p2[1]; h2 = p2[2]; h3 = p2[3]; h4 = p2[4];
+          } else {
+            const double2 *p2 = reinterpret_cast<const double2 *>(a.gates + g2 + ng);
+            h0 = p2[0]; h1 = p2[1]; h2 = p2[2]; h3 = p2[3]; h4 = p2[4];
+          }
+          res = gate3(cfg, e0.x, e0.y, e1.x, e1.y, e2.x, e2.y, e3.x, e3.y, e4.x, e4.y,  // l1: endpoints, rs, re
+                      h0.x, h0.y, h1.x, h1.y, h2.x, h2.y, h3.x, h3.y, h4.x, h4.y, F);   // l2: SegGate fields
+        }
+        const unsigned long long m = __ballot(res != 0);
+        if (res != 0)
+          a.st_row[r0 + wcount + __popcll(m & lanemask_lt())] =
+              (unsigned)(64 * c + lane) | (res == 2 ? 0x80000000u : 0u);
+        wcount += (unsigned)__popcll(m);
+        if (r0 + 64ll * (c + 1) >= re) break;
+      }
+    }
+    LT_TRACE_MARK(0, lin, 2);
+    if (lane == 0) a.surv_count[lin] = wcount;
+  }
+#undef LT_GATES_FETCH
+}
+
+__global__ void __launch_bounds__(256)
+k_tri_rows(GenArgs a, GenCfg cfg) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
+  const int slot = blockIdx.x * 4 + wave;
+  if (slot >= a.n_slots) return;
   const long long rb = a.m_off[b], re = a.m_off[b + 1];
-  const int i1 = a.blk_img[b], i2 = a.blk_nb[b], slot = a.blk_slot[b];
-  const long long g1 = a.seg_off[i1], g2 = a.seg_off[i2];
-  const int M2 = (int)(a.seg_off[i2 + 1] - g2);
-  const long long wg_r0 = rb + (long long)blockIdx.x * kRowsPerWG;
-  const unsigned lin = ((unsigned)b * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
-  if (wg_r0 >= re) {  // nothing for this workgroup (grid.x is sized by the largest block)
+  const long long r0 = rb + (long long)slot * kRowsPerWave;
+  const unsigned lin = (unsigned)b * (unsigned)a.n_slots + (unsigned)slot;
+  LT_TRACE_MARK(1, lin, 0);
+  if (r0 >= re) {
     if (lane == 0) a.wave_count[lin] = 0;
     return;
   }
-  const bool use_lds = a.lds_segs >= M2;
-  const int ts = a.lds_segs;  // table stride
-  if (use_lds) {
-    for (int s = threadIdx.x; s < M2; s += blockDim.x) {
-      const Seg &sg = a.segs[g2 + s];
-      T[0 * ts + s] = sg.n[0]; T[1 * ts + s] = sg.n[1]; T[2 * ts + s] = sg.n[2];
-      T[3 * ts + s] = sg.lc[0]; T[4 * ts + s] = sg.lc[1]; T[5 * ts + s] = sg.lc[2];
-      T[6 * ts + s] = sg.x1; T[7 * ts + s] = sg.y1; T[8 * ts + s] = sg.x2; T[9 * ts + s] = sg.y2;
-    }
-    __syncthreads();
-  }
-  const long long r0 = wg_r0 + (long long)wave * kRowsPerWave;
+  const int i1 = a.blk_img[b], i2 = a.blk_nb[b], nbslot = a.blk_slot[b];
+  const long long g1 = a.seg_off[i1], g2 = a.seg_off[i2];
+  const PairRec *pr = a.pairs + b;
+  const long long lbase = a.cnt_bl ? a.blk_line_base[b] : 0;
+  const unsigned n_s = a.surv_count[lin];
   unsigned wcount = 0;
-  if (r0 < re) {
-    const PairRec *pr = a.pairs + b;
-    const long long lbase = a.cnt_bl ? a.blk_line_base[b] : 0;
-    unsigned *qr = q_all + wave * kGenQCap;
-    int qn = 0;
-
-    auto stage_b = [&](int count) {  // lanes 0..count-1 finish one surviving connection each
-      bool ok = false;
-      GenOut o;
-      int line = 0;
-      if (lane < count) {
-        unsigned r = qr[lane];
-        line = a.m_pairs[2 * (long long)r];
-        int ng = a.m_pairs[2 * (long long)r + 1];
-        ok = gen_finish(cfg, a.cams[i1], a.cams[i2], a.segs[g1 + line], a.segs[g2 + ng], pr->B, &o);
-        o.l.nb_slot = lite_pack(slot, i2);
-        o.l.ng_line = ng;
-      }
-      unsigned long long m = __ballot(ok);
-      if (ok) {
-        long long p = r0 + wcount + __popcll(m & lanemask_lt());
-        a.st_c[p] = o.c;
-        a.st_l[p] = o.l;
-        a.st_key[p] = (unsigned)(g1 + line);
-        if (a.cnt_bl) atomicAdd(&a.cnt_bl[lbase + line], 1u);
-      }
-      wcount += (unsigned)__popcll(m);
-    };
-
-    // Software pipeline over the 64-row chunks: the match rows are fetched two chunks ahead and the
-    // image's own segment (gather by line id) one chunk ahead, so that neither global round trip sits
-    // on the critical path of the gate arithmetic.
-    auto load_rows = [&](int c, int *line, int *ng) {
-      long long r = r0 + 64ll * c + lane;
-      *line = -1;
-      *ng = 0;
-      if (c < kGenChunks && r < re) {
-        const int2 v = *reinterpret_cast<const int2 *>(a.m_pairs + 2 * r);
-        *line = v.x;
-        *ng = v.y;
-      }
-    };
-    struct S1 { double x1, y1, x2, y2, rs[3], re[3]; };
-    auto load_s1 = [&](int line, S1 *o) {
-      if (line >= 0) {
-        const Seg &s = a.segs[g1 + line];
-        o->x1 = s.x1; o->y1 = s.y1; o->x2 = s.x2; o->y2 = s.y2;
-        o->rs[0] = s.rs[0]; o->rs[1] = s.rs[1]; o->rs[2] = s.rs[2];
-        o->re[0] = s.re[0]; o->re[1] = s.re[1]; o->re[2] = s.re[2];
-      }
-    };
-    int line_c, ng_c, line_n, ng_n, line_nn = -1, ng_nn = 0;
-    S1 cur, nxt;
-    load_rows(0, &line_c, &ng_c);
-    load_rows(1, &line_n, &ng_n);
-    load_s1(line_c, &cur);
-    for (int c = 0; c < kGenChunks; ++c) {
-      load_rows(c + 2, &line_nn, &ng_nn);
-      load_s1(line_n, &nxt);
-      const long long r = r0 + 64ll * c + lane;
-      bool pass = false;
-      if (line_c >= 0) {
-        const int ng = ng_c;
-        if (use_lds) {
-          pass = gen_gates_fast(cfg, cur.x1, cur.y1, cur.x2, cur.y2, cur.rs, cur.re, T[0 * ts + ng], T[1 * ts + ng],
-                                T[2 * ts + ng], T[3 * ts + ng], T[4 * ts + ng], T[5 * ts + ng], T[6 * ts + ng],
-                                T[7 * ts + ng], T[8 * ts + ng], T[9 * ts + ng], pr->F, a.segs[g2 + ng]);
-        } else {
-          const Seg &s2 = a.segs[g2 + ng];
-          pass = gen_gates_fast(cfg, cur.x1, cur.y1, cur.x2, cur.y2, cur.rs, cur.re, s2.n[0], s2.n[1], s2.n[2],
-                                s2.lc[0], s2.lc[1], s2.lc[2], s2.x1, s2.y1, s2.x2, s2.y2, pr->F, s2);
-        }
-      }
-      cur = nxt;
-      line_c = line_n; ng_c = ng_n;
-      line_n = line_nn; ng_n = ng_nn;
-      unsigned long long m = __ballot(pass);
-      if (m) {
-        if (pass) qr[qn + __popcll(m & lanemask_lt())] = (unsigned)r;
-        qn += __popcll(m);
-        wave_lds_sync();
-        while (qn >= 64) {  // process the oldest 64, shift the rest down
-          stage_b(64);
-          wave_lds_sync();
-          int rest = qn - 64;
-          unsigned tr = 0;
-          if (lane < rest) tr = qr[64 + lane];
-          wave_lds_sync();
-          if (lane < rest) qr[lane] = tr;
-          wave_lds_sync();
-          qn = rest;
-        }
-      }
+  for (unsigned e0 = 0; e0 < n_s; e0 += 64) {
+    const unsigned e = e0 + lane;
+    bool ok = false;
+    GenOut o;
+    int line = 0;
+    if (e < n_s) {
+      const unsigned u = a.st_row[r0 + e];
+      const long long r = r0 + (long long)(u & 0x7FFFFFFFu);
+      const int2 v = *reinterpret_cast<const int2 *>(a.m_pairs + 2 * r);
+      line = v.x;
+      const int ng = v.y;
+      const Seg &s1 = a.segs[g1 + line];
+      const Seg &s2 = a.segs[g2 + ng];
+      ok = true;
+      if (u >> 31) ok = gen_gates(cfg, s1, s2, pr->F);  // the cheap gates could not decide
+      if (ok) ok = gen_finish(cfg, a.cams[i1], a.cams[i2], s1, s2, pr->B, &o);
+      o.l.nb_slot = lite_pack(nbslot, i2);
+      o.l.ng_line = ng;
     }
-    if (qn > 0) stage_b(qn);
+    const unsigned long long m = __ballot(ok);
+    if (ok) {
+      const long long p = r0 + wcount + __popcll(m & lanemask_lt());
+      a.st_c[p] = o.c;
+      a.st_l[p] = o.l;
+      a.st_key[p] = (unsigned)(g1 + line);
+      if (a.cnt_bl) atomicAdd(&a.cnt_bl[lbase + line], 1u);
+    }
+    wcount += (unsigned)__popcll(m);
   }
+  LT_TRACE_MARK(1, lin, 2);
   if (lane == 0) a.wave_count[lin] = wcount;
 }
 
@@ -211,7 +350,7 @@ __global__ void k_node_prefix(long long G, const int *__restrict__ node_img,
 
 // Fast path: move every staged candidate to its final, reference-ordered position
 //   pos = tri_off[node] + (valid candidates of the node in earlier neighbour blocks) + rank in its run.
-// Same 2D grid as k_gen_rows; one wave per generation wave.  Rows of a block are sorted by line id,
+// One wave per slot.  Rows of a block are sorted by line id,
 // so the candidates of one (block, line) run are adjacent in the row-ordered lists; the rank is
 // found by looking back over equal keys (crossing into the previous wave's list if the run does).
 __global__ void __launch_bounds__(256)
@@ -220,14 +359,16 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
         const unsigned *__restrict__ base_bl, const unsigned *__restrict__ wave_count,
         const long long *__restrict__ tri_off, const Cand *__restrict__ st_c,
         const CandLite *__restrict__ st_l, const unsigned *__restrict__ st_key, Cand *__restrict__ cand,
-        CandLite *__restrict__ lite, unsigned *__restrict__ cand_node) {
+        CandLite *__restrict__ lite, unsigned *__restrict__ cand_node, int n_slots) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
+  const int slot = blockIdx.x * 4 + wave;
+  if (slot >= n_slots) return;
   const long long rb = m_off[b], re = m_off[b + 1];
-  const long long r0 = rb + (long long)blockIdx.x * kRowsPerWG + (long long)wave * kRowsPerWave;
+  const long long r0 = rb + (long long)slot * kRowsPerWave;
   if (r0 >= re) return;
-  const unsigned lin = ((unsigned)b * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
+  const unsigned lin = (unsigned)b * (unsigned)n_slots + (unsigned)slot;
   const unsigned count = wave_count[lin];
   if (count == 0) return;
   const long long g1 = seg_off[blk_img[b]];
@@ -272,14 +413,16 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
 __global__ void __launch_bounds__(256)
 k_pack_keys(const long long *__restrict__ m_off, const unsigned *__restrict__ wave_count,
             const long long *__restrict__ wave_pos, const unsigned *__restrict__ st_key,
-            unsigned *__restrict__ keys_c, unsigned *__restrict__ src_c) {
+            unsigned *__restrict__ keys_c, unsigned *__restrict__ src_c, int n_slots) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
+  const int slot = blockIdx.x * 4 + wave;
+  if (slot >= n_slots) return;
   const long long rb = m_off[b], re = m_off[b + 1];
-  const long long r0 = rb + (long long)blockIdx.x * kRowsPerWG + (long long)wave * kRowsPerWave;
+  const long long r0 = rb + (long long)slot * kRowsPerWave;
   if (r0 >= re) return;
-  const unsigned lin = ((unsigned)b * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
+  const unsigned lin = (unsigned)b * (unsigned)n_slots + (unsigned)slot;
   const unsigned count = wave_count[lin];
   const long long base = wave_pos[lin];
   for (unsigned e = lane; e < count; e += 64) {
@@ -345,7 +488,7 @@ k_cand_node(long long G, const long long *__restrict__ tri_off, unsigned *__rest
 // per-neighbour-image maxima live in LDS (ds_max_u64 on the bit pattern of the non-negative scores)
 // and are summed per lane in ascending image-id order (std::map order, :110-112).
 constexpr int kSQCap = 192;
-constexpr int kWin = 128;
+constexpr int kWin = LT_SCORE_WIN;
 
 struct Score3Args {
   long long G;
@@ -360,7 +503,7 @@ struct Score3Args {
   int max_nb;
 };
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) LT_SCORE_OCC
 k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x;
@@ -503,20 +646,58 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
 // ---------------------------------------------------------------------------------------------
 static inline unsigned nblk2(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
-unsigned gen_grid_x(long long max_rows) { return nblk2(max_rows, kRowsPerWG); }
-size_t gen_lds_bytes(int lds_segs) { return 4 * kGenQCap * 4 + (size_t)lds_segs * 80; }
-void launch_gen_rows(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
-                     const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
-                     const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
-                     const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
-                     unsigned *wave_count, unsigned *cnt_bl, int lds_segs) {
+// slots per block: enough for the largest block, a multiple of the k_gates workgroup
+int gen_slots(long long max_rows) {
+  long long n = (max_rows + kRowsPerWave - 1) / kRowsPerWave;
+  n = (n + kGateWaves - 1) / kGateWaves * kGateWaves;
+  return (int)n;
+}
+#ifdef LT_TRACE
+extern "C" int lt_debug_read_trace(unsigned long long *host, size_t n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), n * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
+size_t seg_gate_bytes() { return sizeof(SegGate); }
+size_t blk_rec_bytes() { return sizeof(BlkRec); }
+// HOT LOOP 1: k_build_gates + k_gates (survivor lists) + k_tri_rows (candidate lists)
+void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
+                      const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
+                      const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
+                      const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
+                      unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, unsigned *st_row,
+                      unsigned *surv_count, long long n_segs, void *gates, void *blkrec) {
   if (n_blk <= 0 || max_rows <= 0) return;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+      n_cu = 256;
+  }
+  hipLaunchKernelGGL(k_build_blk, dim3(nblk2(n_blk, 128)), dim3(128), 0, st, n_blk, m_off, blk_img, blk_nb, blk_slot,
+                     seg_off, blk_line_base, reinterpret_cast<BlkRec *>(blkrec));
+  hipLaunchKernelGGL(k_build_gates, dim3(nblk2(n_segs, 256)), dim3(256), 0, st, n_segs, segs,
+                     reinterpret_cast<SegGate *>(gates));
   GenArgs a;
   a.m_off = m_off; a.m_pairs = m_pairs; a.blk_img = blk_img; a.blk_nb = blk_nb; a.blk_slot = blk_slot;
-  a.seg_off = seg_off; a.cams = cams; a.segs = segs; a.pairs = pairs; a.blk_line_base = blk_line_base;
+  a.seg_off = seg_off; a.cams = cams; a.segs = segs; a.gates = reinterpret_cast<const SegGate *>(gates);
+  a.pairs = pairs; a.blk_line_base = blk_line_base; a.st_row = st_row; a.surv_count = surv_count;
   a.st_c = st_c; a.st_l = st_l; a.st_key = st_key; a.wave_count = wave_count; a.cnt_bl = cnt_bl;
-  a.lds_segs = lds_segs;
-  hipLaunchKernelGGL(k_gen_rows, dim3(gen_grid_x(max_rows), n_blk), dim3(256), gen_lds_bytes(lds_segs), st, a, cfg);
+  a.n_slots = gen_slots(max_rows); a.lds_segs = lds_segs; a.lds_segs1 = lds_segs1;
+  a.blk = reinterpret_cast<const BlkRec *>(blkrec); a.n_blk = n_blk;
+  // persistent grid: as many workgroups as fit at once (registers allow 16 waves per CU)
+  const long long n_items = (long long)n_blk * (a.n_slots / kGateWaves);
+  const size_t lds = (size_t)(lds_segs + lds_segs1) * sizeof(SegGate);
+  int per_cu = std::max(16 / kGateWaves, 1);
+  if (lds > 0) per_cu = (int)std::max<size_t>(std::min<size_t>(160 * 1024 / lds, (size_t)per_cu), 1);
+  const unsigned n_wg = (unsigned)std::min<long long>(n_items, (long long)n_cu * per_cu);
+  // the tables are sized by the largest image of the job, so "fits" is a per-launch property
+  const dim3 grid(n_wg), block(64 * kGateWaves);
+  if (lds_segs1 > 0 && lds_segs > 0) hipLaunchKernelGGL((k_gates<true, true>), grid, block, lds, st, a, cfg);
+  else if (lds_segs > 0) hipLaunchKernelGGL((k_gates<false, true>), grid, block, lds, st, a, cfg);
+  else if (lds_segs1 > 0) hipLaunchKernelGGL((k_gates<true, false>), grid, block, lds, st, a, cfg);
+  else hipLaunchKernelGGL((k_gates<false, false>), grid, block, lds, st, a, cfg);
+  hipLaunchKernelGGL(k_tri_rows, dim3(nblk2(a.n_slots, 4), n_blk), dim3(256), 0, st, a, cfg);
 }
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
@@ -529,15 +710,17 @@ void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long
                   const unsigned *wave_count, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
                   const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node) {
   if (n_blk <= 0 || max_rows <= 0) return;
-  hipLaunchKernelGGL(k_place, dim3(gen_grid_x(max_rows), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
-                     blk_line_base, base_bl, wave_count, tri_off, st_c, st_l, st_key, cand, lite, cand_node);
+  const int n_slots = gen_slots(max_rows);
+  hipLaunchKernelGGL(k_place, dim3(nblk2(n_slots, 4), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
+                     blk_line_base, base_bl, wave_count, tri_off, st_c, st_l, st_key, cand, lite, cand_node, n_slots);
 }
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
                       unsigned *keys_c, unsigned *src_c) {
   if (n_blk <= 0 || max_rows <= 0) return;
-  hipLaunchKernelGGL(k_pack_keys, dim3(gen_grid_x(max_rows), n_blk), dim3(256), 0, st, m_off, wave_count, wave_pos,
-                     st_key, keys_c, src_c);
+  const int n_slots = gen_slots(max_rows);
+  hipLaunchKernelGGL(k_pack_keys, dim3(nblk2(n_slots, 4), n_blk), dim3(256), 0, st, m_off, wave_count, wave_pos,
+                     st_key, keys_c, src_c, n_slots);
 }
 void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const Cand *st_c,
                     const CandLite *st_l, Cand *cand, CandLite *lite, unsigned *cand_node) {
