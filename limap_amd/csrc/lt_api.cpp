@@ -28,6 +28,7 @@ namespace lt {
 void launch_fn_query(hipStream_t st, const double *in30, int by_endpoints, double *out32);
 // lt_kernels_v2.hip
 int gen_slots(long long max_rows);
+int gen_groups(long long max_rows);
 size_t seg_gate_bytes();
 size_t blk_rec_bytes();
 void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
@@ -715,7 +716,8 @@ int lt_run_device(lt_ctx *ctx) {
   if (ctx->job_mode == 1) {
     const size_t Pn = (size_t)std::max<long long>(P, 1);
     const bool fast = ctx->rows_sorted;
-    const long long n_waves = (long long)ctx->n_blk * gen_slots(ctx->max_rows);
+    const long long n_waves = (long long)ctx->n_blk * gen_groups(ctx->max_rows);  // candidate lists
+    const long long n_slots_all = (long long)ctx->n_blk * gen_slots(ctx->max_rows);  // survivor lists
     const long long n_entries = ctx->h_blk_line_base[ctx->n_blk];
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
     // ---- generation in row order; valid candidates appended in row order to per-wave lists ----
@@ -735,7 +737,7 @@ int lt_run_device(lt_ctx *ctx) {
     if (lds_segs + lds_segs1 > 2048) lds_segs1 = 0;
     {
       ENSURE(ctx, ctx->d_st_row, 4 * Pn);
-      ENSURE(ctx, ctx->d_surv_count, 4 * (size_t)(n_waves + 1));
+      ENSURE(ctx, ctx->d_surv_count, 4 * (size_t)(n_slots_all + 1));
       ENSURE(ctx, ctx->d_seg_gates, seg_gate_bytes() * (size_t)std::max<long long>(G, 1));
       ENSURE(ctx, ctx->d_blkrec, blk_rec_bytes() * (size_t)std::max(ctx->n_blk, 1));
       launch_gen_split(st, ctx->n_blk, ctx->max_rows, gcfg, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),

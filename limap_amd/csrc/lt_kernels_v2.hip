@@ -63,6 +63,14 @@ namespace lt {
 constexpr int kGenChunks = LT_GEN_CHUNKS;  // 64-row chunks per slot
 constexpr int kRowsPerWave = 64 * kGenChunks;
 constexpr int kGateWaves = LT_GATE_WAVES;  // waves (= slots) per k_gates workgroup
+// Stage B and the placement work on GROUPS of kTriSlots consecutive slots (one wave per group): the
+// survivors of one slot (~10 % of its rows) would fill only a fraction of a wave64.
+#ifndef LT_TRI_SLOTS
+#define LT_TRI_SLOTS 4
+#endif
+constexpr int kTriSlots = LT_TRI_SLOTS;
+constexpr int kTriRows = kTriSlots * kRowsPerWave;
+static_assert(kGateWaves % kTriSlots == 0, "a group must not straddle k_gates workgroups' slot ranges");
 
 #ifdef LT_TRACE
 // developer build: per-wave timestamps (100 MHz wall clock), read back by lt_debug_read_trace
@@ -272,26 +280,36 @@ k_gates(GenArgs a, GenCfg cfg) {
 #undef LT_GATES_FETCH
 }
 
+// One wave per (block, group).  (A persistent-wave variant with the next item's record prefetched was
+// measured slower: the kernel is bound by gather / scatter throughput, not by latency.)
 __global__ void __launch_bounds__(256)
 k_tri_rows(GenArgs a, GenCfg cfg) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
-  const int slot = blockIdx.x * 4 + wave;
-  if (slot >= a.n_slots) return;
-  const long long rb = a.m_off[b], re = a.m_off[b + 1];
-  const long long r0 = rb + (long long)slot * kRowsPerWave;
-  const unsigned lin = (unsigned)b * (unsigned)a.n_slots + (unsigned)slot;
+  const int n_groups = a.n_slots / kTriSlots;
+  const int g = blockIdx.x * 4 + wave;
+  if (g >= n_groups) return;
+  const BlkRec *rec = a.blk + b;
+  const long long rb = rec->rb, re = rec->re;
+  const long long r0 = rb + (long long)g * kTriRows;
+  const unsigned lin = (unsigned)b * (unsigned)n_groups + (unsigned)g;
   LT_TRACE_MARK(1, lin, 0);
   if (r0 >= re) {
     if (lane == 0) a.wave_count[lin] = 0;
     return;
   }
-  const int i1 = a.blk_img[b], i2 = a.blk_nb[b], nbslot = a.blk_slot[b];
-  const long long g1 = a.seg_off[i1], g2 = a.seg_off[i2];
+  const int i1 = rec->i1, i2 = rec->i2, nbslot = rec->nbslot;
+  const long long g1 = rec->g1, g2 = rec->g2;
   const PairRec *pr = a.pairs + b;
-  const long long lbase = a.cnt_bl ? a.blk_line_base[b] : 0;
-  const unsigned n_s = a.surv_count[lin];
+  const long long lbase = a.cnt_bl ? rec->lbase : 0;
+  // survivor lists of the group's slots, walked as one concatenated list
+  unsigned cs[kTriSlots + 1];
+  cs[0] = 0;
+#pragma unroll
+  for (int k = 0; k < kTriSlots; ++k)
+    cs[k + 1] = cs[k] + a.surv_count[(size_t)b * a.n_slots + (size_t)g * kTriSlots + k];
+  const unsigned n_s = cs[kTriSlots];
   unsigned wcount = 0;
   for (unsigned e0 = 0; e0 < n_s; e0 += 64) {
     const unsigned e = e0 + lane;
@@ -299,8 +317,14 @@ k_tri_rows(GenArgs a, GenCfg cfg) {
     GenOut o;
     int line = 0;
     if (e < n_s) {
-      const unsigned u = a.st_row[r0 + e];
-      const long long r = r0 + (long long)(u & 0x7FFFFFFFu);
+      int k = 0;
+      unsigned first = 0;
+#pragma unroll
+      for (int t = 1; t < kTriSlots; ++t)
+        if (e >= cs[t]) { k = t; first = cs[t]; }
+      const long long rs0 = r0 + (long long)k * kRowsPerWave;
+      const unsigned u = a.st_row[rs0 + (e - first)];
+      const long long r = rs0 + (long long)(u & 0x7FFFFFFFu);
       const int2 v = *reinterpret_cast<const int2 *>(a.m_pairs + 2 * r);
       line = v.x;
       const int ng = v.y;
@@ -308,17 +332,27 @@ k_tri_rows(GenArgs a, GenCfg cfg) {
       const Seg &s2 = a.segs[g2 + ng];
       ok = true;
       if (u >> 31) ok = gen_gates(cfg, s1, s2, pr->F);  // the cheap gates could not decide
+#if defined(LT_X_NOFINISH)
+      if (ok) { ok = ((line + ng) & 1) == 0; o.c.s[0] = s1.rs[0] + s2.re[1]; o.c.e[0] = s1.re[2] + s2.rs[0]; o.l.dir[0] = s2.x1; }
+#else
       if (ok) ok = gen_finish(cfg, a.cams[i1], a.cams[i2], s1, s2, pr->B, &o);
+#endif
       o.l.nb_slot = lite_pack(nbslot, i2);
       o.l.ng_line = ng;
     }
     const unsigned long long m = __ballot(ok);
     if (ok) {
       const long long p = r0 + wcount + __popcll(m & lanemask_lt());
+#if defined(LT_X_NOSTORE)
+      a.st_c[p].s[0] = o.c.s[0] + o.c.e[0] + o.l.dir[0];
+#else
       a.st_c[p] = o.c;
       a.st_l[p] = o.l;
+#endif
       a.st_key[p] = (unsigned)(g1 + line);
+#if !defined(LT_X_NOATOMIC)
       if (a.cnt_bl) atomicAdd(&a.cnt_bl[lbase + line], 1u);
+#endif
     }
     wcount += (unsigned)__popcll(m);
   }
@@ -359,16 +393,16 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
         const unsigned *__restrict__ base_bl, const unsigned *__restrict__ wave_count,
         const long long *__restrict__ tri_off, const Cand *__restrict__ st_c,
         const CandLite *__restrict__ st_l, const unsigned *__restrict__ st_key, Cand *__restrict__ cand,
-        CandLite *__restrict__ lite, unsigned *__restrict__ cand_node, int n_slots) {
+        CandLite *__restrict__ lite, unsigned *__restrict__ cand_node, int n_groups) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
-  const int slot = blockIdx.x * 4 + wave;
-  if (slot >= n_slots) return;
+  const int g = blockIdx.x * 4 + wave;
+  if (g >= n_groups) return;
   const long long rb = m_off[b], re = m_off[b + 1];
-  const long long r0 = rb + (long long)slot * kRowsPerWave;
+  const long long r0 = rb + (long long)g * kTriRows;
   if (r0 >= re) return;
-  const unsigned lin = (unsigned)b * (unsigned)n_slots + (unsigned)slot;
+  const unsigned lin = (unsigned)b * (unsigned)n_groups + (unsigned)g;
   const unsigned count = wave_count[lin];
   if (count == 0) return;
   const long long g1 = seg_off[blk_img[b]];
@@ -389,8 +423,8 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
           --idx;
         }
         if (idx >= 0) break;                 // a different key precedes: run starts inside this list
-        if (cur_r0 - kRowsPerWave < rb) break;  // first wave of the block
-        cur_r0 -= kRowsPerWave;
+        if (cur_r0 - kTriRows < rb) break;  // first group of the block
+        cur_r0 -= kTriRows;
         cur_lin -= 1;
         unsigned pc = wave_count[cur_lin];
         if (pc == 0) {
@@ -413,16 +447,16 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
 __global__ void __launch_bounds__(256)
 k_pack_keys(const long long *__restrict__ m_off, const unsigned *__restrict__ wave_count,
             const long long *__restrict__ wave_pos, const unsigned *__restrict__ st_key,
-            unsigned *__restrict__ keys_c, unsigned *__restrict__ src_c, int n_slots) {
+            unsigned *__restrict__ keys_c, unsigned *__restrict__ src_c, int n_groups) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
-  const int slot = blockIdx.x * 4 + wave;
-  if (slot >= n_slots) return;
+  const int g = blockIdx.x * 4 + wave;
+  if (g >= n_groups) return;
   const long long rb = m_off[b], re = m_off[b + 1];
-  const long long r0 = rb + (long long)slot * kRowsPerWave;
+  const long long r0 = rb + (long long)g * kTriRows;
   if (r0 >= re) return;
-  const unsigned lin = (unsigned)b * (unsigned)n_slots + (unsigned)slot;
+  const unsigned lin = (unsigned)b * (unsigned)n_groups + (unsigned)g;
   const unsigned count = wave_count[lin];
   const long long base = wave_pos[lin];
   for (unsigned e = lane; e < count; e += 64) {
@@ -652,6 +686,8 @@ int gen_slots(long long max_rows) {
   n = (n + kGateWaves - 1) / kGateWaves * kGateWaves;
   return (int)n;
 }
+// groups per block (lists of stage B / placement): wave_count[] has n_blk * gen_groups entries
+int gen_groups(long long max_rows) { return gen_slots(max_rows) / kTriSlots; }
 #ifdef LT_TRACE
 extern "C" int lt_debug_read_trace(unsigned long long *host, size_t n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), n * 8, 0, hipMemcpyDeviceToHost);
@@ -697,7 +733,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   else if (lds_segs > 0) hipLaunchKernelGGL((k_gates<false, true>), grid, block, lds, st, a, cfg);
   else if (lds_segs1 > 0) hipLaunchKernelGGL((k_gates<true, false>), grid, block, lds, st, a, cfg);
   else hipLaunchKernelGGL((k_gates<false, false>), grid, block, lds, st, a, cfg);
-  hipLaunchKernelGGL(k_tri_rows, dim3(nblk2(a.n_slots, 4), n_blk), dim3(256), 0, st, a, cfg);
+  hipLaunchKernelGGL(k_tri_rows, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg);
 }
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
@@ -710,17 +746,17 @@ void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long
                   const unsigned *wave_count, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
                   const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node) {
   if (n_blk <= 0 || max_rows <= 0) return;
-  const int n_slots = gen_slots(max_rows);
-  hipLaunchKernelGGL(k_place, dim3(nblk2(n_slots, 4), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
-                     blk_line_base, base_bl, wave_count, tri_off, st_c, st_l, st_key, cand, lite, cand_node, n_slots);
+  const int n_groups = gen_groups(max_rows);
+  hipLaunchKernelGGL(k_place, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
+                     blk_line_base, base_bl, wave_count, tri_off, st_c, st_l, st_key, cand, lite, cand_node, n_groups);
 }
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
                       unsigned *keys_c, unsigned *src_c) {
   if (n_blk <= 0 || max_rows <= 0) return;
-  const int n_slots = gen_slots(max_rows);
-  hipLaunchKernelGGL(k_pack_keys, dim3(nblk2(n_slots, 4), n_blk), dim3(256), 0, st, m_off, wave_count, wave_pos,
-                     st_key, keys_c, src_c, n_slots);
+  const int n_groups = gen_groups(max_rows);
+  hipLaunchKernelGGL(k_pack_keys, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, wave_count, wave_pos,
+                     st_key, keys_c, src_c, n_groups);
 }
 void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const Cand *st_c,
                     const CandLite *st_l, Cand *cand, CandLite *lite, unsigned *cand_node) {
