@@ -202,8 +202,15 @@ int lt_get_stats(lt_ctx *ctx, int64_t out[8]);
 /* HIP-event timings (ms) of the last lt_run_device on the context's stream:
  * [0] whole run, [1] invariants, [2] connection sort, [3] generation, [4] compaction,
  * [5] scoring kernel, [6] selection + edges, [7] gather; host: [8] upload, [9] download,
- * [10] tail (lt_compute_tracks); [11] candidate pairs that reached the dense evaluation in k_score3 */
+ * [10] tail (lt_compute_tracks); [11] candidate pairs that reached the dense evaluation in k_score3;
+ * [12] host ms spent inside lt_triangulate_image* buffering the match rows of the batch */
 int lt_get_timers(lt_ctx *ctx, double out[16]);
+
+/* The library keeps released device blocks and page-locked staging blocks in a process-wide cache
+ * (contexts are typically created once per scene; hipMalloc / hipHostMalloc / hipFree are the slow part
+ * of that).  This returns the cached memory of all devices to the driver; live contexts are unaffected.
+ * No reference counterpart (the reference holds everything in host std::maps). */
+void lt_release_cached_memory(void);
 
 /* ---- free functions of limap.triangulation (bindings.cc:22-31) on raw arrays, run on the GPU
  * one query per call (convenience / parity checks; the batch path is the API above).

@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = [
     "lt_export_image_results", "lt_import_image_results", "lt_ts_from_ctx", "lt_ts_create", "lt_ts_destroy",
     "lt_ts_num_tracks", "lt_ts_num_members", "lt_ts_get", "lt_ts_filter_by_reprojection",
     "lt_ts_filter_by_sensitivity", "lt_ts_filter_by_overlap", "lt_ts_remerge_once", "lt_get_stats", "lt_get_timers",
+    "lt_release_cached_memory",
     "lt_fn_get_normal_direction", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
     "lt_fn_triangulate_line",
 ]
@@ -88,6 +89,8 @@ def load_library():
     L.lt_create.restype = vp
     L.lt_destroy.argtypes = [vp]
     L.lt_destroy.restype = None
+    L.lt_release_cached_memory.argtypes = []
+    L.lt_release_cached_memory.restype = None
     L.lt_last_error.argtypes = [vp]
     L.lt_last_error.restype = C.c_char_p
     L.lt_set_stream.argtypes = [vp, vp]
@@ -370,7 +373,7 @@ class Context:
         out = np.zeros(16)
         self.chk(self.L.lt_get_timers(self.h, ptr(out, C.c_double)))
         keys = ["run", "invariants", "sort", "gen", "compact", "score", "select", "gather", "upload", "download", "tail",
-                "pairs_eval"]
+                "pairs_eval", "buffer"]
         return dict(zip(keys, out.tolist()))
 
     # --- free functions ---

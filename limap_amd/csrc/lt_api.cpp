@@ -11,11 +11,13 @@
 #include "lt_tail.h"
 
 #include <algorithm>
+#include <parallel/algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <queue>
 #include <set>
 #include <string>
@@ -57,6 +59,137 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2);
 }
+
+// ---- pooled page-locked host blocks (see lt_ctx.h) ----
+namespace lt_host {
+namespace {
+// never destroyed: contexts may be released during process teardown, after static destructors ran
+std::mutex &g_pool_mu = *new std::mutex;
+std::vector<HostBlock> &g_pool = *new std::vector<HostBlock>;  // released blocks, at most kPoolBlocks / kPoolBytes
+constexpr size_t kPoolBlocks = 4;
+constexpr size_t kPoolBytes = 4ull << 30;
+}  // namespace
+HostBlock host_block_acquire(size_t bytes) {
+  bytes = std::max<size_t>(bytes, 4096);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (size_t i = 0; i < g_pool.size(); ++i)
+      if (g_pool[i].bytes >= bytes && (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = (int)i;
+    if (best >= 0) {
+      HostBlock b = g_pool[best];
+      g_pool.erase(g_pool.begin() + best);
+      return b;
+    }
+  }
+  HostBlock b;
+  b.bytes = bytes + bytes / 8;
+  void *q = nullptr;
+  if (hipHostMalloc(&q, b.bytes, hipHostMallocDefault) == hipSuccess) {
+    b.p = q;
+    b.pinned = true;
+  } else {
+    (void)hipGetLastError();
+    b.p = std::malloc(b.bytes);
+    b.pinned = false;
+    if (!b.p) b.bytes = 0;
+  }
+  return b;
+}
+void host_block_release(HostBlock b) {
+  if (!b.p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t total = b.bytes;
+    for (auto &x : g_pool) total += x.bytes;
+    if (b.pinned && g_pool.size() < kPoolBlocks && total <= kPoolBytes) {
+      g_pool.push_back(b);
+      return;
+    }
+  }
+  if (b.pinned) (void)hipHostFree(b.p);
+  else std::free(b.p);
+}
+// ---- cached device blocks (see lt_ctx.h) ----
+namespace {
+struct DevBlock {
+  void *p;
+  size_t cap;
+  int device;
+};
+std::vector<DevBlock> &g_dev_pool = *new std::vector<DevBlock>;
+constexpr size_t kDevPoolBlocks = 512;
+constexpr size_t kDevPoolBytes = 64ull << 30;  // of 288 GB HBM
+}  // namespace
+void *dev_block_acquire(size_t bytes, size_t *cap) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (size_t i = 0; i < g_dev_pool.size(); ++i) {
+      const DevBlock &b = g_dev_pool[i];
+      if (b.device != dev || b.cap < bytes || b.cap > 4 * bytes + (1u << 20)) continue;
+      if (best < 0 || b.cap < g_dev_pool[best].cap) best = (int)i;
+    }
+    if (best >= 0) {
+      DevBlock b = g_dev_pool[best];
+      g_dev_pool.erase(g_dev_pool.begin() + best);
+      *cap = b.cap;
+      return b.p;
+    }
+  }
+  void *p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    // out of device memory: give the cache back and retry once
+    std::vector<DevBlock> drop;
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      drop.swap(g_dev_pool);
+    }
+    for (auto &b : drop) (void)hipFree(b.p);
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      *cap = 0;
+      return nullptr;
+    }
+  }
+  *cap = bytes;
+  return p;
+}
+void dev_block_release(void *p, size_t cap) {
+  if (!p) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t total = cap;
+    for (auto &b : g_dev_pool) total += b.cap;
+    if (g_dev_pool.size() < kDevPoolBlocks && total <= kDevPoolBytes) {
+      g_dev_pool.push_back(DevBlock{p, cap, dev});
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+void release_cached_memory() {
+  std::vector<DevBlock> drop;
+  std::vector<HostBlock> hdrop;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    drop.swap(g_dev_pool);
+    hdrop.swap(g_pool);
+  }
+  for (auto &b : drop) (void)hipFree(b.p);
+  for (auto &b : hdrop) {
+    if (b.pinned) (void)hipHostFree(b.p);
+    else std::free(b.p);
+  }
+}
+}  // namespace lt_host
+
+extern "C" void lt_release_cached_memory(void) { lt_host::release_cached_memory(); }
 
 namespace {
 
@@ -176,12 +309,12 @@ int init_common(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *s
   ctx->best_src2.assign(2 * ctx->G, 0);
   ctx->n_tris.assign(ctx->G, 0);
   ctx->has_best.assign(ctx->G, 0);
-  ctx->valid_edges.assign(ctx->G, {});
+  ctx->valid_edges.reset(ctx->G);
   ctx->tracks.clear();
   ctx->tracks_done = false;
   ctx->job_mode = 0;
   ctx->job_imgs.clear(); ctx->job_nbs.clear(); ctx->job_order.clear();
-  ctx->h_m_off.assign(1, 0); ctx->h_m_pairs.clear();
+  ctx->h_m_off.assign(1, 0); ctx->h_m_pairs.clear(); ctx->streamed_ints = 0;
   ctx->rows_sorted = true;
   ctx->uploaded = ctx->ran = ctx->downloaded = false;
   return LT_OK;
@@ -311,7 +444,8 @@ lt_ctx *lt_create(const lt_config *cfg, int device) {
     return nullptr;
   }
   for (auto &ev : ctx->ev) (void)hipEventCreate(&ev);
-  if (hipHostMalloc((void **)&ctx->h_pinned, 64, hipHostMallocDefault) != hipSuccess) ctx->h_pinned = nullptr;
+  ctx->h_pinned_blk = lt_host::host_block_acquire(4096);
+  ctx->h_pinned = ctx->h_pinned_blk.pinned ? (long long *)ctx->h_pinned_blk.p : nullptr;
   return ctx;
 }
 
@@ -330,7 +464,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
                     &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec};
-  if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  lt_host::host_block_release(ctx->h_pinned_blk);
   for (DevBuf *b : bufs) b->release();
   for (auto &ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -480,7 +614,7 @@ static int begin_image(lt_ctx *ctx, int img_id, int mode, int *idx_out) {
   }
   if (ctx->downloaded) {  // a new batch after results were read: start a fresh job
     ctx->job_imgs.clear(); ctx->job_nbs.clear(); ctx->job_order.clear();
-    ctx->h_m_off.assign(1, 0); ctx->h_m_pairs.clear();
+    ctx->h_m_off.assign(1, 0); ctx->h_m_pairs.clear(); ctx->streamed_ints = 0;
     ctx->rows_sorted = true;
     ctx->uploaded = ctx->ran = ctx->downloaded = false;
   }
@@ -496,6 +630,10 @@ static int begin_image(lt_ctx *ctx, int img_id, int mode, int *idx_out) {
 // sort-free placement and the single copy into the staging buffer run in one parallel pass.
 int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids,
                               const int32_t *const *rows, const int64_t *n_rows) {
+  struct Acc {  // [12] host ms spent buffering match rows (all calls of the batch)
+    lt_ctx *c; double t0;
+    ~Acc() { c->timers[12] += now_ms() - t0; }
+  } acc{ctx, now_ms()};
   int idx;
   int rc = begin_image(ctx, img_id, 1, &idx);
   if (rc) return rc;
@@ -520,8 +658,16 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
     dst[k + 1] = dst[k] + n_rows[o];
   }
   const size_t base = ctx->h_m_pairs.size();
-  if (ctx->job_imgs.empty() && dst[n_nb] > 0)  // first image of a batch: one allocation for the usual case
-    ctx->h_m_pairs.reserve(2 * (size_t)dst[n_nb] * (size_t)std::max(1, ctx->n_img) + 1024);
+  {
+    // the staging block may move when it grows: no asynchronous copy may still be reading it
+    size_t want = base + 2 * (size_t)dst[n_nb];
+    if (ctx->job_imgs.empty() && dst[n_nb] > 0)  // first image of a batch: one allocation for the usual case
+      want = std::max(want, 2 * (size_t)dst[n_nb] * (size_t)std::max(1, ctx->n_img) + 1024);
+    if (want > ctx->h_m_pairs.capacity()) {
+      if (ctx->streamed_ints > 0) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (!ctx->h_m_pairs.reserve(want)) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the match rows");
+    }
+  }
   if (!ctx->h_m_pairs.grow_to(base + 2 * (size_t)dst[n_nb])) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the match rows");
   int *out = ctx->h_m_pairs.data() + base;
   std::vector<int> bad(n_nb, 0);
@@ -557,6 +703,35 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
     return fail(ctx, LT_ERR_RUNTIME, "IndexError! neighbour line id out of range in matches of image " + std::to_string(img_id));
   }
   if (unsorted) ctx->rows_sorted = false;
+  // stream the rows to the device while the caller prepares the next image (they are final: staging
+  // is in call order, which is the device order whenever the images arrive in ascending id order)
+  if (ctx->h_m_pairs.blk.pinned && ctx->streamed_ints == base && dst[n_nb] > 0) {
+    const size_t end = base + 2 * (size_t)dst[n_nb];
+    if (hipSetDevice(ctx->device) == hipSuccess) {
+      bool ok = true;
+      if (sizeof(int) * end > ctx->d_m_pairs.cap) {
+        // grow the device buffer (first image: sized for the whole batch), keeping the streamed prefix
+        DevBuf nb;
+        size_t want = sizeof(int) * std::max(end, ctx->h_m_pairs.capacity());
+        ok = nb.ensure(want);
+        if (ok && base > 0)
+          ok = hipMemcpyAsync(nb.p, ctx->d_m_pairs.p, sizeof(int) * base, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+               hipStreamSynchronize(ctx->stream) == hipSuccess;
+        if (ok) {
+          ctx->d_m_pairs.release();
+          ctx->d_m_pairs = nb;
+        } else {
+          nb.release();
+          (void)hipGetLastError();
+        }
+      }
+      if (ok && hipMemcpyAsync(ctx->d_m_pairs.as<int>() + base, ctx->h_m_pairs.data() + base, sizeof(int) * (end - base),
+                               hipMemcpyHostToDevice, ctx->stream) == hipSuccess)
+        ctx->streamed_ints = end;
+      else
+        (void)hipGetLastError();  // not fatal: lt_upload sends whatever was not streamed
+    }
+  }
   for (int k = 0; k < n_nb; ++k) ctx->h_m_off.push_back(ctx->h_m_off.back() + n_rows[order[k]]);
   ctx->job_imgs.push_back(idx);
   ctx->job_nbs.push_back(nbs);
@@ -643,10 +818,16 @@ int lt_upload(lt_ctx *ctx) {
     ctx->max_rows = 0;
     for (int bq = 0; bq < ctx->n_blk; ++bq) ctx->max_rows = std::max(ctx->max_rows, m_off[bq + 1] - m_off[bq]);
     if (ctx->P >= (1ll << 32) - 1) return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch (>= 2^32-1)");
-    ENSURE(ctx, ctx->d_m_pairs, sizeof(int) * 2 * (size_t)std::max<long long>(ctx->P, 1));
+    if (sizeof(int) * 2 * (size_t)std::max<long long>(ctx->P, 1) > ctx->d_m_pairs.cap) {
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->streamed_ints = 0;  // the buffer is replaced: everything is sent again
+      ENSURE(ctx, ctx->d_m_pairs, sizeof(int) * 2 * (size_t)std::max<long long>(ctx->P, 1));
+    }
     if (in_order) {
-      if (ctx->P > 0)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_m_pairs.p, ctx->h_m_pairs.data(), sizeof(int) * 2 * (size_t)ctx->P,
+      // call order == device order: only what was not streamed during buffering is still to be sent
+      const size_t total = 2 * (size_t)ctx->P, sent = std::min(ctx->streamed_ints, total);
+      if (total > sent)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_m_pairs.as<int>() + sent, ctx->h_m_pairs.data() + sent, sizeof(int) * (total - sent),
                                    hipMemcpyHostToDevice, ctx->stream));
     } else {
       long long b = 0;
@@ -938,21 +1119,40 @@ int lt_download(lt_ctx *ctx) {
   ENSURE(ctx, ctx->d_edges, 8 * (size_t)std::max<long long>(ctx->E, 1));
   launch_edge_fill(st, G, ctx->d_tri_off.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
                    ctx->d_edge_off.as<long long>(), ctx->d_lite.as<CandLite>(), ctx->d_edges.as<int>());
-  std::vector<Cand> bc(G);
-  std::vector<double> bs(G);
-  std::vector<int> bsrc(2 * G), nt(G), edges(2 * std::max<long long>(ctx->E, 1));
+  // one pooled page-locked block for all result arrays
+  const size_t Gn = (size_t)std::max<long long>(G, 1), En = (size_t)std::max<long long>(ctx->E, 1);
+  const size_t o_bc = 0, o_bs = o_bc + sizeof(Cand) * Gn, o_src = o_bs + 8 * Gn, o_nt = o_src + 8 * Gn,
+               o_ed = (o_nt + 4 * Gn + 15) / 16 * 16, total = o_ed + 8 * En;
+  lt_host::HostBlock hb = lt_host::host_block_acquire(total);
+  if (!hb.p) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the results");
+  struct Rel {
+    lt_host::HostBlock b;
+    ~Rel() { lt_host::host_block_release(b); }
+  } rel{hb};
+  char *base = (char *)hb.p;
+  const Cand *bc = (const Cand *)(base + o_bc);
+  const double *bs = (const double *)(base + o_bs);
+  const int *bsrc = (const int *)(base + o_src);
+  const int *nt = (const int *)(base + o_nt);
+  const int *edges = (const int *)(base + o_ed);
   if (G > 0) {
-    HIPCHK(ctx, hipMemcpyAsync(bc.data(), ctx->d_best_c.p, sizeof(Cand) * (size_t)G, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(bs.data(), ctx->d_best_score.p, 8 * (size_t)G, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(bsrc.data(), ctx->d_best_src.p, 8 * (size_t)G, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(nt.data(), ctx->d_ntris.p, 4 * (size_t)G, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(base + o_bc, ctx->d_best_c.p, sizeof(Cand) * (size_t)G, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(base + o_bs, ctx->d_best_score.p, 8 * (size_t)G, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(base + o_src, ctx->d_best_src.p, 8 * (size_t)G, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(base + o_nt, ctx->d_ntris.p, 4 * (size_t)G, hipMemcpyDeviceToHost, st));
   }
   if (ctx->E > 0)
-    HIPCHK(ctx, hipMemcpyAsync(edges.data(), ctx->d_edges.p, 8 * (size_t)ctx->E, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(base + o_ed, ctx->d_edges.p, 8 * (size_t)ctx->E, hipMemcpyDeviceToHost, st));
   HIPCHK(ctx, hipStreamSynchronize(st));
-  // merge the nodes of the job's images into the persistent per-node results
+  // merge the nodes of the job's images into the persistent per-node results; the edge lists of the
+  // whole run are appended to the pool in one piece (nodes outside the job have none)
+  const long long pool_base = (long long)ctx->valid_edges.pool.size();
+  ctx->valid_edges.pool.insert(ctx->valid_edges.pool.end(), edges, edges + 2 * (size_t)ctx->E);
   long long pairs = 0;
-  for (int idx : ctx->job_imgs) {
+  const long long n_job = (long long)ctx->job_imgs.size();
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 4) reduction(+ : pairs)
+  for (long long j = 0; j < n_job; ++j) {
+    const int idx = ctx->job_imgs[(size_t)j];
     for (long long g = ctx->seg_off[idx]; g < ctx->seg_off[idx + 1]; ++g) {
       ctx->n_tris[g] = nt[g];
       pairs += (long long)nt[g] * nt[g];
@@ -962,7 +1162,8 @@ int lt_download(lt_ctx *ctx) {
       // src image index -> id
       ctx->best_src2[2 * g] = nt[g] > 0 ? ctx->img_ids[bsrc[2 * g]] : 0;
       ctx->best_src2[2 * g + 1] = nt[g] > 0 ? bsrc[2 * g + 1] : 0;
-      ctx->valid_edges[g].assign(edges.begin() + 2 * edge_off[g], edges.begin() + 2 * edge_off[g + 1]);
+      ctx->valid_edges.off[(size_t)g] = pool_base + 2 * edge_off[g];
+      ctx->valid_edges.cnt[(size_t)g] = (int)(2 * (edge_off[g + 1] - edge_off[g]));
     }
   }
   ctx->stat_pairs = pairs;
@@ -993,6 +1194,14 @@ int lt_compute_tracks(lt_ctx *ctx) {
   if (ctx->cfg.merging_strategy != 0)  // global_line_triangulator.cc:314-316
     return fail(ctx, LT_ERR_RUNTIME, "Error!The given merging strategy is not implemented");
   double t0 = now_ms();
+  static const bool tail_trace = getenv("LT_TAIL_TRACE") != nullptr;  // developer: stage times to stderr
+  double tprev = t0;
+  auto lap = [&](const char *what) {
+    if (!tail_trace) return;
+    double t = now_ms();
+    fprintf(stderr, "[tail] %-18s %.3f ms\n", what, t - tprev);
+    tprev = t;
+  };
   const long long G = ctx->G;
   const int min_outer = ctx->cfg.min_num_outer_edges;
   auto node2 = [&](long long g, int slot, int ng_line) -> long long {
@@ -1005,7 +1214,7 @@ int lt_compute_tracks(lt_ctx *ctx) {
     std::vector<int> counters(G);
     std::vector<std::vector<unsigned>> parents(G);
     for (long long g = 0; g < G; ++g) {
-      const auto &ve = ctx->valid_edges[g];
+      const auto ve = ctx->valid_edges[g];
       counters[g] = (int)(ve.size() / 2);
       for (size_t e = 0; e + 1 < ve.size(); e += 2) parents[node2(g, ve[e], ve[e + 1])].push_back((unsigned)g);
       if (counters[g] < min_outer) flags[g] = 0;
@@ -1025,21 +1234,41 @@ int lt_compute_tracks(lt_ctx *ctx) {
       }
     }
   }
+  lap("filter nodes");
   // undirected edge set, ordered like std::set<pair<LineNode, LineNode>> (:243-261): the global
   // node index is monotone in (img_id, line_id)
   std::vector<unsigned long long> edges;
-  for (long long g = 0; g < G; ++g) {
-    if (!flags[g]) continue;
-    const auto &ve = ctx->valid_edges[g];
-    for (size_t e = 0; e + 1 < ve.size(); e += 2) {
-      long long h = node2(g, ve[e], ve[e + 1]);
-      if (!flags[h]) continue;
-      unsigned long long a = (unsigned long long)std::min(g, h), b = (unsigned long long)std::max(g, h);
-      edges.push_back((a << 32) | b);
+  {
+    // two passes (count, fill) over the nodes in parallel, then a parallel sort
+    std::vector<long long> eoff((size_t)G + 1, 0);
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(static)
+    for (long long g = 0; g < G; ++g) {
+      long long n = 0;
+      if (flags[g]) {
+        const auto ve = ctx->valid_edges[g];
+        for (size_t e = 0; e + 1 < ve.size(); e += 2) n += flags[node2(g, ve[e], ve[e + 1])] ? 1 : 0;
+      }
+      eoff[(size_t)g + 1] = n;
     }
+    for (long long g = 0; g < G; ++g) eoff[(size_t)g + 1] += eoff[(size_t)g];
+    edges.resize((size_t)eoff[(size_t)G]);
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(static)
+    for (long long g = 0; g < G; ++g) {
+      if (!flags[g]) continue;
+      const auto ve = ctx->valid_edges[g];
+      long long w = eoff[(size_t)g];
+      for (size_t e = 0; e + 1 < ve.size(); e += 2) {
+        long long h = node2(g, ve[e], ve[e + 1]);
+        if (!flags[h]) continue;
+        unsigned long long a = (unsigned long long)std::min(g, h), b = (unsigned long long)std::max(g, h);
+        edges[(size_t)w++] = (a << 32) | b;
+      }
+    }
+    __gnu_parallel::sort(edges.begin(), edges.end(), std::less<unsigned long long>(),
+                         __gnu_parallel::default_parallel_tag(lt::host_threads()));
+    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
   }
-  std::sort(edges.begin(), edges.end());
-  edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+  lap("edge set");
   // edge similarity: score_3d in spatial-merging mode between the two best candidates (:264-290)
   LinkCfg3 l3 = make_l3(ctx->cfg);
   l3.use_angle = 1; l3.use_overlap = 1; l3.use_perp = 0; l3.use_innerseg = 1; l3.use_scaleinv = 0;  // line_linker.h:123-129
@@ -1056,17 +1285,18 @@ int lt_compute_tracks(lt_ctx *ctx) {
     // line scores 0 against everything (direction 0 -> angle 90 deg)
     sims[e] = (ctx->has_best[a] && ctx->has_best[b]) ? score3d(l3, la, lb, ca.unc, cb.unc, ca.depth) : 0.0;
   }
+  lap("edge sims");
   // graph in edge order (base/graph.cc:57-87)
   std::vector<long long> gnode;              // graph node -> global node
-  std::unordered_map<long long, int> gmap;   // global node -> graph node
+  std::vector<int> gmap((size_t)G, -1);      // global node -> graph node
   std::vector<int> e1, e2;
   std::vector<double> es;
+  e1.reserve((size_t)nE); e2.reserve((size_t)nE); es.reserve((size_t)nE);
   auto find_or_create = [&](long long g) {
-    auto it = gmap.find(g);
-    if (it != gmap.end()) return it->second;
+    if (gmap[(size_t)g] >= 0) return gmap[(size_t)g];
     int id = (int)gnode.size();
     gnode.push_back(g);
-    gmap.emplace(g, id);
+    gmap[(size_t)g] = id;
     return id;
   };
   for (long long e = 0; e < nE; ++e) {
@@ -1077,29 +1307,47 @@ int lt_compute_tracks(lt_ctx *ctx) {
   }
   ctx->stat_graph_nodes = (long long)gnode.size();
   ctx->stat_graph_edges = (long long)es.size();
+  lap("graph");
   // ComputeLineTrackLabelsGreedy (merging/merging.cc:18-103)
   const int n_nodes = (int)gnode.size();
   std::vector<int> order(es.size());
   for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-  std::sort(order.begin(), order.end(), [&](int x, int y) {  // descending (sim, idx1, idx2)
+  __gnu_parallel::sort(order.begin(), order.end(), [&](int x, int y) {  // descending (sim, idx1, idx2): a total order
     if (es[x] != es[y]) return es[x] > es[y];
     if (e1[x] != e1[y]) return e1[x] > e1[y];
     return e2[x] > e2[y];
-  });
+  }, __gnu_parallel::default_parallel_tag(lt::host_threads()));
+  lap("edge sort");
   std::vector<int> parent(n_nodes, -1);
-  std::vector<std::set<int>> images_in_track(n_nodes);
-  for (int i = 0; i < n_nodes; ++i) images_in_track[i].insert(ctx->img_ids[ctx->h_node_img[gnode[i]]]);
+  // images_in_track (std::set<int> per root in the reference, :52-84): only the set SIZES steer the
+  // union, so a bit set per node over the image indices is equivalent
+  const size_t W = ((size_t)ctx->n_img + 63) / 64;
+  std::vector<unsigned long long> img_bits((size_t)n_nodes * W, 0ull);
+  std::vector<int> img_cnt(n_nodes, 1);
+  for (int i = 0; i < n_nodes; ++i) {
+    const int im = ctx->h_node_img[gnode[i]];
+    img_bits[(size_t)i * W + (size_t)im / 64] |= 1ull << (im & 63);
+  }
+  auto absorb = [&](int dst, int src) {  // images[dst] |= images[src]; images[src] = {}
+    int c = 0;
+    for (size_t w = 0; w < W; ++w) {
+      unsigned long long v = img_bits[(size_t)dst * W + w] | img_bits[(size_t)src * W + w];
+      img_bits[(size_t)dst * W + w] = v;
+      img_bits[(size_t)src * W + w] = 0ull;
+      c += __builtin_popcountll(v);
+    }
+    img_cnt[dst] = c;
+    img_cnt[src] = 0;
+  };
   for (int oi : order) {
     int r1 = uf_root(e1[oi], parent), r2 = uf_root(e2[oi], parent);
     if (r1 == r2) continue;
-    if (images_in_track[r1].size() < images_in_track[r2].size()) {
+    if (img_cnt[r1] < img_cnt[r2]) {
       parent[r1] = r2;
-      images_in_track[r2].insert(images_in_track[r1].begin(), images_in_track[r1].end());
-      images_in_track[r1].clear();
+      absorb(r2, r1);
     } else {
       parent[r2] = r1;
-      images_in_track[r1].insert(images_in_track[r2].begin(), images_in_track[r2].end());
-      images_in_track[r2].clear();
+      absorb(r1, r2);
     }
   }
   // NOTE: the reference's recursive root lookup compresses paths as a side effect and reads
@@ -1116,6 +1364,7 @@ int lt_compute_tracks(lt_ctx *ctx) {
     if (parent[i] == -1) continue;
     labels[i] = labels[uf_root(i, parent)];
   }
+  lap("union-find");
   // build_tracks_from_clusters (:293-351)
   ctx->tracks.clear();
   if (n_nodes > 0) {
@@ -1143,6 +1392,7 @@ int lt_compute_tracks(lt_ctx *ctx) {
       aggregate(lines, tr.scores, ctx->cfg.num_outliers_aggregator, tr.line);
     }
   }
+  lap("tracks+aggregate");
   ctx->tracks_done = true;
   ctx->timers[10] = now_ms() - t0;
   return LT_OK;
@@ -1189,7 +1439,7 @@ int lt_get_num_tris(lt_ctx *ctx, int32_t *out) {
 int64_t lt_num_valid_edges(lt_ctx *ctx) {
   if (lt_flush(ctx)) return -1;
   int64_t n = 0;
-  for (auto &v : ctx->valid_edges) n += (int64_t)v.size() / 2;
+  for (int c : ctx->valid_edges.cnt) n += (int64_t)c / 2;
   return n;
 }
 
@@ -1199,7 +1449,7 @@ int lt_get_valid_edges(lt_ctx *ctx, int64_t *out_off, int32_t *out_edges2) {
   int64_t e = 0;
   out_off[0] = 0;
   for (long long g = 0; g < ctx->G; ++g) {
-    const auto &v = ctx->valid_edges[g];
+    const auto v = ctx->valid_edges[g];
     if (!v.empty()) std::memcpy(out_edges2 + 2 * e, v.data(), 4 * v.size());
     e += (int64_t)v.size() / 2;
     out_off[g + 1] = e;
@@ -1304,7 +1554,7 @@ int lt_export_image_results(lt_ctx *ctx, int img_id, int32_t *out_nb_ids, int32_
     out_src2[2 * l] = ctx->best_src2[2 * g];
     out_src2[2 * l + 1] = ctx->best_src2[2 * g + 1];
     out_n_tris[l] = ctx->n_tris[g];
-    const auto &v = ctx->valid_edges[g];
+    const auto v = ctx->valid_edges[g];
     if (!v.empty()) std::memcpy(out_edges2 + 2 * e, v.data(), 4 * v.size());
     e += (int64_t)v.size() / 2;
     out_edge_off[l + 1] = e;
@@ -1339,7 +1589,7 @@ int lt_import_image_results(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb
     ctx->best_src2[2 * g + 1] = src2[2 * l + 1];
     ctx->n_tris[g] = n_tris[l];
     ctx->has_best[g] = n_tris[l] > 0 ? 1 : 0;
-    ctx->valid_edges[g].assign(edges2 + 2 * edge_off[l], edges2 + 2 * edge_off[l + 1]);
+    ctx->valid_edges.set(g, edges2 + 2 * edge_off[l], edges2 + 2 * edge_off[l + 1]);
   }
   ctx->tracks_done = false;
   return LT_OK;

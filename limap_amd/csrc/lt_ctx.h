@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <hip/hip_runtime.h>
 #include <unordered_map>
@@ -15,21 +16,29 @@
 namespace lt_host {
 using namespace lt;
 
+// Process-wide cache of device blocks (lt_api.cpp): contexts are short-lived (one per scene), hipMalloc /
+// hipFree are not (each is a driver call, hipFree also synchronises the device).
+void *dev_block_acquire(size_t bytes, size_t *cap);
+void dev_block_release(void *p, size_t cap);
+
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  // NOTE: growing replaces the block (contents are NOT kept); the old block returns to the cache
+  // only after the device is idle, because work of this context may still be using it.
   bool ensure(size_t bytes) {
     if (bytes <= cap) return true;
-    if (p) (void)hipFree(p);
+    if (p) {
+      (void)hipDeviceSynchronize();
+      dev_block_release(p, cap);
+    }
     p = nullptr;
     cap = 0;
-    size_t want = bytes + bytes / 8 + 256;
-    if (hipMalloc(&p, want) != hipSuccess) return false;
-    cap = want;
-    return true;
+    p = dev_block_acquire(bytes + bytes / 8 + 256, &cap);
+    return p != nullptr;
   }
-  void release() {
-    if (p) (void)hipFree(p);
+  void release() {  // callers make sure no work is in flight on the block (lt_destroy synchronises)
+    if (p) dev_block_release(p, cap);
     p = nullptr;
     cap = 0;
   }
@@ -37,25 +46,40 @@ struct DevBuf {
   T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Process-wide pool of page-locked host blocks (lt_api.cpp).  Staging the match rows of a batch needs
+// tens of MB; fresh pageable memory costs a page fault per 4 KB and a bounce copy in the H2D path,
+// a pooled pinned block costs neither after its first use.  Falls back to malloc if pinning fails.
+struct HostBlock {
+  void *p = nullptr;
+  size_t bytes = 0;
+  bool pinned = false;
+};
+HostBlock host_block_acquire(size_t bytes);
+void host_block_release(HostBlock b);
+
 // growable int buffer without value-initialisation (the match rows are overwritten right away)
 struct RawInts {
-  int *p = nullptr;
-  size_t n = 0, cap = 0;
-  ~RawInts() { std::free(p); }
+  HostBlock blk;
+  size_t n = 0;
+  ~RawInts() { host_block_release(blk); }
   RawInts() = default;
   RawInts(const RawInts &) = delete;
   RawInts &operator=(const RawInts &) = delete;
   size_t size() const { return n; }
-  int *data() { return p; }
-  const int *data() const { return p; }
+  size_t capacity() const { return blk.bytes / sizeof(int); }
+  int *data() { return (int *)blk.p; }
+  const int *data() const { return (const int *)blk.p; }
   void clear() { n = 0; }
-  bool grow_to(size_t want) {  // size := want, contents beyond the old size are uninitialised
-    if (want > cap) {
-      size_t nc = std::max(want, cap + cap / 2 + 1024);
-      int *q = (int *)std::realloc(p, nc * sizeof(int));
-      if (!q) return false;
-      p = q;
-      cap = nc;
+  // size := want, contents beyond the old size are uninitialised.  NOTE: may move the data; the caller
+  // must make sure no asynchronous copy still reads the old block (capacity() tells in advance).
+  bool grow_to(size_t want) {
+    if (want > capacity()) {
+      size_t nc = std::max(want, capacity() + capacity() / 2 + 1024);
+      HostBlock q = host_block_acquire(nc * sizeof(int));
+      if (!q.p) return false;
+      if (n) std::memcpy(q.p, blk.p, n * sizeof(int));
+      host_block_release(blk);
+      blk = q;
     }
     n = want;
     return true;
@@ -65,6 +89,29 @@ struct RawInts {
     if (!grow_to(std::max(want, n))) return false;
     n = keep;
     return true;
+  }
+};
+
+// Valid edges of every node, flat (slot, ng_line) pairs: one pool + per-node (offset, count), so that a
+// download is one bulk append instead of one allocation per node.  Nodes of later batches append.
+struct EdgeStore {
+  struct View {
+    const int *p;
+    size_t n;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    const int *data() const { return p; }
+    int operator[](size_t i) const { return p[i]; }
+  };
+  std::vector<long long> off;
+  std::vector<int> cnt;   // ints (2 per edge)
+  std::vector<int> pool;
+  void reset(long long G) { off.assign((size_t)G, 0); cnt.assign((size_t)G, 0); pool.clear(); }
+  View operator[](long long g) const { return View{pool.data() + off[(size_t)g], (size_t)cnt[(size_t)g]}; }
+  void set(long long g, const int *first, const int *last) {
+    off[(size_t)g] = (long long)pool.size();
+    cnt[(size_t)g] = (int)(last - first);
+    pool.insert(pool.end(), first, last);
   }
 };
 
@@ -108,7 +155,8 @@ struct lt_ctx {
   std::vector<std::vector<int>> job_nbs;   // per job image: neighbour image indices, processing order
   std::vector<std::vector<int>> job_order; // per job image: slots in ascending neighbour-id order
   std::vector<long long> h_m_off;          // per block row offsets (n_blk+1), matched mode
-  lt_host::RawInts h_m_pairs;              // 2 * P
+  lt_host::RawInts h_m_pairs;              // 2 * P (pinned staging, call order)
+  size_t streamed_ints = 0;                // prefix of h_m_pairs already enqueued to d_m_pairs
   std::vector<char> triangulated;          // per image: already passed to TriangulateImage*
   bool uploaded = false, ran = false, downloaded = false;
   // neighbours_ of every triangulated image (ids), persists for the tail
@@ -135,6 +183,7 @@ struct lt_ctx {
   long long stat_pairs_eval = 0;
   std::vector<long long> h_blk_line_base;
   bool rows_sorted = true;   // every (image, neighbour) block lists its rows in non-decreasing line id
+  lt_host::HostBlock h_pinned_blk;
   long long *h_pinned = nullptr;  // pinned scratch for small device->host scalars
   DevBuf d_chunks, d_cand_meta, d_st_row, d_surv_count, d_seg_gates, d_blkrec;
   int n_chunks = 0;
@@ -146,7 +195,7 @@ struct lt_ctx {
   std::vector<double> best_score;
   std::vector<int> best_src2, n_tris;
   std::vector<unsigned char> has_best;
-  std::vector<std::vector<int>> valid_edges;  // per node: flat (slot, ng_line) pairs
+  lt_host::EdgeStore valid_edges;  // per node: flat (slot, ng_line) pairs
   // ---- tail ----
   std::vector<Track> tracks;
   bool tracks_done = false;

@@ -24,6 +24,6 @@ for rep in range(3):
     t5 = time.perf_counter()
     tm = T.timers()
     print(f"rep{rep}: ctor {1e3*(t1-t0):.2f}  init {1e3*(t2-t1):.2f}  buffer(100x TriangulateImage) {1e3*(t3-t2):.2f}  "
-          f"compute_tracks {1e3*(t4-t3):.2f} [upload {tm['upload']:.2f} run {tm['run']:.2f} download {tm['download']:.2f} tail {tm['tail']:.2f}]  "
+          f"compute_tracks {1e3*(t4-t3):.2f} [buffer_c {tm['buffer']:.2f} upload {tm['upload']:.2f} run {tm['run']:.2f} download {tm['download']:.2f} tail {tm['tail']:.2f}]  "
           f"get_tracks {1e3*(t5-t4):.2f}  total {1e3*(t4-t0):.2f}")
     del T
