@@ -173,6 +173,34 @@ void dev_block_release(void *p, size_t cap) {
   }
   (void)hipFree(p);
 }
+// streams + timing events of destroyed contexts (creating them costs ~2 ms per context)
+struct StreamSet {
+  int device;
+  hipStream_t stream;
+  hipEvent_t ev[9];
+};
+std::vector<StreamSet> &g_stream_pool = *new std::vector<StreamSet>;
+bool stream_set_acquire(int device, hipStream_t *stream, hipEvent_t ev[9]) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (size_t i = 0; i < g_stream_pool.size(); ++i)
+    if (g_stream_pool[i].device == device) {
+      *stream = g_stream_pool[i].stream;
+      for (int k = 0; k < 9; ++k) ev[k] = g_stream_pool[i].ev[k];
+      g_stream_pool.erase(g_stream_pool.begin() + i);
+      return true;
+    }
+  return false;
+}
+bool stream_set_release(int device, hipStream_t stream, hipEvent_t ev[9]) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (g_stream_pool.size() >= 8) return false;
+  StreamSet s;
+  s.device = device;
+  s.stream = stream;
+  for (int k = 0; k < 9; ++k) s.ev[k] = ev[k];
+  g_stream_pool.push_back(s);
+  return true;
+}
 void release_cached_memory() {
   std::vector<DevBlock> drop;
   std::vector<HostBlock> hdrop;
@@ -439,11 +467,14 @@ lt_ctx *lt_create(const lt_config *cfg, int device) {
   lt_ctx *ctx = new lt_ctx();
   ctx->cfg = *cfg;
   ctx->device = device;
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-    delete ctx;
-    return nullptr;
+  if (!lt_host::stream_set_acquire(device, &ctx->stream, ctx->ev)) {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx;
+      return nullptr;
+    }
+    for (auto &ev : ctx->ev) (void)hipEventCreate(&ev);
   }
-  for (auto &ev : ctx->ev) (void)hipEventCreate(&ev);
+  ctx->pool_stream = ctx->stream;
   ctx->h_pinned_blk = lt_host::host_block_acquire(4096);
   ctx->h_pinned = ctx->h_pinned_blk.pinned ? (long long *)ctx->h_pinned_blk.p : nullptr;
   return ctx;
@@ -466,21 +497,26 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec};
   lt_host::host_block_release(ctx->h_pinned_blk);
   for (DevBuf *b : bufs) b->release();
-  for (auto &ev : ctx->ev)
-    if (ev) (void)hipEventDestroy(ev);
-  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  // a context that still owns its stream hands stream + events to the next context
+  if (ctx->pool_stream) (void)hipStreamSynchronize(ctx->pool_stream);
+  if (!(ctx->pool_stream && lt_host::stream_set_release(ctx->device, ctx->pool_stream, ctx->ev))) {
+    for (auto &ev : ctx->ev)
+      if (ev) (void)hipEventDestroy(ev);
+    if (ctx->pool_stream) (void)hipStreamDestroy(ctx->pool_stream);
+  }
   delete ctx;
 }
 
 const char *lt_last_error(lt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int lt_set_stream(lt_ctx *ctx, void *hip_stream) {
-  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // nothing of this context stays in flight on the old stream
   if (hip_stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     ctx->own_stream = false;
   } else {
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    if (!ctx->pool_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->pool_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->pool_stream;
     ctx->own_stream = true;
   }
   return LT_OK;

@@ -133,6 +133,7 @@ struct lt_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = true;
+  hipStream_t pool_stream = nullptr;  // the stream this context created (returned to the cache on destroy)
   std::string err;
   bool ranges_on = false;
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
