@@ -407,39 +407,75 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
   if (count == 0) return;
   const long long g1 = seg_off[blk_img[b]];
   const long long lbase = blk_line_base[b];
+  static_assert(sizeof(Cand) == 7 * 16 && sizeof(CandLite) == 2 * 16, "record sizes in 16-byte units");
   for (unsigned e0 = 0; e0 < count; e0 += 64) {
-    unsigned e = e0 + lane;
-    if (e >= count) break;
-    const unsigned key = st_key[r0 + e];
-    // rank within the (block, line) run
-    unsigned rank = 0;
+    const unsigned e = e0 + lane;
+    const bool act = e < count;
+    unsigned pos32 = 0;
+    // rank within the (block, line) run, without per-lane pointer chasing: the candidates of a run
+    // are adjacent, so inside the batch the rank is the distance to the run's first lane (ballot of
+    // the run heads); only the run that reaches back beyond the batch needs a look-back, and that
+    // one is wave-uniform (64 earlier keys per step).
+    const unsigned key = act ? st_key[r0 + e] : 0xFFFFFFFFu;
+    const unsigned prev = (unsigned)__shfl_up((int)key, 1);
+    const bool head = act && (lane == 0 || key != prev);
+    const unsigned long long heads = __ballot(head);
+    const int my_head = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull) | 1ull);
+    const unsigned key0 = (unsigned)__builtin_amdgcn_readfirstlane((int)key);
+    unsigned carry = 0;
     {
       long long cur_r0 = r0;
-      long long idx = (long long)e - 1;
+      long long idx_end = (long long)e0;  // entries [0, idx_end) of the current list precede the batch
       unsigned cur_lin = lin;
       while (true) {
-        while (idx >= 0 && st_key[cur_r0 + idx] == key) {
-          ++rank;
-          --idx;
+        bool more = true;
+        while (idx_end > 0) {
+          const long long j = idx_end - 64 + lane;
+          const bool valid = j >= 0;
+          const unsigned k = valid ? st_key[cur_r0 + j] : 0u;
+          const unsigned long long m = __ballot(valid && k == key0);
+          const unsigned lead = m == ~0ull ? 64u : (unsigned)__builtin_clzll(~m);
+          carry += lead;
+          const long long n_valid = idx_end < 64 ? idx_end : 64;
+          if ((long long)lead < n_valid) { more = false; break; }  // a different key precedes: run starts here
+          idx_end -= n_valid;
         }
-        if (idx >= 0) break;                 // a different key precedes: run starts inside this list
+        if (!more) break;
         if (cur_r0 - kTriRows < rb) break;  // first group of the block
         cur_r0 -= kTriRows;
         cur_lin -= 1;
-        unsigned pc = wave_count[cur_lin];
-        if (pc == 0) {
-          // an empty list: the run can only continue further back if that whole wave range belongs
-          // to the same line, which an empty list cannot tell -- keep walking (bounded by the block)
-          idx = -1;
-          continue;
-        }
-        idx = (long long)pc - 1;
+        // an empty list cannot tell whether the run continues further back: keep walking (bounded by the block)
+        idx_end = (long long)wave_count[cur_lin];
       }
     }
-    const long long pos = tri_off[key] + base_bl[lbase + (long long)(key - g1)] + rank;
-    cand[pos] = st_c[r0 + e];
-    lite[pos] = st_l[r0 + e];
-    cand_node[pos] = key;
+    if (act) {
+      const unsigned rank = (unsigned)(lane - my_head) + (my_head == 0 ? carry : 0u);
+      const long long pos = tri_off[key] + base_bl[lbase + (long long)(key - g1)] + rank;
+      pos32 = (unsigned)pos;  // candidate positions fit 32 bits (cand_node / tri counts are 32-bit)
+      cand_node[pos] = key;
+    }
+    // Cooperative copy in 16-byte units: consecutive lanes read consecutive units of the (contiguous)
+    // source list and write consecutive units of a destination record, so a wave touches ~1/8 of the
+    // cache lines a record-per-lane copy would.
+    const unsigned nb = min(64u, count - e0);
+    const double2 *src_c = reinterpret_cast<const double2 *>(st_c + r0 + e0);
+    double2 *dst_c = reinterpret_cast<double2 *>(cand);
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+      const unsigned u = (unsigned)it * 64u + (unsigned)lane;
+      const unsigned ci = min(u / 7u, 63u), piece = u - (u / 7u) * 7u;
+      const unsigned p = (unsigned)__shfl((int)pos32, (int)ci);
+      if (u < nb * 7u) dst_c[(size_t)p * 7u + piece] = src_c[u];
+    }
+    const double2 *src_l = reinterpret_cast<const double2 *>(st_l + r0 + e0);
+    double2 *dst_l = reinterpret_cast<double2 *>(lite);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const unsigned u = (unsigned)it * 64u + (unsigned)lane;
+      const unsigned ci = u >> 1, piece = u & 1u;
+      const unsigned p = (unsigned)__shfl((int)pos32, (int)ci);
+      if (u < nb * 2u) dst_l[(size_t)p * 2u + piece] = src_l[u];
+    }
   }
 }
 
