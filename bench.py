@@ -37,13 +37,19 @@ REMERGE_LINKER = dict(score_th=0.5, th_angle=5.0, th_overlap=0.001, th_smartover
                       th_perp=1.0, th_innerseg=1.0)
 
 
-def algorithmic_bytes(stats, n_img_active, nn):
+def algorithmic_bytes(stats, n_img_active, nn, survivors):
     """SURVEY.md 8(d): bytes_score = 136 C + 104 nodes + 4 E ;
-    bytes_gen = 8 P + 32 (nodes + N nn M) + 88 N (1 + nn) + 96 C."""
+    bytes_gen = 8 P + 32 (nodes + N nn M) + 88 N (1 + nn) + 96 C.
+    HOT LOOP 1 runs as two kernels; its bytes are split where the data is touched:
+      k_gates    : every match row (8 P), the segment and camera records (the 32 / 88 terms), and the
+                   list of rows that pass the gates (4 S, S = stage-A survivors)
+      k_tri_rows : the survivor list and its rows again (12 S) and the candidate records it emits (96 C)."""
     C, E, P, G = stats["candidates"], stats["valid_edges"], stats["connections"], stats["active_nodes"]
     score = 136 * C + 104 * G + 4 * E
     gen = 8 * P + 32 * (G + nn * G) + 88 * n_img_active * (1 + nn) + 96 * C
-    return score, gen
+    gates = 8 * P + 32 * (G + nn * G) + 88 * n_img_active * (1 + nn) + 4 * survivors
+    tri = 12 * survivors + 96 * C
+    return {"score": score, "gen": gen, "gates": gates, "tri": tri}
 
 
 def main():
@@ -171,8 +177,14 @@ def main():
 
     out = None
     if rank == 0:
-        b_score, b_gen = algorithmic_bytes(st, len(my_imgs), args.neighbors)
-        kernels = {"score": (b_score, kt.get("score", 0.0)), "gen": (b_gen, kt.get("gen", 0.0))}
+        ab = algorithmic_bytes(st, len(my_imgs), args.neighbors, kt.get("survivors", 0.0))
+        # per-KERNEL durations: HIP events recorded on the launch stream right around each kernel
+        # (lt_get_timers [13]-[15]); "gen" is the two-kernel stage HOT LOOP 1 for continuity with round-1 lines
+        if args.mode == "matched":
+            kernels = {"k_score3": (ab["score"], kt.get("k_score3", 0.0)), "k_gates": (ab["gates"], kt.get("k_gates", 0.0)),
+                       "k_tri_rows": (ab["tri"], kt.get("k_tri_rows", 0.0))}
+        else:
+            kernels = {"k_score3": (ab["score"], kt.get("k_score3", 0.0)), "k_gen_exhaustive": (ab["gen"], kt.get("gen", 0.0))}
         dom = max(kernels, key=lambda k: kernels[k][1])
         roof = {}
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
@@ -182,12 +194,17 @@ def main():
         default_wl = (args.views, args.segs, args.neighbors, args.topk, args.mode, world) == (100, 500, 20, 10, "matched", 1)
         if default_wl and os.path.exists(tpath):
             tk = json.load(open(tpath))["kernels"]
-            traffic = {"score": tk.get("k_score3", {}).get("hbm_bytes"), "gen": tk.get("k_gen_rows", {}).get("hbm_bytes")}
+            traffic = {k: tk.get(k, {}).get("hbm_bytes") for k in kernels}
         for name, (nbytes, ms) in kernels.items():
             gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             roof[name] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(name), "kernel_ms": ms,
                           "algorithmic_bytes": nbytes}
+        if args.mode == "matched" and kt.get("gen", 0.0) > 0:
+            gbs = ab["gen"] / (kt["gen"] * 1e-3) / 1e9
+            roof["stage_gen(k_gates+k_tri_rows)"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                     "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kt["gen"],
+                                                     "algorithmic_bytes": ab["gen"]}
         out = {
             "metric": "3D line candidates scored/sec (100 views x 500 segs per GPU, matched topk=10)"
                       if args.mode == "matched" else "3D line candidates scored/sec (exhaustive)",
@@ -204,8 +221,7 @@ def main():
                        "valid_edges_rank0": st["valid_edges"], "tracks_rank0": st_after["tracks"]},
             "kernel_ms": kt,
             "connections_per_s": conn_total * args.steps / elapsed,
-            "roofline": dict(roof[dom], kernel=("k_score3" if dom == "score" else
-                                                 ("k_gen_rows" if args.mode == "matched" else "k_gen_exhaustive"))),
+            "roofline": dict(roof[dom], kernel=dom),
             "roofline_all": roof,
             "host_ms": {"upload_matches": 1e3 * t_upload, "tail_compute_tracks": 1e3 * t_tail},
             "tracks_whole_scene": st_after["tracks"], "merge_note": merge_note,

@@ -203,8 +203,10 @@ int lt_get_stats(lt_ctx *ctx, int64_t out[8]);
  * [0] whole run, [1] invariants, [2] connection sort, [3] generation, [4] compaction,
  * [5] scoring kernel, [6] selection + edges, [7] gather; host: [8] upload, [9] download,
  * [10] tail (lt_compute_tracks); [11] candidate pairs that reached the dense evaluation in k_score3;
- * [12] host ms spent inside lt_triangulate_image* buffering the match rows of the batch */
-int lt_get_timers(lt_ctx *ctx, double out[16]);
+ * [12] host ms spent inside lt_triangulate_image* buffering the match rows of the batch;
+ * single-kernel durations (HIP events around the launch): [13] k_gates, [14] k_tri_rows, [15] k_score3;
+ * [16] connections that passed the stage-A gates (k_gates) */
+int lt_get_timers(lt_ctx *ctx, double out[24]);
 
 /* The library keeps released device blocks and page-locked staging blocks in a process-wide cache
  * (contexts are typically created once per scene; hipMalloc / hipHostMalloc / hipFree are the slow part

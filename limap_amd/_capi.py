@@ -370,10 +370,10 @@ class Context:
         return dict(zip(keys, out.tolist()))
 
     def timers(self):
-        out = np.zeros(16)
+        out = np.zeros(24)
         self.chk(self.L.lt_get_timers(self.h, ptr(out, C.c_double)))
         keys = ["run", "invariants", "sort", "gen", "compact", "score", "select", "gather", "upload", "download", "tail",
-                "pairs_eval", "buffer"]
+                "pairs_eval", "buffer", "k_gates", "k_tri_rows", "k_score3", "survivors"]
         return dict(zip(keys, out.tolist()))
 
     # --- free functions ---

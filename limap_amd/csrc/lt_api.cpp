@@ -38,7 +38,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
                       const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
                       unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, unsigned *st_row,
-                      unsigned *surv_count, long long n_segs, void *gates, void *blkrec);
+                      unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3);
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
                         unsigned *n_tris);
@@ -57,7 +57,7 @@ size_t cand_meta_bytes();
 void launch_score3(hipStream_t st, long long C, long long G, const long long *tri_off, const unsigned *cand_node,
                    void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
-                   int max_nb, const ScoreCfg &cfg, double scaleinv_guard2);
+                   int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before);
 }
 
 // ---- pooled page-locked host blocks (see lt_ctx.h) ----
@@ -177,27 +177,27 @@ void dev_block_release(void *p, size_t cap) {
 struct StreamSet {
   int device;
   hipStream_t stream;
-  hipEvent_t ev[9];
+  hipEvent_t ev[12];
 };
 std::vector<StreamSet> &g_stream_pool = *new std::vector<StreamSet>;
-bool stream_set_acquire(int device, hipStream_t *stream, hipEvent_t ev[9]) {
+bool stream_set_acquire(int device, hipStream_t *stream, hipEvent_t ev[12]) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   for (size_t i = 0; i < g_stream_pool.size(); ++i)
     if (g_stream_pool[i].device == device) {
       *stream = g_stream_pool[i].stream;
-      for (int k = 0; k < 9; ++k) ev[k] = g_stream_pool[i].ev[k];
+      for (int k = 0; k < 12; ++k) ev[k] = g_stream_pool[i].ev[k];
       g_stream_pool.erase(g_stream_pool.begin() + i);
       return true;
     }
   return false;
 }
-bool stream_set_release(int device, hipStream_t stream, hipEvent_t ev[9]) {
+bool stream_set_release(int device, hipStream_t stream, hipEvent_t ev[12]) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   if (g_stream_pool.size() >= 8) return false;
   StreamSet s;
   s.device = device;
   s.stream = stream;
-  for (int k = 0; k < 9; ++k) s.ev[k] = ev[k];
+  for (int k = 0; k < 12; ++k) s.ev[k] = ev[k];
   g_stream_pool.push_back(s);
   return true;
 }
@@ -220,6 +220,16 @@ void release_cached_memory() {
 extern "C" void lt_release_cached_memory(void) { lt_host::release_cached_memory(); }
 
 namespace {
+
+// per-kernel HIP events (timers [13]-[15]) cost a few microseconds of stream bubble each: on by
+// default (bench.py prices the dominant kernel with them), LT_FINE_TIMERS=0 turns them off
+bool fine_timers() {
+  static const bool on = [] {
+    const char *e = getenv("LT_FINE_TIMERS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -930,6 +940,7 @@ int lt_run_device(lt_ctx *ctx) {
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
 
   long long C_known = -1;  // candidate count once it is known on the host
+  ctx->C_last = 0;
   if (ctx->job_mode == 1) {
     const size_t Pn = (size_t)std::max<long long>(P, 1);
     const bool fast = ctx->rows_sorted;
@@ -963,7 +974,7 @@ int lt_run_device(lt_ctx *ctx) {
                        ctx->d_pairs.as<PairRec>(), ctx->d_blk_line_base.as<long long>(), ctx->d_st_c.as<Cand>(),
                        ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(), ctx->d_wave_count.as<unsigned>(),
                        fast ? ctx->d_cnt_bl.as<unsigned>() : nullptr, lds_segs, lds_segs1, ctx->d_st_row.as<unsigned>(),
-                       ctx->d_surv_count.as<unsigned>(), G, ctx->d_seg_gates.p, ctx->d_blkrec.p);
+                       ctx->d_surv_count.as<unsigned>(), G, ctx->d_seg_gates.p, ctx->d_blkrec.p, fine_timers() ? &ctx->ev[8] : nullptr);
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
     long long *hC = ctx->h_pinned;
@@ -1084,11 +1095,12 @@ int lt_run_device(lt_ctx *ctx) {
     if (ctx->h_nb_off[ctx->n_img] >= (1ll << 24))
       return fail(ctx, LT_ERR_ARGUMENT, "too many (image, neighbour) blocks in one batch (>= 2^24)");
     ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_known, 1));
+    ctx->C_last = C_known;
     launch_score3(st, C_known, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
                   ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_node_img.as<int>(),
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
                   ctx->d_score.as<double>(), ctx->d_pair_counter.as<unsigned long long>(), ctx->max_nb, scfg,
-                  guard2);
+                  guard2, fine_timers() ? ctx->ev[11] : nullptr);
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));
@@ -1116,14 +1128,25 @@ int lt_run_device(lt_ctx *ctx) {
                      ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(), ctx->d_ntris.as<int>());
   HIPCHK(ctx, hipEventRecord(ctx->ev[7], st));
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(st));
+  // the device error flag and the pair statistic ride on the stream into pinned scratch (two blocking
+  // 8-byte copies after the sync would cost more host time than some of the kernels)
   int derr = 0;
-  HIPCHK(ctx, hipMemcpy(&derr, ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost));
-  {
+  if (ctx->h_pinned) {
+    ctx->h_pinned[1] = 0; ctx->h_pinned[2] = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->h_pinned[1], ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (ctx->C_last > 0)
+      HIPCHK(ctx, hipMemcpyAsync(&ctx->h_pinned[2], ctx->d_pair_counter.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    derr = *reinterpret_cast<int *>(&ctx->h_pinned[1]);
+    ctx->stat_pairs_eval = ctx->h_pinned[2];
+  } else {
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipMemcpy(&derr, ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost));
     unsigned long long pe = 0;
-    HIPCHK(ctx, hipMemcpy(&pe, ctx->d_pair_counter.p, 8, hipMemcpyDeviceToHost));
+    if (ctx->C_last > 0) HIPCHK(ctx, hipMemcpy(&pe, ctx->d_pair_counter.p, 8, hipMemcpyDeviceToHost));
     ctx->stat_pairs_eval = (long long)pe;
   }
+  ctx->stat_survivors = -1;  // summed on demand (lt_get_timers)
   if (derr != 0) return fail(ctx, LT_ERR_RUNTIME, "IndexError! Out-of-index matches detected on the device");
   float ms;
   static const int kMap[7] = {1, 2, 3, 4, 5, 6, 7};
@@ -1133,6 +1156,14 @@ int lt_run_device(lt_ctx *ctx) {
   }
   HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[7]));
   ctx->timers[0] = ms;
+  // single-kernel durations of the matched pipeline: [13] k_gates, [14] k_tri_rows, [15] k_score3
+  ctx->timers[13] = ctx->timers[14] = ctx->timers[15] = 0.0;
+  if (fine_timers() && ctx->job_mode == 1 && ctx->n_blk > 0 && ctx->max_rows > 0) {
+    if (hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[9]) == hipSuccess) ctx->timers[13] = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]) == hipSuccess) ctx->timers[14] = ms;
+  }
+  if (fine_timers() && ctx->C_last > 0 && hipEventElapsedTime(&ms, ctx->ev[11], ctx->ev[5]) == hipSuccess) ctx->timers[15] = ms;
+  (void)hipGetLastError();
   ctx->ran = true;
   ctx->downloaded = false;
   return LT_OK;
@@ -1637,8 +1668,21 @@ int lt_get_stats(lt_ctx *ctx, int64_t out[8]) {
   out[7] = ctx->G;
   return LT_OK;
 }
-int lt_get_timers(lt_ctx *ctx, double out[16]) {
+int lt_get_timers(lt_ctx *ctx, double out[24]) {
   ctx->timers[11] = (double)ctx->stat_pairs_eval;
+  if (ctx->stat_survivors < 0) {
+    ctx->stat_survivors = 0;
+    if (ctx->ran && ctx->job_mode == 1 && ctx->n_blk > 0 && ctx->max_rows > 0 && ctx->d_surv_count.p) {
+      const size_t n = (size_t)ctx->n_blk * (size_t)gen_slots(ctx->max_rows);
+      std::vector<unsigned> sc(n);
+      HIPCHK(ctx, hipSetDevice(ctx->device));
+      HIPCHK(ctx, hipMemcpy(sc.data(), ctx->d_surv_count.p, 4 * n, hipMemcpyDeviceToHost));
+      long long tot = 0;
+      for (unsigned v : sc) tot += v;
+      ctx->stat_survivors = tot;
+    }
+  }
+  ctx->timers[16] = (double)ctx->stat_survivors;
   std::memcpy(out, ctx->timers, sizeof(ctx->timers));
   return LT_OK;
 }

@@ -737,7 +737,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
                       const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
                       unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, unsigned *st_row,
-                      unsigned *surv_count, long long n_segs, void *gates, void *blkrec) {
+                      unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3) {
   if (n_blk <= 0 || max_rows <= 0) return;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -765,11 +765,14 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   const unsigned n_wg = (unsigned)std::min<long long>(n_items, (long long)n_cu * per_cu);
   // the tables are sized by the largest image of the job, so "fits" is a per-launch property
   const dim3 grid(n_wg), block(64 * kGateWaves);
+  if (ev3) (void)hipEventRecord(ev3[0], st);
   if (lds_segs1 > 0 && lds_segs > 0) hipLaunchKernelGGL((k_gates<true, true>), grid, block, lds, st, a, cfg);
   else if (lds_segs > 0) hipLaunchKernelGGL((k_gates<false, true>), grid, block, lds, st, a, cfg);
   else if (lds_segs1 > 0) hipLaunchKernelGGL((k_gates<true, false>), grid, block, lds, st, a, cfg);
   else hipLaunchKernelGGL((k_gates<false, false>), grid, block, lds, st, a, cfg);
+  if (ev3) (void)hipEventRecord(ev3[1], st);
   hipLaunchKernelGGL(k_tri_rows, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg);
+  if (ev3) (void)hipEventRecord(ev3[2], st);
 }
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
@@ -808,10 +811,13 @@ size_t score3_lds_bytes(int max_nb) {
   return 9 * kWin * 8 + (size_t)max_nb * 64 * 8 + 64 * 8 + kWin * 4 + kSQCap * 4 + (size_t)max_nb * 4;
 }
 size_t cand_meta_bytes() { return sizeof(CandMeta); }
+// (A two-kernel form -- light sweep writing per-tile pair lists, then a dense evaluation kernel -- was
+// measured: the sweep alone takes 53 us, but the evaluation does not get cheaper and the two phases no
+// longer overlap across waves: 165+ us against 150 us fused.)
 void launch_score3(hipStream_t st, long long C, long long G, const long long *tri_off, const unsigned *cand_node,
                    void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
-                   int max_nb, const ScoreCfg &cfg, double scaleinv_guard2) {
+                   int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before) {
   if (C <= 0) return;
   hipLaunchKernelGGL(k_cand_meta, dim3(nblk2(C, 256)), dim3(256), 0, st, C, cand_node, tri_off, node_img, nb_off,
                      reinterpret_cast<CandMeta *>(meta));
@@ -819,6 +825,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand; a.lite = lite;
   a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
   a.max_nb = max_nb;
+  if (ev_before) (void)hipEventRecord(ev_before, st);
   hipLaunchKernelGGL(k_score3, dim3(nblk2(C, 64)), dim3(64), score3_lds_bytes(max_nb), st, a, cfg, scaleinv_guard2);
 }
 
