@@ -66,7 +66,7 @@ namespace {
 // never destroyed: contexts may be released during process teardown, after static destructors ran
 std::mutex &g_pool_mu = *new std::mutex;
 std::vector<HostBlock> &g_pool = *new std::vector<HostBlock>;  // released blocks, at most kPoolBlocks / kPoolBytes
-constexpr size_t kPoolBlocks = 4;
+constexpr size_t kPoolBlocks = 8;
 constexpr size_t kPoolBytes = 4ull << 30;
 }  // namespace
 HostBlock host_block_acquire(size_t bytes) {
@@ -75,7 +75,9 @@ HostBlock host_block_acquire(size_t bytes) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     int best = -1;
     for (size_t i = 0; i < g_pool.size(); ++i)
-      if (g_pool[i].bytes >= bytes && (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = (int)i;
+      if (g_pool[i].bytes >= bytes && g_pool[i].bytes <= 8 * bytes + (1u << 20) &&  // a 4 KB scratch must not eat the staging block
+          (best < 0 || g_pool[i].bytes < g_pool[best].bytes))
+        best = (int)i;
     if (best >= 0) {
       HostBlock b = g_pool[best];
       g_pool.erase(g_pool.begin() + best);

@@ -9,3 +9,4 @@ cd /tmp && rm -rf /tmp/prof_$tag && timeout 600 rocprofv3 --kernel-trace -d /tmp
 db=$(find /tmp/prof_$tag -name "*.db" | head -1)
 python $repo/tools/rocpd_kernel_stats.py $db $repo/gpurun_out/${tag}_kernel_stats.csv > /dev/null
 head -14 $repo/gpurun_out/${tag}_kernel_stats.csv | sed 's/"_ZN2lt[0-9]*\(k_[a-z_0-9]*\)[^"]*"/\1/' | cut -c1-120
+python $repo/tools/rocpd_timeline.py $db > $repo/gpurun_out/${tag}_timeline.txt 2>&1
