@@ -271,7 +271,10 @@ GenCfg make_gen(const lt_ctx *ctx) {
   g.sens_th = c.sensitivity_threshold; g.var2d = c.var2d;
   for (int k = 0; k < 3; ++k) { g.lo[k] = ctx->lo[k]; g.hi[k] = ctx->hi[k]; }
   g.use_ranges = ctx->ranges_on; g.use_endpoints = c.use_endpoints_triangulation;
-  g.disable_algebraic = c.disable_algebraic_triangulation; g.pad_ = 0;
+  g.disable_algebraic = c.disable_algebraic_triangulation;
+  // LT_TEST_NO_FAST_GATES: the cheap gates never decide, the reference's exact gates do all the work;
+  // results must not change (tests/test_gpu_guards.py)
+  g.force_undecided = getenv("LT_TEST_NO_FAST_GATES") != nullptr;
   // The gate `90 - acos(a)*180/pi < th` is equivalent to a < sin(th) up to libm rounding; outside
   // a +-1e-7 relative band around sin(th) the comparison of a alone decides, inside it the exact
   // expression is evaluated.  For thresholds outside (0, 90) the band covers everything.
@@ -308,6 +311,9 @@ ScoreCfg make_score(const lt_ctx *ctx) {
   // exactly.  th_angle >= 90 disables the early exit.
   double th = s.l3.th_angle * (1.0 + 1e-6) + 1e-6;
   s.cos_guard = (th < 90.0) ? std::cos(th * kPi / 180.0) : -1.0;
+  // LT_TEST_NO_SCORE_GUARDS: no conservative early exit in the scoring sweep (every pair of a node is
+  // evaluated densely); results must not change (tests/test_gpu_guards.py)
+  if (getenv("LT_TEST_NO_SCORE_GUARDS")) s.cos_guard = -1.0;
   s.fullscore_th = ctx->cfg.fullscore_th;
   s.max_valid_conns = ctx->cfg.max_valid_conns;
   s.pad_ = 0;
@@ -1092,6 +1098,7 @@ int lt_run_device(lt_ctx *ctx) {
     // conservative square of the scale-invariant endpoint gate (see k_score2)
     double th = scfg.l3.th_scaleinv * (1.0 + 1e-6);
     double guard2 = (scfg.l3.th_scaleinv > 0.0 && scfg.l3.score_th > 0.0 && scfg.l3.score_th < 1.0) ? th * th : 1e300;
+    if (getenv("LT_TEST_NO_SCORE_GUARDS")) guard2 = 1e300;
     ENSURE(ctx, ctx->d_pair_counter, 8);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_pair_counter.p, 0, 8, st));
     if (ctx->h_nb_off[ctx->n_img] >= (1ll << 24))

@@ -237,6 +237,7 @@ static __device__ __forceinline__ int gate3(const GenCfg &cfg, double a1x, doubl
   const double margin = __builtin_fma(1e-12, cerr, 1e-7 * (1.0 + fabs(c1v) + fabs(c2v)) * (1.0 + fabs(cfg.iou_th)));
   rej |= well & (delta < -margin);
   und |= !(well & (delta > margin));
+  if (cfg.force_undecided) return 2;  // test switch (LT_TEST_NO_FAST_GATES)
   return rej ? 0 : (und ? 2 : 1);
 }
 

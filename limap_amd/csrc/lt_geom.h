@@ -249,7 +249,8 @@ struct LinkCfg3 {
 struct GenCfg {
   double min_length_2d, angle_th, iou_th, sens_th, var2d;
   double lo[3], hi[3];
-  int use_ranges, use_endpoints, disable_algebraic, pad_;
+  int use_ranges, use_endpoints, disable_algebraic;
+  int force_undecided;  // test switch: stage A never decides (every row goes through the exact gates)
   // conservative cosine-domain guards for the 1-degree ray/plane gate (see gen kernel)
   double sin_lo, sin_hi;
   // squared-length guards of the min_length_2d test: q <= len_lo2 certainly fails `sqrt(q) > min_length`,

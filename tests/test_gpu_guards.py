@@ -1,0 +1,107 @@
+"""-m gpu: the fast paths are conservative.  Stage A (`gate3`) only ever decides when the reference's
+outcome is certain, and the scoring sweep only skips pairs that cannot score; switching either shortcut
+off (everything then runs through the reference-exact expressions) must not change a single bit of the
+results.  Also threshold / option variants of the gates against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from limap_amd import synthetic as syn
+
+from helpers import (compare_best, compare_candidates, compare_tracks, compare_valid_edges, run_oracle,
+                     run_product)
+
+pytestmark = pytest.mark.gpu
+
+
+def _results(T):
+    ctx = T.context()
+    allt = ctx.get_all_tris()
+    best = ctx.get_best()
+    edges = ctx.get_valid_edges()
+    ctx.compute_tracks()
+    return allt, best, edges, ctx.get_tracks(), ctx.timers(), ctx.stats()
+
+
+def _same(a, b):
+    (ta, ba, ea, ka, _, _), (tb, bb, eb, kb, _, _) = a, b
+    for k in ("off", "src", "line", "score"):
+        assert np.array_equal(ta[k], tb[k]), f"all_tris[{k}] changed"
+    for k in ("has_best", "src", "line", "score"):
+        assert np.array_equal(ba[k], bb[k]), f"best[{k}] changed"
+    assert np.array_equal(ea[0], eb[0]) and np.array_equal(ea[1], eb[1]), "valid edges changed"
+    for k in ("off", "image_ids", "line_ids", "node_ids", "scores", "line"):
+        assert np.array_equal(ka[k], kb[k]), f"tracks[{k}] changed"
+
+
+@pytest.fixture
+def clean_env():
+    keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS")
+    saved = {k: os.environ.pop(k, None) for k in keys}
+    yield
+    for k in keys:
+        os.environ.pop(k, None)
+        if saved[k] is not None:
+            os.environ[k] = saved[k]
+
+
+def test_fast_paths_are_conservative(gpu_lib, clean_env):
+    sc = syn.make_scene(n_views=24, n_segs=160, n_neighbors=8, seed=21)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    base = _results(run_product(sc, cfg))
+    assert base[5]["candidates"] > 2000 and base[5]["valid_edges"] > 100
+
+    os.environ["LT_TEST_NO_FAST_GATES"] = "1"
+    exact_gates = _results(run_product(sc, cfg))
+    del os.environ["LT_TEST_NO_FAST_GATES"]
+    _same(base, exact_gates)
+    # every row went to the exact gates, and far more rows than the cheap gates let through
+    assert exact_gates[4]["survivors"] == exact_gates[5]["connections"]
+    assert base[4]["survivors"] < 0.5 * exact_gates[4]["survivors"]
+
+    os.environ["LT_TEST_NO_SCORE_GUARDS"] = "1"
+    no_guards = _results(run_product(sc, cfg))
+    del os.environ["LT_TEST_NO_SCORE_GUARDS"]
+    _same(base, no_guards)
+    assert no_guards[4]["pairs_eval"] > 2 * base[4]["pairs_eval"]
+
+
+@pytest.mark.parametrize("over", [
+    dict(min_length_2d=40.0),                       # the length gate bites (squared-length guard band)
+    dict(line_tri_angle_threshold=5.0),             # wider degeneracy gate
+    dict(IoU_threshold=0.35),                       # stricter weak-epipolar gate
+    dict(sensitivity_threshold=40.0),               # the post-triangulation gate bites
+    dict(min_length_2d=0.0, IoU_threshold=0.0),     # degenerate thresholds
+])
+def test_gate_variants_match_oracle(gpu_lib, oracle, clean_env, over):
+    sc = syn.make_scene(n_views=12, n_segs=90, n_neighbors=5, seed=33)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    cfg.update(over)
+    T = run_product(sc, cfg)
+    O = run_oracle(oracle, sc, cfg)
+    compare_candidates(T.context().get_all_tris(), O.get_all_tris())
+    compare_best(T.context().get_best(), O.get_best())
+    compare_valid_edges(T.context().get_valid_edges(), O.get_valid_edges())
+    T.context().compute_tracks()
+    compare_tracks(T.context().get_tracks(), O.ComputeLineTracks())
+    # and the exact-gates run agrees with the fast one
+    os.environ["LT_TEST_NO_FAST_GATES"] = "1"
+    T2 = run_product(sc, cfg)
+    a, b = T.context().get_all_tris(), T2.context().get_all_tris()
+    del os.environ["LT_TEST_NO_FAST_GATES"]
+    for k in ("off", "src", "line", "score"):
+        assert np.array_equal(a[k], b[k])
+
+
+def test_release_cached_memory(gpu_lib):
+    sc = syn.make_scene(n_views=6, n_segs=40, n_neighbors=3, seed=5)
+    cfg = syn.default_triangulation_cfg()
+    T = run_product(sc, cfg)
+    n1 = len(T.ComputeLineTracks())
+    del T
+    gpu_lib.lt_release_cached_memory()      # everything cached goes back to the driver ...
+    T = run_product(sc, cfg)                # ... and a new context still works (fresh allocations)
+    assert len(T.ComputeLineTracks()) == n1
+    gpu_lib.lt_release_cached_memory()      # live context unaffected
+    assert len(T.context().get_tracks()["off"]) == n1 + 1
