@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LIMAP_AMD_LIB") or os.path.join(_HERE, "liblimap_amd.
 
 EXPORTED_SYMBOLS = [
     "lt_config_default", "lt_abi_version", "lt_sizeof_config", "lt_create", "lt_destroy", "lt_last_error", "lt_set_stream", "lt_set_ranges",
-    "lt_unset_ranges", "lt_init", "lt_init_device", "lt_refresh_scene_device", "lt_set_scene_chunks",
+    "lt_unset_ranges", "lt_init", "lt_init_vp", "lt_init_device", "lt_refresh_scene_device", "lt_set_scene_chunks",
     "lt_refresh_scene_chunks", "lt_triangulate_image", "lt_triangulate_image_rows",
     "lt_triangulate_image_exhaustive", "lt_upload", "lt_run_device", "lt_download", "lt_flush",
     "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
@@ -97,6 +97,7 @@ def load_library():
     L.lt_set_ranges.argtypes = [vp, dp, dp]
     L.lt_unset_ranges.argtypes = [vp]
     L.lt_init.argtypes = [vp, C.c_int, i32p, dp, dp, dp, i64p, dp]
+    L.lt_init_vp.argtypes = [vp, C.c_int, i32p, i64p, i32p, i64p, dp]
     L.lt_init_device.argtypes = [vp, C.c_int, i32p, vp, vp, vp, i64p, vp]
     L.lt_refresh_scene_device.argtypes = [vp, vp, vp, vp, vp]
     vpp = C.POINTER(C.c_void_p)
@@ -255,6 +256,25 @@ class Context:
         nb_ids, m_off, m_pairs = i32(nb_ids), i64(m_off), i32(m_pairs)
         self.chk(self.L.lt_triangulate_image(self.h, int(img_id), len(nb_ids), ptr(nb_ids, C.c_int32),
                                              ptr(m_off, C.c_int64), ptr(m_pairs, C.c_int32)))
+
+    def init_vp(self, vpresults):
+        """vpresults: dict img_id -> (labels (M,) int, vps (V,3) float) -- the content of vplib.VPResult."""
+        ids = sorted(int(k) for k in vpresults)
+        lab_off, vp_off = np.zeros(len(ids) + 1, np.int64), np.zeros(len(ids) + 1, np.int64)
+        labs, vps = [np.zeros(0, np.int32)], [np.zeros((0, 3))]
+        for n, i in enumerate(ids):
+            lab, v = vpresults[i]
+            lab, v = i32(np.asarray(lab).reshape(-1)), f64(np.asarray(v, float).reshape(-1, 3))
+            labs.append(lab); vps.append(v)
+            lab_off[n + 1] = lab_off[n] + len(lab)
+            vp_off[n + 1] = vp_off[n] + len(v)
+        labs = i32(np.concatenate(labs)); vps = f64(np.concatenate(vps, 0))
+        if labs.size == 0:
+            labs = np.zeros(1, np.int32)
+        if vps.size == 0:
+            vps = np.zeros((1, 3))
+        self.chk(self.L.lt_init_vp(self.h, len(ids), ptr(i32(ids), C.c_int32), ptr(lab_off, C.c_int64),
+                                   ptr(labs, C.c_int32), ptr(vp_off, C.c_int64), ptr(vps, C.c_double)))
 
     def triangulate_image_rows(self, img_id, nb_ids, arrays):
         """arrays[k]: C-contiguous int32 (K,2) rows of neighbour nb_ids[k] (kept alive for the call)."""

@@ -38,17 +38,18 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
                       const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
                       unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, unsigned *st_row,
-                      unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3);
+                      unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3,
+                      const double *seg_vp, const unsigned char *seg_has_vp);
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
                         unsigned *n_tris);
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
-                  const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node);
+                  const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node, int mult);
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
-                      unsigned *keys_c, unsigned *src_c);
+                      unsigned *keys_c, unsigned *src_c, int mult);
 void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const Cand *st_c,
                     const CandLite *st_l, Cand *cand, CandLite *lite, unsigned *cand_node);
 void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, unsigned *cand_node);
@@ -275,6 +276,8 @@ GenCfg make_gen(const lt_ctx *ctx) {
   // LT_TEST_NO_FAST_GATES: the cheap gates never decide, the reference's exact gates do all the work;
   // results must not change (tests/test_gpu_guards.py)
   g.force_undecided = getenv("LT_TEST_NO_FAST_GATES") != nullptr;
+  // VP-guided proposals do not depend on the algebraic gates: every row must reach the triangulation kernel
+  if (c.use_vp && !c.disable_vp_triangulation) g.force_undecided = 1;
   // The gate `90 - acos(a)*180/pi < th` is equivalent to a < sin(th) up to libm rounding; outside
   // a +-1e-7 relative band around sin(th) the comparison of a alone decides, inside it the exact
   // expression is evaluated.  For thresholds outside (0, 90) the band covers everything.
@@ -356,6 +359,7 @@ int init_common(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *s
   ctx->n_tris.assign(ctx->G, 0);
   ctx->has_best.assign(ctx->G, 0);
   ctx->valid_edges.reset(ctx->G);
+  ctx->vp_ready = false;
   ctx->tracks.clear();
   ctx->tracks_done = false;
   ctx->job_mode = 0;
@@ -512,7 +516,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
-                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec};
+                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp};
   lt_host::host_block_release(ctx->h_pinned_blk);
   for (DevBuf *b : bufs) b->release();
   // a context that still owns its stream hands stream + events to the next context
@@ -553,7 +557,6 @@ int lt_unset_ranges(lt_ctx *ctx) {
 int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, const double *qvec,
             const double *tvec, const int64_t *seg_off, const double *segs) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (ctx->cfg.use_vp) return fail(ctx, LT_ERR_ARGUMENT, "use_vp (VP-guided proposals) is not implemented in this backend");
   if (n_img < 0) return fail(ctx, LT_ERR_ARGUMENT, "n_img < 0");
   std::vector<int> perm(n_img);
   for (int i = 0; i < n_img; ++i) perm[i] = i;
@@ -577,10 +580,40 @@ int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, 
   return build_invariants(ctx);
 }
 
+int lt_init_vp(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *label_off, const int32_t *labels,
+               const int64_t *vp_off, const double *vps) {
+  if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "InitVPResults before Init");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<double> vp(3 * (size_t)std::max<long long>(ctx->G, 1), 0.0);
+  std::vector<unsigned char> has((size_t)std::max<long long>(ctx->G, 1), 0);
+  for (int i = 0; i < n_img; ++i) {
+    auto it = ctx->id2idx.find(img_ids[i]);
+    if (it == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "InitVPResults: unknown image id " + std::to_string(img_ids[i]));
+    const int idx = it->second;
+    const long long M = ctx->seg_off[idx + 1] - ctx->seg_off[idx];
+    const long long nl = label_off[i + 1] - label_off[i], nv = vp_off[i + 1] - vp_off[i];
+    if (nl != M) return fail(ctx, LT_ERR_ARGUMENT, "InitVPResults: " + std::to_string(nl) + " labels for image " +
+                                                       std::to_string(img_ids[i]) + " with " + std::to_string(M) + " lines");
+    for (long long l = 0; l < M; ++l) {
+      const int lab = labels[label_off[i] + l];
+      if (lab < 0) continue;  // VPResult::HasVP (vplib/vpbase.h:42)
+      if (lab >= nv) return fail(ctx, LT_ERR_ARGUMENT, "InitVPResults: VP label out of range");
+      const long long g = ctx->seg_off[idx] + l;
+      has[(size_t)g] = 1;
+      for (int k = 0; k < 3; ++k) vp[3 * (size_t)g + k] = vps[3 * (vp_off[i] + lab) + k];
+    }
+  }
+  int rc;
+  if ((rc = upload_vec(ctx, ctx->d_seg_vp, vp))) return rc;
+  if ((rc = upload_vec(ctx, ctx->d_seg_has_vp, has))) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->vp_ready = true;
+  return LT_OK;
+}
+
 int lt_init_device(lt_ctx *ctx, int n_img, const int32_t *img_ids, const void *d_kvec, const void *d_qvec,
                    const void *d_tvec, const int64_t *seg_off, const void *d_segs) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (ctx->cfg.use_vp) return fail(ctx, LT_ERR_ARGUMENT, "use_vp (VP-guided proposals) is not implemented in this backend");
   std::vector<int> perm(n_img);
   for (int i = 0; i < n_img; ++i) {
     perm[i] = i;
@@ -807,6 +840,8 @@ int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_id
 }
 
 int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids) {
+  if (ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation)
+    return fail(ctx, LT_ERR_ARGUMENT, "VP-guided proposals (use_vp) are implemented for TriangulateImage (matched mode) only");
   int idx;
   int rc = begin_image(ctx, img_id, 2, &idx);
   if (rc) return rc;
@@ -957,8 +992,13 @@ int lt_run_device(lt_ctx *ctx) {
     const long long n_entries = ctx->h_blk_line_base[ctx->n_blk];
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
     // ---- generation in row order; valid candidates appended in row order to per-wave lists ----
-    ENSURE(ctx, ctx->d_st_c, sizeof(Cand) * Pn); ENSURE(ctx, ctx->d_st_l, sizeof(CandLite) * Pn);
-    ENSURE(ctx, ctx->d_st_key, 4 * Pn);
+    // VP-guided proposals: up to three candidates per match row (vp of l1, vp of l2, algebraic)
+    const bool vp_on = ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation;
+    if (vp_on && !ctx->vp_ready) return fail(ctx, LT_ERR_STATE, "use_vp is set but InitVPResults was not called");
+    const int mult = vp_on ? 3 : 1;
+    if (vp_on && 3 * P >= (1ll << 32) - 1) return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch for VP proposals");
+    ENSURE(ctx, ctx->d_st_c, sizeof(Cand) * Pn * mult); ENSURE(ctx, ctx->d_st_l, sizeof(CandLite) * Pn * mult);
+    ENSURE(ctx, ctx->d_st_key, 4 * Pn * mult);
     ENSURE(ctx, ctx->d_wave_count, 4 * (size_t)(n_waves + 1));
     ENSURE(ctx, ctx->d_ntris_u, 4 * (size_t)(G + 1));
     if (fast) {
@@ -982,7 +1022,9 @@ int lt_run_device(lt_ctx *ctx) {
                        ctx->d_pairs.as<PairRec>(), ctx->d_blk_line_base.as<long long>(), ctx->d_st_c.as<Cand>(),
                        ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(), ctx->d_wave_count.as<unsigned>(),
                        fast ? ctx->d_cnt_bl.as<unsigned>() : nullptr, lds_segs, lds_segs1, ctx->d_st_row.as<unsigned>(),
-                       ctx->d_surv_count.as<unsigned>(), G, ctx->d_seg_gates.p, ctx->d_blkrec.p, fine_timers() ? &ctx->ev[8] : nullptr);
+                       ctx->d_surv_count.as<unsigned>(), G, ctx->d_seg_gates.p, ctx->d_blkrec.p, fine_timers() ? &ctx->ev[8] : nullptr,
+                       vp_on ? ctx->d_seg_vp.as<double>() : nullptr,
+                       vp_on ? ctx->d_seg_has_vp.as<unsigned char>() : nullptr);
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
     long long *hC = ctx->h_pinned;
@@ -1024,13 +1066,13 @@ int lt_run_device(lt_ctx *ctx) {
                    ctx->d_seg_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
                    ctx->d_cnt_bl.as<unsigned>(), ctx->d_wave_count.as<unsigned>(), ctx->d_tri_off.as<long long>(),
                    ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(),
-                   ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_cand_node.as<unsigned>());
+                   ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_cand_node.as<unsigned>(), mult);
     } else {
       ENSURE(ctx, ctx->d_keys, 4 * Cn); ENSURE(ctx, ctx->d_rows, 4 * Cn);
       ENSURE(ctx, ctx->d_skeys, 4 * Cn); ENSURE(ctx, ctx->d_srows, 4 * Cn);
       launch_pack_keys(st, ctx->n_blk, ctx->max_rows, ctx->d_m_off.as<long long>(),
                        ctx->d_wave_count.as<unsigned>(), ctx->d_wave_pos.as<long long>(),
-                       ctx->d_st_key.as<unsigned>(), ctx->d_keys.as<unsigned>(), ctx->d_rows.as<unsigned>());
+                       ctx->d_st_key.as<unsigned>(), ctx->d_keys.as<unsigned>(), ctx->d_rows.as<unsigned>(), mult);
       if (C_known > 0) {
         int end_bit = bits_for(G + 1);
         size_t tmp = sort_temp_bytes(C_known, end_bit);

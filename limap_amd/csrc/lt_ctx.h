@@ -186,7 +186,8 @@ struct lt_ctx {
   bool rows_sorted = true;   // every (image, neighbour) block lists its rows in non-decreasing line id
   lt_host::HostBlock h_pinned_blk;
   long long *h_pinned = nullptr;  // pinned scratch for small device->host scalars
-  DevBuf d_chunks, d_cand_meta, d_st_row, d_surv_count, d_seg_gates, d_blkrec;
+  DevBuf d_chunks, d_cand_meta, d_st_row, d_surv_count, d_seg_gates, d_blkrec, d_seg_vp, d_seg_has_vp;
+  bool vp_ready = false;  // InitVPResults was called for the current scene
   int n_chunks = 0;
   long long cand_cap = 0;
   long long C = 0, E = 0;  // candidates / valid edges of the last run

@@ -286,6 +286,67 @@ static __device__ __forceinline__ bool gen_finish(const GenCfg &cfg, const Cam &
   return true;
 }
 
+// Step 2 of triangulateOneNode (base_line_triangulator.cc:250-281): triangulate_line_with_direction
+// (functions.cc:385-442) with the direction of a vanishing point mapped into the world through VIEW 1
+// (getDirectionFromVP, functions.cc:37-42 -- the reference uses view1 for both lines' VPs), then
+// uncertainty and ranges like every other proposal.  No sensitivity gate on this branch.
+static __device__ __forceinline__ bool vp_candidate(const GenCfg &cfg, const Cam &c1, const Cam &c2, const Seg &s1,
+                                                    const Seg &s2, const double *Bv, const double *vp,
+                                                    GenOut *out) {
+  const d3 direction = unit(mv(c1.Minv, mk3(vp[0], vp[1], vp[2])));
+  const d3 n1 = mk3(s1.n[0], s1.n[1], s1.n[2]);
+  const double nd = dot(n1, direction);
+  d3 direc = sub(direction, scale(n1, nd));
+  if (sqrt(dot(direc, direc)) < kEps) return false;
+  direc = unit(direc);
+  const d3 perp = cross(n1, direc);
+  const d3 v1s = mk3(s1.rs[0], s1.rs[1], s1.rs[2]), v1e = mk3(s1.re[0], s1.re[1], s1.re[2]);
+  double a1s = dot(v1s, perp);
+  double a1e = dot(v1e, perp);
+  if (a1s < 0) {
+    a1s *= -1;
+    a1e *= -1;
+  }
+  if (a1s < 0.001 || a1e < 0.001) return false;
+  const d3 C1 = cam_center(c1);
+  const d3 n2 = mk3(s2.n[0], s2.n[1], s2.n[2]);
+  const double c1s = dot(n2, v1s);
+  const double c1e = dot(n2, v1e);
+  const double b = dot(n2, mk3(Bv[0], Bv[1], Bv[2]));
+  const double cc1 = c1s;
+  const double cc2 = c1e * a1s / a1e;
+  const double d1s_num = (cc1 + cc2) * b;
+  const double d1s_denom = (cc1 * cc1 + cc2 * cc2);
+  const double d1s = d1s_num / d1s_denom;
+  const double d1e = d1s * a1s / a1e;
+  const d3 ps = add(scale(v1s, d1s), C1);
+  const d3 pe = add(scale(v1e, d1e), C1);
+  const double z_start = cam_depth(c1, ps), z_end = cam_depth(c1, pe);
+  if (z_start < kEps || z_end < kEps) return false;
+  const double d21 = cam_depth(c2, ps), d22 = cam_depth(c2, pe);
+  if (d21 < kEps || d22 < kEps) return false;
+  if (isnan(ps.x) || isnan(pe.x)) return false;
+  const double u1 = cfg.var2d * ((z_start + z_end) / 2.0) / c1.f;
+  const double u2 = cfg.var2d * ((d21 + d22) / 2.0) / c2.f;
+  if (cfg.use_ranges) {
+    if (ps.x < cfg.lo[0] || ps.x > cfg.hi[0]) return false;
+    if (ps.y < cfg.lo[1] || ps.y > cfg.hi[1]) return false;
+    if (ps.z < cfg.lo[2] || ps.z > cfg.hi[2]) return false;
+    if (pe.x < cfg.lo[0] || pe.x > cfg.hi[0]) return false;
+    if (pe.y < cfg.lo[1] || pe.y > cfg.hi[1]) return false;
+    if (pe.z < cfg.lo[2] || pe.z > cfg.hi[2]) return false;
+  }
+  const d3 dir3 = unit(sub(pe, ps));
+  out->c.s[0] = ps.x; out->c.s[1] = ps.y; out->c.s[2] = ps.z;
+  out->c.e[0] = pe.x; out->c.e[1] = pe.y; out->c.e[2] = pe.z;
+  out->c.depth[0] = z_start; out->c.depth[1] = z_end;
+  out->c.unc = dmin(u1, u2);
+  out->c.score3 = 1.0;
+  out->c.seg[0] = s2.x1; out->c.seg[1] = s2.y1; out->c.seg[2] = s2.x2; out->c.seg[3] = s2.y2;
+  out->l.dir[0] = dir3.x; out->l.dir[1] = dir3.y; out->l.dir[2] = dir3.z;
+  return true;
+}
+
 static __device__ __forceinline__ bool gen_one(const GenCfg &cfg, const Cam &c1, const Cam &c2,
                                                const Seg &s1, const Seg &s2, const PairRec &pr,
                                                GenOut *out) {

@@ -103,6 +103,10 @@ struct GenArgs {
   int n_slots;            // slots per block (multiple of kGateWaves)
   int lds_segs;           // capacity (in segments) of the LDS table T2; 0 = read the gate records from HBM/L2
   int lds_segs1;          // capacity of T1 (the image's own segments); 0 = gather them from HBM/L2
+  // VP-guided proposals (use_vp): per segment its vanishing point (image homogeneous coordinates) and a flag
+  const double *seg_vp;          // [G][3] or nullptr
+  const unsigned char *seg_has_vp;
+  int mult;               // staging slots per match row: 1, or 3 with VP proposals (vp1, vp2, algebraic)
 };
 
 __global__ void k_build_gates(long long n_segs, const Seg *__restrict__ segs, SegGate *__restrict__ gates) {
@@ -282,6 +286,9 @@ k_gates(GenArgs a, GenCfg cfg) {
 
 // One wave per (block, group).  (A persistent-wave variant with the next item's record prefetched was
 // measured slower: the kernel is bound by gather / scatter throughput, not by latency.)
+// kVP: additionally the VP-guided proposals of step 2 (base_line_triangulator.cc:250-281) -- per
+// connection up to three candidates in the reference's order vp(l1), vp(l2), algebraic.
+template <bool kVP>
 __global__ void __launch_bounds__(256)
 k_tri_rows(GenArgs a, GenCfg cfg) {
   const int wave = threadIdx.x >> 6;
@@ -303,6 +310,7 @@ k_tri_rows(GenArgs a, GenCfg cfg) {
   const long long g1 = rec->g1, g2 = rec->g2;
   const PairRec *pr = a.pairs + b;
   const long long lbase = a.cnt_bl ? rec->lbase : 0;
+  const long long out0 = r0 * (kVP ? (long long)a.mult : 1ll);  // first staging slot of the group
   // survivor lists of the group's slots, walked as one concatenated list
   unsigned cs[kTriSlots + 1];
   cs[0] = 0;
@@ -313,9 +321,9 @@ k_tri_rows(GenArgs a, GenCfg cfg) {
   unsigned wcount = 0;
   for (unsigned e0 = 0; e0 < n_s; e0 += 64) {
     const unsigned e = e0 + lane;
-    bool ok = false;
+    bool ok = false, ok1 = false, ok2 = false;
     GenOut o;
-    int line = 0;
+    int line = 0, ng = 0;
     if (e < n_s) {
       int k = 0;
       unsigned first = 0;
@@ -327,34 +335,62 @@ k_tri_rows(GenArgs a, GenCfg cfg) {
       const long long r = rs0 + (long long)(u & 0x7FFFFFFFu);
       const int2 v = *reinterpret_cast<const int2 *>(a.m_pairs + 2 * r);
       line = v.x;
-      const int ng = v.y;
+      ng = v.y;
       const Seg &s1 = a.segs[g1 + line];
       const Seg &s2 = a.segs[g2 + ng];
       ok = true;
       if (u >> 31) ok = gen_gates(cfg, s1, s2, pr->F);  // the cheap gates could not decide
-#if defined(LT_X_NOFINISH)
-      if (ok) { ok = ((line + ng) & 1) == 0; o.c.s[0] = s1.rs[0] + s2.re[1]; o.c.e[0] = s1.re[2] + s2.rs[0]; o.l.dir[0] = s2.x1; }
-#else
       if (ok) ok = gen_finish(cfg, a.cams[i1], a.cams[i2], s1, s2, pr->B, &o);
-#endif
+      if (kVP) {
+        // both segments long enough (:166,177) -- with VP proposals stage A lets every row through
+        L2 l1{mk2(s1.x1, s1.y1), mk2(s1.x2, s1.y2)};
+        L2 l2{mk2(s2.x1, s2.y1), mk2(s2.x2, s2.y2)};
+        const bool len_ok = !(len(l1) <= cfg.min_length_2d) && !(len(l2) <= cfg.min_length_2d);
+        GenOut tmp;
+        if (len_ok && a.seg_has_vp[g1 + line])
+          ok1 = vp_candidate(cfg, a.cams[i1], a.cams[i2], s1, s2, pr->B, a.seg_vp + 3 * (g1 + line), &tmp);
+        if (len_ok && a.seg_has_vp[g2 + ng])
+          ok2 = vp_candidate(cfg, a.cams[i1], a.cams[i2], s1, s2, pr->B, a.seg_vp + 3 * (g2 + ng), &tmp);
+      }
       o.l.nb_slot = lite_pack(nbslot, i2);
       o.l.ng_line = ng;
     }
     const unsigned long long m = __ballot(ok);
+    unsigned below = (unsigned)__popcll(m & lanemask_lt());
+    unsigned total = (unsigned)__popcll(m);
+    if (kVP) {
+      const unsigned long long m1 = __ballot(ok1), m2 = __ballot(ok2);
+      below += (unsigned)__popcll(m1 & lanemask_lt()) + (unsigned)__popcll(m2 & lanemask_lt());
+      total += (unsigned)__popcll(m1) + (unsigned)__popcll(m2);
+      // the VP candidates come first within the connection; they are evaluated a second time here
+      // instead of being kept in registers next to the algebraic one
+      long long p = out0 + wcount + below;
+      for (int which = 0; which < 2; ++which) {
+        if (which == 0 ? ok1 : ok2) {
+          const Seg &s1 = a.segs[g1 + line];
+          const Seg &s2 = a.segs[g2 + ng];
+          GenOut ov;
+          (void)vp_candidate(cfg, a.cams[i1], a.cams[i2], s1, s2, pr->B,
+                             a.seg_vp + 3 * (which == 0 ? g1 + line : g2 + ng), &ov);
+          ov.l.nb_slot = lite_pack(nbslot, i2);
+          ov.l.ng_line = ng;
+          a.st_c[p] = ov.c;
+          a.st_l[p] = ov.l;
+          a.st_key[p] = (unsigned)(g1 + line);
+          ++p;
+        }
+      }
+      below += (unsigned)ok1 + (unsigned)ok2;
+      if (a.cnt_bl && (ok1 || ok2)) atomicAdd(&a.cnt_bl[lbase + line], (unsigned)ok1 + (unsigned)ok2);
+    }
     if (ok) {
-      const long long p = r0 + wcount + __popcll(m & lanemask_lt());
-#if defined(LT_X_NOSTORE)
-      a.st_c[p].s[0] = o.c.s[0] + o.c.e[0] + o.l.dir[0];
-#else
+      const long long p = out0 + wcount + below;
       a.st_c[p] = o.c;
       a.st_l[p] = o.l;
-#endif
       a.st_key[p] = (unsigned)(g1 + line);
-#if !defined(LT_X_NOATOMIC)
       if (a.cnt_bl) atomicAdd(&a.cnt_bl[lbase + line], 1u);
-#endif
     }
-    wcount += (unsigned)__popcll(m);
+    wcount += total;
   }
   LT_TRACE_MARK(1, lin, 2);
   if (lane == 0) a.wave_count[lin] = wcount;
@@ -393,7 +429,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
         const unsigned *__restrict__ base_bl, const unsigned *__restrict__ wave_count,
         const long long *__restrict__ tri_off, const Cand *__restrict__ st_c,
         const CandLite *__restrict__ st_l, const unsigned *__restrict__ st_key, Cand *__restrict__ cand,
-        CandLite *__restrict__ lite, unsigned *__restrict__ cand_node, int n_groups) {
+        CandLite *__restrict__ lite, unsigned *__restrict__ cand_node, int n_groups, int mult) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
@@ -407,6 +443,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
   if (count == 0) return;
   const long long g1 = seg_off[blk_img[b]];
   const long long lbase = blk_line_base[b];
+  const long long s0 = r0 * mult;  // the group's first staging slot (mult slots per match row)
   static_assert(sizeof(Cand) == 7 * 16 && sizeof(CandLite) == 2 * 16, "record sizes in 16-byte units");
   for (unsigned e0 = 0; e0 < count; e0 += 64) {
     const unsigned e = e0 + lane;
@@ -416,7 +453,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
     // are adjacent, so inside the batch the rank is the distance to the run's first lane (ballot of
     // the run heads); only the run that reaches back beyond the batch needs a look-back, and that
     // one is wave-uniform (64 earlier keys per step).
-    const unsigned key = act ? st_key[r0 + e] : 0xFFFFFFFFu;
+    const unsigned key = act ? st_key[s0 + e] : 0xFFFFFFFFu;
     const unsigned prev = (unsigned)__shfl_up((int)key, 1);
     const bool head = act && (lane == 0 || key != prev);
     const unsigned long long heads = __ballot(head);
@@ -432,7 +469,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
         while (idx_end > 0) {
           const long long j = idx_end - 64 + lane;
           const bool valid = j >= 0;
-          const unsigned k = valid ? st_key[cur_r0 + j] : 0u;
+          const unsigned k = valid ? st_key[cur_r0 * mult + j] : 0u;
           const unsigned long long m = __ballot(valid && k == key0);
           const unsigned lead = m == ~0ull ? 64u : (unsigned)__builtin_clzll(~m);
           carry += lead;
@@ -458,7 +495,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
     // source list and write consecutive units of a destination record, so a wave touches ~1/8 of the
     // cache lines a record-per-lane copy would.
     const unsigned nb = min(64u, count - e0);
-    const double2 *src_c = reinterpret_cast<const double2 *>(st_c + r0 + e0);
+    const double2 *src_c = reinterpret_cast<const double2 *>(st_c + s0 + e0);
     double2 *dst_c = reinterpret_cast<double2 *>(cand);
 #pragma unroll
     for (int it = 0; it < 7; ++it) {
@@ -467,7 +504,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
       const unsigned p = (unsigned)__shfl((int)pos32, (int)ci);
       if (u < nb * 7u) dst_c[(size_t)p * 7u + piece] = src_c[u];
     }
-    const double2 *src_l = reinterpret_cast<const double2 *>(st_l + r0 + e0);
+    const double2 *src_l = reinterpret_cast<const double2 *>(st_l + s0 + e0);
     double2 *dst_l = reinterpret_cast<double2 *>(lite);
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -483,7 +520,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
 __global__ void __launch_bounds__(256)
 k_pack_keys(const long long *__restrict__ m_off, const unsigned *__restrict__ wave_count,
             const long long *__restrict__ wave_pos, const unsigned *__restrict__ st_key,
-            unsigned *__restrict__ keys_c, unsigned *__restrict__ src_c, int n_groups) {
+            unsigned *__restrict__ keys_c, unsigned *__restrict__ src_c, int n_groups, int mult) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
@@ -496,8 +533,8 @@ k_pack_keys(const long long *__restrict__ m_off, const unsigned *__restrict__ wa
   const unsigned count = wave_count[lin];
   const long long base = wave_pos[lin];
   for (unsigned e = lane; e < count; e += 64) {
-    keys_c[base + e] = st_key[r0 + e];
-    src_c[base + e] = (unsigned)(r0 + e);
+    keys_c[base + e] = st_key[r0 * mult + e];
+    src_c[base + e] = (unsigned)(r0 * mult + e);
   }
 }
 
@@ -737,7 +774,8 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
                       const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
                       unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, unsigned *st_row,
-                      unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3) {
+                      unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3,
+                      const double *seg_vp, const unsigned char *seg_has_vp) {
   if (n_blk <= 0 || max_rows <= 0) return;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -756,6 +794,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   a.pairs = pairs; a.blk_line_base = blk_line_base; a.st_row = st_row; a.surv_count = surv_count;
   a.st_c = st_c; a.st_l = st_l; a.st_key = st_key; a.wave_count = wave_count; a.cnt_bl = cnt_bl;
   a.n_slots = gen_slots(max_rows); a.lds_segs = lds_segs; a.lds_segs1 = lds_segs1;
+  a.seg_vp = seg_vp; a.seg_has_vp = seg_has_vp; a.mult = seg_vp ? 3 : 1;
   a.blk = reinterpret_cast<const BlkRec *>(blkrec); a.n_blk = n_blk;
   // persistent grid: as many workgroups as fit at once (registers allow 16 waves per CU)
   const long long n_items = (long long)n_blk * (a.n_slots / kGateWaves);
@@ -771,7 +810,10 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   else if (lds_segs1 > 0) hipLaunchKernelGGL((k_gates<true, false>), grid, block, lds, st, a, cfg);
   else hipLaunchKernelGGL((k_gates<false, false>), grid, block, lds, st, a, cfg);
   if (ev3) (void)hipEventRecord(ev3[1], st);
-  hipLaunchKernelGGL(k_tri_rows, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg);
+  if (seg_vp)
+    hipLaunchKernelGGL(k_tri_rows<true>, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg);
+  else
+    hipLaunchKernelGGL(k_tri_rows<false>, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg);
   if (ev3) (void)hipEventRecord(ev3[2], st);
 }
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
@@ -783,19 +825,20 @@ void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const 
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
-                  const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node) {
+                  const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node, int mult) {
   if (n_blk <= 0 || max_rows <= 0) return;
   const int n_groups = gen_groups(max_rows);
   hipLaunchKernelGGL(k_place, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
-                     blk_line_base, base_bl, wave_count, tri_off, st_c, st_l, st_key, cand, lite, cand_node, n_groups);
+                     blk_line_base, base_bl, wave_count, tri_off, st_c, st_l, st_key, cand, lite, cand_node, n_groups,
+                     mult);
 }
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
-                      unsigned *keys_c, unsigned *src_c) {
+                      unsigned *keys_c, unsigned *src_c, int mult) {
   if (n_blk <= 0 || max_rows <= 0) return;
   const int n_groups = gen_groups(max_rows);
   hipLaunchKernelGGL(k_pack_keys, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, wave_count, wave_pos,
-                     st_key, keys_c, src_c, n_groups);
+                     st_key, keys_c, src_c, n_groups, mult);
 }
 void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const Cand *st_c,
                     const CandLite *st_l, Cand *cand, CandLite *lite, unsigned *cand_node) {

@@ -259,6 +259,34 @@ def make_scene(n_views=100, n_segs=500, n_neighbors=20, n_rooms=1, n_gt=None, se
                              n_gt=n_gt, seed=seed, topk=topk))
 
 
+def make_vp_results(scene, seed=0, drop=0.15, wrong=0.05):
+    """Synthetic vanishing-point detections (the content of limap.vplib.VPResult per image): the three
+    Manhattan directions of the box as vanishing points vp = K R e_axis, every segment of an
+    axis-parallel GT line labelled with its axis -- except `drop` of them unlabelled (-1) and `wrong`
+    of them given another axis; free segments mostly unlabelled.  Returns dict img_id -> (labels, vps)."""
+    out = {}
+    gt_dir = scene.gt_lines[:, 3:] - scene.gt_lines[:, :3]
+    gt_dir /= np.maximum(np.linalg.norm(gt_dir, axis=1, keepdims=True), 1e-300)
+    axis_of = np.full(len(gt_dir), -1)
+    for a in range(3):
+        axis_of[np.abs(gt_dir[:, a]) > 1.0 - 1e-9] = a
+    for n, img_id in enumerate(scene.img_ids):
+        rng = np.random.default_rng([scene.seed, seed, 555, int(img_id)])
+        K = np.array([[scene.kvec[n, 0], 0, scene.kvec[n, 2]], [0, scene.kvec[n, 1], scene.kvec[n, 3]], [0, 0, 1.0]])
+        R = quat_to_rot(scene.qvec[n])
+        vps = (K @ R).T.copy()            # row a = K R e_a
+        g = scene.gt_ids[scene.seg_off[n]:scene.seg_off[n + 1]]
+        lab = np.where(g >= 0, axis_of[np.maximum(g, 0)], -1).astype(np.int32)
+        u = rng.random(len(lab))
+        lab[(lab >= 0) & (u < drop)] = -1
+        flip = (lab >= 0) & (u > 1.0 - wrong)
+        lab[flip] = (lab[flip] + 1 + rng.integers(0, 2, size=int(flip.sum()))) % 3
+        stray = (lab < 0) & (rng.random(len(lab)) < 0.05)
+        lab[stray] = rng.integers(0, 3, size=int(stray.sum()))
+        out[int(img_id)] = (lab, vps)
+    return out
+
+
 def gen_matches(scene, img_id, topk=10):
     """matches_{img_id}: dict ng_img_id -> (K,2) int32, rows grouped by line id, <= topk rows per
     line: the true GT correspondence (when the GT segment is visible in the neighbour) at a random

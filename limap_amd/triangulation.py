@@ -161,7 +161,19 @@ class GlobalLineTriangulator:
         self._tracks = []
 
     def InitVPResults(self, vpresults):
-        raise NotImplementedError("VP-guided proposals (use_vp) are not implemented in the MI355X backend")
+        """vpresults: dict img_id -> limap.vplib.VPResult (or anything with .labels / .vps, a dict with those
+        keys, or a (labels, vps) pair) -- bindings.cc:89, base_line_triangulator.h:47-49."""
+        flat = {}
+        for img_id, r in dict(vpresults).items():
+            if isinstance(r, dict):
+                lab, vps = r["labels"], r["vps"]
+            elif hasattr(r, "labels"):
+                lab, vps = r.labels, r.vps
+            else:
+                lab, vps = r
+            flat[int(img_id)] = (np.asarray(lab, dtype=np.int64).reshape(-1),
+                                 np.asarray(vps, dtype=float).reshape(-1, 3))
+        self._ctx.init_vp(flat)
 
     def SetBipartites2d(self, all_bpt2ds):
         raise NotImplementedError("point-guided proposals (use_pointsfm) are not implemented in the MI355X backend")

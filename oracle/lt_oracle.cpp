@@ -622,6 +622,58 @@ static std::pair<Line3d, bool> line_triangulation(const Line2d &l1, const Camera
   return {Line3d(l3d_start, l3d_end, 1.0, z_start, z_end), true};
 }
 
+static V3 getDirectionFromVP(const V3 &vp, const CameraView &view) {  // functions.cc:37-42
+  const M3 K_inv = view.K_inv();
+  const M3 R = view.R();
+  V3 direc = matvec(matmul(transpose(R), K_inv), vp);
+  return normalized(direc);
+}
+
+// Triangulation with known direction, asymmetric perspective to (view1, l1) -- functions.cc:385-442
+static Line3d triangulate_line_with_direction(const Line2d &l1, const CameraView &view1, const Line2d &l2,
+                                              const CameraView &view2, const V3 &direction) {
+  // Step 1: project direction onto plane 1
+  V3 n1 = getNormalDirection(l1, view1);
+  V3 direc = direction - n1 * dot(n1, direction);
+  if (norm(direc) < EPS) return kSentinel();
+  direc = normalized(direc);
+  // Step 2: parameterize on plane 1 (a1s * d1s - a1e * d1e = 0)
+  V3 perp_direc = cross(n1, direc);
+  V3 v1s = view1.ray_direction(l1.start);
+  double a1s = dot(v1s, perp_direc);
+  V3 v1e = view1.ray_direction(l1.end);
+  double a1e = dot(v1e, perp_direc);
+  const double MIN_VALUE = 0.001;
+  if (a1s < 0) {
+    a1s *= -1;
+    a1e *= -1;
+  }
+  if (a1s < MIN_VALUE || a1e < MIN_VALUE) return kSentinel();
+  // Step 3: min [(c1s * d1s - b)^2 + (c1e * d1e - b)^2]
+  V3 C1 = view1.pose.center();
+  V3 C2 = view2.pose.center();
+  V3 n2 = getNormalDirection(l2, view2);
+  double c1s = dot(n2, v1s);
+  double c1e = dot(n2, v1e);
+  double b = dot(n2, C2 - C1);
+  double c1 = c1s;
+  double c2 = c1e * a1s / a1e;
+  double d1s_num = (c1 + c2) * b;
+  double d1s_denom = (c1 * c1 + c2 * c2);
+  double d1s = d1s_num / d1s_denom;
+  double d1e = d1s * a1s / a1e;
+  V3 lstart = v1s * d1s + C1;
+  V3 lend = v1e * d1e + C1;
+  double z_start = view1.pose.projdepth(lstart);
+  double z_end = view1.pose.projdepth(lend);
+  if (z_start < EPS || z_end < EPS) return kSentinel();
+  double d21 = view2.pose.projdepth(lstart);
+  double d22 = view2.pose.projdepth(lend);
+  if (d21 < EPS || d22 < EPS) return kSentinel();
+  if (std::isnan(lstart.x) || std::isnan(lend.x)) return kSentinel();
+  return Line3d(lstart, lend, 1.0, z_start, z_end);
+}
+
 static Line3d triangulate_line(const Line2d &l1, const CameraView &view1, const Line2d &l2,
                                const CameraView &view2) {  // functions.cc:295-304
   auto res = line_triangulation(l1, view1, l2, view2);
@@ -1016,6 +1068,16 @@ struct Triangulator {
 
   size_t CountLines(int img_id) const { return all_lines_2d_.at(img_id).size(); }
 
+  // vplib::VPResult (vplib/vpbase.h:18-47): labels[line] = VP index or -1; InitVPResults,
+  // base_line_triangulator.h:47-49
+  struct VPResult {
+    std::vector<int> labels;
+    std::vector<V3> vps;
+    bool HasVP(int line_id) const { return labels.at(line_id) >= 0; }
+    V3 GetVP(int line_id) const { return vps.at(labels.at(line_id)); }
+  };
+  std::map<int, VPResult> vpresults_;
+
   void Init() {  // base_line_triangulator.cc:45-63 + global_line_triangulator.cc:31-57
     if (cfg.add_halfpix) {  // offsetHalfPixel, base_line_triangulator.cc:33-43
       for (int img_id : img_ids)
@@ -1080,8 +1142,33 @@ void Triangulator::triangulateOneNode(int img_id, int line_id) {  // base_line_t
     }
     const CameraView &view2 = *view2p;
 
-    // Step 1 (point-guided) and Step 2 (VP-guided) proposals: optional branches, out of scope
-    // (use_pointsfm / use_vp are off in cfgs/triangulation/default.yaml:116,124).
+    auto push = [&](Line3d line) {  // lines 257-264 / 272-279 / 318-324
+      if (line.score > 0) {
+        double u1 = line.computeUncertainty(view1, cfg.var2d);
+        double u2 = line.computeUncertainty(view2, cfg.var2d);
+        line.uncertainty = std::min(u1, u2);
+        TriTuple t;
+        t.line = line;
+        t.score = -1.0;
+        t.ng_img = ng_img_id;
+        t.ng_line = ng_line_id;
+        results[conn_id].push_back(t);
+      }
+    };
+    // Step 1 (point-guided proposals) needs SetBipartites2d: optional branch, out of scope
+    // (use_pointsfm is off in cfgs/triangulation/default.yaml:116).
+
+    // Step 2: triangulation with VPs (lines 250-281); note that BOTH directions are mapped with view1
+    if (cfg.use_vp && !cfg.disable_vp_triangulation) {
+      if (vpresults_.at(img_id).HasVP(line_id)) {
+        V3 direc = getDirectionFromVP(vpresults_.at(img_id).GetVP(line_id), view1);
+        push(triangulate_line_with_direction(l1, view1, l2, view2, direc));
+      }
+      if (vpresults_.at(ng_img_id).HasVP(ng_line_id)) {
+        V3 direc = getDirectionFromVP(vpresults_.at(ng_img_id).GetVP(ng_line_id), view1);
+        push(triangulate_line_with_direction(l1, view1, l2, view2, direc));
+      }
+    }
 
     // Step 3: algebraic line triangulation (lines 291-325)
     if (!cfg.disable_algebraic_triangulation) {
@@ -1104,17 +1191,7 @@ void Triangulator::triangulateOneNode(int img_id, int line_id) {  // base_line_t
       if (line.sensitivity(view1) > cfg.sensitivity_threshold &&
           line.sensitivity(view2) > cfg.sensitivity_threshold)
         line.score = -1;
-      if (line.score > 0) {
-        double u1 = line.computeUncertainty(view1, cfg.var2d);
-        double u2 = line.computeUncertainty(view2, cfg.var2d);
-        line.uncertainty = std::min(u1, u2);
-        TriTuple t;
-        t.line = line;
-        t.score = -1.0;
-        t.ng_img = ng_img_id;
-        t.ng_line = ng_line_id;
-        results[conn_id].push_back(t);
-      }
+      push(line);
     }
   }
   for (size_t conn_id = 0; conn_id < n_conns; ++conn_id) {
@@ -1493,7 +1570,6 @@ int ora_init(ora_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec
              const double *qvec, const double *tvec, const int64_t *seg_off, const double *segs) {
   ORA_TRY(ctx, {
     auto &t = ctx->t;
-    if (t.cfg.use_vp) throw std::runtime_error("use_vp is not restated in the oracle");
     for (int i = 0; i < n_img; ++i) {
       double cam[11];
       for (int k = 0; k < 4; ++k) cam[k] = kvec[4 * i + k];
@@ -1509,6 +1585,20 @@ int ora_init(ora_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec
     t.img_ids.clear();
     for (auto &kv : t.views) t.img_ids.push_back(kv.first);
     t.Init();
+  })
+}
+
+int ora_init_vp(ora_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *label_off, const int32_t *labels,
+                const int64_t *vp_off, const double *vps) {  // InitVPResults
+  ORA_TRY(ctx, {
+    auto &t = ctx->t;
+    t.vpresults_.clear();
+    for (int i = 0; i < n_img; ++i) {
+      ora::Triangulator::VPResult r;
+      r.labels.assign(labels + label_off[i], labels + label_off[i + 1]);
+      for (int64_t v = vp_off[i]; v < vp_off[i + 1]; ++v) r.vps.push_back(ora::V3{vps[3 * v], vps[3 * v + 1], vps[3 * v + 2]});
+      t.vpresults_[img_ids[i]] = r;
+    }
   })
 }
 

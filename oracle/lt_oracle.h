@@ -29,7 +29,7 @@ typedef struct ora_config {
   /* base triangulator */
   int32_t debug_mode;
   int32_t add_halfpix;
-  int32_t use_vp;                       /* accepted, must be 0 (optional branch, out of scope) */
+  int32_t use_vp;                       /* VP-guided proposals (needs ora_init_vp) */
   int32_t use_endpoints_triangulation;
   int32_t disable_many_points_triangulation;
   int32_t disable_one_point_triangulation;
@@ -83,6 +83,10 @@ int ora_init(ora_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec
 
 /* matches for neighbour k are rows m_off[k]..m_off[k+1] of m_pairs (line_id, ng_line_id).
  * Neighbours are processed in ascending nb id order like the reference's std::map. */
+/* InitVPResults (base_line_triangulator.h:47-49): per image the VP label of every line (-1 = none) and
+ * the VP vectors (vplib/vpbase.h:18-47), CSR over the images of ora_init */
+int ora_init_vp(ora_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *label_off, const int32_t *labels,
+                const int64_t *vp_off, const double *vps);
 int ora_triangulate_image(ora_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids,
                           const int64_t *m_off, const int32_t *m_pairs);
 int ora_triangulate_image_exhaustive(ora_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids);

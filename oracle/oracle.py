@@ -197,6 +197,26 @@ class OracleTriangulator:
                                   _p(qvec, C.c_double), _p(tvec, C.c_double), _p(seg_off, C.c_int64),
                                   _p(segs, C.c_double)))
 
+    def InitVPResults(self, vpresults):
+        """vpresults: dict img_id -> (labels (M,) int, vps (V,3) float) -- vplib.VPResult content."""
+        ids = sorted(int(k) for k in vpresults)
+        lab_off, vp_off = np.zeros(len(ids) + 1, np.int64), np.zeros(len(ids) + 1, np.int64)
+        labs, vps = [], []
+        for n, i in enumerate(ids):
+            lab, vp = vpresults[i]
+            lab, vp = _i32(lab).reshape(-1), _f64(vp).reshape(-1, 3)
+            labs.append(lab); vps.append(vp)
+            lab_off[n + 1] = lab_off[n] + len(lab)
+            vp_off[n + 1] = vp_off[n] + len(vp)
+        labs = _i32(np.concatenate(labs)) if labs else np.zeros(1, np.int32)
+        vps = _f64(np.concatenate(vps, 0)) if vps else np.zeros((1, 3))
+        if labs.size == 0:
+            labs = np.zeros(1, np.int32)
+        if vps.size == 0:
+            vps = np.zeros((1, 3))
+        self._chk(self.L.ora_init_vp(self.ctx, len(ids), _p(_i32(ids), C.c_int32), _p(lab_off, C.c_int64),
+                                     _p(labs, C.c_int32), _p(vp_off, C.c_int64), _p(vps, C.c_double)))
+
     def TriangulateImage(self, img_id, matches):
         """matches: dict ng_img_id -> (K,2) int array."""
         nb = _i32(list(matches.keys()))

@@ -27,6 +27,11 @@ def make(name, mode, seed, n_views, n_segs, nn, topk, cfg_over):
     O.Init(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, sc.seg_off, sc.segs)
     data = dict(img_ids=sc.img_ids, kvec=sc.kvec, qvec=sc.qvec, tvec=sc.tvec, seg_off=sc.seg_off, segs=sc.segs,
                 ranges=np.stack(sc.ranges), mode=np.array(mode), cfg_over=np.array(repr(cfg_over)))
+    if cfg_over.get("use_vp"):  # vplib.VPResult content per image: labels of all segments, 3 VPs per image
+        vps = syn.make_vp_results(sc, seed=seed)
+        O.InitVPResults(vps)
+        data.update(vp_labels=np.concatenate([vps[int(i)][0] for i in sc.img_ids]).astype(np.int32),
+                    vp_vps=np.stack([vps[int(i)][1] for i in sc.img_ids]))
     nb_flat, nb_off = [], [0]
     m_img, m_nb, m_off, m_rows = [], [], [0], []
     for i in sc.img_ids:
@@ -65,3 +70,4 @@ if __name__ == "__main__":
     make("exhaustive_s12", "exhaustive", 12, 14, 60, 8, 0, {})
     make("matched_outer2_halfpix_s13", "matched", 13, 14, 80, 8, 6, dict(add_halfpix=True, min_num_outer_edges=2))
     make("matched_endpoints_s14", "matched", 14, 10, 60, 6, 5, dict(use_endpoints_triangulation=True))
+    make("matched_vp_s15", "matched", 15, 12, 70, 6, 5, dict(use_vp=True))

@@ -24,6 +24,9 @@ def _load(path):
 def _feed(T, d, init):
     T.SetRanges((d["ranges"][0], d["ranges"][1]))
     init(T)
+    if "vp_labels" in d:
+        so = d["seg_off"]
+        T.InitVPResults({int(i): (d["vp_labels"][so[n]:so[n + 1]], d["vp_vps"][n]) for n, i in enumerate(d["img_ids"])})
     for n, i in enumerate(d["img_ids"]):
         nbs = d["nb_flat"][d["nb_off"][n]:d["nb_off"][n + 1]].tolist()
         if d["mode"] == "matched":

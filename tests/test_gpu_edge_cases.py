@@ -99,9 +99,11 @@ def test_error_conventions(gpu_lib):
         T3 = tri.GlobalLineTriangulator(dict(cfg, merging_strategy="spectral"))
         T3.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, segs)
         T3.ComputeLineTracks()
-    with pytest.raises(ValueError, match="use_vp"):
+    with pytest.raises(RuntimeError, match="InitVPResults"):  # use_vp needs the VP detections
         T4 = tri.GlobalLineTriangulator(dict(cfg, use_vp=True))
         T4.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, segs)
+        T4.TriangulateImage(0, {1: np.array([[0, 0]], np.int32)})
+        T4.ComputeLineTracks()
     with pytest.raises(NotImplementedError):
         T.SetBipartites2d({})
     with pytest.raises((ValueError, RuntimeError), match="255"):

@@ -275,3 +275,36 @@ def test_out_of_index_match_raises(oracle, two_views):
            np.stack([s, s]))
     with pytest.raises(RuntimeError, match="IndexError"):
         O.TriangulateImage(0, {1: np.array([[3, 0]], np.int32)})
+
+
+def test_kat_vp_direction_triangulation(oracle):
+    """KAT (xii): VP-guided proposal.  A noise-free scene: with the true 3D direction as VP of l1
+    (vp = K R d), triangulate_line_with_direction reproduces the GT segment's endpoints (the
+    rays of l1's endpoints meet the plane of l2 where the GT line is); a VP on neither line adds nothing."""
+    import numpy as np
+    from limap_amd import synthetic as syn
+    K4 = np.array([500.0, 500.0, 320.0, 240.0])
+    # two cameras looking down +z, second shifted in x and y
+    q = np.array([[1.0, 0, 0, 0], [1.0, 0, 0, 0]])
+    t = np.array([[0.0, 0, 0], [-0.6, -0.25, 0.0]])
+    P, Q = np.array([-0.4, 0.1, 4.0]), np.array([0.5, 0.35, 5.0])
+
+    def proj(X, tt):
+        Xc = X + tt
+        return np.array([K4[0] * Xc[0] / Xc[2] + K4[2], K4[1] * Xc[1] / Xc[2] + K4[3]])
+    segs = np.array([[*proj(P, t[0]), *proj(Q, t[0])], [*proj(P, t[1]), *proj(Q, t[1])]])
+    d = (Q - P) / np.linalg.norm(Q - P)
+    Kmat = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1.0]])
+    vp = Kmat @ d
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    cfg.update(use_vp=True, disable_algebraic_triangulation=True, min_num_outer_edges=0)
+    for lab0, lab1, expect in ((0, -1, 1), (-1, 0, 1), (0, 0, 2), (-1, -1, 0)):
+        O = oracle.OracleTriangulator(cfg, faithful=True)
+        O.Init([7, 9], np.tile(K4, (2, 1)), q, t, [0, 1, 2], segs)
+        O.InitVPResults({7: ([lab0], [vp]), 9: ([lab1], [vp])})
+        O.TriangulateImage(7, {9: np.array([[0, 0]], np.int32)})
+        a = O.get_all_tris()
+        assert a["off"][1] - a["off"][0] == expect
+        for k in range(expect):
+            np.testing.assert_allclose(a["line"][k, :3], P, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(a["line"][k, 3:6], Q, rtol=0, atol=1e-9)
