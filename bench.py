@@ -78,9 +78,14 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # LT_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, all-gather, barrier, reductions)
+    # in a one-rank job -- a smoke test of the RCCL plumbing on a single GPU
+    use_dist = world > 1 or os.environ.get("LT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from limap_amd import _capi
     from limap_amd import synthetic as syn
@@ -98,7 +103,7 @@ def main():
     ctx.set_ranges(*scene.ranges)
 
     # ---- scene payload: this rank uploads only its own images, the rest arrives by all-gather ----
-    gather = ltdist.SceneGather(scene.img_ids, scene.seg_off, rank, world, dev)
+    gather = ltdist.SceneGather(scene.img_ids, scene.seg_off, rank, world, dev, force_collective=use_dist)
     gather.load_local(scene.kvec, scene.qvec, scene.tvec, scene.segs)
     d_k, d_q, d_t, d_s = gather.all_gather()
     ctx.init_device(scene.img_ids, d_k.data_ptr(), d_q.data_ptr(), d_t.data_ptr(), scene.seg_off, d_s.data_ptr())
@@ -121,14 +126,22 @@ def main():
     # per-step path: the invariants are rebuilt straight from the all-gather's receive buffer
     ctx.set_scene_chunks(*gather.chunk_pointers())
 
+    # One step = the scene of one batch arrives by all-gather, the invariants are rebuilt from the receive
+    # buffer, the hot path runs.  The collective for the NEXT step is launched as soon as this step's
+    # invariants have been rebuilt (the receive buffer is free again), so it overlaps with the kernels:
+    # K steps contain K all-gathers, the first one is waited for at the top of the first step.
+    pending = [gather.gather_async()]
+
     def step():
-        gather.gather_only()
+        if pending[0] is not None:
+            pending[0].wait()
         ctx.refresh_scene_chunks()
+        pending[0] = gather.gather_async()
         ctx.run_device()
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -143,6 +156,9 @@ def main():
             acc[k] = acc.get(k, 0.0) + v
     sync()
     elapsed = time.perf_counter() - t0
+    if pending[0] is not None:  # the collective launched by the last step
+        pending[0].wait()
+        torch.cuda.synchronize(dev)
     kt = {k: v / max(args.steps, 1) for k, v in acc.items()}  # average HIP-event ms per launch
 
     # results of the last step -> host, then the tail (not part of the timed step)
@@ -162,7 +178,7 @@ def main():
     t_tail = time.perf_counter() - t_tail0
     st_after = ctx.stats()
 
-    if world > 1:
+    if use_dist:
         t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         elapsed = float(t_el.item())
@@ -307,10 +323,19 @@ def main():
                 out["e2e_speedup_vs_cpu"] = cpu_s / (out["e2e_wall_ms"] * 1e-3)
                 out["cpu_parity"] = {"tracks_cpu": so["tracks"], "tracks_gpu": st_after["tracks"],
                                      "candidates_cpu": so["candidates"], "candidates_gpu": st["candidates"]}
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner to the C stdout buffer; flush it first so that the JSON line is the
+        # LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -41,10 +41,12 @@ class SceneGather:
     """Packs this rank's images into one buffer, all-gathers once, unpacks into the global
     kvec / qvec / tvec / segs arrays (ascending image id) on the device."""
 
-    def __init__(self, img_ids, seg_off, rank, world, device, weights=None):
+    def __init__(self, img_ids, seg_off, rank, world, device, weights=None, force_collective=False):
         import torch
         self.torch = torch
         self.rank, self.world, self.device = rank, world, device
+        # force_collective: run the all-gather even in a one-rank job (smoke test of the RCCL path on one GPU)
+        self.collective = world > 1 or force_collective
         ids = np.asarray(img_ids)
         assert np.all(np.diff(ids) > 0), "image ids must be ascending"
         self.n_img = len(ids)
@@ -77,14 +79,24 @@ class SceneGather:
 
     def gather_only(self):
         """The collective alone: afterwards `chunk_pointers()` describe the scene in place."""
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             dist.all_gather_into_tensor(self.recv, self.local)
+
+    def gather_async(self):
+        """Launch the collective without waiting (returns the c10d work handle, or None for a one-rank job
+        without a forced collective).  `handle.wait()` makes the CURRENT stream wait for the gathered data;
+        the collective itself is ordered after everything already enqueued on the current stream, so it may
+        be launched as soon as the previous contents of the receive buffer have been consumed."""
+        if not self.collective:
+            return None
+        import torch.distributed as dist
+        return dist.all_gather_into_tensor(self.recv, self.local, async_op=True)
 
     def chunk_pointers(self):
         """(img_begin, k_ptrs, q_ptrs, t_ptrs, s_ptrs): per-rank views into the receive buffer
         (the local buffer for world == 1), for lt_set_scene_chunks.  Empty shards are skipped."""
-        buf = self.recv if self.world > 1 else self.local
+        buf = self.recv if self.collective else self.local
         base = buf.data_ptr()
         ib, pk, pq, pt, ps = [], [], [], [], []
         for r in range(self.world):
@@ -99,7 +111,7 @@ class SceneGather:
     def all_gather(self):
         """One collective; returns (kvec, qvec, tvec, segs) device tensors of the whole scene."""
         torch = self.torch
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             dist.all_gather_into_tensor(self.recv, self.local)
             recv = self.recv

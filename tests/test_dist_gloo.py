@@ -37,6 +37,17 @@ def _worker(rank, world, port, q):
         k, q_, t, s = g.all_gather()
         ok = (np.array_equal(k.numpy(), sc.kvec) and np.array_equal(q_.numpy(), sc.qvec)
               and np.array_equal(t.numpy(), sc.tvec) and np.array_equal(s.numpy()[:len(segs)], segs))
+        # the asynchronous form used by bench.py (collective of the next step overlapped with the kernels):
+        # wipe the receive buffer, launch, wait, and read the chunks in place
+        g.recv.fill_(float("nan"))
+        h = g.gather_async()
+        h.wait()
+        ib, pk, pq, pt, ps = g.chunk_pointers()
+        ok = ok and ib == [int(x) for x in g.bounds[:-1]] and not bool(torch.isnan(g.recv[:g.sizes[0]]).any())
+        for r in range(world):
+            a_, b_ = g.bounds[r], g.bounds[r + 1]
+            o = r * g.max_size
+            ok = ok and np.array_equal(g.recv[o:o + 4 * (b_ - a_)].numpy().reshape(-1, 4), sc.kvec[a_:b_])
         mine = ltdist.shard_images(sc.img_ids, rank, world).tolist()
         parts = ltdist.gather_results_to_rank0({"rank": rank, "imgs": mine}, rank, world)
         if rank == 0:
