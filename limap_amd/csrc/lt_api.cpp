@@ -1157,26 +1157,18 @@ int lt_run_device(lt_ctx *ctx) {
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));
   ENSURE(ctx, ctx->d_nvalid, 4 * (size_t)(G + 1));
   ENSURE(ctx, ctx->d_edge_off, 8 * (size_t)(G + 1));
-  launch_select(st, G, ctx->d_tri_off.as<long long>(), ctx->d_score.as<double>(), scfg.fullscore_th,
-                scfg.max_valid_conns, ctx->d_best_idx.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
-                ctx->d_nvalid.as<unsigned>());
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_nvalid.as<unsigned>() + G, 0, 4, st));
-  {
-    size_t tmp = scan_temp_bytes_u32_to_i64(G + 1);
-    ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
-    if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, G + 1, ctx->d_nvalid.as<unsigned>(),
-                               ctx->d_edge_off.as<long long>()) != 0)
-      return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
-  }
-  HIPCHK(ctx, hipEventRecord(ctx->ev[6], st));
   ENSURE(ctx, ctx->d_best_c, sizeof(Cand) * (size_t)std::max<long long>(G, 1));
   ENSURE(ctx, ctx->d_best_score, 8 * (size_t)std::max<long long>(G, 1));
   ENSURE(ctx, ctx->d_best_src, 8 * (size_t)std::max<long long>(G, 1));
   ENSURE(ctx, ctx->d_ntris, 4 * (size_t)std::max<long long>(G, 1));
-  launch_gather_best(st, G, ctx->d_best_idx.as<long long>(), ctx->d_tri_off.as<long long>(), ctx->d_cand.as<Cand>(),
-                     ctx->d_lite.as<CandLite>(), ctx->d_score.as<double>(), ctx->d_node_img.as<int>(),
-                     ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_best_c.as<Cand>(),
-                     ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(), ctx->d_ntris.as<int>());
+  // per node: best candidate (gathered into the dense per-node arrays by the same kernel), valid-edge
+  // flags and their number; the edge offsets (a scan) and the edge lists are produced at download time
+  launch_select(st, G, ctx->d_tri_off.as<long long>(), ctx->d_score.as<double>(), scfg.fullscore_th,
+                scfg.max_valid_conns, ctx->d_best_idx.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
+                ctx->d_nvalid.as<unsigned>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
+                ctx->d_best_c.as<Cand>(), ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(),
+                ctx->d_ntris.as<int>());
+  HIPCHK(ctx, hipEventRecord(ctx->ev[6], st));
   HIPCHK(ctx, hipEventRecord(ctx->ev[7], st));
   HIPCHK(ctx, hipGetLastError());
   // the device error flag and the pair statistic ride on the stream into pinned scratch (two blocking
@@ -1227,7 +1219,15 @@ int lt_download(lt_ctx *ctx) {
   double t0 = now_ms();
   hipStream_t st = ctx->stream;
   const long long G = ctx->G;
-  // edges need their final positions: fill on device now that edge_off is known
+  // edges need their final positions: offsets (scan of the per-node counts) and lists are made now
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_nvalid.as<unsigned>() + G, 0, 4, st));
+  {
+    size_t tmp = scan_temp_bytes_u32_to_i64(G + 1);
+    ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
+    if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, G + 1, ctx->d_nvalid.as<unsigned>(),
+                               ctx->d_edge_off.as<long long>()) != 0)
+      return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+  }
   std::vector<long long> tri_off(G + 1), edge_off(G + 1);
   HIPCHK(ctx, hipMemcpyAsync(tri_off.data(), ctx->d_tri_off.p, 8 * (size_t)(G + 1), hipMemcpyDeviceToHost, st));
   HIPCHK(ctx, hipMemcpyAsync(edge_off.data(), ctx->d_edge_off.p, 8 * (size_t)(G + 1), hipMemcpyDeviceToHost, st));

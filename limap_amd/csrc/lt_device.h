@@ -42,13 +42,10 @@ void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_of
                            long long n_items, long long total, long long *tri_off);
 
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
-                   int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid);
+                   int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const Cand *cand,
+                   const CandLite *lite, Cand *best_c, double *best_score, int *best_src2, int *n_tris);
 void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
                       const long long *edge_off, const CandLite *lite, int *edges2);
-void launch_gather_best(hipStream_t st, long long G, const long long *best_idx, const long long *tri_off,
-                        const Cand *cand, const CandLite *lite, const double *score, const int *node_img,
-                        const long long *nb_off, const int *blk_nb, Cand *best_c, double *best_score,
-                        int *best_src2, int *n_tris);
 
 void launch_track_connect(hipStream_t st, int T, const double *line7, const unsigned char *active, int all_active,
                           const LinkCfg3 &cfg, double cos_guard, unsigned long long *edges,

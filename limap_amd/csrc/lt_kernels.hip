@@ -195,7 +195,9 @@ __global__ void k_tri_offsets_ex(long long G, const long long *__restrict__ item
 __global__ void __launch_bounds__(256)
 k_select(long long G, const long long *__restrict__ tri_off, const double *__restrict__ score,
          double fullscore_th, int max_valid_conns, long long *__restrict__ best_idx,
-         unsigned *__restrict__ edge_flag, unsigned *__restrict__ n_valid) {
+         unsigned *__restrict__ edge_flag, unsigned *__restrict__ n_valid, const Cand *__restrict__ cand,
+         const CandLite *__restrict__ lite, Cand *__restrict__ best_c, double *__restrict__ best_score,
+         int *__restrict__ best_src2, int *__restrict__ n_tris) {
   long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (g >= G) return;
   const int lane = lane_id();
@@ -223,6 +225,30 @@ k_select(long long G, const long long *__restrict__ tri_off, const double *__res
     }
   }
   if (lane == 0) best_idx[g] = (bi < 0) ? -1 : off + bi;
+  // the best candidate's record goes to the dense per-node arrays right here (lanes 0-6: the 7 16-byte
+  // units of the Cand, lane 7: score, lane 8: source (image, line), lane 9: candidate count)
+  {
+    static_assert(sizeof(Cand) == 7 * 16, "Cand in 16-byte units");
+    const long long b = (bi < 0) ? -1 : off + bi;
+    if (lane < 7) {
+      double2 v = double2{0.0, 0.0};
+      if (b >= 0) v = reinterpret_cast<const double2 *>(cand + b)[lane];
+      reinterpret_cast<double2 *>(best_c + g)[lane] = v;
+    } else if (lane == 7) {
+      best_score[g] = (b >= 0) ? bs : 0.0;
+    } else if (lane == 8) {
+      int src_img = -1, src_line = -1;
+      if (b >= 0) {
+        const CandLite l = lite[b];
+        src_img = lite_img(l);
+        src_line = l.ng_line;
+      }
+      best_src2[2 * g] = src_img;
+      best_src2[2 * g + 1] = src_line;
+    } else if (lane == 9) {
+      n_tris[g] = n;
+    }
+  }
   // valid edges: the max_valid_conns best by (score, tri_id) descending, kept if score >= th
   const bool need_rank = n_full > max_valid_conns;
   int kept = 0;
@@ -267,38 +293,6 @@ k_edge_fill(long long G, const long long *__restrict__ tri_off, const unsigned *
     }
     base += __popcll(m);
   }
-}
-
-// gather the best candidate of every node into dense per-node arrays
-__global__ void k_gather_best(long long G, const long long *__restrict__ best_idx,
-                              const long long *__restrict__ tri_off, const Cand *__restrict__ cand,
-                              const CandLite *__restrict__ lite, const double *__restrict__ score,
-                              const int *__restrict__ node_img, const long long *__restrict__ nb_off,
-                              const int *__restrict__ blk_nb, Cand *__restrict__ best_c,
-                              double *__restrict__ best_score, int *__restrict__ best_src2,
-                              int *__restrict__ n_tris) {
-  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= G) return;
-  n_tris[g] = (int)(tri_off[g + 1] - tri_off[g]);
-  long long b = best_idx[g];
-  Cand c;
-  double s = 0.0;
-  int src_img = -1, src_line = -1;
-  if (b >= 0) {
-    c = cand[b];
-    s = score[b];
-    src_img = lite_img(lite[b]);
-    src_line = lite[b].ng_line;
-  } else {
-    for (int k = 0; k < 3; ++k) c.s[k] = c.e[k] = 0.0;
-    c.depth[0] = c.depth[1] = 0.0;
-    c.unc = 0.0;
-    c.score3 = 0.0;
-  }
-  best_c[g] = c;
-  best_score[g] = s;
-  best_src2[2 * g] = src_img;
-  best_src2[2 * g + 1] = src_line;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -377,24 +371,17 @@ void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_of
                      total, tri_off);
 }
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
-                   int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid) {
+                   int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const Cand *cand,
+                   const CandLite *lite, Cand *best_c, double *best_score, int *best_src2, int *n_tris) {
   if (G > 0)
     hipLaunchKernelGGL(k_select, dim3(nblk(G * 64, 256)), dim3(256), 0, st, G, tri_off, score, th, max_valid,
-                       best_idx, edge_flag, n_valid);
+                       best_idx, edge_flag, n_valid, cand, lite, best_c, best_score, best_src2, n_tris);
 }
 void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
                       const long long *edge_off, const CandLite *lite, int *edges2) {
   if (G > 0)
     hipLaunchKernelGGL(k_edge_fill, dim3(nblk(G * 64, 256)), dim3(256), 0, st, G, tri_off, edge_flag, edge_off,
                        lite, edges2);
-}
-void launch_gather_best(hipStream_t st, long long G, const long long *best_idx, const long long *tri_off,
-                        const Cand *cand, const CandLite *lite, const double *score, const int *node_img,
-                        const long long *nb_off, const int *blk_nb, Cand *best_c, double *best_score,
-                        int *best_src2, int *n_tris) {
-  if (G > 0)
-    hipLaunchKernelGGL(k_gather_best, dim3(nblk(G, 256)), dim3(256), 0, st, G, best_idx, tri_off, cand, lite,
-                       score, node_img, nb_off, blk_nb, best_c, best_score, best_src2, n_tris);
 }
 
 
