@@ -34,7 +34,7 @@ extern "C" {
 typedef struct lt_config {
   int32_t debug_mode;
   int32_t add_halfpix;
-  int32_t use_vp;                            /* VP-guided proposals (matched mode; needs lt_init_vp) */
+  int32_t use_vp;                            /* VP-guided proposals (needs lt_init_vp) */
   int32_t use_endpoints_triangulation;
   int32_t disable_many_points_triangulation; /* point proposals need SetBipartites2d: n/a */
   int32_t disable_one_point_triangulation;
@@ -89,7 +89,7 @@ int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, 
  * order of the ids given to lt_init) the VP label of every line (-1 = none; vplib/vpbase.h:35,42) and its
  * vanishing points (homogeneous image coordinates, vps[.][3]); CSR: label_off / vp_off [n_img + 1].
  * Used by the VP-guided proposals of triangulateOneNode (base_line_triangulator.cc:250-281) when
- * cfg.use_vp && !cfg.disable_vp_triangulation -- matched mode only.  Call after lt_init. */
+ * cfg.use_vp && !cfg.disable_vp_triangulation (both triangulation modes).  Call after lt_init. */
 int lt_init_vp(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *label_off, const int32_t *labels,
                const int64_t *vp_off, const double *vps);
 /* Same with kvec/qvec/tvec/segs already resident in HBM (e.g. the output of the RCCL all-gather),

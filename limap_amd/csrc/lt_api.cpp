@@ -290,6 +290,18 @@ GenCfg make_gen(const lt_ctx *ctx) {
     g.sin_lo = -1.0;
     g.sin_hi = 1e300;
   }
+  // sensitivity = 90 - acos(c) 180/pi > th  <=>  c > sin(th) (acos is decreasing); same +-1e-7 band as above
+  {
+    const double ths = c.sensitivity_threshold;
+    if (ths > 1e-3 && ths < 89.0) {
+      const double sn = std::sin(ths * kPi / 180.0);
+      g.sens_lo = sn * (1.0 - 1e-7);
+      g.sens_hi = sn * (1.0 + 1e-7);
+    } else {
+      g.sens_lo = -1.0;   // the band covers everything: always the exact expression
+      g.sens_hi = 1e300;
+    }
+  }
   // `length <= min_length` skips the connection (base_line_triangulator.cc:166,177); length = sqrt(q)
   const double L = c.min_length_2d;
   if (L > 0.0) {
@@ -840,8 +852,6 @@ int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_id
 }
 
 int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids) {
-  if (ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation)
-    return fail(ctx, LT_ERR_ARGUMENT, "VP-guided proposals (use_vp) are implemented for TriangulateImage (matched mode) only");
   int idx;
   int rc = begin_image(ctx, img_id, 2, &idx);
   if (rc) return rc;
@@ -1090,13 +1100,19 @@ int lt_run_device(lt_ctx *ctx) {
   } else if (ctx->job_mode == 2) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
     const size_t In = (size_t)std::max<long long>(P, 1);
-    ENSURE(ctx, ctx->d_masks, 8 * In); ENSURE(ctx, ctx->d_mask_cnt, 4 * (In + 1));
+    // VP-guided proposals: three survivor ballots per work item (algebraic, vp of l1, vp of l2)
+    const bool vp_on = ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation;
+    if (vp_on && !ctx->vp_ready) return fail(ctx, LT_ERR_STATE, "use_vp is set but InitVPResults was not called");
+    const double *seg_vp = vp_on ? ctx->d_seg_vp.as<double>() : nullptr;
+    const unsigned char *seg_has_vp = vp_on ? ctx->d_seg_has_vp.as<unsigned char>() : nullptr;
+    const int n_masks = vp_on ? 3 : 1;
+    ENSURE(ctx, ctx->d_masks, 8 * In * n_masks); ENSURE(ctx, ctx->d_mask_cnt, 4 * (In + 1));
     ENSURE(ctx, ctx->d_mask_pos, 8 * (In + 1));
     launch_gen_exhaustive(st, false, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
                           ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
                           ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
-                          ctx->d_masks.as<unsigned long long>(), nullptr, nullptr, nullptr);
-    launch_popc(st, P, ctx->d_masks.as<unsigned long long>(), ctx->d_mask_cnt.as<unsigned>());
+                          ctx->d_masks.as<unsigned long long>(), nullptr, nullptr, nullptr, seg_vp, seg_has_vp);
+    launch_popc(st, P, ctx->d_masks.as<unsigned long long>(), ctx->d_mask_cnt.as<unsigned>(), n_masks);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_mask_cnt.as<unsigned>() + P, 0, 4, st));
     {
       size_t tmp = scan_temp_bytes_u32_to_i64(P + 1);
@@ -1118,7 +1134,7 @@ int lt_run_device(lt_ctx *ctx) {
                           ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
                           ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
                           ctx->d_masks.as<unsigned long long>(), ctx->d_mask_pos.as<long long>(),
-                          ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>());
+                          ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), seg_vp, seg_has_vp);
     launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, total,
                           ctx->d_tri_off.as<long long>());
     ENSURE(ctx, ctx->d_cand_node, 4 * Cn);

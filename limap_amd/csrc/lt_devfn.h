@@ -56,6 +56,18 @@ static __device__ __forceinline__ double sensitivity(const Cam &c, d3 s, d3 e, d
   return 90 - acos(cv) * 180.0 / kPi;
 }
 
+// `line.sensitivity(view) > sens_th` decided in the cosine domain where that is safe (cfg.sens_lo / sens_hi,
+// see make_gen), by the exact expression otherwise: saves the two acos per triangulated connection
+static __device__ __forceinline__ bool sensitivity_gt(const GenCfg &cfg, const Cam &c, d3 s, d3 e, d3 dir3) {
+  d2 ps = cam_project(c, s), pe = cam_project(c, e);
+  d2 mid = d2{0.5 * (ps.x + pe.x), 0.5 * (ps.y + pe.y)};
+  d3 ray = cam_ray(c, mid);
+  double cv = fabs(dot(dir3, ray));
+  if (cv > cfg.sens_hi) return true;
+  if (cv < cfg.sens_lo) return false;
+  return 90 - acos(cv) * 180.0 / kPi > cfg.sens_th;
+}
+
 // compute_epipolar_IoU (functions.cc:76-98) with the fundamental matrix hoisted per image pair
 static __device__ __forceinline__ double epipolar_iou(const Seg &s1, const Seg &s2, const double *F) {
   L2 l2{mk2(s2.x1, s2.y1), mk2(s2.x2, s2.y2)};
@@ -262,7 +274,7 @@ static __device__ __forceinline__ bool gen_finish(const GenCfg &cfg, const Cam &
   }
   d3 dir3 = unit(sub(pe, ps));
   // sensitivity gate (:315-317): rejected only if too sensitive in BOTH views
-  if (sensitivity(c1, ps, pe, dir3) > cfg.sens_th && sensitivity(c2, ps, pe, dir3) > cfg.sens_th)
+  if (sensitivity_gt(cfg, c1, ps, pe, dir3) && sensitivity_gt(cfg, c2, ps, pe, dir3))
     return false;
   // uncertainty (:319-321; linebase.cc:109-116; camera.cc:228-242)
   double u1 = cfg.var2d * ((z_start + z_end) / 2.0) / c1.f;

@@ -256,6 +256,9 @@ struct GenCfg {
   // squared-length guards of the min_length_2d test: q <= len_lo2 certainly fails `sqrt(q) > min_length`,
   // q > len_hi2 certainly passes it, in between the exact expression decides
   double len_lo2, len_hi2;
+  // cosine-domain guards of the sensitivity gate: sensitivity > sens_th  <=>  |dir . ray| > sin(sens_th) up to
+  // libm rounding; outside [sens_lo, sens_hi] the cosine decides, inside the exact expression does
+  double sens_lo, sens_hi;
 };
 struct ScoreCfg {
   LinkCfg2 l2;

@@ -122,7 +122,10 @@ __global__ void k_node_offsets(long long P, long long G, const unsigned *__restr
 // connection list is implicit.  Work item = (node, neighbour block, chunk of 64 ng lines);
 // the wave writes its ballot of survivors as one 64-bit word (pass 1), and after a scan over the
 // popcounts pass 2 re-derives the survivors and writes them at their final, ordered position.
-template <bool kFill>
+// kVP: with VP-guided proposals (base_line_triangulator.cc:250-281) a connection yields up to three
+// candidates in the order vp(l1), vp(l2), algebraic; the item then owns three ballots
+// masks[3 * item + {0: algebraic, 1: vp(l1), 2: vp(l2)}].
+template <bool kFill, bool kVP>
 __global__ void __launch_bounds__(256)
 k_gen_exhaustive(long long n_items, GenCfg cfg, const long long *__restrict__ item_off /* per node: first item */,
                  long long G, const int *__restrict__ node_img, const long long *__restrict__ nb_off,
@@ -130,7 +133,8 @@ k_gen_exhaustive(long long n_items, GenCfg cfg, const long long *__restrict__ it
                  const Cam *__restrict__ cams, const Seg *__restrict__ segs,
                  const PairRec *__restrict__ pairs, unsigned long long *__restrict__ masks,
                  const long long *__restrict__ mask_pos, Cand *__restrict__ out_c,
-                 CandLite *__restrict__ out_l) {
+                 CandLite *__restrict__ out_l, const double *__restrict__ seg_vp,
+                 const unsigned char *__restrict__ seg_has_vp) {
   long long item = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (item >= n_items) return;
   // node of this item: upper_bound(item_off, item) - 1
@@ -154,29 +158,79 @@ k_gen_exhaustive(long long n_items, GenCfg cfg, const long long *__restrict__ it
     rem -= chunks;
   }
   if (b >= b_end) return;
-  int ng_line = (int)(rem << 6) + lane_id();
-  bool ok = false;
+  constexpr int kMasks = kVP ? 3 : 1;
+  const int lane = lane_id();
+  int ng_line = (int)(rem << 6) + lane;
+  const long long g2 = seg_off[i2] + ng_line;
+  bool ok = false, ok1 = false, ok2 = false;
   GenOut o;
-  bool candidate_lane = ng_line < M2;
-  if (kFill) candidate_lane = candidate_lane && ((masks[item] >> lane_id()) & 1ull);
-  if (candidate_lane)
-    ok = gen_one(cfg, cams[i1], cams[i2], segs[g], segs[seg_off[i2] + ng_line], pairs[b], &o);
-  unsigned long long m = __ballot(ok);
+  const bool in_range = ng_line < M2;
+  bool do_alg = in_range, do_vp1 = false, do_vp2 = false;
+  if (kVP && in_range) {
+    // both segments long enough (:166,177)
+    const Seg &s1 = segs[g];
+    const Seg &s2 = segs[g2];
+    L2 l1{mk2(s1.x1, s1.y1), mk2(s1.x2, s1.y2)};
+    L2 l2{mk2(s2.x1, s2.y1), mk2(s2.x2, s2.y2)};
+    const bool len_ok = !(len(l1) <= cfg.min_length_2d) && !(len(l2) <= cfg.min_length_2d);
+    do_vp1 = len_ok && seg_has_vp[g];
+    do_vp2 = len_ok && seg_has_vp[g2];
+  }
+  if (kFill) {
+    do_alg = do_alg && ((masks[kMasks * item] >> lane) & 1ull);
+    if (kVP) {
+      do_vp1 = do_vp1 && ((masks[kMasks * item + 1] >> lane) & 1ull);
+      do_vp2 = do_vp2 && ((masks[kMasks * item + 2] >> lane) & 1ull);
+    }
+  }
+  if (do_alg) ok = gen_one(cfg, cams[i1], cams[i2], segs[g], segs[g2], pairs[b], &o);
+  GenOut o1, o2;
+  if (kVP) {
+    if (do_vp1) ok1 = vp_candidate(cfg, cams[i1], cams[i2], segs[g], segs[g2], pairs[b].B, seg_vp + 3 * g, &o1);
+    if (do_vp2) ok2 = vp_candidate(cfg, cams[i1], cams[i2], segs[g], segs[g2], pairs[b].B, seg_vp + 3 * g2, &o2);
+  }
+  const unsigned long long m = __ballot(ok);
+  unsigned long long m1 = 0, m2 = 0;
+  if (kVP) {
+    m1 = __ballot(ok1);
+    m2 = __ballot(ok2);
+  }
   if (!kFill) {
-    if (lane_id() == 0) masks[item] = m;
-  } else if (ok) {
-    long long pos = mask_pos[item] + __popcll(m & lanemask_lt());
-    o.l.nb_slot = lite_pack((int)(b - nb_off[i1]), i2);
-    o.l.ng_line = ng_line;
-    out_c[pos] = o.c;
-    out_l[pos] = o.l;
+    if (lane == 0) {
+      masks[kMasks * item] = m;
+      if (kVP) {
+        masks[kMasks * item + 1] = m1;
+        masks[kMasks * item + 2] = m2;
+      }
+    }
+  } else {
+    const unsigned long long lt_mask = lanemask_lt();
+    long long pos = mask_pos[item] + __popcll(m & lt_mask) + __popcll(m1 & lt_mask) + __popcll(m2 & lt_mask);
+    const int nbs = lite_pack((int)(b - nb_off[i1]), i2);
+    if (kVP && ok1) {
+      o1.l.nb_slot = nbs; o1.l.ng_line = ng_line;
+      out_c[pos] = o1.c; out_l[pos] = o1.l;
+      ++pos;
+    }
+    if (kVP && ok2) {
+      o2.l.nb_slot = nbs; o2.l.ng_line = ng_line;
+      out_c[pos] = o2.c; out_l[pos] = o2.l;
+      ++pos;
+    }
+    if (ok) {
+      o.l.nb_slot = nbs; o.l.ng_line = ng_line;
+      out_c[pos] = o.c; out_l[pos] = o.l;
+    }
   }
 }
 
 __global__ void k_popc(long long n, const unsigned long long *__restrict__ masks,
-                       unsigned *__restrict__ cnt) {
+                       unsigned *__restrict__ cnt, int n_masks) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) cnt[t] = (unsigned)__popcll(masks[t]);
+  if (t >= n) return;
+  unsigned c = 0;
+  for (int k = 0; k < n_masks; ++k) c += (unsigned)__popcll(masks[(long long)n_masks * t + k]);
+  cnt[t] = c;
 }
 
 // tri_off[g] = mask_pos[item_off[g]]
@@ -352,18 +406,22 @@ void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const G
                            const long long *item_off, long long G, const int *node_img, const long long *nb_off,
                            const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
                            const PairRec *pairs, unsigned long long *masks, const long long *mask_pos,
-                           Cand *out_c, CandLite *out_l) {
+                           Cand *out_c, CandLite *out_l, const double *seg_vp, const unsigned char *seg_has_vp) {
   if (n_items <= 0) return;
   dim3 grid(nblk(n_items * 64, 256)), block(256);
-  if (!fill)
-    hipLaunchKernelGGL(k_gen_exhaustive<false>, grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off,
-                       blk_nb, seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l);
-  else
-    hipLaunchKernelGGL(k_gen_exhaustive<true>, grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off,
-                       blk_nb, seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l);
+#define LT_LAUNCH_EX(FILL, VP)                                                                                     \
+  hipLaunchKernelGGL((k_gen_exhaustive<FILL, VP>), grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off, \
+                     blk_nb, seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l, seg_vp, seg_has_vp)
+  if (seg_vp) {
+    if (!fill) LT_LAUNCH_EX(false, true); else LT_LAUNCH_EX(true, true);
+  } else {
+    if (!fill) LT_LAUNCH_EX(false, false); else LT_LAUNCH_EX(true, false);
+  }
+#undef LT_LAUNCH_EX
 }
-void launch_popc(hipStream_t st, long long n, const unsigned long long *masks, unsigned *cnt) {
-  if (n > 0) hipLaunchKernelGGL(k_popc, dim3(nblk(n, 256)), dim3(256), 0, st, n, masks, cnt);
+// n_masks ballots per item (3 with VP proposals)
+void launch_popc(hipStream_t st, long long n, const unsigned long long *masks, unsigned *cnt, int n_masks) {
+  if (n > 0) hipLaunchKernelGGL(k_popc, dim3(nblk(n, 256)), dim3(256), 0, st, n, masks, cnt, n_masks);
 }
 void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_off, const long long *mask_pos,
                            long long n_items, long long total, long long *tri_off) {

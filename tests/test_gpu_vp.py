@@ -48,6 +48,31 @@ def test_vp_proposals_match_oracle(gpu_lib, oracle, sorted_rows):
     compare_tracks(T.context().get_tracks(), O.ComputeLineTracks())
 
 
+def test_vp_proposals_exhaustive_match_oracle(gpu_lib, oracle):
+    """TriangulateImageExhaustiveMatch with VP proposals: three survivor ballots per work item."""
+    from limap_amd import triangulation as tri
+    sc = syn.make_scene(n_views=8, n_segs=70, n_neighbors=4, seed=47)  # 70 segments: a ragged last chunk of 64
+    vps = syn.make_vp_results(sc, seed=4)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    cfg.update(use_vp=True)
+    T = tri.GlobalLineTriangulator(cfg)
+    O = oracle.OracleTriangulator(cfg, faithful=False)
+    T.SetRanges(sc.ranges); O.SetRanges(sc.ranges)
+    T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+    O.Init(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, sc.seg_off, sc.segs)
+    T.InitVPResults(vps); O.InitVPResults(vps)
+    for i in sc.img_ids:
+        T.TriangulateImageExhaustiveMatch(int(i), sc.neighbors[int(i)])
+        O.TriangulateImageExhaustiveMatch(int(i), sc.neighbors[int(i)])
+    g, o = T.context().get_all_tris(), O.get_all_tris()
+    assert g["off"][-1] > 0
+    compare_candidates(g, o)
+    compare_best(T.context().get_best(), O.get_best())
+    compare_valid_edges(T.context().get_valid_edges(), O.get_valid_edges())
+    T.context().compute_tracks()
+    compare_tracks(T.context().get_tracks(), O.ComputeLineTracks())
+
+
 def test_vp_only(gpu_lib, oracle):
     """disable_algebraic_triangulation: the VP candidates alone."""
     sc = syn.make_scene(n_views=10, n_segs=80, n_neighbors=4, seed=43)
@@ -79,8 +104,6 @@ def test_vp_switches_and_errors(gpu_lib, oracle):
         T.ComputeLineTracks()
     T = tri.GlobalLineTriangulator(cfg)
     T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
-    with pytest.raises((RuntimeError, ValueError), match="matched mode"):
-        T.TriangulateImageExhaustiveMatch(int(sc.img_ids[0]), sc.neighbors[int(sc.img_ids[0])])
     # wrong label count
     bad = dict(vps)
     k = int(sc.img_ids[1])
