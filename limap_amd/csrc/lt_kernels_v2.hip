@@ -150,9 +150,12 @@ __global__ void k_build_blk(int n_blk, const long long *__restrict__ m_off, cons
 // table is free), so the chunk loop sees no global latency beyond the (prefetched) match rows.
 // kLds1 / kLds2: compile-time choice of the operand source (LDS table or HBM/L2 gather) -- a run-time
 // choice would merge the two pointers and turn every operand read into a FLAT load.
+// blk_r / pairs_r: the same arrays as a.blk / a.pairs, as __restrict__ kernel parameters -- only then are
+// the wave-uniform record loads inside the persistent loop scalar (s_load); through the struct they may
+// alias the kernel's stores and are issued per lane.
 template <bool kLds1, bool kLds2>
 __global__ void __launch_bounds__(64 * kGateWaves) LT_GATE_OCC
-k_gates(GenArgs a, GenCfg cfg) {
+k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *__restrict__ pairs_r) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double2 *T2 = reinterpret_cast<double2 *>(smem_raw);   // [lds_segs][5] : SegGate records of the neighbour
   double2 *T1 = T2 + (size_t)a.lds_segs * 5;             // [lds_segs1][5]: own segments (x1 y1 x2 y2 rs re)
@@ -176,8 +179,8 @@ k_gates(GenArgs a, GenCfg cfg) {
   {                                                                                                 \
     const int it_ = (IT);                                                                           \
     const int itc_ = it_ < item_end ? it_ : item_end - 1;                                           \
-    const int bb_ = itc_ / n_parts, pp_ = itc_ - bb_ * n_parts;                                     \
-    const BlkRec *rp_ = a.blk + bb_;                                                                \
+    const int bb_ = __builtin_amdgcn_readfirstlane(itc_ / n_parts), pp_ = itc_ - bb_ * n_parts;     \
+    const BlkRec *rp_ = blk_r + bb_; /* wave-uniform index: scalar loads */                         \
     n_rb = rp_->rb; n_re = rp_->re; n_g1 = rp_->g1; n_g2 = rp_->g2; n_M2 = rp_->M2; n_i1 = rp_->i1; \
     n_live = it_ < item_end && n_rb + (long long)pp_ * kRowsPerPart < n_re;                         \
     if (kLds2 && n_live) {                                                                          \
@@ -198,7 +201,9 @@ k_gates(GenArgs a, GenCfg cfg) {
     const long long rb = n_rb, re = n_re, g1 = n_g1, g2 = n_g2;
     const int M2 = n_M2, i1 = n_i1;
     const bool live = n_live;
-    const int b = item / n_parts, part = item - b * n_parts;
+    // b is wave-uniform; telling the compiler so keeps the pair record (F) in scalar registers --
+    // otherwise it is re-fetched with per-lane vector loads inside the chunk loop
+    const int b = __builtin_amdgcn_readfirstlane(item / n_parts), part = item - b * n_parts;
     const int slot = part * kGateWaves + wave;
     const unsigned lin = (unsigned)b * (unsigned)a.n_slots + (unsigned)slot;
     LT_TRACE_MARK(0, lin, 0);
@@ -230,7 +235,10 @@ k_gates(GenArgs a, GenCfg cfg) {
     const long long r0 = rb + (long long)slot * kRowsPerWave;
     unsigned wcount = 0;
     if (live && r0 < re) {
-      const double *F = (a.pairs + b)->F;
+      double F[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) F[k] = pairs_r[b].F[k];
+      unsigned pass_bits = 0, und_bits = 0;
       int line_n = -1, ng_n = 0;
       {
         long long r = r0 + lane;
@@ -270,12 +278,21 @@ k_gates(GenArgs a, GenCfg cfg) {
           res = gate3(cfg, e0.x, e0.y, e1.x, e1.y, e2.x, e2.y, e3.x, e3.y, e4.x, e4.y,  // l1: endpoints, rs, re
                       h0.x, h0.y, h1.x, h1.y, h2.x, h2.y, h3.x, h3.y, h4.x, h4.y, F);   // l2: SegGate fields
         }
-        const unsigned long long m = __ballot(res != 0);
-        if (res != 0)
-          a.st_row[r0 + wcount + __popcll(m & lanemask_lt())] =
-              (unsigned)(64 * c + lane) | (res == 2 ? 0x80000000u : 0u);
-        wcount += (unsigned)__popcll(m);
+        // the outcome of chunk c is two bits per lane; the survivor list is written after the loop, so
+        // that no global store (and no wait for one) sits between the chunks
+        pass_bits |= (res != 0 ? 1u : 0u) << c;
+        und_bits |= (res == 2 ? 1u : 0u) << c;
         if (r0 + 64ll * (c + 1) >= re) break;
+      }
+      static_assert(kGenChunks <= 32, "one outcome bit per chunk and lane");
+#pragma unroll
+      for (int c = 0; c < kGenChunks; ++c) {
+        const bool pass = (pass_bits >> c) & 1u;
+        const unsigned long long m = __ballot(pass);
+        if (pass)
+          a.st_row[r0 + wcount + __popcll(m & lanemask_lt())] =
+              (unsigned)(64 * c + lane) | (((und_bits >> c) & 1u) ? 0x80000000u : 0u);
+        wcount += (unsigned)__popcll(m);
       }
     }
     LT_TRACE_MARK(0, lin, 2);
@@ -290,14 +307,15 @@ k_gates(GenArgs a, GenCfg cfg) {
 // connection up to three candidates in the reference's order vp(l1), vp(l2), algebraic.
 template <bool kVP>
 __global__ void __launch_bounds__(256)
-k_tri_rows(GenArgs a, GenCfg cfg) {
+k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec *__restrict__ pairs_r,
+           const BlkRec *__restrict__ blk_r) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
   const int n_groups = a.n_slots / kTriSlots;
   const int g = blockIdx.x * 4 + wave;
   if (g >= n_groups) return;
-  const BlkRec *rec = a.blk + b;
+  const BlkRec *rec = blk_r + b;
   const long long rb = rec->rb, re = rec->re;
   const long long r0 = rb + (long long)g * kTriRows;
   const unsigned lin = (unsigned)b * (unsigned)n_groups + (unsigned)g;
@@ -308,7 +326,7 @@ k_tri_rows(GenArgs a, GenCfg cfg) {
   }
   const int i1 = rec->i1, i2 = rec->i2, nbslot = rec->nbslot;
   const long long g1 = rec->g1, g2 = rec->g2;
-  const PairRec *pr = a.pairs + b;
+  const PairRec *pr = pairs_r + b;
   const long long lbase = a.cnt_bl ? rec->lbase : 0;
   const long long out0 = r0 * (kVP ? (long long)a.mult : 1ll);  // first staging slot of the group
   // survivor lists of the group's slots, walked as one concatenated list
@@ -340,7 +358,7 @@ k_tri_rows(GenArgs a, GenCfg cfg) {
       const Seg &s2 = a.segs[g2 + ng];
       ok = true;
       if (u >> 31) ok = gen_gates(cfg, s1, s2, pr->F);  // the cheap gates could not decide
-      if (ok) ok = gen_finish(cfg, a.cams[i1], a.cams[i2], s1, s2, pr->B, &o);
+      if (ok) ok = gen_finish(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B, &o);
       if (kVP) {
         // both segments long enough (:166,177) -- with VP proposals stage A lets every row through
         L2 l1{mk2(s1.x1, s1.y1), mk2(s1.x2, s1.y2)};
@@ -348,9 +366,9 @@ k_tri_rows(GenArgs a, GenCfg cfg) {
         const bool len_ok = !(len(l1) <= cfg.min_length_2d) && !(len(l2) <= cfg.min_length_2d);
         GenOut tmp;
         if (len_ok && a.seg_has_vp[g1 + line])
-          ok1 = vp_candidate(cfg, a.cams[i1], a.cams[i2], s1, s2, pr->B, a.seg_vp + 3 * (g1 + line), &tmp);
+          ok1 = vp_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B, a.seg_vp + 3 * (g1 + line), &tmp);
         if (len_ok && a.seg_has_vp[g2 + ng])
-          ok2 = vp_candidate(cfg, a.cams[i1], a.cams[i2], s1, s2, pr->B, a.seg_vp + 3 * (g2 + ng), &tmp);
+          ok2 = vp_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B, a.seg_vp + 3 * (g2 + ng), &tmp);
       }
       o.l.nb_slot = lite_pack(nbslot, i2);
       o.l.ng_line = ng;
@@ -370,7 +388,7 @@ k_tri_rows(GenArgs a, GenCfg cfg) {
           const Seg &s1 = a.segs[g1 + line];
           const Seg &s2 = a.segs[g2 + ng];
           GenOut ov;
-          (void)vp_candidate(cfg, a.cams[i1], a.cams[i2], s1, s2, pr->B,
+          (void)vp_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B,
                              a.seg_vp + 3 * (which == 0 ? g1 + line : g2 + ng), &ov);
           ov.l.nb_slot = lite_pack(nbslot, i2);
           ov.l.ng_line = ng;
@@ -808,15 +826,17 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   // the tables are sized by the largest image of the job, so "fits" is a per-launch property
   const dim3 grid(n_wg), block(64 * kGateWaves);
   if (ev3) (void)hipEventRecord(ev3[0], st);
-  if (lds_segs1 > 0 && lds_segs > 0) hipLaunchKernelGGL((k_gates<true, true>), grid, block, lds, st, a, cfg);
-  else if (lds_segs > 0) hipLaunchKernelGGL((k_gates<false, true>), grid, block, lds, st, a, cfg);
-  else if (lds_segs1 > 0) hipLaunchKernelGGL((k_gates<true, false>), grid, block, lds, st, a, cfg);
-  else hipLaunchKernelGGL((k_gates<false, false>), grid, block, lds, st, a, cfg);
+  if (lds_segs1 > 0 && lds_segs > 0) hipLaunchKernelGGL((k_gates<true, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
+  else if (lds_segs > 0) hipLaunchKernelGGL((k_gates<false, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
+  else if (lds_segs1 > 0) hipLaunchKernelGGL((k_gates<true, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
+  else hipLaunchKernelGGL((k_gates<false, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
   if (ev3) (void)hipEventRecord(ev3[1], st);
   if (seg_vp)
-    hipLaunchKernelGGL(k_tri_rows<true>, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg);
+    hipLaunchKernelGGL(k_tri_rows<true>, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg, a.cams,
+                       a.pairs, a.blk);
   else
-    hipLaunchKernelGGL(k_tri_rows<false>, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg);
+    hipLaunchKernelGGL(k_tri_rows<false>, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg, a.cams,
+                       a.pairs, a.blk);
   if (ev3) (void)hipEventRecord(ev3[2], st);
 }
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
