@@ -309,6 +309,7 @@ template <bool kVP>
 __global__ void __launch_bounds__(256)
 k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec *__restrict__ pairs_r,
            const BlkRec *__restrict__ blk_r) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];  // per wave: 64 x (Cand | CandLite | key)
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
@@ -401,12 +402,40 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
       below += (unsigned)ok1 + (unsigned)ok2;
       if (a.cnt_bl && (ok1 || ok2)) atomicAdd(&a.cnt_bl[lbase + line], (unsigned)ok1 + (unsigned)ok2);
     }
-    if (ok) {
-      const long long p = out0 + wcount + below;
-      a.st_c[p] = o.c;
-      a.st_l[p] = o.l;
-      a.st_key[p] = (unsigned)(g1 + line);
-      if (a.cnt_bl) atomicAdd(&a.cnt_bl[lbase + line], 1u);
+    if (kVP) {
+      if (ok) {
+        const long long p = out0 + wcount + below;
+        a.st_c[p] = o.c;
+        a.st_l[p] = o.l;
+        a.st_key[p] = (unsigned)(g1 + line);
+        if (a.cnt_bl) atomicAdd(&a.cnt_bl[lbase + line], 1u);
+      }
+    } else {
+      // The batch's valid candidates go to a contiguous piece of the group's list: compact them through
+      // LDS and write the piece with consecutive lanes on consecutive 16-byte units (a record-per-lane
+      // store touches 64 cache lines per instruction).
+      static_assert(sizeof(Cand) == 7 * 16 && sizeof(CandLite) == 2 * 16, "record sizes in 16-byte units");
+      double2 *Lc = reinterpret_cast<double2 *>(smem_raw) + (size_t)wave * (64 * 9 + 16);
+      double2 *Ll = Lc + 64 * 7;
+      unsigned *Lk = reinterpret_cast<unsigned *>(Ll + 64 * 2);
+      if (ok) {
+        const double2 *oc = reinterpret_cast<const double2 *>(&o.c);
+        const double2 *ol = reinterpret_cast<const double2 *>(&o.l);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) Lc[below * 7 + k] = oc[k];
+        Ll[below * 2] = ol[0];
+        Ll[below * 2 + 1] = ol[1];
+        Lk[below] = (unsigned)(g1 + line);
+        if (a.cnt_bl) atomicAdd(&a.cnt_bl[lbase + line], 1u);
+      }
+      wave_lds_sync();
+      const long long p0 = out0 + wcount;
+      double2 *dc = reinterpret_cast<double2 *>(a.st_c + p0);
+      double2 *dl = reinterpret_cast<double2 *>(a.st_l + p0);
+      for (unsigned u = lane; u < total * 7u; u += 64) dc[u] = Lc[u];
+      for (unsigned u = lane; u < total * 2u; u += 64) dl[u] = Ll[u];
+      if ((unsigned)lane < total) a.st_key[p0 + lane] = Lk[lane];
+      wave_lds_sync();
     }
     wcount += total;
   }
@@ -835,7 +864,8 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
     hipLaunchKernelGGL(k_tri_rows<true>, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg, a.cams,
                        a.pairs, a.blk);
   else
-    hipLaunchKernelGGL(k_tri_rows<false>, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg, a.cams,
+    hipLaunchKernelGGL(k_tri_rows<false>, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256),
+                       4 * (64 * 9 + 16) * sizeof(double2), st, a, cfg, a.cams,
                        a.pairs, a.blk);
   if (ev3) (void)hipEventRecord(ev3[2], st);
 }
