@@ -452,13 +452,14 @@ void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, con
 // the parity of i + j (:535-540); that orientation is kept because l1/l2 are not interchangeable
 // bit for bit.
 // ---------------------------------------------------------------------------------------------
+constexpr int kTrackChunk = 64;  // tracks j per workgroup column: small, so that a few thousand tracks already fill the GPU
 __global__ void __launch_bounds__(256)
 k_track_connect(int T, const double *__restrict__ line7, const unsigned char *__restrict__ active, int all_active,
                 LinkCfg3 cfg, double cos_guard, unsigned long long *__restrict__ edges,
                 unsigned long long capacity, unsigned long long *__restrict__ n_edges) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j0 = blockIdx.y * 256;
-  const int j1 = min(T, j0 + 256);
+  const int j0 = blockIdx.y * kTrackChunk;
+  const int j1 = min(T, j0 + kTrackChunk);
   const bool live = (i < T) && active[i];
   L3 li{mk3(0, 0, 0), mk3(0, 0, 0)};
   d3 di = mk3(0, 0, 0);
@@ -471,23 +472,32 @@ k_track_connect(int T, const double *__restrict__ line7, const unsigned char *__
     di = dir(li);
   }
   const double dep[2] = {0.0, 0.0};
-  for (int j = j0; j < j1; ++j) {
+  for (int j = j0; j < j1; ++j) {  // j is wave-uniform
     bool test = live && (j != i);
     if (test && all_active) {
       if (i < j && ((i + j) & 1) == 0) test = false;
       if (i > j && ((i + j) & 1) == 1) test = false;
     }
-    if (!test) continue;
-    const double *q = line7 + 7 * (long long)j;
-    L3 lj{mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5])};
-    if (cfg.use_angle) {
-      double c = fabs(dot(di, dir(lj)));
-      if (c < cos_guard) continue;
+    bool hit = false;
+    if (test) {
+      const double *q = line7 + 7 * (long long)j;
+      L3 lj{mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5])};
+      bool go = true;
+      if (cfg.use_angle) go = !(fabs(dot(di, dir(lj))) < cos_guard);
+      if (go) hit = check3d(cfg, li, lj, ui, q[6], dep);
     }
-    if (!check3d(cfg, li, lj, ui, q[6], dep)) continue;
-    unsigned long long slot = atomicAdd(n_edges, 1ull);
-    unsigned long long a = (unsigned long long)min(i, j), b = (unsigned long long)max(i, j);
-    if (slot < capacity) edges[slot] = (a << 32) | b;
+    // one counter update per wave and j (a device-scope atomic per edge would serialise)
+    const unsigned long long m = __ballot(hit);
+    if (m) {
+      unsigned long long base = 0;
+      if (lane_id() == 0) base = atomicAdd(n_edges, (unsigned long long)__popcll(m));
+      base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), 0) << 32) | (unsigned)__shfl((int)(base & 0xFFFFFFFFull), 0);
+      if (hit) {
+        const unsigned long long slot = base + (unsigned long long)__popcll(m & lanemask_lt());
+        const unsigned long long a = (unsigned long long)min(i, j), b = (unsigned long long)max(i, j);
+        if (slot < capacity) edges[slot] = (a << 32) | b;
+      }
+    }
   }
 }
 
@@ -495,7 +505,7 @@ void launch_track_connect(hipStream_t st, int T, const double *line7, const unsi
                           const LinkCfg3 &cfg, double cos_guard, unsigned long long *edges,
                           unsigned long long capacity, unsigned long long *n_edges) {
   if (T <= 0) return;
-  hipLaunchKernelGGL(k_track_connect, dim3(nblk(T, 256), nblk(T, 256)), dim3(256), 0, st, T, line7, active,
+  hipLaunchKernelGGL(k_track_connect, dim3(nblk(T, 256), nblk(T, kTrackChunk)), dim3(256), 0, st, T, line7, active,
                      all_active, cfg, cos_guard, edges, capacity, n_edges);
 }
 
