@@ -42,7 +42,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const double *seg_vp, const unsigned char *seg_has_vp);
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
-                        unsigned *n_tris);
+                        unsigned *base_bl, unsigned *n_tris);
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
@@ -528,7 +528,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
-                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp};
+                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl};
   lt_host::host_block_release(ctx->h_pinned_blk);
   for (DevBuf *b : bufs) b->release();
   // a context that still owns its stream hands stream + events to the next context
@@ -984,12 +984,13 @@ int lt_run_device(lt_ctx *ctx) {
   const GenCfg gcfg = make_gen(ctx);
   const ScoreCfg scfg = make_score(ctx);
   ENSURE(ctx, ctx->d_err, sizeof(int));
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_err.p, 0, sizeof(int), st));
+  ENSURE(ctx, ctx->d_pair_counter, 8);
   ENSURE(ctx, ctx->d_pairs, sizeof(PairRec) * (size_t)std::max(ctx->n_blk, 1));
   ENSURE(ctx, ctx->d_tri_off, sizeof(long long) * (size_t)(G + 1));
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
   launch_build_pairs(st, ctx->n_blk, ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_cams.as<Cam>(),
-                     ctx->d_pairs.as<PairRec>());
+                     ctx->d_pairs.as<PairRec>(), ctx->d_err.as<int>(),
+                     ctx->d_pair_counter.as<unsigned long long>());  // also zeroes the error flag and the pair statistic
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
 
   long long C_known = -1;  // candidate count once it is known on the host
@@ -1012,8 +1013,17 @@ int lt_run_device(lt_ctx *ctx) {
     ENSURE(ctx, ctx->d_wave_count, 4 * (size_t)(n_waves + 1));
     ENSURE(ctx, ctx->d_ntris_u, 4 * (size_t)(G + 1));
     if (fast) {
-      ENSURE(ctx, ctx->d_cnt_bl, 4 * (size_t)std::max<long long>(n_entries, 1));
-      HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt_bl.p, 0, 4 * (size_t)std::max<long long>(n_entries, 1), st));
+      // per-(block, line) counters: k_node_prefix zeroes every counter it reads, so the array only has to
+      // be cleared when it is new or when the previous run did not get that far
+      const size_t nb = 4 * (size_t)std::max<long long>(n_entries, 1);
+      const void *before = ctx->d_cnt_bl.p;
+      ENSURE(ctx, ctx->d_cnt_bl, nb);
+      ENSURE(ctx, ctx->d_base_bl, nb);
+      if (ctx->d_cnt_bl.p != before || !ctx->cnt_bl_clean || ctx->cnt_bl_bytes != nb) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt_bl.p, 0, ctx->d_cnt_bl.cap, st));
+        ctx->cnt_bl_bytes = nb;
+      }
+      ctx->cnt_bl_clean = false;
     }
     static const bool no_lds_table = getenv("LT_GEN_NO_LDS_TABLE") != nullptr;  // developer A/B switch
     // LDS tables of k_gates: the neighbour's gate records (T2) and the image's own segments (T1), 80 B
@@ -1044,7 +1054,8 @@ int lt_run_device(lt_ctx *ctx) {
       // rows of every block are sorted by line id: sort-free placement
       launch_node_prefix(st, G, ctx->d_node_img.as<int>(), ctx->d_seg_off.as<long long>(),
                          ctx->d_nb_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
-                         ctx->d_cnt_bl.as<unsigned>(), ctx->d_ntris_u.as<unsigned>());
+                         ctx->d_cnt_bl.as<unsigned>(), ctx->d_base_bl.as<unsigned>(), ctx->d_ntris_u.as<unsigned>());
+      ctx->cnt_bl_clean = true;
       size_t tmp = scan_temp_bytes_u32_to_i64(G + 1);
       ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
       if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, G + 1, ctx->d_ntris_u.as<unsigned>(),
@@ -1074,7 +1085,7 @@ int lt_run_device(lt_ctx *ctx) {
     if (fast) {
       launch_place(st, ctx->n_blk, ctx->max_rows, ctx->d_m_off.as<long long>(), ctx->d_blk_img.as<int>(),
                    ctx->d_seg_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
-                   ctx->d_cnt_bl.as<unsigned>(), ctx->d_wave_count.as<unsigned>(), ctx->d_tri_off.as<long long>(),
+                   ctx->d_base_bl.as<unsigned>(), ctx->d_wave_count.as<unsigned>(), ctx->d_tri_off.as<long long>(),
                    ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(),
                    ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_cand_node.as<unsigned>(), mult);
     } else {
@@ -1157,8 +1168,6 @@ int lt_run_device(lt_ctx *ctx) {
     double th = scfg.l3.th_scaleinv * (1.0 + 1e-6);
     double guard2 = (scfg.l3.th_scaleinv > 0.0 && scfg.l3.score_th > 0.0 && scfg.l3.score_th < 1.0) ? th * th : 1e300;
     if (getenv("LT_TEST_NO_SCORE_GUARDS")) guard2 = 1e300;
-    ENSURE(ctx, ctx->d_pair_counter, 8);
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_pair_counter.p, 0, 8, st));
     if (ctx->h_nb_off[ctx->n_img] >= (1ll << 24))
       return fail(ctx, LT_ERR_ARGUMENT, "too many (image, neighbour) blocks in one batch (>= 2^24)");
     ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_known, 1));

@@ -17,6 +17,8 @@
 
 #include "lt_devfn.h"
 
+#include <algorithm>
+
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -93,10 +95,16 @@ __global__ void k_build_segs_chunked(long long n_segs, int n_img, int n_chunks, 
   out[s] = r;
 }
 
+// also clears the run's two device scalars (error flag, pair statistic): one launch instead of three
 __global__ void k_build_pairs(int n_blk, const int *__restrict__ blk_img,
                               const int *__restrict__ blk_nb, const Cam *__restrict__ cams,
-                              PairRec *__restrict__ out) {
+                              PairRec *__restrict__ out, int *__restrict__ err_flag,
+                              unsigned long long *__restrict__ pair_counter) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0) {
+    if (err_flag) *err_flag = 0;
+    if (pair_counter) *pair_counter = 0ull;
+  }
   if (b >= n_blk) return;
   PairRec p;
   pair_build(cams[blk_img[b]], cams[blk_nb[b]], &p);
@@ -372,9 +380,9 @@ void launch_build_scene_chunked(hipStream_t st, int n_img, long long n_segs, int
                        seg_off, halfpix, cams, segs);
 }
 void launch_build_pairs(hipStream_t st, int n_blk, const int *blk_img, const int *blk_nb, const Cam *cams,
-                        PairRec *out) {
-  if (n_blk > 0)
-    hipLaunchKernelGGL(k_build_pairs, dim3(nblk(n_blk, 128)), dim3(128), 0, st, n_blk, blk_img, blk_nb, cams, out);
+                        PairRec *out, int *err_flag, unsigned long long *pair_counter) {
+  hipLaunchKernelGGL(k_build_pairs, dim3(nblk(std::max(n_blk, 1), 128)), dim3(128), 0, st, n_blk, blk_img, blk_nb, cams,
+                     out, err_flag, pair_counter);
 }
 size_t sort_temp_bytes(long long P, int end_bit) {
   size_t bytes = 0;

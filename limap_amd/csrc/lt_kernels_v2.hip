@@ -443,12 +443,12 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
   if (lane == 0) a.wave_count[lin] = wcount;
 }
 
-// Fast path: exclusive prefix of cnt_bl over the neighbour blocks of every node (in place) and the
+// Fast path: exclusive prefix of cnt_bl over the neighbour blocks of every node (into base_bl) and the
 // node's candidate count.
 __global__ void k_node_prefix(long long G, const int *__restrict__ node_img,
                               const long long *__restrict__ seg_off, const long long *__restrict__ nb_off,
                               const long long *__restrict__ blk_line_base, unsigned *__restrict__ cnt_bl,
-                              unsigned *__restrict__ n_tris) {
+                              unsigned *__restrict__ base_bl, unsigned *__restrict__ n_tris) {
   long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g > G) return;
   unsigned run = 0;
@@ -458,7 +458,8 @@ __global__ void k_node_prefix(long long G, const int *__restrict__ node_img,
     for (long long b = nb_off[img]; b < nb_off[img + 1]; ++b) {
       long long e = blk_line_base[b] + line;
       unsigned c = cnt_bl[e];
-      cnt_bl[e] = run;
+      cnt_bl[e] = 0;  // every counter is read exactly once: leave the array clean for the next run
+      base_bl[e] = run;
       run += c;
     }
   }
@@ -871,9 +872,9 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
 }
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
-                        unsigned *n_tris) {
+                        unsigned *base_bl, unsigned *n_tris) {
   hipLaunchKernelGGL(k_node_prefix, dim3(nblk2(G + 1, 256)), dim3(256), 0, st, G, node_img, seg_off, nb_off,
-                     blk_line_base, cnt_bl, n_tris);
+                     blk_line_base, cnt_bl, base_bl, n_tris);
 }
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
