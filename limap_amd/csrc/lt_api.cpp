@@ -1025,7 +1025,7 @@ int lt_run_device(lt_ctx *ctx) {
       }
       ctx->cnt_bl_clean = false;
     }
-    static const bool no_lds_table = getenv("LT_GEN_NO_LDS_TABLE") != nullptr;  // developer A/B switch
+    const bool no_lds_table = getenv("LT_GEN_NO_LDS_TABLE") != nullptr;  // developer / test switch
     // LDS tables of k_gates: the neighbour's gate records (T2) and the image's own segments (T1), 80 B
     // per segment each; two workgroups per CU need both within 80 KB, one workgroup within 160 KB
     int lds_segs = (!no_lds_table && ctx->max_nb_segs <= 1024) ? ctx->max_nb_segs : 0;

@@ -105,3 +105,53 @@ def test_release_cached_memory(gpu_lib):
     assert len(T.ComputeLineTracks()) == n1
     gpu_lib.lt_release_cached_memory()      # live context unaffected
     assert len(T.context().get_tracks()["off"]) == n1 + 1
+
+
+@pytest.mark.parametrize("own_big,nb_big", [(True, True), (False, True), (True, False)])
+def test_operand_table_variants(gpu_lib, oracle, clean_env, own_big, nb_big):
+    """k_gates keeps the operand tables in LDS only for images with <= 1024 segments; the other three
+    instantiations (own and/or neighbour operands gathered from HBM/L2) must give the same lists."""
+    from limap_amd import triangulation as tri
+    sc = syn.make_scene(n_views=6, n_segs=1100, n_neighbors=3, seed=51, topk=3)
+    big = {0, 1, 2}                      # images that keep all 1100 segments; the others keep 200
+    keep = [1100 if i in big else 200 for i in range(6)]
+    segs = [sc.segs_of(i)[:keep[i]] for i in range(6)]
+    off = np.zeros(7, np.int64); off[1:] = np.cumsum(keep)
+    # jobs: images whose size class is `own_big`, matched against neighbours of class `nb_big`
+    jobs = [i for i in range(6) if (i in big) == own_big]
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    T = tri.GlobalLineTriangulator(cfg)
+    O = oracle.OracleTriangulator(cfg, faithful=False)
+    T.SetRanges(sc.ranges); O.SetRanges(sc.ranges)
+    T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, segs)
+    O.Init(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, off, np.concatenate(segs, 0))
+    rng = np.random.default_rng(7)
+    n_rows = 0
+    for i in jobs:
+        m = {}
+        for nb in range(6):
+            if nb == i or (nb in big) != nb_big:
+                continue
+            k = 3 * keep[i]
+            rows = np.stack([np.repeat(np.arange(keep[i]), 3), rng.integers(0, keep[nb], k)], 1).astype(np.int32)
+            m[int(sc.img_ids[nb])] = rows
+            n_rows += k
+        T.TriangulateImage(int(sc.img_ids[i]), m)
+        O.TriangulateImage(int(sc.img_ids[i]), m)
+    assert n_rows > 0
+    compare_candidates(T.context().get_all_tris(), O.get_all_tris())
+    compare_best(T.context().get_best(), O.get_best())
+    compare_valid_edges(T.context().get_valid_edges(), O.get_valid_edges())
+
+
+def test_no_lds_tables_switch(gpu_lib, clean_env):
+    """LT_GEN_NO_LDS_TABLE (developer switch): all operands gathered from HBM/L2, identical results."""
+    sc = syn.make_scene(n_views=10, n_segs=120, n_neighbors=4, seed=52)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    base = _results(run_product(sc, cfg))
+    os.environ["LT_GEN_NO_LDS_TABLE"] = "1"
+    try:
+        other = _results(run_product(sc, cfg))
+    finally:
+        del os.environ["LT_GEN_NO_LDS_TABLE"]
+    _same(base, other)
