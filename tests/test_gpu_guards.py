@@ -155,3 +155,37 @@ def test_no_lds_tables_switch(gpu_lib, clean_env):
     finally:
         del os.environ["LT_GEN_NO_LDS_TABLE"]
     _same(base, other)
+
+
+def test_full_size_invariants(gpu_lib, clean_env):
+    """BASELINE's full size (100 views x 500 segments, 10^7 connections): the oracle needs ~8 s per run
+    here (bench.py times it and checks its counts), so this test uses size-independent properties --
+    the exact-gates run, the no-guards run and a second default run must all reproduce the default run
+    bit for bit -- plus the counts the oracle gives for this seed (bench.py `cpu_parity`)."""
+    sc = syn.make_scene(n_views=100, n_segs=500, n_neighbors=20, seed=0)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    matches = {int(i): sc.matches_of(int(i)) for i in sc.img_ids}
+
+    def run():
+        from limap_amd import triangulation as tri
+        T = tri.GlobalLineTriangulator(cfg)
+        T.SetRanges(sc.ranges)
+        T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+        for i in sc.img_ids:
+            T.TriangulateImage(int(i), matches[int(i)])
+        return _results(T)
+
+    base = run()
+    assert base[5]["connections"] == 10_000_000
+    assert base[5]["candidates"] == 579_235 and base[5]["tracks"] == 1_367 and base[5]["valid_edges"] == 96_488
+    _same(base, run())                                   # idempotent
+    os.environ["LT_TEST_NO_FAST_GATES"] = "1"
+    exact = run()
+    del os.environ["LT_TEST_NO_FAST_GATES"]
+    _same(base, exact)
+    assert exact[4]["survivors"] == 10_000_000
+    os.environ["LT_TEST_NO_SCORE_GUARDS"] = "1"
+    dense = run()
+    del os.environ["LT_TEST_NO_SCORE_GUARDS"]
+    _same(base, dense)
+    assert dense[4]["pairs_eval"] > 10 * base[4]["pairs_eval"]
