@@ -1164,7 +1164,7 @@ int lt_run_device(lt_ctx *ctx) {
   if (score3_lds_bytes(ctx->max_nb) > 160 * 1024)
     return fail(ctx, LT_ERR_ARGUMENT, "too many neighbours for the scoring kernel's LDS budget");
   {
-    // conservative square of the scale-invariant endpoint gate (see k_score2)
+    // conservative square of the scale-invariant endpoint gate (see k_score3)
     double th = scfg.l3.th_scaleinv * (1.0 + 1e-6);
     double guard2 = (scfg.l3.th_scaleinv > 0.0 && scfg.l3.score_th > 0.0 && scfg.l3.score_th < 1.0) ? th * th : 1e300;
     if (getenv("LT_TEST_NO_SCORE_GUARDS")) guard2 = 1e300;

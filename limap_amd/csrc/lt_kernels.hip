@@ -7,7 +7,7 @@
 //   k_gen_exhaustive                            : HOT LOOP 1, triangulateOneNode
 //       (triangulation/base_line_triangulator.cc:161-337) for TriangulateImageExhaustiveMatch:
 //       degeneracy gates, weak epipolar IoU, ray/plane triangulation, sensitivity gate,
-//       uncertainty, ranges.  (Matched mode: k_gen_rows in lt_kernels_v2.hip; scoring: k_score3.)
+//       uncertainty, ranges.  (Matched mode: k_gates + k_tri_rows in lt_kernels_v2.hip; scoring: k_score3.)
 //   k_select                                    : per-node strict arg-max (lowest index wins ties,
 //       global_line_triangulator.cc:145-153) and valid-edge flags (:118-142).
 //
