@@ -528,7 +528,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
-                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl};
+                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off};
   lt_host::host_block_release(ctx->h_pinned_blk);
   for (DevBuf *b : bufs) b->release();
   // a context that still owns its stream hands stream + events to the next context
@@ -946,12 +946,18 @@ int lt_upload(lt_ctx *ctx) {
   } else if (ctx->job_mode == 2) {
     // work items: per node, per neighbour block, chunks of 64 neighbour lines
     ctx->h_item_off.assign(ctx->G + 1, 0);
+    // per block: chunks of the earlier neighbour blocks of the same image (the item index of
+    // (node, block, chunk) is item_off[node] + blk_chunk_off[block] + chunk -- no search on the device)
+    std::vector<int> blk_chunk_off((size_t)std::max(ctx->n_blk, 1), 0);
+    ctx->max_chunks = 1;
     long long items = 0, conns = 0;
     for (int i = 0; i < ctx->n_img; ++i) {
       long long per_node = 0, conn_node = 0;
       for (long long b = ctx->h_nb_off[i]; b < ctx->h_nb_off[i + 1]; ++b) {
         int i2 = ctx->h_blk_nb[b];
         long long M2 = ctx->seg_off[i2 + 1] - ctx->seg_off[i2];
+        blk_chunk_off[(size_t)b] = (int)per_node;
+        ctx->max_chunks = std::max(ctx->max_chunks, (int)((M2 + 63) / 64));
         per_node += (M2 + 63) / 64;
         conn_node += M2;
       }
@@ -965,6 +971,7 @@ int lt_upload(lt_ctx *ctx) {
     ctx->P = items;
     ctx->n_conn = conns;
     if ((rc = upload_vec(ctx, ctx->d_item_off, ctx->h_item_off))) return rc;
+    if ((rc = upload_vec(ctx, ctx->d_blk_chunk_off, blk_chunk_off))) return rc;
   } else {
     ctx->P = 0;
     ctx->n_conn = 0;
@@ -1122,7 +1129,8 @@ int lt_run_device(lt_ctx *ctx) {
     launch_gen_exhaustive(st, false, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
                           ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
                           ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
-                          ctx->d_masks.as<unsigned long long>(), nullptr, nullptr, nullptr, seg_vp, seg_has_vp);
+                          ctx->d_masks.as<unsigned long long>(), nullptr, nullptr, nullptr, seg_vp, seg_has_vp,
+                          ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks);
     launch_popc(st, P, ctx->d_masks.as<unsigned long long>(), ctx->d_mask_cnt.as<unsigned>(), n_masks);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_mask_cnt.as<unsigned>() + P, 0, 4, st));
     {
@@ -1145,7 +1153,8 @@ int lt_run_device(lt_ctx *ctx) {
                           ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
                           ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
                           ctx->d_masks.as<unsigned long long>(), ctx->d_mask_pos.as<long long>(),
-                          ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), seg_vp, seg_has_vp);
+                          ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), seg_vp, seg_has_vp,
+                          ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks);
     launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, total,
                           ctx->d_tri_off.as<long long>());
     ENSURE(ctx, ctx->d_cand_node, 4 * Cn);

@@ -142,30 +142,26 @@ k_gen_exhaustive(long long n_items, GenCfg cfg, const long long *__restrict__ it
                  const PairRec *__restrict__ pairs, unsigned long long *__restrict__ masks,
                  const long long *__restrict__ mask_pos, Cand *__restrict__ out_c,
                  CandLite *__restrict__ out_l, const double *__restrict__ seg_vp,
-                 const unsigned char *__restrict__ seg_has_vp) {
-  long long item = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                 const unsigned char *__restrict__ seg_has_vp, const int *__restrict__ blk_chunk_off,
+                 int max_nb, int max_chunks) {
+  // wave -> (node, neighbour slot, chunk) by arithmetic: every node owns max_nb * max_chunks wave slots
+  // (those beyond its image's neighbours / the neighbour's chunks exit at once); the item index, which
+  // orders the candidates, is item_off[node] + blk_chunk_off[block] + chunk
+  const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long per_node = (long long)max_nb * max_chunks;
+  const long long g = w / per_node;
+  if (g >= G) return;
+  const int rest = (int)(w - g * per_node);
+  const int k = rest / max_chunks;
+  const long long rem = rest - k * max_chunks;
+  const int i1 = node_img[g];
+  const long long b = nb_off[i1] + k;
+  if (b >= nb_off[i1 + 1]) return;
+  const int i2 = blk_nb[b];
+  const long long M2 = seg_off[i2 + 1] - seg_off[i2];
+  if (rem >= ((M2 + 63) >> 6)) return;
+  const long long item = item_off[g] + blk_chunk_off[b] + rem;
   if (item >= n_items) return;
-  // node of this item: upper_bound(item_off, item) - 1
-  long long lo = 0, hi = G;
-  while (hi - lo > 1) {
-    long long mid = (lo + hi) >> 1;
-    if (item_off[mid] <= item) lo = mid; else hi = mid;
-  }
-  long long g = lo;
-  int i1 = node_img[g];
-  long long rem = item - item_off[g];  // chunk index inside the node, neighbour-major
-  long long b = nb_off[i1];
-  const long long b_end = nb_off[i1 + 1];
-  int i2 = -1;
-  long long M2 = 0;
-  for (; b < b_end; ++b) {
-    i2 = blk_nb[b];
-    M2 = seg_off[i2 + 1] - seg_off[i2];
-    long long chunks = (M2 + 63) >> 6;
-    if (rem < chunks) break;
-    rem -= chunks;
-  }
-  if (b >= b_end) return;
   constexpr int kMasks = kVP ? 3 : 1;
   const int lane = lane_id();
   int ng_line = (int)(rem << 6) + lane;
@@ -191,7 +187,23 @@ k_gen_exhaustive(long long n_items, GenCfg cfg, const long long *__restrict__ it
       do_vp2 = do_vp2 && ((masks[kMasks * item + 2] >> lane) & 1ull);
     }
   }
-  if (do_alg) ok = gen_one(cfg, cams[i1], cams[i2], segs[g], segs[g2], pairs[b], &o);
+  if (do_alg) {
+    const Seg &s1 = segs[g];
+    const Seg &s2 = segs[g2];
+    if (kFill) {
+      // pass 1 found this connection valid: its gates pass, only the candidate itself is needed again
+      ok = gen_finish(cfg, cams[i1], cams[i2], s1, s2, pairs[b].B, &o);
+    } else {
+      // cheap three-way gates first (gate3, as in k_gates): most connections of an exhaustive match are
+      // certain rejects; certain passes skip the exact gates, undecided ones go through them
+      SegGate gg;
+      seg_gate_build(s2, &gg);
+      const int res = gate3(cfg, s1.x1, s1.y1, s1.x2, s1.y2, s1.rs[0], s1.rs[1], s1.rs[2], s1.re[0], s1.re[1], s1.re[2],
+                            gg.n[0], gg.n[1], gg.n[2], gg.lcx, gg.lcy, gg.P, gg.Q, gg.w1, gg.sv, gg.q2, pairs[b].F);
+      if (res == 1) ok = gen_finish(cfg, cams[i1], cams[i2], s1, s2, pairs[b].B, &o);
+      else if (res == 2) ok = gen_one(cfg, cams[i1], cams[i2], s1, s2, pairs[b], &o);
+    }
+  }
   GenOut o1, o2;
   if (kVP) {
     if (do_vp1) ok1 = vp_candidate(cfg, cams[i1], cams[i2], segs[g], segs[g2], pairs[b].B, seg_vp + 3 * g, &o1);
@@ -414,12 +426,14 @@ void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const G
                            const long long *item_off, long long G, const int *node_img, const long long *nb_off,
                            const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
                            const PairRec *pairs, unsigned long long *masks, const long long *mask_pos,
-                           Cand *out_c, CandLite *out_l, const double *seg_vp, const unsigned char *seg_has_vp) {
+                           Cand *out_c, CandLite *out_l, const double *seg_vp, const unsigned char *seg_has_vp,
+                           const int *blk_chunk_off, int max_nb, int max_chunks) {
   if (n_items <= 0) return;
-  dim3 grid(nblk(n_items * 64, 256)), block(256);
+  dim3 grid(nblk(G * (long long)max_nb * max_chunks * 64, 256)), block(256);
 #define LT_LAUNCH_EX(FILL, VP)                                                                                     \
   hipLaunchKernelGGL((k_gen_exhaustive<FILL, VP>), grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off, \
-                     blk_nb, seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l, seg_vp, seg_has_vp)
+                     blk_nb, seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l, seg_vp, seg_has_vp, blk_chunk_off, max_nb, \
+                     max_chunks)
   if (seg_vp) {
     if (!fill) LT_LAUNCH_EX(false, true); else LT_LAUNCH_EX(true, true);
   } else {
