@@ -108,7 +108,9 @@ int lt_refresh_scene_device(lt_ctx *ctx, const void *d_kvec, const void *d_qvec,
  * rank of the all-gather), chunk c holding images [img_begin[c], img_begin[c+1]) (indices in
  * ascending-id order) as four device arrays kvec | qvec | tvec | segs.  lt_set_scene_chunks records
  * the (persistent) buffer addresses once; lt_refresh_scene_chunks rebuilds the invariants from them
- * on the context's stream after every all-gather. */
+ * on the context's stream after every all-gather.  While a job is uploaded (lt_upload) only the images
+ * that job references -- triangulated here, or a neighbour -- get their segment records rebuilt (a rank
+ * of an N-GPU job needs ~1/N of the gathered scene); cameras are always rebuilt for all images. */
 int lt_set_scene_chunks(lt_ctx *ctx, int n_chunks, const int32_t *img_begin, const void *const *d_kvec,
                         const void *const *d_qvec, const void *const *d_tvec, const void *const *d_segs);
 int lt_refresh_scene_chunks(lt_ctx *ctx);

@@ -6,6 +6,7 @@ raises ``RuntimeError``.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -69,6 +70,27 @@ MERGING = {"greedy": 0, "exhaustive": 1, "avg": 2}
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (file name without
+    version, SONAME libamdhip64.so.7).  If this extension is loaded first it pulls in /opt/rocm's
+    libamdhip64.so.7, and a later `import torch` then loads the bundled copy AS WELL (the loader matches
+    torch's NEEDED entry by file name, not by SONAME) -- the second runtime finds no usable GPU
+    ("No HIP GPUs are available") and streams could not be shared anyway.  Loading torch's copy first makes
+    this extension's NEEDED libamdhip64.so.7 resolve to it, whatever the import order.  No torch, no-op."""
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # fall back to the system runtime
+
+
 def load_library():
     """dlopen liblimap_amd.so and declare the prototypes.  Raises if the extension is not built."""
     global _lib
@@ -78,6 +100,7 @@ def load_library():
         raise RuntimeError(
             f"limap_amd: HIP extension {LIB_PATH} is not built (run `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C limap_amd/csrc`); there is no CPU fallback")
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32p, i64p, dp, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
     L.lt_config_default.argtypes = [C.POINTER(LtConfig)]

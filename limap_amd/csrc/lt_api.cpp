@@ -528,7 +528,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
-                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off};
+                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed};
   lt_host::host_block_release(ctx->h_pinned_blk);
   for (DevBuf *b : bufs) b->release();
   // a context that still owns its stream hands stream + events to the next context
@@ -695,9 +695,13 @@ int lt_set_scene_chunks(lt_ctx *ctx, int n_chunks, const int32_t *img_begin, con
 int lt_refresh_scene_chunks(lt_ctx *ctx) {
   if (!ctx->inited || ctx->n_chunks <= 0) return fail(ctx, LT_ERR_STATE, "lt_refresh_scene_chunks before lt_set_scene_chunks");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  // with an uploaded job only the images it references (triangulated here, or a neighbour) need their
+  // segment records; without one, everything
+  const bool listed = ctx->uploaded && ctx->n_needed > 0;
   launch_build_scene_chunked(ctx->stream, ctx->n_img, ctx->G, ctx->n_chunks, ctx->d_chunks.as<SceneChunk>(),
                              ctx->d_seg_off.as<long long>(), ctx->cfg.add_halfpix ? 0.5 : 0.0, ctx->d_cams.as<Cam>(),
-                             ctx->d_segs.as<Seg>());
+                             ctx->d_segs.as<Seg>(), listed ? ctx->d_needed.as<int>() : nullptr, ctx->n_needed,
+                             ctx->max_needed_segs);
   HIPCHK(ctx, hipGetLastError());
   ctx->ran = false;
   return LT_OK;
@@ -885,6 +889,24 @@ int lt_upload(lt_ctx *ctx) {
   double t0 = now_ms();
   build_job_tables(ctx);
   int rc;
+  {
+    // images referenced by the job (lt_refresh_scene_chunks rebuilds only their segment records)
+    std::vector<char> need((size_t)std::max(ctx->n_img, 1), 0);
+    for (size_t j = 0; j < ctx->job_imgs.size(); ++j) {
+      need[(size_t)ctx->job_imgs[j]] = 1;
+      for (int nb : ctx->job_nbs[j]) need[(size_t)nb] = 1;
+    }
+    std::vector<int> list;
+    ctx->max_needed_segs = 0;
+    for (int i = 0; i < ctx->n_img; ++i)
+      if (need[(size_t)i]) {
+        list.push_back(i);
+        ctx->max_needed_segs = std::max(ctx->max_needed_segs, ctx->seg_off[i + 1] - ctx->seg_off[i]);
+      }
+    ctx->n_needed = (int)list.size();
+    if (list.empty()) list.push_back(0);
+    if ((rc = upload_vec(ctx, ctx->d_needed, list))) return rc;
+  }
   if ((rc = upload_vec(ctx, ctx->d_nb_off, ctx->h_nb_off))) return rc;
   if ((rc = upload_vec(ctx, ctx->d_blk_img, ctx->h_blk_img))) return rc;
   if ((rc = upload_vec(ctx, ctx->d_blk_nb, ctx->h_blk_nb))) return rc;

@@ -187,6 +187,9 @@ struct lt_ctx {
   lt_host::HostBlock h_pinned_blk;
   long long *h_pinned = nullptr;  // pinned scratch for small device->host scalars
   DevBuf d_chunks, d_cand_meta, d_st_row, d_surv_count, d_seg_gates, d_blkrec, d_seg_vp, d_seg_has_vp;
+  DevBuf d_needed;           // image indices the uploaded job references (own images and neighbours)
+  int n_needed = 0;
+  long long max_needed_segs = 0;
   DevBuf d_blk_chunk_off;    // exhaustive mode: per block, 64-line chunks of the image's earlier blocks
   int max_chunks = 1;        // exhaustive mode: most 64-line chunks of any neighbour
   DevBuf d_base_bl;          // exclusive prefix of cnt_bl over the neighbour blocks of a node

@@ -18,7 +18,8 @@ struct SceneChunk {  // images [img_begin, next chunk's img_begin) live in these
   int img_begin, pad_;
 };
 void launch_build_scene_chunked(hipStream_t st, int n_img, long long n_segs, int n_chunks, const SceneChunk *ch,
-                                const long long *seg_off, double halfpix, Cam *cams, Seg *segs);
+                                const long long *seg_off, double halfpix, Cam *cams, Seg *segs,
+                                const int *img_list, int n_list, long long max_segs_per_img);
 
 void launch_build_cams(hipStream_t st, int n, const double *k, const double *q, const double *t, Cam *cams);
 void launch_build_segs(hipStream_t st, long long n_segs, int n_img, const long long *seg_off,

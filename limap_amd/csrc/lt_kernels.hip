@@ -95,6 +95,29 @@ __global__ void k_build_segs_chunked(long long n_segs, int n_img, int n_chunks, 
   out[s] = r;
 }
 
+// Same per image of a list (grid.y = list entry): no search for the segment's image, and images the
+// buffered job does not reference (neither triangulated here nor a neighbour) can be left out -- with
+// image shards spread over several GPUs a rank needs ~1/N of the gathered scene.
+__global__ void k_build_segs_listed(const int *__restrict__ img_list, int n_chunks, const SceneChunk *__restrict__ ch,
+                                    const long long *__restrict__ seg_off, double halfpix,
+                                    const Cam *__restrict__ cams, Seg *__restrict__ out) {
+  const int img = img_list[blockIdx.y];
+  const long long s0 = seg_off[img], M = seg_off[img + 1] - s0;
+  const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= M) return;
+  int c = 0;
+  while (c + 1 < n_chunks && img >= ch[c + 1].img_begin) ++c;
+  const long long s = s0 + l;
+  const double *p = ch[c].s + 4 * (s - ch[c].seg_begin);
+  double x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+  if (halfpix != 0.0) {
+    x1 = x1 + halfpix; y1 = y1 + halfpix; x2 = x2 + halfpix; y2 = y2 + halfpix;
+  }
+  Seg r;
+  seg_build(cams[img], x1, y1, x2, y2, &r);
+  out[s] = r;
+}
+
 // also clears the run's two device scalars (error flag, pair statistic): one launch instead of three
 __global__ void k_build_pairs(int n_blk, const int *__restrict__ blk_img,
                               const int *__restrict__ blk_nb, const Cam *__restrict__ cams,
@@ -383,13 +406,24 @@ void launch_build_segs(hipStream_t st, long long n_segs, int n_img, const long l
     hipLaunchKernelGGL(k_build_segs, dim3(nblk(n_segs, 256)), dim3(256), 0, st, n_segs, n_img, seg_off, segs,
                        halfpix, cams, out);
 }
+// img_list (n_list entries, at most 65535 per launch) restricts the segment records to those images;
+// nullptr = all images
 void launch_build_scene_chunked(hipStream_t st, int n_img, long long n_segs, int n_chunks, const SceneChunk *ch,
-                                const long long *seg_off, double halfpix, Cam *cams, Seg *segs) {
+                                const long long *seg_off, double halfpix, Cam *cams, Seg *segs,
+                                const int *img_list, int n_list, long long max_segs_per_img) {
   if (n_img > 0)
     hipLaunchKernelGGL(k_build_cams_chunked, dim3(nblk(n_img, 128)), dim3(128), 0, st, n_img, n_chunks, ch, cams);
-  if (n_segs > 0)
+  if (n_segs <= 0) return;
+  if (img_list && n_list > 0 && max_segs_per_img > 0) {
+    for (int y0 = 0; y0 < n_list; y0 += 65535) {
+      const int ny = std::min(65535, n_list - y0);
+      hipLaunchKernelGGL(k_build_segs_listed, dim3(nblk(max_segs_per_img, 256), ny), dim3(256), 0, st, img_list + y0,
+                         n_chunks, ch, seg_off, halfpix, cams, segs);
+    }
+  } else {
     hipLaunchKernelGGL(k_build_segs_chunked, dim3(nblk(n_segs, 256)), dim3(256), 0, st, n_segs, n_img, n_chunks, ch,
                        seg_off, halfpix, cams, segs);
+  }
 }
 void launch_build_pairs(hipStream_t st, int n_blk, const int *blk_img, const int *blk_nb, const Cam *cams,
                         PairRec *out, int *err_flag, unsigned long long *pair_counter) {

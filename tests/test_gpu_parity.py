@@ -116,6 +116,43 @@ def test_device_resident_scene_and_chunked_refresh(gpu_lib, oracle):
     assert np.array_equal(got["line"], ref["line"])
 
 
+def test_refresh_rebuilds_only_referenced_images(gpu_lib, oracle):
+    """A rank of a multi-GPU job triangulates a shard: while its job is uploaded, lt_refresh_scene_chunks
+    rebuilds the segment records of the images that job references only (here: scene data changes under a
+    context that triangulates 4 of 12 images -- the per-step path of bench.py --gpus N)."""
+    import torch
+    from limap_amd import _capi
+    from helpers import run_oracle
+    sc = small_scene(seed=8, n_views=12, n_segs=60, n_neighbors=3)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    mine = [int(i) for i in sc.img_ids[4:8]]
+    O = run_oracle(oracle, sc, cfg, images=mine)
+    dev = torch.device("cuda", 0)
+    ctx = _capi.Context(cfg_dict=cfg, device=0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.set_ranges(*sc.ranges)
+    # Init from garbage-free but WRONG data (everything shifted), the true scene arrives through the chunks
+    wrong = sc.segs + 3.0
+    dk = torch.from_numpy(sc.kvec).to(dev); dq = torch.from_numpy(sc.qvec).to(dev)
+    dt = torch.from_numpy(sc.tvec).to(dev); ds = torch.from_numpy(wrong).to(dev)
+    ctx.init_device(sc.img_ids, dk.data_ptr(), dq.data_ptr(), dt.data_ptr(), sc.seg_off, ds.data_ptr())
+    buf = torch.from_numpy(np.concatenate([sc.kvec.ravel(), sc.qvec.ravel(), sc.tvec.ravel(), sc.segs.ravel()])).to(dev)
+    n = sc.n_images
+    p = buf.data_ptr()
+    ctx.set_scene_chunks([0], [p], [p + 32 * n], [p + 64 * n], [p + 88 * n])
+    for i in mine:
+        m = sc.matches_of(i)
+        nb = list(m.keys())
+        off = np.zeros(len(nb) + 1, np.int64); off[1:] = np.cumsum([len(m[k]) for k in nb])
+        ctx.triangulate_image(i, nb, off, np.concatenate([m[k] for k in nb], 0))
+    ctx.upload()
+    ctx.refresh_scene_chunks()          # job uploaded: only its images and their neighbours are rebuilt
+    ctx.run_device()
+    ctx.download()
+    compare_candidates(ctx.get_all_tris(), O.get_all_tris())
+    compare_best(ctx.get_best(), O.get_best())
+
+
 def test_incremental_batches(gpu_lib, oracle):
     """Images triangulated in several batches with result reads in between (streamed use, config 5):
     every flush merges into the persistent per-node results; the final tracks equal a one-batch run."""
