@@ -227,6 +227,15 @@ void lt_release_cached_memory(void);
  * one query per call (convenience / parity checks; the batch path is the API above).
  * cam = kvec[4] | qvec[4] | tvec[3]; seg = x1,y1,x2,y2; line10 as above. */
 int lt_fn_get_normal_direction(lt_ctx *ctx, const double seg[4], const double cam[11], double out[3]);
+/* get_direction_from_VP(vp, view): functions.cc:37-42 */
+int lt_fn_get_direction_from_vp(lt_ctx *ctx, const double vp[3], const double cam[11], double out[3]);
+/* triangulate_point(p1, view1, p2, view2) -> (point, ok): functions.cc:100-117 */
+int lt_fn_triangulate_point(lt_ctx *ctx, const double p1[2], const double cam1[11], const double p2[2],
+                            const double cam2[11], double out[3], int *ok);
+/* triangulate_line_with_direction(l1, view1, l2, view2, direction): functions.cc:385-442 */
+int lt_fn_triangulate_line_with_direction(lt_ctx *ctx, const double seg1[4], const double cam1[11],
+                                          const double seg2[4], const double cam2[11], const double direction[3],
+                                          double out_line10[10]);
 int lt_fn_compute_fundamental_matrix(lt_ctx *ctx, const double cam1[11], const double cam2[11],
                                      double out[9]);
 int lt_fn_compute_epipolar_IoU(lt_ctx *ctx, const double seg1[4], const double cam1[11],

@@ -26,7 +26,8 @@ EXPORTED_SYMBOLS = [
     "lt_ts_num_tracks", "lt_ts_num_members", "lt_ts_get", "lt_ts_filter_by_reprojection",
     "lt_ts_filter_by_sensitivity", "lt_ts_filter_by_overlap", "lt_ts_remerge_once", "lt_get_stats", "lt_get_timers",
     "lt_release_cached_memory",
-    "lt_fn_get_normal_direction", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
+    "lt_fn_get_normal_direction", "lt_fn_get_direction_from_vp", "lt_fn_triangulate_point",
+    "lt_fn_triangulate_line_with_direction", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
     "lt_fn_triangulate_line",
 ]
 
@@ -163,6 +164,9 @@ def load_library():
     L.lt_get_stats.argtypes = [vp, i64p]
     L.lt_get_timers.argtypes = [vp, dp]
     L.lt_fn_get_normal_direction.argtypes = [vp, dp, dp, dp]
+    L.lt_fn_get_direction_from_vp.argtypes = [vp, dp, dp, dp]
+    L.lt_fn_triangulate_point.argtypes = [vp, dp, dp, dp, dp, dp, C.POINTER(C.c_int)]
+    L.lt_fn_triangulate_line_with_direction.argtypes = [vp, dp, dp, dp, dp, dp, dp]
     L.lt_fn_compute_fundamental_matrix.argtypes = [vp, dp, dp, dp]
     L.lt_fn_compute_epipolar_IoU.argtypes = [vp, dp, dp, dp, dp, dp]
     L.lt_fn_triangulate_line.argtypes = [vp, dp, dp, dp, dp, C.c_int, dp]
@@ -424,6 +428,28 @@ class Context:
         out = np.zeros(3)
         self.chk(self.L.lt_fn_get_normal_direction(self.h, ptr(f64(seg), C.c_double), ptr(f64(cam), C.c_double),
                                                    ptr(out, C.c_double)))
+        return out
+
+    def fn_direction_from_vp(self, vp, cam):
+        out = np.zeros(3)
+        self.chk(self.L.lt_fn_get_direction_from_vp(self.h, ptr(f64(vp), C.c_double), ptr(f64(cam), C.c_double),
+                                                    ptr(out, C.c_double)))
+        return out
+
+    def fn_triangulate_point(self, p1, cam1, p2, cam2):
+        out = np.zeros(3)
+        ok = C.c_int(0)
+        self.chk(self.L.lt_fn_triangulate_point(self.h, ptr(f64(p1), C.c_double), ptr(f64(cam1), C.c_double),
+                                                ptr(f64(p2), C.c_double), ptr(f64(cam2), C.c_double),
+                                                ptr(out, C.c_double), C.byref(ok)))
+        return out, bool(ok.value)
+
+    def fn_triangulate_line_with_direction(self, seg1, cam1, seg2, cam2, direction):
+        out = np.zeros(10)
+        self.chk(self.L.lt_fn_triangulate_line_with_direction(self.h, ptr(f64(seg1), C.c_double),
+                                                              ptr(f64(cam1), C.c_double), ptr(f64(seg2), C.c_double),
+                                                              ptr(f64(cam2), C.c_double), ptr(f64(direction), C.c_double),
+                                                              ptr(out, C.c_double)))
         return out
 
     def fn_fundamental_matrix(self, cam1, cam2):

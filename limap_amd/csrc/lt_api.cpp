@@ -1796,28 +1796,40 @@ int lt_get_timers(lt_ctx *ctx, double out[24]) {
 
 // ---- free functions ----
 static int fn_query(lt_ctx *ctx, const double *seg1, const double *cam1, const double *seg2, const double *cam2,
-                    int by_endpoints, double out32[32]) {
+                    int by_endpoints, double out40[40], const double *v3 = nullptr, const double *p1 = nullptr,
+                    const double *p2 = nullptr) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  double in[30];
+  double in[37] = {0};
   std::memcpy(in, seg1, 32); std::memcpy(in + 4, cam1, 88); std::memcpy(in + 15, seg2, 32); std::memcpy(in + 19, cam2, 88);
+  if (v3) std::memcpy(in + 30, v3, 24);
+  if (p1) std::memcpy(in + 33, p1, 16);
+  if (p2) std::memcpy(in + 35, p2, 16);
   DevBuf din, dout;
-  ENSURE(ctx, din, sizeof(in)); ENSURE(ctx, dout, 32 * 8);
+  ENSURE(ctx, din, sizeof(in)); ENSURE(ctx, dout, 40 * 8);
   HIPCHK(ctx, hipMemcpyAsync(din.p, in, sizeof(in), hipMemcpyHostToDevice, ctx->stream));
   launch_fn_query(ctx->stream, din.as<double>(), by_endpoints, dout.as<double>());
-  HIPCHK(ctx, hipMemcpyAsync(out32, dout.p, 32 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out40, dout.p, 40 * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   din.release(); dout.release();
   return LT_OK;
 }
+
 int lt_fn_get_normal_direction(lt_ctx *ctx, const double seg[4], const double cam[11], double out[3]) {
-  double o[32];
+  double o[40];
   int rc = fn_query(ctx, seg, cam, seg, cam, 0, o);
   if (rc) return rc;
   std::memcpy(out, o, 24);
   return LT_OK;
 }
+int lt_fn_get_direction_from_vp(lt_ctx *ctx, const double vp[3], const double cam[11], double out[3]) {
+  double o[40], seg[4] = {0, 0, 1, 1};
+  int rc = fn_query(ctx, seg, cam, seg, cam, 0, o, vp);
+  if (rc) return rc;
+  std::memcpy(out, o + 23, 24);
+  return LT_OK;
+}
 int lt_fn_compute_fundamental_matrix(lt_ctx *ctx, const double cam1[11], const double cam2[11], double out[9]) {
-  double o[32], seg[4] = {0, 0, 1, 1};
+  double o[40], seg[4] = {0, 0, 1, 1};
   int rc = fn_query(ctx, seg, cam1, seg, cam2, 0, o);
   if (rc) return rc;
   std::memcpy(out, o + 3, 72);
@@ -1825,18 +1837,36 @@ int lt_fn_compute_fundamental_matrix(lt_ctx *ctx, const double cam1[11], const d
 }
 int lt_fn_compute_epipolar_IoU(lt_ctx *ctx, const double seg1[4], const double cam1[11], const double seg2[4],
                                const double cam2[11], double *out) {
-  double o[32];
+  double o[40];
   int rc = fn_query(ctx, seg1, cam1, seg2, cam2, 0, o);
   if (rc) return rc;
   *out = o[12];
   return LT_OK;
 }
+int lt_fn_triangulate_point(lt_ctx *ctx, const double p1[2], const double cam1[11], const double p2[2],
+                            const double cam2[11], double out[3], int *ok) {
+  double o[40], seg[4] = {0, 0, 1, 1};
+  int rc = fn_query(ctx, seg, cam1, seg, cam2, 0, o, nullptr, p1, p2);
+  if (rc) return rc;
+  std::memcpy(out, o + 26, 24);
+  if (ok) *ok = o[29] != 0.0;
+  return LT_OK;
+}
 int lt_fn_triangulate_line(lt_ctx *ctx, const double seg1[4], const double cam1[11], const double seg2[4],
                            const double cam2[11], int by_endpoints, double out_line10[10]) {
-  double o[32];
+  double o[40];
   int rc = fn_query(ctx, seg1, cam1, seg2, cam2, by_endpoints, o);
   if (rc) return rc;
   std::memcpy(out_line10, o + 13, 80);
+  return LT_OK;
+}
+int lt_fn_triangulate_line_with_direction(lt_ctx *ctx, const double seg1[4], const double cam1[11],
+                                          const double seg2[4], const double cam2[11], const double direction[3],
+                                          double out_line10[10]) {
+  double o[40];
+  int rc = fn_query(ctx, seg1, cam1, seg2, cam2, 0, o, direction);
+  if (rc) return rc;
+  std::memcpy(out_line10, o + 30, 80);
   return LT_OK;
 }
 

@@ -302,10 +302,8 @@ static __device__ __forceinline__ bool gen_finish(const GenCfg &cfg, const Cam &
 // (functions.cc:385-442) with the direction of a vanishing point mapped into the world through VIEW 1
 // (getDirectionFromVP, functions.cc:37-42 -- the reference uses view1 for both lines' VPs), then
 // uncertainty and ranges like every other proposal.  No sensitivity gate on this branch.
-static __device__ __forceinline__ bool vp_candidate(const GenCfg &cfg, const Cam &c1, const Cam &c2, const Seg &s1,
-                                                    const Seg &s2, const double *Bv, const double *vp,
-                                                    GenOut *out) {
-  const d3 direction = unit(mv(c1.Minv, mk3(vp[0], vp[1], vp[2])));
+static __device__ __forceinline__ bool dir_candidate(const GenCfg &cfg, const Cam &c1, const Cam &c2, const Seg &s1,
+                                                     const Seg &s2, const double *Bv, d3 direction, GenOut *out) {
   const d3 n1 = mk3(s1.n[0], s1.n[1], s1.n[2]);
   const double nd = dot(n1, direction);
   d3 direc = sub(direction, scale(n1, nd));
@@ -357,6 +355,13 @@ static __device__ __forceinline__ bool vp_candidate(const GenCfg &cfg, const Cam
   out->c.seg[0] = s2.x1; out->c.seg[1] = s2.y1; out->c.seg[2] = s2.x2; out->c.seg[3] = s2.y2;
   out->l.dir[0] = dir3.x; out->l.dir[1] = dir3.y; out->l.dir[2] = dir3.z;
   return true;
+}
+
+static __device__ __forceinline__ bool vp_candidate(const GenCfg &cfg, const Cam &c1, const Cam &c2, const Seg &s1,
+                                                    const Seg &s2, const double *Bv, const double *vp,
+                                                    GenOut *out) {
+  // getDirectionFromVP(vp, view1), functions.cc:37-42
+  return dir_candidate(cfg, c1, c2, s1, s2, Bv, unit(mv(c1.Minv, mk3(vp[0], vp[1], vp[2]))), out);
 }
 
 static __device__ __forceinline__ bool gen_one(const GenCfg &cfg, const Cam &c1, const Cam &c2,

@@ -566,9 +566,11 @@ void launch_track_connect(hipStream_t st, int T, const double *line7, const unsi
 }
 
 // ---------------------------------------------------------------------------------------------
-// free-function queries (limap.triangulation.get_normal_direction / compute_fundamental_matrix /
-// compute_epipolar_IoU / triangulate_line[_by_endpoints], bindings.cc:22-31): one thread.
-// in30 = seg1[4] cam1[11] seg2[4] cam2[11]; out32 = n(seg1)[3] F[9] IoU line10[10]
+// free-function queries (limap.triangulation.get_normal_direction / get_direction_from_VP /
+// compute_fundamental_matrix / compute_epipolar_IoU / triangulate_point / triangulate_line[_by_endpoints] /
+// triangulate_line_with_direction, bindings.cc:22-31): one thread.
+// in37 = seg1[4] cam1[11] seg2[4] cam2[11] v[3] p1[2] p2[2]
+// out40 = n(seg1)[3] F[9] IoU line10[10] | dir_from_vp(v, cam1)[3] | point[3] ok | line10 with direction v [10]
 // ---------------------------------------------------------------------------------------------
 __global__ void k_fn_query(const double *__restrict__ in, int by_endpoints, double *__restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -604,6 +606,36 @@ __global__ void k_fn_query(const double *__restrict__ in, int by_endpoints, doub
   } else {  // failure sentinel Line3d((0,0,0),(1,1,1),-1)  (functions.cc:300)
     l[0] = l[1] = l[2] = 0.0; l[3] = l[4] = l[5] = 1.0;
     l[6] = l[7] = -1.0; l[8] = -1.0; l[9] = -1.0;
+  }
+  // get_direction_from_VP(v, view1)
+  const d3 dvp = unit(mv(c1.Minv, mk3(in[30], in[31], in[32])));
+  out[23] = dvp.x; out[24] = dvp.y; out[25] = dvp.z;
+  // triangulate_point(p1, view1, p2, view2): the product's tri_point without the cheirality part of the
+  // line functions is not exposed separately; the reference's free function returns (point, ok) with the
+  // same cheirality test (functions.cc:100-117)
+  {
+    d3 r1 = cam_ray(c1, d2{in[33], in[34]}), r2 = cam_ray(c2, d2{in[35], in[36]});
+    d3 pt = mk3(0, 0, 0);
+    bool okp = tri_point(c1, r1, c2, r2, &pt);
+    out[26] = pt.x; out[27] = pt.y; out[28] = pt.z; out[29] = okp ? 1.0 : 0.0;
+  }
+  // triangulate_line_with_direction(l1, view1, l2, view2, v): the proposal without uncertainty / ranges
+  {
+    GenCfg cfg0;
+    cfg0.var2d = 0.0; cfg0.use_ranges = 0;
+    GenOut o;
+    // vp_candidate maps a VP through view 1 first; here v already IS the world direction: feed K R v,
+    // which view 1 maps back to unit(v) up to rounding -- not bit-faithful, so evaluate directly instead
+    const d3 direction = mk3(in[30], in[31], in[32]);
+    bool okd = dir_candidate(cfg0, c1, c2, s1, s2, pr.B, direction, &o);
+    double *m = out + 30;
+    if (okd) {
+      m[0] = o.c.s[0]; m[1] = o.c.s[1]; m[2] = o.c.s[2]; m[3] = o.c.e[0]; m[4] = o.c.e[1]; m[5] = o.c.e[2];
+      m[6] = o.c.depth[0]; m[7] = o.c.depth[1]; m[8] = -1.0; m[9] = 1.0;
+    } else {
+      m[0] = m[1] = m[2] = 0.0; m[3] = m[4] = m[5] = 1.0;
+      m[6] = m[7] = -1.0; m[8] = -1.0; m[9] = -1.0;
+    }
   }
 }
 

@@ -360,6 +360,26 @@ def get_normal_direction(l2d, view):
     return _fctx().fn_normal_direction(_segs_array([l2d])[0], _cam11(view))
 
 
+def get_direction_from_VP(vp, view):
+    return _fctx().fn_direction_from_vp(np.asarray(vp, float).reshape(3), _cam11(view))
+
+
+def triangulate_point(p1, view1, p2, view2):
+    """-> (point (3,), ok) like the reference's std::pair<V3D, bool> (functions.cc:100-117)."""
+    return _fctx().fn_triangulate_point(np.asarray(p1, float).reshape(2), _cam11(view1),
+                                        np.asarray(p2, float).reshape(2), _cam11(view2))
+
+
+def triangulate_line_with_direction(l1, view1, l2, view2, direction):
+    return _make_line3d(_fctx().fn_triangulate_line_with_direction(
+        _segs_array([l1])[0], _cam11(view1), _segs_array([l2])[0], _cam11(view2), np.asarray(direction, float).reshape(3)))
+
+
+def triangulate_line_with_one_point(l1, view1, l2, view2, point):
+    raise NotImplementedError("the one-point quartic proposal (solvers/triangulation) is not implemented in the "
+                              "MI355X backend")
+
+
 def compute_fundamental_matrix(view1, view2):
     return _fctx().fn_fundamental_matrix(_cam11(view1), _cam11(view2))
 

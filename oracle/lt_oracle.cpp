@@ -1842,6 +1842,17 @@ int ora_triangulate_point(const double p1[2], const double cam1[11], const doubl
   out[0] = r.first.x; out[1] = r.first.y; out[2] = r.first.z;
   return r.second ? 1 : 0;
 }
+void ora_get_direction_from_vp(const double vp[3], const double cam[11], double out[3]) {
+  ora::V3 d = ora::getDirectionFromVP(ora::V3{vp[0], vp[1], vp[2]}, ora::view_from_cam11(cam));
+  out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+void ora_triangulate_line_with_direction(const double seg1[4], const double cam1[11], const double seg2[4],
+                                         const double cam2[11], const double dir[3], double out10[10]) {
+  ora::line_to10(ora::triangulate_line_with_direction(ora::seg_to_line(seg1), ora::view_from_cam11(cam1),
+                                                      ora::seg_to_line(seg2), ora::view_from_cam11(cam2),
+                                                      ora::V3{dir[0], dir[1], dir[2]}),
+                 out10);
+}
 void ora_triangulate_line(const double seg1[4], const double cam1[11], const double seg2[4],
                           const double cam2[11], double out10[10]) {
   ora::line_to10(ora::triangulate_line(ora::seg_to_line(seg1), ora::view_from_cam11(cam1),

@@ -154,6 +154,10 @@ void ora_triangulate_line_by_endpoints(const double seg1[4], const double cam1[1
 /* camera helpers */
 void ora_cam_project(const double cam[11], const double p[3], double out[2]);
 void ora_cam_ray_direction(const double cam[11], const double p2d[2], double out[3]);
+void ora_get_direction_from_vp(const double vp[3], const double cam[11], double out[3]);  /* functions.cc:37-42 */
+void ora_triangulate_line_with_direction(const double seg1[4], const double cam1[11], const double seg2[4],
+                                         const double cam2[11], const double dir[3],
+                                         double out10[10]);                              /* functions.cc:385-442 */
 double ora_cam_projdepth(const double cam[11], const double p[3]);
 void ora_cam_R(const double cam[11], double out[9]);
 void ora_cam_center(const double cam[11], double out[3]);

@@ -322,6 +322,17 @@ def triangulate_point(p1, cam1, p2, cam2):
     return out, bool(ok)
 
 
+def get_direction_from_vp(vp, cam):
+    out = np.zeros(3); lib().ora_get_direction_from_vp(_d(_f64(vp)), _d(_f64(cam)), _d(out)); return out
+
+
+def triangulate_line_with_direction(seg1, cam1, seg2, cam2, direction):
+    out = np.zeros(10)
+    lib().ora_triangulate_line_with_direction(_d(_f64(seg1)), _d(_f64(cam1)), _d(_f64(seg2)), _d(_f64(cam2)),
+                                              _d(_f64(direction)), _d(out))
+    return out
+
+
 def triangulate_line(seg1, cam1, seg2, cam2):
     out = np.zeros(10); lib().ora_triangulate_line(_d(_f64(seg1)), _d(_f64(cam1)), _d(_f64(seg2)), _d(_f64(cam2)), _d(out))
     return out

@@ -129,6 +129,24 @@ def test_free_functions_match_oracle(gpu_lib, oracle):
         l, o = fn_g(s1, c1, s2, c2), fn_o(s1, c1, s2, c2)
         assert np.array_equal(np.concatenate([l.start, l.end]), o[:6]) and np.array_equal(l.depths, o[6:8])
         assert l.score == o[9]
+    # VP / direction / point functions
+    K = np.array([[c1[0], 0, c1[2]], [0, c1[1], c1[3]], [0, 0, 1.0]])
+    R = syn.quat_to_rot(c1[4:8])
+    gt = sc.gt_lines[common[0]]
+    d = (gt[3:] - gt[:3]) / np.linalg.norm(gt[3:] - gt[:3])
+    vp = K @ R @ d
+    assert np.array_equal(tri.get_direction_from_VP(vp, c1), oracle.get_direction_from_vp(vp, c1))
+    for direction in (d, oracle.get_direction_from_vp(vp, c1), np.array([0.3, -0.2, 0.93])):
+        l, o = tri.triangulate_line_with_direction(s1, c1, s2, c2, direction), \
+            oracle.triangulate_line_with_direction(s1, c1, s2, c2, direction)
+        assert np.array_equal(np.concatenate([l.start, l.end]), o[:6]) and np.array_equal(l.depths, o[6:8])
+        assert l.score == o[9]
+    (pg, okg), (po, oko) = tri.triangulate_point(s1[:2], c1, s2[:2], c2), oracle.triangulate_point(s1[:2], c1, s2[:2], c2)
+    assert okg == oko and (not oko or np.array_equal(pg, po))
+    (pg, okg), (po, oko) = tri.triangulate_point(s1[2:], c1, s2[2:], c2), oracle.triangulate_point(s1[2:], c1, s2[2:], c2)
+    assert okg == oko and (not oko or np.array_equal(pg, po))
+    with pytest.raises(NotImplementedError):
+        tri.triangulate_line_with_one_point(s1, c1, s2, c2, gt[:3])
     E = tri.compute_essential_matrix(c1, c2)
     np.testing.assert_allclose(E / np.linalg.norm(E), oracle.compute_essential_matrix(c1, c2) /
                                np.linalg.norm(oracle.compute_essential_matrix(c1, c2)), atol=1e-9)
