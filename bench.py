@@ -249,6 +249,7 @@ def main():
         matches = {int(i): scene.matches_of(int(i), args.topk) for i in scene.img_ids} if args.mode == "matched" else None
         segs_list = [scene.segs_of(j) for j in range(scene.n_images)]
         e2e = []
+        e2e_all_parts = []
         import gc
         for rep in range(3):
             torch.cuda.synchronize(dev)
@@ -270,6 +271,7 @@ def main():
             gc.enable()
             e2e_parts = {"ctor_init": 1e3 * (t1 - t0), "buffer": 1e3 * (t2 - t1), "compute_tracks": 1e3 * (e2e[-1] - (t2 - t0)),
                          "buffer_native": T.timers().get("buffer", 0.0)}
+            e2e_all_parts.append({k: round(v, 2) for k, v in e2e_parts.items()})
             tm = T.timers()
             if rep == 2:  # the steps that follow in line_triangulation(): filters + remerge (cfg defaults)
                 from limap_amd import merging
@@ -283,6 +285,7 @@ def main():
         out["e2e_wall_ms"] = 1e3 * float(np.median(e2e))
         out["e2e_breakdown_ms"] = dict(e2e_parts, **{k: tm[k] for k in ("upload", "run", "download", "tail")})
         out["e2e_reps_ms"] = [1e3 * x for x in e2e]
+        out["e2e_reps_parts"] = e2e_all_parts
         out["postprocess"] = {"ms": post_ms, "tracks_after": post_tracks,
                               "steps": "filter_by_reprojection, remerge (to fixed point), filter_by_reprojection, "
                                        "filter_by_sensitivity, filter_by_overlap (cfgs/triangulation/default.yaml:102-115)"}
