@@ -287,6 +287,52 @@ def make_vp_results(scene, seed=0, drop=0.15, wrong=0.05):
     return out
 
 
+def make_bipartites(scene, seed=0, pts_per_line=3, noise_px=0.3, noise_3d=0.002):
+    """Synthetic point-line bipartites (the content of limap.structures.PL_Bipartite2d per image) and SfM
+    points: every GT segment carries `pts_per_line` 3D points (id = pts_per_line * g + k, slightly off the
+    line); an image's segment that observes GT segment g is connected to the projections of g's points
+    that fall in front of the camera and inside the image (pixel noise `noise_px`).
+    Returns (bipartites: dict img_id -> dict(point_ids, xy, point3D_ids, line_points), sfm_points: dict)."""
+    rng0 = np.random.default_rng([scene.seed, seed, 909])
+    G = len(scene.gt_lines)
+    ts = (np.arange(pts_per_line) + 0.5) / pts_per_line
+    P3 = {}
+    for g in range(G):
+        a, b = scene.gt_lines[g, :3], scene.gt_lines[g, 3:]
+        for k, t in enumerate(ts):
+            P3[pts_per_line * g + k] = a + t * (b - a) + rng0.normal(0, noise_3d, 3)
+    bpts = {}
+    for n, img_id in enumerate(scene.img_ids):
+        rng = np.random.default_rng([scene.seed, seed, 910, int(img_id)])
+        R = quat_to_rot(scene.qvec[n])
+        fx, fy, cx, cy = scene.kvec[n]
+        gids = scene.gt_ids[scene.seg_off[n]:scene.seg_off[n + 1]]
+        ids, xy, p3d, line_points = [], [], [], []
+        cache = {}
+        for g in gids:
+            mine = []
+            if g >= 0:
+                for k in range(pts_per_line):
+                    pid3 = pts_per_line * int(g) + k
+                    if pid3 not in cache:
+                        Xc = R @ P3[pid3] + scene.tvec[n]
+                        if Xc[2] <= 0.2:
+                            cache[pid3] = -1
+                        else:
+                            u = np.array([fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy]) + rng.normal(0, noise_px, 2)
+                            if 0 <= u[0] <= W_IMG and 0 <= u[1] <= H_IMG:
+                                cache[pid3] = len(ids)
+                                ids.append(len(ids)); xy.append(u); p3d.append(pid3)
+                            else:
+                                cache[pid3] = -1
+                    if cache[pid3] >= 0:
+                        mine.append(cache[pid3])
+            line_points.append(mine)
+        bpts[int(img_id)] = dict(point_ids=np.array(ids, np.int32), xy=np.array(xy, float).reshape(-1, 2),
+                                 point3D_ids=np.array(p3d, np.int32), line_points=line_points)
+    return bpts, {int(k): v for k, v in P3.items()}
+
+
 def gen_matches(scene, img_id, topk=10):
     """matches_{img_id}: dict ng_img_id -> (K,2) int32, rows grouped by line id, <= topk rows per
     line: the true GT correspondence (when the GT segment is visible in the neighbour) at a random

@@ -629,6 +629,34 @@ static V3 getDirectionFromVP(const V3 &vp, const CameraView &view) {  // functio
   return normalized(direc);
 }
 
+// base/infinite_line.h: Pluecker line (direction d, moment m = p x d)
+struct InfiniteLine3d {
+  V3 d, m;
+  InfiniteLine3d(const V3 &p, const V3 &direc) : d(direc), m(cross(p, direc)) {}  // infinite_line.cc:55-59
+  // infinite_line.cc:151-163: the point of THIS line closest to `line`
+  V3 project_from_infinite_line(const InfiniteLine3d &line) const {
+    V3 l1 = d, m1 = m, l2 = line.d, m2 = line.m;
+    V3 cr = cross(l1, l2);
+    V3 p = cross(m1, cross(l2, cr)) * (-1.0) + l1 * dot(m2, cr);
+    p = p / sqnorm(cr);
+    return p;
+  }
+  V3 project_to_infinite_line(const InfiniteLine3d &line) const { return line.project_from_infinite_line(*this); }
+};
+
+// unproject endpoints with known infinite line -- functions.cc:306-321
+static Line3d triangulate_line_with_infinite_line(const Line2d &l1, const CameraView &view1,
+                                                  const InfiniteLine3d &inf_line) {
+  InfiniteLine3d ray1_start(view1.pose.center(), view1.ray_direction(l1.start));
+  V3 pstart = inf_line.project_to_infinite_line(ray1_start);
+  double z_start = view1.pose.projdepth(pstart);
+  InfiniteLine3d ray1_end(view1.pose.center(), view1.ray_direction(l1.end));
+  V3 pend = inf_line.project_to_infinite_line(ray1_end);
+  double z_end = view1.pose.projdepth(pend);
+  if (z_start < EPS || z_end < EPS) return kSentinel();
+  return Line3d(pstart, pend, 1.0, z_start, z_end);
+}
+
 // Triangulation with known direction, asymmetric perspective to (view1, l1) -- functions.cc:385-442
 static Line3d triangulate_line_with_direction(const Line2d &l1, const CameraView &view1, const Line2d &l2,
                                               const CameraView &view2, const V3 &direction) {
@@ -1078,6 +1106,27 @@ struct Triangulator {
   };
   std::map<int, VPResult> vpresults_;
 
+  // structures::PL_Bipartite2d (structures/pl_bipartite_base.h:79-93): points (id -> xy, point3D_id) and
+  // per line the ids of its neighbouring points in ascending id order (std::set); SetBipartites2d /
+  // SetSfMPoints, base_line_triangulator.h:71-77
+  struct Point2d {
+    V2 p;
+    int point3D_id;
+  };
+  struct Bipartite2d {
+    std::map<int, Point2d> points;
+    std::map<int, std::set<int>> nl2p;
+    std::vector<int> neighbor_points(int line_id) const {
+      auto it = nl2p.find(line_id);
+      if (it == nl2p.end()) return {};
+      return std::vector<int>(it->second.begin(), it->second.end());
+    }
+    Point2d point(int point_id) const { return points.at(point_id); }
+  };
+  bool use_pointsfm_ = false;
+  std::map<int, Bipartite2d> all_bpt2ds_;
+  std::map<int, V3> sfm_points_;
+
   void Init() {  // base_line_triangulator.cc:45-63 + global_line_triangulator.cc:31-57
     if (cfg.add_halfpix) {  // offsetHalfPixel, base_line_triangulator.cc:33-43
       for (int img_id : img_ids)
@@ -1155,8 +1204,47 @@ void Triangulator::triangulateOneNode(int img_id, int line_id) {  // base_line_t
         results[conn_id].push_back(t);
       }
     };
-    // Step 1 (point-guided proposals) needs SetBipartites2d: optional branch, out of scope
-    // (use_pointsfm is off in cfgs/triangulation/default.yaml:116).
+    // Step 1.1: many points -> fit a line through the shared 3D points (lines 183-236).  Step 1.2 (the
+    // one-point quartic proposal, solvers/triangulation) is NOT restated: it must be disabled.
+    if (use_pointsfm_ && (!cfg.disable_many_points_triangulation || !cfg.disable_one_point_triangulation)) {
+      if (!cfg.disable_one_point_triangulation)
+        throw std::runtime_error("one-point triangulation is not restated in the oracle: set disable_one_point_triangulation");
+      std::map<int, Point2d> points1;
+      std::set<int> set1;
+      std::map<int, std::pair<V2, V2>> points_info;
+      for (int point_id : all_bpt2ds_.at(img_id).neighbor_points(line_id)) {
+        Point2d p = all_bpt2ds_.at(img_id).point(point_id);
+        set1.insert(p.point3D_id);
+        points1.insert({p.point3D_id, p});
+      }
+      for (int point_id : all_bpt2ds_.at(ng_img_id).neighbor_points(ng_line_id)) {
+        Point2d p = all_bpt2ds_.at(ng_img_id).point(point_id);
+        if (set1.find(p.point3D_id) != set1.end()) {
+          V2 p1 = points1.at(p.point3D_id).p;
+          points_info.insert({p.point3D_id, {p1, p.p}});
+        }
+      }
+      std::vector<V3> points;
+      for (auto it = points_info.begin(); it != points_info.end(); ++it) {
+        if (sfm_points_.empty()) {
+          auto res = triangulate_point(it->second.first, view1, it->second.second, view2);
+          if (res.second) points.push_back(res.first);
+        } else {
+          points.push_back(sfm_points_.at(it->first));
+        }
+      }
+      if (!cfg.disable_many_points_triangulation && points.size() >= 2) {
+        V3 center{0.0, 0.0, 0.0};
+        for (size_t i = 0; i < points.size(); ++i) center = center + points[i];
+        center = center / double(points.size());
+        std::vector<V3> epoints(points.size());
+        for (size_t i = 0; i < points.size(); ++i) epoints[i] = points[i] - center;
+        // Eigen::JacobiSVD(epoints, ComputeThinV).matrixV().col(0).normalized(): stand-in, see principal_direction
+        V3 direc = normalized(principal_direction(epoints));
+        InfiniteLine3d inf_line(center, direc);
+        push(triangulate_line_with_infinite_line(l1, view1, inf_line));
+      }
+    }
 
     // Step 2: triangulation with VPs (lines 250-281); note that BOTH directions are mapped with view1
     if (cfg.use_vp && !cfg.disable_vp_triangulation) {
@@ -1599,6 +1687,32 @@ int ora_init_vp(ora_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *
       for (int64_t v = vp_off[i]; v < vp_off[i + 1]; ++v) r.vps.push_back(ora::V3{vps[3 * v], vps[3 * v + 1], vps[3 * v + 2]});
       t.vpresults_[img_ids[i]] = r;
     }
+  })
+}
+
+int ora_set_bipartites(ora_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *pt_off, const int32_t *pt_ids,
+                       const double *pt_xy, const int32_t *pt_p3d, const int64_t *line_off, const int64_t *lp_off,
+                       const int32_t *lp_ptids) {  // SetBipartites2d
+  ORA_TRY(ctx, {
+    auto &t = ctx->t;
+    t.all_bpt2ds_.clear();
+    for (int i = 0; i < n_img; ++i) {
+      ora::Triangulator::Bipartite2d b;
+      for (int64_t k = pt_off[i]; k < pt_off[i + 1]; ++k)
+        b.points[pt_ids[k]] = ora::Triangulator::Point2d{ora::V2{pt_xy[2 * k], pt_xy[2 * k + 1]}, pt_p3d[k]};
+      for (int64_t l = line_off[i]; l < line_off[i + 1]; ++l)
+        for (int64_t e = lp_off[l]; e < lp_off[l + 1]; ++e) b.nl2p[int(l - line_off[i])].insert(lp_ptids[e]);
+      t.all_bpt2ds_[img_ids[i]] = b;
+    }
+    t.use_pointsfm_ = true;
+  })
+}
+
+int ora_set_sfm_points(ora_ctx *ctx, int64_t n, const int32_t *ids, const double *xyz) {  // SetSfMPoints
+  ORA_TRY(ctx, {
+    auto &t = ctx->t;
+    t.sfm_points_.clear();
+    for (int64_t k = 0; k < n; ++k) t.sfm_points_[ids[k]] = ora::V3{xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2]};
   })
 }
 

@@ -83,6 +83,14 @@ int ora_init(ora_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec
 
 /* matches for neighbour k are rows m_off[k]..m_off[k+1] of m_pairs (line_id, ng_line_id).
  * Neighbours are processed in ascending nb id order like the reference's std::map. */
+/* SetBipartites2d (base_line_triangulator.h:71-76): per image its 2D points (id, xy, point3D_id; CSR pt_off)
+ * and per line (CSR line_off over images, lp_off over lines) the ids of the neighbouring points.
+ * SetSfMPoints (:77): point3D_id -> xyz.  Enable the many-points proposal (lines 183-236); the one-point
+ * proposal is not restated (disable_one_point_triangulation must be set). */
+int ora_set_bipartites(ora_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *pt_off, const int32_t *pt_ids,
+                       const double *pt_xy, const int32_t *pt_p3d, const int64_t *line_off, const int64_t *lp_off,
+                       const int32_t *lp_ptids);
+int ora_set_sfm_points(ora_ctx *ctx, int64_t n, const int32_t *ids, const double *xyz);
 /* InitVPResults (base_line_triangulator.h:47-49): per image the VP label of every line (-1 = none) and
  * the VP vectors (vplib/vpbase.h:18-47), CSR over the images of ora_init */
 int ora_init_vp(ora_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *label_off, const int32_t *labels,

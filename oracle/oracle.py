@@ -163,6 +163,30 @@ def cam11(kvec, qvec, tvec):
     return _f64(np.concatenate([np.asarray(kvec, float), np.asarray(qvec, float), np.asarray(tvec, float)]))
 
 
+def flatten_bipartites(bpts):
+    """dict img_id -> dict(point_ids, xy, point3D_ids, line_points) -> the flat CSR arrays of the C APIs."""
+    ids = sorted(int(k) for k in bpts)
+    pt_off, line_off, lp_off = [0], [0], [0]
+    pt_ids, pt_xy, pt_p3d, lp = [], [], [], []
+    for i in ids:
+        b = bpts[i]
+        pid = np.asarray(b["point_ids"], np.int64).reshape(-1)
+        pt_ids.append(pid); pt_xy.append(np.asarray(b["xy"], float).reshape(-1, 2))
+        pt_p3d.append(np.asarray(b["point3D_ids"], np.int64).reshape(-1))
+        pt_off.append(pt_off[-1] + len(pid))
+        for pts in b["line_points"]:
+            lp.append(np.asarray(pts, np.int64).reshape(-1))
+            lp_off.append(lp_off[-1] + len(lp[-1]))
+        line_off.append(line_off[-1] + len(b["line_points"]))
+
+    def cat(parts, dtype, shape_tail=()):
+        if parts and sum(len(x) for x in parts):
+            return np.ascontiguousarray(np.concatenate(parts, 0), dtype=dtype)
+        return np.zeros((1,) + shape_tail, dtype)
+    return dict(img_ids=_i32(ids), pt_off=_i64(pt_off), pt_ids=cat(pt_ids, np.int32), pt_xy=cat(pt_xy, np.float64, (2,)),
+                pt_p3d=cat(pt_p3d, np.int32), line_off=_i64(line_off), lp_off=_i64(lp_off), lp_ptids=cat(lp, np.int32))
+
+
 class OracleTriangulator:
     """CPU restatement of limap.triangulation.GlobalLineTriangulator on flat arrays."""
 
@@ -216,6 +240,26 @@ class OracleTriangulator:
             vps = np.zeros((1, 3))
         self._chk(self.L.ora_init_vp(self.ctx, len(ids), _p(_i32(ids), C.c_int32), _p(lab_off, C.c_int64),
                                      _p(labs, C.c_int32), _p(vp_off, C.c_int64), _p(vps, C.c_double)))
+
+    def SetBipartites2d(self, bpts):
+        """bpts: dict img_id -> dict(point_ids (Np,), xy (Np,2), point3D_ids (Np,), line_points: list over the
+        image's lines of lists of point ids) -- the content of structures.PL_Bipartite2d."""
+        flat = flatten_bipartites(bpts)
+        self._chk(self.L.ora_set_bipartites(self.ctx, len(flat["img_ids"]), _p(flat["img_ids"], C.c_int32),
+                                            _p(flat["pt_off"], C.c_int64), _p(flat["pt_ids"], C.c_int32),
+                                            _p(flat["pt_xy"], C.c_double), _p(flat["pt_p3d"], C.c_int32),
+                                            _p(flat["line_off"], C.c_int64), _p(flat["lp_off"], C.c_int64),
+                                            _p(flat["lp_ptids"], C.c_int32)))
+
+    def SetSfMPoints(self, points):
+        ids = _i32(sorted(int(k) for k in points))
+        xyz = _f64(np.array([points[int(k)] for k in ids], float).reshape(-1, 3)) if len(ids) else np.zeros((1, 3))
+        if len(ids) == 0:
+            ids = np.zeros(1, np.int32)
+            n = 0
+        else:
+            n = len(ids)
+        self._chk(self.L.ora_set_sfm_points(self.ctx, C.c_int64(n), _p(ids, C.c_int32), _p(xyz, C.c_double)))
 
     def TriangulateImage(self, img_id, matches):
         """matches: dict ng_img_id -> (K,2) int array."""

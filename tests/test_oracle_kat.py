@@ -308,3 +308,46 @@ def test_kat_vp_direction_triangulation(oracle):
         for k in range(expect):
             np.testing.assert_allclose(a["line"][k, :3], P, rtol=0, atol=1e-9)
             np.testing.assert_allclose(a["line"][k, 3:6], Q, rtol=0, atol=1e-9)
+
+
+def test_kat_many_points_triangulation(oracle):
+    """KAT (xiii): many-points proposal (fit + Pluecker projection).  Noise-free: three 3D points exactly on
+    the GT segment, shared by l1 and l2 -> the fitted infinite line IS the GT line and the endpoints of the
+    candidate are where l1's endpoint rays meet it, i.e. the GT endpoints; with SfM points given they are
+    used as they are, without them the points are triangulated from the two views."""
+    import numpy as np
+    from limap_amd import synthetic as syn
+    K4 = np.array([500.0, 500.0, 320.0, 240.0])
+    q = np.array([[1.0, 0, 0, 0], [1.0, 0, 0, 0]])
+    t = np.array([[0.0, 0, 0], [-0.6, -0.25, 0.0]])
+    P, Q = np.array([-0.4, 0.1, 4.0]), np.array([0.5, 0.35, 5.0])
+
+    def proj(X, tt):
+        Xc = X + tt
+        return np.array([K4[0] * Xc[0] / Xc[2] + K4[2], K4[1] * Xc[1] / Xc[2] + K4[3]])
+    segs = np.array([[*proj(P, t[0]), *proj(Q, t[0])], [*proj(P, t[1]), *proj(Q, t[1])]])
+    pts3 = {10 + k: P + s * (Q - P) for k, s in enumerate((0.2, 0.5, 0.9))}
+    bp = {}
+    for n, img in enumerate((7, 9)):
+        bp[img] = dict(point_ids=np.arange(3), xy=np.array([proj(pts3[10 + k], t[n]) for k in range(3)]),
+                       point3D_ids=np.array([10, 11, 12]), line_points=[[0, 1, 2]])
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    cfg.update(disable_algebraic_triangulation=True, disable_one_point_triangulation=True, min_num_outer_edges=0)
+    for with_sfm in (True, False):
+        O = oracle.OracleTriangulator(cfg, faithful=True)
+        O.Init([7, 9], np.tile(K4, (2, 1)), q, t, [0, 1, 2], segs)
+        O.SetBipartites2d(bp)
+        if with_sfm:
+            O.SetSfMPoints(pts3)
+        O.TriangulateImage(7, {9: np.array([[0, 0]], np.int32)})
+        a = O.get_all_tris()
+        assert a["off"][1] - a["off"][0] == 1
+        np.testing.assert_allclose(a["line"][0, :3], P, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(a["line"][0, 3:6], Q, rtol=0, atol=1e-8)
+    # a single shared point is not enough for the fit; no bipartites -> no proposal
+    bp1 = {k: dict(v, line_points=[[0]]) for k, v in bp.items()}
+    O = oracle.OracleTriangulator(cfg, faithful=True)
+    O.Init([7, 9], np.tile(K4, (2, 1)), q, t, [0, 1, 2], segs)
+    O.SetBipartites2d(bp1); O.SetSfMPoints(pts3)
+    O.TriangulateImage(7, {9: np.array([[0, 0]], np.int32)})
+    assert O.get_all_tris()["off"][-1] == 0
