@@ -36,7 +36,7 @@ typedef struct lt_config {
   int32_t add_halfpix;
   int32_t use_vp;                            /* VP-guided proposals (needs lt_init_vp) */
   int32_t use_endpoints_triangulation;
-  int32_t disable_many_points_triangulation; /* point proposals need SetBipartites2d: n/a */
+  int32_t disable_many_points_triangulation; /* many-points proposal (needs lt_set_bipartites) */
   int32_t disable_one_point_triangulation;
   int32_t disable_algebraic_triangulation;
   int32_t disable_vp_triangulation;
@@ -92,6 +92,18 @@ int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, 
  * cfg.use_vp && !cfg.disable_vp_triangulation (both triangulation modes).  Call after lt_init. */
 int lt_init_vp(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *label_off, const int32_t *labels,
                const int64_t *vp_off, const double *vps);
+/* SetBipartites2d(all_bpt2ds) / SetSfMPoints(points) -- base_line_triangulator.h:71-77, bindings.cc:90-91.
+ * Per image (CSR pt_off) its 2D points: id, xy, point3D_id; per line (CSR line_off over the images, lp_off
+ * over the lines -- every line of the image must be listed) the ids of its neighbouring points
+ * (structures::PL_Bipartite2d::neighbor_points).  SfM points: point3D_id -> xyz; with none given the shared
+ * points are triangulated from the two views.  Enables the many-points proposal of triangulateOneNode
+ * (base_line_triangulator.cc:183-236: line fit through the shared 3D points + Pluecker projection) in
+ * matched mode; the one-point proposal (:238-248) is not implemented --
+ * cfg.disable_one_point_triangulation must be set.  Call after lt_init. */
+int lt_set_bipartites(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *pt_off, const int32_t *pt_ids,
+                      const double *pt_xy, const int32_t *pt_p3d, const int64_t *line_off, const int64_t *lp_off,
+                      const int32_t *lp_ptids);
+int lt_set_sfm_points(lt_ctx *ctx, int64_t n, const int32_t *ids, const double *xyz);
 /* Same with kvec/qvec/tvec/segs already resident in HBM (e.g. the output of the RCCL all-gather),
  * images given in ascending id order. */
 int lt_init_device(lt_ctx *ctx, int n_img, const int32_t *img_ids, const void *d_kvec,

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("LIMAP_AMD_LIB") or os.path.join(_HERE, "liblimap_amd.
 
 EXPORTED_SYMBOLS = [
     "lt_config_default", "lt_abi_version", "lt_sizeof_config", "lt_create", "lt_destroy", "lt_last_error", "lt_set_stream", "lt_set_ranges",
-    "lt_unset_ranges", "lt_init", "lt_init_vp", "lt_init_device", "lt_refresh_scene_device", "lt_set_scene_chunks",
+    "lt_unset_ranges", "lt_init", "lt_init_vp", "lt_set_bipartites", "lt_set_sfm_points", "lt_init_device", "lt_refresh_scene_device", "lt_set_scene_chunks",
     "lt_refresh_scene_chunks", "lt_triangulate_image", "lt_triangulate_image_rows",
     "lt_triangulate_image_exhaustive", "lt_upload", "lt_run_device", "lt_download", "lt_flush",
     "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
@@ -122,6 +122,8 @@ def load_library():
     L.lt_unset_ranges.argtypes = [vp]
     L.lt_init.argtypes = [vp, C.c_int, i32p, dp, dp, dp, i64p, dp]
     L.lt_init_vp.argtypes = [vp, C.c_int, i32p, i64p, i32p, i64p, dp]
+    L.lt_set_bipartites.argtypes = [vp, C.c_int, i32p, i64p, i32p, dp, i32p, i64p, i64p, i32p]
+    L.lt_set_sfm_points.argtypes = [vp, C.c_int64, i32p, dp]
     L.lt_init_device.argtypes = [vp, C.c_int, i32p, vp, vp, vp, i64p, vp]
     L.lt_refresh_scene_device.argtypes = [vp, vp, vp, vp, vp]
     vpp = C.POINTER(C.c_void_p)
@@ -302,6 +304,21 @@ class Context:
             vps = np.zeros((1, 3))
         self.chk(self.L.lt_init_vp(self.h, len(ids), ptr(i32(ids), C.c_int32), ptr(lab_off, C.c_int64),
                                    ptr(labs, C.c_int32), ptr(vp_off, C.c_int64), ptr(vps, C.c_double)))
+
+    def set_bipartites(self, flat):
+        """flat: dict of the CSR arrays of lt_set_bipartites (see triangulation.flatten_bipartites)."""
+        self.chk(self.L.lt_set_bipartites(self.h, len(flat["img_ids"]), ptr(i32(flat["img_ids"]), C.c_int32),
+                                          ptr(i64(flat["pt_off"]), C.c_int64), ptr(i32(flat["pt_ids"]), C.c_int32),
+                                          ptr(f64(flat["pt_xy"]), C.c_double), ptr(i32(flat["pt_p3d"]), C.c_int32),
+                                          ptr(i64(flat["line_off"]), C.c_int64), ptr(i64(flat["lp_off"]), C.c_int64),
+                                          ptr(i32(flat["lp_ptids"]), C.c_int32)))
+
+    def set_sfm_points(self, ids, xyz):
+        ids, xyz = i32(ids), f64(np.asarray(xyz, float).reshape(-1, 3))
+        n = len(ids)
+        if n == 0:
+            ids, xyz = np.zeros(1, np.int32), np.zeros((1, 3))
+        self.chk(self.L.lt_set_sfm_points(self.h, n, ptr(ids, C.c_int32), ptr(xyz, C.c_double)))
 
     def triangulate_image_rows(self, img_id, nb_ids, arrays):
         """arrays[k]: C-contiguous int32 (K,2) rows of neighbour nb_ids[k] (kept alive for the call)."""

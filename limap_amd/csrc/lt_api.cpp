@@ -39,7 +39,9 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
                       unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, unsigned *st_row,
                       unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3,
-                      const double *seg_vp, const unsigned char *seg_has_vp);
+                      const double *seg_vp, const unsigned char *seg_has_vp, const long long *seg_pt_off,
+                      const void *seg_pts, const double *sfm_xyz, int *err_flag);
+size_t seg_point_bytes();
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
                         unsigned *base_bl, unsigned *n_tris);
@@ -372,6 +374,8 @@ int init_common(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *s
   ctx->has_best.assign(ctx->G, 0);
   ctx->valid_edges.reset(ctx->G);
   ctx->vp_ready = false;
+  ctx->pts_ready = false; ctx->sfm_given = false; ctx->pts_dirty = false;
+  ctx->h_seg_pts.clear(); ctx->h_seg_pt_off.clear(); ctx->h_sfm_ids.clear(); ctx->h_sfm_xyz.clear();
   ctx->tracks.clear();
   ctx->tracks_done = false;
   ctx->job_mode = 0;
@@ -528,7 +532,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
-                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed};
+                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz};
   lt_host::host_block_release(ctx->h_pinned_blk);
   for (DevBuf *b : bufs) b->release();
   // a context that still owns its stream hands stream + events to the next context
@@ -620,6 +624,97 @@ int lt_init_vp(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *la
   if ((rc = upload_vec(ctx, ctx->d_seg_has_vp, has))) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->vp_ready = true;
+  return LT_OK;
+}
+
+int lt_set_bipartites(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *pt_off, const int32_t *pt_ids,
+                      const double *pt_xy, const int32_t *pt_p3d, const int64_t *line_off, const int64_t *lp_off,
+                      const int32_t *lp_ptids) {
+  if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "SetBipartites2d before Init");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  struct SegPointH { int p3d_id, sfm; double x, y; };
+  static_assert(sizeof(SegPointH) == 24, "SegPoint layout");
+  if (seg_point_bytes() != sizeof(SegPointH)) return fail(ctx, LT_ERR_RUNTIME, "SegPoint layout mismatch");
+  std::vector<std::vector<SegPointH>> per_seg((size_t)std::max<long long>(ctx->G, 1));
+  for (int i = 0; i < n_img; ++i) {
+    auto it = ctx->id2idx.find(img_ids[i]);
+    if (it == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "SetBipartites2d: unknown image id " + std::to_string(img_ids[i]));
+    const int idx = it->second;
+    const long long M = ctx->seg_off[idx + 1] - ctx->seg_off[idx];
+    if (line_off[i + 1] - line_off[i] != M)
+      return fail(ctx, LT_ERR_ARGUMENT, "SetBipartites2d: image " + std::to_string(img_ids[i]) + " has " + std::to_string(M) +
+                                            " lines, the bipartite lists " + std::to_string(line_off[i + 1] - line_off[i]));
+    // point id -> row of this image's point arrays
+    std::unordered_map<int, long long> row;
+    for (long long k = pt_off[i]; k < pt_off[i + 1]; ++k) row[pt_ids[k]] = k;
+    for (long long l = 0; l < M; ++l) {
+      const long long L = line_off[i] + l;
+      // neighbor_points(): ascending point id (std::set); the reference then keys by point3D_id, first wins
+      std::vector<int> ids(lp_ptids + lp_off[L], lp_ptids + lp_off[L + 1]);
+      std::sort(ids.begin(), ids.end());
+      ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+      std::map<int, SegPointH> by3d;
+      for (int pid : ids) {
+        auto r = row.find(pid);
+        if (r == row.end()) return fail(ctx, LT_ERR_ARGUMENT, "SetBipartites2d: a line refers to an unknown point id");
+        SegPointH sp{pt_p3d[r->second], -1, pt_xy[2 * r->second], pt_xy[2 * r->second + 1]};
+        by3d.insert({sp.p3d_id, sp});
+      }
+      auto &dst = per_seg[(size_t)(ctx->seg_off[idx] + l)];
+      dst.clear();
+      for (auto &kv : by3d) dst.push_back(kv.second);
+    }
+  }
+  ctx->h_seg_pt_off.assign((size_t)ctx->G + 1, 0);
+  ctx->h_seg_pts.clear();
+  for (long long g = 0; g < ctx->G; ++g) {
+    ctx->h_seg_pt_off[(size_t)g] = (long long)(ctx->h_seg_pts.size() / 3);
+    for (auto &sp : per_seg[(size_t)g]) {
+      double packed[3];
+      std::memcpy(packed, &sp, 24);
+      ctx->h_seg_pts.insert(ctx->h_seg_pts.end(), packed, packed + 3);
+    }
+  }
+  ctx->h_seg_pt_off[(size_t)ctx->G] = (long long)(ctx->h_seg_pts.size() / 3);
+  ctx->pts_ready = true;
+  ctx->pts_dirty = true;
+  ctx->uploaded = ctx->ran = false;
+  return LT_OK;
+}
+
+int lt_set_sfm_points(lt_ctx *ctx, int64_t n, const int32_t *ids, const double *xyz) {
+  ctx->h_sfm_ids.assign(ids, ids + n);
+  ctx->h_sfm_xyz.assign(xyz, xyz + 3 * n);
+  ctx->sfm_given = n > 0;  // sfm_points_.empty() -> the shared points are triangulated from the two views
+  ctx->pts_dirty = true;
+  ctx->uploaded = ctx->ran = false;
+  return LT_OK;
+}
+
+// resolve point3D ids to SfM rows and upload the point tables (called from lt_run_device when needed)
+static int upload_points(lt_ctx *ctx) {
+  if (!ctx->pts_ready || !ctx->pts_dirty) return LT_OK;
+  std::vector<double> pts = ctx->h_seg_pts;
+  if (ctx->sfm_given) {
+    std::unordered_map<int, int> where;
+    for (size_t k = 0; k < ctx->h_sfm_ids.size(); ++k) where[ctx->h_sfm_ids[k]] = (int)k;
+    for (size_t e = 0; e + 3 <= pts.size(); e += 3) {
+      int head[2];
+      std::memcpy(head, &pts[e], 8);
+      auto it = where.find(head[0]);
+      head[1] = it == where.end() ? -1 : it->second;
+      std::memcpy(&pts[e], head, 8);
+    }
+  }
+  if (pts.empty()) pts.assign(3, 0.0);
+  int rc;
+  if ((rc = upload_vec(ctx, ctx->d_seg_pts, pts))) return rc;
+  if ((rc = upload_vec(ctx, ctx->d_seg_pt_off, ctx->h_seg_pt_off))) return rc;
+  std::vector<double> xyz = ctx->h_sfm_xyz;
+  if (xyz.empty()) xyz.assign(3, 0.0);
+  if ((rc = upload_vec(ctx, ctx->d_sfm_xyz, xyz))) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->pts_dirty = false;
   return LT_OK;
 }
 
@@ -856,6 +951,8 @@ int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_id
 }
 
 int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids) {
+  if (ctx->pts_ready && (!ctx->cfg.disable_many_points_triangulation || !ctx->cfg.disable_one_point_triangulation))
+    return fail(ctx, LT_ERR_ARGUMENT, "point-guided proposals (SetBipartites2d) are implemented for TriangulateImage (matched mode) only");
   int idx;
   int rc = begin_image(ctx, img_id, 2, &idx);
   if (rc) return rc;
@@ -1010,7 +1107,13 @@ int lt_run_device(lt_ctx *ctx) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const long long G = ctx->G, P = ctx->P;
-  const GenCfg gcfg = make_gen(ctx);
+  {
+    int rcp = upload_points(ctx);
+    if (rcp) return rcp;
+  }
+  GenCfg gcfg = make_gen(ctx);
+  // like the VP proposals, the point-guided ones do not depend on the algebraic gates
+  if (ctx->pts_ready && !ctx->cfg.disable_many_points_triangulation) gcfg.force_undecided = 1;
   const ScoreCfg scfg = make_score(ctx);
   ENSURE(ctx, ctx->d_err, sizeof(int));
   ENSURE(ctx, ctx->d_pair_counter, 8);
@@ -1035,8 +1138,15 @@ int lt_run_device(lt_ctx *ctx) {
     // VP-guided proposals: up to three candidates per match row (vp of l1, vp of l2, algebraic)
     const bool vp_on = ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation;
     if (vp_on && !ctx->vp_ready) return fail(ctx, LT_ERR_STATE, "use_vp is set but InitVPResults was not called");
-    const int mult = vp_on ? 3 : 1;
-    if (vp_on && 3 * P >= (1ll << 32) - 1) return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch for VP proposals");
+    // point-guided proposals (SetBipartites2d): the many-points line fit; the one-point quartic proposal is
+    // not implemented and has to be switched off
+    const bool pts_any = ctx->pts_ready && (!ctx->cfg.disable_many_points_triangulation || !ctx->cfg.disable_one_point_triangulation);
+    if (pts_any && !ctx->cfg.disable_one_point_triangulation)
+      return fail(ctx, LT_ERR_ARGUMENT, "the one-point proposal (triangulate_line_with_one_point) is not implemented: set "
+                                        "disable_one_point_triangulation");
+    const bool pts_on = pts_any && !ctx->cfg.disable_many_points_triangulation;
+    const int mult = (vp_on || pts_on) ? 4 : 1;
+    if (mult > 1 && 4 * P >= (1ll << 32) - 1) return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch for the extra proposals");
     ENSURE(ctx, ctx->d_st_c, sizeof(Cand) * Pn * mult); ENSURE(ctx, ctx->d_st_l, sizeof(CandLite) * Pn * mult);
     ENSURE(ctx, ctx->d_st_key, 4 * Pn * mult);
     ENSURE(ctx, ctx->d_wave_count, 4 * (size_t)(n_waves + 1));
@@ -1073,7 +1183,9 @@ int lt_run_device(lt_ctx *ctx) {
                        fast ? ctx->d_cnt_bl.as<unsigned>() : nullptr, lds_segs, lds_segs1, ctx->d_st_row.as<unsigned>(),
                        ctx->d_surv_count.as<unsigned>(), G, ctx->d_seg_gates.p, ctx->d_blkrec.p, fine_timers() ? &ctx->ev[8] : nullptr,
                        vp_on ? ctx->d_seg_vp.as<double>() : nullptr,
-                       vp_on ? ctx->d_seg_has_vp.as<unsigned char>() : nullptr);
+                       vp_on ? ctx->d_seg_has_vp.as<unsigned char>() : nullptr,
+                       pts_on ? ctx->d_seg_pt_off.as<long long>() : nullptr, pts_on ? ctx->d_seg_pts.p : nullptr,
+                       (pts_on && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr, ctx->d_err.as<int>());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
     long long *hC = ctx->h_pinned;
@@ -1246,6 +1358,8 @@ int lt_run_device(lt_ctx *ctx) {
     ctx->stat_pairs_eval = (long long)pe;
   }
   ctx->stat_survivors = -1;  // summed on demand (lt_get_timers)
+  if (derr == 2)
+    return fail(ctx, LT_ERR_RUNTIME, "map::at: a point shared by two lines has a point3D_id that is not among the SfM points");
   if (derr != 0) return fail(ctx, LT_ERR_RUNTIME, "IndexError! Out-of-index matches detected on the device");
   float ms;
   static const int kMap[7] = {1, 2, 3, 4, 5, 6, 7};

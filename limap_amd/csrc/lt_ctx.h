@@ -195,6 +195,12 @@ struct lt_ctx {
   DevBuf d_base_bl;          // exclusive prefix of cnt_bl over the neighbour blocks of a node
   bool cnt_bl_clean = false;  // d_cnt_bl is all zero (k_node_prefix cleans up after itself)
   size_t cnt_bl_bytes = 0;
+  // point-guided proposals: per segment its (point3D_id, sfm row, x, y) records (24 B, kept as 3 doubles), CSR
+  std::vector<double> h_seg_pts, h_sfm_xyz;
+  std::vector<long long> h_seg_pt_off;
+  std::vector<int> h_sfm_ids;
+  DevBuf d_seg_pts, d_seg_pt_off, d_sfm_xyz;
+  bool pts_ready = false, sfm_given = false, pts_dirty = false;
   bool vp_ready = false;  // InitVPResults was called for the current scene
   int n_chunks = 0;
   long long cand_cap = 0;

@@ -357,6 +357,137 @@ static __device__ __forceinline__ bool dir_candidate(const GenCfg &cfg, const Ca
   return true;
 }
 
+// Per-segment point record of the point-guided proposals: the neighbouring 2D points of a line
+// (structures::PL_Bipartite2d) de-duplicated by point3D_id and sorted by it, as the reference's
+// std::map<int, ...> keyed by point3D_id sees them (base_line_triangulator.cc:186-204).
+struct SegPoint {
+  int p3d_id;   // point3D_id
+  int sfm;      // index into the SfM point array, -1 = id not in SetSfMPoints (only read when SfM points are set)
+  double x, y;  // the 2D point
+};
+static_assert(sizeof(SegPoint) == 24, "SegPoint layout");
+
+// Principal axis of a symmetric 3x3 scatter matrix (cyclic Jacobi, fully unrolled: no indexed arrays).
+// Stands in for Eigen::JacobiSVD(points - center, ComputeThinV).matrixV().col(0) of the many-points line
+// fit (base_line_triangulator.cc:218-226); the sign of the axis does not matter for the Pluecker
+// projection that follows.
+static __device__ __forceinline__ d3 scatter_axis(double a00, double a01, double a02, double a11, double a12,
+                                                  double a22) {
+  double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+  for (int sweep = 0; sweep < 32; ++sweep) {
+    const double off = fabs(a01) + fabs(a02) + fabs(a12), diag = fabs(a00) + fabs(a11) + fabs(a22);
+    if (off <= 1e-18 * diag || off == 0.0) break;
+#define LT_JACOBI(app, aqq, apq, apr, aqr, vp0, vp1, vp2, vq0, vq1, vq2)                     \
+  if (apq != 0.0) {                                                                          \
+    const double th = (aqq - app) / (2.0 * apq);                                             \
+    const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));              \
+    const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;                                    \
+    const double npp = app - t * apq, nqq = aqq + t * apq;                                   \
+    const double npr = c * apr - sn * aqr, nqr = sn * apr + c * aqr;                         \
+    app = npp; aqq = nqq; apq = 0.0; apr = npr; aqr = nqr;                                   \
+    double u;                                                                                \
+    u = c * vp0 - sn * vq0; vq0 = sn * vp0 + c * vq0; vp0 = u;                               \
+    u = c * vp1 - sn * vq1; vq1 = sn * vp1 + c * vq1; vp1 = u;                               \
+    u = c * vp2 - sn * vq2; vq2 = sn * vp2 + c * vq2; vp2 = u;                               \
+  }
+    // column p of V is (v0p, v1p, v2p); rotations in the (0,1), (0,2), (1,2) planes
+    LT_JACOBI(a00, a11, a01, a02, a12, v00, v10, v20, v01, v11, v21)
+    LT_JACOBI(a00, a22, a02, a01, a12, v00, v10, v20, v02, v12, v22)
+    LT_JACOBI(a11, a22, a12, a01, a02, v01, v11, v21, v02, v12, v22)
+#undef LT_JACOBI
+  }
+  d3 ax = mk3(v00, v10, v20);
+  double best = a00;
+  if (a11 > best) { best = a11; ax = mk3(v01, v11, v21); }
+  if (a22 > best) { ax = mk3(v02, v12, v22); }
+  return ax;
+}
+
+// Step 1.1 of triangulateOneNode (base_line_triangulator.cc:183-236): the 3D points shared by l1 and l2
+// (SfM points, or triangulated from the two 2D observations), a total-least-squares line through them,
+// and l1's endpoint rays projected onto that infinite line with Pluecker coordinates
+// (triangulate_line_with_infinite_line, functions.cc:306-321; InfiniteLine3d::project_from_infinite_line,
+// infinite_line.cc:151-163).  Cheirality is tested in view 1 only, like the reference.
+// *missing: a shared id without an SfM point (std::map::at would throw in the reference).
+static __device__ __forceinline__ bool points_candidate(const GenCfg &cfg, const Cam &c1, const Cam &c2,
+                                                        const Seg &s1, const Seg &s2, const SegPoint *pa, int na,
+                                                        const SegPoint *pb, int nb, const double *sfm_xyz,
+                                                        GenOut *out, bool *missing) {
+  d3 center = mk3(0, 0, 0);
+  double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+  int n = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    int i = 0, j = 0;
+    while (i < na && j < nb) {
+      const int ia = pa[i].p3d_id, ib = pb[j].p3d_id;
+      if (ia < ib) { ++i; continue; }
+      if (ib < ia) { ++j; continue; }
+      d3 P;
+      bool ok = true;
+      if (sfm_xyz) {
+        const int idx = pa[i].sfm;
+        if (idx < 0) { *missing = true; ok = false; }
+        else P = mk3(sfm_xyz[3 * idx], sfm_xyz[3 * idx + 1], sfm_xyz[3 * idx + 2]);
+      } else {
+        ok = tri_point(c1, cam_ray(c1, d2{pa[i].x, pa[i].y}), c2, cam_ray(c2, d2{pb[j].x, pb[j].y}), &P);
+      }
+      if (ok) {
+        if (pass == 0) {
+          center = add(center, P);
+          ++n;
+        } else {
+          const d3 e = sub(P, center);
+          a00 += e.x * e.x; a01 += e.x * e.y; a02 += e.x * e.z;
+          a11 += e.y * e.y; a12 += e.y * e.z; a22 += e.z * e.z;
+        }
+      }
+      ++i; ++j;
+    }
+    if (pass == 0) {
+      if (n < 2) return false;
+      const double dn = (double)n;
+      center = mk3(center.x / dn, center.y / dn, center.z / dn);
+    }
+  }
+  const d3 direc = unit(scatter_axis(a00, a01, a02, a11, a12, a22));
+  const d3 m2 = cross(center, direc);
+  const d3 C1 = cam_center(c1);
+  d3 pend[2];
+  for (int k = 0; k < 2; ++k) {
+    const d3 v = k == 0 ? mk3(s1.rs[0], s1.rs[1], s1.rs[2]) : mk3(s1.re[0], s1.re[1], s1.re[2]);
+    const d3 m1 = cross(C1, v);
+    const d3 cr = cross(v, direc);
+    const d3 t1 = cross(m1, cross(direc, cr));
+    const double w = dot(m2, cr);
+    d3 pt = add(scale(t1, -1.0), scale(v, w));
+    const double q = dot(cr, cr);
+    pend[k] = mk3(pt.x / q, pt.y / q, pt.z / q);
+  }
+  const d3 ps = pend[0], pe = pend[1];
+  const double z_start = cam_depth(c1, ps), z_end = cam_depth(c1, pe);
+  if (z_start < kEps || z_end < kEps) return false;
+  const double d21 = cam_depth(c2, ps), d22 = cam_depth(c2, pe);
+  const double u1 = cfg.var2d * ((z_start + z_end) / 2.0) / c1.f;
+  const double u2 = cfg.var2d * ((d21 + d22) / 2.0) / c2.f;
+  if (cfg.use_ranges) {
+    if (ps.x < cfg.lo[0] || ps.x > cfg.hi[0]) return false;
+    if (ps.y < cfg.lo[1] || ps.y > cfg.hi[1]) return false;
+    if (ps.z < cfg.lo[2] || ps.z > cfg.hi[2]) return false;
+    if (pe.x < cfg.lo[0] || pe.x > cfg.hi[0]) return false;
+    if (pe.y < cfg.lo[1] || pe.y > cfg.hi[1]) return false;
+    if (pe.z < cfg.lo[2] || pe.z > cfg.hi[2]) return false;
+  }
+  const d3 dir3 = unit(sub(pe, ps));
+  out->c.s[0] = ps.x; out->c.s[1] = ps.y; out->c.s[2] = ps.z;
+  out->c.e[0] = pe.x; out->c.e[1] = pe.y; out->c.e[2] = pe.z;
+  out->c.depth[0] = z_start; out->c.depth[1] = z_end;
+  out->c.unc = dmin(u1, u2);
+  out->c.score3 = 1.0;
+  out->c.seg[0] = s2.x1; out->c.seg[1] = s2.y1; out->c.seg[2] = s2.x2; out->c.seg[3] = s2.y2;
+  out->l.dir[0] = dir3.x; out->l.dir[1] = dir3.y; out->l.dir[2] = dir3.z;
+  return true;
+}
+
 static __device__ __forceinline__ bool vp_candidate(const GenCfg &cfg, const Cam &c1, const Cam &c2, const Seg &s1,
                                                     const Seg &s2, const double *Bv, const double *vp,
                                                     GenOut *out) {

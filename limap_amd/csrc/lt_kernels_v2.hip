@@ -106,7 +106,12 @@ struct GenArgs {
   // VP-guided proposals (use_vp): per segment its vanishing point (image homogeneous coordinates) and a flag
   const double *seg_vp;          // [G][3] or nullptr
   const unsigned char *seg_has_vp;
-  int mult;               // staging slots per match row: 1, or 3 with VP proposals (vp1, vp2, algebraic)
+  // point-guided proposals (SetBipartites2d): per segment its neighbouring points (CSR), SfM points or nullptr
+  const long long *seg_pt_off;   // [G + 1] or nullptr
+  const SegPoint *seg_pts;
+  const double *sfm_xyz;         // [n_sfm][3] or nullptr (points are then triangulated from the two views)
+  int *err_flag;
+  int mult;               // staging slots per match row: 1, or 4 with extra proposals (points, vp1, vp2, algebraic)
 };
 
 __global__ void k_build_gates(long long n_segs, const Seg *__restrict__ segs, SegGate *__restrict__ gates) {
@@ -303,9 +308,10 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
 
 // One wave per (block, group).  (A persistent-wave variant with the next item's record prefetched was
 // measured slower: the kernel is bound by gather / scatter throughput, not by latency.)
-// kVP: additionally the VP-guided proposals of step 2 (base_line_triangulator.cc:250-281) -- per
-// connection up to three candidates in the reference's order vp(l1), vp(l2), algebraic.
-template <bool kVP>
+// kExtra: additionally the optional proposals of steps 1.1 and 2 (base_line_triangulator.cc:183-281) -- per
+// connection up to four candidates in the reference's order many-points, vp(l1), vp(l2), algebraic.  Which
+// of them are active is a run-time property (a.seg_pts / a.seg_vp may be null).
+template <bool kExtra>
 __global__ void __launch_bounds__(256)
 k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec *__restrict__ pairs_r,
            const BlkRec *__restrict__ blk_r) {
@@ -329,7 +335,7 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
   const long long g1 = rec->g1, g2 = rec->g2;
   const PairRec *pr = pairs_r + b;
   const long long lbase = a.cnt_bl ? rec->lbase : 0;
-  const long long out0 = r0 * (kVP ? (long long)a.mult : 1ll);  // first staging slot of the group
+  const long long out0 = r0 * (kExtra ? (long long)a.mult : 1ll);  // first staging slot of the group
   // survivor lists of the group's slots, walked as one concatenated list
   unsigned cs[kTriSlots + 1];
   cs[0] = 0;
@@ -340,9 +346,27 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
   unsigned wcount = 0;
   for (unsigned e0 = 0; e0 < n_s; e0 += 64) {
     const unsigned e = e0 + lane;
-    bool ok = false, ok1 = false, ok2 = false;
+    bool ok = false;
+    bool okx[3] = {false, false, false};  // many-points, vp(l1), vp(l2)
     GenOut o;
     int line = 0, ng = 0;
+    // the extra proposals are evaluated once for their validity and a second time when they are
+    // written (in candidate order), instead of being kept in registers next to the algebraic one
+    auto extra = [&](int which, GenOut *dst) -> bool {
+      const Seg &s1 = a.segs[g1 + line];
+      const Seg &s2 = a.segs[g2 + ng];
+      if (which == 0) {
+        const long long pa0 = a.seg_pt_off[g1 + line], pb0 = a.seg_pt_off[g2 + ng];
+        bool missing = false;
+        const bool r = points_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, a.seg_pts + pa0,
+                                        (int)(a.seg_pt_off[g1 + line + 1] - pa0), a.seg_pts + pb0,
+                                        (int)(a.seg_pt_off[g2 + ng + 1] - pb0), a.sfm_xyz, dst, &missing);
+        if (missing) *a.err_flag = 2;  // a shared point3D_id without an SfM point
+        return r;
+      }
+      return vp_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B,
+                          a.seg_vp + 3 * (which == 1 ? g1 + line : g2 + ng), dst);
+    };
     if (e < n_s) {
       int k = 0;
       unsigned first = 0;
@@ -360,16 +384,15 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
       ok = true;
       if (u >> 31) ok = gen_gates(cfg, s1, s2, pr->F);  // the cheap gates could not decide
       if (ok) ok = gen_finish(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B, &o);
-      if (kVP) {
-        // both segments long enough (:166,177) -- with VP proposals stage A lets every row through
+      if (kExtra) {
+        // both segments long enough (:166,177) -- with extra proposals stage A lets every row through
         L2 l1{mk2(s1.x1, s1.y1), mk2(s1.x2, s1.y2)};
         L2 l2{mk2(s2.x1, s2.y1), mk2(s2.x2, s2.y2)};
         const bool len_ok = !(len(l1) <= cfg.min_length_2d) && !(len(l2) <= cfg.min_length_2d);
         GenOut tmp;
-        if (len_ok && a.seg_has_vp[g1 + line])
-          ok1 = vp_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B, a.seg_vp + 3 * (g1 + line), &tmp);
-        if (len_ok && a.seg_has_vp[g2 + ng])
-          ok2 = vp_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B, a.seg_vp + 3 * (g2 + ng), &tmp);
+        if (len_ok && a.seg_pts) okx[0] = extra(0, &tmp);
+        if (len_ok && a.seg_vp && a.seg_has_vp[g1 + line]) okx[1] = extra(1, &tmp);
+        if (len_ok && a.seg_vp && a.seg_has_vp[g2 + ng]) okx[2] = extra(2, &tmp);
       }
       o.l.nb_slot = lite_pack(nbslot, i2);
       o.l.ng_line = ng;
@@ -377,20 +400,21 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
     const unsigned long long m = __ballot(ok);
     unsigned below = (unsigned)__popcll(m & lanemask_lt());
     unsigned total = (unsigned)__popcll(m);
-    if (kVP) {
-      const unsigned long long m1 = __ballot(ok1), m2 = __ballot(ok2);
-      below += (unsigned)__popcll(m1 & lanemask_lt()) + (unsigned)__popcll(m2 & lanemask_lt());
-      total += (unsigned)__popcll(m1) + (unsigned)__popcll(m2);
-      // the VP candidates come first within the connection; they are evaluated a second time here
-      // instead of being kept in registers next to the algebraic one
+    if (kExtra) {
+      unsigned mine = 0;
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        const unsigned long long mw = __ballot(okx[w]);
+        below += (unsigned)__popcll(mw & lanemask_lt());
+        total += (unsigned)__popcll(mw);
+        mine += okx[w] ? 1u : 0u;
+      }
       long long p = out0 + wcount + below;
-      for (int which = 0; which < 2; ++which) {
-        if (which == 0 ? ok1 : ok2) {
-          const Seg &s1 = a.segs[g1 + line];
-          const Seg &s2 = a.segs[g2 + ng];
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        if (okx[w]) {
           GenOut ov;
-          (void)vp_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B,
-                             a.seg_vp + 3 * (which == 0 ? g1 + line : g2 + ng), &ov);
+          (void)extra(w, &ov);
           ov.l.nb_slot = lite_pack(nbslot, i2);
           ov.l.ng_line = ng;
           a.st_c[p] = ov.c;
@@ -399,15 +423,13 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
           ++p;
         }
       }
-      below += (unsigned)ok1 + (unsigned)ok2;
-      if (a.cnt_bl && (ok1 || ok2)) atomicAdd(&a.cnt_bl[lbase + line], (unsigned)ok1 + (unsigned)ok2);
-    }
-    if (kVP) {
+      below += mine;
+      if (a.cnt_bl && mine) atomicAdd(&a.cnt_bl[lbase + line], mine);
       if (ok) {
-        const long long p = out0 + wcount + below;
-        a.st_c[p] = o.c;
-        a.st_l[p] = o.l;
-        a.st_key[p] = (unsigned)(g1 + line);
+        const long long pq = out0 + wcount + below;
+        a.st_c[pq] = o.c;
+        a.st_l[pq] = o.l;
+        a.st_key[pq] = (unsigned)(g1 + line);
         if (a.cnt_bl) atomicAdd(&a.cnt_bl[lbase + line], 1u);
       }
     } else {
@@ -818,6 +840,7 @@ extern "C" int lt_debug_read_trace(unsigned long long *host, size_t n) {
 }
 #endif
 size_t seg_gate_bytes() { return sizeof(SegGate); }
+size_t seg_point_bytes() { return sizeof(SegPoint); }
 size_t blk_rec_bytes() { return sizeof(BlkRec); }
 // HOT LOOP 1: k_build_gates + k_gates (survivor lists) + k_tri_rows (candidate lists)
 void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
@@ -826,7 +849,8 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
                       unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, unsigned *st_row,
                       unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3,
-                      const double *seg_vp, const unsigned char *seg_has_vp) {
+                      const double *seg_vp, const unsigned char *seg_has_vp, const long long *seg_pt_off,
+                      const void *seg_pts, const double *sfm_xyz, int *err_flag) {
   if (n_blk <= 0 || max_rows <= 0) return;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -845,7 +869,11 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   a.pairs = pairs; a.blk_line_base = blk_line_base; a.st_row = st_row; a.surv_count = surv_count;
   a.st_c = st_c; a.st_l = st_l; a.st_key = st_key; a.wave_count = wave_count; a.cnt_bl = cnt_bl;
   a.n_slots = gen_slots(max_rows); a.lds_segs = lds_segs; a.lds_segs1 = lds_segs1;
-  a.seg_vp = seg_vp; a.seg_has_vp = seg_has_vp; a.mult = seg_vp ? 3 : 1;
+  a.seg_vp = seg_vp; a.seg_has_vp = seg_has_vp;
+  a.seg_pt_off = seg_pt_off; a.seg_pts = reinterpret_cast<const SegPoint *>(seg_pts); a.sfm_xyz = sfm_xyz;
+  a.err_flag = err_flag;
+  const bool extra = seg_vp || seg_pts;
+  a.mult = extra ? 4 : 1;
   a.blk = reinterpret_cast<const BlkRec *>(blkrec); a.n_blk = n_blk;
   // persistent grid: as many workgroups as fit at once (registers allow 16 waves per CU)
   const long long n_items = (long long)n_blk * (a.n_slots / kGateWaves);
@@ -861,7 +889,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   else if (lds_segs1 > 0) hipLaunchKernelGGL((k_gates<true, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
   else hipLaunchKernelGGL((k_gates<false, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
   if (ev3) (void)hipEventRecord(ev3[1], st);
-  if (seg_vp)
+  if (extra)
     hipLaunchKernelGGL(k_tri_rows<true>, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg, a.cams,
                        a.pairs, a.blk);
   else

@@ -22,6 +22,51 @@ __all__ = [
 ]
 
 
+def _bipartite_as_arrays(b, n_lines):
+    """PL_Bipartite2d-like object or plain dict -> dict(point_ids, xy, point3D_ids, line_points)."""
+    if isinstance(b, dict) and "point_ids" in b:
+        return b
+    d = b.as_dict() if hasattr(b, "as_dict") else b
+    pts, nl2p = d["points_"], d["nl2p_"]
+    ids = sorted(int(k) for k in pts)
+
+    def fields(p):
+        if isinstance(p, dict):
+            return np.asarray(p["p"], float).reshape(2), int(p["point3D_id"])
+        return np.asarray(p.p, float).reshape(2), int(p.point3D_id)
+    xy = np.zeros((len(ids), 2)); p3d = np.zeros(len(ids), np.int64)
+    for n, i in enumerate(ids):
+        xy[n], p3d[n] = fields(pts[i])
+    n_lines = max(n_lines, (max((int(k) for k in nl2p), default=-1) + 1))
+    return dict(point_ids=np.array(ids, np.int64), xy=xy, point3D_ids=p3d,
+                line_points=[sorted(int(x) for x in nl2p.get(l, ())) for l in range(n_lines)])
+
+
+def flatten_bipartites(bpts):
+    """dict img_id -> dict(point_ids, xy, point3D_ids, line_points) -> the CSR arrays of lt_set_bipartites."""
+    ids = sorted(int(k) for k in bpts)
+    pt_off, line_off, lp_off = [0], [0], [0]
+    pt_ids, pt_xy, pt_p3d, lp = [], [], [], []
+    for i in ids:
+        b = bpts[i]
+        pid = np.asarray(b["point_ids"], np.int64).reshape(-1)
+        pt_ids.append(pid); pt_xy.append(np.asarray(b["xy"], float).reshape(-1, 2))
+        pt_p3d.append(np.asarray(b["point3D_ids"], np.int64).reshape(-1))
+        pt_off.append(pt_off[-1] + len(pid))
+        for pts in b["line_points"]:
+            lp.append(np.asarray(pts, np.int64).reshape(-1))
+            lp_off.append(lp_off[-1] + len(lp[-1]))
+        line_off.append(line_off[-1] + len(b["line_points"]))
+
+    def cat(parts, dtype, tail=()):
+        if parts and sum(len(x) for x in parts):
+            return np.ascontiguousarray(np.concatenate(parts, 0), dtype=dtype)
+        return np.zeros((1,) + tail, dtype)
+    return dict(img_ids=np.asarray(ids, np.int32), pt_off=np.asarray(pt_off, np.int64), pt_ids=cat(pt_ids, np.int32),
+                pt_xy=cat(pt_xy, np.float64, (2,)), pt_p3d=cat(pt_p3d, np.int32), line_off=np.asarray(line_off, np.int64),
+                lp_off=np.asarray(lp_off, np.int64), lp_ptids=cat(lp, np.int32))
+
+
 class GlobalLineTriangulatorConfig:
     """Mirror of the pybind config class (bindings.cc:40-74): attribute access to every field the
     reference exposes; constructed empty or from the ``cfg["triangulation"]`` dict."""
@@ -176,10 +221,18 @@ class GlobalLineTriangulator:
         self._ctx.init_vp(flat)
 
     def SetBipartites2d(self, all_bpt2ds):
-        raise NotImplementedError("point-guided proposals (use_pointsfm) are not implemented in the MI355X backend")
+        """all_bpt2ds: dict img_id -> limap.structures.PL_Bipartite2d (anything with ``as_dict()`` giving
+        ``points_`` / ``nl2p_``), or a plain dict(point_ids, xy, point3D_ids, line_points) -- bindings.cc:90.
+        Enables the many-points proposal; the one-point proposal is not implemented
+        (``disable_one_point_triangulation`` must be set)."""
+        n_lines = {i: int(self._seg_off[self._idx[i] + 1] - self._seg_off[self._idx[i]]) for i in self._img_ids}
+        self._ctx.set_bipartites(flatten_bipartites({int(k): _bipartite_as_arrays(v, n_lines.get(int(k), 0))
+                                                     for k, v in dict(all_bpt2ds).items()}))
 
     def SetSfMPoints(self, points):
-        raise NotImplementedError("point-guided proposals (use_pointsfm) are not implemented in the MI355X backend")
+        """points: dict point3D_id -> xyz (bindings.cc:91)."""
+        ids = sorted(int(k) for k in points)
+        self._ctx.set_sfm_points(ids, np.array([np.asarray(points[k], float).reshape(3) for k in ids], float).reshape(-1, 3))
 
     def TriangulateImage(self, img_id, matches):
         """matches: dict[int -> ndarray(K,2) int] (the content of matches_{img_id}.npy)."""

@@ -71,15 +71,20 @@ def compare_valid_edges(g, o):
     assert edge_sets(goff, ge) == edge_sets(ooff, oe)
 
 
-def compare_tracks(gt, ot, rtol=1e-5):
+def compare_tracks(gt, ot, rtol=1e-5, score_rtol=1e-12, exact_members=True):
     """Track membership bit-exact (the north-star bar), endpoints within 1e-5 relative modulo the
-    start/end swap left open by the SVD sign (merging/aggregator.cc:76-78)."""
+    start/end swap left open by the SVD sign (merging/aggregator.cc:76-78).  `exact_members=False` /
+    a looser `score_rtol`: for candidates whose coordinates are themselves only equal to rounding (the
+    many-points line fit)."""
     assert np.array_equal(gt["off"], ot["off"]), "track sizes differ"
     assert np.array_equal(gt["image_ids"], ot["image_ids"])
     assert np.array_equal(gt["line_ids"], ot["line_ids"])
     assert np.array_equal(gt["node_ids"], ot["node_ids"])
-    np.testing.assert_allclose(gt["scores"], ot["scores"], rtol=1e-12)
-    assert np.array_equal(gt["line3d"], ot["line3d"])
+    np.testing.assert_allclose(gt["scores"], ot["scores"], rtol=score_rtol)
+    if exact_members:
+        assert np.array_equal(gt["line3d"], ot["line3d"])
+    else:
+        np.testing.assert_allclose(gt["line3d"], ot["line3d"], rtol=1e-9, atol=1e-12)
     gl, ol = gt["line"], ot["line"]
     scale = np.maximum(np.abs(ol[:, :6]).max(axis=1, keepdims=True), 1e-9)
     d_same = np.abs(gl[:, :6] - ol[:, :6]) / scale
@@ -87,7 +92,7 @@ def compare_tracks(gt, ot, rtol=1e-5):
     d_swap = np.abs(gl[:, :6] - swapped) / scale
     err = np.minimum(d_same.max(axis=1), d_swap.max(axis=1))
     assert err.max() <= rtol if len(err) else True, "track endpoints differ: max rel err %g" % err.max()
-    np.testing.assert_allclose(gl[:, 6], ol[:, 6], rtol=1e-12)
+    np.testing.assert_allclose(gl[:, 6], ol[:, 6], rtol=score_rtol)
 
 
 def small_scene(seed=0, n_views=16, n_segs=120, n_neighbors=8, **kw):

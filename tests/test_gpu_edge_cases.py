@@ -104,8 +104,8 @@ def test_error_conventions(gpu_lib):
         T4.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, segs)
         T4.TriangulateImage(0, {1: np.array([[0, 0]], np.int32)})
         T4.ComputeLineTracks()
-    with pytest.raises(NotImplementedError):
-        T.SetBipartites2d({})
+    with pytest.raises(NotImplementedError):  # the one-point quartic proposal is the one piece not built
+        tri.triangulate_line_with_one_point(segs[0][0], sc.cam11(0), segs[1][0], sc.cam11(1), np.zeros(3))
     with pytest.raises((ValueError, RuntimeError), match="255"):
         T5 = tri.GlobalLineTriangulator(cfg)
         T5.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, segs)

@@ -1,0 +1,113 @@
+"""-m gpu: the many-points proposal of triangulateOneNode (base_line_triangulator.cc:183-236): 3D points
+shared by the two lines (SfM points, or triangulated from the two views), total-least-squares line fit,
+Pluecker projection of l1's endpoint rays onto the fitted infinite line.
+
+The fitted direction comes from Eigen::JacobiSVD in the reference; the product (Jacobi eigen-decomposition
+of the 3x3 scatter matrix) and the oracle (one-sided Jacobi on the n x 3 matrix) are two different stand-ins
+that agree to rounding, so THIS branch's candidates are compared to 1e-9 relative instead of bit for bit;
+everything discrete (which candidates exist, their order, sources, best, edges, tracks) must be identical."""
+import numpy as np
+import pytest
+
+from limap_amd import synthetic as syn
+
+from helpers import compare_tracks, compare_valid_edges
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(oracle, sc, cfg, bpts, sfm, vps=None, sorted_rows=True):
+    from limap_amd import triangulation as tri
+    T = tri.GlobalLineTriangulator(cfg)
+    O = oracle.OracleTriangulator(cfg, faithful=False)
+    T.SetRanges(sc.ranges); O.SetRanges(sc.ranges)
+    T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+    O.Init(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, sc.seg_off, sc.segs)
+    T.SetBipartites2d(bpts); O.SetBipartites2d(bpts)
+    if sfm is not None:
+        T.SetSfMPoints(sfm); O.SetSfMPoints(sfm)
+    if vps is not None:
+        T.InitVPResults(vps); O.InitVPResults(vps)
+    rng = np.random.default_rng(5)
+    for i in sc.img_ids:
+        m = sc.matches_of(int(i))
+        if not sorted_rows:
+            m = {k: v[rng.permutation(len(v))] for k, v in m.items()}
+        T.TriangulateImage(int(i), m)
+        O.TriangulateImage(int(i), m)
+    return T, O
+
+
+def _compare(T, O):
+    g, o = T.context().get_all_tris(), O.get_all_tris()
+    assert np.array_equal(g["off"], o["off"]) and np.array_equal(g["src"], o["src"])
+    scale = np.maximum(np.abs(o["line"]).max(1, keepdims=True), 1e-12)
+    assert np.max(np.abs(g["line"] - o["line"]) / scale) < 1e-9
+    assert np.array_equal(g["score"] == 0, o["score"] == 0)
+    np.testing.assert_allclose(g["score"], o["score"], rtol=1e-7, atol=0)
+    gb, ob = T.context().get_best(), O.get_best()
+    assert np.array_equal(gb["has_best"], ob["has_best"]) and np.array_equal(gb["src"], ob["src"])
+    compare_valid_edges(T.context().get_valid_edges(), O.get_valid_edges())
+    T.context().compute_tracks()
+    compare_tracks(T.context().get_tracks(), O.ComputeLineTracks(), score_rtol=1e-7, exact_members=False)
+    return g
+
+
+@pytest.mark.parametrize("with_sfm,sorted_rows", [(True, True), (False, True), (True, False)])
+def test_many_points_match_oracle(gpu_lib, oracle, with_sfm, sorted_rows):
+    sc = syn.make_scene(n_views=12, n_segs=90, n_neighbors=5, seed=61)
+    bpts, sfm = syn.make_bipartites(sc, seed=1)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    cfg.update(disable_one_point_triangulation=True)
+    T, O = _run_both(oracle, sc, cfg, bpts, sfm if with_sfm else None, sorted_rows=sorted_rows)
+    g = _compare(T, O)
+    from helpers import run_product
+    n_alg = run_product(sc, dict(cfg)).context().stats()["candidates"]
+    assert g["off"][-1] > n_alg + 50          # the branch really contributes
+
+
+def test_points_and_vp_together(gpu_lib, oracle):
+    """All optional proposals on: per connection many-points, vp(l1), vp(l2), algebraic, in that order."""
+    sc = syn.make_scene(n_views=10, n_segs=80, n_neighbors=4, seed=62)
+    bpts, sfm = syn.make_bipartites(sc, seed=2)
+    vps = syn.make_vp_results(sc, seed=2)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    cfg.update(disable_one_point_triangulation=True, use_vp=True)
+    T, O = _run_both(oracle, sc, cfg, bpts, sfm, vps=vps)
+    _compare(T, O)
+
+
+def test_points_switches_and_errors(gpu_lib, oracle):
+    from limap_amd import triangulation as tri
+    sc = syn.make_scene(n_views=6, n_segs=40, n_neighbors=3, seed=63)
+    bpts, sfm = syn.make_bipartites(sc, seed=3)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    # both point proposals disabled: the bipartites are ignored
+    cfg.update(disable_one_point_triangulation=True, disable_many_points_triangulation=True)
+    T, O = _run_both(oracle, sc, cfg, bpts, sfm)
+    g, o = T.context().get_all_tris(), O.get_all_tris()
+    assert np.array_equal(g["off"], o["off"]) and np.array_equal(g["line"], o["line"])
+    # the one-point proposal is not implemented: it has to be switched off explicitly
+    cfg.update(disable_one_point_triangulation=False, disable_many_points_triangulation=False)
+    T = tri.GlobalLineTriangulator(cfg)
+    T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+    T.SetBipartites2d(bpts)
+    T.TriangulateImage(int(sc.img_ids[0]), sc.matches_of(int(sc.img_ids[0])))
+    with pytest.raises((RuntimeError, ValueError), match="one-point"):
+        T.ComputeLineTracks()
+    # a shared point3D id that is not among the SfM points: std::map::at throws in the reference
+    cfg.update(disable_one_point_triangulation=True)
+    T = tri.GlobalLineTriangulator(cfg)
+    T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+    T.SetBipartites2d(bpts)
+    T.SetSfMPoints({k: v for k, v in list(sfm.items())[:3]})
+    for i in sc.img_ids:
+        T.TriangulateImage(int(i), sc.matches_of(int(i)))
+    with pytest.raises(RuntimeError, match="point3D_id"):
+        T.ComputeLineTracks()
+    # wrong number of lines
+    bad = dict(bpts)
+    k = int(sc.img_ids[1])
+    bad[k] = dict(bad[k], line_points=bad[k]["line_points"][:-1])
+    with pytest.raises((RuntimeError, ValueError), match="lines"):
+        T.SetBipartites2d(bad)
