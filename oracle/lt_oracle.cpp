@@ -657,6 +657,185 @@ static Line3d triangulate_line_with_infinite_line(const Line2d &l1, const Camera
   return Line3d(pstart, pend, 1.0, z_start, z_end);
 }
 
+// ---------------------------------------------------------------------------------------------
+// triangulate_line_with_one_point (functions.cc:325-383 + solvers/triangulation).
+// The reference's solver is ~600 lines of machine-generated coefficients of a quartic in a Lagrange
+// multiplier, solved by PoseLib's univariate::solve_quartic_real (a dependency that is not in the tree).
+// It is NOT copied here; the same optimisation problem is restated from its definition (the comments at
+// the end of that file): in the 2D coordinates of plane 1, with p1, p2 the unit directions of l1's
+// endpoint rays, p the known point and (lx, ly, lz) the trace of plane 2,
+//     minimise (l . x1)^2 + (l . x2)^2   over x1 = lambda1 p1, x2 = lambda2 p2,
+//     subject to x1, x2, p collinear, lambda1 > 0, lambda2 > 0.
+// Collinearity reads lambda1 lambda2 c - lambda1 a - lambda2 b = 0 with c = p1 x p2, a = p1 x p, b = p x p2,
+// so lambda2 = a u / (c u - b), u = lambda1; the stationary points of the objective in u are the real roots
+// of the quartic  alpha1 (alpha1 u + lz) w^3 - alpha2 a b (alpha2 a u + lz w) = 0,  w = c u - b,
+// alpha_k = lx p_kx + ly p_ky, and the solution is the admissible one with the smallest objective -- the
+// same stationary points and the same selection rule as the reference, up to rounding (parity for this
+// proposal is therefore a tolerance, like the SVD stand-in of the line fit).
+// ---------------------------------------------------------------------------------------------
+static int real_roots_cubic_monic(double A, double B, double C, double out[3]) {  // z^3 + A z^2 + B z + C
+  const double sh = A / 3.0;
+  const double P = B - A * A / 3.0;
+  const double Q = 2.0 * A * A * A / 27.0 - A * B / 3.0 + C;
+  const double disc = Q * Q / 4.0 + P * P * P / 27.0;
+  if (disc > 0) {
+    const double sq = std::sqrt(disc);
+    const double u = std::cbrt(-Q / 2.0 + sq), v = std::cbrt(-Q / 2.0 - sq);
+    out[0] = u + v - sh;
+    return 1;
+  }
+  if (P == 0.0) {
+    out[0] = -sh;
+    return 1;
+  }
+  const double m = 2.0 * std::sqrt(-P / 3.0);
+  double arg = 3.0 * Q / (P * m);
+  arg = arg < -1.0 ? -1.0 : (arg > 1.0 ? 1.0 : arg);
+  const double th = std::acos(arg) / 3.0;
+  for (int k = 0; k < 3; ++k) out[k] = m * std::cos(th - 2.0 * M_PI * k / 3.0) - sh;
+  return 3;
+}
+
+static int real_roots_quadratic(double a, double b, double c, double out[2]) {  // a x^2 + b x + c, a != 0
+  const double d = b * b - 4.0 * a * c;
+  if (d < 0) return 0;
+  const double sq = std::sqrt(d);
+  const double q = -0.5 * (b + (b >= 0 ? sq : -sq));
+  int n = 0;
+  out[n++] = q / a;
+  if (q != 0.0) out[n++] = c / q;
+  else out[n++] = 0.0;
+  return n;
+}
+
+// real roots of A4 x^4 + ... + A0 (degree detected relative to the largest coefficient), Newton-polished
+static int real_roots_poly4(const double Ain[5], double out[4]) {
+  double A[5];
+  double mx = 0;
+  for (int k = 0; k < 5; ++k) mx = std::max(mx, std::abs(Ain[k]));
+  if (!(mx > 0) || !std::isfinite(mx)) return 0;
+  for (int k = 0; k < 5; ++k) A[k] = Ain[k] / mx;
+  int deg = 4;
+  while (deg > 0 && std::abs(A[deg]) < 1e-13) --deg;
+  int n = 0;
+  if (deg == 0) return 0;
+  if (deg == 1) {
+    out[n++] = -A[0] / A[1];
+  } else if (deg == 2) {
+    n = real_roots_quadratic(A[2], A[1], A[0], out);
+  } else if (deg == 3) {
+    n = real_roots_cubic_monic(A[2] / A[3], A[1] / A[3], A[0] / A[3], out);
+  } else {
+    const double a = A[3] / A[4], b = A[2] / A[4], c = A[1] / A[4], d = A[0] / A[4];
+    const double p = b - 3.0 * a * a / 8.0;
+    const double q = c - a * b / 2.0 + a * a * a / 8.0;
+    const double r = d - a * c / 4.0 + a * a * b / 16.0 - 3.0 * a * a * a * a / 256.0;
+    double ys[4];
+    int ny = 0;
+    if (std::abs(q) < 1e-14 * (1.0 + std::abs(p) + std::abs(r))) {  // biquadratic
+      double t[2];
+      int nt = real_roots_quadratic(1.0, p, r, t);
+      for (int k = 0; k < nt; ++k)
+        if (t[k] >= 0) {
+          const double sq = std::sqrt(t[k]);
+          ys[ny++] = sq;
+          ys[ny++] = -sq;
+        }
+    } else {
+      double z[3];
+      int nz = real_roots_cubic_monic(2.0 * p, p * p - 4.0 * r, -q * q, z);
+      double z0 = z[0];
+      for (int k = 1; k < nz; ++k) z0 = std::max(z0, z[k]);
+      if (z0 > 0) {
+        const double sgm = std::sqrt(z0);
+        double t[2];
+        int nt = real_roots_quadratic(1.0, sgm, (p + z0 - q / sgm) / 2.0, t);
+        for (int k = 0; k < nt; ++k) ys[ny++] = t[k];
+        nt = real_roots_quadratic(1.0, -sgm, (p + z0 + q / sgm) / 2.0, t);
+        for (int k = 0; k < nt; ++k) ys[ny++] = t[k];
+      }
+    }
+    for (int k = 0; k < ny; ++k) out[n++] = ys[k] - a / 4.0;
+  }
+  for (int k = 0; k < n; ++k) {  // Newton polish on the scaled polynomial
+    double x = out[k];
+    for (int it = 0; it < 3; ++it) {
+      const double f = (((A[4] * x + A[3]) * x + A[2]) * x + A[1]) * x + A[0];
+      const double df = ((4.0 * A[4] * x + 3.0 * A[3]) * x + 2.0 * A[2]) * x + A[1];
+      if (df == 0.0 || !std::isfinite(f / df)) break;
+      x = x - f / df;
+    }
+    out[k] = x;
+  }
+  return n;
+}
+
+static std::pair<double, double> solve_line_with_one_point(double lx, double ly, double lz, V2 p, V2 p1, V2 p2) {
+  const double al1 = lx * p1.x + ly * p1.y, al2 = lx * p2.x + ly * p2.y;
+  const double c = p1.x * p2.y - p1.y * p2.x, a = p1.x * p.y - p1.y * p.x, b = p.x * p2.y - p.y * p2.x;
+  double A[5];
+  A[4] = al1 * al1 * c * c * c;
+  A[3] = al1 * (lz * c * c * c - 3.0 * al1 * c * c * b);
+  A[2] = al1 * (3.0 * al1 * c * b * b - 3.0 * lz * c * c * b);
+  A[1] = al1 * (3.0 * lz * c * b * b - al1 * b * b * b) - al2 * a * b * (al2 * a + lz * c);
+  A[0] = lz * b * b * (al2 * a - al1 * b);
+  double roots[4];
+  const int n = real_roots_poly4(A, roots);
+  std::pair<double, double> best{-1.0, -1.0};
+  double best_err = std::numeric_limits<double>::max();
+  for (int k = 0; k < n; ++k) {
+    const double u = roots[k];
+    const double w = c * u - b;
+    if (w == 0.0) continue;
+    const double lam2 = a * u / w;
+    if (!(u > 0) || !(lam2 > 0)) continue;  // cheirality (lambda <= 0 is skipped in the reference)
+    const double e1 = al1 * u + lz, e2 = al2 * lam2 + lz;
+    const double err = e1 * e1 + e2 * e2;
+    if (err < best_err) {
+      best_err = err;
+      best = {u, lam2};
+    }
+  }
+  return best;
+}
+
+// Triangulation with a known point, asymmetric perspective to (view1, l1) -- functions.cc:325-383
+static Line3d triangulate_line_with_one_point(const Line2d &l1, const CameraView &view1, const Line2d &l2,
+                                              const CameraView &view2, const V3 &point) {
+  V3 n1 = getNormalDirection(l1, view1);
+  V3 C1 = view1.pose.center();
+  V3 p = point - n1 * dot(n1, point - C1);
+  V3 v1s = view1.ray_direction(l1.start);
+  V3 v1e = view1.ray_direction(l1.end);
+  V3 n2 = getNormalDirection(l2, view2);
+  double alpha = (-1) * dot(n2, view2.pose.center());
+  // plane-1 frame: columns v1s, the part of v1e orthogonal to it, their cross product
+  V3 r0 = v1s;
+  V3 r1 = normalized(v1e - v1s * dot(v1s, v1e));
+  V3 r2 = normalized(cross(r0, r1));
+  V3 t = C1;
+  auto Rt = [&](const V3 &x) { return V3{dot(r0, x), dot(r1, x), dot(r2, x)}; };
+  V3 v2_t = Rt(v1e);
+  V3 p_t = Rt(p - C1);
+  V3 n2_t = Rt(n2);
+  double alpha_t = alpha + dot(n2, t);
+  V2 input_p{p_t.x, p_t.y};
+  V2 input_v1 = normalized(V2{1.0, 0.0});
+  V2 input_v2 = normalized(V2{v2_t.x, v2_t.y});
+  auto res = solve_line_with_one_point(n2_t.x, n2_t.y, alpha_t, input_p, input_v1, input_v2);
+  if (res.first < 0 || res.second < 0) return kSentinel();
+  V2 ls2 = input_v1 * res.first, le2 = input_v2 * res.second;
+  V3 lstart = r0 * ls2.x + r1 * ls2.y + t;  // R * (x, y, 0) + t
+  V3 lend = r0 * le2.x + r1 * le2.y + t;
+  double z_start = view1.pose.projdepth(lstart);
+  double z_end = view1.pose.projdepth(lend);
+  if (z_start < EPS || z_end < EPS) return kSentinel();
+  double d21 = view2.pose.projdepth(lstart);
+  double d22 = view2.pose.projdepth(lend);
+  if (d21 < EPS || d22 < EPS) return kSentinel();
+  return Line3d(lstart, lend, 1.0, z_start, z_end);
+}
+
 // Triangulation with known direction, asymmetric perspective to (view1, l1) -- functions.cc:385-442
 static Line3d triangulate_line_with_direction(const Line2d &l1, const CameraView &view1, const Line2d &l2,
                                               const CameraView &view2, const V3 &direction) {
@@ -1204,11 +1383,9 @@ void Triangulator::triangulateOneNode(int img_id, int line_id) {  // base_line_t
         results[conn_id].push_back(t);
       }
     };
-    // Step 1.1: many points -> fit a line through the shared 3D points (lines 183-236).  Step 1.2 (the
-    // one-point quartic proposal, solvers/triangulation) is NOT restated: it must be disabled.
+    // Step 1.1: many points -> fit a line through the shared 3D points (lines 183-236).  Step 1.2: one
+    // known point (lines 238-248), through a restatement of the optimisation problem of the solver.
     if (use_pointsfm_ && (!cfg.disable_many_points_triangulation || !cfg.disable_one_point_triangulation)) {
-      if (!cfg.disable_one_point_triangulation)
-        throw std::runtime_error("one-point triangulation is not restated in the oracle: set disable_one_point_triangulation");
       std::map<int, Point2d> points1;
       std::set<int> set1;
       std::map<int, std::pair<V2, V2>> points_info;
@@ -1243,6 +1420,10 @@ void Triangulator::triangulateOneNode(int img_id, int line_id) {  // base_line_t
         V3 direc = normalized(principal_direction(epoints));
         InfiniteLine3d inf_line(center, direc);
         push(triangulate_line_with_infinite_line(l1, view1, inf_line));
+      }
+      // Step 1.2: one point triangulation (lines 238-248)
+      if (!cfg.disable_one_point_triangulation && !points.empty()) {
+        for (const V3 &pt : points) push(triangulate_line_with_one_point(l1, view1, l2, view2, pt));
       }
     }
 

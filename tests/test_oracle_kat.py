@@ -351,3 +351,61 @@ def test_kat_many_points_triangulation(oracle):
     O.SetBipartites2d(bp1); O.SetSfMPoints(pts3)
     O.TriangulateImage(7, {9: np.array([[0, 0]], np.int32)})
     assert O.get_all_tris()["off"][-1] == 0
+
+
+def test_kat_one_point_triangulation(oracle):
+    """KAT (xiv): one-point proposal.  Noise-free: a 3D point exactly on the GT segment -- the line through
+    its projection onto plane 1 that meets l1's endpoint rays where they cross plane 2 has zero error, so
+    the minimiser is the GT segment itself.  Also checks the solver on a perturbed point against a brute-force
+    scan of the same objective."""
+    import numpy as np
+    from limap_amd import synthetic as syn
+    K4 = np.array([500.0, 500.0, 320.0, 240.0])
+    q = np.array([[1.0, 0, 0, 0], [1.0, 0, 0, 0]])
+    t = np.array([[0.0, 0, 0], [-0.6, -0.25, 0.0]])
+    P, Q = np.array([-0.4, 0.1, 4.0]), np.array([0.5, 0.35, 5.0])
+
+    def proj(X, tt):
+        Xc = X + tt
+        return np.array([K4[0] * Xc[0] / Xc[2] + K4[2], K4[1] * Xc[1] / Xc[2] + K4[3]])
+    segs = np.array([[*proj(P, t[0]), *proj(Q, t[0])], [*proj(P, t[1]), *proj(Q, t[1])]])
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    cfg.update(disable_algebraic_triangulation=True, disable_many_points_triangulation=True, min_num_outer_edges=0)
+    for s_on_line, off in ((0.3, 0.0), (0.6, 0.0), (0.5, 0.02)):
+        X = P + s_on_line * (Q - P) + off * np.array([0.3, -1.0, 0.2])
+        bp = {}
+        for n, img in enumerate((7, 9)):
+            bp[img] = dict(point_ids=[0], xy=[proj(X, t[n])], point3D_ids=[42], line_points=[[0]])
+        O = oracle.OracleTriangulator(cfg, faithful=True)
+        O.Init([7, 9], np.tile(K4, (2, 1)), q, t, [0, 1, 2], segs)
+        O.SetBipartites2d(bp); O.SetSfMPoints({42: X})
+        O.TriangulateImage(7, {9: np.array([[0, 0]], np.int32)})
+        a = O.get_all_tris()
+        assert a["off"][1] - a["off"][0] == 1
+        s3, e3 = a["line"][0, :3], a["line"][0, 3:6]
+        if off == 0.0:
+            np.testing.assert_allclose(s3, P, rtol=0, atol=1e-8)
+            np.testing.assert_allclose(e3, Q, rtol=0, atol=1e-8)
+        else:
+            # brute force over lambda1: the endpoints lie on l1's rays (camera 1 at the origin, identity pose),
+            # are collinear with the point's projection onto plane 1, and minimise the summed squared distance
+            # to plane 2
+            r1, r2 = P / np.linalg.norm(P), Q / np.linalg.norm(Q)
+            n1 = np.cross(r1, r2); n1 /= np.linalg.norm(n1)
+            Xp = X - n1 * (n1 @ X)
+            C2 = -t[1]
+            n2 = np.cross(P - C2, Q - C2); n2 /= np.linalg.norm(n2)
+
+            def err_of(l1):
+                A = l1 * r1
+                # B on ray 2 collinear with A and Xp:  solve A + s (Xp - A) = l2 r2 in plane 1
+                M = np.stack([Xp - A, -r2], 1)
+                sol, *_ = np.linalg.lstsq(M, -A, rcond=None)
+                l2 = sol[1]
+                B = l2 * r2
+                return (n2 @ (A - C2)) ** 2 + (n2 @ (B - C2)) ** 2, l2
+            l1s = np.linspace(0.5 * np.linalg.norm(P), 1.5 * np.linalg.norm(P), 20001)
+            errs = np.array([err_of(x)[0] if err_of(x)[1] > 0 else np.inf for x in l1s])
+            best = l1s[int(np.argmin(errs))]
+            assert abs(np.linalg.norm(s3) - best) < 2 * (l1s[1] - l1s[0])
+            assert errs.min() >= err_of(np.linalg.norm(s3))[0] - 1e-12
