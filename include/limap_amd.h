@@ -98,8 +98,8 @@ int lt_init_vp(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *la
  * (structures::PL_Bipartite2d::neighbor_points).  SfM points: point3D_id -> xyz; with none given the shared
  * points are triangulated from the two views.  Enables the many-points proposal of triangulateOneNode
  * (base_line_triangulator.cc:183-236: line fit through the shared 3D points + Pluecker projection) in
- * matched mode; the one-point proposal (:238-248) is not implemented --
- * cfg.disable_one_point_triangulation must be set.  Call after lt_init. */
+ * matched mode, and the one-point proposal (:238-248, one candidate per shared point, at most 64 per
+ * connection; see lt_fn_triangulate_line_with_one_point for the solver).  Call after lt_init. */
 int lt_set_bipartites(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *pt_off, const int32_t *pt_ids,
                       const double *pt_xy, const int32_t *pt_p3d, const int64_t *line_off, const int64_t *lp_off,
                       const int32_t *lp_ptids);
@@ -247,6 +247,12 @@ int lt_fn_triangulate_point(lt_ctx *ctx, const double p1[2], const double cam1[1
 /* triangulate_line_with_direction(l1, view1, l2, view2, direction): functions.cc:385-442 */
 int lt_fn_triangulate_line_with_direction(lt_ctx *ctx, const double seg1[4], const double cam1[11],
                                           const double seg2[4], const double cam2[11], const double direction[3],
+                                          double out_line10[10]);
+/* triangulate_line_with_one_point(l1, view1, l2, view2, point): functions.cc:325-383.  The reference's
+ * solver (solvers/triangulation, a generated quartic + PoseLib's root finder) is restated from the
+ * optimisation problem it solves, so this proposal agrees to rounding, not bit for bit. */
+int lt_fn_triangulate_line_with_one_point(lt_ctx *ctx, const double seg1[4], const double cam1[11],
+                                          const double seg2[4], const double cam2[11], const double point[3],
                                           double out_line10[10]);
 int lt_fn_compute_fundamental_matrix(lt_ctx *ctx, const double cam1[11], const double cam2[11],
                                      double out[9]);

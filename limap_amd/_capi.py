@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "lt_ts_filter_by_sensitivity", "lt_ts_filter_by_overlap", "lt_ts_remerge_once", "lt_get_stats", "lt_get_timers",
     "lt_release_cached_memory",
     "lt_fn_get_normal_direction", "lt_fn_get_direction_from_vp", "lt_fn_triangulate_point",
-    "lt_fn_triangulate_line_with_direction", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
+    "lt_fn_triangulate_line_with_direction", "lt_fn_triangulate_line_with_one_point", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
     "lt_fn_triangulate_line",
 ]
 
@@ -169,6 +169,7 @@ def load_library():
     L.lt_fn_get_direction_from_vp.argtypes = [vp, dp, dp, dp]
     L.lt_fn_triangulate_point.argtypes = [vp, dp, dp, dp, dp, dp, C.POINTER(C.c_int)]
     L.lt_fn_triangulate_line_with_direction.argtypes = [vp, dp, dp, dp, dp, dp, dp]
+    L.lt_fn_triangulate_line_with_one_point.argtypes = [vp, dp, dp, dp, dp, dp, dp]
     L.lt_fn_compute_fundamental_matrix.argtypes = [vp, dp, dp, dp]
     L.lt_fn_compute_epipolar_IoU.argtypes = [vp, dp, dp, dp, dp, dp]
     L.lt_fn_triangulate_line.argtypes = [vp, dp, dp, dp, dp, C.c_int, dp]
@@ -466,6 +467,14 @@ class Context:
         self.chk(self.L.lt_fn_triangulate_line_with_direction(self.h, ptr(f64(seg1), C.c_double),
                                                               ptr(f64(cam1), C.c_double), ptr(f64(seg2), C.c_double),
                                                               ptr(f64(cam2), C.c_double), ptr(f64(direction), C.c_double),
+                                                              ptr(out, C.c_double)))
+        return out
+
+    def fn_triangulate_line_with_one_point(self, seg1, cam1, seg2, cam2, point):
+        out = np.zeros(10)
+        self.chk(self.L.lt_fn_triangulate_line_with_one_point(self.h, ptr(f64(seg1), C.c_double),
+                                                              ptr(f64(cam1), C.c_double), ptr(f64(seg2), C.c_double),
+                                                              ptr(f64(cam2), C.c_double), ptr(f64(point), C.c_double),
                                                               ptr(out, C.c_double)))
         return out
 

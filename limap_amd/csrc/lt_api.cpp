@@ -40,7 +40,8 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, unsigned *st_row,
                       unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3,
                       const double *seg_vp, const unsigned char *seg_has_vp, const long long *seg_pt_off,
-                      const void *seg_pts, const double *sfm_xyz, int *err_flag);
+                      const void *seg_pts, const double *sfm_xyz, int *err_flag, int many_on, int one_on,
+                      int mult);
 size_t seg_point_bytes();
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
@@ -676,6 +677,9 @@ int lt_set_bipartites(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int6
     }
   }
   ctx->h_seg_pt_off[(size_t)ctx->G] = (long long)(ctx->h_seg_pts.size() / 3);
+  ctx->max_seg_pts = 0;
+  for (long long g = 0; g < ctx->G; ++g)
+    ctx->max_seg_pts = std::max(ctx->max_seg_pts, ctx->h_seg_pt_off[(size_t)g + 1] - ctx->h_seg_pt_off[(size_t)g]);
   ctx->pts_ready = true;
   ctx->pts_dirty = true;
   ctx->uploaded = ctx->ran = false;
@@ -1113,7 +1117,8 @@ int lt_run_device(lt_ctx *ctx) {
   }
   GenCfg gcfg = make_gen(ctx);
   // like the VP proposals, the point-guided ones do not depend on the algebraic gates
-  if (ctx->pts_ready && !ctx->cfg.disable_many_points_triangulation) gcfg.force_undecided = 1;
+  if (ctx->pts_ready && (!ctx->cfg.disable_many_points_triangulation || !ctx->cfg.disable_one_point_triangulation))
+    gcfg.force_undecided = 1;
   const ScoreCfg scfg = make_score(ctx);
   ENSURE(ctx, ctx->d_err, sizeof(int));
   ENSURE(ctx, ctx->d_pair_counter, 8);
@@ -1141,12 +1146,15 @@ int lt_run_device(lt_ctx *ctx) {
     // point-guided proposals (SetBipartites2d): the many-points line fit; the one-point quartic proposal is
     // not implemented and has to be switched off
     const bool pts_any = ctx->pts_ready && (!ctx->cfg.disable_many_points_triangulation || !ctx->cfg.disable_one_point_triangulation);
-    if (pts_any && !ctx->cfg.disable_one_point_triangulation)
-      return fail(ctx, LT_ERR_ARGUMENT, "the one-point proposal (triangulate_line_with_one_point) is not implemented: set "
-                                        "disable_one_point_triangulation");
-    const bool pts_on = pts_any && !ctx->cfg.disable_many_points_triangulation;
-    const int mult = (vp_on || pts_on) ? 4 : 1;
-    if (mult > 1 && 4 * P >= (1ll << 32) - 1) return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch for the extra proposals");
+    const bool many_on = pts_any && !ctx->cfg.disable_many_points_triangulation;
+    const bool one_on = pts_any && !ctx->cfg.disable_one_point_triangulation;
+    const bool pts_on = pts_any;
+    // staging slots per match row: many-points, one candidate per shared point (at most the most points any
+    // segment has, capped at 64 -- the kernel flags a connection with more), vp(l1), vp(l2), algebraic
+    int mult = (vp_on || pts_on) ? 4 : 1;
+    if (one_on) mult += (int)std::min<long long>(ctx->max_seg_pts, 64);
+    if (mult > 1 && (long long)mult * P >= (1ll << 32) - 1)
+      return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch for the extra proposals");
     ENSURE(ctx, ctx->d_st_c, sizeof(Cand) * Pn * mult); ENSURE(ctx, ctx->d_st_l, sizeof(CandLite) * Pn * mult);
     ENSURE(ctx, ctx->d_st_key, 4 * Pn * mult);
     ENSURE(ctx, ctx->d_wave_count, 4 * (size_t)(n_waves + 1));
@@ -1185,7 +1193,8 @@ int lt_run_device(lt_ctx *ctx) {
                        vp_on ? ctx->d_seg_vp.as<double>() : nullptr,
                        vp_on ? ctx->d_seg_has_vp.as<unsigned char>() : nullptr,
                        pts_on ? ctx->d_seg_pt_off.as<long long>() : nullptr, pts_on ? ctx->d_seg_pts.p : nullptr,
-                       (pts_on && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr, ctx->d_err.as<int>());
+                       (pts_on && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr, ctx->d_err.as<int>(),
+                       many_on ? 1 : 0, one_on ? 1 : 0, mult);
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
     long long *hC = ctx->h_pinned;
@@ -1358,6 +1367,8 @@ int lt_run_device(lt_ctx *ctx) {
     ctx->stat_pairs_eval = (long long)pe;
   }
   ctx->stat_survivors = -1;  // summed on demand (lt_get_timers)
+  if (derr == 3)
+    return fail(ctx, LT_ERR_RUNTIME, "the one-point proposal supports at most 64 shared points per connection");
   if (derr == 2)
     return fail(ctx, LT_ERR_RUNTIME, "map::at: a point shared by two lines has a point3D_id that is not among the SfM points");
   if (derr != 0) return fail(ctx, LT_ERR_RUNTIME, "IndexError! Out-of-index matches detected on the device");
@@ -1910,7 +1921,7 @@ int lt_get_timers(lt_ctx *ctx, double out[24]) {
 
 // ---- free functions ----
 static int fn_query(lt_ctx *ctx, const double *seg1, const double *cam1, const double *seg2, const double *cam2,
-                    int by_endpoints, double out40[40], const double *v3 = nullptr, const double *p1 = nullptr,
+                    int by_endpoints, double out50[50], const double *v3 = nullptr, const double *p1 = nullptr,
                     const double *p2 = nullptr) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   double in[37] = {0};
@@ -1919,31 +1930,31 @@ static int fn_query(lt_ctx *ctx, const double *seg1, const double *cam1, const d
   if (p1) std::memcpy(in + 33, p1, 16);
   if (p2) std::memcpy(in + 35, p2, 16);
   DevBuf din, dout;
-  ENSURE(ctx, din, sizeof(in)); ENSURE(ctx, dout, 40 * 8);
+  ENSURE(ctx, din, sizeof(in)); ENSURE(ctx, dout, 50 * 8);
   HIPCHK(ctx, hipMemcpyAsync(din.p, in, sizeof(in), hipMemcpyHostToDevice, ctx->stream));
   launch_fn_query(ctx->stream, din.as<double>(), by_endpoints, dout.as<double>());
-  HIPCHK(ctx, hipMemcpyAsync(out40, dout.p, 40 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out50, dout.p, 50 * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   din.release(); dout.release();
   return LT_OK;
 }
 
 int lt_fn_get_normal_direction(lt_ctx *ctx, const double seg[4], const double cam[11], double out[3]) {
-  double o[40];
+  double o[50];
   int rc = fn_query(ctx, seg, cam, seg, cam, 0, o);
   if (rc) return rc;
   std::memcpy(out, o, 24);
   return LT_OK;
 }
 int lt_fn_get_direction_from_vp(lt_ctx *ctx, const double vp[3], const double cam[11], double out[3]) {
-  double o[40], seg[4] = {0, 0, 1, 1};
+  double o[50], seg[4] = {0, 0, 1, 1};
   int rc = fn_query(ctx, seg, cam, seg, cam, 0, o, vp);
   if (rc) return rc;
   std::memcpy(out, o + 23, 24);
   return LT_OK;
 }
 int lt_fn_compute_fundamental_matrix(lt_ctx *ctx, const double cam1[11], const double cam2[11], double out[9]) {
-  double o[40], seg[4] = {0, 0, 1, 1};
+  double o[50], seg[4] = {0, 0, 1, 1};
   int rc = fn_query(ctx, seg, cam1, seg, cam2, 0, o);
   if (rc) return rc;
   std::memcpy(out, o + 3, 72);
@@ -1951,7 +1962,7 @@ int lt_fn_compute_fundamental_matrix(lt_ctx *ctx, const double cam1[11], const d
 }
 int lt_fn_compute_epipolar_IoU(lt_ctx *ctx, const double seg1[4], const double cam1[11], const double seg2[4],
                                const double cam2[11], double *out) {
-  double o[40];
+  double o[50];
   int rc = fn_query(ctx, seg1, cam1, seg2, cam2, 0, o);
   if (rc) return rc;
   *out = o[12];
@@ -1959,7 +1970,7 @@ int lt_fn_compute_epipolar_IoU(lt_ctx *ctx, const double seg1[4], const double c
 }
 int lt_fn_triangulate_point(lt_ctx *ctx, const double p1[2], const double cam1[11], const double p2[2],
                             const double cam2[11], double out[3], int *ok) {
-  double o[40], seg[4] = {0, 0, 1, 1};
+  double o[50], seg[4] = {0, 0, 1, 1};
   int rc = fn_query(ctx, seg, cam1, seg, cam2, 0, o, nullptr, p1, p2);
   if (rc) return rc;
   std::memcpy(out, o + 26, 24);
@@ -1968,7 +1979,7 @@ int lt_fn_triangulate_point(lt_ctx *ctx, const double p1[2], const double cam1[1
 }
 int lt_fn_triangulate_line(lt_ctx *ctx, const double seg1[4], const double cam1[11], const double seg2[4],
                            const double cam2[11], int by_endpoints, double out_line10[10]) {
-  double o[40];
+  double o[50];
   int rc = fn_query(ctx, seg1, cam1, seg2, cam2, by_endpoints, o);
   if (rc) return rc;
   std::memcpy(out_line10, o + 13, 80);
@@ -1977,10 +1988,19 @@ int lt_fn_triangulate_line(lt_ctx *ctx, const double seg1[4], const double cam1[
 int lt_fn_triangulate_line_with_direction(lt_ctx *ctx, const double seg1[4], const double cam1[11],
                                           const double seg2[4], const double cam2[11], const double direction[3],
                                           double out_line10[10]) {
-  double o[40];
+  double o[50];
   int rc = fn_query(ctx, seg1, cam1, seg2, cam2, 0, o, direction);
   if (rc) return rc;
   std::memcpy(out_line10, o + 30, 80);
+  return LT_OK;
+}
+int lt_fn_triangulate_line_with_one_point(lt_ctx *ctx, const double seg1[4], const double cam1[11],
+                                          const double seg2[4], const double cam2[11], const double point[3],
+                                          double out_line10[10]) {
+  double o[50];
+  int rc = fn_query(ctx, seg1, cam1, seg2, cam2, 0, o, point);
+  if (rc) return rc;
+  std::memcpy(out_line10, o + 40, 80);
   return LT_OK;
 }
 

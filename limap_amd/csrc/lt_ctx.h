@@ -201,6 +201,7 @@ struct lt_ctx {
   std::vector<int> h_sfm_ids;
   DevBuf d_seg_pts, d_seg_pt_off, d_sfm_xyz;
   bool pts_ready = false, sfm_given = false, pts_dirty = false;
+  long long max_seg_pts = 0;  // most point records of any segment (staging bound of the one-point proposal)
   bool vp_ready = false;  // InitVPResults was called for the current scene
   int n_chunks = 0;
   long long cand_cap = 0;

@@ -488,6 +488,196 @@ static __device__ __forceinline__ bool points_candidate(const GenCfg &cfg, const
   return true;
 }
 
+// ---- one-point proposal (triangulate_line_with_one_point, functions.cc:325-383) -------------------------
+// The reference's solver (solvers/triangulation: generated coefficients of a quartic in a Lagrange
+// multiplier + PoseLib's root finder) is not copied; the optimisation problem it solves is restated:
+// in plane-1 coordinates, p1 / p2 unit directions of l1's endpoint rays, p the known point, (lx, ly, lz)
+// the trace of plane 2:  minimise (l.x1)^2 + (l.x2)^2, x1 = lambda1 p1, x2 = lambda2 p2 collinear with p,
+// lambda > 0.  With c = p1 x p2, a = p1 x p, b = p x p2 collinearity gives lambda2 = a u / (c u - b),
+// u = lambda1, and the stationary points are the real roots of
+//     alpha1 (alpha1 u + lz) w^3 - alpha2 a b (alpha2 a u + lz w) = 0,   w = c u - b.
+static __device__ __forceinline__ int roots_cubic_monic(double A, double B, double C, double *out) {
+  const double sh = A / 3.0;
+  const double P = B - A * A / 3.0;
+  const double Q = 2.0 * A * A * A / 27.0 - A * B / 3.0 + C;
+  const double disc = Q * Q / 4.0 + P * P * P / 27.0;
+  if (disc > 0) {
+    const double sq = sqrt(disc);
+    out[0] = cbrt(-Q / 2.0 + sq) + cbrt(-Q / 2.0 - sq) - sh;
+    return 1;
+  }
+  if (P == 0.0) {
+    out[0] = -sh;
+    return 1;
+  }
+  const double m = 2.0 * sqrt(-P / 3.0);
+  double arg = 3.0 * Q / (P * m);
+  arg = arg < -1.0 ? -1.0 : (arg > 1.0 ? 1.0 : arg);
+  const double th = acos(arg) / 3.0;
+  out[0] = m * cos(th) - sh;
+  out[1] = m * cos(th - 2.0 * kPi / 3.0) - sh;
+  out[2] = m * cos(th - 4.0 * kPi / 3.0) - sh;
+  return 3;
+}
+static __device__ __forceinline__ int roots_quadratic(double a, double b, double c, double *out) {
+  const double d = b * b - 4.0 * a * c;
+  if (d < 0) return 0;
+  const double sq = sqrt(d);
+  const double q = -0.5 * (b + (b >= 0 ? sq : -sq));
+  out[0] = q / a;
+  out[1] = q != 0.0 ? c / q : 0.0;
+  return 2;
+}
+static __device__ int roots_poly4(const double *Ain, double *out) {
+  double A[5];
+  double mx = 0;
+  for (int k = 0; k < 5; ++k) mx = fmax(mx, fabs(Ain[k]));
+  if (!(mx > 0) || !isfinite(mx)) return 0;
+  for (int k = 0; k < 5; ++k) A[k] = Ain[k] / mx;
+  int deg = 4;
+  while (deg > 0 && fabs(A[deg]) < 1e-13) --deg;
+  int n = 0;
+  if (deg == 0) return 0;
+  if (deg == 1) {
+    out[n++] = -A[0] / A[1];
+  } else if (deg == 2) {
+    n = roots_quadratic(A[2], A[1], A[0], out);
+  } else if (deg == 3) {
+    n = roots_cubic_monic(A[2] / A[3], A[1] / A[3], A[0] / A[3], out);
+  } else {
+    const double a = A[3] / A[4], b = A[2] / A[4], c = A[1] / A[4], d = A[0] / A[4];
+    const double p = b - 3.0 * a * a / 8.0;
+    const double q = c - a * b / 2.0 + a * a * a / 8.0;
+    const double r = d - a * c / 4.0 + a * a * b / 16.0 - 3.0 * a * a * a * a / 256.0;
+    double ys[4];
+    int ny = 0;
+    if (fabs(q) < 1e-14 * (1.0 + fabs(p) + fabs(r))) {
+      double t[2];
+      const int nt = roots_quadratic(1.0, p, r, t);
+      for (int k = 0; k < nt; ++k)
+        if (t[k] >= 0) {
+          const double sq = sqrt(t[k]);
+          ys[ny++] = sq;
+          ys[ny++] = -sq;
+        }
+    } else {
+      double z[3];
+      const int nz = roots_cubic_monic(2.0 * p, p * p - 4.0 * r, -q * q, z);
+      double z0 = z[0];
+      for (int k = 1; k < nz; ++k) z0 = fmax(z0, z[k]);
+      if (z0 > 0) {
+        const double sgm = sqrt(z0);
+        double t[2];
+        int nt = roots_quadratic(1.0, sgm, (p + z0 - q / sgm) / 2.0, t);
+        for (int k = 0; k < nt; ++k) ys[ny++] = t[k];
+        nt = roots_quadratic(1.0, -sgm, (p + z0 + q / sgm) / 2.0, t);
+        for (int k = 0; k < nt; ++k) ys[ny++] = t[k];
+      }
+    }
+    for (int k = 0; k < ny; ++k) out[n++] = ys[k] - a / 4.0;
+  }
+  for (int k = 0; k < n; ++k) {
+    double x = out[k];
+    for (int it = 0; it < 3; ++it) {
+      const double f = (((A[4] * x + A[3]) * x + A[2]) * x + A[1]) * x + A[0];
+      const double df = ((4.0 * A[4] * x + 3.0 * A[3]) * x + 2.0 * A[2]) * x + A[1];
+      if (df == 0.0 || !isfinite(f / df)) break;
+      x = x - f / df;
+    }
+    out[k] = x;
+  }
+  return n;
+}
+static __device__ bool solve_one_point(double lx, double ly, double lz, d2 p, d2 p1, d2 p2, double *lam1,
+                                       double *lam2) {
+  const double al1 = lx * p1.x + ly * p1.y, al2 = lx * p2.x + ly * p2.y;
+  const double c = p1.x * p2.y - p1.y * p2.x, a = p1.x * p.y - p1.y * p.x, b = p.x * p2.y - p.y * p2.x;
+  double A[5];
+  A[4] = al1 * al1 * c * c * c;
+  A[3] = al1 * (lz * c * c * c - 3.0 * al1 * c * c * b);
+  A[2] = al1 * (3.0 * al1 * c * b * b - 3.0 * lz * c * c * b);
+  A[1] = al1 * (3.0 * lz * c * b * b - al1 * b * b * b) - al2 * a * b * (al2 * a + lz * c);
+  A[0] = lz * b * b * (al2 * a - al1 * b);
+  double roots[4];
+  const int n = roots_poly4(A, roots);
+  bool found = false;
+  double best_err = 1.7976931348623157e308;
+  for (int k = 0; k < n; ++k) {
+    double u = roots[k];
+    // Newton on the factored form: the expanded coefficients carry the cancellation of (c u - b)^3
+    for (int it = 0; it < 4; ++it) {
+      const double w = c * u - b;
+      const double f = al1 * (al1 * u + lz) * (w * w * w) - al2 * a * b * (al2 * a * u + lz * w);
+      const double df = al1 * al1 * (w * w * w) + 3.0 * al1 * (al1 * u + lz) * (w * w) * c - al2 * a * b * (al2 * a + lz * c);
+      if (df == 0.0 || !isfinite(f / df)) break;
+      u = u - f / df;
+    }
+    const double w = c * u - b;
+    if (w == 0.0) continue;
+    const double l2v = a * u / w;
+    if (!(u > 0) || !(l2v > 0)) continue;
+    const double e1 = al1 * u + lz, e2 = al2 * l2v + lz;
+    const double err = e1 * e1 + e2 * e2;
+    if (err < best_err) {
+      best_err = err;
+      *lam1 = u;
+      *lam2 = l2v;
+      found = true;
+    }
+  }
+  return found;
+}
+
+static __device__ bool one_point_candidate(const GenCfg &cfg, const Cam &c1, const Cam &c2, const Seg &s1,
+                                           const Seg &s2, d3 point, GenOut *out) {
+  const d3 n1 = mk3(s1.n[0], s1.n[1], s1.n[2]);
+  const d3 C1 = cam_center(c1), C2 = cam_center(c2);
+  const d3 pp = sub(point, scale(n1, dot(n1, sub(point, C1))));
+  const d3 v1s = mk3(s1.rs[0], s1.rs[1], s1.rs[2]), v1e = mk3(s1.re[0], s1.re[1], s1.re[2]);
+  const d3 n2 = mk3(s2.n[0], s2.n[1], s2.n[2]);
+  const double alpha = (-1) * dot(n2, C2);
+  const d3 r0 = v1s;
+  const d3 r1 = unit(sub(v1e, scale(v1s, dot(v1s, v1e))));
+  const d3 r2 = unit(cross(r0, r1));
+  const d3 v2_t = mk3(dot(r0, v1e), dot(r1, v1e), dot(r2, v1e));
+  const d3 pc = sub(pp, C1);
+  const d3 p_t = mk3(dot(r0, pc), dot(r1, pc), dot(r2, pc));
+  const d3 n2_t = mk3(dot(r0, n2), dot(r1, n2), dot(r2, n2));
+  const double alpha_t = alpha + dot(n2, C1);
+  const d2 ip = d2{p_t.x, p_t.y};
+  const d2 iv1 = d2{1.0, 0.0};  // (1, 0).normalized()
+  double nv = sqrt(v2_t.x * v2_t.x + v2_t.y * v2_t.y);
+  const d2 iv2 = nv > 0 ? d2{v2_t.x / nv, v2_t.y / nv} : d2{v2_t.x, v2_t.y};
+  double lam1 = -1, lam2 = -1;
+  if (!solve_one_point(n2_t.x, n2_t.y, alpha_t, ip, iv1, iv2, &lam1, &lam2)) return false;
+  const d2 ls2 = d2{iv1.x * lam1, iv1.y * lam1}, le2 = d2{iv2.x * lam2, iv2.y * lam2};
+  const d3 ps = add(add(scale(r0, ls2.x), scale(r1, ls2.y)), C1);
+  const d3 pe = add(add(scale(r0, le2.x), scale(r1, le2.y)), C1);
+  const double z_start = cam_depth(c1, ps), z_end = cam_depth(c1, pe);
+  if (z_start < kEps || z_end < kEps) return false;
+  const double d21 = cam_depth(c2, ps), d22 = cam_depth(c2, pe);
+  if (d21 < kEps || d22 < kEps) return false;
+  const double u1 = cfg.var2d * ((z_start + z_end) / 2.0) / c1.f;
+  const double u2 = cfg.var2d * ((d21 + d22) / 2.0) / c2.f;
+  if (cfg.use_ranges) {
+    if (ps.x < cfg.lo[0] || ps.x > cfg.hi[0]) return false;
+    if (ps.y < cfg.lo[1] || ps.y > cfg.hi[1]) return false;
+    if (ps.z < cfg.lo[2] || ps.z > cfg.hi[2]) return false;
+    if (pe.x < cfg.lo[0] || pe.x > cfg.hi[0]) return false;
+    if (pe.y < cfg.lo[1] || pe.y > cfg.hi[1]) return false;
+    if (pe.z < cfg.lo[2] || pe.z > cfg.hi[2]) return false;
+  }
+  const d3 dir3 = unit(sub(pe, ps));
+  out->c.s[0] = ps.x; out->c.s[1] = ps.y; out->c.s[2] = ps.z;
+  out->c.e[0] = pe.x; out->c.e[1] = pe.y; out->c.e[2] = pe.z;
+  out->c.depth[0] = z_start; out->c.depth[1] = z_end;
+  out->c.unc = dmin(u1, u2);
+  out->c.score3 = 1.0;
+  out->c.seg[0] = s2.x1; out->c.seg[1] = s2.y1; out->c.seg[2] = s2.x2; out->c.seg[3] = s2.y2;
+  out->l.dir[0] = dir3.x; out->l.dir[1] = dir3.y; out->l.dir[2] = dir3.z;
+  return true;
+}
+
 static __device__ __forceinline__ bool vp_candidate(const GenCfg &cfg, const Cam &c1, const Cam &c2, const Seg &s1,
                                                     const Seg &s2, const double *Bv, const double *vp,
                                                     GenOut *out) {

@@ -636,6 +636,17 @@ __global__ void k_fn_query(const double *__restrict__ in, int by_endpoints, doub
       m[0] = m[1] = m[2] = 0.0; m[3] = m[4] = m[5] = 1.0;
       m[6] = m[7] = -1.0; m[8] = -1.0; m[9] = -1.0;
     }
+    // triangulate_line_with_one_point(l1, view1, l2, view2, point): same input slot as the direction
+    GenOut o1;
+    const bool ok1 = one_point_candidate(cfg0, c1, c2, s1, s2, direction, &o1);
+    m = out + 40;
+    if (ok1) {
+      m[0] = o1.c.s[0]; m[1] = o1.c.s[1]; m[2] = o1.c.s[2]; m[3] = o1.c.e[0]; m[4] = o1.c.e[1]; m[5] = o1.c.e[2];
+      m[6] = o1.c.depth[0]; m[7] = o1.c.depth[1]; m[8] = -1.0; m[9] = 1.0;
+    } else {
+      m[0] = m[1] = m[2] = 0.0; m[3] = m[4] = m[5] = 1.0;
+      m[6] = m[7] = -1.0; m[8] = -1.0; m[9] = -1.0;
+    }
   }
 }
 

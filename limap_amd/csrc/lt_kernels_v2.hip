@@ -111,7 +111,9 @@ struct GenArgs {
   const SegPoint *seg_pts;
   const double *sfm_xyz;         // [n_sfm][3] or nullptr (points are then triangulated from the two views)
   int *err_flag;
-  int mult;               // staging slots per match row: 1, or 4 with extra proposals (points, vp1, vp2, algebraic)
+  int mult;               // staging slots per match row: 1, or with extra proposals 4 (many-points, vp1, vp2,
+                          // algebraic) + the most shared points of a connection when the one-point proposal is on
+  int many_on, one_on;    // which point-guided proposals run (seg_pts != null)
 };
 
 __global__ void k_build_gates(long long n_segs, const Seg *__restrict__ segs, SegGate *__restrict__ gates) {
@@ -309,7 +311,8 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
 // One wave per (block, group).  (A persistent-wave variant with the next item's record prefetched was
 // measured slower: the kernel is bound by gather / scatter throughput, not by latency.)
 // kExtra: additionally the optional proposals of steps 1.1 and 2 (base_line_triangulator.cc:183-281) -- per
-// connection up to four candidates in the reference's order many-points, vp(l1), vp(l2), algebraic.  Which
+// connection the candidates in the reference's order many-points, one-point (one per shared point),
+// vp(l1), vp(l2), algebraic.  Which
 // of them are active is a run-time property (a.seg_pts / a.seg_vp may be null).
 template <bool kExtra>
 __global__ void __launch_bounds__(256)
@@ -348,6 +351,7 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
     const unsigned e = e0 + lane;
     bool ok = false;
     bool okx[3] = {false, false, false};  // many-points, vp(l1), vp(l2)
+    unsigned long long one_mask = 0;       // one-point: which shared points gave a candidate
     GenOut o;
     int line = 0, ng = 0;
     // the extra proposals are evaluated once for their validity and a second time when they are
@@ -366,6 +370,53 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
       }
       return vp_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B,
                           a.seg_vp + 3 * (which == 1 ? g1 + line : g2 + ng), dst);
+    };
+    // one-point proposals (step 1.2): one candidate per shared point, in ascending point3D_id.  store ==
+    // false: returns the mask of the points that give a candidate; store == true: recomputes those and
+    // writes them from staging slot p on.
+    auto one_points = [&](unsigned long long want, bool store, long long p) -> unsigned long long {
+      const Seg &s1 = a.segs[g1 + line];
+      const Seg &s2 = a.segs[g2 + ng];
+      const long long pa0 = a.seg_pt_off[g1 + line], pb0 = a.seg_pt_off[g2 + ng];
+      const SegPoint *pa = a.seg_pts + pa0, *pb = a.seg_pts + pb0;
+      const int na = (int)(a.seg_pt_off[g1 + line + 1] - pa0), nb = (int)(a.seg_pt_off[g2 + ng + 1] - pb0);
+      unsigned long long mask = 0;
+      int i = 0, j = 0, idx = 0;
+      while (i < na && j < nb) {
+        const int ia = pa[i].p3d_id, ib = pb[j].p3d_id;
+        if (ia < ib) { ++i; continue; }
+        if (ib < ia) { ++j; continue; }
+        d3 P = mk3(0, 0, 0);
+        bool okp = true;
+        if (a.sfm_xyz) {
+          const int sidx = pa[i].sfm;
+          if (sidx < 0) { *a.err_flag = 2; okp = false; }
+          else P = mk3(a.sfm_xyz[3 * sidx], a.sfm_xyz[3 * sidx + 1], a.sfm_xyz[3 * sidx + 2]);
+        } else {
+          okp = tri_point(cams_r[i1], cam_ray(cams_r[i1], d2{pa[i].x, pa[i].y}), cams_r[i2],
+                          cam_ray(cams_r[i2], d2{pb[j].x, pb[j].y}), &P);
+        }
+        if (okp) {
+          if (idx >= 64) { *a.err_flag = 3; break; }  // more shared points than the mask holds
+          if (!store || ((want >> idx) & 1ull)) {
+            GenOut ov;
+            const bool r = one_point_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, P, &ov);
+            if (!store) {
+              if (r) mask |= 1ull << idx;
+            } else {
+              ov.l.nb_slot = lite_pack(nbslot, i2);
+              ov.l.ng_line = ng;
+              a.st_c[p] = ov.c;
+              a.st_l[p] = ov.l;
+              a.st_key[p] = (unsigned)(g1 + line);
+              ++p;
+            }
+          }
+          ++idx;
+        }
+        ++i; ++j;
+      }
+      return mask;
     };
     if (e < n_s) {
       int k = 0;
@@ -390,7 +441,8 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
         L2 l2{mk2(s2.x1, s2.y1), mk2(s2.x2, s2.y2)};
         const bool len_ok = !(len(l1) <= cfg.min_length_2d) && !(len(l2) <= cfg.min_length_2d);
         GenOut tmp;
-        if (len_ok && a.seg_pts) okx[0] = extra(0, &tmp);
+        if (len_ok && a.seg_pts && a.many_on) okx[0] = extra(0, &tmp);
+        if (len_ok && a.seg_pts && a.one_on) one_mask = one_points(0ull, false, 0);
         if (len_ok && a.seg_vp && a.seg_has_vp[g1 + line]) okx[1] = extra(1, &tmp);
         if (len_ok && a.seg_vp && a.seg_has_vp[g2 + ng]) okx[2] = extra(2, &tmp);
       }
@@ -401,17 +453,27 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
     unsigned below = (unsigned)__popcll(m & lanemask_lt());
     unsigned total = (unsigned)__popcll(m);
     if (kExtra) {
-      unsigned mine = 0;
+      // per-lane candidate counts vary (one per shared point): wave prefix by shuffles
+      const unsigned n_one = (unsigned)__popcll(one_mask);
+      const unsigned mine = (okx[0] ? 1u : 0u) + n_one + (okx[1] ? 1u : 0u) + (okx[2] ? 1u : 0u);
+      const unsigned cnt = mine + (ok ? 1u : 0u);
+      unsigned incl = cnt;
 #pragma unroll
-      for (int w = 0; w < 3; ++w) {
-        const unsigned long long mw = __ballot(okx[w]);
-        below += (unsigned)__popcll(mw & lanemask_lt());
-        total += (unsigned)__popcll(mw);
-        mine += okx[w] ? 1u : 0u;
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = (unsigned)__shfl_up((int)incl, d);
+        if (lane >= d) incl += t;
       }
+      below = incl - cnt;
+      total = (unsigned)__shfl((int)incl, 63);
       long long p = out0 + wcount + below;
+      // the reference's order within a connection: many-points, one-point (ascending point3D_id), vp(l1),
+      // vp(l2), algebraic
 #pragma unroll
       for (int w = 0; w < 3; ++w) {
+        if (w == 1 && n_one) {
+          (void)one_points(one_mask, true, p);
+          p += n_one;
+        }
         if (okx[w]) {
           GenOut ov;
           (void)extra(w, &ov);
@@ -423,13 +485,11 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
           ++p;
         }
       }
-      below += mine;
       if (a.cnt_bl && mine) atomicAdd(&a.cnt_bl[lbase + line], mine);
       if (ok) {
-        const long long pq = out0 + wcount + below;
-        a.st_c[pq] = o.c;
-        a.st_l[pq] = o.l;
-        a.st_key[pq] = (unsigned)(g1 + line);
+        a.st_c[p] = o.c;
+        a.st_l[p] = o.l;
+        a.st_key[p] = (unsigned)(g1 + line);
         if (a.cnt_bl) atomicAdd(&a.cnt_bl[lbase + line], 1u);
       }
     } else {
@@ -850,7 +910,8 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, unsigned *st_row,
                       unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3,
                       const double *seg_vp, const unsigned char *seg_has_vp, const long long *seg_pt_off,
-                      const void *seg_pts, const double *sfm_xyz, int *err_flag) {
+                      const void *seg_pts, const double *sfm_xyz, int *err_flag, int many_on, int one_on,
+                      int mult) {
   if (n_blk <= 0 || max_rows <= 0) return;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -873,7 +934,8 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   a.seg_pt_off = seg_pt_off; a.seg_pts = reinterpret_cast<const SegPoint *>(seg_pts); a.sfm_xyz = sfm_xyz;
   a.err_flag = err_flag;
   const bool extra = seg_vp || seg_pts;
-  a.mult = extra ? 4 : 1;
+  a.mult = extra ? mult : 1;
+  a.many_on = many_on; a.one_on = one_on;
   a.blk = reinterpret_cast<const BlkRec *>(blkrec); a.n_blk = n_blk;
   // persistent grid: as many workgroups as fit at once (registers allow 16 waves per CU)
   const long long n_items = (long long)n_blk * (a.n_slots / kGateWaves);

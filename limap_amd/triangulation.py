@@ -223,8 +223,7 @@ class GlobalLineTriangulator:
     def SetBipartites2d(self, all_bpt2ds):
         """all_bpt2ds: dict img_id -> limap.structures.PL_Bipartite2d (anything with ``as_dict()`` giving
         ``points_`` / ``nl2p_``), or a plain dict(point_ids, xy, point3D_ids, line_points) -- bindings.cc:90.
-        Enables the many-points proposal; the one-point proposal is not implemented
-        (``disable_one_point_triangulation`` must be set)."""
+        Enables the many-points and one-point proposals (cfg ``disable_*_triangulation``)."""
         n_lines = {i: int(self._seg_off[self._idx[i] + 1] - self._seg_off[self._idx[i]]) for i in self._img_ids}
         self._ctx.set_bipartites(flatten_bipartites({int(k): _bipartite_as_arrays(v, n_lines.get(int(k), 0))
                                                      for k, v in dict(all_bpt2ds).items()}))
@@ -429,8 +428,10 @@ def triangulate_line_with_direction(l1, view1, l2, view2, direction):
 
 
 def triangulate_line_with_one_point(l1, view1, l2, view2, point):
-    raise NotImplementedError("the one-point quartic proposal (solvers/triangulation) is not implemented in the "
-                              "MI355X backend")
+    """functions.cc:325-383; the solver is a restatement of the reference's optimisation problem (agrees to
+    rounding, see include/limap_amd.h)."""
+    return _make_line3d(_fctx().fn_triangulate_line_with_one_point(
+        _segs_array([l1])[0], _cam11(view1), _segs_array([l2])[0], _cam11(view2), np.asarray(point, float).reshape(3)))
 
 
 def compute_fundamental_matrix(view1, view2):

@@ -784,7 +784,15 @@ static std::pair<double, double> solve_line_with_one_point(double lx, double ly,
   std::pair<double, double> best{-1.0, -1.0};
   double best_err = std::numeric_limits<double>::max();
   for (int k = 0; k < n; ++k) {
-    const double u = roots[k];
+    double u = roots[k];
+    // Newton on the factored form: the expanded coefficients carry the cancellation of (c u - b)^3
+    for (int it = 0; it < 4; ++it) {
+      const double w = c * u - b;
+      const double f = al1 * (al1 * u + lz) * (w * w * w) - al2 * a * b * (al2 * a * u + lz * w);
+      const double df = al1 * al1 * (w * w * w) + 3.0 * al1 * (al1 * u + lz) * (w * w) * c - al2 * a * b * (al2 * a + lz * c);
+      if (df == 0.0 || !std::isfinite(f / df)) break;
+      u = u - f / df;
+    }
     const double w = c * u - b;
     if (w == 0.0) continue;
     const double lam2 = a * u / w;
@@ -2146,6 +2154,13 @@ void ora_triangulate_line_with_direction(const double seg1[4], const double cam1
   ora::line_to10(ora::triangulate_line_with_direction(ora::seg_to_line(seg1), ora::view_from_cam11(cam1),
                                                       ora::seg_to_line(seg2), ora::view_from_cam11(cam2),
                                                       ora::V3{dir[0], dir[1], dir[2]}),
+                 out10);
+}
+void ora_triangulate_line_with_one_point(const double seg1[4], const double cam1[11], const double seg2[4],
+                                         const double cam2[11], const double point[3], double out10[10]) {
+  ora::line_to10(ora::triangulate_line_with_one_point(ora::seg_to_line(seg1), ora::view_from_cam11(cam1),
+                                                      ora::seg_to_line(seg2), ora::view_from_cam11(cam2),
+                                                      ora::V3{point[0], point[1], point[2]}),
                  out10);
 }
 void ora_triangulate_line(const double seg1[4], const double cam1[11], const double seg2[4],

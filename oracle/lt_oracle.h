@@ -166,6 +166,9 @@ void ora_get_direction_from_vp(const double vp[3], const double cam[11], double 
 void ora_triangulate_line_with_direction(const double seg1[4], const double cam1[11], const double seg2[4],
                                          const double cam2[11], const double dir[3],
                                          double out10[10]);                              /* functions.cc:385-442 */
+void ora_triangulate_line_with_one_point(const double seg1[4], const double cam1[11], const double seg2[4],
+                                         const double cam2[11], const double point[3],
+                                         double out10[10]);                              /* functions.cc:325-383 */
 double ora_cam_projdepth(const double cam[11], const double p[3]);
 void ora_cam_R(const double cam[11], double out[9]);
 void ora_cam_center(const double cam[11], double out[3]);

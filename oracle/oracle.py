@@ -377,6 +377,13 @@ def triangulate_line_with_direction(seg1, cam1, seg2, cam2, direction):
     return out
 
 
+def triangulate_line_with_one_point(seg1, cam1, seg2, cam2, point):
+    out = np.zeros(10)
+    lib().ora_triangulate_line_with_one_point(_d(_f64(seg1)), _d(_f64(cam1)), _d(_f64(seg2)), _d(_f64(cam2)),
+                                              _d(_f64(point)), _d(out))
+    return out
+
+
 def triangulate_line(seg1, cam1, seg2, cam2):
     out = np.zeros(10); lib().ora_triangulate_line(_d(_f64(seg1)), _d(_f64(cam1)), _d(_f64(seg2)), _d(_f64(cam2)), _d(out))
     return out

@@ -1,11 +1,13 @@
-"""-m gpu: the many-points proposal of triangulateOneNode (base_line_triangulator.cc:183-236): 3D points
+"""-m gpu: the point-guided proposals of triangulateOneNode (base_line_triangulator.cc:183-248): 3D points
 shared by the two lines (SfM points, or triangulated from the two views), total-least-squares line fit,
 Pluecker projection of l1's endpoint rays onto the fitted infinite line.
 
 The fitted direction comes from Eigen::JacobiSVD in the reference; the product (Jacobi eigen-decomposition
 of the 3x3 scatter matrix) and the oracle (one-sided Jacobi on the n x 3 matrix) are two different stand-ins
 that agree to rounding, so THIS branch's candidates are compared to 1e-9 relative instead of bit for bit;
-everything discrete (which candidates exist, their order, sources, best, edges, tracks) must be identical."""
+everything discrete (which candidates exist, their order, sources, best, edges, tracks) must be identical.
+The one-point proposal (one candidate per shared point) runs the same restated quartic solver in product
+and oracle with different math libraries: same tolerance."""
 import numpy as np
 import pytest
 
@@ -77,6 +79,33 @@ def test_points_and_vp_together(gpu_lib, oracle):
     _compare(T, O)
 
 
+@pytest.mark.parametrize("with_sfm,many", [(True, True), (False, True), (True, False)])
+def test_one_point_match_oracle(gpu_lib, oracle, with_sfm, many):
+    """Step 1.2 (base_line_triangulator.cc:238-248): one candidate per shared point, after the many-points
+    candidate and before the VP / algebraic ones."""
+    sc = syn.make_scene(n_views=12, n_segs=90, n_neighbors=5, seed=64)
+    bpts, sfm = syn.make_bipartites(sc, seed=4)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    cfg.update(disable_one_point_triangulation=False, disable_many_points_triangulation=not many)
+    T, O = _run_both(oracle, sc, cfg, bpts, sfm if with_sfm else None)
+    g = _compare(T, O)
+    cfg1 = dict(cfg, disable_one_point_triangulation=True)
+    T1, _ = _run_both(oracle, sc, cfg1, bpts, sfm if with_sfm else None)
+    assert g["off"][-1] > T1.context().get_all_tris()["off"][-1] + 100   # the branch really contributes
+
+
+def test_every_proposal_together(gpu_lib, oracle):
+    """many-points, one-point x n, vp(l1), vp(l2), algebraic per connection; unsorted rows (generic path)."""
+    sc = syn.make_scene(n_views=10, n_segs=80, n_neighbors=4, seed=65)
+    bpts, sfm = syn.make_bipartites(sc, seed=5, pts_per_line=5)
+    vps = syn.make_vp_results(sc, seed=5)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    cfg.update(disable_one_point_triangulation=False, use_vp=True)
+    for sorted_rows in (True, False):
+        T, O = _run_both(oracle, sc, cfg, bpts, sfm, vps=vps, sorted_rows=sorted_rows)
+        _compare(T, O)
+
+
 def test_points_switches_and_errors(gpu_lib, oracle):
     from limap_amd import triangulation as tri
     sc = syn.make_scene(n_views=6, n_segs=40, n_neighbors=3, seed=63)
@@ -87,16 +116,19 @@ def test_points_switches_and_errors(gpu_lib, oracle):
     T, O = _run_both(oracle, sc, cfg, bpts, sfm)
     g, o = T.context().get_all_tris(), O.get_all_tris()
     assert np.array_equal(g["off"], o["off"]) and np.array_equal(g["line"], o["line"])
-    # the one-point proposal is not implemented: it has to be switched off explicitly
-    cfg.update(disable_one_point_triangulation=False, disable_many_points_triangulation=False)
+    # more than 64 shared points on one connection: the one-point proposal refuses (documented limit)
+    big, big_sfm = syn.make_bipartites(sc, seed=3, pts_per_line=70)
+    cfg.update(disable_one_point_triangulation=False, disable_many_points_triangulation=True)
     T = tri.GlobalLineTriangulator(cfg)
     T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
-    T.SetBipartites2d(bpts)
-    T.TriangulateImage(int(sc.img_ids[0]), sc.matches_of(int(sc.img_ids[0])))
-    with pytest.raises((RuntimeError, ValueError), match="one-point"):
+    T.SetBipartites2d(big)
+    T.SetSfMPoints(big_sfm)
+    for i in sc.img_ids:
+        T.TriangulateImage(int(i), sc.matches_of(int(i)))
+    with pytest.raises(RuntimeError, match="64 shared points"):
         T.ComputeLineTracks()
     # a shared point3D id that is not among the SfM points: std::map::at throws in the reference
-    cfg.update(disable_one_point_triangulation=True)
+    cfg.update(disable_one_point_triangulation=True, disable_many_points_triangulation=False)
     T = tri.GlobalLineTriangulator(cfg)
     T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
     T.SetBipartites2d(bpts)
