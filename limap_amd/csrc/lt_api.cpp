@@ -955,8 +955,6 @@ int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_id
 }
 
 int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids) {
-  if (ctx->pts_ready && (!ctx->cfg.disable_many_points_triangulation || !ctx->cfg.disable_one_point_triangulation))
-    return fail(ctx, LT_ERR_ARGUMENT, "point-guided proposals (SetBipartites2d) are implemented for TriangulateImage (matched mode) only");
   int idx;
   int rc = begin_image(ctx, img_id, 2, &idx);
   if (rc) return rc;
@@ -1267,14 +1265,30 @@ int lt_run_device(lt_ctx *ctx) {
     const double *seg_vp = vp_on ? ctx->d_seg_vp.as<double>() : nullptr;
     const unsigned char *seg_has_vp = vp_on ? ctx->d_seg_has_vp.as<unsigned char>() : nullptr;
     const int n_masks = vp_on ? 3 : 1;
-    ENSURE(ctx, ctx->d_masks, 8 * In * n_masks); ENSURE(ctx, ctx->d_mask_cnt, 4 * (In + 1));
+    // point-guided proposals: a variable number of candidates per connection -> per-connection counts
+    // (one byte each) instead of ballots, see k_gen_exhaustive_pts
+    const bool pts_any = ctx->pts_ready && (!ctx->cfg.disable_many_points_triangulation || !ctx->cfg.disable_one_point_triangulation);
+    const int many_on = (pts_any && !ctx->cfg.disable_many_points_triangulation) ? 1 : 0;
+    const int one_on = (pts_any && !ctx->cfg.disable_one_point_triangulation) ? 1 : 0;
+    const double *sfm_xyz = (pts_any && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr;
+    ENSURE(ctx, ctx->d_masks, pts_any ? 64 * In : 8 * In * n_masks); ENSURE(ctx, ctx->d_mask_cnt, 4 * (In + 1));
     ENSURE(ctx, ctx->d_mask_pos, 8 * (In + 1));
-    launch_gen_exhaustive(st, false, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
-                          ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
-                          ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
-                          ctx->d_masks.as<unsigned long long>(), nullptr, nullptr, nullptr, seg_vp, seg_has_vp,
-                          ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks);
-    launch_popc(st, P, ctx->d_masks.as<unsigned long long>(), ctx->d_mask_cnt.as<unsigned>(), n_masks);
+    if (pts_any) {
+      launch_gen_exhaustive_pts(st, false, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
+                                ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
+                                ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
+                                ctx->d_masks.as<unsigned char>(), ctx->d_mask_cnt.as<unsigned>(), nullptr, nullptr,
+                                nullptr, seg_vp, seg_has_vp, ctx->d_seg_pt_off.as<long long>(), ctx->d_seg_pts.p,
+                                sfm_xyz, ctx->d_err.as<int>(), many_on, one_on, ctx->d_blk_chunk_off.as<int>(),
+                                ctx->max_nb, ctx->max_chunks);
+    } else {
+      launch_gen_exhaustive(st, false, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
+                            ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
+                            ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
+                            ctx->d_masks.as<unsigned long long>(), nullptr, nullptr, nullptr, seg_vp, seg_has_vp,
+                            ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks);
+      launch_popc(st, P, ctx->d_masks.as<unsigned long long>(), ctx->d_mask_cnt.as<unsigned>(), n_masks);
+    }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_mask_cnt.as<unsigned>() + P, 0, 4, st));
     {
       size_t tmp = scan_temp_bytes_u32_to_i64(P + 1);
@@ -1292,12 +1306,22 @@ int lt_run_device(lt_ctx *ctx) {
     ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);
     ENSURE(ctx, ctx->d_score, 8 * Cn); ENSURE(ctx, ctx->d_edge_flag, 4 * Cn);
     ctx->cand_cap = (long long)Cn;
-    launch_gen_exhaustive(st, true, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
-                          ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
-                          ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
-                          ctx->d_masks.as<unsigned long long>(), ctx->d_mask_pos.as<long long>(),
-                          ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), seg_vp, seg_has_vp,
-                          ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks);
+    if (pts_any)
+      launch_gen_exhaustive_pts(st, true, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
+                                ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
+                                ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
+                                ctx->d_masks.as<unsigned char>(), ctx->d_mask_cnt.as<unsigned>(),
+                                ctx->d_mask_pos.as<long long>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
+                                seg_vp, seg_has_vp, ctx->d_seg_pt_off.as<long long>(), ctx->d_seg_pts.p, sfm_xyz,
+                                ctx->d_err.as<int>(), many_on, one_on, ctx->d_blk_chunk_off.as<int>(), ctx->max_nb,
+                                ctx->max_chunks);
+    else
+      launch_gen_exhaustive(st, true, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
+                            ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
+                            ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
+                            ctx->d_masks.as<unsigned long long>(), ctx->d_mask_pos.as<long long>(),
+                            ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), seg_vp, seg_has_vp,
+                            ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks);
     launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, total,
                           ctx->d_tri_off.as<long long>());
     ENSURE(ctx, ctx->d_cand_node, 4 * Cn);

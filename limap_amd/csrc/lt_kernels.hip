@@ -267,6 +267,136 @@ k_gen_exhaustive(long long n_items, GenCfg cfg, const long long *__restrict__ it
   }
 }
 
+// Exhaustive mode with the point-guided proposals (and, if set, the VP ones): per connection a variable
+// number of candidates in the reference's order many-points, one-point (one per shared point, ascending
+// point3D_id), vp(l1), vp(l2), algebraic (base_line_triangulator.cc:183-325).  Pass 1 (kFill == false)
+// counts them per connection (one byte each, <= 64 + 4) and per work item; pass 2 recomputes them and writes
+// every valid one at  mask_pos[item] + (candidates of the lower lanes) + (rank within the connection).
+// This is the configuration of the reference's third CI run (exhaustive matcher + use_pointsfm).
+template <bool kFill>
+__global__ void __launch_bounds__(256)
+k_gen_exhaustive_pts(long long n_items, GenCfg cfg, const long long *__restrict__ item_off, long long G,
+                     const int *__restrict__ node_img, const long long *__restrict__ nb_off,
+                     const int *__restrict__ blk_nb, const long long *__restrict__ seg_off,
+                     const Cam *__restrict__ cams, const Seg *__restrict__ segs,
+                     const PairRec *__restrict__ pairs, unsigned char *__restrict__ cnt8,
+                     unsigned *__restrict__ item_cnt, const long long *__restrict__ mask_pos,
+                     Cand *__restrict__ out_c, CandLite *__restrict__ out_l, const double *__restrict__ seg_vp,
+                     const unsigned char *__restrict__ seg_has_vp, const long long *__restrict__ seg_pt_off,
+                     const SegPoint *__restrict__ seg_pts, const double *__restrict__ sfm_xyz,
+                     int *__restrict__ err_flag, int many_on, int one_on, const int *__restrict__ blk_chunk_off,
+                     int max_nb, int max_chunks) {
+  const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long per_node = (long long)max_nb * max_chunks;
+  const long long g = w / per_node;
+  if (g >= G) return;
+  const int rest = (int)(w - g * per_node);
+  const int k = rest / max_chunks;
+  const long long rem = rest - k * max_chunks;
+  const int i1 = node_img[g];
+  const long long b = nb_off[i1] + k;
+  if (b >= nb_off[i1 + 1]) return;
+  const int i2 = blk_nb[b];
+  const long long M2 = seg_off[i2 + 1] - seg_off[i2];
+  if (rem >= ((M2 + 63) >> 6)) return;
+  const long long item = item_off[g] + blk_chunk_off[b] + rem;
+  if (item >= n_items) return;
+  const int lane = lane_id();
+  const int ng_line = (int)(rem << 6) + lane;
+  const long long g2 = seg_off[i2] + ng_line;
+  const bool in_range = ng_line < M2;
+  unsigned cnt = 0;
+  long long pos = 0;
+  bool work = in_range;
+  if (kFill) {
+    const unsigned mine = cnt8[item * 64 + lane];
+    unsigned incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned t = (unsigned)__shfl_up((int)incl, d);
+      if (lane >= d) incl += t;
+    }
+    pos = mask_pos[item] + (long long)(incl - mine);
+    work = work && mine != 0;
+  }
+  if (work) {
+    const Seg &s1 = segs[g];
+    const Seg &s2 = segs[g2];
+    const int nbs = lite_pack((int)(b - nb_off[i1]), i2);
+    auto emit = [&](GenOut &o) {
+      if (kFill) {
+        o.l.nb_slot = nbs;
+        o.l.ng_line = ng_line;
+        out_c[pos] = o.c;
+        out_l[pos] = o.l;
+        ++pos;
+      }
+      ++cnt;
+    };
+    L2 l1{mk2(s1.x1, s1.y1), mk2(s1.x2, s1.y2)};
+    L2 l2{mk2(s2.x1, s2.y1), mk2(s2.x2, s2.y2)};
+    const bool len_ok = !(len(l1) <= cfg.min_length_2d) && !(len(l2) <= cfg.min_length_2d);  // :166,177
+    GenOut o;
+    if (len_ok && seg_pts) {
+      const long long pa0 = seg_pt_off[g], pb0 = seg_pt_off[g2];
+      const SegPoint *pa = seg_pts + pa0, *pb = seg_pts + pb0;
+      const int na = (int)(seg_pt_off[g + 1] - pa0), nb = (int)(seg_pt_off[g2 + 1] - pb0);
+      if (na > 0 && nb > 0) {
+        if (many_on) {
+          bool missing = false;
+          if (points_candidate(cfg, cams[i1], cams[i2], s1, s2, pa, na, pb, nb, sfm_xyz, &o, &missing)) emit(o);
+          if (missing) *err_flag = 2;
+        }
+        if (one_on) {
+          int i = 0, j = 0, idx = 0;
+          while (i < na && j < nb) {
+            const int ia = pa[i].p3d_id, ib = pb[j].p3d_id;
+            if (ia < ib) { ++i; continue; }
+            if (ib < ia) { ++j; continue; }
+            d3 P = mk3(0, 0, 0);
+            bool okp = true;
+            if (sfm_xyz) {
+              const int sidx = pa[i].sfm;
+              if (sidx < 0) { *err_flag = 2; okp = false; }
+              else P = mk3(sfm_xyz[3 * sidx], sfm_xyz[3 * sidx + 1], sfm_xyz[3 * sidx + 2]);
+            } else {
+              okp = tri_point(cams[i1], cam_ray(cams[i1], d2{pa[i].x, pa[i].y}), cams[i2],
+                              cam_ray(cams[i2], d2{pb[j].x, pb[j].y}), &P);
+            }
+            if (okp) {
+              if (idx >= 64) { *err_flag = 3; break; }  // same limit as the matched path
+              if (one_point_candidate(cfg, cams[i1], cams[i2], s1, s2, P, &o)) emit(o);
+              ++idx;
+            }
+            ++i; ++j;
+          }
+        }
+      }
+    }
+    if (len_ok && seg_vp) {
+      if (seg_has_vp[g] && vp_candidate(cfg, cams[i1], cams[i2], s1, s2, pairs[b].B, seg_vp + 3 * g, &o)) emit(o);
+      if (seg_has_vp[g2] && vp_candidate(cfg, cams[i1], cams[i2], s1, s2, pairs[b].B, seg_vp + 3 * g2, &o)) emit(o);
+    }
+    {
+      SegGate gg;
+      seg_gate_build(s2, &gg);
+      const int res = gate3(cfg, s1.x1, s1.y1, s1.x2, s1.y2, s1.rs[0], s1.rs[1], s1.rs[2], s1.re[0], s1.re[1], s1.re[2],
+                            gg.n[0], gg.n[1], gg.n[2], gg.lcx, gg.lcy, gg.P, gg.Q, gg.w1, gg.sv, gg.q2, pairs[b].F);
+      bool ok = false;
+      if (res == 1) ok = gen_finish(cfg, cams[i1], cams[i2], s1, s2, pairs[b].B, &o);
+      else if (res == 2) ok = gen_one(cfg, cams[i1], cams[i2], s1, s2, pairs[b], &o);
+      if (ok) emit(o);
+    }
+  }
+  if (!kFill) {
+    cnt8[item * 64 + lane] = (unsigned char)cnt;
+    unsigned tot = cnt;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tot += (unsigned)__shfl_xor((int)tot, d);
+    if (lane == 0) item_cnt[item] = tot;
+  }
+}
+
 __global__ void k_popc(long long n, const unsigned long long *__restrict__ masks,
                        unsigned *__restrict__ cnt, int n_masks) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -474,6 +604,26 @@ void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const G
     if (!fill) LT_LAUNCH_EX(false, false); else LT_LAUNCH_EX(true, false);
   }
 #undef LT_LAUNCH_EX
+}
+void launch_gen_exhaustive_pts(hipStream_t st, bool fill, long long n_items, const GenCfg &cfg,
+                               const long long *item_off, long long G, const int *node_img, const long long *nb_off,
+                               const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
+                               const PairRec *pairs, unsigned char *cnt8, unsigned *item_cnt,
+                               const long long *mask_pos, Cand *out_c, CandLite *out_l, const double *seg_vp,
+                               const unsigned char *seg_has_vp, const long long *seg_pt_off, const void *seg_pts,
+                               const double *sfm_xyz, int *err_flag, int many_on, int one_on,
+                               const int *blk_chunk_off, int max_nb, int max_chunks) {
+  if (n_items <= 0) return;
+  dim3 grid(nblk(G * (long long)max_nb * max_chunks * 64, 256)), block(256);
+  const SegPoint *sp = reinterpret_cast<const SegPoint *>(seg_pts);
+  if (!fill)
+    hipLaunchKernelGGL((k_gen_exhaustive_pts<false>), grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off,
+                       blk_nb, seg_off, cams, segs, pairs, cnt8, item_cnt, mask_pos, out_c, out_l, seg_vp, seg_has_vp,
+                       seg_pt_off, sp, sfm_xyz, err_flag, many_on, one_on, blk_chunk_off, max_nb, max_chunks);
+  else
+    hipLaunchKernelGGL((k_gen_exhaustive_pts<true>), grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off,
+                       blk_nb, seg_off, cams, segs, pairs, cnt8, item_cnt, mask_pos, out_c, out_l, seg_vp, seg_has_vp,
+                       seg_pt_off, sp, sfm_xyz, err_flag, many_on, one_on, blk_chunk_off, max_nb, max_chunks);
 }
 // n_masks ballots per item (3 with VP proposals)
 void launch_popc(hipStream_t st, long long n, const unsigned long long *masks, unsigned *cnt, int n_masks) {

@@ -106,6 +106,41 @@ def test_every_proposal_together(gpu_lib, oracle):
         _compare(T, O)
 
 
+@pytest.mark.parametrize("with_vp,with_sfm", [(False, True), (True, False)])
+def test_point_proposals_exhaustive_match_oracle(gpu_lib, oracle, with_vp, with_sfm):
+    """TriangulateImageExhaustiveMatch with the point proposals (the configuration of the reference's third CI
+    run: exhaustive matcher + use_pointsfm): per-connection candidate counts instead of ballots."""
+    from limap_amd import triangulation as tri
+    sc = syn.make_scene(n_views=8, n_segs=70, n_neighbors=4, seed=66)  # 70 segments: a ragged last chunk of 64
+    bpts, sfm = syn.make_bipartites(sc, seed=6, pts_per_line=4)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    cfg.update(disable_one_point_triangulation=False, disable_many_points_triangulation=False, use_vp=with_vp)
+    T = tri.GlobalLineTriangulator(cfg)
+    O = oracle.OracleTriangulator(cfg, faithful=False)
+    T.SetRanges(sc.ranges); O.SetRanges(sc.ranges)
+    T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+    O.Init(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, sc.seg_off, sc.segs)
+    T.SetBipartites2d(bpts); O.SetBipartites2d(bpts)
+    if with_sfm:
+        T.SetSfMPoints(sfm); O.SetSfMPoints(sfm)
+    if with_vp:
+        vps = syn.make_vp_results(sc, seed=6)
+        T.InitVPResults(vps); O.InitVPResults(vps)
+    for i in sc.img_ids:
+        T.TriangulateImageExhaustiveMatch(int(i), sc.neighbors[int(i)])
+        O.TriangulateImageExhaustiveMatch(int(i), sc.neighbors[int(i)])
+    g = _compare(T, O)
+    cfg0 = dict(cfg, disable_one_point_triangulation=True, disable_many_points_triangulation=True)
+    T0 = tri.GlobalLineTriangulator(cfg0)
+    T0.SetRanges(sc.ranges)
+    T0.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+    if with_vp:
+        T0.InitVPResults(vps)
+    for i in sc.img_ids:
+        T0.TriangulateImageExhaustiveMatch(int(i), sc.neighbors[int(i)])
+    assert g["off"][-1] > T0.context().get_all_tris()["off"][-1] + 100   # the point branches contribute
+
+
 def test_points_switches_and_errors(gpu_lib, oracle):
     from limap_amd import triangulation as tri
     sc = syn.make_scene(n_views=6, n_segs=40, n_neighbors=3, seed=63)
