@@ -228,6 +228,11 @@ int lt_get_stats(lt_ctx *ctx, int64_t out[8]);
  * single-kernel durations (HIP events around the launch): [13] k_gates, [14] k_tri_rows, [15] k_score3;
  * [16] connections that passed the stage-A gates (k_gates) */
 int lt_get_timers(lt_ctx *ctx, double out[24]);
+/* The same slots summed over every lt_run_device since the last reset ([8]-[10], [12] are not summed), and
+ * the number of runs ([16] is not summed either: lt_get_timers counts it on demand with a device readback,
+ * which is why a caller that times many runs should read the sums once instead of lt_get_timers per run).
+ * reset != 0 clears the sums after reading. */
+int lt_get_timer_sums(lt_ctx *ctx, double out[24], int64_t *n_runs, int reset);
 
 /* The library keeps released device blocks and page-locked staging blocks in a process-wide cache
  * (contexts are typically created once per scene; hipMalloc / hipHostMalloc / hipFree are the slow part

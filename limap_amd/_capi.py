@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "lt_num_tracks", "lt_num_track_members", "lt_get_tracks", "lt_image_results_size",
     "lt_export_image_results", "lt_import_image_results", "lt_ts_from_ctx", "lt_ts_create", "lt_ts_destroy",
     "lt_ts_num_tracks", "lt_ts_num_members", "lt_ts_get", "lt_ts_filter_by_reprojection",
-    "lt_ts_filter_by_sensitivity", "lt_ts_filter_by_overlap", "lt_ts_remerge_once", "lt_get_stats", "lt_get_timers",
+    "lt_ts_filter_by_sensitivity", "lt_ts_filter_by_overlap", "lt_ts_remerge_once", "lt_get_stats", "lt_get_timers", "lt_get_timer_sums",
     "lt_release_cached_memory",
     "lt_fn_get_normal_direction", "lt_fn_get_direction_from_vp", "lt_fn_triangulate_point",
     "lt_fn_triangulate_line_with_direction", "lt_fn_triangulate_line_with_one_point", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
@@ -165,6 +165,7 @@ def load_library():
     L.lt_ts_remerge_once.argtypes = [vp, vp, C.POINTER(LtConfig), C.c_int]
     L.lt_get_stats.argtypes = [vp, i64p]
     L.lt_get_timers.argtypes = [vp, dp]
+    L.lt_get_timer_sums.argtypes = [vp, dp, C.POINTER(C.c_int64), C.c_int]
     L.lt_fn_get_normal_direction.argtypes = [vp, dp, dp, dp]
     L.lt_fn_get_direction_from_vp.argtypes = [vp, dp, dp, dp]
     L.lt_fn_triangulate_point.argtypes = [vp, dp, dp, dp, dp, dp, C.POINTER(C.c_int)]
@@ -434,12 +435,20 @@ class Context:
         keys = ["connections", "candidates", "pairs", "valid_edges", "graph_nodes", "graph_edges", "tracks", "nodes"]
         return dict(zip(keys, out.tolist()))
 
+    _TIMER_KEYS = ["run", "invariants", "sort", "gen", "compact", "score", "select", "gather", "upload", "download",
+                   "tail", "pairs_eval", "buffer", "k_gates", "k_tri_rows", "k_score3", "survivors"]
+
     def timers(self):
         out = np.zeros(24)
         self.chk(self.L.lt_get_timers(self.h, ptr(out, C.c_double)))
-        keys = ["run", "invariants", "sort", "gen", "compact", "score", "select", "gather", "upload", "download", "tail",
-                "pairs_eval", "buffer", "k_gates", "k_tri_rows", "k_score3", "survivors"]
-        return dict(zip(keys, out.tolist()))
+        return dict(zip(self._TIMER_KEYS, out.tolist()))
+
+    def timer_sums(self, reset=False):
+        """-> (dict of the timer slots summed over the runs since the last reset, number of runs)."""
+        out = np.zeros(24)
+        n = C.c_int64(0)
+        self.chk(self.L.lt_get_timer_sums(self.h, ptr(out, C.c_double), C.byref(n), 1 if reset else 0))
+        return dict(zip(self._TIMER_KEYS, out.tolist())), int(n.value)
 
     # --- free functions ---
     def fn_normal_direction(self, seg, cam):

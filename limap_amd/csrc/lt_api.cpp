@@ -1412,6 +1412,10 @@ int lt_run_device(lt_ctx *ctx) {
   }
   if (fine_timers() && ctx->C_last > 0 && hipEventElapsedTime(&ms, ctx->ev[11], ctx->ev[5]) == hipSuccess) ctx->timers[15] = ms;
   (void)hipGetLastError();
+  ctx->timers[11] = (double)ctx->stat_pairs_eval;
+  for (int k = 0; k < 24; ++k)  // [16] (survivors) is counted on demand by lt_get_timers, not per run
+    if (k != 8 && k != 9 && k != 10 && k != 12 && k != 16) ctx->timer_sums[k] += ctx->timers[k];
+  ++ctx->timer_runs;
   ctx->ran = true;
   ctx->downloaded = false;
   return LT_OK;
@@ -1940,6 +1944,16 @@ int lt_get_timers(lt_ctx *ctx, double out[24]) {
   }
   ctx->timers[16] = (double)ctx->stat_survivors;
   std::memcpy(out, ctx->timers, sizeof(ctx->timers));
+  return LT_OK;
+}
+
+int lt_get_timer_sums(lt_ctx *ctx, double out[24], int64_t *n_runs, int reset) {
+  std::memcpy(out, ctx->timer_sums, sizeof(ctx->timer_sums));
+  if (n_runs) *n_runs = ctx->timer_runs;
+  if (reset) {
+    std::memset(ctx->timer_sums, 0, sizeof(ctx->timer_sums));
+    ctx->timer_runs = 0;
+  }
   return LT_OK;
 }
 

@@ -218,6 +218,8 @@ struct lt_ctx {
   bool tracks_done = false;
   long long stat_graph_nodes = 0, stat_graph_edges = 0, stat_pairs = 0;
   double timers[24] = {0};
+  double timer_sums[24] = {0};  // over the runs since the last reset (lt_get_timer_sums)
+  long long timer_runs = 0;
   long long stat_survivors = 0;  // connections that passed stage A (k_gates) in the last run
   hipEvent_t ev[12] = {nullptr};
   long long C_last = 0;  // candidates of the last lt_run_device (known on the host once the scoring grid is sized)

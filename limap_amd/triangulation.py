@@ -219,6 +219,14 @@ class GlobalLineTriangulator:
             flat[int(img_id)] = (np.asarray(lab, dtype=np.int64).reshape(-1),
                                  np.asarray(vps, dtype=float).reshape(-1, 3))
         self._ctx.init_vp(flat)
+        self._vpresults = dict(vpresults)  # handed back as given (base_line_triangulator.h:50-55)
+
+    def GetVPResult(self, image_id):
+        """The VPResult passed to InitVPResults for this image (std::map::at -> KeyError if absent)."""
+        return getattr(self, "_vpresults", {})[image_id]
+
+    def GetVPResults(self):
+        return dict(getattr(self, "_vpresults", {}))
 
     def SetBipartites2d(self, all_bpt2ds):
         """all_bpt2ds: dict img_id -> limap.structures.PL_Bipartite2d (anything with ``as_dict()`` giving

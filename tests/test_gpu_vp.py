@@ -18,6 +18,7 @@ def _run_both(oracle, sc, cfg, vps, sorted_rows=True):
     T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
     O.Init(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, sc.seg_off, sc.segs)
     T.InitVPResults(vps); O.InitVPResults(vps)
+    assert set(T.GetVPResults()) == set(vps) and T.GetVPResult(int(sc.img_ids[0])) is vps[int(sc.img_ids[0])]
     rng = np.random.default_rng(3)
     for i in sc.img_ids:
         m = sc.matches_of(int(i))
