@@ -56,12 +56,13 @@ void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long 
 void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const Cand *st_c,
                     const CandLite *st_l, Cand *cand, CandLite *lite, unsigned *cand_node);
 void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, unsigned *cand_node);
-size_t score3_lds_bytes(int max_nb);
+size_t score3_lds_bytes(int max_nb, bool f32);
 size_t cand_meta_bytes();
 void launch_score3(hipStream_t st, long long C, long long G, const long long *tri_off, const unsigned *cand_node,
                    void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
-                   int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before);
+                   int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
+                   bool f32);
 }
 
 // ---- pooled page-locked host blocks (see lt_ctx.h) ----
@@ -533,7 +534,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
-                    &ctx->d_pair_counter, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz};
+                    &ctx->d_pair_counter, &ctx->d_tile_order, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz};
   lt_host::host_block_release(ctx->h_pinned_blk);
   for (DevBuf *b : bufs) b->release();
   // a context that still owns its stream hands stream + events to the next context
@@ -1337,7 +1338,9 @@ int lt_run_device(lt_ctx *ctx) {
   }
 
   // ---- scoring ----
-  if (score3_lds_bytes(ctx->max_nb) > 160 * 1024)
+  // LT_TEST_SCORE_F64: the sweep's early exit in double precision (the default is the bounded single-precision form)
+  const bool score_f32 = !getenv("LT_TEST_SCORE_F64");
+  if (score3_lds_bytes(ctx->max_nb, score_f32) > 160 * 1024)
     return fail(ctx, LT_ERR_ARGUMENT, "too many neighbours for the scoring kernel's LDS budget");
   {
     // conservative square of the scale-invariant endpoint gate (see k_score3)
@@ -1347,12 +1350,14 @@ int lt_run_device(lt_ctx *ctx) {
     if (ctx->h_nb_off[ctx->n_img] >= (1ll << 24))
       return fail(ctx, LT_ERR_ARGUMENT, "too many (image, neighbour) blocks in one batch (>= 2^24)");
     ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_known, 1));
+    ENSURE(ctx, ctx->d_tile_order, 1024);  // the tile draw counters of k_score3 (8 x 128 B)
     ctx->C_last = C_known;
     launch_score3(st, C_known, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
                   ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_node_img.as<int>(),
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
                   ctx->d_score.as<double>(), ctx->d_pair_counter.as<unsigned long long>(), ctx->max_nb, scfg,
-                  guard2, fine_timers() ? ctx->ev[11] : nullptr);
+                  guard2, fine_timers() ? ctx->ev[11] : nullptr,
+                  ctx->d_tile_order.as<unsigned>(), score_f32);
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));

@@ -60,6 +60,9 @@ namespace lt {
 #ifndef LT_SCORE_WIN
 #define LT_SCORE_WIN 128
 #endif
+#ifndef LT_SCORE_RESIDENT
+#define LT_SCORE_RESIDENT 16  // persistent k_score3 workgroups (one wave each) per CU, if LDS and registers allow
+#endif
 constexpr int kGenChunks = LT_GEN_CHUNKS;  // 64-row chunks per slot
 constexpr int kRowsPerWave = 64 * kGenChunks;
 constexpr int kGateWaves = LT_GATE_WAVES;  // waves (= slots) per k_gates workgroup
@@ -691,10 +694,14 @@ __global__ void k_permute(long long C, const unsigned *__restrict__ skeys, const
   cand_node[t] = skeys[t];
 }
 
-__global__ void k_cand_meta(long long C, const unsigned *__restrict__ cand_node,
-                            const long long *__restrict__ tri_off, const int *__restrict__ node_img,
-                            const long long *__restrict__ nb_off, CandMeta *__restrict__ meta) {
+// Also resets the tile draw counters of the persistent k_score3 that follows.
+constexpr int kTileQueues = 8;  // one draw counter per XCD (workgroups are dealt round-robin to the XCDs)
+__global__ void __launch_bounds__(256)
+k_cand_meta(long long C, const unsigned *__restrict__ cand_node, const long long *__restrict__ tri_off,
+            const int *__restrict__ node_img, const long long *__restrict__ nb_off, CandMeta *__restrict__ meta,
+            unsigned *__restrict__ draw) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < kTileQueues) draw[i * 32] = 0;  // 128 bytes apart
   if (i >= C) return;
   const unsigned g = cand_node[i];
   const long long off = tri_off[g];
@@ -727,7 +734,7 @@ k_cand_node(long long G, const long long *__restrict__ tri_off, unsigned *__rest
 // are pushed (ballot + popcount) into an LDS queue and evaluated densely, one pair per lane; the
 // per-neighbour-image maxima live in LDS (ds_max_u64 on the bit pattern of the non-negative scores)
 // and are summed per lane in ascending image-id order (std::map order, :110-112).
-constexpr int kSQCap = 192;
+constexpr int kSQCap = 512;  // the queue is drained when fewer than 256 (4 sweep iterations) slots are free
 constexpr int kWin = LT_SCORE_WIN;
 
 struct Score3Args {
@@ -740,145 +747,267 @@ struct Score3Args {
   const Cam *cams;
   double *score;
   unsigned long long *pair_counter;  // stats: pairs that reached the dense evaluation
+  unsigned *draw;                    // kTileQueues draw counters, 128 bytes apart: queue q = tiles q, q + 8, ...
   int max_nb;
 };
 
+// kF32 (default): the sweep's early exit in single precision on coordinates relative to a wave-local origin,
+// with the rounding of that form bounded and added to the guards, so that it rejects a subset of what the
+// double test rejects, never more: 1e-6 R on a distance (R = largest coordinate magnitude in the window; the
+// bound is 4 sqrt(3) 2^-24 R = 4.2e-7 R), 2e-6 on a cosine of unit vectors (bound 3e-7).  NaN / inf compare
+// false and fall through to the exact evaluation.  Which pairs reach the dense evaluation changes slightly,
+// no result does (tests: LT_TEST_SCORE_F64 = the double-precision sweep, bit-identical outputs).  The window
+// is AoS (3 x float4 per candidate: direction + slot, start, end: three 128-bit LDS reads per pair, broadcast
+// when the lanes of a node walk in step) and the sweep is unrolled by four with the reads hoisted.
+// (A table-free form of the per-image maxima for jobs whose neighbour lists are in ascending image id --
+// running (slot, max, sum) per lane in registers, evaluated pairs handed to their owner lanes by ballot +
+// readlane in queue order -- was measured: 195 us against 142 us, the serial hand-off costs more than the
+// 10 KB of LDS it frees.  Evaluating pair_score without its early returns, for ILP: no difference.)
+template <bool kF32>
 __global__ void __launch_bounds__(64) LT_SCORE_OCC
 k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x;
-  // LDS: W[9][kWin] f64 | S[max_nb][64] u64 | woff[64] i64 | wslot[kWin] i32 | queue[kSQCap] u32 | ord[max_nb] i32
+  // LDS: window (f32: float4[kWin][3]; f64: W[9][kWin] f64 + wslot[kWin] i32) | woff[64] i64 | queue[kSQCap] u32 |
+  //      ord[max_nb] i32 | S[max_nb][64] u64
+  constexpr size_t kWBytes = kF32 ? (size_t)kWin * 48 : (size_t)9 * kWin * 8 + (size_t)kWin * 4;
   double *W = reinterpret_cast<double *>(smem_raw);
-  unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_raw + 9 * kWin * 8);
-  long long *woff = reinterpret_cast<long long *>(smem_raw + 9 * kWin * 8 + (size_t)a.max_nb * 64 * 8);
-  int *wslot = reinterpret_cast<int *>(smem_raw + 9 * kWin * 8 + (size_t)a.max_nb * 64 * 8 + 64 * 8);
-  unsigned *queue = reinterpret_cast<unsigned *>(smem_raw + 9 * kWin * 8 + (size_t)a.max_nb * 64 * 8 + 64 * 8 + kWin * 4);
-  int *ordl = reinterpret_cast<int *>(smem_raw + 9 * kWin * 8 + (size_t)a.max_nb * 64 * 8 + 64 * 8 + kWin * 4 + kSQCap * 4);
+  int *wslot = reinterpret_cast<int *>(smem_raw + (size_t)9 * kWin * 8);
+  float4 *W4 = reinterpret_cast<float4 *>(smem_raw);
+  long long *woff = reinterpret_cast<long long *>(smem_raw + kWBytes);
+  unsigned *queue = reinterpret_cast<unsigned *>(smem_raw + kWBytes + 64 * 8);
+  int *ordl = reinterpret_cast<int *>(smem_raw + kWBytes + 64 * 8 + kSQCap * 4);
+  unsigned long long *S = reinterpret_cast<unsigned long long *>(
+      smem_raw + ((kWBytes + 64 * 8 + kSQCap * 4 + (size_t)a.max_nb * 4 + 15) & ~(size_t)15));
 
   const long long C = a.tri_off[a.G];
-  const long long i0 = (long long)blockIdx.x * 64;
-  if (i0 >= C) return;
-  const long long i = i0 + lane;
-  const bool active = i < C;
-
-  long long off = 0, nb0 = 0;
-  int n = 0, n_nb = 0, sloti = -1;
-  double dix = 0, diy = 0, diz = 0;
-  double six = 0, siy = 0, siz = 0, eix = 0, eiy = 0, eiz = 0, gs2 = 0, ge2 = 0;
-  if (active) {
-    const CandMeta mt = a.meta[i];
-    off = ((long long)mt.off_hi << 32) | (long long)mt.off_lo;
-    n = (int)mt.n;
-    nb0 = (long long)(mt.nb >> 8);
-    n_nb = (int)(mt.nb & 0xFFu);
-    const CandLite li = a.lite[i];
-    const Cand ci = a.cand[i];
-    dix = li.dir[0]; diy = li.dir[1]; diz = li.dir[2];
-    sloti = lite_slot(li);
-    six = ci.s[0]; siy = ci.s[1]; siz = ci.s[2];
-    eix = ci.e[0]; eiy = ci.e[1]; eiz = ci.e[2];
-    // dist / (depth + eps) > th_scaleinv (1 + 1e-6) can never score >= score_th (line_dists.cc:55-60)
-    double zs = ci.depth[0] + kEps, ze = ci.depth[1] + kEps;
-    gs2 = (zs > 0.0) ? scaleinv_guard2 * zs * zs : 1e300;  // odd depths: leave it to the exact path
-    ge2 = (ze > 0.0) ? scaleinv_guard2 * ze * ze : 1e300;
-  }
-  woff[lane] = off;
-  // summation order of the first lane's image, staged once (lanes of another image read it from HBM)
-  const long long wave_nb0 = __shfl(nb0, 0);
-  if (lane < __shfl(n_nb, 0)) ordl[lane] = a.blk_order[wave_nb0 + lane];
-  for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
-  // candidate range of all nodes this wave touches (lane 0 is always active)
-  const long long lo = __shfl(off, 0);
-  long long hi = active ? off + n : 0;
-  for (int d = 32; d >= 1; d >>= 1) {
-    long long o = __shfl_xor(hi, d);
-    hi = o > hi ? o : hi;
-  }
-  int qn = 0;
-  unsigned long long n_eval = 0;
-
-  auto drain = [&]() {
-    wave_lds_sync();
-    for (int q0 = 0; q0 < qn; q0 += 64) {
-      int p = q0 + lane;
-      if (p < qn) {
-        unsigned e = queue[p];
-        int il = (int)(e >> 26);
-        long long j = woff[il] + (long long)(e & 0x3FFFFFFu);
-        long long ii = i0 + il;
-        const Cand ci = a.cand[ii];
-        const CandLite li = a.lite[ii];
-        const CandLite lj = a.lite[j];
-        const Cand cj = a.cand[j];
-        double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
-                               mk3(li.dir[0], li.dir[1], li.dir[2]), ci.depth[0], ci.depth[1],
-                               mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
-                               mk3(lj.dir[0], lj.dir[1], lj.dir[2]), cj.seg, a.cams[lite_img(lj)]);
-        if (sc > 0.0) atomicMax(&S[lite_slot(lj) * 64 + il], (unsigned long long)__double_as_longlong(sc));
-      }
+  const unsigned n_tiles = (unsigned)((C + 63) >> 6);
+  // Persistent wave: tiles (64 consecutive candidates) are drawn through kTileQueues counters -- queue q
+  // holds the tiles q, q + 8, ... and is served by the workgroups of one XCD (round-robin dispatch), an empty
+  // queue sends its waves to the next one.  The draw for the next tile is issued before the current tile's
+  // work and read after it.  (Listing the tiles by the size of their largest node, longest first, was
+  // measured: no gain -- a tile's time is set by how many of its pairs survive the sweep, which neither the
+  // largest node nor the number of pairs of the tile predicts: correlation 0.6.)
+  int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
+  unsigned long long n_eval_total = 0;
+  unsigned k_raw = 0;
+  if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+  auto resolve = [&]() -> unsigned {  // tile of the pending draw, 0xFFFFFFFF when every queue is empty
+    for (;;) {
+      const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
+      const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
+      if (e < n_tiles) return (unsigned)e;
+      if (++tried >= kTileQueues) return 0xFFFFFFFFu;
+      q = (q + 1) & (kTileQueues - 1);
+      if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
     }
-    n_eval += (unsigned long long)qn;
-    qn = 0;
-    wave_lds_sync();
   };
+  unsigned tile = resolve();
+  while (tile != 0xFFFFFFFFu) {
+    if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+    const long long i0 = (long long)tile * 64;
+    const long long i = i0 + lane;
+    const bool active = i < C;
+    LT_TRACE_MARK(2, tile, 0);
 
-  for (long long wb = lo; wb < hi; wb += kWin) {
-    wave_lds_sync();
-    const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
-    for (int e = lane; e < wn; e += 64) {
-      const CandLite l = a.lite[wb + e];
-      const Cand c = a.cand[wb + e];
-      W[0 * kWin + e] = l.dir[0]; W[1 * kWin + e] = l.dir[1]; W[2 * kWin + e] = l.dir[2];
-      W[3 * kWin + e] = c.s[0]; W[4 * kWin + e] = c.s[1]; W[5 * kWin + e] = c.s[2];
-      W[6 * kWin + e] = c.e[0]; W[7 * kWin + e] = c.e[1]; W[8 * kWin + e] = c.e[2];
-      wslot[e] = lite_slot(l);
+    long long off = 0, nb0 = 0;
+    int n = 0, n_nb = 0, sloti = -1;
+    double dix = 0, diy = 0, diz = 0;
+    double six = 0, siy = 0, siz = 0, eix = 0, eiy = 0, eiz = 0, gs2 = 0, ge2 = 0;
+    if (active) {
+      const CandMeta mt = a.meta[i];
+      off = ((long long)mt.off_hi << 32) | (long long)mt.off_lo;
+      n = (int)mt.n;
+      nb0 = (long long)(mt.nb >> 8);
+      n_nb = (int)(mt.nb & 0xFFu);
+      const CandLite li = a.lite[i];
+      const Cand ci = a.cand[i];
+      dix = li.dir[0]; diy = li.dir[1]; diz = li.dir[2];
+      sloti = lite_slot(li);
+      six = ci.s[0]; siy = ci.s[1]; siz = ci.s[2];
+      eix = ci.e[0]; eiy = ci.e[1]; eiz = ci.e[2];
+      // dist / (depth + eps) > th_scaleinv (1 + 1e-6) can never score >= score_th (line_dists.cc:55-60)
+      double zs = ci.depth[0] + kEps, ze = ci.depth[1] + kEps;
+      gs2 = (zs > 0.0) ? scaleinv_guard2 * zs * zs : 1e300;  // odd depths: leave it to the exact path
+      ge2 = (ze > 0.0) ? scaleinv_guard2 * ze * ze : 1e300;
     }
-    wave_lds_sync();
-    // this lane's sub-range of the window
-    long long jlo = off > wb ? off : wb;
-    long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
-    int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
-    int cmax = cnt;
-    for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d));
-    const int w0 = (int)(jlo - wb);
-    const int jj0 = (int)(jlo - off);
-    for (int t = 0; t < cmax; ++t) {
-      bool pass = t < cnt;
-      if (pass) {
-        // one LDS round trip per iteration: fetch every field up front, then test
-        const int w = w0 + t;
-        const int sl = wslot[w];
-        const double jx = W[0 * kWin + w], jy = W[1 * kWin + w], jz = W[2 * kWin + w];
-        const double sx = W[3 * kWin + w], sy = W[4 * kWin + w], sz = W[5 * kWin + w];
-        const double ex = W[6 * kWin + w], ey = W[7 * kWin + w], ez = W[8 * kWin + w];
-        const double c = fabs((dix * jx + diy * jy) + diz * jz);
-        const double ax = six - sx, ay = siy - sy, az = siz - sz;
-        const double bx = eix - ex, by = eiy - ey, bz = eiz - ez;
-        const double ds2 = ax * ax + ay * ay + az * az, de2 = bx * bx + by * by + bz * bz;
-        // below the cosine guard the 3D angle score is certainly gated to 0; beyond the squared
-        // distance guards the scale-invariant endpoint score is
-        pass = (jlo + t != i) && (sl != sloti) && !(c < cfg.cos_guard) && !(ds2 > gs2) && !(de2 > ge2);
-      }
-      unsigned long long m = __ballot(pass);
-      if (m) {
-        if (pass) queue[qn + __popcll(m & lanemask_lt())] = ((unsigned)lane << 26) | (unsigned)(jj0 + t);
-        qn += __popcll(m);
-        if (qn > kSQCap - 64) drain();
-      }
+    woff[lane] = off;
+    // summation order of the first lane's image, staged once (lanes of another image read it from HBM)
+    const long long wave_nb0 = __shfl(nb0, 0);
+    if (lane < __shfl(n_nb, 0)) ordl[lane] = a.blk_order[wave_nb0 + lane];
+    for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
+    // kF32: wave-local origin (the first lane's start point) and this lane's own single-precision operands
+    double ox = 0, oy = 0, oz = 0;
+    float dixf = 0, diyf = 0, dizf = 0, sixf = 0, siyf = 0, sizf = 0, eixf = 0, eiyf = 0, eizf = 0, ri = 0;
+    double gs = 0, ge = 0;
+    float cosf_guard = -2.0f;
+    if (kF32) {
+      ox = __shfl(six, 0); oy = __shfl(siy, 0); oz = __shfl(siz, 0);
+      dixf = (float)dix; diyf = (float)diy; dizf = (float)diz;
+      sixf = (float)(six - ox); siyf = (float)(siy - oy); sizf = (float)(siz - oz);
+      eixf = (float)(eix - ox); eiyf = (float)(eiy - oy); eizf = (float)(eiz - oz);
+      ri = fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)), fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf)));
+      if (!active) ri = 0.0f;
+      gs = sqrt(gs2);
+      ge = sqrt(ge2);
+      cosf_guard = cfg.cos_guard > -1.0 ? (float)(cfg.cos_guard - 2e-6) : -2.0f;
     }
-  }
-  drain();
+    // candidate range of all nodes this wave touches (lane 0 is always active)
+    const long long lo = __shfl(off, 0);
+    long long hi = active ? off + n : 0;
+    for (int d = 32; d >= 1; d >>= 1) {
+      long long o = __shfl_xor(hi, d);
+      hi = o > hi ? o : hi;
+    }
+    int qn = 0;
+    unsigned long long n_eval = 0;
 
-  if (active) {
-    double sum = 0.0;
-    const bool own = nb0 == wave_nb0;
-    for (int r = 0; r < n_nb; ++r) {
-      int k = own ? ordl[r] : a.blk_order[nb0 + r];
-      sum += __longlong_as_double((long long)S[k * 64 + lane]);
+    auto drain = [&]() {
+      wave_lds_sync();
+      for (int q0 = 0; q0 < qn; q0 += 64) {
+        const int p = q0 + lane;
+        if (p < qn) {
+          const unsigned e = queue[p];
+          const int il = (int)(e >> 26);
+          const long long j = woff[il] + (long long)(e & 0x3FFFFFFu);
+          const long long ii = i0 + il;
+          const Cand ci = a.cand[ii];
+          const CandLite li = a.lite[ii];
+          const CandLite lj = a.lite[j];
+          const Cand cj = a.cand[j];
+          const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
+                                       mk3(li.dir[0], li.dir[1], li.dir[2]), ci.depth[0], ci.depth[1],
+                                       mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
+                                       mk3(lj.dir[0], lj.dir[1], lj.dir[2]), cj.seg, a.cams[lite_img(lj)]);
+          if (sc > 0.0) atomicMax(&S[lite_slot(lj) * 64 + il], (unsigned long long)__double_as_longlong(sc));
+        }
+      }
+      n_eval += (unsigned long long)qn;
+      qn = 0;
+      wave_lds_sync();
+    };
+
+    for (long long wb = lo; wb < hi; wb += kWin) {
+      wave_lds_sync();
+      const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
+      float rw = ri;
+      for (int e = lane; e < wn; e += 64) {
+        const CandLite l = a.lite[wb + e];
+        const Cand c = a.cand[wb + e];
+        if (kF32) {
+          const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
+          const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
+          W4[3 * e + 0] = float4{(float)l.dir[0], (float)l.dir[1], (float)l.dir[2], __int_as_float(lite_slot(l))};
+          W4[3 * e + 1] = float4{sx, sy, sz, 0.0f};
+          W4[3 * e + 2] = float4{ex, ey, ez, 0.0f};
+          rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
+        } else {
+          W[0 * kWin + e] = l.dir[0]; W[1 * kWin + e] = l.dir[1]; W[2 * kWin + e] = l.dir[2];
+          W[3 * kWin + e] = c.s[0]; W[4 * kWin + e] = c.s[1]; W[5 * kWin + e] = c.s[2];
+          W[6 * kWin + e] = c.e[0]; W[7 * kWin + e] = c.e[1]; W[8 * kWin + e] = c.e[2];
+          wslot[e] = lite_slot(l);
+        }
+      }
+      float gsf = 0.0f, gef = 0.0f;
+      if (kF32) {
+        // R of the window -> this lane's single-precision distance guards (a NaN coordinate makes R NaN,
+        // the guards NaN and every comparison false: everything goes to the exact evaluation)
+        for (int d = 32; d >= 1; d >>= 1) {
+          const float o = __shfl_xor(rw, d);
+          rw = (o > rw || o != o) ? o : rw;
+        }
+        const double delta = 1e-6 * (double)rw;
+        gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
+        gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
+      }
+      wave_lds_sync();
+      if (wb == lo) { LT_TRACE_MARK(2, tile, 1); }
+      // this lane's sub-range of the window
+      long long jlo = off > wb ? off : wb;
+      long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
+      int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
+      int cmax = cnt;
+      for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d));
+      const int w0 = (int)(jlo - wb);
+      const int jj0 = (int)(jlo - off);
+      const int self_t = (int)(i - jlo);  // iteration at which the lane meets itself (may be out of range)
+      if (kF32) {
+        const int wlast = cnt > 0 ? w0 + cnt - 1 : 0;  // reads beyond the lane's range are clamped, then masked
+        const int wbase = cnt > 0 ? w0 : 0;
+        for (int t = 0; t < cmax; t += 4) {
+          float4 A[4], B[4], E[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int w = min(wbase + t + u, wlast);
+            A[u] = W4[3 * w + 0];
+            B[u] = W4[3 * w + 1];
+            E[u] = W4[3 * w + 2];
+          }
+          bool pass[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float c = fabsf(__builtin_fmaf(dizf, A[u].z, __builtin_fmaf(diyf, A[u].y, dixf * A[u].x)));
+            const float ax = sixf - B[u].x, ay = siyf - B[u].y, az = sizf - B[u].z;
+            const float bx = eixf - E[u].x, by = eiyf - E[u].y, bz = eizf - E[u].z;
+            const float ds2 = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
+            const float de2 = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
+            // below the cosine guard the 3D angle score is certainly gated to 0; beyond the squared
+            // distance guards the scale-invariant endpoint score is
+            pass[u] = (t + u < cnt) && (t + u != self_t) && (__float_as_int(A[u].w) != sloti) && !(c < cosf_guard) &&
+                      !(ds2 > gsf) && !(de2 > gef);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned long long m = __ballot(pass[u]);
+            if (m) {
+              if (pass[u]) queue[qn + __popcll(m & lanemask_lt())] = ((unsigned)lane << 26) | (unsigned)(jj0 + t + u);
+              qn += __popcll(m);
+            }
+          }
+          if (qn > kSQCap - 256) drain();
+        }
+      } else {
+        for (int t = 0; t < cmax; ++t) {
+          bool pass = t < cnt;
+          if (pass) {
+            const int w = w0 + t;
+            const int sl = wslot[w];
+            const double jx = W[0 * kWin + w], jy = W[1 * kWin + w], jz = W[2 * kWin + w];
+            const double sx = W[3 * kWin + w], sy = W[4 * kWin + w], sz = W[5 * kWin + w];
+            const double ex = W[6 * kWin + w], ey = W[7 * kWin + w], ez = W[8 * kWin + w];
+            const double c = fabs((dix * jx + diy * jy) + diz * jz);
+            const double ax = six - sx, ay = siy - sy, az = siz - sz;
+            const double bx = eix - ex, by = eiy - ey, bz = eiz - ez;
+            const double ds2 = ax * ax + ay * ay + az * az, de2 = bx * bx + by * by + bz * bz;
+            pass = (t != self_t) && (sl != sloti) && !(c < cfg.cos_guard) && !(ds2 > gs2) && !(de2 > ge2);
+          }
+          const unsigned long long m = __ballot(pass);
+          if (m) {
+            if (pass) queue[qn + __popcll(m & lanemask_lt())] = ((unsigned)lane << 26) | (unsigned)(jj0 + t);
+            qn += __popcll(m);
+            if (qn > kSQCap - 256) drain();
+          }
+        }
+      }
     }
-    a.score[i] = sum;
+    LT_TRACE_MARK(2, tile, 2);
+    drain();
+    LT_TRACE_MARK(2, tile, 3);
+
+    if (active) {
+      double sum = 0.0;
+      const bool own = nb0 == wave_nb0;
+      for (int r = 0; r < n_nb; ++r) {
+        int k = own ? ordl[r] : a.blk_order[nb0 + r];
+        sum += __longlong_as_double((long long)S[k * 64 + lane]);
+      }
+      a.score[i] = sum;
+    }
+    n_eval_total += n_eval;
+    wave_lds_sync();  // the tables are reused by the next tile
+    tile = resolve();
   }
-  if (lane == 0 && a.pair_counter) atomicAdd(a.pair_counter, n_eval);
+  if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -994,8 +1123,9 @@ void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, uns
   if (G > 0)
     hipLaunchKernelGGL(k_cand_node, dim3(nblk2(G * 64, 256)), dim3(256), 0, st, G, tri_off, cand_node);
 }
-size_t score3_lds_bytes(int max_nb) {
-  return 9 * kWin * 8 + (size_t)max_nb * 64 * 8 + 64 * 8 + kWin * 4 + kSQCap * 4 + (size_t)max_nb * 4;
+size_t score3_lds_bytes(int max_nb, bool f32) {
+  const size_t base = (f32 ? (size_t)kWin * 48 : (size_t)9 * kWin * 8 + (size_t)kWin * 4) + 64 * 8 + kSQCap * 4;
+  return ((base + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
 }
 size_t cand_meta_bytes() { return sizeof(CandMeta); }
 // (A two-kernel form -- light sweep writing per-tile pair lists, then a dense evaluation kernel -- was
@@ -1004,16 +1134,31 @@ size_t cand_meta_bytes() { return sizeof(CandMeta); }
 void launch_score3(hipStream_t st, long long C, long long G, const long long *tri_off, const unsigned *cand_node,
                    void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
-                   int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before) {
+                   int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
+                   bool f32) {
   if (C <= 0) return;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+      n_cu = 256;
+  }
+  const long long n_tiles = (C + 63) / 64;
   hipLaunchKernelGGL(k_cand_meta, dim3(nblk2(C, 256)), dim3(256), 0, st, C, cand_node, tri_off, node_img, nb_off,
-                     reinterpret_cast<CandMeta *>(meta));
+                     reinterpret_cast<CandMeta *>(meta), draw);
   Score3Args a;
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand; a.lite = lite;
   a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
+  a.draw = draw;
   a.max_nb = max_nb;
   if (ev_before) (void)hipEventRecord(ev_before, st);
-  hipLaunchKernelGGL(k_score3, dim3(nblk2(C, 64)), dim3(64), score3_lds_bytes(max_nb), st, a, cfg, scaleinv_guard2);
+  // persistent grid: as many single-wave workgroups as fit at once (LDS; registers allow LT_SCORE_RESIDENT per CU)
+  const size_t lds = score3_lds_bytes(max_nb, f32);
+  const long long per_cu = std::max<long long>(1, std::min<long long>(LT_SCORE_RESIDENT, (long long)(160 * 1024 / lds)));
+  const dim3 grid((unsigned)std::min<long long>(n_tiles, per_cu * n_cu)), block(64);
+  if (f32) hipLaunchKernelGGL((k_score3<true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+  else hipLaunchKernelGGL((k_score3<false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
 }
 
 }  // namespace lt

@@ -54,6 +54,19 @@ class Scene:
         return np.concatenate([self.kvec[idx], self.qvec[idx], self.tvec[idx]])
 
 
+def translate_scene(scene, shift):
+    """The same scene moved by `shift` in world coordinates (x_cam = R x + t  ->  t' = t - R shift): identical
+    2D data, 3D results far from the origin -- exercises code that works on origin-relative coordinates."""
+    import dataclasses
+    shift = np.asarray(shift, float).reshape(3)
+    tvec = np.array([scene.tvec[n] - quat_to_rot(scene.qvec[n]) @ shift for n in range(scene.n_images)])
+    gt = scene.gt_lines.copy()
+    gt[:, :3] += shift
+    gt[:, 3:] += shift
+    ranges = None if scene.ranges is None else (scene.ranges[0] + shift, scene.ranges[1] + shift)
+    return dataclasses.replace(scene, tvec=tvec, gt_lines=gt, ranges=ranges)
+
+
 def _rot_to_quat(R):
     """Rotation matrix -> (w,x,y,z), w >= 0."""
     tr = np.trace(R)

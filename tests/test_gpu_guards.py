@@ -157,6 +157,32 @@ def test_no_lds_tables_switch(gpu_lib, clean_env):
     _same(base, other)
 
 
+@pytest.mark.parametrize("exhaustive", [False, True])
+def test_single_precision_sweep_is_conservative(gpu_lib, clean_env, exhaustive):
+    """k_score3's early exit runs in single precision with its rounding added to the guards; the
+    double-precision sweep (LT_TEST_SCORE_F64) and the sweep that skips nothing (LT_TEST_NO_SCORE_GUARDS) must
+    give the same bits -- also for a scene far from the origin (coordinates ~1e5: the float form works on
+    window-local coordinates) -- and may only evaluate fewer or equally many pairs densely."""
+    for shift in (0.0, 1.0e5):
+        sc = syn.make_scene(n_views=10, n_segs=120, n_neighbors=4, seed=54)
+        if shift:
+            sc = syn.translate_scene(sc, np.array([shift, -0.5 * shift, 0.25 * shift]))
+        cfg = syn.default_triangulation_cfg(debug_mode=True)
+        base = _results(run_product(sc, cfg, exhaustive=exhaustive))
+        outs = {}
+        for var in ("LT_TEST_SCORE_F64", "LT_TEST_NO_SCORE_GUARDS"):
+            os.environ[var] = "1"
+            try:
+                outs[var] = _results(run_product(sc, cfg, exhaustive=exhaustive))
+            finally:
+                del os.environ[var]
+            _same(base, outs[var])
+        assert base[5]["candidates"] > 0
+        # the float guards pass a superset of what the double guards pass, both a subset of everything
+        assert outs["LT_TEST_SCORE_F64"][4]["pairs_eval"] <= base[4]["pairs_eval"] <= outs["LT_TEST_NO_SCORE_GUARDS"][4]["pairs_eval"]
+        assert base[4]["pairs_eval"] <= 1.01 * outs["LT_TEST_SCORE_F64"][4]["pairs_eval"] + 64
+
+
 def test_full_size_invariants(gpu_lib, clean_env):
     """BASELINE's full size (100 views x 500 segments, 10^7 connections): the oracle needs ~8 s per run
     here (bench.py times it and checks its counts), so this test uses size-independent properties --
