@@ -1130,6 +1130,7 @@ int lt_run_device(lt_ctx *ctx) {
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
 
   long long C_known = -1;  // candidate count once it is known on the host
+  long long C_bound = 0;   // what sizes the compact arrays: the count, or an upper bound while it stays on the device
   ctx->C_last = 0;
   if (ctx->job_mode == 1) {
     const size_t Pn = (size_t)std::max<long long>(P, 1);
@@ -1176,7 +1177,9 @@ int lt_run_device(lt_ctx *ctx) {
     // per segment each; two workgroups per CU need both within 80 KB, one workgroup within 160 KB
     int lds_segs = (!no_lds_table && ctx->max_nb_segs <= 1024) ? ctx->max_nb_segs : 0;
     int lds_segs1 = (!no_lds_table && ctx->max_own_segs <= 1024) ? ctx->max_own_segs : 0;
-    if (lds_segs + lds_segs1 > 2048) lds_segs1 = 0;
+    // both tables only while two workgroups still fit a CU (80 KB each): beyond that the own segments come
+    // from L2 -- measured at 700 / 1000 segments per image: k_gates -16 % / -14 % against one workgroup per CU
+    if (lds_segs + lds_segs1 > 1024) lds_segs1 = 0;
     {
       ENSURE(ctx, ctx->d_st_row, 4 * Pn);
       ENSURE(ctx, ctx->d_surv_count, 4 * (size_t)(n_slots_all + 1));
@@ -1210,10 +1213,22 @@ int lt_run_device(lt_ctx *ctx) {
       if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, G + 1, ctx->d_ntris_u.as<unsigned>(),
                                  ctx->d_tri_off.as<long long>()) != 0)
         return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
-      // the candidate count sizes the compact arrays and the scoring grid (8-byte async copy)
-      HIPCHK(ctx, hipMemcpyAsync(hC, ctx->d_tri_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipStreamSynchronize(st));
-      C_known = *hC;
+      // Nothing below needs the candidate count on the host (the kernels read tri_off[G]; the grids of
+      // k_place / k_score3 do not depend on it) except the SIZE of the compact arrays.  While the trivial
+      // bound -- one candidate per staging slot -- fits kCountFreeBytes, the arrays get that size and the
+      // whole run is enqueued without a host round trip (the count then arrives with the error flag);
+      // otherwise (or with LT_TEST_SYNC_COUNT) one 8-byte copy + stream sync fetches the exact count.
+      const long long bound = P * (long long)mult;
+      constexpr long long kCountFreeBytes = 8ll << 30;
+      const long long per_cand = (long long)(sizeof(Cand) + sizeof(CandLite) + 8 + 4 + 4) + (long long)cand_meta_bytes();
+      if (ctx->h_pinned && bound * per_cand <= kCountFreeBytes && !getenv("LT_TEST_SYNC_COUNT")) {
+        C_known = -1;
+        C_bound = bound;
+      } else {
+        HIPCHK(ctx, hipMemcpyAsync(hC, ctx->d_tri_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        C_known = *hC;
+      }
     } else {
       // generic rows: stable radix sort of the candidates by node (input is in row order)
       ENSURE(ctx, ctx->d_wave_pos, 8 * (size_t)(n_waves + 1));
@@ -1227,7 +1242,8 @@ int lt_run_device(lt_ctx *ctx) {
       HIPCHK(ctx, hipStreamSynchronize(st));
       C_known = *hC;
     }
-    const size_t Cn = (size_t)std::max<long long>(C_known, 1);
+    if (C_known >= 0) C_bound = C_known;
+    const size_t Cn = (size_t)std::max<long long>(C_bound, 1);
     ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);
     ENSURE(ctx, ctx->d_score, 8 * Cn); ENSURE(ctx, ctx->d_edge_flag, 4 * Cn); ENSURE(ctx, ctx->d_cand_node, 4 * Cn);
     ctx->cand_cap = (long long)Cn;
@@ -1328,12 +1344,14 @@ int lt_run_device(lt_ctx *ctx) {
     ENSURE(ctx, ctx->d_cand_node, 4 * Cn);
     launch_cand_node(st, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>());
     C_known = total;
+    C_bound = total;
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
   } else {
     HIPCHK(ctx, hipMemsetAsync(ctx->d_tri_off.p, 0, sizeof(long long) * (size_t)(G + 1), st));
     ENSURE(ctx, ctx->d_cand, sizeof(Cand)); ENSURE(ctx, ctx->d_lite, sizeof(CandLite));
     ENSURE(ctx, ctx->d_score, 8); ENSURE(ctx, ctx->d_edge_flag, 4); ENSURE(ctx, ctx->d_cand_node, 4);
     C_known = 0;
+    C_bound = 0;
     for (int k = 2; k <= 4; ++k) HIPCHK(ctx, hipEventRecord(ctx->ev[k], st));
   }
 
@@ -1349,10 +1367,10 @@ int lt_run_device(lt_ctx *ctx) {
     if (getenv("LT_TEST_NO_SCORE_GUARDS")) guard2 = 1e300;
     if (ctx->h_nb_off[ctx->n_img] >= (1ll << 24))
       return fail(ctx, LT_ERR_ARGUMENT, "too many (image, neighbour) blocks in one batch (>= 2^24)");
-    ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_known, 1));
+    ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_bound, 1));
     ENSURE(ctx, ctx->d_tile_order, 1024);  // the tile draw counters of k_score3 (8 x 128 B)
-    ctx->C_last = C_known;
-    launch_score3(st, C_known, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
+    ctx->C_last = C_bound;  // replaced by the exact count below when that arrives with the error flag
+    launch_score3(st, C_bound, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
                   ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_node_img.as<int>(),
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
                   ctx->d_score.as<double>(), ctx->d_pair_counter.as<unsigned long long>(), ctx->max_nb, scfg,
@@ -1383,11 +1401,17 @@ int lt_run_device(lt_ctx *ctx) {
   if (ctx->h_pinned) {
     ctx->h_pinned[1] = 0; ctx->h_pinned[2] = 0;
     HIPCHK(ctx, hipMemcpyAsync(&ctx->h_pinned[1], ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (C_known < 0)
+      HIPCHK(ctx, hipMemcpyAsync(&ctx->h_pinned[0], ctx->d_tri_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
     if (ctx->C_last > 0)
       HIPCHK(ctx, hipMemcpyAsync(&ctx->h_pinned[2], ctx->d_pair_counter.p, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     derr = *reinterpret_cast<int *>(&ctx->h_pinned[1]);
     ctx->stat_pairs_eval = ctx->h_pinned[2];
+    if (C_known < 0) {
+      C_known = ctx->h_pinned[0];
+      ctx->C_last = C_known;
+    }
   } else {
     HIPCHK(ctx, hipStreamSynchronize(st));
     HIPCHK(ctx, hipMemcpy(&derr, ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost));

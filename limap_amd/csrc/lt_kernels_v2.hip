@@ -697,22 +697,26 @@ __global__ void k_permute(long long C, const unsigned *__restrict__ skeys, const
 // Also resets the tile draw counters of the persistent k_score3 that follows.
 constexpr int kTileQueues = 8;  // one draw counter per XCD (workgroups are dealt round-robin to the XCDs)
 __global__ void __launch_bounds__(256)
-k_cand_meta(long long C, const unsigned *__restrict__ cand_node, const long long *__restrict__ tri_off,
+k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long *__restrict__ tri_off,
             const int *__restrict__ node_img, const long long *__restrict__ nb_off, CandMeta *__restrict__ meta,
             unsigned *__restrict__ draw) {
+  // grid-stride over the exact candidate count tri_off[G]; the host may only know an upper bound
+  const long long C = tri_off[G];
+  const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kTileQueues) draw[i * 32] = 0;  // 128 bytes apart
-  if (i >= C) return;
-  const unsigned g = cand_node[i];
-  const long long off = tri_off[g];
-  const int img = node_img[g];
-  const long long nb0 = nb_off[img];
-  CandMeta m;
-  m.off_lo = (unsigned)(off & 0xFFFFFFFFll);
-  m.off_hi = (unsigned)(off >> 32);
-  m.n = (unsigned)(tri_off[g + 1] - off);
-  m.nb = ((unsigned)nb0 << 8) | (unsigned)(nb_off[img + 1] - nb0);
-  meta[i] = m;
+  for (; i < C; i += stride) {
+    const unsigned g = cand_node[i];
+    const long long off = tri_off[g];
+    const int img = node_img[g];
+    const long long nb0 = nb_off[img];
+    CandMeta m;
+    m.off_lo = (unsigned)(off & 0xFFFFFFFFll);
+    m.off_hi = (unsigned)(off >> 32);
+    m.n = (unsigned)(tri_off[g + 1] - off);
+    m.nb = ((unsigned)nb0 << 8) | (unsigned)(nb_off[img + 1] - nb0);
+    meta[i] = m;
+  }
 }
 
 // cand_node for pipelines that produce the compact arrays directly (exhaustive mode)
@@ -1144,9 +1148,10 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
       n_cu = 256;
   }
+  // C: the candidate count or an upper bound of it (the kernels read the exact count from tri_off[G])
   const long long n_tiles = (C + 63) / 64;
-  hipLaunchKernelGGL(k_cand_meta, dim3(nblk2(C, 256)), dim3(256), 0, st, C, cand_node, tri_off, node_img, nb_off,
-                     reinterpret_cast<CandMeta *>(meta), draw);
+  hipLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st, G,
+                     cand_node, tri_off, node_img, nb_off, reinterpret_cast<CandMeta *>(meta), draw);
   Score3Args a;
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand; a.lite = lite;
   a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;

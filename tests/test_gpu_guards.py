@@ -183,6 +183,28 @@ def test_single_precision_sweep_is_conservative(gpu_lib, clean_env, exhaustive):
         assert base[4]["pairs_eval"] <= 1.01 * outs["LT_TEST_SCORE_F64"][4]["pairs_eval"] + 64
 
 
+def test_candidate_count_stays_on_device(gpu_lib, clean_env):
+    """Default (sorted rows, bounded size): the compact arrays are sized by the one-candidate-per-staging-slot
+    bound, the kernels read the exact count on the device and the run has no host round trip.
+    LT_TEST_SYNC_COUNT: exact count through a stream sync.  Identical results, with the algebraic proposal
+    alone and with several candidates per row (VP proposals)."""
+    sc = syn.make_scene(n_views=10, n_segs=120, n_neighbors=4, seed=53)
+    for extra in (False, True):
+        cfg = syn.default_triangulation_cfg(debug_mode=True)
+        vps = None
+        if extra:
+            cfg.update(use_vp=True)
+            vps = syn.make_vp_results(sc, seed=3)
+        base = _results(run_product(sc, cfg, vps=vps))
+        os.environ["LT_TEST_SYNC_COUNT"] = "1"
+        try:
+            other = _results(run_product(sc, cfg, vps=vps))
+        finally:
+            del os.environ["LT_TEST_SYNC_COUNT"]
+        _same(base, other)
+        assert base[5]["candidates"] == other[5]["candidates"] > 0
+
+
 def test_full_size_invariants(gpu_lib, clean_env):
     """BASELINE's full size (100 views x 500 segments, 10^7 connections): the oracle needs ~8 s per run
     here (bench.py times it and checks its counts), so this test uses size-independent properties --
