@@ -137,9 +137,12 @@ def main():
             pending[0].wait()
         ctx.refresh_scene_chunks()
         pending[0] = gather.gather_async()
-        ctx.run_device()
+        # enqueue only: the host's end-of-run bookkeeping of step k (result slots, event timings) happens
+        # after step k+1 has been enqueued; the sync below completes the last one inside the timed region
+        ctx.run_device(wait=False)
 
     def sync():
+        ctx.sync()
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()

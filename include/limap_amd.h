@@ -143,6 +143,13 @@ int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int
 /* Staged execution of the buffered images (lt_flush = upload + run + download). */
 int lt_upload(lt_ctx *ctx);     /* host staging -> HBM (matches, neighbour tables) */
 int lt_run_device(lt_ctx *ctx); /* kernels only, inputs resident in HBM; repeatable */
+/* The same run enqueued without waiting for it.  If the previous lt_run_device_async is still in flight it is
+ * completed AFTER the new run has been enqueued, and ITS status is the return value (a streaming caller keeps
+ * the device busy across the host's end-of-run bookkeeping); lt_sync completes the run in flight and returns
+ * its status.  Every other entry point that touches results or inputs completes it first.  No reference
+ * counterpart (the reference's TriangulateImage is synchronous host code). */
+int lt_run_device_async(lt_ctx *ctx);
+int lt_sync(lt_ctx *ctx);
 int lt_download(lt_ctx *ctx);   /* per-node results -> host */
 int lt_flush(lt_ctx *ctx);
 

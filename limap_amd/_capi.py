@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "lt_num_tracks", "lt_num_track_members", "lt_get_tracks", "lt_image_results_size",
     "lt_export_image_results", "lt_import_image_results", "lt_ts_from_ctx", "lt_ts_create", "lt_ts_destroy",
     "lt_ts_num_tracks", "lt_ts_num_members", "lt_ts_get", "lt_ts_filter_by_reprojection",
-    "lt_ts_filter_by_sensitivity", "lt_ts_filter_by_overlap", "lt_ts_remerge_once", "lt_get_stats", "lt_get_timers", "lt_get_timer_sums",
+    "lt_ts_filter_by_sensitivity", "lt_ts_filter_by_overlap", "lt_ts_remerge_once", "lt_get_stats", "lt_get_timers", "lt_get_timer_sums", "lt_run_device_async", "lt_sync",
     "lt_release_cached_memory",
     "lt_fn_get_normal_direction", "lt_fn_get_direction_from_vp", "lt_fn_triangulate_point",
     "lt_fn_triangulate_line_with_direction", "lt_fn_triangulate_line_with_one_point", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
@@ -132,7 +132,7 @@ def load_library():
     L.lt_triangulate_image.argtypes = [vp, C.c_int, C.c_int, i32p, i64p, i32p]
     L.lt_triangulate_image_rows.argtypes = [vp, C.c_int, C.c_int, i32p, C.POINTER(C.c_void_p), i64p]
     L.lt_triangulate_image_exhaustive.argtypes = [vp, C.c_int, C.c_int, i32p]
-    for n in ("lt_upload", "lt_run_device", "lt_download", "lt_flush", "lt_compute_tracks"):
+    for n in ("lt_upload", "lt_run_device", "lt_run_device_async", "lt_sync", "lt_download", "lt_flush", "lt_compute_tracks"):
         getattr(L, n).argtypes = [vp]
     for n in ("lt_count_images", "lt_num_nodes", "lt_num_valid_edges", "lt_num_all_tris", "lt_num_tracks",
               "lt_num_track_members"):
@@ -337,8 +337,14 @@ class Context:
     def upload(self):
         self.chk(self.L.lt_upload(self.h))
 
-    def run_device(self):
-        self.chk(self.L.lt_run_device(self.h))
+    def run_device(self, wait=True):
+        """wait=False: enqueue only (lt_run_device_async); a run still in flight from the previous such call is
+        completed after the new one is enqueued and its error, if any, is raised here.  sync() completes the
+        run in flight."""
+        self.chk(self.L.lt_run_device(self.h) if wait else self.L.lt_run_device_async(self.h))
+
+    def sync(self):
+        self.chk(self.L.lt_sync(self.h))
 
     def download(self):
         self.chk(self.L.lt_download(self.h))

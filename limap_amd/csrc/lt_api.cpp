@@ -184,27 +184,27 @@ void dev_block_release(void *p, size_t cap) {
 struct StreamSet {
   int device;
   hipStream_t stream;
-  hipEvent_t ev[12];
+  hipEvent_t ev[14];
 };
 std::vector<StreamSet> &g_stream_pool = *new std::vector<StreamSet>;
-bool stream_set_acquire(int device, hipStream_t *stream, hipEvent_t ev[12]) {
+bool stream_set_acquire(int device, hipStream_t *stream, hipEvent_t ev[14]) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   for (size_t i = 0; i < g_stream_pool.size(); ++i)
     if (g_stream_pool[i].device == device) {
       *stream = g_stream_pool[i].stream;
-      for (int k = 0; k < 12; ++k) ev[k] = g_stream_pool[i].ev[k];
+      for (int k = 0; k < 14; ++k) ev[k] = g_stream_pool[i].ev[k];
       g_stream_pool.erase(g_stream_pool.begin() + i);
       return true;
     }
   return false;
 }
-bool stream_set_release(int device, hipStream_t stream, hipEvent_t ev[12]) {
+bool stream_set_release(int device, hipStream_t stream, hipEvent_t ev[14]) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   if (g_stream_pool.size() >= 8) return false;
   StreamSet s;
   s.device = device;
   s.stream = stream;
-  for (int k = 0; k < 12; ++k) s.ev[k] = ev[k];
+  for (int k = 0; k < 14; ++k) s.ev[k] = ev[k];
   g_stream_pool.push_back(s);
   return true;
 }
@@ -520,8 +520,16 @@ lt_ctx *lt_create(const lt_config *cfg, int device) {
   return ctx;
 }
 
+int finish_run(lt_ctx *ctx);
+#define LT_FINISH(ctx)              \
+  do {                              \
+    int rc_fin_ = finish_run(ctx);  \
+    if (rc_fin_) return rc_fin_;    \
+  } while (0)
+
 void lt_destroy(lt_ctx *ctx) {
   if (!ctx) return;
+  (void)finish_run(ctx);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   DevBuf *bufs[] = {&ctx->d_kvec, &ctx->d_qvec, &ctx->d_tvec, &ctx->d_segs_raw, &ctx->d_cams, &ctx->d_segs,
@@ -537,6 +545,8 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_pair_counter, &ctx->d_tile_order, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz};
   lt_host::host_block_release(ctx->h_pinned_blk);
   for (DevBuf *b : bufs) b->release();
+  for (auto &e : ctx->ev_b)
+    if (e) (void)hipEventDestroy(e);
   // a context that still owns its stream hands stream + events to the next context
   if (ctx->pool_stream) (void)hipStreamSynchronize(ctx->pool_stream);
   if (!(ctx->pool_stream && lt_host::stream_set_release(ctx->device, ctx->pool_stream, ctx->ev))) {
@@ -550,6 +560,7 @@ void lt_destroy(lt_ctx *ctx) {
 const char *lt_last_error(lt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int lt_set_stream(lt_ctx *ctx, void *hip_stream) {
+  LT_FINISH(ctx);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // nothing of this context stays in flight on the old stream
   if (hip_stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -574,6 +585,7 @@ int lt_unset_ranges(lt_ctx *ctx) {
 
 int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, const double *qvec,
             const double *tvec, const int64_t *seg_off, const double *segs) {
+  LT_FINISH(ctx);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (n_img < 0) return fail(ctx, LT_ERR_ARGUMENT, "n_img < 0");
   std::vector<int> perm(n_img);
@@ -600,6 +612,7 @@ int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, 
 
 int lt_init_vp(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *label_off, const int32_t *labels,
                const int64_t *vp_off, const double *vps) {
+  LT_FINISH(ctx);
   if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "InitVPResults before Init");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   std::vector<double> vp(3 * (size_t)std::max<long long>(ctx->G, 1), 0.0);
@@ -632,6 +645,7 @@ int lt_init_vp(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *la
 int lt_set_bipartites(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *pt_off, const int32_t *pt_ids,
                       const double *pt_xy, const int32_t *pt_p3d, const int64_t *line_off, const int64_t *lp_off,
                       const int32_t *lp_ptids) {
+  LT_FINISH(ctx);
   if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "SetBipartites2d before Init");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   struct SegPointH { int p3d_id, sfm; double x, y; };
@@ -688,6 +702,7 @@ int lt_set_bipartites(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int6
 }
 
 int lt_set_sfm_points(lt_ctx *ctx, int64_t n, const int32_t *ids, const double *xyz) {
+  LT_FINISH(ctx);
   ctx->h_sfm_ids.assign(ids, ids + n);
   ctx->h_sfm_xyz.assign(xyz, xyz + 3 * n);
   ctx->sfm_given = n > 0;  // sfm_points_.empty() -> the shared points are triangulated from the two views
@@ -725,6 +740,7 @@ static int upload_points(lt_ctx *ctx) {
 
 int lt_init_device(lt_ctx *ctx, int n_img, const int32_t *img_ids, const void *d_kvec, const void *d_qvec,
                    const void *d_tvec, const int64_t *seg_off, const void *d_segs) {
+  LT_FINISH(ctx);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   std::vector<int> perm(n_img);
   for (int i = 0; i < n_img; ++i) {
@@ -773,6 +789,7 @@ int lt_refresh_scene_device(lt_ctx *ctx, const void *d_kvec, const void *d_qvec,
 
 int lt_set_scene_chunks(lt_ctx *ctx, int n_chunks, const int32_t *img_begin, const void *const *d_kvec,
                         const void *const *d_qvec, const void *const *d_tvec, const void *const *d_segs) {
+  LT_FINISH(ctx);
   if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "lt_set_scene_chunks before Init");
   if (n_chunks <= 0 || img_begin[0] != 0) return fail(ctx, LT_ERR_ARGUMENT, "chunks must start at image 0");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -833,6 +850,7 @@ static int begin_image(lt_ctx *ctx, int img_id, int mode, int *idx_out) {
 // sort-free placement and the single copy into the staging buffer run in one parallel pass.
 int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids,
                               const int32_t *const *rows, const int64_t *n_rows) {
+  LT_FINISH(ctx);
   struct Acc {  // [12] host ms spent buffering match rows (all calls of the batch)
     lt_ctx *c; double t0;
     ~Acc() { c->timers[12] += now_ms() - t0; }
@@ -956,6 +974,7 @@ int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_id
 }
 
 int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids) {
+  LT_FINISH(ctx);
   int idx;
   int rc = begin_image(ctx, img_id, 2, &idx);
   if (rc) return rc;
@@ -983,6 +1002,7 @@ int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int
 }
 
 int lt_upload(lt_ctx *ctx) {
+  LT_FINISH(ctx);
   if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "upload before Init");
   if (ctx->uploaded) return LT_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1105,8 +1125,71 @@ int lt_upload(lt_ctx *ctx) {
   return LT_OK;
 }
 
-int lt_run_device(lt_ctx *ctx) {
+// Completes the run that lt_run_device_async left in flight: waits for its end marker, reads the error flag,
+// the candidate count and the pair statistic from the pinned slots of its set, and its event timings.
+int finish_run(lt_ctx *ctx) {
+  if (!ctx->run_pending) return LT_OK;
+  ctx->run_pending = false;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipEvent_t *ev = ctx->pend_set ? ctx->ev_b : ctx->ev;
+  long long *hp = ctx->h_pinned ? ctx->h_pinned + 8 * ctx->pend_set : nullptr;
+  int derr = 0;
+  if (hp) {
+    HIPCHK(ctx, hipEventSynchronize(ev[12]));
+    derr = *reinterpret_cast<int *>(&hp[1]);
+    ctx->stat_pairs_eval = hp[2];
+    ctx->C_last = ctx->pend_count_on_device ? hp[0] : ctx->pend_C;
+  } else {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(&derr, ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost));
+    unsigned long long pe = 0;
+    ctx->C_last = ctx->pend_C;
+    if (ctx->pend_count_on_device)
+      HIPCHK(ctx, hipMemcpy(&ctx->C_last, ctx->d_tri_off.as<long long>() + ctx->G, 8, hipMemcpyDeviceToHost));
+    if (ctx->C_last > 0) HIPCHK(ctx, hipMemcpy(&pe, ctx->d_pair_counter.p, 8, hipMemcpyDeviceToHost));
+    ctx->stat_pairs_eval = (long long)pe;
+  }
+  ctx->stat_survivors = -1;  // summed on demand (lt_get_timers)
+  if (derr == 3)
+    return fail(ctx, LT_ERR_RUNTIME, "the one-point proposal supports at most 64 shared points per connection");
+  if (derr == 2)
+    return fail(ctx, LT_ERR_RUNTIME, "map::at: a point shared by two lines has a point3D_id that is not among the SfM points");
+  if (derr != 0) return fail(ctx, LT_ERR_RUNTIME, "IndexError! Out-of-index matches detected on the device");
+  float ms;
+  static const int kMap[7] = {1, 2, 3, 4, 5, 6, 7};
+  for (int k = 0; k < 7; ++k) {
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+    ctx->timers[kMap[k]] = ms;
+  }
+  HIPCHK(ctx, hipEventElapsedTime(&ms, ev[0], ev[7]));
+  ctx->timers[0] = ms;
+  // single-kernel durations of the matched pipeline: [13] k_gates, [14] k_tri_rows, [15] k_score3
+  ctx->timers[13] = ctx->timers[14] = ctx->timers[15] = 0.0;
+  if (fine_timers() && ctx->job_mode == 1 && ctx->n_blk > 0 && ctx->max_rows > 0) {
+    if (hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) ctx->timers[13] = ms;
+    if (hipEventElapsedTime(&ms, ev[9], ev[10]) == hipSuccess) ctx->timers[14] = ms;
+  }
+  if (fine_timers() && ctx->C_last > 0 && hipEventElapsedTime(&ms, ev[11], ev[5]) == hipSuccess) ctx->timers[15] = ms;
+  (void)hipGetLastError();
+  ctx->timers[11] = (double)ctx->stat_pairs_eval;
+  for (int k = 0; k < 24; ++k)  // [16] (survivors) is counted on demand by lt_get_timers, not per run
+    if (k != 8 && k != 9 && k != 10 && k != 12 && k != 16) ctx->timer_sums[k] += ctx->timers[k];
+  ++ctx->timer_runs;
+  return LT_OK;
+}
+int lt_sync(lt_ctx *ctx) { return finish_run(ctx); }
+
+// Enqueues the whole run and returns.  A run still in flight from the previous call is completed AFTER the
+// new one has been enqueued (its errors are the return value), so a caller that streams batches keeps the
+// device busy across the host's end-of-run bookkeeping.  Two sets of events / pinned result slots alternate.
+int lt_run_device_async(lt_ctx *ctx) {
   if (!ctx->uploaded) return fail(ctx, LT_ERR_STATE, "lt_run_device before lt_upload");
+  if (!ctx->h_pinned) LT_FINISH(ctx);  // no pinned result slots: nothing may stay in flight
+  const int set = ctx->run_pending ? (ctx->pend_set ^ 1) : 0;
+  if (set == 1 && !ctx->ev_b[0])
+    for (auto &e : ctx->ev_b) HIPCHK(ctx, hipEventCreate(&e));
+  hipEvent_t *ev = set ? ctx->ev_b : ctx->ev;
+  long long *hp = ctx->h_pinned ? ctx->h_pinned + 8 * set : nullptr;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const long long G = ctx->G, P = ctx->P;
@@ -1123,22 +1206,22 @@ int lt_run_device(lt_ctx *ctx) {
   ENSURE(ctx, ctx->d_pair_counter, 8);
   ENSURE(ctx, ctx->d_pairs, sizeof(PairRec) * (size_t)std::max(ctx->n_blk, 1));
   ENSURE(ctx, ctx->d_tri_off, sizeof(long long) * (size_t)(G + 1));
-  HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
+  HIPCHK(ctx, hipEventRecord(ev[0], st));
   launch_build_pairs(st, ctx->n_blk, ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_cams.as<Cam>(),
                      ctx->d_pairs.as<PairRec>(), ctx->d_err.as<int>(),
                      ctx->d_pair_counter.as<unsigned long long>());  // also zeroes the error flag and the pair statistic
-  HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
+  HIPCHK(ctx, hipEventRecord(ev[1], st));
 
   long long C_known = -1;  // candidate count once it is known on the host
   long long C_bound = 0;   // what sizes the compact arrays: the count, or an upper bound while it stays on the device
-  ctx->C_last = 0;
+  long long C_run = 0;  // what finish_run reports as the run's candidate count unless the device copy does
   if (ctx->job_mode == 1) {
     const size_t Pn = (size_t)std::max<long long>(P, 1);
     const bool fast = ctx->rows_sorted;
     const long long n_waves = (long long)ctx->n_blk * gen_groups(ctx->max_rows);  // candidate lists
     const long long n_slots_all = (long long)ctx->n_blk * gen_slots(ctx->max_rows);  // survivor lists
     const long long n_entries = ctx->h_blk_line_base[ctx->n_blk];
-    HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+    HIPCHK(ctx, hipEventRecord(ev[2], st));
     // ---- generation in row order; valid candidates appended in row order to per-wave lists ----
     // VP-guided proposals: up to three candidates per match row (vp of l1, vp of l2, algebraic)
     const bool vp_on = ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation;
@@ -1191,15 +1274,15 @@ int lt_run_device(lt_ctx *ctx) {
                        ctx->d_pairs.as<PairRec>(), ctx->d_blk_line_base.as<long long>(), ctx->d_st_c.as<Cand>(),
                        ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(), ctx->d_wave_count.as<unsigned>(),
                        fast ? ctx->d_cnt_bl.as<unsigned>() : nullptr, lds_segs, lds_segs1, ctx->d_st_row.as<unsigned>(),
-                       ctx->d_surv_count.as<unsigned>(), G, ctx->d_seg_gates.p, ctx->d_blkrec.p, fine_timers() ? &ctx->ev[8] : nullptr,
+                       ctx->d_surv_count.as<unsigned>(), G, ctx->d_seg_gates.p, ctx->d_blkrec.p, fine_timers() ? &ev[8] : nullptr,
                        vp_on ? ctx->d_seg_vp.as<double>() : nullptr,
                        vp_on ? ctx->d_seg_has_vp.as<unsigned char>() : nullptr,
                        pts_on ? ctx->d_seg_pt_off.as<long long>() : nullptr, pts_on ? ctx->d_seg_pts.p : nullptr,
                        (pts_on && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr, ctx->d_err.as<int>(),
                        many_on ? 1 : 0, one_on ? 1 : 0, mult);
     }
-    HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
-    long long *hC = ctx->h_pinned;
+    HIPCHK(ctx, hipEventRecord(ev[3], st));
+    long long *hC = hp;  // this set's slot 0
     long long hC_fallback = 0;
     if (!hC) hC = &hC_fallback;
     if (fast) {
@@ -1272,9 +1355,9 @@ int lt_run_device(lt_ctx *ctx) {
                      ctx->d_st_l.as<CandLite>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
                      ctx->d_cand_node.as<unsigned>());
     }
-    HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
+    HIPCHK(ctx, hipEventRecord(ev[4], st));
   } else if (ctx->job_mode == 2) {
-    HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+    HIPCHK(ctx, hipEventRecord(ev[2], st));
     const size_t In = (size_t)std::max<long long>(P, 1);
     // VP-guided proposals: three survivor ballots per work item (algebraic, vp of l1, vp of l2)
     const bool vp_on = ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation;
@@ -1318,7 +1401,7 @@ int lt_run_device(lt_ctx *ctx) {
     long long total = 0;
     HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_mask_pos.as<long long>() + P, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
+    HIPCHK(ctx, hipEventRecord(ev[3], st));
     const size_t Cn = (size_t)std::max<long long>(total, 1);
     ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);
     ENSURE(ctx, ctx->d_score, 8 * Cn); ENSURE(ctx, ctx->d_edge_flag, 4 * Cn);
@@ -1345,14 +1428,14 @@ int lt_run_device(lt_ctx *ctx) {
     launch_cand_node(st, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>());
     C_known = total;
     C_bound = total;
-    HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
+    HIPCHK(ctx, hipEventRecord(ev[4], st));
   } else {
     HIPCHK(ctx, hipMemsetAsync(ctx->d_tri_off.p, 0, sizeof(long long) * (size_t)(G + 1), st));
     ENSURE(ctx, ctx->d_cand, sizeof(Cand)); ENSURE(ctx, ctx->d_lite, sizeof(CandLite));
     ENSURE(ctx, ctx->d_score, 8); ENSURE(ctx, ctx->d_edge_flag, 4); ENSURE(ctx, ctx->d_cand_node, 4);
     C_known = 0;
     C_bound = 0;
-    for (int k = 2; k <= 4; ++k) HIPCHK(ctx, hipEventRecord(ctx->ev[k], st));
+    for (int k = 2; k <= 4; ++k) HIPCHK(ctx, hipEventRecord(ev[k], st));
   }
 
   // ---- scoring ----
@@ -1369,15 +1452,15 @@ int lt_run_device(lt_ctx *ctx) {
       return fail(ctx, LT_ERR_ARGUMENT, "too many (image, neighbour) blocks in one batch (>= 2^24)");
     ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_bound, 1));
     ENSURE(ctx, ctx->d_tile_order, 1024);  // the tile draw counters of k_score3 (8 x 128 B)
-    ctx->C_last = C_bound;  // replaced by the exact count below when that arrives with the error flag
+    C_run = C_bound;  // replaced by the exact count when that arrives with the error flag (finish_run)
     launch_score3(st, C_bound, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
                   ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_node_img.as<int>(),
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
                   ctx->d_score.as<double>(), ctx->d_pair_counter.as<unsigned long long>(), ctx->max_nb, scfg,
-                  guard2, fine_timers() ? ctx->ev[11] : nullptr,
+                  guard2, fine_timers() ? ev[11] : nullptr,
                   ctx->d_tile_order.as<unsigned>(), score_f32);
   }
-  HIPCHK(ctx, hipEventRecord(ctx->ev[5], st));
+  HIPCHK(ctx, hipEventRecord(ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));
   ENSURE(ctx, ctx->d_nvalid, 4 * (size_t)(G + 1));
   ENSURE(ctx, ctx->d_edge_off, 8 * (size_t)(G + 1));
@@ -1392,65 +1475,39 @@ int lt_run_device(lt_ctx *ctx) {
                 ctx->d_nvalid.as<unsigned>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
                 ctx->d_best_c.as<Cand>(), ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(),
                 ctx->d_ntris.as<int>());
-  HIPCHK(ctx, hipEventRecord(ctx->ev[6], st));
-  HIPCHK(ctx, hipEventRecord(ctx->ev[7], st));
+  HIPCHK(ctx, hipEventRecord(ev[6], st));
+  HIPCHK(ctx, hipEventRecord(ev[7], st));
   HIPCHK(ctx, hipGetLastError());
-  // the device error flag and the pair statistic ride on the stream into pinned scratch (two blocking
-  // 8-byte copies after the sync would cost more host time than some of the kernels)
-  int derr = 0;
-  if (ctx->h_pinned) {
-    ctx->h_pinned[1] = 0; ctx->h_pinned[2] = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&ctx->h_pinned[1], ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  // the device error flag, the candidate count and the pair statistic ride on the stream into this set's
+  // pinned slots; finish_run reads them behind the end marker
+  if (hp) {
+    hp[1] = 0; hp[2] = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&hp[1], ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
     if (C_known < 0)
-      HIPCHK(ctx, hipMemcpyAsync(&ctx->h_pinned[0], ctx->d_tri_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
-    if (ctx->C_last > 0)
-      HIPCHK(ctx, hipMemcpyAsync(&ctx->h_pinned[2], ctx->d_pair_counter.p, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    derr = *reinterpret_cast<int *>(&ctx->h_pinned[1]);
-    ctx->stat_pairs_eval = ctx->h_pinned[2];
-    if (C_known < 0) {
-      C_known = ctx->h_pinned[0];
-      ctx->C_last = C_known;
-    }
-  } else {
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    HIPCHK(ctx, hipMemcpy(&derr, ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost));
-    unsigned long long pe = 0;
-    if (ctx->C_last > 0) HIPCHK(ctx, hipMemcpy(&pe, ctx->d_pair_counter.p, 8, hipMemcpyDeviceToHost));
-    ctx->stat_pairs_eval = (long long)pe;
+      HIPCHK(ctx, hipMemcpyAsync(&hp[0], ctx->d_tri_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
+    if (C_run > 0)
+      HIPCHK(ctx, hipMemcpyAsync(&hp[2], ctx->d_pair_counter.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipEventRecord(ev[12], st));
   }
-  ctx->stat_survivors = -1;  // summed on demand (lt_get_timers)
-  if (derr == 3)
-    return fail(ctx, LT_ERR_RUNTIME, "the one-point proposal supports at most 64 shared points per connection");
-  if (derr == 2)
-    return fail(ctx, LT_ERR_RUNTIME, "map::at: a point shared by two lines has a point3D_id that is not among the SfM points");
-  if (derr != 0) return fail(ctx, LT_ERR_RUNTIME, "IndexError! Out-of-index matches detected on the device");
-  float ms;
-  static const int kMap[7] = {1, 2, 3, 4, 5, 6, 7};
-  for (int k = 0; k < 7; ++k) {
-    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
-    ctx->timers[kMap[k]] = ms;
-  }
-  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[7]));
-  ctx->timers[0] = ms;
-  // single-kernel durations of the matched pipeline: [13] k_gates, [14] k_tri_rows, [15] k_score3
-  ctx->timers[13] = ctx->timers[14] = ctx->timers[15] = 0.0;
-  if (fine_timers() && ctx->job_mode == 1 && ctx->n_blk > 0 && ctx->max_rows > 0) {
-    if (hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[9]) == hipSuccess) ctx->timers[13] = ms;
-    if (hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10]) == hipSuccess) ctx->timers[14] = ms;
-  }
-  if (fine_timers() && ctx->C_last > 0 && hipEventElapsedTime(&ms, ctx->ev[11], ctx->ev[5]) == hipSuccess) ctx->timers[15] = ms;
-  (void)hipGetLastError();
-  ctx->timers[11] = (double)ctx->stat_pairs_eval;
-  for (int k = 0; k < 24; ++k)  // [16] (survivors) is counted on demand by lt_get_timers, not per run
-    if (k != 8 && k != 9 && k != 10 && k != 12 && k != 16) ctx->timer_sums[k] += ctx->timers[k];
-  ++ctx->timer_runs;
+  int rc_prev = LT_OK;
+  if (ctx->run_pending) rc_prev = finish_run(ctx);  // the previous run (the other set)
+  ctx->run_pending = true;
+  ctx->pend_set = set;
+  ctx->pend_count_on_device = C_known < 0;
+  ctx->pend_C = C_run;
   ctx->ran = true;
   ctx->downloaded = false;
-  return LT_OK;
+  return rc_prev;
+}
+
+int lt_run_device(lt_ctx *ctx) {
+  int rc = lt_run_device_async(ctx);
+  if (rc) return rc;
+  return finish_run(ctx);
 }
 
 int lt_download(lt_ctx *ctx) {
+  LT_FINISH(ctx);
   if (!ctx->ran) return fail(ctx, LT_ERR_STATE, "lt_download before lt_run_device");
   if (ctx->downloaded) return LT_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1819,6 +1876,7 @@ int64_t lt_num_all_tris(lt_ctx *ctx) {
 }
 
 int lt_get_all_tris(lt_ctx *ctx, int64_t *out_off, double *out_line10, double *out_score, int32_t *out_src2) {
+  LT_FINISH(ctx);
   int rc = lt_flush(ctx);
   if (rc) return rc;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1952,12 +2010,14 @@ int lt_import_image_results(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb
 }
 
 int lt_get_stats(lt_ctx *ctx, int64_t out[8]) {
+  LT_FINISH(ctx);
   out[0] = ctx->n_conn; out[1] = ctx->C; out[2] = ctx->stat_pairs; out[3] = ctx->E;
   out[4] = ctx->stat_graph_nodes; out[5] = ctx->stat_graph_edges; out[6] = (int64_t)ctx->tracks.size();
   out[7] = ctx->G;
   return LT_OK;
 }
 int lt_get_timers(lt_ctx *ctx, double out[24]) {
+  LT_FINISH(ctx);
   ctx->timers[11] = (double)ctx->stat_pairs_eval;
   if (ctx->stat_survivors < 0) {
     ctx->stat_survivors = 0;
@@ -1977,6 +2037,7 @@ int lt_get_timers(lt_ctx *ctx, double out[24]) {
 }
 
 int lt_get_timer_sums(lt_ctx *ctx, double out[24], int64_t *n_runs, int reset) {
+  LT_FINISH(ctx);
   std::memcpy(out, ctx->timer_sums, sizeof(ctx->timer_sums));
   if (n_runs) *n_runs = ctx->timer_runs;
   if (reset) {

@@ -222,7 +222,12 @@ struct lt_ctx {
   double timer_sums[24] = {0};  // over the runs since the last reset (lt_get_timer_sums)
   long long timer_runs = 0;
   long long stat_survivors = 0;  // connections that passed stage A (k_gates) in the last run
-  hipEvent_t ev[12] = {nullptr};
+  hipEvent_t ev[14] = {nullptr};  // [0..11] timing, [12] end-of-run marker
+  hipEvent_t ev_b[14] = {nullptr};  // second set, created when a run is enqueued behind one still in flight
+  bool run_pending = false;         // lt_run_device_async left a run in flight (finish_run completes it)
+  int pend_set = 0;                 // its event / pinned-slot set
+  bool pend_count_on_device = false;
+  long long pend_C = 0;
   long long C_last = 0;  // candidates of the last lt_run_device (known on the host once the scoring grid is sized)
 };
 

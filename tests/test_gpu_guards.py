@@ -205,6 +205,42 @@ def test_candidate_count_stays_on_device(gpu_lib, clean_env):
         assert base[5]["candidates"] == other[5]["candidates"] > 0
 
 
+def test_async_runs_pipeline(gpu_lib, clean_env):
+    """lt_run_device_async: runs enqueued back to back (the previous one is completed after the next one is
+    enqueued, two alternating sets of events / result slots) give the results of a synchronous run; timer sums
+    count every run; an error of a run in flight surfaces at the next call that completes it."""
+    sc = syn.make_scene(n_views=10, n_segs=120, n_neighbors=4, seed=55)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    base = _results(run_product(sc, cfg))
+    T = run_product(sc, cfg)
+    ctx = T.context()
+    ctx.upload()
+    ctx.timer_sums(reset=True)
+    for _ in range(5):
+        ctx.run_device(wait=False)
+    sums, n = ctx.timer_sums()      # completes the run in flight
+    assert n == 5 and sums["run"] > 0
+    _same(base, _results(T))
+    ctx.run_device(wait=False)
+    ctx.sync()
+    assert ctx.timer_sums()[1] == 6
+    # a failing run (a shared point3D id without an SfM point is detected on the device)
+    from limap_amd import triangulation as tri
+    bpts, sfm = syn.make_bipartites(sc, seed=3)
+    cfg2 = dict(cfg, disable_one_point_triangulation=True)
+    T2 = tri.GlobalLineTriangulator(cfg2)
+    T2.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+    T2.SetBipartites2d(bpts)
+    T2.SetSfMPoints({k: v for k, v in list(sfm.items())[:3]})
+    for i in sc.img_ids:
+        T2.TriangulateImage(int(i), sc.matches_of(int(i)))
+    c2 = T2.context()
+    c2.upload()
+    c2.run_device(wait=False)       # enqueued; nothing to complete yet
+    with pytest.raises(RuntimeError, match="point3D_id"):
+        c2.sync()
+
+
 def test_full_size_invariants(gpu_lib, clean_env):
     """BASELINE's full size (100 views x 500 segments, 10^7 connections): the oracle needs ~8 s per run
     here (bench.py times it and checks its counts), so this test uses size-independent properties --
