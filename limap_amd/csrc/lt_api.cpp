@@ -90,7 +90,15 @@ HostBlock host_block_acquire(size_t bytes) {
     }
   }
   HostBlock b;
-  b.bytes = bytes + bytes / 8;
+  // size classes (powers of two up to 64 MB) so that the blocks a context needs -- per-node results, the
+  // download buffer, scratch -- are interchangeable between contexts; pinning a new block costs ~1 ms per MB
+  if (bytes <= (64u << 20)) {
+    size_t c = 4096;
+    while (c < bytes) c <<= 1;
+    b.bytes = c;
+  } else {
+    b.bytes = bytes + bytes / 8;
+  }
   void *q = nullptr;
   if (hipHostMalloc(&q, b.bytes, hipHostMallocDefault) == hipSuccess) {
     b.p = q;
@@ -369,7 +377,11 @@ int init_common(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *s
     for (long long g = ctx->seg_off[i]; g < ctx->seg_off[i + 1]; ++g) ctx->h_node_img[g] = i;
   ctx->triangulated.assign(n_img, 0);
   ctx->neighbors.assign(n_img, {});
-  ctx->best_c.assign(ctx->G, Cand{});
+  lt_host::host_block_release(ctx->best_c_blk);
+  ctx->best_c_blk = lt_host::host_block_acquire(sizeof(Cand) * (size_t)std::max<long long>(ctx->G, 1));
+  ctx->best_c = (Cand *)ctx->best_c_blk.p;
+  if (!ctx->best_c) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the per-node results");
+  ctx->best_c_set.assign(n_img, 0);
   ctx->best_score.assign(ctx->G, 0.0);
   ctx->best_src2.assign(2 * ctx->G, 0);
   ctx->n_tris.assign(ctx->G, 0);
@@ -388,7 +400,9 @@ int init_common(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *s
   return LT_OK;
 }
 
-int build_invariants(lt_ctx *ctx) {
+// hk / hq / ht / hs: the scene in host memory (ascending id order) if the caller has it, else it is read back
+int build_invariants(lt_ctx *ctx, const double *hk = nullptr, const double *hq = nullptr, const double *ht = nullptr,
+                     const double *hs = nullptr) {
   hipStream_t st = ctx->stream;
   ENSURE(ctx, ctx->d_cams, sizeof(Cam) * (size_t)std::max(ctx->n_img, 1));
   ENSURE(ctx, ctx->d_segs, sizeof(Seg) * (size_t)std::max<long long>(ctx->G, 1));
@@ -408,14 +422,21 @@ int build_invariants(lt_ctx *ctx) {
   {  // host copies for the tail-side filters (small: 88 B per image + 32 B per segment)
     const int n = ctx->n_img;
     std::vector<double> k(4 * (size_t)n), q(4 * (size_t)n), t(3 * (size_t)n);
-    ctx->h_segs.assign(4 * (size_t)ctx->G, 0.0);
-    if (n > 0) {
-      HIPCHK(ctx, hipMemcpy(k.data(), ctx->d_kvec.p, 32 * (size_t)n, hipMemcpyDeviceToHost));
-      HIPCHK(ctx, hipMemcpy(q.data(), ctx->d_qvec.p, 32 * (size_t)n, hipMemcpyDeviceToHost));
-      HIPCHK(ctx, hipMemcpy(t.data(), ctx->d_tvec.p, 24 * (size_t)n, hipMemcpyDeviceToHost));
+    if (hk && hq && ht && hs) {
+      std::memcpy(k.data(), hk, 32 * (size_t)n);
+      std::memcpy(q.data(), hq, 32 * (size_t)n);
+      std::memcpy(t.data(), ht, 24 * (size_t)n);
+      ctx->h_segs.assign(hs, hs + 4 * (size_t)ctx->G);
+    } else {
+      ctx->h_segs.assign(4 * (size_t)ctx->G, 0.0);
+      if (n > 0) {
+        HIPCHK(ctx, hipMemcpy(k.data(), ctx->d_kvec.p, 32 * (size_t)n, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(q.data(), ctx->d_qvec.p, 32 * (size_t)n, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(t.data(), ctx->d_tvec.p, 24 * (size_t)n, hipMemcpyDeviceToHost));
+      }
+      if (ctx->G > 0)
+        HIPCHK(ctx, hipMemcpy(ctx->h_segs.data(), ctx->d_segs_raw.p, 32 * (size_t)ctx->G, hipMemcpyDeviceToHost));
     }
-    if (ctx->G > 0)
-      HIPCHK(ctx, hipMemcpy(ctx->h_segs.data(), ctx->d_segs_raw.p, 32 * (size_t)ctx->G, hipMemcpyDeviceToHost));
     if (ctx->cfg.add_halfpix)
       for (double &v : ctx->h_segs) v = v + 0.5;
     ctx->h_cams.resize(n);
@@ -544,6 +565,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
                     &ctx->d_pair_counter, &ctx->d_tile_order, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz};
   lt_host::host_block_release(ctx->h_pinned_blk);
+  lt_host::host_block_release(ctx->best_c_blk);
   for (DevBuf *b : bufs) b->release();
   for (auto &e : ctx->ev_b)
     if (e) (void)hipEventDestroy(e);
@@ -591,8 +613,17 @@ int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, 
   std::vector<int> perm(n_img);
   for (int i = 0; i < n_img; ++i) perm[i] = i;
   std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return img_ids[a] < img_ids[b]; });
+  static const bool init_trace = getenv("LT_TAIL_TRACE") != nullptr;
+  double tl = now_ms();
+  auto lap = [&](const char *what) {
+    if (!init_trace) return;
+    double t = now_ms();
+    std::fprintf(stderr, "[init] %-18s %.3f ms\n", what, t - tl);
+    tl = t;
+  };
   int rc = init_common(ctx, n_img, img_ids, seg_off, perm);
   if (rc) return rc;
+  lap("init_common");
   // gather into ascending-id order
   std::vector<double> k(4 * (size_t)n_img), q(4 * (size_t)n_img), t(3 * (size_t)n_img), s(4 * (size_t)ctx->G);
   for (int i = 0; i < n_img; ++i) {
@@ -603,11 +634,15 @@ int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, 
     long long m = seg_off[p + 1] - seg_off[p];
     if (m > 0) std::memcpy(&s[4 * ctx->seg_off[i]], segs + 4 * seg_off[p], (size_t)m * 32);
   }
+  lap("gather");
   if ((rc = upload_vec(ctx, ctx->d_kvec, k))) return rc;
   if ((rc = upload_vec(ctx, ctx->d_qvec, q))) return rc;
   if ((rc = upload_vec(ctx, ctx->d_tvec, t))) return rc;
   if ((rc = upload_vec(ctx, ctx->d_segs_raw, s))) return rc;
-  return build_invariants(ctx);
+  lap("upload");
+  rc = build_invariants(ctx, k.data(), q.data(), t.data(), s.data());
+  lap("build_invariants");
+  return rc;
 }
 
 int lt_init_vp(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *label_off, const int32_t *labels,
@@ -1506,6 +1541,16 @@ int lt_run_device(lt_ctx *ctx) {
   return finish_run(ctx);
 }
 
+// Images that have no results (yet) hold a value-initialised best candidate, like the reference's TriTuple.
+static void define_best_of_other_images(lt_ctx *ctx) {
+  for (int i = 0; i < ctx->n_img; ++i)
+    if (!ctx->best_c_set[(size_t)i]) {
+      const long long a = ctx->seg_off[i], b = ctx->seg_off[i + 1];
+      if (b > a) std::memset((void *)(ctx->best_c + a), 0, sizeof(Cand) * (size_t)(b - a));
+      ctx->best_c_set[(size_t)i] = 1;
+    }
+}
+
 int lt_download(lt_ctx *ctx) {
   LT_FINISH(ctx);
   if (!ctx->ran) return fail(ctx, LT_ERR_STATE, "lt_download before lt_run_device");
@@ -1566,6 +1611,7 @@ int lt_download(lt_ctx *ctx) {
 #pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 4) reduction(+ : pairs)
   for (long long j = 0; j < n_job; ++j) {
     const int idx = ctx->job_imgs[(size_t)j];
+    ctx->best_c_set[(size_t)idx] = 1;
     for (long long g = ctx->seg_off[idx]; g < ctx->seg_off[idx + 1]; ++g) {
       ctx->n_tris[g] = nt[g];
       pairs += (long long)nt[g] * nt[g];
@@ -1579,6 +1625,7 @@ int lt_download(lt_ctx *ctx) {
       ctx->valid_edges.cnt[(size_t)g] = (int)(2 * (edge_off[g + 1] - edge_off[g]));
     }
   }
+  define_best_of_other_images(ctx);
   ctx->stat_pairs = pairs;
   ctx->downloaded = true;
   ctx->timers[9] = now_ms() - t0;
@@ -1604,6 +1651,7 @@ int lt_flush(lt_ctx *ctx) {
 int lt_compute_tracks(lt_ctx *ctx) {
   int rc = lt_flush(ctx);
   if (rc) return rc;
+  if (ctx->inited) define_best_of_other_images(ctx);
   if (ctx->cfg.merging_strategy != 0)  // global_line_triangulator.cc:314-316
     return fail(ctx, LT_ERR_RUNTIME, "Error!The given merging strategy is not implemented");
   double t0 = now_ms();
@@ -1828,6 +1876,7 @@ int64_t lt_num_nodes(lt_ctx *ctx) { return ctx->G; }
 int lt_get_best(lt_ctx *ctx, double *out_line10, double *out_score, int32_t *out_src2, uint8_t *out_has_best) {
   int rc = lt_flush(ctx);
   if (rc) return rc;
+  if (ctx->inited) define_best_of_other_images(ctx);
   for (long long g = 0; g < ctx->G; ++g) {
     const Cand &c = ctx->best_c[g];
     double *o = out_line10 + 10 * g;
@@ -1995,6 +2044,7 @@ int lt_import_image_results(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb
   for (long long g = g0; g < ctx->seg_off[idx + 1]; ++g) {
     long long l = g - g0;
     Cand &c = ctx->best_c[g];
+    c = Cand{};
     const double *o = line10 + 10 * l;
     for (int k = 0; k < 3; ++k) { c.s[k] = o[k]; c.e[k] = o[3 + k]; }
     c.depth[0] = o[6]; c.depth[1] = o[7]; c.unc = o[8]; c.score3 = o[9];
@@ -2005,6 +2055,8 @@ int lt_import_image_results(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb
     ctx->has_best[g] = n_tris[l] > 0 ? 1 : 0;
     ctx->valid_edges.set(g, edges2 + 2 * edge_off[l], edges2 + 2 * edge_off[l + 1]);
   }
+  ctx->best_c_set[(size_t)idx] = 1;
+  define_best_of_other_images(ctx);
   ctx->tracks_done = false;
   return LT_OK;
 }

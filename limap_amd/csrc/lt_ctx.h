@@ -209,7 +209,11 @@ struct lt_ctx {
   long long C = 0, E = 0;  // candidates / valid edges of the last run
 
   // ---- host results (all nodes) ----
-  std::vector<Cand> best_c;
+  // best candidate per node: a pooled host block (5.6 MB at 50 000 nodes; value-initialising a fresh vector of
+  // that size costs more than the device run) -- an image's range is defined once best_c_set[image] is set
+  lt_host::HostBlock best_c_blk;
+  Cand *best_c = nullptr;
+  std::vector<char> best_c_set;
   std::vector<double> best_score;
   std::vector<int> best_src2, n_tris;
   std::vector<unsigned char> has_best;
