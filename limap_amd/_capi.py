@@ -322,6 +322,14 @@ class Context:
             ids, xyz = np.zeros(1, np.int32), np.zeros((1, 3))
         self.chk(self.L.lt_set_sfm_points(self.h, n, ptr(ids, C.c_int32), ptr(xyz, C.c_double)))
 
+    @property
+    def rows_fn_addr(self):
+        """Address of lt_triangulate_image_rows (for the CPython marshalling helper)."""
+        a = getattr(self, "_rows_fn_addr", None)
+        if a is None:
+            a = self._rows_fn_addr = C.cast(self.L.lt_triangulate_image_rows, C.c_void_p).value
+        return a
+
     def triangulate_image_rows(self, img_id, nb_ids, arrays):
         """arrays[k]: C-contiguous int32 (K,2) rows of neighbour nb_ids[k] (kept alive for the call)."""
         n = len(arrays)

@@ -83,3 +83,31 @@ def test_config_mirror_class():
     assert c.var2d == 4.0 and c.linker2d_config["th_perp"] == 3.0 and c._s.merging_strategy == 2
     with pytest.raises(AttributeError):
         c.sensitivity_threshold_typo = 1  # like the pybind class: unknown attributes are rejected
+
+
+def test_pymarshal_helper_matches_python_path():
+    """limap_amd/_lt_pymarshal (CPython helper): hands the data pointers / row counts of C-contiguous int32
+    (K,2) arrays to the C entry point; anything else returns None (the Python path converts by copy)."""
+    import ctypes as C
+    from limap_amd import triangulation as tri
+    if tri._fast is None:
+        pytest.skip("helper not built")
+    seen = {}
+    proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                        C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int64))
+
+    def fake(ctx, img_id, n_nb, nb, rows, cnt):
+        seen["ctx"], seen["img"], seen["n"] = ctx, img_id, n_nb
+        seen["nb"] = [nb[k] for k in range(n_nb)]
+        seen["cnt"] = [cnt[k] for k in range(n_nb)]
+        seen["first"] = [(rows[k][0], rows[k][1]) if cnt[k] else None for k in range(n_nb)]
+        return 7
+    cb = proto(fake)
+    addr = C.cast(cb, C.c_void_p).value
+    m = {5: np.array([[1, 2], [3, 4]], np.int32), 2: np.zeros((0, 2), np.int32), np.int64(9): np.array([[7, 8]], np.int32)}
+    assert tri._fast.triangulate_image_rows(addr, 1234, 42, m) == 7
+    assert seen == {"ctx": 1234, "img": 42, "n": 3, "nb": [5, 2, 9], "cnt": [2, 0, 1], "first": [(1, 2), None, (7, 8)]}
+    for bad in (np.array([[1, 2]], np.int64), np.array([[1, 2, 3]], np.int32), np.zeros((4, 4), np.int32)[:, :2],
+                np.zeros(0, np.int32), [[1, 2]]):
+        assert tri._fast.triangulate_image_rows(addr, 1234, 42, {1: bad}) is None
+    assert tri._fast.triangulate_image_rows(addr, 1234, 42, {"x": m[5]}) is None
