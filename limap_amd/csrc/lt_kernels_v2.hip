@@ -35,7 +35,7 @@ namespace lt {
 //   k_gates     stage A on every row with the three-way cheap gates (gate3): lean, high occupancy.
 //               The neighbour's gate table (SegGate, 80 B per segment) is staged once per workgroup
 //               in LDS.  Per slot an ordered list of surviving rows:
-//               st_row[r0 + k] = (row - r0) | undecided << 31.
+//               st_row[r0 + k] = (line | undecided << 31, neighbour line).
 //   k_tri_rows  stage B (triangulation / cheirality / sensitivity / uncertainty / ranges) from those
 //               lists on dense wave64s; rows flagged undecided first go through the exact gates
 //               (gen_gates).  Valid candidates are appended IN ROW ORDER to the slot's list
@@ -94,7 +94,8 @@ struct GenArgs {
   const SegGate *gates;
   const PairRec *pairs;
   const long long *blk_line_base;
-  unsigned *st_row;       // [P] surviving rows of stage A, per-slot lists at the slot's first row
+  uint2 *st_row;          // [P] surviving rows of stage A, per-slot lists at the slot's first row:
+                          // (line | undecided << 31, neighbour line)
   unsigned *surv_count;   // [n_blk * n_slots]
   Cand *st_c;             // [P] valid candidates, per-slot lists at the slot's first row
   CandLite *st_l;
@@ -299,9 +300,14 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
       for (int c = 0; c < kGenChunks; ++c) {
         const bool pass = (pass_bits >> c) & 1u;
         const unsigned long long m = __ballot(pass);
-        if (pass)
+        if (pass) {
+          // the survivor entry carries the row itself (line | undecided << 31, neighbour line): stage B then
+          // reads its rows as one contiguous list instead of one scattered 64-byte sector per survivor
+          // (the chunk's rows are re-read here, coalesced and cache-hot, rather than held in registers)
+          const int2 v = *reinterpret_cast<const int2 *>(a.m_pairs + 2 * (r0 + 64ll * c + lane));
           a.st_row[r0 + wcount + __popcll(m & lanemask_lt())] =
-              (unsigned)(64 * c + lane) | (((und_bits >> c) & 1u) ? 0x80000000u : 0u);
+              make_uint2((unsigned)v.x | (((und_bits >> c) & 1u) ? 0x80000000u : 0u), (unsigned)v.y);
+        }
         wcount += (unsigned)__popcll(m);
       }
     }
@@ -428,15 +434,13 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
       for (int t = 1; t < kTriSlots; ++t)
         if (e >= cs[t]) { k = t; first = cs[t]; }
       const long long rs0 = r0 + (long long)k * kRowsPerWave;
-      const unsigned u = a.st_row[rs0 + (e - first)];
-      const long long r = rs0 + (long long)(u & 0x7FFFFFFFu);
-      const int2 v = *reinterpret_cast<const int2 *>(a.m_pairs + 2 * r);
-      line = v.x;
-      ng = v.y;
+      const uint2 u = a.st_row[rs0 + (e - first)];
+      line = (int)(u.x & 0x7FFFFFFFu);
+      ng = (int)u.y;
       const Seg &s1 = a.segs[g1 + line];
       const Seg &s2 = a.segs[g2 + ng];
       ok = true;
-      if (u >> 31) ok = gen_gates(cfg, s1, s2, pr->F);  // the cheap gates could not decide
+      if (u.x >> 31) ok = gen_gates(cfg, s1, s2, pr->F);  // the cheap gates could not decide
       if (ok) ok = gen_finish(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B, &o);
       if (kExtra) {
         // both segments long enough (:166,177) -- with extra proposals stage A lets every row through
@@ -1040,7 +1044,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
                       const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
                       const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
-                      unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, unsigned *st_row,
+                      unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, void *st_row,
                       unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3,
                       const double *seg_vp, const unsigned char *seg_has_vp, const long long *seg_pt_off,
                       const void *seg_pts, const double *sfm_xyz, int *err_flag, int many_on, int one_on,
@@ -1060,7 +1064,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   GenArgs a;
   a.m_off = m_off; a.m_pairs = m_pairs; a.blk_img = blk_img; a.blk_nb = blk_nb; a.blk_slot = blk_slot;
   a.seg_off = seg_off; a.cams = cams; a.segs = segs; a.gates = reinterpret_cast<const SegGate *>(gates);
-  a.pairs = pairs; a.blk_line_base = blk_line_base; a.st_row = st_row; a.surv_count = surv_count;
+  a.pairs = pairs; a.blk_line_base = blk_line_base; a.st_row = reinterpret_cast<uint2 *>(st_row); a.surv_count = surv_count;
   a.st_c = st_c; a.st_l = st_l; a.st_key = st_key; a.wave_count = wave_count; a.cnt_bl = cnt_bl;
   a.n_slots = gen_slots(max_rows); a.lds_segs = lds_segs; a.lds_segs1 = lds_segs1;
   a.seg_vp = seg_vp; a.seg_has_vp = seg_has_vp;
