@@ -1509,7 +1509,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                 scfg.max_valid_conns, ctx->d_best_idx.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
                 ctx->d_nvalid.as<unsigned>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
                 ctx->d_best_c.as<Cand>(), ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(),
-                ctx->d_ntris.as<int>());
+                ctx->d_ntris.as<int>(), /*wide=*/ctx->job_mode == 2);
   HIPCHK(ctx, hipEventRecord(ev[6], st));
   HIPCHK(ctx, hipEventRecord(ev[7], st));
   HIPCHK(ctx, hipGetLastError());

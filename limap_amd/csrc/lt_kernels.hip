@@ -419,21 +419,24 @@ __global__ void k_tri_offsets_ex(long long G, const long long *__restrict__ item
 // ---------------------------------------------------------------------------------------------
 // per-node selection: best candidate = first strict maximum; valid-edge flags
 // ---------------------------------------------------------------------------------------------
+template <int kLanes>  // lanes per node: 16 (matched mode, ~12 candidates per node) or 64 (exhaustive, hundreds)
 __global__ void __launch_bounds__(256)
 k_select(long long G, const long long *__restrict__ tri_off, const double *__restrict__ score,
          double fullscore_th, int max_valid_conns, long long *__restrict__ best_idx,
          unsigned *__restrict__ edge_flag, unsigned *__restrict__ n_valid, const Cand *__restrict__ cand,
          const CandLite *__restrict__ lite, Cand *__restrict__ best_c, double *__restrict__ best_score,
          int *__restrict__ best_src2, int *__restrict__ n_tris) {
-  long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // kLanes = 16: a quarter wave per node -- a whole wave per node left 4/5 of the lanes idle in matched mode;
+  // xor-shuffles below kLanes stay inside the group
+  long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / kLanes;
   if (g >= G) return;
-  const int lane = lane_id();
+  const int lane = lane_id() & (kLanes - 1);
   const long long off = tri_off[g];
   const int n = (int)(tri_off[g + 1] - off);
   double bs = -1.0;
   int bi = -1;
   int n_full = 0;
-  for (int i = lane; i < n; i += 64) {
+  for (int i = lane; i < n; i += kLanes) {
     double s = score[off + i];
     if (s > bs) {  // ascending i inside a lane: first strict max
       bs = s;
@@ -441,7 +444,7 @@ k_select(long long G, const long long *__restrict__ tri_off, const double *__res
     }
     if (s >= fullscore_th) ++n_full;
   }
-  for (int d = 32; d >= 1; d >>= 1) {
+  for (int d = kLanes / 2; d >= 1; d >>= 1) {
     double os = __shfl_xor(bs, d);
     int oi = __shfl_xor(bi, d);
     n_full += __shfl_xor(n_full, d);
@@ -479,7 +482,7 @@ k_select(long long G, const long long *__restrict__ tri_off, const double *__res
   // valid edges: the max_valid_conns best by (score, tri_id) descending, kept if score >= th
   const bool need_rank = n_full > max_valid_conns;
   int kept = 0;
-  for (int i = lane; i < n; i += 64) {
+  for (int i = lane; i < n; i += kLanes) {
     double s = score[off + i];
     unsigned f = s >= fullscore_th ? 1u : 0u;
     if (f && need_rank) {
@@ -493,7 +496,7 @@ k_select(long long G, const long long *__restrict__ tri_off, const double *__res
     edge_flag[off + i] = f;
     kept += (int)f;
   }
-  for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d);
+  for (int d = kLanes / 2; d >= 1; d >>= 1) kept += __shfl_xor(kept, d);
   if (lane == 0) n_valid[g] = (unsigned)kept;
 }
 
@@ -636,10 +639,17 @@ void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_of
 }
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
                    int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const Cand *cand,
-                   const CandLite *lite, Cand *best_c, double *best_score, int *best_src2, int *n_tris) {
+                   const CandLite *lite, Cand *best_c, double *best_score, int *best_src2, int *n_tris,
+                   bool wide) {
   if (G > 0)
-    hipLaunchKernelGGL(k_select, dim3(nblk(G * 64, 256)), dim3(256), 0, st, G, tri_off, score, th, max_valid,
-                       best_idx, edge_flag, n_valid, cand, lite, best_c, best_score, best_src2, n_tris);
+  {
+    if (wide)
+      hipLaunchKernelGGL(k_select<64>, dim3(nblk(G * 64, 256)), dim3(256), 0, st, G, tri_off, score, th, max_valid,
+                         best_idx, edge_flag, n_valid, cand, lite, best_c, best_score, best_src2, n_tris);
+    else
+      hipLaunchKernelGGL(k_select<16>, dim3(nblk(G * 16, 256)), dim3(256), 0, st, G, tri_off, score, th, max_valid,
+                         best_idx, edge_flag, n_valid, cand, lite, best_c, best_score, best_src2, n_tris);
+  }
 }
 void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
                       const long long *edge_off, const CandLite *lite, int *edges2) {
