@@ -544,12 +544,26 @@ __global__ void k_node_prefix(long long G, const int *__restrict__ node_img,
   if (g < G) {
     int img = node_img[g];
     int line = (int)(g - seg_off[img]);
-    for (long long b = nb_off[img]; b < nb_off[img + 1]; ++b) {
-      long long e = blk_line_base[b] + line;
-      unsigned c = cnt_bl[e];
-      cnt_bl[e] = 0;  // every counter is read exactly once: leave the array clean for the next run
-      base_bl[e] = run;
-      run += c;
+    // all loads of a chunk of 16 blocks first, then the stores: interleaved, every load would have to wait for
+    // the store before it (same array as far as the compiler can tell) -- 20 serial round trips per thread
+    const long long b0 = nb_off[img], b1 = nb_off[img + 1];
+    for (long long bb = b0; bb < b1; bb += 16) {
+      long long e[16];
+      unsigned c[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        e[k] = (bb + k < b1) ? blk_line_base[bb + k] + line : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) c[k] = e[k] >= 0 ? cnt_bl[e[k]] : 0u;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (e[k] >= 0) {
+          cnt_bl[e[k]] = 0;  // every counter is read exactly once: leave the array clean for the next run
+          base_bl[e[k]] = run;
+        }
+        run += c[k];
+      }
     }
   }
   n_tris[g] = run;
