@@ -45,7 +45,8 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
 size_t seg_point_bytes();
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
-                        unsigned *base_bl, unsigned *n_tris);
+                        unsigned *base_bl, unsigned *n_tris, long long *tri_off, unsigned long long *status,
+                        int *err_flag);
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
@@ -563,7 +564,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
-                    &ctx->d_pair_counter, &ctx->d_tile_order, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz};
+                    &ctx->d_pair_counter, &ctx->d_tile_order, &ctx->d_scan_status, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz};
   lt_host::host_block_release(ctx->h_pinned_blk);
   lt_host::host_block_release(ctx->best_c_blk);
   for (DevBuf *b : bufs) b->release();
@@ -1185,6 +1186,7 @@ int finish_run(lt_ctx *ctx) {
     ctx->stat_pairs_eval = (long long)pe;
   }
   ctx->stat_survivors = -1;  // summed on demand (lt_get_timers)
+  if (derr == 4) return fail(ctx, LT_ERR_RUNTIME, "internal: the scan of the node counts did not complete");
   if (derr == 3)
     return fail(ctx, LT_ERR_RUNTIME, "the one-point proposal supports at most 64 shared points per connection");
   if (derr == 2)
@@ -1242,9 +1244,13 @@ int lt_run_device_async(lt_ctx *ctx) {
   ENSURE(ctx, ctx->d_pairs, sizeof(PairRec) * (size_t)std::max(ctx->n_blk, 1));
   ENSURE(ctx, ctx->d_tri_off, sizeof(long long) * (size_t)(G + 1));
   HIPCHK(ctx, hipEventRecord(ev[0], st));
+  // also zeroes the error flag, the pair statistic and the look-back state of k_node_prefix's scan
+  const int n_status = (int)((G + 1 + 255) / 256) + 1;
+  ENSURE(ctx, ctx->d_scan_status, 8 * (size_t)n_status);
   launch_build_pairs(st, ctx->n_blk, ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_cams.as<Cam>(),
                      ctx->d_pairs.as<PairRec>(), ctx->d_err.as<int>(),
-                     ctx->d_pair_counter.as<unsigned long long>());  // also zeroes the error flag and the pair statistic
+                     ctx->d_pair_counter.as<unsigned long long>(), ctx->d_scan_status.as<unsigned long long>(),
+                     n_status);
   HIPCHK(ctx, hipEventRecord(ev[1], st));
 
   long long C_known = -1;  // candidate count once it is known on the host
@@ -1324,13 +1330,10 @@ int lt_run_device_async(lt_ctx *ctx) {
       // rows of every block are sorted by line id: sort-free placement
       launch_node_prefix(st, G, ctx->d_node_img.as<int>(), ctx->d_seg_off.as<long long>(),
                          ctx->d_nb_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
-                         ctx->d_cnt_bl.as<unsigned>(), ctx->d_base_bl.as<unsigned>(), ctx->d_ntris_u.as<unsigned>());
+                         ctx->d_cnt_bl.as<unsigned>(), ctx->d_base_bl.as<unsigned>(), ctx->d_ntris_u.as<unsigned>(),
+                         ctx->d_tri_off.as<long long>(), ctx->d_scan_status.as<unsigned long long>(),
+                         ctx->d_err.as<int>());  // tri_off = exclusive scan of the counts, in the same kernel
       ctx->cnt_bl_clean = true;
-      size_t tmp = scan_temp_bytes_u32_to_i64(G + 1);
-      ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
-      if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, G + 1, ctx->d_ntris_u.as<unsigned>(),
-                                 ctx->d_tri_off.as<long long>()) != 0)
-        return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
       // Nothing below needs the candidate count on the host (the kernels read tri_off[G]; the grids of
       // k_place / k_score3 do not depend on it) except the SIZE of the compact arrays.  While the trivial
       // bound -- one candidate per staging slot -- fits kCountFreeBytes, the arrays get that size and the

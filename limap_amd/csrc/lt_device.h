@@ -25,7 +25,8 @@ void launch_build_cams(hipStream_t st, int n, const double *k, const double *q, 
 void launch_build_segs(hipStream_t st, long long n_segs, int n_img, const long long *seg_off,
                        const double *segs, double halfpix, const Cam *cams, Seg *out);
 void launch_build_pairs(hipStream_t st, int n_blk, const int *blk_img, const int *blk_nb, const Cam *cams,
-                        PairRec *out, int *err_flag, unsigned long long *pair_counter);
+                        PairRec *out, int *err_flag, unsigned long long *pair_counter,
+                        unsigned long long *scan_status, int n_status);
 size_t sort_temp_bytes(long long P, int end_bit);
 int launch_sort(hipStream_t st, void *temp, size_t temp_bytes, long long P, const unsigned *keys_in,
                 unsigned *keys_out, const unsigned *vals_in, unsigned *vals_out, int end_bit);

@@ -534,12 +534,26 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
 
 // Fast path: exclusive prefix of cnt_bl over the neighbour blocks of every node (into base_bl) and the
 // node's candidate count.
-__global__ void k_node_prefix(long long G, const int *__restrict__ node_img,
-                              const long long *__restrict__ seg_off, const long long *__restrict__ nb_off,
-                              const long long *__restrict__ blk_line_base, unsigned *__restrict__ cnt_bl,
-                              unsigned *__restrict__ base_bl, unsigned *__restrict__ n_tris) {
-  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g > G) return;
+// The exclusive scan of the node counts (tri_off) is part of the same kernel: single-pass scan with decoupled
+// look-back.  A workgroup takes a ticket (its tile = 256 consecutive nodes in ticket order, so every
+// predecessor is already running), publishes its tile total, and its first wave looks back 64 predecessors at
+// a time until it meets one whose inclusive prefix is known.  status[0] = ticket counter, status[1 + tile] =
+// flag << 62 | value (flag 1: tile total, 2: inclusive prefix); zeroed by k_build_pairs of the same run.
+// State words are read / written with device-scope atomic RMWs (the L2s of the XCDs are not coherent for
+// plain loads).  (rocPRIM's device scan of the same 50 001 entries is two launches, ~10 us.)
+__global__ void __launch_bounds__(256)
+k_node_prefix(long long G, const int *__restrict__ node_img, const long long *__restrict__ seg_off,
+              const long long *__restrict__ nb_off, const long long *__restrict__ blk_line_base,
+              unsigned *__restrict__ cnt_bl, unsigned *__restrict__ base_bl, unsigned *__restrict__ n_tris,
+              long long *__restrict__ tri_off, unsigned long long *__restrict__ status, int *__restrict__ err_flag) {
+  __shared__ unsigned s_tile;
+  __shared__ long long s_wave[4];
+  __shared__ long long s_prefix;
+  if (threadIdx.x == 0) s_tile = (unsigned)atomicAdd(&status[0], 1ull);
+  __syncthreads();
+  const long long tile = s_tile;
+  const long long g = tile * 256 + threadIdx.x;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
   unsigned run = 0;
   if (g < G) {
     int img = node_img[g];
@@ -566,7 +580,57 @@ __global__ void k_node_prefix(long long G, const int *__restrict__ node_img,
       }
     }
   }
-  n_tris[g] = run;
+  // tile-local inclusive scan
+  long long incl = (long long)run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const long long o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  long long wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += s_wave[w];
+  const long long total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  constexpr unsigned long long kMask = (1ull << 62) - 1ull;
+  if (wave == 0) {
+    long long prefix = 0;
+    if (tile > 0) {
+      if (lane == 0) atomicExch(&status[1 + tile], (1ull << 62) | (unsigned long long)total);
+      long long hi = tile;  // predecessors [0, hi) still to be accounted for
+      bool done = false;
+      while (!done) {
+        const long long k = hi - 1 - lane;  // lane 0: the nearest predecessor
+        unsigned long long v = 2ull << 62;   // beyond tile 0: "inclusive prefix 0"
+        if (k >= 0) {
+          int budget = 1 << 22;
+          do {
+            v = atomicAdd(&status[1 + k], 0ull);
+          } while ((v >> 62) == 0ull && --budget > 0);
+          if ((v >> 62) == 0ull) {  // cannot happen (the predecessor holds an earlier ticket); never hang
+            *err_flag = 4;
+            v = 2ull << 62;
+          }
+        }
+        const unsigned long long incl_lanes = __ballot((v >> 62) == 2ull);
+        const int first = incl_lanes ? __builtin_ctzll(incl_lanes) : 64;
+        long long part = (lane <= first) ? (long long)(v & kMask) : 0ll;
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+        prefix += part;
+        if (first < 64) done = true;
+        else hi -= 64;
+      }
+    }
+    if (lane == 0) {
+      atomicExch(&status[1 + tile], (2ull << 62) | (unsigned long long)(prefix + total));
+      s_prefix = prefix;
+    }
+  }
+  __syncthreads();
+  if (g <= G) {
+    tri_off[g] = s_prefix + wbase + incl - (long long)run;
+    n_tris[g] = run;
+  }
 }
 
 // Per-candidate record for the scoring kernel: where its node's candidates start, how many there
@@ -1113,9 +1177,10 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
 }
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
-                        unsigned *base_bl, unsigned *n_tris) {
+                        unsigned *base_bl, unsigned *n_tris, long long *tri_off, unsigned long long *status,
+                        int *err_flag) {
   hipLaunchKernelGGL(k_node_prefix, dim3(nblk2(G + 1, 256)), dim3(256), 0, st, G, node_img, seg_off, nb_off,
-                     blk_line_base, cnt_bl, base_bl, n_tris);
+                     blk_line_base, cnt_bl, base_bl, n_tris, tri_off, status, err_flag);
 }
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
