@@ -416,8 +416,10 @@ int build_invariants(lt_ctx *ctx, const double *hk = nullptr, const double *hq =
                                hipMemcpyHostToDevice, st));
   launch_build_cams(st, ctx->n_img, ctx->d_kvec.as<double>(), ctx->d_qvec.as<double>(), ctx->d_tvec.as<double>(),
                     ctx->d_cams.as<Cam>());
+  // the per-segment gate records of stage A (k_gates) are written by the same kernel as the segment records
+  ENSURE(ctx, ctx->d_seg_gates, seg_gate_bytes() * (size_t)std::max<long long>(ctx->G, 1));
   launch_build_segs(st, ctx->G, ctx->n_img, ctx->d_seg_off.as<long long>(), ctx->d_segs_raw.as<double>(),
-                    ctx->cfg.add_halfpix ? 0.5 : 0.0, ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>());
+                    ctx->cfg.add_halfpix ? 0.5 : 0.0, ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_seg_gates.p);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(st));
   {  // host copies for the tail-side filters (small: 88 B per image + 32 B per segment)
@@ -816,8 +818,9 @@ int lt_refresh_scene_device(lt_ctx *ctx, const void *d_kvec, const void *d_qvec,
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_segs_raw.p, d_segs, 32 * (size_t)ctx->G, hipMemcpyDeviceToDevice, st));
   launch_build_cams(st, n_img, ctx->d_kvec.as<double>(), ctx->d_qvec.as<double>(), ctx->d_tvec.as<double>(),
                     ctx->d_cams.as<Cam>());
+  ENSURE(ctx, ctx->d_seg_gates, seg_gate_bytes() * (size_t)std::max<long long>(ctx->G, 1));
   launch_build_segs(st, ctx->G, n_img, ctx->d_seg_off.as<long long>(), ctx->d_segs_raw.as<double>(),
-                    ctx->cfg.add_halfpix ? 0.5 : 0.0, ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>());
+                    ctx->cfg.add_halfpix ? 0.5 : 0.0, ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_seg_gates.p);
   HIPCHK(ctx, hipGetLastError());
   ctx->ran = false;
   return LT_OK;
@@ -854,7 +857,7 @@ int lt_refresh_scene_chunks(lt_ctx *ctx) {
   launch_build_scene_chunked(ctx->stream, ctx->n_img, ctx->G, ctx->n_chunks, ctx->d_chunks.as<SceneChunk>(),
                              ctx->d_seg_off.as<long long>(), ctx->cfg.add_halfpix ? 0.5 : 0.0, ctx->d_cams.as<Cam>(),
                              ctx->d_segs.as<Seg>(), listed ? ctx->d_needed.as<int>() : nullptr, ctx->n_needed,
-                             ctx->max_needed_segs);
+                             ctx->max_needed_segs, ctx->d_seg_gates.p);
   HIPCHK(ctx, hipGetLastError());
   ctx->ran = false;
   return LT_OK;
@@ -1307,7 +1310,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     {
       ENSURE(ctx, ctx->d_st_row, 8 * Pn);
       ENSURE(ctx, ctx->d_surv_count, 4 * (size_t)(n_slots_all + 1));
-      ENSURE(ctx, ctx->d_seg_gates, seg_gate_bytes() * (size_t)std::max<long long>(G, 1));
+      if (!ctx->d_seg_gates.p) return fail(ctx, LT_ERR_STATE, "segment gate records missing (Init not run?)");
       ENSURE(ctx, ctx->d_blkrec, blk_rec_bytes() * (size_t)std::max(ctx->n_blk, 1));
       launch_gen_split(st, ctx->n_blk, ctx->max_rows, gcfg, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
                        ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(),

@@ -19,11 +19,11 @@ struct SceneChunk {  // images [img_begin, next chunk's img_begin) live in these
 };
 void launch_build_scene_chunked(hipStream_t st, int n_img, long long n_segs, int n_chunks, const SceneChunk *ch,
                                 const long long *seg_off, double halfpix, Cam *cams, Seg *segs,
-                                const int *img_list, int n_list, long long max_segs_per_img);
+                                const int *img_list, int n_list, long long max_segs_per_img, void *gates);
 
 void launch_build_cams(hipStream_t st, int n, const double *k, const double *q, const double *t, Cam *cams);
 void launch_build_segs(hipStream_t st, long long n_segs, int n_img, const long long *seg_off,
-                       const double *segs, double halfpix, const Cam *cams, Seg *out);
+                       const double *segs, double halfpix, const Cam *cams, Seg *out, void *gates);
 void launch_build_pairs(hipStream_t st, int n_blk, const int *blk_img, const int *blk_nb, const Cam *cams,
                         PairRec *out, int *err_flag, unsigned long long *pair_counter,
                         unsigned long long *scan_status, int n_status);

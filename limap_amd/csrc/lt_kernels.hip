@@ -39,7 +39,7 @@ __global__ void k_build_cams(int n, const double *__restrict__ kvec, const doubl
 
 __global__ void k_build_segs(long long n_segs, int n_img, const long long *__restrict__ seg_off,
                              const double *__restrict__ segs, double halfpix,
-                             const Cam *__restrict__ cams, Seg *__restrict__ out) {
+                             const Cam *__restrict__ cams, Seg *__restrict__ out, SegGate *__restrict__ gates) {
   long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_segs) return;
   // image of this segment: upper_bound(seg_off, s) - 1
@@ -57,6 +57,7 @@ __global__ void k_build_segs(long long n_segs, int n_img, const long long *__res
   }
   seg_build(cams[lo], x1, y1, x2, y2, &r);
   out[s] = r;
+  if (gates) seg_gate_build(r, &gates[s]);  // stage A's per-segment record (k_gates), see lt_devfn.h
 }
 
 // Scene given as chunks (one per rank of the all-gather): chunk c holds images [img_begin[c],
@@ -75,7 +76,8 @@ __global__ void k_build_cams_chunked(int n, int n_chunks, const SceneChunk *__re
 
 __global__ void k_build_segs_chunked(long long n_segs, int n_img, int n_chunks, const SceneChunk *__restrict__ ch,
                                      const long long *__restrict__ seg_off, double halfpix,
-                                     const Cam *__restrict__ cams, Seg *__restrict__ out) {
+                                     const Cam *__restrict__ cams, Seg *__restrict__ out,
+                                     SegGate *__restrict__ gates) {
   long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_segs) return;
   int lo = 0, hi = n_img;
@@ -93,6 +95,7 @@ __global__ void k_build_segs_chunked(long long n_segs, int n_img, int n_chunks, 
   Seg r;
   seg_build(cams[lo], x1, y1, x2, y2, &r);
   out[s] = r;
+  if (gates) seg_gate_build(r, &gates[s]);  // stage A's per-segment record (k_gates), see lt_devfn.h
 }
 
 // Same per image of a list (grid.y = list entry): no search for the segment's image, and images the
@@ -100,7 +103,8 @@ __global__ void k_build_segs_chunked(long long n_segs, int n_img, int n_chunks, 
 // image shards spread over several GPUs a rank needs ~1/N of the gathered scene.
 __global__ void k_build_segs_listed(const int *__restrict__ img_list, int n_chunks, const SceneChunk *__restrict__ ch,
                                     const long long *__restrict__ seg_off, double halfpix,
-                                    const Cam *__restrict__ cams, Seg *__restrict__ out) {
+                                    const Cam *__restrict__ cams, Seg *__restrict__ out,
+                                    SegGate *__restrict__ gates) {
   const int img = img_list[blockIdx.y];
   const long long s0 = seg_off[img], M = seg_off[img + 1] - s0;
   const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,6 +120,7 @@ __global__ void k_build_segs_listed(const int *__restrict__ img_list, int n_chun
   Seg r;
   seg_build(cams[img], x1, y1, x2, y2, &r);
   out[s] = r;
+  if (gates) seg_gate_build(r, &gates[s]);
 }
 
 // also clears the run's two device scalars (error flag, pair statistic): one launch instead of three
@@ -536,16 +541,17 @@ void launch_build_cams(hipStream_t st, int n, const double *k, const double *q, 
   if (n > 0) hipLaunchKernelGGL(k_build_cams, dim3(nblk(n, 128)), dim3(128), 0, st, n, k, q, t, cams);
 }
 void launch_build_segs(hipStream_t st, long long n_segs, int n_img, const long long *seg_off,
-                       const double *segs, double halfpix, const Cam *cams, Seg *out) {
+                       const double *segs, double halfpix, const Cam *cams, Seg *out, void *gates) {
   if (n_segs > 0)
     hipLaunchKernelGGL(k_build_segs, dim3(nblk(n_segs, 256)), dim3(256), 0, st, n_segs, n_img, seg_off, segs,
-                       halfpix, cams, out);
+                       halfpix, cams, out, reinterpret_cast<SegGate *>(gates));
 }
 // img_list (n_list entries, at most 65535 per launch) restricts the segment records to those images;
 // nullptr = all images
 void launch_build_scene_chunked(hipStream_t st, int n_img, long long n_segs, int n_chunks, const SceneChunk *ch,
                                 const long long *seg_off, double halfpix, Cam *cams, Seg *segs,
-                                const int *img_list, int n_list, long long max_segs_per_img) {
+                                const int *img_list, int n_list, long long max_segs_per_img, void *gates_v) {
+  SegGate *gates = reinterpret_cast<SegGate *>(gates_v);
   if (n_img > 0)
     hipLaunchKernelGGL(k_build_cams_chunked, dim3(nblk(n_img, 128)), dim3(128), 0, st, n_img, n_chunks, ch, cams);
   if (n_segs <= 0) return;
@@ -553,11 +559,11 @@ void launch_build_scene_chunked(hipStream_t st, int n_img, long long n_segs, int
     for (int y0 = 0; y0 < n_list; y0 += 65535) {
       const int ny = std::min(65535, n_list - y0);
       hipLaunchKernelGGL(k_build_segs_listed, dim3(nblk(max_segs_per_img, 256), ny), dim3(256), 0, st, img_list + y0,
-                         n_chunks, ch, seg_off, halfpix, cams, segs);
+                         n_chunks, ch, seg_off, halfpix, cams, segs, gates);
     }
   } else {
     hipLaunchKernelGGL(k_build_segs_chunked, dim3(nblk(n_segs, 256)), dim3(256), 0, st, n_segs, n_img, n_chunks, ch,
-                       seg_off, halfpix, cams, segs);
+                       seg_off, halfpix, cams, segs, gates);
   }
 }
 void launch_build_pairs(hipStream_t st, int n_blk, const int *blk_img, const int *blk_nb, const Cam *cams,

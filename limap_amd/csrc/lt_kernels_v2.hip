@@ -120,10 +120,6 @@ struct GenArgs {
   int many_on, one_on;    // which point-guided proposals run (seg_pts != null)
 };
 
-__global__ void k_build_gates(long long n_segs, const Seg *__restrict__ segs, SegGate *__restrict__ gates) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_segs) seg_gate_build(segs[i], &gates[i]);
-}
 
 // Per-block record: everything the row kernels need to know about neighbour block b in ONE scalar
 // load (instead of the chain m_off[b] / blk_img[b] / blk_nb[b] -> seg_off[...]).
@@ -1117,7 +1113,7 @@ extern "C" int lt_debug_read_trace(unsigned long long *host, size_t n) {
 size_t seg_gate_bytes() { return sizeof(SegGate); }
 size_t seg_point_bytes() { return sizeof(SegPoint); }
 size_t blk_rec_bytes() { return sizeof(BlkRec); }
-// HOT LOOP 1: k_build_gates + k_gates (survivor lists) + k_tri_rows (candidate lists)
+// HOT LOOP 1: k_gates (survivor lists) + k_tri_rows (candidate lists)
 void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
                       const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
                       const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
@@ -1137,8 +1133,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   }
   hipLaunchKernelGGL(k_build_blk, dim3(nblk2(n_blk, 128)), dim3(128), 0, st, n_blk, m_off, blk_img, blk_nb, blk_slot,
                      seg_off, blk_line_base, reinterpret_cast<BlkRec *>(blkrec));
-  hipLaunchKernelGGL(k_build_gates, dim3(nblk2(n_segs, 256)), dim3(256), 0, st, n_segs, segs,
-                     reinterpret_cast<SegGate *>(gates));
+  // (the SegGate records are written together with the segment records: k_build_segs* in lt_kernels.hip)
   GenArgs a;
   a.m_off = m_off; a.m_pairs = m_pairs; a.blk_img = blk_img; a.blk_nb = blk_nb; a.blk_slot = blk_slot;
   a.seg_off = seg_off; a.cams = cams; a.segs = segs; a.gates = reinterpret_cast<const SegGate *>(gates);
