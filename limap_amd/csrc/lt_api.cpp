@@ -32,6 +32,8 @@ void launch_fn_query(hipStream_t st, const double *in30, int by_endpoints, doubl
 int gen_slots(long long max_rows);
 int gen_groups(long long max_rows);
 size_t seg_gate_bytes();
+void launch_build_blk(hipStream_t st, int n_blk, const long long *m_off, const int *blk_img, const int *blk_nb,
+                      const int *blk_slot, const long long *seg_off, const long long *blk_line_base, void *blkrec);
 size_t blk_rec_bytes();
 void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
                       const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
@@ -1124,6 +1126,11 @@ int lt_upload(lt_ctx *ctx) {
       }
     }
     if ((rc = upload_vec(ctx, ctx->d_m_off, m_off))) return rc;
+    // per-block records of the matched pipeline (row range, images, segment bases): a function of the job
+    ENSURE(ctx, ctx->d_blkrec, blk_rec_bytes() * (size_t)std::max(ctx->n_blk, 1));
+    launch_build_blk(ctx->stream, ctx->n_blk, ctx->d_m_off.as<long long>(), ctx->d_blk_img.as<int>(),
+                     ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(), ctx->d_seg_off.as<long long>(),
+                     ctx->d_blk_line_base.as<long long>(), ctx->d_blkrec.p);
   } else if (ctx->job_mode == 2) {
     // work items: per node, per neighbour block, chunks of 64 neighbour lines
     ctx->h_item_off.assign(ctx->G + 1, 0);
@@ -1311,7 +1318,6 @@ int lt_run_device_async(lt_ctx *ctx) {
       ENSURE(ctx, ctx->d_st_row, 8 * Pn);
       ENSURE(ctx, ctx->d_surv_count, 4 * (size_t)(n_slots_all + 1));
       if (!ctx->d_seg_gates.p) return fail(ctx, LT_ERR_STATE, "segment gate records missing (Init not run?)");
-      ENSURE(ctx, ctx->d_blkrec, blk_rec_bytes() * (size_t)std::max(ctx->n_blk, 1));
       launch_gen_split(st, ctx->n_blk, ctx->max_rows, gcfg, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
                        ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(),
                        ctx->d_seg_off.as<long long>(), ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(),

@@ -1113,6 +1113,12 @@ extern "C" int lt_debug_read_trace(unsigned long long *host, size_t n) {
 size_t seg_gate_bytes() { return sizeof(SegGate); }
 size_t seg_point_bytes() { return sizeof(SegPoint); }
 size_t blk_rec_bytes() { return sizeof(BlkRec); }
+void launch_build_blk(hipStream_t st, int n_blk, const long long *m_off, const int *blk_img, const int *blk_nb,
+                      const int *blk_slot, const long long *seg_off, const long long *blk_line_base, void *blkrec) {
+  if (n_blk > 0)
+    hipLaunchKernelGGL(k_build_blk, dim3(nblk2(n_blk, 128)), dim3(128), 0, st, n_blk, m_off, blk_img, blk_nb, blk_slot,
+                       seg_off, blk_line_base, reinterpret_cast<BlkRec *>(blkrec));
+}
 // HOT LOOP 1: k_gates (survivor lists) + k_tri_rows (candidate lists)
 void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
                       const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
@@ -1131,8 +1137,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
       n_cu = 256;
   }
-  hipLaunchKernelGGL(k_build_blk, dim3(nblk2(n_blk, 128)), dim3(128), 0, st, n_blk, m_off, blk_img, blk_nb, blk_slot,
-                     seg_off, blk_line_base, reinterpret_cast<BlkRec *>(blkrec));
+  // (the BlkRec table depends on the uploaded job only: launch_build_blk, once per lt_upload)
   // (the SegGate records are written together with the segment records: k_build_segs* in lt_kernels.hip)
   GenArgs a;
   a.m_off = m_off; a.m_pairs = m_pairs; a.blk_img = blk_img; a.blk_nb = blk_nb; a.blk_slot = blk_slot;
