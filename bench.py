@@ -42,13 +42,13 @@ def algorithmic_bytes(stats, n_img_active, nn, survivors):
     bytes_gen = 8 P + 32 (nodes + N nn M) + 88 N (1 + nn) + 96 C.
     HOT LOOP 1 runs as two kernels; its bytes are split where the data is touched:
       k_gates    : every match row (8 P), the segment and camera records (the 32 / 88 terms), and the
-                   list of rows that pass the gates (4 S, S = stage-A survivors)
-      k_tri_rows : the survivor list and its rows again (12 S) and the candidate records it emits (96 C)."""
+                   list of rows that pass the gates (8 S, S = stage-A survivors; an entry carries the row)
+      k_tri_rows : the survivor list (8 S) and the candidate records it emits (96 C)."""
     C, E, P, G = stats["candidates"], stats["valid_edges"], stats["connections"], stats["active_nodes"]
     score = 136 * C + 104 * G + 4 * E
     gen = 8 * P + 32 * (G + nn * G) + 88 * n_img_active * (1 + nn) + 96 * C
-    gates = 8 * P + 32 * (G + nn * G) + 88 * n_img_active * (1 + nn) + 4 * survivors
-    tri = 12 * survivors + 96 * C
+    gates = 8 * P + 32 * (G + nn * G) + 88 * n_img_active * (1 + nn) + 8 * survivors
+    tri = 8 * survivors + 96 * C
     return {"score": score, "gen": gen, "gates": gates, "tri": tri}
 
 
