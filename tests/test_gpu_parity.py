@@ -199,3 +199,42 @@ def test_two_rank_shards_merge_on_rank0(gpu_lib, oracle):
     compare_best(ranks[0].get_best(), O.get_best())
     compare_valid_edges(ranks[0].get_valid_edges(), O.get_valid_edges())
     compare_tracks(ranks[0].get_tracks(), O.ComputeLineTracks())
+
+
+_CFG_VARIANTS = [
+    dict(linker3d_config=dict(score_th=0.5, th_angle=2.0, th_overlap=0.05, th_smartoverlap=0.1, th_smartangle=2.0,
+                              th_perp=1.0, th_innerseg=1.0, th_scaleinv=0.002)),          # tight 3D gates
+    dict(linker3d_config=dict(score_th=0.3, th_angle=45.0, th_overlap=0.05, th_smartoverlap=0.1, th_smartangle=2.0,
+                              th_perp=1.0, th_innerseg=1.0, th_scaleinv=0.5)),            # loose: most pairs are evaluated
+    dict(linker3d_config=dict(score_th=0.9, th_angle=89.9, th_overlap=0.05, th_smartoverlap=0.1, th_smartangle=2.0,
+                              th_perp=1.0, th_innerseg=1.0, th_scaleinv=0.05)),           # angle guard near cos -> 0
+    dict(linker2d_config=dict(score_th=0.8, th_angle=1.0, th_perp=0.5, th_overlap=0.3)),   # tight 2D gates
+    dict(linker2d_config=dict(score_th=0.2, th_angle=30.0, th_perp=20.0, th_overlap=0.0)),
+    dict(fullscore_th=3.0, max_valid_conns=3),                                              # ranked valid edges
+    dict(fullscore_th=0.5, max_valid_conns=1, min_num_outer_edges=1),
+    dict(use_endpoints_triangulation=True, add_halfpix=True, sensitivity_threshold=20.0),
+    dict(num_outliers_aggregator=0, var2d=5.0, line_tri_angle_threshold=5.0, IoU_threshold=0.4),
+]
+
+
+@pytest.mark.parametrize("variant", range(len(_CFG_VARIANTS)))
+@pytest.mark.parametrize("exhaustive", [False, True])
+def test_config_variants_match_oracle(gpu_lib, oracle, variant, exhaustive):
+    """Linker thresholds (they set the guards of the scoring sweep), selection knobs and generation switches
+    away from cfgs/triangulation/default.yaml, matched and exhaustive, with and without ranges."""
+    sc = small_scene(seed=20 + variant, n_views=9, n_segs=60, n_neighbors=4)
+    if variant % 2:
+        import dataclasses
+        sc = dataclasses.replace(sc, ranges=None)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    cfg.update(_CFG_VARIANTS[variant])
+    T = run_product(sc, cfg, exhaustive=exhaustive)
+    O = run_oracle(oracle, sc, cfg, exhaustive=exhaustive)
+    compare_candidates(T.context().get_all_tris(), O.get_all_tris())
+    compare_best(T.context().get_best(), O.get_best())
+    compare_valid_edges(T.context().get_valid_edges(), O.get_valid_edges())
+    T.ComputeLineTracks()
+    compare_tracks(T.context().get_tracks(), O.ComputeLineTracks())
+    st, so = T.stats(), O.stats()
+    for k in ("connections", "candidates", "valid_edges", "graph_nodes", "graph_edges", "tracks"):
+        assert st[k] == so[k], k
