@@ -1427,13 +1427,13 @@ int lt_run_device_async(lt_ctx *ctx) {
                                 ctx->d_masks.as<unsigned char>(), ctx->d_mask_cnt.as<unsigned>(), nullptr, nullptr,
                                 nullptr, seg_vp, seg_has_vp, ctx->d_seg_pt_off.as<long long>(), ctx->d_seg_pts.p,
                                 sfm_xyz, ctx->d_err.as<int>(), many_on, one_on, ctx->d_blk_chunk_off.as<int>(),
-                                ctx->max_nb, ctx->max_chunks);
+                                ctx->max_nb, ctx->max_chunks, ctx->d_seg_gates.p);
     } else {
       launch_gen_exhaustive(st, false, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
                             ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
                             ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
                             ctx->d_masks.as<unsigned long long>(), nullptr, nullptr, nullptr, seg_vp, seg_has_vp,
-                            ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks);
+                            ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks, ctx->d_seg_gates.p);
       launch_popc(st, P, ctx->d_masks.as<unsigned long long>(), ctx->d_mask_cnt.as<unsigned>(), n_masks);
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_mask_cnt.as<unsigned>() + P, 0, 4, st));
@@ -1461,14 +1461,14 @@ int lt_run_device_async(lt_ctx *ctx) {
                                 ctx->d_mask_pos.as<long long>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
                                 seg_vp, seg_has_vp, ctx->d_seg_pt_off.as<long long>(), ctx->d_seg_pts.p, sfm_xyz,
                                 ctx->d_err.as<int>(), many_on, one_on, ctx->d_blk_chunk_off.as<int>(), ctx->max_nb,
-                                ctx->max_chunks);
+                                ctx->max_chunks, ctx->d_seg_gates.p);
     else
       launch_gen_exhaustive(st, true, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
                             ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
                             ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
                             ctx->d_masks.as<unsigned long long>(), ctx->d_mask_pos.as<long long>(),
                             ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), seg_vp, seg_has_vp,
-                            ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks);
+                            ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks, ctx->d_seg_gates.p);
     launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, total,
                           ctx->d_tri_off.as<long long>());
     ENSURE(ctx, ctx->d_cand_node, 4 * Cn);

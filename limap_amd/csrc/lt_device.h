@@ -39,7 +39,7 @@ void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const G
                            const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
                            const PairRec *pairs, unsigned long long *masks, const long long *mask_pos,
                            Cand *out_c, CandLite *out_l, const double *seg_vp, const unsigned char *seg_has_vp,
-                           const int *blk_chunk_off, int max_nb, int max_chunks);
+                           const int *blk_chunk_off, int max_nb, int max_chunks, const void *gates);
 void launch_gen_exhaustive_pts(hipStream_t st, bool fill, long long n_items, const GenCfg &cfg,
                                const long long *item_off, long long G, const int *node_img, const long long *nb_off,
                                const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
@@ -47,7 +47,7 @@ void launch_gen_exhaustive_pts(hipStream_t st, bool fill, long long n_items, con
                                const long long *mask_pos, Cand *out_c, CandLite *out_l, const double *seg_vp,
                                const unsigned char *seg_has_vp, const long long *seg_pt_off, const void *seg_pts,
                                const double *sfm_xyz, int *err_flag, int many_on, int one_on,
-                               const int *blk_chunk_off, int max_nb, int max_chunks);
+                               const int *blk_chunk_off, int max_nb, int max_chunks, const void *gates);
 void launch_popc(hipStream_t st, long long n, const unsigned long long *masks, unsigned *cnt, int n_masks);
 void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_off, const long long *mask_pos,
                            long long n_items, long long total, long long *tri_off);

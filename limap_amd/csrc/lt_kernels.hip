@@ -173,7 +173,7 @@ k_gen_exhaustive(long long n_items, GenCfg cfg, const long long *__restrict__ it
                  const long long *__restrict__ mask_pos, Cand *__restrict__ out_c,
                  CandLite *__restrict__ out_l, const double *__restrict__ seg_vp,
                  const unsigned char *__restrict__ seg_has_vp, const int *__restrict__ blk_chunk_off,
-                 int max_nb, int max_chunks) {
+                 int max_nb, int max_chunks, const SegGate *__restrict__ gates) {
   // wave -> (node, neighbour slot, chunk) by arithmetic: every node owns max_nb * max_chunks wave slots
   // (those beyond its image's neighbours / the neighbour's chunks exit at once); the item index, which
   // orders the candidates, is item_off[node] + blk_chunk_off[block] + chunk
@@ -226,8 +226,9 @@ k_gen_exhaustive(long long n_items, GenCfg cfg, const long long *__restrict__ it
     } else {
       // cheap three-way gates first (gate3, as in k_gates): most connections of an exhaustive match are
       // certain rejects; certain passes skip the exact gates, undecided ones go through them
-      SegGate gg;
-      seg_gate_build(s2, &gg);
+      // the neighbour's gate record comes from the table written with the segment records (consecutive
+      // lanes = consecutive neighbour lines: coalesced 80-byte records instead of a rebuild per connection)
+      const SegGate gg = gates[g2];
       const int res = gate3(cfg, s1.x1, s1.y1, s1.x2, s1.y2, s1.rs[0], s1.rs[1], s1.rs[2], s1.re[0], s1.re[1], s1.re[2],
                             gg.n[0], gg.n[1], gg.n[2], gg.lcx, gg.lcy, gg.P, gg.Q, gg.w1, gg.sv, gg.q2, pairs[b].F);
       if (res == 1) ok = gen_finish(cfg, cams[i1], cams[i2], s1, s2, pairs[b].B, &o);
@@ -292,7 +293,7 @@ k_gen_exhaustive_pts(long long n_items, GenCfg cfg, const long long *__restrict_
                      const unsigned char *__restrict__ seg_has_vp, const long long *__restrict__ seg_pt_off,
                      const SegPoint *__restrict__ seg_pts, const double *__restrict__ sfm_xyz,
                      int *__restrict__ err_flag, int many_on, int one_on, const int *__restrict__ blk_chunk_off,
-                     int max_nb, int max_chunks) {
+                     int max_nb, int max_chunks, const SegGate *__restrict__ gates) {
   const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long long per_node = (long long)max_nb * max_chunks;
   const long long g = w / per_node;
@@ -385,8 +386,7 @@ k_gen_exhaustive_pts(long long n_items, GenCfg cfg, const long long *__restrict_
       if (seg_has_vp[g2] && vp_candidate(cfg, cams[i1], cams[i2], s1, s2, pairs[b].B, seg_vp + 3 * g2, &o)) emit(o);
     }
     {
-      SegGate gg;
-      seg_gate_build(s2, &gg);
+      const SegGate gg = gates[g2];
       const int res = gate3(cfg, s1.x1, s1.y1, s1.x2, s1.y2, s1.rs[0], s1.rs[1], s1.rs[2], s1.re[0], s1.re[1], s1.re[2],
                             gg.n[0], gg.n[1], gg.n[2], gg.lcx, gg.lcy, gg.P, gg.Q, gg.w1, gg.sv, gg.q2, pairs[b].F);
       bool ok = false;
@@ -603,13 +603,14 @@ void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const G
                            const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
                            const PairRec *pairs, unsigned long long *masks, const long long *mask_pos,
                            Cand *out_c, CandLite *out_l, const double *seg_vp, const unsigned char *seg_has_vp,
-                           const int *blk_chunk_off, int max_nb, int max_chunks) {
+                           const int *blk_chunk_off, int max_nb, int max_chunks, const void *gates_v) {
   if (n_items <= 0) return;
+  const SegGate *gates = reinterpret_cast<const SegGate *>(gates_v);
   dim3 grid(nblk(G * (long long)max_nb * max_chunks * 64, 256)), block(256);
 #define LT_LAUNCH_EX(FILL, VP)                                                                                     \
   hipLaunchKernelGGL((k_gen_exhaustive<FILL, VP>), grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off, \
                      blk_nb, seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l, seg_vp, seg_has_vp, blk_chunk_off, max_nb, \
-                     max_chunks)
+                     max_chunks, gates)
   if (seg_vp) {
     if (!fill) LT_LAUNCH_EX(false, true); else LT_LAUNCH_EX(true, true);
   } else {
@@ -624,18 +625,19 @@ void launch_gen_exhaustive_pts(hipStream_t st, bool fill, long long n_items, con
                                const long long *mask_pos, Cand *out_c, CandLite *out_l, const double *seg_vp,
                                const unsigned char *seg_has_vp, const long long *seg_pt_off, const void *seg_pts,
                                const double *sfm_xyz, int *err_flag, int many_on, int one_on,
-                               const int *blk_chunk_off, int max_nb, int max_chunks) {
+                               const int *blk_chunk_off, int max_nb, int max_chunks, const void *gates_v) {
   if (n_items <= 0) return;
+  const SegGate *gates = reinterpret_cast<const SegGate *>(gates_v);
   dim3 grid(nblk(G * (long long)max_nb * max_chunks * 64, 256)), block(256);
   const SegPoint *sp = reinterpret_cast<const SegPoint *>(seg_pts);
   if (!fill)
     hipLaunchKernelGGL((k_gen_exhaustive_pts<false>), grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off,
                        blk_nb, seg_off, cams, segs, pairs, cnt8, item_cnt, mask_pos, out_c, out_l, seg_vp, seg_has_vp,
-                       seg_pt_off, sp, sfm_xyz, err_flag, many_on, one_on, blk_chunk_off, max_nb, max_chunks);
+                       seg_pt_off, sp, sfm_xyz, err_flag, many_on, one_on, blk_chunk_off, max_nb, max_chunks, gates);
   else
     hipLaunchKernelGGL((k_gen_exhaustive_pts<true>), grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off,
                        blk_nb, seg_off, cams, segs, pairs, cnt8, item_cnt, mask_pos, out_c, out_l, seg_vp, seg_has_vp,
-                       seg_pt_off, sp, sfm_xyz, err_flag, many_on, one_on, blk_chunk_off, max_nb, max_chunks);
+                       seg_pt_off, sp, sfm_xyz, err_flag, many_on, one_on, blk_chunk_off, max_nb, max_chunks, gates);
 }
 // n_masks ballots per item (3 with VP proposals)
 void launch_popc(hipStream_t st, long long n, const unsigned long long *masks, unsigned *cnt, int n_masks) {
