@@ -4,7 +4,7 @@
 //       per (image, neighbour) pair) -- the reference recomputes them per connection.
 //   radix sort + k_node_offsets                 : matched mode, generic (stable) grouping of the
 //       candidates by node when the rows of a block are not sorted by line id.
-//   k_gen_exhaustive                            : HOT LOOP 1, triangulateOneNode
+//   k_gen_ex_block / k_gen_exhaustive_pts       : HOT LOOP 1, triangulateOneNode (exhaustive mode)
 //       (triangulation/base_line_triangulator.cc:161-337) for TriangulateImageExhaustiveMatch:
 //       degeneracy gates, weak epipolar IoU, ray/plane triangulation, sensitivity gate,
 //       uncertainty, ranges.  (Matched mode: k_gates + k_tri_rows in lt_kernels_v2.hip; scoring: k_score3.)
@@ -163,115 +163,152 @@ __global__ void k_node_offsets(long long P, long long G, const unsigned *__restr
 // kVP: with VP-guided proposals (base_line_triangulator.cc:250-281) a connection yields up to three
 // candidates in the order vp(l1), vp(l2), algebraic; the item then owns three ballots
 // masks[3 * item + {0: algebraic, 1: vp(l1), 2: vp(l2)}].
+// Exhaustive mode, one wave per (node, neighbour image), eight 64-line chunks of the neighbour at a time.
+// Only ~4 % of the connections survive the gates, so with one chunk per wave nearly every chunk ran the
+// triangulation (~900 instructions) for 2-3 active lanes.  Here phase A runs the cheap three-way gates over
+// the eight chunks and compacts the connections that need more work (ballot + popcount) into an LDS list,
+// phase B evaluates the list densely (exact gates where stage A could not decide, triangulation, VP
+// proposals), phase C writes the eight survivor ballots.  kFill: the list is rebuilt from the ballots of
+// pass 1 together with each candidate's output offset (items of a (node, neighbour) block are consecutive, so
+// is their output), and phase B writes the candidates in place.
 template <bool kFill, bool kVP>
 __global__ void __launch_bounds__(256)
-k_gen_exhaustive(long long n_items, GenCfg cfg, const long long *__restrict__ item_off /* per node: first item */,
-                 long long G, const int *__restrict__ node_img, const long long *__restrict__ nb_off,
-                 const int *__restrict__ blk_nb, const long long *__restrict__ seg_off,
-                 const Cam *__restrict__ cams, const Seg *__restrict__ segs,
-                 const PairRec *__restrict__ pairs, unsigned long long *__restrict__ masks,
-                 const long long *__restrict__ mask_pos, Cand *__restrict__ out_c,
-                 CandLite *__restrict__ out_l, const double *__restrict__ seg_vp,
-                 const unsigned char *__restrict__ seg_has_vp, const int *__restrict__ blk_chunk_off,
-                 int max_nb, int max_chunks, const SegGate *__restrict__ gates) {
-  // wave -> (node, neighbour slot, chunk) by arithmetic: every node owns max_nb * max_chunks wave slots
-  // (those beyond its image's neighbours / the neighbour's chunks exit at once); the item index, which
-  // orders the candidates, is item_off[node] + blk_chunk_off[block] + chunk
-  const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long per_node = (long long)max_nb * max_chunks;
-  const long long g = w / per_node;
+k_gen_ex_block(long long n_items, GenCfg cfg, const long long *__restrict__ item_off, long long G,
+               const int *__restrict__ node_img, const long long *__restrict__ nb_off,
+               const int *__restrict__ blk_nb, const long long *__restrict__ seg_off,
+               const Cam *__restrict__ cams, const Seg *__restrict__ segs, const PairRec *__restrict__ pairs,
+               unsigned long long *__restrict__ masks, const long long *__restrict__ mask_pos,
+               Cand *__restrict__ out_c, CandLite *__restrict__ out_l, const double *__restrict__ seg_vp,
+               const unsigned char *__restrict__ seg_has_vp, const int *__restrict__ blk_chunk_off, int max_nb,
+               const SegGate *__restrict__ gates) {
+  constexpr int kMasks = kVP ? 3 : 1;
+  constexpr int kGroup = 8;
+  constexpr int kCap = kGroup * 64 * kMasks;
+  __shared__ unsigned s_list[4][kCap];
+  __shared__ unsigned long long s_mask[4][kGroup * kMasks];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = lane_id();
+  unsigned *list = s_list[wv];
+  unsigned long long *lmask = s_mask[wv];
+  const long long w = (long long)blockIdx.x * 4 + wv;
+  const long long g = w / max_nb;
   if (g >= G) return;
-  const int rest = (int)(w - g * per_node);
-  const int k = rest / max_chunks;
-  const long long rem = rest - k * max_chunks;
+  const int k = (int)(w - g * max_nb);
   const int i1 = node_img[g];
   const long long b = nb_off[i1] + k;
   if (b >= nb_off[i1 + 1]) return;
   const int i2 = blk_nb[b];
-  const long long M2 = seg_off[i2 + 1] - seg_off[i2];
-  if (rem >= ((M2 + 63) >> 6)) return;
-  const long long item = item_off[g] + blk_chunk_off[b] + rem;
-  if (item >= n_items) return;
-  constexpr int kMasks = kVP ? 3 : 1;
-  const int lane = lane_id();
-  int ng_line = (int)(rem << 6) + lane;
-  const long long g2 = seg_off[i2] + ng_line;
-  bool ok = false, ok1 = false, ok2 = false;
-  GenOut o;
-  const bool in_range = ng_line < M2;
-  bool do_alg = in_range, do_vp1 = false, do_vp2 = false;
-  if (kVP && in_range) {
-    // both segments long enough (:166,177)
-    const Seg &s1 = segs[g];
-    const Seg &s2 = segs[g2];
+  const long long g2base = seg_off[i2];
+  const int M2 = (int)(seg_off[i2 + 1] - g2base);
+  const int n_chunks = (M2 + 63) >> 6;
+  const long long item0 = item_off[g] + blk_chunk_off[b];
+  if (item0 >= n_items) return;
+  const Seg &s1 = segs[g];
+  const PairRec &pr = pairs[b];
+  const int nbs = lite_pack(k, i2);
+  bool len1_ok = true, has_vp1 = false;
+  if (kVP) {
     L2 l1{mk2(s1.x1, s1.y1), mk2(s1.x2, s1.y2)};
-    L2 l2{mk2(s2.x1, s2.y1), mk2(s2.x2, s2.y2)};
-    const bool len_ok = !(len(l1) <= cfg.min_length_2d) && !(len(l2) <= cfg.min_length_2d);
-    do_vp1 = len_ok && seg_has_vp[g];
-    do_vp2 = len_ok && seg_has_vp[g2];
+    len1_ok = !(len(l1) <= cfg.min_length_2d);  // :166
+    has_vp1 = seg_has_vp[g] != 0;
   }
-  if (kFill) {
-    do_alg = do_alg && ((masks[kMasks * item] >> lane) & 1ull);
-    if (kVP) {
-      do_vp1 = do_vp1 && ((masks[kMasks * item + 1] >> lane) & 1ull);
-      do_vp2 = do_vp2 && ((masks[kMasks * item + 2] >> lane) & 1ull);
-    }
-  }
-  if (do_alg) {
-    const Seg &s1 = segs[g];
-    const Seg &s2 = segs[g2];
-    if (kFill) {
-      // pass 1 found this connection valid: its gates pass, only the candidate itself is needed again
-      ok = gen_finish(cfg, cams[i1], cams[i2], s1, s2, pairs[b].B, &o);
-    } else {
-      // cheap three-way gates first (gate3, as in k_gates): most connections of an exhaustive match are
-      // certain rejects; certain passes skip the exact gates, undecided ones go through them
-      // the neighbour's gate record comes from the table written with the segment records (consecutive
-      // lanes = consecutive neighbour lines: coalesced 80-byte records instead of a rebuild per connection)
-      const SegGate gg = gates[g2];
-      const int res = gate3(cfg, s1.x1, s1.y1, s1.x2, s1.y2, s1.rs[0], s1.rs[1], s1.rs[2], s1.re[0], s1.re[1], s1.re[2],
-                            gg.n[0], gg.n[1], gg.n[2], gg.lcx, gg.lcy, gg.P, gg.Q, gg.w1, gg.sv, gg.q2, pairs[b].F);
-      if (res == 1) ok = gen_finish(cfg, cams[i1], cams[i2], s1, s2, pairs[b].B, &o);
-      else if (res == 2) ok = gen_one(cfg, cams[i1], cams[i2], s1, s2, pairs[b], &o);
-    }
-  }
-  GenOut o1, o2;
-  if (kVP) {
-    if (do_vp1) ok1 = vp_candidate(cfg, cams[i1], cams[i2], segs[g], segs[g2], pairs[b].B, seg_vp + 3 * g, &o1);
-    if (do_vp2) ok2 = vp_candidate(cfg, cams[i1], cams[i2], segs[g], segs[g2], pairs[b].B, seg_vp + 3 * g2, &o2);
-  }
-  const unsigned long long m = __ballot(ok);
-  unsigned long long m1 = 0, m2 = 0;
-  if (kVP) {
-    m1 = __ballot(ok1);
-    m2 = __ballot(ok2);
-  }
-  if (!kFill) {
-    if (lane == 0) {
-      masks[kMasks * item] = m;
+  const unsigned long long lt_mask = lanemask_lt();
+  for (int c0 = 0; c0 < n_chunks; c0 += kGroup) {
+    const int nc = min(kGroup, n_chunks - c0);
+    int n_ent = 0;
+    if (!kFill && lane < kGroup * kMasks) lmask[lane] = 0ull;
+    unsigned base_off = 0;
+    // ---- phase A: which connections need phase B ----
+    for (int cc = 0; cc < nc; ++cc) {
+      const int ng = ((c0 + cc) << 6) + lane;
+      const bool in_range = ng < M2;
+      bool t0 = false, t1 = false, t2 = false, und = false;
+      unsigned o0 = 0, o1 = 0, o2 = 0;
+      if (!kFill) {
+        if (in_range) {
+          const SegGate gg = gates[g2base + ng];
+          const int res = gate3(cfg, s1.x1, s1.y1, s1.x2, s1.y2, s1.rs[0], s1.rs[1], s1.rs[2], s1.re[0], s1.re[1], s1.re[2],
+                                gg.n[0], gg.n[1], gg.n[2], gg.lcx, gg.lcy, gg.P, gg.Q, gg.w1, gg.sv, gg.q2, pr.F);
+          t0 = res != 0;
+          und = res == 2;
+          if (kVP && len1_ok) {
+            const Seg &s2 = segs[g2base + ng];
+            L2 l2{mk2(s2.x1, s2.y1), mk2(s2.x2, s2.y2)};
+            const bool len_ok = !(len(l2) <= cfg.min_length_2d);  // :177
+            t1 = len_ok && has_vp1;
+            t2 = len_ok && seg_has_vp[g2base + ng] != 0;
+          }
+        }
+      } else {
+        const long long item = item0 + c0 + cc;
+        const unsigned long long m = masks[kMasks * item];
+        unsigned long long m1 = 0, m2 = 0;
+        if (kVP) {
+          m1 = masks[kMasks * item + 1];
+          m2 = masks[kMasks * item + 2];
+        }
+        t0 = (m >> lane) & 1ull;
+        t1 = (m1 >> lane) & 1ull;
+        t2 = (m2 >> lane) & 1ull;
+        // output order inside an item: lanes ascending, per lane vp(l1), vp(l2), algebraic
+        const unsigned lane_off = base_off + (unsigned)(__popcll(m & lt_mask) + __popcll(m1 & lt_mask) + __popcll(m2 & lt_mask));
+        o1 = lane_off;
+        o2 = lane_off + (t1 ? 1u : 0u);
+        o0 = o2 + (t2 ? 1u : 0u);
+        base_off += (unsigned)(__popcll(m) + __popcll(m1) + __popcll(m2));
+      }
+      const unsigned idx = (unsigned)((cc << 6) | lane);
+      {
+        const unsigned long long bm = __ballot(t0);
+        if (t0) list[n_ent + __popcll(bm & lt_mask)] = idx | (0u << 9) | (und ? 1u << 11 : 0u) | (o0 << 12);
+        n_ent += __popcll(bm);
+      }
       if (kVP) {
-        masks[kMasks * item + 1] = m1;
-        masks[kMasks * item + 2] = m2;
+        const unsigned long long b1 = __ballot(t1);
+        if (t1) list[n_ent + __popcll(b1 & lt_mask)] = idx | (1u << 9) | (o1 << 12);
+        n_ent += __popcll(b1);
+        const unsigned long long b2 = __ballot(t2);
+        if (t2) list[n_ent + __popcll(b2 & lt_mask)] = idx | (2u << 9) | (o2 << 12);
+        n_ent += __popcll(b2);
       }
     }
-  } else {
-    const unsigned long long lt_mask = lanemask_lt();
-    long long pos = mask_pos[item] + __popcll(m & lt_mask) + __popcll(m1 & lt_mask) + __popcll(m2 & lt_mask);
-    const int nbs = lite_pack((int)(b - nb_off[i1]), i2);
-    if (kVP && ok1) {
-      o1.l.nb_slot = nbs; o1.l.ng_line = ng_line;
-      out_c[pos] = o1.c; out_l[pos] = o1.l;
-      ++pos;
+    wave_lds_sync();
+    // ---- phase B: dense evaluation ----
+    const long long pos0 = kFill ? mask_pos[item0 + c0] : 0;
+    for (int e0 = 0; e0 < n_ent; e0 += 64) {
+      const int e = e0 + lane;
+      if (e < n_ent) {
+        const unsigned ent = list[e];
+        const int cc = (int)((ent >> 6) & 7u), ln = (int)(ent & 63u), kind = (int)((ent >> 9) & 3u);
+        const int ng = ((c0 + cc) << 6) + ln;
+        const Seg &s2 = segs[g2base + ng];
+        GenOut o;
+        bool ok;
+        if (kind == 0) {
+          if (kFill) ok = gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o);   // pass 1 proved the gates
+          else if ((ent >> 11) & 1u) ok = gen_one(cfg, cams[i1], cams[i2], s1, s2, pr, &o);
+          else ok = gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o);
+        } else {
+          ok = vp_candidate(cfg, cams[i1], cams[i2], s1, s2, pr.B, seg_vp + 3 * (kind == 1 ? g : g2base + ng), &o);
+        }
+        if (!kFill) {
+          if (ok) atomicOr(&lmask[cc * kMasks + kind], 1ull << ln);
+        } else if (ok) {
+          const long long pos = pos0 + (long long)(ent >> 12);
+          o.l.nb_slot = nbs;
+          o.l.ng_line = ng;
+          out_c[pos] = o.c;
+          out_l[pos] = o.l;
+        }
+      }
     }
-    if (kVP && ok2) {
-      o2.l.nb_slot = nbs; o2.l.ng_line = ng_line;
-      out_c[pos] = o2.c; out_l[pos] = o2.l;
-      ++pos;
+    wave_lds_sync();
+    // ---- phase C: the survivor ballots of the group ----
+    if (!kFill && lane < nc * kMasks) {
+      const int cc = lane / kMasks, kind = lane - cc * kMasks;
+      masks[kMasks * (item0 + c0 + cc) + kind] = lmask[cc * kMasks + kind];
     }
-    if (ok) {
-      o.l.nb_slot = nbs; o.l.ng_line = ng_line;
-      out_c[pos] = o.c; out_l[pos] = o.l;
-    }
+    wave_lds_sync();
   }
 }
 
@@ -606,11 +643,11 @@ void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const G
                            const int *blk_chunk_off, int max_nb, int max_chunks, const void *gates_v) {
   if (n_items <= 0) return;
   const SegGate *gates = reinterpret_cast<const SegGate *>(gates_v);
-  dim3 grid(nblk(G * (long long)max_nb * max_chunks * 64, 256)), block(256);
-#define LT_LAUNCH_EX(FILL, VP)                                                                                     \
-  hipLaunchKernelGGL((k_gen_exhaustive<FILL, VP>), grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off, \
-                     blk_nb, seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l, seg_vp, seg_has_vp, blk_chunk_off, max_nb, \
-                     max_chunks, gates)
+  dim3 grid(nblk(G * (long long)max_nb * 64, 256)), block(256);  // one wave per (node, neighbour image)
+#define LT_LAUNCH_EX(FILL, VP)                                                                                       \
+  hipLaunchKernelGGL((k_gen_ex_block<FILL, VP>), grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off, blk_nb, \
+                     seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l, seg_vp, seg_has_vp, blk_chunk_off, max_nb,  \
+                     gates)
   if (seg_vp) {
     if (!fill) LT_LAUNCH_EX(false, true); else LT_LAUNCH_EX(true, true);
   } else {
