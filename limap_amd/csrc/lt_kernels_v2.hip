@@ -830,8 +830,106 @@ struct Score3Args {
   double *score;
   unsigned long long *pair_counter;  // stats: pairs that reached the dense evaluation
   unsigned *draw;                    // kTileQueues draw counters, 128 bytes apart: queue q = tiles q, q + 8, ...
+  const unsigned *perm;              // kSorted: candidate at depth-sorted position t (k_depth_order)
+  const uint2 *rng;                  // kSorted: node-relative range of sorted positions lane t has to sweep
   int max_nb;
 };
+
+// Depth order of a node's candidates (large nodes: exhaustive matching gives ~450 candidates per node and
+// 1.6e10 ordered pairs per scene, of which the sweep passes 0.05 %).  All candidates of a node are seen from
+// the node's own view, and the stored depth of a start point is a linear functional with a unit-norm
+// gradient (third row of R) of the point: |z_i - z_j| <= |start_i - start_j|.  A pair whose depths differ by
+// more than the scale-invariant guard radius of i can therefore not pass the sweep's distance guard -- in
+// depth-sorted order candidate i only has to sweep a contiguous range of positions.  One wave per node:
+// bitonic sort of (float depth, index) in LDS, then the range of every position by binary search.  The float
+// keys only steer the pruning (radius widened by their rounding); nodes above kSortMax candidates or with a
+// non-finite depth keep the identity order and the full range.  Which pairs reach the dense evaluation is
+// unchanged, so is every result (LT_TEST_SCORE_UNSORTED: the plain sweep).
+constexpr int kSortMax = 2048;
+__global__ void __launch_bounds__(256)
+k_depth_order(long long G, const long long *__restrict__ tri_off, const Cand *__restrict__ cand, double guard,
+              unsigned *__restrict__ perm, uint2 *__restrict__ rng) {
+  __shared__ float s_key[4][kSortMax];
+  __shared__ unsigned s_val[4][kSortMax];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = lane_id();
+  const long long g = (long long)blockIdx.x * 4 + wv;
+  if (g >= G) return;
+  const long long off = tri_off[g];
+  const int n = (int)(tri_off[g + 1] - off);
+  if (n <= 0) return;
+  float *key = s_key[wv];
+  unsigned *val = s_val[wv];
+  bool plain = n > kSortMax;
+  if (!plain) {
+    int N = 64;
+    while (N < n) N <<= 1;
+    bool bad = false;
+    for (int e = lane; e < N; e += 64) {
+      float kf = __builtin_huge_valf();
+      if (e < n) {
+        const double z = cand[off + e].depth[0];
+        kf = (float)z;
+        bad = bad || !(fabs(z) < 1e30);  // NaN / inf / absurd: no pruning for this node
+      }
+      key[e] = kf;
+      val[e] = (unsigned)e;
+    }
+    if (__ballot(bad)) plain = true;
+    if (!plain) {
+      wave_lds_sync();
+      for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int e = lane; e < N; e += 64) {
+            const int partner = e ^ j;
+            if (partner > e) {
+              const float ka = key[e], kb = key[partner];
+              const bool up = (e & k) == 0;
+              if (up ? (ka > kb) : (ka < kb)) {
+                const unsigned va = val[e], vb = val[partner];
+                key[e] = kb; key[partner] = ka;
+                val[e] = vb; val[partner] = va;
+              }
+            }
+          }
+          wave_lds_sync();
+        }
+      }
+      for (int r = lane; r < n; r += 64) {
+        perm[off + r] = (unsigned)(off + val[r]);
+        const float z = key[r];
+        const double zz = (double)z + kEps;
+        // radius of the sweep's distance guard for this candidate, widened by the keys' rounding
+        const double rad = (zz > 0.0) ? guard * zz * 1.0001 + 1e-6 * fabs((double)z) + 1e-30 : 1e300;
+        const float lo_v = (float)((double)z - rad), hi_v = (float)((double)z + rad);
+        int lo = 0, hi = n;  // first position with key >= lo_v
+        {
+          int a = 0, b = n;
+          while (a < b) {
+            const int m = (a + b) >> 1;
+            if (key[m] < lo_v) a = m + 1; else b = m;
+          }
+          lo = a;
+          a = lo; b = n;     // first position with key > hi_v
+          while (a < b) {
+            const int m = (a + b) >> 1;
+            if (key[m] <= hi_v) a = m + 1; else b = m;
+          }
+          hi = a;
+        }
+        if (!(rad < 1e299)) { lo = 0; hi = n; }
+        // (float)(z - rad) may round up: step the bounds outwards by one position to stay conservative
+        rng[off + r] = make_uint2((unsigned)max(lo - 1, 0), (unsigned)min(hi + 1, n));
+      }
+    }
+  }
+  if (plain) {
+    for (int r = lane; r < n; r += 64) {
+      perm[off + r] = (unsigned)(off + r);
+      rng[off + r] = make_uint2(0u, (unsigned)n);
+    }
+  }
+}
 
 // kF32 (default): the sweep's early exit in single precision on coordinates relative to a wave-local origin,
 // with the rounding of that form bounded and added to the guards, so that it rejects a subset of what the
@@ -845,7 +943,9 @@ struct Score3Args {
 // running (slot, max, sum) per lane in registers, evaluated pairs handed to their owner lanes by ballot +
 // readlane in queue order -- was measured: 195 us against 142 us, the serial hand-off costs more than the
 // 10 KB of LDS it frees.  Evaluating pair_score without its early returns, for ILP: no difference.)
-template <bool kF32>
+// kSorted: the tile is 64 consecutive DEPTH-SORTED positions of the candidate array (k_depth_order); lane t
+// owns candidate perm[t] and sweeps only the sorted positions rng[t] of its node.
+template <bool kF32, bool kSorted>
 __global__ void __launch_bounds__(64) LT_SCORE_OCC
 k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -888,18 +988,25 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   while (tile != 0xFFFFFFFFu) {
     if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
     const long long i0 = (long long)tile * 64;
-    const long long i = i0 + lane;
-    const bool active = i < C;
+    const long long tpos = i0 + lane;  // position (sorted order if kSorted)
+    const bool active = tpos < C;
+    const long long i = (kSorted && active) ? (long long)a.perm[tpos] : tpos;  // the lane's candidate
     LT_TRACE_MARK(2, tile, 0);
 
     long long off = 0, nb0 = 0;
     int n = 0, n_nb = 0, sloti = -1;
+    int r_lo = 0, r_hi = 0;  // node-relative positions the lane sweeps
     double dix = 0, diy = 0, diz = 0;
     double six = 0, siy = 0, siz = 0, eix = 0, eiy = 0, eiz = 0, gs2 = 0, ge2 = 0;
     if (active) {
-      const CandMeta mt = a.meta[i];
+      const CandMeta mt = a.meta[tpos];  // a position and its candidate belong to the same node
       off = ((long long)mt.off_hi << 32) | (long long)mt.off_lo;
       n = (int)mt.n;
+      r_lo = 0; r_hi = n;
+      if (kSorted) {
+        const uint2 rg = a.rng[tpos];
+        r_lo = (int)rg.x; r_hi = (int)rg.y;
+      }
       nb0 = (long long)(mt.nb >> 8);
       n_nb = (int)(mt.nb & 0xFFu);
       const CandLite li = a.lite[i];
@@ -934,12 +1041,14 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       ge = sqrt(ge2);
       cosf_guard = cfg.cos_guard > -1.0 ? (float)(cfg.cos_guard - 2e-6) : -2.0f;
     }
-    // candidate range of all nodes this wave touches (lane 0 is always active)
-    const long long lo = __shfl(off, 0);
-    long long hi = active ? off + n : 0;
+    // range of positions this wave has to stage (lane 0 is always active)
+    long long lo = active ? off + r_lo : (1ll << 62);
+    long long hi = active ? off + r_hi : 0;
     for (int d = 32; d >= 1; d >>= 1) {
       long long o = __shfl_xor(hi, d);
       hi = o > hi ? o : hi;
+      o = __shfl_xor(lo, d);
+      lo = o < lo ? o : lo;
     }
     int qn = 0;
     unsigned long long n_eval = 0;
@@ -951,8 +1060,9 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
         if (p < qn) {
           const unsigned e = queue[p];
           const int il = (int)(e >> 26);
-          const long long j = woff[il] + (long long)(e & 0x3FFFFFFu);
-          const long long ii = i0 + il;
+          const long long jpos = woff[il] + (long long)(e & 0x3FFFFFFu);
+          const long long j = kSorted ? (long long)a.perm[jpos] : jpos;
+          const long long ii = kSorted ? (long long)a.perm[i0 + il] : i0 + il;
           const Cand ci = a.cand[ii];
           const CandLite li = a.lite[ii];
           const CandLite lj = a.lite[j];
@@ -974,8 +1084,9 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
       float rw = ri;
       for (int e = lane; e < wn; e += 64) {
-        const CandLite l = a.lite[wb + e];
-        const Cand c = a.cand[wb + e];
+        const long long src = kSorted ? (long long)a.perm[wb + e] : wb + e;
+        const CandLite l = a.lite[src];
+        const Cand c = a.cand[src];
         if (kF32) {
           const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
           const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
@@ -1005,14 +1116,14 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       wave_lds_sync();
       if (wb == lo) { LT_TRACE_MARK(2, tile, 1); }
       // this lane's sub-range of the window
-      long long jlo = off > wb ? off : wb;
-      long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
+      long long jlo = (off + r_lo) > wb ? (off + r_lo) : wb;
+      long long jhi = (off + r_hi) < (wb + wn) ? (off + r_hi) : (wb + wn);
       int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
       int cmax = cnt;
       for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d));
       const int w0 = (int)(jlo - wb);
       const int jj0 = (int)(jlo - off);
-      const int self_t = (int)(i - jlo);  // iteration at which the lane meets itself (may be out of range)
+      const int self_t = (int)(tpos - jlo);  // iteration at which the lane meets itself (may be out of range)
       if (kF32) {
         const int wlast = cnt > 0 ? w0 + cnt - 1 : 0;  // reads beyond the lane's range are clamped, then masked
         const int wbase = cnt > 0 ? w0 : 0;
@@ -1222,7 +1333,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
-                   bool f32) {
+                   bool f32, unsigned *perm, void *rng) {
   if (C <= 0) return;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -1239,14 +1350,20 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand; a.lite = lite;
   a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
   a.draw = draw;
+  a.perm = perm; a.rng = reinterpret_cast<const uint2 *>(rng);
   a.max_nb = max_nb;
   if (ev_before) (void)hipEventRecord(ev_before, st);
+  const bool sorted = perm != nullptr && f32;
+  if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
+    hipLaunchKernelGGL(k_depth_order, dim3(nblk2(G, 4)), dim3(256), 0, st, G, tri_off, cand,
+                       scaleinv_guard2 < 1e299 ? std::sqrt(scaleinv_guard2) : 1e300, perm, reinterpret_cast<uint2 *>(rng));
   // persistent grid: as many single-wave workgroups as fit at once (LDS; registers allow LT_SCORE_RESIDENT per CU)
   const size_t lds = score3_lds_bytes(max_nb, f32);
   const long long per_cu = std::max<long long>(1, std::min<long long>(LT_SCORE_RESIDENT, (long long)(160 * 1024 / lds)));
   const dim3 grid((unsigned)std::min<long long>(n_tiles, per_cu * n_cu)), block(64);
-  if (f32) hipLaunchKernelGGL((k_score3<true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-  else hipLaunchKernelGGL((k_score3<false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+  if (sorted) hipLaunchKernelGGL((k_score3<true, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+  else if (f32) hipLaunchKernelGGL((k_score3<true, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+  else hipLaunchKernelGGL((k_score3<false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
 }
 
 }  // namespace lt
