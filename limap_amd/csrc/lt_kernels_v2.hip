@@ -276,7 +276,7 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
             e0 = p1[0]; e1 = p1[1]; e2 = p1[2]; e3 = p1[3]; e4 = p1[4];
           }
           if (kLds2) {
-            const double2 *p2 = T2 + ng * 5;
+            const double2 *p2 = T2 + ng * 5;  // (a conflict-free access pattern was timed: no faster)
             h0 = p2[0]; h1 = p2[1]; h2 = p2[2]; h3 = p2[3]; h4 = p2[4];
           } else {
             const double2 *p2 = reinterpret_cast<const double2 *>(a.gates + g2 + ng);
