@@ -251,6 +251,49 @@ def main():
             "tracks_whole_scene": st_after["tracks"], "merge_note": merge_note,
         }
 
+    # ---- extra (not `value`): independent batches in flight, N = 1 ----
+    # A service that triangulates independent scenes keeps more than one batch in flight; two contexts (each
+    # with its own stream and buffers, the same workload) overlap one batch's kernel tails and launch gaps
+    # with the other's kernels.  `value` above stays the one-batch-at-a-time figure the per-kernel roofline
+    # numbers belong to (HIP-event kernel durations are not meaningful while two streams interleave).
+    if rank == 0 and world == 1 and args.mode == "matched":
+        def make_ctx():
+            c = _capi.Context(cfg_dict=cfg, device=local_rank)
+            c.set_ranges(*scene.ranges)
+            c.init(scene.img_ids, scene.kvec, scene.qvec, scene.tvec, scene.seg_off, scene.segs)
+            for i in my_imgs:
+                m = scene.matches_of(int(i), args.topk)
+                nb = list(m.keys())
+                off = np.zeros(len(nb) + 1, np.int64)
+                off[1:] = np.cumsum([len(m[k]) for k in nb])
+                c.triangulate_image(int(i), nb, off, np.concatenate([m[k] for k in nb], 0) if nb else np.zeros((0, 2), np.int32))
+            c.upload()
+            return c
+        try:
+            pool = [make_ctx(), make_ctx()]
+            res = {}
+            for n_in_flight in (1, 2):
+                use = pool[:n_in_flight]
+                for s in range(2 * n_in_flight):
+                    use[s % n_in_flight].run_device(wait=False)
+                for c in use:
+                    c.sync()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for s in range(args.steps):
+                    use[s % n_in_flight].run_device(wait=False)
+                for c in use:
+                    c.sync()
+                torch.cuda.synchronize(dev)
+                el = time.perf_counter() - t0
+                res[str(n_in_flight)] = {"ms_per_batch": 1e3 * el / max(args.steps, 1),
+                                         "candidates_per_s": cand_total * args.steps / el}
+            out["batches_in_flight"] = dict(res, note="run only (no scene refresh); separate contexts and streams, "
+                                                     "same workload per batch; not the headline value")
+            del pool
+        except Exception as e:  # an extra: never lose the main line over it
+            out["batches_in_flight"] = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- end-to-end wall-clock through the reference's API sequence, rank 0 / N = 1 ----
     if rank == 0 and world == 1:
         from limap_amd import triangulation as tri
