@@ -180,6 +180,7 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
   long long n_rb = 0, n_re = 0, n_g1 = 0, n_g2 = 0;
   int n_M2 = 0, n_i1 = -1;
   bool n_live = false;
+  int n_blk2 = -1, fetched_b2 = -1, staged_b2 = -1;  // block of the next item / whose table is in flight / in T2
   double2 tv0, tv1, tv2, tv3, tv4;
   tv0 = tv1 = tv2 = tv3 = tv4 = double2{0.0, 0.0};
 #define LT_GATES_FETCH(IT)                                                                          \
@@ -190,7 +191,9 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
     const BlkRec *rp_ = blk_r + bb_; /* wave-uniform index: scalar loads */                         \
     n_rb = rp_->rb; n_re = rp_->re; n_g1 = rp_->g1; n_g2 = rp_->g2; n_M2 = rp_->M2; n_i1 = rp_->i1; \
     n_live = it_ < item_end && n_rb + (long long)pp_ * kRowsPerPart < n_re;                         \
-    if (kLds2 && n_live) {                                                                          \
+    n_blk2 = bb_;                                                                                   \
+    if (kLds2 && n_live && bb_ != fetched_b2) { /* the parts of a block share the neighbour's table */ \
+      fetched_b2 = bb_;                                                                             \
       const double2 *src_ = reinterpret_cast<const double2 *>(a.gates + n_g2);                      \
       const int units_ = n_M2 * 5;                                                                  \
       if ((int)threadIdx.x + 0 * nth < units_) tv0 = src_[threadIdx.x + 0 * nth];                   \
@@ -208,6 +211,7 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
     const long long rb = n_rb, re = n_re, g1 = n_g1, g2 = n_g2;
     const int M2 = n_M2, i1 = n_i1;
     const bool live = n_live;
+    const int blk2 = n_blk2;
     // b is wave-uniform; telling the compiler so keeps the pair record (F) in scalar registers --
     // otherwise it is re-fetched with per-lane vector loads inside the chunk loop
     const int b = __builtin_amdgcn_readfirstlane(item / n_parts), part = item - b * n_parts;
@@ -216,8 +220,10 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
     LT_TRACE_MARK(0, lin, 0);
     if (live) {
       const bool new_img = kLds1 && i1 != cur_i1;
-      if (kLds2 || new_img) __syncthreads();  // the previous item's readers are done with the tables
-      if (kLds2) {
+      const bool new_t2 = kLds2 && blk2 != staged_b2;
+      if (new_t2 || new_img) __syncthreads();  // the previous item's readers are done with the tables
+      if (new_t2) {
+        staged_b2 = blk2;
         const int units = M2 * 5;
         if ((int)threadIdx.x + 0 * nth < units) T2[threadIdx.x + 0 * nth] = tv0;
         if ((int)threadIdx.x + 1 * nth < units) T2[threadIdx.x + 1 * nth] = tv1;
@@ -235,7 +241,7 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
           T1[u] = reinterpret_cast<const double2 *>(a.segs + g1 + sidx)[k];
         }
       }
-      if (kLds2 || new_img) __syncthreads();
+      if (new_t2 || new_img) __syncthreads();
     }
     LT_GATES_FETCH(item + 1);
     LT_TRACE_MARK(0, lin, 1);
