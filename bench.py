@@ -317,8 +317,9 @@ def main():
                 else:
                     T.TriangulateImageExhaustiveMatch(int(i), scene.neighbors[int(i)])
             t2 = time.perf_counter()
-            T.context().compute_tracks()
+            tracks_py = T.ComputeLineTracks()  # the call the runner makes (line_triangulation.py:168): returns the tracks
             e2e.append(time.perf_counter() - t0)
+            assert len(tracks_py) == st_after["tracks"] or args.mode != "matched" or world != 1
             gc.enable()
             e2e_parts = {"ctor_init": 1e3 * (t1 - t0), "buffer": 1e3 * (t2 - t1), "compute_tracks": 1e3 * (e2e[-1] - (t2 - t0)),
                          "buffer_native": T.timers().get("buffer", 0.0)}

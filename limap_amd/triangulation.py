@@ -67,6 +67,45 @@ def flatten_bipartites(bpts):
                 lp_off=np.asarray(lp_off, np.int64), lp_ptids=cat(lp, np.int32))
 
 
+class _LazyLineTrack(LineTrack):
+    """A LineTrack over the arrays lt_get_tracks returned: every field is materialised on first access."""
+
+    def __init__(self, t, n, segs):  # deliberately no LineTrack.__init__: the fields appear on demand
+        d = self.__dict__
+        d["_t"], d["_n"], d["_segs"], d["active"] = t, n, segs, True
+
+    def _slice(self):
+        off = self._t["off"]
+        return slice(int(off[self._n]), int(off[self._n + 1]))
+
+    def __getattr__(self, name):  # only reached while the field has not been built yet
+        t = self._t
+        if name == "line":
+            r = t["line"][self._n]
+            v = Line3d(r[0:3], r[3:6], -1.0, -1.0, -1.0, r[6])
+        elif name == "image_id_list":
+            v = t["image_ids"][self._slice()].tolist()
+        elif name == "line_id_list":
+            v = t["line_ids"][self._slice()].tolist()
+        elif name == "node_id_list":
+            v = t["node_ids"][self._slice()].tolist()
+        elif name == "score_list":
+            v = t["scores"][self._slice()].tolist()
+        elif name == "line2d_list":
+            v = [Line2d(self._segs[i][l, 0:2], self._segs[i][l, 2:4])
+                 for i, l in zip(self.image_id_list, self.line_id_list)]
+        elif name == "line3d_list":
+            v = [Line3d(a[0:3], a[3:6]) for a in t["line3d"][self._slice()]]
+        else:
+            raise AttributeError(name)
+        self.__dict__[name] = v
+        return v
+
+    def count_lines(self):
+        s = self._slice()
+        return s.stop - s.start
+
+
 try:  # optional CPython helper (limap_amd/csrc/lt_pymarshal.c): same call, ~20 us less Python per image
     from . import _lt_pymarshal as _fast
 except ImportError:  # pragma: no cover
@@ -396,20 +435,9 @@ class GlobalLineTriangulator:
         raise NotImplementedError("GetAllValidBestTris with min_num_outer_edges > 0: use ComputeLineTracks()")
 
     def _build_tracks(self, t):
-        tracks = []
-        off = t["off"]
-        for n in range(len(off) - 1):
-            sl = slice(int(off[n]), int(off[n + 1]))
-            tr = LineTrack()
-            tr.line = Line3d(t["line"][n, 0:3], t["line"][n, 3:6], -1.0, -1.0, -1.0, t["line"][n, 6])
-            tr.image_id_list = [int(x) for x in t["image_ids"][sl]]
-            tr.line_id_list = [int(x) for x in t["line_ids"][sl]]
-            tr.node_id_list = [int(x) for x in t["node_ids"][sl]]
-            tr.score_list = [float(x) for x in t["scores"][sl]]
-            tr.line2d_list = [Line2d(self._segs[i][l, 0:2], self._segs[i][l, 2:4])
-                              for i, l in zip(tr.image_id_list, tr.line_id_list)]
-            tr.line3d_list = [Line3d(a[0:3], a[3:6]) for a in t["line3d"][sl]]
-            tracks.append(tr)
+        # The reference hands back pybind wrappers of C++ LineTracks (no per-member Python objects until they are
+        # looked at); building ~35 000 Line2d / Line3d objects eagerly here cost 20x the whole triangulation.
+        tracks = [_LazyLineTrack(t, n, self._segs) for n in range(len(t["off"]) - 1)]
         try:  # convert to limap's LineTrack when limap is installed (linetrack.cc:50-74 dict ctor)
             import limap.base as _lb
             return [_lb.LineTrack(tr.as_dict()) for tr in tracks]
