@@ -103,14 +103,22 @@ __global__ void k_build_segs_chunked(long long n_segs, int n_img, int n_chunks, 
 // image shards spread over several GPUs a rank needs ~1/N of the gathered scene.
 __global__ void k_build_segs_listed(const int *__restrict__ img_list, int n_chunks, const SceneChunk *__restrict__ ch,
                                     const long long *__restrict__ seg_off, double halfpix,
-                                    const Cam *__restrict__ cams, Seg *__restrict__ out,
+                                    Cam *__restrict__ cams, Seg *__restrict__ out,
                                     SegGate *__restrict__ gates) {
   const int img = img_list[blockIdx.y];
   const long long s0 = seg_off[img], M = seg_off[img + 1] - s0;
   const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= M) return;
   int c = 0;
   while (c + 1 < n_chunks && img >= ch[c + 1].img_begin) ++c;
+  // the image's camera record is built here as well (every thread for itself, the first one stores it):
+  // one launch per refresh instead of a camera kernel followed by a segment kernel
+  Cam cm;
+  {
+    const int li = img - ch[c].img_begin;
+    cam_build(ch[c].k + 4 * li, ch[c].q + 4 * li, ch[c].t + 3 * li, &cm);
+    if (l == 0) cams[img] = cm;
+  }
+  if (l >= M) return;
   const long long s = s0 + l;
   const double *p = ch[c].s + 4 * (s - ch[c].seg_begin);
   double x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
@@ -118,7 +126,7 @@ __global__ void k_build_segs_listed(const int *__restrict__ img_list, int n_chun
     x1 = x1 + halfpix; y1 = y1 + halfpix; x2 = x2 + halfpix; y2 = y2 + halfpix;
   }
   Seg r;
-  seg_build(cams[img], x1, y1, x2, y2, &r);
+  seg_build(cm, x1, y1, x2, y2, &r);
   out[s] = r;
   if (gates) seg_gate_build(r, &gates[s]);
 }
@@ -589,10 +597,11 @@ void launch_build_scene_chunked(hipStream_t st, int n_img, long long n_segs, int
                                 const long long *seg_off, double halfpix, Cam *cams, Seg *segs,
                                 const int *img_list, int n_list, long long max_segs_per_img, void *gates_v) {
   SegGate *gates = reinterpret_cast<SegGate *>(gates_v);
-  if (n_img > 0)
+  const bool listed = img_list && n_list > 0 && max_segs_per_img > 0 && n_segs > 0;
+  if (n_img > 0 && !listed)  // the listed form builds the cameras of the listed images itself
     hipLaunchKernelGGL(k_build_cams_chunked, dim3(nblk(n_img, 128)), dim3(128), 0, st, n_img, n_chunks, ch, cams);
   if (n_segs <= 0) return;
-  if (img_list && n_list > 0 && max_segs_per_img > 0) {
+  if (listed) {
     for (int y0 = 0; y0 < n_list; y0 += 65535) {
       const int ny = std::min(65535, n_list - y0);
       hipLaunchKernelGGL(k_build_segs_listed, dim3(nblk(max_segs_per_img, 256), ny), dim3(256), 0, st, img_list + y0,
