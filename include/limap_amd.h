@@ -228,8 +228,8 @@ int lt_ts_remerge_once(lt_ctx *ctx, lt_trackset *ts, const lt_config *linker_cfg
  * [5] graph edges, [6] tracks, [7] nodes. */
 int lt_get_stats(lt_ctx *ctx, int64_t out[8]);
 /* HIP-event timings (ms) of the last lt_run_device on the context's stream:
- * [0] whole run, [1] invariants, [2] connection sort, [3] generation, [4] compaction,
- * [5] scoring kernel, [6] selection + edges, [7] gather; host: [8] upload, [9] download,
+ * [0] whole run, [1], [2] unused (0), [3] generation (incl. the per-pair records), [4] placement of the
+ * candidates, [5] scoring (incl. its per-candidate records), [6] selection, [7] unused (0); host: [8] upload, [9] download,
  * [10] tail (lt_compute_tracks); [11] candidate pairs that reached the dense evaluation in k_score3;
  * [12] host ms spent inside lt_triangulate_image* buffering the match rows of the batch;
  * single-kernel durations (HIP events around the launch): [13] k_gates, [14] k_tri_rows, [15] k_score3;

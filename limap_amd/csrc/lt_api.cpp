@@ -1202,11 +1202,16 @@ int finish_run(lt_ctx *ctx) {
   if (derr == 2)
     return fail(ctx, LT_ERR_RUNTIME, "map::at: a point shared by two lines has a point3D_id that is not among the SfM points");
   if (derr != 0) return fail(ctx, LT_ERR_RUNTIME, "IndexError! Out-of-index matches detected on the device");
+  // coarse stages from five events (every hipEventRecord between kernels costs ~1.5 us of device time):
+  // [3] generation incl. the pair records = ev0..ev3, [4] placement = ev3..ev4, [5] scoring incl. its per-candidate
+  // records = ev4..ev5, [6] selection = ev5..ev7; [1], [2], [7] are no longer separate stages
   float ms;
-  static const int kMap[7] = {1, 2, 3, 4, 5, 6, 7};
-  for (int k = 0; k < 7; ++k) {
-    HIPCHK(ctx, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
-    ctx->timers[kMap[k]] = ms;
+  ctx->timers[1] = ctx->timers[2] = ctx->timers[7] = 0.0;
+  const int eg = ctx->pend_ev_gen_end, ep = ctx->pend_ev_place_end;
+  const int kA[4] = {0, eg, ep, 5}, kB[4] = {eg, ep, 5, 7}, kT[4] = {3, 4, 5, 6};
+  for (int k = 0; k < 4; ++k) {
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ev[kA[k]], ev[kB[k]]));
+    ctx->timers[kT[k]] = ms;
   }
   HIPCHK(ctx, hipEventElapsedTime(&ms, ev[0], ev[7]));
   ctx->timers[0] = ms;
@@ -1261,10 +1266,10 @@ int lt_run_device_async(lt_ctx *ctx) {
                      ctx->d_pairs.as<PairRec>(), ctx->d_err.as<int>(),
                      ctx->d_pair_counter.as<unsigned long long>(), ctx->d_scan_status.as<unsigned long long>(),
                      n_status);
-  HIPCHK(ctx, hipEventRecord(ev[1], st));
 
   long long C_known = -1;  // candidate count once it is known on the host
   long long C_bound = 0;   // what sizes the compact arrays: the count, or an upper bound while it stays on the device
+  int ev_gen_end = 3, ev_place_end = 4;  // events that close the generation / placement stage (see finish_run)
   long long C_run = 0;  // what finish_run reports as the run's candidate count unless the device copy does
   if (ctx->job_mode == 1) {
     const size_t Pn = (size_t)std::max<long long>(P, 1);
@@ -1272,7 +1277,6 @@ int lt_run_device_async(lt_ctx *ctx) {
     const long long n_waves = (long long)ctx->n_blk * gen_groups(ctx->max_rows);  // candidate lists
     const long long n_slots_all = (long long)ctx->n_blk * gen_slots(ctx->max_rows);  // survivor lists
     const long long n_entries = ctx->h_blk_line_base[ctx->n_blk];
-    HIPCHK(ctx, hipEventRecord(ev[2], st));
     // ---- generation in row order; valid candidates appended in row order to per-wave lists ----
     // VP-guided proposals: up to three candidates per match row (vp of l1, vp of l2, algebraic)
     const bool vp_on = ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation;
@@ -1331,7 +1335,9 @@ int lt_run_device_async(lt_ctx *ctx) {
                        (pts_on && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr, ctx->d_err.as<int>(),
                        many_on ? 1 : 0, one_on ? 1 : 0, mult);
     }
-    HIPCHK(ctx, hipEventRecord(ev[3], st));
+    // with the per-kernel events on, the one after k_tri_rows also ends the generation stage
+    if (fine_timers() && ctx->n_blk > 0 && ctx->max_rows > 0) ev_gen_end = 10;
+    else HIPCHK(ctx, hipEventRecord(ev[3], st));
     long long *hC = hp;  // this set's slot 0
     long long hC_fallback = 0;
     if (!hC) hC = &hC_fallback;
@@ -1402,9 +1408,10 @@ int lt_run_device_async(lt_ctx *ctx) {
                      ctx->d_st_l.as<CandLite>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
                      ctx->d_cand_node.as<unsigned>());
     }
-    HIPCHK(ctx, hipEventRecord(ev[4], st));
+    // ... and the one in front of k_score3 ends the placement stage (it then includes k_cand_meta)
+    if (fine_timers() && C_bound > 0) ev_place_end = 11;
+    else HIPCHK(ctx, hipEventRecord(ev[4], st));
   } else if (ctx->job_mode == 2) {
-    HIPCHK(ctx, hipEventRecord(ev[2], st));
     const size_t In = (size_t)std::max<long long>(P, 1);
     // VP-guided proposals: three survivor ballots per work item (algebraic, vp of l1, vp of l2)
     const bool vp_on = ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation;
@@ -1482,7 +1489,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     ENSURE(ctx, ctx->d_score, 8); ENSURE(ctx, ctx->d_edge_flag, 4); ENSURE(ctx, ctx->d_cand_node, 4);
     C_known = 0;
     C_bound = 0;
-    for (int k = 2; k <= 4; ++k) HIPCHK(ctx, hipEventRecord(ev[k], st));
+    for (int k = 3; k <= 4; ++k) HIPCHK(ctx, hipEventRecord(ev[k], st));
   }
 
   // ---- scoring ----
@@ -1529,7 +1536,6 @@ int lt_run_device_async(lt_ctx *ctx) {
                 ctx->d_nvalid.as<unsigned>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
                 ctx->d_best_c.as<Cand>(), ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(),
                 ctx->d_ntris.as<int>(), /*wide=*/ctx->job_mode == 2);
-  HIPCHK(ctx, hipEventRecord(ev[6], st));
   HIPCHK(ctx, hipEventRecord(ev[7], st));
   HIPCHK(ctx, hipGetLastError());
   // the device error flag, the candidate count and the pair statistic ride on the stream into this set's
@@ -1549,6 +1555,8 @@ int lt_run_device_async(lt_ctx *ctx) {
   ctx->pend_set = set;
   ctx->pend_count_on_device = C_known < 0;
   ctx->pend_C = C_run;
+  ctx->pend_ev_gen_end = ev_gen_end;
+  ctx->pend_ev_place_end = ev_place_end;
   ctx->ran = true;
   ctx->downloaded = false;
   return rc_prev;

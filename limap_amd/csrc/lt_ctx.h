@@ -234,6 +234,7 @@ struct lt_ctx {
   int pend_set = 0;                 // its event / pinned-slot set
   bool pend_count_on_device = false;
   long long pend_C = 0;
+  int pend_ev_gen_end = 3, pend_ev_place_end = 4;
   long long C_last = 0;  // candidates of the last lt_run_device (known on the host once the scoring grid is sized)
 };
 
