@@ -1208,12 +1208,13 @@ int finish_run(lt_ctx *ctx) {
   float ms;
   ctx->timers[1] = ctx->timers[2] = ctx->timers[7] = 0.0;
   const int eg = ctx->pend_ev_gen_end, ep = ctx->pend_ev_place_end;
-  const int kA[4] = {0, eg, ep, 5}, kB[4] = {eg, ep, 5, 7}, kT[4] = {3, 4, 5, 6};
+  const int ee = hp ? 12 : 7;  // end of the run: the end marker behind the result copies, if there are result slots
+  const int kA[4] = {0, eg, ep, 5}, kB[4] = {eg, ep, 5, ee}, kT[4] = {3, 4, 5, 6};
   for (int k = 0; k < 4; ++k) {
     HIPCHK(ctx, hipEventElapsedTime(&ms, ev[kA[k]], ev[kB[k]]));
     ctx->timers[kT[k]] = ms;
   }
-  HIPCHK(ctx, hipEventElapsedTime(&ms, ev[0], ev[7]));
+  HIPCHK(ctx, hipEventElapsedTime(&ms, ev[0], ev[ee]));
   ctx->timers[0] = ms;
   // single-kernel durations of the matched pipeline: [13] k_gates, [14] k_tri_rows, [15] k_score3
   ctx->timers[13] = ctx->timers[14] = ctx->timers[15] = 0.0;
@@ -1536,7 +1537,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                 ctx->d_nvalid.as<unsigned>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
                 ctx->d_best_c.as<Cand>(), ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(),
                 ctx->d_ntris.as<int>(), /*wide=*/ctx->job_mode == 2);
-  HIPCHK(ctx, hipEventRecord(ev[7], st));
+  if (!hp) HIPCHK(ctx, hipEventRecord(ev[7], st));  // with result slots the end marker below also ends the run
   HIPCHK(ctx, hipGetLastError());
   // the device error flag, the candidate count and the pair statistic ride on the stream into this set's
   // pinned slots; finish_run reads them behind the end marker
