@@ -568,7 +568,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
-                    &ctx->d_pair_counter, &ctx->d_tile_order, &ctx->d_scan_status, &ctx->d_perm, &ctx->d_rng, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz};
+                    &ctx->d_pair_counter, &ctx->d_result3, &ctx->d_tile_order, &ctx->d_scan_status, &ctx->d_perm, &ctx->d_rng, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz};
   lt_host::host_block_release(ctx->h_pinned_blk);
   lt_host::host_block_release(ctx->best_c_blk);
   for (DevBuf *b : bufs) b->release();
@@ -1182,7 +1182,7 @@ int finish_run(lt_ctx *ctx) {
   int derr = 0;
   if (hp) {
     HIPCHK(ctx, hipEventSynchronize(ev[12]));
-    derr = *reinterpret_cast<int *>(&hp[1]);
+    derr = (int)hp[1];
     ctx->stat_pairs_eval = hp[2];
     ctx->C_last = ctx->pend_count_on_device ? hp[0] : ctx->pend_C;
   } else {
@@ -1257,6 +1257,7 @@ int lt_run_device_async(lt_ctx *ctx) {
   const ScoreCfg scfg = make_score(ctx);
   ENSURE(ctx, ctx->d_err, sizeof(int));
   ENSURE(ctx, ctx->d_pair_counter, 8);
+  ENSURE(ctx, ctx->d_result3, 24);
   ENSURE(ctx, ctx->d_pairs, sizeof(PairRec) * (size_t)std::max(ctx->n_blk, 1));
   ENSURE(ctx, ctx->d_tri_off, sizeof(long long) * (size_t)(G + 1));
   HIPCHK(ctx, hipEventRecord(ev[0], st));
@@ -1536,18 +1537,16 @@ int lt_run_device_async(lt_ctx *ctx) {
                 scfg.max_valid_conns, ctx->d_best_idx.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
                 ctx->d_nvalid.as<unsigned>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
                 ctx->d_best_c.as<Cand>(), ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(),
-                ctx->d_ntris.as<int>(), /*wide=*/ctx->job_mode == 2);
+                ctx->d_ntris.as<int>(), /*wide=*/ctx->job_mode == 2, ctx->d_err.as<int>(),
+                ctx->d_pair_counter.as<unsigned long long>(), ctx->d_result3.as<long long>());
   if (!hp) HIPCHK(ctx, hipEventRecord(ev[7], st));  // with result slots the end marker below also ends the run
   HIPCHK(ctx, hipGetLastError());
   // the device error flag, the candidate count and the pair statistic ride on the stream into this set's
   // pinned slots; finish_run reads them behind the end marker
   if (hp) {
-    hp[1] = 0; hp[2] = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&hp[1], ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (C_known < 0)
-      HIPCHK(ctx, hipMemcpyAsync(&hp[0], ctx->d_tri_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
-    if (C_run > 0)
-      HIPCHK(ctx, hipMemcpyAsync(&hp[2], ctx->d_pair_counter.p, 8, hipMemcpyDeviceToHost, st));
+    // hp[0] candidate count, hp[1] error flag, hp[2] pair statistic: one record, gathered by k_select
+    if (G <= 0) HIPCHK(ctx, hipMemsetAsync(ctx->d_result3.p, 0, 24, st));  // no nodes: k_select did not run
+    HIPCHK(ctx, hipMemcpyAsync(&hp[0], ctx->d_result3.p, 24, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipEventRecord(ev[12], st));
   }
   int rc_prev = LT_OK;

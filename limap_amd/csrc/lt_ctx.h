@@ -193,6 +193,7 @@ struct lt_ctx {
   DevBuf d_blk_chunk_off;    // exhaustive mode: per block, 64-line chunks of the image's earlier blocks
   int max_chunks = 1;        // exhaustive mode: most 64-line chunks of any neighbour
   DevBuf d_perm, d_rng;      // k_depth_order: depth-sorted candidate order of every node + per-position sweep range
+  DevBuf d_result3;          // the run's result scalars (candidate count, error flag, pair statistic), one record
   DevBuf d_scan_status;      // k_node_prefix: ticket counter + per-tile look-back state
   DevBuf d_tile_order;       // k_score3: tile draw counters
   DevBuf d_base_bl;          // exclusive prefix of cnt_bl over the neighbour blocks of a node

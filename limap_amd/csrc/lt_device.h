@@ -55,7 +55,7 @@ void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_of
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
                    int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const Cand *cand,
                    const CandLite *lite, Cand *best_c, double *best_score, int *best_src2, int *n_tris,
-                   bool wide);
+                   bool wide, const int *err_flag, const unsigned long long *pair_counter, long long *result3);
 void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
                       const long long *edge_off, const CandLite *lite, int *edges2);
 

@@ -477,7 +477,15 @@ k_select(long long G, const long long *__restrict__ tri_off, const double *__res
          double fullscore_th, int max_valid_conns, long long *__restrict__ best_idx,
          unsigned *__restrict__ edge_flag, unsigned *__restrict__ n_valid, const Cand *__restrict__ cand,
          const CandLite *__restrict__ lite, Cand *__restrict__ best_c, double *__restrict__ best_score,
-         int *__restrict__ best_src2, int *__restrict__ n_tris) {
+         int *__restrict__ best_src2, int *__restrict__ n_tris, const int *__restrict__ err_flag,
+         const unsigned long long *__restrict__ pair_counter, long long *__restrict__ result3) {
+  // the run's three result scalars (error flag, candidate count, pair statistic) are gathered into one record
+  // here, in the last kernel of the run, so that one 24-byte copy brings them to the host instead of three
+  if (result3 && blockIdx.x == 0 && threadIdx.x == 0) {
+    result3[0] = tri_off[G];
+    result3[1] = (long long)*err_flag;
+    result3[2] = (long long)*pair_counter;
+  }
   // kLanes = 16: a quarter wave per node -- a whole wave per node left 4/5 of the lanes idle in matched mode;
   // xor-shuffles below kLanes stay inside the group
   long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / kLanes;
@@ -697,15 +705,17 @@ void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_of
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
                    int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const Cand *cand,
                    const CandLite *lite, Cand *best_c, double *best_score, int *best_src2, int *n_tris,
-                   bool wide) {
+                   bool wide, const int *err_flag, const unsigned long long *pair_counter, long long *result3) {
   if (G > 0)
   {
     if (wide)
       hipLaunchKernelGGL(k_select<64>, dim3(nblk(G * 64, 256)), dim3(256), 0, st, G, tri_off, score, th, max_valid,
-                         best_idx, edge_flag, n_valid, cand, lite, best_c, best_score, best_src2, n_tris);
+                         best_idx, edge_flag, n_valid, cand, lite, best_c, best_score, best_src2, n_tris, err_flag,
+                         pair_counter, result3);
     else
       hipLaunchKernelGGL(k_select<16>, dim3(nblk(G * 16, 256)), dim3(256), 0, st, G, tri_off, score, th, max_valid,
-                         best_idx, edge_flag, n_valid, cand, lite, best_c, best_score, best_src2, n_tris);
+                         best_idx, edge_flag, n_valid, cand, lite, best_c, best_score, best_src2, n_tris, err_flag,
+                         pair_counter, result3);
   }
 }
 void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
