@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--mode", default="matched", choices=["matched", "exhaustive"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the batches-in-flight extra (profiling runs: its overlapped kernels would mix into the per-kernel stats)")
     args = ap.parse_args()
 
     import torch
@@ -256,7 +258,7 @@ def main():
     # with its own stream and buffers, the same workload) overlap one batch's kernel tails and launch gaps
     # with the other's kernels.  `value` above stays the one-batch-at-a-time figure the per-kernel roofline
     # numbers belong to (HIP-event kernel durations are not meaningful while two streams interleave).
-    if rank == 0 and world == 1 and args.mode == "matched":
+    if rank == 0 and world == 1 and args.mode == "matched" and not args.no_extras:
         def make_ctx():
             c = _capi.Context(cfg_dict=cfg, device=local_rank)
             c.set_ranges(*scene.ranges)

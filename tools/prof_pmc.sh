@@ -21,7 +21,7 @@ i=0
 for g in "${groups[@]}"; do
   i=$((i+1))
   cd /tmp && rm -rf /tmp/pmc_${tag}_$i
-  timeout 300 rocprofv3 --pmc $g -d /tmp/pmc_${tag}_$i -- python $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> /tmp/pmc_${tag}_$i.err || { echo "# group $i failed: $g" >> $out; tail -3 /tmp/pmc_${tag}_$i.err >> $out; continue; }
+  timeout 300 rocprofv3 --pmc $g -d /tmp/pmc_${tag}_$i -- python $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > /dev/null 2> /tmp/pmc_${tag}_$i.err || { echo "# group $i failed: $g" >> $out; tail -3 /tmp/pmc_${tag}_$i.err >> $out; continue; }
   db=$(find /tmp/pmc_${tag}_$i -name "*.db" | head -1)
   python $repo/tools/rocpd_pmc.py $db 2>/dev/null | grep -E "k_gates|k_tri_rows|k_place|k_score3|k_gen_rows|k_select|k_gather" >> $out
 done

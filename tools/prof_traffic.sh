@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 mkdir -p $repo/gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
   cd /tmp && rm -rf /tmp/traffic_$c
-  timeout 300 rocprofv3 --pmc $c -d /tmp/traffic_$c -- python $repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> /tmp/traffic_$c.err
+  timeout 300 rocprofv3 --pmc $c -d /tmp/traffic_$c -- python $repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> /tmp/traffic_$c.err
   db=$(find /tmp/traffic_$c -name "*.db" | head -1)
   python $repo/tools/rocpd_pmc.py $db 2>/dev/null > $repo/gpurun_out/traffic_$c.csv
 done
