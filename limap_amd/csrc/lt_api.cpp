@@ -1380,6 +1380,19 @@ int lt_run_device_async(lt_ctx *ctx) {
       HIPCHK(ctx, hipStreamSynchronize(st));
       C_known = *hC;
     }
+    if (C_known < 0) {
+      // the bound is generous: if the device cannot give that much, fetch the exact count after all
+      const size_t Bn = (size_t)std::max<long long>(C_bound, 1);
+      const bool got = ctx->d_cand.ensure(sizeof(Cand) * Bn) && ctx->d_lite.ensure(sizeof(CandLite) * Bn) &&
+                       ctx->d_score.ensure(8 * Bn) && ctx->d_edge_flag.ensure(4 * Bn) && ctx->d_cand_node.ensure(4 * Bn) &&
+                       ctx->d_cand_meta.ensure(cand_meta_bytes() * Bn);
+      if (!got) {
+        (void)hipGetLastError();
+        HIPCHK(ctx, hipMemcpyAsync(hC, ctx->d_tri_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        C_known = *hC;
+      }
+    }
     if (C_known >= 0) C_bound = C_known;
     const size_t Cn = (size_t)std::max<long long>(C_bound, 1);
     ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);

@@ -111,3 +111,26 @@ def test_pymarshal_helper_matches_python_path():
                 np.zeros(0, np.int32), [[1, 2]]):
         assert tri._fast.triangulate_image_rows(addr, 1234, 42, {1: bad}) is None
     assert tri._fast.triangulate_image_rows(addr, 1234, 42, {"x": m[5]}) is None
+
+
+def test_lazy_line_tracks_materialise_on_access():
+    """The tracks ComputeLineTracks() returns build their member lists on first access (like the reference's
+    pybind wrappers of C++ LineTracks) and then behave like plain LineTrack objects."""
+    from limap_amd import triangulation as tri
+    t = dict(off=np.array([0, 2, 5], np.int64),
+             line=np.array([[0, 0, 0, 1, 1, 1, 0.5], [1, 2, 3, 4, 5, 6, 0.25]], float),
+             image_ids=np.array([10, 11, 10, 12, 13], np.int32), line_ids=np.array([0, 1, 1, 0, 0], np.int32),
+             node_ids=np.array([0, 1, 2, 3, 4], np.int32), scores=np.array([1.0, 2.0, 3.0, 4.0, 5.0]),
+             line3d=np.arange(30, dtype=float).reshape(5, 6))
+    segs = {i: np.arange(8, dtype=float).reshape(2, 4) + i for i in (10, 11, 12, 13)}
+    tr = [tri._LazyLineTrack(t, n, segs) for n in range(2)]
+    assert tr[0].count_lines() == 2 and tr[1].count_lines() == 3 and "image_id_list" not in tr[1].__dict__
+    assert tr[1].image_id_list == [10, 12, 13] and tr[1].line_id_list == [1, 0, 0] and tr[1].node_id_list == [2, 3, 4]
+    assert tr[1].score_list == [3.0, 4.0, 5.0] and tr[1].count_images() == 3 and tr[1].HasImage(12)
+    assert np.array_equal(tr[1].line.start, [1, 2, 3]) and tr[1].line.uncertainty == 0.25
+    assert np.array_equal(tr[1].line2d_list[0].start, segs[10][1, 0:2])
+    assert np.array_equal(tr[0].line3d_list[1].end, t["line3d"][1, 3:6])
+    d = tr[1].as_dict()
+    assert d["image_id_list"] == [10, 12, 13] and len(d["line2d_list"]) == 3 and d["active"] is True
+    with pytest.raises(AttributeError):
+        tr[0].no_such_field
