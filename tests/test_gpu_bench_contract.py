@@ -35,3 +35,18 @@ def test_bench_line_has_the_contract_fields(gpu_lib):
     # the oracle's counts for the same scene agree with the device's
     assert d["cpu_parity"]["tracks_cpu"] == d["cpu_parity"]["tracks_gpu"]
     assert d["cpu_parity"]["candidates_cpu"] == d["cpu_parity"]["candidates_gpu"]
+
+
+def test_bench_collective_path_one_rank(gpu_lib):
+    """The N > 1 code path of bench.py (RCCL all-gather per step, overlapped with the kernels, max over ranks) on
+    the one GPU a test box has: LT_BENCH_FORCE_DIST=1 under torch.distributed.run with one rank."""
+    env = dict(os.environ, LT_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "3", "--warmup", "1", "--views", "12", "--segs", "60",
+                          "--neighbors", "5", "--no-cpu-baseline"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["counts"]["candidates"] > 0 and d["tracks_whole_scene"] > 0
