@@ -1,5 +1,5 @@
 """Developer tool: randomised differential run, product (HIP) against the CPU oracle (test infrastructure) on
-random small scenes / modes / a few configuration knobs.  usage (GPU box): python tools/fuzz_parity.py [n] [seed0]"""
+random small scenes / modes / a few configuration knobs.  usage (GPU box): python tools/fuzz_parity.py [n] [seed0] [big]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,11 +11,15 @@ from helpers import compare_best, compare_candidates, compare_tracks, compare_va
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+big = len(sys.argv) > 3 and sys.argv[3] == "big"  # larger scenes: tracks exist, the tail is exercised
 ora.build()
 bad = 0
 for k in range(n):
     rng = np.random.default_rng(seed0 + k)
-    nv, ns, nn = int(rng.integers(5, 15)), int(rng.integers(20, 160)), int(rng.integers(2, 8))
+    if big:
+        nv, ns, nn = int(rng.integers(16, 31)), int(rng.integers(100, 260)), int(rng.integers(6, 11))
+    else:
+        nv, ns, nn = int(rng.integers(5, 15)), int(rng.integers(20, 160)), int(rng.integers(2, 8))
     sc = syn.make_scene(n_views=nv, n_segs=ns, n_neighbors=min(nn, nv - 1), seed=seed0 + k)
     cfg = syn.default_triangulation_cfg(debug_mode=True)
     cfg["linker3d_config"]["th_angle"] = float(rng.choice([5.0, 10.0, 20.0]))
