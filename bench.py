@@ -52,6 +52,43 @@ def algorithmic_bytes(stats, n_img_active, nn, survivors):
     return {"score": score, "gen": gen, "gates": gates, "tri": tri}
 
 
+def cpu_parity(T, O):
+    """Product (after ComputeLineTracks) against the oracle on the same job: the bars of north_star --
+    best candidate per node (global_line_triangulator.cc:145-153), valid-edge sets (:118-142), track
+    membership and order (merging/merging.cc:84-101) identical, track endpoints <= 1e-5 relative modulo
+    the start/end swap the SVD sign leaves open (merging/aggregator.cc:76-78)."""
+    gb, ob = T.context().get_best(), O.get_best()
+    best_ok = bool(np.array_equal(gb["has_best"], ob["has_best"]) and np.array_equal(gb["src"], ob["src"]))
+    best_geom_ok = bool(np.array_equal(gb["line"], ob["line"]))
+    sc_den = np.maximum(np.abs(ob["score"]), 1e-300)
+    best_score_err = float(np.max(np.abs(gb["score"] - ob["score"]) / sc_den)) if len(sc_den) else 0.0
+    (goff, ge), (ooff, oe) = T.context().get_valid_edges(), O.get_valid_edges()
+    edges_ok = bool(np.array_equal(goff, ooff))
+    if edges_ok and len(ge):  # order inside a node is unobservable (std::set): compare sorted per node
+        node = np.repeat(np.arange(len(goff) - 1), np.diff(goff))
+        kg = np.lexsort((ge[:, 1], ge[:, 0], node))
+        ko = np.lexsort((oe[:, 1], oe[:, 0], node))
+        edges_ok = bool(np.array_equal(ge[kg], oe[ko]))
+    gt, ot = T.context().get_tracks(), O.get_tracks()
+    members_ok = bool(all(np.array_equal(gt[k], ot[k]) for k in ("off", "image_ids", "line_ids", "node_ids")))
+    err = None
+    if members_ok and len(gt["line"]):
+        gl, ol = gt["line"], ot["line"]
+        scale = np.maximum(np.abs(ol[:, :6]).max(axis=1, keepdims=True), 1e-9)
+        d_same = (np.abs(gl[:, :6] - ol[:, :6]) / scale).max(axis=1)
+        d_swap = (np.abs(gl[:, :6] - np.concatenate([ol[:, 3:6], ol[:, 0:3]], 1)) / scale).max(axis=1)
+        err = float(np.minimum(d_same, d_swap).max())
+    st, so = T.stats(), O.stats()
+    rep = {"best_src_identical": best_ok, "best_geometry_bit_exact": best_geom_ok, "best_score_max_rel_err": best_score_err,
+           "edges_identical": edges_ok, "track_members_identical": members_ok, "max_endpoint_rel_err": err,
+           "tracks_cpu": so["tracks"], "tracks_gpu": st["tracks"], "candidates_cpu": so["candidates"],
+           "candidates_gpu": st["candidates"], "valid_edges_cpu": so["valid_edges"], "valid_edges_gpu": st["valid_edges"]}
+    ok = (best_ok and best_geom_ok and edges_ok and members_ok and best_score_err <= 1e-12
+          and (err is None or err <= 1e-5) and so["tracks"] == st["tracks"] and so["candidates"] == st["candidates"])
+    rep["ok"] = bool(ok)
+    return ok, rep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +239,7 @@ def main():
     value = cand_total * args.steps / elapsed
 
     out = None
+    parity_ok = True
     if rank == 0:
         ab = algorithmic_bytes(st, len(my_imgs), args.neighbors, kt.get("survivors", 0.0))
         # per-KERNEL durations: HIP events recorded on the launch stream right around each kernel
@@ -335,6 +373,7 @@ def main():
                 ts.filter_by_sensitivity(75.0, 3).filter_by_overlap(0.5, 3)
                 post_ms, post_tracks = 1e3 * (time.perf_counter() - tp0), len(ts)
                 del ts
+                T_last = T  # kept for the cpu_parity comparison below
             del T
         out["e2e_wall_ms"] = 1e3 * float(np.median(e2e))
         out["e2e_breakdown_ms"] = dict(e2e_parts, **{k: tm[k] for k in ("upload", "run", "download", "tail")})
@@ -378,8 +417,20 @@ def main():
             }
             if n_s == len(scene.img_ids):
                 out["e2e_speedup_vs_cpu"] = cpu_s / (out["e2e_wall_ms"] * 1e-3)
-                out["cpu_parity"] = {"tracks_cpu": so["tracks"], "tracks_gpu": st_after["tracks"],
-                                     "candidates_cpu": so["candidates"], "candidates_gpu": st["candidates"]}
+            # stage-by-stage comparison of the product's results with the oracle's on the SAME job (the oracle
+            # just ran it): arg-max per node, valid-edge sets, track memberships, endpoints (north_star bars)
+            if n_s != len(scene.img_ids):  # bounded sample: run the product on the same image subset
+                T_last = tri.GlobalLineTriangulator(cfg, device=local_rank)
+                T_last.SetRanges(scene.ranges)
+                T_last.InitArrays(scene.img_ids, scene.kvec, scene.qvec, scene.tvec, segs_list)
+                for i in scene.img_ids[:n_s]:
+                    if args.mode == "matched":
+                        T_last.TriangulateImage(int(i), matches[int(i)])
+                    else:
+                        T_last.TriangulateImageExhaustiveMatch(int(i), scene.neighbors[int(i)])
+                T_last.ComputeLineTracks()
+            parity_ok, out["cpu_parity"] = cpu_parity(T_last, O)
+            out["cpu_parity"]["images"] = n_s
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -393,6 +444,9 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+        if not parity_ok:
+            sys.stderr.write("bench.py: product and CPU oracle DISAGREE: %s\n" % json.dumps(out.get("cpu_parity")))
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -48,7 +48,9 @@ typedef struct lt_config {
   double fullscore_th;
   int32_t max_valid_conns;
   int32_t min_num_outer_edges;
-  int32_t merging_strategy; /* 0 = "greedy"; others -> LT_ERR_RUNTIME like the reference's throw */
+  int32_t merging_strategy; /* 0 "greedy", 1 "exhaustive", 2 "avg" (merging/merging.cc:18-368); any other
+                               value -> LT_ERR_RUNTIME from lt_compute_tracks, where the reference throws
+                               (global_line_triangulator.cc:314-316) */
   int32_t num_outliers_aggregator;
   double l2_score_th, l2_th_angle, l2_th_overlap, l2_th_smartoverlap, l2_th_smartangle,
       l2_th_perp, l2_th_innerseg;

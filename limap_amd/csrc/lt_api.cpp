@@ -1692,7 +1692,7 @@ int lt_compute_tracks(lt_ctx *ctx) {
   int rc = lt_flush(ctx);
   if (rc) return rc;
   if (ctx->inited) define_best_of_other_images(ctx);
-  if (ctx->cfg.merging_strategy != 0)  // global_line_triangulator.cc:314-316
+  if (ctx->cfg.merging_strategy < 0 || ctx->cfg.merging_strategy > 2)  // global_line_triangulator.cc:314-316
     return fail(ctx, LT_ERR_RUNTIME, "Error!The given merging strategy is not implemented");
   double t0 = now_ms();
   static const bool tail_trace = getenv("LT_TAIL_TRACE") != nullptr;  // developer: stage times to stderr
@@ -1840,15 +1840,69 @@ int lt_compute_tracks(lt_ctx *ctx) {
     img_cnt[dst] = c;
     img_cnt[src] = 0;
   };
+  // merging strategies (global_line_triangulator.cc:306-316): greedy unions every edge; "exhaustive" and "avg"
+  // first test the two unions with LineLinker3d::check_connection in avgtest mode (line_linker.h:131-137)
+  const int strategy = ctx->cfg.merging_strategy;
+  LinkCfg3 lavg = make_l3(ctx->cfg);
+  lavg.use_angle = 1; lavg.use_overlap = 0; lavg.use_perp = 1; lavg.use_innerseg = 0; lavg.use_scaleinv = 0;
+  struct UL {  // a line of a union: endpoints + uncertainty (depths are not read in avgtest mode)
+    L3 l;
+    double unc;
+  };
+  auto node_line = [&](int i) {
+    const Cand &c = ctx->best_c[gnode[(size_t)i]];
+    return UL{L3{mk3(c.s[0], c.s[1], c.s[2]), mk3(c.e[0], c.e[1], c.e[2])}, c.unc};
+  };
+  std::vector<std::vector<UL>> lines_in_track;  // exhaustive: merging.cc:130, members in insertion order
+  std::vector<UL> avg_line;                     // avg: merging.cc:271 (+ the member count)
+  std::vector<int> avg_cnt;
+  if (strategy == 1) {
+    lines_in_track.resize((size_t)n_nodes);
+    for (int i = 0; i < n_nodes; ++i) lines_in_track[(size_t)i].push_back(node_line(i));
+  } else if (strategy == 2) {
+    avg_line.resize((size_t)n_nodes);
+    avg_cnt.assign((size_t)n_nodes, 1);
+    for (int i = 0; i < n_nodes; ++i) avg_line[(size_t)i] = node_line(i);
+  }
+  const double nodepth[2] = {0.0, 0.0};
   for (int oi : order) {
     int r1 = uf_root(e1[oi], parent), r2 = uf_root(e2[oi], parent);
     if (r1 == r2) continue;
-    if (img_cnt[r1] < img_cnt[r2]) {
-      parent[r1] = r2;
-      absorb(r2, r1);
-    } else {
-      parent[r2] = r1;
-      absorb(r1, r2);
+    if (strategy == 1) {  // merging.cc:150-168: every overlapping pair of the two unions must connect
+      bool ok = true;
+      for (const UL &a : lines_in_track[(size_t)r1]) {
+        for (const UL &b : lines_in_track[(size_t)r2]) {
+          if (overlap_oneway(a.l, b.l) <= 0) continue;
+          if (!check3d(lavg, a.l, b.l, a.unc, b.unc, nodepth)) {
+            ok = false;
+            break;
+          }
+        }
+        if (!ok) break;
+      }
+      if (!ok) continue;
+    } else if (strategy == 2) {  // merging.cc:289-292: the running averages must connect
+      const UL &a = avg_line[(size_t)r1], &b = avg_line[(size_t)r2];
+      if (!check3d(lavg, a.l, b.l, a.unc, b.unc, nodepth)) continue;
+    }
+    int dst = r1, src = r2;
+    if (img_cnt[r1] < img_cnt[r2]) { dst = r2; src = r1; }
+    parent[src] = dst;
+    absorb(dst, src);
+    if (strategy == 1) {
+      auto &d = lines_in_track[(size_t)dst];
+      auto &sv = lines_in_track[(size_t)src];
+      d.insert(d.end(), sv.begin(), sv.end());
+      std::vector<UL>().swap(sv);
+    } else if (strategy == 2) {  // merging.cc:300-307: count-weighted mean; the new Line3d has uncertainty -1
+      const UL d1 = avg_line[(size_t)dst], d2 = avg_line[(size_t)src];
+      const double n1 = (double)avg_cnt[(size_t)dst], n2 = (double)avg_cnt[(size_t)src];
+      const double ns = (double)(avg_cnt[(size_t)dst] + avg_cnt[(size_t)src]);
+      auto wmean = [&](d3 p, d3 q) {
+        return mk3((p.x * n1 + q.x * n2) / ns, (p.y * n1 + q.y * n2) / ns, (p.z * n1 + q.z * n2) / ns);
+      };
+      avg_line[(size_t)dst] = UL{L3{wmean(d1.l.s, d2.l.s), wmean(d1.l.e, d2.l.e)}, -1.0};
+      avg_cnt[(size_t)dst] += avg_cnt[(size_t)src];
     }
   }
   // NOTE: the reference's recursive root lookup compresses paths as a side effect and reads

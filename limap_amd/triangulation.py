@@ -78,8 +78,15 @@ class _LazyLineTrack(LineTrack):
         off = self._t["off"]
         return slice(int(off[self._n]), int(off[self._n + 1]))
 
+    _LAZY = ("line", "image_id_list", "line_id_list", "node_id_list", "score_list", "line2d_list", "line3d_list")
+
     def __getattr__(self, name):  # only reached while the field has not been built yet
-        t = self._t
+        # copy / pickle probe attributes on instances whose __dict__ is still empty: never recurse through `_t`
+        if name not in _LazyLineTrack._LAZY:
+            raise AttributeError(name)
+        t = self.__dict__.get("_t")
+        if t is None:
+            raise AttributeError(name)
         if name == "line":
             r = t["line"][self._n]
             v = Line3d(r[0:3], r[3:6], -1.0, -1.0, -1.0, r[6])
@@ -104,6 +111,29 @@ class _LazyLineTrack(LineTrack):
     def count_lines(self):
         s = self._slice()
         return s.stop - s.start
+
+    def materialise(self):
+        """A plain LineTrack with every field built (what copy / pickle hand on; the reference's LineTrack is
+        picklable through its dict form, linetrack.cc:31-74)."""
+        out = LineTrack(self.line, self.image_id_list, self.line_id_list, self.line2d_list)
+        out.node_id_list, out.line3d_list = list(self.node_id_list), list(self.line3d_list)
+        out.score_list, out.active = list(self.score_list), self.active
+        return out
+
+    def __reduce__(self):
+        return (_track_from_state, (self.materialise().__dict__,))
+
+
+def _track_from_state(state):
+    out = LineTrack()
+    out.__dict__.update(state)
+    return out
+
+
+try:  # limap's own value types when limap is installed (resolved once: a failed import is not cached by Python)
+    import limap.base as _limap_base
+except Exception:  # pragma: no cover
+    _limap_base = None
 
 
 try:  # optional CPython helper (limap_amd/csrc/lt_pymarshal.c): same call, ~20 us less Python per image
@@ -189,13 +219,13 @@ def _cam11(view):
 
 
 def _make_line3d(a10):
-    try:  # hand limap's own type back when it is installed
-        import limap.base as _lb  # noqa: F401
-        l = _lb.Line3d(np.asarray(a10[0:3]), np.asarray(a10[3:6]), float(a10[9]), float(a10[6]), float(a10[7]),
-                       float(a10[8]))
-        return l
-    except Exception:
-        return Line3d.from10(a10)
+    if _limap_base is not None:  # hand limap's own type back when it is installed
+        try:
+            return _limap_base.Line3d(np.asarray(a10[0:3]), np.asarray(a10[3:6]), float(a10[9]), float(a10[6]),
+                                      float(a10[7]), float(a10[8]))
+        except Exception:
+            pass
+    return Line3d.from10(a10)
 
 
 class GlobalLineTriangulator:
@@ -438,11 +468,12 @@ class GlobalLineTriangulator:
         # The reference hands back pybind wrappers of C++ LineTracks (no per-member Python objects until they are
         # looked at); building ~35 000 Line2d / Line3d objects eagerly here cost 20x the whole triangulation.
         tracks = [_LazyLineTrack(t, n, self._segs) for n in range(len(t["off"]) - 1)]
-        try:  # convert to limap's LineTrack when limap is installed (linetrack.cc:50-74 dict ctor)
-            import limap.base as _lb
-            return [_lb.LineTrack(tr.as_dict()) for tr in tracks]
-        except Exception:
-            return tracks
+        if _limap_base is not None:  # limap's LineTrack when limap is installed (linetrack.cc:50-74 dict ctor)
+            try:
+                return [_limap_base.LineTrack(tr.as_dict()) for tr in tracks]
+            except Exception:
+                pass
+        return tracks
 
 
 # ---- free functions (bindings.cc:22-31; doc wrappers triangulation.py:1-138 of the reference) ----

@@ -960,6 +960,106 @@ static std::vector<int> ComputeLineTrackLabelsGreedy(const std::vector<int> &nod
   return track_labels;
 }
 
+// Track labels from the parent array as the reference derives them (merging/merging.cc:84-101; the same
+// block closes the exhaustive and avg variants, :222-245 and :345-368).
+static std::vector<int> labels_from_parents(std::vector<int> &parent_nodes) {
+  const size_t n_nodes = parent_nodes.size();
+  std::vector<int> track_labels(n_nodes, -1);
+  int n_tracks = 0;
+  for (size_t i = 0; i < n_nodes; ++i) {
+    if (parent_nodes[i] == -1) continue;
+    int p = parent_nodes[i];
+    if (parent_nodes[p] == -1 && track_labels[p] == -1) track_labels[p] = n_tracks++;
+  }
+  for (size_t i = 0; i < n_nodes; ++i) {
+    if (parent_nodes[i] == -1) continue;
+    track_labels[i] = track_labels[union_find_get_root(int(i), parent_nodes)];
+  }
+  return track_labels;
+}
+
+// merging/merging.cc:105-245: a union is accepted only if every pair of lines of the two unions that
+// overlap (one-way overlap of it1 on it2 > 0) passes check_connection in avgtest mode.
+static std::vector<int> ComputeLineTrackLabelsExhaustive(const std::vector<int> &node_img,
+                                                         std::vector<std::tuple<double, int, int>> edges,
+                                                         const std::vector<Line3d> &line3d_list_nodes,
+                                                         Linker3d linker3d) {
+  linker3d.config.set_to_avgtest_merging();
+  const size_t n_nodes = node_img.size();
+  std::sort(edges.begin(), edges.end());
+  std::reverse(edges.begin(), edges.end());
+  std::vector<int> parent_nodes(n_nodes, -1);
+  std::vector<std::set<int>> images_in_track(n_nodes);
+  std::vector<std::vector<Line3d>> lines_in_track(n_nodes);
+  for (size_t i = 0; i < n_nodes; ++i) {
+    images_in_track[i].insert(node_img[i]);
+    lines_in_track[i].push_back(line3d_list_nodes[i]);
+  }
+  for (const auto &e : edges) {
+    int root1 = union_find_get_root(std::get<1>(e), parent_nodes);
+    int root2 = union_find_get_root(std::get<2>(e), parent_nodes);
+    if (root1 == root2) continue;
+    bool flag = true;
+    for (const Line3d &a : lines_in_track[root1]) {
+      for (const Line3d &b : lines_in_track[root2]) {
+        if (compute_overlap(a, b) <= 0) continue;
+        if (!linker3d.check_connection(a, b)) {
+          flag = false;
+          break;
+        }
+      }
+      if (!flag) break;
+    }
+    if (!flag) continue;
+    int dst = root1, src = root2;
+    if (images_in_track[root1].size() < images_in_track[root2].size()) std::swap(dst, src);
+    parent_nodes[src] = dst;
+    images_in_track[dst].insert(images_in_track[src].begin(), images_in_track[src].end());
+    images_in_track[src].clear();
+    lines_in_track[dst].insert(lines_in_track[dst].end(), lines_in_track[src].begin(), lines_in_track[src].end());
+    lines_in_track[src].clear();
+  }
+  return labels_from_parents(parent_nodes);
+}
+
+// merging/merging.cc:247-368: a union is accepted if the running AVERAGE lines of the two unions pass
+// check_connection in avgtest mode.  The averaged line is a default-constructed Line3d with only start/end
+// set (:300-307, :323-330): uncertainty -1, which enters the perpendicular score through min(u1, u2).
+static std::vector<int> ComputeLineTrackLabelsAvg(const std::vector<int> &node_img,
+                                                  std::vector<std::tuple<double, int, int>> edges,
+                                                  const std::vector<Line3d> &line3d_list_nodes, Linker3d linker3d) {
+  linker3d.config.set_to_avgtest_merging();
+  const size_t n_nodes = node_img.size();
+  std::sort(edges.begin(), edges.end());
+  std::reverse(edges.begin(), edges.end());
+  std::vector<int> parent_nodes(n_nodes, -1);
+  std::vector<std::set<int>> images_in_track(n_nodes);
+  std::vector<std::pair<Line3d, int>> avgline_in_track(n_nodes);
+  for (size_t i = 0; i < n_nodes; ++i) {
+    images_in_track[i].insert(node_img[i]);
+    avgline_in_track[i] = {line3d_list_nodes[i], 1};
+  }
+  for (const auto &e : edges) {
+    int root1 = union_find_get_root(std::get<1>(e), parent_nodes);
+    int root2 = union_find_get_root(std::get<2>(e), parent_nodes);
+    if (root1 == root2) continue;
+    if (!linker3d.check_connection(avgline_in_track[root1].first, avgline_in_track[root2].first)) continue;
+    int dst = root1, src = root2;
+    if (images_in_track[root1].size() < images_in_track[root2].size()) std::swap(dst, src);
+    parent_nodes[src] = dst;
+    images_in_track[dst].insert(images_in_track[src].begin(), images_in_track[src].end());
+    images_in_track[src].clear();
+    auto d1 = avgline_in_track[dst];
+    auto d2 = avgline_in_track[src];
+    Line3d newline;
+    double n1 = d1.second, n2 = d2.second, nsum = d1.second + d2.second;
+    newline.start = (d1.first.start * n1 + d2.first.start * n2) / nsum;
+    newline.end = (d1.first.end * n1 + d2.first.end * n2) / nsum;
+    avgline_in_track[dst] = {newline, d1.second + d2.second};
+  }
+  return labels_from_parents(parent_nodes);
+}
+
 // Principal right-singular vector of an n x 3 matrix by one-sided (Hestenes) Jacobi.
 // Stands in for Eigen::JacobiSVD(ComputeThinV).matrixV().col(0) (aggregator.cc:76-78); the sign
 // of a singular vector is not defined by the SVD, so it is fixed here by a deterministic rule
@@ -1691,11 +1791,23 @@ void Triangulator::run_clustering(Graph &graph) {  // global_line_triangulator.c
 }
 
 void Triangulator::build_tracks_from_clusters(Graph &graph) {  // global_line_triangulator.cc:293-351
-  if (cfg.merging_strategy != 0)
-    throw std::runtime_error("Error!The given merging strategy is not implemented");
+  Linker3d lk3 = this->linker3d;  // :295-296 (the merging variants switch it to avgtest mode themselves too)
+  lk3.config.set_to_avgtest_merging();
   std::vector<int> node_img;
-  for (auto &n : graph.nodes) node_img.push_back(n.first);
-  std::vector<int> track_labels = ComputeLineTrackLabelsGreedy(node_img, graph.edges);
+  std::vector<Line3d> lines_nodes;  // :299-304
+  for (auto &n : graph.nodes) {
+    node_img.push_back(n.first);
+    lines_nodes.push_back(tris_best_[n.first][n.second].line);
+  }
+  std::vector<int> track_labels;
+  if (cfg.merging_strategy == 0)
+    track_labels = ComputeLineTrackLabelsGreedy(node_img, graph.edges);
+  else if (cfg.merging_strategy == 1)
+    track_labels = ComputeLineTrackLabelsExhaustive(node_img, graph.edges, lines_nodes, lk3);
+  else if (cfg.merging_strategy == 2)
+    track_labels = ComputeLineTrackLabelsAvg(node_img, graph.edges, lines_nodes, lk3);
+  else
+    throw std::runtime_error("Error!The given merging strategy is not implemented");
   if (track_labels.empty()) return;
   int n_tracks = *std::max_element(track_labels.begin(), track_labels.end()) + 1;
   tracks_.clear();

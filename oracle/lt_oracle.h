@@ -44,7 +44,7 @@ typedef struct ora_config {
   double fullscore_th;
   int32_t max_valid_conns;
   int32_t min_num_outer_edges;
-  int32_t merging_strategy;             /* 0 = "greedy" (only one restated) */
+  int32_t merging_strategy;             /* 0 greedy, 1 exhaustive, 2 avg (merging/merging.cc:18-368) */
   int32_t num_outliers_aggregator;
   /* linker 2d */
   double l2_score_th, l2_th_angle, l2_th_overlap, l2_th_smartoverlap, l2_th_smartangle,

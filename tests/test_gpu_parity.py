@@ -238,3 +238,19 @@ def test_config_variants_match_oracle(gpu_lib, oracle, variant, exhaustive):
     st, so = T.stats(), O.stats()
     for k in ("connections", "candidates", "valid_edges", "graph_nodes", "graph_edges", "tracks"):
         assert st[k] == so[k], k
+
+
+@pytest.mark.parametrize("strategy", ["exhaustive", "avg"])
+def test_merging_strategies_match_oracle(gpu_lib, oracle, strategy):
+    """merging_strategy "exhaustive" / "avg" (global_line_triangulator.cc:306-316; merging/merging.cc:105-368):
+    unions gated by LineLinker3d::check_connection in avgtest mode.  Same tracks as the oracle, and the gate
+    actually bites on this scene (the tracks differ from the greedy strategy's)."""
+    sc = small_scene(seed=5, n_views=20, n_segs=150, n_neighbors=8)
+    cfg = syn.default_triangulation_cfg(merging_strategy=strategy)
+    T = run_product(sc, cfg)
+    O = run_oracle(oracle, sc, cfg)
+    T.ComputeLineTracks()
+    compare_tracks(T.context().get_tracks(), O.ComputeLineTracks())
+    G = run_oracle(oracle, sc, syn.default_triangulation_cfg())
+    G.ComputeLineTracks()
+    assert not np.array_equal(O.get_tracks()["off"], G.get_tracks()["off"])

@@ -134,3 +134,30 @@ def test_lazy_line_tracks_materialise_on_access():
     assert d["image_id_list"] == [10, 12, 13] and len(d["line2d_list"]) == 3 and d["active"] is True
     with pytest.raises(AttributeError):
         tr[0].no_such_field
+
+
+def test_lazy_line_tracks_copy_and_pickle():
+    """copy / deepcopy / pickle of the tracks ComputeLineTracks() returns (the reference's LineTrack
+    is copyable and picklable) -- no recursion through __getattr__, fields preserved."""
+    import copy
+    import pickle
+    from limap_amd import triangulation as tri
+    from limap_amd.base import LineTrack
+    t = dict(off=np.array([0, 2, 5], np.int64),
+             line=np.array([[0, 0, 0, 1, 1, 1, 0.5], [1, 2, 3, 4, 5, 6, 0.25]], float),
+             image_ids=np.array([10, 11, 10, 12, 13], np.int32), line_ids=np.array([0, 1, 1, 0, 0], np.int32),
+             node_ids=np.array([0, 1, 2, 3, 4], np.int32), scores=np.array([1.0, 2.0, 3.0, 4.0, 5.0]),
+             line3d=np.arange(30, dtype=float).reshape(5, 6))
+    segs = {i: np.arange(8, dtype=float).reshape(2, 4) + i for i in (10, 11, 12, 13)}
+    tr = tri._LazyLineTrack(t, 1, segs)
+    for clone in (copy.copy(tr), copy.deepcopy(tr), pickle.loads(pickle.dumps(tr))):
+        assert isinstance(clone, LineTrack)
+        assert clone.image_id_list == [10, 12, 13] and clone.line_id_list == [1, 0, 0]
+        assert clone.node_id_list == [2, 3, 4] and clone.score_list == [3.0, 4.0, 5.0] and clone.active is True
+        assert np.array_equal(clone.line.end, [4, 5, 6]) and clone.count_lines() == 3
+        assert np.array_equal(clone.line3d_list[2].start, t["line3d"][4, 0:3])
+    arr = np.empty(1, object); arr[0] = tr
+    assert pickle.loads(pickle.dumps(arr))[0].count_images() == 3   # what np.save(allow_pickle) does
+    empty = tri._LazyLineTrack.__new__(tri._LazyLineTrack)            # an instance with an empty __dict__
+    with pytest.raises(AttributeError):
+        empty.line
