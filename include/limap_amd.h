@@ -173,6 +173,10 @@ int lt_get_num_tris(lt_ctx *ctx, int32_t *out_n_tris);
 /* valid_edges_ (global_line_triangulator.cc:138-142) as CSR: (neighbour index, ng_line_id) */
 int64_t lt_num_valid_edges(lt_ctx *ctx);
 int lt_get_valid_edges(lt_ctx *ctx, int64_t *out_off, int32_t *out_edges2);
+/* valid_flags_ (filterNodeByNumOuterEdges, global_line_triangulator.cc:168-232): 1 for nodes that keep at
+ * least min_num_outer_edges valid edges to surviving nodes.  The reference fills it inside run_clustering
+ * (:236), so this needs lt_compute_tracks first (LT_ERR_STATE otherwise); GetAllValidBestTris (:502-514). */
+int lt_get_valid_flags(lt_ctx *ctx, uint8_t *out_flags);
 /* All scored candidates of the last device run (GetScoredTrisNode; kept regardless of
  * debug_mode until the next run): CSR off[n_nodes+1], line10, score, src2. */
 int64_t lt_num_all_tris(lt_ctx *ctx);

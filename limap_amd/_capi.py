@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "lt_refresh_scene_chunks", "lt_triangulate_image", "lt_triangulate_image_rows",
     "lt_triangulate_image_exhaustive", "lt_upload", "lt_run_device", "lt_download", "lt_flush",
     "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
-    "lt_get_num_tris", "lt_num_valid_edges", "lt_get_valid_edges", "lt_num_all_tris", "lt_get_all_tris",
+    "lt_get_num_tris", "lt_get_valid_flags", "lt_num_valid_edges", "lt_get_valid_edges", "lt_num_all_tris", "lt_get_all_tris",
     "lt_num_tracks", "lt_num_track_members", "lt_get_tracks", "lt_image_results_size",
     "lt_export_image_results", "lt_import_image_results", "lt_ts_from_ctx", "lt_ts_create", "lt_ts_destroy",
     "lt_ts_num_tracks", "lt_ts_num_members", "lt_ts_get", "lt_ts_filter_by_reprojection",
@@ -143,6 +143,7 @@ def load_library():
     L.lt_get_best.argtypes = [vp, dp, dp, i32p, u8p]
     L.lt_get_num_tris.argtypes = [vp, i32p]
     L.lt_get_valid_edges.argtypes = [vp, i64p, i32p]
+    L.lt_get_valid_flags.argtypes = [vp, u8p]
     L.lt_get_all_tris.argtypes = [vp, i64p, dp, dp, i32p]
     L.lt_get_tracks.argtypes = [vp, dp, i64p, i32p, i32p, i32p, dp, dp]
     L.lt_image_results_size.argtypes = [vp, C.c_int, i64p]
@@ -387,6 +388,11 @@ class Context:
         out = np.zeros(self.num_nodes(), np.int32)
         self.chk(self.L.lt_get_num_tris(self.h, ptr(out, C.c_int32)))
         return out
+
+    def get_valid_flags(self):
+        out = np.zeros(self.num_nodes(), np.uint8)
+        self.chk(self.L.lt_get_valid_flags(self.h, ptr(out, C.c_uint8)))
+        return out.astype(bool)
 
     def get_valid_edges(self):
         ne = int(self.L.lt_num_valid_edges(self.h))

@@ -390,6 +390,7 @@ int init_common(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *s
   ctx->n_tris.assign(ctx->G, 0);
   ctx->has_best.assign(ctx->G, 0);
   ctx->valid_edges.reset(ctx->G);
+  ctx->dbg_pool.clear(); ctx->dbg_off.assign((size_t)ctx->G, 0); ctx->dbg_cnt.assign((size_t)ctx->G, 0);
   ctx->vp_ready = false;
   ctx->pts_ready = false; ctx->sfm_given = false; ctx->pts_dirty = false;
   ctx->h_seg_pts.clear(); ctx->h_seg_pt_off.clear(); ctx->h_sfm_ids.clear(); ctx->h_sfm_xyz.clear();
@@ -1667,6 +1668,31 @@ int lt_download(lt_ctx *ctx) {
   }
   define_best_of_other_images(ctx);
   ctx->stat_pairs = pairs;
+  if (ctx->cfg.debug_mode && ctx->C > 0) {  // keep this batch's tris_ on the host (later batches reuse the device arrays)
+    const long long C = ctx->C;
+    std::vector<Cand> c((size_t)C);
+    std::vector<CandLite> l((size_t)C);
+    std::vector<double> sc((size_t)C);
+    HIPCHK(ctx, hipMemcpy(c.data(), ctx->d_cand.p, sizeof(Cand) * (size_t)C, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(l.data(), ctx->d_lite.p, sizeof(CandLite) * (size_t)C, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(sc.data(), ctx->d_score.p, 8 * (size_t)C, hipMemcpyDeviceToHost));
+    for (long long j = 0; j < n_job; ++j) {
+      const int idx = ctx->job_imgs[(size_t)j];
+      for (long long g = ctx->seg_off[idx]; g < ctx->seg_off[idx + 1]; ++g) {
+        ctx->dbg_off[(size_t)g] = (long long)ctx->dbg_pool.size();
+        ctx->dbg_cnt[(size_t)g] = (int)(tri_off[g + 1] - tri_off[g]);
+        for (long long t = tri_off[g]; t < tri_off[g + 1]; ++t) {
+          lt_ctx::DebugTri r;
+          for (int k = 0; k < 3; ++k) { r.line10[k] = c[t].s[k]; r.line10[3 + k] = c[t].e[k]; }
+          r.line10[6] = c[t].depth[0]; r.line10[7] = c[t].depth[1]; r.line10[8] = c[t].unc; r.line10[9] = c[t].score3;
+          r.score = sc[t];
+          r.src2[0] = ctx->img_ids[lite_img(l[t])];
+          r.src2[1] = l[t].ng_line;
+          ctx->dbg_pool.push_back(r);
+        }
+      }
+    }
+  }
   ctx->downloaded = true;
   ctx->timers[9] = now_ms() - t0;
   return LT_OK;
@@ -1735,6 +1761,7 @@ int lt_compute_tracks(lt_ctx *ctx) {
       }
     }
   }
+  ctx->valid_flags.assign(flags.begin(), flags.end());
   lap("filter nodes");
   // undirected edge set, ordered like std::set<pair<LineNode, LineNode>> (:243-261): the global
   // node index is monotone in (img_id, line_id)
@@ -1992,6 +2019,14 @@ int lt_get_num_tris(lt_ctx *ctx, int32_t *out) {
   return LT_OK;
 }
 
+// valid_flags_ (global_line_triangulator.cc:168-232, filled by run_clustering :236): needs lt_compute_tracks
+int lt_get_valid_flags(lt_ctx *ctx, uint8_t *out_flags) {
+  if (!ctx->tracks_done || (long long)ctx->valid_flags.size() != ctx->G)
+    return fail(ctx, LT_ERR_STATE, "valid flags are filled by ComputeLineTracks (run_clustering)");
+  std::memcpy(out_flags, ctx->valid_flags.data(), (size_t)ctx->G);
+  return LT_OK;
+}
+
 int64_t lt_num_valid_edges(lt_ctx *ctx) {
   if (lt_flush(ctx)) return -1;
   int64_t n = 0;
@@ -2015,6 +2050,11 @@ int lt_get_valid_edges(lt_ctx *ctx, int64_t *out_off, int32_t *out_edges2) {
 
 int64_t lt_num_all_tris(lt_ctx *ctx) {
   if (lt_flush(ctx)) return -1;
+  if (ctx->cfg.debug_mode) {  // every batch since Init
+    int64_t n = 0;
+    for (int c : ctx->dbg_cnt) n += c;
+    return n;
+  }
   return ctx->C;
 }
 
@@ -2022,6 +2062,21 @@ int lt_get_all_tris(lt_ctx *ctx, int64_t *out_off, double *out_line10, double *o
   LT_FINISH(ctx);
   int rc = lt_flush(ctx);
   if (rc) return rc;
+  if (ctx->cfg.debug_mode) {  // host store: the candidates of every batch since Init
+    int64_t t = 0;
+    out_off[0] = 0;
+    for (long long g = 0; g < ctx->G; ++g) {
+      const lt_ctx::DebugTri *r = ctx->dbg_pool.data() + ctx->dbg_off[(size_t)g];
+      for (int k = 0; k < ctx->dbg_cnt[(size_t)g]; ++k, ++t) {
+        std::memcpy(out_line10 + 10 * t, r[k].line10, 80);
+        out_score[t] = r[k].score;
+        out_src2[2 * t] = r[k].src2[0];
+        out_src2[2 * t + 1] = r[k].src2[1];
+      }
+      out_off[g + 1] = t;
+    }
+    return LT_OK;
+  }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const long long G = ctx->G, C = ctx->C;
   std::vector<long long> tri_off(G + 1);

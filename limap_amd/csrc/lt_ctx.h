@@ -221,8 +221,18 @@ struct lt_ctx {
   std::vector<int> best_src2, n_tris;
   std::vector<unsigned char> has_best;
   lt_host::EdgeStore valid_edges;  // per node: flat (slot, ng_line) pairs
+  // debug_mode: tris_ of EVERY batch (the reference keeps tris_ for all images, global_line_triangulator.cc:156-159);
+  // records appended at download time, per node a range of the pool
+  struct DebugTri {
+    double line10[10], score;
+    int src2[2];
+  };
+  std::vector<DebugTri> dbg_pool;
+  std::vector<long long> dbg_off;
+  std::vector<int> dbg_cnt;
   // ---- tail ----
   std::vector<Track> tracks;
+  std::vector<unsigned char> valid_flags;  // valid_flags_ of run_clustering (filterNodeByNumOuterEdges), per node
   bool tracks_done = false;
   long long stat_graph_nodes = 0, stat_graph_edges = 0, stat_pairs = 0;
   double timers[24] = {0};

@@ -182,7 +182,7 @@ int lt_ts_filter_by_sensitivity(lt_ctx *ctx, lt_trackset *ts, double th_angular3
   const long long nT = (long long)ts->tracks.size();
   std::vector<char> keep((size_t)nT, 0);
   int bad = 0;
-#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 8)
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 8) reduction(| : bad)
   for (long long ti = 0; ti < nT; ++ti) {
     const TrackFull &t = ts->tracks[ti];
     d3 s = mk3(t.line[0], t.line[1], t.line[2]), e = mk3(t.line[3], t.line[4], t.line[5]);
@@ -216,7 +216,7 @@ int lt_ts_filter_by_overlap(lt_ctx *ctx, lt_trackset *ts, double th_overlap, int
   const long long nT = (long long)ts->tracks.size();
   std::vector<char> keep((size_t)nT, 0);
   int bad = 0;
-#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 8)
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 8) reduction(| : bad)
   for (long long ti = 0; ti < nT; ++ti) {
     const TrackFull &t = ts->tracks[ti];
     std::set<int> imgs;

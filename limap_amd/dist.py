@@ -132,31 +132,82 @@ class SceneGather:
         return self.kvec, self.qvec, self.tvec, self.segs
 
 
-def merge_shards_on_rank0(ctx, my_imgs, rank, world):
-    """After every rank has triangulated its shard: ship the per-image results to rank 0 (one object
-    collective) and import them into rank 0's context, which can then run `compute_tracks()` for the
-    whole scene.  Returns the number of images imported (0 on the other ranks)."""
+def pack_image_results(results):
+    """Per-image result dicts (`Context.export_image_results`) -> (int32 blob, float64 blob).
+    int32: n_images, then per image  img_id, n_nb, m, ne, nb_ids[n_nb], src[m,2], n_tris[m], edge_cnt[m], edges[ne,2];
+    float64: per image  line[m,10], score[m]  (104 B best candidate + score per node, 4 B per valid edge ...)."""
+    ints, flts = [np.array([len(results)], np.int32)], []
+    for r in results:
+        nb = np.asarray(r["nb_ids"], np.int32).reshape(-1)
+        m = len(r["score"])
+        eoff = np.asarray(r["edge_off"], np.int64).reshape(-1)
+        edges = np.asarray(r["edges"], np.int32).reshape(-1, 2)
+        ints += [np.array([r["img_id"], len(nb), m, len(edges)], np.int32), nb,
+                 np.asarray(r["src"], np.int32).reshape(-1), np.asarray(r["n_tris"], np.int32).reshape(-1),
+                 np.diff(eoff).astype(np.int32), edges.reshape(-1)]
+        flts += [np.asarray(r["line"], np.float64).reshape(-1), np.asarray(r["score"], np.float64).reshape(-1)]
+    return np.concatenate(ints), (np.concatenate(flts) if flts else np.zeros(0))
+
+
+def unpack_image_results(ints, flts):
+    """Inverse of pack_image_results."""
+    ints, flts = np.asarray(ints, np.int32), np.asarray(flts, np.float64)
+    n, ip, fp, out = int(ints[0]), 1, 0, []
+    for _ in range(n):
+        img_id, n_nb, m, ne = (int(x) for x in ints[ip:ip + 4]); ip += 4
+        nb = ints[ip:ip + n_nb].copy(); ip += n_nb
+        src = ints[ip:ip + 2 * m].reshape(m, 2).copy(); ip += 2 * m
+        nt = ints[ip:ip + m].copy(); ip += m
+        eoff = np.zeros(m + 1, np.int64); eoff[1:] = np.cumsum(ints[ip:ip + m]); ip += m
+        edges = ints[ip:ip + 2 * ne].reshape(ne, 2).copy(); ip += 2 * ne
+        line = flts[fp:fp + 10 * m].reshape(m, 10).copy(); fp += 10 * m
+        score = flts[fp:fp + m].copy(); fp += m
+        out.append(dict(img_id=img_id, nb_ids=nb, line=line, score=score, src=src, n_tris=nt, edge_off=eoff, edges=edges))
+    return out
+
+
+def gather_packed_to_rank0(ints, flts, rank, world, device):
+    """The second, small collective of SURVEY 8(e): every rank's packed per-node results to rank 0 ONLY
+    (`gather`, padded to the largest shard; the sizes travel first in one tiny all-gather).  Returns the list
+    of (ints, flts) per rank on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    sizes = torch.tensor([len(ints), len(flts)], dtype=torch.int64, device=device)
+    all_sizes = torch.zeros((world, 2), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(all_sizes.view(-1), sizes)
+    all_sizes = all_sizes.cpu().numpy()
+    mi, mf = int(all_sizes[:, 0].max()), max(int(all_sizes[:, 1].max()), 1)
+    ti = torch.zeros(mi, dtype=torch.int32, device=device)
+    ti[:len(ints)].copy_(torch.from_numpy(np.ascontiguousarray(ints, np.int32)))
+    tf = torch.zeros(mf, dtype=torch.float64, device=device)
+    if len(flts):
+        tf[:len(flts)].copy_(torch.from_numpy(np.ascontiguousarray(flts, np.float64)))
+    gi = [torch.zeros_like(ti) for _ in range(world)] if rank == 0 else None
+    gf = [torch.zeros_like(tf) for _ in range(world)] if rank == 0 else None
+    dist.gather(ti, gi, dst=0)
+    dist.gather(tf, gf, dst=0)
+    if rank != 0:
+        return None
+    return [(gi[r][:int(all_sizes[r, 0])].cpu().numpy(), gf[r][:int(all_sizes[r, 1])].cpu().numpy()) for r in range(world)]
+
+
+def merge_shards_on_rank0(ctx, my_imgs, rank, world, device=None):
+    """After every rank has triangulated its shard: ship the packed per-image results (best candidate + score
+    per node, valid edges) to rank 0 with one tensor `gather` -- nothing is sent to the other ranks -- and
+    import them into rank 0's context, which can then run `compute_tracks()` for the whole scene.
+    Returns the number of images imported (0 on the other ranks)."""
     if world == 1:
         return 0
-    import torch.distributed as dist
-    mine = [ctx.export_image_results(int(i)) for i in my_imgs]
-    parts = [None] * world
-    dist.all_gather_object(parts, mine if rank != 0 else [])
+    import torch
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    mine = [ctx.export_image_results(int(i)) for i in my_imgs] if rank != 0 else []
+    ints, flts = pack_image_results(mine)
+    parts = gather_packed_to_rank0(ints, flts, rank, world, device)
     n = 0
     if rank == 0:
         for r in range(1, world):
-            for res in parts[r]:
+            for res in unpack_image_results(*parts[r]):
                 ctx.import_image_results(res)
                 n += 1
     return n
-
-
-def gather_results_to_rank0(ctx_results, rank, world):
-    """Gather per-node results (dict of numpy arrays restricted to this rank's nodes) on rank 0
-    with one object gather; used before the host tail."""
-    if world == 1:
-        return [ctx_results]
-    import torch.distributed as dist
-    out = [None] * world if rank == 0 else None
-    dist.gather_object(ctx_results, out, dst=0)
-    return out

@@ -241,6 +241,7 @@ class GlobalLineTriangulator:
         self._seg_off = None
         self._tracks = []
         self._debug = bool(self._ctx.cfg.debug_mode)
+        self._best_cache = self._all_cache = None
 
     # ---- interfaces (bindings.cc:78-95) ----
     def SetRanges(self, ranges):
@@ -279,6 +280,7 @@ class GlobalLineTriangulator:
         self._seg_off = so
         self._idx = {i: n for n, i in enumerate(self._img_ids)}
         self._tracks = []
+        self._best_cache = self._all_cache = None
 
     def InitVPResults(self, vpresults):
         """vpresults: dict img_id -> limap.vplib.VPResult (or anything with .labels / .vps, a dict with those
@@ -318,6 +320,7 @@ class GlobalLineTriangulator:
 
     def TriangulateImage(self, img_id, matches):
         """matches: dict[int -> ndarray(K,2) int] (the content of matches_{img_id}.npy)."""
+        self._best_cache = self._all_cache = None
         if _fast is not None and type(matches) is dict:
             # C-contiguous int32 (K,2) arrays (what matchers write) go straight through the buffer protocol
             rc = _fast.triangulate_image_rows(self._ctx.rows_fn_addr, self._ctx.h.value, int(img_id), matches)
@@ -336,6 +339,7 @@ class GlobalLineTriangulator:
         self._ctx.triangulate_image_rows(img_id, nb, rows)
 
     def TriangulateImageExhaustiveMatch(self, img_id, neighbors):
+        self._best_cache = self._all_cache = None
         self._ctx.triangulate_image_exhaustive(img_id, [int(x) for x in neighbors])
 
     def ComputeLineTracks(self):
@@ -362,7 +366,14 @@ class GlobalLineTriangulator:
         return int(self._seg_off[self._idx[int(img_id)]] + int(line_id))
 
     def _best(self):
-        return self._ctx.get_best()
+        if self._best_cache is None:
+            self._best_cache = self._ctx.get_best()
+        return self._best_cache
+
+    def _all_tris(self):
+        if self._all_cache is None:  # one read-out of tris_ serves the per-node getters until the next batch
+            self._all_cache = self._ctx.get_all_tris()
+        return self._all_cache
 
     def GetAllBestTris(self):
         b = self._best()
@@ -393,7 +404,7 @@ class GlobalLineTriangulator:
     def GetScoredTrisNode(self, img_id, line_id):
         if not self._debug:  # tris_ is cleared after scoring unless debug_mode (global_line_triangulator.cc:156-159)
             return []
-        a = self._ctx.get_all_tris()
+        a = self._all_tris()
         g = self._node(img_id, line_id)
         return [(_make_line3d(a["line"][t]), float(a["score"][t]), (int(a["src"][t, 0]), int(a["src"][t, 1])))
                 for t in range(a["off"][g], a["off"][g + 1])]
@@ -455,14 +466,10 @@ class GlobalLineTriangulator:
 
     # ---- helpers ----
     def _valid_flags(self):
-        """filterNodeByNumOuterEdges (global_line_triangulator.cc:168-232) on the valid edges."""
-        off, edges = self._ctx.get_valid_edges()
-        G = len(off) - 1
-        flags = np.ones(G, bool)
-        k = int(self._ctx.cfg.min_num_outer_edges)
-        if k <= 0:
-            return flags
-        raise NotImplementedError("GetAllValidBestTris with min_num_outer_edges > 0: use ComputeLineTracks()")
+        """valid_flags_ (filterNodeByNumOuterEdges, global_line_triangulator.cc:168-232).  The reference fills
+        it inside run_clustering, i.e. by ComputeLineTracks(); before that its GetAllValidBestTris indexes an
+        empty vector -- here that is a RuntimeError."""
+        return self._ctx.get_valid_flags()
 
     def _build_tracks(self, t):
         # The reference hands back pybind wrappers of C++ LineTracks (no per-member Python objects until they are

@@ -49,10 +49,30 @@ def _worker(rank, world, port, q):
             o = r * g.max_size
             ok = ok and np.array_equal(g.recv[o:o + 4 * (b_ - a_)].numpy().reshape(-1, 4), sc.kvec[a_:b_])
         mine = ltdist.shard_images(sc.img_ids, rank, world).tolist()
-        parts = ltdist.gather_results_to_rank0({"rank": rank, "imgs": mine}, rank, world)
+        # the tail's gather: packed per-image results travel to rank 0 only, as two tensors
+        rng = np.random.default_rng(10 + rank)
+        fake = []
+        for i in mine:
+            m = int(seg_off[sc.img_ids.tolist().index(i) + 1] - seg_off[sc.img_ids.tolist().index(i)])
+            cnt = rng.integers(0, 4, m)
+            eoff = np.zeros(m + 1, np.int64); eoff[1:] = np.cumsum(cnt)
+            fake.append(dict(img_id=int(i), nb_ids=rng.integers(0, 7, 3).astype(np.int32), line=rng.normal(size=(m, 10)),
+                             score=rng.random(m), src=rng.integers(0, 30, (m, 2)).astype(np.int32),
+                             n_tris=rng.integers(0, 9, m).astype(np.int32), edge_off=eoff,
+                             edges=rng.integers(0, 30, (int(eoff[-1]), 2)).astype(np.int32)))
+        ints, flts = ltdist.pack_image_results(fake)
+        parts = ltdist.gather_packed_to_rank0(ints, flts, rank, world, torch.device("cpu"))
         if rank == 0:
-            allimgs = sorted(sum((p["imgs"] for p in parts), []))
-            ok = ok and allimgs == sc.img_ids.tolist() and [p["rank"] for p in parts] == [0, 1]
+            back = ltdist.unpack_image_results(*parts[0])
+            ok = ok and len(back) == len(fake) and all(
+                a["img_id"] == b["img_id"] and all(np.array_equal(a[k], b[k]) for k in
+                                                   ("nb_ids", "line", "score", "src", "n_tris", "edge_off", "edges"))
+                for a, b in zip(back, fake))
+            other = ltdist.unpack_image_results(*parts[1])
+            allimgs = sorted([r["img_id"] for r in back] + [r["img_id"] for r in other])
+            ok = ok and allimgs == sc.img_ids.tolist()
+        else:
+            ok = ok and parts is None
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -61,7 +81,10 @@ def _worker(rank, world, port, q):
 def test_all_gather_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:  # a port the OS says is free (not derived from the pid: parallel CI runs)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -1,0 +1,178 @@
+"""-m gpu: the visualisation getters of GlobalLineTriangulator (SURVEY a28;
+triangulation/global_line_triangulator.cc:362-558, bindings.cc:100-119) against what the same rules give on
+the ORACLE's debug-mode arrays (tris_ with scores and sources, tris_best_, valid_edges_, tracks_)."""
+import numpy as np
+import pytest
+
+from limap_amd import synthetic as syn
+
+from helpers import run_oracle, run_product, small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _l10(line3d):
+    return np.concatenate([line3d.start, line3d.end, line3d.depths, [line3d.uncertainty, line3d.score]])
+
+
+def _expected_valid(o_all, g, cfg):
+    """valid_tris_ of node g (global_line_triangulator.cc:118-142): sort (score, tri_id) descending, take the
+    first max_valid_conns, keep score >= fullscore_th -- as indices into the node's candidate list."""
+    a, b = int(o_all["off"][g]), int(o_all["off"][g + 1])
+    order = sorted(range(b - a), key=lambda t: (o_all["score"][a + t], t), reverse=True)[:cfg["max_valid_conns"]]
+    return [t for t in order if o_all["score"][a + t] >= cfg["fullscore_th"]]
+
+
+def _expected_flags(off, edges, node_of_edge_target, k):
+    """filterNodeByNumOuterEdges (:168-232) as its fixed point: a node stays while it has >= k valid edges
+    (with multiplicity) to nodes that stay."""
+    G = len(off) - 1
+    flags = np.ones(G, bool)
+    if k <= 0:
+        return flags
+    while True:
+        cnt = np.array([int(flags[node_of_edge_target[off[g]:off[g + 1]]].sum()) for g in range(G)])
+        new = flags & (cnt >= k)
+        if np.array_equal(new, flags):
+            return flags
+        flags = new
+
+
+@pytest.mark.parametrize("min_outer,max_conns", [(0, 1000), (2, 3)])
+def test_getters_match_oracle_arrays(gpu_lib, oracle, min_outer, max_conns):
+    sc = small_scene(seed=6, n_views=14, n_segs=100, n_neighbors=7)
+    cfg = syn.default_triangulation_cfg(debug_mode=True, min_num_outer_edges=min_outer, max_valid_conns=max_conns)
+    T = run_product(sc, cfg)
+    O = run_oracle(oracle, sc, cfg)
+    tracks = T.ComputeLineTracks()
+    ot = O.ComputeLineTracks()
+    o_all, ob = O.get_all_tris(), O.get_best()
+    ooff, oedges = O.get_valid_edges()
+    G = len(ob["score"])
+    seg_off = sc.seg_off
+
+    assert T.CountImages() == sc.n_images and T.CountLines(int(sc.img_ids[3])) == seg_off[4] - seg_off[3]
+    assert T.CountAllTris() == int(o_all["off"][-1])                                   # :362-373
+    # GetAllBestTris / GetBestTrisImage / GetBestTriNode / GetBestScoredTriNode (:496-541)
+    best = T.GetAllBestTris()
+    assert len(best) == G
+    assert np.array_equal(np.stack([_l10(l) for l in best]), ob["line"])
+    i3 = int(sc.img_ids[3])
+    img3 = T.GetBestTrisImage(i3)
+    assert np.array_equal(np.stack([_l10(l) for l in img3]), ob["line"][seg_off[3]:seg_off[4]])
+    g = int(np.flatnonzero(ob["has_best"])[5])
+    idx = int(np.searchsorted(seg_off, g, side="right") - 1)
+    img_id, line_id = int(sc.img_ids[idx]), int(g - seg_off[idx])
+    assert np.array_equal(_l10(T.GetBestTriNode(img_id, line_id)), ob["line"][g])
+    l, s, src = T.GetBestScoredTriNode(img_id, line_id)
+    assert np.array_equal(_l10(l), ob["line"][g]) and src == tuple(ob["src"][g].tolist())
+    assert s == pytest.approx(ob["score"][g], rel=1e-12)
+
+    # per-node candidate getters on the nodes with the most candidates + a few ordinary ones
+    n_t = np.diff(o_all["off"])
+    nodes = list(np.argsort(-n_t)[:12]) + list(np.flatnonzero(n_t > 0)[::97][:12]) + [int(np.flatnonzero(n_t == 0)[0])]
+    n_valid_total = 0
+    for g in nodes:
+        idx = int(np.searchsorted(seg_off, g, side="right") - 1)
+        img_id, line_id = int(sc.img_ids[idx]), int(g - seg_off[idx])
+        a, b = int(o_all["off"][g]), int(o_all["off"][g + 1])
+        tris = T.GetScoredTrisNode(img_id, line_id)                                    # :375-379
+        assert len(tris) == b - a
+        if b > a:
+            assert np.array_equal(np.stack([_l10(t[0]) for t in tris]), o_all["line"][a:b])
+            np.testing.assert_allclose([t[1] for t in tris], o_all["score"][a:b], rtol=1e-12)
+            assert [t[2] for t in tris] == [tuple(x) for x in o_all["src"][a:b].tolist()]
+        exp = _expected_valid(o_all, g, cfg)
+        valid = T.GetValidScoredTrisNode(img_id, line_id)                              # :381-385, order of :124-142
+        assert [t[2] for t in valid] == [tuple(o_all["src"][a + t].tolist()) for t in exp]
+        if exp:
+            assert np.array_equal(np.stack([_l10(t[0]) for t in valid]), o_all["line"][a:b][exp])
+        assert len(exp) == ooff[g + 1] - ooff[g]                                       # one valid edge per valid tri
+        assert [_l10(x).tolist() for x in T.GetValidTrisNode(img_id, line_id)] == [_l10(t[0]).tolist() for t in valid]
+        # ...NodeSet (:387-412, :458-494): per source image the FIRST valid tri with the strictly largest score,
+        # in ascending image id
+        table = {}
+        for pos, t in enumerate(exp):
+            k = int(o_all["src"][a + t, 0])
+            if k not in table or o_all["score"][a + t] > table[k][1]:
+                table[k] = (pos, o_all["score"][a + t])
+        exp_set = [exp[table[k][0]] for k in sorted(table)]
+        vset = T.GetValidScoredTrisNodeSet(img_id, line_id)
+        assert [t[2] for t in vset] == [tuple(o_all["src"][a + t].tolist()) for t in exp_set]
+        assert [_l10(x).tolist() for x in T.GetValidTrisNodeSet(img_id, line_id)] == [_l10(t[0]).tolist() for t in vset]
+    # CountAllValidTris / GetValidTrisImage / GetAllValidTris (:414-456)
+    assert T.CountAllValidTris() == int(ooff[-1])
+    exp_img3 = []
+    for g in range(int(seg_off[3]), int(seg_off[4])):
+        a = int(o_all["off"][g])
+        exp_img3 += [o_all["line"][a + t] for t in _expected_valid(o_all, g, cfg)]
+    got_img3 = T.GetValidTrisImage(i3)
+    assert len(got_img3) == len(exp_img3)
+    if exp_img3:
+        assert np.array_equal(np.stack([_l10(x) for x in got_img3]), np.stack(exp_img3))
+    assert len(T.GetAllValidTris()) == int(ooff[-1])
+
+    # GetAllValidBestTris (:502-514): valid_flags_ of filterNodeByNumOuterEdges
+    nbr = {int(i): sorted(int(k) for k in sc.matches_of(int(i)).keys()) for i in sc.img_ids}  # std::map order
+    id2idx = {int(i): n for n, i in enumerate(sc.img_ids)}
+    img_of_node = np.repeat(np.arange(sc.n_images), np.diff(seg_off))
+    tgt = np.array([seg_off[id2idx[nbr[int(sc.img_ids[img_of_node[g]])][int(e[0])]]] + int(e[1])
+                    for g in range(G) for e in oedges[ooff[g]:ooff[g + 1]]], np.int64).reshape(-1)
+    flags = _expected_flags(ooff, oedges, tgt, min_outer)
+    vb = T.GetAllValidBestTris()
+    assert len(vb) == int(flags.sum())
+    assert np.array_equal(np.stack([_l10(l) for l in vb]), ob["line"][flags])
+    if min_outer > 0:
+        assert 0 < flags.sum() < G
+
+    # GetTracks / GetSurvivedLinesImage (:543-558)
+    assert len(T.GetTracks()) == len(tracks) == len(ot["off"]) - 1
+    for n_vis in (2, 4):
+        exp = []
+        for t in range(len(ot["off"]) - 1):
+            sl = slice(int(ot["off"][t]), int(ot["off"][t + 1]))
+            if len(set(ot["image_ids"][sl].tolist())) < n_vis:
+                continue
+            exp += [int(l) for i, l in zip(ot["image_ids"][sl], ot["line_ids"][sl]) if i == i3]
+        assert T.GetSurvivedLinesImage(i3, n_vis) == exp
+    assert set(T.GetLinker()) == {"linker2d", "linker3d"}
+
+
+def test_getters_without_debug_mode_and_flag_errors(gpu_lib, oracle):
+    """Without debug_mode the reference clears tris_ / valid_tris_ after scoring (:156-159): the candidate
+    getters return nothing; the best-candidate getters still work.  GetAllValidBestTris needs ComputeLineTracks."""
+    sc = small_scene(seed=6, n_views=10, n_segs=60, n_neighbors=5)
+    cfg = syn.default_triangulation_cfg(debug_mode=False, min_num_outer_edges=1)
+    T = run_product(sc, cfg)
+    O = run_oracle(oracle, sc, cfg)
+    with pytest.raises(RuntimeError):
+        T.GetAllValidBestTris()
+    T.ComputeLineTracks()
+    O.ComputeLineTracks()
+    i0 = int(sc.img_ids[0])
+    assert T.CountAllTris() == 0 and T.CountAllValidTris() == 0
+    assert T.GetScoredTrisNode(i0, 0) == [] and T.GetValidScoredTrisNode(i0, 0) == [] and T.GetAllValidTris() == []
+    ob = O.get_best()
+    assert np.array_equal(np.stack([_l10(l) for l in T.GetAllBestTris()]), ob["line"])
+    assert 0 < len(T.GetAllValidBestTris()) <= len(ob["score"])
+
+
+def test_debug_getters_cover_every_batch(gpu_lib, oracle):
+    """with debug_mode the candidates of EVERY batch stay readable (the reference keeps tris_ for all
+    images) even when results are read between TriangulateImage calls."""
+    sc = small_scene(seed=7, n_views=10, n_segs=60, n_neighbors=5)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    from limap_amd import triangulation as tri
+    T = tri.GlobalLineTriangulator(cfg)
+    T.SetRanges(sc.ranges)
+    T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+    for n, i in enumerate(sc.img_ids):
+        T.TriangulateImage(int(i), sc.matches_of(int(i)))
+        if n in (2, 6):
+            T.GetBestTriNode(int(sc.img_ids[0]), 0)  # a read between batches starts a new device job
+    O = run_oracle(oracle, sc, cfg)
+    g_all, o_all = T.context().get_all_tris(), O.get_all_tris()
+    assert np.array_equal(g_all["off"], o_all["off"]) and np.array_equal(g_all["src"], o_all["src"])
+    assert np.array_equal(g_all["line"], o_all["line"])
+    np.testing.assert_allclose(g_all["score"], o_all["score"], rtol=1e-12)
+    assert T.CountAllTris() == int(o_all["off"][-1])
