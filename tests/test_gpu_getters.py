@@ -141,7 +141,7 @@ def test_getters_match_oracle_arrays(gpu_lib, oracle, min_outer, max_conns):
 def test_getters_without_debug_mode_and_flag_errors(gpu_lib, oracle):
     """Without debug_mode the reference clears tris_ / valid_tris_ after scoring (:156-159): the candidate
     getters return nothing; the best-candidate getters still work.  GetAllValidBestTris needs ComputeLineTracks."""
-    sc = small_scene(seed=6, n_views=10, n_segs=60, n_neighbors=5)
+    sc = small_scene(seed=6, n_views=14, n_segs=100, n_neighbors=7)
     cfg = syn.default_triangulation_cfg(debug_mode=False, min_num_outer_edges=1)
     T = run_product(sc, cfg)
     O = run_oracle(oracle, sc, cfg)
