@@ -12,7 +12,13 @@
 //   * Matrix3d::inverse() = cofactor matrix times 1/det, det expanded along column 0;
 //   * A*B*v evaluates (A*B) into a temporary first;  products are plain mul/add, no FMA
 //     (the reference builds for baseline x86-64, no -march flag).
-// PARITY UNPINNED against the real reference binary (cannot be built here).
+// PINNED (round 2) against the reference's own sources: oracle/_ref compiles the unmodified hot-path files of
+// /root/reference/src/limap (oracle/Makefile `ref`) against stand-in Eigen / COLMAP / PoseLib headers
+// (oracle/ref_shim/), and tests/test_oracle_vs_ref.py holds this file to it bit for bit -- candidate lists and
+// order, geometry, scores, arg-max, ordered valid edges, graph sizes, tracks, the post-triangulation chain, free
+// functions, on the golden fixtures and on randomised scenes / configurations in both matching modes.  What stays
+// an assumption is ONLY the list above (Eigen's internal evaluation order, shared by the stand-in headers), the
+// SVD's sign convention, and PoseLib's quartic root finder (one-point proposal: compared with a tolerance).
 //
 // Build: see oracle/Makefile (g++ -O2 -fopenmp -ffp-contract=off).
 

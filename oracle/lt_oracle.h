@@ -6,10 +6,13 @@
  * and src/limap/merging it calls).  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load it.  The product (limap_amd/) never links, imports or executes it.
  *
- * PARITY UNPINNED: the reference cannot be built or imported in this environment (needs
- * Eigen/COLMAP/Ceres/PoseLib, none on disk, no network) and its own tests hold no golden
- * vectors for this path.  The restatement is instead pinned by
- * analytic known-answer tests (tests/test_oracle_kat.py).
+ * PINNED against the reference's own sources since round 2: oracle/_ref (oracle/Makefile `ref`,
+ * oracle/ref_driver.cpp) compiles the unmodified hot-path files of /root/reference/src/limap against
+ * stand-in Eigen / COLMAP / PoseLib headers (oracle/ref_shim/ -- those libraries are not on disk), and
+ * tests/test_oracle_vs_ref.py holds this restatement to it bit for bit; the reference's own tests hold no
+ * golden vectors for this path, so tests/golden/*.npz are outputs of the reference
+ * run here.  Still assumptions: Eigen's internal evaluation order at the ulp level (shared by the stand-in),
+ * the SVD sign, PoseLib's quartic root finder.  Analytic known-answer tests: tests/test_oracle_kat.py.
  */
 #ifndef LT_ORACLE_H
 #define LT_ORACLE_H

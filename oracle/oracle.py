@@ -3,7 +3,7 @@
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg.  The product package (limap_amd/) must never import this module.
 
-PARITY UNPINNED against the real reference binary (see lt_oracle.h).
+Pinned against the reference's own sources compiled into oracle/_ref (oracle/ref.py, tests/test_oracle_vs_ref.py).
 """
 import ctypes as C
 import os
@@ -91,23 +91,29 @@ _L3_KEYS = _L2_KEYS[:7] + ["th_scaleinv"] + _L2_KEYS[7:] + ["use_scaleinv"]
 _lib = None
 
 
+def _prototype(L):
+    """Result / argument types of the entry points (shared with oracle/ref.py, whose library exports the same
+    functions under the prefix ref_)."""
+    L.ora_create.restype = C.c_void_p
+    L.ora_create.argtypes = [C.POINTER(OraConfig), C.c_int]
+    L.ora_destroy.argtypes = [C.c_void_p]
+    L.ora_last_error.restype = C.c_char_p
+    L.ora_last_error.argtypes = [C.c_void_p]
+    for name in ("ora_num_nodes", "ora_num_valid_edges", "ora_num_all_tris", "ora_num_tracks",
+                 "ora_num_track_members"):
+        getattr(L, name).restype = C.c_int64
+        getattr(L, name).argtypes = [C.c_void_p]
+    for name in ("ora_compute_epipolar_IoU", "ora_cam_projdepth", "ora_line3d_sensitivity",
+                 "ora_line3d_uncertainty", "ora_linker2d_score", "ora_linker3d_score"):
+        getattr(L, name).restype = C.c_double
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
-        L.ora_create.restype = C.c_void_p
-        L.ora_create.argtypes = [C.POINTER(OraConfig), C.c_int]
-        L.ora_destroy.argtypes = [C.c_void_p]
-        L.ora_last_error.restype = C.c_char_p
-        L.ora_last_error.argtypes = [C.c_void_p]
-        for name in ("ora_num_nodes", "ora_num_valid_edges", "ora_num_all_tris", "ora_num_tracks",
-                     "ora_num_track_members"):
-            getattr(L, name).restype = C.c_int64
-            getattr(L, name).argtypes = [C.c_void_p]
-        for name in ("ora_compute_epipolar_IoU", "ora_cam_projdepth", "ora_line3d_sensitivity",
-                     "ora_line3d_uncertainty", "ora_linker2d_score", "ora_linker3d_score"):
-            getattr(L, name).restype = C.c_double
+        L = _prototype(C.CDLL(_LIB_PATH))
         _lib = L
         # tiny parallel regions (<= topk iterations each) on a 256-core host spend all their time in
         # fork/join; the checker runs with a bounded team.  bench.py sets the count it reports.
