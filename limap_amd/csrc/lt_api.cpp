@@ -940,17 +940,21 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
     const int32_t *src = rows[order[k]];
     const long long n = n_rows[order[k]];
     int *o = out + 2 * dst[k];
-    int prev_line = -1, err = 0, uns = 0;
-    const long long m2 = M2[k];
+    // validation as reductions over the rows (vectorised), then one memcpy: the largest line / neighbour-line id as
+    // unsigned (a negative id wraps to a huge value) and whether any line id is smaller than its predecessor
+    unsigned mx_line = 0, mx_ng = 0;
+    int uns = 0;
+#pragma omp simd reduction(max : mx_line, mx_ng) reduction(| : uns)
     for (long long r = 0; r < n; ++r) {
-      const int line = src[2 * r], ng = src[2 * r + 1];
-      uns |= line < prev_line;
-      prev_line = line;
-      if ((unsigned)line >= (unsigned long long)M1) err |= 1;
-      if ((unsigned)ng >= (unsigned long long)m2) err |= 2;
-      o[2 * r] = line;
-      o[2 * r + 1] = ng;
+      const unsigned line = (unsigned)src[2 * r], ng = (unsigned)src[2 * r + 1];
+      mx_line = line > mx_line ? line : mx_line;
+      mx_ng = ng > mx_ng ? ng : mx_ng;
+      uns |= (r > 0 && src[2 * r] < src[2 * r - 2]) ? 1 : 0;
     }
+    if (n > 0) std::memcpy(o, src, 8 * (size_t)n);
+    int err = 0;
+    if (n > 0 && (unsigned long long)mx_line >= (unsigned long long)M1) err |= 1;
+    if (n > 0 && (unsigned long long)mx_ng >= (unsigned long long)M2[k]) err |= 2;
     bad[k] = err;
     unsorted |= uns;
   }
@@ -968,17 +972,19 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
   if (unsorted) ctx->rows_sorted = false;
   // stream the rows to the device while the caller prepares the next image (they are final: staging
   // is in call order, which is the device order whenever the images arrive in ascending id order)
-  if (ctx->h_m_pairs.blk.pinned && ctx->streamed_ints == base && dst[n_nb] > 0) {
-    const size_t end = base + 2 * (size_t)dst[n_nb];
+  // (one copy per ~4 MB of rows: an enqueue costs the host ~5 us, an image brings ~0.8 MB; lt_upload sends the rest)
+  if (ctx->h_m_pairs.blk.pinned && ctx->streamed_ints <= base && dst[n_nb] > 0 &&
+      base + 2 * (size_t)dst[n_nb] - ctx->streamed_ints >= (1u << 20)) {
+    const size_t from = ctx->streamed_ints, end = base + 2 * (size_t)dst[n_nb];
     if (hipSetDevice(ctx->device) == hipSuccess) {
       bool ok = true;
       if (sizeof(int) * end > ctx->d_m_pairs.cap) {
-        // grow the device buffer (first image: sized for the whole batch), keeping the streamed prefix
+        // grow the device buffer (first copy: sized for the whole batch), keeping the streamed prefix
         DevBuf nb;
         size_t want = sizeof(int) * std::max(end, ctx->h_m_pairs.capacity());
         ok = nb.ensure(want);
-        if (ok && base > 0)
-          ok = hipMemcpyAsync(nb.p, ctx->d_m_pairs.p, sizeof(int) * base, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+        if (ok && from > 0)
+          ok = hipMemcpyAsync(nb.p, ctx->d_m_pairs.p, sizeof(int) * from, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
                hipStreamSynchronize(ctx->stream) == hipSuccess;
         if (ok) {
           ctx->d_m_pairs.release();
@@ -988,7 +994,7 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
           (void)hipGetLastError();
         }
       }
-      if (ok && hipMemcpyAsync(ctx->d_m_pairs.as<int>() + base, ctx->h_m_pairs.data() + base, sizeof(int) * (end - base),
+      if (ok && hipMemcpyAsync(ctx->d_m_pairs.as<int>() + from, ctx->h_m_pairs.data() + from, sizeof(int) * (end - from),
                                hipMemcpyHostToDevice, ctx->stream) == hipSuccess)
         ctx->streamed_ints = end;
       else
@@ -1284,8 +1290,8 @@ int lt_run_device_async(lt_ctx *ctx) {
     // VP-guided proposals: up to three candidates per match row (vp of l1, vp of l2, algebraic)
     const bool vp_on = ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation;
     if (vp_on && !ctx->vp_ready) return fail(ctx, LT_ERR_STATE, "use_vp is set but InitVPResults was not called");
-    // point-guided proposals (SetBipartites2d): the many-points line fit; the one-point quartic proposal is
-    // not implemented and has to be switched off
+    // point-guided proposals (SetBipartites2d): the many-points line fit (base_line_triangulator.cc:183-236) and the
+    // one-point proposal (:238-248, one candidate per shared point; lt_devfn.h: one_point_candidate)
     const bool pts_any = ctx->pts_ready && (!ctx->cfg.disable_many_points_triangulation || !ctx->cfg.disable_one_point_triangulation);
     const bool many_on = pts_any && !ctx->cfg.disable_many_points_triangulation;
     const bool one_on = pts_any && !ctx->cfg.disable_one_point_triangulation;
@@ -1714,12 +1720,157 @@ int lt_flush(lt_ctx *ctx) {
 // ---------------------------------------------------------------------------------------------
 // host tail
 // ---------------------------------------------------------------------------------------------
+// Device half of the tail (lt_kernels_tail.hip): possible when the results of the whole scene are those of the run
+// that is still resident in HBM (one batch, nothing imported, nothing read back yet) and no node filter applies
+// (min_num_outer_edges == 0, the value of cfgs/triangulation/default.yaml:81).  LT_TAIL_HOST=1 forces the host form.
+static bool tail_on_device(const lt_ctx *ctx) {
+  if (getenv("LT_TAIL_HOST") != nullptr || ctx->cfg.min_num_outer_edges > 0) return false;
+  if (!ctx->inited || ctx->job_mode == 0 || ctx->downloaded || ctx->job_imgs.empty()) return false;
+  if (ctx->G <= 0 || ctx->G >= (1ll << 31)) return false;
+  for (char c : ctx->best_c_set)
+    if (c) return false;  // an earlier batch or imported shards live on the host
+  return true;
+}
+
+// sorted unique undirected edges + their similarities; the graph nodes' best candidates land in ctx->best_c etc.
+// Two host synchronisations: one for the number of valid edges (it sizes the sort), one at the end; the graph
+// nodes' records are written by the gather kernel straight into page-locked host memory.
+extern "C++" {
+template <class AddEdge>
+static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
+  LT_FINISH(ctx);
+  static const bool trace = getenv("LT_TAIL_TRACE") != nullptr;
+  double tp = now_ms();
+  auto lap = [&](const char *what) {
+    if (!trace) return;
+    double t = now_ms();
+    fprintf(stderr, "[tail]   %-16s %.3f ms\n", what, t - tp);
+    tp = t;
+  };
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const long long G = ctx->G;
+  // valid-edge offsets (the scan lt_download would run)
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_nvalid.as<unsigned>() + G, 0, 4, st));
+  const size_t scan_tmp = scan_temp_bytes_u32_to_i64(G + 1);
+  ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(scan_tmp, 16));
+  if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, scan_tmp, G + 1, ctx->d_nvalid.as<unsigned>(),
+                             ctx->d_edge_off.as<long long>()) != 0)
+    return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+  long long *hp = ctx->h_pinned ? ctx->h_pinned + 16 : nullptr;  // slots behind the two result sets
+  long long fallback[2] = {0, 0};
+  if (!hp) hp = fallback;
+  HIPCHK(ctx, hipMemcpyAsync(&hp[0], ctx->d_edge_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
+  ENSURE(ctx, ctx->d_tail_mark, 4 * (size_t)(G + 1)); ENSURE(ctx, ctx->d_tail_pos, 8 * (size_t)(G + 1));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tail_mark.p, 0, 4 * (size_t)(G + 1), st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  const long long E = hp[0];
+  lap("scan + sync (E)");
+  ctx->E = E;
+  ctx->C = ctx->C_last;
+  if (E <= 0) return LT_OK;
+  const size_t En = (size_t)E;
+  ENSURE(ctx, ctx->d_tail_keys, 8 * En); ENSURE(ctx, ctx->d_tail_skeys, 8 * En); ENSURE(ctx, ctx->d_tail_sims, 8 * En);
+  ENSURE(ctx, ctx->d_tail_keep, 4 * (En + 1)); ENSURE(ctx, ctx->d_tail_kpos, 8 * (En + 1));
+  const int kb = bits_for(G + 1);  // key = (min node << kb) | max node
+  const int end_bit = 2 * kb;
+  const size_t sort_tmp = tail_sort_temp_bytes(E, end_bit);
+  const size_t scan_tmp2 = scan_temp_bytes_u32_to_i64(E + 1);
+  ENSURE(ctx, ctx->d_tail_tmp, std::max<size_t>(std::max(sort_tmp, scan_tmp2), 16));
+  // host side of the transfer: counts | (key, sim) of the graph's edges | records | node ids, one pooled page-locked
+  // block; at most E distinct edges and min(G, 2 E) nodes enter the graph
+  const size_t max_nodes = (size_t)std::min<long long>(G, 2 * E);
+  const size_t o_pairs = 64, o_recs = o_pairs + 16 * En, o_nodes = o_recs + tail_rec_bytes() * max_nodes;
+  lt_host::HostBlock hb = lt_host::host_block_acquire(o_nodes + 4 * max_nodes);
+  if (!hb.p) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the edge list");
+  struct Rel {
+    lt_host::HostBlock b;
+    ~Rel() { lt_host::host_block_release(b); }
+  } rel{hb};
+  char *base = (char *)hb.p;
+  long long *hn = (long long *)base;  // [0] graph nodes, [1] graph edges
+  hn[0] = hn[1] = 0;
+  const unsigned long long *hpairs = (const unsigned long long *)(base + o_pairs);
+  launch_tail_keys(st, G, ctx->d_tri_off.as<long long>(), ctx->d_edge_flag.as<unsigned>(), ctx->d_edge_off.as<long long>(),
+                   ctx->d_lite.as<CandLite>(), ctx->d_seg_off.as<long long>(), kb, ctx->d_tail_keys.as<unsigned long long>());
+  if (launch_tail_sort(st, ctx->d_tail_tmp.p, sort_tmp, E, ctx->d_tail_keys.as<unsigned long long>(),
+                       ctx->d_tail_skeys.as<unsigned long long>(), end_bit) != 0)
+    return fail(ctx, LT_ERR_HIP, "rocprim radix sort failed");
+  LinkCfg3 l3 = make_l3(ctx->cfg);
+  l3.use_angle = 1; l3.use_overlap = 1; l3.use_perp = 0; l3.use_innerseg = 1; l3.use_scaleinv = 0;  // line_linker.h:123-129
+  launch_tail_sims(st, E, ctx->d_tail_skeys.as<unsigned long long>(), ctx->d_ntris.as<int>(), ctx->d_best_c.as<Cand>(), l3,
+                   kb, ctx->d_tail_sims.as<double>(), ctx->d_tail_mark.as<unsigned>(), ctx->d_tail_keep.as<unsigned>());
+  if (launch_scan_u32_to_i64(st, ctx->d_tail_tmp.p, scan_tmp2, E + 1, ctx->d_tail_keep.as<unsigned>(),
+                             ctx->d_tail_kpos.as<long long>()) != 0 ||
+      launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, scan_tmp, G + 1, ctx->d_tail_mark.as<unsigned>(),
+                             ctx->d_tail_pos.as<long long>()) != 0)
+    return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+  if (hb.pinned) {  // the kernels write across PCIe: the host needs no size before the copies
+    launch_tail_compact(st, E, ctx->d_tail_skeys.as<unsigned long long>(), ctx->d_tail_sims.as<double>(),
+                        ctx->d_tail_keep.as<unsigned>(), ctx->d_tail_kpos.as<long long>(), base + o_pairs, hn + 1);
+    launch_tail_gather(st, G, ctx->d_tail_mark.as<unsigned>(), ctx->d_tail_pos.as<long long>(), ctx->d_best_c.as<Cand>(),
+                       ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(), base + o_recs, (int *)(base + o_nodes), hn);
+  } else {  // no page-locked memory: pack on the device, copy the bounds
+    ENSURE(ctx, ctx->d_tail_recs, 16 * En + tail_rec_bytes() * max_nodes + 64); ENSURE(ctx, ctx->d_tail_nodes, 4 * max_nodes);
+    char *dp = (char *)ctx->d_tail_recs.p;
+    launch_tail_compact(st, E, ctx->d_tail_skeys.as<unsigned long long>(), ctx->d_tail_sims.as<double>(),
+                        ctx->d_tail_keep.as<unsigned>(), ctx->d_tail_kpos.as<long long>(), dp, (long long *)ctx->d_tail_keys.p);
+    launch_tail_gather(st, G, ctx->d_tail_mark.as<unsigned>(), ctx->d_tail_pos.as<long long>(), ctx->d_best_c.as<Cand>(),
+                       ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(), dp + 16 * En, ctx->d_tail_nodes.as<int>(),
+                       nullptr);
+    HIPCHK(ctx, hipMemcpyAsync(hn, ctx->d_tail_pos.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(hn + 1, ctx->d_tail_kpos.as<long long>() + E, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(base + o_pairs, dp, 16 * En, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(base + o_recs, dp + 16 * En, tail_rec_bytes() * max_nodes, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(base + o_nodes, ctx->d_tail_nodes.p, 4 * max_nodes, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(ctx, hipGetLastError());
+  lap("enqueue");
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  lap("sync");
+  const long long Nm = hn[0], Ne = hn[1];
+  if (Nm < 0 || (size_t)Nm > max_nodes || Ne < 0 || Ne > E)
+    return fail(ctx, LT_ERR_RUNTIME, "internal: graph size out of range");
+  const unsigned long long mask = (1ull << kb) - 1ull;
+  for (long long i = 0; i < Ne; ++i) {  // distinct keys with score != 0 (:284-285), in std::set order
+    double sim;
+    std::memcpy(&sim, &hpairs[2 * i + 1], 8);
+    add_edge((long long)(hpairs[2 * i] >> kb), (long long)(hpairs[2 * i] & mask), sim);
+  }
+  lap("graph");
+  struct Rec {
+    Cand c;
+    double score;
+    int src[2];
+  };
+  static_assert(sizeof(Rec) == 128, "TailRec layout");
+  const Rec *recs = (const Rec *)(base + o_recs);
+  const int *nodes = (const int *)(base + o_nodes);
+  for (long long k = 0; k < Nm; ++k) {
+    const long long g = nodes[k];
+    ctx->best_c[g] = recs[k].c;
+    ctx->best_score[g] = recs[k].score;
+    ctx->best_src2[2 * g] = ctx->img_ids[recs[k].src[0]];
+    ctx->best_src2[2 * g + 1] = recs[k].src[1];
+    ctx->has_best[g] = 1;
+  }
+  lap("host unpack");
+  return LT_OK;
+}
+}  // extern "C++"
+
 int lt_compute_tracks(lt_ctx *ctx) {
-  int rc = lt_flush(ctx);
-  if (rc) return rc;
-  if (ctx->inited) define_best_of_other_images(ctx);
   if (ctx->cfg.merging_strategy < 0 || ctx->cfg.merging_strategy > 2)  // global_line_triangulator.cc:314-316
     return fail(ctx, LT_ERR_RUNTIME, "Error!The given merging strategy is not implemented");
+  const bool on_device = tail_on_device(ctx);
+  int rc;
+  if (on_device) {
+    if (!ctx->uploaded && (rc = lt_upload(ctx))) return rc;
+    if (!ctx->ran && (rc = lt_run_device(ctx))) return rc;
+  } else {
+    if ((rc = lt_flush(ctx))) return rc;
+    if (ctx->inited) define_best_of_other_images(ctx);
+  }
   double t0 = now_ms();
   static const bool tail_trace = getenv("LT_TAIL_TRACE") != nullptr;  // developer: stage times to stderr
   double tprev = t0;
@@ -1730,6 +1881,33 @@ int lt_compute_tracks(lt_ctx *ctx) {
     tprev = t;
   };
   const long long G = ctx->G;
+  // graph in edge order (base/graph.cc:57-87); scratch kept in the context
+  using GEdge = lt_ctx::GEdge;
+  std::vector<int> &gmap = ctx->tail_gmap;            // global node -> graph node
+  std::vector<long long> &gnode = ctx->tail_gnode;    // graph node -> global node
+  std::vector<GEdge> &ge = ctx->tail_ge;
+  if ((long long)gmap.size() != G) gmap.assign((size_t)G, -1);
+  gnode.clear();
+  ge.clear();
+  auto find_or_create = [&](long long g) {
+    if (gmap[(size_t)g] >= 0) return gmap[(size_t)g];
+    int id = (int)gnode.size();
+    gnode.push_back(g);
+    gmap[(size_t)g] = id;
+    return id;
+  };
+  auto add_edge = [&](long long a, long long b, double sim) {  // edges arrive in std::set order, score != 0
+    const int n1 = find_or_create(a);
+    const int n2 = find_or_create(b);
+    ge.push_back(GEdge{sim, n1, n2});
+  };
+  std::vector<unsigned long long> edges;
+  std::vector<double> sims;
+  if (on_device) {
+    ctx->valid_flags.assign((size_t)G, 1);
+    if ((rc = tail_from_device(ctx, add_edge))) return rc;
+    lap("device edges+sims");
+  } else {
   const int min_outer = ctx->cfg.min_num_outer_edges;
   auto node2 = [&](long long g, int slot, int ng_line) -> long long {
     int img = ctx->h_node_img[g];
@@ -1765,7 +1943,6 @@ int lt_compute_tracks(lt_ctx *ctx) {
   lap("filter nodes");
   // undirected edge set, ordered like std::set<pair<LineNode, LineNode>> (:243-261): the global
   // node index is monotone in (img_id, line_id)
-  std::vector<unsigned long long> edges;
   {
     // two passes (count, fill) over the nodes in parallel, then a parallel sort
     std::vector<long long> eoff((size_t)G + 1, 0);
@@ -1800,10 +1977,10 @@ int lt_compute_tracks(lt_ctx *ctx) {
   // edge similarity: score_3d in spatial-merging mode between the two best candidates (:264-290)
   LinkCfg3 l3 = make_l3(ctx->cfg);
   l3.use_angle = 1; l3.use_overlap = 1; l3.use_perp = 0; l3.use_innerseg = 1; l3.use_scaleinv = 0;  // line_linker.h:123-129
-  std::vector<double> sims(edges.size());
-  const long long nE = (long long)edges.size();
+  sims.assign(edges.size(), 0.0);
+  const long long nEh = (long long)edges.size();
 #pragma omp parallel for num_threads(lt::host_threads()) schedule(static)
-  for (long long e = 0; e < nE; ++e) {
+  for (long long e = 0; e < nEh; ++e) {
     long long a = (long long)(edges[e] >> 32), b = (long long)(edges[e] & 0xFFFFFFFFull);
     const Cand &ca = ctx->best_c[a];
     const Cand &cb = ctx->best_c[b];
@@ -1814,37 +1991,62 @@ int lt_compute_tracks(lt_ctx *ctx) {
     sims[e] = (ctx->has_best[a] && ctx->has_best[b]) ? score3d(l3, la, lb, ca.unc, cb.unc, ca.depth) : 0.0;
   }
   lap("edge sims");
-  // graph in edge order (base/graph.cc:57-87)
-  std::vector<long long> gnode;              // graph node -> global node
-  std::vector<int> gmap((size_t)G, -1);      // global node -> graph node
-  std::vector<int> e1, e2;
-  std::vector<double> es;
-  e1.reserve((size_t)nE); e2.reserve((size_t)nE); es.reserve((size_t)nE);
-  auto find_or_create = [&](long long g) {
-    if (gmap[(size_t)g] >= 0) return gmap[(size_t)g];
-    int id = (int)gnode.size();
-    gnode.push_back(g);
-    gmap[(size_t)g] = id;
-    return id;
-  };
-  for (long long e = 0; e < nE; ++e) {
-    if (sims[e] == 0) continue;
-    int n1 = find_or_create((long long)(edges[e] >> 32));
-    int n2 = find_or_create((long long)(edges[e] & 0xFFFFFFFFull));
-    e1.push_back(n1); e2.push_back(n2); es.push_back(sims[e]);
+    for (size_t e = 0; e < edges.size(); ++e)
+      if (sims[e] != 0) add_edge((long long)(edges[e] >> 32), (long long)(edges[e] & 0xFFFFFFFFull), sims[e]);
   }
   ctx->stat_graph_nodes = (long long)gnode.size();
-  ctx->stat_graph_edges = (long long)es.size();
+  ctx->stat_graph_edges = (long long)ge.size();
   lap("graph");
-  // ComputeLineTrackLabelsGreedy (merging/merging.cc:18-103)
+  // ComputeLineTrackLabelsGreedy (merging/merging.cc:18-103): edges descending by (sim, idx1, idx2), a total order
   const int n_nodes = (int)gnode.size();
-  std::vector<int> order(es.size());
-  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-  __gnu_parallel::sort(order.begin(), order.end(), [&](int x, int y) {  // descending (sim, idx1, idx2): a total order
-    if (es[x] != es[y]) return es[x] > es[y];
-    if (e1[x] != e1[y]) return e1[x] > e1[y];
-    return e2[x] > e2[y];
-  }, __gnu_parallel::default_parallel_tag(lt::host_threads()));
+  auto ge_before = [](const GEdge &x, const GEdge &y) {
+    if (x.sim != y.sim) return x.sim > y.sim;
+    if (x.n1 != y.n1) return x.n1 > y.n1;
+    return x.n2 > y.n2;
+  };
+  {
+    // similarities are positive doubles: they order like their bit patterns.  LSD radix sort on the 64 bits (six
+    // 11-bit digits, descending), then a comparison sort inside the (rare) runs of equal similarity.
+    std::vector<GEdge> &tmp = ctx->tail_ge2;
+    tmp.resize(ge.size());
+    GEdge *src = ge.data(), *dst = tmp.data();
+    const size_t n = ge.size();
+    bool all_pos = true;
+    for (size_t i = 0; i < n; ++i) all_pos = all_pos && src[i].sim > 0.0;
+    if (all_pos && n > 64) {
+      unsigned cnt[2048];
+      for (int pass = 0; pass < 6; ++pass) {
+        const int sh = 11 * pass;
+        std::memset(cnt, 0, sizeof(cnt));
+        for (size_t i = 0; i < n; ++i) {
+          unsigned long long u;
+          std::memcpy(&u, &src[i].sim, 8);
+          ++cnt[(u >> sh) & 2047u];
+        }
+        unsigned run = 0;  // descending: the largest digit first
+        for (int d = 2047; d >= 0; --d) {
+          const unsigned c = cnt[d];
+          cnt[d] = run;
+          run += c;
+        }
+        for (size_t i = 0; i < n; ++i) {
+          unsigned long long u;
+          std::memcpy(&u, &src[i].sim, 8);
+          dst[cnt[(u >> sh) & 2047u]++] = src[i];
+        }
+        std::swap(src, dst);
+      }
+      // six passes: the result is back in ge (src == ge.data())
+      for (size_t i = 0; i < n;) {
+        size_t j = i + 1;
+        while (j < n && src[j].sim == src[i].sim) ++j;
+        if (j - i > 1) std::sort(src + i, src + j, ge_before);
+        i = j;
+      }
+    } else {
+      std::sort(ge.begin(), ge.end(), ge_before);
+    }
+  }
   lap("edge sort");
   std::vector<int> parent(n_nodes, -1);
   // images_in_track (std::set<int> per root in the reference, :52-84): only the set SIZES steer the
@@ -1892,8 +2094,8 @@ int lt_compute_tracks(lt_ctx *ctx) {
     for (int i = 0; i < n_nodes; ++i) avg_line[(size_t)i] = node_line(i);
   }
   const double nodepth[2] = {0.0, 0.0};
-  for (int oi : order) {
-    int r1 = uf_root(e1[oi], parent), r2 = uf_root(e2[oi], parent);
+  for (const GEdge &ed : ge) {
+    int r1 = uf_root(ed.n1, parent), r2 = uf_root(ed.n2, parent);
     if (r1 == r2) continue;
     if (strategy == 1) {  // merging.cc:150-168: every overlapping pair of the two unions must connect
       bool ok = true;
@@ -1947,33 +2149,46 @@ int lt_compute_tracks(lt_ctx *ctx) {
     labels[i] = labels[uf_root(i, parent)];
   }
   lap("union-find");
-  // build_tracks_from_clusters (:293-351)
+  // build_tracks_from_clusters (:293-351): members in node order per track, flat arrays
   ctx->tracks.clear();
   if (n_nodes > 0) {
     int mx = -1;
     for (int l : labels) mx = std::max(mx, l);
-    ctx->tracks.resize(mx + 1);
+    const size_t nT = (size_t)(mx + 1);
+    TrackStore &ts = ctx->tracks;
+    ts.off.assign(nT + 1, 0);
+    for (int i = 0; i < n_nodes; ++i)
+      if (labels[i] >= 0) ++ts.off[(size_t)labels[i] + 1];
+    for (size_t t = 0; t < nT; ++t) ts.off[t + 1] += ts.off[t];
+    const size_t nM = (size_t)ts.off[nT];
+    ts.img_ids.resize(nM); ts.line_ids.resize(nM); ts.node_ids.resize(nM); ts.scores.resize(nM); ts.gnodes.resize(nM);
+    ts.line7.resize(7 * nT);
+    std::vector<long long> wr(ts.off.begin(), ts.off.end() - 1);
     for (int i = 0; i < n_nodes; ++i) {
-      int tl = labels[i];
+      const int tl = labels[i];
       if (tl == -1) continue;
-      long long g = gnode[i];
-      int img = ctx->h_node_img[g];
-      Track &tr = ctx->tracks[tl];
-      tr.node_ids.push_back(i);
-      tr.img_ids.push_back(ctx->img_ids[img]);
-      tr.line_ids.push_back((int)(g - ctx->seg_off[img]));
-      tr.scores.push_back(ctx->best_score[g]);
-      tr.gnodes.push_back(g);
+      const long long g = gnode[i];
+      const int img = ctx->h_node_img[g];
+      const size_t w = (size_t)wr[(size_t)tl]++;
+      ts.node_ids[w] = i;
+      ts.img_ids[w] = ctx->img_ids[img];
+      ts.line_ids[w] = (int)(g - ctx->seg_off[img]);
+      ts.scores[w] = ctx->best_score[g];
+      ts.gnodes[w] = g;
     }
-    const long long nT = (long long)ctx->tracks.size();
-#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 16)
-    for (long long t = 0; t < nT; ++t) {
-      Track &tr = ctx->tracks[t];
-      std::vector<const Cand *> lines;
-      for (long long g : tr.gnodes) lines.push_back(&ctx->best_c[g]);
-      aggregate(lines, tr.scores, ctx->cfg.num_outliers_aggregator, tr.line);
+    // a few thousand tracks aggregate faster than a thread team forks on a big host
+#pragma omp parallel num_threads(lt::host_threads()) if (nT > 16384)
+    {
+      AggScratch scratch;
+#pragma omp for schedule(dynamic, 64)
+      for (long long t = 0; t < (long long)nT; ++t) {
+        const size_t a = (size_t)ts.off[(size_t)t], n = (size_t)ts.off[(size_t)t + 1] - a;
+        aggregate(ctx->best_c, ts.gnodes.data() + a, ts.scores.data() + a, (int)n, ctx->cfg.num_outliers_aggregator,
+                  ts.line7.data() + 7 * (size_t)t, scratch);
+      }
     }
   }
+  for (long long g : gnode) gmap[(size_t)g] = -1;  // leave the scratch map clean
   lap("tracks+aggregate");
   ctx->tracks_done = true;
   ctx->timers[10] = now_ms() - t0;
@@ -2101,26 +2316,22 @@ int lt_get_all_tris(lt_ctx *ctx, int64_t *out_off, double *out_line10, double *o
 }
 
 int64_t lt_num_tracks(lt_ctx *ctx) { return (int64_t)ctx->tracks.size(); }
-int64_t lt_num_track_members(lt_ctx *ctx) {
-  int64_t n = 0;
-  for (auto &t : ctx->tracks) n += (int64_t)t.img_ids.size();
-  return n;
-}
+int64_t lt_num_track_members(lt_ctx *ctx) { return (int64_t)ctx->tracks.members(); }
 int lt_get_tracks(lt_ctx *ctx, double *out_line7, int64_t *out_off, int32_t *out_img_ids, int32_t *out_line_ids,
                   int32_t *out_node_ids, double *out_scores, double *out_line3d6) {
-  int64_t e = 0, ti = 0;
-  out_off[0] = 0;
-  for (auto &tr : ctx->tracks) {
-    std::memcpy(out_line7 + 7 * ti, tr.line, 56);
-    for (size_t k = 0; k < tr.img_ids.size(); ++k, ++e) {
-      out_img_ids[e] = tr.img_ids[k];
-      out_line_ids[e] = tr.line_ids[k];
-      out_node_ids[e] = tr.node_ids[k];
-      out_scores[e] = tr.scores[k];
-      const Cand &c = ctx->best_c[tr.gnodes[k]];
-      for (int q = 0; q < 3; ++q) { out_line3d6[6 * e + q] = c.s[q]; out_line3d6[6 * e + 3 + q] = c.e[q]; }
-    }
-    out_off[++ti] = e;
+  const TrackStore &ts = ctx->tracks;
+  const size_t nT = ts.size(), nM = ts.members();
+  for (size_t t = 0; t <= nT; ++t) out_off[t] = ts.off[t];
+  if (nT) std::memcpy(out_line7, ts.line7.data(), 56 * nT);
+  if (nM) {
+    std::memcpy(out_img_ids, ts.img_ids.data(), 4 * nM);
+    std::memcpy(out_line_ids, ts.line_ids.data(), 4 * nM);
+    std::memcpy(out_node_ids, ts.node_ids.data(), 4 * nM);
+    std::memcpy(out_scores, ts.scores.data(), 8 * nM);
+  }
+  for (size_t e = 0; e < nM; ++e) {
+    const Cand &c = ctx->best_c[ts.gnodes[e]];
+    for (int q = 0; q < 3; ++q) { out_line3d6[6 * e + q] = c.s[q]; out_line3d6[6 * e + 3 + q] = c.e[q]; }
   }
   return LT_OK;
 }
@@ -2212,6 +2423,10 @@ int lt_import_image_results(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb
 
 int lt_get_stats(lt_ctx *ctx, int64_t out[8]) {
   LT_FINISH(ctx);
+  if (ctx->inited && ctx->ran && !ctx->downloaded) {  // the pair statistic is summed from the per-node counts
+    int rc = lt_download(ctx);
+    if (rc) return rc;
+  }
   out[0] = ctx->n_conn; out[1] = ctx->C; out[2] = ctx->stat_pairs; out[3] = ctx->E;
   out[4] = ctx->stat_graph_nodes; out[5] = ctx->stat_graph_edges; out[6] = (int64_t)ctx->tracks.size();
   out[7] = ctx->G;

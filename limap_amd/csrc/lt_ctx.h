@@ -115,17 +115,25 @@ struct EdgeStore {
   }
 };
 
-struct Track {
-  double line[7];
+// GetTracks() as flat arrays (CSR over the members): LineTrack fields of base/linetrack.h:33-42
+struct TrackStore {
+  std::vector<long long> off{0};          // T + 1
+  std::vector<double> line7;              // start3, end3, uncertainty per track
   std::vector<int> img_ids, line_ids, node_ids;
   std::vector<double> scores;
-  std::vector<long long> gnodes;  // global node index of every member
+  std::vector<long long> gnodes;          // global node index of every member
+  size_t size() const { return off.size() - 1; }
+  size_t members() const { return img_ids.size(); }
+  void clear() {
+    off.assign(1, 0);
+    line7.clear(); img_ids.clear(); line_ids.clear(); node_ids.clear(); scores.clear(); gnodes.clear();
+  }
 };
 
 }  // namespace lt_host
 
 using lt_host::DevBuf;
-using lt_host::Track;
+using lt_host::TrackStore;
 
 struct lt_ctx {
   using Cand = lt::Cand;
@@ -197,6 +205,7 @@ struct lt_ctx {
   DevBuf d_scan_status;      // k_node_prefix: ticket counter + per-tile look-back state
   DevBuf d_tile_order;       // k_score3: tile draw counters
   DevBuf d_base_bl;          // exclusive prefix of cnt_bl over the neighbour blocks of a node
+  DevBuf d_tail_keys, d_tail_skeys, d_tail_sims, d_tail_mark, d_tail_pos, d_tail_recs, d_tail_nodes, d_tail_tmp, d_tail_keep, d_tail_kpos;  // lt_kernels_tail.hip
   bool cnt_bl_clean = false;  // d_cnt_bl is all zero (k_node_prefix cleans up after itself)
   size_t cnt_bl_bytes = 0;
   // point-guided proposals: per segment its (point3D_id, sfm row, x, y) records (24 B, kept as 3 doubles), CSR
@@ -231,7 +240,15 @@ struct lt_ctx {
   std::vector<long long> dbg_off;
   std::vector<int> dbg_cnt;
   // ---- tail ----
-  std::vector<Track> tracks;
+  TrackStore tracks;
+  // scratch of the tail, kept between calls (a fresh 200 KB vector costs more in page faults than the graph build)
+  struct GEdge {
+    double sim;
+    int n1, n2;
+  };
+  std::vector<int> tail_gmap;         // global node -> graph node, -1 outside a call
+  std::vector<long long> tail_gnode;  // graph node -> global node
+  std::vector<GEdge> tail_ge, tail_ge2;
   std::vector<unsigned char> valid_flags;  // valid_flags_ of run_clustering (filterNodeByNumOuterEdges), per node
   bool tracks_done = false;
   long long stat_graph_nodes = 0, stat_graph_edges = 0, stat_pairs = 0;

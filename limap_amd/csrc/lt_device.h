@@ -59,6 +59,21 @@ void launch_select(hipStream_t st, long long G, const long long *tri_off, const 
 void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
                       const long long *edge_off, const CandLite *lite, int *edges2);
 
+// device half of ComputeLineTracks (lt_kernels_tail.hip)
+size_t tail_rec_bytes();
+size_t tail_sort_temp_bytes(long long E, int end_bit);
+void launch_tail_keys(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
+                      const long long *edge_off, const CandLite *lite, const long long *seg_off, int kb,
+                      unsigned long long *keys);
+int launch_tail_sort(hipStream_t st, void *temp, size_t temp_bytes, long long E, const unsigned long long *keys_in,
+                     unsigned long long *keys_out, int end_bit);
+void launch_tail_sims(hipStream_t st, long long E, const unsigned long long *skeys, const int *n_tris, const Cand *best_c,
+                      const LinkCfg3 &cfg, int kb, double *sims, unsigned *mark, unsigned *keep);
+void launch_tail_compact(hipStream_t st, long long E, const unsigned long long *skeys, const double *sims,
+                         const unsigned *keep, const long long *kpos, void *out_pairs, long long *n_out);
+void launch_tail_gather(hipStream_t st, long long G, const unsigned *mark, const long long *pos, const Cand *best_c,
+                        const double *best_score, const int *best_src2, void *recs, int *nodes, long long *n_out);
+
 void launch_track_connect(hipStream_t st, int T, const double *line7, const unsigned char *active, int all_active,
                           const LinkCfg3 &cfg, double cos_guard, unsigned long long *edges,
                           unsigned long long capacity, unsigned long long *n_edges);

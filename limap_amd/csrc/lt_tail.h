@@ -79,13 +79,17 @@ inline void principal_axis(const std::vector<d3> &pts, double out[3]) {
   for (int k = 0; k < 3; ++k) out[k] = sgn * d[k];
 }
 
-// Aggregator::aggregate_line3d_list, merging/aggregator.cc:53-101 (+ takebest :8-29)
-inline void aggregate(const std::vector<const Cand *> &lines, const std::vector<double> &scores, int num_outliers,
-               double out7[7]) {
-  const int n = (int)lines.size();
+// Aggregator::aggregate_line3d_list, merging/aggregator.cc:53-101 (+ takebest :8-29).  Two interfaces: a list of
+// candidate records (track post-processing) and (table, index list) for the tracks of ComputeLineTracks.
+struct AggScratch {
+  std::vector<d3> pts;
+  std::vector<double> proj;
+};
+template <class GetLine>
+inline void aggregate_impl(GetLine line, const double *scores, int n, int num_outliers, double out7[7], AggScratch &sc) {
   double min_unc = kMaxDist;
   for (int i = 0; i < n; ++i)
-    if (lines[i]->unc < min_unc) min_unc = lines[i]->unc;
+    if (line(i).unc < min_unc) min_unc = line(i).unc;
   if (n < 4) {
     double best_score = 0.0;
     int best = -1;
@@ -96,30 +100,32 @@ inline void aggregate(const std::vector<const Cand *> &lines, const std::vector<
       }
     if (best < 0) best = 0;
     for (int k = 0; k < 3; ++k) {
-      out7[k] = lines[best]->s[k];
-      out7[3 + k] = lines[best]->e[k];
+      out7[k] = line(best).s[k];
+      out7[3 + k] = line(best).e[k];
     }
     out7[6] = min_unc;
     return;
   }
   d3 center = mk3(0, 0, 0);
   for (int i = 0; i < n; ++i) {
-    center = add(center, mk3(lines[i]->s[0], lines[i]->s[1], lines[i]->s[2]));
-    center = add(center, mk3(lines[i]->e[0], lines[i]->e[1], lines[i]->e[2]));
+    center = add(center, mk3(line(i).s[0], line(i).s[1], line(i).s[2]));
+    center = add(center, mk3(line(i).e[0], line(i).e[1], line(i).e[2]));
   }
   double dn = (double)(2 * n);
   center = mk3(center.x / dn, center.y / dn, center.z / dn);
-  std::vector<d3> pts(2 * (size_t)n);
+  std::vector<d3> &pts = sc.pts;
+  pts.resize(2 * (size_t)n);
   for (int i = 0; i < n; ++i) {
-    pts[2 * i] = sub(mk3(lines[i]->s[0], lines[i]->s[1], lines[i]->s[2]), center);
-    pts[2 * i + 1] = sub(mk3(lines[i]->e[0], lines[i]->e[1], lines[i]->e[2]), center);
+    pts[2 * i] = sub(mk3(line(i).s[0], line(i).s[1], line(i).s[2]), center);
+    pts[2 * i + 1] = sub(mk3(line(i).e[0], line(i).e[1], line(i).e[2]), center);
   }
   double dv[3];
   principal_axis(pts, dv);
   d3 direc = mk3(dv[0], dv[1], dv[2]);
   double nn = std::sqrt(sqn(direc));
   direc = mk3(direc.x / nn, direc.y / nn, direc.z / nn);
-  std::vector<double> proj(2 * (size_t)n);
+  std::vector<double> &proj = sc.proj;
+  proj.resize(2 * (size_t)n);
   for (int i = 0; i < 2 * n; ++i) proj[i] = dot(pts[i], direc);
   std::sort(proj.begin(), proj.end());
   double a = proj[num_outliers], b = proj[2 * n - 1 - num_outliers];
@@ -127,6 +133,15 @@ inline void aggregate(const std::vector<const Cand *> &lines, const std::vector<
   out7[3] = center.x + direc.x * b; out7[4] = center.y + direc.y * b; out7[5] = center.z + direc.z * b;
   out7[6] = min_unc;
 }
-
+inline void aggregate(const std::vector<const Cand *> &lines, const std::vector<double> &scores, int num_outliers,
+                      double out7[7]) {
+  AggScratch sc;
+  aggregate_impl([&](int i) -> const Cand & { return *lines[(size_t)i]; }, scores.data(), (int)lines.size(), num_outliers,
+                 out7, sc);
+}
+inline void aggregate(const Cand *table, const long long *idx, const double *scores, int n, int num_outliers,
+                      double out7[7], AggScratch &sc) {
+  aggregate_impl([&](int i) -> const Cand & { return table[idx[i]]; }, scores, n, num_outliers, out7, sc);
+}
 
 }  // namespace lt

@@ -59,17 +59,18 @@ extern "C" {
 
 lt_trackset *lt_ts_from_ctx(lt_ctx *ctx) {
   lt_trackset *ts = new lt_trackset();
-  ts->tracks.resize(ctx->tracks.size());
-  for (size_t t = 0; t < ctx->tracks.size(); ++t) {
-    const Track &src = ctx->tracks[t];
+  const lt_host::TrackStore &src = ctx->tracks;
+  ts->tracks.resize(src.size());
+  for (size_t t = 0; t < src.size(); ++t) {
     TrackFull &dst = ts->tracks[t];
-    std::memcpy(dst.line, src.line, sizeof(dst.line));
-    dst.m.resize(src.img_ids.size());
-    for (size_t k = 0; k < src.img_ids.size(); ++k) {
+    std::memcpy(dst.line, src.line7.data() + 7 * t, sizeof(dst.line));
+    const size_t a = (size_t)src.off[t], n = (size_t)src.off[t + 1] - a;
+    dst.m.resize(n);
+    for (size_t k = 0; k < n; ++k) {
       Member &mm = dst.m[k];
-      mm.img_id = src.img_ids[k]; mm.line_id = src.line_ids[k]; mm.node_id = src.node_ids[k];
-      mm.score = src.scores[k];
-      long long g = src.gnodes[k];
+      mm.img_id = src.img_ids[a + k]; mm.line_id = src.line_ids[a + k]; mm.node_id = src.node_ids[a + k];
+      mm.score = src.scores[a + k];
+      long long g = src.gnodes[a + k];
       std::memcpy(mm.l2d, &ctx->h_segs[4 * g], 32);
       mm.l3d = ctx->best_c[g];
     }

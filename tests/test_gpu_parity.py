@@ -254,3 +254,37 @@ def test_merging_strategies_match_oracle(gpu_lib, oracle, strategy):
     G = run_oracle(oracle, sc, syn.default_triangulation_cfg())
     G.ComputeLineTracks()
     assert not np.array_equal(O.get_tracks()["off"], G.get_tracks()["off"])
+
+
+@pytest.mark.parametrize("exhaustive", [False, True])
+def test_device_tail_equals_host_tail(gpu_lib, oracle, exhaustive):
+    """ComputeLineTracks with the edge set + similarities built on the GPU and only the graph nodes downloaded
+    (lt_kernels_tail.hip) gives the tracks of the host form (LT_TAIL_HOST=1: full download, std::set-order edges and
+    score_3d on the host) bit for bit, and the oracle's; getters after the slim path still see every node."""
+    import os
+    sc = (small_scene(seed=9, n_views=9, n_segs=60, n_neighbors=4) if exhaustive
+          else small_scene(seed=8, n_views=18, n_segs=130, n_neighbors=7))
+    cfg = syn.default_triangulation_cfg()
+    O = run_oracle(oracle, sc, cfg, exhaustive=exhaustive)
+    ot = O.ComputeLineTracks()
+    got = []
+    for host in (False, True):
+        if host:
+            os.environ["LT_TAIL_HOST"] = "1"
+        try:
+            T = run_product(sc, cfg, exhaustive=exhaustive)
+            T.ComputeLineTracks()
+            got.append((T.context().get_tracks(), T))
+        finally:
+            os.environ.pop("LT_TAIL_HOST", None)
+    a, b = got[0][0], got[1][0]
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    compare_tracks(a, ot)
+    T = got[0][1]  # the slim path ran; a getter now brings everything else down
+    compare_best(T.context().get_best(), O.get_best())
+    compare_valid_edges(T.context().get_valid_edges(), O.get_valid_edges())
+    st, so = T.stats(), O.stats()
+    for k in ("connections", "candidates", "pairs", "valid_edges", "graph_nodes", "graph_edges", "tracks"):
+        assert st[k] == so[k], k
+    compare_tracks(T.context().get_tracks(), ot)  # unchanged by the later download
