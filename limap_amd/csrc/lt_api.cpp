@@ -52,7 +52,7 @@ void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const 
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
-                  const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node, int mult);
+                  const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node, int mult, unsigned *perm);
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
                       unsigned *keys_c, unsigned *src_c, int mult);
@@ -65,7 +65,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
-                   bool f32, unsigned *perm, void *rng);
+                   bool f32, unsigned *perm, void *rng, bool perm_is_placement);
 }
 
 // ---- pooled page-locked host blocks (see lt_ctx.h) ----
@@ -569,7 +569,10 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
-                    &ctx->d_pair_counter, &ctx->d_result3, &ctx->d_tile_order, &ctx->d_scan_status, &ctx->d_perm, &ctx->d_rng, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz};
+                    &ctx->d_pair_counter, &ctx->d_result3, &ctx->d_tile_order, &ctx->d_scan_status, &ctx->d_perm, &ctx->d_rng, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz,
+                    &ctx->d_place_perm, &ctx->d_tail_keys, &ctx->d_tail_skeys, &ctx->d_tail_sims, &ctx->d_tail_mark,
+                    &ctx->d_tail_pos, &ctx->d_tail_recs, &ctx->d_tail_nodes, &ctx->d_tail_tmp, &ctx->d_tail_keep,
+                    &ctx->d_tail_kpos};
   lt_host::host_block_release(ctx->h_pinned_blk);
   lt_host::host_block_release(ctx->best_c_blk);
   for (DevBuf *b : bufs) b->release();
@@ -1387,10 +1390,15 @@ int lt_run_device_async(lt_ctx *ctx) {
       HIPCHK(ctx, hipStreamSynchronize(st));
       C_known = *hC;
     }
+    // fast path: no record is moved -- k_place writes the permutation only
+    const bool perm_mode = fast && !getenv("LT_TEST_PLACE_COPY");
+    ctx->perm_mode = perm_mode;
+    ctx->compact_valid = !perm_mode;
     if (C_known < 0) {
       // the bound is generous: if the device cannot give that much, fetch the exact count after all
       const size_t Bn = (size_t)std::max<long long>(C_bound, 1);
-      const bool got = ctx->d_cand.ensure(sizeof(Cand) * Bn) && ctx->d_lite.ensure(sizeof(CandLite) * Bn) &&
+      const bool got = (perm_mode ? ctx->d_place_perm.ensure(4 * Bn)
+                                  : (ctx->d_cand.ensure(sizeof(Cand) * Bn) && ctx->d_lite.ensure(sizeof(CandLite) * Bn))) &&
                        ctx->d_score.ensure(8 * Bn) && ctx->d_edge_flag.ensure(4 * Bn) && ctx->d_cand_node.ensure(4 * Bn) &&
                        ctx->d_cand_meta.ensure(cand_meta_bytes() * Bn);
       if (!got) {
@@ -1402,7 +1410,11 @@ int lt_run_device_async(lt_ctx *ctx) {
     }
     if (C_known >= 0) C_bound = C_known;
     const size_t Cn = (size_t)std::max<long long>(C_bound, 1);
-    ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);
+    if (perm_mode) {
+      ENSURE(ctx, ctx->d_place_perm, 4 * Cn);
+    } else {
+      ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);
+    }
     ENSURE(ctx, ctx->d_score, 8 * Cn); ENSURE(ctx, ctx->d_edge_flag, 4 * Cn); ENSURE(ctx, ctx->d_cand_node, 4 * Cn);
     ctx->cand_cap = (long long)Cn;
     if (fast) {
@@ -1410,7 +1422,8 @@ int lt_run_device_async(lt_ctx *ctx) {
                    ctx->d_seg_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
                    ctx->d_base_bl.as<unsigned>(), ctx->d_wave_count.as<unsigned>(), ctx->d_tri_off.as<long long>(),
                    ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(),
-                   ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_cand_node.as<unsigned>(), mult);
+                   ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_cand_node.as<unsigned>(), mult,
+                   perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
     } else {
       ENSURE(ctx, ctx->d_keys, 4 * Cn); ENSURE(ctx, ctx->d_rows, 4 * Cn);
       ENSURE(ctx, ctx->d_skeys, 4 * Cn); ENSURE(ctx, ctx->d_srows, 4 * Cn);
@@ -1434,6 +1447,8 @@ int lt_run_device_async(lt_ctx *ctx) {
     if (fine_timers() && C_bound > 0) ev_place_end = 11;
     else HIPCHK(ctx, hipEventRecord(ev[4], st));
   } else if (ctx->job_mode == 2) {
+    ctx->perm_mode = false;
+    ctx->compact_valid = true;
     const size_t In = (size_t)std::max<long long>(P, 1);
     // VP-guided proposals: three survivor ballots per work item (algebraic, vp of l1, vp of l2)
     const bool vp_on = ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation;
@@ -1506,6 +1521,8 @@ int lt_run_device_async(lt_ctx *ctx) {
     C_bound = total;
     HIPCHK(ctx, hipEventRecord(ev[4], st));
   } else {
+    ctx->perm_mode = false;
+    ctx->compact_valid = true;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_tri_off.p, 0, sizeof(long long) * (size_t)(G + 1), st));
     ENSURE(ctx, ctx->d_cand, sizeof(Cand)); ENSURE(ctx, ctx->d_lite, sizeof(CandLite));
     ENSURE(ctx, ctx->d_score, 8); ENSURE(ctx, ctx->d_edge_flag, 4); ENSURE(ctx, ctx->d_cand_node, 4);
@@ -1536,12 +1553,13 @@ int lt_run_device_async(lt_ctx *ctx) {
     }
     C_run = C_bound;  // replaced by the exact count when that arrives with the error flag (finish_run)
     launch_score3(st, C_bound, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
-                  ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_node_img.as<int>(),
+                  ctx->perm_mode ? ctx->d_st_c.as<Cand>() : ctx->d_cand.as<Cand>(),
+                  ctx->perm_mode ? ctx->d_st_l.as<CandLite>() : ctx->d_lite.as<CandLite>(), ctx->d_node_img.as<int>(),
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
                   ctx->d_score.as<double>(), ctx->d_pair_counter.as<unsigned long long>(), ctx->max_nb, scfg,
-                  guard2, fine_timers() ? ev[11] : nullptr,
-                  ctx->d_tile_order.as<unsigned>(), score_f32, score_sorted ? ctx->d_perm.as<unsigned>() : nullptr,
-                  score_sorted ? ctx->d_rng.p : nullptr);
+                  guard2, fine_timers() ? ev[11] : nullptr, ctx->d_tile_order.as<unsigned>(), score_f32,
+                  ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : (score_sorted ? ctx->d_perm.as<unsigned>() : nullptr),
+                  score_sorted ? ctx->d_rng.p : nullptr, ctx->perm_mode);
   }
   HIPCHK(ctx, hipEventRecord(ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));
@@ -1555,10 +1573,12 @@ int lt_run_device_async(lt_ctx *ctx) {
   // flags and their number; the edge offsets (a scan) and the edge lists are produced at download time
   launch_select(st, G, ctx->d_tri_off.as<long long>(), ctx->d_score.as<double>(), scfg.fullscore_th,
                 scfg.max_valid_conns, ctx->d_best_idx.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
-                ctx->d_nvalid.as<unsigned>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
+                ctx->d_nvalid.as<unsigned>(), ctx->perm_mode ? ctx->d_st_c.as<Cand>() : ctx->d_cand.as<Cand>(),
+                ctx->perm_mode ? ctx->d_st_l.as<CandLite>() : ctx->d_lite.as<CandLite>(),
                 ctx->d_best_c.as<Cand>(), ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(),
                 ctx->d_ntris.as<int>(), /*wide=*/ctx->job_mode == 2, ctx->d_err.as<int>(),
-                ctx->d_pair_counter.as<unsigned long long>(), ctx->d_result3.as<long long>());
+                ctx->d_pair_counter.as<unsigned long long>(), ctx->d_result3.as<long long>(),
+                ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
   if (!hp) HIPCHK(ctx, hipEventRecord(ev[7], st));  // with result slots the end marker below also ends the run
   HIPCHK(ctx, hipGetLastError());
   // the device error flag, the candidate count and the pair statistic ride on the stream into this set's
@@ -1598,6 +1618,20 @@ static void define_best_of_other_images(lt_ctx *ctx) {
     }
 }
 
+// The compact candidate arrays of the last run (debug read-outs): in perm mode they are gathered on demand.
+static int materialize_compact(lt_ctx *ctx) {
+  if (!ctx->perm_mode || ctx->compact_valid) return LT_OK;
+  const long long C = ctx->C_last;
+  const size_t Cn = (size_t)std::max<long long>(C, 1);
+  ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);
+  launch_permute(ctx->stream, C, ctx->d_cand_node.as<unsigned>(), ctx->d_place_perm.as<unsigned>(), ctx->d_st_c.as<Cand>(),
+                 ctx->d_st_l.as<CandLite>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
+                 ctx->d_cand_node.as<unsigned>());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->compact_valid = true;
+  return LT_OK;
+}
+
 int lt_download(lt_ctx *ctx) {
   LT_FINISH(ctx);
   if (!ctx->ran) return fail(ctx, LT_ERR_STATE, "lt_download before lt_run_device");
@@ -1623,7 +1657,8 @@ int lt_download(lt_ctx *ctx) {
   ctx->E = edge_off[G];
   ENSURE(ctx, ctx->d_edges, 8 * (size_t)std::max<long long>(ctx->E, 1));
   launch_edge_fill(st, G, ctx->d_tri_off.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
-                   ctx->d_edge_off.as<long long>(), ctx->d_lite.as<CandLite>(), ctx->d_edges.as<int>());
+                   ctx->d_edge_off.as<long long>(), ctx->perm_mode ? ctx->d_st_l.as<CandLite>() : ctx->d_lite.as<CandLite>(),
+                   ctx->d_edges.as<int>(), ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
   // one pooled page-locked block for all result arrays
   const size_t Gn = (size_t)std::max<long long>(G, 1), En = (size_t)std::max<long long>(ctx->E, 1);
   const size_t o_bc = 0, o_bs = o_bc + sizeof(Cand) * Gn, o_src = o_bs + 8 * Gn, o_nt = o_src + 8 * Gn,
@@ -1676,6 +1711,10 @@ int lt_download(lt_ctx *ctx) {
   ctx->stat_pairs = pairs;
   if (ctx->cfg.debug_mode && ctx->C > 0) {  // keep this batch's tris_ on the host (later batches reuse the device arrays)
     const long long C = ctx->C;
+    {
+      int rcm = materialize_compact(ctx);
+      if (rcm) return rcm;
+    }
     std::vector<Cand> c((size_t)C);
     std::vector<CandLite> l((size_t)C);
     std::vector<double> sc((size_t)C);
@@ -1792,7 +1831,8 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
   hn[0] = hn[1] = 0;
   const unsigned long long *hpairs = (const unsigned long long *)(base + o_pairs);
   launch_tail_keys(st, G, ctx->d_tri_off.as<long long>(), ctx->d_edge_flag.as<unsigned>(), ctx->d_edge_off.as<long long>(),
-                   ctx->d_lite.as<CandLite>(), ctx->d_seg_off.as<long long>(), kb, ctx->d_tail_keys.as<unsigned long long>());
+                   ctx->perm_mode ? ctx->d_st_l.as<CandLite>() : ctx->d_lite.as<CandLite>(), ctx->d_seg_off.as<long long>(), kb,
+                   ctx->d_tail_keys.as<unsigned long long>(), ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
   if (launch_tail_sort(st, ctx->d_tail_tmp.p, sort_tmp, E, ctx->d_tail_keys.as<unsigned long long>(),
                        ctx->d_tail_skeys.as<unsigned long long>(), end_bit) != 0)
     return fail(ctx, LT_ERR_HIP, "rocprim radix sort failed");
@@ -2293,6 +2333,7 @@ int lt_get_all_tris(lt_ctx *ctx, int64_t *out_off, double *out_line10, double *o
     return LT_OK;
   }
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if ((rc = materialize_compact(ctx))) return rc;
   const long long G = ctx->G, C = ctx->C;
   std::vector<long long> tri_off(G + 1);
   HIPCHK(ctx, hipMemcpy(tri_off.data(), ctx->d_tri_off.p, 8 * (size_t)(G + 1), hipMemcpyDeviceToHost));

@@ -55,16 +55,17 @@ void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_of
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
                    int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const Cand *cand,
                    const CandLite *lite, Cand *best_c, double *best_score, int *best_src2, int *n_tris,
-                   bool wide, const int *err_flag, const unsigned long long *pair_counter, long long *result3);
+                   bool wide, const int *err_flag, const unsigned long long *pair_counter, long long *result3,
+                   const unsigned *perm);
 void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
-                      const long long *edge_off, const CandLite *lite, int *edges2);
+                      const long long *edge_off, const CandLite *lite, int *edges2, const unsigned *perm);
 
 // device half of ComputeLineTracks (lt_kernels_tail.hip)
 size_t tail_rec_bytes();
 size_t tail_sort_temp_bytes(long long E, int end_bit);
 void launch_tail_keys(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
                       const long long *edge_off, const CandLite *lite, const long long *seg_off, int kb,
-                      unsigned long long *keys);
+                      unsigned long long *keys, const unsigned *perm);
 int launch_tail_sort(hipStream_t st, void *temp, size_t temp_bytes, long long E, const unsigned long long *keys_in,
                      unsigned long long *keys_out, int end_bit);
 void launch_tail_sims(hipStream_t st, long long E, const unsigned long long *skeys, const int *n_tris, const Cand *best_c,

@@ -478,7 +478,8 @@ k_select(long long G, const long long *__restrict__ tri_off, const double *__res
          unsigned *__restrict__ edge_flag, unsigned *__restrict__ n_valid, const Cand *__restrict__ cand,
          const CandLite *__restrict__ lite, Cand *__restrict__ best_c, double *__restrict__ best_score,
          int *__restrict__ best_src2, int *__restrict__ n_tris, const int *__restrict__ err_flag,
-         const unsigned long long *__restrict__ pair_counter, long long *__restrict__ result3) {
+         const unsigned long long *__restrict__ pair_counter, long long *__restrict__ result3,
+         const unsigned *__restrict__ perm) {
   // the run's three result scalars (error flag, candidate count, pair statistic) are gathered into one record
   // here, in the last kernel of the run, so that one 24-byte copy brings them to the host instead of three
   if (result3 && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -519,7 +520,8 @@ k_select(long long G, const long long *__restrict__ tri_off, const double *__res
   // units of the Cand, lane 7: score, lane 8: source (image, line), lane 9: candidate count)
   {
     static_assert(sizeof(Cand) == 7 * 16, "Cand in 16-byte units");
-    const long long b = (bi < 0) ? -1 : off + bi;
+    long long b = (bi < 0) ? -1 : off + bi;
+    if (perm && b >= 0) b = (long long)perm[b];  // records still in the staging lists (k_place wrote the permutation)
     if (lane < 7) {
       double2 v = double2{0.0, 0.0};
       if (b >= 0) v = reinterpret_cast<const double2 *>(cand + b)[lane];
@@ -564,7 +566,7 @@ k_select(long long G, const long long *__restrict__ tri_off, const double *__res
 __global__ void __launch_bounds__(256)
 k_edge_fill(long long G, const long long *__restrict__ tri_off, const unsigned *__restrict__ edge_flag,
             const long long *__restrict__ edge_off, const CandLite *__restrict__ lite,
-            int *__restrict__ edges2) {
+            int *__restrict__ edges2, const unsigned *__restrict__ perm) {
   long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (g >= G) return;
   const int lane = lane_id();
@@ -578,8 +580,9 @@ k_edge_fill(long long G, const long long *__restrict__ tri_off, const unsigned *
     unsigned long long m = __ballot(f);
     if (f) {
       long long p = base + __popcll(m & lanemask_lt());
-      edges2[2 * p] = lite_slot(lite[off + i]);
-      edges2[2 * p + 1] = lite[off + i].ng_line;
+      const CandLite l = lite[perm ? (long long)perm[off + i] : off + i];
+      edges2[2 * p] = lite_slot(l);
+      edges2[2 * p + 1] = l.ng_line;
     }
     base += __popcll(m);
   }
@@ -705,24 +708,25 @@ void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_of
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
                    int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const Cand *cand,
                    const CandLite *lite, Cand *best_c, double *best_score, int *best_src2, int *n_tris,
-                   bool wide, const int *err_flag, const unsigned long long *pair_counter, long long *result3) {
+                   bool wide, const int *err_flag, const unsigned long long *pair_counter, long long *result3,
+                   const unsigned *perm) {
   if (G > 0)
   {
     if (wide)
       hipLaunchKernelGGL(k_select<64>, dim3(nblk(G * 64, 256)), dim3(256), 0, st, G, tri_off, score, th, max_valid,
                          best_idx, edge_flag, n_valid, cand, lite, best_c, best_score, best_src2, n_tris, err_flag,
-                         pair_counter, result3);
+                         pair_counter, result3, perm);
     else
       hipLaunchKernelGGL(k_select<16>, dim3(nblk(G * 16, 256)), dim3(256), 0, st, G, tri_off, score, th, max_valid,
                          best_idx, edge_flag, n_valid, cand, lite, best_c, best_score, best_src2, n_tris, err_flag,
-                         pair_counter, result3);
+                         pair_counter, result3, perm);
   }
 }
 void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
-                      const long long *edge_off, const CandLite *lite, int *edges2) {
+                      const long long *edge_off, const CandLite *lite, int *edges2, const unsigned *perm) {
   if (G > 0)
     hipLaunchKernelGGL(k_edge_fill, dim3(nblk(G * 64, 256)), dim3(256), 0, st, G, tri_off, edge_flag, edge_off,
-                       lite, edges2);
+                       lite, edges2, perm);
 }
 
 

@@ -654,7 +654,8 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
         const unsigned *__restrict__ base_bl, const unsigned *__restrict__ wave_count,
         const long long *__restrict__ tri_off, const Cand *__restrict__ st_c,
         const CandLite *__restrict__ st_l, const unsigned *__restrict__ st_key, Cand *__restrict__ cand,
-        CandLite *__restrict__ lite, unsigned *__restrict__ cand_node, int n_groups, int mult) {
+        CandLite *__restrict__ lite, unsigned *__restrict__ cand_node, int n_groups, int mult,
+        unsigned *__restrict__ perm) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
@@ -716,12 +717,16 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
       const long long pos = toff + base_bl[lbase + (long long)(key - g1)] + rank;
       pos32 = (unsigned)pos;  // candidate positions fit 32 bits (cand_node / tri counts are 32-bit)
       cand_node[pos] = key;
+      // perm != nullptr: the records stay where stage B staged them and the consumers read them through
+      // perm[final position] = staging slot (4 bytes per candidate instead of moving 144)
+      if (perm) perm[pos] = (unsigned)(s0 + e);
       // (writing the scoring kernel's CandMeta record here instead of running k_cand_meta was measured:
       // +9 us in this kernel against 5 us for the separate pass)
     }
     // Cooperative copy in 16-byte units: consecutive lanes read consecutive units of the (contiguous)
     // source list and write consecutive units of a destination record, so a wave touches ~1/8 of the
     // cache lines a record-per-lane copy would.
+    if (perm) continue;
     const unsigned nb = min(64u, count - e0);
     const double2 *src_c = reinterpret_cast<const double2 *>(st_c + s0 + e0);
     double2 *dst_c = reinterpret_cast<double2 *>(cand);
@@ -992,9 +997,12 @@ k_depth_order(long long G, const long long *__restrict__ tri_off, const Cand *__
 // 10 KB of LDS it frees.  Evaluating pair_score without its early returns, for ILP: no difference.)
 // kSorted: the tile is 64 consecutive DEPTH-SORTED positions of the candidate array (k_depth_order); lane t
 // owns candidate perm[t] and sweeps only the sorted positions rng[t] of its node.
-template <bool kF32, bool kSorted>
+// kPerm: the candidate at position t of the (virtual) compact array is record perm[t] of a.cand / a.lite (the
+// staging lists of stage B: k_place wrote only the permutation); scores are indexed by position.
+template <bool kF32, bool kSorted, bool kPerm>
 __global__ void __launch_bounds__(64) LT_SCORE_OCC
 k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
+  constexpr bool kInd = kSorted || kPerm;  // positions are mapped through a.perm
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x;
   // LDS: window (f32: float4[kWin][3]; f64: W[9][kWin] f64 + wslot[kWin] i32) | woff[64] i64 | queue[kSQCap] u32 |
@@ -1037,7 +1045,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     const long long i0 = (long long)tile * 64;
     const long long tpos = i0 + lane;  // position (sorted order if kSorted)
     const bool active = tpos < C;
-    const long long i = (kSorted && active) ? (long long)a.perm[tpos] : tpos;  // the lane's candidate
+    const long long i = (kInd && active) ? (long long)a.perm[tpos] : tpos;  // the lane's candidate record
     LT_TRACE_MARK(2, tile, 0);
 
     long long off = 0, nb0 = 0;
@@ -1108,8 +1116,8 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
           const unsigned e = queue[p];
           const int il = (int)(e >> 26);
           const long long jpos = woff[il] + (long long)(e & 0x3FFFFFFu);
-          const long long j = kSorted ? (long long)a.perm[jpos] : jpos;
-          const long long ii = kSorted ? (long long)a.perm[i0 + il] : i0 + il;
+          const long long j = kInd ? (long long)a.perm[jpos] : jpos;
+          const long long ii = kInd ? (long long)a.perm[i0 + il] : i0 + il;
           const Cand ci = a.cand[ii];
           const CandLite li = a.lite[ii];
           const CandLite lj = a.lite[j];
@@ -1131,7 +1139,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
       float rw = ri;
       for (int e = lane; e < wn; e += 64) {
-        const long long src = kSorted ? (long long)a.perm[wb + e] : wb + e;
+        const long long src = kInd ? (long long)a.perm[wb + e] : wb + e;
         const CandLite l = a.lite[src];
         const Cand c = a.cand[src];
         if (kF32) {
@@ -1241,7 +1249,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
         int k = own ? ordl[r] : a.blk_order[nb0 + r];
         sum += __longlong_as_double((long long)S[k * 64 + lane]);
       }
-      a.score[i] = sum;
+      a.score[kPerm ? tpos : i] = sum;
     }
     n_eval_total += n_eval;
     wave_lds_sync();  // the tables are reused by the next tile
@@ -1343,12 +1351,12 @@ void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const 
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
-                  const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node, int mult) {
+                  const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node, int mult, unsigned *perm) {
   if (n_blk <= 0 || max_rows <= 0) return;
   const int n_groups = gen_groups(max_rows);
   hipLaunchKernelGGL(k_place, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
                      blk_line_base, base_bl, wave_count, tri_off, st_c, st_l, st_key, cand, lite, cand_node, n_groups,
-                     mult);
+                     mult, perm);
 }
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
@@ -1380,7 +1388,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
-                   bool f32, unsigned *perm, void *rng) {
+                   bool f32, unsigned *perm, void *rng, bool perm_is_placement) {
   if (C <= 0) return;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -1400,7 +1408,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.perm = perm; a.rng = reinterpret_cast<const uint2 *>(rng);
   a.max_nb = max_nb;
   if (ev_before) (void)hipEventRecord(ev_before, st);
-  const bool sorted = perm != nullptr && f32;
+  const bool sorted = perm != nullptr && f32 && !perm_is_placement;
   if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
     hipLaunchKernelGGL(k_depth_order, dim3(nblk2(G, 4)), dim3(256), 0, st, G, tri_off, cand,
                        scaleinv_guard2 < 1e299 ? std::sqrt(scaleinv_guard2) : 1e300, perm, reinterpret_cast<uint2 *>(rng));
@@ -1408,9 +1416,12 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   const size_t lds = score3_lds_bytes(max_nb, f32);
   const long long per_cu = std::max<long long>(1, std::min<long long>(LT_SCORE_RESIDENT, (long long)(160 * 1024 / lds)));
   const dim3 grid((unsigned)std::min<long long>(n_tiles, per_cu * n_cu)), block(64);
-  if (sorted) hipLaunchKernelGGL((k_score3<true, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-  else if (f32) hipLaunchKernelGGL((k_score3<true, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-  else hipLaunchKernelGGL((k_score3<false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+  if (perm_is_placement) {
+    if (f32) hipLaunchKernelGGL((k_score3<true, false, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+    else hipLaunchKernelGGL((k_score3<false, false, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+  } else if (sorted) hipLaunchKernelGGL((k_score3<true, true, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+  else if (f32) hipLaunchKernelGGL((k_score3<true, false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+  else hipLaunchKernelGGL((k_score3<false, false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
 }
 
 }  // namespace lt

@@ -273,3 +273,27 @@ def test_full_size_invariants(gpu_lib, clean_env):
     del os.environ["LT_TEST_NO_SCORE_GUARDS"]
     _same(base, dense)
     assert dense[4]["pairs_eval"] > 10 * base[4]["pairs_eval"]
+
+
+def test_place_by_permutation_equals_place_by_copy(gpu_lib, clean_env):
+    """Matched fast path: k_place writes only perm[final position] = staging slot and every consumer (scoring,
+    selection, edge lists, tail, debug read-outs) reads the records through it; LT_TEST_PLACE_COPY=1 moves the
+    records into compact arrays instead.  Both forms give the same bits everywhere."""
+    sc = syn.make_scene(n_views=24, n_segs=200, n_neighbors=8, seed=12)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+
+    def run():
+        from limap_amd import triangulation as tri
+        T = tri.GlobalLineTriangulator(cfg)
+        T.SetRanges(sc.ranges)
+        T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+        for i in sc.img_ids:
+            T.TriangulateImage(int(i), sc.matches_of(int(i)))
+        return _results(T)
+
+    base = run()
+    os.environ["LT_TEST_PLACE_COPY"] = "1"
+    copy = run()
+    del os.environ["LT_TEST_PLACE_COPY"]
+    _same(base, copy)
+    assert base[5]["candidates"] > 10_000 and base[5]["tracks"] > 50
