@@ -5,22 +5,24 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): synthetic 100 views x 500 segments/view PER GPU, 20
-neighbours, matched mode topk = 10 (10^7 connections per GPU), cfgs/triangulation/default.yaml
-parameters, var2d = 2.0 (LSD).  At N > 1 the scene is N connected rooms with 100 views each
-(weak scaling); every rank owns the 2D segments + poses of its 100 images, and one RCCL
-all-gather over xGMI gives every rank the whole scene before it triangulates its own images.
+Workload (BASELINE.json configs[1]): synthetic 100 views x 500 segments/view PER GPU, 20 neighbours, matched
+mode topk = 10 (10^7 connections per GPU), cfgs/triangulation/default.yaml parameters, var2d = 2.0 (LSD).
+At N > 1 the default is WEAK scaling: N connected rooms with 100 views each; every rank owns the 2D segments +
+poses of its 100 images, and one RCCL all-gather over xGMI gives every rank the whole scene before it
+triangulates its own images.  `--scaling strong` fixes the TOTAL job instead (`--config3` = BASELINE.json
+configs[2]: 1000 views x 1000 segs over 4 rooms, sharded by image with connection-count weights).
 
-One step = [all-gather of the per-image payload (N > 1)] + rebuild of the per-camera / per-segment
-invariants + the whole device pipeline (pair invariants, connection sort, candidate generation,
-compaction, multi-view scoring, per-node arg-max + valid edges) with the match lists already
-resident in HBM.  metric value = 3D line candidates scored per second, whole job.
-The JSON line also carries the end-to-end wall-clock of the reference's API sequence
-(ctor + Init + TriangulateImage x views + ComputeLineTracks, incl. PCIe and the host tail), the
-roofline of the dominant kernel (HIP-event timed on the kernels' stream), and the CPU oracle
-timed on the host cores (rank 0, N = 1 only).
+One step = [all-gather of the per-image payload (N > 1)] + rebuild of the per-camera / per-segment invariants +
+the whole device pipeline (pair invariants, candidate generation, placement, multi-view scoring, per-node
+arg-max + valid edges) with the match lists already resident in HBM.  metric value = 3D line candidates scored
+per second, whole job.  The JSON line also carries the end-to-end wall-clock of the reference's API sequence
+(ctor + Init + TriangulateImage x views + ComputeLineTracks, incl. PCIe and the host tail), the roofline of the
+dominant kernel (HIP-event timed on the kernels' stream) with the FP64-VALU / LDS view next to the HBM one, the
+same measurements for exhaustive matching (CI config 1's mode), and the CPU oracle timed on the host cores with
+a stage-by-stage comparison of its results with the product's (rank 0, N = 1 only; a mismatch fails the run).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,23 +33,37 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TF = 78.6   # MI355X FP64 vector peak (MI355X_MICROARCH.md); nothing here is an MFMA contraction
 # cfgs/triangulation/default.yaml:102-110 (remerging.linker3d)
 REMERGE_LINKER = dict(score_th=0.5, th_angle=5.0, th_overlap=0.001, th_smartoverlap=0.1, th_smartangle=1.0,
                       th_perp=1.0, th_innerseg=1.0)
+DEVICE_SOURCES = ("lt_kernels.hip", "lt_kernels_v2.hip", "lt_kernels_tail.hip", "lt_devfn.h", "lt_geom.h", "lt_device.h")
 
 
-def algorithmic_bytes(stats, n_img_active, nn, survivors):
+def device_source_hash():
+    """Hash of the device code: counter-derived numbers under profiles/ are only quoted for the build they
+    were measured on."""
+    h = hashlib.sha256()
+    for f in DEVICE_SOURCES:
+        with open(os.path.join(ROOT, "limap_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def algorithmic_bytes(stats, n_img_active, nn, survivors, mode):
     """SURVEY.md 8(d): bytes_score = 136 C + 104 nodes + 4 E ;
-    bytes_gen = 8 P + 32 (nodes + N nn M) + 88 N (1 + nn) + 96 C.
-    HOT LOOP 1 runs as two kernels; its bytes are split where the data is touched:
-      k_gates    : every match row (8 P), the segment and camera records (the 32 / 88 terms), and the
-                   list of rows that pass the gates (8 S, S = stage-A survivors; an entry carries the row)
+    bytes_gen = 8 P + 32 (nodes + N nn M) + 88 N (1 + nn) + 96 C, with NO 8 P term in exhaustive mode (the
+    connections are implicit there).
+    Matched mode runs HOT LOOP 1 as two kernels; its bytes are split where the data is touched:
+      k_gates    : every match row (8 P), the segment and camera records (the 32 / 88 terms), and the list of
+                   rows that pass the gates (8 S, S = stage-A survivors; an entry carries the row)
       k_tri_rows : the survivor list (8 S) and the candidate records it emits (96 C)."""
     C, E, P, G = stats["candidates"], stats["valid_edges"], stats["connections"], stats["active_nodes"]
+    rows = 8 * P if mode == "matched" else 0
     score = 136 * C + 104 * G + 4 * E
-    gen = 8 * P + 32 * (G + nn * G) + 88 * n_img_active * (1 + nn) + 96 * C
-    gates = 8 * P + 32 * (G + nn * G) + 88 * n_img_active * (1 + nn) + 8 * survivors
+    gen = rows + 32 * (G + nn * G) + 88 * n_img_active * (1 + nn) + 96 * C
+    gates = rows + 32 * (G + nn * G) + 88 * n_img_active * (1 + nn) + 8 * survivors
     tri = 8 * survivors + 96 * C
     return {"score": score, "gen": gen, "gates": gates, "tri": tri}
 
@@ -89,21 +105,75 @@ def cpu_parity(T, O):
     return ok, rep
 
 
+def load_pmc(world, default_wl):
+    """Counter-derived per-launch numbers (HBM bytes, FP64 VALU flops, LDS bytes) from the rocprofv3 --pmc passes
+    committed under profiles/ -- valid for the default 1-GPU workload and ONLY for the device code they were
+    collected on (source hash recorded in the file); anything else reports null."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    if not (default_wl and world == 1 and os.path.exists(path)):
+        return {}, None
+    d = json.load(open(path))
+    if d.get("device_source_hash") != device_source_hash():
+        return {}, "profiles/r02_pmc.json was collected on different device code: counter-derived fields are null"
+    return d.get("kernels", {}), None
+
+
+def roofline_entry(name, nbytes, ms, pmc):
+    gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    e = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+         "traffic": None, "kernel_ms": ms, "algorithmic_bytes": nbytes}
+    k = pmc.get(name)
+    if k and ms > 0:
+        e["traffic"] = k.get("hbm_bytes")
+        if k.get("valu_flops_f64") is not None:
+            tf = k["valu_flops_f64"] / (ms * 1e-3) / 1e12
+            e["valu_f64"] = {"flops_per_launch": k["valu_flops_f64"], "achieved_tflops": tf, "peak_tflops": FP64_VALU_PEAK_TF,
+                             "frac": tf / FP64_VALU_PEAK_TF, "valu_busy_frac": k.get("valu_busy_frac"),
+                             "valu_insts_per_launch": k.get("valu_insts")}
+        if k.get("lds_active_frac") is not None:
+            e["lds"] = {"active_frac": k["lds_active_frac"], "what": "SQ_ACTIVE_INST_LDS / SQ_BUSY_CU_CYCLES"}
+        fr = {"hbm": e["frac"], "valu_f64": e.get("valu_f64", {}).get("frac", 0.0)}
+        e["nearest_roof"] = max(fr, key=fr.get)
+    return e
+
+
+def feed(ctx, scene, imgs, mode, topk):
+    for i in imgs:
+        if mode == "matched":
+            m = scene.matches_of(int(i), topk)
+            nb = list(m.keys())
+            off = np.zeros(len(nb) + 1, np.int64)
+            off[1:] = np.cumsum([len(m[k]) for k in nb])
+            pairs = np.concatenate([m[k] for k in nb], 0) if nb else np.zeros((0, 2), np.int32)
+            ctx.triangulate_image(int(i), nb, off, pairs)
+        else:
+            ctx.triangulate_image_exhaustive(int(i), scene.neighbors[int(i)])
+    ctx.upload()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--views", type=int, default=100, help="views per GPU")
+    ap.add_argument("--views", type=int, default=100, help="views per GPU (weak scaling) / in total (strong scaling)")
     ap.add_argument("--segs", type=int, default=500)
     ap.add_argument("--neighbors", type=int, default=20)
     ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--rooms", type=int, default=0, help="rooms of the synthetic scene (default: one per 100 views)")
+    ap.add_argument("--gt", type=int, default=0, help="ground-truth 3D segments (default: 600 per room)")
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--mode", default="matched", choices=["matched", "exhaustive"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--config3", action="store_true",
+                    help="BASELINE.json configs[2]: strong scaling, 1000 views x 1000 segs over 4 rooms, 3000 GT segments, seed 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the batches-in-flight extra (profiling runs: its overlapped kernels would mix into the per-kernel stats)")
+                    help="skip the extras (batches in flight, exhaustive leg): profiling runs want the main kernels only")
     args = ap.parse_args()
+    if args.config3:
+        args.scaling, args.views, args.segs, args.rooms, args.gt, args.seed = "strong", 1000, 1000, 4, 3000, 1
 
     import torch
     import torch.distributed as dist
@@ -130,11 +200,22 @@ def main():
     from limap_amd import synthetic as syn
     from limap_amd import dist as ltdist
 
-    n_total = args.views * world
-    scene = syn.make_scene(n_views=n_total, n_segs=args.segs, n_neighbors=args.neighbors, n_rooms=world, seed=0,
-                           topk=args.topk)
+    strong = args.scaling == "strong"
+    n_total = args.views if strong else args.views * world
+    n_rooms = args.rooms or (max(1, n_total // 250) if strong else world)
+    scene = syn.make_scene(n_views=n_total, n_segs=args.segs, n_neighbors=args.neighbors, n_rooms=n_rooms,
+                           n_gt=(args.gt or None), seed=args.seed, topk=args.topk)
     cfg = syn.default_triangulation_cfg()
-    my_imgs = ltdist.shard_images(scene.img_ids, rank, world)
+    # shard by image, balanced by the connections each image brings: matched = rows of its blocks,
+    # exhaustive = its segments x its neighbours' segments
+    n_segs_img = np.diff(scene.seg_off)
+    idx_of = {int(i): n for n, i in enumerate(scene.img_ids)}
+    if args.mode == "matched":
+        weights = np.array([len(scene.neighbors[int(i)]) * n_segs_img[n] * args.topk for n, i in enumerate(scene.img_ids)], float)
+    else:
+        weights = np.array([n_segs_img[n] * sum(n_segs_img[idx_of[j]] for j in scene.neighbors[int(i)])
+                            for n, i in enumerate(scene.img_ids)], float)
+    my_imgs = ltdist.shard_images(scene.img_ids, rank, world, weights)
 
     ctx = _capi.Context(cfg_dict=cfg, device=local_rank)
     stream = torch.cuda.current_stream(dev)
@@ -142,24 +223,14 @@ def main():
     ctx.set_ranges(*scene.ranges)
 
     # ---- scene payload: this rank uploads only its own images, the rest arrives by all-gather ----
-    gather = ltdist.SceneGather(scene.img_ids, scene.seg_off, rank, world, dev, force_collective=use_dist)
+    gather = ltdist.SceneGather(scene.img_ids, scene.seg_off, rank, world, dev, weights=weights, force_collective=use_dist)
     gather.load_local(scene.kvec, scene.qvec, scene.tvec, scene.segs)
     d_k, d_q, d_t, d_s = gather.all_gather()
     ctx.init_device(scene.img_ids, d_k.data_ptr(), d_q.data_ptr(), d_t.data_ptr(), scene.seg_off, d_s.data_ptr())
 
     # ---- this rank's images: buffer + upload the match lists (resident before the timed region) ----
     t_up0 = time.perf_counter()
-    for i in my_imgs:
-        if args.mode == "matched":
-            m = scene.matches_of(int(i), args.topk)
-            nb = list(m.keys())
-            off = np.zeros(len(nb) + 1, np.int64)
-            off[1:] = np.cumsum([len(m[k]) for k in nb])
-            pairs = np.concatenate([m[k] for k in nb], 0) if nb else np.zeros((0, 2), np.int32)
-            ctx.triangulate_image(int(i), nb, off, pairs)
-        else:
-            ctx.triangulate_image_exhaustive(int(i), scene.neighbors[int(i)])
-    ctx.upload()
+    feed(ctx, scene, my_imgs, args.mode, args.topk)
     t_upload = time.perf_counter() - t_up0
 
     # per-step path: the invariants are rebuilt straight from the all-gather's receive buffer
@@ -194,6 +265,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    ctx.sync()
+    torch.cuda.synchronize(dev)
+    elapsed_local = time.perf_counter() - t0   # this rank alone (load imbalance shows here)
     sync()
     elapsed = time.perf_counter() - t0
     acc, n_runs = ctx.timer_sums()  # the library sums its HIP-event timings over the runs (no per-step readout)
@@ -208,16 +282,29 @@ def main():
         torch.cuda.synchronize(dev)
     kt = {k: v / max(args.steps, 1) for k, v in acc.items()}  # average HIP-event ms per launch
 
+    # the collective alone (what the overlap hides): 10 all-gathers back to back
+    allgather_us = None
+    if use_dist:
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        ta = time.perf_counter()
+        for _ in range(10):
+            gather.gather_only()
+        torch.cuda.synchronize(dev)
+        allgather_us = 1e6 * (time.perf_counter() - ta) / 10
+
     # results of the last step -> host, then the tail (not part of the timed step)
     ctx.download()
     st = ctx.stats()
     st["active_nodes"] = int(sum(scene.seg_off[j + 1] - scene.seg_off[j] for j in
                                  np.searchsorted(scene.img_ids, my_imgs)))
     # N > 1: rank 0 imports the other shards' per-node results and runs the tail for the whole scene
-    merge_note = None
+    merge_note, t_merge = None, None
     if world > 1:
         try:
-            ltdist.merge_shards_on_rank0(ctx, my_imgs, rank, world)
+            tm0 = time.perf_counter()
+            ltdist.merge_shards_on_rank0(ctx, my_imgs, rank, world, dev)
+            t_merge = time.perf_counter() - tm0
         except Exception as e:  # never lose the throughput line over the (untimed) merge
             merge_note = f"merge failed: {type(e).__name__}: {e}"
     t_tail0 = time.perf_counter()
@@ -225,6 +312,7 @@ def main():
     t_tail = time.perf_counter() - t_tail0
     st_after = ctx.stats()
 
+    per_rank_ms = [1e3 * elapsed_local / max(args.steps, 1)]
     if use_dist:
         t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
@@ -232,16 +320,27 @@ def main():
         tot = torch.tensor([st["candidates"], st["connections"], st["pairs"]], dtype=torch.float64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         cand_total, conn_total, pairs_total = [float(x) for x in tot.tolist()]
+        loc = torch.tensor([per_rank_ms[0], float(st["candidates"]), float(len(my_imgs))], dtype=torch.float64, device=dev)
+        allr = torch.zeros(3 * world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, loc)
+        allr = allr.cpu().numpy().reshape(world, 3)
+        per_rank_ms = allr[:, 0].tolist()
+        per_rank_cand, per_rank_imgs = allr[:, 1].tolist(), allr[:, 2].tolist()
     else:
         cand_total, conn_total, pairs_total = float(st["candidates"]), float(st["connections"]), float(st["pairs"])
+        per_rank_cand, per_rank_imgs = [float(st["candidates"])], [float(len(my_imgs))]
 
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     value = cand_total * args.steps / elapsed
 
     out = None
     parity_ok = True
+    default_wl = (args.views, args.segs, args.neighbors, args.topk, args.scaling, args.seed, args.rooms, args.gt) == \
+                 (100, 500, 20, 10, "weak", 0, 0, 0)
+    pmc_all, pmc_note = load_pmc(world, default_wl)
     if rank == 0:
-        ab = algorithmic_bytes(st, len(my_imgs), args.neighbors, kt.get("survivors", 0.0))
+        ab = algorithmic_bytes(st, len(my_imgs), args.neighbors, kt.get("survivors", 0.0), args.mode)
+        pmc = pmc_all.get(args.mode, {})
         # per-KERNEL durations: HIP events recorded on the launch stream right around each kernel
         # (lt_get_timers [13]-[15]); "gen" is the two-kernel stage HOT LOOP 1 for continuity with round-1 lines
         if args.mode == "matched":
@@ -250,45 +349,38 @@ def main():
         else:
             kernels = {"k_score3": (ab["score"], kt.get("k_score3", 0.0)), "k_gen_exhaustive": (ab["gen"], kt.get("gen", 0.0))}
         dom = max(kernels, key=lambda k: kernels[k][1])
-        roof = {}
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate runs, gfx950 FETCH_SIZE x2 correction) -- valid for the default workload only
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        default_wl = (args.views, args.segs, args.neighbors, args.topk, args.mode, world) == (100, 500, 20, 10, "matched", 1)
-        if default_wl and os.path.exists(tpath):
-            tk = json.load(open(tpath))["kernels"]
-            traffic = {k: tk.get(k, {}).get("hbm_bytes") for k in kernels}
-        for name, (nbytes, ms) in kernels.items():
-            gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            roof[name] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(name), "kernel_ms": ms,
-                          "algorithmic_bytes": nbytes}
+        roof = {name: roofline_entry(name, nbytes, ms, pmc) for name, (nbytes, ms) in kernels.items()}
         if args.mode == "matched" and kt.get("gen", 0.0) > 0:
-            gbs = ab["gen"] / (kt["gen"] * 1e-3) / 1e9
-            roof["stage_gen(k_gates+k_tri_rows)"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                     "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kt["gen"],
-                                                     "algorithmic_bytes": ab["gen"]}
+            roof["stage_gen(k_gates+k_tri_rows)"] = roofline_entry("stage_gen", ab["gen"], kt["gen"], {})
+        wl = (f"synthetic {args.views} views x {args.segs} segs/view " + ("in total" if strong else "per GPU")
+              + f", {n_rooms} room(s), {args.neighbors} neighbours, {args.mode}"
+              + (f" topk={args.topk}" if args.mode == "matched" else "")
+              + ", cfgs/triangulation/default.yaml params, var2d=2.0")
         out = {
-            "metric": "3D line candidates scored/sec (100 views x 500 segs per GPU, matched topk=10)"
-                      if args.mode == "matched" else "3D line candidates scored/sec (exhaustive)",
+            "metric": ("3D line candidates scored/sec (" + ("100 views x 500 segs per GPU" if default_wl else wl.split(",")[0])
+                       + (", matched topk=%d)" % args.topk if args.mode == "matched" else ", exhaustive)")),
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.views} views x {args.segs} segs/view per GPU, "
-                                   f"{args.neighbors} neighbours, {args.mode}"
-                                   + (f" topk={args.topk}" if args.mode == "matched" else "")
-                                   + ", cfgs/triangulation/default.yaml params, var2d=2.0",
-                       "views_total": n_total, "segs_per_view": args.segs, "n_neighbors": args.neighbors,
-                       "mode": args.mode, "topk": args.topk, "parallelism": f"shard-by-image x{world}"},
+            "config": {"workload": wl, "views_total": n_total, "segs_per_view": args.segs, "n_neighbors": args.neighbors,
+                       "mode": args.mode, "topk": args.topk, "parallelism": f"shard-by-image x{world}",
+                       "scene_seed": args.seed, "rooms": n_rooms},
             "counts": {"connections": conn_total, "candidates": cand_total, "scoring_pairs": pairs_total,
                        "valid_edges_rank0": st["valid_edges"], "tracks_rank0": st_after["tracks"]},
             "kernel_ms": kt,
             "connections_per_s": conn_total * args.steps / elapsed,
             "roofline": dict(roof[dom], kernel=dom),
             "roofline_all": roof,
-            "host_ms": {"upload_matches": 1e3 * t_upload, "tail_compute_tracks": 1e3 * t_tail},
+            "roofline_note": pmc_note or ("traffic / valu_f64 / lds: rocprofv3 --pmc passes over this exact device code "
+                                          "(profiles/r02_pmc.json, tools/prof_pmc_json.sh); FP64 VALU peak 78.6 TF"),
+            "host_ms": {"upload_matches": 1e3 * t_upload, "tail_compute_tracks": 1e3 * t_tail,
+                        "merge_shards_on_rank0": None if t_merge is None else 1e3 * t_merge},
             "tracks_whole_scene": st_after["tracks"], "merge_note": merge_note,
+            "ranks": {"world_size": dist.get_world_size() if use_dist else 1,
+                      "backend": (dist.get_backend() + " (RCCL)") if use_dist else None,
+                      "ms_per_step_per_rank": per_rank_ms, "candidates_per_rank": per_rank_cand,
+                      "images_per_rank": per_rank_imgs, "allgather_alone_us": allgather_us},
+            "device_source_hash": device_source_hash(),
         }
 
     # ---- extra (not `value`): independent batches in flight, N = 1 ----
@@ -301,13 +393,7 @@ def main():
             c = _capi.Context(cfg_dict=cfg, device=local_rank)
             c.set_ranges(*scene.ranges)
             c.init(scene.img_ids, scene.kvec, scene.qvec, scene.tvec, scene.seg_off, scene.segs)
-            for i in my_imgs:
-                m = scene.matches_of(int(i), args.topk)
-                nb = list(m.keys())
-                off = np.zeros(len(nb) + 1, np.int64)
-                off[1:] = np.cumsum([len(m[k]) for k in nb])
-                c.triangulate_image(int(i), nb, off, np.concatenate([m[k] for k in nb], 0) if nb else np.zeros((0, 2), np.int32))
-            c.upload()
+            feed(c, scene, my_imgs, "matched", args.topk)
             return c
         try:
             pool = [make_ctx(), make_ctx()]
@@ -334,6 +420,40 @@ def main():
         except Exception as e:  # an extra: never lose the main line over it
             out["batches_in_flight"] = {"error": f"{type(e).__name__}: {e}"}
 
+    # ---- extra: the same scene with exhaustive matching (CI config 1's mode), N = 1 ----
+    if rank == 0 and world == 1 and args.mode == "matched" and default_wl and not args.no_extras:
+        try:
+            cx = _capi.Context(cfg_dict=cfg, device=local_rank)
+            cx.set_ranges(*scene.ranges)
+            cx.init(scene.img_ids, scene.kvec, scene.qvec, scene.tvec, scene.seg_off, scene.segs)
+            feed(cx, scene, my_imgs, "exhaustive", args.topk)
+            n_x = max(3, min(args.steps, 8))
+            cx.run_device(wait=True)
+            cx.timer_sums(reset=True)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n_x):
+                cx.run_device(wait=False)
+            cx.sync()
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            accx, _ = cx.timer_sums()
+            ktx = {k: v / n_x for k, v in accx.items()}
+            cx.download()
+            sx = cx.stats()
+            sx["active_nodes"] = st["active_nodes"]
+            abx = algorithmic_bytes(sx, len(my_imgs), args.neighbors, 0.0, "exhaustive")
+            pmx = pmc_all.get("exhaustive", {})
+            rx = {"k_score3": roofline_entry("k_score3", abx["score"], ktx.get("k_score3", 0.0), pmx),
+                  "k_gen_exhaustive": roofline_entry("k_gen_exhaustive", abx["gen"], ktx.get("gen", 0.0), pmx)}
+            out["exhaustive"] = {"ms_per_step": 1e3 * el / n_x, "value": sx["candidates"] * n_x / el, "unit": "candidates/s",
+                                 "steps": n_x, "counts": {k: sx[k] for k in ("connections", "candidates", "pairs", "valid_edges")},
+                                 "kernel_ms": {k: ktx[k] for k in ("run", "gen", "compact", "score", "select", "k_score3")},
+                                 "roofline": rx, "note": "same scene, TriangulateImageExhaustiveMatch; run only (no scene refresh)"}
+            del cx
+        except Exception as e:
+            out["exhaustive"] = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- end-to-end wall-clock through the reference's API sequence, rank 0 / N = 1 ----
     if rank == 0 and world == 1:
         from limap_amd import triangulation as tri
@@ -359,7 +479,6 @@ def main():
             t2 = time.perf_counter()
             tracks_py = T.ComputeLineTracks()  # the call the runner makes (line_triangulation.py:168): returns the tracks
             e2e.append(time.perf_counter() - t0)
-            assert len(tracks_py) == st_after["tracks"] or args.mode != "matched" or world != 1
             gc.enable()
             e2e_parts = {"ctor_init": 1e3 * (t1 - t0), "buffer": 1e3 * (t2 - t1), "compute_tracks": 1e3 * (e2e[-1] - (t2 - t0)),
                          "buffer_native": T.timers().get("buffer", 0.0)}
@@ -367,6 +486,7 @@ def main():
             tm = T.timers()
             if rep == 2:  # the steps that follow in line_triangulation(): filters + remerge (cfg defaults)
                 from limap_amd import merging
+                assert len(tracks_py) == st_after["tracks"] or world != 1
                 tp0 = time.perf_counter()
                 ts = merging.TrackSet.from_triangulator(T)
                 ts.filter_by_reprojection(8.0, 5.0).remerge(REMERGE_LINKER).filter_by_reprojection(8.0, 5.0)
@@ -386,34 +506,47 @@ def main():
         if not args.no_cpu_baseline:
             from oracle import oracle as ora
             ora.build()
-            nthreads = args.cpu_threads or min(os.cpu_count() or 1, 16)
-            ora.set_num_threads(nthreads)
+            n_cores = os.cpu_count() or 1
+            cpu_model = None
+            try:
+                cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+            except Exception:
+                pass
+            nthreads = args.cpu_threads or min(n_cores, 16)
+
+            def run_cpu(mod, images, faithful, threads, exhaustive=False, tracks=True):
+                mod.set_num_threads(threads)
+                O = mod.OracleTriangulator(cfg, faithful=faithful)
+                t0 = time.perf_counter()
+                O.SetRanges(scene.ranges)
+                O.Init(scene.img_ids, scene.kvec, scene.qvec, scene.tvec, scene.seg_off, scene.segs)
+                for i in images:
+                    if exhaustive:
+                        O.TriangulateImageExhaustiveMatch(int(i), scene.neighbors[int(i)])
+                    else:
+                        O.TriangulateImage(int(i), matches[int(i)])
+                if tracks:
+                    O.ComputeLineTracks()
+                return O, time.perf_counter() - t0
+
             # bounded sample: the same scene, first `n_s` images triangulated (all images as neighbours)
             n_s = min(len(scene.img_ids), 100 if args.mode == "matched" else 4)
-            O = ora.OracleTriangulator(cfg, faithful=True)
-            t0 = time.perf_counter()
-            O.SetRanges(scene.ranges)
-            O.Init(scene.img_ids, scene.kvec, scene.qvec, scene.tvec, scene.seg_off, scene.segs)
-            for i in scene.img_ids[:n_s]:
-                if args.mode == "matched":
-                    O.TriangulateImage(int(i), matches[int(i)])
-                else:
-                    O.TriangulateImageExhaustiveMatch(int(i), scene.neighbors[int(i)])
-            O.ComputeLineTracks()
-            cpu_s = time.perf_counter() - t0
+            O, cpu_s = run_cpu(ora, scene.img_ids[:n_s], True, nthreads, exhaustive=args.mode != "matched")
             so = O.stats()
             tp0 = time.perf_counter()
             ots = ora.OracleTrackSet(O)
             ots.filter_by_reprojection(8.0, 5.0); ots.remerge(REMERGE_LINKER); ots.filter_by_reprojection(8.0, 5.0)
             ots.filter_by_sensitivity(75.0, 3); ots.filter_by_overlap(0.5, 3)
             cpu_post_s, cpu_post_tracks = time.perf_counter() - tp0, ots.num_tracks()
+            flags = "g++ -O2 -fopenmp -ffp-contract=off"
             out["cpu_baseline"] = {
                 "value": so["candidates"] / cpu_s, "unit": "candidates/s", "cores": nthreads, "kind": "port",
-                "sample": f"oracle (reference-faithful mode, g++ -O2 -fopenmp, {nthreads} OpenMP threads): "
-                          f"Init + TriangulateImage on {n_s} of {len(scene.img_ids)} images + ComputeLineTracks, "
+                "sample": f"oracle (reference-faithful mode: by-value camview copies, per-call R()/K_inv(); {flags}, {nthreads} OpenMP "
+                          f"threads): Init + TriangulateImage on {n_s} of {len(scene.img_ids)} images + ComputeLineTracks, "
                           f"{so['connections']} connections, {so['candidates']} candidates",
                 "wall_s": cpu_s, "timers_s": O.timers(),
                 "postprocess_s": cpu_post_s, "postprocess_tracks_after": cpu_post_tracks,
+                "host": {"logical_cpus": n_cores, "cpu_model": cpu_model},
             }
             if n_s == len(scene.img_ids):
                 out["e2e_speedup_vs_cpu"] = cpu_s / (out["e2e_wall_ms"] * 1e-3)
@@ -431,6 +564,58 @@ def main():
                 T_last.ComputeLineTracks()
             parity_ok, out["cpu_parity"] = cpu_parity(T_last, O)
             out["cpu_parity"]["images"] = n_s
+            del O
+            if args.mode == "matched" and default_wl and not args.no_extras:
+                # the other CPU figures SURVEY 8(d) asks for, so that the GPU/CPU ratio is not read off one number:
+                # one thread (per-core cost, no fork/join), hoisted invariants ("optimised CPU"), and the REFERENCE'S
+                # OWN SOURCES (oracle/_ref, Eigen replaced by the stand-in headers) where that library travelled
+                n1 = 8
+                O1, s1 = run_cpu(ora, scene.img_ids[:n1], True, 1, tracks=False)
+                out["cpu_baseline_1thread"] = {"value": O1.stats()["candidates"] / s1, "unit": "candidates/s", "cores": 1,
+                                               "kind": "port", "wall_s": s1,
+                                               "sample": f"reference-faithful oracle, 1 thread, {n1} of {len(scene.img_ids)} images, no tail"}
+                O2, s2 = run_cpu(ora, scene.img_ids, False, nthreads)
+                out["cpu_baseline_optimised"] = {"value": O2.stats()["candidates"] / s2, "unit": "candidates/s", "cores": nthreads,
+                                                 "kind": "port", "wall_s": s2, "timers_s": O2.timers(),
+                                                 "sample": "oracle with the per-camera invariants hoisted (no by-value camview copies), "
+                                                           f"{nthreads} threads, all images + ComputeLineTracks"}
+                del O1, O2
+                try:
+                    from oracle import ref as oref
+                    if os.path.exists(oref.LIB_PATH):
+                        R = oref.module()
+                        O3, s3 = run_cpu(R, scene.img_ids, True, nthreads)
+                        out["cpu_baseline_reference_build"] = {
+                            "value": O3.stats()["candidates"] / s3, "unit": "candidates/s", "cores": nthreads, "kind": "reference",
+                            "wall_s": s3, "tracks": O3.stats()["tracks"],
+                            "sample": "oracle/_ref: limap::triangulation::GlobalLineTriangulator compiled from the reference's own "
+                                      "sources (Eigen / COLMAP / PoseLib = stand-in headers, so slower than a real Eigen build), "
+                                      f"{nthreads} threads, all images + ComputeLineTracks"}
+                        del O3
+                except Exception as e:
+                    out["cpu_baseline_reference_build"] = {"error": f"{type(e).__name__}: {e}"}
+                ora.set_num_threads(nthreads)
+            # exhaustive leg: parity of the product with the oracle on an image subset
+            if "exhaustive" in out and "error" not in out["exhaustive"]:
+                try:
+                    sub = [int(i) for i in scene.img_ids[:4]]
+                    Tx = tri.GlobalLineTriangulator(cfg, device=local_rank)
+                    Tx.SetRanges(scene.ranges)
+                    Tx.InitArrays(scene.img_ids, scene.kvec, scene.qvec, scene.tvec, segs_list)
+                    for i in sub:
+                        Tx.TriangulateImageExhaustiveMatch(i, scene.neighbors[i])
+                    Tx.ComputeLineTracks()
+                    Ox, sx_s = run_cpu(ora, sub, True, nthreads, exhaustive=True)
+                    okx, repx = cpu_parity(Tx, Ox)
+                    repx["images"] = len(sub)
+                    out["exhaustive"]["cpu_parity"] = repx
+                    out["exhaustive"]["cpu_baseline"] = {"value": Ox.stats()["candidates"] / sx_s, "unit": "candidates/s",
+                                                         "cores": nthreads, "kind": "port", "wall_s": sx_s,
+                                                         "sample": f"reference-faithful oracle, {len(sub)} images exhaustive + tail"}
+                    parity_ok = parity_ok and okx
+                    del Tx, Ox
+                except Exception as e:
+                    out["exhaustive"]["cpu_parity"] = {"error": f"{type(e).__name__}: {e}"}
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,78 @@
+#!/bin/bash
+# Counter-derived per-launch numbers for bench.py's roofline block -> gpurun_out/r02_pmc.json (copy to profiles/).
+#   HBM bytes     : FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (MI355X_MICROARCH.md: kernel
+#                   dispatch only, FETCH_SIZE x2 on gfx950, both counters in KiB)
+#   FP64 VALU     : SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 (wave-level instructions: x64 lanes, FMA = 2 flops)
+#   VALU / LDS    : SQ_ACTIVE_INST_VALU, SQ_ACTIVE_INST_LDS, SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT against
+#                   SQ_BUSY_CU_CYCLES / SQ_WAVE_CYCLES
+# for the matched default workload and for the exhaustive mode of the same scene.  The file records the hash of
+# the device sources; bench.py quotes the numbers only while that hash matches.
+# usage (on the GPU box, repo root): bash tools/prof_pmc_json.sh
+repo=$(pwd)
+export TMPDIR=/tmp
+mkdir -p $repo/gpurun_out
+groups=(
+"FETCH_SIZE"
+"WRITE_SIZE"
+"SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_WAVES"
+"SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"
+"SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+)
+for mode in matched exhaustive; do
+  i=0
+  : > $repo/gpurun_out/pmcj_$mode.csv
+  for g in "${groups[@]}"; do
+    i=$((i+1))
+    cd /tmp && rm -rf /tmp/pmcj_${mode}_$i
+    steps=3; [ $mode = exhaustive ] && steps=2
+    timeout 300 rocprofv3 --pmc $g -d /tmp/pmcj_${mode}_$i -- python $repo/bench.py --steps $steps --warmup 1 --mode $mode --no-cpu-baseline --no-extras > /dev/null 2> /tmp/pmcj_${mode}_$i.err || { echo "# group $i failed: $g"; tail -3 /tmp/pmcj_${mode}_$i.err; continue; }
+    db=$(find /tmp/pmcj_${mode}_$i -name "*.db" | head -1)
+    python $repo/tools/rocpd_pmc.py $db 2>/dev/null >> $repo/gpurun_out/pmcj_$mode.csv
+  done
+done
+cd $repo && python - <<'PY'
+import csv, json, re, sys
+sys.path.insert(0, ".")
+import bench
+out = {"device_source_hash": bench.device_source_hash(),
+       "workload": "bench.py default scene (100 views x 500 segs, nn 20): matched topk 10 / exhaustive",
+       "how": "tools/prof_pmc_json.sh: one rocprofv3 --pmc pass per counter group, kernel dispatch only; averages per launch",
+       "units": {"hbm_bytes": "bytes per launch = 2 x 1024 x FETCH_SIZE + 1024 x WRITE_SIZE (gfx950 correction, KiB counters)",
+                 "valu_flops_f64": "64 x (ADD + MUL + TRANS) + 128 x FMA wave-level FP64 instructions",
+                 "valu_busy_frac": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES... see raw", "lds_active_frac": "SQ_ACTIVE_INST_LDS / SQ_BUSY_CU_CYCLES"},
+       "kernels": {}}
+alias = {"k_gen_ex_block": "k_gen_exhaustive"}
+for mode in ("matched", "exhaustive"):
+    vals = {}
+    try:
+        rows = list(csv.reader(open(f"gpurun_out/pmcj_{mode}.csv")))
+    except FileNotFoundError:
+        continue
+    for row in rows:
+        if len(row) != 5 or row[0] == "kernel":
+            continue
+        m = re.search(r"(k_[a-z_0-9]+)", row[0])
+        if not m:
+            continue
+        vals.setdefault(m.group(1), {})[row[1]] = float(row[3])
+    kern = {}
+    for name, v in vals.items():
+        k = {"raw": v}
+        if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
+            k["hbm_bytes"] = 2.0 * 1024.0 * v.get("FETCH_SIZE", 0.0) + 1024.0 * v.get("WRITE_SIZE", 0.0)
+        if "SQ_INSTS_VALU_FMA_F64" in v:
+            k["valu_flops_f64"] = 64.0 * (v.get("SQ_INSTS_VALU_ADD_F64", 0) + v.get("SQ_INSTS_VALU_MUL_F64", 0)
+                                          + v.get("SQ_INSTS_VALU_TRANS_F64", 0)) + 128.0 * v["SQ_INSTS_VALU_FMA_F64"]
+            k["valu_insts"] = v.get("SQ_INSTS_VALU")
+        if v.get("SQ_BUSY_CU_CYCLES"):
+            k["valu_busy_frac"] = v.get("SQ_ACTIVE_INST_VALU", 0.0) / v["SQ_BUSY_CU_CYCLES"]
+            k["lds_active_frac"] = v.get("SQ_ACTIVE_INST_LDS", 0.0) / v["SQ_BUSY_CU_CYCLES"]
+        kern[alias.get(name, name)] = k
+    # the exhaustive generation is two passes of k_gen_ex_block per run: the per-launch average x 2 is the stage
+    out["kernels"][mode] = kern
+json.dump(out, open("gpurun_out/r02_pmc.json", "w"), indent=1)
+for mode, kern in out["kernels"].items():
+    for n in ("k_score3", "k_gates", "k_tri_rows", "k_place", "k_gen_exhaustive"):
+        if n in kern:
+            print(mode, n, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in kern[n].items() if a != "raw"})
+PY
