@@ -65,7 +65,9 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
-                   bool f32, unsigned *perm, void *rng, bool perm_is_placement);
+                   bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
+                   unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap);
+int score3_tile_buckets();
 }
 
 // ---- pooled page-locked host blocks (see lt_ctx.h) ----
@@ -570,7 +572,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
                     &ctx->d_pair_counter, &ctx->d_result3, &ctx->d_tile_order, &ctx->d_scan_status, &ctx->d_perm, &ctx->d_rng, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz,
-                    &ctx->d_place_perm, &ctx->d_tail_keys, &ctx->d_tail_skeys, &ctx->d_tail_sims, &ctx->d_tail_mark,
+                    &ctx->d_place_perm, &ctx->d_tile_list, &ctx->d_exp_tile_order, &ctx->d_tail_keys, &ctx->d_tail_skeys, &ctx->d_tail_sims, &ctx->d_tail_mark,
                     &ctx->d_tail_pos, &ctx->d_tail_recs, &ctx->d_tail_nodes, &ctx->d_tail_tmp, &ctx->d_tail_keep,
                     &ctx->d_tail_kpos};
   lt_host::host_block_release(ctx->h_pinned_blk);
@@ -1235,6 +1237,32 @@ int finish_run(lt_ctx *ctx) {
   if (fine_timers() && ctx->C_last > 0 && hipEventElapsedTime(&ms, ev[11], ev[5]) == hipSuccess) ctx->timers[15] = ms;
   (void)hipGetLastError();
   ctx->timers[11] = (double)ctx->stat_pairs_eval;
+  if (const char *mode = getenv("LT_EXP_TILE_ORDER")) {  // developer experiment: tile order from the node sizes of this run
+    if (ctx->exp_tile_order_C != ctx->C_last && ctx->C_last > 0 && ctx->job_mode == 1) {
+      const long long G = ctx->G, C = ctx->C_last;
+      std::vector<long long> off((size_t)G + 1);
+      HIPCHK(ctx, hipMemcpy(off.data(), ctx->d_tri_off.p, 8 * (size_t)(G + 1), hipMemcpyDeviceToHost));
+      const long long nt = (C + 63) / 64;
+      std::vector<long long> cost((size_t)nt, 0);
+      for (long long g = 0; g < G; ++g) {
+        const long long n = off[g + 1] - off[g];
+        for (long long c = off[g]; c < off[g + 1]; ++c) cost[(size_t)(c >> 6)] += n;
+      }
+      std::vector<unsigned> order((size_t)nt);
+      for (long long t = 0; t < nt; ++t) order[(size_t)t] = (unsigned)t;
+      if (mode[0] == 'l') {  // lpt
+        std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return cost[x] > cost[y]; });
+      } else {  // cheapest 30 % last, natural order inside the classes
+        std::vector<long long> sorted(cost);
+        std::sort(sorted.begin(), sorted.end());
+        const long long thr = sorted[(size_t)(0.3 * (double)nt)];
+        std::stable_partition(order.begin(), order.end(), [&](unsigned x) { return cost[x] > thr; });
+      }
+      ENSURE(ctx, ctx->d_exp_tile_order, 4 * (size_t)nt);
+      HIPCHK(ctx, hipMemcpy(ctx->d_exp_tile_order.p, order.data(), 4 * (size_t)nt, hipMemcpyHostToDevice));
+      ctx->exp_tile_order_C = C;
+    }
+  }
   for (int k = 0; k < 24; ++k)  // [16] (survivors) is counted on demand by lt_get_timers, not per run
     if (k != 8 && k != 9 && k != 10 && k != 12 && k != 16) ctx->timer_sums[k] += ctx->timers[k];
   ++ctx->timer_runs;
@@ -1272,7 +1300,9 @@ int lt_run_device_async(lt_ctx *ctx) {
   ENSURE(ctx, ctx->d_tri_off, sizeof(long long) * (size_t)(G + 1));
   HIPCHK(ctx, hipEventRecord(ev[0], st));
   // also zeroes the error flag, the pair statistic and the look-back state of k_node_prefix's scan
-  const int n_status = (int)((G + 1 + 255) / 256) + 1;
+  // (+ the tile cost-class counters of k_cand_meta / k_score3 behind the scan's words: zeroed by the same kernel)
+  const int n_status_scan = (int)((G + 1 + 255) / 256) + 1;
+  const int n_status = n_status_scan + score3_tile_buckets() * 16;  // counters 128 bytes apart
   ENSURE(ctx, ctx->d_scan_status, 8 * (size_t)n_status);
   launch_build_pairs(st, ctx->n_blk, ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_cams.as<Cam>(),
                      ctx->d_pairs.as<PairRec>(), ctx->d_err.as<int>(),
@@ -1545,6 +1575,10 @@ int lt_run_device_async(lt_ctx *ctx) {
       return fail(ctx, LT_ERR_ARGUMENT, "too many (image, neighbour) blocks in one batch (>= 2^24)");
     ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_bound, 1));
     ENSURE(ctx, ctx->d_tile_order, 1024);  // the tile draw counters of k_score3 (8 x 128 B)
+    // tiles listed by cost class (LT_TEST_NO_TILE_CLASSES: natural tile order)
+    const bool tile_classes = !getenv("LT_TEST_NO_TILE_CLASSES");
+    const unsigned tile_cap = (unsigned)(((std::max<long long>(C_bound, 1) + 63) / 64 + 7) / 8);  // tiles of one draw queue
+    if (tile_classes) ENSURE(ctx, ctx->d_tile_list, 4 * (size_t)tile_cap * (size_t)score3_tile_buckets());
     // large nodes (exhaustive matching): depth-sorted sweep, see k_depth_order
     const bool score_sorted = score_f32 && ctx->job_mode == 2 && !getenv("LT_TEST_SCORE_UNSORTED");
     if (score_sorted) {
@@ -1559,7 +1593,11 @@ int lt_run_device_async(lt_ctx *ctx) {
                   ctx->d_score.as<double>(), ctx->d_pair_counter.as<unsigned long long>(), ctx->max_nb, scfg,
                   guard2, fine_timers() ? ev[11] : nullptr, ctx->d_tile_order.as<unsigned>(), score_f32,
                   ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : (score_sorted ? ctx->d_perm.as<unsigned>() : nullptr),
-                  score_sorted ? ctx->d_rng.p : nullptr, ctx->perm_mode);
+                  score_sorted ? ctx->d_rng.p : nullptr, ctx->perm_mode,
+                  (ctx->exp_tile_order_C == C_bound || ctx->exp_tile_order_C == ctx->C_last) && ctx->exp_tile_order_C > 0
+                      ? ctx->d_exp_tile_order.as<unsigned>() : nullptr,
+                  tile_classes ? (unsigned *)(ctx->d_scan_status.as<unsigned long long>() + n_status_scan) : nullptr,
+                  tile_classes ? ctx->d_tile_list.as<unsigned>() : nullptr, tile_cap);
   }
   HIPCHK(ctx, hipEventRecord(ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));

@@ -204,11 +204,14 @@ struct lt_ctx {
   DevBuf d_result3;          // the run's result scalars (candidate count, error flag, pair statistic), one record
   DevBuf d_scan_status;      // k_node_prefix: ticket counter + per-tile look-back state
   DevBuf d_tile_order;       // k_score3: tile draw counters
+  DevBuf d_tile_list;        // k_score3: tiles by cost class (kTileBuckets lists of cand_cap / 64 entries)
   DevBuf d_base_bl;          // exclusive prefix of cnt_bl over the neighbour blocks of a node
   // matched fast path: the candidate records stay in the staging lists of stage B; k_place writes only
   // place_perm[final position] = staging slot, and every consumer reads through it (LT_TEST_PLACE_COPY=1: the
   // records are moved into compact arrays instead, as the generic and exhaustive paths do)
   DevBuf d_place_perm;
+  DevBuf d_exp_tile_order;     // developer experiment LT_EXP_TILE_ORDER
+  long long exp_tile_order_C = -1;
   bool perm_mode = false;      // the last run left its candidates in the staging lists
   bool compact_valid = false;  // d_cand / d_lite hold the compact arrays of the last run
   DevBuf d_tail_keys, d_tail_skeys, d_tail_sims, d_tail_mark, d_tail_pos, d_tail_recs, d_tail_nodes, d_tail_tmp, d_tail_keep, d_tail_kpos;  // lt_kernels_tail.hip

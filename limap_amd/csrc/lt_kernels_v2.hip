@@ -783,28 +783,57 @@ __global__ void k_permute(long long C, const unsigned *__restrict__ skeys, const
   cand_node[t] = skeys[t];
 }
 
-// Also resets the tile draw counters of the persistent k_score3 that follows.
+// Also resets the tile draw counters of the persistent k_score3 that follows, and lists the tiles (64 consecutive
+// candidates = what one wave of this kernel handles per iteration) by COST CLASS: a tile's time in k_score3 grows
+// with the sizes of the nodes it touches (correlation 0.62 with the sum over its lanes of the node size), and a
+// persistent grid finishes earlier when the long tiles start first -- measured on the bench scene: k_score3
+// 138 -> 127 us with the tiles in descending cost order.  No sort: per draw queue kTileBuckets lists filled through
+// one counter each (zeroed by k_build_pairs), drawn from the most expensive class down; the order inside a class
+// is arbitrary.
 constexpr int kTileQueues = 8;  // one draw counter per XCD (workgroups are dealt round-robin to the XCDs)
+constexpr int kTileBuckets = 32;
+__device__ __forceinline__ int tile_bucket(unsigned cost_sum_n) {  // mean node size over the 64 lanes, 2 per class
+  const unsigned b = cost_sum_n >> 7;
+  return (int)(b < (unsigned)(kTileBuckets - 1) ? b : (unsigned)(kTileBuckets - 1));
+}
 __global__ void __launch_bounds__(256)
 k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long *__restrict__ tri_off,
             const int *__restrict__ node_img, const long long *__restrict__ nb_off, CandMeta *__restrict__ meta,
-            unsigned *__restrict__ draw) {
+            unsigned *__restrict__ draw, unsigned *__restrict__ bucket_cnt, unsigned *__restrict__ bucket_list,
+            unsigned bucket_cap) {
   // grid-stride over the exact candidate count tri_off[G]; the host may only know an upper bound
   const long long C = tri_off[G];
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kTileQueues) draw[i * 32] = 0;  // 128 bytes apart
-  for (; i < C; i += stride) {
-    const unsigned g = cand_node[i];
-    const long long off = tri_off[g];
-    const int img = node_img[g];
-    const long long nb0 = nb_off[img];
-    CandMeta m;
-    m.off_lo = (unsigned)(off & 0xFFFFFFFFll);
-    m.off_hi = (unsigned)(off >> 32);
-    m.n = (unsigned)(tri_off[g + 1] - off);
-    m.nb = ((unsigned)nb0 << 8) | (unsigned)(nb_off[img + 1] - nb0);
-    meta[i] = m;
+  const long long C_up = (C + 63) & ~63ll;  // whole waves take part in the tile's reduction
+  for (; i < C_up; i += stride) {
+    unsigned n = 0;
+    if (i < C) {
+      const unsigned g = cand_node[i];
+      const long long off = tri_off[g];
+      const int img = node_img[g];
+      const long long nb0 = nb_off[img];
+      CandMeta m;
+      m.off_lo = (unsigned)(off & 0xFFFFFFFFll);
+      m.off_hi = (unsigned)(off >> 32);
+      m.n = (unsigned)(tri_off[g + 1] - off);
+      m.nb = ((unsigned)nb0 << 8) | (unsigned)(nb_off[img + 1] - nb0);
+      meta[i] = m;
+      n = m.n;
+    }
+    if (bucket_cnt) {
+      unsigned sum = n;
+      for (int d = 32; d >= 1; d >>= 1) sum += (unsigned)__shfl_xor((int)sum, d);
+      if (lane_id() == 0) {
+        // one list per (draw queue, class): 128 counters -- a single counter per class would serialise thousands
+        // of device-scope atomics on one address (~15 ns each)
+        const unsigned tile = (unsigned)(i >> 6);
+        const int qb = (int)(tile & (kTileQueues - 1)) * kTileBuckets + tile_bucket(sum);
+        const unsigned idx = atomicAdd(&bucket_cnt[qb * 32], 1u);  // counters 128 bytes apart: one L2 line each
+        if (idx < bucket_cap) bucket_list[(size_t)qb * bucket_cap + idx] = tile;
+      }
+    }
   }
 }
 
@@ -843,6 +872,10 @@ struct Score3Args {
   unsigned *draw;                    // kTileQueues draw counters, 128 bytes apart: queue q = tiles q, q + 8, ...
   const unsigned *perm;              // kSorted: candidate at depth-sorted position t (k_depth_order)
   const uint2 *rng;                  // kSorted: node-relative range of sorted positions lane t has to sweep
+  const unsigned *tile_order;        // developer experiment: draw e processes tile tile_order[e]
+  const unsigned *bucket_cnt;        // tiles by cost class (k_cand_meta): counts, lists of bucket_cap entries each
+  const unsigned *bucket_list;
+  unsigned bucket_cap;
   int max_nb;
 };
 
@@ -1029,13 +1062,37 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   unsigned long long n_eval_total = 0;
   unsigned k_raw = 0;
   if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+  // draws are mapped to tiles through the queue's cost-class lists, most expensive class first: lane b < kTileBuckets
+  // holds the size of class (kTileBuckets - 1 - b) of queue q and the inclusive prefix of the sizes in that order
+  unsigned cls_cnt = 0, cls_incl = 0, q_tiles = 0;
+  auto load_classes = [&]() {
+    cls_cnt = lane < kTileBuckets ? a.bucket_cnt[(q * kTileBuckets + (kTileBuckets - 1 - lane)) * 32] : 0u;
+    cls_incl = cls_cnt;
+#pragma unroll
+    for (int d = 1; d < kTileBuckets; d <<= 1) {
+      const unsigned t = (unsigned)__shfl_up((int)cls_incl, d);
+      if (lane >= d) cls_incl += t;
+    }
+    q_tiles = (unsigned)__shfl((int)cls_incl, kTileBuckets - 1);
+  };
+  if (a.bucket_cnt) load_classes();
   auto resolve = [&]() -> unsigned {  // tile of the pending draw, 0xFFFFFFFF when every queue is empty
     for (;;) {
       const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
-      const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
-      if (e < n_tiles) return (unsigned)e;
+      if (a.bucket_cnt && !a.tile_order) {
+        if (k < q_tiles) {
+          const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
+          const int bl = __builtin_ctzll(m);  // k < q_tiles: some class holds it
+          const unsigned base = (unsigned)__shfl((int)(cls_incl - cls_cnt), bl);
+          return a.bucket_list[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
+        }
+      } else {
+        const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
+        if (e < n_tiles) return a.tile_order ? a.tile_order[e] : (unsigned)e;
+      }
       if (++tried >= kTileQueues) return 0xFFFFFFFFu;
       q = (q + 1) & (kTileQueues - 1);
+      if (a.bucket_cnt && !a.tile_order) load_classes();
       if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
     }
   };
@@ -1381,6 +1438,7 @@ size_t score3_lds_bytes(int max_nb, bool f32) {
   return ((base + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
 }
 size_t cand_meta_bytes() { return sizeof(CandMeta); }
+int score3_tile_buckets() { return kTileBuckets * kTileQueues; }  // counters (128 B apart) / lists: one per (queue, class)
 // (A two-kernel form -- light sweep writing per-tile pair lists, then a dense evaluation kernel -- was
 // measured: the sweep alone takes 53 us, but the evaluation does not get cheaper and the two phases no
 // longer overlap across waves: 165+ us against 150 us fused.)
@@ -1388,7 +1446,8 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
-                   bool f32, unsigned *perm, void *rng, bool perm_is_placement) {
+                   bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
+                   unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap) {
   if (C <= 0) return;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -1400,12 +1459,15 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   // C: the candidate count or an upper bound of it (the kernels read the exact count from tri_off[G])
   const long long n_tiles = (C + 63) / 64;
   hipLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st, G,
-                     cand_node, tri_off, node_img, nb_off, reinterpret_cast<CandMeta *>(meta), draw);
+                     cand_node, tri_off, node_img, nb_off, reinterpret_cast<CandMeta *>(meta), draw, bucket_cnt, bucket_list,
+                     bucket_cap);
   Score3Args a;
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand; a.lite = lite;
   a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
   a.draw = draw;
   a.perm = perm; a.rng = reinterpret_cast<const uint2 *>(rng);
+  a.tile_order = tile_order;
+  a.bucket_cnt = bucket_cnt; a.bucket_list = bucket_list; a.bucket_cap = bucket_cap;
   a.max_nb = max_nb;
   if (ev_before) (void)hipEventRecord(ev_before, st);
   const bool sorted = perm != nullptr && f32 && !perm_is_placement;

@@ -9,7 +9,7 @@ import pytest
 
 from limap_amd import synthetic as syn
 
-from helpers import (compare_best, compare_candidates, compare_tracks, compare_valid_edges, run_oracle,
+from helpers import (compare_best, compare_candidates, compare_tracks, compare_valid_edges, run_oracle, small_scene,
                      run_product)
 
 pytestmark = pytest.mark.gpu
@@ -37,7 +37,7 @@ def _same(a, b):
 
 @pytest.fixture
 def clean_env():
-    keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS")
+    keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -297,3 +297,17 @@ def test_place_by_permutation_equals_place_by_copy(gpu_lib, clean_env):
     del os.environ["LT_TEST_PLACE_COPY"]
     _same(base, copy)
     assert base[5]["candidates"] > 10_000 and base[5]["tracks"] > 50
+
+
+def test_tile_cost_classes_do_not_change_results(gpu_lib, clean_env):
+    """k_score3 draws its tiles by cost class (longest first); LT_TEST_NO_TILE_CLASSES draws them in natural order.
+    Scheduling only: the same bits."""
+    sc = syn.make_scene(n_views=24, n_segs=200, n_neighbors=8, seed=13)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    base = _results(run_product(sc, cfg))
+    os.environ["LT_TEST_NO_TILE_CLASSES"] = "1"
+    plain = _results(run_product(sc, cfg))
+    del os.environ["LT_TEST_NO_TILE_CLASSES"]
+    _same(base, plain)
+    ex = _results(run_product(small_scene(seed=3, n_views=8, n_segs=60, n_neighbors=4), cfg, exhaustive=True))
+    assert ex[5]["candidates"] > 0

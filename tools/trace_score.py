@@ -64,3 +64,49 @@ qs = np.percentile(nsum, [0, 25, 50, 75, 90, 97, 100])
 for lo_, hi_ in zip(qs[:-1], qs[1:]):
     m = (nsum >= lo_) & (nsum <= hi_)
     print(f"sum n in [{int(lo_)},{int(hi_)}]: {m.sum()} tiles, duration pct 10/50/90/100:", np.percentile(dur[m], [10, 50, 90, 100]).round(1))
+
+# ---- what would another tile ORDER buy?  list scheduling of the measured tile durations on the resident waves ----
+import heapq
+def simulate(order, n_workers=2048):
+    h = [0.0] * n_workers
+    heapq.heapify(h)
+    end = 0.0
+    for t_ in order:
+        s = heapq.heappop(h)
+        e = s + dur[t_]
+        end = max(end, e)
+        heapq.heappush(h, e)
+    return end
+nt = len(dur)
+nat = np.arange(nt)
+print("simulated kernel span (us), 2048 waves: natural order", round(simulate(nat), 1),
+      "| by sum n descending", round(simulate(np.argsort(-nsum, kind="stable")), 1),
+      "| by TRUE duration descending (bound)", round(simulate(np.argsort(-dur, kind="stable")), 1),
+      "| ideal", round(dur.sum() / 2048, 1))
+for frac_last in (0.2, 0.3, 0.5):
+    thr = np.quantile(nsum, frac_last)
+    cheap = nsum <= thr
+    for frac_first in (0.0, 0.1, 0.2):
+        thr2 = np.quantile(nsum, 1 - frac_first) if frac_first > 0 else np.inf
+        heavy = nsum >= thr2
+        order = np.concatenate([nat[heavy], nat[~heavy & ~cheap], nat[cheap]])
+        print(f"  heaviest {frac_first:.0%} first, cheapest {frac_last:.0%} last:", round(simulate(order), 1))
+# per-lane predictor: sum over lanes of n (= sum n) vs sum over the tile's nodes of n^2
+# static split of the predicted-heavy tiles into R virtual tiles (each repeats the prologue, shares sweep + drain)
+pro = us[:, 1] - us[:, 0]
+for frac in (0.1, 0.2, 0.3, 0.5, 1.0):
+    for R in (2, 4):
+        thr = np.quantile(nsum, 1 - frac) if frac < 1.0 else -1
+        d2 = []
+        for t_ in range(nt):
+            if nsum[t_] >= thr:
+                d2 += [pro[t_] + (dur[t_] - pro[t_]) / R] * R
+            else:
+                d2.append(dur[t_])
+        d2 = np.array(d2)
+        h = [0.0] * 2048
+        heapq.heapify(h)
+        end = 0.0
+        for x in d2:
+            s = heapq.heappop(h); e = s + x; end = max(end, e); heapq.heappush(h, e)
+        print(f"split top {frac:.0%} by sum n into {R}: span {end:.1f} us, wave time {d2.sum()/1e3:.1f} ms (ideal {d2.sum()/2048:.1f})")
