@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <mutex>
 #include <queue>
@@ -69,6 +70,45 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap);
 int score3_tile_buckets();
 }
+
+// ---- roctx ranges (tracing) around the host-visible stages, so that a `rocprofv3 --marker-trace` timeline
+// shows upload / run / download / tail next to the kernels.  The marker library is looked up at run time (no link
+// dependency); without it, or with LT_ROCTX=0, the ranges cost one branch.
+namespace lt_trace {
+typedef int (*push_fn)(const char *);
+typedef int (*pop_fn)(void);
+static push_fn g_push = nullptr;
+static pop_fn g_pop = nullptr;
+static void init_once() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  const char *sw = getenv("LT_ROCTX");
+  if (sw && sw[0] == '0') return;
+  const char *libs[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+  for (const char *l : libs) {
+    void *h = dlopen(l, RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) continue;
+    g_push = (push_fn)dlsym(h, "roctxRangePushA");
+    g_pop = (pop_fn)dlsym(h, "roctxRangePop");
+    if (g_push && g_pop) return;
+    g_push = nullptr;
+    g_pop = nullptr;
+  }
+}
+struct Range {
+  bool on;
+  explicit Range(const char *name) {
+    init_once();
+    on = g_push != nullptr;
+    if (on) g_push(name);
+  }
+  ~Range() {
+    if (on) g_pop();
+  }
+};
+}  // namespace lt_trace
+#define LT_RANGE(name) lt_trace::Range lt_range_##__LINE__(name)
 
 // ---- pooled page-locked host blocks (see lt_ctx.h) ----
 namespace lt_host {
@@ -1055,6 +1095,7 @@ int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int
 }
 
 int lt_upload(lt_ctx *ctx) {
+  LT_RANGE("lt_upload (match rows + job tables -> HBM)");
   LT_FINISH(ctx);
   if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "upload before Init");
   if (ctx->uploaded) return LT_OK;
@@ -1186,6 +1227,7 @@ int lt_upload(lt_ctx *ctx) {
 // Completes the run that lt_run_device_async left in flight: waits for its end marker, reads the error flag,
 // the candidate count and the pair statistic from the pinned slots of its set, and its event timings.
 int finish_run(lt_ctx *ctx) {
+  LT_RANGE("lt_sync (end of run: result scalars, event timings)");
   if (!ctx->run_pending) return LT_OK;
   ctx->run_pending = false;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1274,6 +1316,7 @@ int lt_sync(lt_ctx *ctx) { return finish_run(ctx); }
 // new one has been enqueued (its errors are the return value), so a caller that streams batches keeps the
 // device busy across the host's end-of-run bookkeeping.  Two sets of events / pinned result slots alternate.
 int lt_run_device_async(lt_ctx *ctx) {
+  LT_RANGE("lt_run_device (enqueue: generation, placement, scoring, selection)");
   if (!ctx->uploaded) return fail(ctx, LT_ERR_STATE, "lt_run_device before lt_upload");
   if (!ctx->h_pinned) LT_FINISH(ctx);  // no pinned result slots: nothing may stay in flight
   const int set = ctx->run_pending ? (ctx->pend_set ^ 1) : 0;
@@ -1671,6 +1714,7 @@ static int materialize_compact(lt_ctx *ctx) {
 }
 
 int lt_download(lt_ctx *ctx) {
+  LT_RANGE("lt_download (per-node results -> host)");
   LT_FINISH(ctx);
   if (!ctx->ran) return fail(ctx, LT_ERR_STATE, "lt_download before lt_run_device");
   if (ctx->downloaded) return LT_OK;
@@ -1938,6 +1982,7 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
 }  // extern "C++"
 
 int lt_compute_tracks(lt_ctx *ctx) {
+  LT_RANGE("lt_compute_tracks (tail: edge set, similarities, union-find, aggregation)");
   if (ctx->cfg.merging_strategy < 0 || ctx->cfg.merging_strategy > 2)  // global_line_triangulator.cc:314-316
     return fail(ctx, LT_ERR_RUNTIME, "Error!The given merging strategy is not implemented");
   const bool on_device = tail_on_device(ctx);

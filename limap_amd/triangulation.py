@@ -136,7 +136,11 @@ except Exception:  # pragma: no cover
     _limap_base = None
 
 
-try:  # optional CPython helper (limap_amd/csrc/lt_pymarshal.c): same call, ~20 us less Python per image
+try:  # the pybind11 shim over the C ABI (limap_amd/csrc/lt_pybind.cpp): the per-image calls and ComputeLineTracks
+    from . import _lt_pybind as _pb
+except ImportError:  # pragma: no cover
+    _pb = None
+try:  # CPython helper (limap_amd/csrc/lt_pymarshal.c), used when the pybind11 module is not built
     from . import _lt_pymarshal as _fast
 except ImportError:  # pragma: no cover
     _fast = None
@@ -242,6 +246,8 @@ class GlobalLineTriangulator:
         self._tracks = []
         self._debug = bool(self._ctx.cfg.debug_mode)
         self._best_cache = self._all_cache = None
+        # non-owning pybind11 view of the same lt_ctx: TriangulateImage / ComputeLineTracks go through it
+        self._pbv = _pb.GlobalLineTriangulator(self._ctx.h.value) if _pb is not None else None
 
     # ---- interfaces (bindings.cc:78-95) ----
     def SetRanges(self, ranges):
@@ -321,6 +327,9 @@ class GlobalLineTriangulator:
     def TriangulateImage(self, img_id, matches):
         """matches: dict[int -> ndarray(K,2) int] (the content of matches_{img_id}.npy)."""
         self._best_cache = self._all_cache = None
+        if self._pbv is not None and type(matches) is dict:
+            self._pbv.TriangulateImage(int(img_id), matches)  # buffer protocol, GIL released around the native call
+            return
         if _fast is not None and type(matches) is dict:
             # C-contiguous int32 (K,2) arrays (what matchers write) go straight through the buffer protocol
             rc = _fast.triangulate_image_rows(self._ctx.rows_fn_addr, self._ctx.h.value, int(img_id), matches)
@@ -343,8 +352,12 @@ class GlobalLineTriangulator:
         self._ctx.triangulate_image_exhaustive(img_id, [int(x) for x in neighbors])
 
     def ComputeLineTracks(self):
-        self._ctx.compute_tracks()
-        self._tracks = self._build_tracks(self._ctx.get_tracks())
+        if self._pbv is not None:
+            t = self._pbv.ComputeLineTracks()  # one call: run + tail + the track arrays
+        else:
+            self._ctx.compute_tracks()
+            t = self._ctx.get_tracks()
+        self._tracks = self._build_tracks(t)
         return self.GetTracks()
 
     def GetTracks(self):

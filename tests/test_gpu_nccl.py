@@ -1,0 +1,111 @@
+"""-m gpu: the N > 1 path over RCCL (backend "nccl") with real processes, one per GPU: the single all-gather of the
+per-image payload into device memory, every rank triangulating its connection-weighted shard, the packed tensor
+gather of the per-node results to rank 0, ComputeLineTracks there -- against the oracle.
+
+world_size 2 needs two GPUs (skipped with the reason on a 1-GPU box; the driver's multi-GPU tier runs it);
+world_size 1 takes the same code path -- process group, collectives, chunk pointers -- on one GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from limap_amd import _capi, dist as ltdist, synthetic as syn
+        sc = syn.make_scene(n_views=14, n_segs=90, n_neighbors=6, seed=21)
+        cfg = syn.default_triangulation_cfg()
+        weights = np.array([len(sc.neighbors[int(i)]) for i in sc.img_ids], float)
+        mine = ltdist.shard_images(sc.img_ids, rank, world, weights)
+        g = ltdist.SceneGather(sc.img_ids, sc.seg_off, rank, world, dev, weights=weights, force_collective=True)
+        # every rank loads ONLY its own slice; the rest must arrive through the collective
+        a, b = g.bounds[rank], g.bounds[rank + 1]
+        kv, qv, tv, sg = sc.kvec.copy(), sc.qvec.copy(), sc.tvec.copy(), sc.segs.copy()
+        mask = np.ones(sc.n_images, bool); mask[a:b] = False
+        kv[mask] = np.nan; qv[mask] = np.nan; tv[mask] = np.nan
+        smask = np.ones(len(sg), bool); smask[sc.seg_off[a]:sc.seg_off[b]] = False
+        sg[smask] = np.nan
+        g.load_local(kv, qv, tv, sg)
+        d_k, d_q, d_t, d_s = g.all_gather()
+        ok = bool(torch.isfinite(d_s).all().item()) and np.array_equal(d_k.cpu().numpy(), sc.kvec)
+        ctx = _capi.Context(cfg_dict=cfg, device=rank)
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ctx.set_ranges(*sc.ranges)
+        ctx.init_device(sc.img_ids, d_k.data_ptr(), d_q.data_ptr(), d_t.data_ptr(), sc.seg_off, d_s.data_ptr())
+        for i in mine:
+            m = sc.matches_of(int(i))
+            nb = list(m.keys())
+            off = np.zeros(len(nb) + 1, np.int64); off[1:] = np.cumsum([len(m[k]) for k in nb])
+            ctx.triangulate_image(int(i), nb, off, np.concatenate([m[k] for k in nb], 0))
+        ctx.upload()
+        ctx.set_scene_chunks(*g.chunk_pointers())
+        h = g.gather_async()
+        h.wait()
+        ctx.refresh_scene_chunks()   # the per-step path: invariants rebuilt straight from the receive buffer
+        ctx.run_device()
+        ctx.download()
+        n_imp = ltdist.merge_shards_on_rank0(ctx, mine, rank, world, dev)
+        res = None
+        if rank == 0:
+            ctx.compute_tracks()
+            t = ctx.get_tracks()
+            b_ = ctx.get_best()
+            res = dict(tracks={k: np.asarray(v) for k, v in t.items()}, best={k: np.asarray(v) for k, v in b_.items()},
+                       imported=n_imp, mine=len(mine))
+        q.put((rank, ok, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return sorted(out, key=lambda x: x[0])
+
+
+def _check(out, world, oracle):
+    from limap_amd import synthetic as syn
+    from helpers import compare_best, compare_tracks, run_oracle
+    assert all(ok for _, ok, _ in out)
+    res = out[0][2]
+    sc = syn.make_scene(n_views=14, n_segs=90, n_neighbors=6, seed=21)
+    assert res["imported"] + res["mine"] == sc.n_images
+    O = run_oracle(oracle, sc, syn.default_triangulation_cfg())
+    compare_best(res["best"], O.get_best())
+    compare_tracks(res["tracks"], O.ComputeLineTracks())
+
+
+def test_rccl_path_world1(gpu_lib, oracle):
+    _check(_run(1), 1, oracle)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the 1-GPU box runs the world_size 1 form)")
+def test_rccl_path_world2(gpu_lib, oracle):
+    _check(_run(2), 2, oracle)
