@@ -239,7 +239,8 @@ int lt_get_stats(lt_ctx *ctx, int64_t out[8]);
  * [10] tail (lt_compute_tracks); [11] candidate pairs that reached the dense evaluation in k_score3;
  * [12] host ms spent inside lt_triangulate_image* buffering the match rows of the batch;
  * single-kernel durations (HIP events around the launch): [13] k_gates, [14] k_tri_rows, [15] k_score3;
- * [16] connections that passed the stage-A gates (k_gates) */
+ * [16] connections that passed the stage-A gates (k_gates);
+ * one-pass exhaustive mode: [17] staging slots needed (fullest region x regions), [18] staging slots provided */
 int lt_get_timers(lt_ctx *ctx, double out[24]);
 /* The same slots summed over every lt_run_device since the last reset ([8]-[10], [12] are not summed), and
  * the number of runs ([16] is not summed either: lt_get_timers counts it on demand with a device readback,

@@ -456,7 +456,7 @@ class Context:
         return dict(zip(keys, out.tolist()))
 
     _TIMER_KEYS = ["run", "invariants", "sort", "gen", "compact", "score", "select", "gather", "upload", "download",
-                   "tail", "pairs_eval", "buffer", "k_gates", "k_tri_rows", "k_score3", "survivors"]
+                   "tail", "pairs_eval", "buffer", "k_gates", "k_tri_rows", "k_score3", "survivors", "ex_slots", "ex_cap"]
 
     def timers(self):
         out = np.zeros(24)

@@ -67,7 +67,8 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
-                   unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap);
+                   unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap, const unsigned *place,
+                   unsigned *rec);
 int score3_tile_buckets();
 }
 
@@ -612,7 +613,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
                     &ctx->d_pair_counter, &ctx->d_result3, &ctx->d_tile_order, &ctx->d_scan_status, &ctx->d_perm, &ctx->d_rng, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz,
-                    &ctx->d_place_perm, &ctx->d_tile_list, &ctx->d_exp_tile_order, &ctx->d_tail_keys, &ctx->d_tail_skeys, &ctx->d_tail_sims, &ctx->d_tail_mark,
+                    &ctx->d_place_perm, &ctx->d_ex_rec, &ctx->d_ex_ent, &ctx->d_tile_list, &ctx->d_exp_tile_order, &ctx->d_tail_keys, &ctx->d_tail_skeys, &ctx->d_tail_sims, &ctx->d_tail_mark,
                     &ctx->d_tail_pos, &ctx->d_tail_recs, &ctx->d_tail_nodes, &ctx->d_tail_tmp, &ctx->d_tail_keep,
                     &ctx->d_tail_kpos};
   lt_host::host_block_release(ctx->h_pinned_blk);
@@ -1250,6 +1251,36 @@ int finish_run(lt_ctx *ctx) {
     ctx->stat_pairs_eval = (long long)pe;
   }
   ctx->stat_survivors = -1;  // summed on demand (lt_get_timers)
+  if (derr == 5) {
+    // the staging capacity of the one-pass exhaustive mode did not hold: repeat the job in the two-pass form (exact
+    // sizes).  When this is the earlier of two runs in flight the later one -- same inputs -- is repeated at its own end.
+    if (ctx->ex_retry_depth > 0 || !ctx->ex_staged_set[ctx->pend_set])
+      return fail(ctx, LT_ERR_RUNTIME, "internal: candidate staging overflow outside the one-pass exhaustive mode");
+    ctx->ex_two_pass = true;
+    // the counters kept counting beyond the capacity: the next run gets what this one would have needed
+    if (hp && hp[3] > 0 && ctx->n_conn > 0)
+      ctx->ex_frac = 1.4 * (double)hp[3] * (double)ex_regions() / (double)ctx->n_conn;
+    if (ctx->in_run_async) return LT_OK;
+    ctx->ex_retry_depth = 1;
+    int rc2 = lt_run_device_async(ctx);
+    if (!rc2) rc2 = finish_run(ctx);
+    ctx->ex_retry_depth = 0;
+    return rc2;
+  }
+  ctx->timers[17] = ctx->timers[18] = 0.0;
+  if (hp && ctx->ex_staged_set[ctx->pend_set]) {
+    ctx->timers[17] = (double)hp[3] * (double)ex_regions();
+    ctx->timers[18] = (double)ctx->ex_region_cap * (double)ex_regions();
+  }
+  if (ctx->job_mode == 2 && derr == 0 && ctx->n_conn > 0) {
+    // this run's need of staging slots -> capacity of the next one: 1.4 x the fullest region (one-pass form), or an
+    // estimate from the candidate count (two-pass form: slots = listed connections + block padding, ~1.5 per candidate)
+    if (hp && ctx->ex_staged_set[ctx->pend_set])
+      ctx->ex_frac = std::max(1.4 * (double)hp[3] * (double)ex_regions() / (double)ctx->n_conn, 1e-4);
+    else if (ctx->ex_frac <= 0.0)
+      ctx->ex_frac = std::max(2.2 * (double)ctx->C_last / (double)ctx->n_conn, 1e-4);
+    ctx->ex_two_pass = false;
+  }
   if (derr == 4) return fail(ctx, LT_ERR_RUNTIME, "internal: the scan of the node counts did not complete");
   if (derr == 3)
     return fail(ctx, LT_ERR_RUNTIME, "the one-point proposal supports at most 64 shared points per connection");
@@ -1324,6 +1355,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     for (auto &e : ctx->ev_b) HIPCHK(ctx, hipEventCreate(&e));
   hipEvent_t *ev = set ? ctx->ev_b : ctx->ev;
   long long *hp = ctx->h_pinned ? ctx->h_pinned + 8 * set : nullptr;
+  ctx->ex_staged_set[set] = false;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const long long G = ctx->G, P = ctx->P;
@@ -1338,14 +1370,15 @@ int lt_run_device_async(lt_ctx *ctx) {
   const ScoreCfg scfg = make_score(ctx);
   ENSURE(ctx, ctx->d_err, sizeof(int));
   ENSURE(ctx, ctx->d_pair_counter, 8);
-  ENSURE(ctx, ctx->d_result3, 24);
+  ENSURE(ctx, ctx->d_result3, 32);
   ENSURE(ctx, ctx->d_pairs, sizeof(PairRec) * (size_t)std::max(ctx->n_blk, 1));
   ENSURE(ctx, ctx->d_tri_off, sizeof(long long) * (size_t)(G + 1));
   HIPCHK(ctx, hipEventRecord(ev[0], st));
   // also zeroes the error flag, the pair statistic and the look-back state of k_node_prefix's scan
   // (+ the tile cost-class counters of k_cand_meta / k_score3 behind the scan's words: zeroed by the same kernel)
   const int n_status_scan = (int)((G + 1 + 255) / 256) + 1;
-  const int n_status = n_status_scan + score3_tile_buckets() * 16;  // counters 128 bytes apart
+  // + the staging counters of the one-pass exhaustive mode; all counters 128 bytes apart
+  const int n_status = n_status_scan + score3_tile_buckets() * 16 + ex_regions() * 16;
   ENSURE(ctx, ctx->d_scan_status, 8 * (size_t)n_status);
   launch_build_pairs(st, ctx->n_blk, ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_cams.as<Cam>(),
                      ctx->d_pairs.as<PairRec>(), ctx->d_err.as<int>(),
@@ -1537,6 +1570,49 @@ int lt_run_device_async(lt_ctx *ctx) {
     const double *sfm_xyz = (pts_any && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr;
     ENSURE(ctx, ctx->d_masks, pts_any ? 64 * In : 8 * In * n_masks); ENSURE(ctx, ctx->d_mask_cnt, 4 * (In + 1));
     ENSURE(ctx, ctx->d_mask_pos, 8 * (In + 1));
+    // Plain exhaustive mode (no VP / point proposals): pass 1 with the neighbour lines held in registers (k_gates_ex;
+    // LT_TEST_EX_PASS1_BLOCK keeps the wave-per-(node, neighbour) form the VP variant uses), and, while the staging
+    // capacity holds, in its ONE-PASS form: pass 1 only lists the connections that pass the cheap gates (k_gates_ex<true>),
+    // k_tri_ex evaluates the list densely and writes the survivors to staging slots, a permutation orders them -- no
+    // second triangulation pass, no host round trip for the candidate count.  The capacity is a
+    // fraction of the connections (1/6 until a run of this context has measured its need, then 1.4 x that); a run that
+    // overflows it (device error flag 5) is repeated in the two-pass form by finish_run.  LT_TEST_EX_TWO_PASS: always
+    // two passes.
+    const bool plain = !pts_any && !vp_on;
+    bool staged = plain && ctx->h_pinned && !ctx->ex_two_pass && P > 0 && !getenv("LT_TEST_EX_TWO_PASS") &&
+                  !getenv("LT_TEST_EX_PASS1_BLOCK");
+    long long ex_cap = 0;
+    unsigned region_cap = 0;
+    unsigned long long *ex_ctr = ctx->d_scan_status.as<unsigned long long>() + n_status_scan + score3_tile_buckets() * 16;
+    if (staged) {
+      double frac = ctx->ex_frac > 0.0 ? ctx->ex_frac : 1.0 / 6.0;
+      long long slack = 65536;
+      if (const char *f = getenv("LT_TEST_EX_CAP_FRAC")) {  // test switch: force a (too small) capacity
+        frac = atof(f);
+        slack = 0;
+      }
+      const long long want = (long long)((double)ctx->n_conn * frac) + slack;
+      const long long nreg = ex_regions();
+      const long long rc8 = ((want + nreg - 1) / nreg + 63) & ~63ll;
+      ex_cap = nreg * rc8;
+      // ~210 bytes per slot over all arrays: beyond 64 GB (or the 32-bit slot index) the two-pass form, whose arrays
+      // have the exact size
+      if (ex_cap >= (1ll << 32) - 1 || ex_cap * 210 > (64ll << 30)) staged = false;
+      else {
+        region_cap = (unsigned)rc8;
+        const size_t Bn = (size_t)ex_cap;
+        const bool got = ctx->d_st_c.ensure(sizeof(Cand) * Bn) && ctx->d_st_l.ensure(sizeof(CandLite) * Bn) &&
+                         ctx->d_st_key.ensure(4 * Bn) && ctx->d_place_perm.ensure(4 * Bn) && ctx->d_score.ensure(8 * Bn) &&
+                         ctx->d_edge_flag.ensure(4 * Bn) && ctx->d_cand_node.ensure(4 * Bn) &&
+                         ctx->d_cand_meta.ensure(cand_meta_bytes() * Bn) && ctx->d_ex_rec.ensure(4 * Bn) &&
+                         ctx->d_ex_ent.ensure(8 * Bn);
+        if (!got) {
+          (void)hipGetLastError();
+          staged = false;
+        }
+      }
+    }
+    ctx->ex_staged_set[set] = staged;
     if (pts_any) {
       launch_gen_exhaustive_pts(st, false, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
                                 ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
@@ -1546,11 +1622,28 @@ int lt_run_device_async(lt_ctx *ctx) {
                                 sfm_xyz, ctx->d_err.as<int>(), many_on, one_on, ctx->d_blk_chunk_off.as<int>(),
                                 ctx->max_nb, ctx->max_chunks, ctx->d_seg_gates.p);
     } else {
+      if (plain && !getenv("LT_TEST_EX_PASS1_BLOCK"))
+        launch_gates_exhaustive(st, ctx->n_blk, ctx->max_chunks, P, gcfg, ctx->d_item_off.as<long long>(),
+                                ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
+                                ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
+                                ctx->d_masks.as<unsigned long long>(), ctx->d_blk_chunk_off.as<int>(), ctx->d_seg_gates.p,
+                                staged ? ctx->d_ex_ent.as<unsigned long long>() : nullptr, ex_ctr, region_cap,
+                                ctx->d_err.as<int>());
+      else
       launch_gen_exhaustive(st, false, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
                             ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
                             ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
                             ctx->d_masks.as<unsigned long long>(), nullptr, nullptr, nullptr, seg_vp, seg_has_vp,
                             ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks, ctx->d_seg_gates.p);
+      if (staged) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_masks.p, 0, 8 * In, st));
+        launch_tri_exhaustive(st, ctx->d_ex_ent.as<unsigned long long>(), ex_ctr, region_cap, gcfg, P,
+                              ctx->d_item_off.as<long long>(), ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(),
+                              ctx->d_nb_off.as<long long>(), ctx->d_seg_off.as<long long>(), ctx->d_cams.as<Cam>(),
+                              ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(), ctx->d_blk_chunk_off.as<int>(),
+                              ctx->d_masks.as<unsigned long long>(), ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(),
+                              ctx->d_st_key.as<unsigned>());
+      }
       launch_popc(st, P, ctx->d_masks.as<unsigned long long>(), ctx->d_mask_cnt.as<unsigned>(), n_masks);
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_mask_cnt.as<unsigned>() + P, 0, 4, st));
@@ -1561,6 +1654,24 @@ int lt_run_device_async(lt_ctx *ctx) {
                                  ctx->d_mask_pos.as<long long>()) != 0)
         return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
     }
+    if (staged) {
+      launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, -1, ex_cap,
+                            ctx->d_tri_off.as<long long>(), ctx->d_err.as<int>());
+      HIPCHK(ctx, hipEventRecord(ev[3], st));
+      launch_place_exhaustive(st, ex_ctr, region_cap, ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(),
+                              ctx->d_node_img.as<int>(), ctx->d_nb_off.as<long long>(), ctx->d_item_off.as<long long>(),
+                              ctx->d_blk_chunk_off.as<int>(), ctx->d_masks.as<unsigned long long>(),
+                              ctx->d_mask_pos.as<long long>(), P, ctx->d_tri_off.as<long long>(), G,
+                              ctx->d_place_perm.as<unsigned>(), ctx->d_result3.as<long long>() + 3);
+      ctx->ex_region_cap = region_cap;
+      launch_cand_node(st, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>());
+      ctx->perm_mode = true;
+      ctx->compact_valid = false;
+      ctx->cand_cap = ex_cap;
+      C_known = -1;
+      C_bound = ex_cap;
+      HIPCHK(ctx, hipEventRecord(ev[4], st));
+    } else {
     // the candidate count sizes the compacted arrays: one small host round trip
     long long total = 0;
     HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_mask_pos.as<long long>() + P, 8, hipMemcpyDeviceToHost, st));
@@ -1579,6 +1690,12 @@ int lt_run_device_async(lt_ctx *ctx) {
                                 seg_vp, seg_has_vp, ctx->d_seg_pt_off.as<long long>(), ctx->d_seg_pts.p, sfm_xyz,
                                 ctx->d_err.as<int>(), many_on, one_on, ctx->d_blk_chunk_off.as<int>(), ctx->max_nb,
                                 ctx->max_chunks, ctx->d_seg_gates.p);
+    else if (!vp_on && !getenv("LT_TEST_EX_PASS2_BLOCK"))
+      launch_fill_exhaustive(st, ctx->n_blk, P, gcfg, ctx->d_item_off.as<long long>(), ctx->d_blk_img.as<int>(),
+                             ctx->d_blk_nb.as<int>(), ctx->d_nb_off.as<long long>(), ctx->d_seg_off.as<long long>(),
+                             ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
+                             ctx->d_masks.as<unsigned long long>(), ctx->d_mask_pos.as<long long>(),
+                             ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_blk_chunk_off.as<int>());
     else
       launch_gen_exhaustive(st, true, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
                             ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
@@ -1586,13 +1703,14 @@ int lt_run_device_async(lt_ctx *ctx) {
                             ctx->d_masks.as<unsigned long long>(), ctx->d_mask_pos.as<long long>(),
                             ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), seg_vp, seg_has_vp,
                             ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks, ctx->d_seg_gates.p);
-    launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, total,
-                          ctx->d_tri_off.as<long long>());
+    launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, total, -1,
+                          ctx->d_tri_off.as<long long>(), ctx->d_err.as<int>());
     ENSURE(ctx, ctx->d_cand_node, 4 * Cn);
     launch_cand_node(st, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>());
     C_known = total;
     C_bound = total;
     HIPCHK(ctx, hipEventRecord(ev[4], st));
+    }
   } else {
     ctx->perm_mode = false;
     ctx->compact_valid = true;
@@ -1619,7 +1737,9 @@ int lt_run_device_async(lt_ctx *ctx) {
     ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_bound, 1));
     ENSURE(ctx, ctx->d_tile_order, 1024);  // the tile draw counters of k_score3 (8 x 128 B)
     // tiles listed by cost class (LT_TEST_NO_TILE_CLASSES: natural tile order)
-    const bool tile_classes = !getenv("LT_TEST_NO_TILE_CLASSES");
+    // (matched mode only: the wide nodes of the exhaustive mode put every tile into the top class, whose one counter
+    // per queue then serialises ~4e4 appends -- k_cand_meta 0.11 -> 0.50 ms -- for an order that changes nothing)
+    const bool tile_classes = !getenv("LT_TEST_NO_TILE_CLASSES") && ctx->job_mode == 1;
     const unsigned tile_cap = (unsigned)(((std::max<long long>(C_bound, 1) + 63) / 64 + 7) / 8);  // tiles of one draw queue
     if (tile_classes) ENSURE(ctx, ctx->d_tile_list, 4 * (size_t)tile_cap * (size_t)score3_tile_buckets());
     // large nodes (exhaustive matching): depth-sorted sweep, see k_depth_order
@@ -1628,6 +1748,8 @@ int lt_run_device_async(lt_ctx *ctx) {
       ENSURE(ctx, ctx->d_perm, 4 * (size_t)std::max<long long>(C_bound, 1));
       ENSURE(ctx, ctx->d_rng, 8 * (size_t)std::max<long long>(C_bound, 1));
     }
+    // depth-sorted sweep over the staged records of the one-pass exhaustive mode: see k_depth_order
+    const bool staged_sorted = score_sorted && ctx->perm_mode && ctx->job_mode == 2;
     C_run = C_bound;  // replaced by the exact count when that arrives with the error flag (finish_run)
     launch_score3(st, C_bound, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
                   ctx->perm_mode ? ctx->d_st_c.as<Cand>() : ctx->d_cand.as<Cand>(),
@@ -1635,12 +1757,15 @@ int lt_run_device_async(lt_ctx *ctx) {
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
                   ctx->d_score.as<double>(), ctx->d_pair_counter.as<unsigned long long>(), ctx->max_nb, scfg,
                   guard2, fine_timers() ? ev[11] : nullptr, ctx->d_tile_order.as<unsigned>(), score_f32,
-                  ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : (score_sorted ? ctx->d_perm.as<unsigned>() : nullptr),
-                  score_sorted ? ctx->d_rng.p : nullptr, ctx->perm_mode,
+                  (ctx->perm_mode && !staged_sorted) ? ctx->d_place_perm.as<unsigned>()
+                                                     : (score_sorted ? ctx->d_perm.as<unsigned>() : nullptr),
+                  score_sorted ? ctx->d_rng.p : nullptr, ctx->perm_mode && !staged_sorted,
                   (ctx->exp_tile_order_C == C_bound || ctx->exp_tile_order_C == ctx->C_last) && ctx->exp_tile_order_C > 0
                       ? ctx->d_exp_tile_order.as<unsigned>() : nullptr,
                   tile_classes ? (unsigned *)(ctx->d_scan_status.as<unsigned long long>() + n_status_scan) : nullptr,
-                  tile_classes ? ctx->d_tile_list.as<unsigned>() : nullptr, tile_cap);
+                  tile_classes ? ctx->d_tile_list.as<unsigned>() : nullptr, tile_cap,
+                  staged_sorted ? ctx->d_place_perm.as<unsigned>() : nullptr,
+                  staged_sorted ? ctx->d_ex_rec.as<unsigned>() : nullptr);
   }
   HIPCHK(ctx, hipEventRecord(ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));
@@ -1667,11 +1792,16 @@ int lt_run_device_async(lt_ctx *ctx) {
   if (hp) {
     // hp[0] candidate count, hp[1] error flag, hp[2] pair statistic: one record, gathered by k_select
     if (G <= 0) HIPCHK(ctx, hipMemsetAsync(ctx->d_result3.p, 0, 24, st));  // no nodes: k_select did not run
-    HIPCHK(ctx, hipMemcpyAsync(&hp[0], ctx->d_result3.p, 24, hipMemcpyDeviceToHost, st));
+    // hp[3]: fullest staging region of the one-pass exhaustive mode (k_place_ex)
+    HIPCHK(ctx, hipMemcpyAsync(&hp[0], ctx->d_result3.p, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipEventRecord(ev[12], st));
   }
   int rc_prev = LT_OK;
-  if (ctx->run_pending) rc_prev = finish_run(ctx);  // the previous run (the other set)
+  if (ctx->run_pending) {  // the previous run (the other set)
+    ctx->in_run_async = true;
+    rc_prev = finish_run(ctx);
+    ctx->in_run_async = false;
+  }
   ctx->run_pending = true;
   ctx->pend_set = set;
   ctx->pend_count_on_device = C_known < 0;

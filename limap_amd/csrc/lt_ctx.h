@@ -213,6 +213,16 @@ struct lt_ctx {
   DevBuf d_exp_tile_order;     // developer experiment LT_EXP_TILE_ORDER
   long long exp_tile_order_C = -1;
   bool perm_mode = false;      // the last run left its candidates in the staging lists
+  // one-pass exhaustive mode (k_gates_ex<true>): staging capacity as a fraction of the connections (0 = not measured
+  // yet), adapted to the last run's yield; ex_two_pass: the next run uses the two-pass form (after an overflow)
+  DevBuf d_ex_rec;             // record of every depth-sorted position (k_depth_order over staged records)
+  DevBuf d_ex_ent;             // entry blocks of k_gates_ex<true> (8 B per staging slot)
+  long long ex_region_cap = 0; // of the run in flight
+  double ex_frac = 0.0;
+  bool ex_two_pass = false;
+  bool ex_staged_set[2] = {false, false};  // the run of event set 0 / 1 used the one-pass form
+  bool in_run_async = false;
+  int ex_retry_depth = 0;
   bool compact_valid = false;  // d_cand / d_lite hold the compact arrays of the last run
   DevBuf d_tail_keys, d_tail_skeys, d_tail_sims, d_tail_mark, d_tail_pos, d_tail_recs, d_tail_nodes, d_tail_tmp, d_tail_keep, d_tail_kpos;  // lt_kernels_tail.hip
   bool cnt_bl_clean = false;  // d_cnt_bl is all zero (k_node_prefix cleans up after itself)

@@ -204,13 +204,27 @@ static __device__ __forceinline__ void seg_gate_build(const Seg &s, SegGate *g) 
   g->q2 = vx * vx + vy * vy;  // == (x1-x2)^2 + (y1-y2)^2 bit for bit (negation is exact)
 }
 
-static __device__ __forceinline__ int gate3(const GenCfg &cfg, double a1x, double a1y, double b1x, double b1y,
-                                            double rs1x, double rs1y, double rs1z, double re1x, double re1y,
-                                            double re1z, double n2x, double n2y, double n2z, double lcx,
-                                            double lcy, double P, double Q, double w1, double sv, double q2,
-                                            const double *F) {
-  const double d1x = a1x - b1x, d1y = a1y - b1y;
-  const double q1 = __builtin_fma(d1x, d1x, d1y * d1y);
+// The view-1 side of the IoU algebra: epipolar line of one endpoint x of l1 (a = F x~), |a|^2 and |a| (float sqrt,
+// see above).  Depends on (l1, image pair) only -- the exhaustive kernel evaluates it once per node and neighbour
+// image instead of once per connection.
+struct GateEpi {
+  double ax, ay, az, n2a, na;
+};
+static __device__ __forceinline__ GateEpi gate3_epi(const double *F, double px, double py) {
+  GateEpi e;
+  e.ax = __builtin_fma(F[0], px, __builtin_fma(F[1], py, F[2]));
+  e.ay = __builtin_fma(F[3], px, __builtin_fma(F[4], py, F[5]));
+  e.az = __builtin_fma(F[6], px, __builtin_fma(F[7], py, F[8]));
+  e.n2a = __builtin_fma(e.ax, e.ax, __builtin_fma(e.ay, e.ay, e.az * e.az));
+  e.na = (double)__builtin_amdgcn_sqrtf((float)e.n2a);
+  return e;
+}
+
+// q1 = squared length of l1
+static __device__ __forceinline__ int gate3_core(const GenCfg &cfg, double q1, double rs1x, double rs1y, double rs1z,
+                                                 double re1x, double re1y, double re1z, double n2x, double n2y,
+                                                 double n2z, double lcx, double lcy, double P, double Q, double w1,
+                                                 double sv, double q2, const GateEpi &ea, const GateEpi &eb) {
   bool rej = (q1 <= cfg.len_lo2) | (q2 <= cfg.len_lo2) | (cfg.disable_algebraic != 0);
   bool und = !(q1 > cfg.len_hi2) | !(q2 > cfg.len_hi2);
   const double as = fabs(__builtin_fma(n2x, rs1x, __builtin_fma(n2y, rs1y, n2z * rs1z)));
@@ -221,12 +235,8 @@ static __device__ __forceinline__ int gate3(const GenCfg &cfg, double a1x, doubl
   bool well = q2 > 0.0;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const double px = k == 0 ? a1x : b1x, py = k == 0 ? a1y : b1y;
-    const double ax = __builtin_fma(F[0], px, __builtin_fma(F[1], py, F[2]));
-    const double ay = __builtin_fma(F[3], px, __builtin_fma(F[4], py, F[5]));
-    const double az = __builtin_fma(F[6], px, __builtin_fma(F[7], py, F[8]));
-    const double n2a = __builtin_fma(ax, ax, __builtin_fma(ay, ay, az * az));
-    const double na = (double)__builtin_amdgcn_sqrtf((float)n2a);
+    const GateEpi &e = k == 0 ? ea : eb;
+    const double ax = e.ax, ay = e.ay, az = e.az, n2a = e.n2a, na = e.na;
     const double t1 = lcx * ay, t2 = lcy * ax;
     const double D = __builtin_fma(kEps, na, t1 - t2);
     const double m0 = az * w1, m1 = ax * P, m2 = ay * Q, m3 = D * sv;
@@ -251,6 +261,17 @@ static __device__ __forceinline__ int gate3(const GenCfg &cfg, double a1x, doubl
   und |= !(well & (delta > margin));
   if (cfg.force_undecided) return 2;  // test switch (LT_TEST_NO_FAST_GATES)
   return rej ? 0 : (und ? 2 : 1);
+}
+
+static __device__ __forceinline__ int gate3(const GenCfg &cfg, double a1x, double a1y, double b1x, double b1y,
+                                            double rs1x, double rs1y, double rs1z, double re1x, double re1y,
+                                            double re1z, double n2x, double n2y, double n2z, double lcx,
+                                            double lcy, double P, double Q, double w1, double sv, double q2,
+                                            const double *F) {
+  const double d1x = a1x - b1x, d1y = a1y - b1y;
+  const double q1 = __builtin_fma(d1x, d1x, d1y * d1y);
+  const GateEpi ea = gate3_epi(F, a1x, a1y), eb = gate3_epi(F, b1x, b1y);
+  return gate3_core(cfg, q1, rs1x, rs1y, rs1z, re1x, re1y, re1z, n2x, n2y, n2z, lcx, lcy, P, Q, w1, sv, q2, ea, eb);
 }
 
 // Stage B: triangulation, cheirality, sensitivity gate, uncertainty, ranges (:309-333).

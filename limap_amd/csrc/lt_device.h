@@ -40,6 +40,26 @@ void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const G
                            const PairRec *pairs, unsigned long long *masks, const long long *mask_pos,
                            Cand *out_c, CandLite *out_l, const double *seg_vp, const unsigned char *seg_has_vp,
                            const int *blk_chunk_off, int max_nb, int max_chunks, const void *gates);
+int ex_regions();
+void launch_gates_exhaustive(hipStream_t st, int n_blk, int max_chunks, long long n_items, const GenCfg &cfg,
+                             const long long *item_off, const int *blk_img, const int *blk_nb, const long long *seg_off,
+                             const Cam *cams, const Seg *segs, const PairRec *pairs, unsigned long long *masks,
+                             const int *blk_chunk_off, const void *gates, unsigned long long *ent_out,
+                             unsigned long long *ctr, unsigned region_cap, int *err_flag);
+void launch_tri_exhaustive(hipStream_t st, const unsigned long long *ent, const unsigned long long *ctr,
+                           unsigned region_cap, const GenCfg &cfg, long long n_items, const long long *item_off,
+                           const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
+                           const Cam *cams, const Seg *segs, const PairRec *pairs, const int *blk_chunk_off,
+                           unsigned long long *masks, Cand *st_c, CandLite *st_l, unsigned *st_node);
+void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsigned region_cap, const CandLite *st_l,
+                             const unsigned *st_node, const int *node_img, const long long *nb_off,
+                             const long long *item_off, const int *blk_chunk_off, const unsigned long long *masks,
+                             const long long *mask_pos, long long n_items, const long long *tri_off, long long G,
+                             unsigned *perm, long long *fill_out);
+void launch_fill_exhaustive(hipStream_t st, int n_blk, long long n_items, const GenCfg &cfg, const long long *item_off,
+                            const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
+                            const Cam *cams, const Seg *segs, const PairRec *pairs, const unsigned long long *masks,
+                            const long long *mask_pos, Cand *out_c, CandLite *out_l, const int *blk_chunk_off);
 void launch_gen_exhaustive_pts(hipStream_t st, bool fill, long long n_items, const GenCfg &cfg,
                                const long long *item_off, long long G, const int *node_img, const long long *nb_off,
                                const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
@@ -50,7 +70,7 @@ void launch_gen_exhaustive_pts(hipStream_t st, bool fill, long long n_items, con
                                const int *blk_chunk_off, int max_nb, int max_chunks, const void *gates);
 void launch_popc(hipStream_t st, long long n, const unsigned long long *masks, unsigned *cnt, int n_masks);
 void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_off, const long long *mask_pos,
-                           long long n_items, long long total, long long *tri_off);
+                           long long n_items, long long total, long long cap, long long *tri_off, int *err_flag);
 
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
                    int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const Cand *cand,

@@ -320,6 +320,281 @@ k_gen_ex_block(long long n_items, GenCfg cfg, const long long *__restrict__ item
   }
 }
 
+// Pass 1 of the exhaustive mode without VP / point proposals, with the loops swapped: one wave per (image pair,
+// 64-line chunk of the NEIGHBOUR image, quarter of the image's nodes).  Every lane keeps the gate operands of its
+// neighbour line in registers for the whole wave; the node side is wave-uniform -- scalar loads of the segment
+// record, and the epipolar lines of its two endpoints (gate3_epi) are computed once per node and image pair (64
+// endpoints per pass, all lanes busy) and broadcast through LDS.  Only ~4 % of the connections survive the cheap
+// gates: the connections that need the dense evaluation (exact gates where the cheap ones could not decide,
+// triangulation: ~1000 instructions) are appended to an LDS list ACROSS nodes and evaluated 64 at a time, so a dense
+// round runs with every lane active (k_gen_ex_block evaluates the ~20 entries of its eight chunks per round: 31 %).
+// The survivor ballots of up to kExSeg nodes are collected in LDS and written once -- the same words, at the same
+// item indices, as k_gen_ex_block<false, false> writes.
+constexpr int kExParts = 4;
+constexpr int kExRegions = 16;  // staging regions of the one-pass form (one bump counter each)
+constexpr int kExSeg = 128;  // nodes per segment (ballots held in LDS)
+constexpr int kExSub = 32;   // nodes per epipolar-line pass
+// kList (one-pass form): the kernel stops after the cheap gates -- the listed connections go, 64 at a time, into
+// blocks of a global entry list (kExRegions regions with one bump counter each, 128 bytes apart, so that the ~4e5
+// draws of a scene do not serialise; the last block of a wave is padded with ~0) and k_tri_ex evaluates them, one
+// block per wave: this kernel then needs no candidate registers and keeps 4 waves per SIMD.  A full region raises
+// error flag 5: the host repeats the run in the two-pass form.
+// entry: ng line | node index within its image << 16 | undecided << 32 | (image, neighbour) block << 33
+template <bool kList>
+__global__ void __launch_bounds__(256)
+k_gates_ex(int n_blk, int max_chunks, long long n_items, GenCfg cfg, const long long *__restrict__ item_off,
+           const int *__restrict__ blk_img, const int *__restrict__ blk_nb, const long long *__restrict__ seg_off,
+           const Cam *__restrict__ cams, const Seg *__restrict__ segs, const PairRec *__restrict__ pairs,
+           unsigned long long *__restrict__ masks, const int *__restrict__ blk_chunk_off,
+           const SegGate *__restrict__ gates, unsigned long long *__restrict__ ent_out,
+           unsigned long long *__restrict__ ctr, unsigned region_cap, int *__restrict__ err_flag) {
+  __shared__ unsigned s_list[4][128];
+  __shared__ unsigned long long s_mask[4][kList ? 1 : kExSeg];
+  __shared__ double s_epi[4][kExSub * 12];  // per node: (ax, ay, az, n2a, na, q1) of the start point, same of the end point
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = lane_id();
+  unsigned *list = s_list[wv];
+  unsigned long long *lmask = s_mask[wv];
+  double *epi = s_epi[wv];
+  const long long w = (long long)blockIdx.x * 4 + wv;
+  const int part = (int)(w % kExParts);
+  const long long r = w / kExParts;
+  const int c = (int)(r % max_chunks);
+  const long long b = r / max_chunks;
+  if (b >= n_blk) return;
+  const int i1 = blk_img[b], i2 = blk_nb[b];
+  const long long g2base = seg_off[i2];
+  const int M2 = (int)(seg_off[i2 + 1] - g2base);
+  if ((c << 6) >= M2) return;
+  const long long g1base = seg_off[i1];
+  const int M1 = (int)(seg_off[i1 + 1] - g1base);
+  const int n_lo = (int)((long long)M1 * part / kExParts), n_hi = (int)((long long)M1 * (part + 1) / kExParts);
+  const int ng = (c << 6) + lane;
+  const bool in_range = ng < M2;
+  const SegGate gg = gates[g2base + (in_range ? ng : M2 - 1)];
+  const PairRec &pr = pairs[b];
+  const int chunk_off = blk_chunk_off[b] + c;
+  const unsigned long long lt_mask = lanemask_lt();
+  const int region = (int)((b + c) & (kExRegions - 1));  // every region sees every chunk index and a spread of image pairs
+  int n_ent = 0;
+  for (int seg0 = n_lo; seg0 < n_hi; seg0 += kExSeg) {
+    const int ns = min(kExSeg, n_hi - seg0);
+    const bool last_seg = seg0 + kExSeg >= n_hi;
+    if (!kList)
+      for (int l = lane; l < ns; l += 64) lmask[l] = 0ull;
+    for (int sub0 = 0; sub0 < ns; sub0 += kExSub) {
+      const int nsub = min(kExSub, ns - sub0);
+      const bool last_sub = sub0 + kExSub >= ns;
+      wave_lds_sync();  // the previous pass' epipolar lines are no longer read
+      if (lane < 2 * nsub) {
+        const Seg &s = segs[g1base + seg0 + sub0 + (lane >> 1)];
+        const bool second = (lane & 1) != 0;
+        const GateEpi e = gate3_epi(pr.F, second ? s.x2 : s.x1, second ? s.y2 : s.y1);
+        const double d1x = s.x1 - s.x2, d1y = s.y1 - s.y2;
+        double *o = epi + 6 * lane;
+        o[0] = e.ax; o[1] = e.ay; o[2] = e.az; o[3] = e.n2a; o[4] = e.na;
+        o[5] = __builtin_fma(d1x, d1x, d1y * d1y);
+      }
+      wave_lds_sync();
+      for (int cc = 0;; ++cc) {
+        const bool more = cc < nsub;
+        if (more) {
+          // ---- phase A: does this connection need the dense evaluation ----
+          const Seg &s1 = segs[g1base + seg0 + sub0 + cc];
+          const double *o = epi + 12 * cc;
+          GateEpi ea, eb;
+          ea.ax = o[0]; ea.ay = o[1]; ea.az = o[2]; ea.n2a = o[3]; ea.na = o[4];
+          eb.ax = o[6]; eb.ay = o[7]; eb.az = o[8]; eb.n2a = o[9]; eb.na = o[10];
+          const int res = gate3_core(cfg, o[5], s1.rs[0], s1.rs[1], s1.rs[2], s1.re[0], s1.re[1], s1.re[2], gg.n[0],
+                                     gg.n[1], gg.n[2], gg.lcx, gg.lcy, gg.P, gg.Q, gg.w1, gg.sv, gg.q2, ea, eb);
+          const bool t0 = in_range && res != 0;
+          const unsigned long long bm = __ballot(t0);
+          if (t0)
+            list[n_ent + __popcll(bm & lt_mask)] = (unsigned)(((seg0 + sub0 + cc) << 7) | lane) | (res == 2 ? 64u : 0u);
+          n_ent += __popcll(bm);
+        }
+        // the list is emptied 64 entries at a time; the rest goes at the end of the segment (of the wave: kList)
+        if (n_ent >= 64 || (!more && last_sub && (last_seg || !kList) && n_ent > 0)) {
+          wave_lds_sync();
+          const int base = max(n_ent - 64, 0);
+          if (kList) {
+            // ---- one block of the global entry list ----
+            unsigned long long first = 0ull;
+            if (lane == 0) first = atomicAdd(&ctr[region * 16], 64ull);
+            first = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(first >> 32)) << 32) |
+                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(first & 0xFFFFFFFFull));
+            unsigned long long e = ~0ull;
+            if (base + lane < n_ent) {
+              const unsigned ent = list[base + lane];
+              e = (unsigned long long)(unsigned)((c << 6) | (int)(ent & 63u)) | ((unsigned long long)(ent >> 7) << 16) |
+                  ((unsigned long long)((ent >> 6) & 1u) << 32) | ((unsigned long long)b << 33);
+            }
+            if (first + 64ull <= (unsigned long long)region_cap) ent_out[(size_t)region * region_cap + (size_t)first + lane] = e;
+            else *err_flag = 5;
+          } else if (base + lane < n_ent) {
+            // ---- phase B: dense evaluation of (up to) 64 listed connections ----
+            const unsigned ent = list[base + lane];
+            const int nd = (int)(ent >> 7), ln = (int)(ent & 63u);
+            const Seg &s1 = segs[g1base + nd];
+            const Seg &s2 = segs[g2base + (c << 6) + ln];
+            GenOut o;
+            const bool ok = (ent & 64u) ? gen_one(cfg, cams[i1], cams[i2], s1, s2, pr, &o)
+                                        : gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o);
+            if (ok) atomicOr(&lmask[nd - seg0], 1ull << ln);
+          }
+          n_ent = base;
+          wave_lds_sync();
+        }
+        if (!more) break;
+      }
+    }
+    if (!kList) {
+      wave_lds_sync();
+      // ---- phase C: the survivor ballots of the segment ----
+      for (int l = lane; l < ns; l += 64) {
+        const long long item = item_off[g1base + seg0 + l] + chunk_off;
+        if (item < n_items) masks[item] = lmask[l];
+      }
+      wave_lds_sync();
+    }
+  }
+}
+
+// One-pass exhaustive mode, dense evaluation: one wave per block of 64 listed connections (all of one image pair).
+// Exact gates where the cheap ones could not decide, triangulation; a survivor is written to the staging slot with
+// the index of its entry (the other slots are holes: node = ~0) and sets its bit in the ballot word of its work
+// item (masks zeroed beforehand) -- from there on the counts, offsets and the permutation are those of the two-pass
+// form.
+__global__ void __launch_bounds__(256)
+k_tri_ex(const unsigned long long *__restrict__ ent, const unsigned long long *__restrict__ ctr, unsigned region_cap,
+         GenCfg cfg, long long n_items, const long long *__restrict__ item_off, const int *__restrict__ blk_img,
+         const int *__restrict__ blk_nb, const long long *__restrict__ nb_off, const long long *__restrict__ seg_off,
+         const Cam *__restrict__ cams, const Seg *__restrict__ segs, const PairRec *__restrict__ pairs,
+         const int *__restrict__ blk_chunk_off, unsigned long long *__restrict__ masks, Cand *__restrict__ st_c,
+         CandLite *__restrict__ st_l, unsigned *__restrict__ st_node) {
+  const int region = blockIdx.y;
+  const unsigned long long n = ctr[region * 16];
+  const unsigned long long t0 = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64ull;
+  if (t0 >= n || t0 + 64ull > (unsigned long long)region_cap) return;
+  const int lane = lane_id();
+  const size_t slot = (size_t)region * region_cap + (size_t)t0 + lane;
+  const unsigned long long e = ent[slot];
+  // lane 0 of a block always holds an entry, and every entry of a block comes from the same wave of k_gates_ex
+  const unsigned e_hi0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(e >> 32));
+  const long long b = (long long)(e_hi0 >> 1);
+  const int i1 = blk_img[b], i2 = blk_nb[b];
+  bool ok = false;
+  unsigned node = 0xFFFFFFFFu;
+  if (e != ~0ull) {
+    const int ng = (int)(e & 0xFFFFu), nd = (int)((e >> 16) & 0xFFFFu);
+    const long long g = seg_off[i1] + nd;
+    const Seg &s1 = segs[g];
+    const Seg &s2 = segs[seg_off[i2] + ng];
+    const PairRec &pr = pairs[b];
+    GenOut o;
+    ok = ((e >> 32) & 1ull) ? gen_one(cfg, cams[i1], cams[i2], s1, s2, pr, &o)
+                            : gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o);
+    if (ok) {
+      o.l.nb_slot = lite_pack((int)(b - nb_off[i1]), i2);
+      o.l.ng_line = ng;
+      st_c[slot] = o.c;
+      st_l[slot] = o.l;
+      node = (unsigned)g;
+      const long long item = item_off[g] + blk_chunk_off[b] + (ng >> 6);
+      if (item < n_items) atomicOr(&masks[item], 1ull << (ng & 63));
+    }
+  }
+  st_node[slot] = node;
+}
+
+// Pass 2 of the plain exhaustive mode: one wave per (image pair, eighth of the image's nodes).  The survivors of
+// pass 1 (ballots masks[item], output offsets mask_pos[item]) are expanded into an LDS list across chunks and nodes
+// and triangulated 64 at a time with every lane active (a (node, neighbour) block has ~20 survivors: the
+// wave-per-block form ran its rounds at 31 %); both cameras and the pair record stay wave-uniform.  Every candidate
+// is written at mask_pos[item] + (survivors of the lower lanes): the order of base_line_triangulator.cc:111-136.
+constexpr int kFillParts = 8;
+__global__ void __launch_bounds__(256)
+k_fill_ex(int n_blk, long long n_items, GenCfg cfg, const long long *__restrict__ item_off,
+          const int *__restrict__ blk_img, const int *__restrict__ blk_nb, const long long *__restrict__ nb_off,
+          const long long *__restrict__ seg_off, const Cam *__restrict__ cams, const Seg *__restrict__ segs,
+          const PairRec *__restrict__ pairs, const unsigned long long *__restrict__ masks,
+          const long long *__restrict__ mask_pos, Cand *__restrict__ out_c, CandLite *__restrict__ out_l,
+          const int *__restrict__ blk_chunk_off) {
+  __shared__ unsigned s_list[4][128];
+  __shared__ long long s_pos[4][128];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = lane_id();
+  unsigned *list = s_list[wv];
+  long long *lpos = s_pos[wv];
+  const long long w = (long long)blockIdx.x * 4 + wv;
+  const int part = (int)(w % kFillParts);
+  const long long b = w / kFillParts;
+  if (b >= n_blk) return;
+  const int i1 = blk_img[b], i2 = blk_nb[b];
+  const long long g2base = seg_off[i2];
+  const int M2 = (int)(seg_off[i2 + 1] - g2base);
+  const int n_chunks = (M2 + 63) >> 6;
+  const long long g1base = seg_off[i1];
+  const int M1 = (int)(seg_off[i1 + 1] - g1base);
+  const int n_lo = (int)((long long)M1 * part / kFillParts), n_hi = (int)((long long)M1 * (part + 1) / kFillParts);
+  const PairRec &pr = pairs[b];
+  const int nbs = lite_pack((int)(b - nb_off[i1]), i2);
+  const int chunk_off = blk_chunk_off[b];
+  const unsigned long long lt_mask = lanemask_lt();
+  int n_ent = 0;
+  auto dense = [&]() {
+    wave_lds_sync();
+    const int base = max(n_ent - 64, 0);
+    if (base + lane < n_ent) {
+      const unsigned ent = list[base + lane];
+      const long long pos = lpos[base + lane];
+      const int nd = (int)(ent >> 16), ng = (int)(ent & 0xFFFFu);
+      const Seg &s1 = segs[g1base + nd];
+      const Seg &s2 = segs[g2base + ng];
+      GenOut o;
+      if (gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o)) {  // pass 1 proved the gates
+        o.l.nb_slot = nbs;
+        o.l.ng_line = ng;
+        out_c[pos] = o.c;
+        out_l[pos] = o.l;
+      }
+    }
+    n_ent = base;
+    wave_lds_sync();
+  };
+  for (int nd = n_lo; nd < n_hi; ++nd) {
+    const long long item0 = item_off[g1base + nd] + chunk_off;
+    for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+      const int ncb = min(64, n_chunks - c0);
+      unsigned long long m_l = 0ull;
+      long long p_l = 0;
+      if (lane < ncb && item0 + c0 + lane < n_items) {
+        m_l = masks[item0 + c0 + lane];
+        p_l = mask_pos[item0 + c0 + lane];
+      }
+      unsigned long long nonempty = __ballot(m_l != 0ull);
+      while (nonempty) {
+        const int cc = __builtin_ctzll(nonempty);
+        nonempty &= nonempty - 1ull;
+        const unsigned long long m =
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(m_l >> 32), cc) << 32) |
+            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(m_l & 0xFFFFFFFFull), cc);
+        const long long p0 =
+            (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)p_l >> 32), cc) << 32) |
+                        (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)p_l & 0xFFFFFFFFull), cc));
+        if ((m >> lane) & 1ull) {
+          const int rank = __popcll(m & lt_mask);
+          list[n_ent + rank] = ((unsigned)nd << 16) | (unsigned)(((c0 + cc) << 6) | lane);
+          lpos[n_ent + rank] = p0 + rank;
+        }
+        n_ent += __popcll(m);
+        if (n_ent >= 64) dense();
+      }
+    }
+  }
+  if (n_ent > 0) dense();
+}
+
 // Exhaustive mode with the point-guided proposals (and, if set, the VP ones): per connection a variable
 // number of candidates in the reference's order many-points, one-point (one per shared point, ascending
 // point3D_id), vp(l1), vp(l2), algebraic (base_line_triangulator.cc:183-325).  Pass 1 (kFill == false)
@@ -458,14 +733,55 @@ __global__ void k_popc(long long n, const unsigned long long *__restrict__ masks
   cnt[t] = c;
 }
 
-// tri_off[g] = mask_pos[item_off[g]]
+// tri_off[g] = mask_pos[item_off[g]].  total < 0: the candidate count stays on the device (mask_pos[n_items]);
+// cap >= 0: the staging capacity of the one-pass form -- a count beyond it leaves every node empty and raises
+// error flag 5 (the host repeats the run in the two-pass form).
 __global__ void k_tri_offsets_ex(long long G, const long long *__restrict__ item_off,
                                  const long long *__restrict__ mask_pos, long long n_items,
-                                 long long total, long long *__restrict__ tri_off) {
+                                 long long total, long long cap, long long *__restrict__ tri_off,
+                                 int *__restrict__ err_flag) {
   long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g > G) return;
+  if (total < 0) total = mask_pos[n_items];
+  if (cap >= 0 && (total > cap || *err_flag == 5)) {  // 5: a staging region of k_gates_ex was full
+    tri_off[g] = 0;
+    if (g == 0) *err_flag = 5;
+    return;
+  }
   long long it = item_off[g];
   tri_off[g] = (it >= n_items) ? total : mask_pos[it];
+}
+
+// One-pass exhaustive mode: the final position of the candidate in staging slot s -- its work item is
+// (node, neighbour block, chunk of its neighbour line), its rank the survivors of the lower lanes of that item.
+__global__ void __launch_bounds__(256)
+k_place_ex(const unsigned long long *__restrict__ ctr, unsigned region_cap, const CandLite *__restrict__ st_l,
+           const unsigned *__restrict__ st_node, const int *__restrict__ node_img, const long long *__restrict__ nb_off,
+           const long long *__restrict__ item_off, const int *__restrict__ blk_chunk_off,
+           const unsigned long long *__restrict__ masks, const long long *__restrict__ mask_pos, long long n_items,
+           const long long *__restrict__ tri_off, long long G, unsigned *__restrict__ perm,
+           long long *__restrict__ fill_out) {
+  const int region = blockIdx.y;
+  const unsigned long long n = ctr[region * 16];
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0 && region == 0) {  // the fullest region: what the host sizes the next run's staging by
+    unsigned long long mx = 0ull;
+    for (int r = 0; r < kExRegions; ++r) mx = ctr[r * 16] > mx ? ctr[r * 16] : mx;
+    *fill_out = (long long)mx;
+  }
+  if (t >= n || t >= (unsigned long long)region_cap) return;
+  if (tri_off[G] == 0) return;  // overflow: nothing is placed
+  const size_t slot = (size_t)region * region_cap + (size_t)t;
+  const unsigned gu = st_node[slot];
+  if (gu == 0xFFFFFFFFu) return;  // a connection that failed the dense evaluation
+  const CandLite l = st_l[slot];
+  const long long g = (long long)gu;
+  const long long b = nb_off[node_img[g]] + lite_slot(l);
+  const long long item = item_off[g] + blk_chunk_off[b] + (l.ng_line >> 6);
+  if (item >= n_items) return;
+  const unsigned long long m = masks[item];
+  const long long pos = mask_pos[item] + __popcll(m & ((1ull << (l.ng_line & 63)) - 1ull));
+  perm[pos] = (unsigned)slot;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -675,6 +991,57 @@ void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const G
   }
 #undef LT_LAUNCH_EX
 }
+// pass 1 of the plain exhaustive mode (no VP / point proposals): see k_gates_ex.  ent_out != nullptr: the one-pass form
+// (gates only; entry blocks into ent_out; ctr = ex_regions() zeroed counters 128 bytes apart; region_cap slots per region)
+int ex_regions() { return kExRegions; }
+void launch_gates_exhaustive(hipStream_t st, int n_blk, int max_chunks, long long n_items, const GenCfg &cfg,
+                             const long long *item_off, const int *blk_img, const int *blk_nb, const long long *seg_off,
+                             const Cam *cams, const Seg *segs, const PairRec *pairs, unsigned long long *masks,
+                             const int *blk_chunk_off, const void *gates_v, unsigned long long *ent_out,
+                             unsigned long long *ctr, unsigned region_cap, int *err_flag) {
+  if (n_items <= 0 || n_blk <= 0) return;
+  const long long waves = (long long)n_blk * max_chunks * kExParts;
+  const dim3 grid(nblk(waves * 64, 256)), block(256);
+  const SegGate *gates = reinterpret_cast<const SegGate *>(gates_v);
+  if (ent_out)
+    hipLaunchKernelGGL(k_gates_ex<true>, grid, block, 0, st, n_blk, max_chunks, n_items, cfg, item_off, blk_img, blk_nb,
+                       seg_off, cams, segs, pairs, masks, blk_chunk_off, gates, ent_out, ctr, region_cap, err_flag);
+  else
+    hipLaunchKernelGGL(k_gates_ex<false>, grid, block, 0, st, n_blk, max_chunks, n_items, cfg, item_off, blk_img, blk_nb,
+                       seg_off, cams, segs, pairs, masks, blk_chunk_off, gates, ent_out, ctr, region_cap, err_flag);
+}
+// one-pass form: dense evaluation of the entry blocks (masks zeroed beforehand)
+void launch_tri_exhaustive(hipStream_t st, const unsigned long long *ent, const unsigned long long *ctr,
+                           unsigned region_cap, const GenCfg &cfg, long long n_items, const long long *item_off,
+                           const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
+                           const Cam *cams, const Seg *segs, const PairRec *pairs, const int *blk_chunk_off,
+                           unsigned long long *masks, Cand *st_c, CandLite *st_l, unsigned *st_node) {
+  if (region_cap == 0) return;
+  hipLaunchKernelGGL(k_tri_ex, dim3(nblk((long long)region_cap, 256), kExRegions), dim3(256), 0, st, ent, ctr, region_cap,
+                     cfg, n_items, item_off, blk_img, blk_nb, nb_off, seg_off, cams, segs, pairs, blk_chunk_off, masks, st_c,
+                     st_l, st_node);
+}
+// one-pass form: perm[final position] = staging slot, for every slot the regions handed out
+void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsigned region_cap, const CandLite *st_l,
+                             const unsigned *st_node, const int *node_img, const long long *nb_off,
+                             const long long *item_off, const int *blk_chunk_off, const unsigned long long *masks,
+                             const long long *mask_pos, long long n_items, const long long *tri_off, long long G,
+                             unsigned *perm, long long *fill_out) {
+  if (region_cap == 0) return;
+  hipLaunchKernelGGL(k_place_ex, dim3(nblk((long long)region_cap, 256), kExRegions), dim3(256), 0, st, ctr, region_cap, st_l,
+                     st_node, node_img, nb_off, item_off, blk_chunk_off, masks, mask_pos, n_items, tri_off, G, perm,
+                     fill_out);
+}
+// pass 2 of the plain exhaustive mode: see k_fill_ex
+void launch_fill_exhaustive(hipStream_t st, int n_blk, long long n_items, const GenCfg &cfg, const long long *item_off,
+                            const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
+                            const Cam *cams, const Seg *segs, const PairRec *pairs, const unsigned long long *masks,
+                            const long long *mask_pos, Cand *out_c, CandLite *out_l, const int *blk_chunk_off) {
+  if (n_items <= 0 || n_blk <= 0) return;
+  const long long waves = (long long)n_blk * kFillParts;
+  hipLaunchKernelGGL(k_fill_ex, dim3(nblk(waves * 64, 256)), dim3(256), 0, st, n_blk, n_items, cfg, item_off, blk_img,
+                     blk_nb, nb_off, seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l, blk_chunk_off);
+}
 void launch_gen_exhaustive_pts(hipStream_t st, bool fill, long long n_items, const GenCfg &cfg,
                                const long long *item_off, long long G, const int *node_img, const long long *nb_off,
                                const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
@@ -701,9 +1068,9 @@ void launch_popc(hipStream_t st, long long n, const unsigned long long *masks, u
   if (n > 0) hipLaunchKernelGGL(k_popc, dim3(nblk(n, 256)), dim3(256), 0, st, n, masks, cnt, n_masks);
 }
 void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_off, const long long *mask_pos,
-                           long long n_items, long long total, long long *tri_off) {
+                           long long n_items, long long total, long long cap, long long *tri_off, int *err_flag) {
   hipLaunchKernelGGL(k_tri_offsets_ex, dim3(nblk(G + 1, 256)), dim3(256), 0, st, G, item_off, mask_pos, n_items,
-                     total, tri_off);
+                     total, cap, tri_off, err_flag);
 }
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
                    int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const Cand *cand,

@@ -870,7 +870,8 @@ struct Score3Args {
   double *score;
   unsigned long long *pair_counter;  // stats: pairs that reached the dense evaluation
   unsigned *draw;                    // kTileQueues draw counters, 128 bytes apart: queue q = tiles q, q + 8, ...
-  const unsigned *perm;              // kSorted: candidate at depth-sorted position t (k_depth_order)
+  const unsigned *perm;              // kSorted: candidate record at depth-sorted position t (k_depth_order)
+  const unsigned *spos;              // kSorted over staged records: natural position (score index) of sorted position t
   const uint2 *rng;                  // kSorted: node-relative range of sorted positions lane t has to sweep
   const unsigned *tile_order;        // developer experiment: draw e processes tile tile_order[e]
   const unsigned *bucket_cnt;        // tiles by cost class (k_cand_meta): counts, lists of bucket_cap entries each
@@ -934,7 +935,8 @@ static __device__ __forceinline__ void wave_bitonic(unsigned long long (&v)[R], 
 // sorts the node's (depth, index) words and leaves the sorted float keys in LDS (key[0..n)) and perm in HBM
 template <int R>
 static __device__ __forceinline__ bool depth_sort_node(const Cand *__restrict__ cand, long long off, int n, int lane,
-                                                       float *key, unsigned *__restrict__ perm) {
+                                                       float *key, unsigned *__restrict__ perm,
+                                                       const unsigned *__restrict__ place, unsigned *__restrict__ rec) {
   unsigned long long v[R];
   bool bad = false;
 #pragma unroll
@@ -942,7 +944,7 @@ static __device__ __forceinline__ bool depth_sort_node(const Cand *__restrict__ 
     const int e = r * 64 + lane;
     v[r] = ~0ull;  // padding sorts to the end
     if (e < n) {
-      const double z = cand[off + e].depth[0];
+      const double z = cand[place ? (long long)place[off + e] : off + e].depth[0];
       const float kf = (float)z;
       bad = bad || !(z > 0.0 && z < 1e30);  // non-positive / NaN / inf / absurd depth: no pruning for this node
       v[r] = ((unsigned long long)__float_as_uint(kf) << 32) | (unsigned)e;  // positive floats order like their bits
@@ -955,7 +957,9 @@ static __device__ __forceinline__ bool depth_sort_node(const Cand *__restrict__ 
     const int e = r * 64 + lane;
     if (e < n) {
       key[e] = __uint_as_float((unsigned)(v[r] >> 32));
-      perm[off + e] = (unsigned)(off + (long long)(unsigned)(v[r] & 0xFFFFFFFFull));
+      const long long nat = off + (long long)(unsigned)(v[r] & 0xFFFFFFFFull);
+      perm[off + e] = (unsigned)nat;
+      if (place) rec[off + e] = place[nat];
     }
   }
   return true;
@@ -963,7 +967,10 @@ static __device__ __forceinline__ bool depth_sort_node(const Cand *__restrict__ 
 
 __global__ void __launch_bounds__(256)
 k_depth_order(long long G, const long long *__restrict__ tri_off, const Cand *__restrict__ cand, double guard,
-              unsigned *__restrict__ perm, uint2 *__restrict__ rng) {
+              unsigned *__restrict__ perm, uint2 *__restrict__ rng, const unsigned *__restrict__ place,
+              unsigned *__restrict__ rec) {
+  // place != nullptr: the records are staged (one-pass exhaustive mode), the candidate at natural position p is record
+  // place[p]; perm then holds the natural position and rec the record of every depth-sorted position
   __shared__ float s_key[4][kSortMax];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
@@ -974,12 +981,12 @@ k_depth_order(long long G, const long long *__restrict__ tri_off, const Cand *__
   if (n <= 0) return;
   float *key = s_key[wv];
   bool sorted = false;
-  if (n <= 64) sorted = depth_sort_node<1>(cand, off, n, lane, key, perm);
-  else if (n <= 128) sorted = depth_sort_node<2>(cand, off, n, lane, key, perm);
-  else if (n <= 256) sorted = depth_sort_node<4>(cand, off, n, lane, key, perm);
-  else if (n <= 512) sorted = depth_sort_node<8>(cand, off, n, lane, key, perm);
-  else if (n <= 1024) sorted = depth_sort_node<16>(cand, off, n, lane, key, perm);
-  else if (n <= 2048) sorted = depth_sort_node<32>(cand, off, n, lane, key, perm);
+  if (n <= 64) sorted = depth_sort_node<1>(cand, off, n, lane, key, perm, place, rec);
+  else if (n <= 128) sorted = depth_sort_node<2>(cand, off, n, lane, key, perm, place, rec);
+  else if (n <= 256) sorted = depth_sort_node<4>(cand, off, n, lane, key, perm, place, rec);
+  else if (n <= 512) sorted = depth_sort_node<8>(cand, off, n, lane, key, perm, place, rec);
+  else if (n <= 1024) sorted = depth_sort_node<16>(cand, off, n, lane, key, perm, place, rec);
+  else if (n <= 2048) sorted = depth_sort_node<32>(cand, off, n, lane, key, perm, place, rec);
   if (sorted) {
     wave_lds_sync();
     for (int r = lane; r < n; r += 64) {
@@ -1011,6 +1018,7 @@ k_depth_order(long long G, const long long *__restrict__ tri_off, const Cand *__
   } else {
     for (int r = lane; r < n; r += 64) {
       perm[off + r] = (unsigned)(off + r);
+      if (place) rec[off + r] = place[off + r];
       rng[off + r] = make_uint2(0u, (unsigned)n);
     }
   }
@@ -1203,8 +1211,8 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
           const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
           const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
           W4[3 * e + 0] = float4{(float)l.dir[0], (float)l.dir[1], (float)l.dir[2], __int_as_float(lite_slot(l))};
-          W4[3 * e + 1] = float4{sx, sy, sz, 0.0f};
-          W4[3 * e + 2] = float4{ex, ey, ez, 0.0f};
+          W4[3 * e + 1] = float4{sx, ex, sy, ey};  // start / end interleaved: the sweep's packed-f32 operand pairs
+          W4[3 * e + 2] = float4{sz, ez, 0.0f, 0.0f};
           rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
         } else {
           W[0 * kWin + e] = l.dir[0]; W[1 * kWin + e] = l.dir[1]; W[2 * kWin + e] = l.dir[2];
@@ -1240,26 +1248,30 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
         const int wlast = cnt > 0 ? w0 + cnt - 1 : 0;  // reads beyond the lane's range are clamped, then masked
         const int wbase = cnt > 0 ? w0 : 0;
         for (int t = 0; t < cmax; t += 4) {
-          float4 A[4], B[4], E[4];
+          float4 A[4], B[4];
+          float2 E[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int w = min(wbase + t + u, wlast);
             A[u] = W4[3 * w + 0];
             B[u] = W4[3 * w + 1];
-            E[u] = W4[3 * w + 2];
+            E[u] = *reinterpret_cast<const float2 *>(&W4[3 * w + 2]);
           }
           bool pass[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const float c = fabsf(__builtin_fmaf(dizf, A[u].z, __builtin_fmaf(diyf, A[u].y, dixf * A[u].x)));
-            const float ax = sixf - B[u].x, ay = siyf - B[u].y, az = sizf - B[u].z;
-            const float bx = eixf - E[u].x, by = eiyf - E[u].y, bz = eizf - E[u].z;
+            // (start, end) pairs: v_pk_add / v_pk_mul / v_pk_fma_f32 straight from the window's layout
+            const float ax = sixf - B[u].x, bx = eixf - B[u].y;
+            const float ay = siyf - B[u].z, by = eiyf - B[u].w;
+            const float az = sizf - E[u].x, bz = eizf - E[u].y;
             const float ds2 = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
             const float de2 = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
             // below the cosine guard the 3D angle score is certainly gated to 0; beyond the squared
-            // distance guards the scale-invariant endpoint score is
-            pass[u] = (t + u < cnt) && (t + u != self_t) && (__float_as_int(A[u].w) != sloti) && !(c < cosf_guard) &&
-                      !(ds2 > gsf) && !(de2 > gef);
+            // distance guards the scale-invariant endpoint score is.  (Bitwise &: no branch per test -- the
+            // reads are clamped, everything may be evaluated.)
+            pass[u] = (t + u < cnt) & (t + u != self_t) & (__float_as_int(A[u].w) != sloti) & !(c < cosf_guard) &
+                      !(ds2 > gsf) & !(de2 > gef);
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -1306,7 +1318,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
         int k = own ? ordl[r] : a.blk_order[nb0 + r];
         sum += __longlong_as_double((long long)S[k * 64 + lane]);
       }
-      a.score[kPerm ? tpos : i] = sum;
+      a.score[kPerm ? tpos : (kSorted && a.spos ? (long long)a.spos[tpos] : i)] = sum;
     }
     n_eval_total += n_eval;
     wave_lds_sync();  // the tables are reused by the next tile
@@ -1447,7 +1459,10 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
-                   unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap) {
+                   unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap, const unsigned *place,
+                   unsigned *rec) {
+  // place / rec: depth-sorted sweep over STAGED records (one-pass exhaustive mode): place[natural position] = record,
+  // rec (scratch, one word per candidate) receives the record of every sorted position
   if (C <= 0) return;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -1466,6 +1481,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
   a.draw = draw;
   a.perm = perm; a.rng = reinterpret_cast<const uint2 *>(rng);
+  a.spos = nullptr;
   a.tile_order = tile_order;
   a.bucket_cnt = bucket_cnt; a.bucket_list = bucket_list; a.bucket_cap = bucket_cap;
   a.max_nb = max_nb;
@@ -1473,7 +1489,12 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   const bool sorted = perm != nullptr && f32 && !perm_is_placement;
   if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
     hipLaunchKernelGGL(k_depth_order, dim3(nblk2(G, 4)), dim3(256), 0, st, G, tri_off, cand,
-                       scaleinv_guard2 < 1e299 ? std::sqrt(scaleinv_guard2) : 1e300, perm, reinterpret_cast<uint2 *>(rng));
+                       scaleinv_guard2 < 1e299 ? std::sqrt(scaleinv_guard2) : 1e300, perm, reinterpret_cast<uint2 *>(rng),
+                       place, rec);
+  if (sorted && place) {
+    a.perm = rec;
+    a.spos = perm;
+  }
   // persistent grid: as many single-wave workgroups as fit at once (LDS; registers allow LT_SCORE_RESIDENT per CU)
   const size_t lds = score3_lds_bytes(max_nb, f32);
   const long long per_cu = std::max<long long>(1, std::min<long long>(LT_SCORE_RESIDENT, (long long)(160 * 1024 / lds)));

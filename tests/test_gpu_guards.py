@@ -37,7 +37,9 @@ def _same(a, b):
 
 @pytest.fixture
 def clean_env():
-    keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES")
+    keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES",
+            "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
+            "LT_TEST_SCORE_UNSORTED")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -311,3 +313,34 @@ def test_tile_cost_classes_do_not_change_results(gpu_lib, clean_env):
     _same(base, plain)
     ex = _results(run_product(small_scene(seed=3, n_views=8, n_segs=60, n_neighbors=4), cfg, exhaustive=True))
     assert ex[5]["candidates"] > 0
+
+
+def test_exhaustive_one_pass_equals_two_pass(gpu_lib, clean_env):
+    """Plain exhaustive mode: the one-pass form (pass 1 writes the survivors to staging slots, a permutation orders
+    them, the depth-sorted sweep runs over the staged records) against the two-pass forms (new kernels, and the
+    wave-per-(node, neighbour) kernels the VP variant uses) -- identical bits everywhere.  A staging capacity that
+    does not hold makes the run repeat itself in the two-pass form; the plain (unsorted) sweep over staged records
+    is the matched path's permutation mode."""
+    sc = small_scene(seed=21, n_views=10, n_segs=150, n_neighbors=5)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    base = _results(run_product(sc, cfg, exhaustive=True))
+    assert base[0]["off"][-1] > 1000
+    variants = ({"LT_TEST_EX_TWO_PASS": "1"},
+                {"LT_TEST_EX_TWO_PASS": "1", "LT_TEST_EX_PASS2_BLOCK": "1"},
+                {"LT_TEST_EX_PASS1_BLOCK": "1", "LT_TEST_EX_PASS2_BLOCK": "1"},
+                {"LT_TEST_EX_CAP_FRAC": "0.0005"},
+                {"LT_TEST_SCORE_UNSORTED": "1"})
+    for env in variants:
+        os.environ.update(env)
+        try:
+            _same(base, _results(run_product(sc, cfg, exhaustive=True)))
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    # a context that runs the job repeatedly adapts the capacity to the measured yield
+    T = run_product(sc, cfg, exhaustive=True)
+    ctx = T.context()
+    ctx.upload()
+    for _ in range(3):
+        ctx.run_device()
+    _same(base, _results(T))

@@ -1,0 +1,15 @@
+import sys
+sys.path.insert(0, "/root/repo")
+from limap_amd import synthetic as syn, triangulation as tri
+sc = syn.make_scene(n_views=100, n_segs=500, n_neighbors=20, seed=0)
+T = tri.GlobalLineTriangulator(syn.default_triangulation_cfg())
+T.SetRanges(sc.ranges)
+T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(j) for j in range(sc.n_images)])
+for i in sc.img_ids:
+    T.TriangulateImageExhaustiveMatch(int(i), sc.neighbors[int(i)])
+ctx = T.context()
+ctx.upload()
+for k in range(5):
+    ctx.run_device()
+    t = ctx.timers()
+    print(k, {a: round(t[a], 3) for a in ("run", "gen", "compact", "score", "ex_slots", "ex_cap")}, ctx.stats()["candidates"])
