@@ -349,11 +349,13 @@ k_gates_ex(int n_blk, int max_chunks, long long n_items, GenCfg cfg, const long 
            const SegGate *__restrict__ gates, unsigned long long *__restrict__ ent_out,
            unsigned long long *__restrict__ ctr, unsigned region_cap, int *__restrict__ err_flag) {
   __shared__ unsigned s_list[4][128];
+  __shared__ unsigned s_list2[4][kList ? 128 : 1];
   __shared__ unsigned long long s_mask[4][kList ? 1 : kExSeg];
   __shared__ double s_epi[4][kExSub * 12];  // per node: (ax, ay, az, n2a, na, q1) of the start point, same of the end point
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
   unsigned *list = s_list[wv];
+  unsigned *list2 = s_list2[wv];
   unsigned long long *lmask = s_mask[wv];
   double *epi = s_epi[wv];
   const long long w = (long long)blockIdx.x * 4 + wv;
@@ -376,7 +378,25 @@ k_gates_ex(int n_blk, int max_chunks, long long n_items, GenCfg cfg, const long 
   const int chunk_off = blk_chunk_off[b] + c;
   const unsigned long long lt_mask = lanemask_lt();
   const int region = (int)((b + c) & (kExRegions - 1));  // every region sees every chunk index and a spread of image pairs
-  int n_ent = 0;
+  int n_ent = 0, n_ent2 = 0;
+  auto flush2 = [&]() {  // kList: (up to) 64 entries of the second list -> one block of the global entry list
+    wave_lds_sync();
+    const int base2 = max(n_ent2 - 64, 0);
+    unsigned long long first = 0ull;
+    if (lane == 0) first = atomicAdd(&ctr[region * 16], 64ull);
+    first = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(first >> 32)) << 32) |
+            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(first & 0xFFFFFFFFull));
+    unsigned long long e = ~0ull;
+    if (base2 + lane < n_ent2) {
+      const unsigned e2 = list2[base2 + lane];
+      e = (unsigned long long)(unsigned)((c << 6) | (int)(e2 & 63u)) | ((unsigned long long)(e2 >> 7) << 16) |
+          ((unsigned long long)((e2 >> 6) & 1u) << 32) | ((unsigned long long)b << 33);
+    }
+    if (first + 64ull <= (unsigned long long)region_cap) ent_out[(size_t)region * region_cap + (size_t)first + lane] = e;
+    else *err_flag = 5;
+    n_ent2 = base2;
+    wave_lds_sync();
+  };
   for (int seg0 = n_lo; seg0 < n_hi; seg0 += kExSeg) {
     const int ns = min(kExSeg, n_hi - seg0);
     const bool last_seg = seg0 + kExSeg >= n_hi;
@@ -400,6 +420,7 @@ k_gates_ex(int n_blk, int max_chunks, long long n_items, GenCfg cfg, const long 
         const bool more = cc < nsub;
         if (more) {
           // ---- phase A: does this connection need the dense evaluation ----
+          // (two nodes per iteration, for two independent dependency chains per lane: measured, no change)
           const Seg &s1 = segs[g1base + seg0 + sub0 + cc];
           const double *o = epi + 12 * cc;
           GateEpi ea, eb;
@@ -418,19 +439,21 @@ k_gates_ex(int n_blk, int max_chunks, long long n_items, GenCfg cfg, const long 
           wave_lds_sync();
           const int base = max(n_ent - 64, 0);
           if (kList) {
-            // ---- one block of the global entry list ----
-            unsigned long long first = 0ull;
-            if (lane == 0) first = atomicAdd(&ctr[region * 16], 64ull);
-            first = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(first >> 32)) << 32) |
-                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(first & 0xFFFFFFFFull));
-            unsigned long long e = ~0ull;
+            // ---- pre-test of (up to) 64 listed connections: the intersections, cheirality and the ranges reject about
+            // half of what the cheap gates pass, for ~5 % of the cost of the full evaluation; the rest goes to the
+            // second list, and from there in blocks of 64 to the global entry list ----
+            bool keep = false;
+            unsigned ent = 0u;
             if (base + lane < n_ent) {
-              const unsigned ent = list[base + lane];
-              e = (unsigned long long)(unsigned)((c << 6) | (int)(ent & 63u)) | ((unsigned long long)(ent >> 7) << 16) |
-                  ((unsigned long long)((ent >> 6) & 1u) << 32) | ((unsigned long long)b << 33);
+              ent = list[base + lane];
+              keep = gen_pretest(cfg, cams[i1], cams[i2], segs[g1base + (int)(ent >> 7)],
+                                 segs[g2base + (c << 6) + (int)(ent & 63u)], pr.B);
             }
-            if (first + 64ull <= (unsigned long long)region_cap) ent_out[(size_t)region * region_cap + (size_t)first + lane] = e;
-            else *err_flag = 5;
+            const unsigned long long km = __ballot(keep);
+            if (keep) list2[n_ent2 + __popcll(km & lt_mask)] = ent;
+            n_ent2 += __popcll(km);
+            n_ent = base;
+            if (n_ent2 >= 64) flush2();
           } else if (base + lane < n_ent) {
             // ---- phase B: dense evaluation of (up to) 64 listed connections ----
             const unsigned ent = list[base + lane];
@@ -458,6 +481,7 @@ k_gates_ex(int n_blk, int max_chunks, long long n_items, GenCfg cfg, const long 
       wave_lds_sync();
     }
   }
+  if (kList && n_ent2 > 0) flush2();
 }
 
 // One-pass exhaustive mode, dense evaluation: one wave per block of 64 listed connections (all of one image pair).
@@ -472,12 +496,18 @@ k_tri_ex(const unsigned long long *__restrict__ ent, const unsigned long long *_
          const Cam *__restrict__ cams, const Seg *__restrict__ segs, const PairRec *__restrict__ pairs,
          const int *__restrict__ blk_chunk_off, unsigned long long *__restrict__ masks, Cand *__restrict__ st_c,
          CandLite *__restrict__ st_l, unsigned *__restrict__ st_node) {
+  // The 64 staging slots of a block are contiguous: the records go through LDS and leave as full 1 KB rows (a lane
+  // storing its own 112-byte record writes 16-byte pieces 112 bytes apart -- every store instruction then touches 64
+  // cache lines, and the kernel was bound by that, not by its arithmetic).  Holes carry stale bytes, nobody reads them.
+  __shared__ double2 s_out[4][64 * 9];
   const int region = blockIdx.y;
   const unsigned long long n = ctr[region * 16];
-  const unsigned long long t0 = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64ull;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned long long t0 = ((unsigned long long)blockIdx.x * 4 + (unsigned)wv) * 64ull;
   if (t0 >= n || t0 + 64ull > (unsigned long long)region_cap) return;
   const int lane = lane_id();
-  const size_t slot = (size_t)region * region_cap + (size_t)t0 + lane;
+  const size_t slot0 = (size_t)region * region_cap + (size_t)t0;
+  const size_t slot = slot0 + lane;
   const unsigned long long e = ent[slot];
   // lane 0 of a block always holds an entry, and every entry of a block comes from the same wave of k_gates_ex
   const unsigned e_hi0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(e >> 32));
@@ -497,14 +527,23 @@ k_tri_ex(const unsigned long long *__restrict__ ent, const unsigned long long *_
     if (ok) {
       o.l.nb_slot = lite_pack((int)(b - nb_off[i1]), i2);
       o.l.ng_line = ng;
-      st_c[slot] = o.c;
-      st_l[slot] = o.l;
+      *reinterpret_cast<Cand *>(&s_out[wv][7 * lane]) = o.c;
+      *reinterpret_cast<CandLite *>(&s_out[wv][64 * 7 + 2 * lane]) = o.l;
       node = (unsigned)g;
       const long long item = item_off[g] + blk_chunk_off[b] + (ng >> 6);
       if (item < n_items) atomicOr(&masks[item], 1ull << (ng & 63));
     }
   }
   st_node[slot] = node;
+  if (__ballot(ok)) {
+    wave_lds_sync();
+    double2 *dc = reinterpret_cast<double2 *>(st_c + slot0);
+    double2 *dl = reinterpret_cast<double2 *>(st_l + slot0);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) dc[k * 64 + lane] = s_out[wv][k * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) dl[k * 64 + lane] = s_out[wv][64 * 7 + k * 64 + lane];
+  }
 }
 
 // Pass 2 of the plain exhaustive mode: one wave per (image pair, eighth of the image's nodes).  The survivors of
