@@ -128,11 +128,14 @@ def roofline_entry(name, nbytes, ms, pmc):
         if k.get("valu_flops_f64") is not None:
             tf = k["valu_flops_f64"] / (ms * 1e-3) / 1e12
             e["valu_f64"] = {"flops_per_launch": k["valu_flops_f64"], "achieved_tflops": tf, "peak_tflops": FP64_VALU_PEAK_TF,
-                             "frac": tf / FP64_VALU_PEAK_TF, "valu_busy_frac": k.get("valu_busy_frac"),
-                             "valu_insts_per_launch": k.get("valu_insts")}
+                             "frac": tf / FP64_VALU_PEAK_TF, "valu_insts_per_launch": k.get("valu_insts")}
+            if k.get("valu_insts"):
+                # share of the VALU issue slots the kernel used: a wave64 VALU instruction occupies its SIMD for 4 cycles
+                # (16 lanes per cycle); 256 CUs x 4 SIMDs at 2.4 GHz
+                e["valu_f64"]["issue_frac"] = k["valu_insts"] * 4.0 / (1024.0 * 2.4e9 * ms * 1e-3)
         if k.get("lds_active_frac") is not None:
             e["lds"] = {"active_frac": k["lds_active_frac"], "what": "SQ_ACTIVE_INST_LDS / SQ_BUSY_CU_CYCLES"}
-        fr = {"hbm": e["frac"], "valu_f64": e.get("valu_f64", {}).get("frac", 0.0)}
+        fr = {"hbm": e["frac"], "valu_issue": e.get("valu_f64", {}).get("issue_frac", e.get("valu_f64", {}).get("frac", 0.0))}
         e["nearest_roof"] = max(fr, key=fr.get)
     return e
 

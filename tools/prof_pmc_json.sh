@@ -39,7 +39,8 @@ out = {"device_source_hash": bench.device_source_hash(),
        "how": "tools/prof_pmc_json.sh: one rocprofv3 --pmc pass per counter group, kernel dispatch only; averages per launch",
        "units": {"hbm_bytes": "bytes per launch = 2 x 1024 x FETCH_SIZE + 1024 x WRITE_SIZE (gfx950 correction, KiB counters)",
                  "valu_flops_f64": "64 x (ADD + MUL + TRANS) + 128 x FMA wave-level FP64 instructions",
-                 "valu_busy_frac": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES... see raw", "lds_active_frac": "SQ_ACTIVE_INST_LDS / SQ_BUSY_CU_CYCLES"},
+                 "valu_insts": "SQ_INSTS_VALU (wave-level; x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time) = share of the VALU issue slots)",
+                 "lds_active_frac": "SQ_ACTIVE_INST_LDS / SQ_BUSY_CU_CYCLES"},
        "kernels": {}}
 alias = {"k_gen_ex_block": "k_gen_exhaustive"}
 for mode in ("matched", "exhaustive"):
@@ -68,7 +69,10 @@ for mode in ("matched", "exhaustive"):
             k["valu_busy_frac"] = v.get("SQ_ACTIVE_INST_VALU", 0.0) / v["SQ_BUSY_CU_CYCLES"]
             k["lds_active_frac"] = v.get("SQ_ACTIVE_INST_LDS", 0.0) / v["SQ_BUSY_CU_CYCLES"]
         kern[alias.get(name, name)] = k
-    # the exhaustive generation is two passes of k_gen_ex_block per run: the per-launch average x 2 is the stage
+    # the generation stage of the exhaustive mode (one-pass form) is k_gates_ex + k_tri_ex: summed per run
+    if "k_gates_ex" in kern and "k_tri_ex" in kern:
+        a, b = kern["k_gates_ex"], kern["k_tri_ex"]
+        kern["k_gen_exhaustive"] = {f: a[f] + b[f] for f in ("hbm_bytes", "valu_flops_f64", "valu_insts") if f in a and f in b}
     out["kernels"][mode] = kern
 json.dump(out, open("gpurun_out/r02_pmc.json", "w"), indent=1)
 for mode, kern in out["kernels"].items():
