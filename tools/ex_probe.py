@@ -1,5 +1,8 @@
+"""Developer tool: five runs of the full-size exhaustive job on one context -- per-run stage times and the
+staging need / capacity of the one-pass form (lt_get_timers [17], [18])."""
 import sys
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from limap_amd import synthetic as syn, triangulation as tri
 sc = syn.make_scene(n_views=100, n_segs=500, n_neighbors=20, seed=0)
 T = tri.GlobalLineTriangulator(syn.default_triangulation_cfg())
