@@ -238,7 +238,8 @@ int lt_get_stats(lt_ctx *ctx, int64_t out[8]);
  * candidates, [5] scoring (incl. its per-candidate records), [6] selection, [7] unused (0); host: [8] upload, [9] download,
  * [10] tail (lt_compute_tracks); [11] candidate pairs that reached the dense evaluation in k_score3;
  * [12] host ms spent inside lt_triangulate_image* buffering the match rows of the batch;
- * single-kernel durations (HIP events around the launch): [13] k_gates, [14] k_tri_rows, [15] k_score3;
+ * single-kernel durations (HIP events around the launch): [13] k_gates, [14] k_tri_rows (only with LT_FINE_TIMERS=2
+ * in the environment at the time of the run), [15] k_score3 (default; LT_FINE_TIMERS=0 turns every per-kernel event off);
  * [16] connections that passed the stage-A gates (k_gates);
  * one-pass exhaustive mode: [17] staging slots needed (fullest region x regions), [18] staging slots provided */
 int lt_get_timers(lt_ctx *ctx, double out[24]);

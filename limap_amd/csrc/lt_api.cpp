@@ -282,15 +282,16 @@ extern "C" void lt_release_cached_memory(void) { lt_host::release_cached_memory(
 
 namespace {
 
-// per-kernel HIP events (timers [13]-[15]) cost a few microseconds of stream bubble each: on by
-// default (bench.py prices the dominant kernel with them), LT_FINE_TIMERS=0 turns them off
-bool fine_timers() {
-  static const bool on = [] {
-    const char *e = getenv("LT_FINE_TIMERS");
-    return !(e && e[0] == '0');
-  }();
-  return on;
+// per-kernel HIP events cost a few microseconds of stream bubble each.  LT_FINE_TIMERS (read per run): unset / 1 =
+// the event in front of k_score3 only (timer [15]: bench.py prices the dominant kernel with it, inside its timed
+// region), 2 = also the events around k_gates and k_tri_rows (timers [13], [14]: +5 us per step), 0 = none
+int fine_level() {
+  const char *e = getenv("LT_FINE_TIMERS");
+  if (!e) return 1;
+  return e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
 }
+bool fine_timers() { return fine_level() >= 1; }
+bool fine_gen_timers() { return fine_level() >= 2; }
 
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -1303,11 +1304,11 @@ int finish_run(lt_ctx *ctx) {
   ctx->timers[0] = ms;
   // single-kernel durations of the matched pipeline: [13] k_gates, [14] k_tri_rows, [15] k_score3
   ctx->timers[13] = ctx->timers[14] = ctx->timers[15] = 0.0;
-  if (fine_timers() && ctx->job_mode == 1 && ctx->n_blk > 0 && ctx->max_rows > 0) {
+  if (ctx->pend_fine_gen && ctx->job_mode == 1 && ctx->n_blk > 0 && ctx->max_rows > 0) {
     if (hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) ctx->timers[13] = ms;
     if (hipEventElapsedTime(&ms, ev[9], ev[10]) == hipSuccess) ctx->timers[14] = ms;
   }
-  if (fine_timers() && ctx->C_last > 0 && hipEventElapsedTime(&ms, ev[11], ev[5]) == hipSuccess) ctx->timers[15] = ms;
+  if (ctx->pend_fine_score && ctx->C_last > 0 && hipEventElapsedTime(&ms, ev[11], ev[5]) == hipSuccess) ctx->timers[15] = ms;
   (void)hipGetLastError();
   ctx->timers[11] = (double)ctx->stat_pairs_eval;
   if (const char *mode = getenv("LT_EXP_TILE_ORDER")) {  // developer experiment: tile order from the node sizes of this run
@@ -1356,6 +1357,7 @@ int lt_run_device_async(lt_ctx *ctx) {
   hipEvent_t *ev = set ? ctx->ev_b : ctx->ev;
   long long *hp = ctx->h_pinned ? ctx->h_pinned + 8 * set : nullptr;
   ctx->ex_staged_set[set] = false;
+  const bool fine_gen = fine_gen_timers(), fine_score = fine_timers();
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const long long G = ctx->G, P = ctx->P;
@@ -1446,7 +1448,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                        ctx->d_pairs.as<PairRec>(), ctx->d_blk_line_base.as<long long>(), ctx->d_st_c.as<Cand>(),
                        ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(), ctx->d_wave_count.as<unsigned>(),
                        fast ? ctx->d_cnt_bl.as<unsigned>() : nullptr, lds_segs, lds_segs1, ctx->d_st_row.p,
-                       ctx->d_surv_count.as<unsigned>(), G, ctx->d_seg_gates.p, ctx->d_blkrec.p, fine_timers() ? &ev[8] : nullptr,
+                       ctx->d_surv_count.as<unsigned>(), G, ctx->d_seg_gates.p, ctx->d_blkrec.p, fine_gen ? &ev[8] : nullptr,
                        vp_on ? ctx->d_seg_vp.as<double>() : nullptr,
                        vp_on ? ctx->d_seg_has_vp.as<unsigned char>() : nullptr,
                        pts_on ? ctx->d_seg_pt_off.as<long long>() : nullptr, pts_on ? ctx->d_seg_pts.p : nullptr,
@@ -1454,7 +1456,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                        many_on ? 1 : 0, one_on ? 1 : 0, mult);
     }
     // with the per-kernel events on, the one after k_tri_rows also ends the generation stage
-    if (fine_timers() && ctx->n_blk > 0 && ctx->max_rows > 0) ev_gen_end = 10;
+    if (fine_gen && ctx->n_blk > 0 && ctx->max_rows > 0) ev_gen_end = 10;
     else HIPCHK(ctx, hipEventRecord(ev[3], st));
     long long *hC = hp;  // this set's slot 0
     long long hC_fallback = 0;
@@ -1550,7 +1552,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                      ctx->d_cand_node.as<unsigned>());
     }
     // ... and the one in front of k_score3 ends the placement stage (it then includes k_cand_meta)
-    if (fine_timers() && C_bound > 0) ev_place_end = 11;
+    if (fine_score && C_bound > 0) ev_place_end = 11;
     else HIPCHK(ctx, hipEventRecord(ev[4], st));
   } else if (ctx->job_mode == 2) {
     ctx->perm_mode = false;
@@ -1756,7 +1758,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                   ctx->perm_mode ? ctx->d_st_l.as<CandLite>() : ctx->d_lite.as<CandLite>(), ctx->d_node_img.as<int>(),
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
                   ctx->d_score.as<double>(), ctx->d_pair_counter.as<unsigned long long>(), ctx->max_nb, scfg,
-                  guard2, fine_timers() ? ev[11] : nullptr, ctx->d_tile_order.as<unsigned>(), score_f32,
+                  guard2, fine_score ? ev[11] : nullptr, ctx->d_tile_order.as<unsigned>(), score_f32,
                   (ctx->perm_mode && !staged_sorted) ? ctx->d_place_perm.as<unsigned>()
                                                      : (score_sorted ? ctx->d_perm.as<unsigned>() : nullptr),
                   score_sorted ? ctx->d_rng.p : nullptr, ctx->perm_mode && !staged_sorted,
@@ -1805,6 +1807,8 @@ int lt_run_device_async(lt_ctx *ctx) {
   ctx->run_pending = true;
   ctx->pend_set = set;
   ctx->pend_count_on_device = C_known < 0;
+  ctx->pend_fine_gen = fine_gen;
+  ctx->pend_fine_score = fine_score;
   ctx->pend_C = C_run;
   ctx->pend_ev_gen_end = ev_gen_end;
   ctx->pend_ev_place_end = ev_place_end;

@@ -222,6 +222,7 @@ struct lt_ctx {
   bool ex_two_pass = false;
   bool ex_staged_set[2] = {false, false};  // the run of event set 0 / 1 used the one-pass form
   bool in_run_async = false;
+  bool pend_fine_gen = false, pend_fine_score = false;  // which per-kernel events the run in flight recorded
   int ex_retry_depth = 0;
   bool compact_valid = false;  // d_cand / d_lite hold the compact arrays of the last run
   DevBuf d_tail_keys, d_tail_skeys, d_tail_sims, d_tail_mark, d_tail_pos, d_tail_recs, d_tail_nodes, d_tail_tmp, d_tail_keep, d_tail_kpos;  // lt_kernels_tail.hip
