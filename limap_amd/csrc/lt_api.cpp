@@ -972,7 +972,9 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
     // the staging block may move when it grows: no asynchronous copy may still be reading it
     size_t want = base + 2 * (size_t)dst[n_nb];
     if (ctx->job_imgs.empty() && dst[n_nb] > 0)  // first image of a batch: one allocation for the usual case
-      want = std::max(want, 2 * (size_t)dst[n_nb] * (size_t)std::max(1, ctx->n_img) + 1024);
+      // (every image of the scene in one batch; capped at 1 GB -- a large scene arrives in batches, and a
+      // page-locked allocation costs ~0.1 s per GB)
+      want = std::max(want, std::min<size_t>(2 * (size_t)dst[n_nb] * (size_t)std::max(1, ctx->n_img) + 1024, (size_t)1 << 28));
     if (want > ctx->h_m_pairs.capacity()) {
       if (ctx->streamed_ints > 0) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       if (!ctx->h_m_pairs.reserve(want)) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the match rows");

@@ -47,12 +47,12 @@ def run(scene, batch):
         ctx.run_device()
         acc["run"] += time.perf_counter() - t
         dev_ms += ctx.timers()["run"]
-        st = ctx.stats()
-        conns += st["connections"]
-        cands += st["candidates"]
         t = time.perf_counter()
         ctx.download()
         acc["download"] += time.perf_counter() - t
+        st = ctx.stats()
+        conns += st["connections"]
+        cands += st["candidates"]
     t = time.perf_counter()
     tracks = T.ComputeLineTracks()
     acc["compute_tracks"] = time.perf_counter() - t
