@@ -344,3 +344,34 @@ def test_exhaustive_one_pass_equals_two_pass(gpu_lib, clean_env):
     for _ in range(3):
         ctx.run_device()
     _same(base, _results(T))
+
+
+def test_exhaustive_many_chunks(gpu_lib, clean_env):
+    """More than 64 chunks of 64 neighbour lines per image (4200 segments): the chunk loops of the one-pass and
+    two-pass kernels against the wave-per-(node, neighbour) kernels (which the parity tests pin to the oracle at
+    sizes the oracle can do)."""
+    sc = small_scene(seed=32, n_views=6, n_segs=4200, n_neighbors=3)
+    cfg = syn.default_triangulation_cfg()
+
+    def res():
+        T = run_product(sc, cfg, exhaustive=True)
+        ctx = T.context()
+        best, edges = ctx.get_best(), ctx.get_valid_edges()
+        ctx.compute_tracks()
+        return best, edges, ctx.get_tracks(), ctx.stats()
+
+    base = res()
+    assert base[3]["candidates"] > 10000
+    for env in ({"LT_TEST_EX_TWO_PASS": "1"}, {"LT_TEST_EX_PASS1_BLOCK": "1", "LT_TEST_EX_PASS2_BLOCK": "1"}):
+        os.environ.update(env)
+        try:
+            other = res()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert other[3]["candidates"] == base[3]["candidates"]
+        for k in ("has_best", "src", "line", "score"):
+            assert np.array_equal(base[0][k], other[0][k]), k
+        assert np.array_equal(base[1][0], other[1][0]) and np.array_equal(base[1][1], other[1][1])
+        for k in ("off", "image_ids", "line_ids", "node_ids", "scores", "line"):
+            assert np.array_equal(base[2][k], other[2][k]), k
