@@ -4,10 +4,13 @@
 //       per (image, neighbour) pair) -- the reference recomputes them per connection.
 //   radix sort + k_node_offsets                 : matched mode, generic (stable) grouping of the
 //       candidates by node when the rows of a block are not sorted by line id.
-//   k_gen_ex_block / k_gen_exhaustive_pts       : HOT LOOP 1, triangulateOneNode (exhaustive mode)
+//   k_gates_ex / k_tri_ex / k_place_ex / k_fill_ex : HOT LOOP 1, triangulateOneNode (exhaustive mode)
 //       (triangulation/base_line_triangulator.cc:161-337) for TriangulateImageExhaustiveMatch:
-//       degeneracy gates, weak epipolar IoU, ray/plane triangulation, sensitivity gate,
-//       uncertainty, ranges.  (Matched mode: k_gates + k_tri_rows in lt_kernels_v2.hip; scoring: k_score3.)
+//       degeneracy gates, weak epipolar IoU, ray/plane triangulation, sensitivity gate, uncertainty, ranges.
+//       One-pass form: cheap gates with the neighbour lines in registers -> cheirality / range pre-test -> entry
+//       blocks -> dense evaluation into staging slots -> permutation; k_gates_ex<false> + k_fill_ex are the exact
+//       two-pass fallback.  k_gen_ex_block / k_gen_exhaustive_pts: the same with VP-guided / point-guided proposals
+//       (wave per (node, neighbour image)).  (Matched mode: k_gates + k_tri_rows in lt_kernels_v2.hip; scoring: k_score3.)
 //   k_select                                    : per-node strict arg-max (lowest index wins ties,
 //       global_line_triangulator.cc:145-153) and valid-edge flags (:118-142).
 //
