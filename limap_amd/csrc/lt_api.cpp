@@ -68,7 +68,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
                    unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap, const unsigned *place,
-                   unsigned *rec);
+                   unsigned *rec, const float *st_z);
 int score3_tile_buckets();
 }
 
@@ -614,7 +614,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
                     &ctx->d_pair_counter, &ctx->d_result3, &ctx->d_tile_order, &ctx->d_scan_status, &ctx->d_perm, &ctx->d_rng, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz,
-                    &ctx->d_place_perm, &ctx->d_ex_rec, &ctx->d_ex_ent, &ctx->d_tile_list, &ctx->d_exp_tile_order, &ctx->d_tail_keys, &ctx->d_tail_skeys, &ctx->d_tail_sims, &ctx->d_tail_mark,
+                    &ctx->d_place_perm, &ctx->d_ex_rec, &ctx->d_ex_ent, &ctx->d_ex_z, &ctx->d_tile_list, &ctx->d_exp_tile_order, &ctx->d_tail_keys, &ctx->d_tail_skeys, &ctx->d_tail_sims, &ctx->d_tail_mark,
                     &ctx->d_tail_pos, &ctx->d_tail_recs, &ctx->d_tail_nodes, &ctx->d_tail_tmp, &ctx->d_tail_keep,
                     &ctx->d_tail_kpos};
   lt_host::host_block_release(ctx->h_pinned_blk);
@@ -1609,7 +1609,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                          ctx->d_st_key.ensure(4 * Bn) && ctx->d_place_perm.ensure(4 * Bn) && ctx->d_score.ensure(8 * Bn) &&
                          ctx->d_edge_flag.ensure(4 * Bn) && ctx->d_cand_node.ensure(4 * Bn) &&
                          ctx->d_cand_meta.ensure(cand_meta_bytes() * Bn) && ctx->d_ex_rec.ensure(4 * Bn) &&
-                         ctx->d_ex_ent.ensure(8 * Bn);
+                         ctx->d_ex_ent.ensure(8 * Bn) && ctx->d_ex_z.ensure(4 * Bn);
         if (!got) {
           (void)hipGetLastError();
           staged = false;
@@ -1646,7 +1646,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                               ctx->d_nb_off.as<long long>(), ctx->d_seg_off.as<long long>(), ctx->d_cams.as<Cam>(),
                               ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(), ctx->d_blk_chunk_off.as<int>(),
                               ctx->d_masks.as<unsigned long long>(), ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(),
-                              ctx->d_st_key.as<unsigned>());
+                              ctx->d_st_key.as<unsigned>(), ctx->d_ex_z.as<float>());
       }
       launch_popc(st, P, ctx->d_masks.as<unsigned long long>(), ctx->d_mask_cnt.as<unsigned>(), n_masks);
     }
@@ -1769,7 +1769,8 @@ int lt_run_device_async(lt_ctx *ctx) {
                   tile_classes ? (unsigned *)(ctx->d_scan_status.as<unsigned long long>() + n_status_scan) : nullptr,
                   tile_classes ? ctx->d_tile_list.as<unsigned>() : nullptr, tile_cap,
                   staged_sorted ? ctx->d_place_perm.as<unsigned>() : nullptr,
-                  staged_sorted ? ctx->d_ex_rec.as<unsigned>() : nullptr);
+                  staged_sorted ? ctx->d_ex_rec.as<unsigned>() : nullptr,
+                  staged_sorted ? ctx->d_ex_z.as<float>() : nullptr);
   }
   HIPCHK(ctx, hipEventRecord(ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));

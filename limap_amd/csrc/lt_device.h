@@ -50,7 +50,7 @@ void launch_tri_exhaustive(hipStream_t st, const unsigned long long *ent, const 
                            unsigned region_cap, const GenCfg &cfg, long long n_items, const long long *item_off,
                            const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
                            const Cam *cams, const Seg *segs, const PairRec *pairs, const int *blk_chunk_off,
-                           unsigned long long *masks, Cand *st_c, CandLite *st_l, unsigned *st_node);
+                           unsigned long long *masks, Cand *st_c, CandLite *st_l, unsigned *st_node, float *st_z);
 void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsigned region_cap, const CandLite *st_l,
                              const unsigned *st_node, const int *node_img, const long long *nb_off,
                              const long long *item_off, const int *blk_chunk_off, const unsigned long long *masks,

@@ -498,7 +498,7 @@ k_tri_ex(const unsigned long long *__restrict__ ent, const unsigned long long *_
          const int *__restrict__ blk_nb, const long long *__restrict__ nb_off, const long long *__restrict__ seg_off,
          const Cam *__restrict__ cams, const Seg *__restrict__ segs, const PairRec *__restrict__ pairs,
          const int *__restrict__ blk_chunk_off, unsigned long long *__restrict__ masks, Cand *__restrict__ st_c,
-         CandLite *__restrict__ st_l, unsigned *__restrict__ st_node) {
+         CandLite *__restrict__ st_l, unsigned *__restrict__ st_node, float *__restrict__ st_z) {
   // The 64 staging slots of a block are contiguous: the records go through LDS and leave as full 1 KB rows (a lane
   // storing its own 112-byte record writes 16-byte pieces 112 bytes apart -- every store instruction then touches 64
   // cache lines, and the kernel was bound by that, not by its arithmetic).  Holes carry stale bytes, nobody reads them.
@@ -518,6 +518,7 @@ k_tri_ex(const unsigned long long *__restrict__ ent, const unsigned long long *_
   const int i1 = blk_img[b], i2 = blk_nb[b];
   bool ok = false;
   unsigned node = 0xFFFFFFFFu;
+  double o_depth0 = 0.0;
   if (e != ~0ull) {
     const int ng = (int)(e & 0xFFFFu), nd = (int)((e >> 16) & 0xFFFFu);
     const long long g = seg_off[i1] + nd;
@@ -533,11 +534,15 @@ k_tri_ex(const unsigned long long *__restrict__ ent, const unsigned long long *_
       *reinterpret_cast<Cand *>(&s_out[wv][7 * lane]) = o.c;
       *reinterpret_cast<CandLite *>(&s_out[wv][64 * 7 + 2 * lane]) = o.l;
       node = (unsigned)g;
+      o_depth0 = o.c.depth[0];
       const long long item = item_off[g] + blk_chunk_off[b] + (ng >> 6);
       if (item < n_items) atomicOr(&masks[item], 1ull << (ng & 63));
     }
   }
   st_node[slot] = node;
+  // the depth-order keys of the scoring stage (single-precision start depth), 4 bytes per slot: k_depth_order then
+  // gathers from a 0.1 GB array that stays in the last-level cache instead of one 112-byte record per key
+  st_z[slot] = ok ? (float)o_depth0 : 0.0f;
   if (__ballot(ok)) {
     wave_lds_sync();
     double2 *dc = reinterpret_cast<double2 *>(st_c + slot0);
@@ -1057,11 +1062,11 @@ void launch_tri_exhaustive(hipStream_t st, const unsigned long long *ent, const 
                            unsigned region_cap, const GenCfg &cfg, long long n_items, const long long *item_off,
                            const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
                            const Cam *cams, const Seg *segs, const PairRec *pairs, const int *blk_chunk_off,
-                           unsigned long long *masks, Cand *st_c, CandLite *st_l, unsigned *st_node) {
+                           unsigned long long *masks, Cand *st_c, CandLite *st_l, unsigned *st_node, float *st_z) {
   if (region_cap == 0) return;
   hipLaunchKernelGGL(k_tri_ex, dim3(nblk((long long)region_cap, 256), kExRegions), dim3(256), 0, st, ent, ctr, region_cap,
                      cfg, n_items, item_off, blk_img, blk_nb, nb_off, seg_off, cams, segs, pairs, blk_chunk_off, masks, st_c,
-                     st_l, st_node);
+                     st_l, st_node, st_z);
 }
 // one-pass form: perm[final position] = staging slot, for every slot the regions handed out
 void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsigned region_cap, const CandLite *st_l,

@@ -890,14 +890,14 @@ struct Score3Args {
 // keys only steer the pruning (radius widened by their rounding); nodes above kSortMax candidates or with a
 // non-finite depth keep the identity order and the full range.  Which pairs reach the dense evaluation is
 // unchanged, so is every result (LT_TEST_SCORE_UNSORTED: the plain sweep).
-constexpr int kSortMax = 2048;
+constexpr int kSortMax = 2048;  // the index takes the 11 low bits of the sort word
 
-// Bitonic sort of R * 64 packed (key << 32 | index) words held R per lane (element e = r * 64 + lane): a
+// Bitonic sort of R * 64 packed 32-bit words (21 key bits | 11 index bits) held R per lane (element e = r * 64 + lane): a
 // compare-exchange distance >= 64 pairs two registers of the same lane, a smaller one the same register of
 // two lanes (one shuffle).  No LDS traffic, every loop unrolled.  (A first version that kept the arrays in
 // LDS and synchronised per stage took 5 ms for the 50 000 nodes of the exhaustive benchmark; this one 0.5.)
 template <int R>
-static __device__ __forceinline__ void wave_bitonic(unsigned long long (&v)[R], int lane) {
+static __device__ __forceinline__ void wave_bitonic(unsigned (&v)[R], int lane) {
   constexpr int N = R * 64;
 #pragma unroll
   for (int k = 2; k <= N; k <<= 1) {
@@ -909,10 +909,10 @@ static __device__ __forceinline__ void wave_bitonic(unsigned long long (&v)[R], 
         for (int r = 0; r < R; ++r) {
           if ((r & rj) == 0) {
             const bool up = (((r * 64) & k) == 0);  // bit k of e = r * 64 + lane lies above the lane bits
-            const unsigned long long x = v[r], y = v[r | rj];
-            const bool sw = up ? (x > y) : (x < y);
-            v[r] = sw ? y : x;
-            v[r | rj] = sw ? x : y;
+            const unsigned x = v[r], y = v[r | rj];
+            const unsigned mn = min(x, y), mx = max(x, y);
+            v[r] = up ? mn : mx;
+            v[r | rj] = up ? mx : mn;
           }
         }
       } else {
@@ -921,11 +921,8 @@ static __device__ __forceinline__ void wave_bitonic(unsigned long long (&v)[R], 
         for (int r = 0; r < R; ++r) {
           const int e = r * 64 + lane;
           const bool up = (e & k) == 0;
-          const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(v[r] & 0xFFFFFFFFull), j);
-          const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v[r] >> 32), j);
-          const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-          const bool keep_min = (up == lower);
-          v[r] = keep_min ? (v[r] < o ? v[r] : o) : (v[r] > o ? v[r] : o);
+          const unsigned o = (unsigned)__shfl_xor((int)v[r], j);
+          v[r] = (up == lower) ? min(v[r], o) : max(v[r], o);
         }
       }
     }
@@ -936,18 +933,23 @@ static __device__ __forceinline__ void wave_bitonic(unsigned long long (&v)[R], 
 template <int R>
 static __device__ __forceinline__ bool depth_sort_node(const Cand *__restrict__ cand, long long off, int n, int lane,
                                                        float *key, unsigned *__restrict__ perm,
-                                                       const unsigned *__restrict__ place, unsigned *__restrict__ rec) {
-  unsigned long long v[R];
+                                                       const unsigned *__restrict__ place, unsigned *__restrict__ rec,
+                                                       const float *__restrict__ st_z) {
+  // word = the float key with its 11 low mantissa bits replaced by the index (n <= 2048): half the compare-exchange
+  // and shuffle work of a (key, index) pair of words; the keys only steer the pruning, k_depth_order widens the
+  // radius by the 2^-12 the truncation can cost
+  unsigned v[R];
   bool bad = false;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int e = r * 64 + lane;
-    v[r] = ~0ull;  // padding sorts to the end
+    v[r] = ~0u;  // padding sorts to the end
     if (e < n) {
-      const double z = cand[place ? (long long)place[off + e] : off + e].depth[0];
+      // st_z: the same key, already rounded to single precision, from the compact per-slot array of k_tri_ex
+      const double z = st_z ? (double)st_z[place[off + e]] : cand[place ? (long long)place[off + e] : off + e].depth[0];
       const float kf = (float)z;
       bad = bad || !(z > 0.0 && z < 1e30);  // non-positive / NaN / inf / absurd depth: no pruning for this node
-      v[r] = ((unsigned long long)__float_as_uint(kf) << 32) | (unsigned)e;  // positive floats order like their bits
+      v[r] = (__float_as_uint(kf) & 0xFFFFF800u) | (unsigned)e;  // positive floats order like their bits
     }
   }
   if (__ballot(bad)) return false;
@@ -956,8 +958,8 @@ static __device__ __forceinline__ bool depth_sort_node(const Cand *__restrict__ 
   for (int r = 0; r < R; ++r) {
     const int e = r * 64 + lane;
     if (e < n) {
-      key[e] = __uint_as_float((unsigned)(v[r] >> 32));
-      const long long nat = off + (long long)(unsigned)(v[r] & 0xFFFFFFFFull);
+      key[e] = __uint_as_float(v[r] & 0xFFFFF800u);
+      const long long nat = off + (long long)(v[r] & 0x7FFu);
       perm[off + e] = (unsigned)nat;
       if (place) rec[off + e] = place[nat];
     }
@@ -968,7 +970,7 @@ static __device__ __forceinline__ bool depth_sort_node(const Cand *__restrict__ 
 __global__ void __launch_bounds__(256)
 k_depth_order(long long G, const long long *__restrict__ tri_off, const Cand *__restrict__ cand, double guard,
               unsigned *__restrict__ perm, uint2 *__restrict__ rng, const unsigned *__restrict__ place,
-              unsigned *__restrict__ rec) {
+              unsigned *__restrict__ rec, const float *__restrict__ st_z) {
   // place != nullptr: the records are staged (one-pass exhaustive mode), the candidate at natural position p is record
   // place[p]; perm then holds the natural position and rec the record of every depth-sorted position
   __shared__ float s_key[4][kSortMax];
@@ -981,19 +983,20 @@ k_depth_order(long long G, const long long *__restrict__ tri_off, const Cand *__
   if (n <= 0) return;
   float *key = s_key[wv];
   bool sorted = false;
-  if (n <= 64) sorted = depth_sort_node<1>(cand, off, n, lane, key, perm, place, rec);
-  else if (n <= 128) sorted = depth_sort_node<2>(cand, off, n, lane, key, perm, place, rec);
-  else if (n <= 256) sorted = depth_sort_node<4>(cand, off, n, lane, key, perm, place, rec);
-  else if (n <= 512) sorted = depth_sort_node<8>(cand, off, n, lane, key, perm, place, rec);
-  else if (n <= 1024) sorted = depth_sort_node<16>(cand, off, n, lane, key, perm, place, rec);
-  else if (n <= 2048) sorted = depth_sort_node<32>(cand, off, n, lane, key, perm, place, rec);
+  if (n <= 64) sorted = depth_sort_node<1>(cand, off, n, lane, key, perm, place, rec, st_z);
+  else if (n <= 128) sorted = depth_sort_node<2>(cand, off, n, lane, key, perm, place, rec, st_z);
+  else if (n <= 256) sorted = depth_sort_node<4>(cand, off, n, lane, key, perm, place, rec, st_z);
+  else if (n <= 512) sorted = depth_sort_node<8>(cand, off, n, lane, key, perm, place, rec, st_z);
+  else if (n <= 1024) sorted = depth_sort_node<16>(cand, off, n, lane, key, perm, place, rec, st_z);
+  else if (n <= 2048) sorted = depth_sort_node<32>(cand, off, n, lane, key, perm, place, rec, st_z);
   if (sorted) {
     wave_lds_sync();
     for (int r = lane; r < n; r += 64) {
       const float z = key[r];
       const double zz = (double)z + kEps;
-      // radius of the sweep's distance guard for this candidate, widened by the keys' rounding
-      const double rad = guard * zz * 1.0001 + 1e-6 * (double)z + 1e-30;
+      // radius of the sweep's distance guard for this candidate, widened by what the keys lost: a key is the depth
+      // truncated to 13 mantissa bits, k <= z < k (1 + 2^-12), so |k_i - k_j| <= (rad(z_i) + 2.5e-4 k_i)(1 + 2.6e-4)
+      const double rad = guard * zz * 1.001 + 3e-4 * (double)z + 1e-30;
       int lo = 0, hi = n;
       if (rad < 1e299) {
         const float lo_v = (float)((double)z - rad), hi_v = (float)((double)z + rad);
@@ -1460,7 +1463,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
                    unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap, const unsigned *place,
-                   unsigned *rec) {
+                   unsigned *rec, const float *st_z) {
   // place / rec: depth-sorted sweep over STAGED records (one-pass exhaustive mode): place[natural position] = record,
   // rec (scratch, one word per candidate) receives the record of every sorted position
   if (C <= 0) return;
@@ -1490,7 +1493,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
     hipLaunchKernelGGL(k_depth_order, dim3(nblk2(G, 4)), dim3(256), 0, st, G, tri_off, cand,
                        scaleinv_guard2 < 1e299 ? std::sqrt(scaleinv_guard2) : 1e300, perm, reinterpret_cast<uint2 *>(rng),
-                       place, rec);
+                       place, rec, place ? st_z : nullptr);
   if (sorted && place) {
     a.perm = rec;
     a.spos = perm;
