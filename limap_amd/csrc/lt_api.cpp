@@ -1572,7 +1572,8 @@ int lt_run_device_async(lt_ctx *ctx) {
     const int many_on = (pts_any && !ctx->cfg.disable_many_points_triangulation) ? 1 : 0;
     const int one_on = (pts_any && !ctx->cfg.disable_one_point_triangulation) ? 1 : 0;
     const double *sfm_xyz = (pts_any && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr;
-    ENSURE(ctx, ctx->d_masks, pts_any ? 64 * In : 8 * In * n_masks); ENSURE(ctx, ctx->d_mask_cnt, 4 * (In + 1));
+    // (+ one ballot word: the plain mode scans the popcounts of the ballots directly, the word behind the last is 0)
+    ENSURE(ctx, ctx->d_masks, pts_any ? 64 * In : 8 * (In * n_masks + 1)); ENSURE(ctx, ctx->d_mask_cnt, 4 * (In + 1));
     ENSURE(ctx, ctx->d_mask_pos, 8 * (In + 1));
     // Plain exhaustive mode (no VP / point proposals): pass 1 with the neighbour lines held in registers (k_gates_ex;
     // LT_TEST_EX_PASS1_BLOCK keeps the wave-per-(node, neighbour) form the VP variant uses), and, while the staging
@@ -1648,10 +1649,18 @@ int lt_run_device_async(lt_ctx *ctx) {
                               ctx->d_masks.as<unsigned long long>(), ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(),
                               ctx->d_st_key.as<unsigned>(), ctx->d_ex_z.as<float>());
       }
-      launch_popc(st, P, ctx->d_masks.as<unsigned long long>(), ctx->d_mask_cnt.as<unsigned>(), n_masks);
+      if (!plain) launch_popc(st, P, ctx->d_masks.as<unsigned long long>(), ctx->d_mask_cnt.as<unsigned>(), n_masks);
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_mask_cnt.as<unsigned>() + P, 0, 4, st));
-    {
+    if (plain) {
+      // one ballot per item: the scan reads the ballots through a popcount iterator (no count pass, no count array)
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_masks.as<unsigned long long>() + P, 0, 8, st));
+      size_t tmp = scan_temp_bytes_popc(P + 1);
+      ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
+      if (launch_scan_popc(st, ctx->d_scan_tmp.p, tmp, P + 1, ctx->d_masks.as<unsigned long long>(),
+                           ctx->d_mask_pos.as<long long>()) != 0)
+        return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+    } else {
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_mask_cnt.as<unsigned>() + P, 0, 4, st));
       size_t tmp = scan_temp_bytes_u32_to_i64(P + 1);
       ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
       if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, P + 1, ctx->d_mask_cnt.as<unsigned>(),

@@ -32,6 +32,9 @@ int launch_sort(hipStream_t st, void *temp, size_t temp_bytes, long long P, cons
                 unsigned *keys_out, const unsigned *vals_in, unsigned *vals_out, int end_bit);
 void launch_node_offsets(hipStream_t st, long long P, long long G, const unsigned *skeys, long long *conn_off);
 size_t scan_temp_bytes_u32_to_i64(long long n);
+size_t scan_temp_bytes_popc(long long n);
+int launch_scan_popc(hipStream_t st, void *temp, size_t temp_bytes, long long n, const unsigned long long *masks,
+                     long long *out);
 int launch_scan_u32_to_i64(hipStream_t st, void *temp, size_t temp_bytes, long long n, const unsigned *in,
                            long long *out);
 void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const GenCfg &cfg,

@@ -25,6 +25,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace lt {
 
@@ -1012,6 +1013,29 @@ size_t scan_temp_bytes_u32_to_i64(long long n) {
   (void)rocprim::exclusive_scan(nullptr, bytes, (unsigned *)nullptr, (long long *)nullptr, 0ll, (size_t)n,
                           rocprim::plus<long long>(), (hipStream_t)0);
   return bytes;
+}
+// exclusive scan of the popcounts of n 64-bit ballots (the plain exhaustive mode: no separate count pass or array)
+struct PopcFn {
+  __host__ __device__ long long operator()(unsigned long long m) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (long long)__popcll(m);
+#else
+    return (long long)__builtin_popcountll(m);
+#endif
+  }
+};
+size_t scan_temp_bytes_popc(long long n) {
+  size_t bytes = 0;
+  auto it = rocprim::make_transform_iterator((const unsigned long long *)nullptr, PopcFn());
+  (void)rocprim::exclusive_scan(nullptr, bytes, it, (long long *)nullptr, 0ll, (size_t)n, rocprim::plus<long long>(),
+                                (hipStream_t)0);
+  return bytes;
+}
+int launch_scan_popc(hipStream_t st, void *temp, size_t temp_bytes, long long n, const unsigned long long *masks,
+                     long long *out) {
+  if (n <= 0) return 0;
+  auto it = rocprim::make_transform_iterator(masks, PopcFn());
+  return (int)rocprim::exclusive_scan(temp, temp_bytes, it, out, 0ll, (size_t)n, rocprim::plus<long long>(), st);
 }
 int launch_scan_u32_to_i64(hipStream_t st, void *temp, size_t temp_bytes, long long n, const unsigned *in,
                            long long *out) {
