@@ -2114,7 +2114,8 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
   static_assert(sizeof(Rec) == 128, "TailRec layout");
   const Rec *recs = (const Rec *)(base + o_recs);
   const int *nodes = (const int *)(base + o_nodes);
-  for (long long k = 0; k < Nm; ++k) {
+#pragma omp parallel for num_threads(std::min(lt::host_threads(), 8)) schedule(static) if (Nm > 2048)
+  for (long long k = 0; k < Nm; ++k) {  // distinct nodes: no two iterations touch the same entry
     const long long g = nodes[k];
     ctx->best_c[g] = recs[k].c;
     ctx->best_score[g] = recs[k].score;
@@ -2446,10 +2447,10 @@ int lt_compute_tracks(lt_ctx *ctx) {
       ts.gnodes[w] = g;
     }
     // a few thousand tracks aggregate faster than a thread team forks on a big host
-#pragma omp parallel num_threads(lt::host_threads()) if (nT > 16384)
+#pragma omp parallel num_threads(std::min(lt::host_threads(), 8)) if (nT > 256)
     {
       AggScratch scratch;
-#pragma omp for schedule(dynamic, 64)
+#pragma omp for schedule(dynamic, 16)
       for (long long t = 0; t < (long long)nT; ++t) {
         const size_t a = (size_t)ts.off[(size_t)t], n = (size_t)ts.off[(size_t)t + 1] - a;
         aggregate(ctx->best_c, ts.gnodes.data() + a, ts.scores.data() + a, (int)n, ctx->cfg.num_outliers_aggregator,
