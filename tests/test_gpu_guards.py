@@ -39,7 +39,7 @@ def _same(a, b):
 def clean_env():
     keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES",
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
-            "LT_TEST_SCORE_UNSORTED")
+            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -375,3 +375,27 @@ def test_exhaustive_many_chunks(gpu_lib, clean_env):
         assert np.array_equal(base[1][0], other[1][0]) and np.array_equal(base[1][1], other[1][1])
         for k in ("off", "image_ids", "line_ids", "node_ids", "scores", "line"):
             assert np.array_equal(base[2][k], other[2][k]), k
+
+
+def test_per_kernel_event_levels(gpu_lib, clean_env):
+    """LT_FINE_TIMERS is read per run: by default only k_score3 carries its own HIP events (what bench.py prices the
+    dominant kernel with), 2 adds the generation kernels' (timers [13], [14]), 0 turns all of them off -- the stage
+    timers [3]-[6] do not depend on it."""
+    sc = small_scene(seed=41, n_views=12, n_segs=150, n_neighbors=6)
+    T = run_product(sc, syn.default_triangulation_cfg())
+    ctx = T.context()
+    ctx.upload()
+    seen = {}
+    for level in (None, "2", "0"):
+        if level is None:
+            os.environ.pop("LT_FINE_TIMERS", None)
+        else:
+            os.environ["LT_FINE_TIMERS"] = level
+        ctx.run_device()
+        seen[level] = ctx.timers()
+    os.environ.pop("LT_FINE_TIMERS", None)
+    assert seen[None]["k_score3"] > 0 and seen[None]["k_gates"] == 0 and seen[None]["k_tri_rows"] == 0
+    assert seen["2"]["k_score3"] > 0 and seen["2"]["k_gates"] > 0 and seen["2"]["k_tri_rows"] > 0
+    assert seen["0"]["k_score3"] == 0 and seen["0"]["k_gates"] == 0
+    for t in seen.values():
+        assert t["gen"] > 0 and t["score"] > 0 and t["run"] >= t["gen"] + t["score"]
