@@ -99,8 +99,12 @@ def cpu_parity(T, O):
            "edges_identical": edges_ok, "track_members_identical": members_ok, "max_endpoint_rel_err": err,
            "tracks_cpu": so["tracks"], "tracks_gpu": st["tracks"], "candidates_cpu": so["candidates"],
            "candidates_gpu": st["candidates"], "valid_edges_cpu": so["valid_edges"], "valid_edges_gpu": st["valid_edges"]}
+    from limap_amd.base import track_report  # limap's track report as a secondary signal
+    rep["track_report_cpu"] = track_report(ot["off"], ot["image_ids"])
+    rep["track_report_gpu"] = track_report(gt["off"], gt["image_ids"])
     ok = (best_ok and best_geom_ok and edges_ok and members_ok and best_score_err <= 1e-12
-          and (err is None or err <= 1e-5) and so["tracks"] == st["tracks"] and so["candidates"] == st["candidates"])
+          and (err is None or err <= 1e-5) and so["tracks"] == st["tracks"] and so["candidates"] == st["candidates"]
+          and rep["track_report_cpu"] == rep["track_report_gpu"])
     rep["ok"] = bool(ok)
     return ok, rep
 
@@ -330,6 +334,11 @@ def main():
     ctx.compute_tracks()
     t_tail = time.perf_counter() - t_tail0
     st_after = ctx.stats()
+    track_report_gpu = None
+    if rank == 0:  # limap's track report (visualize/trackvis/base.py:25-50): a secondary parity signal
+        from limap_amd.base import track_report
+        trk = ctx.get_tracks()
+        track_report_gpu = track_report(trk["off"], trk["image_ids"])
 
     per_rank_ms = [1e3 * elapsed_local / max(args.steps, 1)]
     if use_dist:
@@ -395,6 +404,7 @@ def main():
             "host_ms": {"upload_matches": 1e3 * t_upload, "tail_compute_tracks": 1e3 * t_tail,
                         "merge_shards_on_rank0": None if t_merge is None else 1e3 * t_merge},
             "tracks_whole_scene": st_after["tracks"], "merge_note": merge_note,
+            "track_report": track_report_gpu,
             "ranks": {"world_size": dist.get_world_size() if use_dist else 1,
                       "backend": (dist.get_backend() + " (RCCL)") if use_dist else None,
                       "ms_per_step_per_rank": per_rank_ms, "candidates_per_rank": per_rank_cand,

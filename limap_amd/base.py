@@ -162,3 +162,22 @@ class ImageCollection:
 
     def IsUndistorted(self):
         return True
+
+
+def track_report(off, image_ids):
+    """The numbers of limap's track report (visualize/trackvis/base.py:25-50) from a CSR track set (`off`,
+    `image_ids` as returned by Context.get_tracks()): tracks with >= 2, 4, 6, 8, 10, 20, 50 supporting IMAGES, and the
+    average number of supporting images / lines over the tracks seen from >= 3 and >= 4 images."""
+    import numpy as np
+    off = np.asarray(off, np.int64)
+    image_ids = np.asarray(image_ids)
+    n = len(off) - 1
+    counts = np.array([len(np.unique(image_ids[off[t]:off[t + 1]])) for t in range(n)], np.int64)
+    lines = np.diff(off)
+    rep = {f"N{k}": int((counts >= k).sum()) for k in (2, 4, 6, 8, 10, 20, 50)}
+    for k in (3, 4):
+        m = counts >= k
+        rep[f"avg_supporting_images_ge{k}"] = float(counts[m].mean()) if m.any() else 0.0
+        rep[f"avg_supporting_lines_ge{k}"] = float(lines[m].mean()) if m.any() else 0.0
+    return rep
+

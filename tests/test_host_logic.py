@@ -161,3 +161,12 @@ def test_lazy_line_tracks_copy_and_pickle():
     empty = tri._LazyLineTrack.__new__(tri._LazyLineTrack)            # an instance with an empty __dict__
     with pytest.raises(AttributeError):
         empty.line
+
+
+def test_track_report_counts_images_not_lines():
+    """limap's track report (visualize/trackvis/base.py:25-50): N_k counts tracks by supporting IMAGES."""
+    from limap_amd.base import track_report
+    rep = track_report([0, 2, 5, 5, 9], [1, 2, 3, 3, 4, 1, 2, 3, 4])
+    assert rep["N2"] == 3 and rep["N4"] == 1 and rep["N6"] == 0
+    assert rep["avg_supporting_images_ge3"] == 4.0 and rep["avg_supporting_lines_ge4"] == 4.0
+    assert track_report([0], [])["N2"] == 0
