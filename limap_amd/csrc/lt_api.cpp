@@ -39,7 +39,7 @@ size_t blk_rec_bytes();
 void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
                       const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
                       const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
-                      const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
+                      const long long *blk_line_base, CRec *st_r, double *st_unc, unsigned *st_key,
                       unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, void *st_row,
                       unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3,
                       const double *seg_vp, const unsigned char *seg_has_vp, const long long *seg_pt_off,
@@ -52,23 +52,25 @@ void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const 
                         int *err_flag);
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
-                  const unsigned *wave_count, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
-                  const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node, int mult, unsigned *perm);
+                  const unsigned *wave_count, const long long *tri_off, const CRec *st_r, const double *st_unc,
+                  const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, int mult, unsigned *perm);
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
                       unsigned *keys_c, unsigned *src_c, int mult);
-void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const Cand *st_c,
-                    const CandLite *st_l, Cand *cand, CandLite *lite, unsigned *cand_node);
+void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const CRec *st_r,
+                    const double *st_unc, CRec *cand, double *cand_unc, unsigned *cand_node);
+void launch_host_view(hipStream_t st, long long C, const unsigned *perm, const CRec *rec, const double *unc, Cand *out_c,
+                      CandLite *out_l);
 void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, unsigned *cand_node);
 size_t score3_lds_bytes(int max_nb, bool f32);
 size_t cand_meta_bytes();
 void launch_score3(hipStream_t st, long long C, long long G, const long long *tri_off, const unsigned *cand_node,
-                   void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
+                   void *meta, const CRec *cand, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
                    unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap, const unsigned *place,
-                   unsigned *rec, const float *st_z);
+                   unsigned *rec, const float *st_z, int *err_flag);
 int score3_tile_buckets();
 }
 
@@ -608,7 +610,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_blk_slot, &ctx->d_blk_order, &ctx->d_m_off, &ctx->d_m_pairs, &ctx->d_pairs,
                     &ctx->d_keys, &ctx->d_rows, &ctx->d_row_blk, &ctx->d_skeys, &ctx->d_srows, &ctx->d_sort_tmp,
                     &ctx->d_conn_off, &ctx->d_st_c, &ctx->d_st_l, &ctx->d_flags, &ctx->d_pos, &ctx->d_scan_tmp,
-                    &ctx->d_item_off, &ctx->d_masks, &ctx->d_mask_cnt, &ctx->d_mask_pos, &ctx->d_cand,
+                    &ctx->d_item_off, &ctx->d_masks, &ctx->d_mask_cnt, &ctx->d_mask_pos, &ctx->d_cand, &ctx->d_hcand, &ctx->d_hlite,
                     &ctx->d_lite, &ctx->d_tri_off, &ctx->d_score, &ctx->d_best_idx, &ctx->d_edge_flag,
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
@@ -1285,6 +1287,7 @@ int finish_run(lt_ctx *ctx) {
     ctx->ex_two_pass = false;
   }
   if (derr == 4) return fail(ctx, LT_ERR_RUNTIME, "internal: the scan of the node counts did not complete");
+  if (derr == 6) return fail(ctx, LT_ERR_RUNTIME, "internal: the scoring kernel's workgroup queue protocol failed");
   if (derr == 3)
     return fail(ctx, LT_ERR_RUNTIME, "the one-point proposal supports at most 64 shared points per connection");
   if (derr == 2)
@@ -1415,7 +1418,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     if (one_on) mult += (int)std::min<long long>(ctx->max_seg_pts, 64);
     if (mult > 1 && (long long)mult * P >= (1ll << 32) - 1)
       return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch for the extra proposals");
-    ENSURE(ctx, ctx->d_st_c, sizeof(Cand) * Pn * mult); ENSURE(ctx, ctx->d_st_l, sizeof(CandLite) * Pn * mult);
+    ENSURE(ctx, ctx->d_st_c, sizeof(CRec) * Pn * mult); ENSURE(ctx, ctx->d_st_l, sizeof(double) * Pn * mult);
     ENSURE(ctx, ctx->d_st_key, 4 * Pn * mult);
     ENSURE(ctx, ctx->d_wave_count, 4 * (size_t)(n_waves + 1));
     ENSURE(ctx, ctx->d_ntris_u, 4 * (size_t)(G + 1));
@@ -1447,8 +1450,8 @@ int lt_run_device_async(lt_ctx *ctx) {
       launch_gen_split(st, ctx->n_blk, ctx->max_rows, gcfg, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
                        ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(),
                        ctx->d_seg_off.as<long long>(), ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(),
-                       ctx->d_pairs.as<PairRec>(), ctx->d_blk_line_base.as<long long>(), ctx->d_st_c.as<Cand>(),
-                       ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(), ctx->d_wave_count.as<unsigned>(),
+                       ctx->d_pairs.as<PairRec>(), ctx->d_blk_line_base.as<long long>(), ctx->d_st_c.as<CRec>(),
+                       ctx->d_st_l.as<double>(), ctx->d_st_key.as<unsigned>(), ctx->d_wave_count.as<unsigned>(),
                        fast ? ctx->d_cnt_bl.as<unsigned>() : nullptr, lds_segs, lds_segs1, ctx->d_st_row.p,
                        ctx->d_surv_count.as<unsigned>(), G, ctx->d_seg_gates.p, ctx->d_blkrec.p, fine_gen ? &ev[8] : nullptr,
                        vp_on ? ctx->d_seg_vp.as<double>() : nullptr,
@@ -1478,7 +1481,7 @@ int lt_run_device_async(lt_ctx *ctx) {
       // otherwise (or with LT_TEST_SYNC_COUNT) one 8-byte copy + stream sync fetches the exact count.
       const long long bound = P * (long long)mult;
       constexpr long long kCountFreeBytes = 8ll << 30;
-      const long long per_cand = (long long)(sizeof(Cand) + sizeof(CandLite) + 8 + 4 + 4) + (long long)cand_meta_bytes();
+      const long long per_cand = (long long)(sizeof(CRec) + 8 + 8 + 4 + 4) + (long long)cand_meta_bytes();
       if (ctx->h_pinned && bound * per_cand <= kCountFreeBytes && !getenv("LT_TEST_SYNC_COUNT")) {
         C_known = -1;
         C_bound = bound;
@@ -1508,7 +1511,7 @@ int lt_run_device_async(lt_ctx *ctx) {
       // the bound is generous: if the device cannot give that much, fetch the exact count after all
       const size_t Bn = (size_t)std::max<long long>(C_bound, 1);
       const bool got = (perm_mode ? ctx->d_place_perm.ensure(4 * Bn)
-                                  : (ctx->d_cand.ensure(sizeof(Cand) * Bn) && ctx->d_lite.ensure(sizeof(CandLite) * Bn))) &&
+                                  : (ctx->d_cand.ensure(sizeof(CRec) * Bn) && ctx->d_lite.ensure(sizeof(double) * Bn))) &&
                        ctx->d_score.ensure(8 * Bn) && ctx->d_edge_flag.ensure(4 * Bn) && ctx->d_cand_node.ensure(4 * Bn) &&
                        ctx->d_cand_meta.ensure(cand_meta_bytes() * Bn);
       if (!got) {
@@ -1523,7 +1526,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     if (perm_mode) {
       ENSURE(ctx, ctx->d_place_perm, 4 * Cn);
     } else {
-      ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);
+      ENSURE(ctx, ctx->d_cand, sizeof(CRec) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(double) * Cn);
     }
     ENSURE(ctx, ctx->d_score, 8 * Cn); ENSURE(ctx, ctx->d_edge_flag, 4 * Cn); ENSURE(ctx, ctx->d_cand_node, 4 * Cn);
     ctx->cand_cap = (long long)Cn;
@@ -1531,8 +1534,8 @@ int lt_run_device_async(lt_ctx *ctx) {
       launch_place(st, ctx->n_blk, ctx->max_rows, ctx->d_m_off.as<long long>(), ctx->d_blk_img.as<int>(),
                    ctx->d_seg_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
                    ctx->d_base_bl.as<unsigned>(), ctx->d_wave_count.as<unsigned>(), ctx->d_tri_off.as<long long>(),
-                   ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(),
-                   ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_cand_node.as<unsigned>(), mult,
+                   ctx->d_st_c.as<CRec>(), ctx->d_st_l.as<double>(), ctx->d_st_key.as<unsigned>(),
+                   ctx->d_cand.as<CRec>(), ctx->d_lite.as<double>(), ctx->d_cand_node.as<unsigned>(), mult,
                    perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
     } else {
       ENSURE(ctx, ctx->d_keys, 4 * Cn); ENSURE(ctx, ctx->d_rows, 4 * Cn);
@@ -1549,8 +1552,8 @@ int lt_run_device_async(lt_ctx *ctx) {
           return fail(ctx, LT_ERR_HIP, "rocprim radix sort failed");
       }
       launch_node_offsets(st, C_known, G, ctx->d_skeys.as<unsigned>(), ctx->d_tri_off.as<long long>());
-      launch_permute(st, C_known, ctx->d_skeys.as<unsigned>(), ctx->d_srows.as<unsigned>(), ctx->d_st_c.as<Cand>(),
-                     ctx->d_st_l.as<CandLite>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
+      launch_permute(st, C_known, ctx->d_skeys.as<unsigned>(), ctx->d_srows.as<unsigned>(), ctx->d_st_c.as<CRec>(),
+                     ctx->d_st_l.as<double>(), ctx->d_cand.as<CRec>(), ctx->d_lite.as<double>(),
                      ctx->d_cand_node.as<unsigned>());
     }
     // ... and the one in front of k_score3 ends the placement stage (it then includes k_cand_meta)
@@ -1606,7 +1609,7 @@ int lt_run_device_async(lt_ctx *ctx) {
       else {
         region_cap = (unsigned)rc8;
         const size_t Bn = (size_t)ex_cap;
-        const bool got = ctx->d_st_c.ensure(sizeof(Cand) * Bn) && ctx->d_st_l.ensure(sizeof(CandLite) * Bn) &&
+        const bool got = ctx->d_st_c.ensure(sizeof(CRec) * Bn) && ctx->d_st_l.ensure(sizeof(double) * Bn) &&
                          ctx->d_st_key.ensure(4 * Bn) && ctx->d_place_perm.ensure(4 * Bn) && ctx->d_score.ensure(8 * Bn) &&
                          ctx->d_edge_flag.ensure(4 * Bn) && ctx->d_cand_node.ensure(4 * Bn) &&
                          ctx->d_cand_meta.ensure(cand_meta_bytes() * Bn) && ctx->d_ex_rec.ensure(4 * Bn) &&
@@ -1646,7 +1649,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                               ctx->d_item_off.as<long long>(), ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(),
                               ctx->d_nb_off.as<long long>(), ctx->d_seg_off.as<long long>(), ctx->d_cams.as<Cam>(),
                               ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(), ctx->d_blk_chunk_off.as<int>(),
-                              ctx->d_masks.as<unsigned long long>(), ctx->d_st_c.as<Cand>(), ctx->d_st_l.as<CandLite>(),
+                              ctx->d_masks.as<unsigned long long>(), ctx->d_st_c.as<CRec>(), ctx->d_st_l.as<double>(),
                               ctx->d_st_key.as<unsigned>(), ctx->d_ex_z.as<float>());
       }
       if (!plain) launch_popc(st, P, ctx->d_masks.as<unsigned long long>(), ctx->d_mask_cnt.as<unsigned>(), n_masks);
@@ -1671,7 +1674,7 @@ int lt_run_device_async(lt_ctx *ctx) {
       launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, -1, ex_cap,
                             ctx->d_tri_off.as<long long>(), ctx->d_err.as<int>());
       HIPCHK(ctx, hipEventRecord(ev[3], st));
-      launch_place_exhaustive(st, ex_ctr, region_cap, ctx->d_st_l.as<CandLite>(), ctx->d_st_key.as<unsigned>(),
+      launch_place_exhaustive(st, ex_ctr, region_cap, ctx->d_st_c.as<CRec>(), ctx->d_st_key.as<unsigned>(),
                               ctx->d_node_img.as<int>(), ctx->d_nb_off.as<long long>(), ctx->d_item_off.as<long long>(),
                               ctx->d_blk_chunk_off.as<int>(), ctx->d_masks.as<unsigned long long>(),
                               ctx->d_mask_pos.as<long long>(), P, ctx->d_tri_off.as<long long>(), G,
@@ -1691,7 +1694,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     HIPCHK(ctx, hipStreamSynchronize(st));
     HIPCHK(ctx, hipEventRecord(ev[3], st));
     const size_t Cn = (size_t)std::max<long long>(total, 1);
-    ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);
+    ENSURE(ctx, ctx->d_cand, sizeof(CRec) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(double) * Cn);
     ENSURE(ctx, ctx->d_score, 8 * Cn); ENSURE(ctx, ctx->d_edge_flag, 4 * Cn);
     ctx->cand_cap = (long long)Cn;
     if (pts_any)
@@ -1699,7 +1702,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                                 ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
                                 ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
                                 ctx->d_masks.as<unsigned char>(), ctx->d_mask_cnt.as<unsigned>(),
-                                ctx->d_mask_pos.as<long long>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
+                                ctx->d_mask_pos.as<long long>(), ctx->d_cand.as<CRec>(), ctx->d_lite.as<double>(),
                                 seg_vp, seg_has_vp, ctx->d_seg_pt_off.as<long long>(), ctx->d_seg_pts.p, sfm_xyz,
                                 ctx->d_err.as<int>(), many_on, one_on, ctx->d_blk_chunk_off.as<int>(), ctx->max_nb,
                                 ctx->max_chunks, ctx->d_seg_gates.p);
@@ -1708,13 +1711,13 @@ int lt_run_device_async(lt_ctx *ctx) {
                              ctx->d_blk_nb.as<int>(), ctx->d_nb_off.as<long long>(), ctx->d_seg_off.as<long long>(),
                              ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
                              ctx->d_masks.as<unsigned long long>(), ctx->d_mask_pos.as<long long>(),
-                             ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), ctx->d_blk_chunk_off.as<int>());
+                             ctx->d_cand.as<CRec>(), ctx->d_lite.as<double>(), ctx->d_blk_chunk_off.as<int>());
     else
       launch_gen_exhaustive(st, true, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
                             ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
                             ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
                             ctx->d_masks.as<unsigned long long>(), ctx->d_mask_pos.as<long long>(),
-                            ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(), seg_vp, seg_has_vp,
+                            ctx->d_cand.as<CRec>(), ctx->d_lite.as<double>(), seg_vp, seg_has_vp,
                             ctx->d_blk_chunk_off.as<int>(), ctx->max_nb, ctx->max_chunks, ctx->d_seg_gates.p);
     launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, total, -1,
                           ctx->d_tri_off.as<long long>(), ctx->d_err.as<int>());
@@ -1728,7 +1731,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     ctx->perm_mode = false;
     ctx->compact_valid = true;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_tri_off.p, 0, sizeof(long long) * (size_t)(G + 1), st));
-    ENSURE(ctx, ctx->d_cand, sizeof(Cand)); ENSURE(ctx, ctx->d_lite, sizeof(CandLite));
+    ENSURE(ctx, ctx->d_cand, sizeof(CRec)); ENSURE(ctx, ctx->d_lite, sizeof(double));
     ENSURE(ctx, ctx->d_score, 8); ENSURE(ctx, ctx->d_edge_flag, 4); ENSURE(ctx, ctx->d_cand_node, 4);
     C_known = 0;
     C_bound = 0;
@@ -1765,8 +1768,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     const bool staged_sorted = score_sorted && ctx->perm_mode && ctx->job_mode == 2;
     C_run = C_bound;  // replaced by the exact count when that arrives with the error flag (finish_run)
     launch_score3(st, C_bound, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
-                  ctx->perm_mode ? ctx->d_st_c.as<Cand>() : ctx->d_cand.as<Cand>(),
-                  ctx->perm_mode ? ctx->d_st_l.as<CandLite>() : ctx->d_lite.as<CandLite>(), ctx->d_node_img.as<int>(),
+                  ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(), ctx->d_node_img.as<int>(),
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
                   ctx->d_score.as<double>(), ctx->d_pair_counter.as<unsigned long long>(), ctx->max_nb, scfg,
                   guard2, fine_score ? ev[11] : nullptr, ctx->d_tile_order.as<unsigned>(), score_f32,
@@ -1779,7 +1781,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                   tile_classes ? ctx->d_tile_list.as<unsigned>() : nullptr, tile_cap,
                   staged_sorted ? ctx->d_place_perm.as<unsigned>() : nullptr,
                   staged_sorted ? ctx->d_ex_rec.as<unsigned>() : nullptr,
-                  staged_sorted ? ctx->d_ex_z.as<float>() : nullptr);
+                  staged_sorted ? ctx->d_ex_z.as<float>() : nullptr, ctx->d_err.as<int>());
   }
   HIPCHK(ctx, hipEventRecord(ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));
@@ -1793,8 +1795,8 @@ int lt_run_device_async(lt_ctx *ctx) {
   // flags and their number; the edge offsets (a scan) and the edge lists are produced at download time
   launch_select(st, G, ctx->d_tri_off.as<long long>(), ctx->d_score.as<double>(), scfg.fullscore_th,
                 scfg.max_valid_conns, ctx->d_best_idx.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
-                ctx->d_nvalid.as<unsigned>(), ctx->perm_mode ? ctx->d_st_c.as<Cand>() : ctx->d_cand.as<Cand>(),
-                ctx->perm_mode ? ctx->d_st_l.as<CandLite>() : ctx->d_lite.as<CandLite>(),
+                ctx->d_nvalid.as<unsigned>(), ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(),
+                ctx->perm_mode ? ctx->d_st_l.as<double>() : ctx->d_lite.as<double>(),
                 ctx->d_best_c.as<Cand>(), ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(),
                 ctx->d_ntris.as<int>(), /*wide=*/ctx->job_mode == 2, ctx->d_err.as<int>(),
                 ctx->d_pair_counter.as<unsigned long long>(), ctx->d_result3.as<long long>(),
@@ -1826,6 +1828,7 @@ int lt_run_device_async(lt_ctx *ctx) {
   ctx->pend_ev_place_end = ev_place_end;
   ctx->ran = true;
   ctx->downloaded = false;
+  ctx->host_view_valid = false;
   return rc_prev;
 }
 
@@ -1845,17 +1848,20 @@ static void define_best_of_other_images(lt_ctx *ctx) {
     }
 }
 
-// The compact candidate arrays of the last run (debug read-outs): in perm mode they are gathered on demand.
+// The split host-side view (Cand / CandLite in candidate order) of the last run's candidates, for the debug
+// read-outs: converted on demand from the 128-byte device records -- through the placement permutation when the
+// records are still in the staging lists.
 static int materialize_compact(lt_ctx *ctx) {
-  if (!ctx->perm_mode || ctx->compact_valid) return LT_OK;
+  if (ctx->host_view_valid) return LT_OK;
   const long long C = ctx->C_last;
   const size_t Cn = (size_t)std::max<long long>(C, 1);
-  ENSURE(ctx, ctx->d_cand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(CandLite) * Cn);
-  launch_permute(ctx->stream, C, ctx->d_cand_node.as<unsigned>(), ctx->d_place_perm.as<unsigned>(), ctx->d_st_c.as<Cand>(),
-                 ctx->d_st_l.as<CandLite>(), ctx->d_cand.as<Cand>(), ctx->d_lite.as<CandLite>(),
-                 ctx->d_cand_node.as<unsigned>());
+  ENSURE(ctx, ctx->d_hcand, sizeof(Cand) * Cn); ENSURE(ctx, ctx->d_hlite, sizeof(CandLite) * Cn);
+  launch_host_view(ctx->stream, C, ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr,
+                   ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(),
+                   ctx->perm_mode ? ctx->d_st_l.as<double>() : ctx->d_lite.as<double>(), ctx->d_hcand.as<Cand>(),
+                   ctx->d_hlite.as<CandLite>());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->compact_valid = true;
+  ctx->host_view_valid = true;
   return LT_OK;
 }
 
@@ -1885,7 +1891,7 @@ int lt_download(lt_ctx *ctx) {
   ctx->E = edge_off[G];
   ENSURE(ctx, ctx->d_edges, 8 * (size_t)std::max<long long>(ctx->E, 1));
   launch_edge_fill(st, G, ctx->d_tri_off.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
-                   ctx->d_edge_off.as<long long>(), ctx->perm_mode ? ctx->d_st_l.as<CandLite>() : ctx->d_lite.as<CandLite>(),
+                   ctx->d_edge_off.as<long long>(), ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(),
                    ctx->d_edges.as<int>(), ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
   // one pooled page-locked block for all result arrays
   const size_t Gn = (size_t)std::max<long long>(G, 1), En = (size_t)std::max<long long>(ctx->E, 1);
@@ -1946,8 +1952,8 @@ int lt_download(lt_ctx *ctx) {
     std::vector<Cand> c((size_t)C);
     std::vector<CandLite> l((size_t)C);
     std::vector<double> sc((size_t)C);
-    HIPCHK(ctx, hipMemcpy(c.data(), ctx->d_cand.p, sizeof(Cand) * (size_t)C, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(l.data(), ctx->d_lite.p, sizeof(CandLite) * (size_t)C, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(c.data(), ctx->d_hcand.p, sizeof(Cand) * (size_t)C, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(l.data(), ctx->d_hlite.p, sizeof(CandLite) * (size_t)C, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(sc.data(), ctx->d_score.p, 8 * (size_t)C, hipMemcpyDeviceToHost));
     for (long long j = 0; j < n_job; ++j) {
       const int idx = ctx->job_imgs[(size_t)j];
@@ -2059,7 +2065,7 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
   hn[0] = hn[1] = 0;
   const unsigned long long *hpairs = (const unsigned long long *)(base + o_pairs);
   launch_tail_keys(st, G, ctx->d_tri_off.as<long long>(), ctx->d_edge_flag.as<unsigned>(), ctx->d_edge_off.as<long long>(),
-                   ctx->perm_mode ? ctx->d_st_l.as<CandLite>() : ctx->d_lite.as<CandLite>(), ctx->d_seg_off.as<long long>(), kb,
+                   ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(), ctx->d_seg_off.as<long long>(), kb,
                    ctx->d_tail_keys.as<unsigned long long>(), ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
   if (launch_tail_sort(st, ctx->d_tail_tmp.p, sort_tmp, E, ctx->d_tail_keys.as<unsigned long long>(),
                        ctx->d_tail_skeys.as<unsigned long long>(), end_bit) != 0)
@@ -2571,8 +2577,8 @@ int lt_get_all_tris(lt_ctx *ctx, int64_t *out_off, double *out_line10, double *o
   if (C == 0) return LT_OK;
   std::vector<Cand> c(C);
   std::vector<CandLite> l(C);
-  HIPCHK(ctx, hipMemcpy(c.data(), ctx->d_cand.p, sizeof(Cand) * (size_t)C, hipMemcpyDeviceToHost));
-  HIPCHK(ctx, hipMemcpy(l.data(), ctx->d_lite.p, sizeof(CandLite) * (size_t)C, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(c.data(), ctx->d_hcand.p, sizeof(Cand) * (size_t)C, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(l.data(), ctx->d_hlite.p, sizeof(CandLite) * (size_t)C, hipMemcpyDeviceToHost));
   HIPCHK(ctx, hipMemcpy(out_score, ctx->d_score.p, 8 * (size_t)C, hipMemcpyDeviceToHost));
   for (long long g = 0; g < G; ++g) {
     for (long long t = tri_off[g]; t < tri_off[g + 1]; ++t) {

@@ -184,6 +184,7 @@ struct lt_ctx {
   DevBuf d_keys, d_rows, d_row_blk, d_skeys, d_srows, d_sort_tmp, d_conn_off;
   DevBuf d_st_c, d_st_l, d_flags, d_pos, d_scan_tmp;
   DevBuf d_item_off, d_masks, d_mask_cnt, d_mask_pos;
+  DevBuf d_hcand, d_hlite;  // split host-side view of the candidates (debug read-outs), see materialize_compact
   DevBuf d_cand, d_lite, d_tri_off, d_score, d_best_idx, d_edge_flag, d_nvalid, d_edge_off, d_edges;
   DevBuf d_best_c, d_best_score, d_best_src, d_ntris, d_err;
   DevBuf d_blk_line_base, d_cnt_bl, d_st_key, d_wave_count, d_wave_pos, d_ntris_u, d_cand_node, d_pair_counter;
@@ -225,6 +226,7 @@ struct lt_ctx {
   bool in_run_async = false;
   bool pend_fine_gen = false, pend_fine_score = false;  // which per-kernel events the run in flight recorded
   int ex_retry_depth = 0;
+  bool host_view_valid = false;  // d_hcand / d_hlite hold the last run's candidates
   bool compact_valid = false;  // d_cand / d_lite hold the compact arrays of the last run
   DevBuf d_tail_keys, d_tail_skeys, d_tail_sims, d_tail_mark, d_tail_pos, d_tail_recs, d_tail_nodes, d_tail_tmp, d_tail_keep, d_tail_kpos;  // lt_kernels_tail.hip
   bool cnt_bl_clean = false;  // d_cnt_bl is all zero (k_node_prefix cleans up after itself)

@@ -21,8 +21,8 @@ static __device__ __forceinline__ void wave_lds_sync() {
 
 
 struct GenOut {
-  Cand c;
-  CandLite l;
+  CRec r;      // nb_slot / ng_line are filled in by the caller
+  double unc;  // min of the two views' uncertainties (side array of the candidate store)
 };
 
 // triangulate_point, functions.cc:100-117 (2x2 LDLT solve with diagonal pivoting)
@@ -309,13 +309,12 @@ static __device__ __forceinline__ bool gen_finish(const GenCfg &cfg, const Cam &
     if (pe.y < cfg.lo[1] || pe.y > cfg.hi[1]) return false;
     if (pe.z < cfg.lo[2] || pe.z > cfg.hi[2]) return false;
   }
-  out->c.s[0] = ps.x; out->c.s[1] = ps.y; out->c.s[2] = ps.z;
-  out->c.e[0] = pe.x; out->c.e[1] = pe.y; out->c.e[2] = pe.z;
-  out->c.depth[0] = z_start; out->c.depth[1] = z_end;
-  out->c.unc = dmin(u1, u2);
-  out->c.score3 = 1.0;
-  out->c.seg[0] = s2.x1; out->c.seg[1] = s2.y1; out->c.seg[2] = s2.x2; out->c.seg[3] = s2.y2;
-  out->l.dir[0] = dir3.x; out->l.dir[1] = dir3.y; out->l.dir[2] = dir3.z;
+  out->r.s[0] = ps.x; out->r.s[1] = ps.y; out->r.s[2] = ps.z;
+  out->r.e[0] = pe.x; out->r.e[1] = pe.y; out->r.e[2] = pe.z;
+  out->r.depth[0] = z_start; out->r.depth[1] = z_end;
+  out->unc = dmin(u1, u2);
+  out->r.seg[0] = s2.x1; out->r.seg[1] = s2.y1; out->r.seg[2] = s2.x2; out->r.seg[3] = s2.y2;
+  out->r.dir[0] = dir3.x; out->r.dir[1] = dir3.y; out->r.dir[2] = dir3.z;
   return true;
 }
 
@@ -389,13 +388,12 @@ static __device__ __forceinline__ bool dir_candidate(const GenCfg &cfg, const Ca
     if (pe.z < cfg.lo[2] || pe.z > cfg.hi[2]) return false;
   }
   const d3 dir3 = unit(sub(pe, ps));
-  out->c.s[0] = ps.x; out->c.s[1] = ps.y; out->c.s[2] = ps.z;
-  out->c.e[0] = pe.x; out->c.e[1] = pe.y; out->c.e[2] = pe.z;
-  out->c.depth[0] = z_start; out->c.depth[1] = z_end;
-  out->c.unc = dmin(u1, u2);
-  out->c.score3 = 1.0;
-  out->c.seg[0] = s2.x1; out->c.seg[1] = s2.y1; out->c.seg[2] = s2.x2; out->c.seg[3] = s2.y2;
-  out->l.dir[0] = dir3.x; out->l.dir[1] = dir3.y; out->l.dir[2] = dir3.z;
+  out->r.s[0] = ps.x; out->r.s[1] = ps.y; out->r.s[2] = ps.z;
+  out->r.e[0] = pe.x; out->r.e[1] = pe.y; out->r.e[2] = pe.z;
+  out->r.depth[0] = z_start; out->r.depth[1] = z_end;
+  out->unc = dmin(u1, u2);
+  out->r.seg[0] = s2.x1; out->r.seg[1] = s2.y1; out->r.seg[2] = s2.x2; out->r.seg[3] = s2.y2;
+  out->r.dir[0] = dir3.x; out->r.dir[1] = dir3.y; out->r.dir[2] = dir3.z;
   return true;
 }
 
@@ -520,13 +518,12 @@ static __device__ __forceinline__ bool points_candidate(const GenCfg &cfg, const
     if (pe.z < cfg.lo[2] || pe.z > cfg.hi[2]) return false;
   }
   const d3 dir3 = unit(sub(pe, ps));
-  out->c.s[0] = ps.x; out->c.s[1] = ps.y; out->c.s[2] = ps.z;
-  out->c.e[0] = pe.x; out->c.e[1] = pe.y; out->c.e[2] = pe.z;
-  out->c.depth[0] = z_start; out->c.depth[1] = z_end;
-  out->c.unc = dmin(u1, u2);
-  out->c.score3 = 1.0;
-  out->c.seg[0] = s2.x1; out->c.seg[1] = s2.y1; out->c.seg[2] = s2.x2; out->c.seg[3] = s2.y2;
-  out->l.dir[0] = dir3.x; out->l.dir[1] = dir3.y; out->l.dir[2] = dir3.z;
+  out->r.s[0] = ps.x; out->r.s[1] = ps.y; out->r.s[2] = ps.z;
+  out->r.e[0] = pe.x; out->r.e[1] = pe.y; out->r.e[2] = pe.z;
+  out->r.depth[0] = z_start; out->r.depth[1] = z_end;
+  out->unc = dmin(u1, u2);
+  out->r.seg[0] = s2.x1; out->r.seg[1] = s2.y1; out->r.seg[2] = s2.x2; out->r.seg[3] = s2.y2;
+  out->r.dir[0] = dir3.x; out->r.dir[1] = dir3.y; out->r.dir[2] = dir3.z;
   return true;
 }
 
@@ -710,13 +707,12 @@ static __device__ bool one_point_candidate(const GenCfg &cfg, const Cam &c1, con
     if (pe.z < cfg.lo[2] || pe.z > cfg.hi[2]) return false;
   }
   const d3 dir3 = unit(sub(pe, ps));
-  out->c.s[0] = ps.x; out->c.s[1] = ps.y; out->c.s[2] = ps.z;
-  out->c.e[0] = pe.x; out->c.e[1] = pe.y; out->c.e[2] = pe.z;
-  out->c.depth[0] = z_start; out->c.depth[1] = z_end;
-  out->c.unc = dmin(u1, u2);
-  out->c.score3 = 1.0;
-  out->c.seg[0] = s2.x1; out->c.seg[1] = s2.y1; out->c.seg[2] = s2.x2; out->c.seg[3] = s2.y2;
-  out->l.dir[0] = dir3.x; out->l.dir[1] = dir3.y; out->l.dir[2] = dir3.z;
+  out->r.s[0] = ps.x; out->r.s[1] = ps.y; out->r.s[2] = ps.z;
+  out->r.e[0] = pe.x; out->r.e[1] = pe.y; out->r.e[2] = pe.z;
+  out->r.depth[0] = z_start; out->r.depth[1] = z_end;
+  out->unc = dmin(u1, u2);
+  out->r.seg[0] = s2.x1; out->r.seg[1] = s2.y1; out->r.seg[2] = s2.x2; out->r.seg[3] = s2.y2;
+  out->r.dir[0] = dir3.x; out->r.dir[1] = dir3.y; out->r.dir[2] = dir3.z;
   return true;
 }
 

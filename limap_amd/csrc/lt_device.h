@@ -41,7 +41,7 @@ void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const G
                            const long long *item_off, long long G, const int *node_img, const long long *nb_off,
                            const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
                            const PairRec *pairs, unsigned long long *masks, const long long *mask_pos,
-                           Cand *out_c, CandLite *out_l, const double *seg_vp, const unsigned char *seg_has_vp,
+                           CRec *out_r, double *out_unc, const double *seg_vp, const unsigned char *seg_has_vp,
                            const int *blk_chunk_off, int max_nb, int max_chunks, const void *gates);
 int ex_regions();
 void launch_gates_exhaustive(hipStream_t st, int n_blk, int max_chunks, long long n_items, const GenCfg &cfg,
@@ -53,8 +53,8 @@ void launch_tri_exhaustive(hipStream_t st, const unsigned long long *ent, const 
                            unsigned region_cap, const GenCfg &cfg, long long n_items, const long long *item_off,
                            const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
                            const Cam *cams, const Seg *segs, const PairRec *pairs, const int *blk_chunk_off,
-                           unsigned long long *masks, Cand *st_c, CandLite *st_l, unsigned *st_node, float *st_z);
-void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsigned region_cap, const CandLite *st_l,
+                           unsigned long long *masks, CRec *st_r, double *st_unc, unsigned *st_node, float *st_z);
+void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsigned region_cap, const CRec *st_r,
                              const unsigned *st_node, const int *node_img, const long long *nb_off,
                              const long long *item_off, const int *blk_chunk_off, const unsigned long long *masks,
                              const long long *mask_pos, long long n_items, const long long *tri_off, long long G,
@@ -62,12 +62,12 @@ void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsi
 void launch_fill_exhaustive(hipStream_t st, int n_blk, long long n_items, const GenCfg &cfg, const long long *item_off,
                             const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
                             const Cam *cams, const Seg *segs, const PairRec *pairs, const unsigned long long *masks,
-                            const long long *mask_pos, Cand *out_c, CandLite *out_l, const int *blk_chunk_off);
+                            const long long *mask_pos, CRec *out_r, double *out_unc, const int *blk_chunk_off);
 void launch_gen_exhaustive_pts(hipStream_t st, bool fill, long long n_items, const GenCfg &cfg,
                                const long long *item_off, long long G, const int *node_img, const long long *nb_off,
                                const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
                                const PairRec *pairs, unsigned char *cnt8, unsigned *item_cnt,
-                               const long long *mask_pos, Cand *out_c, CandLite *out_l, const double *seg_vp,
+                               const long long *mask_pos, CRec *out_r, double *out_unc, const double *seg_vp,
                                const unsigned char *seg_has_vp, const long long *seg_pt_off, const void *seg_pts,
                                const double *sfm_xyz, int *err_flag, int many_on, int one_on,
                                const int *blk_chunk_off, int max_nb, int max_chunks, const void *gates);
@@ -76,18 +76,18 @@ void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_of
                            long long n_items, long long total, long long cap, long long *tri_off, int *err_flag);
 
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
-                   int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const Cand *cand,
-                   const CandLite *lite, Cand *best_c, double *best_score, int *best_src2, int *n_tris,
+                   int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const CRec *cand,
+                   const double *cand_unc, Cand *best_c, double *best_score, int *best_src2, int *n_tris,
                    bool wide, const int *err_flag, const unsigned long long *pair_counter, long long *result3,
                    const unsigned *perm);
 void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
-                      const long long *edge_off, const CandLite *lite, int *edges2, const unsigned *perm);
+                      const long long *edge_off, const CRec *cand, int *edges2, const unsigned *perm);
 
 // device half of ComputeLineTracks (lt_kernels_tail.hip)
 size_t tail_rec_bytes();
 size_t tail_sort_temp_bytes(long long E, int end_bit);
 void launch_tail_keys(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
-                      const long long *edge_off, const CandLite *lite, const long long *seg_off, int kb,
+                      const long long *edge_off, const CRec *cand, const long long *seg_off, int kb,
                       unsigned long long *keys, const unsigned *perm);
 int launch_tail_sort(hipStream_t st, void *temp, size_t temp_bytes, long long E, const unsigned long long *keys_in,
                      unsigned long long *keys_out, int end_bit);

@@ -210,16 +210,29 @@ LT_HD void pair_build(const Cam &c1, const Cam &c2, PairRec *p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3D candidate ("TriTuple", base_line_triangulator.h:17-18) split into a heavy and a light
-// record: the O(n^2) scoring sweep only streams the 32 B light record.
+// 3D candidate ("TriTuple", base_line_triangulator.h:17-18).
+// CRec (128 B = one cache line, 128-byte aligned arrays) is THE record of the device pipeline: everything the
+// scoring, selection and edge kernels read of a candidate comes with one line.  The uncertainty -- needed only
+// for the per-node best candidate and the debug read-outs -- lives in a side array (8 B per record).
+// Cand / CandLite are the split host-side view (per-node best record, getters, import / export): Line3d::score
+// is 1.0 for every generated proposal, so it is not stored per candidate on the device.
 // ---------------------------------------------------------------------------------------------
+struct CRec {  // 128 B
+  double s[3], e[3];
+  double depth[2];  // depths in the source view (view1)
+  double seg[4];    // the neighbour's 2D segment that generated the candidate (scoring compares
+                    // reprojections against exactly this segment, global_line_triangulator.cc:100-101)
+  double dir[3];    // Line3d::direction()
+  int nb_slot;      // (neighbour image index << 8) | index of that image in neighbors_[img]
+  int ng_line;      // line id in that neighbour image
+};
+static_assert(sizeof(CRec) == 128, "candidate record = one cache line");
 struct Cand {  // 112 B
   double s[3], e[3];
   double depth[2];  // depths in the source view (view1)
   double unc;
   double score3;    // Line3d::score (1.0 for a valid proposal)
-  double seg[4];    // the neighbour's 2D segment that generated the candidate (scoring compares
-                    // reprojections against exactly this segment, global_line_triangulator.cc:100-101)
+  double seg[4];
 };
 struct CandLite {  // 32 B
   double dir[3];   // Line3d::direction()
@@ -227,6 +240,15 @@ struct CandLite {  // 32 B
   int ng_line;     // line id in that neighbour image
 };
 static_assert(sizeof(Cand) == 112 && sizeof(CandLite) == 32, "candidate layout");
+LT_HD void crec_split(const CRec &r, double unc, Cand *c, CandLite *l) {
+  for (int k = 0; k < 3; ++k) { c->s[k] = r.s[k]; c->e[k] = r.e[k]; l->dir[k] = r.dir[k]; }
+  c->depth[0] = r.depth[0]; c->depth[1] = r.depth[1];
+  c->unc = unc; c->score3 = 1.0;
+  for (int k = 0; k < 4; ++k) c->seg[k] = r.seg[k];
+  l->nb_slot = r.nb_slot; l->ng_line = r.ng_line;
+}
+LT_HD int crec_slot(const CRec &r) { return r.nb_slot & 0xFF; }
+LT_HD int crec_img(const CRec &r) { return (int)((unsigned)r.nb_slot >> 8); }
 LT_HD int lite_pack(int slot, int img) { return (img << 8) | (slot & 0xFF); }
 LT_HD int lite_slot(const CandLite &l) { return l.nb_slot & 0xFF; }
 LT_HD int lite_img(const CandLite &l) { return (int)((unsigned)l.nb_slot >> 8); }

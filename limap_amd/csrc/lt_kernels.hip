@@ -190,7 +190,7 @@ k_gen_ex_block(long long n_items, GenCfg cfg, const long long *__restrict__ item
                const int *__restrict__ blk_nb, const long long *__restrict__ seg_off,
                const Cam *__restrict__ cams, const Seg *__restrict__ segs, const PairRec *__restrict__ pairs,
                unsigned long long *__restrict__ masks, const long long *__restrict__ mask_pos,
-               Cand *__restrict__ out_c, CandLite *__restrict__ out_l, const double *__restrict__ seg_vp,
+               CRec *__restrict__ out_r, double *__restrict__ out_unc, const double *__restrict__ seg_vp,
                const unsigned char *__restrict__ seg_has_vp, const int *__restrict__ blk_chunk_off, int max_nb,
                const SegGate *__restrict__ gates) {
   constexpr int kMasks = kVP ? 3 : 1;
@@ -307,10 +307,10 @@ k_gen_ex_block(long long n_items, GenCfg cfg, const long long *__restrict__ item
           if (ok) atomicOr(&lmask[cc * kMasks + kind], 1ull << ln);
         } else if (ok) {
           const long long pos = pos0 + (long long)(ent >> 12);
-          o.l.nb_slot = nbs;
-          o.l.ng_line = ng;
-          out_c[pos] = o.c;
-          out_l[pos] = o.l;
+          o.r.nb_slot = nbs;
+          o.r.ng_line = ng;
+          out_r[pos] = o.r;
+          out_unc[pos] = o.unc;
         }
       }
     }
@@ -498,12 +498,12 @@ k_tri_ex(const unsigned long long *__restrict__ ent, const unsigned long long *_
          GenCfg cfg, long long n_items, const long long *__restrict__ item_off, const int *__restrict__ blk_img,
          const int *__restrict__ blk_nb, const long long *__restrict__ nb_off, const long long *__restrict__ seg_off,
          const Cam *__restrict__ cams, const Seg *__restrict__ segs, const PairRec *__restrict__ pairs,
-         const int *__restrict__ blk_chunk_off, unsigned long long *__restrict__ masks, Cand *__restrict__ st_c,
-         CandLite *__restrict__ st_l, unsigned *__restrict__ st_node, float *__restrict__ st_z) {
+         const int *__restrict__ blk_chunk_off, unsigned long long *__restrict__ masks, CRec *__restrict__ st_r,
+         double *__restrict__ st_unc, unsigned *__restrict__ st_node, float *__restrict__ st_z) {
   // The 64 staging slots of a block are contiguous: the records go through LDS and leave as full 1 KB rows (a lane
-  // storing its own 112-byte record writes 16-byte pieces 112 bytes apart -- every store instruction then touches 64
+  // storing its own 128-byte record writes 16-byte pieces 128 bytes apart -- every store instruction then touches 64
   // cache lines, and the kernel was bound by that, not by its arithmetic).  Holes carry stale bytes, nobody reads them.
-  __shared__ double2 s_out[4][64 * 9];
+  __shared__ double2 s_out[4][64 * 8];
   const int region = blockIdx.y;
   const unsigned long long n = ctr[region * 16];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -530,12 +530,12 @@ k_tri_ex(const unsigned long long *__restrict__ ent, const unsigned long long *_
     ok = ((e >> 32) & 1ull) ? gen_one(cfg, cams[i1], cams[i2], s1, s2, pr, &o)
                             : gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o);
     if (ok) {
-      o.l.nb_slot = lite_pack((int)(b - nb_off[i1]), i2);
-      o.l.ng_line = ng;
-      *reinterpret_cast<Cand *>(&s_out[wv][7 * lane]) = o.c;
-      *reinterpret_cast<CandLite *>(&s_out[wv][64 * 7 + 2 * lane]) = o.l;
+      o.r.nb_slot = lite_pack((int)(b - nb_off[i1]), i2);
+      o.r.ng_line = ng;
+      *reinterpret_cast<CRec *>(&s_out[wv][8 * lane]) = o.r;
+      st_unc[slot] = o.unc;
       node = (unsigned)g;
-      o_depth0 = o.c.depth[0];
+      o_depth0 = o.r.depth[0];
       const long long item = item_off[g] + blk_chunk_off[b] + (ng >> 6);
       if (item < n_items) atomicOr(&masks[item], 1ull << (ng & 63));
     }
@@ -546,12 +546,9 @@ k_tri_ex(const unsigned long long *__restrict__ ent, const unsigned long long *_
   st_z[slot] = ok ? (float)o_depth0 : 0.0f;
   if (__ballot(ok)) {
     wave_lds_sync();
-    double2 *dc = reinterpret_cast<double2 *>(st_c + slot0);
-    double2 *dl = reinterpret_cast<double2 *>(st_l + slot0);
+    double2 *dc = reinterpret_cast<double2 *>(st_r + slot0);
 #pragma unroll
-    for (int k = 0; k < 7; ++k) dc[k * 64 + lane] = s_out[wv][k * 64 + lane];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) dl[k * 64 + lane] = s_out[wv][64 * 7 + k * 64 + lane];
+    for (int k = 0; k < 8; ++k) dc[k * 64 + lane] = s_out[wv][k * 64 + lane];
   }
 }
 
@@ -566,7 +563,7 @@ k_fill_ex(int n_blk, long long n_items, GenCfg cfg, const long long *__restrict_
           const int *__restrict__ blk_img, const int *__restrict__ blk_nb, const long long *__restrict__ nb_off,
           const long long *__restrict__ seg_off, const Cam *__restrict__ cams, const Seg *__restrict__ segs,
           const PairRec *__restrict__ pairs, const unsigned long long *__restrict__ masks,
-          const long long *__restrict__ mask_pos, Cand *__restrict__ out_c, CandLite *__restrict__ out_l,
+          const long long *__restrict__ mask_pos, CRec *__restrict__ out_r, double *__restrict__ out_unc,
           const int *__restrict__ blk_chunk_off) {
   __shared__ unsigned s_list[4][128];
   __shared__ long long s_pos[4][128];
@@ -601,10 +598,10 @@ k_fill_ex(int n_blk, long long n_items, GenCfg cfg, const long long *__restrict_
       const Seg &s2 = segs[g2base + ng];
       GenOut o;
       if (gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o)) {  // pass 1 proved the gates
-        o.l.nb_slot = nbs;
-        o.l.ng_line = ng;
-        out_c[pos] = o.c;
-        out_l[pos] = o.l;
+        o.r.nb_slot = nbs;
+        o.r.ng_line = ng;
+        out_r[pos] = o.r;
+        out_unc[pos] = o.unc;
       }
     }
     n_ent = base;
@@ -657,7 +654,7 @@ k_gen_exhaustive_pts(long long n_items, GenCfg cfg, const long long *__restrict_
                      const Cam *__restrict__ cams, const Seg *__restrict__ segs,
                      const PairRec *__restrict__ pairs, unsigned char *__restrict__ cnt8,
                      unsigned *__restrict__ item_cnt, const long long *__restrict__ mask_pos,
-                     Cand *__restrict__ out_c, CandLite *__restrict__ out_l, const double *__restrict__ seg_vp,
+                     CRec *__restrict__ out_r, double *__restrict__ out_unc, const double *__restrict__ seg_vp,
                      const unsigned char *__restrict__ seg_has_vp, const long long *__restrict__ seg_pt_off,
                      const SegPoint *__restrict__ seg_pts, const double *__restrict__ sfm_xyz,
                      int *__restrict__ err_flag, int many_on, int one_on, const int *__restrict__ blk_chunk_off,
@@ -701,10 +698,10 @@ k_gen_exhaustive_pts(long long n_items, GenCfg cfg, const long long *__restrict_
     const int nbs = lite_pack((int)(b - nb_off[i1]), i2);
     auto emit = [&](GenOut &o) {
       if (kFill) {
-        o.l.nb_slot = nbs;
-        o.l.ng_line = ng_line;
-        out_c[pos] = o.c;
-        out_l[pos] = o.l;
+        o.r.nb_slot = nbs;
+        o.r.ng_line = ng_line;
+        out_r[pos] = o.r;
+        out_unc[pos] = o.unc;
         ++pos;
       }
       ++cnt;
@@ -803,7 +800,7 @@ __global__ void k_tri_offsets_ex(long long G, const long long *__restrict__ item
 // One-pass exhaustive mode: the final position of the candidate in staging slot s -- its work item is
 // (node, neighbour block, chunk of its neighbour line), its rank the survivors of the lower lanes of that item.
 __global__ void __launch_bounds__(256)
-k_place_ex(const unsigned long long *__restrict__ ctr, unsigned region_cap, const CandLite *__restrict__ st_l,
+k_place_ex(const unsigned long long *__restrict__ ctr, unsigned region_cap, const CRec *__restrict__ st_r,
            const unsigned *__restrict__ st_node, const int *__restrict__ node_img, const long long *__restrict__ nb_off,
            const long long *__restrict__ item_off, const int *__restrict__ blk_chunk_off,
            const unsigned long long *__restrict__ masks, const long long *__restrict__ mask_pos, long long n_items,
@@ -822,13 +819,13 @@ k_place_ex(const unsigned long long *__restrict__ ctr, unsigned region_cap, cons
   const size_t slot = (size_t)region * region_cap + (size_t)t;
   const unsigned gu = st_node[slot];
   if (gu == 0xFFFFFFFFu) return;  // a connection that failed the dense evaluation
-  const CandLite l = st_l[slot];
+  const int2 l = *reinterpret_cast<const int2 *>(&st_r[slot].nb_slot);  // (nb_slot, ng_line)
   const long long g = (long long)gu;
-  const long long b = nb_off[node_img[g]] + lite_slot(l);
-  const long long item = item_off[g] + blk_chunk_off[b] + (l.ng_line >> 6);
+  const long long b = nb_off[node_img[g]] + (l.x & 0xFF);
+  const long long item = item_off[g] + blk_chunk_off[b] + (l.y >> 6);
   if (item >= n_items) return;
   const unsigned long long m = masks[item];
-  const long long pos = mask_pos[item] + __popcll(m & ((1ull << (l.ng_line & 63)) - 1ull));
+  const long long pos = mask_pos[item] + __popcll(m & ((1ull << (l.y & 63)) - 1ull));
   perm[pos] = (unsigned)slot;
 }
 
@@ -839,8 +836,8 @@ template <int kLanes>  // lanes per node: 16 (matched mode, ~12 candidates per n
 __global__ void __launch_bounds__(256)
 k_select(long long G, const long long *__restrict__ tri_off, const double *__restrict__ score,
          double fullscore_th, int max_valid_conns, long long *__restrict__ best_idx,
-         unsigned *__restrict__ edge_flag, unsigned *__restrict__ n_valid, const Cand *__restrict__ cand,
-         const CandLite *__restrict__ lite, Cand *__restrict__ best_c, double *__restrict__ best_score,
+         unsigned *__restrict__ edge_flag, unsigned *__restrict__ n_valid, const CRec *__restrict__ cand,
+         const double *__restrict__ cand_unc, Cand *__restrict__ best_c, double *__restrict__ best_score,
          int *__restrict__ best_src2, int *__restrict__ n_tris, const int *__restrict__ err_flag,
          const unsigned long long *__restrict__ pair_counter, long long *__restrict__ result3,
          const unsigned *__restrict__ perm) {
@@ -883,21 +880,25 @@ k_select(long long G, const long long *__restrict__ tri_off, const double *__res
   // the best candidate's record goes to the dense per-node arrays right here (lanes 0-6: the 7 16-byte
   // units of the Cand, lane 7: score, lane 8: source (image, line), lane 9: candidate count)
   {
-    static_assert(sizeof(Cand) == 7 * 16, "Cand in 16-byte units");
+    static_assert(sizeof(Cand) == 7 * 16 && sizeof(CRec) == 8 * 16, "records in 16-byte units");
     long long b = (bi < 0) ? -1 : off + bi;
     if (perm && b >= 0) b = (long long)perm[b];  // records still in the staging lists (k_place wrote the permutation)
     if (lane < 7) {
+      // Cand units: 0-3 = s, e, depth (CRec units 0-3), 4 = (unc, score3 = 1), 5-6 = seg (CRec units 4-5)
       double2 v = double2{0.0, 0.0};
-      if (b >= 0) v = reinterpret_cast<const double2 *>(cand + b)[lane];
+      if (b >= 0) {
+        if (lane == 4) v = double2{cand_unc[b], 1.0};
+        else v = reinterpret_cast<const double2 *>(cand + b)[lane < 4 ? lane : lane - 1];
+      }
       reinterpret_cast<double2 *>(best_c + g)[lane] = v;
     } else if (lane == 7) {
       best_score[g] = (b >= 0) ? bs : 0.0;
     } else if (lane == 8) {
       int src_img = -1, src_line = -1;
       if (b >= 0) {
-        const CandLite l = lite[b];
-        src_img = lite_img(l);
-        src_line = l.ng_line;
+        const int2 l = *reinterpret_cast<const int2 *>(&cand[b].nb_slot);
+        src_img = (int)((unsigned)l.x >> 8);
+        src_line = l.y;
       }
       best_src2[2 * g] = src_img;
       best_src2[2 * g + 1] = src_line;
@@ -929,7 +930,7 @@ k_select(long long G, const long long *__restrict__ tri_off, const double *__res
 // valid edges of a node, in candidate order, at edge_off[g] (one wave per node)
 __global__ void __launch_bounds__(256)
 k_edge_fill(long long G, const long long *__restrict__ tri_off, const unsigned *__restrict__ edge_flag,
-            const long long *__restrict__ edge_off, const CandLite *__restrict__ lite,
+            const long long *__restrict__ edge_off, const CRec *__restrict__ cand,
             int *__restrict__ edges2, const unsigned *__restrict__ perm) {
   long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (g >= G) return;
@@ -944,9 +945,9 @@ k_edge_fill(long long G, const long long *__restrict__ tri_off, const unsigned *
     unsigned long long m = __ballot(f);
     if (f) {
       long long p = base + __popcll(m & lanemask_lt());
-      const CandLite l = lite[perm ? (long long)perm[off + i] : off + i];
-      edges2[2 * p] = lite_slot(l);
-      edges2[2 * p + 1] = l.ng_line;
+      const int2 l = *reinterpret_cast<const int2 *>(&cand[perm ? (long long)perm[off + i] : off + i].nb_slot);
+      edges2[2 * p] = l.x & 0xFF;
+      edges2[2 * p + 1] = l.y;
     }
     base += __popcll(m);
   }
@@ -1046,14 +1047,14 @@ void launch_gen_exhaustive(hipStream_t st, bool fill, long long n_items, const G
                            const long long *item_off, long long G, const int *node_img, const long long *nb_off,
                            const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
                            const PairRec *pairs, unsigned long long *masks, const long long *mask_pos,
-                           Cand *out_c, CandLite *out_l, const double *seg_vp, const unsigned char *seg_has_vp,
+                           CRec *out_r, double *out_unc, const double *seg_vp, const unsigned char *seg_has_vp,
                            const int *blk_chunk_off, int max_nb, int max_chunks, const void *gates_v) {
   if (n_items <= 0) return;
   const SegGate *gates = reinterpret_cast<const SegGate *>(gates_v);
   dim3 grid(nblk(G * (long long)max_nb * 64, 256)), block(256);  // one wave per (node, neighbour image)
 #define LT_LAUNCH_EX(FILL, VP)                                                                                       \
   hipLaunchKernelGGL((k_gen_ex_block<FILL, VP>), grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off, blk_nb, \
-                     seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l, seg_vp, seg_has_vp, blk_chunk_off, max_nb,  \
+                     seg_off, cams, segs, pairs, masks, mask_pos, out_r, out_unc, seg_vp, seg_has_vp, blk_chunk_off, max_nb,  \
                      gates)
   if (seg_vp) {
     if (!fill) LT_LAUNCH_EX(false, true); else LT_LAUNCH_EX(true, true);
@@ -1086,20 +1087,20 @@ void launch_tri_exhaustive(hipStream_t st, const unsigned long long *ent, const 
                            unsigned region_cap, const GenCfg &cfg, long long n_items, const long long *item_off,
                            const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
                            const Cam *cams, const Seg *segs, const PairRec *pairs, const int *blk_chunk_off,
-                           unsigned long long *masks, Cand *st_c, CandLite *st_l, unsigned *st_node, float *st_z) {
+                           unsigned long long *masks, CRec *st_r, double *st_unc, unsigned *st_node, float *st_z) {
   if (region_cap == 0) return;
   hipLaunchKernelGGL(k_tri_ex, dim3(nblk((long long)region_cap, 256), kExRegions), dim3(256), 0, st, ent, ctr, region_cap,
-                     cfg, n_items, item_off, blk_img, blk_nb, nb_off, seg_off, cams, segs, pairs, blk_chunk_off, masks, st_c,
-                     st_l, st_node, st_z);
+                     cfg, n_items, item_off, blk_img, blk_nb, nb_off, seg_off, cams, segs, pairs, blk_chunk_off, masks, st_r,
+                     st_unc, st_node, st_z);
 }
 // one-pass form: perm[final position] = staging slot, for every slot the regions handed out
-void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsigned region_cap, const CandLite *st_l,
+void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsigned region_cap, const CRec *st_r,
                              const unsigned *st_node, const int *node_img, const long long *nb_off,
                              const long long *item_off, const int *blk_chunk_off, const unsigned long long *masks,
                              const long long *mask_pos, long long n_items, const long long *tri_off, long long G,
                              unsigned *perm, long long *fill_out) {
   if (region_cap == 0) return;
-  hipLaunchKernelGGL(k_place_ex, dim3(nblk((long long)region_cap, 256), kExRegions), dim3(256), 0, st, ctr, region_cap, st_l,
+  hipLaunchKernelGGL(k_place_ex, dim3(nblk((long long)region_cap, 256), kExRegions), dim3(256), 0, st, ctr, region_cap, st_r,
                      st_node, node_img, nb_off, item_off, blk_chunk_off, masks, mask_pos, n_items, tri_off, G, perm,
                      fill_out);
 }
@@ -1107,17 +1108,17 @@ void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsi
 void launch_fill_exhaustive(hipStream_t st, int n_blk, long long n_items, const GenCfg &cfg, const long long *item_off,
                             const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
                             const Cam *cams, const Seg *segs, const PairRec *pairs, const unsigned long long *masks,
-                            const long long *mask_pos, Cand *out_c, CandLite *out_l, const int *blk_chunk_off) {
+                            const long long *mask_pos, CRec *out_r, double *out_unc, const int *blk_chunk_off) {
   if (n_items <= 0 || n_blk <= 0) return;
   const long long waves = (long long)n_blk * kFillParts;
   hipLaunchKernelGGL(k_fill_ex, dim3(nblk(waves * 64, 256)), dim3(256), 0, st, n_blk, n_items, cfg, item_off, blk_img,
-                     blk_nb, nb_off, seg_off, cams, segs, pairs, masks, mask_pos, out_c, out_l, blk_chunk_off);
+                     blk_nb, nb_off, seg_off, cams, segs, pairs, masks, mask_pos, out_r, out_unc, blk_chunk_off);
 }
 void launch_gen_exhaustive_pts(hipStream_t st, bool fill, long long n_items, const GenCfg &cfg,
                                const long long *item_off, long long G, const int *node_img, const long long *nb_off,
                                const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
                                const PairRec *pairs, unsigned char *cnt8, unsigned *item_cnt,
-                               const long long *mask_pos, Cand *out_c, CandLite *out_l, const double *seg_vp,
+                               const long long *mask_pos, CRec *out_r, double *out_unc, const double *seg_vp,
                                const unsigned char *seg_has_vp, const long long *seg_pt_off, const void *seg_pts,
                                const double *sfm_xyz, int *err_flag, int many_on, int one_on,
                                const int *blk_chunk_off, int max_nb, int max_chunks, const void *gates_v) {
@@ -1127,11 +1128,11 @@ void launch_gen_exhaustive_pts(hipStream_t st, bool fill, long long n_items, con
   const SegPoint *sp = reinterpret_cast<const SegPoint *>(seg_pts);
   if (!fill)
     hipLaunchKernelGGL((k_gen_exhaustive_pts<false>), grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off,
-                       blk_nb, seg_off, cams, segs, pairs, cnt8, item_cnt, mask_pos, out_c, out_l, seg_vp, seg_has_vp,
+                       blk_nb, seg_off, cams, segs, pairs, cnt8, item_cnt, mask_pos, out_r, out_unc, seg_vp, seg_has_vp,
                        seg_pt_off, sp, sfm_xyz, err_flag, many_on, one_on, blk_chunk_off, max_nb, max_chunks, gates);
   else
     hipLaunchKernelGGL((k_gen_exhaustive_pts<true>), grid, block, 0, st, n_items, cfg, item_off, G, node_img, nb_off,
-                       blk_nb, seg_off, cams, segs, pairs, cnt8, item_cnt, mask_pos, out_c, out_l, seg_vp, seg_has_vp,
+                       blk_nb, seg_off, cams, segs, pairs, cnt8, item_cnt, mask_pos, out_r, out_unc, seg_vp, seg_has_vp,
                        seg_pt_off, sp, sfm_xyz, err_flag, many_on, one_on, blk_chunk_off, max_nb, max_chunks, gates);
 }
 // n_masks ballots per item (3 with VP proposals)
@@ -1144,27 +1145,27 @@ void launch_tri_offsets_ex(hipStream_t st, long long G, const long long *item_of
                      total, cap, tri_off, err_flag);
 }
 void launch_select(hipStream_t st, long long G, const long long *tri_off, const double *score, double th,
-                   int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const Cand *cand,
-                   const CandLite *lite, Cand *best_c, double *best_score, int *best_src2, int *n_tris,
+                   int max_valid, long long *best_idx, unsigned *edge_flag, unsigned *n_valid, const CRec *cand,
+                   const double *cand_unc, Cand *best_c, double *best_score, int *best_src2, int *n_tris,
                    bool wide, const int *err_flag, const unsigned long long *pair_counter, long long *result3,
                    const unsigned *perm) {
   if (G > 0)
   {
     if (wide)
       hipLaunchKernelGGL(k_select<64>, dim3(nblk(G * 64, 256)), dim3(256), 0, st, G, tri_off, score, th, max_valid,
-                         best_idx, edge_flag, n_valid, cand, lite, best_c, best_score, best_src2, n_tris, err_flag,
+                         best_idx, edge_flag, n_valid, cand, cand_unc, best_c, best_score, best_src2, n_tris, err_flag,
                          pair_counter, result3, perm);
     else
       hipLaunchKernelGGL(k_select<16>, dim3(nblk(G * 16, 256)), dim3(256), 0, st, G, tri_off, score, th, max_valid,
-                         best_idx, edge_flag, n_valid, cand, lite, best_c, best_score, best_src2, n_tris, err_flag,
+                         best_idx, edge_flag, n_valid, cand, cand_unc, best_c, best_score, best_src2, n_tris, err_flag,
                          pair_counter, result3, perm);
   }
 }
 void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
-                      const long long *edge_off, const CandLite *lite, int *edges2, const unsigned *perm) {
+                      const long long *edge_off, const CRec *cand, int *edges2, const unsigned *perm) {
   if (G > 0)
     hipLaunchKernelGGL(k_edge_fill, dim3(nblk(G * 64, 256)), dim3(256), 0, st, G, tri_off, edge_flag, edge_off,
-                       lite, edges2, perm);
+                       cand, edges2, perm);
 }
 
 
@@ -1299,8 +1300,8 @@ __global__ void k_fn_query(const double *__restrict__ in, int by_endpoints, doub
     bool okd = dir_candidate(cfg0, c1, c2, s1, s2, pr.B, direction, &o);
     double *m = out + 30;
     if (okd) {
-      m[0] = o.c.s[0]; m[1] = o.c.s[1]; m[2] = o.c.s[2]; m[3] = o.c.e[0]; m[4] = o.c.e[1]; m[5] = o.c.e[2];
-      m[6] = o.c.depth[0]; m[7] = o.c.depth[1]; m[8] = -1.0; m[9] = 1.0;
+      m[0] = o.r.s[0]; m[1] = o.r.s[1]; m[2] = o.r.s[2]; m[3] = o.r.e[0]; m[4] = o.r.e[1]; m[5] = o.r.e[2];
+      m[6] = o.r.depth[0]; m[7] = o.r.depth[1]; m[8] = -1.0; m[9] = 1.0;
     } else {
       m[0] = m[1] = m[2] = 0.0; m[3] = m[4] = m[5] = 1.0;
       m[6] = m[7] = -1.0; m[8] = -1.0; m[9] = -1.0;
@@ -1310,8 +1311,8 @@ __global__ void k_fn_query(const double *__restrict__ in, int by_endpoints, doub
     const bool ok1 = one_point_candidate(cfg0, c1, c2, s1, s2, direction, &o1);
     m = out + 40;
     if (ok1) {
-      m[0] = o1.c.s[0]; m[1] = o1.c.s[1]; m[2] = o1.c.s[2]; m[3] = o1.c.e[0]; m[4] = o1.c.e[1]; m[5] = o1.c.e[2];
-      m[6] = o1.c.depth[0]; m[7] = o1.c.depth[1]; m[8] = -1.0; m[9] = 1.0;
+      m[0] = o1.r.s[0]; m[1] = o1.r.s[1]; m[2] = o1.r.s[2]; m[3] = o1.r.e[0]; m[4] = o1.r.e[1]; m[5] = o1.r.e[2];
+      m[6] = o1.r.depth[0]; m[7] = o1.r.depth[1]; m[8] = -1.0; m[9] = 1.0;
     } else {
       m[0] = m[1] = m[2] = 0.0; m[3] = m[4] = m[5] = 1.0;
       m[6] = m[7] = -1.0; m[8] = -1.0; m[9] = -1.0;

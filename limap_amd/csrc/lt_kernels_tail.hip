@@ -17,7 +17,7 @@ namespace lt {
 // directed valid edges of node g (candidate order, like k_edge_fill) -> undirected keys (min << kb | max)
 __global__ void __launch_bounds__(256)
 k_tail_keys(long long G, const long long *__restrict__ tri_off, const unsigned *__restrict__ edge_flag,
-            const long long *__restrict__ edge_off, const CandLite *__restrict__ lite,
+            const long long *__restrict__ edge_off, const CRec *__restrict__ cand,
             const long long *__restrict__ seg_off, int kb, unsigned long long *__restrict__ keys,
             const unsigned *__restrict__ perm) {
   const long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -32,8 +32,8 @@ k_tail_keys(long long G, const long long *__restrict__ tri_off, const unsigned *
     const bool f = (i < n) && edge_flag[off + i];
     const unsigned long long m = __ballot(f);
     if (f) {
-      const CandLite l = lite[perm ? (long long)perm[off + i] : off + i];
-      const unsigned long long h = (unsigned long long)(seg_off[lite_img(l)] + (long long)l.ng_line);
+      const int2 l = *reinterpret_cast<const int2 *>(&cand[perm ? (long long)perm[off + i] : off + i].nb_slot);
+      const unsigned long long h = (unsigned long long)(seg_off[(int)((unsigned)l.x >> 8)] + (long long)l.y);
       const unsigned long long a = (unsigned long long)g < h ? (unsigned long long)g : h;
       const unsigned long long b = (unsigned long long)g < h ? h : (unsigned long long)g;
       keys[base + __popcll(m & lanemask_lt())] = (a << kb) | b;  // kb = bits of a node index: fewer sort passes
@@ -131,11 +131,11 @@ size_t tail_sort_temp_bytes(long long E, int end_bit) {
 }
 
 void launch_tail_keys(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
-                      const long long *edge_off, const CandLite *lite, const long long *seg_off, int kb,
+                      const long long *edge_off, const CRec *cand, const long long *seg_off, int kb,
                       unsigned long long *keys, const unsigned *perm) {
   if (G > 0)
     hipLaunchKernelGGL(k_tail_keys, dim3((unsigned)((G * 64 + 255) / 256)), dim3(256), 0, st, G, tri_off, edge_flag,
-                       edge_off, lite, seg_off, kb, keys, perm);
+                       edge_off, cand, seg_off, kb, keys, perm);
 }
 
 int launch_tail_sort(hipStream_t st, void *temp, size_t temp_bytes, long long E, const unsigned long long *keys_in,

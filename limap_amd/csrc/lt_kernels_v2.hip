@@ -97,8 +97,8 @@ struct GenArgs {
   uint2 *st_row;          // [P] surviving rows of stage A, per-slot lists at the slot's first row:
                           // (line | undecided << 31, neighbour line)
   unsigned *surv_count;   // [n_blk * n_slots]
-  Cand *st_c;             // [P] valid candidates, per-slot lists at the slot's first row
-  CandLite *st_l;
+  CRec *st_r;             // [P] valid candidates, per-slot lists at the slot's first row
+  double *st_unc;         // their uncertainties
   unsigned *st_key;       // node id of every staged candidate
   unsigned *wave_count;   // [n_blk * n_slots]
   unsigned *cnt_bl;       // valid candidates per (block, line) or nullptr (generic path)
@@ -329,7 +329,7 @@ template <bool kExtra>
 __global__ void __launch_bounds__(256)
 k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec *__restrict__ pairs_r,
            const BlkRec *__restrict__ blk_r) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];  // per wave: 64 x (Cand | CandLite | key)
+  extern __shared__ __align__(16) unsigned char smem_raw[];  // per wave: 64 x (CRec | unc | key)
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
@@ -415,10 +415,10 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
             if (!store) {
               if (r) mask |= 1ull << idx;
             } else {
-              ov.l.nb_slot = lite_pack(nbslot, i2);
-              ov.l.ng_line = ng;
-              a.st_c[p] = ov.c;
-              a.st_l[p] = ov.l;
+              ov.r.nb_slot = lite_pack(nbslot, i2);
+              ov.r.ng_line = ng;
+              a.st_r[p] = ov.r;
+              a.st_unc[p] = ov.unc;
               a.st_key[p] = (unsigned)(g1 + line);
               ++p;
             }
@@ -455,8 +455,8 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
         if (len_ok && a.seg_vp && a.seg_has_vp[g1 + line]) okx[1] = extra(1, &tmp);
         if (len_ok && a.seg_vp && a.seg_has_vp[g2 + ng]) okx[2] = extra(2, &tmp);
       }
-      o.l.nb_slot = lite_pack(nbslot, i2);
-      o.l.ng_line = ng;
+      o.r.nb_slot = lite_pack(nbslot, i2);
+      o.r.ng_line = ng;
     }
     const unsigned long long m = __ballot(ok);
     unsigned below = (unsigned)__popcll(m & lanemask_lt());
@@ -486,18 +486,18 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
         if (okx[w]) {
           GenOut ov;
           (void)extra(w, &ov);
-          ov.l.nb_slot = lite_pack(nbslot, i2);
-          ov.l.ng_line = ng;
-          a.st_c[p] = ov.c;
-          a.st_l[p] = ov.l;
+          ov.r.nb_slot = lite_pack(nbslot, i2);
+          ov.r.ng_line = ng;
+          a.st_r[p] = ov.r;
+          a.st_unc[p] = ov.unc;
           a.st_key[p] = (unsigned)(g1 + line);
           ++p;
         }
       }
       if (a.cnt_bl && mine) atomicAdd(&a.cnt_bl[lbase + line], mine);
       if (ok) {
-        a.st_c[p] = o.c;
-        a.st_l[p] = o.l;
+        a.st_r[p] = o.r;
+        a.st_unc[p] = o.unc;
         a.st_key[p] = (unsigned)(g1 + line);
         if (a.cnt_bl) atomicAdd(&a.cnt_bl[lbase + line], 1u);
       }
@@ -505,27 +505,26 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
       // The batch's valid candidates go to a contiguous piece of the group's list: compact them through
       // LDS and write the piece with consecutive lanes on consecutive 16-byte units (a record-per-lane
       // store touches 64 cache lines per instruction).
-      static_assert(sizeof(Cand) == 7 * 16 && sizeof(CandLite) == 2 * 16, "record sizes in 16-byte units");
+      static_assert(sizeof(CRec) == 8 * 16, "record size in 16-byte units");
       double2 *Lc = reinterpret_cast<double2 *>(smem_raw) + (size_t)wave * (64 * 9 + 16);
-      double2 *Ll = Lc + 64 * 7;
-      unsigned *Lk = reinterpret_cast<unsigned *>(Ll + 64 * 2);
+      double *Lu = reinterpret_cast<double *>(Lc + 64 * 8);
+      unsigned *Lk = reinterpret_cast<unsigned *>(Lu + 64);
       if (ok) {
-        const double2 *oc = reinterpret_cast<const double2 *>(&o.c);
-        const double2 *ol = reinterpret_cast<const double2 *>(&o.l);
+        const double2 *oc = reinterpret_cast<const double2 *>(&o.r);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) Lc[below * 7 + k] = oc[k];
-        Ll[below * 2] = ol[0];
-        Ll[below * 2 + 1] = ol[1];
+        for (int k = 0; k < 8; ++k) Lc[below * 8 + k] = oc[k];
+        Lu[below] = o.unc;
         Lk[below] = (unsigned)(g1 + line);
         if (a.cnt_bl) atomicAdd(&a.cnt_bl[lbase + line], 1u);
       }
       wave_lds_sync();
       const long long p0 = out0 + wcount;
-      double2 *dc = reinterpret_cast<double2 *>(a.st_c + p0);
-      double2 *dl = reinterpret_cast<double2 *>(a.st_l + p0);
-      for (unsigned u = lane; u < total * 7u; u += 64) dc[u] = Lc[u];
-      for (unsigned u = lane; u < total * 2u; u += 64) dl[u] = Ll[u];
-      if ((unsigned)lane < total) a.st_key[p0 + lane] = Lk[lane];
+      double2 *dc = reinterpret_cast<double2 *>(a.st_r + p0);
+      for (unsigned u = lane; u < total * 8u; u += 64) dc[u] = Lc[u];
+      if ((unsigned)lane < total) {
+        a.st_unc[p0 + lane] = Lu[lane];
+        a.st_key[p0 + lane] = Lk[lane];
+      }
       wave_lds_sync();
     }
     wcount += total;
@@ -652,9 +651,9 @@ __global__ void __launch_bounds__(256)
 k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
         const long long *__restrict__ seg_off, const long long *__restrict__ blk_line_base,
         const unsigned *__restrict__ base_bl, const unsigned *__restrict__ wave_count,
-        const long long *__restrict__ tri_off, const Cand *__restrict__ st_c,
-        const CandLite *__restrict__ st_l, const unsigned *__restrict__ st_key, Cand *__restrict__ cand,
-        CandLite *__restrict__ lite, unsigned *__restrict__ cand_node, int n_groups, int mult,
+        const long long *__restrict__ tri_off, const CRec *__restrict__ st_r,
+        const double *__restrict__ st_unc, const unsigned *__restrict__ st_key, CRec *__restrict__ cand,
+        double *__restrict__ cand_unc, unsigned *__restrict__ cand_node, int n_groups, int mult,
         unsigned *__restrict__ perm) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
@@ -670,7 +669,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
   const long long g1 = seg_off[blk_img[b]];
   const long long lbase = blk_line_base[b];
   const long long s0 = r0 * mult;  // the group's first staging slot (mult slots per match row)
-  static_assert(sizeof(Cand) == 7 * 16 && sizeof(CandLite) == 2 * 16, "record sizes in 16-byte units");
+  static_assert(sizeof(CRec) == 8 * 16, "record size in 16-byte units");
   for (unsigned e0 = 0; e0 < count; e0 += 64) {
     const unsigned e = e0 + lane;
     const bool act = e < count;
@@ -728,24 +727,16 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
     // cache lines a record-per-lane copy would.
     if (perm) continue;
     const unsigned nb = min(64u, count - e0);
-    const double2 *src_c = reinterpret_cast<const double2 *>(st_c + s0 + e0);
+    const double2 *src_c = reinterpret_cast<const double2 *>(st_r + s0 + e0);
     double2 *dst_c = reinterpret_cast<double2 *>(cand);
 #pragma unroll
-    for (int it = 0; it < 7; ++it) {
+    for (int it = 0; it < 8; ++it) {
       const unsigned u = (unsigned)it * 64u + (unsigned)lane;
-      const unsigned ci = min(u / 7u, 63u), piece = u - (u / 7u) * 7u;
+      const unsigned ci = u >> 3, piece = u & 7u;
       const unsigned p = (unsigned)__shfl((int)pos32, (int)ci);
-      if (u < nb * 7u) dst_c[(size_t)p * 7u + piece] = src_c[u];
+      if (u < nb * 8u) dst_c[(size_t)p * 8u + piece] = src_c[u];
     }
-    const double2 *src_l = reinterpret_cast<const double2 *>(st_l + s0 + e0);
-    double2 *dst_l = reinterpret_cast<double2 *>(lite);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const unsigned u = (unsigned)it * 64u + (unsigned)lane;
-      const unsigned ci = u >> 1, piece = u & 1u;
-      const unsigned p = (unsigned)__shfl((int)pos32, (int)ci);
-      if (u < nb * 2u) dst_l[(size_t)p * 2u + piece] = src_l[u];
-    }
+    if (act) cand_unc[pos32] = st_unc[s0 + e];
   }
 }
 
@@ -773,14 +764,28 @@ k_pack_keys(const long long *__restrict__ m_off, const unsigned *__restrict__ wa
 
 // Generic path: gather the candidates into sorted (node-major, stable) order
 __global__ void k_permute(long long C, const unsigned *__restrict__ skeys, const unsigned *__restrict__ ssrc,
-                          const Cand *__restrict__ st_c, const CandLite *__restrict__ st_l,
-                          Cand *__restrict__ cand, CandLite *__restrict__ lite, unsigned *__restrict__ cand_node) {
+                          const CRec *__restrict__ st_r, const double *__restrict__ st_unc,
+                          CRec *__restrict__ cand, double *__restrict__ cand_unc, unsigned *__restrict__ cand_node) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= C) return;
   unsigned src = ssrc[t];
-  cand[t] = st_c[src];
-  lite[t] = st_l[src];
+  cand[t] = st_r[src];
+  cand_unc[t] = st_unc[src];
   cand_node[t] = skeys[t];
+}
+
+// The split host-side view of the candidates (debug read-outs): Cand / CandLite at position t from record
+// perm[t] (the staged records of the permutation-based store) or t (compact arrays).
+__global__ void k_host_view(long long C, const unsigned *__restrict__ perm, const CRec *__restrict__ rec,
+                            const double *__restrict__ unc, Cand *__restrict__ out_c, CandLite *__restrict__ out_l) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= C) return;
+  const long long src = perm ? (long long)perm[t] : t;
+  Cand c;
+  CandLite l;
+  crec_split(rec[src], unc[src], &c, &l);
+  out_c[t] = c;
+  out_l[t] = l;
 }
 
 // Also resets the tile draw counters of the persistent k_score3 that follows, and lists the tiles (64 consecutive
@@ -856,6 +861,7 @@ k_cand_node(long long G, const long long *__restrict__ tri_off, unsigned *__rest
 // are pushed (ballot + popcount) into an LDS queue and evaluated densely, one pair per lane; the
 // per-neighbour-image maxima live in LDS (ds_max_u64 on the bit pattern of the non-negative scores)
 // and are summed per lane in ascending image-id order (std::map order, :110-112).
+static __device__ __forceinline__ unsigned mt_key(long long off) { return (unsigned)off & 0xFFFFFFu; }
 constexpr int kSQCap = 512;  // the queue is drained when fewer than 256 (4 sweep iterations) slots are free
 constexpr int kWin = LT_SCORE_WIN;
 
@@ -863,8 +869,7 @@ struct Score3Args {
   long long G;
   const long long *tri_off;  // tri_off[G] = C
   const CandMeta *meta;
-  const Cand *cand;
-  const CandLite *lite;
+  const CRec *cand;
   const int *blk_order;
   const Cam *cams;
   double *score;
@@ -878,6 +883,7 @@ struct Score3Args {
   const unsigned *bucket_list;
   unsigned bucket_cap;
   int max_nb;
+  int *err_flag;  // device error flag of the run (6: k_score5's workgroup protocol failed)
 };
 
 // Depth order of a node's candidates (large nodes: exhaustive matching gives ~450 candidates per node and
@@ -931,7 +937,7 @@ static __device__ __forceinline__ void wave_bitonic(unsigned (&v)[R], int lane) 
 
 // sorts the node's (depth, index) words and leaves the sorted float keys in LDS (key[0..n)) and perm in HBM
 template <int R>
-static __device__ __forceinline__ bool depth_sort_node(const Cand *__restrict__ cand, long long off, int n, int lane,
+static __device__ __forceinline__ bool depth_sort_node(const CRec *__restrict__ cand, long long off, int n, int lane,
                                                        float *key, unsigned *__restrict__ perm,
                                                        const unsigned *__restrict__ place, unsigned *__restrict__ rec,
                                                        const float *__restrict__ st_z) {
@@ -968,7 +974,7 @@ static __device__ __forceinline__ bool depth_sort_node(const Cand *__restrict__ 
 }
 
 __global__ void __launch_bounds__(256)
-k_depth_order(long long G, const long long *__restrict__ tri_off, const Cand *__restrict__ cand, double guard,
+k_depth_order(long long G, const long long *__restrict__ tri_off, const CRec *__restrict__ cand, double guard,
               unsigned *__restrict__ perm, uint2 *__restrict__ rng, const unsigned *__restrict__ place,
               unsigned *__restrict__ rec, const float *__restrict__ st_z) {
   // place != nullptr: the records are staged (one-pass exhaustive mode), the candidate at natural position p is record
@@ -1132,10 +1138,9 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       }
       nb0 = (long long)(mt.nb >> 8);
       n_nb = (int)(mt.nb & 0xFFu);
-      const CandLite li = a.lite[i];
-      const Cand ci = a.cand[i];
-      dix = li.dir[0]; diy = li.dir[1]; diz = li.dir[2];
-      sloti = lite_slot(li);
+      const CRec &ci = a.cand[i];
+      dix = ci.dir[0]; diy = ci.dir[1]; diz = ci.dir[2];
+      sloti = crec_slot(ci);
       six = ci.s[0]; siy = ci.s[1]; siz = ci.s[2];
       eix = ci.e[0]; eiy = ci.e[1]; eiz = ci.e[2];
       // dist / (depth + eps) > th_scaleinv (1 + 1e-6) can never score >= score_th (line_dists.cc:55-60)
@@ -1186,15 +1191,15 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
           const long long jpos = woff[il] + (long long)(e & 0x3FFFFFFu);
           const long long j = kInd ? (long long)a.perm[jpos] : jpos;
           const long long ii = kInd ? (long long)a.perm[i0 + il] : i0 + il;
-          const Cand ci = a.cand[ii];
-          const CandLite li = a.lite[ii];
-          const CandLite lj = a.lite[j];
-          const Cand cj = a.cand[j];
+          const CRec &ci = a.cand[ii];
+          const CRec &cj = a.cand[j];
+          const int nbs_j = cj.nb_slot;
           const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
-                                       mk3(li.dir[0], li.dir[1], li.dir[2]), ci.depth[0], ci.depth[1],
+                                       mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
                                        mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
-                                       mk3(lj.dir[0], lj.dir[1], lj.dir[2]), cj.seg, a.cams[lite_img(lj)]);
-          if (sc > 0.0) atomicMax(&S[lite_slot(lj) * 64 + il], (unsigned long long)__double_as_longlong(sc));
+                                       mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg,
+                                       a.cams[(int)((unsigned)nbs_j >> 8)]);
+          if (sc > 0.0) atomicMax(&S[(nbs_j & 0xFF) * 64 + il], (unsigned long long)__double_as_longlong(sc));
         }
       }
       n_eval += (unsigned long long)qn;
@@ -1208,12 +1213,12 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       float rw = ri;
       for (int e = lane; e < wn; e += 64) {
         const long long src = kInd ? (long long)a.perm[wb + e] : wb + e;
-        const CandLite l = a.lite[src];
-        const Cand c = a.cand[src];
+        const CRec &c = a.cand[src];
+        const CRec &l = c;
         if (kF32) {
           const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
           const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
-          W4[3 * e + 0] = float4{(float)l.dir[0], (float)l.dir[1], (float)l.dir[2], __int_as_float(lite_slot(l))};
+          W4[3 * e + 0] = float4{(float)l.dir[0], (float)l.dir[1], (float)l.dir[2], __int_as_float(crec_slot(l))};
           W4[3 * e + 1] = float4{sx, ex, sy, ey};  // start / end interleaved: the sweep's packed-f32 operand pairs
           W4[3 * e + 2] = float4{sz, ez, 0.0f, 0.0f};
           rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
@@ -1221,7 +1226,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
           W[0 * kWin + e] = l.dir[0]; W[1 * kWin + e] = l.dir[1]; W[2 * kWin + e] = l.dir[2];
           W[3 * kWin + e] = c.s[0]; W[4 * kWin + e] = c.s[1]; W[5 * kWin + e] = c.s[2];
           W[6 * kWin + e] = c.e[0]; W[7 * kWin + e] = c.e[1]; W[8 * kWin + e] = c.e[2];
-          wslot[e] = lite_slot(l);
+          wslot[e] = crec_slot(l);
         }
       }
       float gsf = 0.0f, gef = 0.0f;
@@ -1331,6 +1336,718 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// HOT LOOP 2, current form for the natural candidate order (matched mode; also the unsorted exhaustive runs).
+// Same tiles, same draw queues, same per-image maxima and ordered sums as k_score3 above -- what changed is
+// where the time went there (two waves per SIMD waiting on dependent gathers):
+//   * one 128-byte CRec per candidate instead of Cand + CandLite through two dependent levels;
+//   * the window keeps, next to the sweep operands, each entry's record index and packed (image, slot), so a dense
+//     round reads queue -> window (LDS) and then issues its three gathers (record i, record j, camera K R t) at
+//     once: ONE global latency per round instead of three;
+//   * the sweep tests only the squared scale-invariant endpoint guards (the cosine guard rejected 2.5 % of what
+//     they let through and cost a quarter of the loop); "same node, other neighbour image" is one compare on a
+//     key (node start << 8 | slot), which also masks the lanes that ran past their node -- no range / self tests;
+//   * the queue is a ring of 16-bit entries drained in FULL rounds of 64 while the sweep runs (the partial round
+//     is paid once per tile, not once per drain);
+//   * LDS per wave 14.5 KB at 20 neighbours (S 10 KB + window 3.5 KB + queue 1 KB) and <= 168 registers:
+//     11 resident waves per CU instead of 8.
+// Conservative exactly like k_score3: a pair is dropped only when the double-precision guard certainly fails;
+// every pair that reaches pair_score is evaluated by the same function.  LT_TEST_SCORE_V3 runs k_score3.
+// ---------------------------------------------------------------------------------------------
+#ifndef LT_SCORE4_WIN
+#define LT_SCORE4_WIN 96
+#endif
+constexpr int kWin4 = LT_SCORE4_WIN;  // window entries per chunk (<= 252: 8-bit window index in the queue)
+constexpr int kQ4 = 512;              // ring capacity (entries), power of two, >= 256 + 4 * 64
+static_assert(kWin4 % 4 == 0 && kWin4 <= 252, "window size");
+#ifndef LT_SCORE4_RESIDENT
+#define LT_SCORE4_RESIDENT 12  // persistent single-wave workgroups per CU, if LDS and registers allow (168 registers: 3 per SIMD)
+#endif
+#ifdef LT_SCORE4_WAVES_PER_EU
+#define LT_SCORE4_OCC __attribute__((amdgpu_waves_per_eu(LT_SCORE4_WAVES_PER_EU, LT_SCORE4_WAVES_PER_EU)))
+#else
+#define LT_SCORE4_OCC
+#endif
+
+template <bool kPerm>
+__global__ void __launch_bounds__(64) LT_SCORE4_OCC
+k_score4(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x;
+  // LDS: WB float4[kWin4 + 4] (sx, ex, sy, ey) | WE float4[kWin4 + 4] (sz, ez, key, nb_slot) | WP u32[kWin4] |
+  //      Q u16[kQ4] | S u64[max_nb][64]
+  float4 *WB = reinterpret_cast<float4 *>(smem_raw);
+  float4 *WE = WB + (kWin4 + 4);
+  unsigned *WP = reinterpret_cast<unsigned *>(WE + (kWin4 + 4));
+  unsigned short *Q = reinterpret_cast<unsigned short *>(WP + kWin4);
+  unsigned long long *S = reinterpret_cast<unsigned long long *>(Q + kQ4);
+
+  const long long C = a.tri_off[a.G];
+  const unsigned n_tiles = (unsigned)((C + 63) >> 6);
+  int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
+  unsigned long long n_eval_total = 0;
+  unsigned k_raw = 0;
+  if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+  unsigned cls_cnt = 0, cls_incl = 0, q_tiles = 0;
+  auto load_classes = [&]() {
+    cls_cnt = lane < kTileBuckets ? a.bucket_cnt[(q * kTileBuckets + (kTileBuckets - 1 - lane)) * 32] : 0u;
+    cls_incl = cls_cnt;
+#pragma unroll
+    for (int d = 1; d < kTileBuckets; d <<= 1) {
+      const unsigned t = (unsigned)__shfl_up((int)cls_incl, d);
+      if (lane >= d) cls_incl += t;
+    }
+    q_tiles = (unsigned)__shfl((int)cls_incl, kTileBuckets - 1);
+  };
+  if (a.bucket_cnt) load_classes();
+  auto resolve = [&]() -> unsigned {  // tile of the pending draw, 0xFFFFFFFF when every queue is empty (see k_score3)
+    for (;;) {
+      const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
+      if (a.bucket_cnt && !a.tile_order) {
+        if (k < q_tiles) {
+          const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
+          const int bl = __builtin_ctzll(m);
+          const unsigned base = (unsigned)__shfl((int)(cls_incl - cls_cnt), bl);
+          return a.bucket_list[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
+        }
+      } else {
+        const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
+        if (e < n_tiles) return a.tile_order ? a.tile_order[e] : (unsigned)e;
+      }
+      if (++tried >= kTileQueues) return 0xFFFFFFFFu;
+      q = (q + 1) & (kTileQueues - 1);
+      if (a.bucket_cnt && !a.tile_order) load_classes();
+      if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+    }
+  };
+  unsigned tile = resolve();
+  while (tile != 0xFFFFFFFFu) {
+    if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+    const long long i0 = (long long)tile * 64;
+    const long long tpos = i0 + lane;
+    const bool active = tpos < C;
+    LT_TRACE_MARK(2, tile, 0);
+    long long off = 0, nb0 = 0;
+    int n = 0, n_nb = 0;
+    unsigned ri = 0;  // the lane's own record
+    if (active) {
+      const CandMeta mt = a.meta[tpos];
+      ri = kPerm ? a.perm[tpos] : (unsigned)tpos;
+      off = ((long long)mt.off_hi << 32) | (long long)mt.off_lo;
+      n = (int)mt.n;
+      nb0 = (long long)(mt.nb >> 8);
+      n_nb = (int)(mt.nb & 0xFFu);
+    }
+    // the window of the tile: the nodes of its first and last candidate, whole (positions ascend with the lanes)
+    const int last = 63 - __builtin_clzll(__ballot(active));
+    const long long lo = __shfl(off, 0);
+    const long long hi = __shfl(off + n, last);
+    double six = 0, siy = 0, siz = 0, eix = 0, eiy = 0, eiz = 0, gs = 0, ge = 0;
+    // Sentinel key of the tile: node part = (window start - 1) mod 2^24, which no node of the window has (a window is
+    // far shorter than 2^24 candidates); it ends every chunk and is the key of the idle lanes (x == 0: no match).
+    const unsigned key_sentinel = (((unsigned)lo - 1u) << 8) | 0xFFu;
+    unsigned keyi = key_sentinel;
+    if (active) {
+      const CRec &ci = a.cand[ri];
+      six = ci.s[0]; siy = ci.s[1]; siz = ci.s[2];
+      eix = ci.e[0]; eiy = ci.e[1]; eiz = ci.e[2];
+      // dist / (depth + eps) > th_scaleinv (1 + 1e-6) can never score >= score_th (line_dists.cc:55-60)
+      const double zs = ci.depth[0] + kEps, ze = ci.depth[1] + kEps;
+      gs = (zs > 0.0) ? sqrt(scaleinv_guard2 * zs * zs) : 1e150;  // odd depths: leave it to the exact path
+      ge = (ze > 0.0) ? sqrt(scaleinv_guard2 * ze * ze) : 1e150;
+      keyi = ((unsigned)mt_key(off) << 8) | (unsigned)(ci.nb_slot & 0xFF);
+    }
+    // summation order of the first lane's image in registers (lane r: r-th neighbour block in image-id order);
+    // lanes of another image read theirs from memory
+    const long long wave_nb0 = __shfl(nb0, 0);
+    const int wave_nnb = __shfl(n_nb, 0);
+    const int ordv = lane < wave_nnb ? a.blk_order[wave_nb0 + lane] : 0;
+    for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
+    // wave-local origin (the first lane's start point) and this lane's single-precision operands (start / end
+    // interleaved: the sweep's packed-f32 operand pairs)
+    const double ox = __shfl(six, 0), oy = __shfl(siy, 0), oz = __shfl(siz, 0);
+    const float sixf = (float)(six - ox), siyf = (float)(siy - oy), sizf = (float)(siz - oz);
+    const float eixf = (float)(eix - ox), eiyf = (float)(eiy - oy), eizf = (float)(eiz - oz);
+    float ri_mag = fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)), fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf)));
+    if (!active) ri_mag = 0.0f;
+    int qh = 0, qc = 0;  // ring: head, count (wave-uniform)
+    unsigned long long n_eval = 0;
+#ifdef LT_TRACE
+    unsigned long long tr_dense = 0, tr_rounds = 0;
+#endif
+
+    // one dense round: the (up to) 64 oldest queue entries, one pair per lane
+    auto round = [&]() {
+#ifdef LT_TRACE
+      const unsigned long long tr0 = wall_clock64();
+#endif
+      wave_lds_sync();
+      const int nr = qc < 64 ? qc : 64;
+      // (the owner's record index comes by a cross-lane read: done by all lanes, outside the branch)
+      const unsigned e = Q[(qh + lane) & (kQ4 - 1)];
+      const int il = (int)((e >> 8) & 63u), w = (int)(e & 0xFFu);
+      const unsigned irec = (unsigned)__shfl((int)ri, il);
+      if (lane < nr) {
+        const unsigned jrec = WP[w];
+        const int nbs_j = __float_as_int(WE[w].w);
+        const CRec &ci = a.cand[irec];
+        const CRec &cj = a.cand[jrec];
+        const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
+                                     mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
+                                     mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
+                                     mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg, a.cams[(int)((unsigned)nbs_j >> 8)]);
+        if (sc > 0.0) atomicMax(&S[(nbs_j & 0xFF) * 64 + il], (unsigned long long)__double_as_longlong(sc));
+      }
+      n_eval += (unsigned long long)nr;
+      qh = (qh + nr) & (kQ4 - 1);
+      qc -= nr;
+#ifdef LT_TRACE
+      wave_lds_sync();
+      tr_dense += wall_clock64() - tr0;
+      ++tr_rounds;
+#endif
+    };
+
+    for (long long wb = lo; wb < hi; wb += kWin4) {
+      wave_lds_sync();  // the previous chunk's readers are done (its queue entries were drained)
+      const int wn = (int)((hi - wb) < kWin4 ? (hi - wb) : kWin4);
+      float rw = ri_mag;
+      for (int e = lane; e < wn + 4; e += 64) {
+        if (e < wn) {
+          const long long pos = wb + e;
+          const unsigned pr = kPerm ? a.perm[pos] : (unsigned)pos;
+          const unsigned eoff = a.meta[pos].off_lo;
+          const CRec &c = a.cand[pr];
+          const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
+          const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
+          const int nbs = c.nb_slot;
+          WB[e] = float4{sx, ex, sy, ey};
+          WE[e] = float4{sz, ez, __uint_as_float((eoff << 8) | (unsigned)(nbs & 0xFF)), __int_as_float(nbs)};
+          WP[e] = pr;
+          rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
+        } else {
+          WE[e] = float4{0.0f, 0.0f, __uint_as_float(key_sentinel), 0.0f};  // every chunk ends in four sentinels
+        }
+      }
+      // R of the window -> this lane's single-precision distance guards (a NaN coordinate makes R NaN, the guards
+      // NaN and every comparison false: everything goes to the exact evaluation)
+      for (int d = 32; d >= 1; d >>= 1) {
+        const float o = __shfl_xor(rw, d);
+        rw = (o > rw || o != o) ? o : rw;
+      }
+      const double delta = 1e-6 * (double)rw;
+      const float gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
+      const float gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
+      wave_lds_sync();
+      if (wb == lo) { LT_TRACE_MARK(2, tile, 1); }
+      // this lane's sub-range of the window; past it the index is clamped onto the first entry behind the range --
+      // another node's candidate or a sentinel, never a key match
+      const long long jlo = off > wb ? off : wb;
+      const long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
+      const int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
+      int cmax = cnt;
+      for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d));
+      const int w0 = cnt > 0 ? (int)(jlo - wb) : wn;
+      const int wend = w0 + cnt;
+      // one loop, ONE instance of the dense round in the code: full rounds while the sweep runs and the ring is more
+      // than half full, then -- the entries index this chunk's window -- everything that is left
+      for (int t = 0;;) {
+        const bool swept = t >= cmax;
+        if (swept ? qc > 0 : qc > kQ4 - 256) {
+          round();
+          continue;
+        }
+        if (swept) break;
+        float4 B[4], E[4];
+        int wi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          wi[u] = min(w0 + t + u, wend);
+          B[u] = WB[wi[u]];
+          E[u] = WE[wi[u]];
+        }
+        bool pass[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          // (start, end) pairs: v_pk_add / v_pk_mul / v_pk_fma_f32 straight from the window's layout
+          const float ax = sixf - B[u].x, bx = eixf - B[u].y;
+          const float ay = siyf - B[u].z, by = eiyf - B[u].w;
+          const float az = sizf - E[u].x, bz = eizf - E[u].y;
+          const float ds2 = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
+          const float de2 = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
+          // same node and another neighbour image  <=>  0 < (key_j ^ key_i) < 256
+          const unsigned x = __float_as_uint(E[u].z) ^ keyi;
+          pass[u] = ((x - 1u) < 255u) & !(ds2 > gsf) & !(de2 > gef);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned long long m = __ballot(pass[u]);
+          if (m) {
+            if (pass[u])
+              Q[(qh + qc + __popcll(m & lanemask_lt())) & (kQ4 - 1)] = (unsigned short)(((unsigned)lane << 8) | (unsigned)wi[u]);
+            qc += __popcll(m);
+          }
+        }
+        t += 4;
+      }
+    }
+    LT_TRACE_MARK(2, tile, 2);
+    wave_lds_sync();
+    LT_TRACE_MARK(2, tile, 3);
+
+    {
+      double sum = 0.0;
+      const bool own = nb0 == wave_nb0;
+      int rmax = n_nb;
+      for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d));
+      for (int r = 0; r < rmax; ++r) {  // r is wave-uniform: the first image's order comes by readlane
+        const int k_own = __builtin_amdgcn_readlane(ordv, r);
+        if (r < n_nb) {
+          const int k = own ? k_own : a.blk_order[nb0 + r];
+          sum += __longlong_as_double((long long)S[k * 64 + lane]);
+        }
+      }
+      if (active) a.score[tpos] = sum;
+    }
+#ifdef LT_TRACE
+    if (lane == 0 && tile < 65536u) {
+      g_trace[3 * 4 * 65536 + 4 * tile + 0] = tr_dense;
+      g_trace[3 * 4 * 65536 + 4 * tile + 1] = tr_rounds;
+      g_trace[3 * 4 * 65536 + 4 * tile + 2] = n_eval;
+      g_trace[3 * 4 * 65536 + 4 * tile + 3] = wall_clock64();
+    }
+#endif
+    n_eval_total += n_eval;
+    wave_lds_sync();  // the tables are reused by the next tile
+    tile = resolve();
+  }
+  if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_score5: k_score4 with the dense evaluation POOLED per workgroup.  Four persistent waves per workgroup, each
+// drawing, staging and sweeping its own tiles exactly like k_score4 -- but the pairs that survive a sweep are
+// moved, 64 at a time, from the wave's private ring into one ring shared by the workgroup, and a dense round takes
+// the 64 oldest entries of THAT ring, whoever produced them (an entry names its producer: window, record indices
+// and the table S of the per-image maxima all live in the producer's part of the LDS).
+//   * one partial round per workgroup and quiet period instead of one per tile: k_score4 ran its rounds at 43 of
+//     64 lanes (the evaluation is 2/3 of the kernel's instructions);
+//   * a tile with many surviving pairs is evaluated by all four waves: tile times varied 11-80 us and set a tail
+//     of a quarter of the kernel; the unit that has to fit the tail is now a quarter as long.
+// Protocol (LDS atomics, workgroup scope; no workgroup barrier after the start):
+//   tail / head    reserved / claimed entries of the shared ring (monotone counters, ring index = counter mod kQ5)
+//   pend[w]        entries of wave w that were moved to the shared ring and are not evaluated yet; wave w restages
+//                  its window or sums its tile only at pend[w] == 0 (and evaluates rounds while it waits)
+//   an entry is written after its slot was reserved: a claimed slot is read in a (bounded) spin until it is valid and
+//   then reset.  Producers keep 512 slots clear of the head: more than the four rounds that can be in flight.
+//   A waiting wave takes a partial round only when nobody is sweeping or after a short patience.
+// Nothing here changes WHICH pairs are evaluated or how: pair_score on the same operands, maxima by ds_max_u64,
+// sums in image-id order by the tile's own wave.  LT_TEST_SCORE_V4 runs k_score4, LT_TEST_SCORE_V3 k_score3.
+// ---------------------------------------------------------------------------------------------
+constexpr int kQ5 = 2048;  // shared ring capacity (entries, power of two)
+struct Ctl5 {
+  unsigned tail, head, n_sweeping, n_active;
+  unsigned pend[4];
+  unsigned err;
+};
+static __device__ __forceinline__ unsigned lds_ld(unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __host__ __device__ inline size_t score5_wave_bytes(int max_nb) {
+  return (size_t)(kWin4 + 4) * 32 + (size_t)kWin4 * 4 + 64 * 4 + (size_t)kQ4 * 2 + (size_t)max_nb * 64 * 8;
+}
+
+template <bool kPerm>
+__global__ void __launch_bounds__(256)
+k_score5(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t per_wave = score5_wave_bytes(a.max_nb);
+  // per wave: WB float4[kWin4 + 4] | WE float4[kWin4 + 4] | WP u32[kWin4] | RI u32[64] | P u16[kQ4] | S u64[max_nb][64]
+  constexpr size_t oWE = (size_t)(kWin4 + 4) * 16, oWP = oWE * 2, oRI = oWP + (size_t)kWin4 * 4, oP = oRI + 64 * 4,
+                   oS = oP + (size_t)kQ4 * 2;
+  unsigned char *mine = smem_raw + (size_t)wv * per_wave;
+  float4 *WB = reinterpret_cast<float4 *>(mine);
+  float4 *WE = reinterpret_cast<float4 *>(mine + oWE);
+  unsigned *WP = reinterpret_cast<unsigned *>(mine + oWP);
+  unsigned *RI = reinterpret_cast<unsigned *>(mine + oRI);
+  unsigned short *P = reinterpret_cast<unsigned short *>(mine + oP);
+  unsigned long long *S = reinterpret_cast<unsigned long long *>(mine + oS);
+  unsigned short *Q = reinterpret_cast<unsigned short *>(smem_raw + 4 * per_wave);
+  Ctl5 *ctl = reinterpret_cast<Ctl5 *>(Q + kQ5);
+  for (int e = threadIdx.x; e < kQ5; e += 256) Q[e] = 0xFFFFu;
+  if (threadIdx.x == 0) {
+    ctl->tail = 0; ctl->head = 0; ctl->n_sweeping = 0; ctl->n_active = 4;
+    ctl->pend[0] = ctl->pend[1] = ctl->pend[2] = ctl->pend[3] = 0;
+    ctl->err = 0;
+  }
+  __syncthreads();
+
+  const long long C = a.tri_off[a.G];
+  const unsigned n_tiles = (unsigned)((C + 63) >> 6);
+  int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
+  unsigned long long n_eval_total = 0;
+  unsigned k_raw = 0;
+  if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+  unsigned cls_cnt = 0, cls_incl = 0, q_tiles = 0;
+  auto load_classes = [&]() {
+    cls_cnt = lane < kTileBuckets ? a.bucket_cnt[(q * kTileBuckets + (kTileBuckets - 1 - lane)) * 32] : 0u;
+    cls_incl = cls_cnt;
+#pragma unroll
+    for (int d = 1; d < kTileBuckets; d <<= 1) {
+      const unsigned t = (unsigned)__shfl_up((int)cls_incl, d);
+      if (lane >= d) cls_incl += t;
+    }
+    q_tiles = (unsigned)__shfl((int)cls_incl, kTileBuckets - 1);
+  };
+  if (a.bucket_cnt) load_classes();
+  auto resolve = [&]() -> unsigned {  // tile of the pending draw, 0xFFFFFFFF when every queue is empty (see k_score3)
+    for (;;) {
+      const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
+      if (a.bucket_cnt && !a.tile_order) {
+        if (k < q_tiles) {
+          const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
+          const int bl = __builtin_ctzll(m);
+          const unsigned base = (unsigned)__shfl((int)(cls_incl - cls_cnt), bl);
+          return a.bucket_list[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
+        }
+      } else {
+        const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
+        if (e < n_tiles) return a.tile_order ? a.tile_order[e] : (unsigned)e;
+      }
+      if (++tried >= kTileQueues) return 0xFFFFFFFFu;
+      q = (q + 1) & (kTileQueues - 1);
+      if (a.bucket_cnt && !a.tile_order) load_classes();
+      if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+    }
+  };
+
+  enum { kNext = 0, kQuiesceStage = 1, kSweep = 2, kQuiesceEnd = 3, kFinal = 4 };
+  int st = kNext;
+#ifdef LT_TRACE
+  unsigned long long tr_rounds = 0, tr_sleeps = 0, tr_tiles = 0, tr_dense = 0, tr_final0 = 0;
+  unsigned long long tr_acc[7] = {0, 0, 0, 0, 0, 0, 0};  // prologue, stage, sweep, flush, wait, (dense), sums
+  unsigned long long tr_last = wall_clock64();
+#define TR_ACC(k) { const unsigned long long now_ = wall_clock64(); tr_acc[k] += now_ - tr_last; tr_last = now_; }
+  const unsigned tr_id = blockIdx.x * 4 + wv;
+  LT_TRACE_MARK(2, tr_id, 0);
+#else
+#define TR_ACC(k)
+#endif
+  // tile state
+  long long tpos = 0, off = 0, nb0 = 0, lo = 0, hi = 0, wb = 0, wave_nb0 = 0;
+  int n = 0, n_nb = 0, ordv = 0;
+  bool active = false;
+  unsigned ri = 0, keyi = 0, key_sentinel = 0;
+  double ox = 0, oy = 0, oz = 0, gs = 0, ge = 0;
+  float sixf = 0, siyf = 0, sizf = 0, eixf = 0, eiyf = 0, eizf = 0, ri_mag = 0, gsf = 0, gef = 0;
+  // chunk state
+  int wn = 0, cmax = 0, w0 = 0, wend = 0, t = 0;
+  int qh = 0, qc = 0;  // private ring: head, count (wave-uniform)
+  int patience = 0;
+
+  // moves the (up to) 64 oldest private entries to the shared ring; false: no room there (evaluate a round first)
+  auto flush_block = [&]() -> bool {
+    unsigned base = 0;
+    const int nmove = qc < 64 ? qc : 64;
+    int ok = 0;
+    if (lane == 0) {
+      const unsigned hh = lds_ld(&ctl->head), tt = lds_ld(&ctl->tail);
+      if ((int)(tt - hh) <= kQ5 - 512 - 64) {
+        __hip_atomic_fetch_add(&ctl->pend[wv], (unsigned)nmove, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = __hip_atomic_fetch_add(&ctl->tail, (unsigned)nmove, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ok = 1;
+      }
+    }
+    ok = __builtin_amdgcn_readfirstlane(ok);
+    if (!ok) return false;
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    wave_lds_sync();  // the private entries are written
+    if (lane < nmove) {
+      const unsigned e = P[(qh + lane) & (kQ4 - 1)];
+      *reinterpret_cast<volatile unsigned short *>(&Q[(base + (unsigned)lane) & (kQ5 - 1)]) =
+          (unsigned short)(e | ((unsigned)wv << 14));
+    }
+    qh = (qh + nmove) & (kQ4 - 1);
+    qc -= nmove;
+    return true;
+  };
+
+  // (the pass counter bounds a protocol error to a wrong result + error flag instead of a hung device: a wave makes
+  // ~30 passes per tile; 2^22 is far beyond any real run)
+  for (unsigned pass_guard = 0;; ++pass_guard) {
+    if (pass_guard > (1u << 22)) {
+      ctl->err = 2;
+      break;
+    }
+    bool do_round = false;
+    if (st == kSweep) {
+      if (qc >= 64 || (t >= cmax && qc > 0)) {
+        const bool fl_ = flush_block();
+        TR_ACC(3);
+        if (fl_) continue;
+        do_round = true;
+      } else if (t >= cmax) {
+        if (lane == 0) __hip_atomic_fetch_sub(&ctl->n_sweeping, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        wb += kWin4;
+        st = wb < hi ? kQuiesceStage : kQuiesceEnd;
+        patience = 0;
+        continue;
+      } else {
+        float4 B[4], E[4];
+        int wi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          wi[u] = min(w0 + t + u, wend);
+          B[u] = WB[wi[u]];
+          E[u] = WE[wi[u]];
+        }
+        bool pass[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float ax = sixf - B[u].x, bx = eixf - B[u].y;
+          const float ay = siyf - B[u].z, by = eiyf - B[u].w;
+          const float az = sizf - E[u].x, bz = eizf - E[u].y;
+          const float ds2 = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
+          const float de2 = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
+          const unsigned x = __float_as_uint(E[u].z) ^ keyi;  // same node, another neighbour image: 0 < x < 256
+          pass[u] = ((x - 1u) < 255u) & !(ds2 > gsf) & !(de2 > gef);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned long long m = __ballot(pass[u]);
+          if (m) {
+            if (pass[u])
+              P[(qh + qc + __popcll(m & lanemask_lt())) & (kQ4 - 1)] = (unsigned short)(((unsigned)lane << 8) | (unsigned)wi[u]);
+            qc += __popcll(m);
+          }
+        }
+        t += 4;
+        TR_ACC(2);
+        continue;
+      }
+    } else if (st == kQuiesceStage || st == kQuiesceEnd) {
+      const unsigned mypend = (unsigned)__builtin_amdgcn_readfirstlane(
+          (int)__hip_atomic_load(&ctl->pend[wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (mypend != 0) {
+        do_round = true;
+      } else if (st == kQuiesceStage) {
+        // ---- stage the window chunk [wb, wb + wn) ----
+        wn = (int)((hi - wb) < kWin4 ? (hi - wb) : kWin4);
+        float rw = ri_mag;
+        for (int e = lane; e < wn + 4; e += 64) {
+          if (e < wn) {
+            const long long pos = wb + e;
+            const unsigned pr = kPerm ? a.perm[pos] : (unsigned)pos;
+            const unsigned eoff = a.meta[pos].off_lo;
+            const CRec &c = a.cand[pr];
+            const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
+            const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
+            const int nbs = c.nb_slot;
+            WB[e] = float4{sx, ex, sy, ey};
+            WE[e] = float4{sz, ez, __uint_as_float((eoff << 8) | (unsigned)(nbs & 0xFF)), __int_as_float(nbs)};
+            WP[e] = pr;
+            rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
+          } else {
+            WE[e] = float4{0.0f, 0.0f, __uint_as_float(key_sentinel), 0.0f};
+          }
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+          const float o = __shfl_xor(rw, d);
+          rw = (o > rw || o != o) ? o : rw;
+        }
+        const double delta = 1e-6 * (double)rw;
+        gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
+        gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
+        const long long jlo = off > wb ? off : wb;
+        const long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
+        const int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
+        cmax = cnt;
+        for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d));
+        w0 = cnt > 0 ? (int)(jlo - wb) : wn;
+        wend = w0 + cnt;
+        t = 0;
+        if (lane == 0) __hip_atomic_fetch_add(&ctl->n_sweeping, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        wave_lds_sync();
+        st = kSweep;
+        TR_ACC(1);
+        continue;
+      } else {
+        // ---- the tile's ordered sums (every pair of the tile has been evaluated: pend == 0) ----
+        double sum = 0.0;
+        const bool own = nb0 == wave_nb0;
+        int rmax = n_nb;
+        for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d));
+        for (int r = 0; r < rmax; ++r) {
+          const int k_own = __builtin_amdgcn_readlane(ordv, r);
+          if (r < n_nb) {
+            const int k = own ? k_own : a.blk_order[nb0 + r];
+            sum += __longlong_as_double((long long)S[k * 64 + lane]);
+          }
+        }
+        if (active) a.score[tpos] = sum;
+        wave_lds_sync();
+        st = kNext;
+        TR_ACC(6);
+        continue;
+      }
+    } else if (st == kNext) {
+      const unsigned tile = resolve();
+      if (tile == 0xFFFFFFFFu) {
+        if (lane == 0) __hip_atomic_fetch_sub(&ctl->n_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        st = kFinal;
+        patience = 0;
+#ifdef LT_TRACE
+        tr_final0 = wall_clock64();
+#endif
+        continue;
+      }
+      if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+#ifdef LT_TRACE
+      ++tr_tiles;
+#endif
+      tpos = (long long)tile * 64 + lane;
+      active = tpos < C;
+      off = 0; nb0 = 0; n = 0; n_nb = 0; ri = 0;
+      if (active) {
+        const CandMeta mt = a.meta[tpos];
+        ri = kPerm ? a.perm[tpos] : (unsigned)tpos;
+        off = ((long long)mt.off_hi << 32) | (long long)mt.off_lo;
+        n = (int)mt.n;
+        nb0 = (long long)(mt.nb >> 8);
+        n_nb = (int)(mt.nb & 0xFFu);
+      }
+      const int last = 63 - __builtin_clzll(__ballot(active));
+      lo = __shfl(off, 0);
+      hi = __shfl(off + n, last);
+      key_sentinel = (((unsigned)lo - 1u) << 8) | 0xFFu;
+      keyi = key_sentinel;
+      double six = 0, siy = 0, siz = 0, eix = 0, eiy = 0, eiz = 0;
+      gs = 0; ge = 0;
+      if (active) {
+        const CRec &ci = a.cand[ri];
+        six = ci.s[0]; siy = ci.s[1]; siz = ci.s[2];
+        eix = ci.e[0]; eiy = ci.e[1]; eiz = ci.e[2];
+        const double zs = ci.depth[0] + kEps, ze = ci.depth[1] + kEps;
+        gs = (zs > 0.0) ? sqrt(scaleinv_guard2 * zs * zs) : 1e150;
+        ge = (ze > 0.0) ? sqrt(scaleinv_guard2 * ze * ze) : 1e150;
+        keyi = ((unsigned)mt_key(off) << 8) | (unsigned)(ci.nb_slot & 0xFF);
+      }
+      RI[lane] = ri;
+      wave_nb0 = __shfl(nb0, 0);
+      const int wave_nnb = __shfl(n_nb, 0);
+      ordv = lane < wave_nnb ? a.blk_order[wave_nb0 + lane] : 0;
+      for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
+      ox = __shfl(six, 0); oy = __shfl(siy, 0); oz = __shfl(siz, 0);
+      sixf = (float)(six - ox); siyf = (float)(siy - oy); sizf = (float)(siz - oz);
+      eixf = (float)(eix - ox); eiyf = (float)(eiy - oy); eizf = (float)(eiz - oz);
+      ri_mag = fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)), fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf)));
+      if (!active) ri_mag = 0.0f;
+      wb = lo;
+      st = kQuiesceStage;  // pend[wv] == 0 here: the previous tile was summed
+      patience = 0;
+      TR_ACC(0);
+      continue;
+    } else {  // kFinal: no tiles left for this wave; help until the workgroup is done
+      unsigned done = 0;
+      if (lane == 0)
+        done = (lds_ld(&ctl->n_active) == 0u && lds_ld(&ctl->head) == lds_ld(&ctl->tail)) ? 1u : 0u;
+      if (__builtin_amdgcn_readfirstlane((int)done)) break;
+      do_round = true;
+    }
+    if (!do_round) continue;
+
+    // ---- one dense round from the shared ring (the only instance of the evaluation in the kernel) ----
+    unsigned h = 0;
+    int take = 0;
+    if (lane == 0) {
+      const unsigned hh = lds_ld(&ctl->head), tt = lds_ld(&ctl->tail);
+      const int avail = (int)(tt - hh);
+      // a partial round only when nobody is sweeping (nothing will fill it up soon), when the producer itself is
+      // blocked on the ring (kSweep), or when the wait has lasted
+      const bool partial_ok = st == kSweep || lds_ld(&ctl->n_sweeping) == 0u || patience > 24;
+      const int want = avail >= 64 ? 64 : (partial_ok ? avail : 0);
+      if (want > 0) {
+        unsigned expect = hh;
+        if (__hip_atomic_compare_exchange_strong(&ctl->head, &expect, hh + (unsigned)want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          h = hh;
+          take = want;
+        }
+      }
+    }
+    h = (unsigned)__builtin_amdgcn_readfirstlane((int)h);
+    take = __builtin_amdgcn_readfirstlane(take);
+    if (take == 0) {
+      ++patience;
+#ifdef LT_TRACE
+      ++tr_sleeps;
+#endif
+      __builtin_amdgcn_s_sleep(2);
+      TR_ACC(4);
+      continue;
+    }
+    patience = 0;
+#ifdef LT_TRACE
+    ++tr_rounds;
+    const unsigned long long tr0 = wall_clock64();
+#endif
+    unsigned e = 0xFFFFu;
+    if (lane < take) {
+      volatile unsigned short *slot = reinterpret_cast<volatile unsigned short *>(&Q[(h + (unsigned)lane) & (kQ5 - 1)]);
+      int spins = 0;
+      do {
+        e = *slot;
+      } while (e == 0xFFFFu && ++spins < (1 << 22));
+      if (e == 0xFFFFu) ctl->err = 1;  // cannot happen: the producer writes its slots right after reserving them
+      *slot = 0xFFFFu;
+    }
+    const int ew = (int)(e >> 14), il = (int)((e >> 8) & 63u), w = (int)(e & 0xFFu);
+    const bool valid = lane < take && e != 0xFFFFu;
+    if (valid) {
+      unsigned char *theirs = smem_raw + (size_t)ew * per_wave;
+      const unsigned jrec = reinterpret_cast<const unsigned *>(theirs + oWP)[w];
+      const int nbs_j = __float_as_int(reinterpret_cast<const float4 *>(theirs + oWE)[w].w);
+      const unsigned irec = reinterpret_cast<const unsigned *>(theirs + oRI)[il];
+      const CRec &ci = a.cand[irec];
+      const CRec &cj = a.cand[jrec];
+      const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
+                                   mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
+                                   mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
+                                   mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg, a.cams[(int)((unsigned)nbs_j >> 8)]);
+      if (sc > 0.0)
+        atomicMax(&reinterpret_cast<unsigned long long *>(theirs + oS)[(nbs_j & 0xFF) * 64 + il],
+                  (unsigned long long)__double_as_longlong(sc));
+    }
+    n_eval_total += (unsigned long long)take;
+    // the producers' outstanding counts: behind the maxima (DS operations of a wave execute in order)
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const int c = __popcll(__ballot(lane < take && ew == w2));
+      if (c && lane == 0)
+        __hip_atomic_fetch_sub(&ctl->pend[w2], (unsigned)c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#ifdef LT_TRACE
+    tr_dense += wall_clock64() - tr0;
+#endif
+    TR_ACC(5);
+  }
+#ifdef LT_TRACE
+  if (lane == 0 && tr_id < 65536u) {
+    g_trace[2 * 4 * 65536 + 4 * tr_id + 1] = tr_final0;
+    g_trace[2 * 4 * 65536 + 4 * tr_id + 3] = wall_clock64();
+    g_trace[3 * 4 * 65536 + 4 * tr_id + 0] = tr_dense;
+    g_trace[3 * 4 * 65536 + 4 * tr_id + 1] = tr_rounds;
+    g_trace[3 * 4 * 65536 + 4 * tr_id + 2] = n_eval_total;
+    g_trace[3 * 4 * 65536 + 4 * tr_id + 3] = tr_sleeps | (tr_tiles << 32);
+    for (int k = 0; k < 7; ++k) g_trace[(k < 4 ? 0 : 1) * 4 * 65536 + 4 * tr_id + (k & 3)] = tr_acc[k];
+  }
+#endif
+  if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
+  if (lane == 0 && a.err_flag && lds_ld(&ctl->err) != 0u) *a.err_flag = 6;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
 static inline unsigned nblk2(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
@@ -1361,7 +2078,7 @@ void launch_build_blk(hipStream_t st, int n_blk, const long long *m_off, const i
 void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCfg &cfg, const long long *m_off,
                       const int *m_pairs, const int *blk_img, const int *blk_nb, const int *blk_slot,
                       const long long *seg_off, const Cam *cams, const Seg *segs, const PairRec *pairs,
-                      const long long *blk_line_base, Cand *st_c, CandLite *st_l, unsigned *st_key,
+                      const long long *blk_line_base, CRec *st_r, double *st_unc, unsigned *st_key,
                       unsigned *wave_count, unsigned *cnt_bl, int lds_segs, int lds_segs1, void *st_row,
                       unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3,
                       const double *seg_vp, const unsigned char *seg_has_vp, const long long *seg_pt_off,
@@ -1381,7 +2098,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   a.m_off = m_off; a.m_pairs = m_pairs; a.blk_img = blk_img; a.blk_nb = blk_nb; a.blk_slot = blk_slot;
   a.seg_off = seg_off; a.cams = cams; a.segs = segs; a.gates = reinterpret_cast<const SegGate *>(gates);
   a.pairs = pairs; a.blk_line_base = blk_line_base; a.st_row = reinterpret_cast<uint2 *>(st_row); a.surv_count = surv_count;
-  a.st_c = st_c; a.st_l = st_l; a.st_key = st_key; a.wave_count = wave_count; a.cnt_bl = cnt_bl;
+  a.st_r = st_r; a.st_unc = st_unc; a.st_key = st_key; a.wave_count = wave_count; a.cnt_bl = cnt_bl;
   a.n_slots = gen_slots(max_rows); a.lds_segs = lds_segs; a.lds_segs1 = lds_segs1;
   a.seg_vp = seg_vp; a.seg_has_vp = seg_has_vp;
   a.seg_pt_off = seg_pt_off; a.seg_pts = reinterpret_cast<const SegPoint *>(seg_pts); a.sfm_xyz = sfm_xyz;
@@ -1422,12 +2139,12 @@ void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const 
 }
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
-                  const unsigned *wave_count, const long long *tri_off, const Cand *st_c, const CandLite *st_l,
-                  const unsigned *st_key, Cand *cand, CandLite *lite, unsigned *cand_node, int mult, unsigned *perm) {
+                  const unsigned *wave_count, const long long *tri_off, const CRec *st_r, const double *st_unc,
+                  const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, int mult, unsigned *perm) {
   if (n_blk <= 0 || max_rows <= 0) return;
   const int n_groups = gen_groups(max_rows);
   hipLaunchKernelGGL(k_place, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
-                     blk_line_base, base_bl, wave_count, tri_off, st_c, st_l, st_key, cand, lite, cand_node, n_groups,
+                     blk_line_base, base_bl, wave_count, tri_off, st_r, st_unc, st_key, cand, cand_unc, cand_node, n_groups,
                      mult, perm);
 }
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
@@ -1438,11 +2155,15 @@ void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long 
   hipLaunchKernelGGL(k_pack_keys, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, wave_count, wave_pos,
                      st_key, keys_c, src_c, n_groups, mult);
 }
-void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const Cand *st_c,
-                    const CandLite *st_l, Cand *cand, CandLite *lite, unsigned *cand_node) {
+void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const CRec *st_r,
+                    const double *st_unc, CRec *cand, double *cand_unc, unsigned *cand_node) {
   if (C > 0)
-    hipLaunchKernelGGL(k_permute, dim3(nblk2(C, 256)), dim3(256), 0, st, C, skeys, ssrc, st_c, st_l, cand, lite,
+    hipLaunchKernelGGL(k_permute, dim3(nblk2(C, 256)), dim3(256), 0, st, C, skeys, ssrc, st_r, st_unc, cand, cand_unc,
                        cand_node);
+}
+void launch_host_view(hipStream_t st, long long C, const unsigned *perm, const CRec *rec, const double *unc, Cand *out_c,
+                      CandLite *out_l) {
+  if (C > 0) hipLaunchKernelGGL(k_host_view, dim3(nblk2(C, 256)), dim3(256), 0, st, C, perm, rec, unc, out_c, out_l);
 }
 void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, unsigned *cand_node) {
   if (G > 0)
@@ -1452,18 +2173,25 @@ size_t score3_lds_bytes(int max_nb, bool f32) {
   const size_t base = (f32 ? (size_t)kWin * 48 : (size_t)9 * kWin * 8 + (size_t)kWin * 4) + 64 * 8 + kSQCap * 4;
   return ((base + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
 }
+size_t score4_lds_bytes(int max_nb) {
+  return (size_t)(kWin4 + 4) * 32 + (size_t)kWin4 * 4 + (size_t)kQ4 * 2 + (size_t)max_nb * 64 * 8;
+}
+#ifndef LT_SCORE5_RESIDENT
+#define LT_SCORE5_RESIDENT 2  // persistent 4-wave workgroups per CU (two waves per SIMD at <= 256 registers)
+#endif
+size_t score5_lds_bytes(int max_nb) { return 4 * score5_wave_bytes(max_nb) + (size_t)kQ5 * 2 + sizeof(Ctl5) + 28; }
 size_t cand_meta_bytes() { return sizeof(CandMeta); }
 int score3_tile_buckets() { return kTileBuckets * kTileQueues; }  // counters (128 B apart) / lists: one per (queue, class)
 // (A two-kernel form -- light sweep writing per-tile pair lists, then a dense evaluation kernel -- was
 // measured: the sweep alone takes 53 us, but the evaluation does not get cheaper and the two phases no
 // longer overlap across waves: 165+ us against 150 us fused.)
 void launch_score3(hipStream_t st, long long C, long long G, const long long *tri_off, const unsigned *cand_node,
-                   void *meta, const Cand *cand, const CandLite *lite, const int *node_img, const long long *nb_off,
+                   void *meta, const CRec *cand, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
                    unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap, const unsigned *place,
-                   unsigned *rec, const float *st_z) {
+                   unsigned *rec, const float *st_z, int *err_flag) {
   // place / rec: depth-sorted sweep over STAGED records (one-pass exhaustive mode): place[natural position] = record,
   // rec (scratch, one word per candidate) receives the record of every sorted position
   if (C <= 0) return;
@@ -1480,7 +2208,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                      cand_node, tri_off, node_img, nb_off, reinterpret_cast<CandMeta *>(meta), draw, bucket_cnt, bucket_list,
                      bucket_cap);
   Score3Args a;
-  a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand; a.lite = lite;
+  a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand;
   a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
   a.draw = draw;
   a.perm = perm; a.rng = reinterpret_cast<const uint2 *>(rng);
@@ -1488,6 +2216,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.tile_order = tile_order;
   a.bucket_cnt = bucket_cnt; a.bucket_list = bucket_list; a.bucket_cap = bucket_cap;
   a.max_nb = max_nb;
+  a.err_flag = err_flag;
   if (ev_before) (void)hipEventRecord(ev_before, st);
   const bool sorted = perm != nullptr && f32 && !perm_is_placement;
   if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
@@ -1497,6 +2226,25 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   if (sorted && place) {
     a.perm = rec;
     a.spos = perm;
+  }
+  // the natural order (no depth sort): k_score4; LT_TEST_SCORE_V3 keeps k_score3 for it, LT_TEST_SCORE_F64 implies that
+  static const bool force_v3 = getenv("LT_TEST_SCORE_V3") != nullptr;
+  static const bool force_v4 = getenv("LT_TEST_SCORE_V4") != nullptr;
+  if (f32 && !sorted && !force_v3 && !force_v4 && max_nb <= 255 && score5_lds_bytes(max_nb) <= 160 * 1024) {
+    const size_t lds5 = score5_lds_bytes(max_nb);
+    const long long per_cu5 = std::max<long long>(1, std::min<long long>(LT_SCORE5_RESIDENT, (long long)(160 * 1024 / lds5)));
+    const dim3 grid5((unsigned)std::min<long long>((n_tiles + 3) / 4, per_cu5 * n_cu)), block5(256);
+    if (perm_is_placement) hipLaunchKernelGGL((k_score5<true>), grid5, block5, lds5, st, a, cfg, scaleinv_guard2);
+    else hipLaunchKernelGGL((k_score5<false>), grid5, block5, lds5, st, a, cfg, scaleinv_guard2);
+    return;
+  }
+  if (f32 && !sorted && !force_v3 && max_nb <= 255) {
+    const size_t lds4 = score4_lds_bytes(max_nb);
+    const long long per_cu4 = std::max<long long>(1, std::min<long long>(LT_SCORE4_RESIDENT, (long long)(160 * 1024 / lds4)));
+    const dim3 grid4((unsigned)std::min<long long>(n_tiles, per_cu4 * n_cu)), block4(64);
+    if (perm_is_placement) hipLaunchKernelGGL((k_score4<true>), grid4, block4, lds4, st, a, cfg, scaleinv_guard2);
+    else hipLaunchKernelGGL((k_score4<false>), grid4, block4, lds4, st, a, cfg, scaleinv_guard2);
+    return;
   }
   // persistent grid: as many single-wave workgroups as fit at once (LDS; registers allow LT_SCORE_RESIDENT per CU)
   const size_t lds = score3_lds_bytes(max_nb, f32);

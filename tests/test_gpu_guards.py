@@ -182,7 +182,9 @@ def test_single_precision_sweep_is_conservative(gpu_lib, clean_env, exhaustive):
         assert base[5]["candidates"] > 0
         # the float guards pass a superset of what the double guards pass, both a subset of everything
         assert outs["LT_TEST_SCORE_F64"][4]["pairs_eval"] <= base[4]["pairs_eval"] <= outs["LT_TEST_NO_SCORE_GUARDS"][4]["pairs_eval"]
-        assert base[4]["pairs_eval"] <= 1.01 * outs["LT_TEST_SCORE_F64"][4]["pairs_eval"] + 64
+        # (k_score4 sweeps on the endpoint-distance guards only; k_score3's cosine guard -- the double-precision sweep
+        # keeps it -- rejects a further ~2.5 % of the pairs before the exact evaluation does)
+        assert base[4]["pairs_eval"] <= 1.10 * outs["LT_TEST_SCORE_F64"][4]["pairs_eval"] + 64
 
 
 def test_candidate_count_stays_on_device(gpu_lib, clean_env):
