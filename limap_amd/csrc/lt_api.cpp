@@ -70,7 +70,8 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
                    unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap, const unsigned *place,
-                   unsigned *rec, const float *st_z, int *err_flag);
+                   unsigned *rec, const float *st_z, int *err_flag, void *split_pairs, unsigned *split_tile_head,
+                   unsigned *split_counters, unsigned split_region_cap, void *split_tile_lohi);
 int score3_tile_buckets();
 }
 
@@ -611,6 +612,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_keys, &ctx->d_rows, &ctx->d_row_blk, &ctx->d_skeys, &ctx->d_srows, &ctx->d_sort_tmp,
                     &ctx->d_conn_off, &ctx->d_st_c, &ctx->d_st_l, &ctx->d_flags, &ctx->d_pos, &ctx->d_scan_tmp,
                     &ctx->d_item_off, &ctx->d_masks, &ctx->d_mask_cnt, &ctx->d_mask_pos, &ctx->d_cand, &ctx->d_hcand, &ctx->d_hlite,
+                    &ctx->d_split_pairs, &ctx->d_split_segs, &ctx->d_split_head, &ctx->d_split_tot,
                     &ctx->d_lite, &ctx->d_tri_off, &ctx->d_score, &ctx->d_best_idx, &ctx->d_edge_flag,
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
@@ -1287,7 +1289,15 @@ int finish_run(lt_ctx *ctx) {
     ctx->ex_two_pass = false;
   }
   if (derr == 4) return fail(ctx, LT_ERR_RUNTIME, "internal: the scan of the node counts did not complete");
-  if (derr == 6) return fail(ctx, LT_ERR_RUNTIME, "internal: the scoring kernel's workgroup queue protocol failed");
+  if (derr == 7) {
+    // the pair list of the three-kernel scoring did not hold: repeat the run with the fused kernel (same results)
+    if (ctx->score_split_off) return fail(ctx, LT_ERR_RUNTIME, "internal: pair list overflow with the fused scoring kernel");
+    ctx->score_split_off = true;
+    if (ctx->in_run_async) return LT_OK;
+    int rc2 = lt_run_device_async(ctx);
+    if (!rc2) rc2 = finish_run(ctx);
+    return rc2;
+  }
   if (derr == 3)
     return fail(ctx, LT_ERR_RUNTIME, "the one-point proposal supports at most 64 shared points per connection");
   if (derr == 2)
@@ -1751,7 +1761,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     if (ctx->h_nb_off[ctx->n_img] >= (1ll << 24))
       return fail(ctx, LT_ERR_ARGUMENT, "too many (image, neighbour) blocks in one batch (>= 2^24)");
     ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_bound, 1));
-    ENSURE(ctx, ctx->d_tile_order, 1024);  // the tile draw counters of k_score3 (8 x 128 B)
+    ENSURE(ctx, ctx->d_tile_order, 64 * 128);  // the tile draw counters of k_score3 (8 x 128 B)
     // tiles listed by cost class (LT_TEST_NO_TILE_CLASSES: natural tile order)
     // (matched mode only: the wide nodes of the exhaustive mode put every tile into the top class, whose one counter
     // per queue then serialises ~4e4 appends -- k_cand_meta 0.11 -> 0.50 ms -- for an order that changes nothing)
@@ -1767,6 +1777,25 @@ int lt_run_device_async(lt_ctx *ctx) {
     // depth-sorted sweep over the staged records of the one-pass exhaustive mode: see k_depth_order
     const bool staged_sorted = score_sorted && ctx->perm_mode && ctx->job_mode == 2;
     C_run = C_bound;  // replaced by the exact count when that arrives with the error flag (finish_run)
+    // LT_SCORE_SPLIT: the three-kernel scoring (k_sweep6 / k_eval6 / k_reduce6) and its pair list -- capacity from the
+    // candidate bound; a run that overflows it (device flag 7) is repeated with the fused kernel by finish_run
+    unsigned split_region_cap = 0;
+    long long split_tiles_b = 0;  // d_split_head = [tiles] window bounds (8 B) | [tiles] newest segment + count (8 B)
+    const bool split = score_f32 && !score_sorted && !ctx->score_split_off && getenv("LT_SCORE_SPLIT") != nullptr;
+    if (split) {
+      const long long tiles_b = (std::max<long long>(C_bound, 1) + 63) / 64;
+      split_tiles_b = tiles_b;
+      long long pc = std::min<long long>(std::max<long long>(2 * C_bound, 4ll << 20), (1ll << 31) - 64);
+      if (const char *e = getenv("LT_TEST_SPLIT_PAIR_CAP")) pc = std::max<long long>(64, atoll(e));  // test: force an overflow
+      // 64 regions (one bump counter each); a record is a pair or a segment header
+      const long long rcap = (pc + tiles_b * 2 + 63) / 64;
+      if (ctx->d_split_pairs.ensure(16 * (size_t)rcap * 64) && ctx->d_split_head.ensure(16 * (size_t)tiles_b + 16) &&
+          ctx->d_split_tot.ensure(64 * 128)) {
+        split_region_cap = (unsigned)rcap;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     launch_score3(st, C_bound, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
                   ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(), ctx->d_node_img.as<int>(),
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
@@ -1781,7 +1810,11 @@ int lt_run_device_async(lt_ctx *ctx) {
                   tile_classes ? ctx->d_tile_list.as<unsigned>() : nullptr, tile_cap,
                   staged_sorted ? ctx->d_place_perm.as<unsigned>() : nullptr,
                   staged_sorted ? ctx->d_ex_rec.as<unsigned>() : nullptr,
-                  staged_sorted ? ctx->d_ex_z.as<float>() : nullptr, ctx->d_err.as<int>());
+                  staged_sorted ? ctx->d_ex_z.as<float>() : nullptr, ctx->d_err.as<int>(),
+                  split_region_cap ? ctx->d_split_pairs.p : nullptr,
+                  split_region_cap ? (unsigned *)((char *)ctx->d_split_head.p + 8 * (size_t)split_tiles_b) : nullptr,
+                  split_region_cap ? ctx->d_split_tot.as<unsigned>() : nullptr, split_region_cap,
+                  split_region_cap ? ctx->d_split_head.p : nullptr);
   }
   HIPCHK(ctx, hipEventRecord(ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));

@@ -184,6 +184,8 @@ struct lt_ctx {
   DevBuf d_keys, d_rows, d_row_blk, d_skeys, d_srows, d_sort_tmp, d_conn_off;
   DevBuf d_st_c, d_st_l, d_flags, d_pos, d_scan_tmp;
   DevBuf d_item_off, d_masks, d_mask_cnt, d_mask_pos;
+  DevBuf d_split_pairs, d_split_segs, d_split_head, d_split_tot;  // pair list of the three-kernel scoring
+  bool score_split_off = false;  // set when a run overflowed the pair list: the fused scoring kernel from then on
   DevBuf d_hcand, d_hlite;  // split host-side view of the candidates (debug read-outs), see materialize_compact
   DevBuf d_cand, d_lite, d_tri_off, d_score, d_best_idx, d_edge_flag, d_nvalid, d_edge_off, d_edges;
   DevBuf d_best_c, d_best_score, d_best_src, d_ntris, d_err;

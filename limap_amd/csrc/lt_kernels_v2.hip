@@ -805,12 +805,13 @@ __global__ void __launch_bounds__(256)
 k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long *__restrict__ tri_off,
             const int *__restrict__ node_img, const long long *__restrict__ nb_off, CandMeta *__restrict__ meta,
             unsigned *__restrict__ draw, unsigned *__restrict__ bucket_cnt, unsigned *__restrict__ bucket_list,
-            unsigned bucket_cap) {
+            unsigned bucket_cap, unsigned *__restrict__ split_counters, uint2 *__restrict__ tile_lohi) {
   // grid-stride over the exact candidate count tri_off[G]; the host may only know an upper bound
   const long long C = tri_off[G];
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < kTileQueues) draw[i * 32] = 0;  // 128 bytes apart
+  if (i < 64) draw[i * 32] = 0;  // 128 bytes apart (k_score3 / 4 / 5 use the first eight, k_sweep6 all 64)
+  if (split_counters && i < 64) split_counters[i * 32] = 0;  // the region counters of the pair list (k_sweep6)
   const long long C_up = (C + 63) & ~63ll;  // whole waves take part in the tile's reduction
   for (; i < C_up; i += stride) {
     unsigned n = 0;
@@ -826,6 +827,10 @@ k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long
       m.nb = ((unsigned)nb0 << 8) | (unsigned)(nb_off[img + 1] - nb0);
       meta[i] = m;
       n = m.n;
+      if (tile_lohi) {  // window bounds of the tile (k_sweep6): the nodes of its first and last candidate, whole
+        if ((i & 63) == 0) tile_lohi[i >> 6].x = (unsigned)off;
+        if ((i & 63) == 63 || i == C - 1) tile_lohi[i >> 6].y = (unsigned)(off + (long long)m.n);
+      }
     }
     if (bucket_cnt) {
       unsigned sum = n;
@@ -883,7 +888,8 @@ struct Score3Args {
   const unsigned *bucket_list;
   unsigned bucket_cap;
   int max_nb;
-  int *err_flag;  // device error flag of the run (6: k_score5's workgroup protocol failed)
+  int *err_flag;  // device error flag of the run (7: the pair list of the three-kernel form overflowed)
+  const uint2 *tile_lohi;  // per tile: window bounds = [start of its first candidate's node, end of its last one's)
 };
 
 // Depth order of a node's candidates (large nodes: exhaustive matching gives ~450 candidates per node and
@@ -1107,8 +1113,19 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
         const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
         if (e < n_tiles) return a.tile_order ? a.tile_order[e] : (unsigned)e;
       }
-      if (++tried >= kTileQueues) return 0xFFFFFFFFu;
-      q = (q + 1) & (kTileQueues - 1);
+      // This queue is exhausted.  PEEK at all eight counters (plain loads; a counter only grows, so a queue that looks
+      // exhausted is) and draw only from one that looks open: without this every wave ended with eight failing device
+      // atomics -- dependent round trips behind the kernel's last tiles.
+      if (++tried > 4 * kTileQueues) return 0xFFFFFFFFu;
+      unsigned peek = 0xFFFFFFFFu, cap_l = 0;
+      if (lane < kTileQueues) {
+        peek = __hip_atomic_load(&a.draw[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cap_l = (n_tiles + (unsigned)(kTileQueues - 1 - lane)) / (unsigned)kTileQueues;  // tiles lane, lane + 8, ...
+      }
+      const unsigned long long open_q = __ballot(lane < kTileQueues && lane != q && peek < cap_l);
+      if (!open_q) return 0xFFFFFFFFu;
+      const unsigned long long after = open_q & ~((2ull << q) - 1ull);
+      q = __builtin_ctzll(after ? after : open_q);
       if (a.bucket_cnt && !a.tile_order) load_classes();
       if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
     }
@@ -1335,212 +1352,339 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
 }
 
-// ---------------------------------------------------------------------------------------------
-// HOT LOOP 2, current form for the natural candidate order (matched mode; also the unsorted exhaustive runs).
-// Same tiles, same draw queues, same per-image maxima and ordered sums as k_score3 above -- what changed is
-// where the time went there (two waves per SIMD waiting on dependent gathers):
-//   * one 128-byte CRec per candidate instead of Cand + CandLite through two dependent levels;
-//   * the window keeps, next to the sweep operands, each entry's record index and packed (image, slot), so a dense
-//     round reads queue -> window (LDS) and then issues its three gathers (record i, record j, camera K R t) at
-//     once: ONE global latency per round instead of three;
-//   * the sweep tests only the squared scale-invariant endpoint guards (the cosine guard rejected 2.5 % of what
-//     they let through and cost a quarter of the loop); "same node, other neighbour image" is one compare on a
-//     key (node start << 8 | slot), which also masks the lanes that ran past their node -- no range / self tests;
-//   * the queue is a ring of 16-bit entries drained in FULL rounds of 64 while the sweep runs (the partial round
-//     is paid once per tile, not once per drain);
-//   * LDS per wave 14.5 KB at 20 neighbours (S 10 KB + window 3.5 KB + queue 1 KB) and <= 168 registers:
-//     11 resident waves per CU instead of 8.
-// Conservative exactly like k_score3: a pair is dropped only when the double-precision guard certainly fails;
-// every pair that reaches pair_score is evaluated by the same function.  LT_TEST_SCORE_V3 runs k_score3.
-// ---------------------------------------------------------------------------------------------
-#ifndef LT_SCORE4_WIN
-#define LT_SCORE4_WIN 96
+#ifndef LT_SWEEP6_WIN
+#define LT_SWEEP6_WIN 96
 #endif
-constexpr int kWin4 = LT_SCORE4_WIN;  // window entries per chunk (<= 252: 8-bit window index in the queue)
-constexpr int kQ4 = 512;              // ring capacity (entries), power of two, >= 256 + 4 * 64
+constexpr int kWin4 = LT_SWEEP6_WIN;  // k_sweep6: window entries per chunk (<= 252: 8-bit window index in the queue)
+constexpr int kQ4 = 512;              // k_sweep6: queue capacity (entries), >= 256 + 4 * 64
 static_assert(kWin4 % 4 == 0 && kWin4 <= 252, "window size");
-#ifndef LT_SCORE4_RESIDENT
-#define LT_SCORE4_RESIDENT 12  // persistent single-wave workgroups per CU, if LDS and registers allow (168 registers: 3 per SIMD)
-#endif
-#ifdef LT_SCORE4_WAVES_PER_EU
-#define LT_SCORE4_OCC __attribute__((amdgpu_waves_per_eu(LT_SCORE4_WAVES_PER_EU, LT_SCORE4_WAVES_PER_EU)))
-#else
-#define LT_SCORE4_OCC
+
+// ---------------------------------------------------------------------------------------------
+// HOT LOOP 2 as THREE kernels (LT_SCORE_SPLIT=1; the fused k_score3 is the default -- see the measurements below):
+//   k_sweep6   per tile of 64 candidates: stage the window of the tile's nodes in LDS (single precision, relative to
+//              a wave-local origin, start / end interleaved for packed-f32 arithmetic; per entry a key = node start
+//              << 8 | neighbour slot, the record index and single-precision guard radii), sweep every lane over the
+//              candidates of its own node -- "same node, other neighbour image" is ONE compare on the keys, which also
+//              masks the lanes that ran past their node; the tests are the squared scale-invariant endpoint guards of
+//              k_score3 (conservative in the same way: a pair is dropped only if the exact gate certainly zeroes
+//              it) -- and WRITE the surviving pairs (record i, record j, image | slot of j, lane of i) to a global
+//              list, a tile's pairs as contiguous segments chained from tile_head[tile].  No evaluation in this
+//              kernel: 114 registers instead of 230.  The chain draw -> window bounds -> record indices -> records is
+//              software-pipelined across tiles; tiles are assigned statically in cost-class order.
+//   k_eval6    flat over the list, 64 pairs per wave-round, every round full (the fused kernel runs its rounds at 43
+//              of 64 lanes), 140 registers = 3 waves per SIMD.  The score overwrites the pair's record indices.
+//   k_reduce6  per tile: the per-(candidate, neighbour image) maxima (ds_max_u64 on a table in LDS) over the tile's
+//              segments, summed per candidate in image-id order (std::map order, global_line_triangulator.cc:110-112).
+// Same pairs, same pair_score, same maxima and sums as the fused kernel (tests: bit-identical scores).
+// Measured at 100 x 500 (us): k_sweep6 68 + k_eval6 41 + k_reduce6 18.5 = 128 against 118 for the fused k_score3 --
+// the evaluation alone got cheaper (41 us against ~47 us-equivalent in the fused kernel), the sweep did not: 16 us of
+// VALU issue take 68 us.  What was tried on the sweep, each measured: dynamic tile draws (one device atomic per tile,
+// 8 or 64 counters: 84-111 us -- the later loads of a wave queue behind the atomic's round trip), static natural
+// order 66, static cost-class order 68, compact records instead of gathers through the permutation 92 -> 92,
+// 8 / 12 / 16 resident waves per CU 71 / 72 / 82-93, a branch-free queue push 77; ablations: without the record
+// gathers 70, without the LDS reads 73, without the sweep loop 20, with the loop but without ballots / pushes 41.
+// The pair list's capacity is a multiple of the candidate bound; a run that overflows it raises device flag 7 and is
+// repeated with the fused kernel (finish_run).
+// ---------------------------------------------------------------------------------------------
+struct PairRec6 {  // 16 B
+  unsigned irec, jrec;  // k_eval6 replaces these two words by the pair's score (f64)
+  unsigned nbs_j;       // (image << 8) | slot of j
+  unsigned il;          // lane (candidate of the tile) of i
+};
+// The list is kRegions6 independent regions, each with its own bump counter (a device-scope atomic on ONE address
+// costs ~15 ns serialised -- one counter for the ~2e4 flushes of a run took 260 us; the counters are 128 bytes apart,
+// one L2 line each).  A segment is a header record {kNoSeg, count, index of the tile's previous header | kNoSeg, tile}
+// followed by its pairs; tile_head[tile] = index of the tile's newest header.
+constexpr unsigned kNoSeg = 0xFFFFFFFFu;
+constexpr int kRegions6 = 64;
+struct Split6 {
+  PairRec6 *pairs;      // [kRegions6][region_cap]
+  uint2 *tile_head;     // [tiles] (newest header of the tile or kNoSeg, its pair count | older segment exists << 31)
+  unsigned *counters;   // [kRegions6 * 32] records used per region (zeroed by k_cand_meta)
+  unsigned region_cap;
+};
+#ifndef LT_SWEEP6_RESIDENT
+#define LT_SWEEP6_RESIDENT 16  // persistent single-wave workgroups per CU, if registers and LDS allow
 #endif
 
 template <bool kPerm>
-__global__ void __launch_bounds__(64) LT_SCORE4_OCC
-k_score4(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
+__global__ void __launch_bounds__(64)
+k_sweep6(Score3Args a, Split6 sp, double scaleinv_guard2) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x;
-  // LDS: WB float4[kWin4 + 4] (sx, ex, sy, ey) | WE float4[kWin4 + 4] (sz, ez, key, nb_slot) | WP u32[kWin4] |
-  //      Q u16[kQ4] | S u64[max_nb][64]
+  // LDS: WB float4[kWin4 + 4] (sx, ex, sy, ey) | WE float4[kWin4 + 4] (sz, ez, key, nb_slot) | WG float2[kWin4] (guard
+  //      radii of the entry as a candidate i) | WP u32[kWin4] | Q u16[kQ4 + 64] (queue + one dump word per lane)
   float4 *WB = reinterpret_cast<float4 *>(smem_raw);
   float4 *WE = WB + (kWin4 + 4);
-  unsigned *WP = reinterpret_cast<unsigned *>(WE + (kWin4 + 4));
+  float2 *WG = reinterpret_cast<float2 *>(WE + (kWin4 + 4));
+  unsigned *WP = reinterpret_cast<unsigned *>(WG + kWin4);
   unsigned short *Q = reinterpret_cast<unsigned short *>(WP + kWin4);
-  unsigned long long *S = reinterpret_cast<unsigned long long *>(Q + kQ4);
 
   const long long C = a.tri_off[a.G];
   const unsigned n_tiles = (unsigned)((C + 63) >> 6);
-  int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
+  // STATIC assignment, longest first: wave w of W takes the tiles of rank w, w + W, w + 2 W, ... in k_cand_meta's
+  // cost-class order (most expensive class first; natural order without the classes).  The sweep's tile times vary
+  // 1:5 and a wave handles only 2-4 tiles, so an even split needs the expensive tiles spread over the waves; a
+  // dynamic draw did that worse here than it costs: a device atomic per tile, with every later load of the wave
+  // queued behind its round trip (memory operations return in order) -- measured 84 us (64 draw counters) against
+  // 66 us (static, natural order) and the figure in profiles/ for this order.
+  // Rank -> tile: the 256 (class, queue) lists of k_cand_meta in rank order, four per lane, prefix by shuffles.
   unsigned long long n_eval_total = 0;
-  unsigned k_raw = 0;
-  if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-  unsigned cls_cnt = 0, cls_incl = 0, q_tiles = 0;
-  auto load_classes = [&]() {
-    cls_cnt = lane < kTileBuckets ? a.bucket_cnt[(q * kTileBuckets + (kTileBuckets - 1 - lane)) * 32] : 0u;
-    cls_incl = cls_cnt;
+  unsigned lc[4] = {0, 0, 0, 0}, lane_incl = 0;
+  if (a.bucket_cnt) {
 #pragma unroll
-    for (int d = 1; d < kTileBuckets; d <<= 1) {
-      const unsigned t = (unsigned)__shfl_up((int)cls_incl, d);
-      if (lane >= d) cls_incl += t;
+    for (int u = 0; u < 4; ++u) {
+      const int bk = 4 * lane + u;  // rank order: class kTileBuckets - 1 first, queues 0..7 inside a class
+      const int cls = kTileBuckets - 1 - (bk >> 3), qq = bk & (kTileQueues - 1);
+      lc[u] = a.bucket_cnt[(qq * kTileBuckets + cls) * 32];
     }
-    q_tiles = (unsigned)__shfl((int)cls_incl, kTileBuckets - 1);
+    lane_incl = lc[0] + lc[1] + lc[2] + lc[3];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned t = (unsigned)__shfl_up((int)lane_incl, d);
+      if (lane >= d) lane_incl += t;
+    }
+  }
+  static_assert(kTileBuckets * kTileQueues == 256, "four class lists per lane");
+  unsigned rank_next = blockIdx.x;
+  auto resolve = [&]() -> unsigned {  // the wave's next tile, 0xFFFFFFFF when it has none left
+    const unsigned g = rank_next;
+    rank_next += gridDim.x;
+    if (g >= n_tiles) return 0xFFFFFFFFu;
+    if (!a.bucket_cnt) return g;
+    const unsigned long long m = __ballot(lane_incl > g);
+    if (!m) return 0xFFFFFFFFu;  // (cannot happen: the lists hold every tile)
+    const int ln = __builtin_ctzll(m);
+    unsigned base = (unsigned)__shfl((int)lane_incl, ln);
+    const unsigned c0 = (unsigned)__shfl((int)lc[0], ln), c1 = (unsigned)__shfl((int)lc[1], ln),
+                   c2 = (unsigned)__shfl((int)lc[2], ln), c3 = (unsigned)__shfl((int)lc[3], ln);
+    base -= c0 + c1 + c2 + c3;  // exclusive prefix of lane ln
+    unsigned r = g - base;
+    int u = 0;
+    if (r >= c0) { r -= c0; u = 1; if (r >= c1) { r -= c1; u = 2; if (r >= c2) { r -= c2; u = 3; } } }
+    const int bk = 4 * ln + u;
+    const int cls = kTileBuckets - 1 - (bk >> 3), qq = bk & (kTileQueues - 1);
+    return a.bucket_list[(size_t)(qq * kTileBuckets + cls) * a.bucket_cap + r];
   };
-  if (a.bucket_cnt) load_classes();
-  auto resolve = [&]() -> unsigned {  // tile of the pending draw, 0xFFFFFFFF when every queue is empty (see k_score3)
-    for (;;) {
-      const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
-      if (a.bucket_cnt && !a.tile_order) {
-        if (k < q_tiles) {
-          const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
-          const int bl = __builtin_ctzll(m);
-          const unsigned base = (unsigned)__shfl((int)(cls_incl - cls_cnt), bl);
-          return a.bucket_list[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
-        }
-      } else {
-        const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
-        if (e < n_tiles) return a.tile_order ? a.tile_order[e] : (unsigned)e;
+  // The dependent chain of a tile -- draw -> window bounds -> record indices (placement permutation) and node starts
+  // of the window's entries -> records -- is SOFTWARE-PIPELINED across tiles: while tile T is swept, the bounds of
+  // T + 1 (k_cand_meta's per-tile record) and then its record indices / node starts are loaded into registers, so
+  // that a tile starts with the one level that is left: the gather of its records.  (Unpipelined, the five levels
+  // took 9 us of a 15 us tile.)  The first kWin4 entries of a window are covered; a longer window stages its further
+  // chunks the plain way.
+  struct Pre {
+    unsigned tile;
+    unsigned lo, hi;        // window bounds (candidate positions fit 32 bits)
+    unsigned p[2], o[2];    // record index and node start of window entries lane, lane + 64
+    unsigned own_off, own_n;
+  };
+  auto pre_bounds = [&](Pre &x) {
+    const uint2 d = a.tile_lohi[x.tile];
+    x.lo = d.x; x.hi = d.y;
+  };
+  auto pre_entries = [&](Pre &x) {
+    const unsigned wn = min(x.hi - x.lo, (unsigned)kWin4);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const unsigned e = (unsigned)lane + 64u * u;
+      x.p[u] = 0; x.o[u] = 0;
+      if (e < wn) {
+        const unsigned pos = x.lo + e;
+        x.p[u] = kPerm ? a.perm[pos] : pos;
+        x.o[u] = a.meta[pos].off_lo;
       }
-      if (++tried >= kTileQueues) return 0xFFFFFFFFu;
-      q = (q + 1) & (kTileQueues - 1);
-      if (a.bucket_cnt && !a.tile_order) load_classes();
-      if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+    }
+    const long long tpos = (long long)x.tile * 64 + lane;
+    x.own_off = 0; x.own_n = 0;
+    if (tpos < C) {
+      const CandMeta mt = a.meta[tpos];
+      x.own_off = mt.off_lo;
+      x.own_n = mt.n;
     }
   };
-  unsigned tile = resolve();
-  while (tile != 0xFFFFFFFFu) {
-    if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-    const long long i0 = (long long)tile * 64;
-    const long long tpos = i0 + lane;
+  static_assert(kWin4 <= 128, "two prefetched entries per lane");
+  Pre cur, nxt;
+  cur.tile = resolve();
+  if (cur.tile != 0xFFFFFFFFu) {
+    pre_bounds(cur);
+    pre_entries(cur);
+  }
+  while (cur.tile != 0xFFFFFFFFu) {
+    const unsigned tile = cur.tile;
+    const long long tpos = (long long)tile * 64 + lane;
     const bool active = tpos < C;
     LT_TRACE_MARK(2, tile, 0);
-    long long off = 0, nb0 = 0;
-    int n = 0, n_nb = 0;
-    unsigned ri = 0;  // the lane's own record
-    if (active) {
-      const CandMeta mt = a.meta[tpos];
-      ri = kPerm ? a.perm[tpos] : (unsigned)tpos;
-      off = ((long long)mt.off_hi << 32) | (long long)mt.off_lo;
-      n = (int)mt.n;
-      nb0 = (long long)(mt.nb >> 8);
-      n_nb = (int)(mt.nb & 0xFFu);
-    }
-    // the window of the tile: the nodes of its first and last candidate, whole (positions ascend with the lanes)
-    const int last = 63 - __builtin_clzll(__ballot(active));
-    const long long lo = __shfl(off, 0);
-    const long long hi = __shfl(off + n, last);
-    double six = 0, siy = 0, siz = 0, eix = 0, eiy = 0, eiz = 0, gs = 0, ge = 0;
-    // Sentinel key of the tile: node part = (window start - 1) mod 2^24, which no node of the window has (a window is
-    // far shorter than 2^24 candidates); it ends every chunk and is the key of the idle lanes (x == 0: no match).
-    const unsigned key_sentinel = (((unsigned)lo - 1u) << 8) | 0xFFu;
-    unsigned keyi = key_sentinel;
-    if (active) {
-      const CRec &ci = a.cand[ri];
-      six = ci.s[0]; siy = ci.s[1]; siz = ci.s[2];
-      eix = ci.e[0]; eiy = ci.e[1]; eiz = ci.e[2];
-      // dist / (depth + eps) > th_scaleinv (1 + 1e-6) can never score >= score_th (line_dists.cc:55-60)
-      const double zs = ci.depth[0] + kEps, ze = ci.depth[1] + kEps;
-      gs = (zs > 0.0) ? sqrt(scaleinv_guard2 * zs * zs) : 1e150;  // odd depths: leave it to the exact path
-      ge = (ze > 0.0) ? sqrt(scaleinv_guard2 * ze * ze) : 1e150;
-      keyi = ((unsigned)mt_key(off) << 8) | (unsigned)(ci.nb_slot & 0xFF);
-    }
-    // summation order of the first lane's image in registers (lane r: r-th neighbour block in image-id order);
-    // lanes of another image read theirs from memory
-    const long long wave_nb0 = __shfl(nb0, 0);
-    const int wave_nnb = __shfl(n_nb, 0);
-    const int ordv = lane < wave_nnb ? a.blk_order[wave_nb0 + lane] : 0;
-    for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
-    // wave-local origin (the first lane's start point) and this lane's single-precision operands (start / end
-    // interleaved: the sweep's packed-f32 operand pairs)
-    const double ox = __shfl(six, 0), oy = __shfl(siy, 0), oz = __shfl(siz, 0);
-    const float sixf = (float)(six - ox), siyf = (float)(siy - oy), sizf = (float)(siz - oz);
-    const float eixf = (float)(eix - ox), eiyf = (float)(eiy - oy), eizf = (float)(eiz - oz);
-    float ri_mag = fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)), fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf)));
-    if (!active) ri_mag = 0.0f;
-    int qh = 0, qc = 0;  // ring: head, count (wave-uniform)
-    unsigned long long n_eval = 0;
 #ifdef LT_TRACE
-    unsigned long long tr_dense = 0, tr_rounds = 0;
+    unsigned long long tr_flush = 0, tr_nflush = 0;
 #endif
+    const long long lo = (long long)cur.lo, hi = (long long)cur.hi;
+    const long long off = (long long)cur.own_off;
+    const int n = (int)cur.own_n;
+    const int wn0 = (int)((hi - lo) < kWin4 ? (hi - lo) : kWin4);
+    // ---- the one exposed level: the records of the first chunk's entries ----
+    double rs[2][6], rd[2][2];
+    int rnbs[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u;
+      rnbs[u] = 0;
+      for (int k = 0; k < 6; ++k) rs[u][k] = 0.0;
+      rd[u][0] = rd[u][1] = 0.0;
+      if (e < wn0) {
+        const CRec &c = a.cand[cur.p[u]];
+        rs[u][0] = c.s[0]; rs[u][1] = c.s[1]; rs[u][2] = c.s[2];
+        rs[u][3] = c.e[0]; rs[u][4] = c.e[1]; rs[u][5] = c.e[2];
+        rd[u][0] = c.depth[0]; rd[u][1] = c.depth[1];
+        rnbs[u] = c.nb_slot;
+      }
+    }
+    // meanwhile: the next tile and its bounds (the draw was issued while the previous tile was swept)
+    nxt.tile = resolve();
+    if (nxt.tile != 0xFFFFFFFFu) pre_bounds(nxt);
+    // sentinel key of the tile: node part = (window start - 1) mod 2^24, which no node of the window has; it ends
+    // every chunk and is the key of the idle lanes, wave-local origin = start point of the window's first entry
+    const unsigned key_sentinel = (((unsigned)lo - 1u) << 8) | 0xFFu;
+    const double ox = __shfl(rs[0][0], 0), oy = __shfl(rs[0][1], 0), oz = __shfl(rs[0][2], 0);
+    wave_lds_sync();  // the previous tile's window is no longer read
+    float rw = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u;
+      if (e < wn0) {
+        const float sx = (float)(rs[u][0] - ox), sy = (float)(rs[u][1] - oy), sz = (float)(rs[u][2] - oz);
+        const float ex = (float)(rs[u][3] - ox), ey = (float)(rs[u][4] - oy), ez = (float)(rs[u][5] - oz);
+        WB[e] = float4{sx, ex, sy, ey};
+        WE[e] = float4{sz, ez, __uint_as_float((cur.o[u] << 8) | (unsigned)(rnbs[u] & 0xFF)), __int_as_float(rnbs[u])};
+        WP[e] = cur.p[u];
+        // guard radii of this entry as candidate i: dist / (depth + eps) > th_scaleinv (1 + 1e-6) can never score
+        // >= score_th (line_dists.cc:55-60); single precision, rounded UP (odd depths: leave it to the exact path)
+        const double zs = rd[u][0] + kEps, ze = rd[u][1] + kEps;
+        const double gs = (zs > 0.0) ? sqrt(scaleinv_guard2 * zs * zs) : 1e150;
+        const double ge = (ze > 0.0) ? sqrt(scaleinv_guard2 * ze * ze) : 1e150;
+        float gsf0 = (float)gs, gef0 = (float)ge;
+        if ((double)gsf0 < gs) gsf0 = __uint_as_float(__float_as_uint(gsf0) + 1u);
+        if ((double)gef0 < ge) gef0 = __uint_as_float(__float_as_uint(gef0) + 1u);
+        WG[e] = float2{gsf0, gef0};
+        rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
+      } else if (e < wn0 + 4) {
+        WE[e] = float4{0.0f, 0.0f, __uint_as_float(key_sentinel), 0.0f};  // every chunk ends in four sentinels
+      }
+    }
+    wave_lds_sync();
+    // this lane's own candidate = window entry tpos - lo (a lane whose entry lies beyond the first chunk -- its node
+    // starts more than kWin4 - 64 positions before the tile -- loads its record itself)
+    float sixf = 0, siyf = 0, sizf = 0, eixf = 0, eiyf = 0, eizf = 0, g0 = 0, g1 = 0;
+    unsigned keyi = key_sentinel, ri = 0;
+    if (active) {
+      const long long own = tpos - lo;
+      if (own < wn0) {
+        const float4 b = WB[own], e4 = WE[own];
+        const float2 g = WG[own];
+        sixf = b.x; eixf = b.y; siyf = b.z; eiyf = b.w; sizf = e4.x; eizf = e4.y;
+        keyi = __float_as_uint(e4.z);
+        g0 = g.x; g1 = g.y;
+        ri = WP[own];
+      } else {
+        ri = kPerm ? a.perm[tpos] : (unsigned)tpos;
+        const CRec &ci = a.cand[ri];
+        sixf = (float)(ci.s[0] - ox); siyf = (float)(ci.s[1] - oy); sizf = (float)(ci.s[2] - oz);
+        eixf = (float)(ci.e[0] - ox); eiyf = (float)(ci.e[1] - oy); eizf = (float)(ci.e[2] - oz);
+        const double zs = ci.depth[0] + kEps, ze = ci.depth[1] + kEps;
+        const double gs = (zs > 0.0) ? sqrt(scaleinv_guard2 * zs * zs) : 1e150;
+        const double ge = (ze > 0.0) ? sqrt(scaleinv_guard2 * ze * ze) : 1e150;
+        g0 = (float)gs; g1 = (float)ge;
+        if ((double)g0 < gs) g0 = __uint_as_float(__float_as_uint(g0) + 1u);
+        if ((double)g1 < ge) g1 = __uint_as_float(__float_as_uint(g1) + 1u);
+        keyi = ((unsigned)mt_key(off) << 8) | (unsigned)(ci.nb_slot & 0xFF);
+      }
+    }
+    const float ri_mag = active ? fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)),
+                                        fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf))) : 0.0f;
+    LT_TRACE_MARK(2, tile, 1);
+    int qc = 0;  // queued entries (wave-uniform); the queue is linear: it is emptied by every flush
+    const unsigned long long lt_mask = lanemask_lt();
+    unsigned seg_prev = kNoSeg, seg_prev_n = 0;
+    const unsigned region = blockIdx.x & (kRegions6 - 1);
 
-    // one dense round: the (up to) 64 oldest queue entries, one pair per lane
-    auto round = [&]() {
+    // the queued pairs -> one contiguous segment of the global list (the entries index the current window)
+    auto flush = [&]() {
 #ifdef LT_TRACE
       const unsigned long long tr0 = wall_clock64();
 #endif
       wave_lds_sync();
-      const int nr = qc < 64 ? qc : 64;
-      // (the owner's record index comes by a cross-lane read: done by all lanes, outside the branch)
-      const unsigned e = Q[(qh + lane) & (kQ4 - 1)];
-      const int il = (int)((e >> 8) & 63u), w = (int)(e & 0xFFu);
-      const unsigned irec = (unsigned)__shfl((int)ri, il);
-      if (lane < nr) {
-        const unsigned jrec = WP[w];
-        const int nbs_j = __float_as_int(WE[w].w);
-        const CRec &ci = a.cand[irec];
-        const CRec &cj = a.cand[jrec];
-        const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
-                                     mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
-                                     mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
-                                     mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg, a.cams[(int)((unsigned)nbs_j >> 8)]);
-        if (sc > 0.0) atomicMax(&S[(nbs_j & 0xFF) * 64 + il], (unsigned long long)__double_as_longlong(sc));
+      unsigned start = 0;
+      if (lane == 0) start = atomicAdd(&sp.counters[region * 32], (unsigned)qc + 1u);
+      start = (unsigned)__builtin_amdgcn_readfirstlane((int)start);
+      const bool fits = (unsigned long long)start + (unsigned)qc + 1ull <= (unsigned long long)sp.region_cap;
+      if (!fits) {
+        if (lane == 0 && a.err_flag) *a.err_flag = 7;
+      } else {
+        const size_t hdr = (size_t)region * sp.region_cap + start;
+        for (int k0 = 0; k0 < qc; k0 += 64) {
+          const int k = k0 + lane;
+          const unsigned e = Q[k < qc ? k : 0];
+          const int il = (int)((e >> 8) & 63u), w = (int)(e & 0xFFu);
+          const unsigned irec = (unsigned)__shfl((int)ri, il);  // cross-lane read by all lanes
+          if (k < qc) {
+            PairRec6 r;
+            r.irec = irec;
+            r.jrec = WP[w];
+            r.nbs_j = __float_as_uint(WE[w].w);
+            r.il = (unsigned)il;
+            *reinterpret_cast<uint4 *>(&sp.pairs[hdr + 1 + (unsigned)k]) = *reinterpret_cast<const uint4 *>(&r);
+          }
+        }
+        if (lane == 0) *reinterpret_cast<uint4 *>(&sp.pairs[hdr]) = uint4{kNoSeg, (unsigned)qc, seg_prev, tile};
+        seg_prev_n = (unsigned)qc | (seg_prev != kNoSeg ? 0x80000000u : 0u);  // top bit: an older segment exists
+        seg_prev = (unsigned)hdr;
       }
-      n_eval += (unsigned long long)nr;
-      qh = (qh + nr) & (kQ4 - 1);
-      qc -= nr;
+      n_eval_total += (unsigned long long)qc;
 #ifdef LT_TRACE
+      tr_nflush += (unsigned long long)qc << 16 | 1ull;
+#endif
+      qc = 0;
       wave_lds_sync();
-      tr_dense += wall_clock64() - tr0;
-      ++tr_rounds;
+#ifdef LT_TRACE
+      tr_flush += wall_clock64() - tr0;
 #endif
     };
 
     for (long long wb = lo; wb < hi; wb += kWin4) {
-      wave_lds_sync();  // the previous chunk's readers are done (its queue entries were drained)
       const int wn = (int)((hi - wb) < kWin4 ? (hi - wb) : kWin4);
-      float rw = ri_mag;
-      for (int e = lane; e < wn + 4; e += 64) {
-        if (e < wn) {
-          const long long pos = wb + e;
-          const unsigned pr = kPerm ? a.perm[pos] : (unsigned)pos;
-          const unsigned eoff = a.meta[pos].off_lo;
-          const CRec &c = a.cand[pr];
-          const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
-          const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
-          const int nbs = c.nb_slot;
-          WB[e] = float4{sx, ex, sy, ey};
-          WE[e] = float4{sz, ez, __uint_as_float((eoff << 8) | (unsigned)(nbs & 0xFF)), __int_as_float(nbs)};
-          WP[e] = pr;
-          rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
-        } else {
-          WE[e] = float4{0.0f, 0.0f, __uint_as_float(key_sentinel), 0.0f};  // every chunk ends in four sentinels
+      if (wb != lo) {
+        // a further chunk of a long window, staged the plain way (its entries were flushed at the end of the last one)
+        wave_lds_sync();
+        rw = 0.0f;
+        for (int e = lane; e < wn + 4; e += 64) {
+          if (e < wn) {
+            const long long pos = wb + e;
+            const unsigned pr = kPerm ? a.perm[pos] : (unsigned)pos;
+            const unsigned eoff = a.meta[pos].off_lo;
+            const CRec &c = a.cand[pr];
+            const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
+            const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
+            const int nbs = c.nb_slot;
+            WB[e] = float4{sx, ex, sy, ey};
+            WE[e] = float4{sz, ez, __uint_as_float((eoff << 8) | (unsigned)(nbs & 0xFF)), __int_as_float(nbs)};
+            WP[e] = pr;
+            rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
+          } else {
+            WE[e] = float4{0.0f, 0.0f, __uint_as_float(key_sentinel), 0.0f};
+          }
         }
+        wave_lds_sync();
       }
       // R of the window -> this lane's single-precision distance guards (a NaN coordinate makes R NaN, the guards
       // NaN and every comparison false: everything goes to the exact evaluation)
+      float rmax = fmaxf(rw, ri_mag);
+      if (rw != rw) rmax = rw;
       for (int d = 32; d >= 1; d >>= 1) {
-        const float o = __shfl_xor(rw, d);
-        rw = (o > rw || o != o) ? o : rw;
+        const float o = __shfl_xor(rmax, d);
+        rmax = (o > rmax || o != o) ? o : rmax;
       }
-      const double delta = 1e-6 * (double)rw;
-      const float gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
-      const float gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
-      wave_lds_sync();
-      if (wb == lo) { LT_TRACE_MARK(2, tile, 1); }
-      // this lane's sub-range of the window; past it the index is clamped onto the first entry behind the range --
-      // another node's candidate or a sentinel, never a key match
+      const double delta = 1e-6 * (double)rmax;
+      const float gsf = (float)(((double)g0 + delta) * ((double)g0 + delta) * (1.0 + 2e-6));
+      const float gef = (float)(((double)g1 + delta) * ((double)g1 + delta) * (1.0 + 2e-6));
       const long long jlo = off > wb ? off : wb;
       const long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
       const int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
@@ -1548,252 +1692,8 @@ k_score4(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d));
       const int w0 = cnt > 0 ? (int)(jlo - wb) : wn;
       const int wend = w0 + cnt;
-      // one loop, ONE instance of the dense round in the code: full rounds while the sweep runs and the ring is more
-      // than half full, then -- the entries index this chunk's window -- everything that is left
-      for (int t = 0;;) {
-        const bool swept = t >= cmax;
-        if (swept ? qc > 0 : qc > kQ4 - 256) {
-          round();
-          continue;
-        }
-        if (swept) break;
-        float4 B[4], E[4];
-        int wi[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          wi[u] = min(w0 + t + u, wend);
-          B[u] = WB[wi[u]];
-          E[u] = WE[wi[u]];
-        }
-        bool pass[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          // (start, end) pairs: v_pk_add / v_pk_mul / v_pk_fma_f32 straight from the window's layout
-          const float ax = sixf - B[u].x, bx = eixf - B[u].y;
-          const float ay = siyf - B[u].z, by = eiyf - B[u].w;
-          const float az = sizf - E[u].x, bz = eizf - E[u].y;
-          const float ds2 = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
-          const float de2 = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
-          // same node and another neighbour image  <=>  0 < (key_j ^ key_i) < 256
-          const unsigned x = __float_as_uint(E[u].z) ^ keyi;
-          pass[u] = ((x - 1u) < 255u) & !(ds2 > gsf) & !(de2 > gef);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned long long m = __ballot(pass[u]);
-          if (m) {
-            if (pass[u])
-              Q[(qh + qc + __popcll(m & lanemask_lt())) & (kQ4 - 1)] = (unsigned short)(((unsigned)lane << 8) | (unsigned)wi[u]);
-            qc += __popcll(m);
-          }
-        }
-        t += 4;
-      }
-    }
-    LT_TRACE_MARK(2, tile, 2);
-    wave_lds_sync();
-    LT_TRACE_MARK(2, tile, 3);
-
-    {
-      double sum = 0.0;
-      const bool own = nb0 == wave_nb0;
-      int rmax = n_nb;
-      for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d));
-      for (int r = 0; r < rmax; ++r) {  // r is wave-uniform: the first image's order comes by readlane
-        const int k_own = __builtin_amdgcn_readlane(ordv, r);
-        if (r < n_nb) {
-          const int k = own ? k_own : a.blk_order[nb0 + r];
-          sum += __longlong_as_double((long long)S[k * 64 + lane]);
-        }
-      }
-      if (active) a.score[tpos] = sum;
-    }
-#ifdef LT_TRACE
-    if (lane == 0 && tile < 65536u) {
-      g_trace[3 * 4 * 65536 + 4 * tile + 0] = tr_dense;
-      g_trace[3 * 4 * 65536 + 4 * tile + 1] = tr_rounds;
-      g_trace[3 * 4 * 65536 + 4 * tile + 2] = n_eval;
-      g_trace[3 * 4 * 65536 + 4 * tile + 3] = wall_clock64();
-    }
-#endif
-    n_eval_total += n_eval;
-    wave_lds_sync();  // the tables are reused by the next tile
-    tile = resolve();
-  }
-  if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_score5: k_score4 with the dense evaluation POOLED per workgroup.  Four persistent waves per workgroup, each
-// drawing, staging and sweeping its own tiles exactly like k_score4 -- but the pairs that survive a sweep are
-// moved, 64 at a time, from the wave's private ring into one ring shared by the workgroup, and a dense round takes
-// the 64 oldest entries of THAT ring, whoever produced them (an entry names its producer: window, record indices
-// and the table S of the per-image maxima all live in the producer's part of the LDS).
-//   * one partial round per workgroup and quiet period instead of one per tile: k_score4 ran its rounds at 43 of
-//     64 lanes (the evaluation is 2/3 of the kernel's instructions);
-//   * a tile with many surviving pairs is evaluated by all four waves: tile times varied 11-80 us and set a tail
-//     of a quarter of the kernel; the unit that has to fit the tail is now a quarter as long.
-// Protocol (LDS atomics, workgroup scope; no workgroup barrier after the start):
-//   tail / head    reserved / claimed entries of the shared ring (monotone counters, ring index = counter mod kQ5)
-//   pend[w]        entries of wave w that were moved to the shared ring and are not evaluated yet; wave w restages
-//                  its window or sums its tile only at pend[w] == 0 (and evaluates rounds while it waits)
-//   an entry is written after its slot was reserved: a claimed slot is read in a (bounded) spin until it is valid and
-//   then reset.  Producers keep 512 slots clear of the head: more than the four rounds that can be in flight.
-//   A waiting wave takes a partial round only when nobody is sweeping or after a short patience.
-// Nothing here changes WHICH pairs are evaluated or how: pair_score on the same operands, maxima by ds_max_u64,
-// sums in image-id order by the tile's own wave.  LT_TEST_SCORE_V4 runs k_score4, LT_TEST_SCORE_V3 k_score3.
-// ---------------------------------------------------------------------------------------------
-constexpr int kQ5 = 2048;  // shared ring capacity (entries, power of two)
-struct Ctl5 {
-  unsigned tail, head, n_sweeping, n_active;
-  unsigned pend[4];
-  unsigned err;
-};
-static __device__ __forceinline__ unsigned lds_ld(unsigned *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-static __host__ __device__ inline size_t score5_wave_bytes(int max_nb) {
-  return (size_t)(kWin4 + 4) * 32 + (size_t)kWin4 * 4 + 64 * 4 + (size_t)kQ4 * 2 + (size_t)max_nb * 64 * 8;
-}
-
-template <bool kPerm>
-__global__ void __launch_bounds__(256)
-k_score5(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const size_t per_wave = score5_wave_bytes(a.max_nb);
-  // per wave: WB float4[kWin4 + 4] | WE float4[kWin4 + 4] | WP u32[kWin4] | RI u32[64] | P u16[kQ4] | S u64[max_nb][64]
-  constexpr size_t oWE = (size_t)(kWin4 + 4) * 16, oWP = oWE * 2, oRI = oWP + (size_t)kWin4 * 4, oP = oRI + 64 * 4,
-                   oS = oP + (size_t)kQ4 * 2;
-  unsigned char *mine = smem_raw + (size_t)wv * per_wave;
-  float4 *WB = reinterpret_cast<float4 *>(mine);
-  float4 *WE = reinterpret_cast<float4 *>(mine + oWE);
-  unsigned *WP = reinterpret_cast<unsigned *>(mine + oWP);
-  unsigned *RI = reinterpret_cast<unsigned *>(mine + oRI);
-  unsigned short *P = reinterpret_cast<unsigned short *>(mine + oP);
-  unsigned long long *S = reinterpret_cast<unsigned long long *>(mine + oS);
-  unsigned short *Q = reinterpret_cast<unsigned short *>(smem_raw + 4 * per_wave);
-  Ctl5 *ctl = reinterpret_cast<Ctl5 *>(Q + kQ5);
-  for (int e = threadIdx.x; e < kQ5; e += 256) Q[e] = 0xFFFFu;
-  if (threadIdx.x == 0) {
-    ctl->tail = 0; ctl->head = 0; ctl->n_sweeping = 0; ctl->n_active = 4;
-    ctl->pend[0] = ctl->pend[1] = ctl->pend[2] = ctl->pend[3] = 0;
-    ctl->err = 0;
-  }
-  __syncthreads();
-
-  const long long C = a.tri_off[a.G];
-  const unsigned n_tiles = (unsigned)((C + 63) >> 6);
-  int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
-  unsigned long long n_eval_total = 0;
-  unsigned k_raw = 0;
-  if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-  unsigned cls_cnt = 0, cls_incl = 0, q_tiles = 0;
-  auto load_classes = [&]() {
-    cls_cnt = lane < kTileBuckets ? a.bucket_cnt[(q * kTileBuckets + (kTileBuckets - 1 - lane)) * 32] : 0u;
-    cls_incl = cls_cnt;
-#pragma unroll
-    for (int d = 1; d < kTileBuckets; d <<= 1) {
-      const unsigned t = (unsigned)__shfl_up((int)cls_incl, d);
-      if (lane >= d) cls_incl += t;
-    }
-    q_tiles = (unsigned)__shfl((int)cls_incl, kTileBuckets - 1);
-  };
-  if (a.bucket_cnt) load_classes();
-  auto resolve = [&]() -> unsigned {  // tile of the pending draw, 0xFFFFFFFF when every queue is empty (see k_score3)
-    for (;;) {
-      const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
-      if (a.bucket_cnt && !a.tile_order) {
-        if (k < q_tiles) {
-          const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
-          const int bl = __builtin_ctzll(m);
-          const unsigned base = (unsigned)__shfl((int)(cls_incl - cls_cnt), bl);
-          return a.bucket_list[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
-        }
-      } else {
-        const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
-        if (e < n_tiles) return a.tile_order ? a.tile_order[e] : (unsigned)e;
-      }
-      if (++tried >= kTileQueues) return 0xFFFFFFFFu;
-      q = (q + 1) & (kTileQueues - 1);
-      if (a.bucket_cnt && !a.tile_order) load_classes();
-      if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-    }
-  };
-
-  enum { kNext = 0, kQuiesceStage = 1, kSweep = 2, kQuiesceEnd = 3, kFinal = 4 };
-  int st = kNext;
-#ifdef LT_TRACE
-  unsigned long long tr_rounds = 0, tr_sleeps = 0, tr_tiles = 0, tr_dense = 0, tr_final0 = 0;
-  unsigned long long tr_acc[7] = {0, 0, 0, 0, 0, 0, 0};  // prologue, stage, sweep, flush, wait, (dense), sums
-  unsigned long long tr_last = wall_clock64();
-#define TR_ACC(k) { const unsigned long long now_ = wall_clock64(); tr_acc[k] += now_ - tr_last; tr_last = now_; }
-  const unsigned tr_id = blockIdx.x * 4 + wv;
-  LT_TRACE_MARK(2, tr_id, 0);
-#else
-#define TR_ACC(k)
-#endif
-  // tile state
-  long long tpos = 0, off = 0, nb0 = 0, lo = 0, hi = 0, wb = 0, wave_nb0 = 0;
-  int n = 0, n_nb = 0, ordv = 0;
-  bool active = false;
-  unsigned ri = 0, keyi = 0, key_sentinel = 0;
-  double ox = 0, oy = 0, oz = 0, gs = 0, ge = 0;
-  float sixf = 0, siyf = 0, sizf = 0, eixf = 0, eiyf = 0, eizf = 0, ri_mag = 0, gsf = 0, gef = 0;
-  // chunk state
-  int wn = 0, cmax = 0, w0 = 0, wend = 0, t = 0;
-  int qh = 0, qc = 0;  // private ring: head, count (wave-uniform)
-  int patience = 0;
-
-  // moves the (up to) 64 oldest private entries to the shared ring; false: no room there (evaluate a round first)
-  auto flush_block = [&]() -> bool {
-    unsigned base = 0;
-    const int nmove = qc < 64 ? qc : 64;
-    int ok = 0;
-    if (lane == 0) {
-      const unsigned hh = lds_ld(&ctl->head), tt = lds_ld(&ctl->tail);
-      if ((int)(tt - hh) <= kQ5 - 512 - 64) {
-        __hip_atomic_fetch_add(&ctl->pend[wv], (unsigned)nmove, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        base = __hip_atomic_fetch_add(&ctl->tail, (unsigned)nmove, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        ok = 1;
-      }
-    }
-    ok = __builtin_amdgcn_readfirstlane(ok);
-    if (!ok) return false;
-    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    wave_lds_sync();  // the private entries are written
-    if (lane < nmove) {
-      const unsigned e = P[(qh + lane) & (kQ4 - 1)];
-      *reinterpret_cast<volatile unsigned short *>(&Q[(base + (unsigned)lane) & (kQ5 - 1)]) =
-          (unsigned short)(e | ((unsigned)wv << 14));
-    }
-    qh = (qh + nmove) & (kQ4 - 1);
-    qc -= nmove;
-    return true;
-  };
-
-  // (the pass counter bounds a protocol error to a wrong result + error flag instead of a hung device: a wave makes
-  // ~30 passes per tile; 2^22 is far beyond any real run)
-  for (unsigned pass_guard = 0;; ++pass_guard) {
-    if (pass_guard > (1u << 22)) {
-      ctl->err = 2;
-      break;
-    }
-    bool do_round = false;
-    if (st == kSweep) {
-      if (qc >= 64 || (t >= cmax && qc > 0)) {
-        const bool fl_ = flush_block();
-        TR_ACC(3);
-        if (fl_) continue;
-        do_round = true;
-      } else if (t >= cmax) {
-        if (lane == 0) __hip_atomic_fetch_sub(&ctl->n_sweeping, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        wb += kWin4;
-        st = wb < hi ? kQuiesceStage : kQuiesceEnd;
-        patience = 0;
-        continue;
-      } else {
+      for (int t = 0; t < cmax; t += 4) {
+        if (qc > kQ4 - 256) flush();
         float4 B[4], E[4];
         int wi[4];
 #pragma unroll
@@ -1813,238 +1713,146 @@ k_score5(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
           const unsigned x = __float_as_uint(E[u].z) ^ keyi;  // same node, another neighbour image: 0 < x < 256
           pass[u] = ((x - 1u) < 255u) & !(ds2 > gsf) & !(de2 > gef);
         }
+        // Branch-free push: every lane stores, a lane without a pair into its own word of a dump area behind the
+        // queue.  (The natural form -- `if (ballot) { if (pass) store; }` per step -- compiles to two branches per
+        // step, eight per iteration; their fetch bubbles were 40 % of this kernel: 68 -> 41 us without them.)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const unsigned long long m = __ballot(pass[u]);
-          if (m) {
-            if (pass[u])
-              P[(qh + qc + __popcll(m & lanemask_lt())) & (kQ4 - 1)] = (unsigned short)(((unsigned)lane << 8) | (unsigned)wi[u]);
-            qc += __popcll(m);
-          }
+          const int slot = pass[u] ? qc + (int)__popcll(m & lt_mask) : kQ4 + lane;
+          Q[slot] = (unsigned short)(((unsigned)lane << 8) | (unsigned)wi[u]);
+          qc += (int)__popcll(m);
         }
-        t += 4;
-        TR_ACC(2);
-        continue;
       }
-    } else if (st == kQuiesceStage || st == kQuiesceEnd) {
-      const unsigned mypend = (unsigned)__builtin_amdgcn_readfirstlane(
-          (int)__hip_atomic_load(&ctl->pend[wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-      if (mypend != 0) {
-        do_round = true;
-      } else if (st == kQuiesceStage) {
-        // ---- stage the window chunk [wb, wb + wn) ----
-        wn = (int)((hi - wb) < kWin4 ? (hi - wb) : kWin4);
-        float rw = ri_mag;
-        for (int e = lane; e < wn + 4; e += 64) {
-          if (e < wn) {
-            const long long pos = wb + e;
-            const unsigned pr = kPerm ? a.perm[pos] : (unsigned)pos;
-            const unsigned eoff = a.meta[pos].off_lo;
-            const CRec &c = a.cand[pr];
-            const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
-            const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
-            const int nbs = c.nb_slot;
-            WB[e] = float4{sx, ex, sy, ey};
-            WE[e] = float4{sz, ez, __uint_as_float((eoff << 8) | (unsigned)(nbs & 0xFF)), __int_as_float(nbs)};
-            WP[e] = pr;
-            rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
-          } else {
-            WE[e] = float4{0.0f, 0.0f, __uint_as_float(key_sentinel), 0.0f};
-          }
-        }
-        for (int d = 32; d >= 1; d >>= 1) {
-          const float o = __shfl_xor(rw, d);
-          rw = (o > rw || o != o) ? o : rw;
-        }
-        const double delta = 1e-6 * (double)rw;
-        gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
-        gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
-        const long long jlo = off > wb ? off : wb;
-        const long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
-        const int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
-        cmax = cnt;
-        for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d));
-        w0 = cnt > 0 ? (int)(jlo - wb) : wn;
-        wend = w0 + cnt;
-        t = 0;
-        if (lane == 0) __hip_atomic_fetch_add(&ctl->n_sweeping, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        wave_lds_sync();
-        st = kSweep;
-        TR_ACC(1);
-        continue;
-      } else {
-        // ---- the tile's ordered sums (every pair of the tile has been evaluated: pend == 0) ----
-        double sum = 0.0;
-        const bool own = nb0 == wave_nb0;
-        int rmax = n_nb;
-        for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d));
-        for (int r = 0; r < rmax; ++r) {
-          const int k_own = __builtin_amdgcn_readlane(ordv, r);
-          if (r < n_nb) {
-            const int k = own ? k_own : a.blk_order[nb0 + r];
-            sum += __longlong_as_double((long long)S[k * 64 + lane]);
-          }
-        }
-        if (active) a.score[tpos] = sum;
-        wave_lds_sync();
-        st = kNext;
-        TR_ACC(6);
-        continue;
-      }
-    } else if (st == kNext) {
-      const unsigned tile = resolve();
-      if (tile == 0xFFFFFFFFu) {
-        if (lane == 0) __hip_atomic_fetch_sub(&ctl->n_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        st = kFinal;
-        patience = 0;
-#ifdef LT_TRACE
-        tr_final0 = wall_clock64();
-#endif
-        continue;
-      }
-      if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-#ifdef LT_TRACE
-      ++tr_tiles;
-#endif
-      tpos = (long long)tile * 64 + lane;
-      active = tpos < C;
-      off = 0; nb0 = 0; n = 0; n_nb = 0; ri = 0;
-      if (active) {
-        const CandMeta mt = a.meta[tpos];
-        ri = kPerm ? a.perm[tpos] : (unsigned)tpos;
-        off = ((long long)mt.off_hi << 32) | (long long)mt.off_lo;
-        n = (int)mt.n;
-        nb0 = (long long)(mt.nb >> 8);
-        n_nb = (int)(mt.nb & 0xFFu);
-      }
-      const int last = 63 - __builtin_clzll(__ballot(active));
-      lo = __shfl(off, 0);
-      hi = __shfl(off + n, last);
-      key_sentinel = (((unsigned)lo - 1u) << 8) | 0xFFu;
-      keyi = key_sentinel;
-      double six = 0, siy = 0, siz = 0, eix = 0, eiy = 0, eiz = 0;
-      gs = 0; ge = 0;
-      if (active) {
-        const CRec &ci = a.cand[ri];
-        six = ci.s[0]; siy = ci.s[1]; siz = ci.s[2];
-        eix = ci.e[0]; eiy = ci.e[1]; eiz = ci.e[2];
-        const double zs = ci.depth[0] + kEps, ze = ci.depth[1] + kEps;
-        gs = (zs > 0.0) ? sqrt(scaleinv_guard2 * zs * zs) : 1e150;
-        ge = (ze > 0.0) ? sqrt(scaleinv_guard2 * ze * ze) : 1e150;
-        keyi = ((unsigned)mt_key(off) << 8) | (unsigned)(ci.nb_slot & 0xFF);
-      }
-      RI[lane] = ri;
-      wave_nb0 = __shfl(nb0, 0);
-      const int wave_nnb = __shfl(n_nb, 0);
-      ordv = lane < wave_nnb ? a.blk_order[wave_nb0 + lane] : 0;
-      for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
-      ox = __shfl(six, 0); oy = __shfl(siy, 0); oz = __shfl(siz, 0);
-      sixf = (float)(six - ox); siyf = (float)(siy - oy); sizf = (float)(siz - oz);
-      eixf = (float)(eix - ox); eiyf = (float)(eiy - oy); eizf = (float)(eiz - oz);
-      ri_mag = fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)), fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf)));
-      if (!active) ri_mag = 0.0f;
-      wb = lo;
-      st = kQuiesceStage;  // pend[wv] == 0 here: the previous tile was summed
-      patience = 0;
-      TR_ACC(0);
-      continue;
-    } else {  // kFinal: no tiles left for this wave; help until the workgroup is done
-      unsigned done = 0;
-      if (lane == 0)
-        done = (lds_ld(&ctl->n_active) == 0u && lds_ld(&ctl->head) == lds_ld(&ctl->tail)) ? 1u : 0u;
-      if (__builtin_amdgcn_readfirstlane((int)done)) break;
-      do_round = true;
+      if (qc > 0 && wb + kWin4 < hi) flush();  // the entries index this chunk's window
     }
-    if (!do_round) continue;
+    LT_TRACE_MARK(2, tile, 2);
+    // the next tile's record indices and node starts (its bounds arrived long ago): in flight during the flush
+    if (nxt.tile != 0xFFFFFFFFu) pre_entries(nxt);
+    if (qc > 0) flush();
+    if (lane == 0) sp.tile_head[tile] = uint2{seg_prev, seg_prev_n};
+#ifdef LT_TRACE
+    if (lane == 0 && tile < 65536u) {
+      g_trace[3 * 4 * 65536 + 4 * tile + 0] = tr_flush;
+      g_trace[3 * 4 * 65536 + 4 * tile + 1] = tr_nflush & 0xFFFFull;
+      g_trace[3 * 4 * 65536 + 4 * tile + 2] = tr_nflush >> 16;
+      g_trace[3 * 4 * 65536 + 4 * tile + 3] = wall_clock64();
+    }
+#endif
+    cur = nxt;
+  }
+  if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
+}
 
-    // ---- one dense round from the shared ring (the only instance of the evaluation in the kernel) ----
-    unsigned h = 0;
-    int take = 0;
-    if (lane == 0) {
-      const unsigned hh = lds_ld(&ctl->head), tt = lds_ld(&ctl->tail);
-      const int avail = (int)(tt - hh);
-      // a partial round only when nobody is sweeping (nothing will fill it up soon), when the producer itself is
-      // blocked on the ring (kSweep), or when the wait has lasted
-      const bool partial_ok = st == kSweep || lds_ld(&ctl->n_sweeping) == 0u || patience > 24;
-      const int want = avail >= 64 ? 64 : (partial_ok ? avail : 0);
-      if (want > 0) {
-        unsigned expect = hh;
-        if (__hip_atomic_compare_exchange_strong(&ctl->head, &expect, hh + (unsigned)want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_WORKGROUP)) {
-          h = hh;
-          take = want;
-        }
-      }
+// Flat evaluation of the pair list: chunk c = pairs [64 c, 64 c + 64), dealt round-robin to the persistent waves.
+__global__ void __launch_bounds__(256)
+k_eval6(Score3Args a, Split6 sp, ScoreCfg cfg) {
+  if (a.err_flag && *a.err_flag == 7) return;  // the list overflowed: it has holes, the run is repeated (finish_run)
+  const unsigned n_waves = gridDim.x * 4u;
+  const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const int lane = lane_id();
+  // chunks of 64 records per region: lane r holds region r's record count and the inclusive prefix of the chunk counts
+  static_assert(kRegions6 == 64, "one lane per region");
+  const unsigned cnt_r = min(sp.counters[lane * 32], sp.region_cap);
+  const unsigned chunks_r = (cnt_r + 63u) >> 6;
+  unsigned incl = chunks_r;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned t = (unsigned)__shfl_up((int)incl, d);
+    if (lane >= d) incl += t;
+  }
+  const unsigned total_chunks = (unsigned)__shfl((int)incl, 63);
+  // the pair record of the wave's NEXT chunk is loaded while this one is evaluated (one dependent level less per round)
+  auto fetch = [&](unsigned c, size_t &p) -> uint4 {
+    uint4 r = uint4{kNoSeg, 0u, 0u, 0u};
+    p = 0;
+    if (c < total_chunks) {
+      const int reg = __builtin_ctzll(__ballot(incl > c));
+      const unsigned first = (unsigned)__shfl((int)(incl - chunks_r), reg);
+      const unsigned cnt = (unsigned)__shfl((int)cnt_r, reg);
+      const unsigned k = ((c - first) << 6) + (unsigned)lane;
+      p = (size_t)reg * sp.region_cap + k;
+      if (k < cnt) r = *reinterpret_cast<const uint4 *>(&sp.pairs[p]);
     }
-    h = (unsigned)__builtin_amdgcn_readfirstlane((int)h);
-    take = __builtin_amdgcn_readfirstlane(take);
-    if (take == 0) {
-      ++patience;
-#ifdef LT_TRACE
-      ++tr_sleeps;
-#endif
-      __builtin_amdgcn_s_sleep(2);
-      TR_ACC(4);
-      continue;
-    }
-    patience = 0;
-#ifdef LT_TRACE
-    ++tr_rounds;
-    const unsigned long long tr0 = wall_clock64();
-#endif
-    unsigned e = 0xFFFFu;
-    if (lane < take) {
-      volatile unsigned short *slot = reinterpret_cast<volatile unsigned short *>(&Q[(h + (unsigned)lane) & (kQ5 - 1)]);
-      int spins = 0;
-      do {
-        e = *slot;
-      } while (e == 0xFFFFu && ++spins < (1 << 22));
-      if (e == 0xFFFFu) ctl->err = 1;  // cannot happen: the producer writes its slots right after reserving them
-      *slot = 0xFFFFu;
-    }
-    const int ew = (int)(e >> 14), il = (int)((e >> 8) & 63u), w = (int)(e & 0xFFu);
-    const bool valid = lane < take && e != 0xFFFFu;
-    if (valid) {
-      unsigned char *theirs = smem_raw + (size_t)ew * per_wave;
-      const unsigned jrec = reinterpret_cast<const unsigned *>(theirs + oWP)[w];
-      const int nbs_j = __float_as_int(reinterpret_cast<const float4 *>(theirs + oWE)[w].w);
-      const unsigned irec = reinterpret_cast<const unsigned *>(theirs + oRI)[il];
-      const CRec &ci = a.cand[irec];
-      const CRec &cj = a.cand[jrec];
+    return r;
+  };
+  size_t p = 0, p_next = 0;
+  uint4 r = fetch(wave, p);
+  for (unsigned c = wave; c < total_chunks; c += n_waves) {
+    const uint4 r_next = fetch(c + n_waves, p_next);
+    if (r.x != kNoSeg) {  // not a segment header
+      const CRec &ci = a.cand[r.x];
+      const CRec &cj = a.cand[r.y];
       const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
                                    mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
                                    mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
-                                   mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg, a.cams[(int)((unsigned)nbs_j >> 8)]);
-      if (sc > 0.0)
-        atomicMax(&reinterpret_cast<unsigned long long *>(theirs + oS)[(nbs_j & 0xFF) * 64 + il],
-                  (unsigned long long)__double_as_longlong(sc));
+                                   mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg, a.cams[(int)(r.z >> 8)]);
+      *reinterpret_cast<double *>(&sp.pairs[p]) = sc;  // replaces (irec, jrec)
     }
-    n_eval_total += (unsigned long long)take;
-    // the producers' outstanding counts: behind the maxima (DS operations of a wave execute in order)
-#pragma unroll
-    for (int w2 = 0; w2 < 4; ++w2) {
-      const int c = __popcll(__ballot(lane < take && ew == w2));
-      if (c && lane == 0)
-        __hip_atomic_fetch_sub(&ctl->pend[w2], (unsigned)c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    r = r_next;
+    p = p_next;
+  }
+}
+
+// Per tile: maxima per (candidate, neighbour slot) over the tile's segments, sums in image-id order.
+template <bool kPerm>
+__global__ void __launch_bounds__(256)
+k_reduce6(Score3Args a, Split6 sp) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = lane_id();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_raw) + (size_t)wv * (size_t)a.max_nb * 64;
+  if (a.err_flag && *a.err_flag == 7) return;  // see k_eval6
+  const long long C = a.tri_off[a.G];
+  const unsigned n_tiles = (unsigned)((C + 63) >> 6);
+  for (unsigned tile = blockIdx.x * 4u + (unsigned)wv; tile < n_tiles; tile += gridDim.x * 4u) {
+  const long long tpos = (long long)tile * 64 + lane;
+  const bool active = tpos < C;
+  long long nb0 = 0;
+  int n_nb = 0;
+  if (active) {
+    const CandMeta mt = a.meta[tpos];
+    nb0 = (long long)(mt.nb >> 8);
+    n_nb = (int)(mt.nb & 0xFFu);
+  }
+  const uint2 th = sp.tile_head[tile];
+  unsigned seg = th.x, seg_n = th.y;  // the newest segment's count comes with the head: its pairs need no header read
+  if (seg == kNoSeg) {  // no pair survived the sweep: every candidate of the tile scores 0
+    if (active) a.score[tpos] = 0.0;
+    continue;
+  }
+  for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
+  const long long wave_nb0 = __shfl(nb0, 0);
+  const int wave_nnb = __shfl(n_nb, 0);
+  const int ordv = lane < wave_nnb ? a.blk_order[wave_nb0 + lane] : 0;
+  wave_lds_sync();
+  int guard = 0;
+  while (seg != kNoSeg && guard++ < (1 << 20)) {
+    // header: {kNoSeg, count, previous header, tile}; only a tile with several segments waits for it
+    uint4 sr = uint4{kNoSeg, seg_n & 0x7FFFFFFFu, kNoSeg, 0u};
+    if (guard > 1 || (seg_n >> 31)) sr = *reinterpret_cast<const uint4 *>(&sp.pairs[seg]);
+    for (unsigned k = (unsigned)lane; k < sr.y; k += 64) {
+      const uint4 r = *reinterpret_cast<const uint4 *>(&sp.pairs[(size_t)seg + 1 + k]);
+      const unsigned long long bits = ((unsigned long long)r.y << 32) | (unsigned long long)r.x;
+      if (__longlong_as_double((long long)bits) > 0.0) atomicMax(&S[(r.z & 0xFFu) * 64 + (r.w & 63u)], bits);
     }
-#ifdef LT_TRACE
-    tr_dense += wall_clock64() - tr0;
-#endif
-    TR_ACC(5);
+    seg = sr.z;
   }
-#ifdef LT_TRACE
-  if (lane == 0 && tr_id < 65536u) {
-    g_trace[2 * 4 * 65536 + 4 * tr_id + 1] = tr_final0;
-    g_trace[2 * 4 * 65536 + 4 * tr_id + 3] = wall_clock64();
-    g_trace[3 * 4 * 65536 + 4 * tr_id + 0] = tr_dense;
-    g_trace[3 * 4 * 65536 + 4 * tr_id + 1] = tr_rounds;
-    g_trace[3 * 4 * 65536 + 4 * tr_id + 2] = n_eval_total;
-    g_trace[3 * 4 * 65536 + 4 * tr_id + 3] = tr_sleeps | (tr_tiles << 32);
-    for (int k = 0; k < 7; ++k) g_trace[(k < 4 ? 0 : 1) * 4 * 65536 + 4 * tr_id + (k & 3)] = tr_acc[k];
+  wave_lds_sync();
+  double sum = 0.0;
+  const bool own = nb0 == wave_nb0;
+  int rmax = n_nb;
+  for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d));
+  for (int r = 0; r < rmax; ++r) {  // r is wave-uniform: the first image's order comes by readlane
+    const int k_own = __builtin_amdgcn_readlane(ordv, r);
+    if (r < n_nb) {
+      const int k = own ? k_own : a.blk_order[nb0 + r];
+      sum += __longlong_as_double((long long)S[k * 64 + lane]);
+    }
   }
-#endif
-  if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
-  if (lane == 0 && a.err_flag && lds_ld(&ctl->err) != 0u) *a.err_flag = 6;
+  if (active) a.score[tpos] = sum;
+  wave_lds_sync();  // S is reused by the wave's next tile
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2173,13 +1981,6 @@ size_t score3_lds_bytes(int max_nb, bool f32) {
   const size_t base = (f32 ? (size_t)kWin * 48 : (size_t)9 * kWin * 8 + (size_t)kWin * 4) + 64 * 8 + kSQCap * 4;
   return ((base + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
 }
-size_t score4_lds_bytes(int max_nb) {
-  return (size_t)(kWin4 + 4) * 32 + (size_t)kWin4 * 4 + (size_t)kQ4 * 2 + (size_t)max_nb * 64 * 8;
-}
-#ifndef LT_SCORE5_RESIDENT
-#define LT_SCORE5_RESIDENT 2  // persistent 4-wave workgroups per CU (two waves per SIMD at <= 256 registers)
-#endif
-size_t score5_lds_bytes(int max_nb) { return 4 * score5_wave_bytes(max_nb) + (size_t)kQ5 * 2 + sizeof(Ctl5) + 28; }
 size_t cand_meta_bytes() { return sizeof(CandMeta); }
 int score3_tile_buckets() { return kTileBuckets * kTileQueues; }  // counters (128 B apart) / lists: one per (queue, class)
 // (A two-kernel form -- light sweep writing per-tile pair lists, then a dense evaluation kernel -- was
@@ -2191,7 +1992,8 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
                    unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap, const unsigned *place,
-                   unsigned *rec, const float *st_z, int *err_flag) {
+                   unsigned *rec, const float *st_z, int *err_flag, void *split_pairs, unsigned *split_tile_head,
+                   unsigned *split_counters, unsigned split_region_cap, void *split_tile_lohi) {
   // place / rec: depth-sorted sweep over STAGED records (one-pass exhaustive mode): place[natural position] = record,
   // rec (scratch, one word per candidate) receives the record of every sorted position
   if (C <= 0) return;
@@ -2206,7 +2008,8 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   const long long n_tiles = (C + 63) / 64;
   hipLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st, G,
                      cand_node, tri_off, node_img, nb_off, reinterpret_cast<CandMeta *>(meta), draw, bucket_cnt, bucket_list,
-                     bucket_cap);
+                     bucket_cap, split_pairs ? split_counters : nullptr,
+                     split_pairs ? reinterpret_cast<uint2 *>(split_tile_lohi) : nullptr);
   Score3Args a;
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand;
   a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
@@ -2217,6 +2020,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.bucket_cnt = bucket_cnt; a.bucket_list = bucket_list; a.bucket_cap = bucket_cap;
   a.max_nb = max_nb;
   a.err_flag = err_flag;
+  a.tile_lohi = reinterpret_cast<const uint2 *>(split_tile_lohi);
   if (ev_before) (void)hipEventRecord(ev_before, st);
   const bool sorted = perm != nullptr && f32 && !perm_is_placement;
   if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
@@ -2227,23 +2031,32 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
     a.perm = rec;
     a.spos = perm;
   }
-  // the natural order (no depth sort): k_score4; LT_TEST_SCORE_V3 keeps k_score3 for it, LT_TEST_SCORE_F64 implies that
-  static const bool force_v3 = getenv("LT_TEST_SCORE_V3") != nullptr;
-  static const bool force_v4 = getenv("LT_TEST_SCORE_V4") != nullptr;
-  if (f32 && !sorted && !force_v3 && !force_v4 && max_nb <= 255 && score5_lds_bytes(max_nb) <= 160 * 1024) {
-    const size_t lds5 = score5_lds_bytes(max_nb);
-    const long long per_cu5 = std::max<long long>(1, std::min<long long>(LT_SCORE5_RESIDENT, (long long)(160 * 1024 / lds5)));
-    const dim3 grid5((unsigned)std::min<long long>((n_tiles + 3) / 4, per_cu5 * n_cu)), block5(256);
-    if (perm_is_placement) hipLaunchKernelGGL((k_score5<true>), grid5, block5, lds5, st, a, cfg, scaleinv_guard2);
-    else hipLaunchKernelGGL((k_score5<false>), grid5, block5, lds5, st, a, cfg, scaleinv_guard2);
-    return;
-  }
-  if (f32 && !sorted && !force_v3 && max_nb <= 255) {
-    const size_t lds4 = score4_lds_bytes(max_nb);
-    const long long per_cu4 = std::max<long long>(1, std::min<long long>(LT_SCORE4_RESIDENT, (long long)(160 * 1024 / lds4)));
-    const dim3 grid4((unsigned)std::min<long long>(n_tiles, per_cu4 * n_cu)), block4(64);
-    if (perm_is_placement) hipLaunchKernelGGL((k_score4<true>), grid4, block4, lds4, st, a, cfg, scaleinv_guard2);
-    else hipLaunchKernelGGL((k_score4<false>), grid4, block4, lds4, st, a, cfg, scaleinv_guard2);
+  // LT_SCORE_SPLIT: the natural order (no depth sort) through the three-kernel form k_sweep6 / k_eval6 / k_reduce6
+  // (measured: not faster than the fused kernel; kept selectable, same results)
+  if (f32 && !sorted && max_nb <= 255 && split_pairs) {
+    Split6 sp;
+    sp.pairs = reinterpret_cast<PairRec6 *>(split_pairs);
+    sp.tile_head = reinterpret_cast<uint2 *>(split_tile_head); sp.counters = split_counters; sp.region_cap = split_region_cap;
+    // resident waves of the three kernels (occupancy query once per process; the grids are persistent)
+    static int occ_sweep = 0, occ_eval = 0, occ_red = 0;
+    const size_t lds_sw = (size_t)(kWin4 + 4) * 32 + (size_t)kWin4 * 8 + (size_t)kWin4 * 4 + (size_t)(kQ4 + 64) * 2;
+    const size_t lds_red = (size_t)4 * max_nb * 64 * 8;
+    if (occ_sweep == 0) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_sweep, k_sweep6<true>, 64, lds_sw) != hipSuccess || occ_sweep <= 0) occ_sweep = 8;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_eval, k_eval6, 256, 0) != hipSuccess || occ_eval <= 0) occ_eval = 2;
+      occ_sweep = std::min(occ_sweep, (int)LT_SWEEP6_RESIDENT);  // (the API counts LDS and registers; 64-thread workgroups)
+      if (const char *e = getenv("LT_SWEEP6_RESIDENT")) occ_sweep = std::max(1, atoi(e));
+      if (const char *e = getenv("LT_EVAL6_RESIDENT")) occ_eval = std::max(1, atoi(e));
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_red, k_reduce6<true>, 256, lds_red) != hipSuccess || occ_red <= 0) occ_red = 1;
+    const dim3 g_sw((unsigned)std::min<long long>(n_tiles, (long long)occ_sweep * n_cu));
+    const dim3 g_ev((unsigned)((long long)occ_eval * n_cu));
+    const dim3 g_rd((unsigned)std::min<long long>((n_tiles + 3) / 4, (long long)occ_red * n_cu));
+    if (perm_is_placement) hipLaunchKernelGGL((k_sweep6<true>), g_sw, dim3(64), lds_sw, st, a, sp, scaleinv_guard2);
+    else hipLaunchKernelGGL((k_sweep6<false>), g_sw, dim3(64), lds_sw, st, a, sp, scaleinv_guard2);
+    hipLaunchKernelGGL(k_eval6, g_ev, dim3(256), 0, st, a, sp, cfg);
+    if (perm_is_placement) hipLaunchKernelGGL((k_reduce6<true>), g_rd, dim3(256), lds_red, st, a, sp);
+    else hipLaunchKernelGGL((k_reduce6<false>), g_rd, dim3(256), lds_red, st, a, sp);
     return;
   }
   // persistent grid: as many single-wave workgroups as fit at once (LDS; registers allow LT_SCORE_RESIDENT per CU)

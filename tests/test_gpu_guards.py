@@ -39,7 +39,7 @@ def _same(a, b):
 def clean_env():
     keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES",
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
-            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS")
+            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_SCORE_SPLIT", "LT_TEST_SPLIT_PAIR_CAP")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -182,9 +182,7 @@ def test_single_precision_sweep_is_conservative(gpu_lib, clean_env, exhaustive):
         assert base[5]["candidates"] > 0
         # the float guards pass a superset of what the double guards pass, both a subset of everything
         assert outs["LT_TEST_SCORE_F64"][4]["pairs_eval"] <= base[4]["pairs_eval"] <= outs["LT_TEST_NO_SCORE_GUARDS"][4]["pairs_eval"]
-        # (k_score4 sweeps on the endpoint-distance guards only; k_score3's cosine guard -- the double-precision sweep
-        # keeps it -- rejects a further ~2.5 % of the pairs before the exact evaluation does)
-        assert base[4]["pairs_eval"] <= 1.10 * outs["LT_TEST_SCORE_F64"][4]["pairs_eval"] + 64
+        assert base[4]["pairs_eval"] <= 1.01 * outs["LT_TEST_SCORE_F64"][4]["pairs_eval"] + 64
 
 
 def test_candidate_count_stays_on_device(gpu_lib, clean_env):
@@ -401,3 +399,26 @@ def test_per_kernel_event_levels(gpu_lib, clean_env):
     assert seen["0"]["k_score3"] == 0 and seen["0"]["k_gates"] == 0
     for t in seen.values():
         assert t["gen"] > 0 and t["score"] > 0 and t["run"] >= t["gen"] + t["score"]
+
+
+@pytest.mark.parametrize("exhaustive", [False, True])
+def test_three_kernel_scoring_equals_fused(gpu_lib, clean_env, exhaustive):
+    """LT_SCORE_SPLIT: k_sweep6 (sweep -> global pair list) + k_eval6 (flat evaluation) + k_reduce6 (per-tile maxima and
+    ordered sums) must give the bits of the fused k_score3 -- same pairs up to the sweep's conservative guards (the split
+    sweep has no cosine guard: a few per cent more pairs reach pair_score, which gates them to 0), same pair_score,
+    same maxima and sums.  Exhaustive mode runs it on the unsorted order.  A pair list that is too small (forced
+    here) raises the device flag and the run is repeated with the fused kernel."""
+    sc = syn.make_scene(n_views=14, n_segs=140, n_neighbors=6, seed=77)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    if exhaustive:
+        os.environ["LT_TEST_SCORE_UNSORTED"] = "1"
+    base = _results(run_product(sc, cfg, exhaustive=exhaustive))
+    assert base[5]["candidates"] > 1000
+    os.environ["LT_SCORE_SPLIT"] = "1"
+    split = _results(run_product(sc, cfg, exhaustive=exhaustive))
+    _same(base, split)
+    assert base[4]["pairs_eval"] <= split[4]["pairs_eval"] <= 1.25 * base[4]["pairs_eval"] + 64
+    os.environ["LT_TEST_SPLIT_PAIR_CAP"] = "64"
+    overflow = _results(run_product(sc, cfg, exhaustive=exhaustive))
+    _same(base, overflow)
+    assert overflow[4]["pairs_eval"] == base[4]["pairs_eval"]  # the repeated run used the fused kernel

@@ -1,4 +1,4 @@
-"""Developer tool: per-tile phase breakdown of k_score4 from a -DLT_TRACE build (limap_amd/variants/libT.so, made by
+"""Developer tool: per-tile phase breakdown of k_sweep6 from a -DLT_TRACE build (limap_amd/variants/libT.so, made by
    bash tools/build_variant.sh T -DLT_TRACE):  python tools/trace_score4.py   (on the GPU box)"""
 import ctypes as C, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +23,7 @@ buf = np.zeros(n, dtype=np.uint64)
 assert L.lt_debug_read_trace(buf.ctypes.data_as(C.c_void_p), C.c_size_t(n)) == 0
 all_ = buf.reshape(4, 65536, 4).astype(np.int64)
 t, x = all_[2], all_[3]
-act = t[:, 3] > 0
+act = x[:, 3] > 0
 t, x = t[act], x[act]
 t0 = t[:, 0].min()
 us = (t - t0) / 100.0
@@ -43,7 +43,7 @@ def line(name, d):
           np.percentile(d, [10, 50, 90, 100]).round(2))
 line("prologue + first window", stage)
 line("sweep (+ later windows)", sweep)
-line("dense rounds", dense)
+line("flush (atomic + pair writes)", dense)
 line("ordered sums / store", epi)
 line("tile total", tot)
 print("per dense round us:", (dense.sum() / max(rounds.sum(), 1)).round(2))
