@@ -1272,7 +1272,16 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       if (kF32) {
         const int wlast = cnt > 0 ? w0 + cnt - 1 : 0;  // reads beyond the lane's range are clamped, then masked
         const int wbase = cnt > 0 ? w0 : 0;
-        for (int t = 0; t < cmax; t += 4) {
+        // one loop, ONE instance of the dense evaluation in the kernel's code (it is ~2000 instructions): in the sweep
+        // when the queue runs full, and behind the last chunk's sweep for whatever is left
+        const bool last_chunk = wb + kWin >= hi;
+        for (int t = 0;;) {
+          const bool swept = t >= cmax;
+          if (swept ? (last_chunk && qn > 0) : (qn > kSQCap - 256)) {
+            drain();
+            continue;
+          }
+          if (swept) break;
           float4 A[4], B[4];
           float2 E[4];
 #pragma unroll
@@ -1306,7 +1315,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
               qn += __popcll(m);
             }
           }
-          if (qn > kSQCap - 256) drain();
+          t += 4;
         }
       } else {
         for (int t = 0; t < cmax; ++t) {
@@ -1333,7 +1342,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       }
     }
     LT_TRACE_MARK(2, tile, 2);
-    drain();
+    if (!kF32) drain();  // (the single-precision sweep drains behind its last chunk, see above)
     LT_TRACE_MARK(2, tile, 3);
 
     if (active) {

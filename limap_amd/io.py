@@ -127,12 +127,15 @@ def imagecols_from_dict(d):
     return ImageCollection(views)
 
 
-def imagecols_to_dict(imagecols, hw=(-1, -1)):
+def imagecols_to_dict(imagecols, hw=(0, 0)):
+    """``ImageCollection::as_dict()`` (base/image_collection.cc:158-171) with one PINHOLE camera per image, as
+    ``Camera(model, params, cam_id)`` leaves it (camera.cc:65-75, 265-274: height / width of a camera built without
+    them are colmap's defaults 0 / 0, its ``initialized`` list is empty)."""
     cameras, images = {}, {}
     for n, img_id in enumerate(imagecols.get_img_ids()):
         v = imagecols.camview(img_id)
         cameras[n] = dict(model_id=1, params=[float(x) for x in v.kvec], cam_id=n, height=int(hw[0]), width=int(hw[1]),
-                          initialized=[True] * 4)
+                          initialized=[])
         images[int(img_id)] = dict(cam_id=n, pose=dict(qvec=np.asarray(v.qvec, float), tvec=np.asarray(v.tvec, float),
                                                        initialized=True), image_name=v.image_name())
     return dict(cameras=cameras, images=images)
@@ -230,6 +233,9 @@ def read_folder_linetracks(folder):
     return [read_track(os.path.join(folder, f"track_{i}.txt")) for i in range(n)]
 
 
+_ALLTRACKS_SEP = " " + " " * 18
+
+
 def save_txt_linetracks(fname, tracks, n_visible_views=4):
     """alltracks.txt (util/io.py:259-292): only tracks seen in >= n_visible_views images."""
     os.makedirs(os.path.dirname(os.path.abspath(fname)), exist_ok=True)
@@ -238,8 +244,10 @@ def save_txt_linetracks(fname, tracks, n_visible_views=4):
         f.write(f"{len(keep)}\n")
         for i, t in enumerate(keep):
             f.write(f"{i} {t.count_lines()} {t.count_images()}\n")
-            f.write(" ".join(f"{v:.10f}" for v in t.line.start) + "\n")
-            f.write(" ".join(f"{v:.10f}" for v in t.line.end) + "\n")
+            # the reference's f-strings continue over source lines with a backslash: the three coordinates are
+            # separated by one blank plus the 18 blanks of the next line's indentation (util/io.py:277-286)
+            f.write(_ALLTRACKS_SEP.join(f"{v:.10f}" for v in t.line.start) + "\n")
+            f.write(_ALLTRACKS_SEP.join(f"{v:.10f}" for v in t.line.end) + "\n")
             f.write("".join(f"{v} " for v in t.image_id_list) + "\n")
             f.write("".join(f"{v} " for v in t.line_id_list) + "\n")
 

@@ -71,3 +71,76 @@ def module():
         mod.KIND = "reference"
         _mod = mod
     return _mod
+
+
+# ---- file formats through the reference's own code (tests/test_io_formats.py, tests/golden/make_io_golden.py) -------
+_raw = None
+
+
+def _dll():
+    """The reference-backed library itself (entry points that have no ora_* counterpart)."""
+    global _raw
+    if _raw is None:
+        path = build()
+        if path is None:
+            raise RuntimeError("oracle/_ref is not built and /root/reference is not present")
+        _raw = C.PyDLL(path)
+        _raw.ref_imagecols_as_dict.restype = C.py_object
+        _raw.ref_imagecols_from_dict.argtypes = [C.py_object, C.c_int] + [C.c_void_p] * 4
+        _raw.ref_track_write.restype = C.c_int
+        _raw.ref_track_read.restype = C.c_int
+    return _raw
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def track_write(fname, line6, image_ids, line_ids, line2d, node_ids=None, scores=None, line3d=None):
+    """limap::LineTrack::Write (base/linetrack.cc:133-209) on a track given as arrays."""
+    import numpy as np
+    n = len(image_ids)
+    line6 = np.ascontiguousarray(line6, np.float64)
+    img = np.ascontiguousarray(image_ids, np.int32); lid = np.ascontiguousarray(line_ids, np.int32)
+    l2 = np.ascontiguousarray(line2d, np.float64).reshape(n, 4)
+    flags = (1 if node_ids is not None else 0) | (2 if scores is not None else 0) | (4 if line3d is not None else 0)
+    nid = np.ascontiguousarray(node_ids if node_ids is not None else np.zeros(n), np.int32)
+    sc = np.ascontiguousarray(scores if scores is not None else np.zeros(n), np.float64)
+    l3 = np.ascontiguousarray(line3d if line3d is not None else np.zeros((n, 6)), np.float64).reshape(n, 6)
+    rc = _dll().ref_track_write(os.fsencode(fname), _ptr(line6), C.c_int(n), _ptr(img), _ptr(lid), _ptr(l2), C.c_int(flags),
+                                _ptr(nid), _ptr(sc), _ptr(l3))
+    if rc != 0:
+        raise RuntimeError("LineTrack::Write failed")
+
+
+def track_read(fname, cap=1 << 16):
+    """limap::LineTrack::Read (base/linetrack.cc:211-270): dict of arrays (aux lists zero where the file has none)."""
+    import numpy as np
+    line6 = np.zeros(6); img = np.zeros(cap, np.int32); lid = np.zeros(cap, np.int32); l2 = np.zeros((cap, 4))
+    nid = np.zeros(cap, np.int32); sc = np.zeros(cap); l3 = np.zeros((cap, 6))
+    n = _dll().ref_track_read(os.fsencode(fname), _ptr(line6), C.c_int(cap), _ptr(img), _ptr(lid), _ptr(l2), _ptr(nid),
+                              _ptr(sc), _ptr(l3))
+    if n < 0:
+        raise RuntimeError("LineTrack::Read failed (%d)" % n)
+    return dict(line=line6, image_ids=img[:n].copy(), line_ids=lid[:n].copy(), line2d=l2[:n].copy(), node_ids=nid[:n].copy(),
+                scores=sc[:n].copy(), line3d=l3[:n].copy())
+
+
+def imagecols_as_dict(img_ids, kvec, qvec, tvec):
+    """limap::ImageCollection::as_dict() (base/image_collection.cc:158-171) for PINHOLE cameras, one per image."""
+    import numpy as np
+    ids = np.ascontiguousarray(img_ids, np.int32)
+    k = np.ascontiguousarray(kvec, np.float64); q = np.ascontiguousarray(qvec, np.float64)
+    t = np.ascontiguousarray(tvec, np.float64)
+    return _dll().ref_imagecols_as_dict(C.c_int(len(ids)), _ptr(ids), _ptr(k), _ptr(q), _ptr(t))
+
+
+def imagecols_from_dict(d):
+    """limap::ImageCollection(py::dict) -> (img_ids, kvec, qvec, tvec) in ascending image id."""
+    import numpy as np
+    cap = len(d["images"]) + 1
+    ids = np.zeros(cap, np.int32); k = np.zeros((cap, 4)); q = np.zeros((cap, 4)); t = np.zeros((cap, 3))
+    n = _dll().ref_imagecols_from_dict(d, C.c_int(cap), _ptr(ids), _ptr(k), _ptr(q), _ptr(t))
+    if n < 0:
+        raise RuntimeError("ImageCollection(dict) failed (%d)" % n)
+    return ids[:n], k[:n], q[:n], t[:n]

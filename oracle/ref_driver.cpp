@@ -592,4 +592,98 @@ void ref_aggregate_line3d_list(int n, const double *lines10, const double *score
   out7[6] = r.uncertainty;
 }
 
+// LineTrack::Write / LineTrack::Read (base/linetrack.cc:133-209, 211-270) over flat arrays: the reference's own file
+// format code, for the byte-level comparison with limap_amd/io.py (tests/test_io_formats.py).  These two exist only
+// in the reference-backed library (no ora_* counterpart).  flags: bit 0 node_id_list, bit 1 score_list, bit 2 line3d_list.
+int ref_track_write(const char *filename, const double line6[6], int n, const int32_t *img_ids, const int32_t *line_ids,
+                    const double *line2d4, int flags, const int32_t *node_ids, const double *scores, const double *line3d6) {
+  LineTrack tr;
+  tr.line = Line3d(V3D(line6[0], line6[1], line6[2]), V3D(line6[3], line6[4], line6[5]));
+  for (int i = 0; i < n; ++i) {
+    tr.image_id_list.push_back(img_ids[i]);
+    tr.line_id_list.push_back(line_ids[i]);
+    tr.line2d_list.push_back(Line2d(V2D(line2d4[4 * i], line2d4[4 * i + 1]), V2D(line2d4[4 * i + 2], line2d4[4 * i + 3])));
+    if (flags & 1) tr.node_id_list.push_back(node_ids[i]);
+    if (flags & 2) tr.score_list.push_back(scores[i]);
+    if (flags & 4)
+      tr.line3d_list.push_back(Line3d(V3D(line3d6[6 * i], line3d6[6 * i + 1], line3d6[6 * i + 2]),
+                                      V3D(line3d6[6 * i + 3], line3d6[6 * i + 4], line3d6[6 * i + 5])));
+  }
+  try {
+    tr.Write(filename);
+  } catch (const std::exception &) {
+    return 1;
+  }
+  return 0;
+}
+// returns the number of supporting lines (-1: error, -2: more than cap); the aux arrays are filled as far as the file
+// has them (LineTrack::Read resizes all lists to n and returns early at "END")
+int ref_track_read(const char *filename, double line6[6], int cap, int32_t *img_ids, int32_t *line_ids, double *line2d4,
+                   int32_t *node_ids, double *scores, double *line3d6) {
+  LineTrack tr;
+  try {
+    tr.Read(filename);
+  } catch (const std::exception &) {
+    return -1;
+  }
+  const int n = (int)tr.image_id_list.size();
+  if (n > cap) return -2;
+  for (int k = 0; k < 3; ++k) { line6[k] = tr.line.start[k]; line6[3 + k] = tr.line.end[k]; }
+  for (int i = 0; i < n; ++i) {
+    img_ids[i] = tr.image_id_list[i];
+    line_ids[i] = tr.line_id_list[i];
+    const Line2d &l = tr.line2d_list[i];
+    line2d4[4 * i] = l.start[0]; line2d4[4 * i + 1] = l.start[1]; line2d4[4 * i + 2] = l.end[0]; line2d4[4 * i + 3] = l.end[1];
+    node_ids[i] = (size_t)i < tr.node_id_list.size() ? tr.node_id_list[i] : 0;
+    scores[i] = (size_t)i < tr.score_list.size() ? tr.score_list[i] : 0.0;
+    for (int k = 0; k < 3; ++k) {
+      line3d6[6 * i + k] = (size_t)i < tr.line3d_list.size() ? tr.line3d_list[i].start[k] : 0.0;
+      line3d6[6 * i + 3 + k] = (size_t)i < tr.line3d_list.size() ? tr.line3d_list[i].end[k] : 0.0;
+    }
+  }
+  return n;
+}
+
+// ImageCollection::as_dict() (base/image_collection.cc:158-171, camera.cc:265-294) of a collection built like ref_init
+// builds it, plus ImageCollection(py::dict) -> arrays for the way back: what limap's imagecols.npy holds.  Returns a new
+// reference to the dict (call through ctypes.PyDLL with restype py_object).
+PyObject *ref_imagecols_as_dict(int n_img, const int32_t *img_ids, const double *kvec, const double *qvec, const double *tvec) {
+  try {
+    std::map<int, Camera> cameras;
+    std::map<int, CameraImage> images;
+    for (int i = 0; i < n_img; ++i) {
+      const int id = img_ids[i];
+      Camera cam(1, std::vector<double>{kvec[4 * i], kvec[4 * i + 1], kvec[4 * i + 2], kvec[4 * i + 3]}, i);
+      cameras.insert(std::make_pair(i, cam));
+      CameraPose pose(V4D(qvec[4 * i], qvec[4 * i + 1], qvec[4 * i + 2], qvec[4 * i + 3]),
+                      V3D(tvec[3 * i], tvec[3 * i + 1], tvec[3 * i + 2]));
+      images.insert(std::make_pair(id, CameraImage(i, pose)));
+    }
+    ImageCollection ic(cameras, images);
+    py::dict d = ic.as_dict();
+    return d.release().ptr();
+  } catch (const std::exception &) {
+    Py_RETURN_NONE;
+  }
+}
+// ImageCollection(py::dict) as the reference parses it: out arrays in ascending image id; returns the image count
+int ref_imagecols_from_dict(PyObject *dict, int cap, int32_t *img_ids, double *kvec, double *qvec, double *tvec) {
+  try {
+    ImageCollection ic(py::reinterpret_borrow<py::dict>(dict));
+    std::vector<int> ids = ic.get_img_ids();
+    if ((int)ids.size() > cap) return -2;
+    for (size_t i = 0; i < ids.size(); ++i) {
+      CameraView v = ic.camview(ids[i]);
+      img_ids[i] = ids[i];
+      M3D K = v.K();
+      kvec[4 * i] = K(0, 0); kvec[4 * i + 1] = K(1, 1); kvec[4 * i + 2] = K(0, 2); kvec[4 * i + 3] = K(1, 2);
+      for (int k = 0; k < 4; ++k) qvec[4 * i + k] = v.pose.qvec[k];
+      for (int k = 0; k < 3; ++k) tvec[3 * i + k] = v.pose.tvec[k];
+    }
+    return (int)ids.size();
+  } catch (const std::exception &) {
+    return -1;
+  }
+}
+
 }  // extern "C"

@@ -122,3 +122,155 @@ def test_scene_folder_end_to_end(gpu_lib, oracle, tmp_path):
     ltio.save_folder_linetracks(str(tmp_path / "finaltracks"), tracks)
     back = ltio.read_folder_linetracks(str(tmp_path / "finaltracks"))
     assert len(back) == len(tracks) and back[0].image_id_list == tracks[0].image_id_list
+
+
+# ---- against the reference's own writers / readers ---------------------------------------------
+# tests/golden/io/ was written by /root/reference/src/limap/util/io.py (imported under stub modules) and by
+# limap::LineTrack::Write / limap::ImageCollection::as_dict of oracle/_ref = the reference's sources compiled unmodified
+# (tests/golden/make_io_golden.py).  limap_amd/io.py must write the same BYTES and read the same values.
+import importlib.util
+import sys
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io")
+
+
+def _golden_module():
+    spec = importlib.util.spec_from_file_location("make_io_golden", os.path.join(os.path.dirname(GOLD), "make_io_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _tracks_from(inputs):
+    out = []
+    for t in inputs["tracks"]:
+        tr = base.LineTrack()
+        tr.line = base.Line3d(t["line"][:3], t["line"][3:])
+        tr.image_id_list = [int(i) for i in t["image_ids"]]
+        tr.line_id_list = [int(i) for i in t["line_ids"]]
+        tr.line2d_list = [base.Line2d(s[:2], s[2:]) for s in t["line2d"]]
+        tr.node_id_list = [int(i) for i in t["node_ids"]]
+        tr.score_list = [float(s) for s in t["scores"]]
+        tr.line3d_list = [base.Line3d(s[:3], s[3:]) for s in t["line3d"]]
+        out.append(tr)
+    return out
+
+
+def _bytes(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def test_writers_produce_the_references_bytes(tmp_path):
+    x = _golden_module().fixed_inputs()
+    out = str(tmp_path)
+    ltio.save_txt_metainfos(os.path.join(out, "metainfos.txt"), x["neighbors"], x["ranges"])
+    ltio.save_txt_segments(out, 12, x["segs"])
+    ltio.save_txt_segments(out, 13, np.zeros((0, 4)))
+    ltio.save_matches(out, 3, x["matches"])
+    tracks = _tracks_from(x)
+    ltio.save_txt_linetracks(os.path.join(out, "alltracks_nv1.txt"), tracks, n_visible_views=1)
+    ltio.save_txt_linetracks(os.path.join(out, "alltracks_nv4.txt"), tracks, n_visible_views=4)
+    ltio.save_folder_linetracks(os.path.join(out, "finaltracks"), tracks)
+    t0 = _tracks_from(x)[0]
+    t0.node_id_list, t0.score_list, t0.line3d_list = [], [], []
+    ltio.write_track(os.path.join(out, "track_noaux.txt"), t0)
+    c = x["cams"]
+    ltio.save_imagecols(os.path.join(out, "imagecols.npy"), base.ImageCollection.from_arrays(c["img_ids"], c["kvec"], c["qvec"], c["tvec"]))
+    names = ["metainfos.txt", "segments_12.txt", "segments_13.txt", "alltracks_nv1.txt", "alltracks_nv4.txt",
+             "track_noaux.txt"] + [os.path.join("finaltracks", f"track_{i}.txt") for i in range(3)]
+    for n in names:
+        assert _bytes(os.path.join(out, n)) == _bytes(os.path.join(GOLD, n)), f"{n}: bytes differ from the reference's file"
+    # pickled objects: same structure, types and values (the pickle stream itself depends on numpy's version)
+    got, ref = ltio.read_npy(os.path.join(out, "matches_3.npy")).item(), np.load(os.path.join(GOLD, "matches_3.npy"), allow_pickle=True).item()
+    assert list(got) == list(ref)
+    for k in ref:
+        assert got[k].dtype == ref[k].dtype and np.array_equal(got[k], ref[k])
+    got, ref = ltio.read_npy(os.path.join(out, "imagecols.npy")).item(), np.load(os.path.join(GOLD, "imagecols.npy"), allow_pickle=True).item()
+    assert list(got) == list(ref) == ["cameras", "images"]
+    assert list(got["cameras"]) == list(ref["cameras"]) and list(got["images"]) == list(ref["images"])
+    for k in ref["cameras"]:
+        assert list(got["cameras"][k]) == list(ref["cameras"][k])
+        for f in ref["cameras"][k]:
+            assert got["cameras"][k][f] == ref["cameras"][k][f], (k, f)
+    for k in ref["images"]:
+        g, r = got["images"][k], ref["images"][k]
+        assert list(g) == list(r) and g["cam_id"] == r["cam_id"] and g["image_name"] == r["image_name"]
+        assert list(g["pose"]) == list(r["pose"]) and g["pose"]["initialized"] == r["pose"]["initialized"]
+        np.testing.assert_allclose(g["pose"]["qvec"], r["pose"]["qvec"], rtol=0, atol=1e-16)  # CameraPose normalises
+        assert np.array_equal(g["pose"]["tvec"], r["pose"]["tvec"])
+
+
+def test_readers_parse_the_references_files():
+    x = _golden_module().fixed_inputs()
+    nb, rng = ltio.read_txt_metainfos(os.path.join(GOLD, "metainfos.txt"))
+    assert nb == x["neighbors"] and list(nb) == list(x["neighbors"])
+    assert np.array_equal(rng[0], x["ranges"][0]) and np.array_equal(rng[1], x["ranges"][1])
+    assert np.array_equal(ltio.read_txt_segments(GOLD, 12), x["segs"])
+    assert ltio.read_txt_segments(GOLD, 13).shape == (0, 4)
+    m = ltio.read_matches(GOLD, 3)
+    assert sorted(m) == sorted(x["matches"]) and all(np.array_equal(m[k], x["matches"][k]) for k in m)
+    tracks = ltio.read_folder_linetracks(os.path.join(GOLD, "finaltracks"))
+    assert len(tracks) == 3
+    for tr, t in zip(tracks, x["tracks"]):
+        assert tr.image_id_list == [int(i) for i in t["image_ids"]] and tr.line_id_list == [int(i) for i in t["line_ids"]]
+        assert tr.node_id_list == [int(i) for i in t["node_ids"]]
+        want = np.where(np.isnan(t["line"]), 0.0, t["line"])
+        np.testing.assert_allclose(tr.line.as_array().ravel(), want, rtol=0, atol=0.5e-10 + 1e-16)
+        np.testing.assert_allclose(np.array([l.as_array().ravel() for l in tr.line2d_list]), t["line2d"], rtol=0, atol=0.51e-10)
+        np.testing.assert_allclose(tr.score_list, t["scores"], rtol=0, atol=0.51e-10)
+        np.testing.assert_allclose(np.array([l.as_array().ravel() for l in tr.line3d_list]), t["line3d"], rtol=0, atol=0.51e-10)
+    t0 = ltio.read_track(os.path.join(GOLD, "track_noaux.txt"))
+    assert t0.node_id_list == [] and t0.score_list == [] and t0.line3d_list == [] and len(t0.line2d_list) == 3
+    ic = ltio.read_imagecols(os.path.join(GOLD, "imagecols.npy"))
+    c = x["cams"]
+    assert ic.get_img_ids() == [int(i) for i in c["img_ids"]]
+    for n, i in enumerate(ic.get_img_ids()):
+        assert np.array_equal(ic.camview(i).kvec, c["kvec"][n]) and np.array_equal(ic.camview(i).tvec, c["tvec"][n])
+        np.testing.assert_allclose(ic.camview(i).qvec, c["qvec"][n] / np.linalg.norm(c["qvec"][n]), rtol=0, atol=1e-15)
+
+
+def test_track_files_both_ways_through_the_reference(tmp_path):
+    """limap::LineTrack::Read (oracle/_ref) on files written here, and read_track on files written by LineTrack::Write."""
+    from oracle import ref as oref
+    if not oref.available():
+        pytest.skip("oracle/_ref is not built and /root/reference is not present")
+    x = _golden_module().fixed_inputs()
+    for n, (tr, t) in enumerate(zip(_tracks_from(x), x["tracks"])):
+        mine, theirs = str(tmp_path / f"mine_{n}.txt"), str(tmp_path / f"theirs_{n}.txt")
+        ltio.write_track(mine, tr)
+        oref.track_write(theirs, t["line"], t["image_ids"], t["line_ids"], t["line2d"], t["node_ids"], t["scores"], t["line3d"])
+        assert _bytes(mine) == _bytes(theirs)
+        back = oref.track_read(mine)       # the reference reads our file
+        again = ltio.read_track(theirs)    # we read the reference's file
+        assert list(back["image_ids"]) == again.image_id_list == tr.image_id_list
+        assert list(back["line_ids"]) == again.line_id_list and list(back["node_ids"]) == again.node_id_list
+        assert np.array_equal(back["line"], again.line.as_array().ravel())
+        assert np.array_equal(back["line2d"], np.array([l.as_array().ravel() for l in again.line2d_list]))
+        assert np.array_equal(back["scores"], np.array(again.score_list))
+        assert np.array_equal(back["line3d"], np.array([l.as_array().ravel() for l in again.line3d_list]))
+    # ImageCollection: our dict through the reference's constructor, the reference's dict through ours
+    c = x["cams"]
+    ic = base.ImageCollection.from_arrays(c["img_ids"], c["kvec"], c["qvec"], c["tvec"])
+    ids, k, q, t = oref.imagecols_from_dict(ltio.imagecols_to_dict(ic))
+    assert np.array_equal(ids, c["img_ids"]) and np.array_equal(k, c["kvec"]) and np.array_equal(t, c["tvec"])
+    np.testing.assert_allclose(q, c["qvec"] / np.linalg.norm(c["qvec"], axis=1, keepdims=True), rtol=0, atol=1e-15)
+    ic2 = ltio.imagecols_from_dict(oref.imagecols_as_dict(c["img_ids"], c["kvec"], c["qvec"], c["tvec"]))
+    assert ic2.get_img_ids() == [int(i) for i in c["img_ids"]]
+
+
+def test_golden_io_files_are_what_the_reference_writes_today(tmp_path):
+    """Where /root/reference exists (the build container): regenerate the golden files and compare with the committed ones."""
+    mod = _golden_module()
+    if not os.path.exists(mod.REF_IO):
+        pytest.skip("/root/reference is not present")
+    mod.write_all(str(tmp_path))
+    for root, _, files in os.walk(GOLD):
+        for f in files:
+            rel = os.path.relpath(os.path.join(root, f), GOLD)
+            if rel.endswith(".npy"):
+                a = np.load(os.path.join(GOLD, rel), allow_pickle=True).item()
+                b = np.load(os.path.join(str(tmp_path), rel), allow_pickle=True).item()
+                assert repr(a) == repr(b), rel
+            else:
+                assert _bytes(os.path.join(GOLD, rel)) == _bytes(os.path.join(str(tmp_path), rel)), rel
