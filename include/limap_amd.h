@@ -282,6 +282,13 @@ int lt_fn_triangulate_line(lt_ctx *ctx, const double seg1[4], const double cam1[
                            const double seg2[4], const double cam2[11], int by_endpoints,
                            double out_line10[10]);
 
+/* merging::Aggregator::aggregate_line3d_list(lines, scores, num_outliers) (merging/aggregator.cc:53-101; takebest
+ * :8-29 below four lines) as ComputeLineTracks and the track post-processing apply it (call sites
+ * global_line_triangulator.cc:348, merging/merging_utils.cc:77, merging/merging.cc:509,635).  Host code of the tail: no
+ * context, no device.  lines10 = n x line10 (uncertainty at [8]); out7 = start, end, uncertainty.  The orientation of
+ * the result (which end is `start`) follows the sign rule documented in DESIGN.md section 5. */
+int lt_fn_aggregate_line3d_list(int n, const double *lines10, const double *scores, int num_outliers, double out7[7]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2858,4 +2858,20 @@ int lt_fn_triangulate_line_with_one_point(lt_ctx *ctx, const double seg1[4], con
   return LT_OK;
 }
 
+int lt_fn_aggregate_line3d_list(int n, const double *lines10, const double *scores, int num_outliers, double out7[7]) {
+  if (n <= 0 || !lines10 || !scores || !out7 || num_outliers < 0) return LT_ERR_ARGUMENT;
+  if (n >= 4 && 2 * num_outliers >= 2 * n) return LT_ERR_ARGUMENT;  // projections[num_outliers] would be out of range
+  std::vector<Cand> c((size_t)n);
+  std::vector<const Cand *> ptr((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const double *o = lines10 + 10 * (size_t)i;
+    for (int k = 0; k < 3; ++k) { c[(size_t)i].s[k] = o[k]; c[(size_t)i].e[k] = o[3 + k]; }
+    c[(size_t)i].depth[0] = o[6]; c[(size_t)i].depth[1] = o[7]; c[(size_t)i].unc = o[8]; c[(size_t)i].score3 = o[9];
+    ptr[(size_t)i] = &c[(size_t)i];
+  }
+  std::vector<double> sc(scores, scores + n);
+  lt::aggregate(ptr, sc, num_outliers, out7);
+  return LT_OK;
+}
+
 }  // extern "C"

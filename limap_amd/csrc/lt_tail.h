@@ -31,58 +31,68 @@ inline int uf_root(int i, std::vector<int> &parent) {  // base/graph.cc:156-165 
   return r;
 }
 
-// principal axis of a point set: eigenvector of the largest eigenvalue of the 3x3 scatter matrix
-// (cyclic Jacobi).  Replaces Eigen::JacobiSVD(...).matrixV().col(0) (merging/aggregator.cc:76-78);
-// sign fixed so that the largest-magnitude component is positive.
-inline void principal_axis(const std::vector<d3> &pts, double out[3]) {
-  double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  for (const d3 &p : pts) {
-    double v[3] = {p.x, p.y, p.z};
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) A[i][j] += v[i] * v[j];
-  }
+// Principal axis of a centred point set = first right-singular vector of the n x 3 point matrix, by one-sided
+// (Hestenes) Jacobi rotations of the columns: what Eigen::JacobiSVD(points, ComputeThinV).matrixV().col(0) stands
+// for in merging/aggregator.cc:76-78.  An SVD leaves the sign of a singular vector open; it decides which end of the
+// aggregated line is `start`.  The rule here -- the component of largest magnitude is positive -- is the one of the
+// CPU checker this backend is tested against and of the Eigen stand-in the reference sources are compiled with for that
+// checker; a real Eigen build may orient a track the other way round.  The rotations work on the
+// points themselves, in the same order as there, so the direction agrees to the last bit and no start / end swap is
+// left to tolerate in the comparisons.
+// `pts` is overwritten.
+inline void principal_axis(std::vector<d3> &pts, double out[3]) {
   double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  for (int sweep = 0; sweep < 64; ++sweep) {
-    double off = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]);
-    double diag = std::fabs(A[0][0]) + std::fabs(A[1][1]) + std::fabs(A[2][2]);
-    if (off <= 1e-18 * diag || off == 0.0) break;
+  const int n = (int)pts.size();
+  auto col = [&](int r, int c) -> double & { return c == 0 ? pts[(size_t)r].x : (c == 1 ? pts[(size_t)r].y : pts[(size_t)r].z); };
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0;
     for (int p = 0; p < 2; ++p)
       for (int q = p + 1; q < 3; ++q) {
-        if (A[p][q] == 0.0) continue;
-        double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 3; ++k) {
-          double akp = A[k][p], akq = A[k][q];
-          A[k][p] = c * akp - s * akq;
-          A[k][q] = s * akp + c * akq;
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int r = 0; r < n; ++r) {
+          alpha += col(r, p) * col(r, p);
+          beta += col(r, q) * col(r, q);
+          gamma += col(r, p) * col(r, q);
         }
-        for (int k = 0; k < 3; ++k) {
-          double apk = A[p][k], aqk = A[q][k];
-          A[p][k] = c * apk - s * aqk;
-          A[q][k] = s * apk + c * aqk;
+        if (gamma == 0.0) continue;
+        off = std::max(off, std::fabs(gamma) / std::sqrt(alpha * beta + 1e-300));
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+        for (int r = 0; r < n; ++r) {
+          const double a = col(r, p), b = col(r, q);
+          col(r, p) = c * a - s * b;
+          col(r, q) = s * a + c * b;
         }
-        for (int k = 0; k < 3; ++k) {
-          double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - s * vkq;
-          V[k][q] = s * vkp + c * vkq;
+        for (int r = 0; r < 3; ++r) {
+          const double a = V[r][p], b = V[r][q];
+          V[r][p] = c * a - s * b;
+          V[r][q] = s * a + c * b;
         }
       }
+    if (off < 1e-15) break;
   }
-  int b = 0;
-  if (A[1][1] > A[b][b]) b = 1;
-  if (A[2][2] > A[b][b]) b = 2;
-  double d[3] = {V[0][b], V[1][b], V[2][b]};
-  double ax = std::fabs(d[0]), ay = std::fabs(d[1]), az = std::fabs(d[2]);
-  double lead = (ax >= ay && ax >= az) ? d[0] : (ay >= az ? d[1] : d[2]);
-  double sgn = lead < 0 ? -1.0 : 1.0;
+  int best = 0;
+  double best_n = -1;
+  for (int c = 0; c < 3; ++c) {
+    double sq = 0;
+    for (int r = 0; r < n; ++r) sq += col(r, c) * col(r, c);
+    if (sq > best_n) {
+      best_n = sq;
+      best = c;
+    }
+  }
+  const double d[3] = {V[0][best], V[1][best], V[2][best]};
+  const double ax = std::fabs(d[0]), ay = std::fabs(d[1]), az = std::fabs(d[2]);
+  const double lead = (ax >= ay && ax >= az) ? d[0] : (ay >= az ? d[1] : d[2]);
+  const double sgn = lead < 0 ? -1.0 : 1.0;
   for (int k = 0; k < 3; ++k) out[k] = sgn * d[k];
 }
 
 // Aggregator::aggregate_line3d_list, merging/aggregator.cc:53-101 (+ takebest :8-29).  Two interfaces: a list of
 // candidate records (track post-processing) and (table, index list) for the tracks of ComputeLineTracks.
 struct AggScratch {
-  std::vector<d3> pts;
+  std::vector<d3> pts, rot;
   std::vector<double> proj;
 };
 template <class GetLine>
@@ -120,7 +130,8 @@ inline void aggregate_impl(GetLine line, const double *scores, int n, int num_ou
     pts[2 * i + 1] = sub(mk3(line(i).e[0], line(i).e[1], line(i).e[2]), center);
   }
   double dv[3];
-  principal_axis(pts, dv);
+  sc.rot = pts;  // the rotations overwrite their matrix; the projections below use the points
+  principal_axis(sc.rot, dv);
   d3 direc = mk3(dv[0], dv[1], dv[2]);
   double nn = std::sqrt(sqn(direc));
   direc = mk3(direc.x / nn, direc.y / nn, direc.z / nn);

@@ -74,10 +74,11 @@ def compare_valid_edges(g, o):
 
 
 def compare_tracks(gt, ot, rtol=1e-5, score_rtol=1e-12, exact_members=True):
-    """Track membership bit-exact (the north-star bar), endpoints within 1e-5 relative modulo the
-    start/end swap left open by the SVD sign (merging/aggregator.cc:76-78).  `exact_members=False` /
-    a looser `score_rtol`: for candidates whose coordinates are themselves only equal to rounding (the
-    many-points line fit)."""
+    """Track membership bit-exact (the north-star bar), endpoints within 1e-5 relative IN THE SAME ORIENTATION
+    (start to start, end to end: the product's principal axis follows the oracle's / the Eigen stand-in's sign rule
+    for the SVD of merging/aggregator.cc:76-78, no start / end swap is tolerated).  `exact_members=False` / a looser
+    `score_rtol`: for candidates whose coordinates are themselves only equal to rounding (the many-points line fit).
+    Returns (max relative endpoint error, number of tracks that would only match swapped)."""
     assert np.array_equal(gt["off"], ot["off"]), "track sizes differ"
     assert np.array_equal(gt["image_ids"], ot["image_ids"])
     assert np.array_equal(gt["line_ids"], ot["line_ids"])
@@ -89,12 +90,14 @@ def compare_tracks(gt, ot, rtol=1e-5, score_rtol=1e-12, exact_members=True):
         np.testing.assert_allclose(gt["line3d"], ot["line3d"], rtol=1e-9, atol=1e-12)
     gl, ol = gt["line"], ot["line"]
     scale = np.maximum(np.abs(ol[:, :6]).max(axis=1, keepdims=True), 1e-9)
-    d_same = np.abs(gl[:, :6] - ol[:, :6]) / scale
+    d_same = (np.abs(gl[:, :6] - ol[:, :6]) / scale).max(axis=1)
     swapped = np.concatenate([ol[:, 3:6], ol[:, 0:3]], 1)
-    d_swap = np.abs(gl[:, :6] - swapped) / scale
-    err = np.minimum(d_same.max(axis=1), d_swap.max(axis=1))
-    assert err.max() <= rtol if len(err) else True, "track endpoints differ: max rel err %g" % err.max()
+    d_swap = (np.abs(gl[:, :6] - swapped) / scale).max(axis=1)
+    n_swapped = int(np.count_nonzero((d_swap < d_same) & (d_same > rtol)))
+    assert n_swapped == 0, "%d of %d tracks have start and end exchanged" % (n_swapped, len(d_same))
+    assert d_same.max() <= rtol if len(d_same) else True, "track endpoints differ: max rel err %g" % d_same.max()
     np.testing.assert_allclose(gl[:, 6], ol[:, 6], rtol=score_rtol)
+    return (float(d_same.max()) if len(d_same) else 0.0), n_swapped
 
 
 def small_scene(seed=0, n_views=16, n_segs=120, n_neighbors=8, **kw):

@@ -7,7 +7,7 @@
 
 Same bars as tests/test_gpu_parity.py: candidate lists, best candidate per node (arg-max,
 global_line_triangulator.cc:145-153), valid-edge sets (:118-142), track memberships and node ids
-(merging/merging.cc:84-101 label order) identical; endpoints <= 1e-5 relative modulo swap."""
+(merging/merging.cc:84-101 label order) identical; endpoints <= 1e-5 relative, same orientation."""
 import numpy as np
 import pytest
 

@@ -170,3 +170,37 @@ def test_track_report_counts_images_not_lines():
     assert rep["N2"] == 3 and rep["N4"] == 1 and rep["N6"] == 0
     assert rep["avg_supporting_images_ge3"] == 4.0 and rep["avg_supporting_lines_ge4"] == 4.0
     assert track_report([0], [])["N2"] == 0
+
+
+def test_aggregator_matches_the_oracle_bit_for_bit_including_orientation():
+    """Aggregator::aggregate_line3d_list (merging/aggregator.cc:53-101): the product's host tail against the oracle (which
+    is pinned to oracle/_ref) on random bundles of near-parallel segments -- centre, principal axis, its SIGN (which end
+    of the track line is `start`), the outlier-trimmed extent and the uncertainty, bit for bit.  No device involved."""
+    import ctypes as C
+    from limap_amd import _capi
+    from oracle import oracle as ora
+    L = _capi.load_library()
+    rng = np.random.default_rng(5)
+    dp = C.POINTER(C.c_double)
+    for trial in range(300):
+        n = int(rng.integers(1, 40))
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        c0 = rng.normal(size=3) * 5
+        lines = np.zeros((n, 10))
+        for i in range(n):
+            a, b = np.sort(rng.uniform(-3, 3, 2))
+            flip = rng.random() < 0.3          # supporting lines come in either orientation
+            s, e = c0 + a * d + rng.normal(size=3) * 0.02, c0 + b * d + rng.normal(size=3) * 0.02
+            lines[i, :3], lines[i, 3:6] = (e, s) if flip else (s, e)
+            lines[i, 6:8] = rng.uniform(1, 9, 2)
+            lines[i, 8] = rng.uniform(0.01, 0.2)
+            lines[i, 9] = 1.0
+        scores = rng.uniform(0, 10, n)
+        num_outliers = int(rng.integers(0, 3)) if n >= 4 else 2
+        if n >= 4:
+            num_outliers = min(num_outliers, n - 1)
+        out = np.zeros(7)
+        rc = L.lt_fn_aggregate_line3d_list(n, lines.ctypes.data_as(dp), scores.ctypes.data_as(dp), num_outliers, out.ctypes.data_as(dp))
+        assert rc == 0
+        want = ora.aggregate_line3d_list(lines, scores, num_outliers)
+        assert np.array_equal(out, np.asarray(want).ravel()[:7]), (trial, n, out, want)
