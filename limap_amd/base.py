@@ -105,6 +105,15 @@ class LineTrack:
                     score_list=list(self.score_list), line2d_list=[l.as_array() for l in self.line2d_list],
                     line3d_list=[l.as_array() for l in self.line3d_list], active=self.active)
 
+    def Write(self, filename):  # linetrack.cc:133-209
+        from . import io as _io
+        _io.write_track(filename, self)
+
+    def Read(self, filename):  # linetrack.cc:211-270
+        from . import io as _io
+        other = _io.read_track(filename)
+        self.__dict__.update(other.__dict__)
+
 
 class CameraView:
     """camera_view.h:56-88 reduced to the undistorted pinhole the hot path requires
@@ -162,6 +171,48 @@ class ImageCollection:
 
     def IsUndistorted(self):
         return True
+
+    def get_image_name_dict(self):  # image_collection.cc: img_id -> image name
+        return {i: self._views[i].image_name() for i in self.get_img_ids()}
+
+    def as_dict(self):  # image_collection.cc:158-171
+        from . import io as _io
+        return _io.imagecols_to_dict(self)
+
+    def set_max_image_dim(self, val):
+        """image_collection.cc:399-403 / camera.cc:216-226: cameras larger than `val` are rescaled.  The views here carry
+        no image size (height = width = 0, like a reference Camera built without one): max(h, w) = 0 makes the ratio
+        infinite, nothing is rescaled -- the same as the reference does for such cameras."""
+        if val <= 0:
+            raise ValueError("Check failed: val > 0")
+
+    def update_neighbors(self, neighbors):  # image_collection.cc:322-341
+        if len(neighbors) == self.NumImages():
+            return neighbors
+        out = {}
+        for img_id in self.get_img_ids():
+            if img_id not in neighbors:
+                raise RuntimeError("Error! The image id is not found in the input neighbors.")
+            out[img_id] = [n for n in neighbors[img_id] if self.exist_image(n)]
+        return out
+
+    def get_map_camviews(self):
+        return {i: self._views[i] for i in self.get_img_ids()}
+
+
+def get_all_lines_2d(all_2d_segs):
+    """base/functions.py:4-24: dict img_id -> (N, 4+) array  ->  dict img_id -> list of Line2d."""
+    return {int(i): [Line2d(s[0:2], s[2:4]) for s in np.asarray(segs, float).reshape(-1, np.asarray(segs).shape[-1] if np.asarray(segs).ndim == 2 else 4)]
+            for i, segs in all_2d_segs.items()}
+
+
+class LineLinker3d:
+    """base/line_linker.h:168-185 as far as the path needs it: a holder of the 3D linker configuration (dict of
+    cfg["triangulation"]["remerging"]["linker3d"]); `limap_amd.merging.remerge` reads the fields."""
+
+    def __init__(self, cfg=None):
+        from types import SimpleNamespace
+        self.config = SimpleNamespace(**dict(cfg or {}))
 
 
 def track_report(off, image_ids):

@@ -112,7 +112,9 @@ struct Range {
   }
 };
 }  // namespace lt_trace
-#define LT_RANGE(name) lt_trace::Range lt_range_##__LINE__(name)
+#define LT_CONCAT2(a, b) a##b
+#define LT_CONCAT(a, b) LT_CONCAT2(a, b)
+#define LT_RANGE(name) lt_trace::Range LT_CONCAT(lt_range_, __LINE__)(name)
 
 // ---- pooled page-locked host blocks (see lt_ctx.h) ----
 namespace lt_host {
@@ -921,6 +923,17 @@ static int begin_image(lt_ctx *ctx, int img_id, int mode, int *idx_out) {
   if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "TriangulateImage called before Init");
   auto it = ctx->id2idx.find(img_id);
   if (it == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "unknown image id " + std::to_string(img_id));
+  *idx_out = it->second;
+  // already_scored_ guard (global_line_triangulator.cc:73): the call changes nothing -- in particular it does not
+  // invalidate the results or tracks of the batch this image belongs to (the callers return right behind this)
+  if (ctx->triangulated[(size_t)it->second]) return LT_OK;
+  // ComputeLineTracks ended the batch: with the tail on the device the per-node results are still there -- fetch them
+  // now, so that this call starts a new batch (like the host tail, which downloads before it runs) instead of
+  // appending to the finished one
+  if (ctx->tracks_done && ctx->ran && !ctx->downloaded) {
+    int rc = lt_download(ctx);
+    if (rc) return rc;
+  }
   if (ctx->job_mode != 0 && ctx->job_mode != mode && !ctx->downloaded) {
     int rc = lt_flush(ctx);  // switching between matched and exhaustive calls: run what is buffered
     if (rc) return rc;
@@ -934,7 +947,6 @@ static int begin_image(lt_ctx *ctx, int img_id, int mode, int *idx_out) {
   ctx->job_mode = mode;
   ctx->uploaded = ctx->ran = false;
   ctx->tracks_done = false;
-  *idx_out = it->second;
   return LT_OK;
 }
 
@@ -1840,7 +1852,7 @@ int lt_run_device_async(lt_ctx *ctx) {
   // pinned slots; finish_run reads them behind the end marker
   if (hp) {
     // hp[0] candidate count, hp[1] error flag, hp[2] pair statistic: one record, gathered by k_select
-    if (G <= 0) HIPCHK(ctx, hipMemsetAsync(ctx->d_result3.p, 0, 24, st));  // no nodes: k_select did not run
+    if (G <= 0) HIPCHK(ctx, hipMemsetAsync(ctx->d_result3.p, 0, 32, st));  // no nodes: k_select did not run
     // hp[3]: fullest staging region of the one-pass exhaustive mode (k_place_ex)
     HIPCHK(ctx, hipMemcpyAsync(&hp[0], ctx->d_result3.p, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipEventRecord(ev[12], st));

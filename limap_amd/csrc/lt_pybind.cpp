@@ -40,7 +40,7 @@ void assign_cfg(lt_config &c, const py::dict &d) {
   LT_KEY(sensitivity_threshold, double) LT_KEY(var2d, double) LT_KEY(fullscore_th, double)
   LT_KEY(max_valid_conns, int) LT_KEY(min_num_outer_edges, int) LT_KEY(num_outliers_aggregator, int)
 #undef LT_KEY
-  if (d.contains("merging_strategy")) {
+  if (d.contains("merging_strategy") && !d["merging_strategy"].is_none()) {
     const std::string s = d["merging_strategy"].cast<std::string>();
     c.merging_strategy = s == "greedy" ? 0 : (s == "exhaustive" ? 1 : (s == "avg" ? 2 : 99));
   }

@@ -199,8 +199,12 @@ def merge_shards_on_rank0(ctx, my_imgs, rank, world, device=None):
     if world == 1:
         return 0
     import torch
+    import torch.distributed as dist
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        # the collective's tensors live where the process group's backend can move them: gloo gathers host tensors,
+        # nccl (= RCCL) device tensors
+        backend = dist.get_backend() if dist.is_initialized() else "gloo"
+        device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     mine = [ctx.export_image_results(int(i)) for i in my_imgs] if rank != 0 else []
     ints, flts = pack_image_results(mine)
     parts = gather_packed_to_rank0(ints, flts, rank, world, device)

@@ -252,6 +252,40 @@ def save_txt_linetracks(fname, tracks, n_visible_views=4):
             f.write("".join(f"{v} " for v in t.line_id_list) + "\n")
 
 
+def save_folder_linetracks_with_info(folder, linetracks, config=None, imagecols=None, all_2d_segs=None):
+    """util/io.py:323-333."""
+    save_folder_linetracks(folder, linetracks)
+    if config is not None:
+        save_npy(os.path.join(folder, "config.npy"), config)
+    if imagecols is not None:
+        save_npy(os.path.join(folder, "imagecols.npy"), imagecols.as_dict())
+    if all_2d_segs is not None:
+        save_npy(os.path.join(folder, "all_2d_segs.npy"), all_2d_segs)
+
+
+def save_txt_imname_dict(fname, imname_dict):
+    """util/io.py:157-163: `number of images, N` then one `img_id, name` row per image."""
+    os.makedirs(os.path.dirname(os.path.abspath(fname)), exist_ok=True)
+    with open(fname, "w") as f:
+        f.write(f"number of images, {len(imname_dict)}\n")
+        for img_id, name in imname_dict.items():
+            f.write(f"{img_id}, {name}\n")
+
+
+def save_obj(fname, lines):
+    """util/io.py:181-199: every 3D segment as two vertices and one `l` element."""
+    if isinstance(lines, list):
+        lines = np.array(lines)
+    n = 0 if lines is None or len(lines) == 0 else lines.shape[0]
+    os.makedirs(os.path.dirname(os.path.abspath(fname)), exist_ok=True)
+    with open(fname, "w") as f:
+        for k in range(n):
+            for p in lines[k]:
+                f.write(f"v {p[0]} {p[1]} {p[2]}\n")
+        for k in range(n):
+            f.write(f"l {2 * k + 1} {2 * k + 2}\n")
+
+
 # ---- a scene folder as written by limap.runners.line_triangulation ---------------------------
 def triangulate_scene_folder(imagecols_npy, metainfos_txt, segments_folder, matches_folder, cfg, device=0,
                              exhaustive=False):

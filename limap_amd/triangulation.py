@@ -352,6 +352,7 @@ class GlobalLineTriangulator:
         self._ctx.triangulate_image_exhaustive(img_id, [int(x) for x in neighbors])
 
     def ComputeLineTracks(self):
+        self._best_cache = self._all_cache = None  # the call may run a pending batch: the getters read afresh
         if self._pbv is not None:
             t = self._pbv.ComputeLineTracks()  # one call: run + tail + the track arrays
         else:
@@ -475,6 +476,9 @@ class GlobalLineTriangulator:
         return self._ctx.timers()
 
     def context(self):
+        """The underlying C-ABI context.  Whoever drives it directly (import_image_results, run_device, ...) changes the
+        results behind this object's back: the cached getter arrays are dropped here."""
+        self._best_cache = self._all_cache = None
         return self._ctx
 
     # ---- helpers ----

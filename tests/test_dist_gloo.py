@@ -93,3 +93,84 @@ def test_all_gather_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _worker8(rank, world, port, q):
+    """Config-3-shaped sharding (BASELINE configs[2]: 1000 views x 1000 segs over 8 ranks) without the segments' bulk:
+    1000 images with ragged segment counts and connection weights, the weighted shard bounds, the all-gather with
+    padded per-rank payloads, and the packed gather of per-image results to rank 0 with eight senders."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from limap_amd import dist as ltdist
+        rng = np.random.default_rng(123)  # the same scene on every rank
+        n_img = 1000
+        img_ids = np.sort(rng.choice(5000, n_img, replace=False)).astype(np.int32)
+        n_seg = rng.integers(3, 40, n_img)  # ragged (a real scene has ~1000 per image; the layout logic is the same)
+        seg_off = np.zeros(n_img + 1, np.int64); seg_off[1:] = np.cumsum(n_seg)
+        kvec = rng.uniform(300, 900, (n_img, 4)); qvec = rng.normal(size=(n_img, 4)); tvec = rng.normal(size=(n_img, 3))
+        segs = rng.uniform(0, 800, (int(seg_off[-1]), 4))
+        weights = n_seg.astype(float) * rng.integers(5, 21, n_img) * 10  # connections an image brings (matched, topk 10)
+        g = ltdist.SceneGather(img_ids, seg_off, rank, world, torch.device("cpu"), weights=weights)
+        b = g.bounds
+        ok = b[0] == 0 and b[-1] == n_img and all(b[r] < b[r + 1] for r in range(world))
+        # connection-weighted bounds: no shard more than 1.35x the mean load
+        loads = np.array([weights[b[r]:b[r + 1]].sum() for r in range(world)])
+        ok = ok and loads.max() <= 1.35 * loads.mean()
+        kv, qv, tv, sg = kvec.copy(), qvec.copy(), tvec.copy(), segs.copy()
+        mask = np.ones(n_img, bool); mask[b[rank]:b[rank + 1]] = False
+        kv[mask] = np.nan; qv[mask] = np.nan; tv[mask] = np.nan
+        smask = np.ones(len(sg), bool); smask[seg_off[b[rank]]:seg_off[b[rank + 1]]] = False
+        sg[smask] = np.nan
+        g.load_local(kv, qv, tv, sg)
+        k, q_, t, s = g.all_gather()
+        ok = ok and np.array_equal(k.numpy(), kvec) and np.array_equal(q_.numpy(), qvec) and np.array_equal(t.numpy(), tvec)
+        ok = ok and np.array_equal(s.numpy()[:len(segs)], segs)
+        mine = ltdist.shard_images(img_ids, rank, world, weights)
+        ok = ok and np.array_equal(mine, img_ids[b[rank]:b[rank + 1]])
+        # packed per-image results of this shard -> rank 0 (sizes differ per rank: padding + size exchange)
+        r2 = np.random.default_rng(1000 + rank)
+        fake = []
+        for i in mine:
+            m = int(n_seg[int(np.searchsorted(img_ids, i))])
+            cnt = r2.integers(0, 3, m)
+            eoff = np.zeros(m + 1, np.int64); eoff[1:] = np.cumsum(cnt)
+            fake.append(dict(img_id=int(i), nb_ids=r2.integers(0, 5000, 4).astype(np.int32), line=r2.normal(size=(m, 10)),
+                             score=r2.random(m), src=r2.integers(0, 40, (m, 2)).astype(np.int32),
+                             n_tris=r2.integers(0, 9, m).astype(np.int32), edge_off=eoff,
+                             edges=r2.integers(0, 40, (int(eoff[-1]), 2)).astype(np.int32)))
+        ints, flts = ltdist.pack_image_results(fake)
+        parts = ltdist.gather_packed_to_rank0(ints, flts, rank, world, torch.device("cpu"))
+        if rank == 0:
+            seen = []
+            for r in range(world):
+                got = ltdist.unpack_image_results(*parts[r])
+                seen += [x["img_id"] for x in got]
+                if r == 0:
+                    ok = ok and all(np.array_equal(a_["line"], b_["line"]) and np.array_equal(a_["edges"], b_["edges"])
+                                    for a_, b_ in zip(got, fake))
+            ok = ok and sorted(seen) == img_ids.tolist()
+        else:
+            ok = ok and parts is None
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config3_shaped_sharding_world8_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(8)]

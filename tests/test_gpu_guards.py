@@ -422,3 +422,46 @@ def test_three_kernel_scoring_equals_fused(gpu_lib, clean_env, exhaustive):
     overflow = _results(run_product(sc, cfg, exhaustive=exhaustive))
     _same(base, overflow)
     assert overflow[4]["pairs_eval"] == base[4]["pairs_eval"]  # the repeated run used the fused kernel
+
+
+def test_second_batch_after_compute_tracks_device_and_host_tail(gpu_lib, oracle, clean_env):
+    """ComputeLineTracks ends a batch.  A TriangulateImage call after it starts a NEW batch (the first one's results stay
+    on the host) whether the tail ran on the device (default) or on the host (LT_TAIL_HOST); a repeated call for an image
+    that is already triangulated is a no-op (already_scored_, global_line_triangulator.cc:73) and invalidates nothing.
+    Tracks after the second ComputeLineTracks = the whole scene's, equal in both forms and equal to the oracle's."""
+    from helpers import compare_tracks, run_oracle
+    from limap_amd import triangulation as tri
+    sc = syn.make_scene(n_views=12, n_segs=100, n_neighbors=5, seed=9)
+    cfg = syn.default_triangulation_cfg()
+    ids = [int(i) for i in sc.img_ids]
+
+    def run():
+        T = tri.GlobalLineTriangulator(cfg)
+        T.SetRanges(sc.ranges)
+        T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+        for i in ids[:6]:
+            T.TriangulateImage(i, sc.matches_of(i))
+        first = T.ComputeLineTracks()
+        st1 = T.stats()
+        T.TriangulateImage(ids[0], sc.matches_of(ids[0]))      # already scored: nothing changes, nothing re-runs
+        assert T.stats() == st1 and len(T.GetTracks()) == len(first)
+        for i in ids[6:]:
+            T.TriangulateImage(i, sc.matches_of(i))
+        T.ComputeLineTracks()
+        t = T.context().get_tracks()
+        # the second run handled the second batch only
+        assert T.stats()["connections"] < st1["connections"] * 3
+        return len(first), t
+
+    os.environ.pop("LT_TAIL_HOST", None)
+    n1_dev, t_dev = run()
+    os.environ["LT_TAIL_HOST"] = "1"
+    try:
+        n1_host, t_host = run()
+    finally:
+        del os.environ["LT_TAIL_HOST"]
+    assert n1_dev == n1_host > 0
+    for k in ("off", "image_ids", "line_ids", "node_ids", "scores", "line"):
+        assert np.array_equal(t_dev[k], t_host[k]), k
+    O = run_oracle(oracle, sc, cfg)
+    compare_tracks(t_dev, O.ComputeLineTracks())

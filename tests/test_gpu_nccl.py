@@ -17,23 +17,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="nccl"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # backend "gloo": every rank on cuda:0 (RCCL needs a device per rank; gloo moves host tensors, the gathered scene is
+    # copied to the device afterwards) -- the two-rank shard / merge path with two real contexts on a 1-GPU box
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
     try:
         from limap_amd import _capi, dist as ltdist, synthetic as syn
         sc = syn.make_scene(n_views=14, n_segs=90, n_neighbors=6, seed=21)
         cfg = syn.default_triangulation_cfg()
         weights = np.array([len(sc.neighbors[int(i)]) for i in sc.img_ids], float)
         mine = ltdist.shard_images(sc.img_ids, rank, world, weights)
-        g = ltdist.SceneGather(sc.img_ids, sc.seg_off, rank, world, dev, weights=weights, force_collective=True)
+        g = ltdist.SceneGather(sc.img_ids, sc.seg_off, rank, world, cdev, weights=weights, force_collective=True)
         # every rank loads ONLY its own slice; the rest must arrive through the collective
         a, b = g.bounds[rank], g.bounds[rank + 1]
         kv, qv, tv, sg = sc.kvec.copy(), sc.qvec.copy(), sc.tvec.copy(), sc.segs.copy()
@@ -44,7 +50,9 @@ def _worker(rank, world, port, q):
         g.load_local(kv, qv, tv, sg)
         d_k, d_q, d_t, d_s = g.all_gather()
         ok = bool(torch.isfinite(d_s).all().item()) and np.array_equal(d_k.cpu().numpy(), sc.kvec)
-        ctx = _capi.Context(cfg_dict=cfg, device=rank)
+        if backend != "nccl":
+            d_k, d_q, d_t, d_s = d_k.to(dev), d_q.to(dev), d_t.to(dev), d_s.to(dev)
+        ctx = _capi.Context(cfg_dict=cfg, device=dev.index)
         ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         ctx.set_ranges(*sc.ranges)
         ctx.init_device(sc.img_ids, d_k.data_ptr(), d_q.data_ptr(), d_t.data_ptr(), sc.seg_off, d_s.data_ptr())
@@ -54,13 +62,15 @@ def _worker(rank, world, port, q):
             off = np.zeros(len(nb) + 1, np.int64); off[1:] = np.cumsum([len(m[k]) for k in nb])
             ctx.triangulate_image(int(i), nb, off, np.concatenate([m[k] for k in nb], 0))
         ctx.upload()
-        ctx.set_scene_chunks(*g.chunk_pointers())
-        h = g.gather_async()
-        h.wait()
-        ctx.refresh_scene_chunks()   # the per-step path: invariants rebuilt straight from the receive buffer
+        if backend == "nccl":
+            ctx.set_scene_chunks(*g.chunk_pointers())
+            h = g.gather_async()
+            h.wait()
+            ctx.refresh_scene_chunks()   # the per-step path: invariants rebuilt straight from the receive buffer
         ctx.run_device()
         ctx.download()
-        n_imp = ltdist.merge_shards_on_rank0(ctx, mine, rank, world, dev)
+        # device None: merge_shards_on_rank0 picks it from the process group's backend (host tensors under gloo)
+        n_imp = ltdist.merge_shards_on_rank0(ctx, mine, rank, world, dev if backend == "nccl" else None)
         res = None
         if rank == 0:
             ctx.compute_tracks()
@@ -74,13 +84,13 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _run(world):
+def _run(world, backend="nccl"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=300) for _ in procs]
@@ -109,3 +119,10 @@ def test_rccl_path_world1(gpu_lib, oracle):
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the 1-GPU box runs the world_size 1 form)")
 def test_rccl_path_world2(gpu_lib, oracle):
     _check(_run(2), 2, oracle)
+
+
+def test_two_ranks_two_contexts_on_one_gpu_gloo(gpu_lib, oracle):
+    """N > 1 end to end where only one GPU exists: two processes, two contexts on cuda:0, gloo process group -- shards,
+    the scene all-gather, per-shard triangulation, merge_shards_on_rank0 (device from the backend) and the tail on rank 0
+    against the oracle's whole-scene result."""
+    _check(_run(2, "gloo"), 2, oracle)
