@@ -1311,7 +1311,7 @@ int finish_run(lt_ctx *ctx) {
     return rc2;
   }
   if (derr == 3)
-    return fail(ctx, LT_ERR_RUNTIME, "the one-point proposal supports at most 64 shared points per connection");
+    return fail(ctx, LT_ERR_RUNTIME, "the one-point proposal supports at most 250 shared points per connection");
   if (derr == 2)
     return fail(ctx, LT_ERR_RUNTIME, "map::at: a point shared by two lines has a point3D_id that is not among the SfM points");
   if (derr != 0) return fail(ctx, LT_ERR_RUNTIME, "IndexError! Out-of-index matches detected on the device");
@@ -1435,9 +1435,9 @@ int lt_run_device_async(lt_ctx *ctx) {
     const bool one_on = pts_any && !ctx->cfg.disable_one_point_triangulation;
     const bool pts_on = pts_any;
     // staging slots per match row: many-points, one candidate per shared point (at most the most points any
-    // segment has, capped at 64 -- the kernel flags a connection with more), vp(l1), vp(l2), algebraic
+    // segment has, capped at kMaxOnePoints = 250 -- the kernel flags a connection with more), vp(l1), vp(l2), algebraic
     int mult = (vp_on || pts_on) ? 4 : 1;
-    if (one_on) mult += (int)std::min<long long>(ctx->max_seg_pts, 64);
+    if (one_on) mult += (int)std::min<long long>(ctx->max_seg_pts, kMaxOnePoints);
     if (mult > 1 && (long long)mult * P >= (1ll << 32) - 1)
       return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch for the extra proposals");
     ENSURE(ctx, ctx->d_st_c, sizeof(CRec) * Pn * mult); ENSURE(ctx, ctx->d_st_l, sizeof(double) * Pn * mult);

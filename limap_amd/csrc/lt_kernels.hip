@@ -737,7 +737,7 @@ k_gen_exhaustive_pts(long long n_items, GenCfg cfg, const long long *__restrict_
                               cam_ray(cams[i2], d2{pb[j].x, pb[j].y}), &P);
             }
             if (okp) {
-              if (idx >= 64) { *err_flag = 3; break; }  // same limit as the matched path
+              if (idx >= kMaxOnePoints) { *err_flag = 3; break; }  // same limit as the matched path (one byte counts a connection)
               if (one_point_candidate(cfg, cams[i1], cams[i2], s1, s2, P, &o)) emit(o);
               ++idx;
             }

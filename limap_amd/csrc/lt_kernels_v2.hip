@@ -362,7 +362,7 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
     const unsigned e = e0 + lane;
     bool ok = false;
     bool okx[3] = {false, false, false};  // many-points, vp(l1), vp(l2)
-    unsigned long long one_mask = 0;       // one-point: which shared points gave a candidate
+    unsigned n_one = 0;                    // one-point: shared points that gave a candidate
     GenOut o;
     int line = 0, ng = 0;
     // the extra proposals are evaluated once for their validity and a second time when they are
@@ -383,15 +383,16 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
                           a.seg_vp + 3 * (which == 1 ? g1 + line : g2 + ng), dst);
     };
     // one-point proposals (step 1.2): one candidate per shared point, in ascending point3D_id.  store ==
-    // false: returns the mask of the points that give a candidate; store == true: recomputes those and
-    // writes them from staging slot p on.
-    auto one_points = [&](unsigned long long want, bool store, long long p) -> unsigned long long {
+    // false: returns the NUMBER of shared points that give a candidate; store == true: evaluates them again (same
+    // function, same result) and writes the candidates from staging slot p on.  kMaxOnePoints bounds the staging
+    // slots a row can need (mult, lt_api.cpp); a connection with more shared points raises device flag 3.
+    auto one_points = [&](bool store, long long p) -> unsigned {
       const Seg &s1 = a.segs[g1 + line];
       const Seg &s2 = a.segs[g2 + ng];
       const long long pa0 = a.seg_pt_off[g1 + line], pb0 = a.seg_pt_off[g2 + ng];
       const SegPoint *pa = a.seg_pts + pa0, *pb = a.seg_pts + pb0;
       const int na = (int)(a.seg_pt_off[g1 + line + 1] - pa0), nb = (int)(a.seg_pt_off[g2 + ng + 1] - pb0);
-      unsigned long long mask = 0;
+      unsigned n_ok = 0;
       int i = 0, j = 0, idx = 0;
       while (i < na && j < nb) {
         const int ia = pa[i].p3d_id, ib = pb[j].p3d_id;
@@ -408,13 +409,11 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
                           cam_ray(cams_r[i2], d2{pb[j].x, pb[j].y}), &P);
         }
         if (okp) {
-          if (idx >= 64) { *a.err_flag = 3; break; }  // more shared points than the mask holds
-          if (!store || ((want >> idx) & 1ull)) {
-            GenOut ov;
-            const bool r = one_point_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, P, &ov);
-            if (!store) {
-              if (r) mask |= 1ull << idx;
-            } else {
+          if (idx >= kMaxOnePoints) { *a.err_flag = 3; break; }  // more shared points than a row has staging slots
+          GenOut ov;
+          if (one_point_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, P, &ov)) {
+            ++n_ok;
+            if (store) {
               ov.r.nb_slot = lite_pack(nbslot, i2);
               ov.r.ng_line = ng;
               a.st_r[p] = ov.r;
@@ -427,7 +426,7 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
         }
         ++i; ++j;
       }
-      return mask;
+      return n_ok;
     };
     if (e < n_s) {
       int k = 0;
@@ -451,7 +450,7 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
         const bool len_ok = !(len(l1) <= cfg.min_length_2d) && !(len(l2) <= cfg.min_length_2d);
         GenOut tmp;
         if (len_ok && a.seg_pts && a.many_on) okx[0] = extra(0, &tmp);
-        if (len_ok && a.seg_pts && a.one_on) one_mask = one_points(0ull, false, 0);
+        if (len_ok && a.seg_pts && a.one_on) n_one = one_points(false, 0);
         if (len_ok && a.seg_vp && a.seg_has_vp[g1 + line]) okx[1] = extra(1, &tmp);
         if (len_ok && a.seg_vp && a.seg_has_vp[g2 + ng]) okx[2] = extra(2, &tmp);
       }
@@ -463,7 +462,6 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
     unsigned total = (unsigned)__popcll(m);
     if (kExtra) {
       // per-lane candidate counts vary (one per shared point): wave prefix by shuffles
-      const unsigned n_one = (unsigned)__popcll(one_mask);
       const unsigned mine = (okx[0] ? 1u : 0u) + n_one + (okx[1] ? 1u : 0u) + (okx[2] ? 1u : 0u);
       const unsigned cnt = mine + (ok ? 1u : 0u);
       unsigned incl = cnt;
@@ -480,7 +478,7 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
 #pragma unroll
       for (int w = 0; w < 3; ++w) {
         if (w == 1 && n_one) {
-          (void)one_points(one_mask, true, p);
+          (void)one_points(true, p);
           p += n_one;
         }
         if (okx[w]) {

@@ -151,16 +151,23 @@ def test_points_switches_and_errors(gpu_lib, oracle):
     T, O = _run_both(oracle, sc, cfg, bpts, sfm)
     g, o = T.context().get_all_tris(), O.get_all_tris()
     assert np.array_equal(g["off"], o["off"]) and np.array_equal(g["line"], o["line"])
-    # more than 64 shared points on one connection: the one-point proposal refuses (documented limit)
+    # more than 64 shared points on one connection (the limit of earlier rounds): one candidate per shared point, like
+    # the reference, which has no limit (base_line_triangulator.cc:238-248)
     big, big_sfm = syn.make_bipartites(sc, seed=3, pts_per_line=70)
     cfg.update(disable_one_point_triangulation=False, disable_many_points_triangulation=True)
+    T, O = _run_both(oracle, sc, cfg, big, big_sfm)
+    g, o = T.context().get_all_tris(), O.get_all_tris()
+    assert np.array_equal(g["off"], o["off"]) and np.array_equal(g["src"], o["src"])
+    np.testing.assert_allclose(g["line"][:, :8], o["line"][:, :8], rtol=1e-7, atol=1e-9)
+    # beyond 250 shared points a connection is refused (staging slots per row / one-byte counters)
+    huge, huge_sfm = syn.make_bipartites(sc, seed=3, pts_per_line=260)
     T = tri.GlobalLineTriangulator(cfg)
     T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
-    T.SetBipartites2d(big)
-    T.SetSfMPoints(big_sfm)
+    T.SetBipartites2d(huge)
+    T.SetSfMPoints(huge_sfm)
     for i in sc.img_ids:
         T.TriangulateImage(int(i), sc.matches_of(int(i)))
-    with pytest.raises(RuntimeError, match="64 shared points"):
+    with pytest.raises(RuntimeError, match="250 shared points"):
         T.ComputeLineTracks()
     # a shared point3D id that is not among the SfM points: std::map::at throws in the reference
     cfg.update(disable_one_point_triangulation=True, disable_many_points_triangulation=False)
