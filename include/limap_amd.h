@@ -139,6 +139,15 @@ int lt_triangulate_image(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_id
  * form of the std::map<int, Eigen::MatrixXi> argument; saves the caller a concatenation. */
 int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids,
                               const int32_t *const *rows, const int64_t *n_rows);
+/* The TriangulateImage loop of the caller (runners/line_triangulation.py:160-167: `for img_id in imagecols.get_img_ids():
+ * Triangulator.TriangulateImage(img_id, matches)`) as ONE call: image k has the neighbours nb_ids[nb_off[k] .. nb_off[k+1])
+ * and, for neighbour entry e in that range, the (n_rows[e], 2) int32 row array rows[e].  Same buffering, same validation
+ * and the same errors as n calls of lt_triangulate_image_rows in the given order -- but one pass over all rows (one
+ * parallel region over the (image, neighbour) blocks instead of one per call: the per-call form spends 2.1 ms of a
+ * 5 ms end-to-end run on 100 calls of 0.8 MB each).  Atomic: on an error nothing of the call is kept.  No reference
+ * counterpart (the reference's per-image call does the work itself). */
+int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, const int64_t *nb_off, const int32_t *nb_ids,
+                            const int32_t *const *rows, const int64_t *n_rows);
 /* TriangulateImageExhaustiveMatch(img_id, neighbors) -- base_line_triangulator.cc:111-136 */
 int lt_triangulate_image_exhaustive(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids);
 

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("LIMAP_AMD_LIB") or os.path.join(_HERE, "liblimap_amd.
 EXPORTED_SYMBOLS = [
     "lt_config_default", "lt_abi_version", "lt_sizeof_config", "lt_create", "lt_destroy", "lt_last_error", "lt_set_stream", "lt_set_ranges",
     "lt_unset_ranges", "lt_init", "lt_init_vp", "lt_set_bipartites", "lt_set_sfm_points", "lt_init_device", "lt_refresh_scene_device", "lt_set_scene_chunks",
-    "lt_refresh_scene_chunks", "lt_triangulate_image", "lt_triangulate_image_rows",
+    "lt_refresh_scene_chunks", "lt_triangulate_image", "lt_triangulate_image_rows", "lt_triangulate_all_rows",
     "lt_triangulate_image_exhaustive", "lt_upload", "lt_run_device", "lt_download", "lt_flush",
     "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
     "lt_get_num_tris", "lt_get_valid_flags", "lt_num_valid_edges", "lt_get_valid_edges", "lt_num_all_tris", "lt_get_all_tris",
@@ -131,6 +131,7 @@ def load_library():
     L.lt_refresh_scene_chunks.argtypes = [vp]
     L.lt_triangulate_image.argtypes = [vp, C.c_int, C.c_int, i32p, i64p, i32p]
     L.lt_triangulate_image_rows.argtypes = [vp, C.c_int, C.c_int, i32p, C.POINTER(C.c_void_p), i64p]
+    L.lt_triangulate_all_rows.argtypes = [vp, C.c_int, i32p, i64p, i32p, C.POINTER(C.c_void_p), i64p]
     L.lt_triangulate_image_exhaustive.argtypes = [vp, C.c_int, C.c_int, i32p]
     for n in ("lt_upload", "lt_run_device", "lt_run_device_async", "lt_sync", "lt_download", "lt_flush", "lt_compute_tracks"):
         getattr(L, n).argtypes = [vp]
@@ -339,6 +340,19 @@ class Context:
         ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrays])
         cnt = np.fromiter((a.shape[0] for a in arrays), np.int64, n) if n else np.zeros(1, np.int64)
         self.chk(self.L.lt_triangulate_image_rows(self.h, int(img_id), n, ptr(nb, C.c_int32), ptrs, ptr(cnt, C.c_int64)))
+
+    def triangulate_all_rows(self, img_ids, nb_lists, arrays):
+        """One call for the TriangulateImage loop: image img_ids[k] has the neighbours nb_lists[k] with the C-contiguous
+        int32 (K,2) row arrays arrays[k] (same order).  lt_triangulate_all_rows."""
+        ids = i32(img_ids)
+        nb_off = np.zeros(len(ids) + 1, np.int64)
+        nb_off[1:] = np.cumsum([len(n) for n in nb_lists]) if len(ids) else 0
+        nb = i32([x for n in nb_lists for x in n]) if nb_off[-1] else np.zeros(1, np.int32)
+        flat = [a for arrs in arrays for a in arrs]
+        ptrs = (C.c_void_p * max(len(flat), 1))(*[a.ctypes.data for a in flat])
+        cnt = np.fromiter((a.shape[0] for a in flat), np.int64, len(flat)) if flat else np.zeros(1, np.int64)
+        self.chk(self.L.lt_triangulate_all_rows(self.h, len(ids), ptr(ids, C.c_int32), ptr(nb_off, C.c_int64), ptr(nb, C.c_int32),
+                                                ptrs, ptr(cnt, C.c_int64)))
 
     def triangulate_image_exhaustive(self, img_id, nb_ids):
         nb_ids = i32(nb_ids)

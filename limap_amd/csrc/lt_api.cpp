@@ -11,6 +11,7 @@
 #include "lt_tail.h"
 
 #include <algorithm>
+#include <atomic>
 #include <parallel/algorithm>
 #include <chrono>
 #include <cmath>
@@ -986,17 +987,17 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
   const size_t base = ctx->h_m_pairs.size();
   {
     // the staging block may move when it grows: no asynchronous copy may still be reading it
-    size_t want = base + 2 * (size_t)dst[n_nb];
+    size_t want = base + (size_t)dst[n_nb];
     if (ctx->job_imgs.empty() && dst[n_nb] > 0)  // first image of a batch: one allocation for the usual case
       // (every image of the scene in one batch; capped at 1 GB -- a large scene arrives in batches, and a
       // page-locked allocation costs ~0.1 s per GB)
-      want = std::max(want, std::min<size_t>(2 * (size_t)dst[n_nb] * (size_t)std::max(1, ctx->n_img) + 1024, (size_t)1 << 28));
+      want = std::max(want, std::min<size_t>((size_t)dst[n_nb] * (size_t)std::max(1, ctx->n_img) + 1024, (size_t)1 << 28));
     if (want > ctx->h_m_pairs.capacity()) {
       if (ctx->streamed_ints > 0) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       if (!ctx->h_m_pairs.reserve(want)) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the match rows");
     }
   }
-  if (!ctx->h_m_pairs.grow_to(base + 2 * (size_t)dst[n_nb])) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the match rows");
+  if (!ctx->h_m_pairs.grow_to(base + (size_t)dst[n_nb])) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the match rows");
   int *out = ctx->h_m_pairs.data() + base;
   std::vector<int> bad(n_nb, 0);
   int unsorted = 0;
@@ -1004,9 +1005,11 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
   for (int k = 0; k < n_nb; ++k) {
     const int32_t *src = rows[order[k]];
     const long long n = n_rows[order[k]];
-    int *o = out + 2 * dst[k];
-    // validation as reductions over the rows (vectorised), then one memcpy: the largest line / neighbour-line id as
-    // unsigned (a negative id wraps to a huge value) and whether any line id is smaller than its predecessor
+    unsigned *o = reinterpret_cast<unsigned *>(out) + dst[k];
+    // ONE pass over the rows: validation as reductions (the largest line / neighbour-line id as unsigned -- a negative
+    // id wraps to a huge value -- and whether any line id is smaller than its predecessor) and the staged copy, PACKED
+    // to one word per row (line | neighbour line << 16: both are below 65536 for every row that passes the
+    // validation, util/types.h:16) -- half the bytes over PCIe and for k_gates
     unsigned mx_line = 0, mx_ng = 0;
     int uns = 0;
 #pragma omp simd reduction(max : mx_line, mx_ng) reduction(| : uns)
@@ -1015,8 +1018,8 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
       mx_line = line > mx_line ? line : mx_line;
       mx_ng = ng > mx_ng ? ng : mx_ng;
       uns |= (r > 0 && src[2 * r] < src[2 * r - 2]) ? 1 : 0;
+      o[r] = (line & 0xFFFFu) | (ng << 16);
     }
-    if (n > 0) std::memcpy(o, src, 8 * (size_t)n);
     int err = 0;
     if (n > 0 && (unsigned long long)mx_line >= (unsigned long long)M1) err |= 1;
     if (n > 0 && (unsigned long long)mx_ng >= (unsigned long long)M2[k]) err |= 2;
@@ -1039,8 +1042,8 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
   // is in call order, which is the device order whenever the images arrive in ascending id order)
   // (one copy per ~4 MB of rows: an enqueue costs the host ~5 us, an image brings ~0.8 MB; lt_upload sends the rest)
   if (ctx->h_m_pairs.blk.pinned && ctx->streamed_ints <= base && dst[n_nb] > 0 &&
-      base + 2 * (size_t)dst[n_nb] - ctx->streamed_ints >= (1u << 20)) {
-    const size_t from = ctx->streamed_ints, end = base + 2 * (size_t)dst[n_nb];
+      base + (size_t)dst[n_nb] - ctx->streamed_ints >= (1u << 20)) {
+    const size_t from = ctx->streamed_ints, end = base + (size_t)dst[n_nb];
     if (hipSetDevice(ctx->device) == hipSuccess) {
       bool ok = true;
       if (sizeof(int) * end > ctx->d_m_pairs.cap) {
@@ -1072,6 +1075,216 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
   ctx->job_order.push_back(ord);
   ctx->neighbors[idx] = nbs;
   ctx->triangulated[idx] = 1;
+  return LT_OK;
+}
+
+int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, const int64_t *nb_off, const int32_t *nb_ids,
+                            const int32_t *const *rows, const int64_t *n_rows) {
+  LT_FINISH(ctx);
+  struct Acc {  // [12] host ms spent buffering match rows
+    lt_ctx *c; double t0;
+    ~Acc() { c->timers[12] += now_ms() - t0; }
+  } acc{ctx, now_ms()};
+  if (n_images < 0 || (n_images > 0 && (!img_ids || !nb_off))) return fail(ctx, LT_ERR_ARGUMENT, "null argument");
+  struct Blk {  // one (image, neighbour) block of rows
+    const int32_t *src; long long n, dst; long long M1, M2; int img_id, nb_id;
+  };
+  struct Img {
+    int idx; std::vector<int> nbs, ord; std::vector<long long> cnt;
+  };
+  std::vector<Blk> blks;
+  std::vector<Img> imgs;
+  const size_t base = ctx->h_m_pairs.size();
+  long long total_rows = 0;
+  std::vector<char> seen_here((size_t)std::max(ctx->n_img, 1), 0);
+  // ---- pass 1 (serial, cheap): the per-image bookkeeping of lt_triangulate_image_rows, block descriptors ----
+  for (int k = 0; k < n_images; ++k) {
+    int idx;
+    int rc = begin_image(ctx, img_ids[k], 1, &idx);
+    if (rc) return rc;
+    if (ctx->triangulated[idx] || seen_here[(size_t)idx]) continue;  // already_scored_ guard (global_line_triangulator.cc:73)
+    seen_here[(size_t)idx] = 1;
+    const int n_nb = (int)(nb_off[k + 1] - nb_off[k]);
+    const int32_t *nb = nb_ids + nb_off[k];
+    if (n_nb > 255) return fail(ctx, LT_ERR_ARGUMENT, "more than 255 neighbours (uint8 neighbour index, base_line_triangulator.h:15)");
+    std::vector<int> order(n_nb);
+    for (int e = 0; e < n_nb; ++e) order[e] = e;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nb[a] < nb[b]; });  // std::map order
+    Img im;
+    im.idx = idx;
+    const long long M1 = ctx->seg_off[idx + 1] - ctx->seg_off[idx];
+    for (int e = 0; e < n_nb; ++e) {
+      const int o = order[e];
+      if (e > 0 && nb[o] == nb[order[e - 1]]) return fail(ctx, LT_ERR_ARGUMENT, "duplicate neighbour id in matches");
+      auto it = ctx->id2idx.find(nb[o]);
+      if (it == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "unknown neighbour image id " + std::to_string(nb[o]));
+      const long long n = n_rows[nb_off[k] + o];
+      if (n < 0) return fail(ctx, LT_ERR_ARGUMENT, "negative row count");
+      im.nbs.push_back(it->second);
+      im.ord.push_back(e);
+      im.cnt.push_back(n);
+      blks.push_back(Blk{rows[nb_off[k] + o], n, total_rows, M1, ctx->seg_off[it->second + 1] - ctx->seg_off[it->second],
+                         img_ids[k], nb[o]});
+      total_rows += n;
+    }
+    imgs.push_back(std::move(im));
+  }
+  if (imgs.empty()) return LT_OK;
+  // ---- staging: one allocation for the whole call ----
+  {
+    const size_t want = base + (size_t)total_rows;
+    if (want > ctx->h_m_pairs.capacity()) {
+      if (ctx->streamed_ints > 0) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (!ctx->h_m_pairs.reserve(want)) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the match rows");
+    }
+    if (!ctx->h_m_pairs.grow_to(want)) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the match rows");
+  }
+  int *out = ctx->h_m_pairs.data() + base;
+  // ---- pass 2: validation (reductions over the rows) + the single copy, in CHUNKS of >= 8 MB of rows: one parallel
+  // region per chunk over its (image, neighbour) blocks, and the chunk's host -> device copy enqueued right behind it, so
+  // that the DMA of chunk c runs under the host pass of chunk c + 1 (one copy at the end left 1.5 ms of DMA exposed) ----
+  const int nb_total = (int)blks.size();
+  std::vector<int> bad((size_t)nb_total, 0);
+  int unsorted = 0;
+  bool stream_ok = ctx->h_m_pairs.blk.pinned && ctx->streamed_ints <= base && total_rows > 0 &&
+                   hipSetDevice(ctx->device) == hipSuccess;
+  if (stream_ok && ctx->streamed_ints < base) {
+    // rows of earlier calls that were not streamed yet go first (the device buffer is filled in order)
+    stream_ok = false;
+  }
+  if (stream_ok) {
+    const size_t end = base + (size_t)total_rows;
+    if (sizeof(int) * end > ctx->d_m_pairs.cap) {
+      DevBuf nbuf;
+      bool ok = nbuf.ensure(sizeof(int) * std::max(end, ctx->h_m_pairs.capacity()));
+      if (ok && base > 0)
+        ok = hipMemcpyAsync(nbuf.p, ctx->d_m_pairs.p, sizeof(int) * base, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+      if (ok) {
+        ctx->d_m_pairs.release();
+        ctx->d_m_pairs = nbuf;
+      } else {
+        nbuf.release();
+        (void)hipGetLastError();
+        stream_ok = false;
+      }
+    }
+  }
+  // ONE parallel region: the workers take blocks in order from a shared counter; thread 0 does no copying -- it waits
+  // for each chunk (>= 8 MB of rows) to be complete and enqueues its host -> device copy, so the DMA of chunk c runs
+  // under the workers' pass over chunk c + 1 (a copy at the very end left 1.5 ms of DMA exposed; a parallel region per
+  // chunk paid ten fork/joins)
+  constexpr long long kChunkRows = 2 << 20;  // 8 MB of packed rows
+  std::vector<int> chunk_end;  // block index behind every chunk
+  {
+    long long acc_rows = 0;
+    for (int b = 0; b < nb_total; ++b) {
+      acc_rows += blks[(size_t)b].n;
+      if (acc_rows >= kChunkRows || b == nb_total - 1) {
+        chunk_end.push_back(b + 1);
+        acc_rows = 0;
+      }
+    }
+  }
+  const int n_chunks = (int)chunk_end.size();
+  std::vector<int> chunk_of((size_t)nb_total);
+  for (int c = 0, b = 0; c < n_chunks; ++c)
+    for (; b < chunk_end[(size_t)c]; ++b) chunk_of[(size_t)b] = c;
+  std::vector<std::atomic<int>> chunk_done((size_t)n_chunks);
+  for (auto &x : chunk_done) x.store(0, std::memory_order_relaxed);
+  std::atomic<int> next_blk{0};
+  std::atomic<int> bad_any{0}, uns_any{0};
+  const int n_thr = std::min(std::max(lt::host_threads(), 2), 17);  // 16 workers + the copy thread
+  int *const d_rows = stream_ok ? ctx->d_m_pairs.as<int>() : nullptr;
+  int *const h_rows = ctx->h_m_pairs.data();
+  hipStream_t st_rows = ctx->stream;
+  size_t streamed_to = ctx->streamed_ints;
+  const int dev_id = ctx->device;
+#pragma omp parallel num_threads(n_thr)
+  {
+    const bool copier = omp_get_thread_num() == 0 && omp_get_num_threads() > 1;
+    if (copier) {
+      if (d_rows) (void)hipSetDevice(dev_id);
+      bool ok = d_rows != nullptr;
+      for (int c = 0; c < n_chunks; ++c) {
+        const int first = c == 0 ? 0 : chunk_end[(size_t)c - 1], want = chunk_end[(size_t)c] - first;
+        while (chunk_done[(size_t)c].load(std::memory_order_acquire) < want) {
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+        }
+        if (!ok || bad_any.load(std::memory_order_relaxed)) continue;
+        const size_t from = base + (size_t)blks[(size_t)first].dst;
+        const size_t to = base + (size_t)(blks[(size_t)chunk_end[(size_t)c] - 1].dst + blks[(size_t)chunk_end[(size_t)c] - 1].n);
+        if (to > from) {
+          if (hipMemcpyAsync(d_rows + from, h_rows + from, sizeof(int) * (to - from), hipMemcpyHostToDevice, st_rows) == hipSuccess)
+            streamed_to = to;
+          else {
+            (void)hipGetLastError();  // not fatal: lt_upload sends whatever was not streamed
+            ok = false;
+          }
+        }
+      }
+    } else {
+      int uns_t = 0, bad_t = 0;
+      for (;;) {
+        const int b = next_blk.fetch_add(1, std::memory_order_relaxed);
+        if (b >= nb_total) break;
+        const Blk &B = blks[(size_t)b];
+        const int32_t *src = B.src;
+        const long long n = B.n;
+        unsigned mx_line = 0, mx_ng = 0;
+        int uns = 0;
+        unsigned *o = reinterpret_cast<unsigned *>(out) + B.dst;  // packed: line | neighbour line << 16 (see above)
+#pragma omp simd reduction(max : mx_line, mx_ng) reduction(| : uns)
+        for (long long r = 0; r < n; ++r) {
+          const unsigned line = (unsigned)src[2 * r], ng = (unsigned)src[2 * r + 1];
+          mx_line = line > mx_line ? line : mx_line;
+          mx_ng = ng > mx_ng ? ng : mx_ng;
+          uns |= (r > 0 && src[2 * r] < src[2 * r - 2]) ? 1 : 0;
+          o[r] = (line & 0xFFFFu) | (ng << 16);
+        }
+        int err = 0;
+        if (n > 0 && (unsigned long long)mx_line >= (unsigned long long)B.M1) err |= 1;
+        if (n > 0 && (unsigned long long)mx_ng >= (unsigned long long)B.M2) err |= 2;
+        bad[(size_t)b] = err;
+        uns_t |= uns;
+        bad_t |= err;
+        if (err) bad_any.store(1, std::memory_order_relaxed);
+        chunk_done[(size_t)chunk_of[(size_t)b]].fetch_add(1, std::memory_order_release);
+      }
+      if (uns_t) uns_any.store(1, std::memory_order_relaxed);
+      (void)bad_t;
+    }
+  }
+  unsorted = uns_any.load();
+  const bool any_bad = bad_any.load() != 0;
+  if (streamed_to > ctx->streamed_ints) ctx->streamed_ints = streamed_to;
+  for (int b = 0; b < nb_total && any_bad; ++b) {  // the first offending block in call order raises, like the per-image calls
+    if (!bad[(size_t)b]) continue;
+    if (ctx->streamed_ints > base) {  // chunks of this call are already on their way: they are void
+      (void)hipStreamSynchronize(ctx->stream);
+      ctx->streamed_ints = base;
+    }
+    ctx->h_m_pairs.grow_to(base);
+    const Blk &B = blks[(size_t)b];
+    if (bad[(size_t)b] & 1)  // base_line_triangulator.cc:87-94
+      return fail(ctx, LT_ERR_RUNTIME,
+                  "IndexError! Out-of-index matches exist between image (img_id = " + std::to_string(B.img_id) +
+                      ") and neighbor image (img_id = " + std::to_string(B.nb_id) +
+                      "). Please make sure you are reusing the correct descriptors and matches when using the "
+                      "--skip_exists option.");
+    return fail(ctx, LT_ERR_RUNTIME, "IndexError! neighbour line id out of range in matches of image " + std::to_string(B.img_id));
+  }
+  if (unsorted) ctx->rows_sorted = false;
+  for (Img &im : imgs) {
+    for (long long n : im.cnt) ctx->h_m_off.push_back(ctx->h_m_off.back() + n);
+    ctx->job_imgs.push_back(im.idx);
+    ctx->neighbors[im.idx] = im.nbs;
+    ctx->job_nbs.push_back(std::move(im.nbs));
+    ctx->job_order.push_back(std::move(im.ord));
+    ctx->triangulated[im.idx] = 1;
+  }
   return LT_OK;
 }
 
@@ -1173,14 +1386,14 @@ int lt_upload(lt_ctx *ctx) {
     ctx->max_rows = 0;
     for (int bq = 0; bq < ctx->n_blk; ++bq) ctx->max_rows = std::max(ctx->max_rows, m_off[bq + 1] - m_off[bq]);
     if (ctx->P >= (1ll << 32) - 1) return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch (>= 2^32-1)");
-    if (sizeof(int) * 2 * (size_t)std::max<long long>(ctx->P, 1) > ctx->d_m_pairs.cap) {
+    if (sizeof(int) * (size_t)std::max<long long>(ctx->P, 1) > ctx->d_m_pairs.cap) {
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       ctx->streamed_ints = 0;  // the buffer is replaced: everything is sent again
-      ENSURE(ctx, ctx->d_m_pairs, sizeof(int) * 2 * (size_t)std::max<long long>(ctx->P, 1));
+      ENSURE(ctx, ctx->d_m_pairs, sizeof(int) * (size_t)std::max<long long>(ctx->P, 1));
     }
     if (in_order) {
       // call order == device order: only what was not streamed during buffering is still to be sent
-      const size_t total = 2 * (size_t)ctx->P, sent = std::min(ctx->streamed_ints, total);
+      const size_t total = (size_t)ctx->P, sent = std::min(ctx->streamed_ints, total);
       if (total > sent)
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_m_pairs.as<int>() + sent, ctx->h_m_pairs.data() + sent, sizeof(int) * (total - sent),
                                    hipMemcpyHostToDevice, ctx->stream));
@@ -1193,8 +1406,8 @@ int lt_upload(lt_ctx *ctx) {
           long long cb = call_first_blk[j] + (long long)k;
           long long n = ctx->h_m_off[cb + 1] - ctx->h_m_off[cb];
           if (n > 0)
-            HIPCHK(ctx, hipMemcpyAsync(ctx->d_m_pairs.as<int>() + 2 * m_off[b], ctx->h_m_pairs.data() + 2 * ctx->h_m_off[cb],
-                                       sizeof(int) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_m_pairs.as<int>() + m_off[b], ctx->h_m_pairs.data() + ctx->h_m_off[cb],
+                                       sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
         }
       }
     }

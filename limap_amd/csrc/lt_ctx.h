@@ -164,7 +164,7 @@ struct lt_ctx {
   std::vector<std::vector<int>> job_nbs;   // per job image: neighbour image indices, processing order
   std::vector<std::vector<int>> job_order; // per job image: slots in ascending neighbour-id order
   std::vector<long long> h_m_off;          // per block row offsets (n_blk+1), matched mode
-  lt_host::RawInts h_m_pairs;              // 2 * P (pinned staging, call order)
+  lt_host::RawInts h_m_pairs;              // P packed match rows, line | neighbour line << 16 (pinned staging, call order)
   size_t streamed_ints = 0;                // prefix of h_m_pairs already enqueued to d_m_pairs
   std::vector<char> triangulated;          // per image: already passed to TriangulateImage*
   bool uploaded = false, ran = false, downloaded = false;

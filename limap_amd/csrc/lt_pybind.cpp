@@ -150,6 +150,39 @@ class Triangulator {
     chk(rc);
   }
 
+  // TriangulateAll(matches_by_image: dict[int -> dict[int -> ndarray (K,2) int]]): the caller's TriangulateImage loop
+  // (runners/line_triangulation.py:160-167) as one native call -- the images in the dict's order, one pass over all rows
+  // (lt_triangulate_all_rows).  No reference counterpart.
+  void TriangulateAll(const py::dict &by_image) {
+    std::vector<int32_t> ids, nb;
+    std::vector<int64_t> nb_off(1, 0), cnt;
+    std::vector<const int32_t *> rows;
+    std::vector<carr<int32_t>> keep;
+    for (auto im : by_image) {
+      ids.push_back(im.first.cast<int32_t>());
+      if (!py::isinstance<py::dict>(im.second)) throw py::value_error("TriangulateAll: dict of dicts expected");
+      py::dict matches = py::reinterpret_borrow<py::dict>(im.second);
+      for (auto item : matches) {
+        nb.push_back(item.first.cast<int32_t>());
+        py::array a = py::array::ensure(item.second);
+        if (!a) throw py::value_error("matches: array expected");
+        if (a.size() != 0 && (a.ndim() != 2 || a.shape(1) != 2))
+          throw py::value_error("Check failed: match_info.cols() == 2");  // base_line_triangulator.cc:79
+        keep.emplace_back(carr<int32_t>::ensure(a));
+        if (!keep.back()) throw py::value_error("matches: integer array expected");
+        rows.push_back(keep.back().data());
+        cnt.push_back(a.size() / 2);
+      }
+      nb_off.push_back((int64_t)nb.size());
+    }
+    int rc;
+    {
+      py::gil_scoped_release nogil;
+      rc = lt_triangulate_all_rows(ctx_, (int)ids.size(), ids.data(), nb_off.data(), nb.data(), rows.data(), cnt.data());
+    }
+    chk(rc);
+  }
+
   void TriangulateImageExhaustiveMatch(int img_id, const std::vector<int32_t> &neighbors) {  // bindings.cc:84-85
     chk(lt_triangulate_image_exhaustive(ctx_, img_id, (int)neighbors.size(), neighbors.data()));
   }
@@ -231,6 +264,7 @@ PYBIND11_MODULE(_lt_pybind, m) {
       .def("UnsetRanges", &Triangulator::UnsetRanges)
       .def("InitArrays", &Triangulator::InitArrays)
       .def("TriangulateImage", &Triangulator::TriangulateImage)
+.def("TriangulateAll", &Triangulator::TriangulateAll)
       .def("TriangulateImageExhaustiveMatch", &Triangulator::TriangulateImageExhaustiveMatch)
       .def("ComputeLineTracks", &Triangulator::ComputeLineTracks)
       .def("GetTracks", &Triangulator::GetTracks)

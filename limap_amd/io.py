@@ -298,9 +298,9 @@ def triangulate_scene_folder(imagecols_npy, metainfos_txt, segments_folder, matc
     T = tri.GlobalLineTriangulator(cfg, device=device)
     T.SetRanges(ranges)
     T.Init(all_2d_segs, imagecols)
-    for i in imagecols.get_img_ids():
-        if exhaustive:
+    if exhaustive:
+        for i in imagecols.get_img_ids():
             T.TriangulateImageExhaustiveMatch(i, neighbors[i])
-        else:
-            T.TriangulateImage(i, read_matches(matches_folder, i))
+    else:  # the whole loop of runners/line_triangulation.py:160-167 in one native call
+        T.TriangulateAll({i: read_matches(matches_folder, i) for i in imagecols.get_img_ids()})
     return T, T.ComputeLineTracks()

@@ -157,3 +157,56 @@ def test_free_functions_match_oracle(gpu_lib, oracle):
     E = tri.compute_essential_matrix(c1, c2)
     np.testing.assert_allclose(E / np.linalg.norm(E), oracle.compute_essential_matrix(c1, c2) /
                                np.linalg.norm(oracle.compute_essential_matrix(c1, c2)), atol=1e-9)
+
+
+def test_triangulate_all_equals_the_per_image_loop(gpu_lib):
+    """TriangulateAll(matches_by_image) = the caller's TriangulateImage loop as one call: identical candidates, best
+    lines, edges and tracks (through the pybind shim and through the ctypes path); an out-of-index row raises the
+    reference's IndexError text and keeps NOTHING of the call; images that are already triangulated are skipped."""
+    import numpy as np
+    from limap_amd import synthetic as syn, triangulation as tri
+    sc = syn.make_scene(n_views=10, n_segs=90, n_neighbors=5, seed=17)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    matches = {int(i): sc.matches_of(int(i)) for i in sc.img_ids}
+
+    def new():
+        T = tri.GlobalLineTriangulator(cfg)
+        T.SetRanges(sc.ranges)
+        T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+        return T
+
+    def results(T):
+        T.ComputeLineTracks()
+        c = T.context()
+        return c.get_all_tris(), c.get_best(), c.get_valid_edges(), c.get_tracks()
+
+    A = new()
+    for i in sc.img_ids:
+        A.TriangulateImage(int(i), matches[int(i)])
+    ra = results(A)
+    for use_shim in (True, False):
+        B = new()
+        if not use_shim:
+            B._pbv = None  # the ctypes path
+        B.TriangulateAll(matches)
+        B.TriangulateAll({int(sc.img_ids[0]): matches[int(sc.img_ids[0])]})  # already scored: nothing happens
+        rb = results(B)
+        for k in ("off", "src", "line", "score"):
+            assert np.array_equal(ra[0][k], rb[0][k]), k
+        assert np.array_equal(ra[1]["line"], rb[1]["line"]) and np.array_equal(ra[1]["src"], rb[1]["src"])
+        assert np.array_equal(ra[2][0], rb[2][0]) and np.array_equal(ra[2][1], rb[2][1])
+        for k in ("off", "image_ids", "line_ids", "node_ids", "line"):
+            assert np.array_equal(ra[3][k], rb[3][k]), k
+    # an out-of-index line id in the third image: the reference's message, and nothing of the call is buffered
+    bad = {k: dict(v) for k, v in matches.items()}
+    i3 = int(sc.img_ids[2])
+    nb0 = next(iter(bad[i3]))
+    rows = bad[i3][nb0].copy()
+    rows[0, 0] = 10_000
+    bad[i3][nb0] = rows
+    Cx = new()
+    with pytest.raises(RuntimeError, match="Out-of-index matches exist between image"):
+        Cx.TriangulateAll(bad)
+    Cx.TriangulateAll(matches)  # the failed call left no image marked as triangulated
+    rc = results(Cx)
+    assert np.array_equal(ra[3]["off"], rc[3]["off"]) and np.array_equal(ra[3]["line"], rc[3]["line"])
