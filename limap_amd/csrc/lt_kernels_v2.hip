@@ -252,39 +252,43 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
 #pragma unroll
       for (int k = 0; k < 9; ++k) F[k] = pairs_r[b].F[k];
       unsigned pass_bits = 0, und_bits = 0;
-      int line_n = -1, ng_n = 0;
+      // a match row is one packed word: line | neighbour line << 16 (lt_api.cpp packs while it validates; both ids are
+      // below 65535 -- util/types.h:16 -- so 0xFFFFFFFF marks "no row")
+      constexpr unsigned kNoRow = 0xFFFFFFFFu;
+      unsigned row_n = kNoRow;
       {
         long long r = r0 + lane;
-        if (r < re) {
-          const unsigned v = (unsigned)a.m_pairs[r];  // packed row: line | neighbour line << 16
-          line_n = (int)(v & 0xFFFFu); ng_n = (int)(v >> 16);
-        }
+        if (r < re) row_n = (unsigned)a.m_pairs[r];
       }
       for (int c = 0; c < kGenChunks; ++c) {
-        const int line = line_n, ng = ng_n;
-        line_n = -1;
+        const unsigned row = row_n;
+        row_n = kNoRow;
         {  // next chunk's rows
           long long r = r0 + 64ll * (c + 1) + lane;
-          if (c + 1 < kGenChunks && r < re) {
-            const unsigned v = (unsigned)a.m_pairs[r];
-            line_n = (int)(v & 0xFFFFu); ng_n = (int)(v >> 16);
-          }
+          if (c + 1 < kGenChunks && r < re) row_n = (unsigned)a.m_pairs[r];
         }
         int res = 0;
-        if (line >= 0) {
+        if (row != kNoRow) {
           // separate LDS / global code paths: a selected pointer would turn these into FLAT loads
           double2 e0, e1, e2, e3, e4, h0, h1, h2, h3, h4;
           if (kLds1) {
-            const double2 *p1 = T1 + line * 5;
+            // table offset = (low half of the row) x 80 bytes in ONE instruction (16-bit multiply-add with operand
+            // select): unpacking the halves first cost two more VALU instructions per row in an issue-bound kernel
+            unsigned off1;
+            asm("v_mad_u32_u16 %0, %1, %2, 0" : "=v"(off1) : "v"(row), "s"(80u));
+            const double2 *p1 = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T1) + off1);
             e0 = p1[0]; e1 = p1[1]; e2 = p1[2]; e3 = p1[3]; e4 = p1[4];
           } else {
-            const double2 *p1 = reinterpret_cast<const double2 *>(a.segs + g1 + line);
+            const double2 *p1 = reinterpret_cast<const double2 *>(a.segs + g1 + (int)(row & 0xFFFFu));
             e0 = p1[0]; e1 = p1[1]; e2 = p1[2]; e3 = p1[3]; e4 = p1[4];
           }
           if (kLds2) {
-            const double2 *p2 = T2 + ng * 5;  // (a conflict-free access pattern was timed: no faster)
-            h0 = p2[0]; h1 = p2[1]; h2 = p2[2]; h3 = p2[3]; h4 = p2[4];
+            unsigned off2;  // (high half of the row) x 80
+            asm("v_mad_u32_u16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(off2) : "v"(row), "s"(80u));
+            const double2 *p2 = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T2) + off2);
+            h0 = p2[0]; h1 = p2[1]; h2 = p2[2]; h3 = p2[3]; h4 = p2[4];  // (a conflict-free access pattern was timed: no faster)
           } else {
+            const int ng = (int)(row >> 16);
             const double2 *p2 = reinterpret_cast<const double2 *>(a.gates + g2 + ng);
             h0 = p2[0]; h1 = p2[1]; h2 = p2[2]; h3 = p2[3]; h4 = p2[4];
           }
