@@ -616,6 +616,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_conn_off, &ctx->d_st_c, &ctx->d_st_l, &ctx->d_flags, &ctx->d_pos, &ctx->d_scan_tmp,
                     &ctx->d_item_off, &ctx->d_masks, &ctx->d_mask_cnt, &ctx->d_mask_pos, &ctx->d_cand, &ctx->d_hcand, &ctx->d_hlite,
                     &ctx->d_split_pairs, &ctx->d_split_segs, &ctx->d_split_head, &ctx->d_split_tot,
+                    &ctx->d_rm_line, &ctx->d_rm_act, &ctx->d_rm_edges, &ctx->d_rm_cnt,
                     &ctx->d_lite, &ctx->d_tri_off, &ctx->d_score, &ctx->d_best_idx, &ctx->d_edge_flag,
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
@@ -1909,8 +1910,8 @@ int lt_run_device_async(lt_ctx *ctx) {
       launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, -1, ex_cap,
                             ctx->d_tri_off.as<long long>(), ctx->d_err.as<int>());
       HIPCHK(ctx, hipEventRecord(ev[3], st));
-      launch_place_exhaustive(st, ex_ctr, region_cap, ctx->d_st_c.as<CRec>(), ctx->d_st_key.as<unsigned>(),
-                              ctx->d_node_img.as<int>(), ctx->d_nb_off.as<long long>(), ctx->d_item_off.as<long long>(),
+      launch_place_exhaustive(st, ex_ctr, region_cap, ctx->d_ex_ent.as<unsigned long long>(),
+                              ctx->d_st_key.as<unsigned>(), ctx->d_item_off.as<long long>(),
                               ctx->d_blk_chunk_off.as<int>(), ctx->d_masks.as<unsigned long long>(),
                               ctx->d_mask_pos.as<long long>(), P, ctx->d_tri_off.as<long long>(), G,
                               ctx->d_place_perm.as<unsigned>(), ctx->d_result3.as<long long>() + 3);

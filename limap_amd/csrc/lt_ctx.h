@@ -185,6 +185,8 @@ struct lt_ctx {
   DevBuf d_st_c, d_st_l, d_flags, d_pos, d_scan_tmp;
   DevBuf d_item_off, d_masks, d_mask_cnt, d_mask_pos;
   DevBuf d_split_pairs, d_split_segs, d_split_head, d_split_tot;  // pair list of the three-kernel scoring
+  DevBuf d_rm_line, d_rm_act, d_rm_edges, d_rm_cnt;  // lt_ts_remerge_once: kept across the passes of a remerge
+  std::vector<unsigned long long> h_rm_edges;
   bool score_split_off = false;  // set when a run overflowed the pair list: the fused scoring kernel from then on
   DevBuf d_hcand, d_hlite;  // split host-side view of the candidates (debug read-outs), see materialize_compact
   DevBuf d_cand, d_lite, d_tri_off, d_score, d_best_idx, d_edge_flag, d_nvalid, d_edge_off, d_edges;

@@ -54,11 +54,11 @@ void launch_tri_exhaustive(hipStream_t st, const unsigned long long *ent, const 
                            const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
                            const Cam *cams, const Seg *segs, const PairRec *pairs, const int *blk_chunk_off,
                            unsigned long long *masks, CRec *st_r, double *st_unc, unsigned *st_node, float *st_z);
-void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsigned region_cap, const CRec *st_r,
-                             const unsigned *st_node, const int *node_img, const long long *nb_off,
-                             const long long *item_off, const int *blk_chunk_off, const unsigned long long *masks,
-                             const long long *mask_pos, long long n_items, const long long *tri_off, long long G,
-                             unsigned *perm, long long *fill_out);
+void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsigned region_cap,
+                             const unsigned long long *ent, const unsigned *st_node, const long long *item_off,
+                             const int *blk_chunk_off, const unsigned long long *masks, const long long *mask_pos,
+                             long long n_items, const long long *tri_off, long long G, unsigned *perm,
+                             long long *fill_out);
 void launch_fill_exhaustive(hipStream_t st, int n_blk, long long n_items, const GenCfg &cfg, const long long *item_off,
                             const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
                             const Cam *cams, const Seg *segs, const PairRec *pairs, const unsigned long long *masks,

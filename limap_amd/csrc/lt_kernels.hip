@@ -799,13 +799,14 @@ __global__ void k_tri_offsets_ex(long long G, const long long *__restrict__ item
 
 // One-pass exhaustive mode: the final position of the candidate in staging slot s -- its work item is
 // (node, neighbour block, chunk of its neighbour line), its rank the survivors of the lower lanes of that item.
+// Block and neighbour line come from the slot's 8-byte entry (a coalesced stream), not from the 128-byte record:
+// two ints out of every record cost one cache line per slot, 3.6 GB of the kernel's 4.5 GB.
 __global__ void __launch_bounds__(256)
-k_place_ex(const unsigned long long *__restrict__ ctr, unsigned region_cap, const CRec *__restrict__ st_r,
-           const unsigned *__restrict__ st_node, const int *__restrict__ node_img, const long long *__restrict__ nb_off,
-           const long long *__restrict__ item_off, const int *__restrict__ blk_chunk_off,
-           const unsigned long long *__restrict__ masks, const long long *__restrict__ mask_pos, long long n_items,
-           const long long *__restrict__ tri_off, long long G, unsigned *__restrict__ perm,
-           long long *__restrict__ fill_out) {
+k_place_ex(const unsigned long long *__restrict__ ctr, unsigned region_cap, const unsigned long long *__restrict__ ent,
+           const unsigned *__restrict__ st_node, const long long *__restrict__ item_off,
+           const int *__restrict__ blk_chunk_off, const unsigned long long *__restrict__ masks,
+           const long long *__restrict__ mask_pos, long long n_items, const long long *__restrict__ tri_off,
+           long long G, unsigned *__restrict__ perm, long long *__restrict__ fill_out) {
   const int region = blockIdx.y;
   const unsigned long long n = ctr[region * 16];
   const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -819,13 +820,13 @@ k_place_ex(const unsigned long long *__restrict__ ctr, unsigned region_cap, cons
   const size_t slot = (size_t)region * region_cap + (size_t)t;
   const unsigned gu = st_node[slot];
   if (gu == 0xFFFFFFFFu) return;  // a connection that failed the dense evaluation
-  const int2 l = *reinterpret_cast<const int2 *>(&st_r[slot].nb_slot);  // (nb_slot, ng_line)
-  const long long g = (long long)gu;
-  const long long b = nb_off[node_img[g]] + (l.x & 0xFF);
-  const long long item = item_off[g] + blk_chunk_off[b] + (l.y >> 6);
+  const unsigned long long e = ent[slot];
+  const int ng = (int)(e & 0xFFFFu);
+  const long long b = (long long)(e >> 33);
+  const long long item = item_off[(long long)gu] + blk_chunk_off[b] + (ng >> 6);
   if (item >= n_items) return;
   const unsigned long long m = masks[item];
-  const long long pos = mask_pos[item] + __popcll(m & ((1ull << (l.y & 63)) - 1ull));
+  const long long pos = mask_pos[item] + __popcll(m & ((1ull << (ng & 63)) - 1ull));
   perm[pos] = (unsigned)slot;
 }
 
@@ -1094,15 +1095,14 @@ void launch_tri_exhaustive(hipStream_t st, const unsigned long long *ent, const 
                      st_unc, st_node, st_z);
 }
 // one-pass form: perm[final position] = staging slot, for every slot the regions handed out
-void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsigned region_cap, const CRec *st_r,
-                             const unsigned *st_node, const int *node_img, const long long *nb_off,
-                             const long long *item_off, const int *blk_chunk_off, const unsigned long long *masks,
-                             const long long *mask_pos, long long n_items, const long long *tri_off, long long G,
-                             unsigned *perm, long long *fill_out) {
+void launch_place_exhaustive(hipStream_t st, const unsigned long long *ctr, unsigned region_cap,
+                             const unsigned long long *ent, const unsigned *st_node, const long long *item_off,
+                             const int *blk_chunk_off, const unsigned long long *masks, const long long *mask_pos,
+                             long long n_items, const long long *tri_off, long long G, unsigned *perm,
+                             long long *fill_out) {
   if (region_cap == 0) return;
-  hipLaunchKernelGGL(k_place_ex, dim3(nblk((long long)region_cap, 256), kExRegions), dim3(256), 0, st, ctr, region_cap, st_r,
-                     st_node, node_img, nb_off, item_off, blk_chunk_off, masks, mask_pos, n_items, tri_off, G, perm,
-                     fill_out);
+  hipLaunchKernelGGL(k_place_ex, dim3(nblk((long long)region_cap, 256), kExRegions), dim3(256), 0, st, ctr, region_cap, ent,
+                     st_node, item_off, blk_chunk_off, masks, mask_pos, n_items, tri_off, G, perm, fill_out);
 }
 // pass 2 of the plain exhaustive mode: see k_fill_ex
 void launch_fill_exhaustive(hipStream_t st, int n_blk, long long n_items, const GenCfg &cfg, const long long *item_off,

@@ -266,9 +266,11 @@ int lt_ts_remerge_once(lt_ctx *ctx, lt_trackset *ts, const lt_config *linker_cfg
     active[t] = ts->tracks[t].active ? 1 : 0;
     n_active += active[t];
   }
-  DevBuf d_line, d_act, d_edges, d_cnt;
+  // the device buffers and the edge list live in the context: a remerge to its fixed point calls this several times
+  DevBuf &d_line = ctx->d_rm_line, &d_act = ctx->d_rm_act, &d_edges = ctx->d_rm_edges, &d_cnt = ctx->d_rm_cnt;
   hipStream_t st = ctx->stream;
-  std::vector<unsigned long long> edges;
+  std::vector<unsigned long long> &edges = ctx->h_rm_edges;
+  edges.clear();
   unsigned long long capacity = std::max<unsigned long long>(1ull << 16, 32ull * (unsigned long long)T);
   int rc = LT_OK;
   for (int attempt = 0; attempt < 8; ++attempt) {
@@ -299,7 +301,6 @@ int lt_ts_remerge_once(lt_ctx *ctx, lt_trackset *ts, const lt_config *linker_cfg
       rc = fail(ctx, LT_ERR_HIP, "HIP copy failed in remerge");
     break;
   }
-  d_line.release(); d_act.release(); d_edges.release(); d_cnt.release();
   if (rc) return rc;
   // std::set<pair<size_t,size_t>> order + dedupe
   std::sort(edges.begin(), edges.end());
