@@ -298,6 +298,14 @@ int lt_fn_triangulate_line(lt_ctx *ctx, const double seg1[4], const double cam1[
  * the result (which end is `start`) follows the sign rule documented in DESIGN.md section 5. */
 int lt_fn_aggregate_line3d_list(int n, const double *lines10, const double *scores, int num_outliers, double out7[7]);
 
+/* The host pass TriangulateImage / TriangulateAll make over one (image, neighbour) block of match rows -- the (n, 2)
+ * int32 matrix `matches[ng_img_id]` of base_line_triangulator.cc:82-98 -- exposed for tests: out[r] = rows[r][0] |
+ * rows[r][1] << 16 (the staged form), stats = {largest rows[:,0], largest rows[:,1] (as unsigned: a negative id wraps),
+ * 1 if any rows[r][0] < rows[r-1][0]}.  The out-of-index error of :87-94 is raised from these maxima.  level: 0 = the
+ * widest vector path the CPU has, 1 = scalar, 2 = AVX2, 3 = AVX-512 (a level the CPU lacks falls back to the widest).
+ * No context, no device. */
+int lt_fn_pack_match_rows(const int32_t *rows, int64_t n, uint32_t *out, uint32_t stats[3], int level);
+
 #ifdef __cplusplus
 }
 #endif

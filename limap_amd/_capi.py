@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "lt_release_cached_memory",
     "lt_fn_get_normal_direction", "lt_fn_get_direction_from_vp", "lt_fn_triangulate_point",
     "lt_fn_triangulate_line_with_direction", "lt_fn_triangulate_line_with_one_point", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
-    "lt_fn_triangulate_line", "lt_fn_aggregate_line3d_list",
+    "lt_fn_triangulate_line", "lt_fn_aggregate_line3d_list", "lt_fn_pack_match_rows",
 ]
 
 
@@ -176,6 +176,7 @@ def load_library():
     L.lt_fn_compute_fundamental_matrix.argtypes = [vp, dp, dp, dp]
     L.lt_fn_compute_epipolar_IoU.argtypes = [vp, dp, dp, dp, dp, dp]
     L.lt_fn_aggregate_line3d_list.argtypes = [C.c_int, dp, dp, C.c_int, dp]
+    L.lt_fn_pack_match_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
     L.lt_fn_triangulate_line.argtypes = [vp, dp, dp, dp, dp, C.c_int, dp]
     _lib = L
     return L

@@ -9,6 +9,8 @@
 
 #include "lt_ctx.h"
 #include "lt_tail.h"
+#include "lt_rows.h"
+#include "lt_pool.h"
 
 #include <algorithm>
 #include <atomic>
@@ -671,6 +673,8 @@ int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, 
   LT_FINISH(ctx);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (n_img < 0) return fail(ctx, LT_ERR_ARGUMENT, "n_img < 0");
+  // the TriangulateImage calls follow Init: start waking the team of the row pass now (lt_pool.h; returns at once)
+  lt_host::SpinPool::get(lt_host::row_workers()).wake();
   std::vector<int> perm(n_img);
   for (int i = 0; i < n_img; ++i) perm[i] = i;
   std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return img_ids[a] < img_ids[b]; });
@@ -921,6 +925,33 @@ int lt_refresh_scene_chunks(lt_ctx *ctx) {
   return LT_OK;
 }
 
+// ---- the host pass over the match rows (lt_rows.h), shared out over the persistent team (lt_pool.h) ----
+struct RowBlk {  // one (image, neighbour) block of rows
+  const int32_t *src; long long n, dst; long long M1, M2; int img_id, nb_id;
+};
+struct RowJob {
+  const RowBlk *blks; int nb_total; const int *chunk_of; std::atomic<int> *chunk_done; int *bad; unsigned *out;
+  std::atomic<int> next_blk{0}, bad_any{0}, uns_any{0};
+  static void run(void *arg, int, int) {
+    RowJob &J = *static_cast<RowJob *>(arg);
+    int uns_t = 0;
+    for (;;) {
+      const int b = J.next_blk.fetch_add(1, std::memory_order_relaxed);
+      if (b >= J.nb_total) break;
+      const RowBlk &B = J.blks[b];
+      const lt::RowStats rs = lt::pack_rows(B.src, B.n, J.out + B.dst);  // packed: line | neighbour line << 16
+      int err = 0;
+      if (B.n > 0 && (unsigned long long)rs.mx_line >= (unsigned long long)B.M1) err |= 1;
+      if (B.n > 0 && (unsigned long long)rs.mx_ng >= (unsigned long long)B.M2) err |= 2;
+      J.bad[b] = err;
+      uns_t |= rs.unsorted;
+      if (err) J.bad_any.store(1, std::memory_order_relaxed);
+      if (J.chunk_done) J.chunk_done[J.chunk_of[b]].fetch_add(1, std::memory_order_release);
+    }
+    if (uns_t) J.uns_any.store(1, std::memory_order_relaxed);
+  }
+};
+
 static int begin_image(lt_ctx *ctx, int img_id, int mode, int *idx_out) {
   if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "TriangulateImage called before Init");
   auto it = ctx->id2idx.find(img_id);
@@ -1000,33 +1031,24 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
   }
   if (!ctx->h_m_pairs.grow_to(base + (size_t)dst[n_nb])) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the match rows");
   int *out = ctx->h_m_pairs.data() + base;
+  // ONE pass over the rows (lt_rows.h): validation as reductions + the staged copy, packed to one word per row; the
+  // blocks are shared out between this thread and the workers of the persistent team that are awake (lt_pool.h)
   std::vector<int> bad(n_nb, 0);
-  int unsorted = 0;
-#pragma omp parallel for num_threads(std::min(lt::host_threads(), 8)) schedule(dynamic, 1) reduction(| : unsorted)
-  for (int k = 0; k < n_nb; ++k) {
-    const int32_t *src = rows[order[k]];
-    const long long n = n_rows[order[k]];
-    unsigned *o = reinterpret_cast<unsigned *>(out) + dst[k];
-    // ONE pass over the rows: validation as reductions (the largest line / neighbour-line id as unsigned -- a negative
-    // id wraps to a huge value -- and whether any line id is smaller than its predecessor) and the staged copy, PACKED
-    // to one word per row (line | neighbour line << 16: both are below 65536 for every row that passes the
-    // validation, util/types.h:16) -- half the bytes over PCIe and for k_gates
-    unsigned mx_line = 0, mx_ng = 0;
-    int uns = 0;
-#pragma omp simd reduction(max : mx_line, mx_ng) reduction(| : uns)
-    for (long long r = 0; r < n; ++r) {
-      const unsigned line = (unsigned)src[2 * r], ng = (unsigned)src[2 * r + 1];
-      mx_line = line > mx_line ? line : mx_line;
-      mx_ng = ng > mx_ng ? ng : mx_ng;
-      uns |= (r > 0 && src[2 * r] < src[2 * r - 2]) ? 1 : 0;
-      o[r] = (line & 0xFFFFu) | (ng << 16);
-    }
-    int err = 0;
-    if (n > 0 && (unsigned long long)mx_line >= (unsigned long long)M1) err |= 1;
-    if (n > 0 && (unsigned long long)mx_ng >= (unsigned long long)M2[k]) err |= 2;
-    bad[k] = err;
-    unsorted |= uns;
+  std::vector<RowBlk> blks((size_t)n_nb);
+  for (int k = 0; k < n_nb; ++k)
+    blks[(size_t)k] = RowBlk{rows[order[k]], n_rows[order[k]], dst[k], M1, M2[k], img_id, nb_ids[order[k]]};
+  RowJob job;
+  job.blks = blks.data(); job.nb_total = n_nb; job.chunk_of = nullptr; job.chunk_done = nullptr;
+  job.bad = bad.data(); job.out = reinterpret_cast<unsigned *>(out);
+  if (dst[n_nb] >= (1 << 14)) {
+    lt_host::SpinPool &pool = lt_host::SpinPool::get(lt_host::row_workers());
+    pool.begin(&RowJob::run, &job);
+    RowJob::run(&job, 0, 0);
+    pool.end();
+  } else {
+    RowJob::run(&job, 0, 0);  // a few rows: not worth a notify
   }
+  if (job.uns_any.load()) ctx->rows_sorted = false;
   for (int k = 0; k < n_nb; ++k) {
     if (!bad[k]) continue;
     ctx->h_m_pairs.grow_to(base);
@@ -1038,7 +1060,6 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
                       "--skip_exists option.");
     return fail(ctx, LT_ERR_RUNTIME, "IndexError! neighbour line id out of range in matches of image " + std::to_string(img_id));
   }
-  if (unsorted) ctx->rows_sorted = false;
   // stream the rows to the device while the caller prepares the next image (they are final: staging
   // is in call order, which is the device order whenever the images arrive in ascending id order)
   // (one copy per ~4 MB of rows: an enqueue costs the host ~5 us, an image brings ~0.8 MB; lt_upload sends the rest)
@@ -1087,13 +1108,18 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
     ~Acc() { c->timers[12] += now_ms() - t0; }
   } acc{ctx, now_ms()};
   if (n_images < 0 || (n_images > 0 && (!img_ids || !nb_off))) return fail(ctx, LT_ERR_ARGUMENT, "null argument");
-  struct Blk {  // one (image, neighbour) block of rows
-    const int32_t *src; long long n, dst; long long M1, M2; int img_id, nb_id;
-  };
   struct Img {
     int idx; std::vector<int> nbs, ord; std::vector<long long> cnt;
   };
-  std::vector<Blk> blks;
+  static const bool all_trace = getenv("LT_TAIL_TRACE") != nullptr;
+  double tl = acc.t0;
+  auto lap = [&](const char *what) {
+    if (!all_trace) return;
+    double t = now_ms();
+    std::fprintf(stderr, "[all] %-18s %.3f ms\n", what, t - tl);
+    tl = t;
+  };
+  std::vector<RowBlk> blks;
   std::vector<Img> imgs;
   const size_t base = ctx->h_m_pairs.size();
   long long total_rows = 0;
@@ -1124,13 +1150,14 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
       im.nbs.push_back(it->second);
       im.ord.push_back(e);
       im.cnt.push_back(n);
-      blks.push_back(Blk{rows[nb_off[k] + o], n, total_rows, M1, ctx->seg_off[it->second + 1] - ctx->seg_off[it->second],
+      blks.push_back(RowBlk{rows[nb_off[k] + o], n, total_rows, M1, ctx->seg_off[it->second + 1] - ctx->seg_off[it->second],
                          img_ids[k], nb[o]});
       total_rows += n;
     }
     imgs.push_back(std::move(im));
   }
   if (imgs.empty()) return LT_OK;
+  lap("bookkeeping");
   // ---- staging: one allocation for the whole call ----
   {
     const size_t want = base + (size_t)total_rows;
@@ -1141,6 +1168,7 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
     if (!ctx->h_m_pairs.grow_to(want)) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the match rows");
   }
   int *out = ctx->h_m_pairs.data() + base;
+  lap("staging");
   // ---- pass 2: validation (reductions over the rows) + the single copy, in CHUNKS of >= 8 MB of rows: one parallel
   // region per chunk over its (image, neighbour) blocks, and the chunk's host -> device copy enqueued right behind it, so
   // that the DMA of chunk c runs under the host pass of chunk c + 1 (one copy at the end left 1.5 ms of DMA exposed) ----
@@ -1171,11 +1199,11 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
       }
     }
   }
-  // ONE parallel region: the workers take blocks in order from a shared counter; thread 0 does no copying -- it waits
-  // for each chunk (>= 8 MB of rows) to be complete and enqueues its host -> device copy, so the DMA of chunk c runs
-  // under the workers' pass over chunk c + 1 (a copy at the very end left 1.5 ms of DMA exposed; a parallel region per
-  // chunk paid ten fork/joins)
-  constexpr long long kChunkRows = 2 << 20;  // 8 MB of packed rows
+  // The workers (lt_pool.h: a persistent team, already awake when Init preceded this call) take blocks in order from
+  // a shared counter; this thread does no row work -- it waits for each chunk (>= 2 MB of packed rows) to be complete
+  // and enqueues its host -> device copy, so the DMA of chunk c runs under the workers' pass over chunk c + 1 (a copy
+  // at the very end left 1.5 ms of DMA exposed; 8 MB chunks delayed the first copy by a fifth of the pass)
+  constexpr long long kChunkRows = 512 << 10;
   std::vector<int> chunk_end;  // block index behind every chunk
   {
     long long acc_rows = 0;
@@ -1193,73 +1221,41 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
     for (; b < chunk_end[(size_t)c]; ++b) chunk_of[(size_t)b] = c;
   std::vector<std::atomic<int>> chunk_done((size_t)n_chunks);
   for (auto &x : chunk_done) x.store(0, std::memory_order_relaxed);
-  std::atomic<int> next_blk{0};
-  std::atomic<int> bad_any{0}, uns_any{0};
-  const int n_thr = std::min(std::max(lt::host_threads(), 2), 17);  // 16 workers + the copy thread
+  RowJob job;
+  job.blks = blks.data(); job.nb_total = nb_total; job.chunk_of = chunk_of.data(); job.chunk_done = chunk_done.data();
+  job.bad = bad.data(); job.out = reinterpret_cast<unsigned *>(out);
   int *const d_rows = stream_ok ? ctx->d_m_pairs.as<int>() : nullptr;
   int *const h_rows = ctx->h_m_pairs.data();
-  hipStream_t st_rows = ctx->stream;
   size_t streamed_to = ctx->streamed_ints;
-  const int dev_id = ctx->device;
-#pragma omp parallel num_threads(n_thr)
+  lap("device buffer");
+  lt_host::SpinPool &pool = lt_host::SpinPool::get(lt_host::row_workers());
+  pool.begin(&RowJob::run, &job);
   {
-    const bool copier = omp_get_thread_num() == 0 && omp_get_num_threads() > 1;
-    if (copier) {
-      if (d_rows) (void)hipSetDevice(dev_id);
-      bool ok = d_rows != nullptr;
-      for (int c = 0; c < n_chunks; ++c) {
-        const int first = c == 0 ? 0 : chunk_end[(size_t)c - 1], want = chunk_end[(size_t)c] - first;
-        while (chunk_done[(size_t)c].load(std::memory_order_acquire) < want) {
+    bool ok = d_rows != nullptr;
+    for (int c = 0; c < n_chunks; ++c) {
+      const int first = c == 0 ? 0 : chunk_end[(size_t)c - 1], want = chunk_end[(size_t)c] - first;
+      while (chunk_done[(size_t)c].load(std::memory_order_acquire) < want) {
 #if defined(__x86_64__)
-          __builtin_ia32_pause();
+        __builtin_ia32_pause();
 #endif
-        }
-        if (!ok || bad_any.load(std::memory_order_relaxed)) continue;
-        const size_t from = base + (size_t)blks[(size_t)first].dst;
-        const size_t to = base + (size_t)(blks[(size_t)chunk_end[(size_t)c] - 1].dst + blks[(size_t)chunk_end[(size_t)c] - 1].n);
-        if (to > from) {
-          if (hipMemcpyAsync(d_rows + from, h_rows + from, sizeof(int) * (to - from), hipMemcpyHostToDevice, st_rows) == hipSuccess)
-            streamed_to = to;
-          else {
-            (void)hipGetLastError();  // not fatal: lt_upload sends whatever was not streamed
-            ok = false;
-          }
+      }
+      if (!ok || job.bad_any.load(std::memory_order_relaxed)) continue;
+      const size_t from = base + (size_t)blks[(size_t)first].dst;
+      const size_t to = base + (size_t)(blks[(size_t)chunk_end[(size_t)c] - 1].dst + blks[(size_t)chunk_end[(size_t)c] - 1].n);
+      if (to > from) {
+        if (hipMemcpyAsync(d_rows + from, h_rows + from, sizeof(int) * (to - from), hipMemcpyHostToDevice, ctx->stream) == hipSuccess)
+          streamed_to = to;
+        else {
+          (void)hipGetLastError();  // not fatal: lt_upload sends whatever was not streamed
+          ok = false;
         }
       }
-    } else {
-      int uns_t = 0, bad_t = 0;
-      for (;;) {
-        const int b = next_blk.fetch_add(1, std::memory_order_relaxed);
-        if (b >= nb_total) break;
-        const Blk &B = blks[(size_t)b];
-        const int32_t *src = B.src;
-        const long long n = B.n;
-        unsigned mx_line = 0, mx_ng = 0;
-        int uns = 0;
-        unsigned *o = reinterpret_cast<unsigned *>(out) + B.dst;  // packed: line | neighbour line << 16 (see above)
-#pragma omp simd reduction(max : mx_line, mx_ng) reduction(| : uns)
-        for (long long r = 0; r < n; ++r) {
-          const unsigned line = (unsigned)src[2 * r], ng = (unsigned)src[2 * r + 1];
-          mx_line = line > mx_line ? line : mx_line;
-          mx_ng = ng > mx_ng ? ng : mx_ng;
-          uns |= (r > 0 && src[2 * r] < src[2 * r - 2]) ? 1 : 0;
-          o[r] = (line & 0xFFFFu) | (ng << 16);
-        }
-        int err = 0;
-        if (n > 0 && (unsigned long long)mx_line >= (unsigned long long)B.M1) err |= 1;
-        if (n > 0 && (unsigned long long)mx_ng >= (unsigned long long)B.M2) err |= 2;
-        bad[(size_t)b] = err;
-        uns_t |= uns;
-        bad_t |= err;
-        if (err) bad_any.store(1, std::memory_order_relaxed);
-        chunk_done[(size_t)chunk_of[(size_t)b]].fetch_add(1, std::memory_order_release);
-      }
-      if (uns_t) uns_any.store(1, std::memory_order_relaxed);
-      (void)bad_t;
     }
   }
-  unsorted = uns_any.load();
-  const bool any_bad = bad_any.load() != 0;
+  pool.end();
+  lap("row pass");
+  unsorted = job.uns_any.load();
+  const bool any_bad = job.bad_any.load() != 0;
   if (streamed_to > ctx->streamed_ints) ctx->streamed_ints = streamed_to;
   for (int b = 0; b < nb_total && any_bad; ++b) {  // the first offending block in call order raises, like the per-image calls
     if (!bad[(size_t)b]) continue;
@@ -1268,7 +1264,7 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
       ctx->streamed_ints = base;
     }
     ctx->h_m_pairs.grow_to(base);
-    const Blk &B = blks[(size_t)b];
+    const RowBlk &B = blks[(size_t)b];
     if (bad[(size_t)b] & 1)  // base_line_triangulator.cc:87-94
       return fail(ctx, LT_ERR_RUNTIME,
                   "IndexError! Out-of-index matches exist between image (img_id = " + std::to_string(B.img_id) +
@@ -3081,6 +3077,15 @@ int lt_fn_triangulate_line_with_one_point(lt_ctx *ctx, const double seg1[4], con
   int rc = fn_query(ctx, seg1, cam1, seg2, cam2, 0, o, point);
   if (rc) return rc;
   std::memcpy(out_line10, o + 40, 80);
+  return LT_OK;
+}
+
+int lt_fn_pack_match_rows(const int32_t *rows, int64_t n, uint32_t *out, uint32_t stats[3], int level) {
+  if (n < 0 || (n > 0 && (!rows || !out)) || !stats) return LT_ERR_ARGUMENT;
+  const lt::RowStats rs = lt::pack_rows(rows, n, out, level);
+  stats[0] = rs.mx_line;
+  stats[1] = rs.mx_ng;
+  stats[2] = (uint32_t)rs.unsorted;
   return LT_OK;
 }
 

@@ -204,3 +204,38 @@ def test_aggregator_matches_the_oracle_bit_for_bit_including_orientation():
         assert rc == 0
         want = ora.aggregate_line3d_list(lines, scores, num_outliers)
         assert np.array_equal(out, np.asarray(want).ravel()[:7]), (trial, n, out, want)
+
+
+def test_match_row_pass_vector_paths_equal_plain_numpy():
+    """The host pass over a block of match rows (lt_rows.h: staged word line | neighbour line << 16, column maxima as
+    unsigned, sortedness) -- scalar, AVX2 and AVX-512 forms against numpy, on ragged lengths around the vector widths,
+    unaligned starts, negative and out-of-range ids and unsorted blocks (base_line_triangulator.cc:82-98)."""
+    from limap_amd import _capi
+    L = _capi.load_library()
+    rng = np.random.default_rng(5)
+    lengths = list(range(0, 70)) + [127, 128, 129, 1000, 5003]
+    for n in lengths:
+        for variant in range(4):
+            rows = np.stack([np.sort(rng.integers(0, 500, n)), rng.integers(0, 65536, n)], 1).astype(np.int32)
+            if variant == 1 and n > 2:   # one inversion somewhere (also at the vector seams)
+                k = int(rng.integers(1, n))
+                rows[k, 0] = rows[k - 1, 0] - 1
+            if variant == 2 and n > 0:   # a negative / too large id in either column
+                rows[int(rng.integers(0, n)), int(rng.integers(0, 2))] = int(rng.choice([-1, -70000, 65536, 2**31 - 1]))
+            if variant == 3 and n > 1:   # inversion between the last two rows
+                rows[n - 1, 0] = rows[n - 2, 0] - 3
+            buf = np.zeros(2 * n + 3, np.int32)   # odd offset: the block does not start on a vector boundary
+            src = buf[1:1 + 2 * n].reshape(n, 2)
+            src[:] = rows
+            u = rows.astype(np.int64) & 0xFFFFFFFF
+            want = ((u[:, 0] & 0xFFFF) | ((u[:, 1] << 16) & 0xFFFFFFFF)).astype(np.uint32)
+            want_stats = [int(u[:, 0].max()) if n else 0, int(u[:, 1].max()) if n else 0,
+                          int(n > 1 and bool((rows[1:, 0] < rows[:-1, 0]).any()))]
+            for level in (1, 2, 3, 0):
+                out = np.full(n + 1, 0xABCDABCD, np.uint32)
+                stats = np.zeros(3, np.uint32)
+                rc = L.lt_fn_pack_match_rows(src.ctypes.data, n, out.ctypes.data, stats.ctypes.data, level)
+                assert rc == 0
+                assert np.array_equal(out[:n], want), (n, variant, level)
+                assert out[n] == 0xABCDABCD, "wrote past the block"
+                assert stats.tolist() == want_stats, (n, variant, level, stats.tolist(), want_stats)
