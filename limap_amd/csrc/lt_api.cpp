@@ -2375,15 +2375,16 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
   static_assert(sizeof(Rec) == 128, "TailRec layout");
   const Rec *recs = (const Rec *)(base + o_recs);
   const int *nodes = (const int *)(base + o_nodes);
-#pragma omp parallel for num_threads(std::min(lt::host_threads(), 8)) schedule(static) if (Nm > 2048)
-  for (long long k = 0; k < Nm; ++k) {  // distinct nodes: no two iterations touch the same entry
-    const long long g = nodes[k];
-    ctx->best_c[g] = recs[k].c;
-    ctx->best_score[g] = recs[k].score;
-    ctx->best_src2[2 * g] = ctx->img_ids[recs[k].src[0]];
-    ctx->best_src2[2 * g + 1] = recs[k].src[1];
-    ctx->has_best[g] = 1;
-  }
+  lt_host::pool_for(Nm, 1024, [&](long long k0, long long k1) {
+    for (long long k = k0; k < k1; ++k) {  // distinct nodes: no two iterations touch the same entry
+      const long long g = nodes[k];
+      ctx->best_c[g] = recs[k].c;
+      ctx->best_score[g] = recs[k].score;
+      ctx->best_src2[2 * g] = ctx->img_ids[recs[k].src[0]];
+      ctx->best_src2[2 * g + 1] = recs[k].src[1];
+      ctx->has_best[g] = 1;
+    }
+  });
   lap("host unpack");
   return LT_OK;
 }
@@ -2394,6 +2395,7 @@ int lt_compute_tracks(lt_ctx *ctx) {
   if (ctx->cfg.merging_strategy < 0 || ctx->cfg.merging_strategy > 2)  // global_line_triangulator.cc:314-316
     return fail(ctx, LT_ERR_RUNTIME, "Error!The given merging strategy is not implemented");
   const bool on_device = tail_on_device(ctx);
+  lt_host::SpinPool::get(lt_host::row_workers()).wake();  // the host half of the tail shares its loops with the team
   int rc;
   if (on_device) {
     if (!ctx->uploaded && (rc = lt_upload(ctx))) return rc;
@@ -2707,17 +2709,16 @@ int lt_compute_tracks(lt_ctx *ctx) {
       ts.scores[w] = ctx->best_score[g];
       ts.gnodes[w] = g;
     }
-    // a few thousand tracks aggregate faster than a thread team forks on a big host
-#pragma omp parallel num_threads(std::min(lt::host_threads(), 8)) if (nT > 256)
-    {
-      AggScratch scratch;
-#pragma omp for schedule(dynamic, 16)
-      for (long long t = 0; t < (long long)nT; ++t) {
+    // shared with the workers of the persistent team that are awake (lt_pool.h): a few thousand tracks aggregate
+    // faster than a sleeping OpenMP team starts on a big host
+    lt_host::pool_for((long long)nT, 16, [&](long long t0_, long long t1_) {
+      static thread_local AggScratch scratch;
+      for (long long t = t0_; t < t1_; ++t) {
         const size_t a = (size_t)ts.off[(size_t)t], n = (size_t)ts.off[(size_t)t + 1] - a;
         aggregate(ctx->best_c, ts.gnodes.data() + a, ts.scores.data() + a, (int)n, ctx->cfg.num_outliers_aggregator,
                   ts.line7.data() + 7 * (size_t)t, scratch);
       }
-    }
+    });
   }
   for (long long g : gnode) gmap[(size_t)g] = -1;  // leave the scratch map clean
   lap("tracks+aggregate");

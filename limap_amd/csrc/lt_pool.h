@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <unistd.h>
 #include <vector>
 #if defined(__x86_64__)
@@ -132,6 +133,36 @@ inline int row_workers() {
     return w;
   }();
   return n;
+}
+
+// body(begin, end) over [0, n) in pieces of `grain`, shared between the calling thread and the workers that are awake
+template <class F>
+void pool_for(long long n, long long grain, F &&body) {
+  if (n <= 0) return;
+  if (n <= grain) {
+    body(0ll, n);
+    return;
+  }
+  struct Job {
+    std::atomic<long long> next{0};
+    long long n, grain;
+    typename std::remove_reference<F>::type *f;
+    static void run(void *a, int, int) {
+      Job &j = *static_cast<Job *>(a);
+      for (;;) {
+        const long long b = j.next.fetch_add(j.grain, std::memory_order_relaxed);
+        if (b >= j.n) break;
+        (*j.f)(b, std::min(b + j.grain, j.n));
+      }
+    }
+  } job;
+  job.n = n;
+  job.grain = grain;
+  job.f = &body;
+  SpinPool &pool = SpinPool::get(row_workers());
+  pool.begin(&Job::run, &job);
+  Job::run(&job, 0, 0);
+  pool.end();
 }
 
 }  // namespace lt_host
