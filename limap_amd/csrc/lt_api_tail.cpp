@@ -1,0 +1,492 @@
+// lt_api_tail.cpp -- C ABI, part 4: ComputeLineTracks (global_line_triangulator.cc:168-351) -- edge set and similarities on
+// the device (lt_kernels_tail.hip), union-find labels, tracks and aggregation on the host (lt_tail.h).
+#include "lt_host.h"
+
+using namespace lt;
+using namespace lt_impl;
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+// host tail
+// ---------------------------------------------------------------------------------------------
+// Device half of the tail (lt_kernels_tail.hip): possible when the results of the whole scene are those of the run
+// that is still resident in HBM (one batch, nothing imported, nothing read back yet) and no node filter applies
+// (min_num_outer_edges == 0, the value of cfgs/triangulation/default.yaml:81).  LT_TAIL_HOST=1 forces the host form.
+static bool tail_on_device(const lt_ctx *ctx) {
+  if (getenv("LT_TAIL_HOST") != nullptr || ctx->cfg.min_num_outer_edges > 0) return false;
+  if (!ctx->inited || ctx->job_mode == 0 || ctx->downloaded || ctx->job_imgs.empty()) return false;
+  if (ctx->G <= 0 || ctx->G >= (1ll << 31)) return false;
+  for (char c : ctx->best_c_set)
+    if (c) return false;  // an earlier batch or imported shards live on the host
+  return true;
+}
+
+// sorted unique undirected edges + their similarities; the graph nodes' best candidates land in ctx->best_c etc.
+// Two host synchronisations: one for the number of valid edges (it sizes the sort), one at the end; the graph
+// nodes' records are written by the gather kernel straight into page-locked host memory.
+extern "C++" {
+template <class AddEdge>
+static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
+  LT_FINISH(ctx);
+  static const bool trace = getenv("LT_TAIL_TRACE") != nullptr;
+  double tp = now_ms();
+  auto lap = [&](const char *what) {
+    if (!trace) return;
+    double t = now_ms();
+    fprintf(stderr, "[tail]   %-16s %.3f ms\n", what, t - tp);
+    tp = t;
+  };
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const long long G = ctx->G;
+  // valid-edge offsets (the scan lt_download would run)
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_nvalid.as<unsigned>() + G, 0, 4, st));
+  const size_t scan_tmp = scan_temp_bytes_u32_to_i64(G + 1);
+  ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(scan_tmp, 16));
+  if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, scan_tmp, G + 1, ctx->d_nvalid.as<unsigned>(),
+                             ctx->d_edge_off.as<long long>()) != 0)
+    return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+  long long *hp = ctx->h_pinned ? ctx->h_pinned + 16 : nullptr;  // slots behind the two result sets
+  long long fallback[2] = {0, 0};
+  if (!hp) hp = fallback;
+  HIPCHK(ctx, hipMemcpyAsync(&hp[0], ctx->d_edge_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
+  ENSURE(ctx, ctx->d_tail_mark, 4 * (size_t)(G + 1)); ENSURE(ctx, ctx->d_tail_pos, 8 * (size_t)(G + 1));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_tail_mark.p, 0, 4 * (size_t)(G + 1), st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  const long long E = hp[0];
+  lap("scan + sync (E)");
+  ctx->E = E;
+  ctx->C = ctx->C_last;
+  if (E <= 0) return LT_OK;
+  const size_t En = (size_t)E;
+  ENSURE(ctx, ctx->d_tail_keys, 8 * En); ENSURE(ctx, ctx->d_tail_skeys, 8 * En); ENSURE(ctx, ctx->d_tail_sims, 8 * En);
+  ENSURE(ctx, ctx->d_tail_keep, 4 * (En + 1)); ENSURE(ctx, ctx->d_tail_kpos, 8 * (En + 1));
+  const int kb = bits_for(G + 1);  // key = (min node << kb) | max node
+  const int end_bit = 2 * kb;
+  const size_t sort_tmp = tail_sort_temp_bytes(E, end_bit);
+  const size_t scan_tmp2 = scan_temp_bytes_u32_to_i64(E + 1);
+  ENSURE(ctx, ctx->d_tail_tmp, std::max<size_t>(std::max(sort_tmp, scan_tmp2), 16));
+  // host side of the transfer: counts | (key, sim) of the graph's edges | records | node ids, one pooled page-locked
+  // block; at most E distinct edges and min(G, 2 E) nodes enter the graph
+  const size_t max_nodes = (size_t)std::min<long long>(G, 2 * E);
+  const size_t o_pairs = 64, o_recs = o_pairs + 16 * En, o_nodes = o_recs + tail_rec_bytes() * max_nodes;
+  lt_host::HostBlock hb = lt_host::host_block_acquire(o_nodes + 4 * max_nodes);
+  if (!hb.p) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the edge list");
+  struct Rel {
+    lt_host::HostBlock b;
+    ~Rel() { lt_host::host_block_release(b); }
+  } rel{hb};
+  char *base = (char *)hb.p;
+  long long *hn = (long long *)base;  // [0] graph nodes, [1] graph edges
+  hn[0] = hn[1] = 0;
+  const unsigned long long *hpairs = (const unsigned long long *)(base + o_pairs);
+  launch_tail_keys(st, G, ctx->d_tri_off.as<long long>(), ctx->d_edge_flag.as<unsigned>(), ctx->d_edge_off.as<long long>(),
+                   ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(), ctx->d_seg_off.as<long long>(), kb,
+                   ctx->d_tail_keys.as<unsigned long long>(), ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
+  if (launch_tail_sort(st, ctx->d_tail_tmp.p, sort_tmp, E, ctx->d_tail_keys.as<unsigned long long>(),
+                       ctx->d_tail_skeys.as<unsigned long long>(), end_bit) != 0)
+    return fail(ctx, LT_ERR_HIP, "rocprim radix sort failed");
+  LinkCfg3 l3 = make_l3(ctx->cfg);
+  l3.use_angle = 1; l3.use_overlap = 1; l3.use_perp = 0; l3.use_innerseg = 1; l3.use_scaleinv = 0;  // line_linker.h:123-129
+  launch_tail_sims(st, E, ctx->d_tail_skeys.as<unsigned long long>(), ctx->d_ntris.as<int>(), ctx->d_best_c.as<Cand>(), l3,
+                   kb, ctx->d_tail_sims.as<double>(), ctx->d_tail_mark.as<unsigned>(), ctx->d_tail_keep.as<unsigned>());
+  if (launch_scan_u32_to_i64(st, ctx->d_tail_tmp.p, scan_tmp2, E + 1, ctx->d_tail_keep.as<unsigned>(),
+                             ctx->d_tail_kpos.as<long long>()) != 0 ||
+      launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, scan_tmp, G + 1, ctx->d_tail_mark.as<unsigned>(),
+                             ctx->d_tail_pos.as<long long>()) != 0)
+    return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+  if (hb.pinned) {  // the kernels write across PCIe: the host needs no size before the copies
+    launch_tail_compact(st, E, ctx->d_tail_skeys.as<unsigned long long>(), ctx->d_tail_sims.as<double>(),
+                        ctx->d_tail_keep.as<unsigned>(), ctx->d_tail_kpos.as<long long>(), base + o_pairs, hn + 1);
+    launch_tail_gather(st, G, ctx->d_tail_mark.as<unsigned>(), ctx->d_tail_pos.as<long long>(), ctx->d_best_c.as<Cand>(),
+                       ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(), base + o_recs, (int *)(base + o_nodes), hn);
+  } else {  // no page-locked memory: pack on the device, copy the bounds
+    ENSURE(ctx, ctx->d_tail_recs, 16 * En + tail_rec_bytes() * max_nodes + 64); ENSURE(ctx, ctx->d_tail_nodes, 4 * max_nodes);
+    char *dp = (char *)ctx->d_tail_recs.p;
+    launch_tail_compact(st, E, ctx->d_tail_skeys.as<unsigned long long>(), ctx->d_tail_sims.as<double>(),
+                        ctx->d_tail_keep.as<unsigned>(), ctx->d_tail_kpos.as<long long>(), dp, (long long *)ctx->d_tail_keys.p);
+    launch_tail_gather(st, G, ctx->d_tail_mark.as<unsigned>(), ctx->d_tail_pos.as<long long>(), ctx->d_best_c.as<Cand>(),
+                       ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(), dp + 16 * En, ctx->d_tail_nodes.as<int>(),
+                       nullptr);
+    HIPCHK(ctx, hipMemcpyAsync(hn, ctx->d_tail_pos.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(hn + 1, ctx->d_tail_kpos.as<long long>() + E, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(base + o_pairs, dp, 16 * En, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(base + o_recs, dp + 16 * En, tail_rec_bytes() * max_nodes, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(base + o_nodes, ctx->d_tail_nodes.p, 4 * max_nodes, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(ctx, hipGetLastError());
+  lap("enqueue");
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  lap("sync");
+  const long long Nm = hn[0], Ne = hn[1];
+  if (Nm < 0 || (size_t)Nm > max_nodes || Ne < 0 || Ne > E)
+    return fail(ctx, LT_ERR_RUNTIME, "internal: graph size out of range");
+  const unsigned long long mask = (1ull << kb) - 1ull;
+  for (long long i = 0; i < Ne; ++i) {  // distinct keys with score != 0 (:284-285), in std::set order
+    double sim;
+    std::memcpy(&sim, &hpairs[2 * i + 1], 8);
+    add_edge((long long)(hpairs[2 * i] >> kb), (long long)(hpairs[2 * i] & mask), sim);
+  }
+  lap("graph");
+  struct Rec {
+    Cand c;
+    double score;
+    int src[2];
+  };
+  static_assert(sizeof(Rec) == 128, "TailRec layout");
+  const Rec *recs = (const Rec *)(base + o_recs);
+  const int *nodes = (const int *)(base + o_nodes);
+  lt_host::pool_for(Nm, 1024, [&](long long k0, long long k1) {
+    for (long long k = k0; k < k1; ++k) {  // distinct nodes: no two iterations touch the same entry
+      const long long g = nodes[k];
+      ctx->best_c[g] = recs[k].c;
+      ctx->best_score[g] = recs[k].score;
+      ctx->best_src2[2 * g] = ctx->img_ids[recs[k].src[0]];
+      ctx->best_src2[2 * g + 1] = recs[k].src[1];
+      ctx->has_best[g] = 1;
+    }
+  });
+  lap("host unpack");
+  return LT_OK;
+}
+}  // extern "C++"
+
+int lt_compute_tracks(lt_ctx *ctx) {
+  LT_RANGE("lt_compute_tracks (tail: edge set, similarities, union-find, aggregation)");
+  if (ctx->cfg.merging_strategy < 0 || ctx->cfg.merging_strategy > 2)  // global_line_triangulator.cc:314-316
+    return fail(ctx, LT_ERR_RUNTIME, "Error!The given merging strategy is not implemented");
+  const bool on_device = tail_on_device(ctx);
+  lt_host::SpinPool::get(lt_host::row_workers()).wake();  // the host half of the tail shares its loops with the team
+  int rc;
+  if (on_device) {
+    if (!ctx->uploaded && (rc = lt_upload(ctx))) return rc;
+    if (!ctx->ran && (rc = lt_run_device(ctx))) return rc;
+  } else {
+    if ((rc = lt_flush(ctx))) return rc;
+    if (ctx->inited) define_best_of_other_images(ctx);
+  }
+  double t0 = now_ms();
+  static const bool tail_trace = getenv("LT_TAIL_TRACE") != nullptr;  // developer: stage times to stderr
+  double tprev = t0;
+  auto lap = [&](const char *what) {
+    if (!tail_trace) return;
+    double t = now_ms();
+    fprintf(stderr, "[tail] %-18s %.3f ms\n", what, t - tprev);
+    tprev = t;
+  };
+  const long long G = ctx->G;
+  // graph in edge order (base/graph.cc:57-87); scratch kept in the context
+  using GEdge = lt_ctx::GEdge;
+  std::vector<int> &gmap = ctx->tail_gmap;            // global node -> graph node
+  std::vector<long long> &gnode = ctx->tail_gnode;    // graph node -> global node
+  std::vector<GEdge> &ge = ctx->tail_ge;
+  if ((long long)gmap.size() != G) gmap.assign((size_t)G, -1);
+  gnode.clear();
+  ge.clear();
+  auto find_or_create = [&](long long g) {
+    if (gmap[(size_t)g] >= 0) return gmap[(size_t)g];
+    int id = (int)gnode.size();
+    gnode.push_back(g);
+    gmap[(size_t)g] = id;
+    return id;
+  };
+  auto add_edge = [&](long long a, long long b, double sim) {  // edges arrive in std::set order, score != 0
+    const int n1 = find_or_create(a);
+    const int n2 = find_or_create(b);
+    ge.push_back(GEdge{sim, n1, n2});
+  };
+  std::vector<unsigned long long> edges;
+  std::vector<double> sims;
+  if (on_device) {
+    ctx->valid_flags.assign((size_t)G, 1);
+    if ((rc = tail_from_device(ctx, add_edge))) return rc;
+    lap("device edges+sims");
+  } else {
+  const int min_outer = ctx->cfg.min_num_outer_edges;
+  auto node2 = [&](long long g, int slot, int ng_line) -> long long {
+    int img = ctx->h_node_img[g];
+    return ctx->seg_off[ctx->neighbors[img][slot]] + ng_line;
+  };
+  // filterNodeByNumOuterEdges (global_line_triangulator.cc:168-232)
+  std::vector<char> flags(G, 1);
+  if (min_outer > 0) {
+    std::vector<int> counters(G);
+    std::vector<std::vector<unsigned>> parents(G);
+    for (long long g = 0; g < G; ++g) {
+      const auto ve = ctx->valid_edges[g];
+      counters[g] = (int)(ve.size() / 2);
+      for (size_t e = 0; e + 1 < ve.size(); e += 2) parents[node2(g, ve[e], ve[e + 1])].push_back((unsigned)g);
+      if (counters[g] < min_outer) flags[g] = 0;
+    }
+    std::queue<long long> q;
+    for (long long g = 0; g < G; ++g)
+      if (!flags[g]) q.push(g);
+    while (!q.empty()) {
+      long long nd = q.front();
+      q.pop();
+      for (unsigned p : parents[nd]) {
+        if (!flags[p]) continue;
+        if (--counters[p] < min_outer) {
+          flags[p] = 0;
+          q.push(p);
+        }
+      }
+    }
+  }
+  ctx->valid_flags.assign(flags.begin(), flags.end());
+  lap("filter nodes");
+  // undirected edge set, ordered like std::set<pair<LineNode, LineNode>> (:243-261): the global
+  // node index is monotone in (img_id, line_id)
+  {
+    // two passes (count, fill) over the nodes in parallel, then a parallel sort
+    std::vector<long long> eoff((size_t)G + 1, 0);
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(static)
+    for (long long g = 0; g < G; ++g) {
+      long long n = 0;
+      if (flags[g]) {
+        const auto ve = ctx->valid_edges[g];
+        for (size_t e = 0; e + 1 < ve.size(); e += 2) n += flags[node2(g, ve[e], ve[e + 1])] ? 1 : 0;
+      }
+      eoff[(size_t)g + 1] = n;
+    }
+    for (long long g = 0; g < G; ++g) eoff[(size_t)g + 1] += eoff[(size_t)g];
+    edges.resize((size_t)eoff[(size_t)G]);
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(static)
+    for (long long g = 0; g < G; ++g) {
+      if (!flags[g]) continue;
+      const auto ve = ctx->valid_edges[g];
+      long long w = eoff[(size_t)g];
+      for (size_t e = 0; e + 1 < ve.size(); e += 2) {
+        long long h = node2(g, ve[e], ve[e + 1]);
+        if (!flags[h]) continue;
+        unsigned long long a = (unsigned long long)std::min(g, h), b = (unsigned long long)std::max(g, h);
+        edges[(size_t)w++] = (a << 32) | b;
+      }
+    }
+    __gnu_parallel::sort(edges.begin(), edges.end(), std::less<unsigned long long>(),
+                         __gnu_parallel::default_parallel_tag(lt::host_threads()));
+    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+  }
+  lap("edge set");
+  // edge similarity: score_3d in spatial-merging mode between the two best candidates (:264-290)
+  LinkCfg3 l3 = make_l3(ctx->cfg);
+  l3.use_angle = 1; l3.use_overlap = 1; l3.use_perp = 0; l3.use_innerseg = 1; l3.use_scaleinv = 0;  // line_linker.h:123-129
+  sims.assign(edges.size(), 0.0);
+  const long long nEh = (long long)edges.size();
+#pragma omp parallel for num_threads(lt::host_threads()) schedule(static)
+  for (long long e = 0; e < nEh; ++e) {
+    long long a = (long long)(edges[e] >> 32), b = (long long)(edges[e] & 0xFFFFFFFFull);
+    const Cand &ca = ctx->best_c[a];
+    const Cand &cb = ctx->best_c[b];
+    L3 la{mk3(ca.s[0], ca.s[1], ca.s[2]), mk3(ca.e[0], ca.e[1], ca.e[2])};
+    L3 lb{mk3(cb.s[0], cb.s[1], cb.s[2]), mk3(cb.e[0], cb.e[1], cb.e[2])};
+    // nodes without any candidate hold a value-initialised TriTuple in the reference; its zero
+    // line scores 0 against everything (direction 0 -> angle 90 deg)
+    sims[e] = (ctx->has_best[a] && ctx->has_best[b]) ? score3d(l3, la, lb, ca.unc, cb.unc, ca.depth) : 0.0;
+  }
+  lap("edge sims");
+    for (size_t e = 0; e < edges.size(); ++e)
+      if (sims[e] != 0) add_edge((long long)(edges[e] >> 32), (long long)(edges[e] & 0xFFFFFFFFull), sims[e]);
+  }
+  ctx->stat_graph_nodes = (long long)gnode.size();
+  ctx->stat_graph_edges = (long long)ge.size();
+  lap("graph");
+  // ComputeLineTrackLabelsGreedy (merging/merging.cc:18-103): edges descending by (sim, idx1, idx2), a total order
+  const int n_nodes = (int)gnode.size();
+  auto ge_before = [](const GEdge &x, const GEdge &y) {
+    if (x.sim != y.sim) return x.sim > y.sim;
+    if (x.n1 != y.n1) return x.n1 > y.n1;
+    return x.n2 > y.n2;
+  };
+  {
+    // similarities are positive doubles: they order like their bit patterns.  LSD radix sort on the 64 bits (six
+    // 11-bit digits, descending), then a comparison sort inside the (rare) runs of equal similarity.
+    std::vector<GEdge> &tmp = ctx->tail_ge2;
+    tmp.resize(ge.size());
+    GEdge *src = ge.data(), *dst = tmp.data();
+    const size_t n = ge.size();
+    bool all_pos = true;
+    for (size_t i = 0; i < n; ++i) all_pos = all_pos && src[i].sim > 0.0;
+    if (all_pos && n > 64) {
+      unsigned cnt[2048];
+      for (int pass = 0; pass < 6; ++pass) {
+        const int sh = 11 * pass;
+        std::memset(cnt, 0, sizeof(cnt));
+        for (size_t i = 0; i < n; ++i) {
+          unsigned long long u;
+          std::memcpy(&u, &src[i].sim, 8);
+          ++cnt[(u >> sh) & 2047u];
+        }
+        unsigned run = 0;  // descending: the largest digit first
+        for (int d = 2047; d >= 0; --d) {
+          const unsigned c = cnt[d];
+          cnt[d] = run;
+          run += c;
+        }
+        for (size_t i = 0; i < n; ++i) {
+          unsigned long long u;
+          std::memcpy(&u, &src[i].sim, 8);
+          dst[cnt[(u >> sh) & 2047u]++] = src[i];
+        }
+        std::swap(src, dst);
+      }
+      // six passes: the result is back in ge (src == ge.data())
+      for (size_t i = 0; i < n;) {
+        size_t j = i + 1;
+        while (j < n && src[j].sim == src[i].sim) ++j;
+        if (j - i > 1) std::sort(src + i, src + j, ge_before);
+        i = j;
+      }
+    } else {
+      std::sort(ge.begin(), ge.end(), ge_before);
+    }
+  }
+  lap("edge sort");
+  std::vector<int> parent(n_nodes, -1);
+  // images_in_track (std::set<int> per root in the reference, :52-84): only the set SIZES steer the
+  // union, so a bit set per node over the image indices is equivalent
+  const size_t W = ((size_t)ctx->n_img + 63) / 64;
+  std::vector<unsigned long long> img_bits((size_t)n_nodes * W, 0ull);
+  std::vector<int> img_cnt(n_nodes, 1);
+  for (int i = 0; i < n_nodes; ++i) {
+    const int im = ctx->h_node_img[gnode[i]];
+    img_bits[(size_t)i * W + (size_t)im / 64] |= 1ull << (im & 63);
+  }
+  auto absorb = [&](int dst, int src) {  // images[dst] |= images[src]; images[src] = {}
+    int c = 0;
+    for (size_t w = 0; w < W; ++w) {
+      unsigned long long v = img_bits[(size_t)dst * W + w] | img_bits[(size_t)src * W + w];
+      img_bits[(size_t)dst * W + w] = v;
+      img_bits[(size_t)src * W + w] = 0ull;
+      c += __builtin_popcountll(v);
+    }
+    img_cnt[dst] = c;
+    img_cnt[src] = 0;
+  };
+  // merging strategies (global_line_triangulator.cc:306-316): greedy unions every edge; "exhaustive" and "avg"
+  // first test the two unions with LineLinker3d::check_connection in avgtest mode (line_linker.h:131-137)
+  const int strategy = ctx->cfg.merging_strategy;
+  LinkCfg3 lavg = make_l3(ctx->cfg);
+  lavg.use_angle = 1; lavg.use_overlap = 0; lavg.use_perp = 1; lavg.use_innerseg = 0; lavg.use_scaleinv = 0;
+  struct UL {  // a line of a union: endpoints + uncertainty (depths are not read in avgtest mode)
+    L3 l;
+    double unc;
+  };
+  auto node_line = [&](int i) {
+    const Cand &c = ctx->best_c[gnode[(size_t)i]];
+    return UL{L3{mk3(c.s[0], c.s[1], c.s[2]), mk3(c.e[0], c.e[1], c.e[2])}, c.unc};
+  };
+  std::vector<std::vector<UL>> lines_in_track;  // exhaustive: merging.cc:130, members in insertion order
+  std::vector<UL> avg_line;                     // avg: merging.cc:271 (+ the member count)
+  std::vector<int> avg_cnt;
+  if (strategy == 1) {
+    lines_in_track.resize((size_t)n_nodes);
+    for (int i = 0; i < n_nodes; ++i) lines_in_track[(size_t)i].push_back(node_line(i));
+  } else if (strategy == 2) {
+    avg_line.resize((size_t)n_nodes);
+    avg_cnt.assign((size_t)n_nodes, 1);
+    for (int i = 0; i < n_nodes; ++i) avg_line[(size_t)i] = node_line(i);
+  }
+  const double nodepth[2] = {0.0, 0.0};
+  for (const GEdge &ed : ge) {
+    int r1 = uf_root(ed.n1, parent), r2 = uf_root(ed.n2, parent);
+    if (r1 == r2) continue;
+    if (strategy == 1) {  // merging.cc:150-168: every overlapping pair of the two unions must connect
+      bool ok = true;
+      for (const UL &a : lines_in_track[(size_t)r1]) {
+        for (const UL &b : lines_in_track[(size_t)r2]) {
+          if (overlap_oneway(a.l, b.l) <= 0) continue;
+          if (!check3d(lavg, a.l, b.l, a.unc, b.unc, nodepth)) {
+            ok = false;
+            break;
+          }
+        }
+        if (!ok) break;
+      }
+      if (!ok) continue;
+    } else if (strategy == 2) {  // merging.cc:289-292: the running averages must connect
+      const UL &a = avg_line[(size_t)r1], &b = avg_line[(size_t)r2];
+      if (!check3d(lavg, a.l, b.l, a.unc, b.unc, nodepth)) continue;
+    }
+    int dst = r1, src = r2;
+    if (img_cnt[r1] < img_cnt[r2]) { dst = r2; src = r1; }
+    parent[src] = dst;
+    absorb(dst, src);
+    if (strategy == 1) {
+      auto &d = lines_in_track[(size_t)dst];
+      auto &sv = lines_in_track[(size_t)src];
+      d.insert(d.end(), sv.begin(), sv.end());
+      std::vector<UL>().swap(sv);
+    } else if (strategy == 2) {  // merging.cc:300-307: count-weighted mean; the new Line3d has uncertainty -1
+      const UL d1 = avg_line[(size_t)dst], d2 = avg_line[(size_t)src];
+      const double n1 = (double)avg_cnt[(size_t)dst], n2 = (double)avg_cnt[(size_t)src];
+      const double ns = (double)(avg_cnt[(size_t)dst] + avg_cnt[(size_t)src]);
+      auto wmean = [&](d3 p, d3 q) {
+        return mk3((p.x * n1 + q.x * n2) / ns, (p.y * n1 + q.y * n2) / ns, (p.z * n1 + q.z * n2) / ns);
+      };
+      avg_line[(size_t)dst] = UL{L3{wmean(d1.l.s, d2.l.s), wmean(d1.l.e, d2.l.e)}, -1.0};
+      avg_cnt[(size_t)dst] += avg_cnt[(size_t)src];
+    }
+  }
+  // NOTE: the reference's recursive root lookup compresses paths as a side effect and reads
+  // parent_nodes[node] afterwards; labels are assigned from the parent array as it stands after
+  // the union loop.  uf_root() above applies the same full path compression per lookup.
+  std::vector<int> labels(n_nodes, -1);
+  int n_tracks = 0;
+  for (int i = 0; i < n_nodes; ++i) {
+    if (parent[i] == -1) continue;
+    int p = parent[i];
+    if (parent[p] == -1 && labels[p] == -1) labels[p] = n_tracks++;
+  }
+  for (int i = 0; i < n_nodes; ++i) {
+    if (parent[i] == -1) continue;
+    labels[i] = labels[uf_root(i, parent)];
+  }
+  lap("union-find");
+  // build_tracks_from_clusters (:293-351): members in node order per track, flat arrays
+  ctx->tracks.clear();
+  if (n_nodes > 0) {
+    int mx = -1;
+    for (int l : labels) mx = std::max(mx, l);
+    const size_t nT = (size_t)(mx + 1);
+    TrackStore &ts = ctx->tracks;
+    ts.off.assign(nT + 1, 0);
+    for (int i = 0; i < n_nodes; ++i)
+      if (labels[i] >= 0) ++ts.off[(size_t)labels[i] + 1];
+    for (size_t t = 0; t < nT; ++t) ts.off[t + 1] += ts.off[t];
+    const size_t nM = (size_t)ts.off[nT];
+    ts.img_ids.resize(nM); ts.line_ids.resize(nM); ts.node_ids.resize(nM); ts.scores.resize(nM); ts.gnodes.resize(nM);
+    ts.line7.resize(7 * nT);
+    std::vector<long long> wr(ts.off.begin(), ts.off.end() - 1);
+    for (int i = 0; i < n_nodes; ++i) {
+      const int tl = labels[i];
+      if (tl == -1) continue;
+      const long long g = gnode[i];
+      const int img = ctx->h_node_img[g];
+      const size_t w = (size_t)wr[(size_t)tl]++;
+      ts.node_ids[w] = i;
+      ts.img_ids[w] = ctx->img_ids[img];
+      ts.line_ids[w] = (int)(g - ctx->seg_off[img]);
+      ts.scores[w] = ctx->best_score[g];
+      ts.gnodes[w] = g;
+    }
+    // shared with the workers of the persistent team that are awake (lt_pool.h): a few thousand tracks aggregate
+    // faster than a sleeping OpenMP team starts on a big host
+    lt_host::pool_for((long long)nT, 16, [&](long long t0_, long long t1_) {
+      static thread_local AggScratch scratch;
+      for (long long t = t0_; t < t1_; ++t) {
+        const size_t a = (size_t)ts.off[(size_t)t], n = (size_t)ts.off[(size_t)t + 1] - a;
+        aggregate(ctx->best_c, ts.gnodes.data() + a, ts.scores.data() + a, (int)n, ctx->cfg.num_outliers_aggregator,
+                  ts.line7.data() + 7 * (size_t)t, scratch);
+      }
+    });
+  }
+  for (long long g : gnode) gmap[(size_t)g] = -1;  // leave the scratch map clean
+  lap("tracks+aggregate");
+  ctx->tracks_done = true;
+  ctx->timers[10] = now_ms() - t0;
+  return LT_OK;
+}
+
+}  // extern "C"
