@@ -388,8 +388,10 @@ int init_common(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *s
 }
 
 // hk / hq / ht / hs: the scene in host memory (ascending id order) if the caller has it, else it is read back
+// sync = false: the caller's uploads read page-locked memory that outlives them (lt_init) -- nothing here needs the
+// device to have finished, later work is ordered behind it on the context's stream
 int build_invariants(lt_ctx *ctx, const double *hk = nullptr, const double *hq = nullptr, const double *ht = nullptr,
-                     const double *hs = nullptr) {
+                     const double *hs = nullptr, bool sync = true) {
   hipStream_t st = ctx->stream;
   ENSURE(ctx, ctx->d_cams, sizeof(Cam) * (size_t)std::max(ctx->n_img, 1));
   ENSURE(ctx, ctx->d_segs, sizeof(Seg) * (size_t)std::max<long long>(ctx->G, 1));
@@ -407,7 +409,7 @@ int build_invariants(lt_ctx *ctx, const double *hk = nullptr, const double *hq =
   launch_build_segs(st, ctx->G, ctx->n_img, ctx->d_seg_off.as<long long>(), ctx->d_segs_raw.as<double>(),
                     ctx->cfg.add_halfpix ? 0.5 : 0.0, ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_seg_gates.p);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(st));
+  if (sync) HIPCHK(ctx, hipStreamSynchronize(st));
   {  // host copies for the tail-side filters (small: 88 B per image + 32 B per segment)
     const int n = ctx->n_img;
     std::vector<double> k(4 * (size_t)n), q(4 * (size_t)n), t(3 * (size_t)n);
@@ -545,6 +547,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_tail_kpos};
   lt_host::host_block_release(ctx->h_pinned_blk);
   lt_host::host_block_release(ctx->best_c_blk);
+  lt_host::host_block_release(ctx->init_blk);
   for (DevBuf *b : bufs) b->release();
   for (auto &e : ctx->ev_b)
     if (e) (void)hipEventDestroy(e);
@@ -605,8 +608,18 @@ int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, 
   int rc = init_common(ctx, n_img, img_ids, seg_off, perm);
   if (rc) return rc;
   lap("init_common");
-  // gather into ascending-id order
-  std::vector<double> k(4 * (size_t)n_img), q(4 * (size_t)n_img), t(3 * (size_t)n_img), s(4 * (size_t)ctx->G);
+  // gather into ascending-id order, into ONE pooled page-locked block [k | q | t | s]: the uploads are then truly
+  // asynchronous (from pageable memory the runtime stages every copy before it returns) and Init does not wait for them
+  const size_t nI = (size_t)n_img, nG = (size_t)ctx->G;
+  const size_t o_q = 4 * nI, o_t = 8 * nI, o_s = 11 * nI + (nI & 1), n_dbl = o_s + 4 * nG;
+  if (ctx->init_blk.p) {  // an earlier Init of this context: its copies may not have been consumed yet
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    lt_host::host_block_release(ctx->init_blk);
+    ctx->init_blk = lt_host::HostBlock{};
+  }
+  ctx->init_blk = lt_host::host_block_acquire(8 * std::max<size_t>(n_dbl, 1));
+  if (!ctx->init_blk.p) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the scene");
+  double *k = (double *)ctx->init_blk.p, *q = k + o_q, *t = k + o_t, *s = k + o_s;
   for (int i = 0; i < n_img; ++i) {
     int p = perm[i];
     std::memcpy(&k[4 * i], kvec + 4 * p, 32);
@@ -616,12 +629,19 @@ int lt_init(lt_ctx *ctx, int n_img, const int32_t *img_ids, const double *kvec, 
     if (m > 0) std::memcpy(&s[4 * ctx->seg_off[i]], segs + 4 * seg_off[p], (size_t)m * 32);
   }
   lap("gather");
-  if ((rc = upload_vec(ctx, ctx->d_kvec, k))) return rc;
-  if ((rc = upload_vec(ctx, ctx->d_qvec, q))) return rc;
-  if ((rc = upload_vec(ctx, ctx->d_tvec, t))) return rc;
-  if ((rc = upload_vec(ctx, ctx->d_segs_raw, s))) return rc;
+  {
+    hipStream_t st = ctx->stream;
+    ENSURE(ctx, ctx->d_kvec, 32 * std::max<size_t>(nI, 1)); ENSURE(ctx, ctx->d_qvec, 32 * std::max<size_t>(nI, 1));
+    ENSURE(ctx, ctx->d_tvec, 24 * std::max<size_t>(nI, 1)); ENSURE(ctx, ctx->d_segs_raw, 32 * std::max<size_t>(nG, 1));
+    if (nI > 0) {
+      HIPCHK(ctx, hipMemcpyAsync(ctx->d_kvec.p, k, 32 * nI, hipMemcpyHostToDevice, st));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->d_qvec.p, q, 32 * nI, hipMemcpyHostToDevice, st));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->d_tvec.p, t, 24 * nI, hipMemcpyHostToDevice, st));
+    }
+    if (nG > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->d_segs_raw.p, s, 32 * nG, hipMemcpyHostToDevice, st));
+  }
   lap("upload");
-  rc = build_invariants(ctx, k.data(), q.data(), t.data(), s.data());
+  rc = build_invariants(ctx, k, q, t, s, /*sync=*/!ctx->init_blk.pinned);
   lap("build_invariants");
   return rc;
 }

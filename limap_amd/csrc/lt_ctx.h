@@ -251,6 +251,7 @@ struct lt_ctx {
   // best candidate per node: a pooled host block (5.6 MB at 50 000 nodes; value-initialising a fresh vector of
   // that size costs more than the device run) -- an image's range is defined once best_c_set[image] is set
   lt_host::HostBlock best_c_blk;
+  lt_host::HostBlock init_blk;  // page-locked copy of the scene lt_init uploads from (copies may still be in flight)
   Cand *best_c = nullptr;
   std::vector<char> best_c_set;
   std::vector<double> best_score;

@@ -67,6 +67,18 @@ def flatten_bipartites(bpts):
                 lp_off=np.asarray(lp_off, np.int64), lp_ptids=cat(lp, np.int32))
 
 
+class _LazySegs:
+    """img_id -> (M, 4) segments of a triangulator, resolved when a track's 2D lines are first looked at."""
+
+    __slots__ = ("_tri",)
+
+    def __init__(self, tri):
+        self._tri = tri
+
+    def __getitem__(self, img_id):
+        return self._tri._segs[img_id]
+
+
 class _LazyLineTrack(LineTrack):
     """A LineTrack over the arrays lt_get_tracks returned: every field is materialised on first access."""
 
@@ -241,7 +253,7 @@ class GlobalLineTriangulator:
         else:
             self._ctx = _capi.Context(cfg_dict=dict(cfg) if cfg is not None else None, device=device)
         self._img_ids = []
-        self._segs = {}
+        self._segs_src, self._segs_cache = ([], None), {}
         self._seg_off = None
         self._tracks = []
         self._debug = bool(self._ctx.cfg.debug_mode)
@@ -274,19 +286,36 @@ class GlobalLineTriangulator:
 
     def InitArrays(self, img_ids, kvec, qvec, tvec, segs_per_image):
         """Flat-array form of Init (what the C ABI takes)."""
-        seg_off = np.zeros(len(img_ids) + 1, np.int64)
-        seg_off[1:] = np.cumsum([len(s) for s in segs_per_image])
-        segs = np.concatenate(segs_per_image, 0) if len(segs_per_image) else np.zeros((0, 4))
+        n = len(img_ids)
+        seg_off = np.zeros(n + 1, np.int64)
+        np.cumsum([len(s) for s in segs_per_image], out=seg_off[1:])
+        segs = np.concatenate(segs_per_image, 0) if n else np.zeros((0, 4))
         self._ctx.init(img_ids, kvec, qvec, tvec, seg_off, segs.reshape(-1, 4))
-        order = np.argsort(np.asarray(img_ids), kind="stable")
-        self._img_ids = [int(img_ids[o]) for o in order]
-        self._segs = {int(img_ids[o]): np.asarray(segs_per_image[o], float).reshape(-1, 4) for o in order}
-        so = np.zeros(len(img_ids) + 1, np.int64)
-        so[1:] = np.cumsum([len(self._segs[i]) for i in self._img_ids])
-        self._seg_off = so
-        self._idx = {i: n for n, i in enumerate(self._img_ids)}
+        ids = np.asarray(img_ids).astype(np.int64, copy=False).reshape(-1)
+        if n < 2 or bool((ids[1:] > ids[:-1]).all()):  # already in the native order (ascending id): the usual case
+            self._img_ids = ids.tolist()
+            self._seg_off = seg_off
+            self._segs_src = (segs_per_image, None)
+        else:
+            order = np.argsort(ids, kind="stable")
+            self._img_ids = ids[order].tolist()
+            so = np.zeros(n + 1, np.int64)
+            np.cumsum((seg_off[1:] - seg_off[:-1])[order], out=so[1:])
+            self._seg_off = so
+            self._segs_src = (segs_per_image, order.tolist())
+        self._segs_cache = None
+        self._idx = dict(zip(self._img_ids, range(n)))
         self._tracks = []
         self._best_cache = self._all_cache = None
+
+    @property
+    def _segs(self):
+        """img_id -> (M, 4) array of the image's 2D segments, built when a getter first needs the 2D lines."""
+        if self._segs_cache is None:
+            src, order = self._segs_src
+            pos = range(len(self._img_ids)) if order is None else order
+            self._segs_cache = {i: np.asarray(src[o], float).reshape(-1, 4) for i, o in zip(self._img_ids, pos)}
+        return self._segs_cache
 
     def InitVPResults(self, vpresults):
         """vpresults: dict img_id -> limap.vplib.VPResult (or anything with .labels / .vps, a dict with those
@@ -514,7 +543,8 @@ class GlobalLineTriangulator:
     def _build_tracks(self, t):
         # The reference hands back pybind wrappers of C++ LineTracks (no per-member Python objects until they are
         # looked at); building ~35 000 Line2d / Line3d objects eagerly here cost 20x the whole triangulation.
-        tracks = [_LazyLineTrack(t, n, self._segs) for n in range(len(t["off"]) - 1)]
+        segs = _LazySegs(self)
+        tracks = [_LazyLineTrack(t, n, segs) for n in range(len(t["off"]) - 1)]
         if _limap_base is not None:  # limap's LineTrack when limap is installed (linetrack.cc:50-74 dict ctor)
             try:
                 return [_limap_base.LineTrack(tr.as_dict()) for tr in tracks]
