@@ -192,12 +192,14 @@ int64_t lt_num_all_tris(lt_ctx *ctx);
 int lt_get_all_tris(lt_ctx *ctx, int64_t *out_off, double *out_line10, double *out_score,
                     int32_t *out_src2);
 /* GetTracks() -- tracks as CSR over members (LineTrack fields, base/linetrack.h:33-42):
- * line7 = start3,end3,uncertainty */
+ * line7 = start3,end3,uncertainty; line3d10 = per support the Line3d of line3d_list in full: start3, end3, depths2,
+ * uncertainty, score -- the post-triangulation steps read the uncertainties (merging/merging.cc:513-644 re-aggregates
+ * from them), a (start, end) pair alone changes their outcome */
 int64_t lt_num_tracks(lt_ctx *ctx);
 int64_t lt_num_track_members(lt_ctx *ctx);
 int lt_get_tracks(lt_ctx *ctx, double *out_line7, int64_t *out_off, int32_t *out_img_ids,
                   int32_t *out_line_ids, int32_t *out_node_ids, double *out_scores,
-                  double *out_line3d6);
+                  double *out_line3d10);
 
 /* Multi-GPU tail: the rank that triangulated an image exports its per-node results (neighbour list,
  * best candidate per line, valid edges); the rank that runs ComputeLineTracks imports them for the

@@ -432,7 +432,7 @@ class Context:
         T = int(self.L.lt_num_tracks(self.h)); M = int(self.L.lt_num_track_members(self.h))
         line = np.zeros((max(T, 1), 7)); off = np.zeros(T + 1, np.int64)
         img = np.zeros(max(M, 1), np.int32); lid = np.zeros(max(M, 1), np.int32); nid = np.zeros(max(M, 1), np.int32)
-        sc = np.zeros(max(M, 1)); l3d = np.zeros((max(M, 1), 6))
+        sc = np.zeros(max(M, 1)); l3d = np.zeros((max(M, 1), 10))
         self.chk(self.L.lt_get_tracks(self.h, ptr(line, C.c_double), ptr(off, C.c_int64), ptr(img, C.c_int32),
                                       ptr(lid, C.c_int32), ptr(nid, C.c_int32), ptr(sc, C.c_double),
                                       ptr(l3d, C.c_double)))

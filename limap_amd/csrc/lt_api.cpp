@@ -492,7 +492,7 @@ void lt_config_default(lt_config *c) {
   c->l3_use_innerseg = 1; c->l3_use_scaleinv = 0;
 }
 
-int lt_abi_version(void) { return 1; }
+int lt_abi_version(void) { return 2; }  // 2: lt_get_tracks hands out line10 per support (was start3, end3)
 uint64_t lt_sizeof_config(void) { return (uint64_t)sizeof(lt_config); }
 
 lt_ctx *lt_create(const lt_config *cfg, int device) {

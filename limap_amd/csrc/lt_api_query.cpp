@@ -131,7 +131,7 @@ int lt_get_all_tris(lt_ctx *ctx, int64_t *out_off, double *out_line10, double *o
 int64_t lt_num_tracks(lt_ctx *ctx) { return (int64_t)ctx->tracks.size(); }
 int64_t lt_num_track_members(lt_ctx *ctx) { return (int64_t)ctx->tracks.members(); }
 int lt_get_tracks(lt_ctx *ctx, double *out_line7, int64_t *out_off, int32_t *out_img_ids, int32_t *out_line_ids,
-                  int32_t *out_node_ids, double *out_scores, double *out_line3d6) {
+                  int32_t *out_node_ids, double *out_scores, double *out_line3d10) {
   const TrackStore &ts = ctx->tracks;
   const size_t nT = ts.size(), nM = ts.members();
   for (size_t t = 0; t <= nT; ++t) out_off[t] = ts.off[t];
@@ -144,7 +144,9 @@ int lt_get_tracks(lt_ctx *ctx, double *out_line7, int64_t *out_off, int32_t *out
   }
   for (size_t e = 0; e < nM; ++e) {
     const Cand &c = ctx->best_c[ts.gnodes[e]];
-    for (int q = 0; q < 3; ++q) { out_line3d6[6 * e + q] = c.s[q]; out_line3d6[6 * e + 3 + q] = c.e[q]; }
+    double *o = out_line3d10 + 10 * e;  // the supporting Line3d as the reference's LineTrack::line3d_list holds it
+    for (int q = 0; q < 3; ++q) { o[q] = c.s[q]; o[3 + q] = c.e[q]; }
+    o[6] = c.depth[0]; o[7] = c.depth[1]; o[8] = c.unc; o[9] = c.score3;
   }
   return LT_OK;
 }

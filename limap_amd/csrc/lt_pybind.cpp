@@ -199,7 +199,7 @@ class Triangulator {
   }
   py::dict GetTracks() {
     const int64_t T = lt_num_tracks(ctx_), M = lt_num_track_members(ctx_);
-    py::array_t<double> line({(py::ssize_t)T, (py::ssize_t)7}), scores((py::ssize_t)M), l3d({(py::ssize_t)M, (py::ssize_t)6});
+    py::array_t<double> line({(py::ssize_t)T, (py::ssize_t)7}), scores((py::ssize_t)M), l3d({(py::ssize_t)M, (py::ssize_t)10});
     py::array_t<int64_t> off((py::ssize_t)T + 1);
     py::array_t<int32_t> img((py::ssize_t)M), lid((py::ssize_t)M), nid((py::ssize_t)M);
     // (a zero-size numpy array still has a valid data pointer)

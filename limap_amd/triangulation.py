@@ -114,7 +114,7 @@ class _LazyLineTrack(LineTrack):
             v = [Line2d(self._segs[i][l, 0:2], self._segs[i][l, 2:4])
                  for i, l in zip(self.image_id_list, self.line_id_list)]
         elif name == "line3d_list":
-            v = [Line3d(a[0:3], a[3:6]) for a in t["line3d"][self._slice()]]
+            v = [Line3d.from10(a) for a in t["line3d"][self._slice()]]  # full Line3d: depths, uncertainty, score
         else:
             raise AttributeError(name)
         self.__dict__[name] = v

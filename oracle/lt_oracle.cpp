@@ -2135,7 +2135,7 @@ int64_t ora_num_track_members(ora_ctx *ctx) {
 }
 int ora_get_tracks(ora_ctx *ctx, double *out_line7, int64_t *out_off, int32_t *out_img_ids,
                    int32_t *out_line_ids, int32_t *out_node_ids, double *out_scores,
-                   double *out_line3d6) {
+                   double *out_line3d10) {
   int64_t e = 0, ti = 0;
   out_off[0] = 0;
   for (auto &tr : ctx->t.tracks_) {
@@ -2149,9 +2149,10 @@ int ora_get_tracks(ora_ctx *ctx, double *out_line7, int64_t *out_off, int32_t *o
       out_node_ids[e] = tr.node_id_list[k];
       out_scores[e] = tr.score_list[k];
       const ora::Line3d &l = tr.line3d_list[k];
-      double *p = out_line3d6 + 6 * e;
+      double *p = out_line3d10 + 10 * e;  // the supporting Line3d in full (linebase.h:37-60)
       p[0] = l.start.x; p[1] = l.start.y; p[2] = l.start.z;
       p[3] = l.end.x;   p[4] = l.end.y;   p[5] = l.end.z;
+      p[6] = l.depths[0]; p[7] = l.depths[1]; p[8] = l.uncertainty; p[9] = l.score;
     }
     out_off[++ti] = e;
   }

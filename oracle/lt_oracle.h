@@ -123,7 +123,8 @@ int64_t ora_num_tracks(ora_ctx *ctx);
 int64_t ora_num_track_members(ora_ctx *ctx);
 int ora_get_tracks(ora_ctx *ctx, double *out_line7 /* start3,end3,uncertainty */,
                    int64_t *out_off /* T+1 */, int32_t *out_img_ids, int32_t *out_line_ids,
-                   int32_t *out_node_ids, double *out_scores, double *out_line3d6);
+                   int32_t *out_node_ids, double *out_scores,
+                   double *out_line3d10 /* per support: start3, end3, depths2, uncertainty, score */);
 /* stats: [0] connections tested, [1] candidates, [2] candidate pairs visited in scoring,
  * [3] valid edges, [4] graph nodes, [5] graph edges, [6] tracks */
 int ora_get_stats(ora_ctx *ctx, int64_t out[8]);

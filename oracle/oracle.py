@@ -325,7 +325,7 @@ class OracleTriangulator:
         T = int(self.L.ora_num_tracks(self.ctx)); M = int(self.L.ora_num_track_members(self.ctx))
         line = np.zeros((max(T, 1), 7)); off = np.zeros(T + 1, np.int64)
         img = np.zeros(max(M, 1), np.int32); lid = np.zeros(max(M, 1), np.int32)
-        nid = np.zeros(max(M, 1), np.int32); sc = np.zeros(max(M, 1)); l3d = np.zeros((max(M, 1), 6))
+        nid = np.zeros(max(M, 1), np.int32); sc = np.zeros(max(M, 1)); l3d = np.zeros((max(M, 1), 10))
         self.L.ora_get_tracks(self.ctx, _p(line, C.c_double), _p(off, C.c_int64), _p(img, C.c_int32),
                               _p(lid, C.c_int32), _p(nid, C.c_int32), _p(sc, C.c_double), _p(l3d, C.c_double))
         return dict(line=line[:T], off=off, image_ids=img[:M], line_ids=lid[:M], node_ids=nid[:M],

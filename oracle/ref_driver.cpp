@@ -392,7 +392,7 @@ int64_t ref_num_track_members(ora_ctx *ctx) {
   return n;
 }
 int ref_get_tracks(ora_ctx *ctx, double *out_line7, int64_t *out_off, int32_t *out_img_ids, int32_t *out_line_ids,
-                   int32_t *out_node_ids, double *out_scores, double *out_line3d6) {
+                   int32_t *out_node_ids, double *out_scores, double *out_line3d10) {
   int64_t e = 0, ti = 0;
   out_off[0] = 0;
   for (auto &tr : ctx->t->GetTracks()) {
@@ -404,10 +404,13 @@ int ref_get_tracks(ora_ctx *ctx, double *out_line7, int64_t *out_off, int32_t *o
       out_line_ids[e] = tr.line_id_list[k];
       out_node_ids[e] = tr.node_id_list[k];
       out_scores[e] = tr.score_list[k];
+      const Line3d &l3 = tr.line3d_list[k];
+      double *p = out_line3d10 + 10 * e;
       for (int q = 0; q < 3; ++q) {
-        out_line3d6[6 * e + q] = tr.line3d_list[k].start[q];
-        out_line3d6[6 * e + 3 + q] = tr.line3d_list[k].end[q];
+        p[q] = l3.start[q];
+        p[3 + q] = l3.end[q];
       }
+      p[6] = l3.depths[0]; p[7] = l3.depths[1]; p[8] = l3.uncertainty; p[9] = l3.score;
     }
     out_off[++ti] = e;
   }

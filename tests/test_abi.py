@@ -35,7 +35,7 @@ def test_binding_covers_every_symbol():
 def test_config_layout_and_defaults(gpu_lib):
     from limap_amd import _capi
     assert gpu_lib.lt_sizeof_config() == C.sizeof(_capi.LtConfig)
-    assert gpu_lib.lt_abi_version() == 1
+    assert gpu_lib.lt_abi_version() == 2
     cfg = _capi.config_from_dict(None)
     # C++ defaults of the reference (base_line_triangulator.h:27-42, global_line_triangulator.h:16-23,
     # line_linker.h:24-45,94-112)

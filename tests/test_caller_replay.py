@@ -8,8 +8,15 @@ from /root/reference AS IT IS and executed with `limap.*` rebound the way INTEGR
                                                                         segments and write its matches_*.npy files
     pycolmap, tqdm, limap.optimize / pointsfm / vplib / visualize   ->  inert stubs (refinement and visualisation off)
 
-The tracks it returns are compared with the CPU oracle driven through the same sequence.  Skipped where /root/reference
-does not exist (the GPU box): the runner's source cannot travel."""
+The tracks it returns are compared with the CPU oracle driven through the same sequence.  Those two tests need the
+reference tree AND (the second one) a GPU -- the runner's source cannot travel to the GPU box, and the build container
+has no GPU.  What does travel is a RECORD of the real caller: tests/golden/make_caller_trace.py runs the runner body in
+the build container against a recording, oracle-backed `limap.triangulation` / `limap.merging` and writes every call
+with its arguments, plus the tracks the caller got, to tests/golden/caller_trace.json;
+test_recorded_caller_trace_on_this_backend replays that record call by call against the HIP backend on the GPU box.
+(Its first run found a real drop-in defect: the LineTrack lists handed back to the caller carried (start, end) only for
+their supporting 3D lines, and remerge, which re-aggregates from the supports' uncertainties, merged 96 tracks into 48
+where the reference's objects give 96.)"""
 import importlib.util
 import os
 import sys
@@ -243,3 +250,58 @@ def test_reference_runner_body_on_this_backend(gpu_lib, oracle, tmp_path, exhaus
         got = np.concatenate([tr.line.start, tr.line.end])
         scale = max(np.abs(want["line"][k, :6]).max(), 1e-9)
         assert np.abs(got - want["line"][k, :6]).max() / scale <= 1e-5, (k, got, want["line"][k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exhaustive", [False, True])
+def test_recorded_caller_trace_on_this_backend(gpu_lib, exhaustive):
+    """Runs on the GPU box, where the reference tree is absent: tests/golden/caller_trace.json is the record of every
+    call the reference's own runner body made on `limap.triangulation` / `limap.merging` (written by
+    tests/golden/make_caller_trace.py in the build container, answered there by the CPU oracle) -- replayed here call
+    by call, same order, same arguments, against this backend.  The tracks must be the ones the caller got there."""
+    import json
+    import zlib
+    from limap_amd import base, merging, triangulation as tri
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "caller_trace.json")))
+    run = [r for r in doc["runs"] if r["exhaustive"] == exhaustive][0]
+    sc = syn.make_scene(**doc["scene"])
+    imagecols = base.ImageCollection.from_arrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec)
+    all_2d_segs = base.get_all_lines_2d({int(i): sc.segs_of(k) for k, i in enumerate(sc.img_ids)})
+    T, tracks = None, None
+    names = []
+    for call in run["calls"]:
+        name, args = call[0], call[1:]
+        names.append(name)
+        if name == "GlobalLineTriangulator":
+            T = tri.GlobalLineTriangulator(args[0])
+        elif name == "SetRanges":
+            T.SetRanges((np.asarray(args[0][0]), np.asarray(args[0][1])))
+        elif name == "Init":
+            assert args[0] == imagecols.get_img_ids() and args[1] == [len(all_2d_segs[i]) for i in args[0]]
+            T.Init(all_2d_segs, imagecols)
+        elif name == "TriangulateImage":
+            img_id, keys, counts, crc = args
+            full = sc.matches_of(img_id, doc["topk"])
+            m = {k: full[k] for k in keys}
+            got = 0
+            for k in keys:
+                got = zlib.crc32(np.ascontiguousarray(m[k], dtype=np.int32).tobytes(), got)
+            assert [len(m[k]) for k in keys] == counts and got == crc, "the scene generator changed: regenerate the trace"
+            T.TriangulateImage(img_id, m)
+        elif name == "TriangulateImageExhaustiveMatch":
+            T.TriangulateImageExhaustiveMatch(args[0], args[1])
+        elif name == "ComputeLineTracks":
+            tracks = T.ComputeLineTracks()
+        elif name == "remerge":
+            tracks = merging.remerge(base.LineLinker3d(args[0]), tracks)
+        else:
+            tracks = getattr(merging, name)(tracks, imagecols, args[0], args[1])
+    assert names[:3] == ["GlobalLineTriangulator", "SetRanges", "Init"] and "ComputeLineTracks" in names
+    want = run["tracks"]
+    assert len(tracks) == len(want) > 10
+    for k, (tr, w) in enumerate(zip(tracks, want)):
+        assert list(tr.image_id_list) == w["image_ids"] and list(tr.line_id_list) == w["line_ids"], k
+        assert list(tr.node_id_list) == w["node_ids"], k
+        got = np.concatenate([tr.line.start, tr.line.end])
+        scale = max(np.abs(np.asarray(w["line"])).max(), 1e-9)
+        assert np.abs(got - np.asarray(w["line"])).max() / scale <= 1e-9, (k, got, w["line"])

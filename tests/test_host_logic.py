@@ -121,7 +121,7 @@ def test_lazy_line_tracks_materialise_on_access():
              line=np.array([[0, 0, 0, 1, 1, 1, 0.5], [1, 2, 3, 4, 5, 6, 0.25]], float),
              image_ids=np.array([10, 11, 10, 12, 13], np.int32), line_ids=np.array([0, 1, 1, 0, 0], np.int32),
              node_ids=np.array([0, 1, 2, 3, 4], np.int32), scores=np.array([1.0, 2.0, 3.0, 4.0, 5.0]),
-             line3d=np.arange(30, dtype=float).reshape(5, 6))
+             line3d=np.arange(50, dtype=float).reshape(5, 10))
     segs = {i: np.arange(8, dtype=float).reshape(2, 4) + i for i in (10, 11, 12, 13)}
     tr = [tri._LazyLineTrack(t, n, segs) for n in range(2)]
     assert tr[0].count_lines() == 2 and tr[1].count_lines() == 3 and "image_id_list" not in tr[1].__dict__
@@ -130,6 +130,7 @@ def test_lazy_line_tracks_materialise_on_access():
     assert np.array_equal(tr[1].line.start, [1, 2, 3]) and tr[1].line.uncertainty == 0.25
     assert np.array_equal(tr[1].line2d_list[0].start, segs[10][1, 0:2])
     assert np.array_equal(tr[0].line3d_list[1].end, t["line3d"][1, 3:6])
+    assert tr[0].line3d_list[1].uncertainty == t["line3d"][1, 8] and tr[0].line3d_list[1].depths[1] == t["line3d"][1, 7]
     d = tr[1].as_dict()
     assert d["image_id_list"] == [10, 12, 13] and len(d["line2d_list"]) == 3 and d["active"] is True
     with pytest.raises(AttributeError):
@@ -147,7 +148,7 @@ def test_lazy_line_tracks_copy_and_pickle():
              line=np.array([[0, 0, 0, 1, 1, 1, 0.5], [1, 2, 3, 4, 5, 6, 0.25]], float),
              image_ids=np.array([10, 11, 10, 12, 13], np.int32), line_ids=np.array([0, 1, 1, 0, 0], np.int32),
              node_ids=np.array([0, 1, 2, 3, 4], np.int32), scores=np.array([1.0, 2.0, 3.0, 4.0, 5.0]),
-             line3d=np.arange(30, dtype=float).reshape(5, 6))
+             line3d=np.arange(50, dtype=float).reshape(5, 10))
     segs = {i: np.arange(8, dtype=float).reshape(2, 4) + i for i in (10, 11, 12, 13)}
     tr = tri._LazyLineTrack(t, 1, segs)
     for clone in (copy.copy(tr), copy.deepcopy(tr), pickle.loads(pickle.dumps(tr))):
