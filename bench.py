@@ -55,9 +55,10 @@ def device_source_hash():
 def algorithmic_bytes(stats, n_img_active, nn, survivors, mode):
     """SURVEY.md 8(d): bytes_score = 136 C + 104 nodes + 4 E ;
     bytes_gen = 8 P + 32 (nodes + N nn M) + 88 N (1 + nn) + 96 C, with NO 8 P term in exhaustive mode (the
-    connections are implicit there).
+    connections are implicit there).  The rows reach the device packed to one 32-bit word each since round 3, so the
+    row term priced here is 4 P (the smaller, i.e. stricter, figure: `achieved` = algorithmic bytes / time).
     Matched mode runs HOT LOOP 1 as two kernels; its bytes are split where the data is touched:
-      k_gates    : every match row (8 P), the segment and camera records (the 32 / 88 terms), and the list of
+      k_gates    : every match row (4 P), the segment and camera records (the 32 / 88 terms), and the list of
                    rows that pass the gates (8 S, S = stage-A survivors; an entry carries the row)
       k_tri_rows : the survivor list (8 S) and the candidate records it emits (96 C)."""
     C, E, P, G = stats["candidates"], stats["valid_edges"], stats["connections"], stats["active_nodes"]
