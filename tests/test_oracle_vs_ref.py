@@ -1,6 +1,9 @@
 """Pins the ORACLE (oracle/lt_oracle.cpp, the checker of every GPU parity test) against the REFERENCE ITSELF:
 oracle/_ref = the unmodified hot-path sources of /root/reference/src/limap compiled where they lie
 (oracle/Makefile `ref`; Eigen / COLMAP / PoseLib replaced by the stand-in headers of oracle/ref_shim/).
+"Bit for bit" below therefore means: against the reference's sources AS COMPILED AGAINST THAT SHIM -- Eigen's evaluation
+orders and its SVD sign rule are assumptions shared by shim and oracle, not facts checked against a real Eigen build
+(DESIGN.md section 5).
 
 CPU only.  What is compared is what the GPU tests compare: candidate lists in order, candidate geometry bit for
 bit, scores, arg-max, valid edges IN ORDER, graph sizes, track membership and order, aggregated lines, the
