@@ -39,7 +39,7 @@ FP64_VALU_PEAK_TF = 78.6   # MI355X FP64 vector peak: AMD's product specificatio
 # cfgs/triangulation/default.yaml:102-110 (remerging.linker3d)
 REMERGE_LINKER = dict(score_th=0.5, th_angle=5.0, th_overlap=0.001, th_smartoverlap=0.1, th_smartangle=1.0,
                       th_perp=1.0, th_innerseg=1.0)
-DEVICE_SOURCES = ("lt_kernels.hip", "lt_kernels_v2.hip", "lt_kernels_tail.hip", "lt_devfn.h", "lt_geom.h", "lt_device.h")
+DEVICE_SOURCES = ("lt_kernels.hip", "lt_kernels_v2.hip", "lt_kernels_score.hip", "lt_kernels_tail.hip", "lt_devfn.h", "lt_geom.h", "lt_device.h")
 
 
 def device_source_hash():

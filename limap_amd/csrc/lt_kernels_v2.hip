@@ -12,11 +12,7 @@
 //       match-row order -- base_line_triangulator.cc:71-103): per-(block, line) counts -> per-node
 //       prefix over the neighbour blocks -> final position of every candidate.
 //   k_pack_keys + radix sort + k_permute (generic rows): stable sort of the candidates by node.
-//   k_score3
-//       HOT LOOP 2, candidate-major: lane = candidate (nodes packed densely into waves), LDS-staged
-//       sweep over the candidates of the lane's own node with a two-level conservative early exit
-//       (cosine, then squared scale-invariant endpoint distance), survivors evaluated densely from
-//       an LDS queue.
+// The scoring stage (k_cand_meta, k_score3, ...) lives in lt_kernels_score.hip.
 // Compiled with -ffp-contract=off (see lt_geom.h).
 
 #include "lt_devfn.h"
@@ -52,17 +48,6 @@ namespace lt {
 #define LT_GATE_WAVES_PER_EU 4  // two 8-wave workgroups per CU: the register budget is 128
 #endif
 #define LT_GATE_OCC __attribute__((amdgpu_waves_per_eu(LT_GATE_WAVES_PER_EU, LT_GATE_WAVES_PER_EU)))
-#ifdef LT_SCORE_WAVES_PER_EU
-#define LT_SCORE_OCC __attribute__((amdgpu_waves_per_eu(LT_SCORE_WAVES_PER_EU, LT_SCORE_WAVES_PER_EU)))
-#else
-#define LT_SCORE_OCC
-#endif
-#ifndef LT_SCORE_WIN
-#define LT_SCORE_WIN 128
-#endif
-#ifndef LT_SCORE_RESIDENT
-#define LT_SCORE_RESIDENT 16  // persistent k_score3 workgroups (one wave each) per CU, if LDS and registers allow
-#endif
 constexpr int kGenChunks = LT_GEN_CHUNKS;  // 64-row chunks per slot
 constexpr int kRowsPerWave = 64 * kGenChunks;
 constexpr int kGateWaves = LT_GATE_WAVES;  // waves (= slots) per k_gates workgroup
@@ -636,14 +621,6 @@ k_node_prefix(long long G, const int *__restrict__ node_img, const long long *__
   }
 }
 
-// Per-candidate record for the scoring kernel: where its node's candidates start, how many there
-// are, and the neighbour table of its image -- so that the scoring prologue is ONE load level
-// instead of the chain cand_node -> tri_off / node_img -> nb_off.
-struct CandMeta {
-  unsigned off_lo, off_hi;  // tri_off[node] (64-bit split)
-  unsigned n;               // candidates of the node
-  unsigned nb;              // (nb_off[img] << 8) | number of neighbours  (nb_off < 2^24)
-};
 // Fast path: move every staged candidate to its final, reference-ordered position
 //   pos = tri_off[node] + (valid candidates of the node in earlier neighbour blocks) + rank in its run.
 // One wave per slot.  Rows of a block are sorted by line id,
@@ -790,1078 +767,6 @@ __global__ void k_host_view(long long C, const unsigned *__restrict__ perm, cons
   out_l[t] = l;
 }
 
-// Also resets the tile draw counters of the persistent k_score3 that follows, and lists the tiles (64 consecutive
-// candidates = what one wave of this kernel handles per iteration) by COST CLASS: a tile's time in k_score3 grows
-// with the sizes of the nodes it touches (correlation 0.62 with the sum over its lanes of the node size), and a
-// persistent grid finishes earlier when the long tiles start first -- measured on the bench scene: k_score3
-// 138 -> 127 us with the tiles in descending cost order.  No sort: per draw queue kTileBuckets lists filled through
-// one counter each (zeroed by k_build_pairs), drawn from the most expensive class down; the order inside a class
-// is arbitrary.
-constexpr int kTileQueues = 8;  // one draw counter per XCD (workgroups are dealt round-robin to the XCDs)
-constexpr int kTileBuckets = 32;
-__device__ __forceinline__ int tile_bucket(unsigned cost_sum_n) {  // mean node size over the 64 lanes, 2 per class
-  const unsigned b = cost_sum_n >> 7;
-  return (int)(b < (unsigned)(kTileBuckets - 1) ? b : (unsigned)(kTileBuckets - 1));
-}
-__global__ void __launch_bounds__(256)
-k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long *__restrict__ tri_off,
-            const int *__restrict__ node_img, const long long *__restrict__ nb_off, CandMeta *__restrict__ meta,
-            unsigned *__restrict__ draw, unsigned *__restrict__ bucket_cnt, unsigned *__restrict__ bucket_list,
-            unsigned bucket_cap, unsigned *__restrict__ split_counters, uint2 *__restrict__ tile_lohi) {
-  // grid-stride over the exact candidate count tri_off[G]; the host may only know an upper bound
-  const long long C = tri_off[G];
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 64) draw[i * 32] = 0;  // 128 bytes apart (k_score3 / 4 / 5 use the first eight, k_sweep6 all 64)
-  if (split_counters && i < 64) split_counters[i * 32] = 0;  // the region counters of the pair list (k_sweep6)
-  const long long C_up = (C + 63) & ~63ll;  // whole waves take part in the tile's reduction
-  for (; i < C_up; i += stride) {
-    unsigned n = 0;
-    if (i < C) {
-      const unsigned g = cand_node[i];
-      const long long off = tri_off[g];
-      const int img = node_img[g];
-      const long long nb0 = nb_off[img];
-      CandMeta m;
-      m.off_lo = (unsigned)(off & 0xFFFFFFFFll);
-      m.off_hi = (unsigned)(off >> 32);
-      m.n = (unsigned)(tri_off[g + 1] - off);
-      m.nb = ((unsigned)nb0 << 8) | (unsigned)(nb_off[img + 1] - nb0);
-      meta[i] = m;
-      n = m.n;
-      if (tile_lohi) {  // window bounds of the tile (k_sweep6): the nodes of its first and last candidate, whole
-        if ((i & 63) == 0) tile_lohi[i >> 6].x = (unsigned)off;
-        if ((i & 63) == 63 || i == C - 1) tile_lohi[i >> 6].y = (unsigned)(off + (long long)m.n);
-      }
-    }
-    if (bucket_cnt) {
-      unsigned sum = n;
-      for (int d = 32; d >= 1; d >>= 1) sum += (unsigned)__shfl_xor((int)sum, d);
-      if (lane_id() == 0) {
-        // one list per (draw queue, class): 128 counters -- a single counter per class would serialise thousands
-        // of device-scope atomics on one address (~15 ns each)
-        const unsigned tile = (unsigned)(i >> 6);
-        const int qb = (int)(tile & (kTileQueues - 1)) * kTileBuckets + tile_bucket(sum);
-        const unsigned idx = atomicAdd(&bucket_cnt[qb * 32], 1u);  // counters 128 bytes apart: one L2 line each
-        if (idx < bucket_cap) bucket_list[(size_t)qb * bucket_cap + idx] = tile;
-      }
-    }
-  }
-}
-
-// cand_node for pipelines that produce the compact arrays directly (exhaustive mode)
-__global__ void __launch_bounds__(256)
-k_cand_node(long long G, const long long *__restrict__ tri_off, unsigned *__restrict__ cand_node) {
-  long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (g >= G) return;
-  for (long long t = tri_off[g] + lane_id(); t < tri_off[g + 1]; t += 64) cand_node[t] = (unsigned)g;
-}
-
-// ---------------------------------------------------------------------------------------------
-// HOT LOOP 2, candidate-major (scoreOneNode, global_line_triangulator.cc:71-116)
-// ---------------------------------------------------------------------------------------------
-// One wave64 per 64 consecutive candidates (lane = candidate i; small nodes are packed densely into
-// the wave).  The candidates of all nodes the wave touches are staged through an LDS window (SoA:
-// direction, endpoints, neighbour slot), so the O(n^2) sweep runs out of LDS: every lane walks the
-// candidates j of ITS OWN node and applies a two-level conservative early exit (cosine of the 3D
-// angle gate, then the squared one-way scale-invariant endpoint gate with l_i's depths).  Survivors
-// are pushed (ballot + popcount) into an LDS queue and evaluated densely, one pair per lane; the
-// per-neighbour-image maxima live in LDS (ds_max_u64 on the bit pattern of the non-negative scores)
-// and are summed per lane in ascending image-id order (std::map order, :110-112).
-static __device__ __forceinline__ unsigned mt_key(long long off) { return (unsigned)off & 0xFFFFFFu; }
-constexpr int kSQCap = 512;  // the queue is drained when fewer than 256 (4 sweep iterations) slots are free
-constexpr int kWin = LT_SCORE_WIN;
-
-struct Score3Args {
-  long long G;
-  const long long *tri_off;  // tri_off[G] = C
-  const CandMeta *meta;
-  const CRec *cand;
-  const int *blk_order;
-  const Cam *cams;
-  double *score;
-  unsigned long long *pair_counter;  // stats: pairs that reached the dense evaluation
-  unsigned *draw;                    // kTileQueues draw counters, 128 bytes apart: queue q = tiles q, q + 8, ...
-  const unsigned *perm;              // kSorted: candidate record at depth-sorted position t (k_depth_order)
-  const unsigned *spos;              // kSorted over staged records: natural position (score index) of sorted position t
-  const uint2 *rng;                  // kSorted: node-relative range of sorted positions lane t has to sweep
-  const unsigned *tile_order;        // developer experiment: draw e processes tile tile_order[e]
-  const unsigned *bucket_cnt;        // tiles by cost class (k_cand_meta): counts, lists of bucket_cap entries each
-  const unsigned *bucket_list;
-  unsigned bucket_cap;
-  int max_nb;
-  int *err_flag;  // device error flag of the run (7: the pair list of the three-kernel form overflowed)
-  const uint2 *tile_lohi;  // per tile: window bounds = [start of its first candidate's node, end of its last one's)
-};
-
-// Depth order of a node's candidates (large nodes: exhaustive matching gives ~450 candidates per node and
-// 1.6e10 ordered pairs per scene, of which the sweep passes 0.05 %).  All candidates of a node are seen from
-// the node's own view, and the stored depth of a start point is a linear functional with a unit-norm
-// gradient (third row of R) of the point: |z_i - z_j| <= |start_i - start_j|.  A pair whose depths differ by
-// more than the scale-invariant guard radius of i can therefore not pass the sweep's distance guard -- in
-// depth-sorted order candidate i only has to sweep a contiguous range of positions.  One wave per node:
-// bitonic sort of (float depth, index) in LDS, then the range of every position by binary search.  The float
-// keys only steer the pruning (radius widened by their rounding); nodes above kSortMax candidates or with a
-// non-finite depth keep the identity order and the full range.  Which pairs reach the dense evaluation is
-// unchanged, so is every result (LT_TEST_SCORE_UNSORTED: the plain sweep).
-constexpr int kSortMax = 2048;  // the index takes the 11 low bits of the sort word
-
-// Bitonic sort of R * 64 packed 32-bit words (21 key bits | 11 index bits) held R per lane (element e = r * 64 + lane): a
-// compare-exchange distance >= 64 pairs two registers of the same lane, a smaller one the same register of
-// two lanes (one shuffle).  No LDS traffic, every loop unrolled.  (A first version that kept the arrays in
-// LDS and synchronised per stage took 5 ms for the 50 000 nodes of the exhaustive benchmark; this one 0.5.)
-template <int R>
-static __device__ __forceinline__ void wave_bitonic(unsigned (&v)[R], int lane) {
-  constexpr int N = R * 64;
-#pragma unroll
-  for (int k = 2; k <= N; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      if (j >= 64) {
-        const int rj = j >> 6;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          if ((r & rj) == 0) {
-            const bool up = (((r * 64) & k) == 0);  // bit k of e = r * 64 + lane lies above the lane bits
-            const unsigned x = v[r], y = v[r | rj];
-            const unsigned mn = min(x, y), mx = max(x, y);
-            v[r] = up ? mn : mx;
-            v[r | rj] = up ? mx : mn;
-          }
-        }
-      } else {
-        const bool lower = (lane & j) == 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int e = r * 64 + lane;
-          const bool up = (e & k) == 0;
-          const unsigned o = (unsigned)__shfl_xor((int)v[r], j);
-          v[r] = (up == lower) ? min(v[r], o) : max(v[r], o);
-        }
-      }
-    }
-  }
-}
-
-// sorts the node's (depth, index) words and leaves the sorted float keys in LDS (key[0..n)) and perm in HBM
-template <int R>
-static __device__ __forceinline__ bool depth_sort_node(const CRec *__restrict__ cand, long long off, int n, int lane,
-                                                       float *key, unsigned *__restrict__ perm,
-                                                       const unsigned *__restrict__ place, unsigned *__restrict__ rec,
-                                                       const float *__restrict__ st_z) {
-  // word = the float key with its 11 low mantissa bits replaced by the index (n <= 2048): half the compare-exchange
-  // and shuffle work of a (key, index) pair of words; the keys only steer the pruning, k_depth_order widens the
-  // radius by the 2^-12 the truncation can cost
-  unsigned v[R];
-  bool bad = false;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int e = r * 64 + lane;
-    v[r] = ~0u;  // padding sorts to the end
-    if (e < n) {
-      // st_z: the same key, already rounded to single precision, from the compact per-slot array of k_tri_ex
-      const double z = st_z ? (double)st_z[place[off + e]] : cand[place ? (long long)place[off + e] : off + e].depth[0];
-      const float kf = (float)z;
-      bad = bad || !(z > 0.0 && z < 1e30);  // non-positive / NaN / inf / absurd depth: no pruning for this node
-      v[r] = (__float_as_uint(kf) & 0xFFFFF800u) | (unsigned)e;  // positive floats order like their bits
-    }
-  }
-  if (__ballot(bad)) return false;
-  wave_bitonic<R>(v, lane);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int e = r * 64 + lane;
-    if (e < n) {
-      key[e] = __uint_as_float(v[r] & 0xFFFFF800u);
-      const long long nat = off + (long long)(v[r] & 0x7FFu);
-      perm[off + e] = (unsigned)nat;
-      if (place) rec[off + e] = place[nat];
-    }
-  }
-  return true;
-}
-
-__global__ void __launch_bounds__(256)
-k_depth_order(long long G, const long long *__restrict__ tri_off, const CRec *__restrict__ cand, double guard,
-              unsigned *__restrict__ perm, uint2 *__restrict__ rng, const unsigned *__restrict__ place,
-              unsigned *__restrict__ rec, const float *__restrict__ st_z) {
-  // place != nullptr: the records are staged (one-pass exhaustive mode), the candidate at natural position p is record
-  // place[p]; perm then holds the natural position and rec the record of every depth-sorted position
-  __shared__ float s_key[4][kSortMax];
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = lane_id();
-  const long long g = (long long)blockIdx.x * 4 + wv;
-  if (g >= G) return;
-  const long long off = tri_off[g];
-  const int n = (int)(tri_off[g + 1] - off);
-  if (n <= 0) return;
-  float *key = s_key[wv];
-  bool sorted = false;
-  if (n <= 64) sorted = depth_sort_node<1>(cand, off, n, lane, key, perm, place, rec, st_z);
-  else if (n <= 128) sorted = depth_sort_node<2>(cand, off, n, lane, key, perm, place, rec, st_z);
-  else if (n <= 256) sorted = depth_sort_node<4>(cand, off, n, lane, key, perm, place, rec, st_z);
-  else if (n <= 512) sorted = depth_sort_node<8>(cand, off, n, lane, key, perm, place, rec, st_z);
-  else if (n <= 1024) sorted = depth_sort_node<16>(cand, off, n, lane, key, perm, place, rec, st_z);
-  else if (n <= 2048) sorted = depth_sort_node<32>(cand, off, n, lane, key, perm, place, rec, st_z);
-  if (sorted) {
-    wave_lds_sync();
-    for (int r = lane; r < n; r += 64) {
-      const float z = key[r];
-      const double zz = (double)z + kEps;
-      // radius of the sweep's distance guard for this candidate, widened by what the keys lost: a key is the depth
-      // truncated to 13 mantissa bits, k <= z < k (1 + 2^-12), so |k_i - k_j| <= (rad(z_i) + 2.5e-4 k_i)(1 + 2.6e-4)
-      const double rad = guard * zz * 1.001 + 3e-4 * (double)z + 1e-30;
-      int lo = 0, hi = n;
-      if (rad < 1e299) {
-        const float lo_v = (float)((double)z - rad), hi_v = (float)((double)z + rad);
-        int a = 0, b = n;  // first position with key >= lo_v
-        while (a < b) {
-          const int m = (a + b) >> 1;
-          if (key[m] < lo_v) a = m + 1; else b = m;
-        }
-        lo = a;
-        b = n;             // first position with key > hi_v
-        while (a < b) {
-          const int m = (a + b) >> 1;
-          if (key[m] <= hi_v) a = m + 1; else b = m;
-        }
-        hi = a;
-        // (float)(z -+ rad) rounds either way: one more position on each side
-        lo = max(lo - 1, 0);
-        hi = min(hi + 1, n);
-      }
-      rng[off + r] = make_uint2((unsigned)lo, (unsigned)hi);
-    }
-  } else {
-    for (int r = lane; r < n; r += 64) {
-      perm[off + r] = (unsigned)(off + r);
-      if (place) rec[off + r] = place[off + r];
-      rng[off + r] = make_uint2(0u, (unsigned)n);
-    }
-  }
-}
-
-// kF32 (default): the sweep's early exit in single precision on coordinates relative to a wave-local origin,
-// with the rounding of that form bounded and added to the guards, so that it rejects a subset of what the
-// double test rejects, never more: 1e-6 R on a distance (R = largest coordinate magnitude in the window; the
-// bound is 4 sqrt(3) 2^-24 R = 4.2e-7 R), 2e-6 on a cosine of unit vectors (bound 3e-7).  NaN / inf compare
-// false and fall through to the exact evaluation.  Which pairs reach the dense evaluation changes slightly,
-// no result does (tests: LT_TEST_SCORE_F64 = the double-precision sweep, bit-identical outputs).  The window
-// is AoS (3 x float4 per candidate: direction + slot, start, end: three 128-bit LDS reads per pair, broadcast
-// when the lanes of a node walk in step) and the sweep is unrolled by four with the reads hoisted.
-// (A table-free form of the per-image maxima for jobs whose neighbour lists are in ascending image id --
-// running (slot, max, sum) per lane in registers, evaluated pairs handed to their owner lanes by ballot +
-// readlane in queue order -- was measured: 195 us against 142 us, the serial hand-off costs more than the
-// 10 KB of LDS it frees.  Evaluating pair_score without its early returns, for ILP: no difference.)
-// kSorted: the tile is 64 consecutive DEPTH-SORTED positions of the candidate array (k_depth_order); lane t
-// owns candidate perm[t] and sweeps only the sorted positions rng[t] of its node.
-// kPerm: the candidate at position t of the (virtual) compact array is record perm[t] of a.cand / a.lite (the
-// staging lists of stage B: k_place wrote only the permutation); scores are indexed by position.
-template <bool kF32, bool kSorted, bool kPerm>
-__global__ void __launch_bounds__(64) LT_SCORE_OCC
-k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
-  constexpr bool kInd = kSorted || kPerm;  // positions are mapped through a.perm
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int lane = threadIdx.x;
-  // LDS: window (f32: float4[kWin][3]; f64: W[9][kWin] f64 + wslot[kWin] i32) | woff[64] i64 | queue[kSQCap] u32 |
-  //      ord[max_nb] i32 | S[max_nb][64] u64
-  constexpr size_t kWBytes = kF32 ? (size_t)kWin * 48 : (size_t)9 * kWin * 8 + (size_t)kWin * 4;
-  double *W = reinterpret_cast<double *>(smem_raw);
-  int *wslot = reinterpret_cast<int *>(smem_raw + (size_t)9 * kWin * 8);
-  float4 *W4 = reinterpret_cast<float4 *>(smem_raw);
-  long long *woff = reinterpret_cast<long long *>(smem_raw + kWBytes);
-  unsigned *queue = reinterpret_cast<unsigned *>(smem_raw + kWBytes + 64 * 8);
-  int *ordl = reinterpret_cast<int *>(smem_raw + kWBytes + 64 * 8 + kSQCap * 4);
-  unsigned long long *S = reinterpret_cast<unsigned long long *>(
-      smem_raw + ((kWBytes + 64 * 8 + kSQCap * 4 + (size_t)a.max_nb * 4 + 15) & ~(size_t)15));
-
-  const long long C = a.tri_off[a.G];
-  const unsigned n_tiles = (unsigned)((C + 63) >> 6);
-  // Persistent wave: tiles (64 consecutive candidates) are drawn through kTileQueues counters -- queue q
-  // holds the tiles q, q + 8, ... and is served by the workgroups of one XCD (round-robin dispatch), an empty
-  // queue sends its waves to the next one.  The draw for the next tile is issued before the current tile's
-  // work and read after it.  (Listing the tiles by the size of their largest node, longest first, was
-  // measured: no gain -- a tile's time is set by how many of its pairs survive the sweep, which neither the
-  // largest node nor the number of pairs of the tile predicts: correlation 0.6.)
-  int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
-  unsigned long long n_eval_total = 0;
-  unsigned k_raw = 0;
-  if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-  // draws are mapped to tiles through the queue's cost-class lists, most expensive class first: lane b < kTileBuckets
-  // holds the size of class (kTileBuckets - 1 - b) of queue q and the inclusive prefix of the sizes in that order
-  unsigned cls_cnt = 0, cls_incl = 0, q_tiles = 0;
-  auto load_classes = [&]() {
-    cls_cnt = lane < kTileBuckets ? a.bucket_cnt[(q * kTileBuckets + (kTileBuckets - 1 - lane)) * 32] : 0u;
-    cls_incl = cls_cnt;
-#pragma unroll
-    for (int d = 1; d < kTileBuckets; d <<= 1) {
-      const unsigned t = (unsigned)__shfl_up((int)cls_incl, d);
-      if (lane >= d) cls_incl += t;
-    }
-    q_tiles = (unsigned)__shfl((int)cls_incl, kTileBuckets - 1);
-  };
-  if (a.bucket_cnt) load_classes();
-  auto resolve = [&]() -> unsigned {  // tile of the pending draw, 0xFFFFFFFF when every queue is empty
-    for (;;) {
-      const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
-      if (a.bucket_cnt && !a.tile_order) {
-        if (k < q_tiles) {
-          const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
-          const int bl = __builtin_ctzll(m);  // k < q_tiles: some class holds it
-          const unsigned base = (unsigned)__shfl((int)(cls_incl - cls_cnt), bl);
-          return a.bucket_list[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
-        }
-      } else {
-        const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
-        if (e < n_tiles) return a.tile_order ? a.tile_order[e] : (unsigned)e;
-      }
-      // This queue is exhausted.  PEEK at all eight counters (plain loads; a counter only grows, so a queue that looks
-      // exhausted is) and draw only from one that looks open: without this every wave ended with eight failing device
-      // atomics -- dependent round trips behind the kernel's last tiles.
-      if (++tried > 4 * kTileQueues) return 0xFFFFFFFFu;
-      unsigned peek = 0xFFFFFFFFu, cap_l = 0;
-      if (lane < kTileQueues) {
-        peek = __hip_atomic_load(&a.draw[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cap_l = (n_tiles + (unsigned)(kTileQueues - 1 - lane)) / (unsigned)kTileQueues;  // tiles lane, lane + 8, ...
-      }
-      const unsigned long long open_q = __ballot(lane < kTileQueues && lane != q && peek < cap_l);
-      if (!open_q) return 0xFFFFFFFFu;
-      const unsigned long long after = open_q & ~((2ull << q) - 1ull);
-      q = __builtin_ctzll(after ? after : open_q);
-      if (a.bucket_cnt && !a.tile_order) load_classes();
-      if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-    }
-  };
-  unsigned tile = resolve();
-  while (tile != 0xFFFFFFFFu) {
-    if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-    const long long i0 = (long long)tile * 64;
-    const long long tpos = i0 + lane;  // position (sorted order if kSorted)
-    const bool active = tpos < C;
-    const long long i = (kInd && active) ? (long long)a.perm[tpos] : tpos;  // the lane's candidate record
-    LT_TRACE_MARK(2, tile, 0);
-
-    long long off = 0, nb0 = 0;
-    int n = 0, n_nb = 0, sloti = -1;
-    int r_lo = 0, r_hi = 0;  // node-relative positions the lane sweeps
-    double dix = 0, diy = 0, diz = 0;
-    double six = 0, siy = 0, siz = 0, eix = 0, eiy = 0, eiz = 0, gs2 = 0, ge2 = 0;
-    if (active) {
-      const CandMeta mt = a.meta[tpos];  // a position and its candidate belong to the same node
-      off = ((long long)mt.off_hi << 32) | (long long)mt.off_lo;
-      n = (int)mt.n;
-      r_lo = 0; r_hi = n;
-      if (kSorted) {
-        const uint2 rg = a.rng[tpos];
-        r_lo = (int)rg.x; r_hi = (int)rg.y;
-      }
-      nb0 = (long long)(mt.nb >> 8);
-      n_nb = (int)(mt.nb & 0xFFu);
-      const CRec &ci = a.cand[i];
-      dix = ci.dir[0]; diy = ci.dir[1]; diz = ci.dir[2];
-      sloti = crec_slot(ci);
-      six = ci.s[0]; siy = ci.s[1]; siz = ci.s[2];
-      eix = ci.e[0]; eiy = ci.e[1]; eiz = ci.e[2];
-      // dist / (depth + eps) > th_scaleinv (1 + 1e-6) can never score >= score_th (line_dists.cc:55-60)
-      double zs = ci.depth[0] + kEps, ze = ci.depth[1] + kEps;
-      gs2 = (zs > 0.0) ? scaleinv_guard2 * zs * zs : 1e300;  // odd depths: leave it to the exact path
-      ge2 = (ze > 0.0) ? scaleinv_guard2 * ze * ze : 1e300;
-    }
-    woff[lane] = off;
-    // summation order of the first lane's image, staged once (lanes of another image read it from HBM)
-    const long long wave_nb0 = __shfl(nb0, 0);
-    if (lane < __shfl(n_nb, 0)) ordl[lane] = a.blk_order[wave_nb0 + lane];
-    for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
-    // kF32: wave-local origin (the first lane's start point) and this lane's own single-precision operands
-    double ox = 0, oy = 0, oz = 0;
-    float dixf = 0, diyf = 0, dizf = 0, sixf = 0, siyf = 0, sizf = 0, eixf = 0, eiyf = 0, eizf = 0, ri = 0;
-    double gs = 0, ge = 0;
-    float cosf_guard = -2.0f;
-    if (kF32) {
-      ox = __shfl(six, 0); oy = __shfl(siy, 0); oz = __shfl(siz, 0);
-      dixf = (float)dix; diyf = (float)diy; dizf = (float)diz;
-      sixf = (float)(six - ox); siyf = (float)(siy - oy); sizf = (float)(siz - oz);
-      eixf = (float)(eix - ox); eiyf = (float)(eiy - oy); eizf = (float)(eiz - oz);
-      ri = fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)), fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf)));
-      if (!active) ri = 0.0f;
-      gs = sqrt(gs2);
-      ge = sqrt(ge2);
-      cosf_guard = cfg.cos_guard > -1.0 ? (float)(cfg.cos_guard - 2e-6) : -2.0f;
-    }
-    // range of positions this wave has to stage (lane 0 is always active)
-    long long lo = active ? off + r_lo : (1ll << 62);
-    long long hi = active ? off + r_hi : 0;
-    for (int d = 32; d >= 1; d >>= 1) {
-      long long o = __shfl_xor(hi, d);
-      hi = o > hi ? o : hi;
-      o = __shfl_xor(lo, d);
-      lo = o < lo ? o : lo;
-    }
-    int qn = 0;
-    unsigned long long n_eval = 0;
-
-    auto drain = [&]() {
-      wave_lds_sync();
-      for (int q0 = 0; q0 < qn; q0 += 64) {
-        const int p = q0 + lane;
-        if (p < qn) {
-          const unsigned e = queue[p];
-          const int il = (int)(e >> 26);
-          const long long jpos = woff[il] + (long long)(e & 0x3FFFFFFu);
-          const long long j = kInd ? (long long)a.perm[jpos] : jpos;
-          const long long ii = kInd ? (long long)a.perm[i0 + il] : i0 + il;
-          const CRec &ci = a.cand[ii];
-          const CRec &cj = a.cand[j];
-          const int nbs_j = cj.nb_slot;
-          const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
-                                       mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
-                                       mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
-                                       mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg,
-                                       a.cams[(int)((unsigned)nbs_j >> 8)]);
-          if (sc > 0.0) atomicMax(&S[(nbs_j & 0xFF) * 64 + il], (unsigned long long)__double_as_longlong(sc));
-        }
-      }
-      n_eval += (unsigned long long)qn;
-      qn = 0;
-      wave_lds_sync();
-    };
-
-    for (long long wb = lo; wb < hi; wb += kWin) {
-      wave_lds_sync();
-      const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
-      float rw = ri;
-      for (int e = lane; e < wn; e += 64) {
-        const long long src = kInd ? (long long)a.perm[wb + e] : wb + e;
-        const CRec &c = a.cand[src];
-        const CRec &l = c;
-        if (kF32) {
-          const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
-          const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
-          W4[3 * e + 0] = float4{(float)l.dir[0], (float)l.dir[1], (float)l.dir[2], __int_as_float(crec_slot(l))};
-          W4[3 * e + 1] = float4{sx, ex, sy, ey};  // start / end interleaved: the sweep's packed-f32 operand pairs
-          W4[3 * e + 2] = float4{sz, ez, 0.0f, 0.0f};
-          rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
-        } else {
-          W[0 * kWin + e] = l.dir[0]; W[1 * kWin + e] = l.dir[1]; W[2 * kWin + e] = l.dir[2];
-          W[3 * kWin + e] = c.s[0]; W[4 * kWin + e] = c.s[1]; W[5 * kWin + e] = c.s[2];
-          W[6 * kWin + e] = c.e[0]; W[7 * kWin + e] = c.e[1]; W[8 * kWin + e] = c.e[2];
-          wslot[e] = crec_slot(l);
-        }
-      }
-      float gsf = 0.0f, gef = 0.0f;
-      if (kF32) {
-        // R of the window -> this lane's single-precision distance guards (a NaN coordinate makes R NaN,
-        // the guards NaN and every comparison false: everything goes to the exact evaluation)
-        for (int d = 32; d >= 1; d >>= 1) {
-          const float o = __shfl_xor(rw, d);
-          rw = (o > rw || o != o) ? o : rw;
-        }
-        const double delta = 1e-6 * (double)rw;
-        gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
-        gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
-      }
-      wave_lds_sync();
-      if (wb == lo) { LT_TRACE_MARK(2, tile, 1); }
-      // this lane's sub-range of the window
-      long long jlo = (off + r_lo) > wb ? (off + r_lo) : wb;
-      long long jhi = (off + r_hi) < (wb + wn) ? (off + r_hi) : (wb + wn);
-      int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
-      int cmax = cnt;
-      for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d));
-      const int w0 = (int)(jlo - wb);
-      const int jj0 = (int)(jlo - off);
-      const int self_t = (int)(tpos - jlo);  // iteration at which the lane meets itself (may be out of range)
-      if (kF32) {
-        const int wlast = cnt > 0 ? w0 + cnt - 1 : 0;  // reads beyond the lane's range are clamped, then masked
-        const int wbase = cnt > 0 ? w0 : 0;
-        // (one instance of drain() in the code instead of two -- 4040 instead of 5951 lines of ISA -- was measured:
-        // 128.9 against 124.7 us)
-        for (int t = 0; t < cmax; t += 4) {
-          float4 A[4], B[4];
-          float2 E[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int w = min(wbase + t + u, wlast);
-            A[u] = W4[3 * w + 0];
-            B[u] = W4[3 * w + 1];
-            E[u] = *reinterpret_cast<const float2 *>(&W4[3 * w + 2]);
-          }
-          bool pass[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float c = fabsf(__builtin_fmaf(dizf, A[u].z, __builtin_fmaf(diyf, A[u].y, dixf * A[u].x)));
-            // (start, end) pairs: v_pk_add / v_pk_mul / v_pk_fma_f32 straight from the window's layout
-            const float ax = sixf - B[u].x, bx = eixf - B[u].y;
-            const float ay = siyf - B[u].z, by = eiyf - B[u].w;
-            const float az = sizf - E[u].x, bz = eizf - E[u].y;
-            const float ds2 = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
-            const float de2 = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
-            // below the cosine guard the 3D angle score is certainly gated to 0; beyond the squared
-            // distance guards the scale-invariant endpoint score is.  (Bitwise &: no branch per test -- the
-            // reads are clamped, everything may be evaluated.)
-            pass[u] = (t + u < cnt) & (t + u != self_t) & (__float_as_int(A[u].w) != sloti) & !(c < cosf_guard) &
-                      !(ds2 > gsf) & !(de2 > gef);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const unsigned long long m = __ballot(pass[u]);
-            if (m) {
-              if (pass[u]) queue[qn + __popcll(m & lanemask_lt())] = ((unsigned)lane << 26) | (unsigned)(jj0 + t + u);
-              qn += __popcll(m);
-            }
-          }
-          if (qn > kSQCap - 256) drain();
-        }
-      } else {
-        for (int t = 0; t < cmax; ++t) {
-          bool pass = t < cnt;
-          if (pass) {
-            const int w = w0 + t;
-            const int sl = wslot[w];
-            const double jx = W[0 * kWin + w], jy = W[1 * kWin + w], jz = W[2 * kWin + w];
-            const double sx = W[3 * kWin + w], sy = W[4 * kWin + w], sz = W[5 * kWin + w];
-            const double ex = W[6 * kWin + w], ey = W[7 * kWin + w], ez = W[8 * kWin + w];
-            const double c = fabs((dix * jx + diy * jy) + diz * jz);
-            const double ax = six - sx, ay = siy - sy, az = siz - sz;
-            const double bx = eix - ex, by = eiy - ey, bz = eiz - ez;
-            const double ds2 = ax * ax + ay * ay + az * az, de2 = bx * bx + by * by + bz * bz;
-            pass = (t != self_t) && (sl != sloti) && !(c < cfg.cos_guard) && !(ds2 > gs2) && !(de2 > ge2);
-          }
-          const unsigned long long m = __ballot(pass);
-          if (m) {
-            if (pass) queue[qn + __popcll(m & lanemask_lt())] = ((unsigned)lane << 26) | (unsigned)(jj0 + t);
-            qn += __popcll(m);
-            if (qn > kSQCap - 256) drain();
-          }
-        }
-      }
-    }
-    LT_TRACE_MARK(2, tile, 2);
-    drain();
-    LT_TRACE_MARK(2, tile, 3);
-
-    if (active) {
-      double sum = 0.0;
-      const bool own = nb0 == wave_nb0;
-      for (int r = 0; r < n_nb; ++r) {
-        int k = own ? ordl[r] : a.blk_order[nb0 + r];
-        sum += __longlong_as_double((long long)S[k * 64 + lane]);
-      }
-      a.score[kPerm ? tpos : (kSorted && a.spos ? (long long)a.spos[tpos] : i)] = sum;
-    }
-    n_eval_total += n_eval;
-    wave_lds_sync();  // the tables are reused by the next tile
-    tile = resolve();
-  }
-  if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
-}
-
-#ifndef LT_SWEEP6_WIN
-#define LT_SWEEP6_WIN 96
-#endif
-constexpr int kWin4 = LT_SWEEP6_WIN;  // k_sweep6: window entries per chunk (<= 252: 8-bit window index in the queue)
-constexpr int kQ4 = 512;              // k_sweep6: queue capacity (entries), >= 256 + 4 * 64
-static_assert(kWin4 % 4 == 0 && kWin4 <= 252, "window size");
-
-// ---------------------------------------------------------------------------------------------
-// HOT LOOP 2 as THREE kernels (LT_SCORE_SPLIT=1; the fused k_score3 is the default -- see the measurements below):
-//   k_sweep6   per tile of 64 candidates: stage the window of the tile's nodes in LDS (single precision, relative to
-//              a wave-local origin, start / end interleaved for packed-f32 arithmetic; per entry a key = node start
-//              << 8 | neighbour slot, the record index and single-precision guard radii), sweep every lane over the
-//              candidates of its own node -- "same node, other neighbour image" is ONE compare on the keys, which also
-//              masks the lanes that ran past their node; the tests are the squared scale-invariant endpoint guards of
-//              k_score3 (conservative in the same way: a pair is dropped only if the exact gate certainly zeroes
-//              it) -- and WRITE the surviving pairs (record i, record j, image | slot of j, lane of i) to a global
-//              list, a tile's pairs as contiguous segments chained from tile_head[tile].  No evaluation in this
-//              kernel: 114 registers instead of 230.  The chain draw -> window bounds -> record indices -> records is
-//              software-pipelined across tiles; tiles are assigned statically in cost-class order.
-//   k_eval6    flat over the list, 64 pairs per wave-round, every round full (the fused kernel runs its rounds at 43
-//              of 64 lanes), 140 registers = 3 waves per SIMD.  The score overwrites the pair's record indices.
-//   k_reduce6  per tile: the per-(candidate, neighbour image) maxima (ds_max_u64 on a table in LDS) over the tile's
-//              segments, summed per candidate in image-id order (std::map order, global_line_triangulator.cc:110-112).
-// Same pairs, same pair_score, same maxima and sums as the fused kernel (tests: bit-identical scores).
-// Measured at 100 x 500 (us): k_sweep6 68 + k_eval6 41 + k_reduce6 18.5 = 128 against 118 for the fused k_score3 --
-// the evaluation alone got cheaper (41 us against ~47 us-equivalent in the fused kernel), the sweep did not: 16 us of
-// VALU issue take 68 us.  What was tried on the sweep, each measured: dynamic tile draws (one device atomic per tile,
-// 8 or 64 counters: 84-111 us -- the later loads of a wave queue behind the atomic's round trip), static natural
-// order 66, static cost-class order 68, compact records instead of gathers through the permutation 92 -> 92,
-// 8 / 12 / 16 resident waves per CU 71 / 72 / 82-93, a branch-free queue push 77; ablations: without the record
-// gathers 70, without the LDS reads 73, without the sweep loop 20, with the loop but without ballots / pushes 41.
-// The pair list's capacity is a multiple of the candidate bound; a run that overflows it raises device flag 7 and is
-// repeated with the fused kernel (finish_run).
-// ---------------------------------------------------------------------------------------------
-struct PairRec6 {  // 16 B
-  unsigned irec, jrec;  // k_eval6 replaces these two words by the pair's score (f64)
-  unsigned nbs_j;       // (image << 8) | slot of j
-  unsigned il;          // lane (candidate of the tile) of i
-};
-// The list is kRegions6 independent regions, each with its own bump counter (a device-scope atomic on ONE address
-// costs ~15 ns serialised -- one counter for the ~2e4 flushes of a run took 260 us; the counters are 128 bytes apart,
-// one L2 line each).  A segment is a header record {kNoSeg, count, index of the tile's previous header | kNoSeg, tile}
-// followed by its pairs; tile_head[tile] = index of the tile's newest header.
-constexpr unsigned kNoSeg = 0xFFFFFFFFu;
-constexpr int kRegions6 = 64;
-struct Split6 {
-  PairRec6 *pairs;      // [kRegions6][region_cap]
-  uint2 *tile_head;     // [tiles] (newest header of the tile or kNoSeg, its pair count | older segment exists << 31)
-  unsigned *counters;   // [kRegions6 * 32] records used per region (zeroed by k_cand_meta)
-  unsigned region_cap;
-};
-#ifndef LT_SWEEP6_RESIDENT
-#define LT_SWEEP6_RESIDENT 16  // persistent single-wave workgroups per CU, if registers and LDS allow
-#endif
-
-template <bool kPerm>
-__global__ void __launch_bounds__(64)
-k_sweep6(Score3Args a, Split6 sp, double scaleinv_guard2) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int lane = threadIdx.x;
-  // LDS: WB float4[kWin4 + 4] (sx, ex, sy, ey) | WE float4[kWin4 + 4] (sz, ez, key, nb_slot) | WG float2[kWin4] (guard
-  //      radii of the entry as a candidate i) | WP u32[kWin4] | Q u16[kQ4 + 64] (queue + one dump word per lane)
-  float4 *WB = reinterpret_cast<float4 *>(smem_raw);
-  float4 *WE = WB + (kWin4 + 4);
-  float2 *WG = reinterpret_cast<float2 *>(WE + (kWin4 + 4));
-  unsigned *WP = reinterpret_cast<unsigned *>(WG + kWin4);
-  unsigned short *Q = reinterpret_cast<unsigned short *>(WP + kWin4);
-
-  const long long C = a.tri_off[a.G];
-  const unsigned n_tiles = (unsigned)((C + 63) >> 6);
-  // STATIC assignment, longest first: wave w of W takes the tiles of rank w, w + W, w + 2 W, ... in k_cand_meta's
-  // cost-class order (most expensive class first; natural order without the classes).  The sweep's tile times vary
-  // 1:5 and a wave handles only 2-4 tiles, so an even split needs the expensive tiles spread over the waves; a
-  // dynamic draw did that worse here than it costs: a device atomic per tile, with every later load of the wave
-  // queued behind its round trip (memory operations return in order) -- measured 84 us (64 draw counters) against
-  // 66 us (static, natural order) and the figure in profiles/ for this order.
-  // Rank -> tile: the 256 (class, queue) lists of k_cand_meta in rank order, four per lane, prefix by shuffles.
-  unsigned long long n_eval_total = 0;
-  unsigned lc[4] = {0, 0, 0, 0}, lane_incl = 0;
-  if (a.bucket_cnt) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int bk = 4 * lane + u;  // rank order: class kTileBuckets - 1 first, queues 0..7 inside a class
-      const int cls = kTileBuckets - 1 - (bk >> 3), qq = bk & (kTileQueues - 1);
-      lc[u] = a.bucket_cnt[(qq * kTileBuckets + cls) * 32];
-    }
-    lane_incl = lc[0] + lc[1] + lc[2] + lc[3];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned t = (unsigned)__shfl_up((int)lane_incl, d);
-      if (lane >= d) lane_incl += t;
-    }
-  }
-  static_assert(kTileBuckets * kTileQueues == 256, "four class lists per lane");
-  unsigned rank_next = blockIdx.x;
-  auto resolve = [&]() -> unsigned {  // the wave's next tile, 0xFFFFFFFF when it has none left
-    const unsigned g = rank_next;
-    rank_next += gridDim.x;
-    if (g >= n_tiles) return 0xFFFFFFFFu;
-    if (!a.bucket_cnt) return g;
-    const unsigned long long m = __ballot(lane_incl > g);
-    if (!m) return 0xFFFFFFFFu;  // (cannot happen: the lists hold every tile)
-    const int ln = __builtin_ctzll(m);
-    unsigned base = (unsigned)__shfl((int)lane_incl, ln);
-    const unsigned c0 = (unsigned)__shfl((int)lc[0], ln), c1 = (unsigned)__shfl((int)lc[1], ln),
-                   c2 = (unsigned)__shfl((int)lc[2], ln), c3 = (unsigned)__shfl((int)lc[3], ln);
-    base -= c0 + c1 + c2 + c3;  // exclusive prefix of lane ln
-    unsigned r = g - base;
-    int u = 0;
-    if (r >= c0) { r -= c0; u = 1; if (r >= c1) { r -= c1; u = 2; if (r >= c2) { r -= c2; u = 3; } } }
-    const int bk = 4 * ln + u;
-    const int cls = kTileBuckets - 1 - (bk >> 3), qq = bk & (kTileQueues - 1);
-    return a.bucket_list[(size_t)(qq * kTileBuckets + cls) * a.bucket_cap + r];
-  };
-  // The dependent chain of a tile -- draw -> window bounds -> record indices (placement permutation) and node starts
-  // of the window's entries -> records -- is SOFTWARE-PIPELINED across tiles: while tile T is swept, the bounds of
-  // T + 1 (k_cand_meta's per-tile record) and then its record indices / node starts are loaded into registers, so
-  // that a tile starts with the one level that is left: the gather of its records.  (Unpipelined, the five levels
-  // took 9 us of a 15 us tile.)  The first kWin4 entries of a window are covered; a longer window stages its further
-  // chunks the plain way.
-  struct Pre {
-    unsigned tile;
-    unsigned lo, hi;        // window bounds (candidate positions fit 32 bits)
-    unsigned p[2], o[2];    // record index and node start of window entries lane, lane + 64
-    unsigned own_off, own_n;
-  };
-  auto pre_bounds = [&](Pre &x) {
-    const uint2 d = a.tile_lohi[x.tile];
-    x.lo = d.x; x.hi = d.y;
-  };
-  auto pre_entries = [&](Pre &x) {
-    const unsigned wn = min(x.hi - x.lo, (unsigned)kWin4);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const unsigned e = (unsigned)lane + 64u * u;
-      x.p[u] = 0; x.o[u] = 0;
-      if (e < wn) {
-        const unsigned pos = x.lo + e;
-        x.p[u] = kPerm ? a.perm[pos] : pos;
-        x.o[u] = a.meta[pos].off_lo;
-      }
-    }
-    const long long tpos = (long long)x.tile * 64 + lane;
-    x.own_off = 0; x.own_n = 0;
-    if (tpos < C) {
-      const CandMeta mt = a.meta[tpos];
-      x.own_off = mt.off_lo;
-      x.own_n = mt.n;
-    }
-  };
-  static_assert(kWin4 <= 128, "two prefetched entries per lane");
-  Pre cur, nxt;
-  cur.tile = resolve();
-  if (cur.tile != 0xFFFFFFFFu) {
-    pre_bounds(cur);
-    pre_entries(cur);
-  }
-  while (cur.tile != 0xFFFFFFFFu) {
-    const unsigned tile = cur.tile;
-    const long long tpos = (long long)tile * 64 + lane;
-    const bool active = tpos < C;
-    LT_TRACE_MARK(2, tile, 0);
-#ifdef LT_TRACE
-    unsigned long long tr_flush = 0, tr_nflush = 0;
-#endif
-    const long long lo = (long long)cur.lo, hi = (long long)cur.hi;
-    const long long off = (long long)cur.own_off;
-    const int n = (int)cur.own_n;
-    const int wn0 = (int)((hi - lo) < kWin4 ? (hi - lo) : kWin4);
-    // ---- the one exposed level: the records of the first chunk's entries ----
-    double rs[2][6], rd[2][2];
-    int rnbs[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = lane + 64 * u;
-      rnbs[u] = 0;
-      for (int k = 0; k < 6; ++k) rs[u][k] = 0.0;
-      rd[u][0] = rd[u][1] = 0.0;
-      if (e < wn0) {
-        const CRec &c = a.cand[cur.p[u]];
-        rs[u][0] = c.s[0]; rs[u][1] = c.s[1]; rs[u][2] = c.s[2];
-        rs[u][3] = c.e[0]; rs[u][4] = c.e[1]; rs[u][5] = c.e[2];
-        rd[u][0] = c.depth[0]; rd[u][1] = c.depth[1];
-        rnbs[u] = c.nb_slot;
-      }
-    }
-    // meanwhile: the next tile and its bounds (the draw was issued while the previous tile was swept)
-    nxt.tile = resolve();
-    if (nxt.tile != 0xFFFFFFFFu) pre_bounds(nxt);
-    // sentinel key of the tile: node part = (window start - 1) mod 2^24, which no node of the window has; it ends
-    // every chunk and is the key of the idle lanes, wave-local origin = start point of the window's first entry
-    const unsigned key_sentinel = (((unsigned)lo - 1u) << 8) | 0xFFu;
-    const double ox = __shfl(rs[0][0], 0), oy = __shfl(rs[0][1], 0), oz = __shfl(rs[0][2], 0);
-    wave_lds_sync();  // the previous tile's window is no longer read
-    float rw = 0.0f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = lane + 64 * u;
-      if (e < wn0) {
-        const float sx = (float)(rs[u][0] - ox), sy = (float)(rs[u][1] - oy), sz = (float)(rs[u][2] - oz);
-        const float ex = (float)(rs[u][3] - ox), ey = (float)(rs[u][4] - oy), ez = (float)(rs[u][5] - oz);
-        WB[e] = float4{sx, ex, sy, ey};
-        WE[e] = float4{sz, ez, __uint_as_float((cur.o[u] << 8) | (unsigned)(rnbs[u] & 0xFF)), __int_as_float(rnbs[u])};
-        WP[e] = cur.p[u];
-        // guard radii of this entry as candidate i: dist / (depth + eps) > th_scaleinv (1 + 1e-6) can never score
-        // >= score_th (line_dists.cc:55-60); single precision, rounded UP (odd depths: leave it to the exact path)
-        const double zs = rd[u][0] + kEps, ze = rd[u][1] + kEps;
-        const double gs = (zs > 0.0) ? sqrt(scaleinv_guard2 * zs * zs) : 1e150;
-        const double ge = (ze > 0.0) ? sqrt(scaleinv_guard2 * ze * ze) : 1e150;
-        float gsf0 = (float)gs, gef0 = (float)ge;
-        if ((double)gsf0 < gs) gsf0 = __uint_as_float(__float_as_uint(gsf0) + 1u);
-        if ((double)gef0 < ge) gef0 = __uint_as_float(__float_as_uint(gef0) + 1u);
-        WG[e] = float2{gsf0, gef0};
-        rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
-      } else if (e < wn0 + 4) {
-        WE[e] = float4{0.0f, 0.0f, __uint_as_float(key_sentinel), 0.0f};  // every chunk ends in four sentinels
-      }
-    }
-    wave_lds_sync();
-    // this lane's own candidate = window entry tpos - lo (a lane whose entry lies beyond the first chunk -- its node
-    // starts more than kWin4 - 64 positions before the tile -- loads its record itself)
-    float sixf = 0, siyf = 0, sizf = 0, eixf = 0, eiyf = 0, eizf = 0, g0 = 0, g1 = 0;
-    unsigned keyi = key_sentinel, ri = 0;
-    if (active) {
-      const long long own = tpos - lo;
-      if (own < wn0) {
-        const float4 b = WB[own], e4 = WE[own];
-        const float2 g = WG[own];
-        sixf = b.x; eixf = b.y; siyf = b.z; eiyf = b.w; sizf = e4.x; eizf = e4.y;
-        keyi = __float_as_uint(e4.z);
-        g0 = g.x; g1 = g.y;
-        ri = WP[own];
-      } else {
-        ri = kPerm ? a.perm[tpos] : (unsigned)tpos;
-        const CRec &ci = a.cand[ri];
-        sixf = (float)(ci.s[0] - ox); siyf = (float)(ci.s[1] - oy); sizf = (float)(ci.s[2] - oz);
-        eixf = (float)(ci.e[0] - ox); eiyf = (float)(ci.e[1] - oy); eizf = (float)(ci.e[2] - oz);
-        const double zs = ci.depth[0] + kEps, ze = ci.depth[1] + kEps;
-        const double gs = (zs > 0.0) ? sqrt(scaleinv_guard2 * zs * zs) : 1e150;
-        const double ge = (ze > 0.0) ? sqrt(scaleinv_guard2 * ze * ze) : 1e150;
-        g0 = (float)gs; g1 = (float)ge;
-        if ((double)g0 < gs) g0 = __uint_as_float(__float_as_uint(g0) + 1u);
-        if ((double)g1 < ge) g1 = __uint_as_float(__float_as_uint(g1) + 1u);
-        keyi = ((unsigned)mt_key(off) << 8) | (unsigned)(ci.nb_slot & 0xFF);
-      }
-    }
-    const float ri_mag = active ? fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)),
-                                        fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf))) : 0.0f;
-    LT_TRACE_MARK(2, tile, 1);
-    int qc = 0;  // queued entries (wave-uniform); the queue is linear: it is emptied by every flush
-    const unsigned long long lt_mask = lanemask_lt();
-    unsigned seg_prev = kNoSeg, seg_prev_n = 0;
-    const unsigned region = blockIdx.x & (kRegions6 - 1);
-
-    // the queued pairs -> one contiguous segment of the global list (the entries index the current window)
-    auto flush = [&]() {
-#ifdef LT_TRACE
-      const unsigned long long tr0 = wall_clock64();
-#endif
-      wave_lds_sync();
-      unsigned start = 0;
-      if (lane == 0) start = atomicAdd(&sp.counters[region * 32], (unsigned)qc + 1u);
-      start = (unsigned)__builtin_amdgcn_readfirstlane((int)start);
-      const bool fits = (unsigned long long)start + (unsigned)qc + 1ull <= (unsigned long long)sp.region_cap;
-      if (!fits) {
-        if (lane == 0 && a.err_flag) *a.err_flag = 7;
-      } else {
-        const size_t hdr = (size_t)region * sp.region_cap + start;
-        for (int k0 = 0; k0 < qc; k0 += 64) {
-          const int k = k0 + lane;
-          const unsigned e = Q[k < qc ? k : 0];
-          const int il = (int)((e >> 8) & 63u), w = (int)(e & 0xFFu);
-          const unsigned irec = (unsigned)__shfl((int)ri, il);  // cross-lane read by all lanes
-          if (k < qc) {
-            PairRec6 r;
-            r.irec = irec;
-            r.jrec = WP[w];
-            r.nbs_j = __float_as_uint(WE[w].w);
-            r.il = (unsigned)il;
-            *reinterpret_cast<uint4 *>(&sp.pairs[hdr + 1 + (unsigned)k]) = *reinterpret_cast<const uint4 *>(&r);
-          }
-        }
-        if (lane == 0) *reinterpret_cast<uint4 *>(&sp.pairs[hdr]) = uint4{kNoSeg, (unsigned)qc, seg_prev, tile};
-        seg_prev_n = (unsigned)qc | (seg_prev != kNoSeg ? 0x80000000u : 0u);  // top bit: an older segment exists
-        seg_prev = (unsigned)hdr;
-      }
-      n_eval_total += (unsigned long long)qc;
-#ifdef LT_TRACE
-      tr_nflush += (unsigned long long)qc << 16 | 1ull;
-#endif
-      qc = 0;
-      wave_lds_sync();
-#ifdef LT_TRACE
-      tr_flush += wall_clock64() - tr0;
-#endif
-    };
-
-    for (long long wb = lo; wb < hi; wb += kWin4) {
-      const int wn = (int)((hi - wb) < kWin4 ? (hi - wb) : kWin4);
-      if (wb != lo) {
-        // a further chunk of a long window, staged the plain way (its entries were flushed at the end of the last one)
-        wave_lds_sync();
-        rw = 0.0f;
-        for (int e = lane; e < wn + 4; e += 64) {
-          if (e < wn) {
-            const long long pos = wb + e;
-            const unsigned pr = kPerm ? a.perm[pos] : (unsigned)pos;
-            const unsigned eoff = a.meta[pos].off_lo;
-            const CRec &c = a.cand[pr];
-            const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
-            const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
-            const int nbs = c.nb_slot;
-            WB[e] = float4{sx, ex, sy, ey};
-            WE[e] = float4{sz, ez, __uint_as_float((eoff << 8) | (unsigned)(nbs & 0xFF)), __int_as_float(nbs)};
-            WP[e] = pr;
-            rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
-          } else {
-            WE[e] = float4{0.0f, 0.0f, __uint_as_float(key_sentinel), 0.0f};
-          }
-        }
-        wave_lds_sync();
-      }
-      // R of the window -> this lane's single-precision distance guards (a NaN coordinate makes R NaN, the guards
-      // NaN and every comparison false: everything goes to the exact evaluation)
-      float rmax = fmaxf(rw, ri_mag);
-      if (rw != rw) rmax = rw;
-      for (int d = 32; d >= 1; d >>= 1) {
-        const float o = __shfl_xor(rmax, d);
-        rmax = (o > rmax || o != o) ? o : rmax;
-      }
-      const double delta = 1e-6 * (double)rmax;
-      const float gsf = (float)(((double)g0 + delta) * ((double)g0 + delta) * (1.0 + 2e-6));
-      const float gef = (float)(((double)g1 + delta) * ((double)g1 + delta) * (1.0 + 2e-6));
-      const long long jlo = off > wb ? off : wb;
-      const long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
-      const int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
-      int cmax = cnt;
-      for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d));
-      const int w0 = cnt > 0 ? (int)(jlo - wb) : wn;
-      const int wend = w0 + cnt;
-      for (int t = 0; t < cmax; t += 4) {
-        if (qc > kQ4 - 256) flush();
-        float4 B[4], E[4];
-        int wi[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          wi[u] = min(w0 + t + u, wend);
-          B[u] = WB[wi[u]];
-          E[u] = WE[wi[u]];
-        }
-        bool pass[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float ax = sixf - B[u].x, bx = eixf - B[u].y;
-          const float ay = siyf - B[u].z, by = eiyf - B[u].w;
-          const float az = sizf - E[u].x, bz = eizf - E[u].y;
-          const float ds2 = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
-          const float de2 = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
-          const unsigned x = __float_as_uint(E[u].z) ^ keyi;  // same node, another neighbour image: 0 < x < 256
-          pass[u] = ((x - 1u) < 255u) & !(ds2 > gsf) & !(de2 > gef);
-        }
-        // Branch-free push: every lane stores, a lane without a pair into its own word of a dump area behind the
-        // queue.  (The natural form -- `if (ballot) { if (pass) store; }` per step -- compiles to two branches per
-        // step, eight per iteration; their fetch bubbles were 40 % of this kernel: 68 -> 41 us without them.)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned long long m = __ballot(pass[u]);
-          const int slot = pass[u] ? qc + (int)__popcll(m & lt_mask) : kQ4 + lane;
-          Q[slot] = (unsigned short)(((unsigned)lane << 8) | (unsigned)wi[u]);
-          qc += (int)__popcll(m);
-        }
-      }
-      if (qc > 0 && wb + kWin4 < hi) flush();  // the entries index this chunk's window
-    }
-    LT_TRACE_MARK(2, tile, 2);
-    // the next tile's record indices and node starts (its bounds arrived long ago): in flight during the flush
-    if (nxt.tile != 0xFFFFFFFFu) pre_entries(nxt);
-    if (qc > 0) flush();
-    if (lane == 0) sp.tile_head[tile] = uint2{seg_prev, seg_prev_n};
-#ifdef LT_TRACE
-    if (lane == 0 && tile < 65536u) {
-      g_trace[3 * 4 * 65536 + 4 * tile + 0] = tr_flush;
-      g_trace[3 * 4 * 65536 + 4 * tile + 1] = tr_nflush & 0xFFFFull;
-      g_trace[3 * 4 * 65536 + 4 * tile + 2] = tr_nflush >> 16;
-      g_trace[3 * 4 * 65536 + 4 * tile + 3] = wall_clock64();
-    }
-#endif
-    cur = nxt;
-  }
-  if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
-}
-
-// Flat evaluation of the pair list: chunk c = pairs [64 c, 64 c + 64), dealt round-robin to the persistent waves.
-__global__ void __launch_bounds__(256)
-k_eval6(Score3Args a, Split6 sp, ScoreCfg cfg) {
-  if (a.err_flag && *a.err_flag == 7) return;  // the list overflowed: it has holes, the run is repeated (finish_run)
-  const unsigned n_waves = gridDim.x * 4u;
-  const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-  const int lane = lane_id();
-  // chunks of 64 records per region: lane r holds region r's record count and the inclusive prefix of the chunk counts
-  static_assert(kRegions6 == 64, "one lane per region");
-  const unsigned cnt_r = min(sp.counters[lane * 32], sp.region_cap);
-  const unsigned chunks_r = (cnt_r + 63u) >> 6;
-  unsigned incl = chunks_r;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const unsigned t = (unsigned)__shfl_up((int)incl, d);
-    if (lane >= d) incl += t;
-  }
-  const unsigned total_chunks = (unsigned)__shfl((int)incl, 63);
-  // the pair record of the wave's NEXT chunk is loaded while this one is evaluated (one dependent level less per round)
-  auto fetch = [&](unsigned c, size_t &p) -> uint4 {
-    uint4 r = uint4{kNoSeg, 0u, 0u, 0u};
-    p = 0;
-    if (c < total_chunks) {
-      const int reg = __builtin_ctzll(__ballot(incl > c));
-      const unsigned first = (unsigned)__shfl((int)(incl - chunks_r), reg);
-      const unsigned cnt = (unsigned)__shfl((int)cnt_r, reg);
-      const unsigned k = ((c - first) << 6) + (unsigned)lane;
-      p = (size_t)reg * sp.region_cap + k;
-      if (k < cnt) r = *reinterpret_cast<const uint4 *>(&sp.pairs[p]);
-    }
-    return r;
-  };
-  size_t p = 0, p_next = 0;
-  uint4 r = fetch(wave, p);
-  for (unsigned c = wave; c < total_chunks; c += n_waves) {
-    const uint4 r_next = fetch(c + n_waves, p_next);
-    if (r.x != kNoSeg) {  // not a segment header
-      const CRec &ci = a.cand[r.x];
-      const CRec &cj = a.cand[r.y];
-      const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
-                                   mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
-                                   mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
-                                   mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg, a.cams[(int)(r.z >> 8)]);
-      *reinterpret_cast<double *>(&sp.pairs[p]) = sc;  // replaces (irec, jrec)
-    }
-    r = r_next;
-    p = p_next;
-  }
-}
-
-// Per tile: maxima per (candidate, neighbour slot) over the tile's segments, sums in image-id order.
-template <bool kPerm>
-__global__ void __launch_bounds__(256)
-k_reduce6(Score3Args a, Split6 sp) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int lane = lane_id();
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_raw) + (size_t)wv * (size_t)a.max_nb * 64;
-  if (a.err_flag && *a.err_flag == 7) return;  // see k_eval6
-  const long long C = a.tri_off[a.G];
-  const unsigned n_tiles = (unsigned)((C + 63) >> 6);
-  for (unsigned tile = blockIdx.x * 4u + (unsigned)wv; tile < n_tiles; tile += gridDim.x * 4u) {
-  const long long tpos = (long long)tile * 64 + lane;
-  const bool active = tpos < C;
-  long long nb0 = 0;
-  int n_nb = 0;
-  if (active) {
-    const CandMeta mt = a.meta[tpos];
-    nb0 = (long long)(mt.nb >> 8);
-    n_nb = (int)(mt.nb & 0xFFu);
-  }
-  const uint2 th = sp.tile_head[tile];
-  unsigned seg = th.x, seg_n = th.y;  // the newest segment's count comes with the head: its pairs need no header read
-  if (seg == kNoSeg) {  // no pair survived the sweep: every candidate of the tile scores 0
-    if (active) a.score[tpos] = 0.0;
-    continue;
-  }
-  for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
-  const long long wave_nb0 = __shfl(nb0, 0);
-  const int wave_nnb = __shfl(n_nb, 0);
-  const int ordv = lane < wave_nnb ? a.blk_order[wave_nb0 + lane] : 0;
-  wave_lds_sync();
-  int guard = 0;
-  while (seg != kNoSeg && guard++ < (1 << 20)) {
-    // header: {kNoSeg, count, previous header, tile}; only a tile with several segments waits for it
-    uint4 sr = uint4{kNoSeg, seg_n & 0x7FFFFFFFu, kNoSeg, 0u};
-    if (guard > 1 || (seg_n >> 31)) sr = *reinterpret_cast<const uint4 *>(&sp.pairs[seg]);
-    for (unsigned k = (unsigned)lane; k < sr.y; k += 64) {
-      const uint4 r = *reinterpret_cast<const uint4 *>(&sp.pairs[(size_t)seg + 1 + k]);
-      const unsigned long long bits = ((unsigned long long)r.y << 32) | (unsigned long long)r.x;
-      if (__longlong_as_double((long long)bits) > 0.0) atomicMax(&S[(r.z & 0xFFu) * 64 + (r.w & 63u)], bits);
-    }
-    seg = sr.z;
-  }
-  wave_lds_sync();
-  double sum = 0.0;
-  const bool own = nb0 == wave_nb0;
-  int rmax = n_nb;
-  for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d));
-  for (int r = 0; r < rmax; ++r) {  // r is wave-uniform: the first image's order comes by readlane
-    const int k_own = __builtin_amdgcn_readlane(ordv, r);
-    if (r < n_nb) {
-      const int k = own ? k_own : a.blk_order[nb0 + r];
-      sum += __longlong_as_double((long long)S[k * 64 + lane]);
-    }
-  }
-  if (active) a.score[tpos] = sum;
-  wave_lds_sync();  // S is reused by the wave's next tile
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// launch wrappers
-// ---------------------------------------------------------------------------------------------
 static inline unsigned nblk2(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 // slots per block: enough for the largest block, a multiple of the k_gates workgroup
@@ -1873,8 +778,10 @@ int gen_slots(long long max_rows) {
 // groups per block (lists of stage B / placement): wave_count[] has n_blk * gen_groups entries
 int gen_groups(long long max_rows) { return gen_slots(max_rows) / kTriSlots; }
 #ifdef LT_TRACE
+int score_read_trace(unsigned long long *host, size_t n);  // lt_kernels_score.hip: slices 2 and 3
 extern "C" int lt_debug_read_trace(unsigned long long *host, size_t n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), n * 8, 0, hipMemcpyDeviceToHost);
+  const int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), n * 8, 0, hipMemcpyDeviceToHost);
+  return rc ? rc : score_read_trace(host, n);
 }
 #endif
 size_t seg_gate_bytes() { return sizeof(SegGate); }
@@ -1977,102 +884,4 @@ void launch_host_view(hipStream_t st, long long C, const unsigned *perm, const C
                       CandLite *out_l) {
   if (C > 0) hipLaunchKernelGGL(k_host_view, dim3(nblk2(C, 256)), dim3(256), 0, st, C, perm, rec, unc, out_c, out_l);
 }
-void launch_cand_node(hipStream_t st, long long G, const long long *tri_off, unsigned *cand_node) {
-  if (G > 0)
-    hipLaunchKernelGGL(k_cand_node, dim3(nblk2(G * 64, 256)), dim3(256), 0, st, G, tri_off, cand_node);
-}
-size_t score3_lds_bytes(int max_nb, bool f32) {
-  const size_t base = (f32 ? (size_t)kWin * 48 : (size_t)9 * kWin * 8 + (size_t)kWin * 4) + 64 * 8 + kSQCap * 4;
-  return ((base + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
-}
-size_t cand_meta_bytes() { return sizeof(CandMeta); }
-int score3_tile_buckets() { return kTileBuckets * kTileQueues; }  // counters (128 B apart) / lists: one per (queue, class)
-// (A two-kernel form -- light sweep writing per-tile pair lists, then a dense evaluation kernel -- was
-// measured: the sweep alone takes 53 us, but the evaluation does not get cheaper and the two phases no
-// longer overlap across waves: 165+ us against 150 us fused.)
-void launch_score3(hipStream_t st, long long C, long long G, const long long *tri_off, const unsigned *cand_node,
-                   void *meta, const CRec *cand, const int *node_img, const long long *nb_off,
-                   const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
-                   int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
-                   bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
-                   unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap, const unsigned *place,
-                   unsigned *rec, const float *st_z, int *err_flag, void *split_pairs, unsigned *split_tile_head,
-                   unsigned *split_counters, unsigned split_region_cap, void *split_tile_lohi) {
-  // place / rec: depth-sorted sweep over STAGED records (one-pass exhaustive mode): place[natural position] = record,
-  // rec (scratch, one word per candidate) receives the record of every sorted position
-  if (C <= 0) return;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-      n_cu = 256;
-  }
-  // C: the candidate count or an upper bound of it (the kernels read the exact count from tri_off[G])
-  const long long n_tiles = (C + 63) / 64;
-  hipLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st, G,
-                     cand_node, tri_off, node_img, nb_off, reinterpret_cast<CandMeta *>(meta), draw, bucket_cnt, bucket_list,
-                     bucket_cap, split_pairs ? split_counters : nullptr,
-                     split_pairs ? reinterpret_cast<uint2 *>(split_tile_lohi) : nullptr);
-  Score3Args a;
-  a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand;
-  a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
-  a.draw = draw;
-  a.perm = perm; a.rng = reinterpret_cast<const uint2 *>(rng);
-  a.spos = nullptr;
-  a.tile_order = tile_order;
-  a.bucket_cnt = bucket_cnt; a.bucket_list = bucket_list; a.bucket_cap = bucket_cap;
-  a.max_nb = max_nb;
-  a.err_flag = err_flag;
-  a.tile_lohi = reinterpret_cast<const uint2 *>(split_tile_lohi);
-  if (ev_before) (void)hipEventRecord(ev_before, st);
-  const bool sorted = perm != nullptr && f32 && !perm_is_placement;
-  if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
-    hipLaunchKernelGGL(k_depth_order, dim3(nblk2(G, 4)), dim3(256), 0, st, G, tri_off, cand,
-                       scaleinv_guard2 < 1e299 ? std::sqrt(scaleinv_guard2) : 1e300, perm, reinterpret_cast<uint2 *>(rng),
-                       place, rec, place ? st_z : nullptr);
-  if (sorted && place) {
-    a.perm = rec;
-    a.spos = perm;
-  }
-  // LT_SCORE_SPLIT: the natural order (no depth sort) through the three-kernel form k_sweep6 / k_eval6 / k_reduce6
-  // (measured: not faster than the fused kernel; kept selectable, same results)
-  if (f32 && !sorted && max_nb <= 255 && split_pairs) {
-    Split6 sp;
-    sp.pairs = reinterpret_cast<PairRec6 *>(split_pairs);
-    sp.tile_head = reinterpret_cast<uint2 *>(split_tile_head); sp.counters = split_counters; sp.region_cap = split_region_cap;
-    // resident waves of the three kernels (occupancy query once per process; the grids are persistent)
-    static int occ_sweep = 0, occ_eval = 0, occ_red = 0;
-    const size_t lds_sw = (size_t)(kWin4 + 4) * 32 + (size_t)kWin4 * 8 + (size_t)kWin4 * 4 + (size_t)(kQ4 + 64) * 2;
-    const size_t lds_red = (size_t)4 * max_nb * 64 * 8;
-    if (occ_sweep == 0) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_sweep, k_sweep6<true>, 64, lds_sw) != hipSuccess || occ_sweep <= 0) occ_sweep = 8;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_eval, k_eval6, 256, 0) != hipSuccess || occ_eval <= 0) occ_eval = 2;
-      occ_sweep = std::min(occ_sweep, (int)LT_SWEEP6_RESIDENT);  // (the API counts LDS and registers; 64-thread workgroups)
-      if (const char *e = getenv("LT_SWEEP6_RESIDENT")) occ_sweep = std::max(1, atoi(e));
-      if (const char *e = getenv("LT_EVAL6_RESIDENT")) occ_eval = std::max(1, atoi(e));
-    }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_red, k_reduce6<true>, 256, lds_red) != hipSuccess || occ_red <= 0) occ_red = 1;
-    const dim3 g_sw((unsigned)std::min<long long>(n_tiles, (long long)occ_sweep * n_cu));
-    const dim3 g_ev((unsigned)((long long)occ_eval * n_cu));
-    const dim3 g_rd((unsigned)std::min<long long>((n_tiles + 3) / 4, (long long)occ_red * n_cu));
-    if (perm_is_placement) hipLaunchKernelGGL((k_sweep6<true>), g_sw, dim3(64), lds_sw, st, a, sp, scaleinv_guard2);
-    else hipLaunchKernelGGL((k_sweep6<false>), g_sw, dim3(64), lds_sw, st, a, sp, scaleinv_guard2);
-    hipLaunchKernelGGL(k_eval6, g_ev, dim3(256), 0, st, a, sp, cfg);
-    if (perm_is_placement) hipLaunchKernelGGL((k_reduce6<true>), g_rd, dim3(256), lds_red, st, a, sp);
-    else hipLaunchKernelGGL((k_reduce6<false>), g_rd, dim3(256), lds_red, st, a, sp);
-    return;
-  }
-  // persistent grid: as many single-wave workgroups as fit at once (LDS; registers allow LT_SCORE_RESIDENT per CU)
-  const size_t lds = score3_lds_bytes(max_nb, f32);
-  const long long per_cu = std::max<long long>(1, std::min<long long>(LT_SCORE_RESIDENT, (long long)(160 * 1024 / lds)));
-  const dim3 grid((unsigned)std::min<long long>(n_tiles, per_cu * n_cu)), block(64);
-  if (perm_is_placement) {
-    if (f32) hipLaunchKernelGGL((k_score3<true, false, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-    else hipLaunchKernelGGL((k_score3<false, false, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-  } else if (sorted) hipLaunchKernelGGL((k_score3<true, true, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-  else if (f32) hipLaunchKernelGGL((k_score3<true, false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-  else hipLaunchKernelGGL((k_score3<false, false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-}
-
 }  // namespace lt
