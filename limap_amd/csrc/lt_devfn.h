@@ -10,6 +10,42 @@ static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 static __device__ __forceinline__ unsigned long long lanemask_lt() {
   return (1ull << lane_id()) - 1ull;
 }
+// Wave-wide reductions on the VALU's DPP path (row shifts + row broadcasts, result read from lane 63 into a scalar
+// register): a butterfly of __shfl_xor is six DEPENDENT ds_bpermute round trips through the LDS pipe (~100+ cycles
+// each, more when other waves keep that pipe busy); this is a dozen VALU instructions.  Idempotent operators only
+// (lanes without a DPP source combine with themselves).  All 64 lanes must be active.
+template <class Op>
+static __device__ __forceinline__ int wave_reduce_dpp(int v, Op op) {
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xF, 0xF, false));  // row_shr:1
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xF, 0xF, false));  // row_shr:2
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xF, 0xF, false));  // row_shr:4
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xF, 0xF, false));  // row_shr:8  -> lane 15 of every row
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+static __device__ __forceinline__ int wave_max_i32(int v) {
+  return wave_reduce_dpp(v, [](int a, int b) { return a > b ? a : b; });
+}
+static __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  return (unsigned)wave_reduce_dpp((int)v, [](int a, int b) { return (unsigned)a > (unsigned)b ? a : b; });
+}
+static __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  return (unsigned)wave_reduce_dpp((int)v, [](int a, int b) { return (unsigned)a < (unsigned)b ? a : b; });
+}
+// maximum of floats in which a NaN anywhere wins (the sweep's window radius: NaN -> no pruning)
+static __device__ __forceinline__ float wave_max_f32_nan(float v) {
+  return __int_as_float(wave_reduce_dpp(__float_as_int(v), [](int a, int b) {
+    const float x = __int_as_float(a), y = __int_as_float(b);
+    return (y > x || y != y) ? b : a;
+  }));
+}
+static __device__ __forceinline__ double readlane_f64(double v, int src) {  // src: wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
 // Lanes of ONE wave exchanging data through LDS.  DS operations of a wave execute in order, so all
 // that is needed is (a) the compiler must not move LDS accesses across this point (asm memory clobber)
 // and (b) earlier DS results must have landed (lgkmcnt(0)).  Deliberately NOT a fence: an acq_rel

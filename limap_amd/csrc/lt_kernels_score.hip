@@ -357,7 +357,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       const unsigned t = (unsigned)__shfl_up((int)cls_incl, d);
       if (lane >= d) cls_incl += t;
     }
-    q_tiles = (unsigned)__shfl((int)cls_incl, kTileBuckets - 1);
+    q_tiles = (unsigned)__builtin_amdgcn_readlane((int)cls_incl, kTileBuckets - 1);
   };
   if (a.bucket_cnt) load_classes();
   auto resolve = [&]() -> unsigned {  // tile of the pending draw, 0xFFFFFFFF when every queue is empty
@@ -367,7 +367,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
         if (k < q_tiles) {
           const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
           const int bl = __builtin_ctzll(m);  // k < q_tiles: some class holds it
-          const unsigned base = (unsigned)__shfl((int)(cls_incl - cls_cnt), bl);
+          const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)(cls_incl - cls_cnt), bl);
           return a.bucket_list[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
         }
       } else {
@@ -428,8 +428,8 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     }
     woff[lane] = off;
     // summation order of the first lane's image, staged once (lanes of another image read it from HBM)
-    const long long wave_nb0 = __shfl(nb0, 0);
-    if (lane < __shfl(n_nb, 0)) ordl[lane] = a.blk_order[wave_nb0 + lane];
+    const long long wave_nb0 = (long long)__builtin_amdgcn_readfirstlane((int)nb0);  // nb_off < 2^24
+    if (lane < __builtin_amdgcn_readfirstlane(n_nb)) ordl[lane] = a.blk_order[wave_nb0 + lane];
     for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
     // kF32: wave-local origin (the first lane's start point) and this lane's own single-precision operands
     double ox = 0, oy = 0, oz = 0;
@@ -437,7 +437,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     double gs = 0, ge = 0;
     float cosf_guard = -2.0f;
     if (kF32) {
-      ox = __shfl(six, 0); oy = __shfl(siy, 0); oz = __shfl(siz, 0);
+      ox = readlane_f64(six, 0); oy = readlane_f64(siy, 0); oz = readlane_f64(siz, 0);
       dixf = (float)dix; diyf = (float)diy; dizf = (float)diz;
       sixf = (float)(six - ox); siyf = (float)(siy - oy); sizf = (float)(siz - oz);
       eixf = (float)(eix - ox); eiyf = (float)(eiy - oy); eizf = (float)(eiz - oz);
@@ -447,14 +447,18 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       ge = sqrt(ge2);
       cosf_guard = cfg.cos_guard > -1.0 ? (float)(cfg.cos_guard - 2e-6) : -2.0f;
     }
-    // range of positions this wave has to stage (lane 0 is always active)
-    long long lo = active ? off + r_lo : (1ll << 62);
-    long long hi = active ? off + r_hi : 0;
-    for (int d = 32; d >= 1; d >>= 1) {
-      long long o = __shfl_xor(hi, d);
-      hi = o > hi ? o : hi;
-      o = __shfl_xor(lo, d);
-      lo = o < lo ? o : lo;
+    // Range of positions this wave has to stage (lane 0 is always active; positions fit 32 bits).  Natural order: the
+    // lanes' nodes ascend with the lane, so the range runs from the first lane's node to the end of the last active
+    // lane's -- two scalar reads.  Depth-sorted ranges take a DPP reduction (no ds_bpermute butterflies: every level
+    // of those is a round trip through the LDS pipe, and a tile had eighteen of them in a row).
+    long long lo, hi;
+    if (!kSorted) {
+      const int last = (int)((C - i0) < 64 ? (C - i0) : 64) - 1;
+      lo = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(off + r_lo));
+      hi = (long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(off + r_hi), last);
+    } else {
+      lo = (long long)wave_min_u32(active ? (unsigned)(off + r_lo) : 0xFFFFFFFFu);
+      hi = (long long)wave_max_u32(active ? (unsigned)(off + r_hi) : 0u);
     }
     int qn = 0;
     unsigned long long n_eval = 0;
@@ -518,10 +522,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       if (kF32) {
         // R of the window -> this lane's single-precision distance guards (a NaN coordinate makes R NaN,
         // the guards NaN and every comparison false: everything goes to the exact evaluation)
-        for (int d = 32; d >= 1; d >>= 1) {
-          const float o = __shfl_xor(rw, d);
-          rw = (o > rw || o != o) ? o : rw;
-        }
+        rw = wave_max_f32_nan(rw);
         const double delta = 1e-6 * (double)rw;
         gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
         gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
@@ -532,8 +533,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       long long jlo = (off + r_lo) > wb ? (off + r_lo) : wb;
       long long jhi = (off + r_hi) < (wb + wn) ? (off + r_hi) : (wb + wn);
       int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
-      int cmax = cnt;
-      for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d));
+      const int cmax = wave_max_i32(cnt);
       const int w0 = (int)(jlo - wb);
       const int jj0 = (int)(jlo - off);
       const int self_t = (int)(tpos - jlo);  // iteration at which the lane meets itself (may be out of range)
