@@ -677,7 +677,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     // per queue then serialises ~4e4 appends -- k_cand_meta 0.11 -> 0.50 ms -- for an order that changes nothing)
     const bool tile_classes = !getenv("LT_TEST_NO_TILE_CLASSES") && ctx->job_mode == 1;
     const unsigned tile_cap = (unsigned)(((std::max<long long>(C_bound, 1) + 63) / 64 + 7) / 8);  // tiles of one draw queue
-    if (tile_classes) ENSURE(ctx, ctx->d_tile_list, 4 * (size_t)tile_cap * (size_t)score3_tile_buckets());
+    if (tile_classes) ENSURE(ctx, ctx->d_tile_list, 16 * (size_t)tile_cap * (size_t)score3_tile_buckets());  // 16-byte entries
     // large nodes (exhaustive matching): depth-sorted sweep, see k_depth_order
     const bool score_sorted = score_f32 && ctx->job_mode == 2 && !getenv("LT_TEST_SCORE_UNSORTED");
     if (score_sorted) {

@@ -22,6 +22,15 @@ namespace lt {
 #else
 #define LT_SCORE_OCC
 #endif
+// When a wave CLAIMS its next tile (the draw's device atomic) -- measured at 100 x 500, k_score3 in us:
+//   0  at the start of the current tile (rounds 1-2: the atomic's round trip hides behind the whole tile, but a wave
+//      in a long tile sits on a tile nobody else can take while the queues run dry)            122.7
+//   1  before the final dense rounds                                                             122.0
+//   2  at the LAST dense round (round trip behind one round + the ordered sums)                  118.8   <- default
+//   3  after the sums (no reservation at all, the round trip exposed)                            124.9
+#ifndef LT_SCORE_CLAIM
+#define LT_SCORE_CLAIM 2
+#endif
 #ifndef LT_ABL
 // developer ablations of k_score3 (tools/build_variant.sh NAME -DLT_ABL=n; timing only, the results are wrong):
 // 1 no ordered sums, 2 dense rounds without arithmetic, 3 no sweep, 6 no dense rounds, 7 neither
@@ -75,7 +84,7 @@ k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long
   if (split_counters && i < 64) split_counters[i * 32] = 0;  // the region counters of the pair list (k_sweep6)
   const long long C_up = (C + 63) & ~63ll;  // whole waves take part in the tile's reduction
   for (; i < C_up; i += stride) {
-    unsigned n = 0;
+    unsigned n = 0, w_lo = 0, w_hi = 0;
     if (i < C) {
       const unsigned g = cand_node[i];
       const long long off = tri_off[g];
@@ -88,6 +97,7 @@ k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long
       m.nb = ((unsigned)nb0 << 8) | (unsigned)(nb_off[img + 1] - nb0);
       meta[i] = m;
       n = m.n;
+      w_lo = m.off_lo; w_hi = m.off_lo + m.n;
       if (tile_lohi) {  // window bounds of the tile (k_sweep6): the nodes of its first and last candidate, whole
         if ((i & 63) == 0) tile_lohi[i >> 6].x = (unsigned)off;
         if ((i & 63) == 63 || i == C - 1) tile_lohi[i >> 6].y = (unsigned)(off + (long long)m.n);
@@ -96,13 +106,19 @@ k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long
     if (bucket_cnt) {
       unsigned sum = n;
       for (int d = 32; d >= 1; d >>= 1) sum += (unsigned)__shfl_xor((int)sum, d);
-      if (lane_id() == 0) {
+      // the tile's window (natural order): from the node of its first candidate to the end of the node of its last one
+      const long long base = i - lane_id();
+      const int last = (int)((C - base) < 64 ? (C - base) : 64) - 1;
+      const unsigned t_hi = last >= 0 ? (unsigned)__builtin_amdgcn_readlane((int)w_hi, last < 0 ? 0 : last) : 0u;
+      if (lane_id() == 0 && base < C) {
         // one list per (draw queue, class): 128 counters -- a single counter per class would serialise thousands
-        // of device-scope atomics on one address (~15 ns each)
+        // of device-scope atomics on one address (~15 ns each).  An entry is 16 bytes: the tile and its window bounds,
+        // so that k_score3 knows what to stage from the draw alone.
         const unsigned tile = (unsigned)(i >> 6);
         const int qb = (int)(tile & (kTileQueues - 1)) * kTileBuckets + tile_bucket(sum);
         const unsigned idx = atomicAdd(&bucket_cnt[qb * 32], 1u);  // counters 128 bytes apart: one L2 line each
-        if (idx < bucket_cap) bucket_list[(size_t)qb * bucket_cap + idx] = tile;
+        if (idx < bucket_cap)
+          reinterpret_cast<uint4 *>(bucket_list)[(size_t)qb * bucket_cap + idx] = uint4{tile, w_lo, t_hi, 0u};
       }
     }
   }
@@ -146,7 +162,7 @@ struct Score3Args {
   const uint2 *rng;                  // kSorted: node-relative range of sorted positions lane t has to sweep
   const unsigned *tile_order;        // developer experiment: draw e processes tile tile_order[e]
   const unsigned *bucket_cnt;        // tiles by cost class (k_cand_meta): counts, lists of bucket_cap entries each
-  const unsigned *bucket_list;
+  const unsigned *bucket_list;       // entries of four words: tile, first and end position of its window, 0
   unsigned bucket_cap;
   int max_nb;
   int *err_flag;  // device error flag of the run (7: the pair list of the three-kernel form overflowed)
@@ -338,8 +354,8 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   const unsigned n_tiles = (unsigned)((C + 63) >> 6);
   // Persistent wave: tiles (64 consecutive candidates) are drawn through kTileQueues counters -- queue q
   // holds the tiles q, q + 8, ... and is served by the workgroups of one XCD (round-robin dispatch), an empty
-  // queue sends its waves to the next one.  The draw for the next tile is issued before the current tile's
-  // work and read after it.  (Listing the tiles by the size of their largest node, longest first, was
+  // queue sends its waves to the next one.  The draw for the next tile is issued at the current tile's last dense
+  // round (LT_SCORE_CLAIM) and read after its sums.  (Listing the tiles by the size of their largest node, longest first, was
   // measured: no gain -- a tile's time is set by how many of its pairs survive the sweep, which neither the
   // largest node nor the number of pairs of the tile predicts: correlation 0.6.)
   int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
@@ -360,7 +376,9 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     q_tiles = (unsigned)__builtin_amdgcn_readlane((int)cls_incl, kTileBuckets - 1);
   };
   if (a.bucket_cnt) load_classes();
-  auto resolve = [&]() -> unsigned {  // tile of the pending draw, 0xFFFFFFFF when every queue is empty
+  // a draw resolves to the tile and -- from the class lists -- the bounds of its window (x: tile, 0xFFFFFFFF when
+  // every queue is empty; y, z: first and end position of the window, z == 0: not known, derived from the lanes' nodes)
+  auto resolve = [&]() -> uint4 {
     for (;;) {
       const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
       if (a.bucket_cnt && !a.tile_order) {
@@ -368,36 +386,66 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
           const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
           const int bl = __builtin_ctzll(m);  // k < q_tiles: some class holds it
           const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)(cls_incl - cls_cnt), bl);
-          return a.bucket_list[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
+          return reinterpret_cast<const uint4 *>(
+              a.bucket_list)[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
         }
       } else {
         const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
-        if (e < n_tiles) return a.tile_order ? a.tile_order[e] : (unsigned)e;
+        if (e < n_tiles) return uint4{a.tile_order ? a.tile_order[e] : (unsigned)e, 0u, 0u, 0u};
       }
       // This queue is exhausted.  PEEK at all eight counters (plain loads; a counter only grows, so a queue that looks
       // exhausted is) and draw only from one that looks open: without this every wave ended with eight failing device
       // atomics -- dependent round trips behind the kernel's last tiles.
-      if (++tried > 4 * kTileQueues) return 0xFFFFFFFFu;
+      if (++tried > 4 * kTileQueues) return uint4{0xFFFFFFFFu, 0u, 0u, 0u};
       unsigned peek = 0xFFFFFFFFu, cap_l = 0;
       if (lane < kTileQueues) {
         peek = __hip_atomic_load(&a.draw[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cap_l = (n_tiles + (unsigned)(kTileQueues - 1 - lane)) / (unsigned)kTileQueues;  // tiles lane, lane + 8, ...
       }
       const unsigned long long open_q = __ballot(lane < kTileQueues && lane != q && peek < cap_l);
-      if (!open_q) return 0xFFFFFFFFu;
+      if (!open_q) return uint4{0xFFFFFFFFu, 0u, 0u, 0u};
       const unsigned long long after = open_q & ~((2ull << q) - 1ull);
       q = __builtin_ctzll(after ? after : open_q);
       if (a.bucket_cnt && !a.tile_order) load_classes();
       if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
     }
   };
-  unsigned tile = resolve();
-  while (tile != 0xFFFFFFFFu) {
-    if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+  // First level of a tile's loads, issued as soon as its draw is resolved: node record, record index and -- the class
+  // lists carry the window bounds -- the record indices of the first window chunk, so that the chain to the first
+  // window entry in LDS is draw -> {node record, indices} -> records instead of draw -> node record -> (bounds by
+  // shuffles) -> indices -> records.  (Issuing this level BEFORE the previous tile's final dense rounds, so that it lands
+  // while they run, was measured twice -- rounds 2 and 3: 133 against 122 us; the dense rounds' own loads queue behind
+  // it on the in-order vmcnt.)
+  CandMeta p_mt = {0u, 0u, 0u, 0u};
+  uint2 p_rg = make_uint2(0u, 0u);
+  unsigned p_i = 0, p_w0 = 0, p_w1 = 0;
+  static_assert(kWin <= 128, "the first window chunk's record indices are two per lane");
+  auto load_first_level = [&](const uint4 h) {
+    const long long tp = (long long)h.x * 64 + lane;
+    if (tp < C) {
+      p_mt = a.meta[tp];  // a position and its candidate belong to the same node
+      p_i = kInd ? a.perm[tp] : (unsigned)tp;
+      if (kSorted) p_rg = a.rng[tp];
+    }
+    if (kInd && !kSorted && h.z > h.y) {
+      const unsigned w = (h.z - h.y) < (unsigned)kWin ? (h.z - h.y) : (unsigned)kWin;
+      if ((unsigned)lane < w) p_w0 = a.perm[(size_t)h.y + lane];
+      if ((unsigned)lane + 64u < w) p_w1 = a.perm[(size_t)h.y + 64 + lane];
+    }
+  };
+  uint4 hdr = resolve();
+  if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
+  while (hdr.x != 0xFFFFFFFFu) {
+    if (LT_SCORE_CLAIM == 0 && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+    const unsigned tile = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.x);
+    const unsigned h_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.y);
+    const unsigned h_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.z);
+    const bool h_bounds = !kSorted && h_hi > h_lo;
     const long long i0 = (long long)tile * 64;
     const long long tpos = i0 + lane;  // position (sorted order if kSorted)
     const bool active = tpos < C;
-    const long long i = (kInd && active) ? (long long)a.perm[tpos] : tpos;  // the lane's candidate record
+    const long long i = active ? (long long)p_i : tpos;  // the lane's candidate record
+    const unsigned w0src = p_w0, w1src = p_w1;           // records of the first window chunk's entries lane, lane + 64
     LT_TRACE_MARK(2, tile, 0);
 
     long long off = 0, nb0 = 0;
@@ -406,12 +454,12 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     double dix = 0, diy = 0, diz = 0;
     double six = 0, siy = 0, siz = 0, eix = 0, eiy = 0, eiz = 0, gs2 = 0, ge2 = 0;
     if (active) {
-      const CandMeta mt = a.meta[tpos];  // a position and its candidate belong to the same node
+      const CandMeta mt = p_mt;
       off = ((long long)mt.off_hi << 32) | (long long)mt.off_lo;
       n = (int)mt.n;
       r_lo = 0; r_hi = n;
       if (kSorted) {
-        const uint2 rg = a.rng[tpos];
+        const uint2 rg = p_rg;
         r_lo = (int)rg.x; r_hi = (int)rg.y;
       }
       nb0 = (long long)(mt.nb >> 8);
@@ -452,7 +500,9 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     // lane's -- two scalar reads.  Depth-sorted ranges take a DPP reduction (no ds_bpermute butterflies: every level
     // of those is a round trip through the LDS pipe, and a tile had eighteen of them in a row).
     long long lo, hi;
-    if (!kSorted) {
+    if (h_bounds) {
+      lo = (long long)h_lo; hi = (long long)h_hi;
+    } else if (!kSorted) {
       const int last = (int)((C - i0) < 64 ? (C - i0) : 64) - 1;
       lo = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(off + r_lo));
       hi = (long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(off + r_hi), last);
@@ -463,9 +513,11 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     int qn = 0;
     unsigned long long n_eval = 0;
 
-    auto drain = [&]() {
+    auto drain = [&](bool final) {
       wave_lds_sync();
+      if (LT_SCORE_CLAIM == 2 && final && qn == 0 && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
       for (int q0 = 0; q0 < qn; q0 += 64) {
+        if (LT_SCORE_CLAIM == 2 && final && q0 + 64 >= qn && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
         const int p = q0 + lane;
         if (p < qn) {
           const unsigned e = queue[p];
@@ -501,7 +553,8 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
       float rw = ri;
       for (int e = lane; e < wn; e += 64) {
-        const long long src = kInd ? (long long)a.perm[wb + e] : wb + e;
+        const long long src = !kInd ? wb + e
+                              : ((h_bounds && wb == lo && e < 128) ? (long long)(e < 64 ? w0src : w1src) : (long long)a.perm[wb + e]);
         const CRec &c = a.cand[src];
         const CRec &l = c;
         if (kF32) {
@@ -576,7 +629,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
               qn += __popcll(m);
             }
           }
-          if (qn > kSQCap - 256) drain();
+          if (qn > kSQCap - 256) drain(false);
         }
       } else {
         for (int t = 0; t < cmax; ++t) {
@@ -597,7 +650,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
           if (m) {
             if (pass) queue[qn + __popcll(m & lanemask_lt())] = ((unsigned)lane << 26) | (unsigned)(jj0 + t);
             qn += __popcll(m);
-            if (qn > kSQCap - 256) drain();
+            if (qn > kSQCap - 256) drain(false);
           }
         }
       }
@@ -606,7 +659,8 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
 #if LT_ABL == 6 || LT_ABL == 7
     qn = 0;
 #endif
-    drain();
+    if (LT_SCORE_CLAIM == 1 && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+    drain(true);
     LT_TRACE_MARK(2, tile, 3);
 
     if (active) {
@@ -620,7 +674,9 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     }
     n_eval_total += n_eval;
     wave_lds_sync();  // the tables are reused by the next tile
-    tile = resolve();
+    if (LT_SCORE_CLAIM == 3 && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+    hdr = resolve();
+    if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
   }
   if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
 }
@@ -737,7 +793,7 @@ k_sweep6(Score3Args a, Split6 sp, double scaleinv_guard2) {
     if (r >= c0) { r -= c0; u = 1; if (r >= c1) { r -= c1; u = 2; if (r >= c2) { r -= c2; u = 3; } } }
     const int bk = 4 * ln + u;
     const int cls = kTileBuckets - 1 - (bk >> 3), qq = bk & (kTileQueues - 1);
-    return a.bucket_list[(size_t)(qq * kTileBuckets + cls) * a.bucket_cap + r];
+    return a.bucket_list[4 * ((size_t)(qq * kTileBuckets + cls) * a.bucket_cap + r)];
   };
   // The dependent chain of a tile -- draw -> window bounds -> record indices (placement permutation) and node starts
   // of the window's entries -> records -- is SOFTWARE-PIPELINED across tiles: while tile T is swept, the bounds of
