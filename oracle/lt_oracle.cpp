@@ -667,8 +667,11 @@ static Line3d triangulate_line_with_infinite_line(const Line2d &l1, const Camera
 // triangulate_line_with_one_point (functions.cc:325-383 + solvers/triangulation).
 // The reference's solver is ~600 lines of machine-generated coefficients of a quartic in a Lagrange
 // multiplier, solved by PoseLib's univariate::solve_quartic_real (a dependency that is not in the tree).
-// It is NOT copied here; the same optimisation problem is restated from its definition (the comments at
-// the end of that file): in the 2D coordinates of plane 1, with p1, p2 the unit directions of l1's
+// TWO forms live here.  (1) solve_line_with_one_point_generated below: the generated polynomials as data, evaluated
+// term by term in the reference's order -- the default, bit-identical to oracle/_ref.  (2) The same optimisation
+// problem restated from its definition (the comments at the end of that file), which is what the device code follows
+// (ora_set_one_point_solver(0); tests/test_oracle_kat.py ties the two together to the conditioning of form 1):
+// in the 2D coordinates of plane 1, with p1, p2 the unit directions of l1's
 // endpoint rays, p the known point and (lx, ly, lz) the trace of plane 2,
 //     minimise (l . x1)^2 + (l . x2)^2   over x1 = lambda1 p1, x2 = lambda2 p2,
 //     subject to x1, x2, p collinear, lambda1 > 0, lambda2 > 0.
@@ -813,6 +816,65 @@ static std::pair<double, double> solve_line_with_one_point(double lx, double ly,
   return best;
 }
 
+// The reference's solver itself, term by term (solvers/triangulation/triangulate_line_with_one_point.cc:11-645): the
+// generated polynomials are DATA here (onepoint_terms.inc, written by oracle/make_onepoint_terms.py from that file) and
+// are evaluated in the reference's order -- a term left to right ((coef * f1) * f2) ..., a sum left to right,
+// std::pow(x, 2) as x * x (GCC folds it), higher powers through libm -- followed by the same root loop (:556-644).
+// poselib::univariate::solve_quartic_real is the stand-in the reference is compiled against here (PoseLib is not on
+// disk).  Bit-identical to oracle/_ref (tests/test_oracle_vs_ref.py).  The expanded coefficients cancel over ~10
+// digits, so their value -- and the reference's result -- moves by ~1e-6 relative with the last bit of a libm pow();
+// the restated form above is what the device code follows, the two are compared with that tolerance on the CPU.
+#include "onepoint_terms.inc"
+#include "ref_shim/PoseLib/misc/univariate.h"
+static int g_one_point_generated = 1;  // ora_set_one_point_solver: 1 = the reference's generated solver, 0 = restated problem
+static inline double onepoint_pow(double x, int k) { return k == 1 ? x : (k == 2 ? x * x : std::pow(x, (double)k)); }
+static double onepoint_eval(const OnePointTerm *T, int n, const double v[10]) {
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const OnePointTerm &t = T[i];
+    double x;
+    int k = 0;
+    if (t.has_coef) {
+      x = (double)(t.coef < 0 ? -t.coef : t.coef);
+    } else {
+      x = onepoint_pow(v[t.f[0] >> 4], t.f[0] & 15);
+      k = 1;
+    }
+    for (; k < t.n; ++k) x = x * onepoint_pow(v[t.f[k] >> 4], t.f[k] & 15);
+    if (i == 0) acc = t.coef < 0 ? -x : x;
+    else acc = t.coef < 0 ? acc - x : acc + x;
+  }
+  return acc;
+}
+#define ONEPOINT_EVAL(name, v) onepoint_eval(kOnePoint_##name, (int)(sizeof(kOnePoint_##name) / sizeof(OnePointTerm)), v)
+static std::pair<double, double> solve_line_with_one_point_generated(double lx, double ly, double lz, V2 p, V2 p1, V2 p2) {
+  double v[10] = {lx, ly, lz, p.x, p.y, p1.x, p1.y, p2.x, p2.y, 0.0};
+  const double c4 = ONEPOINT_EVAL(c4, v);
+  const double c3 = 0.0;
+  const double c2 = ONEPOINT_EVAL(c2, v);
+  const double c1 = ONEPOINT_EVAL(c1, v);
+  const double c0 = ONEPOINT_EVAL(c0, v);
+  double mu_sols[4];
+  const int sols = poselib::univariate::solve_quartic_real(c3 / c4, c2 / c4, c1 / c4, c0 / c4, mu_sols);
+  std::pair<double, double> best{-1.0, -1.0};
+  double best_err = std::numeric_limits<double>::max();
+  for (int k = 0; k < sols; ++k) {
+    v[9] = mu_sols[k];
+    const double lambda_denom = ONEPOINT_EVAL(lambda_denom, v);
+    const double lambda_1 = ONEPOINT_EVAL(lambda_1, v) / lambda_denom;
+    const double lambda_2 = ONEPOINT_EVAL(lambda_2, v) / lambda_denom;
+    if (lambda_1 <= 0 || lambda_2 <= 0) continue;  // cheirality
+    const double err1 = lx * (lambda_1 * p1.x) + ly * (lambda_1 * p1.y) + lz;
+    const double err2 = lx * (lambda_2 * p2.x) + ly * (lambda_2 * p2.y) + lz;
+    const double err = err1 * err1 + err2 * err2;
+    if (err < best_err) {
+      best_err = err;
+      best = {lambda_1, lambda_2};
+    }
+  }
+  return best;
+}
+
 // Triangulation with a known point, asymmetric perspective to (view1, l1) -- functions.cc:325-383
 static Line3d triangulate_line_with_one_point(const Line2d &l1, const CameraView &view1, const Line2d &l2,
                                               const CameraView &view2, const V3 &point) {
@@ -836,7 +898,8 @@ static Line3d triangulate_line_with_one_point(const Line2d &l1, const CameraView
   V2 input_p{p_t.x, p_t.y};
   V2 input_v1 = normalized(V2{1.0, 0.0});
   V2 input_v2 = normalized(V2{v2_t.x, v2_t.y});
-  auto res = solve_line_with_one_point(n2_t.x, n2_t.y, alpha_t, input_p, input_v1, input_v2);
+  auto res = g_one_point_generated ? solve_line_with_one_point_generated(n2_t.x, n2_t.y, alpha_t, input_p, input_v1, input_v2)
+                                   : solve_line_with_one_point(n2_t.x, n2_t.y, alpha_t, input_p, input_v1, input_v2);
   if (res.first < 0 || res.second < 0) return kSentinel();
   V2 ls2 = input_v1 * res.first, le2 = input_v2 * res.second;
   V3 lstart = r0 * ls2.x + r1 * ls2.y + t;  // R * (x, y, 0) + t
@@ -2275,6 +2338,8 @@ void ora_triangulate_line_with_direction(const double seg1[4], const double cam1
                                                       ora::V3{dir[0], dir[1], dir[2]}),
                  out10);
 }
+void ora_set_one_point_solver(int generated) { ora::g_one_point_generated = generated ? 1 : 0; }
+int ora_get_one_point_solver(void) { return ora::g_one_point_generated; }
 void ora_triangulate_line_with_one_point(const double seg1[4], const double cam1[11], const double seg2[4],
                                          const double cam2[11], const double point[3], double out10[10]) {
   ora::line_to10(ora::triangulate_line_with_one_point(ora::seg_to_line(seg1), ora::view_from_cam11(cam1),

@@ -170,6 +170,10 @@ void ora_get_direction_from_vp(const double vp[3], const double cam[11], double 
 void ora_triangulate_line_with_direction(const double seg1[4], const double cam1[11], const double seg2[4],
                                          const double cam2[11], const double dir[3],
                                          double out10[10]);                              /* functions.cc:385-442 */
+/* one-point proposal: 1 (default) = the reference's generated solver evaluated term by term (bit-identical to
+   oracle/_ref), 0 = the restated optimisation problem (what the device code follows; equal to 1e-6 relative) */
+void ora_set_one_point_solver(int generated);
+int ora_get_one_point_solver(void);
 void ora_triangulate_line_with_one_point(const double seg1[4], const double cam1[11], const double seg2[4],
                                          const double cam2[11], const double point[3],
                                          double out10[10]);                              /* functions.cc:325-383 */

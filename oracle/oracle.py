@@ -21,7 +21,8 @@ def build(force=False):
     if (
         force
         or not os.path.exists(_LIB_PATH)
-        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "lt_oracle.h")))
+        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "lt_oracle.h")),
+                                             os.path.getmtime(os.path.join(_HERE, "onepoint_terms.inc")))
     ):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -123,6 +124,16 @@ def lib():
 
 def set_num_threads(n):
     lib().ora_set_num_threads(int(n))
+
+
+def set_one_point_solver(generated):
+    """One-point proposal: True (default) = the reference's generated solver, term by term (bit-identical to oracle/_ref);
+    False = the restated optimisation problem the device code follows (equal to ~1e-6 relative)."""
+    lib().ora_set_one_point_solver(1 if generated else 0)
+
+
+def get_one_point_solver():
+    return bool(lib().ora_get_one_point_solver())
 
 
 def get_max_threads():

@@ -102,3 +102,20 @@ def compare_tracks(gt, ot, rtol=1e-5, score_rtol=1e-12, exact_members=True):
 
 def small_scene(seed=0, n_views=16, n_segs=120, n_neighbors=8, **kw):
     return syn.make_scene(n_views=n_views, n_segs=n_segs, n_neighbors=n_neighbors, seed=seed, **kw)
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def restated_one_point(oracle):
+    """The oracle's one-point proposal on the restated optimisation problem -- the form the device code follows, bit
+    for bit -- instead of the reference's generated polynomials (the default, bit-identical to oracle/_ref; the two forms
+    are tied together on the CPU by tests/test_oracle_kat.py::test_one_point_restated_problem_equals_generated_solver)."""
+    prev = oracle.get_one_point_solver()
+    oracle.set_one_point_solver(False)
+    try:
+        yield
+    finally:
+        oracle.set_one_point_solver(prev)
+

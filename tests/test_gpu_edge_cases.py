@@ -148,12 +148,14 @@ def test_free_functions_match_oracle(gpu_lib, oracle):
     (pg, okg), (po, oko) = tri.triangulate_point(s1[2:], c1, s2[2:], c2), oracle.triangulate_point(s1[2:], c1, s2[2:], c2)
     assert okg == oko and (not oko or np.array_equal(pg, po))
     # one-point proposal: product and oracle run the same restated solver with different libm's -> 1e-9
-    for pt in (0.5 * (gt[:3] + gt[3:]) + 0.003, gt[:3] * 0.7 + gt[3:] * 0.3 - 0.002, gt[3:] + 0.01):
-        l, o = tri.triangulate_line_with_one_point(s1, c1, s2, c2, pt), \
-            oracle.triangulate_line_with_one_point(s1, c1, s2, c2, pt)
-        assert l.score == o[9]
-        if o[9] > 0:
-            np.testing.assert_allclose(np.concatenate([l.start, l.end, l.depths]), o[:8], rtol=1e-9, atol=1e-12)
+    from helpers import restated_one_point
+    with restated_one_point(oracle):
+        for pt in (0.5 * (gt[:3] + gt[3:]) + 0.003, gt[:3] * 0.7 + gt[3:] * 0.3 - 0.002, gt[3:] + 0.01):
+            l, o = tri.triangulate_line_with_one_point(s1, c1, s2, c2, pt), \
+                oracle.triangulate_line_with_one_point(s1, c1, s2, c2, pt)
+            assert l.score == o[9]
+            if o[9] > 0:
+                np.testing.assert_allclose(np.concatenate([l.start, l.end, l.depths]), o[:8], rtol=1e-9, atol=1e-12)
     E = tri.compute_essential_matrix(c1, c2)
     np.testing.assert_allclose(E / np.linalg.norm(E), oracle.compute_essential_matrix(c1, c2) /
                                np.linalg.norm(oracle.compute_essential_matrix(c1, c2)), atol=1e-9)

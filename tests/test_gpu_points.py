@@ -6,8 +6,10 @@ The fitted direction comes from Eigen::JacobiSVD in the reference; the product (
 of the 3x3 scatter matrix) and the oracle (one-sided Jacobi on the n x 3 matrix) are two different stand-ins
 that agree to rounding, so THIS branch's candidates are compared to 1e-9 relative instead of bit for bit;
 everything discrete (which candidates exist, their order, sources, best, edges, tracks) must be identical.
-The one-point proposal (one candidate per shared point) runs the same restated quartic solver in product
-and oracle with different math libraries: same tolerance."""
+The one-point proposal (one candidate per shared point): the product follows the RESTATED optimisation problem, and
+so does the oracle in this file (helpers.restated_one_point) -- same arithmetic, different math libraries: same
+tolerance.  The chain to the reference: restated == generated solver to the generated form's own conditioning (CPU,
+tests/test_oracle_kat.py), generated solver == the reference's file bit for bit (tests/test_oracle_vs_ref.py)."""
 import numpy as np
 import pytest
 
@@ -16,6 +18,13 @@ from limap_amd import synthetic as syn
 from helpers import compare_tracks, compare_valid_edges
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _oracle_on_the_restated_one_point_problem(oracle):
+    from helpers import restated_one_point
+    with restated_one_point(oracle):
+        yield
 
 
 def _run_both(oracle, sc, cfg, bpts, sfm, vps=None, sorted_rows=True):

@@ -409,3 +409,55 @@ def test_kat_one_point_triangulation(oracle):
             best = l1s[int(np.argmin(errs))]
             assert abs(np.linalg.norm(s3) - best) < 2 * (l1s[1] - l1s[0])
             assert errs.min() >= err_of(np.linalg.norm(s3))[0] - 1e-12
+
+
+def test_one_point_restated_problem_equals_generated_solver(oracle):
+    """The middle link of the one-point chain (HIP == restated solver bit for bit in tests/test_gpu_points.py; generated
+    solver == oracle/_ref bit for bit in tests/test_oracle_vs_ref.py): the restated optimisation problem against the
+    reference's generated polynomials on the CPU.  Same stationary points, same selection rule => same line, to the
+    conditioning of the GENERATED form: its expanded coefficients cancel over many digits, so where the two differ by
+    more than rounding, the generated solver's own answer moves by a comparable amount when the known point is
+    perturbed in its last bits -- the difference is the reference's noise, not a second solution."""
+    import numpy as np
+    from limap_amd import synthetic as syn
+    sc = syn.make_scene(n_views=8, n_segs=60, n_neighbors=4, seed=43)
+    rng = np.random.default_rng(11)
+    rel, noisy, sentinel_mismatch = [], 0, 0
+    try:
+        for trial in range(1500):
+            a, b = rng.choice(sc.n_images, 2, replace=False)
+            cam1, cam2 = sc.cam11(int(a)), sc.cam11(int(b))
+            s1 = sc.segs_of(int(a))[rng.integers(0, 40)]
+            s2 = sc.segs_of(int(b))[rng.integers(0, 40)]
+            t = rng.uniform(0.1, 0.9)
+            px = (1 - t) * s1[0:2] + t * s1[2:4] + rng.normal(0, 0.5, 2)
+            point = oracle.cam_center(cam1) + oracle.cam_ray_direction(cam1, px) * rng.uniform(1.5, 6.0)
+            oracle.set_one_point_solver(True)
+            lg = oracle.triangulate_line_with_one_point(s1, cam1, s2, cam2, point)
+            oracle.set_one_point_solver(False)
+            lr = oracle.triangulate_line_with_one_point(s1, cam1, s2, cam2, point)
+            if (lg[9] < 0) != (lr[9] < 0):
+                sentinel_mismatch += 1  # a root at the edge of the cheirality test
+                continue
+            if lg[9] < 0:
+                continue
+            scale = max(1.0, float(np.abs(lg[:6]).max()))
+            d = float(np.abs(lg[:8] - lr[:8]).max()) / scale
+            rel.append(d)
+            if d > 1e-11:
+                # the generated solver's own sensitivity: the point moved by a few ulps
+                oracle.set_one_point_solver(True)
+                moved = 0.0
+                for k in range(4):
+                    pp = point * (1.0 + 4e-16 * np.array([(-1) ** k, (-1) ** (k // 2), 1.0]))
+                    lp = oracle.triangulate_line_with_one_point(s1, cam1, s2, cam2, pp)
+                    if lp[9] >= 0:
+                        moved = max(moved, float(np.abs(lp[:8] - lg[:8]).max()) / scale)
+                noisy += 1
+                assert moved > 1e-3 * d, (trial, d, moved)  # ill-conditioned there, by its own evidence
+    finally:
+        oracle.set_one_point_solver(True)
+    rel = np.array(rel)
+    assert len(rel) > 500 and sentinel_mismatch <= 3, (len(rel), sentinel_mismatch)
+    assert np.median(rel) < 1e-14 and np.percentile(rel, 95) < 1e-11 and rel.max() < 1e-6, \
+        (np.median(rel), np.percentile(rel, 95), rel.max(), noisy)
