@@ -80,7 +80,7 @@ k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long
   const long long C = tri_off[G];
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 64) draw[i * 32] = 0;  // 128 bytes apart (k_score3 / 4 / 5 use the first eight, k_sweep6 all 64)
+  if (i < 64) draw[i * 32] = 0;  // 128 bytes apart (k_score3 uses the first eight, k_sweep6 all 64)
   if (split_counters && i < 64) split_counters[i * 32] = 0;  // the region counters of the pair list (k_sweep6)
   const long long C_up = (C + 63) & ~63ll;  // whole waves take part in the tile's reduction
   for (; i < C_up; i += stride) {
@@ -107,10 +107,10 @@ k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long
       unsigned sum = n;
       for (int d = 32; d >= 1; d >>= 1) sum += (unsigned)__shfl_xor((int)sum, d);
       // the tile's window (natural order): from the node of its first candidate to the end of the node of its last one
-      const long long base = i - lane_id();
+      const long long base = i - lane_id();  // < C: the loop runs over whole waves up to C rounded up
       const int last = (int)((C - base) < 64 ? (C - base) : 64) - 1;
-      const unsigned t_hi = last >= 0 ? (unsigned)__builtin_amdgcn_readlane((int)w_hi, last < 0 ? 0 : last) : 0u;
-      if (lane_id() == 0 && base < C) {
+      const unsigned t_hi = (unsigned)__builtin_amdgcn_readlane((int)w_hi, last);
+      if (lane_id() == 0) {
         // one list per (draw queue, class): 128 counters -- a single counter per class would serialise thousands
         // of device-scope atomics on one address (~15 ns each).  An entry is 16 bytes: the tile and its window bounds,
         // so that k_score3 knows what to stage from the draw alone.
