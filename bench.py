@@ -625,6 +625,34 @@ def main():
             out["e2e_batched_breakdown_ms"] = parts_b
             out["e2e_batched_reps_ms"] = [1e3 * x for x in e2e_b]
         out["e2e_reps_parts"] = e2e_all_parts
+        # a FRESH process that calls limap_amd.warmup() (a synthetic scene of this shape, another seed, once through the
+        # whole sequence) and then runs this scene once: what the first real scene of a pre-warmed service costs
+        if args.mode == "matched" and default_wl and not args.no_extras:
+            try:
+                import subprocess
+                code = ("import sys, time, gc; sys.path.insert(0, %r)\n"
+                        "import limap_amd\nfrom limap_amd import synthetic as syn, triangulation as tri\n"
+                        "sc = syn.make_scene(n_views=%d, n_segs=%d, n_neighbors=%d, seed=%d)\n"
+                        "m = {int(i): sc.matches_of(int(i), %d) for i in sc.img_ids}\n"
+                        "sl = [sc.segs_of(j) for j in range(sc.n_images)]\n"
+                        "w = limap_amd.warmup(%d, %d, %d, %d)\ngc.collect(); gc.disable()\n"
+                        "t0 = time.perf_counter()\nT = tri.GlobalLineTriangulator(syn.default_triangulation_cfg())\n"
+                        "T.SetRanges(sc.ranges); T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, sl)\n"
+                        "[T.TriangulateImage(int(i), m[int(i)]) for i in sc.img_ids]\nn = len(T.ComputeLineTracks())\n"
+                        "print('AFTER_WARMUP', 1e3 * (time.perf_counter() - t0), 1e3 * w, n)\n"
+                        % (os.path.dirname(os.path.abspath(__file__)), args.views, args.segs, args.neighbors, args.seed,
+                           args.topk, args.views, args.segs, args.neighbors, args.topk))
+                pr = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+                line = [l for l in pr.stdout.splitlines() if l.startswith("AFTER_WARMUP")]
+                if line:
+                    _, ms, wms, ntr = line[-1].split()
+                    out["e2e_after_warmup_ms"] = float(ms)
+                    out["warmup_ms"] = float(wms)
+                    assert int(ntr) == len(tracks_py)
+                else:
+                    out["e2e_after_warmup_ms"] = {"error": pr.stderr[-300:]}
+            except Exception as e:  # an extra: never lose the main line over it
+                out["e2e_after_warmup_ms"] = {"error": f"{type(e).__name__}: {e}"}
         out["postprocess"] = {"ms": post_ms, "tracks_after": post_tracks,
                               "steps": "filter_by_reprojection, remerge (to fixed point), filter_by_reprojection, "
                                        "filter_by_sensitivity, filter_by_overlap (cfgs/triangulation/default.yaml:102-115)"}

@@ -266,6 +266,11 @@ int lt_get_timer_sums(lt_ctx *ctx, double out[24], int64_t *n_runs, int reset);
  * No reference counterpart (the reference holds everything in host std::maps). */
 void lt_release_cached_memory(void);
 
+/* Puts `blocks` page-locked staging blocks of `bytes` each (rounded up to the cache's size class) into that cache, so
+ * that the first scene of a process does not pin its match-row staging inside TriangulateImage (pinning costs
+ * ~0.1 ms per MB).  Used by limap_amd.warmup(); LT_OK or LT_ERR_HIP.  No reference counterpart. */
+int lt_reserve_host(uint64_t bytes, int blocks);
+
 /* ---- free functions of limap.triangulation (bindings.cc:22-31) on raw arrays, run on the GPU
  * one query per call (convenience / parity checks; the batch path is the API above).
  * cam = kvec[4] | qvec[4] | tvec[3]; seg = x1,y1,x2,y2; line10 as above. */

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "lt_export_image_results", "lt_import_image_results", "lt_ts_from_ctx", "lt_ts_create", "lt_ts_destroy",
     "lt_ts_num_tracks", "lt_ts_num_members", "lt_ts_get", "lt_ts_filter_by_reprojection",
     "lt_ts_filter_by_sensitivity", "lt_ts_filter_by_overlap", "lt_ts_remerge_once", "lt_get_stats", "lt_get_timers", "lt_get_timer_sums", "lt_run_device_async", "lt_sync",
-    "lt_release_cached_memory",
+    "lt_release_cached_memory", "lt_reserve_host",
     "lt_fn_get_normal_direction", "lt_fn_get_direction_from_vp", "lt_fn_triangulate_point",
     "lt_fn_triangulate_line_with_direction", "lt_fn_triangulate_line_with_one_point", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
     "lt_fn_triangulate_line", "lt_fn_aggregate_line3d_list", "lt_fn_pack_match_rows",
@@ -115,6 +115,8 @@ def load_library():
     L.lt_destroy.restype = None
     L.lt_release_cached_memory.argtypes = []
     L.lt_release_cached_memory.restype = None
+    L.lt_reserve_host.argtypes = [C.c_uint64, C.c_int]
+    L.lt_reserve_host.restype = C.c_int
     L.lt_last_error.argtypes = [vp]
     L.lt_last_error.restype = C.c_char_p
     L.lt_set_stream.argtypes = [vp, vp]

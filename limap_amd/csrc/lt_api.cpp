@@ -219,6 +219,19 @@ void release_cached_memory() {
 
 extern "C" void lt_release_cached_memory(void) { lt_host::release_cached_memory(); }
 
+extern "C" int lt_reserve_host(uint64_t bytes, int blocks) {
+  if (blocks <= 0 || bytes == 0) return LT_OK;
+  std::vector<lt_host::HostBlock> held;
+  bool ok = true;
+  for (int k = 0; k < blocks && k < 8; ++k) {  // held together so that they are distinct blocks
+    lt_host::HostBlock b = lt_host::host_block_acquire((size_t)bytes);
+    ok = ok && b.p != nullptr && b.pinned;
+    held.push_back(b);
+  }
+  for (auto &b : held) lt_host::host_block_release(b);
+  return ok ? LT_OK : LT_ERR_HIP;
+}
+
 namespace lt_impl {
 
 // per-kernel HIP events cost a few microseconds of stream bubble each.  LT_FINE_TIMERS (read per run): unset / 1 =

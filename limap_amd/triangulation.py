@@ -67,16 +67,25 @@ def flatten_bipartites(bpts):
                 lp_off=np.asarray(lp_off, np.int64), lp_ptids=cat(lp, np.int32))
 
 
-class _LazySegs:
-    """img_id -> (M, 4) segments of a triangulator, resolved when a track's 2D lines are first looked at."""
+class _SegStore:
+    """img_id -> (M, 4) segments of a scene, resolved when a 2D line is first looked at.  Holds the caller's arrays only
+    -- NOT the triangulator: the tracks a triangulator hands out point here, and a reference back to it would be a cycle
+    (triangulator -> tracks -> store -> triangulator) that keeps the context and its device memory alive until Python's
+    cyclic collector happens to run (measured: every scene of a loop then pays the first-use allocations again)."""
 
-    __slots__ = ("_tri",)
+    __slots__ = ("_src", "_order", "_img_ids", "_table")
 
-    def __init__(self, tri):
-        self._tri = tri
+    def __init__(self, src=(), order=None, img_ids=()):
+        self._src, self._order, self._img_ids, self._table = src, order, img_ids, None
+
+    def table(self):
+        if self._table is None:
+            pos = range(len(self._img_ids)) if self._order is None else self._order
+            self._table = {i: np.asarray(self._src[o], float).reshape(-1, 4) for i, o in zip(self._img_ids, pos)}
+        return self._table
 
     def __getitem__(self, img_id):
-        return self._tri._segs[img_id]
+        return self.table()[img_id]
 
 
 class _LazyLineTrack(LineTrack):
@@ -253,7 +262,7 @@ class GlobalLineTriangulator:
         else:
             self._ctx = _capi.Context(cfg_dict=dict(cfg) if cfg is not None else None, device=device)
         self._img_ids = []
-        self._segs_src, self._segs_cache = ([], None), {}
+        self._seg_store = _SegStore()
         self._seg_off = None
         self._tracks = []
         self._debug = bool(self._ctx.cfg.debug_mode)
@@ -295,15 +304,14 @@ class GlobalLineTriangulator:
         if n < 2 or bool((ids[1:] > ids[:-1]).all()):  # already in the native order (ascending id): the usual case
             self._img_ids = ids.tolist()
             self._seg_off = seg_off
-            self._segs_src = (segs_per_image, None)
+            self._seg_store = _SegStore(segs_per_image, None, self._img_ids)
         else:
             order = np.argsort(ids, kind="stable")
             self._img_ids = ids[order].tolist()
             so = np.zeros(n + 1, np.int64)
             np.cumsum((seg_off[1:] - seg_off[:-1])[order], out=so[1:])
             self._seg_off = so
-            self._segs_src = (segs_per_image, order.tolist())
-        self._segs_cache = None
+            self._seg_store = _SegStore(segs_per_image, order.tolist(), self._img_ids)
         self._idx = dict(zip(self._img_ids, range(n)))
         self._tracks = []
         self._best_cache = self._all_cache = None
@@ -311,11 +319,7 @@ class GlobalLineTriangulator:
     @property
     def _segs(self):
         """img_id -> (M, 4) array of the image's 2D segments, built when a getter first needs the 2D lines."""
-        if self._segs_cache is None:
-            src, order = self._segs_src
-            pos = range(len(self._img_ids)) if order is None else order
-            self._segs_cache = {i: np.asarray(src[o], float).reshape(-1, 4) for i, o in zip(self._img_ids, pos)}
-        return self._segs_cache
+        return self._seg_store.table()
 
     def InitVPResults(self, vpresults):
         """vpresults: dict img_id -> limap.vplib.VPResult (or anything with .labels / .vps, a dict with those
@@ -543,7 +547,7 @@ class GlobalLineTriangulator:
     def _build_tracks(self, t):
         # The reference hands back pybind wrappers of C++ LineTracks (no per-member Python objects until they are
         # looked at); building ~35 000 Line2d / Line3d objects eagerly here cost 20x the whole triangulation.
-        segs = _LazySegs(self)
+        segs = self._seg_store  # (not the triangulator: see _SegStore)
         tracks = [_LazyLineTrack(t, n, segs) for n in range(len(t["off"]) - 1)]
         if _limap_base is not None:  # limap's LineTrack when limap is installed (linetrack.cc:50-74 dict ctor)
             try:
