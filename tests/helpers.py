@@ -73,18 +73,19 @@ def compare_valid_edges(g, o):
     assert edge_sets(goff, ge) == edge_sets(ooff, oe)
 
 
-def compare_tracks(gt, ot, rtol=1e-5, score_rtol=1e-12, exact_members=True):
-    """Track membership bit-exact (the north-star bar), endpoints within 1e-5 relative IN THE SAME ORIENTATION
-    (start to start, end to end: the product's principal axis follows the oracle's / the Eigen stand-in's sign rule
-    for the SVD of merging/aggregator.cc:76-78, no start / end swap is tolerated).  `exact_members=False` / a looser
-    `score_rtol`: for candidates whose coordinates are themselves only equal to rounding (the many-points line fit).
+def compare_tracks(gt, ot, rtol=1e-5, score_rtol=1e-12, exact_supports=True):
+    """Track MEMBERSHIP always bit-exact (images, lines, node ids of every track: the north-star bar), endpoints within
+    1e-5 relative IN THE SAME ORIENTATION (start to start, end to end: the product's principal axis follows the oracle's
+    / the Eigen stand-in's sign rule for the SVD of merging/aggregator.cc:76-78, no start / end swap is tolerated).
+    `exact_supports=False` / a looser `score_rtol` only relax the COORDINATES of the supporting 3D lines and the scores
+    to 1e-9 / score_rtol, for candidates whose coordinates are themselves only equal to rounding (point proposals).
     Returns (max relative endpoint error, number of tracks that would only match swapped)."""
     assert np.array_equal(gt["off"], ot["off"]), "track sizes differ"
     assert np.array_equal(gt["image_ids"], ot["image_ids"])
     assert np.array_equal(gt["line_ids"], ot["line_ids"])
     assert np.array_equal(gt["node_ids"], ot["node_ids"])
     np.testing.assert_allclose(gt["scores"], ot["scores"], rtol=score_rtol)
-    if exact_members:
+    if exact_supports:
         assert np.array_equal(gt["line3d"], ot["line3d"])
     else:
         np.testing.assert_allclose(gt["line3d"], ot["line3d"], rtol=1e-9, atol=1e-12)

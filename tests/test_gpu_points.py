@@ -60,7 +60,7 @@ def _compare(T, O):
     assert np.array_equal(gb["has_best"], ob["has_best"]) and np.array_equal(gb["src"], ob["src"])
     compare_valid_edges(T.context().get_valid_edges(), O.get_valid_edges())
     T.context().compute_tracks()
-    compare_tracks(T.context().get_tracks(), O.ComputeLineTracks(), score_rtol=1e-7, exact_members=False)
+    compare_tracks(T.context().get_tracks(), O.ComputeLineTracks(), score_rtol=1e-7, exact_supports=False)
     return g
 
 

@@ -41,13 +41,13 @@ def _same_edges_in_order(a, b):
     assert np.array_equal(ae, be), "valid edges differ (order = descending (score, tri_id), :118-142)"
 
 
-def _stage_by_stage(R, O, exact_members=True, score_rtol=1e-12):
+def _stage_by_stage(R, O, exact_supports=True, score_rtol=1e-12):
     compare_candidates(R.get_all_tris(), O.get_all_tris())
     assert np.array_equal(R.get_num_tris(), O.get_num_tris())
     compare_best(R.get_best(), O.get_best())
     _same_edges_in_order(R.get_valid_edges(), O.get_valid_edges())
     rt, ot = R.ComputeLineTracks(), O.ComputeLineTracks()
-    compare_tracks(rt, ot, exact_members=exact_members, score_rtol=score_rtol)
+    compare_tracks(rt, ot, exact_supports=exact_supports, score_rtol=score_rtol)
     sr, so = R.stats(), O.stats()
     for k in ("connections", "candidates", "pairs", "valid_edges", "graph_nodes", "graph_edges", "tracks"):
         assert sr[k] == so[k], (k, sr[k], so[k])
