@@ -38,6 +38,9 @@ namespace lt {
 //               st_*[r0 ...]; wave_count[] holds the list lengths.  In the fast path the number of
 //               valid candidates per (block, line) run is counted in cnt_bl for the placement pass.
 // Tuning knobs (compile-time; Makefile EXTRA=-D...)
+#ifndef LT_TABL
+#define LT_TABL 0  // developer ablations of k_tri_rows (timing only): 1 no segment gathers, 2 no triangulation arithmetic
+#endif
 #ifndef LT_GABL
 #define LT_GABL 0  // developer ablations of k_gates (timing only): 1 conflict-free table reads, 2 no gate arithmetic
 #endif
@@ -60,6 +63,11 @@ constexpr int kGateWaves = LT_GATE_WAVES;  // waves (= slots) per k_gates workgr
 #define LT_TRI_SLOTS 4
 #endif
 constexpr int kTriSlots = LT_TRI_SLOTS;
+#ifndef LT_TRI_WAVES
+#define LT_TRI_WAVES 4
+#endif
+constexpr int kTriWaves = LT_TRI_WAVES;  // waves (= groups of one block) per k_tri_rows workgroup; they share nothing
+                                         // (measured: 1 -> 68.5 us, 2 -> 65.0, 4 -> 60.6)
 constexpr int kTriRows = kTriSlots * kRowsPerWave;
 static_assert(kGateWaves % kTriSlots == 0, "a group must not straddle k_gates workgroups' slot ranges");
 
@@ -328,7 +336,7 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
 // vp(l1), vp(l2), algebraic.  Which
 // of them are active is a run-time property (a.seg_pts / a.seg_vp may be null).
 template <bool kExtra>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * kTriWaves)
 k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec *__restrict__ pairs_r,
            const BlkRec *__restrict__ blk_r) {
   extern __shared__ __align__(16) unsigned char smem_raw[];  // per wave: 64 x (CRec | unc | key)
@@ -336,7 +344,7 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
   const int lane = lane_id();
   const int b = blockIdx.y;
   const int n_groups = a.n_slots / kTriSlots;
-  const int g = blockIdx.x * 4 + wave;
+  const int g = blockIdx.x * kTriWaves + wave;
   if (g >= n_groups) return;
   const BlkRec *rec = blk_r + b;
   const long long rb = rec->rb, re = rec->re;
@@ -440,11 +448,23 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
       const uint2 u = a.st_row[rs0 + (e - first)];
       line = (int)(u.x & 0x7FFFFFFFu);
       ng = (int)u.y;
+#if LT_TABL == 1  // ablation: segment records read lane-consecutively (no gathers; results wrong)
+      const Seg &s1 = a.segs[g1 + (lane & 31)];
+      const Seg &s2 = a.segs[g2 + (lane & 31)];
+#else
       const Seg &s1 = a.segs[g1 + line];
       const Seg &s2 = a.segs[g2 + ng];
+#endif
       ok = true;
+#if LT_TABL == 2  // ablation: gathers kept, no triangulation arithmetic (every survivor "valid", record = raw segment)
+      o.r.s[0] = s1.x1; o.r.s[1] = s1.y1; o.r.s[2] = s2.x1; o.r.e[0] = s2.y1; o.r.e[1] = s1.n[0]; o.r.e[2] = s2.n[0];
+      o.r.depth[0] = 1.0; o.r.depth[1] = 1.0; o.unc = 1.0;
+      o.r.seg[0] = s2.x1; o.r.seg[1] = s2.y1; o.r.seg[2] = s2.x2; o.r.seg[3] = s2.y2;
+      o.r.dir[0] = 1.0; o.r.dir[1] = 0.0; o.r.dir[2] = 0.0;
+#else
       if (u.x >> 31) ok = gen_gates(cfg, s1, s2, pr->F);  // the cheap gates could not decide
       if (ok) ok = gen_finish(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B, &o);
+#endif
       if (kExtra) {
         // both segments long enough (:166,177) -- with extra proposals stage A lets every row through
         L2 l1{mk2(s1.x1, s1.y1), mk2(s1.x2, s1.y2)};
@@ -854,12 +874,11 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   else hipLaunchKernelGGL((k_gates<false, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
   if (ev3) (void)hipEventRecord(ev3[1], st);
   if (extra)
-    hipLaunchKernelGGL(k_tri_rows<true>, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256), 0, st, a, cfg, a.cams,
-                       a.pairs, a.blk);
+    hipLaunchKernelGGL(k_tri_rows<true>, dim3(nblk2(a.n_slots / kTriSlots, kTriWaves), n_blk), dim3(64 * kTriWaves), 0, st,
+                       a, cfg, a.cams, a.pairs, a.blk);
   else
-    hipLaunchKernelGGL(k_tri_rows<false>, dim3(nblk2(a.n_slots / kTriSlots, 4), n_blk), dim3(256),
-                       4 * (64 * 9 + 16) * sizeof(double2), st, a, cfg, a.cams,
-                       a.pairs, a.blk);
+    hipLaunchKernelGGL(k_tri_rows<false>, dim3(nblk2(a.n_slots / kTriSlots, kTriWaves), n_blk), dim3(64 * kTriWaves),
+                       kTriWaves * (64 * 9 + 16) * sizeof(double2), st, a, cfg, a.cams, a.pairs, a.blk);
   if (ev3) (void)hipEventRecord(ev3[2], st);
 }
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
