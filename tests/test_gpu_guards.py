@@ -109,6 +109,24 @@ def test_release_cached_memory(gpu_lib):
     assert len(T.context().get_tracks()["off"]) == n1 + 1
 
 
+def test_warmup_and_reserved_staging(gpu_lib):
+    """limap_amd.warmup() (a synthetic scene of the expected shape through the whole call sequence in both modes + the
+    post-triangulation chain) leaves results untouched, and lt_reserve_host puts distinct page-locked blocks into the
+    host cache that the next context picks up."""
+    import limap_amd
+    sc = syn.make_scene(n_views=6, n_segs=40, n_neighbors=3, seed=5)
+    cfg = syn.default_triangulation_cfg()
+    T = run_product(sc, cfg)
+    n1 = len(T.ComputeLineTracks())
+    del T
+    assert limap_amd.warmup(n_views=8, n_segs=50, n_neighbors=4) > 0.0
+    assert gpu_lib.lt_reserve_host(1 << 20, 3) == 0 and gpu_lib.lt_reserve_host(0, 2) == 0
+    T = run_product(sc, cfg)
+    assert len(T.ComputeLineTracks()) == n1
+    del T
+    gpu_lib.lt_release_cached_memory()
+
+
 @pytest.mark.parametrize("own_big,nb_big", [(True, True), (False, True), (True, False)])
 def test_operand_table_variants(gpu_lib, oracle, clean_env, own_big, nb_big):
     """k_gates keeps the operand tables in LDS only for images with <= 1024 segments; the other three
