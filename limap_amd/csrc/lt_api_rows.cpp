@@ -124,9 +124,9 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
   job.bad = bad.data(); job.out = reinterpret_cast<unsigned *>(out);
   if (dst[n_nb] >= (1 << 14)) {
     lt_host::SpinPool &pool = lt_host::SpinPool::get(lt_host::row_workers());
-    pool.begin(&RowJob::run, &job);
+    const bool shared = pool.begin(&RowJob::run, &job);  // false: the team is busy with another caller's job
     RowJob::run(&job, 0, 0);
-    pool.end();
+    if (shared) pool.end();
   } else {
     RowJob::run(&job, 0, 0);  // a few rows: not worth a notify
   }
@@ -203,7 +203,6 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
   };
   std::vector<RowBlk> blks;
   std::vector<Img> imgs;
-  const size_t base = ctx->h_m_pairs.size();
   long long total_rows = 0;
   std::vector<char> seen_here((size_t)std::max(ctx->n_img, 1), 0);
   // ---- pass 1 (serial, cheap): the per-image bookkeeping of lt_triangulate_image_rows, block descriptors ----
@@ -239,6 +238,9 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
     imgs.push_back(std::move(im));
   }
   if (imgs.empty()) return LT_OK;
+  // read only now: pass 1 writes no rows, but its first begin_image() starts a new batch when the previous one has been
+  // read back (results downloaded / tracks computed) and then clears the staging block, its offsets and streamed_ints
+  const size_t base = ctx->h_m_pairs.size();
   lap("bookkeeping");
   // ---- staging: one allocation for the whole call ----
   {
@@ -311,7 +313,9 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
   size_t streamed_to = ctx->streamed_ints;
   lap("device buffer");
   lt_host::SpinPool &pool = lt_host::SpinPool::get(lt_host::row_workers());
-  pool.begin(&RowJob::run, &job);
+  const bool shared = pool.begin(&RowJob::run, &job);
+  if (!shared) RowJob::run(&job, 0, 0);  // the team is busy with another caller's job (or has no threads): this thread
+                                         // packs every block itself, the chunk loop below then only enqueues the copies
   {
     bool ok = d_rows != nullptr;
     for (int c = 0; c < n_chunks; ++c) {
@@ -334,7 +338,7 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
       }
     }
   }
-  pool.end();
+  if (shared) pool.end();
   lap("row pass");
   unsorted = job.uns_any.load();
   const bool any_bad = job.bad_any.load() != 0;

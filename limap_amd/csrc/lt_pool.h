@@ -16,6 +16,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <exception>
 #include <mutex>
 #include <thread>
 #include <type_traits>
@@ -51,22 +52,37 @@ class SpinPool {
   // waits for the workers inside fn -- it does NOT wait for sleepers, so a caller that arrives while the team sleeps
   // pays one notify and not the team's wake-up time.  The caller therefore needs its own completion condition: it
   // either runs fn itself until the shared work counter is exhausted, or waits on counters fn advances.
-  void begin(JobFn fn, void *arg) {
+  // The team has ONE job slot.  begin() takes it without waiting and returns false when another thread's job holds it
+  // (two triangulators on two Python threads: the shim releases the GIL around the blocking calls) or when no worker
+  // thread could be created; the caller then runs fn itself and must NOT call end().
+  bool begin(JobFn fn, void *arg) {
+    if (n_live_ == 0 || !job_mu_.try_lock()) return false;
     fn_ = fn;
     arg_ = arg;
     const unsigned long long e = job_epoch_.load(std::memory_order_relaxed) + 1;
     open_epoch_.store(e);
     job_epoch_.store(e);  // sequentially consistent with the sleepers count: a worker going to sleep either sees the
     if (sleepers_.load() > 0) notify();  // new epoch in its wait predicate or is counted here and notified
+    return true;
   }
   void end() {
     open_epoch_.store(0);  // a worker that has not entered yet stays out (it re-checks after announcing itself)
     while (active_.load() != 0) relax();
+    job_mu_.unlock();
   }
 
  private:
   explicit SpinPool(int n) : n_(n), pid_(getpid()) {
-    for (int w = 0; w < n; ++w) std::thread([this, w] { loop(w); }).detach();
+    // a thread that cannot be created (rlimit-constrained container) is simply absent: jobs never wait for a
+    // particular worker, and with no worker at all begin() sends the caller to run the job itself
+    for (int w = 0; w < n; ++w) {
+      try {
+        std::thread([this, w] { loop(w); }).detach();
+        ++n_live_;
+      } catch (...) {
+        break;
+      }
+    }
   }
   static void relax() {
 #if defined(__x86_64__)
@@ -89,7 +105,12 @@ class SpinPool {
       if (e != seen_job) {
         seen_job = e;
         active_.fetch_add(1);
-        if (open_epoch_.load() == e) fn_(arg_, w, n_);
+        if (open_epoch_.load() == e) {
+          try {
+            fn_(arg_, w, n_);
+          } catch (...) {  // job functions report through their own state (pool_for hands the exception to its caller);
+          }                // nothing may unwind through a detached thread
+        }
         active_.fetch_sub(1);
         deadline = now_ms() + kSpinMs;
         continue;
@@ -115,6 +136,8 @@ class SpinPool {
 
   const int n_;
   const pid_t pid_;
+  int n_live_ = 0;       // worker threads that exist
+  std::mutex job_mu_;    // held from begin() to end(): one job at a time
   JobFn fn_ = nullptr;
   void *arg_ = nullptr;
   std::atomic<unsigned long long> job_epoch_{0}, open_epoch_{0}, wake_epoch_{0};
@@ -147,12 +170,20 @@ void pool_for(long long n, long long grain, F &&body) {
     std::atomic<long long> next{0};
     long long n, grain;
     typename std::remove_reference<F>::type *f;
+    std::mutex err_mu;
+    std::exception_ptr err;  // first exception of any piece (e.g. bad_alloc in a worker's scratch): rethrown by the caller
     static void run(void *a, int, int) {
       Job &j = *static_cast<Job *>(a);
       for (;;) {
         const long long b = j.next.fetch_add(j.grain, std::memory_order_relaxed);
         if (b >= j.n) break;
-        (*j.f)(b, std::min(b + j.grain, j.n));
+        try {
+          (*j.f)(b, std::min(b + j.grain, j.n));
+        } catch (...) {
+          std::lock_guard<std::mutex> lk(j.err_mu);
+          if (!j.err) j.err = std::current_exception();
+          j.next.store(j.n, std::memory_order_relaxed);  // the remaining pieces are not started
+        }
       }
     }
   } job;
@@ -160,9 +191,10 @@ void pool_for(long long n, long long grain, F &&body) {
   job.grain = grain;
   job.f = &body;
   SpinPool &pool = SpinPool::get(row_workers());
-  pool.begin(&Job::run, &job);
+  const bool shared = pool.begin(&Job::run, &job);
   Job::run(&job, 0, 0);
-  pool.end();
+  if (shared) pool.end();
+  if (job.err) std::rethrow_exception(job.err);
 }
 
 }  // namespace lt_host

@@ -274,8 +274,12 @@ def save_txt_imname_dict(fname, imname_dict):
 
 def save_obj(fname, lines):
     """util/io.py:181-199: every 3D segment as two vertices and one `l` element."""
-    if isinstance(lines, list):
-        lines = np.array(lines)
+    if isinstance(lines, list) and len(lines) > 0:
+        # a list of (2, 3) arrays or of Line3d objects (anything with as_array()), as the reference accepts
+        if isinstance(lines[0], np.ndarray):
+            lines = np.array(lines)
+        else:
+            lines = np.array([line.as_array() for line in lines])
     n = 0 if lines is None or len(lines) == 0 else lines.shape[0]
     os.makedirs(os.path.dirname(os.path.abspath(fname)), exist_ok=True)
     with open(fname, "w") as f:

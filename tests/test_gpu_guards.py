@@ -483,3 +483,45 @@ def test_second_batch_after_compute_tracks_device_and_host_tail(gpu_lib, oracle,
         assert np.array_equal(t_dev[k], t_host[k]), k
     O = run_oracle(oracle, sc, cfg)
     compare_tracks(t_dev, O.ComputeLineTracks())
+
+
+@pytest.mark.parametrize("between", ["tracks", "getter"])
+def test_triangulate_all_second_batch_after_results_were_read(gpu_lib, oracle, clean_env, between):
+    """TriangulateAll(first half) -> ComputeLineTracks or a getter -> TriangulateAll(second half).  Reading the results
+    ends the first batch: the second call's begin_image() clears the staged rows, so its rows must be written at the
+    start of the (emptied) staging block, not behind the first batch's old size (`base` was read before the
+    loop that may clear the block, the device then received the FIRST batch's packed rows again).  Compared with the
+    per-image loop in the same two batches and with the oracle on the whole scene."""
+    from helpers import compare_best, compare_tracks, run_oracle
+    from limap_amd import triangulation as tri
+    sc = syn.make_scene(n_views=12, n_segs=100, n_neighbors=5, seed=21)
+    cfg = syn.default_triangulation_cfg()
+    ids = [int(i) for i in sc.img_ids]
+
+    def run(batched):
+        T = tri.GlobalLineTriangulator(cfg)
+        T.SetRanges(sc.ranges)
+        T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+        for part in (ids[:6], ids[6:]):
+            if batched:
+                T.TriangulateAll({i: sc.matches_of(i) for i in part})
+            else:
+                for i in part:
+                    T.TriangulateImage(i, sc.matches_of(i))
+            if part is not ids[6:] and between == "tracks":
+                T.ComputeLineTracks()
+            elif between == "getter":
+                T.context().get_best()
+        T.ComputeLineTracks()
+        return T.context().get_best(), T.context().get_tracks(), T.stats()
+
+    b_all, t_all, st_all = run(True)
+    b_one, t_one, st_one = run(False)
+    assert st_all["candidates"] == st_one["candidates"] > 0
+    for k in b_all:
+        assert np.array_equal(b_all[k], b_one[k]), k
+    for k in ("off", "image_ids", "line_ids", "node_ids", "scores", "line"):
+        assert np.array_equal(t_all[k], t_one[k]), k
+    O = run_oracle(oracle, sc, cfg)
+    compare_best(b_all, O.get_best())
+    compare_tracks(t_all, O.ComputeLineTracks())

@@ -274,3 +274,20 @@ def test_golden_io_files_are_what_the_reference_writes_today(tmp_path):
                 assert repr(a) == repr(b), rel
             else:
                 assert _bytes(os.path.join(GOLD, rel)) == _bytes(os.path.join(str(tmp_path), rel)), rel
+
+
+def test_save_obj_accepts_arrays_lists_and_line3d_objects(tmp_path):
+    """util/io.py:181-199: a (N, 2, 3) array, a list of (2, 3) arrays and a list of Line3d objects (as_array()) give the
+    same file."""
+    from limap_amd import base, io as lio
+    rng = np.random.default_rng(5)
+    arr = rng.normal(size=(4, 2, 3))
+    outs = []
+    for k, lines in enumerate((arr, [a for a in arr], [base.Line3d(a[0], a[1]) for a in arr])):
+        f = tmp_path / f"l{k}.obj"
+        lio.save_obj(str(f), lines)
+        outs.append(f.read_text())
+    assert outs[0] == outs[1] == outs[2]
+    assert outs[0].count("\nl ") + outs[0].startswith("l ") == 4 and outs[0].count("v ") == 8
+    lio.save_obj(str(tmp_path / "empty.obj"), [])
+    assert (tmp_path / "empty.obj").read_text() == ""
