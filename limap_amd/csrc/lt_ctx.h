@@ -184,10 +184,11 @@ struct lt_ctx {
   DevBuf d_keys, d_rows, d_row_blk, d_skeys, d_srows, d_sort_tmp, d_conn_off;
   DevBuf d_st_c, d_st_l, d_flags, d_pos, d_scan_tmp;
   DevBuf d_item_off, d_masks, d_mask_cnt, d_mask_pos;
-  DevBuf d_split_pairs, d_split_segs, d_split_head, d_split_tot;  // pair list of the three-kernel scoring
+  DevBuf d_srec;  // sweep records of the scoring kernels (SRec, 64 B per candidate at its final position; k_place)
+  DevBuf d_pairlist, d_tile_more, d_split_S, d_split_done;  // k_sweep_rec -> k_dense_rec: the pairs that reach pair_score, extra segments per tile
+  bool score_fused_only = false;   // set when a run overflowed the pair list: the fused k_score_rec from then on
   DevBuf d_rm_line, d_rm_act, d_rm_edges, d_rm_cnt;  // lt_ts_remerge_once: kept across the passes of a remerge
   std::vector<unsigned long long> h_rm_edges;
-  bool score_split_off = false;  // set when a run overflowed the pair list: the fused scoring kernel from then on
   DevBuf d_hcand, d_hlite;  // split host-side view of the candidates (debug read-outs), see materialize_compact
   DevBuf d_cand, d_lite, d_tri_off, d_score, d_best_idx, d_edge_flag, d_nvalid, d_edge_off, d_edges;
   DevBuf d_best_c, d_best_score, d_best_src, d_ntris, d_err;
@@ -215,8 +216,6 @@ struct lt_ctx {
   // place_perm[final position] = staging slot, and every consumer reads through it (LT_TEST_PLACE_COPY=1: the
   // records are moved into compact arrays instead, as the generic and exhaustive paths do)
   DevBuf d_place_perm;
-  DevBuf d_exp_tile_order;     // developer experiment LT_EXP_TILE_ORDER
-  long long exp_tile_order_C = -1;
   bool perm_mode = false;      // the last run left its candidates in the staging lists
   // one-pass exhaustive mode (k_gates_ex<true>): staging capacity as a fraction of the connections (0 = not measured
   // yet), adapted to the last run's yield; ex_two_pass: the next run uses the two-pass form (after an overflow)

@@ -49,7 +49,8 @@ void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const 
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const CRec *st_r, const double *st_unc,
-                  const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, int mult, unsigned *perm);
+                  const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, int mult, unsigned *perm,
+                  SRec *srec, const Cam *cams, const unsigned *n_tris, const long long *nb_off, double guard);
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
                       unsigned *keys_c, unsigned *src_c, int mult);
@@ -64,10 +65,13 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    void *meta, const CRec *cand, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
-                   bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
-                   unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap, const unsigned *place,
-                   unsigned *rec, const float *st_z, int *err_flag, void *split_pairs, unsigned *split_tile_head,
-                   unsigned *split_counters, unsigned split_region_cap, void *split_tile_lohi);
+                   bool f32, unsigned *perm, void *rng, bool perm_is_placement, unsigned *bucket_cnt,
+                   unsigned *bucket_list, unsigned bucket_cap, const unsigned *place, unsigned *rec, const float *st_z,
+                   int *err_flag, const SRec *srec, void *pair_list, unsigned *pair_region_ctr, unsigned pair_region_cap,
+                   void *tile_more, void *split_S, unsigned *split_done, unsigned split_cap);
+size_t score_rec_lds_bytes(int max_nb);
+int score_pair_regions();
+int score_tile_more_segs();
 int score3_tile_buckets();
 }
 

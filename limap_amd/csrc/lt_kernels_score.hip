@@ -1,6 +1,6 @@
 // lt_kernels_score.hip -- the scoring stage (scoreOneNode, global_line_triangulator.cc:71-116): k_cand_meta (prologue
-// records, tiles by cost class), k_depth_order (exhaustive mode), the fused k_score3, and the three-kernel form
-// k_sweep6 / k_eval6 / k_reduce6 (LT_SCORE_SPLIT).  A translation unit of its own since round 3: the stage kernels of
+// records, tiles by cost class), k_depth_order (exhaustive mode) and the fused scoring kernels k_score3 / k_score_rec.
+// A translation unit of its own since round 3: the stage kernels of
 // lt_kernels_v2.hip are compiled with -mllvm -disable-machine-licm (the hoisted constants cost k_tri_rows 32
 // registers and 8 % of its time), k_score3 is 2.5 % faster with the default pipeline (csrc/Makefile).
 // Compiled with -ffp-contract=off (see lt_geom.h).
@@ -22,20 +22,9 @@ namespace lt {
 #else
 #define LT_SCORE_OCC
 #endif
-// When a wave CLAIMS its next tile (the draw's device atomic) -- measured at 100 x 500, k_score3 in us:
-//   0  at the start of the current tile (rounds 1-2: the atomic's round trip hides behind the whole tile, but a wave
-//      in a long tile sits on a tile nobody else can take while the queues run dry)            122.7
-//   1  before the final dense rounds                                                             122.0
-//   2  at the LAST dense round (round trip behind one round + the ordered sums)                  118.8   <- default
-//   3  after the sums (no reservation at all, the round trip exposed)                            124.9
-#ifndef LT_SCORE_CLAIM
-#define LT_SCORE_CLAIM 2
-#endif
-#ifndef LT_ABL
-// developer ablations of k_score3 (tools/build_variant.sh NAME -DLT_ABL=n; timing only, the results are wrong):
-// 1 no ordered sums, 2 dense rounds without arithmetic, 3 no sweep, 6 no dense rounds, 7 neither
-#define LT_ABL 0
-#endif
+// A wave CLAIMS its next tile (the draw's device atomic) at the current tile's LAST dense round: the round trip hides
+// behind one round + the ordered sums, and no wave sits on a tile nobody else can take while the queues run dry
+// (measured in round 3 at 100 x 500: claim at the start of the tile 122.7 us, at the last round 118.8, after the sums 124.9).
 
 #ifdef LT_TRACE
 // developer build: per-wave timestamps (100 MHz wall clock) of the scoring kernels; lt_debug_read_trace
@@ -75,13 +64,12 @@ __global__ void __launch_bounds__(256)
 k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long *__restrict__ tri_off,
             const int *__restrict__ node_img, const long long *__restrict__ nb_off, CandMeta *__restrict__ meta,
             unsigned *__restrict__ draw, unsigned *__restrict__ bucket_cnt, unsigned *__restrict__ bucket_list,
-            unsigned bucket_cap, unsigned *__restrict__ split_counters, uint2 *__restrict__ tile_lohi) {
+            unsigned bucket_cap) {
   // grid-stride over the exact candidate count tri_off[G]; the host may only know an upper bound
   const long long C = tri_off[G];
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 64) draw[i * 32] = 0;  // 128 bytes apart (k_score3 uses the first eight, k_sweep6 all 64)
-  if (split_counters && i < 64) split_counters[i * 32] = 0;  // the region counters of the pair list (k_sweep6)
+  if (i < kTileQueues) draw[i * 32] = 0;  // 128 bytes apart
   const long long C_up = (C + 63) & ~63ll;  // whole waves take part in the tile's reduction
   for (; i < C_up; i += stride) {
     unsigned n = 0, w_lo = 0, w_hi = 0;
@@ -95,13 +83,9 @@ k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long
       m.off_hi = (unsigned)(off >> 32);
       m.n = (unsigned)(tri_off[g + 1] - off);
       m.nb = ((unsigned)nb0 << 8) | (unsigned)(nb_off[img + 1] - nb0);
-      meta[i] = m;
+      if (meta) meta[i] = m;  // (k_score_rec reads the same fields from the sweep records k_place wrote)
       n = m.n;
       w_lo = m.off_lo; w_hi = m.off_lo + m.n;
-      if (tile_lohi) {  // window bounds of the tile (k_sweep6): the nodes of its first and last candidate, whole
-        if ((i & 63) == 0) tile_lohi[i >> 6].x = (unsigned)off;
-        if ((i & 63) == 63 || i == C - 1) tile_lohi[i >> 6].y = (unsigned)(off + (long long)m.n);
-      }
     }
     if (bucket_cnt) {
       unsigned sum = n;
@@ -160,13 +144,13 @@ struct Score3Args {
   const unsigned *perm;              // kSorted: candidate record at depth-sorted position t (k_depth_order)
   const unsigned *spos;              // kSorted over staged records: natural position (score index) of sorted position t
   const uint2 *rng;                  // kSorted: node-relative range of sorted positions lane t has to sweep
-  const unsigned *tile_order;        // developer experiment: draw e processes tile tile_order[e]
   const unsigned *bucket_cnt;        // tiles by cost class (k_cand_meta): counts, lists of bucket_cap entries each
   const unsigned *bucket_list;       // entries of four words: tile, first and end position of its window, 0
   unsigned bucket_cap;
   int max_nb;
-  int *err_flag;  // device error flag of the run (7: the pair list of the three-kernel form overflowed)
-  const uint2 *tile_lohi;  // per tile: window bounds = [start of its first candidate's node, end of its last one's)
+  int *err_flag;  // device error flag of the run
+  const SRec *srec;  // k_score_rec / k_sweep_rec / k_dense_rec: sweep records at the candidates' final positions (k_place)
+  unsigned *bucket_cnt_w, *bucket_list_w;  // k_sweep_rec appends: the same arrays, writable
 };
 
 // Depth order of a node's candidates (large nodes: exhaustive matching gives ~450 candidates per node and
@@ -355,7 +339,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   // Persistent wave: tiles (64 consecutive candidates) are drawn through kTileQueues counters -- queue q
   // holds the tiles q, q + 8, ... and is served by the workgroups of one XCD (round-robin dispatch), an empty
   // queue sends its waves to the next one.  The draw for the next tile is issued at the current tile's last dense
-  // round (LT_SCORE_CLAIM) and read after its sums.  (Listing the tiles by the size of their largest node, longest first, was
+  // round and read after its sums.  (Listing the tiles by the size of their largest node, longest first, was
   // measured: no gain -- a tile's time is set by how many of its pairs survive the sweep, which neither the
   // largest node nor the number of pairs of the tile predicts: correlation 0.6.)
   int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
@@ -381,7 +365,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   auto resolve = [&]() -> uint4 {
     for (;;) {
       const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
-      if (a.bucket_cnt && !a.tile_order) {
+      if (a.bucket_cnt) {
         if (k < q_tiles) {
           const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
           const int bl = __builtin_ctzll(m);  // k < q_tiles: some class holds it
@@ -391,7 +375,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
         }
       } else {
         const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
-        if (e < n_tiles) return uint4{a.tile_order ? a.tile_order[e] : (unsigned)e, 0u, 0u, 0u};
+        if (e < n_tiles) return uint4{(unsigned)e, 0u, 0u, 0u};
       }
       // This queue is exhausted.  PEEK at all eight counters (plain loads; a counter only grows, so a queue that looks
       // exhausted is) and draw only from one that looks open: without this every wave ended with eight failing device
@@ -406,7 +390,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       if (!open_q) return uint4{0xFFFFFFFFu, 0u, 0u, 0u};
       const unsigned long long after = open_q & ~((2ull << q) - 1ull);
       q = __builtin_ctzll(after ? after : open_q);
-      if (a.bucket_cnt && !a.tile_order) load_classes();
+      if (a.bucket_cnt) load_classes();
       if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
     }
   };
@@ -436,7 +420,6 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   uint4 hdr = resolve();
   if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
   while (hdr.x != 0xFFFFFFFFu) {
-    if (LT_SCORE_CLAIM == 0 && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
     const unsigned tile = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.x);
     const unsigned h_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.y);
     const unsigned h_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.z);
@@ -515,9 +498,9 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
 
     auto drain = [&](bool final) {
       wave_lds_sync();
-      if (LT_SCORE_CLAIM == 2 && final && qn == 0 && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+      if (final && qn == 0 && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
       for (int q0 = 0; q0 < qn; q0 += 64) {
-        if (LT_SCORE_CLAIM == 2 && final && q0 + 64 >= qn && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+        if (final && q0 + 64 >= qn && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
         const int p = q0 + lane;
         if (p < qn) {
           const unsigned e = queue[p];
@@ -528,15 +511,11 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
           const CRec &ci = a.cand[ii];
           const CRec &cj = a.cand[j];
           const int nbs_j = cj.nb_slot;
-#if LT_ABL == 2  // records and camera loaded, no arithmetic
-          const double sc = ci.s[0] + cj.s[1] + a.cams[(int)((unsigned)nbs_j >> 8)].f;
-#else
           const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
                                        mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
                                        mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
                                        mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg,
                                        a.cams[(int)((unsigned)nbs_j >> 8)]);
-#endif
           if (sc > 0.0) atomicMax(&S[(nbs_j & 0xFF) * 64 + il], (unsigned long long)__double_as_longlong(sc));
         }
       }
@@ -547,9 +526,6 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
 
     for (long long wb = lo; wb < hi; wb += kWin) {
       wave_lds_sync();
-#if LT_ABL == 6 || LT_ABL == 7  // no dense rounds
-      qn = 0;
-#endif
       const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
       float rw = ri;
       for (int e = lane; e < wn; e += 64) {
@@ -595,7 +571,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
         const int wbase = cnt > 0 ? w0 : 0;
         // (one instance of drain() in the code instead of two -- 4040 instead of 5951 lines of ISA -- was measured:
         // 128.9 against 124.7 us)
-        for (int t = 0; t < ((LT_ABL == 3 || LT_ABL == 7) ? min(cmax, 4) : cmax); t += 4) {  // LT_ABL 3 / 7: no sweep
+        for (int t = 0; t < cmax; t += 4) {
           float4 A[4], B[4];
           float2 E[4];
 #pragma unroll
@@ -656,17 +632,13 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       }
     }
     LT_TRACE_MARK(2, tile, 2);
-#if LT_ABL == 6 || LT_ABL == 7
-    qn = 0;
-#endif
-    if (LT_SCORE_CLAIM == 1 && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
     drain(true);
     LT_TRACE_MARK(2, tile, 3);
 
     if (active) {
       double sum = 0.0;
       const bool own = nb0 == wave_nb0;
-      for (int r = 0; r < (LT_ABL == 1 ? 1 : n_nb); ++r) {  // LT_ABL 1: no ordered sums
+      for (int r = 0; r < n_nb; ++r) {
         int k = own ? ordl[r] : a.blk_order[nb0 + r];
         sum += __longlong_as_double((long long)S[k * 64 + lane]);
       }
@@ -674,519 +646,678 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     }
     n_eval_total += n_eval;
     wave_lds_sync();  // the tables are reused by the next tile
-    if (LT_SCORE_CLAIM == 3 && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
     hdr = resolve();
     if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
   }
   if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
 }
 
-#ifndef LT_SWEEP6_WIN
-#define LT_SWEEP6_WIN 96
-#endif
-constexpr int kWin4 = LT_SWEEP6_WIN;  // k_sweep6: window entries per chunk (<= 252: 8-bit window index in the queue)
-constexpr int kQ4 = 512;              // k_sweep6: queue capacity (entries), >= 256 + 4 * 64
-static_assert(kWin4 % 4 == 0 && kWin4 <= 252, "window size");
-
 // ---------------------------------------------------------------------------------------------
-// HOT LOOP 2 as THREE kernels (LT_SCORE_SPLIT=1; the fused k_score3 is the default -- see the measurements below):
-//   k_sweep6   per tile of 64 candidates: stage the window of the tile's nodes in LDS (single precision, relative to
-//              a wave-local origin, start / end interleaved for packed-f32 arithmetic; per entry a key = node start
-//              << 8 | neighbour slot, the record index and single-precision guard radii), sweep every lane over the
-//              candidates of its own node -- "same node, other neighbour image" is ONE compare on the keys, which also
-//              masks the lanes that ran past their node; the tests are the squared scale-invariant endpoint guards of
-//              k_score3 (conservative in the same way: a pair is dropped only if the exact gate certainly zeroes
-//              it) -- and WRITE the surviving pairs (record i, record j, image | slot of j, lane of i) to a global
-//              list, a tile's pairs as contiguous segments chained from tile_head[tile].  No evaluation in this
-//              kernel: 114 registers instead of 230.  The chain draw -> window bounds -> record indices -> records is
-//              software-pipelined across tiles; tiles are assigned statically in cost-class order.
-//   k_eval6    flat over the list, 64 pairs per wave-round, every round full (the fused kernel runs its rounds at 43
-//              of 64 lanes), 140 registers = 3 waves per SIMD.  The score overwrites the pair's record indices.
-//   k_reduce6  per tile: the per-(candidate, neighbour image) maxima (ds_max_u64 on a table in LDS) over the tile's
-//              segments, summed per candidate in image-id order (std::map order, global_line_triangulator.cc:110-112).
-// Same pairs, same pair_score, same maxima and sums as the fused kernel (tests: bit-identical scores).
-// Measured at 100 x 500 (us): k_sweep6 68 + k_eval6 41 + k_reduce6 18.5 = 128 against 118 for the fused k_score3 --
-// the evaluation alone got cheaper (41 us against ~47 us-equivalent in the fused kernel), the sweep did not: 16 us of
-// VALU issue take 68 us.  What was tried on the sweep, each measured: dynamic tile draws (one device atomic per tile,
-// 8 or 64 counters: 84-111 us -- the later loads of a wave queue behind the atomic's round trip), static natural
-// order 66, static cost-class order 68, compact records instead of gathers through the permutation 92 -> 92,
-// 8 / 12 / 16 resident waves per CU 71 / 72 / 82-93, a branch-free queue push 77; ablations: without the record
-// gathers 70, without the LDS reads 73, without the sweep loop 20, with the loop but without ballots / pushes 41.
-// The pair list's capacity is a multiple of the candidate bound; a run that overflows it raises device flag 7 and is
-// repeated with the fused kernel (finish_run).
+// HOT LOOP 2 on SWEEP RECORDS (matched mode, permutation placement; round 4)
 // ---------------------------------------------------------------------------------------------
-struct PairRec6 {  // 16 B
-  unsigned irec, jrec;  // k_eval6 replaces these two words by the pair's score (f64)
-  unsigned nbs_j;       // (image << 8) | slot of j
-  unsigned il;          // lane (candidate of the tile) of i
-};
-// The list is kRegions6 independent regions, each with its own bump counter (a device-scope atomic on ONE address
-// costs ~15 ns serialised -- one counter for the ~2e4 flushes of a run took 260 us; the counters are 128 bytes apart,
-// one L2 line each).  A segment is a header record {kNoSeg, count, index of the tile's previous header | kNoSeg, tile}
-// followed by its pairs; tile_head[tile] = index of the tile's newest header.
-constexpr unsigned kNoSeg = 0xFFFFFFFFu;
-constexpr int kRegions6 = 64;
-struct Split6 {
-  PairRec6 *pairs;      // [kRegions6][region_cap]
-  uint2 *tile_head;     // [tiles] (newest header of the tile or kNoSeg, its pair count | older segment exists << 31)
-  unsigned *counters;   // [kRegions6 * 32] records used per region (zeroed by k_cand_meta)
-  unsigned region_cap;
-};
-#ifndef LT_SWEEP6_RESIDENT
-#define LT_SWEEP6_RESIDENT 16  // persistent single-wave workgroups per CU, if registers and LDS allow
-#endif
-
-template <bool kPerm>
-__global__ void __launch_bounds__(64)
-k_sweep6(Score3Args a, Split6 sp, double scaleinv_guard2) {
+// Same tile (64 consecutive candidates in the reference's order), same sweep, same dense evaluation and ordered sums as
+// k_score3<true, false, true>; what changed is where a tile's data comes from.  k_score3's chain per tile was
+//   draw -> class-list entry -> {CandMeta, perm (own), perm (window)} -> {CRec (own), CRec (window): 128-byte gathers,
+//   converted to single precision} -> LDS -> sweep, and per dense round queue -> perm (i, j) -> CRec (i, j):
+// three load levels in front of the first pair of a tile, two in front of every round, and ~150 record gathers per tile of
+// which the window's (mean 84 entries for 64 candidates: nodes straddle tiles) were measured at 23 us of the kernel
+// (round 3, ablation 4).  Here k_place has written one 64-byte SRec per candidate AT ITS FINAL POSITION: the lane's
+// own operands, node bounds and summation order (CandMeta's fields) and the window entries are ONE coalesced level
+// behind the class-list entry, the window is copied to LDS as it is, and a dense round finds its two CRec indices in LDS
+// (the window entry carries the staging slot), so the CRecs -- still gathered, they are what pair_score needs -- are one
+// level behind the queue.  The queue entry shrinks to 16 bits (lane | window index): the queue is drained before a
+// window chunk is replaced.
+constexpr int kRQCap = 512;
+static_assert(kWin <= 256, "8-bit window index in the queue entries");
+size_t score_rec_lds_bytes(int max_nb) {
+  const size_t base = (size_t)kWin * 64 + 64 * 4 + (size_t)kRQCap * 2;
+  return ((base + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
+}
+__global__ void __launch_bounds__(64) LT_SCORE_OCC
+k_score_rec(Score3Args a, ScoreCfg cfg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x;
-  // LDS: WB float4[kWin4 + 4] (sx, ex, sy, ey) | WE float4[kWin4 + 4] (sz, ez, key, nb_slot) | WG float2[kWin4] (guard
-  //      radii of the entry as a candidate i) | WP u32[kWin4] | Q u16[kQ4 + 64] (queue + one dump word per lane)
-  float4 *WB = reinterpret_cast<float4 *>(smem_raw);
-  float4 *WE = WB + (kWin4 + 4);
-  float2 *WG = reinterpret_cast<float2 *>(WE + (kWin4 + 4));
-  unsigned *WP = reinterpret_cast<unsigned *>(WG + kWin4);
-  unsigned short *Q = reinterpret_cast<unsigned short *>(WP + kWin4);
+  // LDS: window float4[kWin][4] (SRec as it is) | lrec[64] u32 | queue[kRQCap] u16 | ord[max_nb] i32 | S[max_nb][64] u64
+  float4 *W4 = reinterpret_cast<float4 *>(smem_raw);
+  unsigned *lrec = reinterpret_cast<unsigned *>(smem_raw + (size_t)kWin * 64);
+  unsigned short *queue = reinterpret_cast<unsigned short *>(smem_raw + (size_t)kWin * 64 + 64 * 4);
+  int *ordl = reinterpret_cast<int *>(smem_raw + (size_t)kWin * 64 + 64 * 4 + (size_t)kRQCap * 2);
+  unsigned long long *S = reinterpret_cast<unsigned long long *>(
+      smem_raw + (((size_t)kWin * 64 + 64 * 4 + (size_t)kRQCap * 2 + (size_t)a.max_nb * 4 + 15) & ~(size_t)15));
 
   const long long C = a.tri_off[a.G];
   const unsigned n_tiles = (unsigned)((C + 63) >> 6);
-  // STATIC assignment, longest first: wave w of W takes the tiles of rank w, w + W, w + 2 W, ... in k_cand_meta's
-  // cost-class order (most expensive class first; natural order without the classes).  The sweep's tile times vary
-  // 1:5 and a wave handles only 2-4 tiles, so an even split needs the expensive tiles spread over the waves; a
-  // dynamic draw did that worse here than it costs: a device atomic per tile, with every later load of the wave
-  // queued behind its round trip (memory operations return in order) -- measured 84 us (64 draw counters) against
-  // 66 us (static, natural order) and the figure in profiles/ for this order.
-  // Rank -> tile: the 256 (class, queue) lists of k_cand_meta in rank order, four per lane, prefix by shuffles.
+  // persistent wave, tiles drawn through the per-XCD queues by cost class exactly as in k_score3
+  int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
   unsigned long long n_eval_total = 0;
-  unsigned lc[4] = {0, 0, 0, 0}, lane_incl = 0;
-  if (a.bucket_cnt) {
+  unsigned k_raw = 0;
+  if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+  unsigned cls_cnt = 0, cls_incl = 0, q_tiles = 0;
+  auto load_classes = [&]() {
+    cls_cnt = lane < kTileBuckets ? a.bucket_cnt[(q * kTileBuckets + (kTileBuckets - 1 - lane)) * 32] : 0u;
+    cls_incl = cls_cnt;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int bk = 4 * lane + u;  // rank order: class kTileBuckets - 1 first, queues 0..7 inside a class
-      const int cls = kTileBuckets - 1 - (bk >> 3), qq = bk & (kTileQueues - 1);
-      lc[u] = a.bucket_cnt[(qq * kTileBuckets + cls) * 32];
+    for (int d = 1; d < kTileBuckets; d <<= 1) {
+      const unsigned t = (unsigned)__shfl_up((int)cls_incl, d);
+      if (lane >= d) cls_incl += t;
     }
-    lane_incl = lc[0] + lc[1] + lc[2] + lc[3];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned t = (unsigned)__shfl_up((int)lane_incl, d);
-      if (lane >= d) lane_incl += t;
-    }
-  }
-  static_assert(kTileBuckets * kTileQueues == 256, "four class lists per lane");
-  unsigned rank_next = blockIdx.x;
-  auto resolve = [&]() -> unsigned {  // the wave's next tile, 0xFFFFFFFF when it has none left
-    const unsigned g = rank_next;
-    rank_next += gridDim.x;
-    if (g >= n_tiles) return 0xFFFFFFFFu;
-    if (!a.bucket_cnt) return g;
-    const unsigned long long m = __ballot(lane_incl > g);
-    if (!m) return 0xFFFFFFFFu;  // (cannot happen: the lists hold every tile)
-    const int ln = __builtin_ctzll(m);
-    unsigned base = (unsigned)__shfl((int)lane_incl, ln);
-    const unsigned c0 = (unsigned)__shfl((int)lc[0], ln), c1 = (unsigned)__shfl((int)lc[1], ln),
-                   c2 = (unsigned)__shfl((int)lc[2], ln), c3 = (unsigned)__shfl((int)lc[3], ln);
-    base -= c0 + c1 + c2 + c3;  // exclusive prefix of lane ln
-    unsigned r = g - base;
-    int u = 0;
-    if (r >= c0) { r -= c0; u = 1; if (r >= c1) { r -= c1; u = 2; if (r >= c2) { r -= c2; u = 3; } } }
-    const int bk = 4 * ln + u;
-    const int cls = kTileBuckets - 1 - (bk >> 3), qq = bk & (kTileQueues - 1);
-    return a.bucket_list[4 * ((size_t)(qq * kTileBuckets + cls) * a.bucket_cap + r)];
+    q_tiles = (unsigned)__builtin_amdgcn_readlane((int)cls_incl, kTileBuckets - 1);
   };
-  // The dependent chain of a tile -- draw -> window bounds -> record indices (placement permutation) and node starts
-  // of the window's entries -> records -- is SOFTWARE-PIPELINED across tiles: while tile T is swept, the bounds of
-  // T + 1 (k_cand_meta's per-tile record) and then its record indices / node starts are loaded into registers, so
-  // that a tile starts with the one level that is left: the gather of its records.  (Unpipelined, the five levels
-  // took 9 us of a 15 us tile.)  The first kWin4 entries of a window are covered; a longer window stages its further
-  // chunks the plain way.
-  struct Pre {
-    unsigned tile;
-    unsigned lo, hi;        // window bounds (candidate positions fit 32 bits)
-    unsigned p[2], o[2];    // record index and node start of window entries lane, lane + 64
-    unsigned own_off, own_n;
-  };
-  auto pre_bounds = [&](Pre &x) {
-    const uint2 d = a.tile_lohi[x.tile];
-    x.lo = d.x; x.hi = d.y;
-  };
-  auto pre_entries = [&](Pre &x) {
-    const unsigned wn = min(x.hi - x.lo, (unsigned)kWin4);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const unsigned e = (unsigned)lane + 64u * u;
-      x.p[u] = 0; x.o[u] = 0;
-      if (e < wn) {
-        const unsigned pos = x.lo + e;
-        x.p[u] = kPerm ? a.perm[pos] : pos;
-        x.o[u] = a.meta[pos].off_lo;
+  if (a.bucket_cnt) load_classes();
+  auto resolve = [&]() -> uint4 {
+    for (;;) {
+      const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
+      if (a.bucket_cnt) {
+        if (k < q_tiles) {
+          const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
+          const int bl = __builtin_ctzll(m);
+          const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)(cls_incl - cls_cnt), bl);
+          return reinterpret_cast<const uint4 *>(
+              a.bucket_list)[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
+        }
+      } else {
+        const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
+        if (e < n_tiles) return uint4{(unsigned)e, 0u, 0u, 0u};
       }
-    }
-    const long long tpos = (long long)x.tile * 64 + lane;
-    x.own_off = 0; x.own_n = 0;
-    if (tpos < C) {
-      const CandMeta mt = a.meta[tpos];
-      x.own_off = mt.off_lo;
-      x.own_n = mt.n;
+      if (++tried > 4 * kTileQueues) return uint4{0xFFFFFFFFu, 0u, 0u, 0u};
+      unsigned peek = 0xFFFFFFFFu, cap_l = 0;
+      if (lane < kTileQueues) {
+        peek = __hip_atomic_load(&a.draw[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cap_l = (n_tiles + (unsigned)(kTileQueues - 1 - lane)) / (unsigned)kTileQueues;
+      }
+      const unsigned long long open_q = __ballot(lane < kTileQueues && lane != q && peek < cap_l);
+      if (!open_q) return uint4{0xFFFFFFFFu, 0u, 0u, 0u};
+      const unsigned long long after = open_q & ~((2ull << q) - 1ull);
+      q = __builtin_ctzll(after ? after : open_q);
+      if (a.bucket_cnt) load_classes();
+      if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
     }
   };
-  static_assert(kWin4 <= 128, "two prefetched entries per lane");
-  Pre cur, nxt;
-  cur.tile = resolve();
-  if (cur.tile != 0xFFFFFFFFu) {
-    pre_bounds(cur);
-    pre_entries(cur);
-  }
-  while (cur.tile != 0xFFFFFFFFu) {
-    const unsigned tile = cur.tile;
-    const long long tpos = (long long)tile * 64 + lane;
+  // A window chunk is a contiguous piece of the SRec array and its LDS image is the same bytes: copied by the LDS-DMA path
+  // (global_load_lds_dwordx4: 1 KB per instruction, destination = wave-uniform base + lane x 16), no staging registers.
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef const __attribute__((address_space(1))) void gbl_void_t;
+  auto stage_window = [&](long long wb, int wn) {
+    const char *src = reinterpret_cast<const char *>(a.srec + wb);
+    const int bytes = wn * 64;
+#pragma unroll
+    for (int o = 0; o < kWin * 64; o += 1024)
+      if (o + lane * 16 < bytes)
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + o + lane * 16), (lds_void_t *)(smem_raw + o), 16, 0, 0);
+  };
+  // the ONE load level of a tile, issued as soon as its draw is resolved (the previous tile's window is dead by then): the
+  // lane's own record into registers and -- the class lists carry the window bounds -- the first window chunk into LDS
+  const float4 *srec4 = reinterpret_cast<const float4 *>(a.srec);
+  const float4 z4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+  float4 o0 = z4, o1 = z4, o2 = z4, o3 = z4;
+  auto load_first_level = [&](const uint4 h) {
+    const long long tp = (long long)h.x * 64 + lane;
+    if (tp < C) {
+      const float4 *r = srec4 + 4 * (size_t)tp;
+      o0 = r[0]; o1 = r[1]; o2 = r[2]; o3 = r[3];
+    }
+    if (h.z > h.y) stage_window((long long)h.y, (int)((h.z - h.y) < (unsigned)kWin ? (h.z - h.y) : (unsigned)kWin));
+  };
+  const float cosf_guard = cfg.cos_guard > -1.0 ? (float)(cfg.cos_guard - 2e-6) : -2.0f;
+  uint4 hdr = resolve();
+  if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
+  while (hdr.x != 0xFFFFFFFFu) {
+    const unsigned tile = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.x);
+    const unsigned h_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.y);
+    const unsigned h_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.z);
+    const bool h_bounds = h_hi > h_lo;
+    const long long i0 = (long long)tile * 64;
+    const long long tpos = i0 + lane;
     const bool active = tpos < C;
     LT_TRACE_MARK(2, tile, 0);
-#ifdef LT_TRACE
-    unsigned long long tr_flush = 0, tr_nflush = 0;
-#endif
-    const long long lo = (long long)cur.lo, hi = (long long)cur.hi;
-    const long long off = (long long)cur.own_off;
-    const int n = (int)cur.own_n;
-    const int wn0 = (int)((hi - lo) < kWin4 ? (hi - lo) : kWin4);
-    // ---- the one exposed level: the records of the first chunk's entries ----
-    double rs[2][6], rd[2][2];
-    int rnbs[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = lane + 64 * u;
-      rnbs[u] = 0;
-      for (int k = 0; k < 6; ++k) rs[u][k] = 0.0;
-      rd[u][0] = rd[u][1] = 0.0;
-      if (e < wn0) {
-        const CRec &c = a.cand[cur.p[u]];
-        rs[u][0] = c.s[0]; rs[u][1] = c.s[1]; rs[u][2] = c.s[2];
-        rs[u][3] = c.e[0]; rs[u][4] = c.e[1]; rs[u][5] = c.e[2];
-        rd[u][0] = c.depth[0]; rd[u][1] = c.depth[1];
-        rnbs[u] = c.nb_slot;
-      }
-    }
-    // meanwhile: the next tile and its bounds (the draw was issued while the previous tile was swept)
-    nxt.tile = resolve();
-    if (nxt.tile != 0xFFFFFFFFu) pre_bounds(nxt);
-    // sentinel key of the tile: node part = (window start - 1) mod 2^24, which no node of the window has; it ends
-    // every chunk and is the key of the idle lanes, wave-local origin = start point of the window's first entry
-    const unsigned key_sentinel = (((unsigned)lo - 1u) << 8) | 0xFFu;
-    const double ox = __shfl(rs[0][0], 0), oy = __shfl(rs[0][1], 0), oz = __shfl(rs[0][2], 0);
-    wave_lds_sync();  // the previous tile's window is no longer read
-    float rw = 0.0f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = lane + 64 * u;
-      if (e < wn0) {
-        const float sx = (float)(rs[u][0] - ox), sy = (float)(rs[u][1] - oy), sz = (float)(rs[u][2] - oz);
-        const float ex = (float)(rs[u][3] - ox), ey = (float)(rs[u][4] - oy), ez = (float)(rs[u][5] - oz);
-        WB[e] = float4{sx, ex, sy, ey};
-        WE[e] = float4{sz, ez, __uint_as_float((cur.o[u] << 8) | (unsigned)(rnbs[u] & 0xFF)), __int_as_float(rnbs[u])};
-        WP[e] = cur.p[u];
-        // guard radii of this entry as candidate i: dist / (depth + eps) > th_scaleinv (1 + 1e-6) can never score
-        // >= score_th (line_dists.cc:55-60); single precision, rounded UP (odd depths: leave it to the exact path)
-        const double zs = rd[u][0] + kEps, ze = rd[u][1] + kEps;
-        const double gs = (zs > 0.0) ? sqrt(scaleinv_guard2 * zs * zs) : 1e150;
-        const double ge = (ze > 0.0) ? sqrt(scaleinv_guard2 * ze * ze) : 1e150;
-        float gsf0 = (float)gs, gef0 = (float)ge;
-        if ((double)gsf0 < gs) gsf0 = __uint_as_float(__float_as_uint(gsf0) + 1u);
-        if ((double)gef0 < ge) gef0 = __uint_as_float(__float_as_uint(gef0) + 1u);
-        WG[e] = float2{gsf0, gef0};
-        rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
-      } else if (e < wn0 + 4) {
-        WE[e] = float4{0.0f, 0.0f, __uint_as_float(key_sentinel), 0.0f};  // every chunk ends in four sentinels
-      }
-    }
-    wave_lds_sync();
-    // this lane's own candidate = window entry tpos - lo (a lane whose entry lies beyond the first chunk -- its node
-    // starts more than kWin4 - 64 positions before the tile -- loads its record itself)
-    float sixf = 0, siyf = 0, sizf = 0, eixf = 0, eiyf = 0, eizf = 0, g0 = 0, g1 = 0;
-    unsigned keyi = key_sentinel, ri = 0;
-    if (active) {
-      const long long own = tpos - lo;
-      if (own < wn0) {
-        const float4 b = WB[own], e4 = WE[own];
-        const float2 g = WG[own];
-        sixf = b.x; eixf = b.y; siyf = b.z; eiyf = b.w; sizf = e4.x; eizf = e4.y;
-        keyi = __float_as_uint(e4.z);
-        g0 = g.x; g1 = g.y;
-        ri = WP[own];
-      } else {
-        ri = kPerm ? a.perm[tpos] : (unsigned)tpos;
-        const CRec &ci = a.cand[ri];
-        sixf = (float)(ci.s[0] - ox); siyf = (float)(ci.s[1] - oy); sizf = (float)(ci.s[2] - oz);
-        eixf = (float)(ci.e[0] - ox); eiyf = (float)(ci.e[1] - oy); eizf = (float)(ci.e[2] - oz);
-        const double zs = ci.depth[0] + kEps, ze = ci.depth[1] + kEps;
-        const double gs = (zs > 0.0) ? sqrt(scaleinv_guard2 * zs * zs) : 1e150;
-        const double ge = (ze > 0.0) ? sqrt(scaleinv_guard2 * ze * ze) : 1e150;
-        g0 = (float)gs; g1 = (float)ge;
-        if ((double)g0 < gs) g0 = __uint_as_float(__float_as_uint(g0) + 1u);
-        if ((double)g1 < ge) g1 = __uint_as_float(__float_as_uint(g1) + 1u);
-        keyi = ((unsigned)mt_key(off) << 8) | (unsigned)(ci.nb_slot & 0xFF);
-      }
-    }
-    const float ri_mag = active ? fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)),
-                                        fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf))) : 0.0f;
-    LT_TRACE_MARK(2, tile, 1);
-    int qc = 0;  // queued entries (wave-uniform); the queue is linear: it is emptied by every flush
-    const unsigned long long lt_mask = lanemask_lt();
-    unsigned seg_prev = kNoSeg, seg_prev_n = 0;
-    const unsigned region = blockIdx.x & (kRegions6 - 1);
 
-    // the queued pairs -> one contiguous segment of the global list (the entries index the current window)
-    auto flush = [&]() {
-#ifdef LT_TRACE
-      const unsigned long long tr0 = wall_clock64();
-#endif
+    // the lane's own operands: its sweep record
+    long long off = 0, nb0 = 0;
+    int n = 0, n_nb = 0, sloti = -1;
+    float dixf = 0, diyf = 0, dizf = 0, sixf = 0, siyf = 0, sizf = 0, eixf = 0, eiyf = 0, eizf = 0, ri = 0.0f;
+    double gs = 0, ge = 0;
+    unsigned own_rec = 0;
+    if (active) {
+      dixf = o0.x; diyf = o0.y; dizf = o0.z; sloti = __float_as_int(o0.w);
+      sixf = o1.x; eixf = o1.y; siyf = o1.z; eiyf = o1.w;
+      sizf = o2.x; eizf = o2.y; gs = (double)o2.z; ge = (double)o2.w;
+      off = (long long)__float_as_uint(o3.x);
+      n = (int)__float_as_uint(o3.y);
+      const unsigned nbw = __float_as_uint(o3.z);
+      nb0 = (long long)(nbw >> 8);
+      n_nb = (int)(nbw & 0xFFu);
+      own_rec = __float_as_uint(o3.w);
+      ri = fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)), fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf)));
+    }
+    lrec[lane] = own_rec;
+    const long long wave_nb0 = (long long)__builtin_amdgcn_readfirstlane((int)nb0);  // nb_off < 2^24
+    if (lane < __builtin_amdgcn_readfirstlane(n_nb)) ordl[lane] = a.blk_order[wave_nb0 + lane];
+    for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
+    // window = the nodes of the tile's first and last candidate, whole (lane 0 is always active)
+    long long lo, hi;
+    if (h_bounds) {
+      lo = (long long)h_lo; hi = (long long)h_hi;
+    } else {
+      const int last = (int)((C - i0) < 64 ? (C - i0) : 64) - 1;
+      lo = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)off);
+      hi = (long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(off + n), last);
+    }
+    int qn = 0;
+    unsigned long long n_eval = 0;
+
+    auto drain = [&](bool final) {
       wave_lds_sync();
-      unsigned start = 0;
-      if (lane == 0) start = atomicAdd(&sp.counters[region * 32], (unsigned)qc + 1u);
-      start = (unsigned)__builtin_amdgcn_readfirstlane((int)start);
-      const bool fits = (unsigned long long)start + (unsigned)qc + 1ull <= (unsigned long long)sp.region_cap;
-      if (!fits) {
-        if (lane == 0 && a.err_flag) *a.err_flag = 7;
-      } else {
-        const size_t hdr = (size_t)region * sp.region_cap + start;
-        for (int k0 = 0; k0 < qc; k0 += 64) {
-          const int k = k0 + lane;
-          const unsigned e = Q[k < qc ? k : 0];
-          const int il = (int)((e >> 8) & 63u), w = (int)(e & 0xFFu);
-          const unsigned irec = (unsigned)__shfl((int)ri, il);  // cross-lane read by all lanes
-          if (k < qc) {
-            PairRec6 r;
-            r.irec = irec;
-            r.jrec = WP[w];
-            r.nbs_j = __float_as_uint(WE[w].w);
-            r.il = (unsigned)il;
-            *reinterpret_cast<uint4 *>(&sp.pairs[hdr + 1 + (unsigned)k]) = *reinterpret_cast<const uint4 *>(&r);
-          }
+      if (final && qn == 0 && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+      for (int q0 = 0; q0 < qn; q0 += 64) {
+        if (final && q0 + 64 >= qn && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+        const int p = q0 + lane;
+        if (p < qn) {
+          const unsigned e = queue[p];
+          const int il = (int)(e >> 8);
+          const unsigned rj = reinterpret_cast<const unsigned *>(W4)[16 * (e & 0xFFu) + 15];  // SRec::rec of the window entry
+          const CRec &ci = a.cand[lrec[il]];
+          const CRec &cj = a.cand[rj];
+          const int nbs_j = cj.nb_slot;
+          const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
+                                       mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
+                                       mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
+                                       mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg,
+                                       a.cams[(int)((unsigned)nbs_j >> 8)]);
+          if (sc > 0.0) atomicMax(&S[(nbs_j & 0xFF) * 64 + il], (unsigned long long)__double_as_longlong(sc));
         }
-        if (lane == 0) *reinterpret_cast<uint4 *>(&sp.pairs[hdr]) = uint4{kNoSeg, (unsigned)qc, seg_prev, tile};
-        seg_prev_n = (unsigned)qc | (seg_prev != kNoSeg ? 0x80000000u : 0u);  // top bit: an older segment exists
-        seg_prev = (unsigned)hdr;
       }
-      n_eval_total += (unsigned long long)qc;
-#ifdef LT_TRACE
-      tr_nflush += (unsigned long long)qc << 16 | 1ull;
-#endif
-      qc = 0;
+      n_eval += (unsigned long long)qn;
+      qn = 0;
       wave_lds_sync();
-#ifdef LT_TRACE
-      tr_flush += wall_clock64() - tr0;
-#endif
     };
 
-    for (long long wb = lo; wb < hi; wb += kWin4) {
-      const int wn = (int)((hi - wb) < kWin4 ? (hi - wb) : kWin4);
-      if (wb != lo) {
-        // a further chunk of a long window, staged the plain way (its entries were flushed at the end of the last one)
+    for (long long wb = lo; wb < hi; wb += kWin) {
+      const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
+      // the first chunk is already on its way when the class list gave the bounds (load_first_level); later chunks
+      // (windows beyond kWin entries) and tiles without listed bounds are staged here -- the queue was drained, nobody
+      // reads the window any more
+      if (!(h_bounds && wb == lo)) {
         wave_lds_sync();
-        rw = 0.0f;
-        for (int e = lane; e < wn + 4; e += 64) {
-          if (e < wn) {
-            const long long pos = wb + e;
-            const unsigned pr = kPerm ? a.perm[pos] : (unsigned)pos;
-            const unsigned eoff = a.meta[pos].off_lo;
-            const CRec &c = a.cand[pr];
-            const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
-            const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
-            const int nbs = c.nb_slot;
-            WB[e] = float4{sx, ex, sy, ey};
-            WE[e] = float4{sz, ez, __uint_as_float((eoff << 8) | (unsigned)(nbs & 0xFF)), __int_as_float(nbs)};
-            WP[e] = pr;
-            rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
-          } else {
-            WE[e] = float4{0.0f, 0.0f, __uint_as_float(key_sentinel), 0.0f};
-          }
-        }
-        wave_lds_sync();
+        stage_window(wb, wn);
       }
-      // R of the window -> this lane's single-precision distance guards (a NaN coordinate makes R NaN, the guards
-      // NaN and every comparison false: everything goes to the exact evaluation)
-      float rmax = fmaxf(rw, ri_mag);
-      if (rw != rw) rmax = rw;
-      for (int d = 32; d >= 1; d >>= 1) {
-        const float o = __shfl_xor(rmax, d);
-        rmax = (o > rmax || o != o) ? o : rmax;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA counts as a vector memory operation
+      wave_lds_sync();
+      float rw = ri;
+      for (int e = lane; e < wn; e += 64) {
+        const float4 r1 = W4[4 * e + 1];
+        const float2 r2 = *reinterpret_cast<const float2 *>(&W4[4 * e + 2]);
+        rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(r1.x), fabsf(r1.y)), fmaxf(fabsf(r1.z), fabsf(r1.w))),
+                             fmaxf(fabsf(r2.x), fabsf(r2.y))));
       }
-      const double delta = 1e-6 * (double)rmax;
-      const float gsf = (float)(((double)g0 + delta) * ((double)g0 + delta) * (1.0 + 2e-6));
-      const float gef = (float)(((double)g1 + delta) * ((double)g1 + delta) * (1.0 + 2e-6));
+      // R of the window -> the lane's single-precision squared distance guards (see k_score3: 1e-6 R bounds the rounding
+      // of a single-precision distance; a NaN coordinate makes every comparison false: everything goes to the exact path)
+      rw = wave_max_f32_nan(rw);
+      const double delta = 1e-6 * (double)rw;
+      const float gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
+      const float gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
+      wave_lds_sync();
+      if (wb == lo) { LT_TRACE_MARK(2, tile, 1); }
       const long long jlo = off > wb ? off : wb;
       const long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
       const int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
-      int cmax = cnt;
-      for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d));
-      const int w0 = cnt > 0 ? (int)(jlo - wb) : wn;
-      const int wend = w0 + cnt;
+      const int cmax = wave_max_i32(cnt);
+      const int wbase = cnt > 0 ? (int)(jlo - wb) : 0;
+      const int wlast = cnt > 0 ? wbase + cnt - 1 : 0;  // reads beyond the lane's range are clamped, then masked
+      const int self_t = (int)(tpos - jlo);             // iteration at which the lane meets itself (may be out of range)
+#if defined(LT_RABL) && LT_RABL >= 2
+      for (int t = 0; t < min(cmax, 4); t += 4) {
+#else
       for (int t = 0; t < cmax; t += 4) {
-        if (qc > kQ4 - 256) flush();
-        float4 B[4], E[4];
-        int wi[4];
+#endif
+        float4 A[4], B[4];
+        float2 E[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          wi[u] = min(w0 + t + u, wend);
-          B[u] = WB[wi[u]];
-          E[u] = WE[wi[u]];
+          const int w = min(wbase + t + u, wlast);
+          A[u] = W4[4 * w + 0];
+          B[u] = W4[4 * w + 1];
+          E[u] = *reinterpret_cast<const float2 *>(&W4[4 * w + 2]);
         }
         bool pass[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+          const float c = fabsf(__builtin_fmaf(dizf, A[u].z, __builtin_fmaf(diyf, A[u].y, dixf * A[u].x)));
           const float ax = sixf - B[u].x, bx = eixf - B[u].y;
           const float ay = siyf - B[u].z, by = eiyf - B[u].w;
           const float az = sizf - E[u].x, bz = eizf - E[u].y;
           const float ds2 = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
           const float de2 = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
-          const unsigned x = __float_as_uint(E[u].z) ^ keyi;  // same node, another neighbour image: 0 < x < 256
-          pass[u] = ((x - 1u) < 255u) & !(ds2 > gsf) & !(de2 > gef);
+          pass[u] = (t + u < cnt) & (t + u != self_t) & (__float_as_int(A[u].w) != sloti) & !(c < cosf_guard) &
+                    !(ds2 > gsf) & !(de2 > gef);
         }
-        // Branch-free push: every lane stores, a lane without a pair into its own word of a dump area behind the
-        // queue.  (The natural form -- `if (ballot) { if (pass) store; }` per step -- compiles to two branches per
-        // step, eight per iteration; their fetch bubbles were 40 % of this kernel: 68 -> 41 us without them.)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const unsigned long long m = __ballot(pass[u]);
-          const int slot = pass[u] ? qc + (int)__popcll(m & lt_mask) : kQ4 + lane;
-          Q[slot] = (unsigned short)(((unsigned)lane << 8) | (unsigned)wi[u]);
-          qc += (int)__popcll(m);
+          if (m) {
+            if (pass[u]) queue[qn + __popcll(m & lanemask_lt())] = (unsigned short)(((unsigned)lane << 8) | (unsigned)(wbase + t + u));
+            qn += __popcll(m);
+          }
         }
+        if (qn > kRQCap - 256) drain(false);
       }
-      if (qc > 0 && wb + kWin4 < hi) flush();  // the entries index this chunk's window
-    }
-    LT_TRACE_MARK(2, tile, 2);
-    // the next tile's record indices and node starts (its bounds arrived long ago): in flight during the flush
-    if (nxt.tile != 0xFFFFFFFFu) pre_entries(nxt);
-    if (qc > 0) flush();
-    if (lane == 0) sp.tile_head[tile] = uint2{seg_prev, seg_prev_n};
-#ifdef LT_TRACE
-    if (lane == 0 && tile < 65536u) {
-      g_trace[3 * 4 * 65536 + 4 * tile + 0] = tr_flush;
-      g_trace[3 * 4 * 65536 + 4 * tile + 1] = tr_nflush & 0xFFFFull;
-      g_trace[3 * 4 * 65536 + 4 * tile + 2] = tr_nflush >> 16;
-      g_trace[3 * 4 * 65536 + 4 * tile + 3] = wall_clock64();
-    }
+      // the queue entries name window indices: evaluate them before the window is replaced
+      const bool last_chunk = wb + kWin >= hi;
+      if (last_chunk) { LT_TRACE_MARK(2, tile, 2); }
+#if defined(LT_RABL) && LT_RABL >= 1
+      qn = 0;
 #endif
-    cur = nxt;
+      drain(last_chunk);
+    }
+    LT_TRACE_MARK(2, tile, 3);
+
+    if (active) {
+      double sum = 0.0;
+      const bool own = nb0 == wave_nb0;
+      for (int r = 0; r < n_nb; ++r) {
+        const int k = own ? ordl[r] : a.blk_order[nb0 + r];
+        sum += __longlong_as_double((long long)S[k * 64 + lane]);
+      }
+      a.score[tpos] = sum;
+    }
+    n_eval_total += n_eval;
+    wave_lds_sync();  // the tables are reused by the next tile
+    hdr = resolve();
+    if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
   }
   if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
 }
 
-// Flat evaluation of the pair list: chunk c = pairs [64 c, 64 c + 64), dealt round-robin to the persistent waves.
-__global__ void __launch_bounds__(256)
-k_eval6(Score3Args a, Split6 sp, ScoreCfg cfg) {
-  if (a.err_flag && *a.err_flag == 7) return;  // the list overflowed: it has holes, the run is repeated (finish_run)
-  const unsigned n_waves = gridDim.x * 4u;
-  const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-  const int lane = lane_id();
-  // chunks of 64 records per region: lane r holds region r's record count and the inclusive prefix of the chunk counts
-  static_assert(kRegions6 == 64, "one lane per region");
-  const unsigned cnt_r = min(sp.counters[lane * 32], sp.region_cap);
-  const unsigned chunks_r = (cnt_r + 63u) >> 6;
-  unsigned incl = chunks_r;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const unsigned t = (unsigned)__shfl_up((int)incl, d);
-    if (lane >= d) incl += t;
-  }
-  const unsigned total_chunks = (unsigned)__shfl((int)incl, 63);
-  // the pair record of the wave's NEXT chunk is loaded while this one is evaluated (one dependent level less per round)
-  auto fetch = [&](unsigned c, size_t &p) -> uint4 {
-    uint4 r = uint4{kNoSeg, 0u, 0u, 0u};
-    p = 0;
-    if (c < total_chunks) {
-      const int reg = __builtin_ctzll(__ballot(incl > c));
-      const unsigned first = (unsigned)__shfl((int)(incl - chunks_r), reg);
-      const unsigned cnt = (unsigned)__shfl((int)cnt_r, reg);
-      const unsigned k = ((c - first) << 6) + (unsigned)lane;
-      p = (size_t)reg * sp.region_cap + k;
-      if (k < cnt) r = *reinterpret_cast<const uint4 *>(&sp.pairs[p]);
-    }
-    return r;
-  };
-  size_t p = 0, p_next = 0;
-  uint4 r = fetch(wave, p);
-  for (unsigned c = wave; c < total_chunks; c += n_waves) {
-    const uint4 r_next = fetch(c + n_waves, p_next);
-    if (r.x != kNoSeg) {  // not a segment header
-      const CRec &ci = a.cand[r.x];
-      const CRec &cj = a.cand[r.y];
-      const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
-                                   mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
-                                   mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
-                                   mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg, a.cams[(int)(r.z >> 8)]);
-      *reinterpret_cast<double *>(&sp.pairs[p]) = sc;  // replaces (irec, jrec)
-    }
-    r = r_next;
-    p = p_next;
-  }
-}
+// ---------------------------------------------------------------------------------------------
+// HOT LOOP 2 in TWO kernels on the sweep records (matched mode; the default since round 4)
+// ---------------------------------------------------------------------------------------------
+// What bounds the fused kernels (k_score3, k_score_rec) is not a roof but their schedule: per tile a light, latency-bound
+// sweep and a heavy, issue-bound dense phase whose length nobody knows before the sweep has run (0 ... 537 pairs per
+// tile at 100 x 500: 0 ... 9 rounds of ~5 us), on waves that need pair_score's ~200 registers -- two per SIMD -- for the
+// whole tile.  The trace of round 4 (profiles/r04_score_trace.txt): wave time inside tiles 142 ms over 2 048 resident
+// waves = 69 us, the kernel 102: ~15 us of gaps between tiles (draw -> class-list entry -> records) and ~17 us of tail
+// (tiles that turn out heavy start late: the cost classes know the node sizes, not the pairs).  So:
+//   k_sweep_rec   one wave per tile, no pair_score in the kernel: 40 registers, 13 waves per CU -- the window streams
+//                 in (SRec, LDS-DMA), the pairs that pass the conservative guards go to a global list (8 bytes: CRec
+//                 slot of j, lane of i; a tile's pairs = one contiguous segment, rarely more), and the tile is listed
+//                 by its EXACT pair count (per-XCD queue x 32 classes of 16 pairs); tiles without a pair are finished
+//                 here (score 0).
+//   k_dense_rec   persistent waves draw the tiles heaviest first (longest-processing-time order on the true cost) and do
+//                 only the dense rounds, the per-image maxima (LDS, ds_max_u64) and the ordered sums of a tile.
+// A pair list that does not hold (LT_TEST_PAIR_CAP forces it) raises device flag 7; the host repeats the run with the
+// fused k_score_rec (finish_run), same results.
+constexpr int kSwQCap = 768;      // LDS queue of k_sweep_rec (entries); flushed when fewer than 256 are free
+constexpr int kPairRegions = 64;  // bump counters of the pair list, 128 bytes apart (one address serialises at ~15 ns)
+constexpr int kMaxMoreSegs = 3;   // segments of a tile beyond the first (a tile flushes its queue at 512 pairs)
+struct PairList {
+  uint2 *pairs;           // [kPairRegions][region_cap]: x = CRec slot of j, y = lane of i in the tile
+  unsigned *region_ctr;   // kPairRegions counters, 128 bytes apart, zeroed by k_build_pairs
+  unsigned region_cap;
+  uint2 *tile_more;       // [tiles][kMaxMoreSegs]: (first pair, count) of a tile's segments beyond the first
+  // heavy tiles are evaluated in PARTS of <= kPartPairs pairs by several waves: per split tile a table of per-image
+  // maxima in HBM (zeroed by k_sweep_rec, combined by atomic max) and a counter of finished parts; the wave that
+  // finishes the last part sums and writes the tile's scores
+  unsigned long long *split_S;  // [split_cap][max_nb][64]
+  unsigned *split_done;         // [split_cap]
+  unsigned *split_ctr;          // split tiles so far (zeroed by k_build_pairs with the region counters)
+  unsigned split_cap;
+};
+constexpr unsigned kSplitMin = 192;   // tiles with more pairs than this (3 dense rounds) are split
+constexpr unsigned kPartPairs = 128;  // pairs per part (2 rounds)
+size_t sweep_rec_lds_bytes() { return (size_t)kWin * 64 + (size_t)kSwQCap * 4 + (size_t)kSwQCap + 4 * 8; }
 
-// Per tile: maxima per (candidate, neighbour slot) over the tile's segments, sums in image-id order.
-template <bool kPerm>
-__global__ void __launch_bounds__(256)
-k_reduce6(Score3Args a, Split6 sp) {
+__global__ void __launch_bounds__(64)
+k_sweep_rec(Score3Args a, ScoreCfg cfg, PairList pl) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int lane = lane_id();
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_raw) + (size_t)wv * (size_t)a.max_nb * 64;
-  if (a.err_flag && *a.err_flag == 7) return;  // see k_eval6
+  const int lane = threadIdx.x;
+  float4 *W4 = reinterpret_cast<float4 *>(smem_raw);                                      // window: SRec as it is
+  unsigned *qrec = reinterpret_cast<unsigned *>(smem_raw + (size_t)kWin * 64);            // queue: CRec slot of j
+  unsigned char *qil = smem_raw + (size_t)kWin * 64 + (size_t)kSwQCap * 4;                //        lane of i
+  uint2 *segl = reinterpret_cast<uint2 *>(smem_raw + (size_t)kWin * 64 + (size_t)kSwQCap * 5);  // the tile's segments
+  static_assert(kSwQCap % 8 == 0, "alignment of the segment table");
   const long long C = a.tri_off[a.G];
+  if (blockIdx.x == 0 && lane < kTileQueues) a.draw[lane * 32] = 0;  // the draw counters of k_dense_rec
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef const __attribute__((address_space(1))) void gbl_void_t;
+  const float4 *srec4 = reinterpret_cast<const float4 *>(a.srec);
+  const float cosf_guard = cfg.cos_guard > -1.0 ? (float)(cfg.cos_guard - 2e-6) : -2.0f;
   const unsigned n_tiles = (unsigned)((C + 63) >> 6);
-  for (unsigned tile = blockIdx.x * 4u + (unsigned)wv; tile < n_tiles; tile += gridDim.x * 4u) {
-  const long long tpos = (long long)tile * 64 + lane;
+  // the grid is sized by an upper bound of the candidate count (the exact one stays on the device): waves stride over the tiles
+  for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  const long long i0 = (long long)tile * 64;
+  const long long tpos = i0 + lane;
   const bool active = tpos < C;
-  long long nb0 = 0;
-  int n_nb = 0;
+  LT_TRACE_MARK(3, tile, 0);
+  const float4 z4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+  float4 o0 = z4, o1 = z4, o2 = z4, o3 = z4;
   if (active) {
-    const CandMeta mt = a.meta[tpos];
-    nb0 = (long long)(mt.nb >> 8);
-    n_nb = (int)(mt.nb & 0xFFu);
+    const float4 *r = srec4 + 4 * (size_t)tpos;
+    o0 = r[0]; o1 = r[1]; o2 = r[2]; o3 = r[3];
   }
-  const uint2 th = sp.tile_head[tile];
-  unsigned seg = th.x, seg_n = th.y;  // the newest segment's count comes with the head: its pairs need no header read
-  if (seg == kNoSeg) {  // no pair survived the sweep: every candidate of the tile scores 0
-    if (active) a.score[tpos] = 0.0;
-    continue;
+  long long off = 0;
+  int n = 0, sloti = -1;
+  float dixf = 0, diyf = 0, dizf = 0, sixf = 0, siyf = 0, sizf = 0, eixf = 0, eiyf = 0, eizf = 0, ri = 0.0f;
+  double gs = 0, ge = 0;
+  if (active) {
+    dixf = o0.x; diyf = o0.y; dizf = o0.z; sloti = __float_as_int(o0.w);
+    sixf = o1.x; eixf = o1.y; siyf = o1.z; eiyf = o1.w;
+    sizf = o2.x; eizf = o2.y; gs = (double)o2.z; ge = (double)o2.w;
+    off = (long long)__float_as_uint(o3.x);
+    n = (int)__float_as_uint(o3.y);
+    ri = fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)), fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf)));
   }
-  for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
-  const long long wave_nb0 = __shfl(nb0, 0);
-  const int wave_nnb = __shfl(n_nb, 0);
-  const int ordv = lane < wave_nnb ? a.blk_order[wave_nb0 + lane] : 0;
-  wave_lds_sync();
-  int guard = 0;
-  while (seg != kNoSeg && guard++ < (1 << 20)) {
-    // header: {kNoSeg, count, previous header, tile}; only a tile with several segments waits for it
-    uint4 sr = uint4{kNoSeg, seg_n & 0x7FFFFFFFu, kNoSeg, 0u};
-    if (guard > 1 || (seg_n >> 31)) sr = *reinterpret_cast<const uint4 *>(&sp.pairs[seg]);
-    for (unsigned k = (unsigned)lane; k < sr.y; k += 64) {
-      const uint4 r = *reinterpret_cast<const uint4 *>(&sp.pairs[(size_t)seg + 1 + k]);
-      const unsigned long long bits = ((unsigned long long)r.y << 32) | (unsigned long long)r.x;
-      if (__longlong_as_double((long long)bits) > 0.0) atomicMax(&S[(r.z & 0xFFu) * 64 + (r.w & 63u)], bits);
+  // window = the nodes of the tile's first and last candidate, whole (lane 0 is always active)
+  const int last = (int)((C - i0) < 64 ? (C - i0) : 64) - 1;
+  const long long lo = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)off);
+  const long long hi = (long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(off + n), last);
+  const unsigned region = tile & (unsigned)(kPairRegions - 1);
+  int qn = 0;
+  unsigned n_seg = 0, total = 0;
+  // ((first pair, count) of the tile's segments: LDS table segl -- registers indexed by n_seg end up in scratch)
+  if (lane < 4) segl[lane] = make_uint2(0u, 0u);
+  static_assert(kMaxMoreSegs == 3, "four segments per tile are kept in registers");
+  auto flush = [&]() __attribute__((always_inline)) {
+    wave_lds_sync();
+    if (qn > 0) {
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(&pl.region_ctr[region * 32], (unsigned)qn);
+      base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+      if ((unsigned long long)base + (unsigned)qn > (unsigned long long)pl.region_cap || n_seg > (unsigned)kMaxMoreSegs) {
+        if (lane == 0) *a.err_flag = 7;  // the host repeats the run with the fused kernel (these pairs are dropped)
+      } else {
+        const unsigned g0 = region * pl.region_cap + base;
+        for (int p = lane; p < qn; p += 64) pl.pairs[(size_t)g0 + p] = make_uint2(qrec[p], (unsigned)qil[p]);
+        if (lane == 0) segl[n_seg] = make_uint2(g0, (unsigned)qn);
+        if (n_seg > 0 && lane == 0) pl.tile_more[(size_t)tile * kMaxMoreSegs + (n_seg - 1)] = make_uint2(g0, (unsigned)qn);
+        ++n_seg;
+        total += (unsigned)qn;
+      }
+      qn = 0;
     }
-    seg = sr.z;
-  }
-  wave_lds_sync();
-  double sum = 0.0;
-  const bool own = nb0 == wave_nb0;
-  int rmax = n_nb;
-  for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d));
-  for (int r = 0; r < rmax; ++r) {  // r is wave-uniform: the first image's order comes by readlane
-    const int k_own = __builtin_amdgcn_readlane(ordv, r);
-    if (r < n_nb) {
-      const int k = own ? k_own : a.blk_order[nb0 + r];
-      sum += __longlong_as_double((long long)S[k * 64 + lane]);
+    wave_lds_sync();
+  };
+  for (long long wb = lo; wb < hi; wb += kWin) {
+    const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
+    wave_lds_sync();  // the previous chunk's readers are done
+    {
+      const char *src = reinterpret_cast<const char *>(a.srec + wb);
+      const int bytes = wn * 64;
+#pragma unroll
+      for (int o = 0; o < kWin * 64; o += 1024)
+        if (o + lane * 16 < bytes)
+          __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + o + lane * 16), (lds_void_t *)(smem_raw + o), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_lds_sync();
+    float rw = ri;
+    for (int e = lane; e < wn; e += 64) {
+      const float4 r1 = W4[4 * e + 1];
+      const float2 r2 = *reinterpret_cast<const float2 *>(&W4[4 * e + 2]);
+      rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(r1.x), fabsf(r1.y)), fmaxf(fabsf(r1.z), fabsf(r1.w))),
+                           fmaxf(fabsf(r2.x), fabsf(r2.y))));
+    }
+    rw = wave_max_f32_nan(rw);
+    const double delta = 1e-6 * (double)rw;  // see k_score3: bounds the rounding of a single-precision distance
+    const float gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
+    const float gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
+    const long long jlo = off > wb ? off : wb;
+    const long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
+    const int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
+    const int cmax = wave_max_i32(cnt);
+    const int wbase = cnt > 0 ? (int)(jlo - wb) : 0;
+    const int wlast = cnt > 0 ? wbase + cnt - 1 : 0;  // reads beyond the lane's range are clamped, then masked
+    const int self_t = (int)(tpos - jlo);
+    for (int t = 0; t < cmax; t += 4) {
+      float4 A[4], B[4];
+      float2 E[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int w = min(wbase + t + u, wlast);
+        A[u] = W4[4 * w + 0];
+        B[u] = W4[4 * w + 1];
+        E[u] = *reinterpret_cast<const float2 *>(&W4[4 * w + 2]);
+      }
+      bool pass[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float c = fabsf(__builtin_fmaf(dizf, A[u].z, __builtin_fmaf(diyf, A[u].y, dixf * A[u].x)));
+        const float ax = sixf - B[u].x, bx = eixf - B[u].y;
+        const float ay = siyf - B[u].z, by = eiyf - B[u].w;
+        const float az = sizf - E[u].x, bz = eizf - E[u].y;
+        const float ds2 = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
+        const float de2 = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
+        pass[u] = (t + u < cnt) & (t + u != self_t) & (__float_as_int(A[u].w) != sloti) & !(c < cosf_guard) &
+                  !(ds2 > gsf) & !(de2 > gef);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned long long m = __ballot(pass[u]);
+        if (m) {
+          if (pass[u]) {
+            const int p = qn + __popcll(m & lanemask_lt());
+            qrec[p] = reinterpret_cast<const unsigned *>(W4)[16 * (wbase + t + u) + 15];  // SRec::rec of j
+            qil[p] = (unsigned char)lane;
+          }
+          qn += __popcll(m);
+        }
+      }
+      if (qn > kSwQCap - 256) flush();
     }
   }
-  if (active) a.score[tpos] = sum;
-  wave_lds_sync();  // S is reused by the wave's next tile
+  flush();
+  LT_TRACE_MARK(3, tile, 1);
+  // a work item of k_dense_rec, listed by its exact cost: 16 pairs per class, the last class open-ended
+  auto list_item = [&](unsigned pairs_of_item, unsigned e_y, unsigned e_z, unsigned e_w, unsigned spread) __attribute__((always_inline)) {
+    const unsigned cls = (pairs_of_item >> 4) < (unsigned)(kTileBuckets - 1) ? (pairs_of_item >> 4) : (unsigned)(kTileBuckets - 1);
+    const int qb = (int)((tile + spread) & (kTileQueues - 1)) * kTileBuckets + (int)cls;
+    const unsigned idx = atomicAdd(&a.bucket_cnt_w[qb * 32], 1u);
+    if (idx < a.bucket_cap) reinterpret_cast<uint4 *>(a.bucket_list_w)[(size_t)qb * a.bucket_cap + idx] = uint4{tile, e_y, e_z, e_w};
+    else *a.err_flag = 7;  // a list is full (the host sizes them for three items per tile): repeated with the fused kernel
+  };
+  if (total == 0) {
+    if (active) a.score[tpos] = 0.0;  // no pair reaches pair_score: every per-image maximum is 0
+  } else {
+    // heavy tile: parts of <= kPartPairs pairs for several waves (see PairList); needs a slot of the split tables
+    unsigned sidx = 0xFFFFFFFFu;
+    if (total > kSplitMin && pl.split_cap > 0) {
+      if (lane == 0) sidx = atomicAdd(pl.split_ctr, 1u);
+      sidx = (unsigned)__builtin_amdgcn_readfirstlane((int)sidx);
+      if (sidx >= pl.split_cap) sidx = 0xFFFFFFFFu;
+    }
+    if (sidx != 0xFFFFFFFFu) {
+      unsigned long long *gS = pl.split_S + (size_t)sidx * (size_t)a.max_nb * 64;
+      for (int k = 0; k < a.max_nb; ++k) gS[k * 64 + lane] = 0ull;
+      if (lane == 0) {
+        unsigned n_parts = 0;
+        for (unsigned sg = 0; sg < n_seg; ++sg) n_parts += (segl[sg].y + kPartPairs - 1) / kPartPairs;
+        pl.split_done[sidx] = 0u;
+        unsigned part = 0;
+        for (unsigned sg = 0; sg < n_seg; ++sg) {
+          const unsigned sb = segl[sg].x, sc = segl[sg].y;
+          for (unsigned p0 = 0; p0 < sc; p0 += kPartPairs, ++part) {
+            const unsigned c = (sc - p0) < kPartPairs ? (sc - p0) : kPartPairs;
+            // parts of one tile go to different queues (XCDs): they are meant to run side by side
+            list_item(c, sb + p0, c | (n_parts << 16), 0x80000000u | sidx, part);
+          }
+        }
+      }
+    } else if (lane == 0) {
+      list_item(total, segl[0].x, segl[0].y, n_seg, 0u);
+    }
   }
+  // (the pair statistic is counted by k_dense_rec, once per wave: 9 000 atomics on ONE address here serialised at
+  // ~15 ns each and made this kernel 114 us long)
+  }  // tiles
 }
 
-// ---------------------------------------------------------------------------------------------
-// launch wrappers
-// ---------------------------------------------------------------------------------------------
+size_t dense_rec_lds_bytes(int max_nb) {
+  return (((size_t)64 * 4 + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
+}
+__global__ void __launch_bounds__(64) LT_SCORE_OCC
+k_dense_rec(Score3Args a, ScoreCfg cfg, PairList pl) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x;
+  // LDS: lrec[64] u32 | ord[max_nb] i32 | S[max_nb][64] u64
+  unsigned *lrec = reinterpret_cast<unsigned *>(smem_raw);
+  int *ordl = reinterpret_cast<int *>(smem_raw + 64 * 4);
+  unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_raw + (((size_t)64 * 4 + (size_t)a.max_nb * 4 + 15) & ~(size_t)15));
+  const long long C = a.tri_off[a.G];
+  // the tiles with pairs, listed per (queue, class) by k_sweep_rec; lane q < kTileQueues keeps the size of queue q
+  unsigned q_size = 0;
+  if (lane < kTileQueues)
+    for (int c = 0; c < kTileBuckets; ++c) q_size += a.bucket_cnt[(lane * kTileBuckets + c) * 32];
+  int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
+  unsigned k_raw = 0;
+  if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+  unsigned cls_cnt = 0, cls_incl = 0, q_tiles = 0;
+  auto load_classes = [&]() {
+    cls_cnt = lane < kTileBuckets ? a.bucket_cnt[(q * kTileBuckets + (kTileBuckets - 1 - lane)) * 32] : 0u;
+    cls_incl = cls_cnt;
+#pragma unroll
+    for (int d = 1; d < kTileBuckets; d <<= 1) {
+      const unsigned t = (unsigned)__shfl_up((int)cls_incl, d);
+      if (lane >= d) cls_incl += t;
+    }
+    q_tiles = (unsigned)__builtin_amdgcn_readlane((int)cls_incl, kTileBuckets - 1);
+  };
+  load_classes();
+  auto resolve = [&]() -> uint4 {
+    for (;;) {
+      const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
+      if (k < q_tiles) {
+        const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
+        const int bl = __builtin_ctzll(m);
+        const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)(cls_incl - cls_cnt), bl);
+        return reinterpret_cast<const uint4 *>(
+            a.bucket_list)[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
+      }
+      // this queue is exhausted: peek at the counters (plain loads) and move to one that still has tiles
+      if (++tried > 4 * kTileQueues) return uint4{0xFFFFFFFFu, 0u, 0u, 0u};
+      unsigned peek = 0xFFFFFFFFu;
+      if (lane < kTileQueues) peek = __hip_atomic_load(&a.draw[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long open_q = __ballot(lane < kTileQueues && lane != q && peek < q_size);
+      if (!open_q) return uint4{0xFFFFFFFFu, 0u, 0u, 0u};
+      const unsigned long long after = open_q & ~((2ull << q) - 1ull);
+      q = __builtin_ctzll(after ? after : open_q);
+      load_classes();
+      if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+    }
+  };
+  const float4 *srec4 = reinterpret_cast<const float4 *>(a.srec);
+  float4 o3 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+  uint2 pr0 = make_uint2(0u, 0u);
+  auto load_first_level = [&](const uint4 h) {  // the lane's node words / CRec slot and the first round's pairs
+    const long long tp = (long long)h.x * 64 + lane;
+    if (tp < C) o3 = srec4[4 * (size_t)tp + 3];
+    if ((unsigned)lane < ((h.w >> 31) ? (h.z & 0xFFFFu) : h.z)) pr0 = pl.pairs[(size_t)h.y + lane];
+  };
+  unsigned long long n_eval_total = 0;
+  uint4 hdr = resolve();
+  if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
+  while (hdr.x != 0xFFFFFFFFu) {
+    const unsigned tile = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.x);
+    const unsigned s0_base = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.y);
+    const unsigned h_z = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.z);
+    const unsigned h_w = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.w);
+    // a whole tile (w = its segments) or one part of a split tile (w = 0x80000000 | split slot, z = pairs | parts << 16)
+    const bool is_part = (h_w >> 31) != 0u;
+    const unsigned s0_cnt = is_part ? (h_z & 0xFFFFu) : h_z;
+    const unsigned n_seg = is_part ? 1u : h_w;
+    const unsigned n_parts = h_z >> 16, sidx = h_w & 0x7FFFFFFFu;
+    const long long tpos = (long long)tile * 64 + lane;
+    const bool active = tpos < C;
+    LT_TRACE_MARK(2, tile, 0);
+    long long nb0 = 0;
+    int n_nb = 0;
+    unsigned own_rec = 0;
+    if (active) {
+      const unsigned nbw = __float_as_uint(o3.z);
+      nb0 = (long long)(nbw >> 8);
+      n_nb = (int)(nbw & 0xFFu);
+      own_rec = __float_as_uint(o3.w);
+    }
+    lrec[lane] = own_rec;
+    const long long wave_nb0 = (long long)__builtin_amdgcn_readfirstlane((int)nb0);  // nb_off < 2^24
+    if (lane < __builtin_amdgcn_readfirstlane(n_nb)) ordl[lane] = a.blk_order[wave_nb0 + lane];
+    for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
+    wave_lds_sync();
+    LT_TRACE_MARK(2, tile, 1);
+    uint2 pr = pr0;
+    bool claimed = false;
+    for (unsigned sg = 0; sg < n_seg; ++sg) {
+      unsigned base = s0_base, cnt = s0_cnt;
+      if (sg > 0) {
+        const uint2 m = pl.tile_more[(size_t)tile * kMaxMoreSegs + (sg - 1)];
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)m.x);
+        cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)m.y);
+        if ((unsigned)lane < cnt) pr = pl.pairs[(size_t)base + lane];
+      }
+      for (unsigned q0 = 0; q0 < cnt; q0 += 64) {
+        const bool last_round = sg + 1 == n_seg && q0 + 64 >= cnt;
+        if (last_round) {  // claim the next tile (see k_score3)
+          claimed = true;
+          if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+        }
+        const uint2 cur = pr;
+        if (q0 + 64 + (unsigned)lane < cnt) pr = pl.pairs[(size_t)base + q0 + 64 + lane];  // the next round's pairs
+        if (q0 + (unsigned)lane < cnt) {
+          const int il = (int)(cur.y & 63u);
+          const CRec &ci = a.cand[lrec[il]];
+          const CRec &cj = a.cand[cur.x];
+          const int nbs_j = cj.nb_slot;
+          const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
+                                       mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
+                                       mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
+                                       mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg,
+                                       a.cams[(int)((unsigned)nbs_j >> 8)]);
+          if (sc > 0.0) atomicMax(&S[(nbs_j & 0xFF) * 64 + il], (unsigned long long)__double_as_longlong(sc));
+        }
+      }
+      n_eval_total += cnt;
+    }
+    if (!claimed && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);  // (a tile listed without pairs: an overflowed run)
+    wave_lds_sync();
+    LT_TRACE_MARK(2, tile, 2);
+    bool do_sums = true;
+    if (is_part) {
+      // this part's maxima into the tile's table in HBM (scores are non-negative doubles: their bit patterns order like
+      // the values); the wave that finishes the tile's LAST part reads the combined table back and does the sums
+      unsigned long long *gS = pl.split_S + (size_t)sidx * (size_t)a.max_nb * 64;
+      // No fences (a release / acquire fence at device scope writes back / invalidates the XCD's whole L2 -- measured:
+      // the kernel 80 -> 193 us): every access to the shared table and the counter is a device-scope atomic RMW, which is
+      // performed at the memory side for all XCDs; the maxima RETURN their old value, so waiting for the returns
+      // (acc feeds the counter's operand) orders them before the count.
+      unsigned long long acc = 0ull;
+      for (int k = 0; k < a.max_nb; ++k) {
+        const unsigned long long v = S[k * 64 + lane];
+        if (v) acc |= __hip_atomic_fetch_max(&gS[k * 64 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const unsigned dep = (unsigned)(__ballot(acc == 0xFFFFFFFFFFFFFFFFull) != 0ull);  // always 0 (a score is never NaN-all-ones)
+      unsigned old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(&pl.split_done[sidx], 1u + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+      do_sums = old + 1u == n_parts;
+      if (do_sums) {
+        for (int k = 0; k < a.max_nb; ++k)
+          S[k * 64 + lane] = __hip_atomic_fetch_or(&gS[k * 64 + lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (active && do_sums) {
+      double sum = 0.0;
+      const bool own = nb0 == wave_nb0;
+      for (int r = 0; r < n_nb; ++r) {
+        const int k = own ? ordl[r] : a.blk_order[nb0 + r];
+        sum += __longlong_as_double((long long)S[k * 64 + lane]);
+      }
+      a.score[tpos] = sum;
+    }
+    LT_TRACE_MARK(2, tile, 3);
+    wave_lds_sync();  // the tables are reused by the next tile
+    hdr = resolve();
+    if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
+  }
+  if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
+}
+
 #ifdef LT_TRACE
 int score_read_trace(unsigned long long *host, size_t n) {  // slices 2 and 3 of the trace array
   if (n < 4 * 4 * 65536) return -1;
@@ -1203,6 +1334,8 @@ size_t score3_lds_bytes(int max_nb, bool f32) {
   return ((base + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
 }
 size_t cand_meta_bytes() { return sizeof(CandMeta); }
+int score_pair_regions() { return kPairRegions + 1; }  // + the split-tile counter (128 bytes each)
+int score_tile_more_segs() { return kMaxMoreSegs; }
 int score3_tile_buckets() { return kTileBuckets * kTileQueues; }  // counters (128 B apart) / lists: one per (queue, class)
 // (A two-kernel form -- light sweep writing per-tile pair lists, then a dense evaluation kernel -- was
 // measured: the sweep alone takes 53 us, but the evaluation does not get cheaper and the two phases no
@@ -1211,12 +1344,14 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    void *meta, const CRec *cand, const int *node_img, const long long *nb_off,
                    const int *blk_order, const Cam *cams, double *score, unsigned long long *pair_counter,
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
-                   bool f32, unsigned *perm, void *rng, bool perm_is_placement, const unsigned *tile_order,
-                   unsigned *bucket_cnt, unsigned *bucket_list, unsigned bucket_cap, const unsigned *place,
-                   unsigned *rec, const float *st_z, int *err_flag, void *split_pairs, unsigned *split_tile_head,
-                   unsigned *split_counters, unsigned split_region_cap, void *split_tile_lohi) {
+                   bool f32, unsigned *perm, void *rng, bool perm_is_placement, unsigned *bucket_cnt,
+                   unsigned *bucket_list, unsigned bucket_cap, const unsigned *place, unsigned *rec, const float *st_z,
+                   int *err_flag, const SRec *srec, void *pair_list, unsigned *pair_region_ctr, unsigned pair_region_cap,
+                   void *tile_more, void *split_S, unsigned *split_done, unsigned split_cap) {
   // place / rec: depth-sorted sweep over STAGED records (one-pass exhaustive mode): place[natural position] = record,
   // rec (scratch, one word per candidate) receives the record of every sorted position
+  // srec: the sweep records k_place wrote at the candidates' final positions (matched mode, permutation placement):
+  // k_score_rec instead of k_score3, no CandMeta records
   if (C <= 0) return;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -1227,22 +1362,53 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   }
   // C: the candidate count or an upper bound of it (the kernels read the exact count from tri_off[G])
   const long long n_tiles = (C + 63) / 64;
-  hipLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st, G,
-                     cand_node, tri_off, node_img, nb_off, reinterpret_cast<CandMeta *>(meta), draw, bucket_cnt, bucket_list,
-                     bucket_cap, split_pairs ? split_counters : nullptr,
-                     split_pairs ? reinterpret_cast<uint2 *>(split_tile_lohi) : nullptr);
+  const bool use_rec = srec != nullptr && f32 && perm_is_placement;
+  // (the two-kernel form needs no prologue pass: k_sweep_rec lists the tiles itself and resets the draw counters)
+  if (!(use_rec && pair_list && bucket_cnt))
+    hipLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st, G,
+                       cand_node, tri_off, node_img, nb_off, use_rec ? nullptr : reinterpret_cast<CandMeta *>(meta), draw,
+                       bucket_cnt, bucket_list, bucket_cap);
   Score3Args a;
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand;
   a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
   a.draw = draw;
   a.perm = perm; a.rng = reinterpret_cast<const uint2 *>(rng);
   a.spos = nullptr;
-  a.tile_order = tile_order;
   a.bucket_cnt = bucket_cnt; a.bucket_list = bucket_list; a.bucket_cap = bucket_cap;
   a.max_nb = max_nb;
   a.err_flag = err_flag;
-  a.tile_lohi = reinterpret_cast<const uint2 *>(split_tile_lohi);
+  a.srec = srec;
   if (ev_before) (void)hipEventRecord(ev_before, st);
+  a.bucket_cnt_w = bucket_cnt; a.bucket_list_w = bucket_list;
+  if (use_rec && pair_list && bucket_cnt) {
+    // two kernels: sweep -> pair list + tiles listed by their exact pair count; dense rounds, maxima and sums
+    PairList pl;
+    pl.pairs = reinterpret_cast<uint2 *>(pair_list); pl.region_ctr = pair_region_ctr; pl.region_cap = pair_region_cap;
+    pl.tile_more = reinterpret_cast<uint2 *>(tile_more);
+    pl.split_S = reinterpret_cast<unsigned long long *>(split_S); pl.split_done = split_done; pl.split_cap = split_cap;
+    pl.split_ctr = pair_region_ctr + kPairRegions * 32;  // the counter behind the region counters
+    const size_t lds_sw = sweep_rec_lds_bytes();
+    const size_t lds = dense_rec_lds_bytes(max_nb);
+    // persistent grids: what is resident at once (registers and LDS; the occupancy API counts both)
+    static int occ_sw = 0, occ_dn = 0, occ_nb = -1;
+    if (occ_sw == 0 || occ_nb != max_nb) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_sw, k_sweep_rec, 64, lds_sw) != hipSuccess || occ_sw <= 0) occ_sw = 8;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_dn, k_dense_rec, 64, lds) != hipSuccess || occ_dn <= 0) occ_dn = 8;
+      if (const char *e = getenv("LT_SWEEP_RESIDENT")) occ_sw = std::max(1, atoi(e));
+      if (const char *e = getenv("LT_DENSE_RESIDENT")) occ_dn = std::max(1, atoi(e));
+      occ_nb = max_nb;
+      (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_sweep_rec, dim3((unsigned)std::min<long long>(n_tiles, (long long)occ_sw * n_cu)), dim3(64), lds_sw, st, a, cfg, pl);
+    hipLaunchKernelGGL(k_dense_rec, dim3((unsigned)std::min<long long>(n_tiles, (long long)occ_dn * n_cu)), dim3(64), lds, st, a, cfg, pl);
+    return;
+  }
+  if (use_rec) {
+    const size_t lds = score_rec_lds_bytes(max_nb);
+    const long long per_cu = std::max<long long>(1, std::min<long long>(LT_SCORE_RESIDENT, (long long)(160 * 1024 / lds)));
+    hipLaunchKernelGGL(k_score_rec, dim3((unsigned)std::min<long long>(n_tiles, per_cu * n_cu)), dim3(64), lds, st, a, cfg);
+    return;
+  }
   const bool sorted = perm != nullptr && f32 && !perm_is_placement;
   if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
     hipLaunchKernelGGL(k_depth_order, dim3(nblk2(G, 4)), dim3(256), 0, st, G, tri_off, cand,
@@ -1251,34 +1417,6 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   if (sorted && place) {
     a.perm = rec;
     a.spos = perm;
-  }
-  // LT_SCORE_SPLIT: the natural order (no depth sort) through the three-kernel form k_sweep6 / k_eval6 / k_reduce6
-  // (measured: not faster than the fused kernel; kept selectable, same results)
-  if (f32 && !sorted && max_nb <= 255 && split_pairs) {
-    Split6 sp;
-    sp.pairs = reinterpret_cast<PairRec6 *>(split_pairs);
-    sp.tile_head = reinterpret_cast<uint2 *>(split_tile_head); sp.counters = split_counters; sp.region_cap = split_region_cap;
-    // resident waves of the three kernels (occupancy query once per process; the grids are persistent)
-    static int occ_sweep = 0, occ_eval = 0, occ_red = 0;
-    const size_t lds_sw = (size_t)(kWin4 + 4) * 32 + (size_t)kWin4 * 8 + (size_t)kWin4 * 4 + (size_t)(kQ4 + 64) * 2;
-    const size_t lds_red = (size_t)4 * max_nb * 64 * 8;
-    if (occ_sweep == 0) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_sweep, k_sweep6<true>, 64, lds_sw) != hipSuccess || occ_sweep <= 0) occ_sweep = 8;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_eval, k_eval6, 256, 0) != hipSuccess || occ_eval <= 0) occ_eval = 2;
-      occ_sweep = std::min(occ_sweep, (int)LT_SWEEP6_RESIDENT);  // (the API counts LDS and registers; 64-thread workgroups)
-      if (const char *e = getenv("LT_SWEEP6_RESIDENT")) occ_sweep = std::max(1, atoi(e));
-      if (const char *e = getenv("LT_EVAL6_RESIDENT")) occ_eval = std::max(1, atoi(e));
-    }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_red, k_reduce6<true>, 256, lds_red) != hipSuccess || occ_red <= 0) occ_red = 1;
-    const dim3 g_sw((unsigned)std::min<long long>(n_tiles, (long long)occ_sweep * n_cu));
-    const dim3 g_ev((unsigned)((long long)occ_eval * n_cu));
-    const dim3 g_rd((unsigned)std::min<long long>((n_tiles + 3) / 4, (long long)occ_red * n_cu));
-    if (perm_is_placement) hipLaunchKernelGGL((k_sweep6<true>), g_sw, dim3(64), lds_sw, st, a, sp, scaleinv_guard2);
-    else hipLaunchKernelGGL((k_sweep6<false>), g_sw, dim3(64), lds_sw, st, a, sp, scaleinv_guard2);
-    hipLaunchKernelGGL(k_eval6, g_ev, dim3(256), 0, st, a, sp, cfg);
-    if (perm_is_placement) hipLaunchKernelGGL((k_reduce6<true>), g_rd, dim3(256), lds_red, st, a, sp);
-    else hipLaunchKernelGGL((k_reduce6<false>), g_rd, dim3(256), lds_red, st, a, sp);
-    return;
   }
   // persistent grid: as many single-wave workgroups as fit at once (LDS; registers allow LT_SCORE_RESIDENT per CU)
   const size_t lds = score3_lds_bytes(max_nb, f32);

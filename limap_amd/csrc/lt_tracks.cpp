@@ -6,13 +6,16 @@
 // CheckSensitivity, FilterTracksBySensitivity, FilterTracksByOverlap), merging/merging.cc:513-644
 // (RemergeLineTracks), merging/merging.py:24-42 (the fixed-point loop).
 //
-// The per-support tests are a few 10^3..10^6 independent projections: they run on the host with
-// OpenMP through the same lt_geom.h code as the kernels.  The all-pairs check_connection of the
+// The per-support tests are a few 10^3..10^6 independent projections: they run on the host, shared out
+// over the persistent thread team of lt_pool.h, through the same lt_geom.h code as the kernels.  The all-pairs check_connection of the
 // remerge (O(T^2), the next hotspot on big scenes) runs on the GPU (k_track_connect); the union-find
 // over its edges and the aggregation stay on the host like the rest of the tail.
 
 #include "lt_ctx.h"
+#include "lt_pool.h"
 #include "lt_tail.h"
+
+#include <atomic>
 
 #include <algorithm>
 #include <cmath>
@@ -49,6 +52,10 @@ void reaggregate(TrackFull &t, int num_outliers) {
 
 double multiplier(double score_th) { return 1.0 / std::sqrt(-std::log(score_th) * 2.0); }
 
+// Tracks per piece of the per-track loops below, shared out over the persistent host team (lt_pool.h) -- not OpenMP
+// regions: a team that has gone to sleep costs 0.25-0.55 ms to start on the GPU box's host, five times per chain.
+constexpr long long kTrackGrain = 8;
+
 }  // namespace
 
 struct lt_trackset {
@@ -58,6 +65,7 @@ struct lt_trackset {
 extern "C" {
 
 lt_trackset *lt_ts_from_ctx(lt_ctx *ctx) {
+  lt_host::SpinPool::get(lt_host::row_workers()).wake();  // the filters follow: the team leaves its sleep meanwhile
   lt_trackset *ts = new lt_trackset();
   const lt_host::TrackStore &src = ctx->tracks;
   ts->tracks.resize(src.size());
@@ -81,6 +89,7 @@ lt_trackset *lt_ts_from_ctx(lt_ctx *ctx) {
 lt_trackset *lt_ts_create(int64_t T, const double *line7, const uint8_t *active, const int64_t *off,
                           const int32_t *img, const int32_t *lid, const int32_t *nid, const double *score,
                           const double *line2d4, const double *line3d10) {
+  lt_host::SpinPool::get(lt_host::row_workers()).wake();
   lt_trackset *ts = new lt_trackset();
   ts->tracks.resize((size_t)T);
   for (int64_t t = 0; t < T; ++t) {
@@ -149,8 +158,8 @@ int lt_ts_filter_by_reprojection(lt_ctx *ctx, lt_trackset *ts, double th_angular
     }
   std::vector<TrackFull> out((size_t)nT);
   std::vector<char> keep((size_t)nT, 0);
-#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 8)
-  for (long long ti = 0; ti < nT; ++ti) {
+  lt_host::pool_for(nT, kTrackGrain, [&](long long t0_, long long t1_) {
+  for (long long ti = t0_; ti < t1_; ++ti) {
     const TrackFull &t = ts->tracks[ti];
     TrackFull nt;
     for (const Member &mm : t.m) {
@@ -170,6 +179,7 @@ int lt_ts_filter_by_reprojection(lt_ctx *ctx, lt_trackset *ts, double th_angular
     out[ti] = std::move(nt);
     keep[ti] = 1;
   }
+  });
   std::vector<TrackFull> packed;
   for (long long ti = 0; ti < nT; ++ti)
     if (keep[ti]) packed.push_back(std::move(out[ti]));
@@ -182,9 +192,9 @@ int lt_ts_filter_by_sensitivity(lt_ctx *ctx, lt_trackset *ts, double th_angular3
   if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "filter before Init");
   const long long nT = (long long)ts->tracks.size();
   std::vector<char> keep((size_t)nT, 0);
-  int bad = 0;
-#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 8) reduction(| : bad)
-  for (long long ti = 0; ti < nT; ++ti) {
+  std::atomic<int> bad{0};
+  lt_host::pool_for(nT, kTrackGrain, [&](long long t0_, long long t1_) {
+  for (long long ti = t0_; ti < t1_; ++ti) {
     const TrackFull &t = ts->tracks[ti];
     d3 s = mk3(t.line[0], t.line[1], t.line[2]), e = mk3(t.line[3], t.line[4], t.line[5]);
     d3 dir3 = unit(sub(e, s));
@@ -192,7 +202,7 @@ int lt_ts_filter_by_sensitivity(lt_ctx *ctx, lt_trackset *ts, double th_angular3
     for (const Member &mm : t.m) {
       auto it = ctx->id2idx.find(mm.img_id);
       if (it == ctx->id2idx.end()) {
-        bad = 1;
+        bad.store(1, std::memory_order_relaxed);
         continue;
       }
       const Cam &c = ctx->h_cams[it->second];
@@ -203,7 +213,8 @@ int lt_ts_filter_by_sensitivity(lt_ctx *ctx, lt_trackset *ts, double th_angular3
     }
     keep[ti] = (int)imgs.size() >= min_supports;
   }
-  if (bad) return fail(ctx, LT_ERR_ARGUMENT, "track references an unknown image id");
+  });
+  if (bad.load()) return fail(ctx, LT_ERR_ARGUMENT, "track references an unknown image id");
   std::vector<TrackFull> packed;
   for (long long ti = 0; ti < nT; ++ti)
     if (keep[ti]) packed.push_back(std::move(ts->tracks[ti]));
@@ -216,15 +227,15 @@ int lt_ts_filter_by_overlap(lt_ctx *ctx, lt_trackset *ts, double th_overlap, int
   if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "filter before Init");
   const long long nT = (long long)ts->tracks.size();
   std::vector<char> keep((size_t)nT, 0);
-  int bad = 0;
-#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 8) reduction(| : bad)
-  for (long long ti = 0; ti < nT; ++ti) {
+  std::atomic<int> bad{0};
+  lt_host::pool_for(nT, kTrackGrain, [&](long long t0_, long long t1_) {
+  for (long long ti = t0_; ti < t1_; ++ti) {
     const TrackFull &t = ts->tracks[ti];
     std::set<int> imgs;
     for (const Member &mm : t.m) {
       auto it = ctx->id2idx.find(mm.img_id);
       if (it == ctx->id2idx.end()) {
-        bad = 1;
+        bad.store(1, std::memory_order_relaxed);
         continue;
       }
       const Cam &c = ctx->h_cams[it->second];
@@ -234,7 +245,8 @@ int lt_ts_filter_by_overlap(lt_ctx *ctx, lt_trackset *ts, double th_overlap, int
     }
     keep[ti] = (int)imgs.size() >= min_supports;
   }
-  if (bad) return fail(ctx, LT_ERR_ARGUMENT, "track references an unknown image id");
+  });
+  if (bad.load()) return fail(ctx, LT_ERR_ARGUMENT, "track references an unknown image id");
   std::vector<TrackFull> packed;
   for (long long ti = 0; ti < nT; ++ti)
     if (keep[ti]) packed.push_back(std::move(ts->tracks[ti]));
@@ -333,11 +345,14 @@ int lt_ts_remerge_once(lt_ctx *ctx, lt_trackset *ts, const lt_config *linker_cfg
     counter[labels[t]]++;
     g.m.insert(g.m.end(), ts->tracks[t].m.begin(), ts->tracks[t].m.end());
   }
-#pragma omp parallel for num_threads(lt::host_threads()) schedule(dynamic, 8)
-  for (long gi = 0; gi < n_groups; ++gi) {
-    reaggregate(out[gi], num_outliers);
-    out[gi].active = counter[gi] != 1;
-  }
+  lt_host::pool_for((long long)n_groups, kTrackGrain, [&](long long g0_, long long g1_) {
+    for (long long gi = g0_; gi < g1_; ++gi) {
+      // a group of one keeps its track as it is in the reference only as far as `active` goes: the line is
+      // re-aggregated either way (merging.cc:629-640)
+      reaggregate(out[gi], num_outliers);
+      out[gi].active = counter[gi] != 1;
+    }
+  });
   ts->tracks.swap(out);
   return LT_OK;
 }

@@ -39,7 +39,7 @@ def _same(a, b):
 def clean_env():
     keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES",
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
-            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_SCORE_SPLIT", "LT_TEST_SPLIT_PAIR_CAP")
+            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_SCORE_OLD", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_TEST_PAIR_CAP")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -419,27 +419,47 @@ def test_per_kernel_event_levels(gpu_lib, clean_env):
         assert t["gen"] > 0 and t["score"] > 0 and t["run"] >= t["gen"] + t["score"]
 
 
-@pytest.mark.parametrize("exhaustive", [False, True])
-def test_three_kernel_scoring_equals_fused(gpu_lib, clean_env, exhaustive):
-    """LT_SCORE_SPLIT: k_sweep6 (sweep -> global pair list) + k_eval6 (flat evaluation) + k_reduce6 (per-tile maxima and
-    ordered sums) must give the bits of the fused k_score3 -- same pairs up to the sweep's conservative guards (the split
-    sweep has no cosine guard: a few per cent more pairs reach pair_score, which gates them to 0), same pair_score,
-    same maxima and sums.  Exhaustive mode runs it on the unsorted order.  A pair list that is too small (forced
-    here) raises the device flag and the run is repeated with the fused kernel."""
-    sc = syn.make_scene(n_views=14, n_segs=140, n_neighbors=6, seed=77)
+@pytest.mark.parametrize("topk,n_nb", [(10, 6), (60, 13)])
+def test_sweep_record_scoring_equals_permutation_scoring(gpu_lib, clean_env, topk, n_nb):
+    """Scoring on sweep records (round 4: k_place writes a 64-byte single-precision record per candidate at its final
+    position; k_sweep_rec streams the windows and lists the pairs that pass the conservative guards, k_dense_rec evaluates
+    them tile by tile, heaviest tile first) must give the bits of k_score3 through the permutation (LT_SCORE_OLD): same
+    pair_score, same maxima and ordered sums; only WHICH pairs reach the exact evaluation may differ by the guards'
+    rounding (another origin, radii rounded up).  Also: the fused kernel on the same records (LT_SCORE_FUSED), a pair list
+    that is too small (the run is repeated with the fused kernel), the double-precision sweep, tiles in natural order, no
+    guards at all.  The second scene has nodes of up to 106 candidates: windows beyond one LDS chunk (128 entries)."""
+    sc = syn.make_scene(n_views=14, n_segs=140, n_neighbors=n_nb, seed=77, topk=topk)
     cfg = syn.default_triangulation_cfg(debug_mode=True)
-    if exhaustive:
-        os.environ["LT_TEST_SCORE_UNSORTED"] = "1"
-    base = _results(run_product(sc, cfg, exhaustive=exhaustive))
-    assert base[5]["candidates"] > 1000
-    os.environ["LT_SCORE_SPLIT"] = "1"
-    split = _results(run_product(sc, cfg, exhaustive=exhaustive))
-    _same(base, split)
-    assert base[4]["pairs_eval"] <= split[4]["pairs_eval"] <= 1.25 * base[4]["pairs_eval"] + 64
-    os.environ["LT_TEST_SPLIT_PAIR_CAP"] = "64"
-    overflow = _results(run_product(sc, cfg, exhaustive=exhaustive))
-    _same(base, overflow)
-    assert overflow[4]["pairs_eval"] == base[4]["pairs_eval"]  # the repeated run used the fused kernel
+    new = _results(run_product(sc, cfg, topk=topk))
+    assert new[5]["candidates"] > 1000
+    if topk > 10:  # (checked with the oracle: 79 of the 624 tiles of this scene have windows of 129-197 entries)
+        assert np.diff(new[0]["off"]).max() > 100, "the scene is meant to have windows beyond one chunk"
+    os.environ["LT_SCORE_OLD"] = "1"
+    old = _results(run_product(sc, cfg, topk=topk))
+    _same(new, old)
+    assert 0.8 * old[4]["pairs_eval"] <= new[4]["pairs_eval"] <= 1.25 * old[4]["pairs_eval"] + 64
+    del os.environ["LT_SCORE_OLD"]
+    os.environ["LT_SCORE_FUSED"] = "1"
+    fused = _results(run_product(sc, cfg, topk=topk))
+    _same(new, fused)
+    assert fused[4]["pairs_eval"] == new[4]["pairs_eval"]  # the same sweep on the same records
+    del os.environ["LT_SCORE_FUSED"]
+    os.environ["LT_TEST_PAIR_CAP"] = "64"          # one pair per region: device flag 7, repeated with the fused kernel
+    over = _results(run_product(sc, cfg, topk=topk))
+    _same(new, over)
+    del os.environ["LT_TEST_PAIR_CAP"]
+    os.environ["LT_TEST_SCORE_F64"] = "1"
+    f64 = _results(run_product(sc, cfg, topk=topk))
+    _same(new, f64)
+    del os.environ["LT_TEST_SCORE_F64"]
+    os.environ["LT_TEST_NO_TILE_CLASSES"] = "1"   # fused kernel, tiles in natural order: window bounds from the lanes' records
+    nat = _results(run_product(sc, cfg, topk=topk))
+    _same(new, nat)
+    del os.environ["LT_TEST_NO_TILE_CLASSES"]
+    os.environ["LT_TEST_NO_SCORE_GUARDS"] = "1"   # every pair of a node evaluated exactly (segments beyond the first)
+    allp = _results(run_product(sc, cfg, topk=topk))
+    _same(new, allp)
+    assert allp[4]["pairs_eval"] > new[4]["pairs_eval"]
 
 
 def test_second_batch_after_compute_tracks_device_and_host_tail(gpu_lib, oracle, clean_env):
