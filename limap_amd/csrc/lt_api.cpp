@@ -548,7 +548,6 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_keys, &ctx->d_rows, &ctx->d_row_blk, &ctx->d_skeys, &ctx->d_srows, &ctx->d_sort_tmp,
                     &ctx->d_conn_off, &ctx->d_st_c, &ctx->d_st_l, &ctx->d_flags, &ctx->d_pos, &ctx->d_scan_tmp,
                     &ctx->d_item_off, &ctx->d_masks, &ctx->d_mask_cnt, &ctx->d_mask_pos, &ctx->d_cand, &ctx->d_hcand, &ctx->d_hlite,
-                    &ctx->d_srec, &ctx->d_pairlist, &ctx->d_tile_more, &ctx->d_split_S, &ctx->d_split_done,
                     &ctx->d_rm_line, &ctx->d_rm_act, &ctx->d_rm_edges, &ctx->d_rm_cnt,
                     &ctx->d_lite, &ctx->d_tri_off, &ctx->d_score, &ctx->d_best_idx, &ctx->d_edge_flag,
                     &ctx->d_nvalid, &ctx->d_edge_off, &ctx->d_edges, &ctx->d_best_c, &ctx->d_best_score,

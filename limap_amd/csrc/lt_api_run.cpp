@@ -197,15 +197,6 @@ int finish_run(lt_ctx *ctx) {
     ctx->ex_two_pass = false;
   }
   if (derr == 4) return fail(ctx, LT_ERR_RUNTIME, "internal: the scan of the node counts did not complete");
-  if (derr == 7) {
-    // the pair list of the two-kernel scoring did not hold: repeat the run with the fused kernel (same results)
-    if (ctx->score_fused_only) return fail(ctx, LT_ERR_RUNTIME, "internal: pair list overflow with the fused scoring kernel");
-    ctx->score_fused_only = true;
-    if (ctx->in_run_async) return LT_OK;
-    int rc2 = lt_run_device_async(ctx);
-    if (!rc2) rc2 = finish_run(ctx);
-    return rc2;
-  }
   if (derr == 3)
     return fail(ctx, LT_ERR_RUNTIME, "the one-point proposal supports at most 250 shared points per connection");
   if (derr == 2)
@@ -271,14 +262,10 @@ int lt_run_device_async(lt_ctx *ctx) {
   const ScoreCfg scfg = make_score(ctx);
   // LT_TEST_SCORE_F64: the sweep's early exit in double precision (the default is the bounded single-precision form)
   const bool score_f32 = !getenv("LT_TEST_SCORE_F64");
-  // conservative form of the scale-invariant endpoint gate (see k_score3): radius factor and its square
+  // conservative square of the scale-invariant endpoint gate (see k_score3)
   const bool guards_on = scfg.l3.th_scaleinv > 0.0 && scfg.l3.score_th > 0.0 && scfg.l3.score_th < 1.0 &&
                          !getenv("LT_TEST_NO_SCORE_GUARDS");
-  const double guard1 = guards_on ? scfg.l3.th_scaleinv * (1.0 + 1e-6) : 1e150;  // x depth = an SRec's guard radius
-  const double guard2 = guards_on ? guard1 * guard1 : 1e300;
-  // matched mode, sort-free placement, single-precision sweep: k_place writes sweep records, k_score_rec reads them
-  // (LT_SCORE_OLD: the round-3 path -- k_score3 through the permutation -- kept for the equality test)
-  bool srec_on = false;
+  const double guard2 = guards_on ? (scfg.l3.th_scaleinv * (1.0 + 1e-6)) * (scfg.l3.th_scaleinv * (1.0 + 1e-6)) : 1e300;
   ENSURE(ctx, ctx->d_err, sizeof(int));
   ENSURE(ctx, ctx->d_pair_counter, 8);
   ENSURE(ctx, ctx->d_result3, 32);
@@ -289,7 +276,7 @@ int lt_run_device_async(lt_ctx *ctx) {
   // (+ the tile cost-class counters of k_cand_meta / k_score3 behind the scan's words: zeroed by the same kernel)
   const int n_status_scan = (int)((G + 1 + 255) / 256) + 1;
   // + the staging counters of the one-pass exhaustive mode; all counters 128 bytes apart
-  const int n_status = n_status_scan + score3_tile_buckets() * 16 + ex_regions() * 16 + score_pair_regions() * 16;
+  const int n_status = n_status_scan + score3_tile_buckets() * 16 + ex_regions() * 16;
   ENSURE(ctx, ctx->d_scan_status, 8 * (size_t)n_status);
   launch_build_pairs(st, ctx->n_blk, ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_cams.as<Cam>(),
                      ctx->d_pairs.as<PairRec>(), ctx->d_err.as<int>(),
@@ -385,7 +372,7 @@ int lt_run_device_async(lt_ctx *ctx) {
       // otherwise (or with LT_TEST_SYNC_COUNT) one 8-byte copy + stream sync fetches the exact count.
       const long long bound = P * (long long)mult;
       constexpr long long kCountFreeBytes = 8ll << 30;
-      const long long per_cand = (long long)(sizeof(CRec) + 8 + 8 + 4 + 4) + (long long)cand_meta_bytes() + (long long)sizeof(SRec);
+      const long long per_cand = (long long)(sizeof(CRec) + 8 + 8 + 4 + 4) + (long long)cand_meta_bytes();
       if (ctx->h_pinned && bound * per_cand <= kCountFreeBytes && !getenv("LT_TEST_SYNC_COUNT")) {
         C_known = -1;
         C_bound = bound;
@@ -411,14 +398,13 @@ int lt_run_device_async(lt_ctx *ctx) {
     const bool perm_mode = fast && !getenv("LT_TEST_PLACE_COPY");
     ctx->perm_mode = perm_mode;
     ctx->compact_valid = !perm_mode;
-    srec_on = perm_mode && score_f32 && !getenv("LT_SCORE_OLD");
     if (C_known < 0) {
       // the bound is generous: if the device cannot give that much, fetch the exact count after all
       const size_t Bn = (size_t)std::max<long long>(C_bound, 1);
       const bool got = (perm_mode ? ctx->d_place_perm.ensure(4 * Bn)
                                   : (ctx->d_cand.ensure(sizeof(CRec) * Bn) && ctx->d_lite.ensure(sizeof(double) * Bn))) &&
                        ctx->d_score.ensure(8 * Bn) && ctx->d_edge_flag.ensure(4 * Bn) && ctx->d_cand_node.ensure(4 * Bn) &&
-                       (srec_on ? ctx->d_srec.ensure(sizeof(SRec) * Bn) : ctx->d_cand_meta.ensure(cand_meta_bytes() * Bn));
+                       ctx->d_cand_meta.ensure(cand_meta_bytes() * Bn);
       if (!got) {
         (void)hipGetLastError();
         HIPCHK(ctx, hipMemcpyAsync(hC, ctx->d_tri_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
@@ -434,7 +420,6 @@ int lt_run_device_async(lt_ctx *ctx) {
       ENSURE(ctx, ctx->d_cand, sizeof(CRec) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(double) * Cn);
     }
     ENSURE(ctx, ctx->d_score, 8 * Cn); ENSURE(ctx, ctx->d_edge_flag, 4 * Cn); ENSURE(ctx, ctx->d_cand_node, 4 * Cn);
-    if (srec_on) ENSURE(ctx, ctx->d_srec, sizeof(SRec) * Cn);
     ctx->cand_cap = (long long)Cn;
     if (fast) {
       launch_place(st, ctx->n_blk, ctx->max_rows, ctx->d_m_off.as<long long>(), ctx->d_blk_img.as<int>(),
@@ -442,8 +427,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                    ctx->d_base_bl.as<unsigned>(), ctx->d_wave_count.as<unsigned>(), ctx->d_tri_off.as<long long>(),
                    ctx->d_st_c.as<CRec>(), ctx->d_st_l.as<double>(), ctx->d_st_key.as<unsigned>(),
                    ctx->d_cand.as<CRec>(), ctx->d_lite.as<double>(), ctx->d_cand_node.as<unsigned>(), mult,
-                   perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr, srec_on ? ctx->d_srec.as<SRec>() : nullptr,
-                   ctx->d_cams.as<Cam>(), ctx->d_ntris_u.as<unsigned>(), ctx->d_nb_off.as<long long>(), guard1);
+                   perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
     } else {
       ENSURE(ctx, ctx->d_keys, 4 * Cn); ENSURE(ctx, ctx->d_rows, 4 * Cn);
       ENSURE(ctx, ctx->d_skeys, 4 * Cn); ENSURE(ctx, ctx->d_srows, 4 * Cn);
@@ -646,19 +630,18 @@ int lt_run_device_async(lt_ctx *ctx) {
   }
 
   // ---- scoring ----
-  if (std::max(score3_lds_bytes(ctx->max_nb, score_f32), score_rec_lds_bytes(ctx->max_nb)) > 160 * 1024)
+  if (score3_lds_bytes(ctx->max_nb, score_f32) > 160 * 1024)
     return fail(ctx, LT_ERR_ARGUMENT, "too many neighbours for the scoring kernel's LDS budget");
   {
     if (ctx->h_nb_off[ctx->n_img] >= (1ll << 24))
       return fail(ctx, LT_ERR_ARGUMENT, "too many (image, neighbour) blocks in one batch (>= 2^24)");
-    if (!srec_on) ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_bound, 1));
+    ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_bound, 1));
     ENSURE(ctx, ctx->d_tile_order, 64 * 128);  // the tile draw counters of k_score3 (8 x 128 B)
     // tiles listed by cost class (LT_TEST_NO_TILE_CLASSES: natural tile order)
     // (matched mode only: the wide nodes of the exhaustive mode put every tile into the top class, whose one counter
     // per queue then serialises ~4e4 appends -- k_cand_meta 0.11 -> 0.50 ms -- for an order that changes nothing)
     const bool tile_classes = !getenv("LT_TEST_NO_TILE_CLASSES") && ctx->job_mode == 1;
-    // entries of one draw queue: its tiles -- x 3 with the sweep records, where k_sweep_rec lists heavy tiles in parts
-    const unsigned tile_cap = (unsigned)((((std::max<long long>(C_bound, 1) + 63) / 64 + 7) / 8) * (srec_on ? 3 : 1));
+    const unsigned tile_cap = (unsigned)(((std::max<long long>(C_bound, 1) + 63) / 64 + 7) / 8);  // tiles of one draw queue
     if (tile_classes) ENSURE(ctx, ctx->d_tile_list, 16 * (size_t)tile_cap * (size_t)score3_tile_buckets());  // 16-byte entries
     // large nodes (exhaustive matching): depth-sorted sweep, see k_depth_order
     const bool score_sorted = score_f32 && ctx->job_mode == 2 && !getenv("LT_TEST_SCORE_UNSORTED");
@@ -669,28 +652,6 @@ int lt_run_device_async(lt_ctx *ctx) {
     // depth-sorted sweep over the staged records of the one-pass exhaustive mode: see k_depth_order
     const bool staged_sorted = score_sorted && ctx->perm_mode && ctx->job_mode == 2;
     C_run = C_bound;  // replaced by the exact count when that arrives with the error flag (finish_run)
-    // two-kernel scoring on the sweep records (k_sweep_rec -> pair list -> k_dense_rec); LT_SCORE_FUSED: the fused k_score_rec
-    unsigned pair_region_cap = 0, split_cap = 0;
-    if (srec_on && tile_classes && !ctx->score_fused_only && !getenv("LT_SCORE_FUSED")) {
-      const long long tiles_b = (std::max<long long>(C_bound, 1) + 63) / 64;
-      // capacity from the candidate bound (the bench scene has 1.2 pairs per candidate); a run that overflows it raises
-      // device flag 7 and is repeated with the fused kernel by finish_run
-      long long pc = std::min<long long>(std::max<long long>(2 * C_bound, 4ll << 20), 1ll << 31);
-      if (const char *e = getenv("LT_TEST_PAIR_CAP")) pc = std::max<long long>(64, atoll(e));  // test: force an overflow
-      const int n_reg = score_pair_regions() - 1;
-      const long long rcap = (pc + n_reg - 1) / n_reg;
-      // heavy tiles are evaluated in parts by several waves: per split tile a table of maxima in HBM (LT_SCORE_NO_SPLIT: off)
-      const size_t tab = (size_t)std::max(ctx->max_nb, 1) * 64 * 8;
-      const long long scap = getenv("LT_SCORE_NO_SPLIT") ? 0 : std::min<long long>(4096, (64ll << 20) / (long long)tab);
-      if (ctx->d_pairlist.ensure(8 * (size_t)rcap * (size_t)n_reg) &&
-          ctx->d_tile_more.ensure(8 * (size_t)tiles_b * (size_t)score_tile_more_segs()) &&
-          ctx->d_split_S.ensure(std::max<size_t>(tab * (size_t)scap, 16)) && ctx->d_split_done.ensure(4 * (size_t)std::max<long long>(scap, 1))) {
-        pair_region_cap = (unsigned)rcap;
-        split_cap = (unsigned)scap;
-      } else {
-        (void)hipGetLastError();
-      }
-    }
     launch_score3(st, C_bound, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
                   ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(), ctx->d_node_img.as<int>(),
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
@@ -703,12 +664,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                   tile_classes ? ctx->d_tile_list.as<unsigned>() : nullptr, tile_cap,
                   staged_sorted ? ctx->d_place_perm.as<unsigned>() : nullptr,
                   staged_sorted ? ctx->d_ex_rec.as<unsigned>() : nullptr,
-                  staged_sorted ? ctx->d_ex_z.as<float>() : nullptr, ctx->d_err.as<int>(),
-                  srec_on ? ctx->d_srec.as<SRec>() : nullptr, pair_region_cap ? ctx->d_pairlist.p : nullptr,
-                  (unsigned *)(ctx->d_scan_status.as<unsigned long long>() + n_status_scan + score3_tile_buckets() * 16 +
-                               ex_regions() * 16),
-                  pair_region_cap, pair_region_cap ? ctx->d_tile_more.p : nullptr, ctx->d_split_S.p,
-                  ctx->d_split_done.as<unsigned>(), split_cap);
+                  staged_sorted ? ctx->d_ex_z.as<float>() : nullptr, ctx->d_err.as<int>());
   }
   HIPCHK(ctx, hipEventRecord(ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));

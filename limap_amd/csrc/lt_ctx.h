@@ -184,9 +184,6 @@ struct lt_ctx {
   DevBuf d_keys, d_rows, d_row_blk, d_skeys, d_srows, d_sort_tmp, d_conn_off;
   DevBuf d_st_c, d_st_l, d_flags, d_pos, d_scan_tmp;
   DevBuf d_item_off, d_masks, d_mask_cnt, d_mask_pos;
-  DevBuf d_srec;  // sweep records of the scoring kernels (SRec, 64 B per candidate at its final position; k_place)
-  DevBuf d_pairlist, d_tile_more, d_split_S, d_split_done;  // k_sweep_rec -> k_dense_rec: the pairs that reach pair_score, extra segments per tile
-  bool score_fused_only = false;   // set when a run overflowed the pair list: the fused k_score_rec from then on
   DevBuf d_rm_line, d_rm_act, d_rm_edges, d_rm_cnt;  // lt_ts_remerge_once: kept across the passes of a remerge
   std::vector<unsigned long long> h_rm_edges;
   DevBuf d_hcand, d_hlite;  // split host-side view of the candidates (debug read-outs), see materialize_compact

@@ -227,21 +227,6 @@ struct CRec {  // 128 B
   int ng_line;      // line id in that neighbour image
 };
 static_assert(sizeof(CRec) == 128, "candidate record = one cache line");
-// Sweep record (matched mode): what the scoring kernel's O(n^2) sweep and its prologue need of a candidate, written by
-// the placement pass (k_place) at the candidate's FINAL position, so that a tile of k_score_rec stages its window with
-// coalesced loads -- no permutation level, no 128-byte gathers, no conversion.  Coordinates are single precision relative
-// to the camera centre of the node's image (all candidates of a node share it; their magnitude is the depth, which is
-// also the scale of the guards they are compared with).
-struct SRec {  // 64 B
-  float dx, dy, dz;  // unit direction
-  int slot;          // index of the neighbour image in the node image's list
-  float sx, ex, sy, ey, sz, ez;  // start / end, interleaved for the sweep's packed-f32 operand pairs
-  float gs, ge;      // guard radii th_scaleinv (1 + 1e-6) (depth + eps) of start / end, rounded UP (inf: no early exit)
-  unsigned off, n;   // the node's first position and candidate count
-  unsigned nb;       // (nb_off[img] << 8) | number of neighbours: where the node image's summation order starts
-  unsigned rec;      // staging slot of the candidate's CRec
-};
-static_assert(sizeof(SRec) == 64, "sweep record = half a cache line");
 struct Cand {  // 112 B
   double s[3], e[3];
   double depth[2];  // depths in the source view (view1)

@@ -49,8 +49,7 @@ void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const 
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const CRec *st_r, const double *st_unc,
-                  const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, int mult, unsigned *perm,
-                  SRec *srec, const Cam *cams, const unsigned *n_tris, const long long *nb_off, double guard);
+                  const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, int mult, unsigned *perm);
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
                       unsigned *keys_c, unsigned *src_c, int mult);
@@ -67,11 +66,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, unsigned *bucket_cnt,
                    unsigned *bucket_list, unsigned bucket_cap, const unsigned *place, unsigned *rec, const float *st_z,
-                   int *err_flag, const SRec *srec, void *pair_list, unsigned *pair_region_ctr, unsigned pair_region_cap,
-                   void *tile_more, void *split_S, unsigned *split_done, unsigned split_cap);
-size_t score_rec_lds_bytes(int max_nb);
-int score_pair_regions();
-int score_tile_more_segs();
+                   int *err_flag);
 int score3_tile_buckets();
 }
 

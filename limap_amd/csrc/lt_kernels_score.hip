@@ -1,5 +1,5 @@
 // lt_kernels_score.hip -- the scoring stage (scoreOneNode, global_line_triangulator.cc:71-116): k_cand_meta (prologue
-// records, tiles by cost class), k_depth_order (exhaustive mode) and the fused scoring kernels k_score3 / k_score_rec.
+// records, tiles by cost class), k_depth_order (exhaustive mode) and the fused scoring kernel k_score3.
 // A translation unit of its own since round 3: the stage kernels of
 // lt_kernels_v2.hip are compiled with -mllvm -disable-machine-licm (the hoisted constants cost k_tri_rows 32
 // registers and 8 % of its time), k_score3 is 2.5 % faster with the default pipeline (csrc/Makefile).
@@ -83,7 +83,7 @@ k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long
       m.off_hi = (unsigned)(off >> 32);
       m.n = (unsigned)(tri_off[g + 1] - off);
       m.nb = ((unsigned)nb0 << 8) | (unsigned)(nb_off[img + 1] - nb0);
-      if (meta) meta[i] = m;  // (k_score_rec reads the same fields from the sweep records k_place wrote)
+      meta[i] = m;
       n = m.n;
       w_lo = m.off_lo; w_hi = m.off_lo + m.n;
     }
@@ -149,8 +149,6 @@ struct Score3Args {
   unsigned bucket_cap;
   int max_nb;
   int *err_flag;  // device error flag of the run
-  const SRec *srec;  // k_score_rec / k_sweep_rec / k_dense_rec: sweep records at the candidates' final positions (k_place)
-  unsigned *bucket_cnt_w, *bucket_list_w;  // k_sweep_rec appends: the same arrays, writable
 };
 
 // Depth order of a node's candidates (large nodes: exhaustive matching gives ~450 candidates per node and
@@ -652,672 +650,6 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
 }
 
-// ---------------------------------------------------------------------------------------------
-// HOT LOOP 2 on SWEEP RECORDS (matched mode, permutation placement; round 4)
-// ---------------------------------------------------------------------------------------------
-// Same tile (64 consecutive candidates in the reference's order), same sweep, same dense evaluation and ordered sums as
-// k_score3<true, false, true>; what changed is where a tile's data comes from.  k_score3's chain per tile was
-//   draw -> class-list entry -> {CandMeta, perm (own), perm (window)} -> {CRec (own), CRec (window): 128-byte gathers,
-//   converted to single precision} -> LDS -> sweep, and per dense round queue -> perm (i, j) -> CRec (i, j):
-// three load levels in front of the first pair of a tile, two in front of every round, and ~150 record gathers per tile of
-// which the window's (mean 84 entries for 64 candidates: nodes straddle tiles) were measured at 23 us of the kernel
-// (round 3, ablation 4).  Here k_place has written one 64-byte SRec per candidate AT ITS FINAL POSITION: the lane's
-// own operands, node bounds and summation order (CandMeta's fields) and the window entries are ONE coalesced level
-// behind the class-list entry, the window is copied to LDS as it is, and a dense round finds its two CRec indices in LDS
-// (the window entry carries the staging slot), so the CRecs -- still gathered, they are what pair_score needs -- are one
-// level behind the queue.  The queue entry shrinks to 16 bits (lane | window index): the queue is drained before a
-// window chunk is replaced.
-constexpr int kRQCap = 512;
-static_assert(kWin <= 256, "8-bit window index in the queue entries");
-size_t score_rec_lds_bytes(int max_nb) {
-  const size_t base = (size_t)kWin * 64 + 64 * 4 + (size_t)kRQCap * 2;
-  return ((base + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
-}
-__global__ void __launch_bounds__(64) LT_SCORE_OCC
-k_score_rec(Score3Args a, ScoreCfg cfg) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int lane = threadIdx.x;
-  // LDS: window float4[kWin][4] (SRec as it is) | lrec[64] u32 | queue[kRQCap] u16 | ord[max_nb] i32 | S[max_nb][64] u64
-  float4 *W4 = reinterpret_cast<float4 *>(smem_raw);
-  unsigned *lrec = reinterpret_cast<unsigned *>(smem_raw + (size_t)kWin * 64);
-  unsigned short *queue = reinterpret_cast<unsigned short *>(smem_raw + (size_t)kWin * 64 + 64 * 4);
-  int *ordl = reinterpret_cast<int *>(smem_raw + (size_t)kWin * 64 + 64 * 4 + (size_t)kRQCap * 2);
-  unsigned long long *S = reinterpret_cast<unsigned long long *>(
-      smem_raw + (((size_t)kWin * 64 + 64 * 4 + (size_t)kRQCap * 2 + (size_t)a.max_nb * 4 + 15) & ~(size_t)15));
-
-  const long long C = a.tri_off[a.G];
-  const unsigned n_tiles = (unsigned)((C + 63) >> 6);
-  // persistent wave, tiles drawn through the per-XCD queues by cost class exactly as in k_score3
-  int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
-  unsigned long long n_eval_total = 0;
-  unsigned k_raw = 0;
-  if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-  unsigned cls_cnt = 0, cls_incl = 0, q_tiles = 0;
-  auto load_classes = [&]() {
-    cls_cnt = lane < kTileBuckets ? a.bucket_cnt[(q * kTileBuckets + (kTileBuckets - 1 - lane)) * 32] : 0u;
-    cls_incl = cls_cnt;
-#pragma unroll
-    for (int d = 1; d < kTileBuckets; d <<= 1) {
-      const unsigned t = (unsigned)__shfl_up((int)cls_incl, d);
-      if (lane >= d) cls_incl += t;
-    }
-    q_tiles = (unsigned)__builtin_amdgcn_readlane((int)cls_incl, kTileBuckets - 1);
-  };
-  if (a.bucket_cnt) load_classes();
-  auto resolve = [&]() -> uint4 {
-    for (;;) {
-      const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
-      if (a.bucket_cnt) {
-        if (k < q_tiles) {
-          const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
-          const int bl = __builtin_ctzll(m);
-          const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)(cls_incl - cls_cnt), bl);
-          return reinterpret_cast<const uint4 *>(
-              a.bucket_list)[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
-        }
-      } else {
-        const unsigned long long e = (unsigned long long)k * kTileQueues + (unsigned)q;
-        if (e < n_tiles) return uint4{(unsigned)e, 0u, 0u, 0u};
-      }
-      if (++tried > 4 * kTileQueues) return uint4{0xFFFFFFFFu, 0u, 0u, 0u};
-      unsigned peek = 0xFFFFFFFFu, cap_l = 0;
-      if (lane < kTileQueues) {
-        peek = __hip_atomic_load(&a.draw[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cap_l = (n_tiles + (unsigned)(kTileQueues - 1 - lane)) / (unsigned)kTileQueues;
-      }
-      const unsigned long long open_q = __ballot(lane < kTileQueues && lane != q && peek < cap_l);
-      if (!open_q) return uint4{0xFFFFFFFFu, 0u, 0u, 0u};
-      const unsigned long long after = open_q & ~((2ull << q) - 1ull);
-      q = __builtin_ctzll(after ? after : open_q);
-      if (a.bucket_cnt) load_classes();
-      if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-    }
-  };
-  // A window chunk is a contiguous piece of the SRec array and its LDS image is the same bytes: copied by the LDS-DMA path
-  // (global_load_lds_dwordx4: 1 KB per instruction, destination = wave-uniform base + lane x 16), no staging registers.
-  typedef __attribute__((address_space(3))) void lds_void_t;
-  typedef const __attribute__((address_space(1))) void gbl_void_t;
-  auto stage_window = [&](long long wb, int wn) {
-    const char *src = reinterpret_cast<const char *>(a.srec + wb);
-    const int bytes = wn * 64;
-#pragma unroll
-    for (int o = 0; o < kWin * 64; o += 1024)
-      if (o + lane * 16 < bytes)
-        __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + o + lane * 16), (lds_void_t *)(smem_raw + o), 16, 0, 0);
-  };
-  // the ONE load level of a tile, issued as soon as its draw is resolved (the previous tile's window is dead by then): the
-  // lane's own record into registers and -- the class lists carry the window bounds -- the first window chunk into LDS
-  const float4 *srec4 = reinterpret_cast<const float4 *>(a.srec);
-  const float4 z4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
-  float4 o0 = z4, o1 = z4, o2 = z4, o3 = z4;
-  auto load_first_level = [&](const uint4 h) {
-    const long long tp = (long long)h.x * 64 + lane;
-    if (tp < C) {
-      const float4 *r = srec4 + 4 * (size_t)tp;
-      o0 = r[0]; o1 = r[1]; o2 = r[2]; o3 = r[3];
-    }
-    if (h.z > h.y) stage_window((long long)h.y, (int)((h.z - h.y) < (unsigned)kWin ? (h.z - h.y) : (unsigned)kWin));
-  };
-  const float cosf_guard = cfg.cos_guard > -1.0 ? (float)(cfg.cos_guard - 2e-6) : -2.0f;
-  uint4 hdr = resolve();
-  if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
-  while (hdr.x != 0xFFFFFFFFu) {
-    const unsigned tile = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.x);
-    const unsigned h_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.y);
-    const unsigned h_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.z);
-    const bool h_bounds = h_hi > h_lo;
-    const long long i0 = (long long)tile * 64;
-    const long long tpos = i0 + lane;
-    const bool active = tpos < C;
-    LT_TRACE_MARK(2, tile, 0);
-
-    // the lane's own operands: its sweep record
-    long long off = 0, nb0 = 0;
-    int n = 0, n_nb = 0, sloti = -1;
-    float dixf = 0, diyf = 0, dizf = 0, sixf = 0, siyf = 0, sizf = 0, eixf = 0, eiyf = 0, eizf = 0, ri = 0.0f;
-    double gs = 0, ge = 0;
-    unsigned own_rec = 0;
-    if (active) {
-      dixf = o0.x; diyf = o0.y; dizf = o0.z; sloti = __float_as_int(o0.w);
-      sixf = o1.x; eixf = o1.y; siyf = o1.z; eiyf = o1.w;
-      sizf = o2.x; eizf = o2.y; gs = (double)o2.z; ge = (double)o2.w;
-      off = (long long)__float_as_uint(o3.x);
-      n = (int)__float_as_uint(o3.y);
-      const unsigned nbw = __float_as_uint(o3.z);
-      nb0 = (long long)(nbw >> 8);
-      n_nb = (int)(nbw & 0xFFu);
-      own_rec = __float_as_uint(o3.w);
-      ri = fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)), fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf)));
-    }
-    lrec[lane] = own_rec;
-    const long long wave_nb0 = (long long)__builtin_amdgcn_readfirstlane((int)nb0);  // nb_off < 2^24
-    if (lane < __builtin_amdgcn_readfirstlane(n_nb)) ordl[lane] = a.blk_order[wave_nb0 + lane];
-    for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
-    // window = the nodes of the tile's first and last candidate, whole (lane 0 is always active)
-    long long lo, hi;
-    if (h_bounds) {
-      lo = (long long)h_lo; hi = (long long)h_hi;
-    } else {
-      const int last = (int)((C - i0) < 64 ? (C - i0) : 64) - 1;
-      lo = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)off);
-      hi = (long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(off + n), last);
-    }
-    int qn = 0;
-    unsigned long long n_eval = 0;
-
-    auto drain = [&](bool final) {
-      wave_lds_sync();
-      if (final && qn == 0 && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-      for (int q0 = 0; q0 < qn; q0 += 64) {
-        if (final && q0 + 64 >= qn && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-        const int p = q0 + lane;
-        if (p < qn) {
-          const unsigned e = queue[p];
-          const int il = (int)(e >> 8);
-          const unsigned rj = reinterpret_cast<const unsigned *>(W4)[16 * (e & 0xFFu) + 15];  // SRec::rec of the window entry
-          const CRec &ci = a.cand[lrec[il]];
-          const CRec &cj = a.cand[rj];
-          const int nbs_j = cj.nb_slot;
-          const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
-                                       mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
-                                       mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
-                                       mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg,
-                                       a.cams[(int)((unsigned)nbs_j >> 8)]);
-          if (sc > 0.0) atomicMax(&S[(nbs_j & 0xFF) * 64 + il], (unsigned long long)__double_as_longlong(sc));
-        }
-      }
-      n_eval += (unsigned long long)qn;
-      qn = 0;
-      wave_lds_sync();
-    };
-
-    for (long long wb = lo; wb < hi; wb += kWin) {
-      const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
-      // the first chunk is already on its way when the class list gave the bounds (load_first_level); later chunks
-      // (windows beyond kWin entries) and tiles without listed bounds are staged here -- the queue was drained, nobody
-      // reads the window any more
-      if (!(h_bounds && wb == lo)) {
-        wave_lds_sync();
-        stage_window(wb, wn);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA counts as a vector memory operation
-      wave_lds_sync();
-      float rw = ri;
-      for (int e = lane; e < wn; e += 64) {
-        const float4 r1 = W4[4 * e + 1];
-        const float2 r2 = *reinterpret_cast<const float2 *>(&W4[4 * e + 2]);
-        rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(r1.x), fabsf(r1.y)), fmaxf(fabsf(r1.z), fabsf(r1.w))),
-                             fmaxf(fabsf(r2.x), fabsf(r2.y))));
-      }
-      // R of the window -> the lane's single-precision squared distance guards (see k_score3: 1e-6 R bounds the rounding
-      // of a single-precision distance; a NaN coordinate makes every comparison false: everything goes to the exact path)
-      rw = wave_max_f32_nan(rw);
-      const double delta = 1e-6 * (double)rw;
-      const float gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
-      const float gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
-      wave_lds_sync();
-      if (wb == lo) { LT_TRACE_MARK(2, tile, 1); }
-      const long long jlo = off > wb ? off : wb;
-      const long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
-      const int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
-      const int cmax = wave_max_i32(cnt);
-      const int wbase = cnt > 0 ? (int)(jlo - wb) : 0;
-      const int wlast = cnt > 0 ? wbase + cnt - 1 : 0;  // reads beyond the lane's range are clamped, then masked
-      const int self_t = (int)(tpos - jlo);             // iteration at which the lane meets itself (may be out of range)
-#if defined(LT_RABL) && LT_RABL >= 2
-      for (int t = 0; t < min(cmax, 4); t += 4) {
-#else
-      for (int t = 0; t < cmax; t += 4) {
-#endif
-        float4 A[4], B[4];
-        float2 E[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int w = min(wbase + t + u, wlast);
-          A[u] = W4[4 * w + 0];
-          B[u] = W4[4 * w + 1];
-          E[u] = *reinterpret_cast<const float2 *>(&W4[4 * w + 2]);
-        }
-        bool pass[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float c = fabsf(__builtin_fmaf(dizf, A[u].z, __builtin_fmaf(diyf, A[u].y, dixf * A[u].x)));
-          const float ax = sixf - B[u].x, bx = eixf - B[u].y;
-          const float ay = siyf - B[u].z, by = eiyf - B[u].w;
-          const float az = sizf - E[u].x, bz = eizf - E[u].y;
-          const float ds2 = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
-          const float de2 = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
-          pass[u] = (t + u < cnt) & (t + u != self_t) & (__float_as_int(A[u].w) != sloti) & !(c < cosf_guard) &
-                    !(ds2 > gsf) & !(de2 > gef);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned long long m = __ballot(pass[u]);
-          if (m) {
-            if (pass[u]) queue[qn + __popcll(m & lanemask_lt())] = (unsigned short)(((unsigned)lane << 8) | (unsigned)(wbase + t + u));
-            qn += __popcll(m);
-          }
-        }
-        if (qn > kRQCap - 256) drain(false);
-      }
-      // the queue entries name window indices: evaluate them before the window is replaced
-      const bool last_chunk = wb + kWin >= hi;
-      if (last_chunk) { LT_TRACE_MARK(2, tile, 2); }
-#if defined(LT_RABL) && LT_RABL >= 1
-      qn = 0;
-#endif
-      drain(last_chunk);
-    }
-    LT_TRACE_MARK(2, tile, 3);
-
-    if (active) {
-      double sum = 0.0;
-      const bool own = nb0 == wave_nb0;
-      for (int r = 0; r < n_nb; ++r) {
-        const int k = own ? ordl[r] : a.blk_order[nb0 + r];
-        sum += __longlong_as_double((long long)S[k * 64 + lane]);
-      }
-      a.score[tpos] = sum;
-    }
-    n_eval_total += n_eval;
-    wave_lds_sync();  // the tables are reused by the next tile
-    hdr = resolve();
-    if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
-  }
-  if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
-}
-
-// ---------------------------------------------------------------------------------------------
-// HOT LOOP 2 in TWO kernels on the sweep records (matched mode; the default since round 4)
-// ---------------------------------------------------------------------------------------------
-// What bounds the fused kernels (k_score3, k_score_rec) is not a roof but their schedule: per tile a light, latency-bound
-// sweep and a heavy, issue-bound dense phase whose length nobody knows before the sweep has run (0 ... 537 pairs per
-// tile at 100 x 500: 0 ... 9 rounds of ~5 us), on waves that need pair_score's ~200 registers -- two per SIMD -- for the
-// whole tile.  The trace of round 4 (profiles/r04_score_trace.txt): wave time inside tiles 142 ms over 2 048 resident
-// waves = 69 us, the kernel 102: ~15 us of gaps between tiles (draw -> class-list entry -> records) and ~17 us of tail
-// (tiles that turn out heavy start late: the cost classes know the node sizes, not the pairs).  So:
-//   k_sweep_rec   one wave per tile, no pair_score in the kernel: 40 registers, 13 waves per CU -- the window streams
-//                 in (SRec, LDS-DMA), the pairs that pass the conservative guards go to a global list (8 bytes: CRec
-//                 slot of j, lane of i; a tile's pairs = one contiguous segment, rarely more), and the tile is listed
-//                 by its EXACT pair count (per-XCD queue x 32 classes of 16 pairs); tiles without a pair are finished
-//                 here (score 0).
-//   k_dense_rec   persistent waves draw the tiles heaviest first (longest-processing-time order on the true cost) and do
-//                 only the dense rounds, the per-image maxima (LDS, ds_max_u64) and the ordered sums of a tile.
-// A pair list that does not hold (LT_TEST_PAIR_CAP forces it) raises device flag 7; the host repeats the run with the
-// fused k_score_rec (finish_run), same results.
-constexpr int kSwQCap = 768;      // LDS queue of k_sweep_rec (entries); flushed when fewer than 256 are free
-constexpr int kPairRegions = 64;  // bump counters of the pair list, 128 bytes apart (one address serialises at ~15 ns)
-constexpr int kMaxMoreSegs = 3;   // segments of a tile beyond the first (a tile flushes its queue at 512 pairs)
-struct PairList {
-  uint2 *pairs;           // [kPairRegions][region_cap]: x = CRec slot of j, y = lane of i in the tile
-  unsigned *region_ctr;   // kPairRegions counters, 128 bytes apart, zeroed by k_build_pairs
-  unsigned region_cap;
-  uint2 *tile_more;       // [tiles][kMaxMoreSegs]: (first pair, count) of a tile's segments beyond the first
-  // heavy tiles are evaluated in PARTS of <= kPartPairs pairs by several waves: per split tile a table of per-image
-  // maxima in HBM (zeroed by k_sweep_rec, combined by atomic max) and a counter of finished parts; the wave that
-  // finishes the last part sums and writes the tile's scores
-  unsigned long long *split_S;  // [split_cap][max_nb][64]
-  unsigned *split_done;         // [split_cap]
-  unsigned *split_ctr;          // split tiles so far (zeroed by k_build_pairs with the region counters)
-  unsigned split_cap;
-};
-constexpr unsigned kSplitMin = 192;   // tiles with more pairs than this (3 dense rounds) are split
-constexpr unsigned kPartPairs = 128;  // pairs per part (2 rounds)
-size_t sweep_rec_lds_bytes() { return (size_t)kWin * 64 + (size_t)kSwQCap * 4 + (size_t)kSwQCap + 4 * 8; }
-
-__global__ void __launch_bounds__(64)
-k_sweep_rec(Score3Args a, ScoreCfg cfg, PairList pl) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int lane = threadIdx.x;
-  float4 *W4 = reinterpret_cast<float4 *>(smem_raw);                                      // window: SRec as it is
-  unsigned *qrec = reinterpret_cast<unsigned *>(smem_raw + (size_t)kWin * 64);            // queue: CRec slot of j
-  unsigned char *qil = smem_raw + (size_t)kWin * 64 + (size_t)kSwQCap * 4;                //        lane of i
-  uint2 *segl = reinterpret_cast<uint2 *>(smem_raw + (size_t)kWin * 64 + (size_t)kSwQCap * 5);  // the tile's segments
-  static_assert(kSwQCap % 8 == 0, "alignment of the segment table");
-  const long long C = a.tri_off[a.G];
-  if (blockIdx.x == 0 && lane < kTileQueues) a.draw[lane * 32] = 0;  // the draw counters of k_dense_rec
-  typedef __attribute__((address_space(3))) void lds_void_t;
-  typedef const __attribute__((address_space(1))) void gbl_void_t;
-  const float4 *srec4 = reinterpret_cast<const float4 *>(a.srec);
-  const float cosf_guard = cfg.cos_guard > -1.0 ? (float)(cfg.cos_guard - 2e-6) : -2.0f;
-  const unsigned n_tiles = (unsigned)((C + 63) >> 6);
-  // the grid is sized by an upper bound of the candidate count (the exact one stays on the device): waves stride over the tiles
-  for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-  const long long i0 = (long long)tile * 64;
-  const long long tpos = i0 + lane;
-  const bool active = tpos < C;
-  LT_TRACE_MARK(3, tile, 0);
-  const float4 z4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
-  float4 o0 = z4, o1 = z4, o2 = z4, o3 = z4;
-  if (active) {
-    const float4 *r = srec4 + 4 * (size_t)tpos;
-    o0 = r[0]; o1 = r[1]; o2 = r[2]; o3 = r[3];
-  }
-  long long off = 0;
-  int n = 0, sloti = -1;
-  float dixf = 0, diyf = 0, dizf = 0, sixf = 0, siyf = 0, sizf = 0, eixf = 0, eiyf = 0, eizf = 0, ri = 0.0f;
-  double gs = 0, ge = 0;
-  if (active) {
-    dixf = o0.x; diyf = o0.y; dizf = o0.z; sloti = __float_as_int(o0.w);
-    sixf = o1.x; eixf = o1.y; siyf = o1.z; eiyf = o1.w;
-    sizf = o2.x; eizf = o2.y; gs = (double)o2.z; ge = (double)o2.w;
-    off = (long long)__float_as_uint(o3.x);
-    n = (int)__float_as_uint(o3.y);
-    ri = fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)), fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf)));
-  }
-  // window = the nodes of the tile's first and last candidate, whole (lane 0 is always active)
-  const int last = (int)((C - i0) < 64 ? (C - i0) : 64) - 1;
-  const long long lo = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)off);
-  const long long hi = (long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(off + n), last);
-  const unsigned region = tile & (unsigned)(kPairRegions - 1);
-  int qn = 0;
-  unsigned n_seg = 0, total = 0;
-  // ((first pair, count) of the tile's segments: LDS table segl -- registers indexed by n_seg end up in scratch)
-  if (lane < 4) segl[lane] = make_uint2(0u, 0u);
-  static_assert(kMaxMoreSegs == 3, "four segments per tile are kept in registers");
-  auto flush = [&]() __attribute__((always_inline)) {
-    wave_lds_sync();
-    if (qn > 0) {
-      unsigned base = 0;
-      if (lane == 0) base = atomicAdd(&pl.region_ctr[region * 32], (unsigned)qn);
-      base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-      if ((unsigned long long)base + (unsigned)qn > (unsigned long long)pl.region_cap || n_seg > (unsigned)kMaxMoreSegs) {
-        if (lane == 0) *a.err_flag = 7;  // the host repeats the run with the fused kernel (these pairs are dropped)
-      } else {
-        const unsigned g0 = region * pl.region_cap + base;
-        for (int p = lane; p < qn; p += 64) pl.pairs[(size_t)g0 + p] = make_uint2(qrec[p], (unsigned)qil[p]);
-        if (lane == 0) segl[n_seg] = make_uint2(g0, (unsigned)qn);
-        if (n_seg > 0 && lane == 0) pl.tile_more[(size_t)tile * kMaxMoreSegs + (n_seg - 1)] = make_uint2(g0, (unsigned)qn);
-        ++n_seg;
-        total += (unsigned)qn;
-      }
-      qn = 0;
-    }
-    wave_lds_sync();
-  };
-  for (long long wb = lo; wb < hi; wb += kWin) {
-    const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
-    wave_lds_sync();  // the previous chunk's readers are done
-    {
-      const char *src = reinterpret_cast<const char *>(a.srec + wb);
-      const int bytes = wn * 64;
-#pragma unroll
-      for (int o = 0; o < kWin * 64; o += 1024)
-        if (o + lane * 16 < bytes)
-          __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + o + lane * 16), (lds_void_t *)(smem_raw + o), 16, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wave_lds_sync();
-    float rw = ri;
-    for (int e = lane; e < wn; e += 64) {
-      const float4 r1 = W4[4 * e + 1];
-      const float2 r2 = *reinterpret_cast<const float2 *>(&W4[4 * e + 2]);
-      rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(r1.x), fabsf(r1.y)), fmaxf(fabsf(r1.z), fabsf(r1.w))),
-                           fmaxf(fabsf(r2.x), fabsf(r2.y))));
-    }
-    rw = wave_max_f32_nan(rw);
-    const double delta = 1e-6 * (double)rw;  // see k_score3: bounds the rounding of a single-precision distance
-    const float gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
-    const float gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
-    const long long jlo = off > wb ? off : wb;
-    const long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
-    const int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
-    const int cmax = wave_max_i32(cnt);
-    const int wbase = cnt > 0 ? (int)(jlo - wb) : 0;
-    const int wlast = cnt > 0 ? wbase + cnt - 1 : 0;  // reads beyond the lane's range are clamped, then masked
-    const int self_t = (int)(tpos - jlo);
-    for (int t = 0; t < cmax; t += 4) {
-      float4 A[4], B[4];
-      float2 E[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int w = min(wbase + t + u, wlast);
-        A[u] = W4[4 * w + 0];
-        B[u] = W4[4 * w + 1];
-        E[u] = *reinterpret_cast<const float2 *>(&W4[4 * w + 2]);
-      }
-      bool pass[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float c = fabsf(__builtin_fmaf(dizf, A[u].z, __builtin_fmaf(diyf, A[u].y, dixf * A[u].x)));
-        const float ax = sixf - B[u].x, bx = eixf - B[u].y;
-        const float ay = siyf - B[u].z, by = eiyf - B[u].w;
-        const float az = sizf - E[u].x, bz = eizf - E[u].y;
-        const float ds2 = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
-        const float de2 = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
-        pass[u] = (t + u < cnt) & (t + u != self_t) & (__float_as_int(A[u].w) != sloti) & !(c < cosf_guard) &
-                  !(ds2 > gsf) & !(de2 > gef);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned long long m = __ballot(pass[u]);
-        if (m) {
-          if (pass[u]) {
-            const int p = qn + __popcll(m & lanemask_lt());
-            qrec[p] = reinterpret_cast<const unsigned *>(W4)[16 * (wbase + t + u) + 15];  // SRec::rec of j
-            qil[p] = (unsigned char)lane;
-          }
-          qn += __popcll(m);
-        }
-      }
-      if (qn > kSwQCap - 256) flush();
-    }
-  }
-  flush();
-  LT_TRACE_MARK(3, tile, 1);
-  // a work item of k_dense_rec, listed by its exact cost: 16 pairs per class, the last class open-ended
-  auto list_item = [&](unsigned pairs_of_item, unsigned e_y, unsigned e_z, unsigned e_w, unsigned spread) __attribute__((always_inline)) {
-    const unsigned cls = (pairs_of_item >> 4) < (unsigned)(kTileBuckets - 1) ? (pairs_of_item >> 4) : (unsigned)(kTileBuckets - 1);
-    const int qb = (int)((tile + spread) & (kTileQueues - 1)) * kTileBuckets + (int)cls;
-    const unsigned idx = atomicAdd(&a.bucket_cnt_w[qb * 32], 1u);
-    if (idx < a.bucket_cap) reinterpret_cast<uint4 *>(a.bucket_list_w)[(size_t)qb * a.bucket_cap + idx] = uint4{tile, e_y, e_z, e_w};
-    else *a.err_flag = 7;  // a list is full (the host sizes them for three items per tile): repeated with the fused kernel
-  };
-  if (total == 0) {
-    if (active) a.score[tpos] = 0.0;  // no pair reaches pair_score: every per-image maximum is 0
-  } else {
-    // heavy tile: parts of <= kPartPairs pairs for several waves (see PairList); needs a slot of the split tables
-    unsigned sidx = 0xFFFFFFFFu;
-    if (total > kSplitMin && pl.split_cap > 0) {
-      if (lane == 0) sidx = atomicAdd(pl.split_ctr, 1u);
-      sidx = (unsigned)__builtin_amdgcn_readfirstlane((int)sidx);
-      if (sidx >= pl.split_cap) sidx = 0xFFFFFFFFu;
-    }
-    if (sidx != 0xFFFFFFFFu) {
-      unsigned long long *gS = pl.split_S + (size_t)sidx * (size_t)a.max_nb * 64;
-      for (int k = 0; k < a.max_nb; ++k) gS[k * 64 + lane] = 0ull;
-      if (lane == 0) {
-        unsigned n_parts = 0;
-        for (unsigned sg = 0; sg < n_seg; ++sg) n_parts += (segl[sg].y + kPartPairs - 1) / kPartPairs;
-        pl.split_done[sidx] = 0u;
-        unsigned part = 0;
-        for (unsigned sg = 0; sg < n_seg; ++sg) {
-          const unsigned sb = segl[sg].x, sc = segl[sg].y;
-          for (unsigned p0 = 0; p0 < sc; p0 += kPartPairs, ++part) {
-            const unsigned c = (sc - p0) < kPartPairs ? (sc - p0) : kPartPairs;
-            // parts of one tile go to different queues (XCDs): they are meant to run side by side
-            list_item(c, sb + p0, c | (n_parts << 16), 0x80000000u | sidx, part);
-          }
-        }
-      }
-    } else if (lane == 0) {
-      list_item(total, segl[0].x, segl[0].y, n_seg, 0u);
-    }
-  }
-  // (the pair statistic is counted by k_dense_rec, once per wave: 9 000 atomics on ONE address here serialised at
-  // ~15 ns each and made this kernel 114 us long)
-  }  // tiles
-}
-
-size_t dense_rec_lds_bytes(int max_nb) {
-  return (((size_t)64 * 4 + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
-}
-__global__ void __launch_bounds__(64) LT_SCORE_OCC
-k_dense_rec(Score3Args a, ScoreCfg cfg, PairList pl) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int lane = threadIdx.x;
-  // LDS: lrec[64] u32 | ord[max_nb] i32 | S[max_nb][64] u64
-  unsigned *lrec = reinterpret_cast<unsigned *>(smem_raw);
-  int *ordl = reinterpret_cast<int *>(smem_raw + 64 * 4);
-  unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_raw + (((size_t)64 * 4 + (size_t)a.max_nb * 4 + 15) & ~(size_t)15));
-  const long long C = a.tri_off[a.G];
-  // the tiles with pairs, listed per (queue, class) by k_sweep_rec; lane q < kTileQueues keeps the size of queue q
-  unsigned q_size = 0;
-  if (lane < kTileQueues)
-    for (int c = 0; c < kTileBuckets; ++c) q_size += a.bucket_cnt[(lane * kTileBuckets + c) * 32];
-  int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
-  unsigned k_raw = 0;
-  if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-  unsigned cls_cnt = 0, cls_incl = 0, q_tiles = 0;
-  auto load_classes = [&]() {
-    cls_cnt = lane < kTileBuckets ? a.bucket_cnt[(q * kTileBuckets + (kTileBuckets - 1 - lane)) * 32] : 0u;
-    cls_incl = cls_cnt;
-#pragma unroll
-    for (int d = 1; d < kTileBuckets; d <<= 1) {
-      const unsigned t = (unsigned)__shfl_up((int)cls_incl, d);
-      if (lane >= d) cls_incl += t;
-    }
-    q_tiles = (unsigned)__builtin_amdgcn_readlane((int)cls_incl, kTileBuckets - 1);
-  };
-  load_classes();
-  auto resolve = [&]() -> uint4 {
-    for (;;) {
-      const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_raw);
-      if (k < q_tiles) {
-        const unsigned long long m = __ballot(lane < kTileBuckets && cls_incl > k);
-        const int bl = __builtin_ctzll(m);
-        const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)(cls_incl - cls_cnt), bl);
-        return reinterpret_cast<const uint4 *>(
-            a.bucket_list)[(size_t)(q * kTileBuckets + (kTileBuckets - 1 - bl)) * a.bucket_cap + (k - base)];
-      }
-      // this queue is exhausted: peek at the counters (plain loads) and move to one that still has tiles
-      if (++tried > 4 * kTileQueues) return uint4{0xFFFFFFFFu, 0u, 0u, 0u};
-      unsigned peek = 0xFFFFFFFFu;
-      if (lane < kTileQueues) peek = __hip_atomic_load(&a.draw[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long open_q = __ballot(lane < kTileQueues && lane != q && peek < q_size);
-      if (!open_q) return uint4{0xFFFFFFFFu, 0u, 0u, 0u};
-      const unsigned long long after = open_q & ~((2ull << q) - 1ull);
-      q = __builtin_ctzll(after ? after : open_q);
-      load_classes();
-      if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-    }
-  };
-  const float4 *srec4 = reinterpret_cast<const float4 *>(a.srec);
-  float4 o3 = float4{0.0f, 0.0f, 0.0f, 0.0f};
-  uint2 pr0 = make_uint2(0u, 0u);
-  auto load_first_level = [&](const uint4 h) {  // the lane's node words / CRec slot and the first round's pairs
-    const long long tp = (long long)h.x * 64 + lane;
-    if (tp < C) o3 = srec4[4 * (size_t)tp + 3];
-    if ((unsigned)lane < ((h.w >> 31) ? (h.z & 0xFFFFu) : h.z)) pr0 = pl.pairs[(size_t)h.y + lane];
-  };
-  unsigned long long n_eval_total = 0;
-  uint4 hdr = resolve();
-  if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
-  while (hdr.x != 0xFFFFFFFFu) {
-    const unsigned tile = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.x);
-    const unsigned s0_base = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.y);
-    const unsigned h_z = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.z);
-    const unsigned h_w = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.w);
-    // a whole tile (w = its segments) or one part of a split tile (w = 0x80000000 | split slot, z = pairs | parts << 16)
-    const bool is_part = (h_w >> 31) != 0u;
-    const unsigned s0_cnt = is_part ? (h_z & 0xFFFFu) : h_z;
-    const unsigned n_seg = is_part ? 1u : h_w;
-    const unsigned n_parts = h_z >> 16, sidx = h_w & 0x7FFFFFFFu;
-    const long long tpos = (long long)tile * 64 + lane;
-    const bool active = tpos < C;
-    LT_TRACE_MARK(2, tile, 0);
-    long long nb0 = 0;
-    int n_nb = 0;
-    unsigned own_rec = 0;
-    if (active) {
-      const unsigned nbw = __float_as_uint(o3.z);
-      nb0 = (long long)(nbw >> 8);
-      n_nb = (int)(nbw & 0xFFu);
-      own_rec = __float_as_uint(o3.w);
-    }
-    lrec[lane] = own_rec;
-    const long long wave_nb0 = (long long)__builtin_amdgcn_readfirstlane((int)nb0);  // nb_off < 2^24
-    if (lane < __builtin_amdgcn_readfirstlane(n_nb)) ordl[lane] = a.blk_order[wave_nb0 + lane];
-    for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
-    wave_lds_sync();
-    LT_TRACE_MARK(2, tile, 1);
-    uint2 pr = pr0;
-    bool claimed = false;
-    for (unsigned sg = 0; sg < n_seg; ++sg) {
-      unsigned base = s0_base, cnt = s0_cnt;
-      if (sg > 0) {
-        const uint2 m = pl.tile_more[(size_t)tile * kMaxMoreSegs + (sg - 1)];
-        base = (unsigned)__builtin_amdgcn_readfirstlane((int)m.x);
-        cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)m.y);
-        if ((unsigned)lane < cnt) pr = pl.pairs[(size_t)base + lane];
-      }
-      for (unsigned q0 = 0; q0 < cnt; q0 += 64) {
-        const bool last_round = sg + 1 == n_seg && q0 + 64 >= cnt;
-        if (last_round) {  // claim the next tile (see k_score3)
-          claimed = true;
-          if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
-        }
-        const uint2 cur = pr;
-        if (q0 + 64 + (unsigned)lane < cnt) pr = pl.pairs[(size_t)base + q0 + 64 + lane];  // the next round's pairs
-        if (q0 + (unsigned)lane < cnt) {
-          const int il = (int)(cur.y & 63u);
-          const CRec &ci = a.cand[lrec[il]];
-          const CRec &cj = a.cand[cur.x];
-          const int nbs_j = cj.nb_slot;
-          const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
-                                       mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
-                                       mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
-                                       mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg,
-                                       a.cams[(int)((unsigned)nbs_j >> 8)]);
-          if (sc > 0.0) atomicMax(&S[(nbs_j & 0xFF) * 64 + il], (unsigned long long)__double_as_longlong(sc));
-        }
-      }
-      n_eval_total += cnt;
-    }
-    if (!claimed && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);  // (a tile listed without pairs: an overflowed run)
-    wave_lds_sync();
-    LT_TRACE_MARK(2, tile, 2);
-    bool do_sums = true;
-    if (is_part) {
-      // this part's maxima into the tile's table in HBM (scores are non-negative doubles: their bit patterns order like
-      // the values); the wave that finishes the tile's LAST part reads the combined table back and does the sums
-      unsigned long long *gS = pl.split_S + (size_t)sidx * (size_t)a.max_nb * 64;
-      // No fences (a release / acquire fence at device scope writes back / invalidates the XCD's whole L2 -- measured:
-      // the kernel 80 -> 193 us): every access to the shared table and the counter is a device-scope atomic RMW, which is
-      // performed at the memory side for all XCDs; the maxima RETURN their old value, so waiting for the returns
-      // (acc feeds the counter's operand) orders them before the count.
-      unsigned long long acc = 0ull;
-      for (int k = 0; k < a.max_nb; ++k) {
-        const unsigned long long v = S[k * 64 + lane];
-        if (v) acc |= __hip_atomic_fetch_max(&gS[k * 64 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      const unsigned dep = (unsigned)(__ballot(acc == 0xFFFFFFFFFFFFFFFFull) != 0ull);  // always 0 (a score is never NaN-all-ones)
-      unsigned old = 0;
-      if (lane == 0) old = __hip_atomic_fetch_add(&pl.split_done[sidx], 1u + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-      do_sums = old + 1u == n_parts;
-      if (do_sums) {
-        for (int k = 0; k < a.max_nb; ++k)
-          S[k * 64 + lane] = __hip_atomic_fetch_or(&gS[k * 64 + lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    if (active && do_sums) {
-      double sum = 0.0;
-      const bool own = nb0 == wave_nb0;
-      for (int r = 0; r < n_nb; ++r) {
-        const int k = own ? ordl[r] : a.blk_order[nb0 + r];
-        sum += __longlong_as_double((long long)S[k * 64 + lane]);
-      }
-      a.score[tpos] = sum;
-    }
-    LT_TRACE_MARK(2, tile, 3);
-    wave_lds_sync();  // the tables are reused by the next tile
-    hdr = resolve();
-    if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
-  }
-  if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
-}
-
 #ifdef LT_TRACE
 int score_read_trace(unsigned long long *host, size_t n) {  // slices 2 and 3 of the trace array
   if (n < 4 * 4 * 65536) return -1;
@@ -1334,8 +666,6 @@ size_t score3_lds_bytes(int max_nb, bool f32) {
   return ((base + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
 }
 size_t cand_meta_bytes() { return sizeof(CandMeta); }
-int score_pair_regions() { return kPairRegions + 1; }  // + the split-tile counter (128 bytes each)
-int score_tile_more_segs() { return kMaxMoreSegs; }
 int score3_tile_buckets() { return kTileBuckets * kTileQueues; }  // counters (128 B apart) / lists: one per (queue, class)
 // (A two-kernel form -- light sweep writing per-tile pair lists, then a dense evaluation kernel -- was
 // measured: the sweep alone takes 53 us, but the evaluation does not get cheaper and the two phases no
@@ -1346,12 +676,9 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, unsigned *bucket_cnt,
                    unsigned *bucket_list, unsigned bucket_cap, const unsigned *place, unsigned *rec, const float *st_z,
-                   int *err_flag, const SRec *srec, void *pair_list, unsigned *pair_region_ctr, unsigned pair_region_cap,
-                   void *tile_more, void *split_S, unsigned *split_done, unsigned split_cap) {
+                   int *err_flag) {
   // place / rec: depth-sorted sweep over STAGED records (one-pass exhaustive mode): place[natural position] = record,
   // rec (scratch, one word per candidate) receives the record of every sorted position
-  // srec: the sweep records k_place wrote at the candidates' final positions (matched mode, permutation placement):
-  // k_score_rec instead of k_score3, no CandMeta records
   if (C <= 0) return;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -1362,12 +689,9 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   }
   // C: the candidate count or an upper bound of it (the kernels read the exact count from tri_off[G])
   const long long n_tiles = (C + 63) / 64;
-  const bool use_rec = srec != nullptr && f32 && perm_is_placement;
-  // (the two-kernel form needs no prologue pass: k_sweep_rec lists the tiles itself and resets the draw counters)
-  if (!(use_rec && pair_list && bucket_cnt))
-    hipLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st, G,
-                       cand_node, tri_off, node_img, nb_off, use_rec ? nullptr : reinterpret_cast<CandMeta *>(meta), draw,
-                       bucket_cnt, bucket_list, bucket_cap);
+  hipLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st, G,
+                     cand_node, tri_off, node_img, nb_off, reinterpret_cast<CandMeta *>(meta), draw, bucket_cnt, bucket_list,
+                     bucket_cap);
   Score3Args a;
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand;
   a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
@@ -1377,38 +701,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.bucket_cnt = bucket_cnt; a.bucket_list = bucket_list; a.bucket_cap = bucket_cap;
   a.max_nb = max_nb;
   a.err_flag = err_flag;
-  a.srec = srec;
   if (ev_before) (void)hipEventRecord(ev_before, st);
-  a.bucket_cnt_w = bucket_cnt; a.bucket_list_w = bucket_list;
-  if (use_rec && pair_list && bucket_cnt) {
-    // two kernels: sweep -> pair list + tiles listed by their exact pair count; dense rounds, maxima and sums
-    PairList pl;
-    pl.pairs = reinterpret_cast<uint2 *>(pair_list); pl.region_ctr = pair_region_ctr; pl.region_cap = pair_region_cap;
-    pl.tile_more = reinterpret_cast<uint2 *>(tile_more);
-    pl.split_S = reinterpret_cast<unsigned long long *>(split_S); pl.split_done = split_done; pl.split_cap = split_cap;
-    pl.split_ctr = pair_region_ctr + kPairRegions * 32;  // the counter behind the region counters
-    const size_t lds_sw = sweep_rec_lds_bytes();
-    const size_t lds = dense_rec_lds_bytes(max_nb);
-    // persistent grids: what is resident at once (registers and LDS; the occupancy API counts both)
-    static int occ_sw = 0, occ_dn = 0, occ_nb = -1;
-    if (occ_sw == 0 || occ_nb != max_nb) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_sw, k_sweep_rec, 64, lds_sw) != hipSuccess || occ_sw <= 0) occ_sw = 8;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_dn, k_dense_rec, 64, lds) != hipSuccess || occ_dn <= 0) occ_dn = 8;
-      if (const char *e = getenv("LT_SWEEP_RESIDENT")) occ_sw = std::max(1, atoi(e));
-      if (const char *e = getenv("LT_DENSE_RESIDENT")) occ_dn = std::max(1, atoi(e));
-      occ_nb = max_nb;
-      (void)hipGetLastError();
-    }
-    hipLaunchKernelGGL(k_sweep_rec, dim3((unsigned)std::min<long long>(n_tiles, (long long)occ_sw * n_cu)), dim3(64), lds_sw, st, a, cfg, pl);
-    hipLaunchKernelGGL(k_dense_rec, dim3((unsigned)std::min<long long>(n_tiles, (long long)occ_dn * n_cu)), dim3(64), lds, st, a, cfg, pl);
-    return;
-  }
-  if (use_rec) {
-    const size_t lds = score_rec_lds_bytes(max_nb);
-    const long long per_cu = std::max<long long>(1, std::min<long long>(LT_SCORE_RESIDENT, (long long)(160 * 1024 / lds)));
-    hipLaunchKernelGGL(k_score_rec, dim3((unsigned)std::min<long long>(n_tiles, per_cu * n_cu)), dim3(64), lds, st, a, cfg);
-    return;
-  }
   const bool sorted = perm != nullptr && f32 && !perm_is_placement;
   if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
     hipLaunchKernelGGL(k_depth_order, dim3(nblk2(G, 4)), dim3(256), 0, st, G, tri_off, cand,

@@ -666,8 +666,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
         const long long *__restrict__ tri_off, const CRec *__restrict__ st_r,
         const double *__restrict__ st_unc, const unsigned *__restrict__ st_key, CRec *__restrict__ cand,
         double *__restrict__ cand_unc, unsigned *__restrict__ cand_node, int n_groups, int mult,
-        unsigned *__restrict__ perm, SRec *__restrict__ srec, const Cam *__restrict__ cams,
-        const unsigned *__restrict__ n_tris, const long long *__restrict__ nb_off, double guard) {
+        unsigned *__restrict__ perm) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
@@ -679,16 +678,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
   const unsigned lin = (unsigned)b * (unsigned)n_groups + (unsigned)g;
   const unsigned count = wave_count[lin];
   if (count == 0) return;
-  const int i1 = blk_img[b];
-  const long long g1 = seg_off[i1];
-  // sweep records (srec != nullptr): origin = the image's camera centre, summation-order word of the image -- wave-uniform
-  double ox = 0.0, oy = 0.0, oz = 0.0;
-  unsigned nbw = 0;
-  if (srec) {
-    ox = cams[i1].C[0]; oy = cams[i1].C[1]; oz = cams[i1].C[2];
-    const long long nb0 = nb_off[i1];
-    nbw = ((unsigned)nb0 << 8) | (unsigned)(nb_off[i1 + 1] - nb0);
-  }
+  const long long g1 = seg_off[blk_img[b]];
   const long long lbase = blk_line_base[b];
   const long long s0 = r0 * mult;  // the group's first staging slot (mult slots per match row)
   static_assert(sizeof(CRec) == 8 * 16, "record size in 16-byte units");
@@ -741,20 +731,6 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
       // perm != nullptr: the records stay where stage B staged them and the consumers read them through
       // perm[final position] = staging slot (4 bytes per candidate instead of moving 144)
       if (perm) perm[pos] = (unsigned)(s0 + e);
-      if (srec) {
-        // the scoring kernel's view of the candidate (lt_geom.h: SRec), at its final position.  The guard radii are
-        // rounded UP (x (1 + 2e-7) covers the conversion): the sweep may only reject what the exact gate rejects;
-        // a non-positive / NaN depth gives inf, i.e. no early exit for this candidate.
-        const CRec &c = st_r[s0 + e];
-        const double zs = c.depth[0] + kEps, ze = c.depth[1] + kEps;
-        const double gsd = (zs > 0.0) ? guard * zs : 1e300, ged = (ze > 0.0) ? guard * ze : 1e300;
-        float4 *dst = reinterpret_cast<float4 *>(srec + pos);
-        dst[0] = float4{(float)c.dir[0], (float)c.dir[1], (float)c.dir[2], __int_as_float(crec_slot(c))};
-        dst[1] = float4{(float)(c.s[0] - ox), (float)(c.e[0] - ox), (float)(c.s[1] - oy), (float)(c.e[1] - oy)};
-        dst[2] = float4{(float)(c.s[2] - oz), (float)(c.e[2] - oz), (float)(gsd * (1.0 + 2e-7)), (float)(ged * (1.0 + 2e-7))};
-        dst[3] = float4{__uint_as_float((unsigned)toff), __uint_as_float(n_tris[key]), __uint_as_float(nbw),
-                        __uint_as_float((unsigned)(s0 + e))};
-      }
       // (writing the scoring kernel's CandMeta record here instead of running k_cand_meta was measured:
       // +9 us in this kernel against 5 us for the separate pass)
     }
@@ -915,13 +891,12 @@ void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const 
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const CRec *st_r, const double *st_unc,
-                  const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, int mult, unsigned *perm,
-                  SRec *srec, const Cam *cams, const unsigned *n_tris, const long long *nb_off, double guard) {
+                  const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, int mult, unsigned *perm) {
   if (n_blk <= 0 || max_rows <= 0) return;
   const int n_groups = gen_groups(max_rows);
   hipLaunchKernelGGL(k_place, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
                      blk_line_base, base_bl, wave_count, tri_off, st_r, st_unc, st_key, cand, cand_unc, cand_node, n_groups,
-                     mult, perm, perm ? srec : nullptr, cams, n_tris, nb_off, guard);
+                     mult, perm);
 }
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,

@@ -39,7 +39,7 @@ def _same(a, b):
 def clean_env():
     keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES",
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
-            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_SCORE_OLD", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_TEST_PAIR_CAP")
+            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TEST_SCORE_F64")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -420,46 +420,29 @@ def test_per_kernel_event_levels(gpu_lib, clean_env):
 
 
 @pytest.mark.parametrize("topk,n_nb", [(10, 6), (60, 13)])
-def test_sweep_record_scoring_equals_permutation_scoring(gpu_lib, clean_env, topk, n_nb):
-    """Scoring on sweep records (round 4: k_place writes a 64-byte single-precision record per candidate at its final
-    position; k_sweep_rec streams the windows and lists the pairs that pass the conservative guards, k_dense_rec evaluates
-    them tile by tile, heaviest tile first) must give the bits of k_score3 through the permutation (LT_SCORE_OLD): same
-    pair_score, same maxima and ordered sums; only WHICH pairs reach the exact evaluation may differ by the guards'
-    rounding (another origin, radii rounded up).  Also: the fused kernel on the same records (LT_SCORE_FUSED), a pair list
-    that is too small (the run is repeated with the fused kernel), the double-precision sweep, tiles in natural order, no
-    guards at all.  The second scene has nodes of up to 106 candidates: windows beyond one LDS chunk (128 entries)."""
+def test_scoring_sweep_forms_agree(gpu_lib, clean_env, topk, n_nb):
+    """k_score3's single-precision conservative sweep against the double-precision sweep (LT_TEST_SCORE_F64), tiles in
+    natural order instead of cost classes (window bounds from the lanes' records), and no guards at all (every pair of a
+    node evaluated exactly): same bits everywhere; only WHICH pairs reach pair_score differs.  The second scene has nodes
+    of up to 106 candidates: windows beyond one LDS chunk (79 of its 624 tiles have 129-197 window entries)."""
     sc = syn.make_scene(n_views=14, n_segs=140, n_neighbors=n_nb, seed=77, topk=topk)
     cfg = syn.default_triangulation_cfg(debug_mode=True)
-    new = _results(run_product(sc, cfg, topk=topk))
-    assert new[5]["candidates"] > 1000
-    if topk > 10:  # (checked with the oracle: 79 of the 624 tiles of this scene have windows of 129-197 entries)
-        assert np.diff(new[0]["off"]).max() > 100, "the scene is meant to have windows beyond one chunk"
-    os.environ["LT_SCORE_OLD"] = "1"
-    old = _results(run_product(sc, cfg, topk=topk))
-    _same(new, old)
-    assert 0.8 * old[4]["pairs_eval"] <= new[4]["pairs_eval"] <= 1.25 * old[4]["pairs_eval"] + 64
-    del os.environ["LT_SCORE_OLD"]
-    os.environ["LT_SCORE_FUSED"] = "1"
-    fused = _results(run_product(sc, cfg, topk=topk))
-    _same(new, fused)
-    assert fused[4]["pairs_eval"] == new[4]["pairs_eval"]  # the same sweep on the same records
-    del os.environ["LT_SCORE_FUSED"]
-    os.environ["LT_TEST_PAIR_CAP"] = "64"          # one pair per region: device flag 7, repeated with the fused kernel
-    over = _results(run_product(sc, cfg, topk=topk))
-    _same(new, over)
-    del os.environ["LT_TEST_PAIR_CAP"]
+    base = _results(run_product(sc, cfg, topk=topk))
+    assert base[5]["candidates"] > 1000
+    if topk > 10:
+        assert np.diff(base[0]["off"]).max() > 100, "the scene is meant to have windows beyond one chunk"
     os.environ["LT_TEST_SCORE_F64"] = "1"
     f64 = _results(run_product(sc, cfg, topk=topk))
-    _same(new, f64)
+    _same(base, f64)
     del os.environ["LT_TEST_SCORE_F64"]
-    os.environ["LT_TEST_NO_TILE_CLASSES"] = "1"   # fused kernel, tiles in natural order: window bounds from the lanes' records
+    os.environ["LT_TEST_NO_TILE_CLASSES"] = "1"
     nat = _results(run_product(sc, cfg, topk=topk))
-    _same(new, nat)
+    _same(base, nat)
     del os.environ["LT_TEST_NO_TILE_CLASSES"]
-    os.environ["LT_TEST_NO_SCORE_GUARDS"] = "1"   # every pair of a node evaluated exactly (segments beyond the first)
+    os.environ["LT_TEST_NO_SCORE_GUARDS"] = "1"
     allp = _results(run_product(sc, cfg, topk=topk))
-    _same(new, allp)
-    assert allp[4]["pairs_eval"] > new[4]["pairs_eval"]
+    _same(base, allp)
+    assert allp[4]["pairs_eval"] > base[4]["pairs_eval"]
 
 
 def test_second_batch_after_compute_tracks_device_and_host_tail(gpu_lib, oracle, clean_env):
