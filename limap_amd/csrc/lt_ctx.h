@@ -186,6 +186,8 @@ struct lt_ctx {
   DevBuf d_item_off, d_masks, d_mask_cnt, d_mask_pos;
   DevBuf d_rm_line, d_rm_act, d_rm_edges, d_rm_cnt;  // lt_ts_remerge_once: kept across the passes of a remerge
   std::vector<unsigned long long> h_rm_edges;
+  std::vector<unsigned long long> h_rm_back;  // count + first edges of a remerge pass (one copy)
+  std::vector<double> h_rm_in;                // host image of a pass's input (lines | active flags)
   DevBuf d_hcand, d_hlite;  // split host-side view of the candidates (debug read-outs), see materialize_compact
   DevBuf d_cand, d_lite, d_tri_off, d_score, d_best_idx, d_edge_flag, d_nvalid, d_edge_off, d_edges;
   DevBuf d_best_c, d_best_score, d_best_src, d_ntris, d_err;

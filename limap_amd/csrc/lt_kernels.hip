@@ -1179,48 +1179,80 @@ void launch_edge_fill(hipStream_t st, long long G, const long long *tri_off, con
 // bit for bit.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTrackChunk = 64;  // tracks j per workgroup column: small, so that a few thousand tracks already fill the GPU
+// Two phases per wave (round 4; the one-phase form ran check3d -- ~700 instructions -- for the whole wave whenever ONE lane's
+// pair passed the cosine test: 100-165 us for 1 340 tracks): a sweep of the 64 x 64 pairs of the wave with the cosine test
+// only (unit directions of the j tracks once per workgroup in LDS) that queues the survivors in LDS, then check3d over the
+// queue with every lane busy.  Same tests on the same operands, same edges.
 __global__ void __launch_bounds__(256)
 k_track_connect(int T, const double *__restrict__ line7, const unsigned char *__restrict__ active, int all_active,
                 LinkCfg3 cfg, double cos_guard, unsigned long long *__restrict__ edges,
                 unsigned long long capacity, unsigned long long *__restrict__ n_edges) {
+  __shared__ double s_lj[kTrackChunk][7];     // the j tracks of this column
+  __shared__ double s_dj[kTrackChunk][3];     // their unit directions
+  __shared__ double s_li[4][64][7];           // per wave: its i tracks
+  __shared__ unsigned short s_q[4][64 * kTrackChunk];  // per wave: surviving pairs (lane of i << 8 | j - j0)
+  const int wave = threadIdx.x >> 6, lane = lane_id();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j0 = blockIdx.y * kTrackChunk;
   const int j1 = min(T, j0 + kTrackChunk);
   const bool live = (i < T) && active[i];
-  L3 li{mk3(0, 0, 0), mk3(0, 0, 0)};
+  if (__syncthreads_or(live ? 1 : 0) == 0) return;  // no active track among the workgroup's 256
+  if (threadIdx.x < (unsigned)(j1 - j0)) {
+    const double *q = line7 + 7 * (long long)(j0 + (int)threadIdx.x);
+    for (int k = 0; k < 7; ++k) s_lj[threadIdx.x][k] = q[k];
+    const d3 dj = dir(L3{mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5])});
+    s_dj[threadIdx.x][0] = dj.x; s_dj[threadIdx.x][1] = dj.y; s_dj[threadIdx.x][2] = dj.z;
+  }
   d3 di = mk3(0, 0, 0);
-  double ui = 0.0;
   if (live) {
     const double *p = line7 + 7 * (long long)i;
-    li.s = mk3(p[0], p[1], p[2]);
-    li.e = mk3(p[3], p[4], p[5]);
-    ui = p[6];
-    di = dir(li);
+    for (int k = 0; k < 7; ++k) s_li[wave][lane][k] = p[k];
+    di = dir(L3{mk3(p[0], p[1], p[2]), mk3(p[3], p[4], p[5])});
   }
-  const double dep[2] = {0.0, 0.0};
-  for (int j = j0; j < j1; ++j) {  // j is wave-uniform
+  __syncthreads();
+  // phase 1: which pairs go on (j is wave-uniform)
+  int qn = 0;
+  for (int j = j0; j < j1; ++j) {
     bool test = live && (j != i);
     if (test && all_active) {
       if (i < j && ((i + j) & 1) == 0) test = false;
       if (i > j && ((i + j) & 1) == 1) test = false;
     }
-    bool hit = false;
-    if (test) {
-      const double *q = line7 + 7 * (long long)j;
-      L3 lj{mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5])};
-      bool go = true;
-      if (cfg.use_angle) go = !(fabs(dot(di, dir(lj))) < cos_guard);
-      if (go) hit = check3d(cfg, li, lj, ui, q[6], dep);
+    if (test && cfg.use_angle) {
+      const d3 dj = mk3(s_dj[j - j0][0], s_dj[j - j0][1], s_dj[j - j0][2]);
+      test = !(fabs(dot(di, dj)) < cos_guard);
     }
-    // one counter update per wave and j (a device-scope atomic per edge would serialise)
+    const unsigned long long m = __ballot(test);
+    if (m) {
+      if (test) s_q[wave][qn + __popcll(m & lanemask_lt())] = (unsigned short)((lane << 8) | (j - j0));
+      qn += __popcll(m);
+    }
+  }
+  wave_lds_sync();
+  // phase 2: the exact check, one pair per lane
+  const double dep[2] = {0.0, 0.0};
+  for (int q0 = 0; q0 < qn; q0 += 64) {
+    const int p = q0 + lane;
+    bool hit = false;
+    int ii = 0, jj = 0;
+    if (p < qn) {
+      const unsigned e = s_q[wave][p];
+      const int il = (int)(e >> 8), jl = (int)(e & 0xFFu);
+      const double *a = s_li[wave][il], *b = s_lj[jl];
+      ii = (int)(blockIdx.x * blockDim.x) + wave * 64 + il;
+      jj = j0 + jl;
+      hit = check3d(cfg, L3{mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5])}, L3{mk3(b[0], b[1], b[2]), mk3(b[3], b[4], b[5])},
+                    a[6], b[6], dep);
+    }
+    // one counter update per wave and round (a device-scope atomic per edge would serialise)
     const unsigned long long m = __ballot(hit);
     if (m) {
       unsigned long long base = 0;
-      if (lane_id() == 0) base = atomicAdd(n_edges, (unsigned long long)__popcll(m));
+      if (lane == 0) base = atomicAdd(n_edges, (unsigned long long)__popcll(m));
       base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), 0) << 32) | (unsigned)__shfl((int)(base & 0xFFFFFFFFull), 0);
       if (hit) {
         const unsigned long long slot = base + (unsigned long long)__popcll(m & lanemask_lt());
-        const unsigned long long a = (unsigned long long)min(i, j), b = (unsigned long long)max(i, j);
+        const unsigned long long a = (unsigned long long)min(ii, jj), b = (unsigned long long)max(ii, jj);
         if (slot < capacity) edges[slot] = (a << 32) | b;
       }
     }

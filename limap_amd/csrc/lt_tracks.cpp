@@ -35,19 +35,28 @@ struct Member {
 struct TrackFull {
   double line[7];  // start, end, uncertainty
   bool active = true;
+  // `line` is aggregate(m, agg_k) bit for bit (the aggregator is a pure function of the members in their order and of
+  // num_outliers; lt_tail.h), or -1 when that is not known: lets the filters and the remerge skip re-aggregating tracks
+  // whose members did not change -- the reference recomputes them and gets the same bits
+  int agg_k = -1;
   std::vector<Member> m;
 };
 
 d2 project(const Cam &c, const double *p) { return cam_project(c, mk3(p[0], p[1], p[2])); }
 
 void reaggregate(TrackFull &t, int num_outliers) {
-  std::vector<const Cand *> lines;
-  std::vector<double> scores;
-  for (const Member &mm : t.m) {
-    lines.push_back(&mm.l3d);
-    scores.push_back(mm.score);
-  }
-  aggregate(lines, scores, num_outliers, t.line);
+  static thread_local AggScratch scratch;
+  static thread_local std::vector<double> scores;
+  scores.resize(t.m.size());
+  for (size_t k = 0; k < t.m.size(); ++k) scores[k] = t.m[k].score;
+  aggregate_impl([&](int i) -> const Cand & { return t.m[(size_t)i].l3d; }, scores.data(), (int)t.m.size(), num_outliers,
+                 t.line, scratch);
+  t.agg_k = num_outliers;
+}
+
+int distinct(std::vector<int> &v) {  // number of different values (the size of the reference's std::set)
+  std::sort(v.begin(), v.end());
+  return (int)(std::unique(v.begin(), v.end()) - v.begin());
 }
 
 double multiplier(double score_th) { return 1.0 / std::sqrt(-std::log(score_th) * 2.0); }
@@ -69,9 +78,11 @@ lt_trackset *lt_ts_from_ctx(lt_ctx *ctx) {
   lt_trackset *ts = new lt_trackset();
   const lt_host::TrackStore &src = ctx->tracks;
   ts->tracks.resize(src.size());
-  for (size_t t = 0; t < src.size(); ++t) {
+  lt_host::pool_for((long long)src.size(), 32, [&](long long t0_, long long t1_) {
+  for (size_t t = (size_t)t0_; t < (size_t)t1_; ++t) {
     TrackFull &dst = ts->tracks[t];
     std::memcpy(dst.line, src.line7.data() + 7 * t, sizeof(dst.line));
+    dst.agg_k = ctx->cfg.num_outliers_aggregator;  // lt_compute_tracks aggregated exactly these members with it
     const size_t a = (size_t)src.off[t], n = (size_t)src.off[t + 1] - a;
     dst.m.resize(n);
     for (size_t k = 0; k < n; ++k) {
@@ -83,6 +94,7 @@ lt_trackset *lt_ts_from_ctx(lt_ctx *ctx) {
       mm.l3d = ctx->best_c[g];
     }
   }
+  });
   return ts;
 }
 
@@ -160,9 +172,13 @@ int lt_ts_filter_by_reprojection(lt_ctx *ctx, lt_trackset *ts, double th_angular
   std::vector<char> keep((size_t)nT, 0);
   lt_host::pool_for(nT, kTrackGrain, [&](long long t0_, long long t1_) {
   for (long long ti = t0_; ti < t1_; ++ti) {
-    const TrackFull &t = ts->tracks[ti];
+    TrackFull &t = ts->tracks[ti];
     TrackFull nt;
-    for (const Member &mm : t.m) {
+    size_t n_kept = 0;
+    static thread_local std::vector<char> ok;
+    ok.assign(t.m.size(), 0);
+    for (size_t k = 0; k < t.m.size(); ++k) {
+      const Member &mm = t.m[k];
       const Cam &c = ctx->h_cams[ctx->id2idx.at(mm.img_id)];
       L2 det{mk2(mm.l2d[0], mm.l2d[1]), mk2(mm.l2d[2], mm.l2d[3])};
       L2 proj{project(c, t.line), project(c, t.line + 3)};
@@ -171,10 +187,26 @@ int lt_ts_filter_by_reprojection(lt_ctx *ctx, lt_trackset *ts, double th_angular
       double ds, de;
       perp_oneway(det, proj, &ds, &de);  // dist_endpoints_perpendicular_oneway (line_dists.h:113-120)
       if (dmax(ds, de) > th_perp2d) continue;
-      nt.m.push_back(mm);
+      ok[k] = 1;
+      ++n_kept;
     }
-    if (nt.m.empty()) continue;
-    reaggregate(nt, num_outliers);
+    if (n_kept == 0) continue;
+    if (n_kept == t.m.size()) {
+      // every support stays: the new track has the old one's members; its line is their aggregate -- which the old
+      // line already is when it was aggregated with the same num_outliers
+      nt.m = std::move(t.m);
+      if (t.agg_k == num_outliers) {
+        std::memcpy(nt.line, t.line, sizeof(nt.line));
+        nt.agg_k = t.agg_k;
+      } else {
+        reaggregate(nt, num_outliers);
+      }
+    } else {
+      nt.m.reserve(n_kept);
+      for (size_t k = 0; k < t.m.size(); ++k)
+        if (ok[k]) nt.m.push_back(t.m[k]);
+      reaggregate(nt, num_outliers);
+    }
     nt.active = true;  // a fresh LineTrack in the reference
     out[ti] = std::move(nt);
     keep[ti] = 1;
@@ -198,7 +230,8 @@ int lt_ts_filter_by_sensitivity(lt_ctx *ctx, lt_trackset *ts, double th_angular3
     const TrackFull &t = ts->tracks[ti];
     d3 s = mk3(t.line[0], t.line[1], t.line[2]), e = mk3(t.line[3], t.line[4], t.line[5]);
     d3 dir3 = unit(sub(e, s));
-    std::set<int> imgs;
+    static thread_local std::vector<int> imgs;  // (std::set<int> in the reference: only its size is used)
+    imgs.clear();
     for (const Member &mm : t.m) {
       auto it = ctx->id2idx.find(mm.img_id);
       if (it == ctx->id2idx.end()) {
@@ -209,9 +242,9 @@ int lt_ts_filter_by_sensitivity(lt_ctx *ctx, lt_trackset *ts, double th_angular3
       d2 ps = cam_project(c, s), pe = cam_project(c, e);
       d3 ray = cam_ray(c, d2{0.5 * (ps.x + pe.x), 0.5 * (ps.y + pe.y)});
       double sens = 90 - acos(fabs(dot(dir3, ray))) * 180.0 / kPi;
-      if (!(sens > th_angular3d)) imgs.insert(mm.img_id);
+      if (!(sens > th_angular3d)) imgs.push_back(mm.img_id);
     }
-    keep[ti] = (int)imgs.size() >= min_supports;
+    keep[ti] = distinct(imgs) >= min_supports;
   }
   });
   if (bad.load()) return fail(ctx, LT_ERR_ARGUMENT, "track references an unknown image id");
@@ -231,7 +264,8 @@ int lt_ts_filter_by_overlap(lt_ctx *ctx, lt_trackset *ts, double th_overlap, int
   lt_host::pool_for(nT, kTrackGrain, [&](long long t0_, long long t1_) {
   for (long long ti = t0_; ti < t1_; ++ti) {
     const TrackFull &t = ts->tracks[ti];
-    std::set<int> imgs;
+    static thread_local std::vector<int> imgs;
+    imgs.clear();
     for (const Member &mm : t.m) {
       auto it = ctx->id2idx.find(mm.img_id);
       if (it == ctx->id2idx.end()) {
@@ -241,9 +275,9 @@ int lt_ts_filter_by_overlap(lt_ctx *ctx, lt_trackset *ts, double th_overlap, int
       const Cam &c = ctx->h_cams[it->second];
       L2 proj{project(c, t.line), project(c, t.line + 3)};
       L2 det{mk2(mm.l2d[0], mm.l2d[1]), mk2(mm.l2d[2], mm.l2d[3])};
-      if (overlap_oneway(proj, det) >= th_overlap) imgs.insert(mm.img_id);
+      if (overlap_oneway(proj, det) >= th_overlap) imgs.push_back(mm.img_id);
     }
-    keep[ti] = (int)imgs.size() >= min_supports;
+    keep[ti] = distinct(imgs) >= min_supports;
   }
   });
   if (bad.load()) return fail(ctx, LT_ERR_ARGUMENT, "track references an unknown image id");
@@ -270,47 +304,58 @@ int lt_ts_remerge_once(lt_ctx *ctx, lt_trackset *ts, const lt_config *linker_cfg
   double th = l3.th_angle * (1.0 + 1e-6) + 1e-6;
   double cos_guard = (th < 90.0) ? std::cos(th * kPi / 180.0) : -1.0;
 
-  std::vector<double> line7(7 * (size_t)T);
-  std::vector<unsigned char> active((size_t)T);
+  // host image of the device input: [7 T doubles: the track lines | T bytes: active flags], one copy
+  std::vector<double> &inbuf = ctx->h_rm_in;
+  const size_t in_bytes = 56 * (size_t)T + (size_t)T;
+  inbuf.resize((in_bytes + 7) / 8);
+  unsigned char *active = reinterpret_cast<unsigned char *>(inbuf.data() + 7 * (size_t)T);
   int n_active = 0;
   for (int t = 0; t < T; ++t) {
-    std::memcpy(&line7[7 * (size_t)t], ts->tracks[t].line, 56);
+    std::memcpy(&inbuf[7 * (size_t)t], ts->tracks[t].line, 56);
     active[t] = ts->tracks[t].active ? 1 : 0;
     n_active += active[t];
   }
   // the device buffers and the edge list live in the context: a remerge to its fixed point calls this several times
-  DevBuf &d_line = ctx->d_rm_line, &d_act = ctx->d_rm_act, &d_edges = ctx->d_rm_edges, &d_cnt = ctx->d_rm_cnt;
+  DevBuf &d_in = ctx->d_rm_line, &d_edges = ctx->d_rm_edges;
   hipStream_t st = ctx->stream;
   std::vector<unsigned long long> &edges = ctx->h_rm_edges;
   edges.clear();
+  // d_edges = [edge count | edges ...]: count and the first kFirst edges come back in ONE copy behind the kernel
+  constexpr unsigned long long kFirst = 4095;
   unsigned long long capacity = std::max<unsigned long long>(1ull << 16, 32ull * (unsigned long long)T);
   int rc = LT_OK;
+  std::vector<unsigned long long> &back = ctx->h_rm_back;
+  back.resize((size_t)kFirst + 1);
   for (int attempt = 0; attempt < 8; ++attempt) {
-    if (!d_line.ensure(line7.size() * 8) || !d_act.ensure((size_t)T) || !d_edges.ensure(capacity * 8) || !d_cnt.ensure(8)) {
+    if (!d_in.ensure(inbuf.size() * 8) || !d_edges.ensure((capacity + 1) * 8)) {
       rc = fail(ctx, LT_ERR_HIP, "hipMalloc failed in remerge");
       break;
     }
-    unsigned long long n = 0;
-    if (hipMemcpyAsync(d_line.p, line7.data(), line7.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(d_act.p, active.data(), (size_t)T, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemsetAsync(d_cnt.p, 0, 8, st) != hipSuccess) {
+    if (hipMemcpyAsync(d_in.p, inbuf.data(), inbuf.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(d_edges.p, 0, 8, st) != hipSuccess) {
       rc = fail(ctx, LT_ERR_HIP, "HIP copy failed in remerge");
       break;
     }
-    launch_track_connect(st, T, d_line.as<double>(), d_act.as<unsigned char>(), n_active == T ? 1 : 0, l3, cos_guard,
-                         d_edges.as<unsigned long long>(), capacity, d_cnt.as<unsigned long long>());
-    if (hipMemcpyAsync(&n, d_cnt.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+    launch_track_connect(st, T, d_in.as<double>(), reinterpret_cast<const unsigned char *>(d_in.as<double>() + 7 * (size_t)T),
+                         n_active == T ? 1 : 0, l3, cos_guard, d_edges.as<unsigned long long>() + 1, capacity,
+                         d_edges.as<unsigned long long>());
+    if (hipMemcpyAsync(back.data(), d_edges.p, (kFirst + 1) * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) {
       rc = fail(ctx, LT_ERR_HIP, "HIP failure in k_track_connect");
       break;
     }
+    const unsigned long long n = back[0];
     if (n > capacity) {  // rare: more edges than reserved, run again with room for all of them
       capacity = n + 1024;
       continue;
     }
-    edges.resize((size_t)n);
-    if (n > 0 && hipMemcpy(edges.data(), d_edges.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess)
-      rc = fail(ctx, LT_ERR_HIP, "HIP copy failed in remerge");
+    edges.assign(back.begin() + 1, back.begin() + 1 + (size_t)std::min(n, kFirst));
+    if (n > kFirst) {
+      edges.resize((size_t)n);
+      if (hipMemcpy(edges.data() + kFirst, d_edges.as<unsigned long long>() + 1 + kFirst, (size_t)(n - kFirst) * 8,
+                    hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(ctx, LT_ERR_HIP, "HIP copy failed in remerge");
+    }
     break;
   }
   if (rc) return rc;
@@ -340,16 +385,23 @@ int lt_ts_remerge_once(lt_ctx *ctx, lt_trackset *ts, const lt_config *linker_cfg
     if (labels[t] == -1) labels[t] = labels[uf_root(t, parent)];
   std::vector<TrackFull> out((size_t)n_groups);
   std::vector<int> counter((size_t)n_groups, 0);
+  for (int t = 0; t < T; ++t) counter[labels[t]]++;
   for (int t = 0; t < T; ++t) {
     TrackFull &g = out[labels[t]];
-    counter[labels[t]]++;
-    g.m.insert(g.m.end(), ts->tracks[t].m.begin(), ts->tracks[t].m.end());
+    if (counter[labels[t]] == 1) {
+      // a group of one: the new track has this track's members, and its line is their aggregate -- the line it has
+      g.m = std::move(ts->tracks[t].m);
+      g.agg_k = ts->tracks[t].agg_k;
+      std::memcpy(g.line, ts->tracks[t].line, sizeof(g.line));
+    } else {
+      g.m.insert(g.m.end(), ts->tracks[t].m.begin(), ts->tracks[t].m.end());
+    }
   }
   lt_host::pool_for((long long)n_groups, kTrackGrain, [&](long long g0_, long long g1_) {
     for (long long gi = g0_; gi < g1_; ++gi) {
-      // a group of one keeps its track as it is in the reference only as far as `active` goes: the line is
-      // re-aggregated either way (merging.cc:629-640)
-      reaggregate(out[gi], num_outliers);
+      // the reference re-aggregates every group (merging.cc:629-640); for a group of one whose line already is the
+      // aggregate of its members with this num_outliers that gives the same bits
+      if (counter[gi] != 1 || out[gi].agg_k != num_outliers) reaggregate(out[gi], num_outliers);
       out[gi].active = counter[gi] != 1;
     }
   });
