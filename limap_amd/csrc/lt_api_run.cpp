@@ -198,7 +198,7 @@ int finish_run(lt_ctx *ctx) {
   }
   if (derr == 4) return fail(ctx, LT_ERR_RUNTIME, "internal: the scan of the node counts did not complete");
   if (derr == 3)
-    return fail(ctx, LT_ERR_RUNTIME, "the one-point proposal supports at most 250 shared points per connection");
+    return fail(ctx, LT_ERR_RUNTIME, "more than 65 000 candidates on one connection of the exhaustive mode (16-bit counts)");
   if (derr == 2)
     return fail(ctx, LT_ERR_RUNTIME, "map::at: a point shared by two lines has a point3D_id that is not among the SfM points");
   if (derr != 0) return fail(ctx, LT_ERR_RUNTIME, "IndexError! Out-of-index matches detected on the device");
@@ -303,15 +303,18 @@ int lt_run_device_async(lt_ctx *ctx) {
     const bool many_on = pts_any && !ctx->cfg.disable_many_points_triangulation;
     const bool one_on = pts_any && !ctx->cfg.disable_one_point_triangulation;
     const bool pts_on = pts_any;
-    // staging slots per match row: many-points, one candidate per shared point (at most the most points any
-    // segment has, capped at kMaxOnePoints = 250 -- the kernel flags a connection with more), vp(l1), vp(l2), algebraic
-    int mult = (vp_on || pts_on) ? 4 : 1;
-    if (one_on) mult += (int)std::min<long long>(ctx->max_seg_pts, kMaxOnePoints);
-    if (mult > 1 && (long long)mult * P >= (1ll << 32) - 1)
-      return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch for the extra proposals");
-    ENSURE(ctx, ctx->d_st_c, sizeof(CRec) * Pn * mult); ENSURE(ctx, ctx->d_st_l, sizeof(double) * Pn * mult);
-    ENSURE(ctx, ctx->d_st_key, 4 * Pn * mult);
+    // Without extra proposals a match row yields at most one candidate: the staging has one slot per row.  With them a
+    // connection yields a variable number (many-points, one per shared point -- no limit, as in the reference --, vp(l1),
+    // vp(l2), algebraic): stage B runs twice, counting then storing, and the staging gets the exact size in between.
+    const bool extras = vp_on || pts_on;
+    long long staged_total = -1;  // extras: candidates of the batch, known on the host after the counting run
+    if (!extras) {
+      ENSURE(ctx, ctx->d_st_c, sizeof(CRec) * Pn); ENSURE(ctx, ctx->d_st_l, sizeof(double) * Pn);
+      ENSURE(ctx, ctx->d_st_key, 4 * Pn);
+    }
     ENSURE(ctx, ctx->d_wave_count, 4 * (size_t)(n_waves + 1));
+    if (extras) ENSURE(ctx, ctx->d_wave_pos, 8 * (size_t)(n_waves + 1));
+    const long long *group_base = extras ? ctx->d_wave_pos.as<long long>() : nullptr;
     ENSURE(ctx, ctx->d_ntris_u, 4 * (size_t)(G + 1));
     if (fast) {
       // per-(block, line) counters: k_node_prefix zeroes every counter it reads, so the array only has to
@@ -338,6 +341,7 @@ int lt_run_device_async(lt_ctx *ctx) {
       ENSURE(ctx, ctx->d_st_row, 8 * Pn);
       ENSURE(ctx, ctx->d_surv_count, 4 * (size_t)(n_slots_all + 1));
       if (!ctx->d_seg_gates.p) return fail(ctx, LT_ERR_STATE, "segment gate records missing (Init not run?)");
+      auto gen = [&](int phase) {
       launch_gen_split(st, ctx->n_blk, ctx->max_rows, gcfg, ctx->d_m_off.as<long long>(), ctx->d_m_pairs.as<int>(),
                        ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(),
                        ctx->d_seg_off.as<long long>(), ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(),
@@ -349,7 +353,27 @@ int lt_run_device_async(lt_ctx *ctx) {
                        vp_on ? ctx->d_seg_has_vp.as<unsigned char>() : nullptr,
                        pts_on ? ctx->d_seg_pt_off.as<long long>() : nullptr, pts_on ? ctx->d_seg_pts.p : nullptr,
                        (pts_on && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr, ctx->d_err.as<int>(),
-                       many_on ? 1 : 0, one_on ? 1 : 0, mult);
+                       many_on ? 1 : 0, one_on ? 1 : 0, group_base, phase);
+      };
+      if (!extras) {
+        gen(0);
+      } else {
+        gen(1);  // k_gates + the counting run of stage B
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_wave_count.as<unsigned>() + n_waves, 0, 4, st));
+        size_t tmp = scan_temp_bytes_u32_to_i64(n_waves + 1);
+        ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(tmp, 16));
+        if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, tmp, n_waves + 1, ctx->d_wave_count.as<unsigned>(),
+                                   ctx->d_wave_pos.as<long long>()) != 0)
+          return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+        HIPCHK(ctx, hipMemcpyAsync(&staged_total, ctx->d_wave_pos.as<long long>() + n_waves, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (staged_total >= (1ll << 32) - 1)
+          return fail(ctx, LT_ERR_ARGUMENT, "too many candidates in one batch (>= 2^32-1): triangulate the images in smaller batches");
+        const size_t Sn = (size_t)std::max<long long>(staged_total, 1);
+        ENSURE(ctx, ctx->d_st_c, sizeof(CRec) * Sn); ENSURE(ctx, ctx->d_st_l, sizeof(double) * Sn);
+        ENSURE(ctx, ctx->d_st_key, 4 * Sn);
+        gen(2);  // the storing run, lists back to back
+      }
     }
     // with the per-kernel events on, the one after k_tri_rows also ends the generation stage
     if (fine_gen && ctx->n_blk > 0 && ctx->max_rows > 0) ev_gen_end = 10;
@@ -370,10 +394,12 @@ int lt_run_device_async(lt_ctx *ctx) {
       // bound -- one candidate per staging slot -- fits kCountFreeBytes, the arrays get that size and the
       // whole run is enqueued without a host round trip (the count then arrives with the error flag);
       // otherwise (or with LT_TEST_SYNC_COUNT) one 8-byte copy + stream sync fetches the exact count.
-      const long long bound = P * (long long)mult;
+      const long long bound = P;
       constexpr long long kCountFreeBytes = 8ll << 30;
       const long long per_cand = (long long)(sizeof(CRec) + 8 + 8 + 4 + 4) + (long long)cand_meta_bytes();
-      if (ctx->h_pinned && bound * per_cand <= kCountFreeBytes && !getenv("LT_TEST_SYNC_COUNT")) {
+      if (extras) {
+        C_known = staged_total;  // the counting run of stage B already brought the count to the host
+      } else if (ctx->h_pinned && bound * per_cand <= kCountFreeBytes && !getenv("LT_TEST_SYNC_COUNT")) {
         C_known = -1;
         C_bound = bound;
       } else {
@@ -426,14 +452,14 @@ int lt_run_device_async(lt_ctx *ctx) {
                    ctx->d_seg_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
                    ctx->d_base_bl.as<unsigned>(), ctx->d_wave_count.as<unsigned>(), ctx->d_tri_off.as<long long>(),
                    ctx->d_st_c.as<CRec>(), ctx->d_st_l.as<double>(), ctx->d_st_key.as<unsigned>(),
-                   ctx->d_cand.as<CRec>(), ctx->d_lite.as<double>(), ctx->d_cand_node.as<unsigned>(), mult,
+                   ctx->d_cand.as<CRec>(), ctx->d_lite.as<double>(), ctx->d_cand_node.as<unsigned>(), group_base,
                    perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
     } else {
       ENSURE(ctx, ctx->d_keys, 4 * Cn); ENSURE(ctx, ctx->d_rows, 4 * Cn);
       ENSURE(ctx, ctx->d_skeys, 4 * Cn); ENSURE(ctx, ctx->d_srows, 4 * Cn);
       launch_pack_keys(st, ctx->n_blk, ctx->max_rows, ctx->d_m_off.as<long long>(),
                        ctx->d_wave_count.as<unsigned>(), ctx->d_wave_pos.as<long long>(),
-                       ctx->d_st_key.as<unsigned>(), ctx->d_keys.as<unsigned>(), ctx->d_rows.as<unsigned>(), mult);
+                       ctx->d_st_key.as<unsigned>(), ctx->d_keys.as<unsigned>(), ctx->d_rows.as<unsigned>(), group_base);
       if (C_known > 0) {
         int end_bit = bits_for(G + 1);
         size_t tmp = sort_temp_bytes(C_known, end_bit);
@@ -467,7 +493,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     const int one_on = (pts_any && !ctx->cfg.disable_one_point_triangulation) ? 1 : 0;
     const double *sfm_xyz = (pts_any && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr;
     // (+ one ballot word: the plain mode scans the popcounts of the ballots directly, the word behind the last is 0)
-    ENSURE(ctx, ctx->d_masks, pts_any ? 64 * In : 8 * (In * n_masks + 1)); ENSURE(ctx, ctx->d_mask_cnt, 4 * (In + 1));
+    ENSURE(ctx, ctx->d_masks, pts_any ? 128 * In : 8 * (In * n_masks + 1)); ENSURE(ctx, ctx->d_mask_cnt, 4 * (In + 1));
     ENSURE(ctx, ctx->d_mask_pos, 8 * (In + 1));
     // Plain exhaustive mode (no VP / point proposals): pass 1 with the neighbour lines held in registers (k_gates_ex;
     // LT_TEST_EX_PASS1_BLOCK keeps the wave-per-(node, neighbour) form the VP variant uses), and, while the staging
@@ -516,7 +542,7 @@ int lt_run_device_async(lt_ctx *ctx) {
       launch_gen_exhaustive_pts(st, false, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
                                 ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
                                 ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
-                                ctx->d_masks.as<unsigned char>(), ctx->d_mask_cnt.as<unsigned>(), nullptr, nullptr,
+                                ctx->d_masks.as<unsigned short>(), ctx->d_mask_cnt.as<unsigned>(), nullptr, nullptr,
                                 nullptr, seg_vp, seg_has_vp, ctx->d_seg_pt_off.as<long long>(), ctx->d_seg_pts.p,
                                 sfm_xyz, ctx->d_err.as<int>(), many_on, one_on, ctx->d_blk_chunk_off.as<int>(),
                                 ctx->max_nb, ctx->max_chunks, ctx->d_seg_gates.p);
@@ -592,7 +618,7 @@ int lt_run_device_async(lt_ctx *ctx) {
       launch_gen_exhaustive_pts(st, true, P, gcfg, ctx->d_item_off.as<long long>(), G, ctx->d_node_img.as<int>(),
                                 ctx->d_nb_off.as<long long>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
                                 ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
-                                ctx->d_masks.as<unsigned char>(), ctx->d_mask_cnt.as<unsigned>(),
+                                ctx->d_masks.as<unsigned short>(), ctx->d_mask_cnt.as<unsigned>(),
                                 ctx->d_mask_pos.as<long long>(), ctx->d_cand.as<CRec>(), ctx->d_lite.as<double>(),
                                 seg_vp, seg_has_vp, ctx->d_seg_pt_off.as<long long>(), ctx->d_seg_pts.p, sfm_xyz,
                                 ctx->d_err.as<int>(), many_on, one_on, ctx->d_blk_chunk_off.as<int>(), ctx->max_nb,

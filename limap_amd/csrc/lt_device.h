@@ -66,7 +66,7 @@ void launch_fill_exhaustive(hipStream_t st, int n_blk, long long n_items, const 
 void launch_gen_exhaustive_pts(hipStream_t st, bool fill, long long n_items, const GenCfg &cfg,
                                const long long *item_off, long long G, const int *node_img, const long long *nb_off,
                                const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
-                               const PairRec *pairs, unsigned char *cnt8, unsigned *item_cnt,
+                               const PairRec *pairs, unsigned short *cnt8, unsigned *item_cnt,
                                const long long *mask_pos, CRec *out_r, double *out_unc, const double *seg_vp,
                                const unsigned char *seg_has_vp, const long long *seg_pt_off, const void *seg_pts,
                                const double *sfm_xyz, int *err_flag, int many_on, int one_on,

@@ -249,9 +249,6 @@ LT_HD void crec_split(const CRec &r, double unc, Cand *c, CandLite *l) {
 }
 LT_HD int crec_slot(const CRec &r) { return r.nb_slot & 0xFF; }
 LT_HD int crec_img(const CRec &r) { return (int)((unsigned)r.nb_slot >> 8); }
-// most shared points of a connection the one-point proposal handles (base_line_triangulator.cc:238-248 has no limit): a
-// matched row reserves that many staging slots, the exhaustive pass counts a connection's candidates in one byte
-constexpr int kMaxOnePoints = 250;
 LT_HD int lite_pack(int slot, int img) { return (img << 8) | (slot & 0xFF); }
 LT_HD int lite_slot(const CandLite &l) { return l.nb_slot & 0xFF; }
 LT_HD int lite_img(const CandLite &l) { return (int)((unsigned)l.nb_slot >> 8); }

@@ -40,7 +40,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3,
                       const double *seg_vp, const unsigned char *seg_has_vp, const long long *seg_pt_off,
                       const void *seg_pts, const double *sfm_xyz, int *err_flag, int many_on, int one_on,
-                      int mult);
+                      const long long *group_base, int phase);
 size_t seg_point_bytes();
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
@@ -49,10 +49,11 @@ void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const 
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const CRec *st_r, const double *st_unc,
-                  const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, int mult, unsigned *perm);
+                  const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, const long long *group_base,
+                  unsigned *perm);
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
-                      unsigned *keys_c, unsigned *src_c, int mult);
+                      unsigned *keys_c, unsigned *src_c, const long long *group_base);
 void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const CRec *st_r,
                     const double *st_unc, CRec *cand, double *cand_unc, unsigned *cand_node);
 void launch_host_view(hipStream_t st, long long C, const unsigned *perm, const CRec *rec, const double *unc, Cand *out_c,

@@ -643,7 +643,7 @@ k_fill_ex(int n_blk, long long n_items, GenCfg cfg, const long long *__restrict_
 // Exhaustive mode with the point-guided proposals (and, if set, the VP ones): per connection a variable
 // number of candidates in the reference's order many-points, one-point (one per shared point, ascending
 // point3D_id), vp(l1), vp(l2), algebraic (base_line_triangulator.cc:183-325).  Pass 1 (kFill == false)
-// counts them per connection (one byte each, <= 64 + 4) and per work item; pass 2 recomputes them and writes
+// counts them per connection (16 bits each: no practical limit on the shared points) and per work item; pass 2 recomputes them and writes
 // every valid one at  mask_pos[item] + (candidates of the lower lanes) + (rank within the connection).
 // This is the configuration of the reference's third CI run (exhaustive matcher + use_pointsfm).
 template <bool kFill>
@@ -652,7 +652,7 @@ k_gen_exhaustive_pts(long long n_items, GenCfg cfg, const long long *__restrict_
                      const int *__restrict__ node_img, const long long *__restrict__ nb_off,
                      const int *__restrict__ blk_nb, const long long *__restrict__ seg_off,
                      const Cam *__restrict__ cams, const Seg *__restrict__ segs,
-                     const PairRec *__restrict__ pairs, unsigned char *__restrict__ cnt8,
+                     const PairRec *__restrict__ pairs, unsigned short *__restrict__ cnt8,
                      unsigned *__restrict__ item_cnt, const long long *__restrict__ mask_pos,
                      CRec *__restrict__ out_r, double *__restrict__ out_unc, const double *__restrict__ seg_vp,
                      const unsigned char *__restrict__ seg_has_vp, const long long *__restrict__ seg_pt_off,
@@ -737,7 +737,7 @@ k_gen_exhaustive_pts(long long n_items, GenCfg cfg, const long long *__restrict_
                               cam_ray(cams[i2], d2{pb[j].x, pb[j].y}), &P);
             }
             if (okp) {
-              if (idx >= kMaxOnePoints) { *err_flag = 3; break; }  // same limit as the matched path (one byte counts a connection)
+              if (idx >= 65000) { *err_flag = 3; break; }  // the per-connection count is 16 bits wide
               if (one_point_candidate(cfg, cams[i1], cams[i2], s1, s2, P, &o)) emit(o);
               ++idx;
             }
@@ -761,7 +761,7 @@ k_gen_exhaustive_pts(long long n_items, GenCfg cfg, const long long *__restrict_
     }
   }
   if (!kFill) {
-    cnt8[item * 64 + lane] = (unsigned char)cnt;
+    cnt8[item * 64 + lane] = (unsigned short)cnt;
     unsigned tot = cnt;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) tot += (unsigned)__shfl_xor((int)tot, d);
@@ -1117,7 +1117,7 @@ void launch_fill_exhaustive(hipStream_t st, int n_blk, long long n_items, const 
 void launch_gen_exhaustive_pts(hipStream_t st, bool fill, long long n_items, const GenCfg &cfg,
                                const long long *item_off, long long G, const int *node_img, const long long *nb_off,
                                const int *blk_nb, const long long *seg_off, const Cam *cams, const Seg *segs,
-                               const PairRec *pairs, unsigned char *cnt8, unsigned *item_cnt,
+                               const PairRec *pairs, unsigned short *cnt8, unsigned *item_cnt,
                                const long long *mask_pos, CRec *out_r, double *out_unc, const double *seg_vp,
                                const unsigned char *seg_has_vp, const long long *seg_pt_off, const void *seg_pts,
                                const double *sfm_xyz, int *err_flag, int many_on, int one_on,

@@ -111,8 +111,13 @@ struct GenArgs {
   const SegPoint *seg_pts;
   const double *sfm_xyz;         // [n_sfm][3] or nullptr (points are then triangulated from the two views)
   int *err_flag;
-  int mult;               // staging slots per match row: 1, or with extra proposals 4 (many-points, vp1, vp2,
-                          // algebraic) + the most shared points of a connection when the one-point proposal is on
+  // Extra proposals (kExtra): a connection yields a VARIABLE number of candidates (many-points, one per shared point,
+  // vp(l1), vp(l2), algebraic -- the reference sets no limit, base_line_triangulator.cc:238-248), so stage B runs twice:
+  // count_only = 1 counts the candidates of every (block, group) list into wave_count without storing anything, the host
+  // scans the counts, and the second run writes the lists back to back at group_base[list] -- exact staging, no cap.
+  // Without extras a row yields at most one candidate: group_base == nullptr, a group's list starts at its first row.
+  const long long *group_base;
+  int count_only;
   int many_on, one_on;    // which point-guided proposals run (seg_pts != null)
 };
 
@@ -359,7 +364,8 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
   const long long g1 = rec->g1, g2 = rec->g2;
   const PairRec *pr = pairs_r + b;
   const long long lbase = a.cnt_bl ? rec->lbase : 0;
-  const long long out0 = r0 * (kExtra ? (long long)a.mult : 1ll);  // first staging slot of the group
+  const long long out0 = (kExtra && a.group_base) ? a.group_base[lin] : r0;  // first staging slot of the group's list
+  const bool wr = !(kExtra && a.count_only);
   // survivor lists of the group's slots, walked as one concatenated list
   unsigned cs[kTriSlots + 1];
   cs[0] = 0;
@@ -394,8 +400,8 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
     };
     // one-point proposals (step 1.2): one candidate per shared point, in ascending point3D_id.  store ==
     // false: returns the NUMBER of shared points that give a candidate; store == true: evaluates them again (same
-    // function, same result) and writes the candidates from staging slot p on.  kMaxOnePoints bounds the staging
-    // slots a row can need (mult, lt_api.cpp); a connection with more shared points raises device flag 3.
+    // function, same result) and writes the candidates from staging slot p on.  No limit on the shared points of a
+    // connection (round 4: the counting run sizes the staging exactly).
     auto one_points = [&](bool store, long long p) -> unsigned {
       const Seg &s1 = a.segs[g1 + line];
       const Seg &s2 = a.segs[g2 + ng];
@@ -403,7 +409,7 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
       const SegPoint *pa = a.seg_pts + pa0, *pb = a.seg_pts + pb0;
       const int na = (int)(a.seg_pt_off[g1 + line + 1] - pa0), nb = (int)(a.seg_pt_off[g2 + ng + 1] - pb0);
       unsigned n_ok = 0;
-      int i = 0, j = 0, idx = 0;
+      int i = 0, j = 0;
       while (i < na && j < nb) {
         const int ia = pa[i].p3d_id, ib = pb[j].p3d_id;
         if (ia < ib) { ++i; continue; }
@@ -419,7 +425,6 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
                           cam_ray(cams_r[i2], d2{pb[j].x, pb[j].y}), &P);
         }
         if (okp) {
-          if (idx >= kMaxOnePoints) { *a.err_flag = 3; break; }  // more shared points than a row has staging slots
           GenOut ov;
           if (one_point_candidate(cfg, cams_r[i1], cams_r[i2], s1, s2, P, &ov)) {
             ++n_ok;
@@ -432,7 +437,6 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
               ++p;
             }
           }
-          ++idx;
         }
         ++i; ++j;
       }
@@ -498,7 +502,7 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
       // the reference's order within a connection: many-points, one-point (ascending point3D_id), vp(l1),
       // vp(l2), algebraic
 #pragma unroll
-      for (int w = 0; w < 3; ++w) {
+      for (int w = 0; w < 3 && wr; ++w) {
         if (w == 1 && n_one) {
           (void)one_points(true, p);
           p += n_one;
@@ -514,8 +518,8 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
           ++p;
         }
       }
-      if (a.cnt_bl && mine) atomicAdd(&a.cnt_bl[lbase + line], mine);
-      if (ok) {
+      if (wr && a.cnt_bl && mine) atomicAdd(&a.cnt_bl[lbase + line], mine);
+      if (ok && wr) {
         a.st_r[p] = o.r;
         a.st_unc[p] = o.unc;
         a.st_key[p] = (unsigned)(g1 + line);
@@ -665,8 +669,8 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
         const unsigned *__restrict__ base_bl, const unsigned *__restrict__ wave_count,
         const long long *__restrict__ tri_off, const CRec *__restrict__ st_r,
         const double *__restrict__ st_unc, const unsigned *__restrict__ st_key, CRec *__restrict__ cand,
-        double *__restrict__ cand_unc, unsigned *__restrict__ cand_node, int n_groups, int mult,
-        unsigned *__restrict__ perm) {
+        double *__restrict__ cand_unc, unsigned *__restrict__ cand_node, int n_groups,
+        const long long *__restrict__ group_base, unsigned *__restrict__ perm) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
@@ -680,7 +684,8 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
   if (count == 0) return;
   const long long g1 = seg_off[blk_img[b]];
   const long long lbase = blk_line_base[b];
-  const long long s0 = r0 * mult;  // the group's first staging slot (mult slots per match row)
+  // the group's first staging slot: its first row, or -- extra proposals -- the scanned list counts (GenArgs::group_base)
+  const long long s0 = group_base ? group_base[lin] : r0;
   static_assert(sizeof(CRec) == 8 * 16, "record size in 16-byte units");
   for (unsigned e0 = 0; e0 < count; e0 += 64) {
     const unsigned e = e0 + lane;
@@ -706,7 +711,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
         while (idx_end > 0) {
           const long long j = idx_end - 64 + lane;
           const bool valid = j >= 0;
-          const unsigned k = valid ? st_key[cur_r0 * mult + j] : 0u;
+          const unsigned k = valid ? st_key[(group_base ? group_base[cur_lin] : cur_r0) + j] : 0u;
           const unsigned long long m = __ballot(valid && k == key0);
           const unsigned lead = m == ~0ull ? 64u : (unsigned)__builtin_clzll(~m);
           carry += lead;
@@ -756,7 +761,8 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
 __global__ void __launch_bounds__(256)
 k_pack_keys(const long long *__restrict__ m_off, const unsigned *__restrict__ wave_count,
             const long long *__restrict__ wave_pos, const unsigned *__restrict__ st_key,
-            unsigned *__restrict__ keys_c, unsigned *__restrict__ src_c, int n_groups, int mult) {
+            unsigned *__restrict__ keys_c, unsigned *__restrict__ src_c, int n_groups,
+            const long long *__restrict__ group_base) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
@@ -769,8 +775,9 @@ k_pack_keys(const long long *__restrict__ m_off, const unsigned *__restrict__ wa
   const unsigned count = wave_count[lin];
   const long long base = wave_pos[lin];
   for (unsigned e = lane; e < count; e += 64) {
-    keys_c[base + e] = st_key[r0 * mult + e];
-    src_c[base + e] = (unsigned)(r0 * mult + e);
+    const long long s0 = group_base ? group_base[lin] : r0;
+    keys_c[base + e] = st_key[s0 + e];
+    src_c[base + e] = (unsigned)(s0 + e);
   }
 }
 
@@ -835,7 +842,9 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3,
                       const double *seg_vp, const unsigned char *seg_has_vp, const long long *seg_pt_off,
                       const void *seg_pts, const double *sfm_xyz, int *err_flag, int many_on, int one_on,
-                      int mult) {
+                      const long long *group_base, int phase) {
+  // phase 0: k_gates + k_tri_rows (no extra proposals).  Extra proposals: phase 1 = k_gates + the COUNTING run of
+  // k_tri_rows (wave_count only), phase 2 = the storing run at group_base (the scanned counts), see GenArgs
   if (n_blk <= 0 || max_rows <= 0) return;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -856,7 +865,8 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   a.seg_pt_off = seg_pt_off; a.seg_pts = reinterpret_cast<const SegPoint *>(seg_pts); a.sfm_xyz = sfm_xyz;
   a.err_flag = err_flag;
   const bool extra = seg_vp || seg_pts;
-  a.mult = extra ? mult : 1;
+  a.group_base = extra ? group_base : nullptr;
+  a.count_only = (extra && phase == 1) ? 1 : 0;
   a.many_on = many_on; a.one_on = one_on;
   a.blk = reinterpret_cast<const BlkRec *>(blkrec); a.n_blk = n_blk;
   // persistent grid: as many workgroups as fit at once (registers allow 16 waves per CU)
@@ -868,10 +878,12 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   // the tables are sized by the largest image of the job, so "fits" is a per-launch property
   const dim3 grid(n_wg), block(64 * kGateWaves);
   if (ev3) (void)hipEventRecord(ev3[0], st);
-  if (lds_segs1 > 0 && lds_segs > 0) hipLaunchKernelGGL((k_gates<true, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
-  else if (lds_segs > 0) hipLaunchKernelGGL((k_gates<false, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
-  else if (lds_segs1 > 0) hipLaunchKernelGGL((k_gates<true, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
-  else hipLaunchKernelGGL((k_gates<false, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
+  if (phase != 2) {
+    if (lds_segs1 > 0 && lds_segs > 0) hipLaunchKernelGGL((k_gates<true, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
+    else if (lds_segs > 0) hipLaunchKernelGGL((k_gates<false, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
+    else if (lds_segs1 > 0) hipLaunchKernelGGL((k_gates<true, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
+    else hipLaunchKernelGGL((k_gates<false, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
+  }
   if (ev3) (void)hipEventRecord(ev3[1], st);
   if (extra)
     hipLaunchKernelGGL(k_tri_rows<true>, dim3(nblk2(a.n_slots / kTriSlots, kTriWaves), n_blk), dim3(64 * kTriWaves), 0, st,
@@ -891,20 +903,21 @@ void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const 
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const CRec *st_r, const double *st_unc,
-                  const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, int mult, unsigned *perm) {
+                  const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, const long long *group_base,
+                  unsigned *perm) {
   if (n_blk <= 0 || max_rows <= 0) return;
   const int n_groups = gen_groups(max_rows);
   hipLaunchKernelGGL(k_place, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
                      blk_line_base, base_bl, wave_count, tri_off, st_r, st_unc, st_key, cand, cand_unc, cand_node, n_groups,
-                     mult, perm);
+                     group_base, perm);
 }
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
-                      unsigned *keys_c, unsigned *src_c, int mult) {
+                      unsigned *keys_c, unsigned *src_c, const long long *group_base) {
   if (n_blk <= 0 || max_rows <= 0) return;
   const int n_groups = gen_groups(max_rows);
   hipLaunchKernelGGL(k_pack_keys, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, wave_count, wave_pos,
-                     st_key, keys_c, src_c, n_groups, mult);
+                     st_key, keys_c, src_c, n_groups, group_base);
 }
 void launch_permute(hipStream_t st, long long C, const unsigned *skeys, const unsigned *ssrc, const CRec *st_r,
                     const double *st_unc, CRec *cand, double *cand_unc, unsigned *cand_node) {

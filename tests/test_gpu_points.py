@@ -168,16 +168,6 @@ def test_points_switches_and_errors(gpu_lib, oracle):
     g, o = T.context().get_all_tris(), O.get_all_tris()
     assert np.array_equal(g["off"], o["off"]) and np.array_equal(g["src"], o["src"])
     np.testing.assert_allclose(g["line"][:, :8], o["line"][:, :8], rtol=1e-7, atol=1e-9)
-    # beyond 250 shared points a connection is refused (staging slots per row / one-byte counters)
-    huge, huge_sfm = syn.make_bipartites(sc, seed=3, pts_per_line=260)
-    T = tri.GlobalLineTriangulator(cfg)
-    T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
-    T.SetBipartites2d(huge)
-    T.SetSfMPoints(huge_sfm)
-    for i in sc.img_ids:
-        T.TriangulateImage(int(i), sc.matches_of(int(i)))
-    with pytest.raises(RuntimeError, match="250 shared points"):
-        T.ComputeLineTracks()
     # a shared point3D id that is not among the SfM points: std::map::at throws in the reference
     cfg.update(disable_one_point_triangulation=True, disable_many_points_triangulation=False)
     T = tri.GlobalLineTriangulator(cfg)
@@ -194,3 +184,87 @@ def test_points_switches_and_errors(gpu_lib, oracle):
     bad[k] = dict(bad[k], line_points=bad[k]["line_points"][:-1])
     with pytest.raises((RuntimeError, ValueError), match="lines"):
         T.SetBipartites2d(bad)
+
+
+def _one_crowded_line(sc, n_pts, seed=3):
+    """Bipartites in which ONE ground-truth line carries n_pts points (every other line three): the line whose two
+    observing segments in neighbouring images share the most of them -- a connection with several hundred shared points,
+    one one-point candidate each in the reference, which sets no limit (base_line_triangulator.cc:238-248) --, while the
+    rest of the scene stays small enough for the oracle.  Returns (bipartites, SfM points, shared points of that connection)."""
+    bpts, sfm = syn.make_bipartites(sc, seed=seed, pts_per_line=n_pts)
+    per = []
+    for n, img_id in enumerate(sc.img_ids):
+        gids = sc.gt_ids[sc.seg_off[n]:sc.seg_off[n + 1]]
+        b = bpts[int(img_id)]
+        per.append({int(g): set(b["point3D_ids"][pts].tolist()) for g, pts in zip(gids, b["line_points"]) if g >= 0})
+    best, g0 = 0, -1
+    for n, img_id in enumerate(sc.img_ids):
+        for nb in sc.neighbors[int(img_id)]:
+            j = int(np.searchsorted(sc.img_ids, nb))
+            for g in per[n]:
+                c = len(per[n][g] & per[j].get(g, set()))
+                if c > best:
+                    best, g0 = c, g
+    for n, img_id in enumerate(sc.img_ids):
+        gids = sc.gt_ids[sc.seg_off[n]:sc.seg_off[n + 1]]
+        lp = bpts[int(img_id)]["line_points"]
+        bpts[int(img_id)]["line_points"] = [pts if g == g0 else pts[:3] for g, pts in zip(gids, lp)]
+    return bpts, sfm, best
+
+
+@pytest.mark.parametrize("exhaustive", [False, True])
+def test_six_hundred_shared_points_on_one_connection(gpu_lib, oracle, exhaustive):
+    """rounds 2-3 refused a connection with more than 250 shared points (staging slots per match row,
+    one-byte counts).  Now stage B counts first and stages exactly (matched mode), the exhaustive pass counts in 16 bits:
+    600 points on one line give several hundred candidates per connection, the same ones as the oracle's, in the same order.
+    Also measured here: the distance between the device's one-point candidates (restated problem) and the oracle
+    running the REFERENCE'S GENERATED solver (solvers/triangulation/triangulate_line_with_one_point.cc, bit-identical to
+    oracle/_ref): asserted below 1e-6 relative, measured ~1e-8 at worst (the generated coefficients cancel over ten digits;
+    tests/test_oracle_kat.py shows the difference is the generated form's own noise)."""
+    from limap_amd import triangulation as tri
+    sc = syn.make_scene(n_views=5, n_segs=24, n_neighbors=2, seed=63)
+    bpts, sfm, n_shared = _one_crowded_line(sc, 600)
+    assert n_shared == 600
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    cfg.update(disable_one_point_triangulation=False, disable_many_points_triangulation=True)
+
+    def both():
+        T = tri.GlobalLineTriangulator(cfg)
+        O = oracle.OracleTriangulator(cfg, faithful=False)
+        T.SetRanges(sc.ranges); O.SetRanges(sc.ranges)
+        T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(i) for i in range(sc.n_images)])
+        O.Init(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, sc.seg_off, sc.segs)
+        T.SetBipartites2d(bpts); O.SetBipartites2d(bpts)
+        T.SetSfMPoints(sfm); O.SetSfMPoints(sfm)
+        for i in sc.img_ids:
+            if exhaustive:
+                T.TriangulateImageExhaustiveMatch(int(i), sc.neighbors[int(i)])
+                O.TriangulateImageExhaustiveMatch(int(i), sc.neighbors[int(i)])
+            else:
+                m = sc.matches_of(int(i))
+                T.TriangulateImage(int(i), m)
+                O.TriangulateImage(int(i), m)
+        return T, O
+
+    T, O = both()   # (the autouse fixture has the oracle on the restated problem)
+    g, o = T.context().get_all_tris(), O.get_all_tris()
+    n_per_node = np.diff(o["off"])
+    assert n_per_node.max() > 500, "a node is meant to have several hundred candidates"
+    assert np.array_equal(g["off"], o["off"]) and np.array_equal(g["src"], o["src"])
+    scale = np.maximum(np.abs(o["line"][:, :6]).max(1, keepdims=True), 1e-12)
+    assert np.max(np.abs(g["line"][:, :6] - o["line"][:, :6]) / scale) < 1e-9
+    gb, ob = T.context().get_best(), O.get_best()
+    assert np.array_equal(gb["has_best"], ob["has_best"]) and np.array_equal(gb["src"], ob["src"])
+    # ... and against the reference's generated solver
+    oracle.set_one_point_solver(True)
+    try:
+        _, O2 = both()
+        o2 = O2.get_all_tris()
+    finally:
+        oracle.set_one_point_solver(False)
+    assert np.array_equal(g["off"], o2["off"]) and np.array_equal(g["src"], o2["src"])
+    scale2 = np.maximum(np.abs(o2["line"][:, :6]).max(1, keepdims=True), 1e-12)
+    d = float(np.max(np.abs(g["line"][:, :6] - o2["line"][:, :6]) / scale2))
+    print("HIP (restated problem) vs the reference's generated one-point solver: max relative difference %.3g over %d candidates"
+          % (d, len(g["line"])))
+    assert d < 1e-6
