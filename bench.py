@@ -349,23 +349,25 @@ def main():
         torch.cuda.synchronize(dev)
         allgather_us = 1e6 * (time.perf_counter() - ta) / 10
 
-    # results of the last step -> host, then the tail (not part of the timed step)
-    ctx.download()
-    st = ctx.stats()
-    st["active_nodes"] = int(sum(scene.seg_off[j + 1] - scene.seg_off[j] for j in
-                                 np.searchsorted(scene.img_ids, my_imgs)))
-    # N > 1: rank 0 imports the other shards' per-node results and runs the tail for the whole scene
+    # the tail (not part of the timed step).  N > 1: the other shards' per-node results and valid-edge keys travel to
+    # rank 0 device to device (ltdist.merge_shards_device: one gather of two flat buffers, no host copy, no per-image
+    # export), and rank 0's tail runs on its device over the whole scene.  This rank's nodes are one range of the
+    # global node index (images are sharded in id order).
+    my_idx = np.searchsorted(scene.img_ids, my_imgs)
+    node_range = (int(scene.seg_off[my_idx[0]]), int(scene.seg_off[my_idx[-1] + 1])) if len(my_idx) else (0, 0)
     merge_note, t_merge = None, None
     if world > 1:
         try:
             tm0 = time.perf_counter()
-            ltdist.merge_shards_on_rank0(ctx, my_imgs, rank, world, dev)
+            ltdist.merge_shards_device(ctx, node_range, rank, world, dev)
             t_merge = time.perf_counter() - tm0
         except Exception as e:  # never lose the throughput line over the (untimed) merge
             merge_note = f"merge failed: {type(e).__name__}: {e}"
     t_tail0 = time.perf_counter()
     ctx.compute_tracks()
     t_tail = time.perf_counter() - t_tail0
+    st = ctx.stats()   # (reads this rank's per-node results back: the pair statistic is summed on the host)
+    st["active_nodes"] = int(sum(scene.seg_off[j + 1] - scene.seg_off[j] for j in my_idx))
     st_after = ctx.stats()
     # ---- second figure (not `value`): the step INCLUDING what `value` leaves out -- the per-node results' way to the
     # host, rank 0's import of the other shards (one tensor gather) and the serial tail ComputeLineTracks on rank 0
@@ -379,9 +381,8 @@ def main():
         for _ in range(n_full):
             step()
             ctx.sync()
-            ctx.download()
-            if world > 1:
-                ltdist.merge_shards_on_rank0(ctx, my_imgs, rank, world, dev)
+            if world > 1:  # (nothing is downloaded: the tail works from device-resident results, merged on the device)
+                ltdist.merge_shards_device(ctx, node_range, rank, world, dev)
             if rank == 0 or world == 1:
                 ctx.compute_tracks()
         sync()
@@ -468,7 +469,7 @@ def main():
             "roofline_note": pmc_note or ("traffic / valu_f64 / lds: rocprofv3 --pmc passes over this exact device code "
                                           "(profiles/r03_pmc.json, tools/prof_pmc_json.sh); FP64 VALU peak 78.6 TF"),
             "host_ms": {"upload_matches": 1e3 * t_upload, "tail_compute_tracks": 1e3 * t_tail,
-                        "merge_shards_on_rank0": None if t_merge is None else 1e3 * t_merge},
+                        "merge_shards_device": None if t_merge is None else 1e3 * t_merge},
             "tracks_whole_scene": st_after["tracks"], "merge_note": merge_note,
             "track_report": track_report_gpu,
             "ranks": {"world_size": dist.get_world_size() if use_dist else 1,

@@ -213,6 +213,21 @@ int lt_import_image_results(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb
                             const double *score, const int32_t *src2, const int32_t *n_tris,
                             const int64_t *edge_off, const int32_t *edges2);
 
+/* ---- shards of a multi-GPU run, device to device (no reference counterpart: the reference is one process).
+ * Images are sharded over the ranks in id order, so a rank's nodes are one range [g_lo, g_hi) of the global node index
+ * (node = first node of its image + line id).  A shard travels as two blobs -- lt_shard_node_bytes() bytes per node
+ * (best candidate, score, source, candidate count of global_line_triangulator.cc:145-153, as arrays one behind the
+ * other) and 8 bytes per valid edge (undirected node-pair keys of run_clustering, :243-290) -- written and read by
+ * device copies; the pointers may be device or host memory.  Order of calls: every rank lt_shard_count; lt_shard_build
+ * (total_keys = the sum over the ranks on the rank that merges, the own count elsewhere); the other ranks lt_shard_export;
+ * the merging rank lt_shard_import once per other rank, then lt_compute_tracks (which needs the device form of the
+ * tail: min_num_outer_edges == 0). */
+int lt_shard_node_bytes(void);
+int lt_shard_count(lt_ctx *ctx, int64_t *n_keys);
+int lt_shard_build(lt_ctx *ctx, int64_t total_keys);
+int lt_shard_export(lt_ctx *ctx, int64_t g_lo, int64_t g_hi, void *nodes_blob, void *keys_blob);
+int lt_shard_import(lt_ctx *ctx, int64_t g_lo, int64_t g_hi, const void *nodes_blob, int64_t n_keys, const void *keys_blob);
+
 /* ---- post-triangulation steps of limap.runners.line_triangulation (:171-200), SURVEY 8(f) rank 2:
  * limap.merging.filter_tracks_by_reprojection / remerge / filter_tracks_by_sensitivity /
  * filter_tracks_by_overlap (merging/merging_utils.cc:27-155, merging/merging.cc:513-644).

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
     "lt_get_num_tris", "lt_get_valid_flags", "lt_num_valid_edges", "lt_get_valid_edges", "lt_num_all_tris", "lt_get_all_tris",
     "lt_num_tracks", "lt_num_track_members", "lt_get_tracks", "lt_image_results_size",
-    "lt_export_image_results", "lt_import_image_results", "lt_ts_from_ctx", "lt_ts_create", "lt_ts_destroy",
+    "lt_export_image_results", "lt_import_image_results", "lt_shard_node_bytes", "lt_shard_count", "lt_shard_build", "lt_shard_export", "lt_shard_import", "lt_ts_from_ctx", "lt_ts_create", "lt_ts_destroy",
     "lt_ts_num_tracks", "lt_ts_num_members", "lt_ts_get", "lt_ts_filter_by_reprojection",
     "lt_ts_filter_by_sensitivity", "lt_ts_filter_by_overlap", "lt_ts_remerge_once", "lt_get_stats", "lt_get_timers", "lt_get_timer_sums", "lt_run_device_async", "lt_sync",
     "lt_release_cached_memory", "lt_reserve_host",
@@ -153,6 +153,11 @@ def load_library():
     L.lt_image_results_size.restype = C.c_int64
     L.lt_export_image_results.argtypes = [vp, C.c_int, i32p, i32p, dp, dp, i32p, i32p, i64p, i32p]
     L.lt_import_image_results.argtypes = [vp, C.c_int, C.c_int, i32p, dp, dp, i32p, i32p, i64p, i32p]
+    L.lt_shard_node_bytes.argtypes = []
+    L.lt_shard_count.argtypes = [vp, i64p]
+    L.lt_shard_build.argtypes = [vp, C.c_int64]
+    L.lt_shard_export.argtypes = [vp, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.lt_shard_import.argtypes = [vp, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.lt_ts_from_ctx.argtypes = [vp]
     L.lt_ts_from_ctx.restype = vp
     L.lt_ts_create.argtypes = [C.c_int64, dp, u8p, i64p, i32p, i32p, i32p, dp, dp, dp]
@@ -466,6 +471,25 @@ class Context:
         self.chk(self.L.lt_import_image_results(self.h, int(r["img_id"]), len(nb), ptr(nb, C.c_int32), ptr(line, C.c_double),
                                                 ptr(score, C.c_double), ptr(src, C.c_int32), ptr(nt, C.c_int32),
                                                 ptr(eoff, C.c_int64), ptr(edges, C.c_int32)))
+
+    # --- shards of a multi-GPU run, device to device (include/limap_amd.h: lt_shard_*) ---
+    def shard_node_bytes(self):
+        return int(self.L.lt_shard_node_bytes())
+
+    def shard_count(self):
+        n = C.c_int64(0)
+        self.chk(self.L.lt_shard_count(self.h, C.byref(n)))
+        return int(n.value)
+
+    def shard_build(self, total_keys):
+        self.chk(self.L.lt_shard_build(self.h, int(total_keys)))
+
+    def shard_export(self, g_lo, g_hi, nodes_ptr, keys_ptr):
+        self.chk(self.L.lt_shard_export(self.h, int(g_lo), int(g_hi), C.c_void_p(int(nodes_ptr)), C.c_void_p(int(keys_ptr))))
+
+    def shard_import(self, g_lo, g_hi, nodes_ptr, n_keys, keys_ptr):
+        self.chk(self.L.lt_shard_import(self.h, int(g_lo), int(g_hi), C.c_void_p(int(nodes_ptr)), int(n_keys),
+                                        C.c_void_p(int(keys_ptr))))
 
     def stats(self):
         out = np.zeros(8, np.int64)

@@ -241,6 +241,7 @@ int lt_run_device_async(lt_ctx *ctx) {
   LT_RANGE("lt_run_device (enqueue: generation, placement, scoring, selection)");
   if (!ctx->uploaded) return fail(ctx, LT_ERR_STATE, "lt_run_device before lt_upload");
   if (!ctx->h_pinned) LT_FINISH(ctx);  // no pinned result slots: nothing may stay in flight
+  ctx->shard_keys = ctx->shard_own_keys = -1;  // a new run: nothing of an earlier merge is pending
   const int set = ctx->run_pending ? (ctx->pend_set ^ 1) : 0;
   if (set == 1 && !ctx->ev_b[0])
     for (auto &e : ctx->ev_b) HIPCHK(ctx, hipEventCreate(&e));
@@ -755,7 +756,7 @@ void define_best_of_other_images(lt_ctx *ctx) {
     if (!ctx->best_c_set[(size_t)i]) {
       const long long a = ctx->seg_off[i], b = ctx->seg_off[i + 1];
       if (b > a) std::memset((void *)(ctx->best_c + a), 0, sizeof(Cand) * (size_t)(b - a));
-      ctx->best_c_set[(size_t)i] = 1;
+      ctx->best_c_set[(size_t)i] = 2;  // defined, but no results: nothing the device does not know
     }
 }
 }  // namespace lt_impl

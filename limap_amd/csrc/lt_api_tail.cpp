@@ -17,9 +17,43 @@ static bool tail_on_device(const lt_ctx *ctx) {
   if (getenv("LT_TAIL_HOST") != nullptr || ctx->cfg.min_num_outer_edges > 0) return false;
   if (!ctx->inited || ctx->job_mode == 0 || ctx->downloaded || ctx->job_imgs.empty()) return false;
   if (ctx->G <= 0 || ctx->G >= (1ll << 31)) return false;
-  for (char c : ctx->best_c_set)
-    if (c) return false;  // an earlier batch or imported shards live on the host
+  // results that live only on the host -- an earlier batch that was read back, imported shards -- rule the device form
+  // out; host copies of the CURRENT job's images do not (the resident run supersedes them: the same job run again after
+  // its results were read), nor do images that merely hold the value-initialised candidate (best_c_set == 2)
+  bool foreign = false;
+  for (char c : ctx->best_c_set) foreign = foreign || c == 1;
+  if (!foreign) return true;
+  std::vector<char> in_job((size_t)ctx->n_img, 0);
+  for (int idx : ctx->job_imgs) in_job[(size_t)idx] = 1;
+  for (int i = 0; i < ctx->n_img; ++i)
+    if (ctx->best_c_set[(size_t)i] == 1 && !in_job[(size_t)i]) return false;
   return true;
+}
+
+// number of directed valid edges of the resident run = keys it contributes (one scan of the per-node counts + a sync)
+static int tail_count_keys(lt_ctx *ctx, long long *E_out) {
+  hipStream_t st = ctx->stream;
+  const long long G = ctx->G;
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_nvalid.as<unsigned>() + G, 0, 4, st));
+  const size_t scan_tmp = scan_temp_bytes_u32_to_i64(G + 1);
+  ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(scan_tmp, 16));
+  if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, scan_tmp, G + 1, ctx->d_nvalid.as<unsigned>(),
+                             ctx->d_edge_off.as<long long>()) != 0)
+    return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
+  long long *hp = ctx->h_pinned ? ctx->h_pinned + 16 : nullptr;  // slots behind the two result sets
+  long long fallback[2] = {0, 0};
+  if (!hp) hp = fallback;
+  HIPCHK(ctx, hipMemcpyAsync(&hp[0], ctx->d_edge_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  *E_out = hp[0];
+  return LT_OK;
+}
+// keys (min node << kb | max node) of the resident run's valid edges -> d_tail_keys[0 .. E), in node / candidate order
+static void tail_build_keys(lt_ctx *ctx, int kb) {
+  launch_tail_keys(ctx->stream, ctx->G, ctx->d_tri_off.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
+                   ctx->d_edge_off.as<long long>(), ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(),
+                   ctx->d_seg_off.as<long long>(), kb, ctx->d_tail_keys.as<unsigned long long>(),
+                   ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
 }
 
 // sorted unique undirected edges + their similarities; the graph nodes' best candidates land in ctx->best_c etc.
@@ -40,27 +74,28 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const long long G = ctx->G;
-  // valid-edge offsets (the scan lt_download would run)
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_nvalid.as<unsigned>() + G, 0, 4, st));
   const size_t scan_tmp = scan_temp_bytes_u32_to_i64(G + 1);
+  // the undirected edge keys: of the resident run (counted and built here), or -- shards of other ranks were imported
+  // (lt_shard_*) -- the list that is already complete in d_tail_keys
+  const bool merged = ctx->shard_keys >= 0;
   ENSURE(ctx, ctx->d_scan_tmp, std::max<size_t>(scan_tmp, 16));
-  if (launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, scan_tmp, G + 1, ctx->d_nvalid.as<unsigned>(),
-                             ctx->d_edge_off.as<long long>()) != 0)
-    return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
-  long long *hp = ctx->h_pinned ? ctx->h_pinned + 16 : nullptr;  // slots behind the two result sets
-  long long fallback[2] = {0, 0};
-  if (!hp) hp = fallback;
-  HIPCHK(ctx, hipMemcpyAsync(&hp[0], ctx->d_edge_off.as<long long>() + G, 8, hipMemcpyDeviceToHost, st));
+  long long E = 0;
+  if (merged) {
+    E = ctx->shard_keys;
+    ctx->shard_keys = -1;
+  } else {
+    int rck = tail_count_keys(ctx, &E);
+    if (rck) return rck;
+  }
   ENSURE(ctx, ctx->d_tail_mark, 4 * (size_t)(G + 1)); ENSURE(ctx, ctx->d_tail_pos, 8 * (size_t)(G + 1));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_tail_mark.p, 0, 4 * (size_t)(G + 1), st));
-  HIPCHK(ctx, hipStreamSynchronize(st));
-  const long long E = hp[0];
   lap("scan + sync (E)");
   ctx->E = E;
   ctx->C = ctx->C_last;
   if (E <= 0) return LT_OK;
   const size_t En = (size_t)E;
-  ENSURE(ctx, ctx->d_tail_keys, 8 * En); ENSURE(ctx, ctx->d_tail_skeys, 8 * En); ENSURE(ctx, ctx->d_tail_sims, 8 * En);
+  if (!merged) ENSURE(ctx, ctx->d_tail_keys, 8 * En);
+  ENSURE(ctx, ctx->d_tail_skeys, 8 * En); ENSURE(ctx, ctx->d_tail_sims, 8 * En);
   ENSURE(ctx, ctx->d_tail_keep, 4 * (En + 1)); ENSURE(ctx, ctx->d_tail_kpos, 8 * (En + 1));
   const int kb = bits_for(G + 1);  // key = (min node << kb) | max node
   const int end_bit = 2 * kb;
@@ -81,9 +116,7 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
   long long *hn = (long long *)base;  // [0] graph nodes, [1] graph edges
   hn[0] = hn[1] = 0;
   const unsigned long long *hpairs = (const unsigned long long *)(base + o_pairs);
-  launch_tail_keys(st, G, ctx->d_tri_off.as<long long>(), ctx->d_edge_flag.as<unsigned>(), ctx->d_edge_off.as<long long>(),
-                   ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(), ctx->d_seg_off.as<long long>(), kb,
-                   ctx->d_tail_keys.as<unsigned long long>(), ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
+  if (!merged) tail_build_keys(ctx, kb);
   if (launch_tail_sort(st, ctx->d_tail_tmp.p, sort_tmp, E, ctx->d_tail_keys.as<unsigned long long>(),
                        ctx->d_tail_skeys.as<unsigned long long>(), end_bit) != 0)
     return fail(ctx, LT_ERR_HIP, "rocprim radix sort failed");
@@ -157,6 +190,11 @@ int lt_compute_tracks(lt_ctx *ctx) {
   if (ctx->cfg.merging_strategy < 0 || ctx->cfg.merging_strategy > 2)  // global_line_triangulator.cc:314-316
     return fail(ctx, LT_ERR_RUNTIME, "Error!The given merging strategy is not implemented");
   const bool on_device = tail_on_device(ctx);
+  if (ctx->shard_keys >= 0 && !on_device) {
+    ctx->shard_keys = -1;
+    return fail(ctx, LT_ERR_STATE, "shards were imported on the device (lt_shard_import), but the device form of the tail "
+                                   "is not available (min_num_outer_edges > 0, LT_TAIL_HOST, or results already read back)");
+  }
   lt_host::SpinPool::get(lt_host::row_workers()).wake();  // the host half of the tail shares its loops with the team
   int rc;
   if (on_device) {
@@ -486,6 +524,95 @@ int lt_compute_tracks(lt_ctx *ctx) {
   lap("tracks+aggregate");
   ctx->tracks_done = true;
   ctx->timers[10] = now_ms() - t0;
+  return LT_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Shards of a multi-GPU run, device to device (round 4).  Images are sharded over the ranks in id order, so a
+// rank's nodes are ONE range [g_lo, g_hi) of the global node index and its per-node results are slices of the arrays the
+// device tail reads.  What rank 0 needs of another rank is therefore
+//   nodes blob  [n x 112 B best candidate | n x 8 B score | n x 8 B source (image index, line) | n x 4 B candidate count]
+//   keys blob   the rank's undirected valid-edge keys (min node << kb | max node: G is global, so is kb), 8 B each,
+// both produced and consumed by copies / kernels on the devices -- no per-image export, no Python loop, no host tail.
+// Protocol: every rank lt_shard_count -> (the counts travel) -> lt_shard_build(total on rank 0) -> the others
+// lt_shard_export into the collective's send buffers -> gather -> rank 0 lt_shard_import per rank -> lt_compute_tracks.
+// Pointers may be device or host memory (hipMemcpyDefault): a gloo group gathers host tensors.
+// ---------------------------------------------------------------------------------------------
+int lt_shard_node_bytes(void) { return (int)(sizeof(Cand) + 8 + 8 + 4); }
+
+int lt_shard_count(lt_ctx *ctx, int64_t *n_keys) {
+  LT_FINISH(ctx);
+  if (!ctx->ran || ctx->downloaded) return fail(ctx, LT_ERR_STATE, "lt_shard_count needs the results of a run resident on the device");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  long long E = 0;
+  int rc = tail_count_keys(ctx, &E);
+  if (rc) return rc;
+  ctx->shard_own_keys = E;
+  *n_keys = E;
+  return LT_OK;
+}
+
+int lt_shard_build(lt_ctx *ctx, int64_t total_keys) {
+  if (ctx->shard_own_keys < 0) return fail(ctx, LT_ERR_STATE, "lt_shard_build before lt_shard_count");
+  if (total_keys < ctx->shard_own_keys) return fail(ctx, LT_ERR_ARGUMENT, "lt_shard_build: fewer keys than this rank's own");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENSURE(ctx, ctx->d_tail_keys, 8 * (size_t)std::max<long long>(total_keys, 1));
+  if (ctx->shard_own_keys > 0) tail_build_keys(ctx, bits_for(ctx->G + 1));
+  HIPCHK(ctx, hipGetLastError());
+  ctx->shard_keys = ctx->shard_own_keys;  // imports append behind them
+  ctx->shard_keys_cap = total_keys;
+  return LT_OK;
+}
+
+static int shard_range_ok(lt_ctx *ctx, int64_t g_lo, int64_t g_hi) {
+  if (g_lo < 0 || g_hi < g_lo || g_hi > ctx->G) return fail(ctx, LT_ERR_ARGUMENT, "node range out of bounds");
+  return LT_OK;
+}
+
+int lt_shard_export(lt_ctx *ctx, int64_t g_lo, int64_t g_hi, void *nodes_blob, void *keys_blob) {
+  int rc = shard_range_ok(ctx, g_lo, g_hi);
+  if (rc) return rc;
+  if (ctx->shard_keys < 0) return fail(ctx, LT_ERR_STATE, "lt_shard_export before lt_shard_build");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t n = (size_t)(g_hi - g_lo);
+  char *out = static_cast<char *>(nodes_blob);
+  if (n > 0) {
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_best_c.as<Cand>() + g_lo, sizeof(Cand) * n, hipMemcpyDefault, st));
+    HIPCHK(ctx, hipMemcpyAsync(out + sizeof(Cand) * n, ctx->d_best_score.as<double>() + g_lo, 8 * n, hipMemcpyDefault, st));
+    HIPCHK(ctx, hipMemcpyAsync(out + (sizeof(Cand) + 8) * n, ctx->d_best_src.as<int>() + 2 * g_lo, 8 * n, hipMemcpyDefault, st));
+    HIPCHK(ctx, hipMemcpyAsync(out + (sizeof(Cand) + 16) * n, ctx->d_ntris.as<int>() + g_lo, 4 * n, hipMemcpyDefault, st));
+  }
+  if (ctx->shard_own_keys > 0)
+    HIPCHK(ctx, hipMemcpyAsync(keys_blob, ctx->d_tail_keys.p, 8 * (size_t)ctx->shard_own_keys, hipMemcpyDefault, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));  // the collective that follows runs on another stream
+  ctx->shard_keys = -1;  // this rank's part is done: it does not run a merged tail itself
+  return LT_OK;
+}
+
+int lt_shard_import(lt_ctx *ctx, int64_t g_lo, int64_t g_hi, const void *nodes_blob, int64_t n_keys, const void *keys_blob) {
+  int rc = shard_range_ok(ctx, g_lo, g_hi);
+  if (rc) return rc;
+  if (ctx->shard_keys < 0) return fail(ctx, LT_ERR_STATE, "lt_shard_import before lt_shard_build");
+  if (n_keys < 0 || ctx->shard_keys + n_keys > ctx->shard_keys_cap)
+    return fail(ctx, LT_ERR_ARGUMENT, "lt_shard_import: more keys than lt_shard_build reserved");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t n = (size_t)(g_hi - g_lo);
+  const char *in = static_cast<const char *>(nodes_blob);
+  if (n > 0) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_best_c.as<Cand>() + g_lo, in, sizeof(Cand) * n, hipMemcpyDefault, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_best_score.as<double>() + g_lo, in + sizeof(Cand) * n, 8 * n, hipMemcpyDefault, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_best_src.as<int>() + 2 * g_lo, in + (sizeof(Cand) + 8) * n, 8 * n, hipMemcpyDefault, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_ntris.as<int>() + g_lo, in + (sizeof(Cand) + 16) * n, 4 * n, hipMemcpyDefault, st));
+  }
+  if (n_keys > 0)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_tail_keys.as<unsigned long long>() + ctx->shard_keys, keys_blob, 8 * (size_t)n_keys,
+                               hipMemcpyDefault, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));  // the source buffers belong to the caller
+  ctx->shard_keys += n_keys;
+  ctx->tracks_done = false;
   return LT_OK;
 }
 

@@ -244,6 +244,9 @@ struct lt_ctx {
   int n_chunks = 0;
   long long cand_cap = 0;
   long long C = 0, E = 0;  // candidates / valid edges of the last run
+  // multi-GPU merge on the device (lt_shard_*): keys accumulated in d_tail_keys for the next tail (-1: the tail builds
+  // them from the resident run), their capacity, this rank's own count
+  long long shard_keys = -1, shard_keys_cap = 0, shard_own_keys = -1;
 
   // ---- host results (all nodes) ----
   // best candidate per node: a pooled host block (5.6 MB at 50 000 nodes; value-initialising a fresh vector of

@@ -191,6 +191,50 @@ def gather_packed_to_rank0(ints, flts, rank, world, device):
     return [(gi[r][:int(all_sizes[r, 0])].cpu().numpy(), gf[r][:int(all_sizes[r, 1])].cpu().numpy()) for r in range(world)]
 
 
+def merge_shards_device(ctx, node_range, rank, world, device=None):
+    """Round 4: the shards' way to rank 0 WITHOUT the host -- every rank builds the undirected valid-edge keys of its
+    own nodes on its device, the per-node results are slices [g_lo, g_hi) of the arrays the device tail reads (images are
+    sharded in id order), and both travel as two flat buffers through ONE tensor `gather` each (sizes first, one small
+    all-gather); rank 0 copies them into place on its device (`lt_shard_import`) and its `compute_tracks()` then runs
+    the device form of the tail over the whole scene.  No per-image export, no numpy packing, no host tail.
+    node_range = (g_lo, g_hi): this rank's node range.  Under a gloo group the buffers are host tensors (the copies in
+    `lt_shard_export` / `_import` take either).  Returns the number of keys merged on rank 0 (0 elsewhere)."""
+    if world == 1:
+        return 0
+    import torch
+    import torch.distributed as dist
+    if device is None:
+        backend = dist.get_backend() if dist.is_initialized() else "gloo"
+        device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    g_lo, g_hi = int(node_range[0]), int(node_range[1])
+    n_keys = ctx.shard_count()
+    mine = torch.tensor([n_keys, g_lo, g_hi], dtype=torch.int64, device=device)
+    allv = torch.zeros(3 * world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allv, mine)
+    allv = allv.cpu().numpy().reshape(world, 3)
+    total = int(allv[:, 0].sum())
+    ctx.shard_build(total if rank == 0 else n_keys)
+    nb = ctx.shard_node_bytes()
+    max_nodes = max(int((allv[:, 2] - allv[:, 1]).max()), 1)
+    max_keys = max(int(allv[:, 0].max()), 1)
+    # rank 0 sends nothing: its own slices are already in place
+    t_nodes = torch.empty(max_nodes * nb, dtype=torch.uint8, device=device)
+    t_keys = torch.empty(max_keys * 8, dtype=torch.uint8, device=device)
+    if rank != 0:
+        ctx.shard_export(g_lo, g_hi, t_nodes.data_ptr(), t_keys.data_ptr())
+    g_nodes = [torch.empty_like(t_nodes) for _ in range(world)] if rank == 0 else None
+    g_keys = [torch.empty_like(t_keys) for _ in range(world)] if rank == 0 else None
+    dist.gather(t_nodes, g_nodes, dst=0)
+    dist.gather(t_keys, g_keys, dst=0)
+    if rank != 0:
+        return 0
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)  # the gathered buffers are read on the context's own stream
+    for r in range(1, world):
+        ctx.shard_import(int(allv[r, 1]), int(allv[r, 2]), g_nodes[r].data_ptr(), int(allv[r, 0]), g_keys[r].data_ptr())
+    return total
+
+
 def merge_shards_on_rank0(ctx, my_imgs, rank, world, device=None):
     """After every rank has triangulated its shard: ship the packed per-image results (best candidate + score
     per node, valid edges) to rank 0 with one tensor `gather` -- nothing is sent to the other ranks -- and
