@@ -376,9 +376,13 @@ int lt_run_device_async(lt_ctx *ctx) {
         gen(2);  // the storing run, lists back to back
       }
     }
-    // with the per-kernel events on, the one after k_tri_rows also ends the generation stage
+    // with the per-kernel events on, the one after k_tri_rows also ends the generation stage; without them NO event is
+    // recorded here (an event between two kernels opens a 5-6 us gap in the stream; round 4): the generation stage's
+    // timer then runs to the end of the placement and the placement's reads 0 -- bench.py prices both in its extra
+    // steps with LT_FINE_TIMERS=2
+    bool gen_event_pending = false;
     if (fine_gen && ctx->n_blk > 0 && ctx->max_rows > 0) ev_gen_end = 10;
-    else HIPCHK(ctx, hipEventRecord(ev[3], st));
+    else gen_event_pending = true;
     long long *hC = hp;  // this set's slot 0
     long long hC_fallback = 0;
     if (!hC) hC = &hC_fallback;
@@ -477,6 +481,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     // ... and the one in front of k_score3 ends the placement stage (it then includes k_cand_meta)
     if (fine_score && C_bound > 0) ev_place_end = 11;
     else HIPCHK(ctx, hipEventRecord(ev[4], st));
+    if (gen_event_pending) ev_gen_end = ev_place_end;
   } else if (ctx->job_mode == 2) {
     ctx->perm_mode = false;
     ctx->compact_valid = true;
