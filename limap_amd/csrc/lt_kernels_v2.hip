@@ -38,12 +38,6 @@ namespace lt {
 //               st_*[r0 ...]; wave_count[] holds the list lengths.  In the fast path the number of
 //               valid candidates per (block, line) run is counted in cnt_bl for the placement pass.
 // Tuning knobs (compile-time; Makefile EXTRA=-D...)
-#ifndef LT_TABL
-#define LT_TABL 0  // developer ablations of k_tri_rows (timing only): 1 no segment gathers, 2 no triangulation arithmetic
-#endif
-#ifndef LT_GABL
-#define LT_GABL 0  // developer ablations of k_gates (timing only): 1 conflict-free table reads, 2 no gate arithmetic
-#endif
 #ifndef LT_GEN_CHUNKS
 #define LT_GEN_CHUNKS 5
 #endif
@@ -277,9 +271,6 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
             // select): unpacking the halves first cost two more VALU instructions per row in an issue-bound kernel
             unsigned off1;
             asm("v_mad_u32_u16 %0, %1, %2, 0" : "=v"(off1) : "v"(row), "s"(80u));
-#if LT_GABL == 1  // ablation: conflict-free LDS reads (every lane its own consecutive record)
-            off1 = (unsigned)lane * 80u;
-#endif
             const double2 *p1 = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T1) + off1);
             e0 = p1[0]; e1 = p1[1]; e2 = p1[2]; e3 = p1[3]; e4 = p1[4];
           } else {
@@ -289,9 +280,6 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
           if (kLds2) {
             unsigned off2;  // (high half of the row) x 80
             asm("v_mad_u32_u16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(off2) : "v"(row), "s"(80u));
-#if LT_GABL == 1
-            off2 = (unsigned)lane * 80u;
-#endif
             const double2 *p2 = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(T2) + off2);
             h0 = p2[0]; h1 = p2[1]; h2 = p2[2]; h3 = p2[3]; h4 = p2[4];  // (a conflict-free access pattern was timed: no faster)
           } else {
@@ -299,12 +287,8 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
             const double2 *p2 = reinterpret_cast<const double2 *>(a.gates + g2 + ng);
             h0 = p2[0]; h1 = p2[1]; h2 = p2[2]; h3 = p2[3]; h4 = p2[4];
           }
-#if LT_GABL == 2  // ablation: table reads kept, no gate arithmetic
-          res = (e0.x + e1.x + e2.x + e3.x + e4.x + h0.x + h1.x + h2.x + h3.x + h4.x + e0.y + h0.y + e4.y + h4.y > 1e300) ? 1 : 0;
-#else
           res = gate3(cfg, e0.x, e0.y, e1.x, e1.y, e2.x, e2.y, e3.x, e3.y, e4.x, e4.y,  // l1: endpoints, rs, re
                       h0.x, h0.y, h1.x, h1.y, h2.x, h2.y, h3.x, h3.y, h4.x, h4.y, F);   // l2: SegGate fields
-#endif
         }
         // the outcome of chunk c is two bits per lane; the survivor list is written after the loop, so
         // that no global store (and no wait for one) sits between the chunks
@@ -452,23 +436,11 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
       const uint2 u = a.st_row[rs0 + (e - first)];
       line = (int)(u.x & 0x7FFFFFFFu);
       ng = (int)u.y;
-#if LT_TABL == 1  // ablation: segment records read lane-consecutively (no gathers; results wrong)
-      const Seg &s1 = a.segs[g1 + (lane & 31)];
-      const Seg &s2 = a.segs[g2 + (lane & 31)];
-#else
       const Seg &s1 = a.segs[g1 + line];
       const Seg &s2 = a.segs[g2 + ng];
-#endif
       ok = true;
-#if LT_TABL == 2  // ablation: gathers kept, no triangulation arithmetic (every survivor "valid", record = raw segment)
-      o.r.s[0] = s1.x1; o.r.s[1] = s1.y1; o.r.s[2] = s2.x1; o.r.e[0] = s2.y1; o.r.e[1] = s1.n[0]; o.r.e[2] = s2.n[0];
-      o.r.depth[0] = 1.0; o.r.depth[1] = 1.0; o.unc = 1.0;
-      o.r.seg[0] = s2.x1; o.r.seg[1] = s2.y1; o.r.seg[2] = s2.x2; o.r.seg[3] = s2.y2;
-      o.r.dir[0] = 1.0; o.r.dir[1] = 0.0; o.r.dir[2] = 0.0;
-#else
       if (u.x >> 31) ok = gen_gates(cfg, s1, s2, pr->F);  // the cheap gates could not decide
       if (ok) ok = gen_finish(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B, &o);
-#endif
       if (kExtra) {
         // both segments long enough (:166,177) -- with extra proposals stage A lets every row through
         L2 l1{mk2(s1.x1, s1.y1), mk2(s1.x2, s1.y2)};
