@@ -243,6 +243,7 @@ int lt_run_device_async(lt_ctx *ctx) {
   if (!ctx->h_pinned) LT_FINISH(ctx);  // no pinned result slots: nothing may stay in flight
   ctx->shard_keys = ctx->shard_own_keys = -1;  // a new run: nothing of an earlier merge is pending
   const int set = ctx->run_pending ? (ctx->pend_set ^ 1) : 0;
+  if (ctx->h_pinned) std::memset(ctx->h_pinned + 8 * set, 0, 32);  // this set's result slots (its previous run is finished)
   if (set == 1 && !ctx->ev_b[0])
     for (auto &e : ctx->ev_b) HIPCHK(ctx, hipEventCreate(&e));
   hipEvent_t *ev = set ? ctx->ev_b : ctx->ev;
@@ -601,7 +602,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                               ctx->d_st_key.as<unsigned>(), ctx->d_item_off.as<long long>(),
                               ctx->d_blk_chunk_off.as<int>(), ctx->d_masks.as<unsigned long long>(),
                               ctx->d_mask_pos.as<long long>(), P, ctx->d_tri_off.as<long long>(), G,
-                              ctx->d_place_perm.as<unsigned>(), ctx->d_result3.as<long long>() + 3);
+                              ctx->d_place_perm.as<unsigned>(), (hp ? hp : ctx->d_result3.as<long long>()) + 3);
       ctx->ex_region_cap = region_cap;
       launch_cand_node(st, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>());
       ctx->perm_mode = true;
@@ -714,17 +715,17 @@ int lt_run_device_async(lt_ctx *ctx) {
                 ctx->perm_mode ? ctx->d_st_l.as<double>() : ctx->d_lite.as<double>(),
                 ctx->d_best_c.as<Cand>(), ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(),
                 ctx->d_ntris.as<int>(), /*wide=*/ctx->job_mode == 2, ctx->d_err.as<int>(),
-                ctx->d_pair_counter.as<unsigned long long>(), ctx->d_result3.as<long long>(),
+                ctx->d_pair_counter.as<unsigned long long>(), hp ? hp : ctx->d_result3.as<long long>(),
                 ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
   if (!hp) HIPCHK(ctx, hipEventRecord(ev[7], st));  // with result slots the end marker below also ends the run
   HIPCHK(ctx, hipGetLastError());
   // the device error flag, the candidate count and the pair statistic ride on the stream into this set's
   // pinned slots; finish_run reads them behind the end marker
   if (hp) {
-    // hp[0] candidate count, hp[1] error flag, hp[2] pair statistic: one record, gathered by k_select
-    if (G <= 0) HIPCHK(ctx, hipMemsetAsync(ctx->d_result3.p, 0, 32, st));  // no nodes: k_select did not run
-    // hp[3]: fullest staging region of the one-pass exhaustive mode (k_place_ex)
-    HIPCHK(ctx, hipMemcpyAsync(&hp[0], ctx->d_result3.p, 32, hipMemcpyDeviceToHost, st));
+    // hp[0] candidate count, hp[1] error flag, hp[2] pair statistic: one record, WRITTEN BY k_select straight into this
+    // set's page-locked slots (round 4: the 32-byte device-to-host copy was a 4 us blit kernel in every step); hp[3]: fullest
+    // staging region of the one-pass exhaustive mode (k_place_ex).  The slots were zeroed when the run was enqueued (no
+    // nodes: k_select does not run).
     HIPCHK(ctx, hipEventRecord(ev[12], st));
   }
   int rc_prev = LT_OK;
