@@ -327,6 +327,12 @@ int lt_fn_aggregate_line3d_list(int n, const double *lines10, const double *scor
  * widest vector path the CPU has, 1 = scalar, 2 = AVX2, 3 = AVX-512 (a level the CPU lacks falls back to the widest).
  * No context, no device. */
 int lt_fn_pack_match_rows(const int32_t *rows, int64_t n, uint32_t *out, uint32_t stats[3], int level);
+/* the same pass into the COMPRESSED block form the rows cross PCIe in since round 4 (17 bits per row: the neighbour line
+ * of every row + one "a new line starts here" bit; limap_amd/csrc/lt_rows.h), for blocks sorted by line id with steps of
+ * 0 / +1 -- what limap's matchers write.  out: lt_fn_compressed_block_words(n) words, 8-byte aligned; stats[3] != 0: the
+ * block is not of that shape (it is then staged in the plain form above). */
+int64_t lt_fn_compressed_block_words(int64_t n);
+int lt_fn_pack_match_rows_compressed(const int32_t *rows, int64_t n, uint32_t *out, uint32_t stats[4], int level);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "lt_fn_get_normal_direction", "lt_fn_get_direction_from_vp", "lt_fn_triangulate_point",
     "lt_fn_triangulate_line_with_direction", "lt_fn_triangulate_line_with_one_point", "lt_fn_compute_fundamental_matrix", "lt_fn_compute_epipolar_IoU",
     "lt_fn_triangulate_line", "lt_fn_aggregate_line3d_list", "lt_fn_pack_match_rows",
+    "lt_fn_compressed_block_words", "lt_fn_pack_match_rows_compressed",
 ]
 
 
@@ -184,6 +185,9 @@ def load_library():
     L.lt_fn_compute_epipolar_IoU.argtypes = [vp, dp, dp, dp, dp, dp]
     L.lt_fn_aggregate_line3d_list.argtypes = [C.c_int, dp, dp, C.c_int, dp]
     L.lt_fn_pack_match_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+    L.lt_fn_compressed_block_words.argtypes = [C.c_int64]
+    L.lt_fn_compressed_block_words.restype = C.c_int64
+    L.lt_fn_pack_match_rows_compressed.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
     L.lt_fn_triangulate_line.argtypes = [vp, dp, dp, dp, dp, C.c_int, dp]
     _lib = L
     return L

@@ -395,6 +395,7 @@ int init_common(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *s
   ctx->job_mode = 0;
   ctx->job_imgs.clear(); ctx->job_nbs.clear(); ctx->job_order.clear();
   ctx->h_m_off.assign(1, 0); ctx->h_m_pairs.clear(); ctx->streamed_ints = 0;
+  ctx->h_c_off.clear(); ctx->h_ovf_off.clear(); ctx->h_line0.clear(); ctx->h_ovf.clear();
   ctx->rows_sorted = true;
   ctx->uploaded = ctx->ran = ctx->downloaded = false;
   return LT_OK;
@@ -544,7 +545,7 @@ void lt_destroy(lt_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   DevBuf *bufs[] = {&ctx->d_kvec, &ctx->d_qvec, &ctx->d_tvec, &ctx->d_segs_raw, &ctx->d_cams, &ctx->d_segs,
                     &ctx->d_seg_off, &ctx->d_node_img, &ctx->d_nb_off, &ctx->d_blk_img, &ctx->d_blk_nb,
-                    &ctx->d_blk_slot, &ctx->d_blk_order, &ctx->d_m_off, &ctx->d_m_pairs, &ctx->d_pairs,
+                    &ctx->d_blk_slot, &ctx->d_blk_order, &ctx->d_m_off, &ctx->d_m_pairs, &ctx->d_c_stream, &ctx->d_ovf, &ctx->d_rowdesc, &ctx->d_pairs,
                     &ctx->d_keys, &ctx->d_rows, &ctx->d_row_blk, &ctx->d_skeys, &ctx->d_srows, &ctx->d_sort_tmp,
                     &ctx->d_conn_off, &ctx->d_st_c, &ctx->d_st_l, &ctx->d_flags, &ctx->d_pos, &ctx->d_scan_tmp,
                     &ctx->d_item_off, &ctx->d_masks, &ctx->d_mask_cnt, &ctx->d_mask_pos, &ctx->d_cand, &ctx->d_hcand, &ctx->d_hlite,

@@ -372,6 +372,18 @@ int lt_fn_pack_match_rows(const int32_t *rows, int64_t n, uint32_t *out, uint32_
   return LT_OK;
 }
 
+int64_t lt_fn_compressed_block_words(int64_t n) { return n < 0 ? -1 : (int64_t)lt::cb_words(n); }
+int lt_fn_pack_match_rows_compressed(const int32_t *rows, int64_t n, uint32_t *out, uint32_t stats[4], int level) {
+  if (n < 0 || (n > 0 && (!rows || !out)) || !stats) return LT_ERR_ARGUMENT;
+  if ((reinterpret_cast<uintptr_t>(out) & 7u) != 0) return LT_ERR_ARGUMENT;  // the bit words are 64-bit
+  const lt::RowStats rs = lt::pack_rows_cb(rows, n, out, level);
+  stats[0] = rs.mx_line;
+  stats[1] = rs.mx_ng;
+  stats[2] = (uint32_t)rs.unsorted;
+  stats[3] = (uint32_t)rs.irregular;
+  return LT_OK;
+}
+
 int lt_fn_aggregate_line3d_list(int n, const double *lines10, const double *scores, int num_outliers, double out7[7]) {
   if (n <= 0 || !lines10 || !scores || !out7 || num_outliers < 0) return LT_ERR_ARGUMENT;
   if (n >= 4 && 2 * num_outliers >= 2 * n) return LT_ERR_ARGUMENT;  // projections[num_outliers] would be out of range

@@ -8,11 +8,18 @@ using namespace lt_impl;
 extern "C" {
 
 // ---- the host pass over the match rows (lt_rows.h), shared out over the persistent team (lt_pool.h) ----
+// The staged form of a block is the COMPRESSED one of lt_rows.h (17 bits per row) at word offset `dst` of the stream
+// (cb_words(n) words, known before the pass); a block that cannot take it (a line step other than 0 / +1) goes in the
+// plain one-word-per-row form to the context's overflow array instead, and its place in the stream stays unused.
 struct RowBlk {  // one (image, neighbour) block of rows
   const int32_t *src; long long n, dst; long long M1, M2; int img_id, nb_id;
 };
 struct RowJob {
   const RowBlk *blks; int nb_total; const int *chunk_of; std::atomic<int> *chunk_done; int *bad; unsigned *out;
+  long long *ovf_off = nullptr;  // per block: -1 = compressed in the stream, else first word in the overflow array
+  int *line0 = nullptr;          // per block: line id of its first row
+  std::vector<unsigned> *ovf = nullptr;
+  std::mutex *ovf_mu = nullptr;
   std::atomic<int> next_blk{0}, bad_any{0}, uns_any{0};
   static void run(void *arg, int, int) {
     RowJob &J = *static_cast<RowJob *>(arg);
@@ -21,11 +28,21 @@ struct RowJob {
       const int b = J.next_blk.fetch_add(1, std::memory_order_relaxed);
       if (b >= J.nb_total) break;
       const RowBlk &B = J.blks[b];
-      const lt::RowStats rs = lt::pack_rows(B.src, B.n, J.out + B.dst);  // packed: line | neighbour line << 16
+      const lt::RowStats rs = lt::pack_rows_cb(B.src, B.n, J.out + B.dst);
       int err = 0;
       if (B.n > 0 && (unsigned long long)rs.mx_line >= (unsigned long long)B.M1) err |= 1;
       if (B.n > 0 && (unsigned long long)rs.mx_ng >= (unsigned long long)B.M2) err |= 2;
       J.bad[b] = err;
+      J.line0[b] = B.n > 0 ? (int)B.src[0] : 0;
+      J.ovf_off[b] = -1;
+      if (rs.irregular && !err) {  // not the matchers' shape: the plain form, line | neighbour line << 16
+        static thread_local std::vector<unsigned> tmp;
+        tmp.resize((size_t)B.n);
+        (void)lt::pack_rows(B.src, B.n, tmp.data());
+        std::lock_guard<std::mutex> lk(*J.ovf_mu);
+        J.ovf_off[b] = (long long)J.ovf->size();
+        J.ovf->insert(J.ovf->end(), tmp.begin(), tmp.end());
+      }
       uns_t |= rs.unsorted;
       if (err) J.bad_any.store(1, std::memory_order_relaxed);
       if (J.chunk_done) J.chunk_done[J.chunk_of[b]].fetch_add(1, std::memory_order_release);
@@ -56,6 +73,7 @@ static int begin_image(lt_ctx *ctx, int img_id, int mode, int *idx_out) {
   if (ctx->downloaded) {  // a new batch after results were read: start a fresh job
     ctx->job_imgs.clear(); ctx->job_nbs.clear(); ctx->job_order.clear();
     ctx->h_m_off.assign(1, 0); ctx->h_m_pairs.clear(); ctx->streamed_ints = 0;
+    ctx->h_c_off.clear(); ctx->h_ovf_off.clear(); ctx->h_line0.clear(); ctx->h_ovf.clear();
     ctx->rows_sorted = true;
     ctx->uploaded = ctx->ran = ctx->downloaded = false;
   }
@@ -85,7 +103,7 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
   for (int k = 0; k < n_nb; ++k) order[k] = k;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nb_ids[a] < nb_ids[b]; });
   std::vector<int> nbs(n_nb), ord(n_nb);
-  std::vector<long long> M2(n_nb), dst(n_nb + 1, 0);
+  std::vector<long long> M2(n_nb), dst(n_nb + 1, 0);  // dst: word offsets of the blocks' compressed forms
   const long long M1 = ctx->seg_off[idx + 1] - ctx->seg_off[idx];
   for (int k = 0; k < n_nb; ++k) {
     int o = order[k];
@@ -96,9 +114,10 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
     nbs[k] = it->second;
     ord[k] = k;  // already ascending id
     M2[k] = ctx->seg_off[it->second + 1] - ctx->seg_off[it->second];
-    dst[k + 1] = dst[k] + n_rows[o];
+    dst[k + 1] = dst[k] + (long long)lt::cb_words(n_rows[o]);
   }
   const size_t base = ctx->h_m_pairs.size();
+  const size_t ovf_base = ctx->h_ovf.size();
   {
     // the staging block may move when it grows: no asynchronous copy may still be reading it
     size_t want = base + (size_t)dst[n_nb];
@@ -119,10 +138,13 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
   std::vector<RowBlk> blks((size_t)n_nb);
   for (int k = 0; k < n_nb; ++k)
     blks[(size_t)k] = RowBlk{rows[order[k]], n_rows[order[k]], dst[k], M1, M2[k], img_id, nb_ids[order[k]]};
+  std::vector<long long> ovf_off((size_t)std::max(n_nb, 1), -1);
+  std::vector<int> line0((size_t)std::max(n_nb, 1), 0);
   RowJob job;
   job.blks = blks.data(); job.nb_total = n_nb; job.chunk_of = nullptr; job.chunk_done = nullptr;
   job.bad = bad.data(); job.out = reinterpret_cast<unsigned *>(out);
-  if (dst[n_nb] >= (1 << 14)) {
+  job.ovf_off = ovf_off.data(); job.line0 = line0.data(); job.ovf = &ctx->h_ovf; job.ovf_mu = &ctx->ovf_mu;
+  if (dst[n_nb] >= (1 << 13)) {
     lt_host::SpinPool &pool = lt_host::SpinPool::get(lt_host::row_workers());
     const bool shared = pool.begin(&RowJob::run, &job);  // false: the team is busy with another caller's job
     RowJob::run(&job, 0, 0);
@@ -134,6 +156,7 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
   for (int k = 0; k < n_nb; ++k) {
     if (!bad[k]) continue;
     ctx->h_m_pairs.grow_to(base);
+    ctx->h_ovf.resize(ovf_base);
     if (bad[k] & 1)  // base_line_triangulator.cc:87-94
       return fail(ctx, LT_ERR_RUNTIME,
                   "IndexError! Out-of-index matches exist between image (img_id = " + std::to_string(img_id) +
@@ -150,30 +173,35 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
     const size_t from = ctx->streamed_ints, end = base + (size_t)dst[n_nb];
     if (hipSetDevice(ctx->device) == hipSuccess) {
       bool ok = true;
-      if (sizeof(int) * end > ctx->d_m_pairs.cap) {
+      if (sizeof(int) * end > ctx->d_c_stream.cap) {
         // grow the device buffer (first copy: sized for the whole batch), keeping the streamed prefix
         DevBuf nb;
         size_t want = sizeof(int) * std::max(end, ctx->h_m_pairs.capacity());
         ok = nb.ensure(want);
         if (ok && from > 0)
-          ok = hipMemcpyAsync(nb.p, ctx->d_m_pairs.p, sizeof(int) * from, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+          ok = hipMemcpyAsync(nb.p, ctx->d_c_stream.p, sizeof(int) * from, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
                hipStreamSynchronize(ctx->stream) == hipSuccess;
         if (ok) {
-          ctx->d_m_pairs.release();
-          ctx->d_m_pairs = nb;
+          ctx->d_c_stream.release();
+          ctx->d_c_stream = nb;
         } else {
           nb.release();
           (void)hipGetLastError();
         }
       }
-      if (ok && hipMemcpyAsync(ctx->d_m_pairs.as<int>() + from, ctx->h_m_pairs.data() + from, sizeof(int) * (end - from),
+      if (ok && hipMemcpyAsync(ctx->d_c_stream.as<int>() + from, ctx->h_m_pairs.data() + from, sizeof(int) * (end - from),
                                hipMemcpyHostToDevice, ctx->stream) == hipSuccess)
         ctx->streamed_ints = end;
       else
         (void)hipGetLastError();  // not fatal: lt_upload sends whatever was not streamed
     }
   }
-  for (int k = 0; k < n_nb; ++k) ctx->h_m_off.push_back(ctx->h_m_off.back() + n_rows[order[k]]);
+  for (int k = 0; k < n_nb; ++k) {
+    ctx->h_m_off.push_back(ctx->h_m_off.back() + n_rows[order[k]]);
+    ctx->h_c_off.push_back((long long)base + dst[k]);
+    ctx->h_ovf_off.push_back(ovf_off[(size_t)k]);
+    ctx->h_line0.push_back(line0[(size_t)k]);
+  }
   ctx->job_imgs.push_back(idx);
   ctx->job_nbs.push_back(nbs);
   ctx->job_order.push_back(ord);
@@ -203,7 +231,7 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
   };
   std::vector<RowBlk> blks;
   std::vector<Img> imgs;
-  long long total_rows = 0;
+  long long total_rows = 0;  // in WORDS of the stream: the blocks' compressed forms one behind the other
   std::vector<char> seen_here((size_t)std::max(ctx->n_img, 1), 0);
   // ---- pass 1 (serial, cheap): the per-image bookkeeping of lt_triangulate_image_rows, block descriptors ----
   for (int k = 0; k < n_images; ++k) {
@@ -233,7 +261,7 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
       im.cnt.push_back(n);
       blks.push_back(RowBlk{rows[nb_off[k] + o], n, total_rows, M1, ctx->seg_off[it->second + 1] - ctx->seg_off[it->second],
                          img_ids[k], nb[o]});
-      total_rows += n;
+      total_rows += (long long)lt::cb_words(n);
     }
     imgs.push_back(std::move(im));
   }
@@ -241,6 +269,7 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
   // read only now: pass 1 writes no rows, but its first begin_image() starts a new batch when the previous one has been
   // read back (results downloaded / tracks computed) and then clears the staging block, its offsets and streamed_ints
   const size_t base = ctx->h_m_pairs.size();
+  const size_t ovf_base = ctx->h_ovf.size();
   lap("bookkeeping");
   // ---- staging: one allocation for the whole call ----
   {
@@ -267,15 +296,15 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
   }
   if (stream_ok) {
     const size_t end = base + (size_t)total_rows;
-    if (sizeof(int) * end > ctx->d_m_pairs.cap) {
+    if (sizeof(int) * end > ctx->d_c_stream.cap) {
       DevBuf nbuf;
       bool ok = nbuf.ensure(sizeof(int) * std::max(end, ctx->h_m_pairs.capacity()));
       if (ok && base > 0)
-        ok = hipMemcpyAsync(nbuf.p, ctx->d_m_pairs.p, sizeof(int) * base, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+        ok = hipMemcpyAsync(nbuf.p, ctx->d_c_stream.p, sizeof(int) * base, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
              hipStreamSynchronize(ctx->stream) == hipSuccess;
       if (ok) {
-        ctx->d_m_pairs.release();
-        ctx->d_m_pairs = nbuf;
+        ctx->d_c_stream.release();
+        ctx->d_c_stream = nbuf;
       } else {
         nbuf.release();
         (void)hipGetLastError();
@@ -292,7 +321,7 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
   {
     long long acc_rows = 0;
     for (int b = 0; b < nb_total; ++b) {
-      acc_rows += blks[(size_t)b].n;
+      acc_rows += (long long)lt::cb_words(blks[(size_t)b].n);
       if (acc_rows >= kChunkRows || b == nb_total - 1) {
         chunk_end.push_back(b + 1);
         acc_rows = 0;
@@ -305,10 +334,13 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
     for (; b < chunk_end[(size_t)c]; ++b) chunk_of[(size_t)b] = c;
   std::vector<std::atomic<int>> chunk_done((size_t)n_chunks);
   for (auto &x : chunk_done) x.store(0, std::memory_order_relaxed);
+  std::vector<long long> ovf_off((size_t)std::max(nb_total, 1), -1);
+  std::vector<int> line0((size_t)std::max(nb_total, 1), 0);
   RowJob job;
   job.blks = blks.data(); job.nb_total = nb_total; job.chunk_of = chunk_of.data(); job.chunk_done = chunk_done.data();
   job.bad = bad.data(); job.out = reinterpret_cast<unsigned *>(out);
-  int *const d_rows = stream_ok ? ctx->d_m_pairs.as<int>() : nullptr;
+  job.ovf_off = ovf_off.data(); job.line0 = line0.data(); job.ovf = &ctx->h_ovf; job.ovf_mu = &ctx->ovf_mu;
+  int *const d_rows = stream_ok ? ctx->d_c_stream.as<int>() : nullptr;
   int *const h_rows = ctx->h_m_pairs.data();
   size_t streamed_to = ctx->streamed_ints;
   lap("device buffer");
@@ -327,7 +359,8 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
       }
       if (!ok || job.bad_any.load(std::memory_order_relaxed)) continue;
       const size_t from = base + (size_t)blks[(size_t)first].dst;
-      const size_t to = base + (size_t)(blks[(size_t)chunk_end[(size_t)c] - 1].dst + blks[(size_t)chunk_end[(size_t)c] - 1].n);
+      const size_t to = base + (size_t)(blks[(size_t)chunk_end[(size_t)c] - 1].dst +
+                                        (long long)lt::cb_words(blks[(size_t)chunk_end[(size_t)c] - 1].n));
       if (to > from) {
         if (hipMemcpyAsync(d_rows + from, h_rows + from, sizeof(int) * (to - from), hipMemcpyHostToDevice, ctx->stream) == hipSuccess)
           streamed_to = to;
@@ -350,6 +383,7 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
       ctx->streamed_ints = base;
     }
     ctx->h_m_pairs.grow_to(base);
+    ctx->h_ovf.resize(ovf_base);
     const RowBlk &B = blks[(size_t)b];
     if (bad[(size_t)b] & 1)  // base_line_triangulator.cc:87-94
       return fail(ctx, LT_ERR_RUNTIME,
@@ -360,6 +394,15 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
     return fail(ctx, LT_ERR_RUNTIME, "IndexError! neighbour line id out of range in matches of image " + std::to_string(B.img_id));
   }
   if (unsorted) ctx->rows_sorted = false;
+  {
+    size_t b = 0;
+    for (Img &im : imgs)
+      for (size_t e = 0; e < im.cnt.size(); ++e, ++b) {
+        ctx->h_c_off.push_back((long long)base + blks[b].dst);
+        ctx->h_ovf_off.push_back(ovf_off[b]);
+        ctx->h_line0.push_back(line0[b]);
+      }
+  }
   for (Img &im : imgs) {
     for (long long n : im.cnt) ctx->h_m_off.push_back(ctx->h_m_off.back() + n);
     ctx->job_imgs.push_back(im.idx);

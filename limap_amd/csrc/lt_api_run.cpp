@@ -49,16 +49,18 @@ int lt_upload(lt_ctx *ctx) {
     std::vector<int> job_pos(ctx->n_img, -1);
     for (size_t j = 0; j < ctx->job_imgs.size(); ++j) job_pos[ctx->job_imgs[j]] = (int)j;
     std::vector<long long> m_off(ctx->n_blk + 1, 0);
-    bool in_order = true;
+    // per device block: where its staged form lies (stream / overflow) and where its rows go
+    std::vector<lt::RowDesc> desc((size_t)std::max(ctx->n_blk, 1));
     {
       long long b = 0;
       for (int i = 0; i < ctx->n_img; ++i) {
         int j = job_pos[i];
         if (j < 0) continue;
-        if (call_first_blk[j] != b) in_order = false;
         for (size_t k = 0; k < ctx->job_nbs[j].size(); ++k, ++b) {
           long long cb = call_first_blk[j] + (long long)k;
-          m_off[b + 1] = m_off[b] + (ctx->h_m_off[cb + 1] - ctx->h_m_off[cb]);
+          const long long n = ctx->h_m_off[cb + 1] - ctx->h_m_off[cb];
+          m_off[b + 1] = m_off[b] + n;
+          desc[(size_t)b] = lt::RowDesc{ctx->h_c_off[(size_t)cb], ctx->h_ovf_off[(size_t)cb], m_off[b], (int)n, ctx->h_line0[(size_t)cb]};
         }
       }
     }
@@ -67,31 +69,26 @@ int lt_upload(lt_ctx *ctx) {
     ctx->max_rows = 0;
     for (int bq = 0; bq < ctx->n_blk; ++bq) ctx->max_rows = std::max(ctx->max_rows, m_off[bq + 1] - m_off[bq]);
     if (ctx->P >= (1ll << 32) - 1) return fail(ctx, LT_ERR_ARGUMENT, "too many match rows in one batch (>= 2^32-1)");
-    if (sizeof(int) * (size_t)std::max<long long>(ctx->P, 1) > ctx->d_m_pairs.cap) {
+    ENSURE(ctx, ctx->d_m_pairs, sizeof(int) * (size_t)std::max<long long>(ctx->P, 1));
+    // the stream travels in call order, whatever part of it was not sent while the calls were still buffering; the
+    // blocks are expanded on the device into device block order (so out-of-order calls need no re-packing any more)
+    const size_t total_w = ctx->h_m_pairs.size();
+    if (sizeof(int) * std::max<size_t>(total_w, 1) > ctx->d_c_stream.cap) {
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       ctx->streamed_ints = 0;  // the buffer is replaced: everything is sent again
-      ENSURE(ctx, ctx->d_m_pairs, sizeof(int) * (size_t)std::max<long long>(ctx->P, 1));
+      ENSURE(ctx, ctx->d_c_stream, sizeof(int) * std::max<size_t>(total_w, 1));
     }
-    if (in_order) {
-      // call order == device order: only what was not streamed during buffering is still to be sent
-      const size_t total = (size_t)ctx->P, sent = std::min(ctx->streamed_ints, total);
-      if (total > sent)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_m_pairs.as<int>() + sent, ctx->h_m_pairs.data() + sent, sizeof(int) * (total - sent),
+    {
+      const size_t sent = std::min(ctx->streamed_ints, total_w);
+      if (total_w > sent)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_c_stream.as<int>() + sent, ctx->h_m_pairs.data() + sent, sizeof(int) * (total_w - sent),
                                    hipMemcpyHostToDevice, ctx->stream));
-    } else {
-      long long b = 0;
-      for (int i = 0; i < ctx->n_img; ++i) {
-        int j = job_pos[i];
-        if (j < 0) continue;
-        for (size_t k = 0; k < ctx->job_nbs[j].size(); ++k, ++b) {
-          long long cb = call_first_blk[j] + (long long)k;
-          long long n = ctx->h_m_off[cb + 1] - ctx->h_m_off[cb];
-          if (n > 0)
-            HIPCHK(ctx, hipMemcpyAsync(ctx->d_m_pairs.as<int>() + m_off[b], ctx->h_m_pairs.data() + ctx->h_m_off[cb],
-                                       sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-        }
-      }
+      ctx->streamed_ints = total_w;
     }
+    if ((rc = upload_vec(ctx, ctx->d_ovf, ctx->h_ovf))) return rc;
+    if ((rc = upload_vec(ctx, ctx->d_rowdesc, desc))) return rc;
+    launch_expand_rows(ctx->stream, ctx->n_blk, ctx->d_rowdesc.p, ctx->d_c_stream.as<unsigned>(), ctx->d_ovf.as<unsigned>(),
+                       ctx->d_m_pairs.as<unsigned>());
     if ((rc = upload_vec(ctx, ctx->d_m_off, m_off))) return rc;
     // per-block records of the matched pipeline (row range, images, segment bases): a function of the job
     ENSURE(ctx, ctx->d_blkrec, blk_rec_bytes() * (size_t)std::max(ctx->n_blk, 1));

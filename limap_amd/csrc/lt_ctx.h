@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <hip/hip_runtime.h>
 #include <unordered_map>
@@ -164,8 +165,17 @@ struct lt_ctx {
   std::vector<std::vector<int>> job_nbs;   // per job image: neighbour image indices, processing order
   std::vector<std::vector<int>> job_order; // per job image: slots in ascending neighbour-id order
   std::vector<long long> h_m_off;          // per block row offsets (n_blk+1), matched mode
-  lt_host::RawInts h_m_pairs;              // P packed match rows, line | neighbour line << 16 (pinned staging, call order)
-  size_t streamed_ints = 0;                // prefix of h_m_pairs already enqueued to d_m_pairs
+  // the staged match rows: a stream of 32-bit words (pinned, call order) holding every block in the COMPRESSED form of
+  // lt_rows.h (17 bits per row: neighbour lines + "new line" bits) at h_c_off[block]; blocks that cannot take that form
+  // lie in the plain form (line | neighbour line << 16) in h_ovf at h_ovf_off[block] (-1: compressed).  k_expand_rows
+  // rebuilds the plain rows of every block on the device (d_m_pairs, device block order) from both.
+  lt_host::RawInts h_m_pairs;
+  size_t streamed_ints = 0;                // prefix of the stream already enqueued to d_c_stream
+  std::vector<long long> h_c_off, h_ovf_off;  // per call-order block
+  std::vector<int> h_line0;                // per call-order block: line id of its first row
+  std::vector<unsigned> h_ovf;
+  std::mutex ovf_mu;
+  DevBuf d_c_stream, d_ovf, d_rowdesc;
   std::vector<char> triangulated;          // per image: already passed to TriangulateImage*
   bool uploaded = false, ran = false, downloaded = false;
   // neighbours_ of every triangulated image (ids), persists for the tail

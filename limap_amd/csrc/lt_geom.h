@@ -159,6 +159,15 @@ LT_HD d3 cam_backproject(const Cam &c, d2 p) {  // (R^T K^-1) x~, not normalised
 }
 LT_HD d3 cam_ray(const Cam &c, d2 p) { return unit(cam_backproject(c, p)); }
 
+// Where the staged form of a block of match rows lies and where its rows go (host: lt_upload, device: k_expand_rows)
+struct RowDesc {
+  long long coff;     // first word of the compressed block in the stream
+  long long ooff;     // first word of the plain block in the overflow array, -1: compressed
+  long long row_off;  // first row of the block in the device's row array
+  int n, line0;       // rows, line id of the first row
+};
+static_assert(sizeof(RowDesc) == 32, "RowDesc layout");
+
 // ---------------------------------------------------------------------------------------------
 // Per-segment record (128 B): endpoints + view-only invariants of the generation stage.
 // ---------------------------------------------------------------------------------------------

@@ -46,6 +46,7 @@ void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const 
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
                         unsigned *base_bl, unsigned *n_tris, long long *tri_off, unsigned long long *status,
                         int *err_flag);
+void launch_expand_rows(hipStream_t st, int n_blk, const void *desc, const unsigned *stream, const unsigned *ovf, unsigned *rows);
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const CRec *st_r, const double *st_unc,

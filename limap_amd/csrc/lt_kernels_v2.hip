@@ -144,6 +144,34 @@ __global__ void k_build_blk(int n_blk, const long long *__restrict__ m_off, cons
   out[b] = r;
 }
 
+// The staged match rows arrive in the compressed block format of lt_rows.h (17 bits per row; blocks that cannot take it:
+// plain words in the overflow array).  One wave per block rebuilds the plain row words line | neighbour line << 16 that
+// k_gates reads, at the block's rows in DEVICE block order: line = first line + number of "new line" bits up to the row.
+__global__ void __launch_bounds__(64)
+k_expand_rows(int n_blk, const RowDesc *__restrict__ desc, const unsigned *__restrict__ stream,
+              const unsigned *__restrict__ ovf, unsigned *__restrict__ rows) {
+  const int b = blockIdx.x;
+  if (b >= n_blk) return;
+  const RowDesc d = desc[b];
+  const int lane = lane_id();
+  unsigned *out = rows + d.row_off;
+  if (d.ooff >= 0) {  // plain form
+    for (int r = lane; r < d.n; r += 64) out[r] = ovf[d.ooff + r];
+    return;
+  }
+  const long long nbw = ((((long long)d.n + 1) / 2) + 1) & ~1ll;  // lt_rows.h: cb_nb_words
+  const unsigned short *nb = reinterpret_cast<const unsigned short *>(stream + d.coff);
+  const unsigned long long *bits = reinterpret_cast<const unsigned long long *>(stream + d.coff + nbw);
+  unsigned base = (unsigned)d.line0;
+  for (int r0 = 0; r0 < d.n; r0 += 64) {
+    const unsigned long long w = bits[r0 >> 6];  // wave-uniform
+    const int r = r0 + lane;
+    const unsigned line = base + (unsigned)__popcll(w & ((2ull << lane) - 1ull));
+    if (r < d.n) out[r] = (line & 0xFFFFu) | ((unsigned)nb[r] << 16);
+    base += (unsigned)__popcll(w);
+  }
+}
+
 // Persistent workgroups: workgroup w takes a contiguous range of items, where item = (block, part) and
 // a part is kGateWaves slots.  Both operand tables of an item live in LDS: T1 = the first 80 bytes
 // (endpoints, start / end rays) of the image's own Seg records, reloaded only when the image changes
@@ -799,6 +827,11 @@ extern "C" int lt_debug_read_trace(unsigned long long *host, size_t n) {
 size_t seg_gate_bytes() { return sizeof(SegGate); }
 size_t seg_point_bytes() { return sizeof(SegPoint); }
 size_t blk_rec_bytes() { return sizeof(BlkRec); }
+void launch_expand_rows(hipStream_t st, int n_blk, const void *desc, const unsigned *stream, const unsigned *ovf, unsigned *rows) {
+  if (n_blk > 0)
+    hipLaunchKernelGGL(k_expand_rows, dim3((unsigned)n_blk), dim3(64), 0, st, n_blk, reinterpret_cast<const RowDesc *>(desc), stream,
+                       ovf, rows);
+}
 void launch_build_blk(hipStream_t st, int n_blk, const long long *m_off, const int *blk_img, const int *blk_nb,
                       const int *blk_slot, const long long *seg_off, const long long *blk_line_base, void *blkrec) {
   if (n_blk > 0)

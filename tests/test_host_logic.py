@@ -240,3 +240,59 @@ def test_match_row_pass_vector_paths_equal_plain_numpy():
                 assert np.array_equal(out[:n], want), (n, variant, level)
                 assert out[n] == 0xABCDABCD, "wrote past the block"
                 assert stats.tolist() == want_stats, (n, variant, level, stats.tolist(), want_stats)
+
+
+def test_compressed_match_rows_decode_to_the_rows():
+    """The compressed block form the match rows cross PCIe in (lt_rows.h, round 4): 16 bits of neighbour line per row + one
+    "new line" bit, for blocks sorted by line with steps of 0 / +1.  Scalar and AVX-512 forms against numpy: the decoded
+    rows equal the input, the column maxima / sortedness as in the plain pass, and every other shape (a gap in the line
+    ids, an inversion) is reported irregular."""
+    from limap_amd import _capi
+    L = _capi.load_library()
+    rng = np.random.default_rng(11)
+    lengths = list(range(0, 70)) + [127, 128, 129, 130, 1000, 5003]
+    for n in lengths:
+        for variant in range(5):
+            # regular: every line 0..M-1 present with 1..k rows, starting at an arbitrary first line
+            reps = rng.integers(1, 12, max(n, 1))
+            lines = np.repeat(np.arange(len(reps)), reps)[:n] + int(rng.integers(0, 40))
+            rows = np.stack([lines, rng.integers(0, 65536, n)], 1).astype(np.int32)
+            irregular = False
+            if variant == 1 and n > 2:   # a line without rows: a step of +2 somewhere
+                k = int(rng.integers(1, n))
+                rows[k:, 0] += 1 if rows[k, 0] != rows[k - 1, 0] else 2
+                irregular = True
+            if variant == 2 and n > 2:   # an inversion
+                k = int(rng.integers(1, n))
+                rows[k, 0] = rows[k - 1, 0] - 1
+                irregular = True
+            if variant == 3 and n > 0:   # a too large neighbour id: reported through the maxima, like the plain pass
+                rows[int(rng.integers(0, n)), 1] = 70000
+            if variant == 4 and n > 1:   # all rows of one line
+                rows[:, 0] = 7
+            nw = int(L.lt_fn_compressed_block_words(n))
+            assert nw % 2 == 0 and nw == ((((n + 1) // 2) + 1) & ~1) + 2 * ((n + 63) // 64)
+            buf = np.zeros(2 * n + 3, np.int32)
+            src = buf[1:1 + 2 * n].reshape(n, 2)
+            src[:] = rows
+            u = rows.astype(np.int64) & 0xFFFFFFFF
+            for level in (1, 3, 0):
+                out = np.full(nw + 2, 0xABCDABCD, np.uint32)
+                assert out.ctypes.data % 8 == 0
+                stats = np.zeros(4, np.uint32)
+                assert L.lt_fn_pack_match_rows_compressed(src.ctypes.data, n, out.ctypes.data, stats.ctypes.data, level) == 0
+                assert out[nw] == 0xABCDABCD and out[nw + 1] == 0xABCDABCD, "wrote past the block"
+                assert stats[0] == (int(u[:, 0].max()) if n else 0) and stats[1] == (int(u[:, 1].max()) if n else 0)
+                assert stats[2] == int(n > 1 and bool((rows[1:, 0] < rows[:-1, 0]).any()))
+                d = np.diff(rows[:, 0].astype(np.int64)) if n > 1 else np.zeros(0, np.int64)
+                assert bool(stats[3]) == bool(((d < 0) | (d > 1)).any()), (n, variant, level)
+                assert bool(stats[3]) == irregular or variant in (3, 4)
+                if stats[3] or variant == 3:
+                    continue
+                # decode like k_expand_rows: line = first line + number of "new line" bits up to the row
+                nbw = (((n + 1) // 2) + 1) & ~1
+                nb = out[:nbw].view(np.uint16)[:n]
+                bits = out[nbw:nw].view(np.uint64)
+                bit = np.array([(int(bits[r >> 6]) >> (r & 63)) & 1 for r in range(n)], np.int64)
+                line = (rows[0, 0] if n else 0) + np.cumsum(bit)
+                assert np.array_equal(line, rows[:, 0]) and np.array_equal(nb, rows[:, 1].astype(np.uint16)), (n, variant, level)

@@ -8,7 +8,7 @@ sc = syn.make_scene(n_views=100, n_segs=500, n_neighbors=20, seed=0)
 cfg = syn.default_triangulation_cfg()
 matches = {int(i): sc.matches_of(int(i)) for i in sc.img_ids}
 segs_list = [sc.segs_of(j) for j in range(sc.n_images)]
-for rep in range(3):
+for rep in range(6):
     t0 = time.perf_counter()
     T = tri.GlobalLineTriangulator(cfg)
     T.SetRanges(sc.ranges)
