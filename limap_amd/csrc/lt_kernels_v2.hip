@@ -147,28 +147,48 @@ __global__ void k_build_blk(int n_blk, const long long *__restrict__ m_off, cons
 // The staged match rows arrive in the compressed block format of lt_rows.h (17 bits per row; blocks that cannot take it:
 // plain words in the overflow array).  One wave per block rebuilds the plain row words line | neighbour line << 16 that
 // k_gates reads, at the block's rows in DEVICE block order: line = first line + number of "new line" bits up to the row.
-__global__ void __launch_bounds__(64)
+constexpr int kExpandWaves = 4;
+__global__ void __launch_bounds__(64 * kExpandWaves)
 k_expand_rows(int n_blk, const RowDesc *__restrict__ desc, const unsigned *__restrict__ stream,
               const unsigned *__restrict__ ovf, unsigned *__restrict__ rows) {
   const int b = blockIdx.x;
   if (b >= n_blk) return;
   const RowDesc d = desc[b];
   const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
   unsigned *out = rows + d.row_off;
   if (d.ooff >= 0) {  // plain form
-    for (int r = lane; r < d.n; r += 64) out[r] = ovf[d.ooff + r];
+    for (int r = threadIdx.x; r < d.n; r += 64 * kExpandWaves) out[r] = ovf[d.ooff + r];
     return;
   }
   const long long nbw = ((((long long)d.n + 1) / 2) + 1) & ~1ll;  // lt_rows.h: cb_nb_words
   const unsigned short *nb = reinterpret_cast<const unsigned short *>(stream + d.coff);
   const unsigned long long *bits = reinterpret_cast<const unsigned long long *>(stream + d.coff + nbw);
+  const int n_words = (d.n + 63) >> 6;
   unsigned base = (unsigned)d.line0;
-  for (int r0 = 0; r0 < d.n; r0 += 64) {
-    const unsigned long long w = bits[r0 >> 6];  // wave-uniform
-    const int r = r0 + lane;
-    const unsigned line = base + (unsigned)__popcll(w & ((2ull << lane) - 1ull));
-    if (r < d.n) out[r] = (line & 0xFFFFu) | ((unsigned)nb[r] << 16);
-    base += (unsigned)__popcll(w);
+  // 64 bit words (4096 rows) at a time: lane l holds word l and, after a scan over the wave, the line number at the
+  // word's first row; every wave does that (a few instructions) and then takes every kExpandWaves-th word, so that the
+  // row loads of different words are independent of each other (the serial form was bound by one load latency per word)
+  for (int w0 = 0; w0 < n_words; w0 += 64) {
+    const unsigned long long mine = (w0 + lane < n_words) ? bits[w0 + lane] : 0ull;
+    const unsigned cnt = (unsigned)__popcll(mine);
+    unsigned incl = cnt;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const unsigned o = __shfl_up(incl, s, 64);
+      if (lane >= s) incl += o;
+    }
+    const unsigned first = base + incl - cnt;
+    const int k_end = min(64, n_words - w0);
+#pragma unroll 4
+    for (int k = wave; k < k_end; k += kExpandWaves) {
+      const unsigned long long w = __shfl(mine, k, 64);
+      const unsigned lb = __shfl(first, k, 64);
+      const int r = ((w0 + k) << 6) + lane;
+      const unsigned line = lb + (unsigned)__popcll(w & ((2ull << lane) - 1ull));
+      if (r < d.n) out[r] = (line & 0xFFFFu) | ((unsigned)nb[r] << 16);
+    }
+    base += __shfl(incl, 63, 64);
   }
 }
 
@@ -829,7 +849,7 @@ size_t seg_point_bytes() { return sizeof(SegPoint); }
 size_t blk_rec_bytes() { return sizeof(BlkRec); }
 void launch_expand_rows(hipStream_t st, int n_blk, const void *desc, const unsigned *stream, const unsigned *ovf, unsigned *rows) {
   if (n_blk > 0)
-    hipLaunchKernelGGL(k_expand_rows, dim3((unsigned)n_blk), dim3(64), 0, st, n_blk, reinterpret_cast<const RowDesc *>(desc), stream,
+    hipLaunchKernelGGL(k_expand_rows, dim3((unsigned)n_blk), dim3(64 * kExpandWaves), 0, st, n_blk, reinterpret_cast<const RowDesc *>(desc), stream,
                        ovf, rows);
 }
 void launch_build_blk(hipStream_t st, int n_blk, const long long *m_off, const int *blk_img, const int *blk_nb,
