@@ -179,6 +179,20 @@ int finish_run(lt_ctx *ctx) {
     ctx->ex_retry_depth = 0;
     return rc2;
   }
+  if (derr == 7) {
+    // the chunk store of the split scoring form did not hold the pairs that passed the sweep: this context scores with the
+    // fused kernel from now on (no store), the run is repeated
+    if (ctx->ex_retry_depth > 1)
+      return fail(ctx, LT_ERR_RUNTIME, "internal: pair chunk overflow outside the split scoring form");
+    ctx->score_fused = true;
+    if (ctx->in_run_async) return LT_OK;
+    const int depth = ctx->ex_retry_depth;
+    ctx->ex_retry_depth = depth + 1;
+    int rc2 = lt_run_device_async(ctx);
+    if (!rc2) rc2 = finish_run(ctx);
+    ctx->ex_retry_depth = depth;
+    return rc2;
+  }
   ctx->timers[17] = ctx->timers[18] = 0.0;
   if (hp && ctx->ex_staged_set[ctx->pend_set]) {
     ctx->timers[17] = (double)hp[3] * (double)ex_regions();
@@ -682,6 +696,22 @@ int lt_run_device_async(lt_ctx *ctx) {
     // depth-sorted sweep over the staged records of the one-pass exhaustive mode: see k_depth_order
     const bool staged_sorted = score_sorted && ctx->perm_mode && ctx->job_mode == 2;
     C_run = C_bound;  // replaced by the exact count when that arrives with the error flag (finish_run)
+    // split form (default for the single-precision sweep): the sweep writes pair chunks, k_dense8 evaluates them with
+    // full rounds; LT_SCORE_FUSED=1 or a chunk store that overflowed once: the fused kernel
+    const bool split = score_f32 && !ctx->score_fused && !getenv("LT_SCORE_FUSED");
+    long long sp_chunks = 0;
+    int sp_slot_cap = ctx->job_mode == 2 ? 64 : 256;  // entries per tile slot (matched: p90 of the bench scene is 182 pairs)
+    if (split) {
+      const long long n_tiles_b = (std::max<long long>(C_bound, 1) + 63) / 64;
+      sp_chunks = score_split_chunks(std::max<long long>(C_bound, 1));
+      if (const char *e = getenv("LT_TEST_SPLIT_CHUNKS")) sp_chunks = std::max(0, atoi(e));
+      if (const char *e = getenv("LT_TEST_SPLIT_SLOT")) sp_slot_cap = std::max(1, atoi(e));
+      ENSURE(ctx, ctx->d_sp_slots, 8 * (size_t)sp_slot_cap * (size_t)n_tiles_b);
+      ENSURE(ctx, ctx->d_sp_cnt, 4 * (size_t)n_tiles_b);
+      ENSURE(ctx, ctx->d_sp_ovf, 4 * (size_t)n_tiles_b);
+      ENSURE(ctx, ctx->d_sp_pairs, score_split_chunk_bytes() * (size_t)std::max<long long>(sp_chunks, 1));
+      ENSURE(ctx, ctx->d_sp_desc, 8 * (size_t)std::max<long long>(sp_chunks, 1));
+    }
     launch_score3(st, C_bound, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
                   ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(), ctx->d_node_img.as<int>(),
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
@@ -694,7 +724,9 @@ int lt_run_device_async(lt_ctx *ctx) {
                   tile_classes ? ctx->d_tile_list.as<unsigned>() : nullptr, tile_cap,
                   staged_sorted ? ctx->d_place_perm.as<unsigned>() : nullptr,
                   staged_sorted ? ctx->d_ex_rec.as<unsigned>() : nullptr,
-                  staged_sorted ? ctx->d_ex_z.as<float>() : nullptr, ctx->d_err.as<int>());
+                  staged_sorted ? ctx->d_ex_z.as<float>() : nullptr, ctx->d_err.as<int>(),
+                  split ? ctx->d_sp_slots.p : nullptr, sp_slot_cap, ctx->d_sp_cnt.as<unsigned>(),
+                  ctx->d_sp_ovf.as<unsigned>(), ctx->d_sp_pairs.p, ctx->d_sp_desc.p, sp_chunks);
   }
   HIPCHK(ctx, hipEventRecord(ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));

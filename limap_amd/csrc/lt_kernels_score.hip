@@ -31,7 +31,7 @@ namespace lt {
 // (lt_kernels_v2.hip) merges them into its own array's slices 2 and 3
 __device__ unsigned long long g_trace[4 * 4 * 65536];
 #define LT_TRACE_MARK(kern, id, slot) \
-  if (lane_id() == 0 && (id) < 65536u) g_trace[(kern) * 4 * 65536 + 4 * (id) + (slot)] = wall_clock64()
+  if ((threadIdx.x == 0) && (id) < 65536u) g_trace[(kern) * 4 * 65536 + 4 * (id) + (slot)] = wall_clock64()
 #else
 #define LT_TRACE_MARK(kern, id, slot)
 #endif
@@ -69,7 +69,7 @@ k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long
   const long long C = tri_off[G];
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < kTileQueues) draw[i * 32] = 0;  // 128 bytes apart
+  if (i < kTileQueues + 2) draw[i * 32] = 0;  // 128 bytes apart; the two behind the queues: chunk counters of the split form
   const long long C_up = (C + 63) & ~63ll;  // whole waves take part in the tile's reduction
   for (; i < C_up; i += stride) {
     unsigned n = 0, w_lo = 0, w_hi = 0;
@@ -129,6 +129,7 @@ k_cand_node(long long G, const long long *__restrict__ tri_off, unsigned *__rest
 // and are summed per lane in ascending image-id order (std::map order, :110-112).
 static __device__ __forceinline__ unsigned mt_key(long long off) { return (unsigned)off & 0xFFFFFFu; }
 constexpr int kSQCap = 512;  // the queue is drained when fewer than 256 (4 sweep iterations) slots are free
+constexpr int kSQCapSplit = 384;  // split form: 8-byte entries, emptied into the chunk store
 constexpr int kWin = LT_SCORE_WIN;
 
 struct Score3Args {
@@ -149,7 +150,28 @@ struct Score3Args {
   unsigned bucket_cap;
   int max_nb;
   int *err_flag;  // device error flag of the run
+  // split form (k_score3<.., kSplit> writes the pairs that pass the sweep, k_dense8 evaluates them)
+  uint2 *sp_slots;        // tile t: entries [t * sp_slot_cap, ..): x = record of j, y = lane of i in the tile
+  unsigned *sp_cnt;       // pairs of tile t
+  unsigned *sp_ovf;       // first overflow chunk of tile t (valid when sp_cnt[t] > sp_slot_cap)
+  uint2 *sp_pairs;        // overflow chunks of kChunkCap entries
+  uint2 *sp_desc;         // overflow chunk: x = entries, y = next chunk of the tile or kNoChunk
+  unsigned *sp_counters;  // [0] overflow chunks handed out (sweep), [32] units claimed (dense)
+  unsigned sp_chunk_cap;
+  int sp_slot_cap;
+  int sp_t_max;           // tiles per unit of k_dense8 (one table of maxima per tile in its LDS)
 };
+
+// Split form of the scoring stage (round 4).  The sweep kernel writes the pairs that pass its guards to the SLOT of their
+// tile in HBM (sp_slot_cap entries of 8 bytes; what does not fit goes to a chain of overflow chunks handed out through a
+// counter); k_dense8 then gives units of sp_t_max consecutive tiles to workgroups of four waves: the rounds of pair_score
+// run over the unit's pairs as one list, whatever the tile they came from, and the pairs of a heavy tile are spread over
+// four SIMDs instead of running as nine rounds of one wave.
+constexpr int kChunkCap = 512;
+constexpr int kChunkTiles = 8;
+constexpr unsigned kNoChunk = 0xFFFFFFFFu;
+constexpr int kErrPairChunks = 7;
+constexpr int kDenseHdrBytes = kChunkTiles * 64 * 4 + 16 + kChunkTiles * 8 + 256 * 8 + 64 * 4;  // k_dense8's LDS in front of the tables  // device error flag: the overflow store is full (finish_run repeats the run fused)
 
 // Depth order of a node's candidates (large nodes: exhaustive matching gives ~450 candidates per node and
 // 1.6e10 ordered pairs per scene, of which the sweep passes 0.05 %).  All candidates of a node are seen from
@@ -314,10 +336,12 @@ k_depth_order(long long G, const long long *__restrict__ tri_off, const CRec *__
 // owns candidate perm[t] and sweeps only the sorted positions rng[t] of its node.
 // kPerm: the candidate at position t of the (virtual) compact array is record perm[t] of a.cand / a.lite (the
 // staging lists of stage B: k_place wrote only the permutation); scores are indexed by position.
-template <bool kF32, bool kSorted, bool kPerm>
+template <bool kF32, bool kSorted, bool kPerm, bool kSplit>
 __global__ void __launch_bounds__(64) LT_SCORE_OCC
 k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
+  static_assert(!kSplit || kF32, "the split form exists for the single-precision sweep");
   constexpr bool kInd = kSorted || kPerm;  // positions are mapped through a.perm
+  constexpr int kQCap = kSplit ? kSQCapSplit : kSQCap;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x;
   // LDS: window (f32: float4[kWin][3]; f64: W[9][kWin] f64 + wslot[kWin] i32) | woff[64] i64 | queue[kSQCap] u32 |
@@ -328,6 +352,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   float4 *W4 = reinterpret_cast<float4 *>(smem_raw);
   long long *woff = reinterpret_cast<long long *>(smem_raw + kWBytes);
   unsigned *queue = reinterpret_cast<unsigned *>(smem_raw + kWBytes + 64 * 8);
+  uint2 *queue2 = reinterpret_cast<uint2 *>(smem_raw + kWBytes + 64 * 8);  // kSplit: (record of j, lane of i)
   int *ordl = reinterpret_cast<int *>(smem_raw + kWBytes + 64 * 8 + kSQCap * 4);
   unsigned long long *S = reinterpret_cast<unsigned long long *>(
       smem_raw + ((kWBytes + 64 * 8 + kSQCap * 4 + (size_t)a.max_nb * 4 + 15) & ~(size_t)15));
@@ -343,7 +368,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
   unsigned long long n_eval_total = 0;
   unsigned k_raw = 0;
-  if (lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
+  if (!kSplit && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
   // draws are mapped to tiles through the queue's cost-class lists, most expensive class first: lane b < kTileBuckets
   // holds the size of class (kTileBuckets - 1 - b) of queue q and the inclusive prefix of the sizes in that order
   unsigned cls_cnt = 0, cls_incl = 0, q_tiles = 0;
@@ -357,7 +382,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     }
     q_tiles = (unsigned)__builtin_amdgcn_readlane((int)cls_incl, kTileBuckets - 1);
   };
-  if (a.bucket_cnt) load_classes();
+  if (!kSplit && a.bucket_cnt) load_classes();
   // a draw resolves to the tile and -- from the class lists -- the bounds of its window (x: tile, 0xFFFFFFFF when
   // every queue is empty; y, z: first and end position of the window, z == 0: not known, derived from the lanes' nodes)
   auto resolve = [&]() -> uint4 {
@@ -415,9 +440,66 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       if ((unsigned)lane + 64u < w) p_w1 = a.perm[(size_t)h.y + 64 + lane];
     }
   };
-  uint4 hdr = resolve();
+  bool ch_dead = false;  // kSplit: the overflow store is full, the run is repeated with the fused kernel
+  auto ch_alloc = [&]() -> unsigned {
+    unsigned id = 0;
+    if (lane == 0) id = atomicAdd(&a.sp_counters[0], 1u);
+    id = (unsigned)__builtin_amdgcn_readfirstlane((int)id);
+    if (id >= a.sp_chunk_cap) {
+      ch_dead = true;
+      if (lane == 0 && a.err_flag) atomicCAS(a.err_flag, 0, kErrPairChunks);
+      return kNoChunk;
+    }
+    return id;
+  };
+  // kSplit: STATIC schedule.  Without the dense rounds a tile's time follows its cost class closely, so wave w takes
+  // entries w, w + waves, w + 2 waves, ... of the tiles in class order (all queues' lists of the most expensive class first):
+  // one expensive, one medium and one cheap tile each, no draw and no round trip between tiles -- the next tile's list
+  // entry is loaded at the start of the current one and its first load level while the current one sweeps (measured with
+  // draws: 1 300 of 3 072 waves inside a tile at any time, the rest between tiles).
+  // flat order f = class rank * kTileQueues + queue (rank 0 = most expensive); lane l holds f = 4 l .. 4 l + 3
+  unsigned o_cnt[4] = {0u, 0u, 0u, 0u}, o_tot = 0, o_incl = 0, n_order = n_tiles;
+  if (kSplit && a.bucket_cnt) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = 4 * lane + u;
+      o_cnt[u] = a.bucket_cnt[((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * 32];
+      o_tot += o_cnt[u];
+    }
+    o_incl = o_tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned t = (unsigned)__shfl_up((int)o_incl, d);
+      if (lane >= d) o_incl += t;
+    }
+    n_order = (unsigned)__builtin_amdgcn_readlane((int)o_incl, 63);
+  }
+  static_assert(kTileQueues * kTileBuckets == 256, "four (queue, class) lists per lane");
+  auto fetch_order = [&](unsigned k) -> uint4 {  // k < n_order, wave-uniform
+    if (!a.bucket_cnt) return uint4{k, 0u, 0u, 0u};
+    const int l = __builtin_ctzll(__ballot(o_incl > k));
+    unsigned r = k - (unsigned)__builtin_amdgcn_readlane((int)(o_incl - o_tot), l);
+    int u = 0;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)o_cnt[v], l);
+      if (u == v && r >= c) { r -= c; u = v + 1; }
+    }
+    const int f = 4 * l + u;
+    return reinterpret_cast<const uint4 *>(
+        a.bucket_list)[(size_t)((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * a.bucket_cap + r];
+  };
+  const uint4 kNoTile = uint4{0xFFFFFFFFu, 0u, 0u, 0u};
+  unsigned o_k = blockIdx.x;
+  uint4 hdr_next = kNoTile;
+  uint4 hdr = kSplit ? (o_k < n_order ? fetch_order(o_k) : kNoTile) : resolve();
   if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
   while (hdr.x != 0xFFFFFFFFu) {
+    bool next_level_issued = false;
+    if (kSplit) {
+      o_k += gridDim.x;
+      hdr_next = o_k < n_order ? fetch_order(o_k) : kNoTile;
+    }
     const unsigned tile = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.x);
     const unsigned h_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.y);
     const unsigned h_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.z);
@@ -458,8 +540,10 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     woff[lane] = off;
     // summation order of the first lane's image, staged once (lanes of another image read it from HBM)
     const long long wave_nb0 = (long long)__builtin_amdgcn_readfirstlane((int)nb0);  // nb_off < 2^24
-    if (lane < __builtin_amdgcn_readfirstlane(n_nb)) ordl[lane] = a.blk_order[wave_nb0 + lane];
-    for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
+    if (!kSplit) {
+      if (lane < __builtin_amdgcn_readfirstlane(n_nb)) ordl[lane] = a.blk_order[wave_nb0 + lane];
+      for (int k = 0; k < a.max_nb; ++k) S[k * 64 + lane] = 0ull;
+    }
     // kF32: wave-local origin (the first lane's start point) and this lane's own single-precision operands
     double ox = 0, oy = 0, oz = 0;
     float dixf = 0, diyf = 0, dizf = 0, sixf = 0, siyf = 0, sizf = 0, eixf = 0, eiyf = 0, eizf = 0, ri = 0;
@@ -494,8 +578,42 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     int qn = 0;
     unsigned long long n_eval = 0;
 
+    int t_cnt = 0, ov_fill = 0;  // kSplit: pairs of this tile so far, fill of its current overflow chunk
+    unsigned ov_cur = kNoChunk;
     auto drain = [&](bool final) {
       wave_lds_sync();
+      if (kSplit) {
+        const int k0 = min(qn, max(0, a.sp_slot_cap - t_cnt));
+        uint2 *dst = a.sp_slots + (size_t)tile * (size_t)a.sp_slot_cap + t_cnt;
+        for (int p = lane; p < k0; p += 64) dst[p] = queue2[p];
+        int done = k0;
+        while (done < qn && !ch_dead) {  // beyond the slot: the tile's chain of overflow chunks
+          if (ov_cur == kNoChunk || ov_fill == kChunkCap) {
+            const unsigned nxt = ch_alloc();
+            if (ch_dead) break;
+            if (lane == 0) {
+              if (ov_cur == kNoChunk) a.sp_ovf[tile] = nxt;
+              else a.sp_desc[ov_cur] = make_uint2((unsigned)ov_fill, nxt);
+            }
+            ov_cur = nxt;
+            ov_fill = 0;
+          }
+          const int k = min(qn - done, kChunkCap - ov_fill);
+          uint2 *od = a.sp_pairs + (size_t)ov_cur * kChunkCap + ov_fill;
+          for (int p = lane; p < k; p += 64) od[p] = queue2[done + p];
+          ov_fill += k;
+          done += k;
+        }
+        t_cnt += qn;
+        n_eval += (unsigned long long)qn;
+        qn = 0;
+        if (final && lane == 0) {
+          a.sp_cnt[tile] = (unsigned)t_cnt;
+          if (ov_cur != kNoChunk) a.sp_desc[ov_cur] = make_uint2((unsigned)ov_fill, kNoChunk);
+        }
+        wave_lds_sync();
+        return;
+      }
       if (final && qn == 0 && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
       for (int q0 = 0; q0 < qn; q0 += 64) {
         if (final && q0 + 64 >= qn && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
@@ -536,7 +654,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
           const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
           W4[3 * e + 0] = float4{(float)l.dir[0], (float)l.dir[1], (float)l.dir[2], __int_as_float(crec_slot(l))};
           W4[3 * e + 1] = float4{sx, ex, sy, ey};  // start / end interleaved: the sweep's packed-f32 operand pairs
-          W4[3 * e + 2] = float4{sz, ez, 0.0f, 0.0f};
+          W4[3 * e + 2] = float4{sz, ez, __uint_as_float((unsigned)src), 0.0f};  // .z: the record (kSplit's pair entries)
           rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
         } else {
           W[0 * kWin + e] = l.dir[0]; W[1 * kWin + e] = l.dir[1]; W[2 * kWin + e] = l.dir[2];
@@ -556,6 +674,10 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       }
       wave_lds_sync();
       if (wb == lo) { LT_TRACE_MARK(2, tile, 1); }
+      if (kSplit && !next_level_issued) {  // the registers of this tile's first level are free now
+        next_level_issued = true;
+        if (hdr_next.x != 0xFFFFFFFFu) load_first_level(hdr_next);
+      }
       // this lane's sub-range of the window
       long long jlo = (off + r_lo) > wb ? (off + r_lo) : wb;
       long long jhi = (off + r_hi) < (wb + wn) ? (off + r_hi) : (wb + wn);
@@ -572,12 +694,19 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
         for (int t = 0; t < cmax; t += 4) {
           float4 A[4], B[4];
           float2 E[4];
+          unsigned Jr[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int w = min(wbase + t + u, wlast);
             A[u] = W4[3 * w + 0];
             B[u] = W4[3 * w + 1];
-            E[u] = *reinterpret_cast<const float2 *>(&W4[3 * w + 2]);
+            if (kSplit) {
+              const float4 e4 = W4[3 * w + 2];
+              E[u] = make_float2(e4.x, e4.y);
+              Jr[u] = __float_as_uint(e4.z);
+            } else {
+              E[u] = *reinterpret_cast<const float2 *>(&W4[3 * w + 2]);
+            }
           }
           bool pass[4];
 #pragma unroll
@@ -599,11 +728,15 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
           for (int u = 0; u < 4; ++u) {
             const unsigned long long m = __ballot(pass[u]);
             if (m) {
-              if (pass[u]) queue[qn + __popcll(m & lanemask_lt())] = ((unsigned)lane << 26) | (unsigned)(jj0 + t + u);
+              if (kSplit) {
+                if (pass[u]) queue2[qn + __popcll(m & lanemask_lt())] = make_uint2(Jr[u], (unsigned)lane);
+              } else {
+                if (pass[u]) queue[qn + __popcll(m & lanemask_lt())] = ((unsigned)lane << 26) | (unsigned)(jj0 + t + u);
+              }
               qn += __popcll(m);
             }
           }
-          if (qn > kSQCap - 256) drain(false);
+          if (qn > kQCap - 256) drain(false);
         }
       } else {
         for (int t = 0; t < cmax; ++t) {
@@ -633,7 +766,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     drain(true);
     LT_TRACE_MARK(2, tile, 3);
 
-    if (active) {
+    if (!kSplit && active) {
       double sum = 0.0;
       const bool own = nb0 == wave_nb0;
       for (int r = 0; r < n_nb; ++r) {
@@ -644,10 +777,188 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     }
     n_eval_total += n_eval;
     wave_lds_sync();  // the tables are reused by the next tile
-    hdr = resolve();
-    if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
+    if (kSplit) {
+      if (!next_level_issued && hdr_next.x != 0xFFFFFFFFu) load_first_level(hdr_next);
+      hdr = hdr_next;
+    } else {
+      hdr = resolve();
+      if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
+    }
   }
-  if (lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
+  // (kSplit: the pair statistic is summed by k_dense8 from the tiles' counts -- here every wave ends at about the same time,
+  // and three thousand atomics on one address in a burst held up the loads of the waves that still had a tile: 20-40 us)
+  if (!kSplit && lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
+}
+
+// Dense half of the split form: one workgroup of four waves per unit of sp_t_max consecutive tiles, units claimed through
+// a counter.  Tables of per-image maxima as in the fused kernel, one per tile of the unit; the sums in image-id order.
+template <int kWaves>
+__global__ void __launch_bounds__(64 * kWaves)
+k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of the candidate, 1 = position, 2 = spos[position]
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  unsigned *reci = reinterpret_cast<unsigned *>(smem_raw);  // [kChunkTiles * 64] record of the candidate of a table row
+  unsigned *s_next = reci + kChunkTiles * 64;               // [4]
+  unsigned *s_cnt = s_next + 4;                             // [kChunkTiles] pairs of the unit's tiles
+  unsigned *s_tile = s_cnt + kChunkTiles;                   // [kChunkTiles] the unit's tiles
+  unsigned *s_ocnt = s_tile + kChunkTiles;                  // [256] tiles of the (queue, class) lists in flat order
+  unsigned *s_ounits = s_ocnt + 256;                        // [256] units of the lists
+  unsigned *s_uincl = s_ounits + 256;                       // [64] inclusive prefix of the units, four lists per entry
+  unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_raw + kDenseHdrBytes);
+  if (a.err_flag && *a.err_flag == kErrPairChunks) return;  // the overflow store was full: the run is repeated
+  const long long C = a.tri_off[a.G];
+  const unsigned n_tiles = (unsigned)((C + 63) >> 6);
+  const int T = a.sp_t_max;
+  constexpr int kThreads = 64 * kWaves;  // (two table rows per thread: the host limits the tiles per unit to 2 kWaves)
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  // Units in the sweep's class order, most expensive class first (the workgroups claim them through a counter: the long
+  // units start first).  A unit = T consecutive entries of one (queue, class) list.  (Fewer tiles per unit in the expensive
+  // classes -- one from class 22 / two from class 12, from 26 / 18, from 30 / 22: 120 / 106 / 105 us, no gain over T everywhere.)
+  // flat order f = class rank * kTileQueues + queue as in the sweep; lane l holds the lists f = 4 l .. 4 l + 3
+  // (the lists' counts live in LDS: ten more registers held across the rounds cost the third wave per SIMD)
+  unsigned n_units = (n_tiles + (unsigned)T - 1) / (unsigned)T;
+  if (a.bucket_cnt) {
+    if (tid < 64) {
+      unsigned u_tot = 0;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int f = 4 * lane + v;
+        const unsigned c = a.bucket_cnt[((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * 32];
+        const unsigned tf = (unsigned)T;
+        s_ocnt[f] = c;
+        s_ounits[f] = (c + tf - 1) / tf;
+        u_tot += (c + tf - 1) / tf;
+      }
+      unsigned u_incl = u_tot;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = (unsigned)__shfl_up((int)u_incl, d);
+        if (lane >= d) u_incl += t;
+      }
+      s_uincl[lane] = u_incl;
+    }
+    __syncthreads();
+    n_units = s_uincl[63];
+  }
+  const int max_nb = a.max_nb;
+  const int cap = a.sp_slot_cap;
+  unsigned u = blockIdx.x;
+  unsigned long long n_pairs_wg = 0;  // pair statistic, threads < T
+  while (u < n_units) {
+    LT_TRACE_MARK(3, u, 0);
+    int nt;
+    if (a.bucket_cnt) {
+      const int l = __builtin_ctzll(__ballot(s_uincl[lane] > u));
+      unsigned r = u - (l > 0 ? s_uincl[l - 1] : 0u);
+      int v = 0;
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        const unsigned c = s_ounits[4 * l + w];
+        if (v == w && r >= c) { r -= c; v = w + 1; }
+      }
+      const int f = 4 * l + v;
+      const unsigned cf = s_ocnt[f];
+      const unsigned tf = (unsigned)T;
+      const unsigned first = r * tf;
+      nt = (int)min(tf, cf - first);
+      if (tid < nt) {
+        const unsigned tile = reinterpret_cast<const uint4 *>(a.bucket_list)[
+            (size_t)((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * a.bucket_cap + first + tid].x;
+        s_tile[tid] = tile;
+        const unsigned c = a.sp_cnt[tile];
+        s_cnt[tid] = c;
+        n_pairs_wg += (unsigned long long)c;
+      }
+    } else {
+      const unsigned t0 = u * (unsigned)T;
+      nt = (int)min((unsigned)T, n_tiles - t0);
+      if (tid < nt) {
+        s_tile[tid] = t0 + tid;
+        const unsigned c = a.sp_cnt[t0 + tid];
+        s_cnt[tid] = c;
+        n_pairs_wg += (unsigned long long)c;
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < nt * max_nb * 64; k += kThreads) S[k] = 0ull;
+    CandMeta mt[2];
+    long long pos[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = tid + kThreads * h;
+      pos[h] = -1;
+      mt[h] = CandMeta{0u, 0u, 0u, 0u};
+      if (r < nt * 64) {
+        const long long p = (long long)s_tile[r >> 6] * 64 + (r & 63);
+        if (p < C) {
+          pos[h] = p;
+          reci[r] = a.perm ? a.perm[p] : (unsigned)p;
+          mt[h] = a.meta[p];
+        }
+      }
+    }
+    __syncthreads();
+    LT_TRACE_MARK(3, u, 1);
+    // the unit's pairs as one list: slot parts first (offsets from the tiles' counts), then the overflow chains
+    int off[kChunkTiles + 1];
+    off[0] = 0;
+#pragma unroll
+    for (int k = 0; k < kChunkTiles; ++k) off[k + 1] = off[k] + (k < nt ? min((int)s_cnt[k], cap) : 0);
+    auto eval = [&](const uint2 e, const int k) {
+      const CRec &ci = a.cand[reci[k * 64 + (int)e.y]];
+      const CRec &cj = a.cand[e.x];
+      const int nbs_j = cj.nb_slot;
+      const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
+                                   mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
+                                   mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
+                                   mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg, a.cams[(int)((unsigned)nbs_j >> 8)]);
+      if (sc > 0.0)
+        atomicMax(&S[(k * max_nb + (nbs_j & 0xFF)) * 64 + (int)e.y], (unsigned long long)__double_as_longlong(sc));
+    };
+    for (int p = tid; p < off[kChunkTiles]; p += kThreads) {
+      int k = 0;
+#pragma unroll
+      for (int m = 1; m < kChunkTiles; ++m) k += (p >= off[m]) ? 1 : 0;
+      int o = off[0];
+#pragma unroll
+      for (int m = 1; m < kChunkTiles; ++m) o = (k >= m) ? off[m] : o;
+      eval(a.sp_slots[(size_t)s_tile[k] * (size_t)cap + (p - o)], k);
+    }
+    for (int k = 0; k < nt; ++k) {
+      if ((int)s_cnt[k] <= cap) continue;
+      unsigned cc = a.sp_ovf[s_tile[k]];
+      while (cc != kNoChunk) {
+        const uint2 d = a.sp_desc[cc];
+        for (int p = tid; p < (int)d.x; p += kThreads) eval(a.sp_pairs[(size_t)cc * kChunkCap + p], k);
+        cc = d.y;
+      }
+    }
+    // the next unit is claimed here: the round trip hides behind the barrier and the sums (at the start of the unit it
+    // was a burst of one atomic per workgroup on one address when the kernel starts)
+    if (tid == 0) s_next[0] = gridDim.x + atomicAdd(&a.sp_counters[32], 1u);
+    __syncthreads();
+    LT_TRACE_MARK(3, u, 2);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (pos[h] >= 0) {
+        const int r = tid + kThreads * h;
+        const long long nb0 = (long long)(mt[h].nb >> 8);
+        const int n_nb = (int)(mt[h].nb & 0xFFu);
+        double sum = 0.0;
+        for (int k = 0; k < n_nb; ++k)
+          sum += __longlong_as_double((long long)S[((r >> 6) * max_nb + a.blk_order[nb0 + k]) * 64 + (r & 63)]);
+        a.score[score_by == 1 ? pos[h] : (score_by == 2 ? (long long)a.spos[pos[h]] : (long long)reci[r])] = sum;
+      }
+    }
+    __syncthreads();
+    LT_TRACE_MARK(3, u, 3);
+    u = (unsigned)__builtin_amdgcn_readfirstlane((int)s_next[0]);
+    __syncthreads();
+  }
+  if (a.pair_counter && tid < 64) {
+    for (int d = 32; d >= 1; d >>= 1) n_pairs_wg += (unsigned long long)__shfl_xor((long long)n_pairs_wg, d);
+    if (tid == 0 && n_pairs_wg) atomicAdd(a.pair_counter, n_pairs_wg);
+  }
 }
 
 #ifdef LT_TRACE
@@ -666,6 +977,19 @@ size_t score3_lds_bytes(int max_nb, bool f32) {
   return ((base + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
 }
 size_t cand_meta_bytes() { return sizeof(CandMeta); }
+// split form: tiles per chunk for a job's widest neighbour list (k_dense8 holds one table of maxima per tile: three
+// workgroups per CU at 48 KB), bytes of chunk store per chunk, and the number of chunks for C candidates
+int score_split_t_max(int max_nb) {
+  static int t_env = -1;
+  if (t_env < 0) {
+    const char *e = getenv("LT_DENSE_TILES");
+    t_env = e ? atoi(e) : 0;
+  }
+  const int t = (48 * 1024) / (std::max(max_nb, 1) * 512);
+  return std::max(1, std::min(t_env > 0 ? std::min(t_env, kChunkTiles) : kChunkTiles, t));
+}
+size_t score_split_chunk_bytes() { return (size_t)kChunkCap * 8; }
+long long score_split_chunks(long long C) { return C / kChunkCap + 1024; }
 int score3_tile_buckets() { return kTileBuckets * kTileQueues; }  // counters (128 B apart) / lists: one per (queue, class)
 // (A two-kernel form -- light sweep writing per-tile pair lists, then a dense evaluation kernel -- was
 // measured: the sweep alone takes 53 us, but the evaluation does not get cheaper and the two phases no
@@ -676,7 +1000,10 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    int max_nb, const ScoreCfg &cfg, double scaleinv_guard2, hipEvent_t ev_before, unsigned *draw,
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, unsigned *bucket_cnt,
                    unsigned *bucket_list, unsigned bucket_cap, const unsigned *place, unsigned *rec, const float *st_z,
-                   int *err_flag) {
+                   int *err_flag, void *sp_slots, int sp_slot_cap, unsigned *sp_cnt, unsigned *sp_ovf, void *sp_pairs,
+                   void *sp_desc, long long sp_chunks) {
+  // sp_*: the pair store of the split form (sp_slots == nullptr: the fused kernel): slots of sp_slot_cap entries per tile,
+  // pair counts and first overflow chunk per tile, sp_chunks overflow chunks with their (count, next) records
   // place / rec: depth-sorted sweep over STAGED records (one-pass exhaustive mode): place[natural position] = record,
   // rec (scratch, one word per candidate) receives the record of every sorted position
   if (C <= 0) return;
@@ -701,6 +1028,17 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.bucket_cnt = bucket_cnt; a.bucket_list = bucket_list; a.bucket_cap = bucket_cap;
   a.max_nb = max_nb;
   a.err_flag = err_flag;
+  const bool split = sp_slots != nullptr && f32;
+  a.sp_slots = reinterpret_cast<uint2 *>(sp_slots);
+  a.sp_cnt = sp_cnt;
+  a.sp_ovf = sp_ovf;
+  a.sp_pairs = reinterpret_cast<uint2 *>(sp_pairs);
+  a.sp_desc = reinterpret_cast<uint2 *>(sp_desc);
+  a.sp_counters = draw + kTileQueues * 32;
+  a.sp_chunk_cap = (unsigned)std::max<long long>(0, std::min<long long>(sp_chunks, 0x7FFFFFFFll));
+  a.sp_slot_cap = sp_slot_cap;
+  a.sp_t_max = score_split_t_max(max_nb);
+  if (const char *e = getenv("LT_DENSE_WAVES")) a.sp_t_max = std::min(a.sp_t_max, 2 * std::max(1, atoi(e)));
   if (ev_before) (void)hipEventRecord(ev_before, st);
   const bool sorted = perm != nullptr && f32 && !perm_is_placement;
   if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
@@ -712,15 +1050,51 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
     a.spos = perm;
   }
   // persistent grid: as many single-wave workgroups as fit at once (LDS; registers allow LT_SCORE_RESIDENT per CU)
-  const size_t lds = score3_lds_bytes(max_nb, f32);
+  const size_t lds = split ? (size_t)kWin * 48 + 64 * 8 + (size_t)kSQCapSplit * 8 : score3_lds_bytes(max_nb, f32);
   const long long per_cu = std::max<long long>(1, std::min<long long>(LT_SCORE_RESIDENT, (long long)(160 * 1024 / lds)));
   const dim3 grid((unsigned)std::min<long long>(n_tiles, per_cu * n_cu)), block(64);
+  if (split) {
+    // static schedule: exactly the workgroups that are resident at once
+    static int occ_split[3] = {0, 0, 0};
+    const int var = perm_is_placement ? 0 : (sorted ? 1 : 2);
+    if (occ_split[var] == 0) {
+      int o = 0;
+      hipError_t e = var == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score3<true, false, true, true>, 64, lds)
+                   : var == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score3<true, true, false, true>, 64, lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score3<true, false, false, true>, 64, lds);
+      occ_split[var] = (e == hipSuccess && o > 0) ? o : 8;
+      if (const char *ev = getenv("LT_SWEEP_PER_CU")) occ_split[var] = std::max(1, atoi(ev));
+    }
+    const dim3 grid((unsigned)std::min<long long>(n_tiles, (long long)occ_split[var] * n_cu));
+    if (perm_is_placement) hipLaunchKernelGGL((k_score3<true, false, true, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+    else if (sorted) hipLaunchKernelGGL((k_score3<true, true, false, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+    else hipLaunchKernelGGL((k_score3<true, false, false, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+    const size_t lds2 = (size_t)kDenseHdrBytes + (size_t)a.sp_t_max * (size_t)max_nb * 512;
+    static int dense_per_cu = 0;
+    if (dense_per_cu == 0) {
+      const char *e = getenv("LT_DENSE_PER_CU");
+      dense_per_cu = e ? std::max(1, atoi(e)) : 3;
+    }
+    static int dense_waves = 0;
+    if (dense_waves == 0) {
+      const char *e = getenv("LT_DENSE_WAVES");
+      dense_waves = e ? atoi(e) : 4;
+      if (dense_waves != 1 && dense_waves != 2) dense_waves = 4;
+    }
+    const long long fit = std::max<long long>(1, std::min<long long>(dense_per_cu, (long long)(160 * 1024 / lds2)));
+    const int by = perm_is_placement ? 1 : (sorted && a.spos ? 2 : 0);
+    const dim3 g2((unsigned)(fit * n_cu));
+    if (dense_waves == 4) hipLaunchKernelGGL(k_dense8<4>, g2, dim3(256), lds2, st, a, cfg, by);
+    else if (dense_waves == 2) hipLaunchKernelGGL(k_dense8<2>, g2, dim3(128), lds2, st, a, cfg, by);
+    else hipLaunchKernelGGL(k_dense8<1>, g2, dim3(64), lds2, st, a, cfg, by);
+    return;
+  }
   if (perm_is_placement) {
-    if (f32) hipLaunchKernelGGL((k_score3<true, false, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-    else hipLaunchKernelGGL((k_score3<false, false, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-  } else if (sorted) hipLaunchKernelGGL((k_score3<true, true, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-  else if (f32) hipLaunchKernelGGL((k_score3<true, false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-  else hipLaunchKernelGGL((k_score3<false, false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+    if (f32) hipLaunchKernelGGL((k_score3<true, false, true, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+    else hipLaunchKernelGGL((k_score3<false, false, true, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+  } else if (sorted) hipLaunchKernelGGL((k_score3<true, true, false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+  else if (f32) hipLaunchKernelGGL((k_score3<true, false, false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+  else hipLaunchKernelGGL((k_score3<false, false, false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
 }
 
 }  // namespace lt
