@@ -706,7 +706,7 @@ int lt_run_device_async(lt_ctx *ctx) {
       sp_chunks = score_split_chunks(std::max<long long>(C_bound, 1));
       if (const char *e = getenv("LT_TEST_SPLIT_CHUNKS")) sp_chunks = std::max(0, atoi(e));
       if (const char *e = getenv("LT_TEST_SPLIT_SLOT")) sp_slot_cap = std::max(1, atoi(e));
-      ENSURE(ctx, ctx->d_sp_slots, 8 * (size_t)sp_slot_cap * (size_t)n_tiles_b);
+      ENSURE(ctx, ctx->d_sp_slots, score_split_entry_bytes() * (size_t)sp_slot_cap * (size_t)n_tiles_b);
       ENSURE(ctx, ctx->d_sp_cnt, 4 * (size_t)n_tiles_b);
       ENSURE(ctx, ctx->d_sp_ovf, 4 * (size_t)n_tiles_b);
       ENSURE(ctx, ctx->d_sp_pairs, score_split_chunk_bytes() * (size_t)std::max<long long>(sp_chunks, 1));

@@ -71,6 +71,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    int *err_flag, void *sp_slots, int sp_slot_cap, unsigned *sp_cnt, unsigned *sp_ovf, void *sp_pairs,
                    void *sp_desc, long long sp_chunks);
 size_t score_split_chunk_bytes();
+size_t score_split_entry_bytes();
 long long score_split_chunks(long long C);
 int score3_tile_buckets();
 }

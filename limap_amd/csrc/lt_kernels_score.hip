@@ -31,7 +31,7 @@ namespace lt {
 // (lt_kernels_v2.hip) merges them into its own array's slices 2 and 3
 __device__ unsigned long long g_trace[4 * 4 * 65536];
 #define LT_TRACE_MARK(kern, id, slot) \
-  if ((threadIdx.x == 0) && (id) < 65536u) g_trace[(kern) * 4 * 65536 + 4 * (id) + (slot)] = wall_clock64()
+  if (((kern) == 3 ? threadIdx.x == 0 : lane_id() == 0) && (id) < 65536u) g_trace[(kern) * 4 * 65536 + 4 * (id) + (slot)] = wall_clock64()
 #else
 #define LT_TRACE_MARK(kern, id, slot)
 #endif
@@ -69,7 +69,7 @@ k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long
   const long long C = tri_off[G];
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < kTileQueues + 2) draw[i * 32] = 0;  // 128 bytes apart; the two behind the queues: chunk counters of the split form
+  if (i < 2 * kTileQueues + 1) draw[i * 32] = 0;  // 128 bytes apart; the two behind the queues: chunk counters of the split form
   const long long C_up = (C + 63) & ~63ll;  // whole waves take part in the tile's reduction
   for (; i < C_up; i += stride) {
     unsigned n = 0, w_lo = 0, w_hi = 0;
@@ -151,27 +151,28 @@ struct Score3Args {
   int max_nb;
   int *err_flag;  // device error flag of the run
   // split form (k_score3<.., kSplit> writes the pairs that pass the sweep, k_dense8 evaluates them)
-  uint2 *sp_slots;        // tile t: entries [t * sp_slot_cap, ..): x = record of j, y = lane of i in the tile
-  unsigned *sp_cnt;       // pairs of tile t
+  uint4 *sp_slots;        // tile t: entries [t * sp_slot_cap, ..): x = record of j, y = record of i, z = lane of i in the tile
+  unsigned *sp_cnt;       // pairs of tile t (also left in word 3 of the tile's class-list entry: k_dense8 reads that)
   unsigned *sp_ovf;       // first overflow chunk of tile t (valid when sp_cnt[t] > sp_slot_cap)
-  uint2 *sp_pairs;        // overflow chunks of kChunkCap entries
+  uint4 *sp_pairs;        // overflow chunks of kChunkCap entries
   uint2 *sp_desc;         // overflow chunk: x = entries, y = next chunk of the tile or kNoChunk
-  unsigned *sp_counters;  // [0] overflow chunks handed out (sweep), [32] units claimed (dense)
+  unsigned *sp_counters;  // [0] overflow chunks handed out (sweep), [32 (1 + q)] units of queue q claimed (dense)
   unsigned sp_chunk_cap;
   int sp_slot_cap;
   int sp_t_max;           // tiles per unit of k_dense8 (one table of maxima per tile in its LDS)
+  int sp_wave_lds;        // LDS bytes of one wave of the sweep kernel
 };
 
 // Split form of the scoring stage (round 4).  The sweep kernel writes the pairs that pass its guards to the SLOT of their
-// tile in HBM (sp_slot_cap entries of 8 bytes; what does not fit goes to a chain of overflow chunks handed out through a
+// tile in HBM (sp_slot_cap entries of 16 bytes; what does not fit goes to a chain of overflow chunks handed out through a
 // counter); k_dense8 then gives units of sp_t_max consecutive tiles to workgroups of four waves: the rounds of pair_score
 // run over the unit's pairs as one list, whatever the tile they came from, and the pairs of a heavy tile are spread over
 // four SIMDs instead of running as nine rounds of one wave.
 constexpr int kChunkCap = 512;
 constexpr int kChunkTiles = 8;
 constexpr unsigned kNoChunk = 0xFFFFFFFFu;
-constexpr int kErrPairChunks = 7;
-constexpr int kDenseHdrBytes = kChunkTiles * 64 * 4 + 16 + kChunkTiles * 8 + 256 * 8 + 64 * 4;  // k_dense8's LDS in front of the tables  // device error flag: the overflow store is full (finish_run repeats the run fused)
+constexpr int kErrPairChunks = 7;  // device error flag: the overflow store is full (finish_run repeats the run fused)
+constexpr int kDenseHdrBytes = 16 + kChunkTiles * 8 + 256 * 8 + 64 * 4;  // k_dense8's LDS in front of the tables
 
 // Depth order of a node's candidates (large nodes: exhaustive matching gives ~450 candidates per node and
 // 1.6e10 ordered pairs per scene, of which the sweep passes 0.05 %).  All candidates of a node are seen from
@@ -336,14 +337,22 @@ k_depth_order(long long G, const long long *__restrict__ tri_off, const CRec *__
 // owns candidate perm[t] and sweeps only the sorted positions rng[t] of its node.
 // kPerm: the candidate at position t of the (virtual) compact array is record perm[t] of a.cand / a.lite (the
 // staging lists of stage B: k_place wrote only the permutation); scores are indexed by position.
+// (split form with four independent waves to a workgroup, 1 024 workgroups instead of 4 096: resident 6 us earlier, the first
+// tiles' prologues slower by as much -- 41.3 against 40.2 us; one wave per workgroup stays)
+constexpr int kSweepWaves = 1;
 template <bool kF32, bool kSorted, bool kPerm, bool kSplit>
-__global__ void __launch_bounds__(64) LT_SCORE_OCC
+__global__ void __launch_bounds__(kSplit ? 64 * kSweepWaves : 64) LT_SCORE_OCC
 k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   static_assert(!kSplit || kF32, "the split form exists for the single-precision sweep");
   constexpr bool kInd = kSorted || kPerm;  // positions are mapped through a.perm
   constexpr int kQCap = kSplit ? kSQCapSplit : kSQCap;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int lane = threadIdx.x;
+  extern __shared__ __align__(16) unsigned char smem_all[];
+  const int lane = (int)(threadIdx.x & 63u);
+  // kSplit: the waves of a workgroup are independent of each other (own LDS part, own tiles)
+  const unsigned wave_in_wg = kSplit ? (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
+  const unsigned wave_id = kSplit ? blockIdx.x * (unsigned)kSweepWaves + wave_in_wg : blockIdx.x;
+  const unsigned n_waves = kSplit ? gridDim.x * (unsigned)kSweepWaves : gridDim.x;
+  unsigned char *smem_raw = smem_all + (kSplit ? (size_t)wave_in_wg * (size_t)a.sp_wave_lds : (size_t)0);
   // LDS: window (f32: float4[kWin][3]; f64: W[9][kWin] f64 + wslot[kWin] i32) | woff[64] i64 | queue[kSQCap] u32 |
   //      ord[max_nb] i32 | S[max_nb][64] u64
   constexpr size_t kWBytes = kF32 ? (size_t)kWin * 48 : (size_t)9 * kWin * 8 + (size_t)kWin * 4;
@@ -353,6 +362,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   long long *woff = reinterpret_cast<long long *>(smem_raw + kWBytes);
   unsigned *queue = reinterpret_cast<unsigned *>(smem_raw + kWBytes + 64 * 8);
   uint2 *queue2 = reinterpret_cast<uint2 *>(smem_raw + kWBytes + 64 * 8);  // kSplit: (record of j, lane of i)
+  unsigned *reci_l = reinterpret_cast<unsigned *>(smem_raw + kWBytes + 64 * 8 + (size_t)kSQCapSplit * 8);  // kSplit: records of the lanes
   int *ordl = reinterpret_cast<int *>(smem_raw + kWBytes + 64 * 8 + kSQCap * 4);
   unsigned long long *S = reinterpret_cast<unsigned long long *>(
       smem_raw + ((kWBytes + 64 * 8 + kSQCap * 4 + (size_t)a.max_nb * 4 + 15) & ~(size_t)15));
@@ -475,7 +485,8 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     n_order = (unsigned)__builtin_amdgcn_readlane((int)o_incl, 63);
   }
   static_assert(kTileQueues * kTileBuckets == 256, "four (queue, class) lists per lane");
-  auto fetch_order = [&](unsigned k) -> uint4 {  // k < n_order, wave-uniform
+  auto fetch_order = [&](unsigned k, size_t &ent) -> uint4 {  // k < n_order, wave-uniform; ent: the entry's index in the lists
+    ent = 0;
     if (!a.bucket_cnt) return uint4{k, 0u, 0u, 0u};
     const int l = __builtin_ctzll(__ballot(o_incl > k));
     unsigned r = k - (unsigned)__builtin_amdgcn_readlane((int)(o_incl - o_tot), l);
@@ -486,19 +497,29 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       if (u == v && r >= c) { r -= c; u = v + 1; }
     }
     const int f = 4 * l + u;
-    return reinterpret_cast<const uint4 *>(
-        a.bucket_list)[(size_t)((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * a.bucket_cap + r];
+    ent = (size_t)((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * a.bucket_cap + r;
+    return reinterpret_cast<const uint4 *>(a.bucket_list)[ent];
   };
   const uint4 kNoTile = uint4{0xFFFFFFFFu, 0u, 0u, 0u};
-  unsigned o_k = blockIdx.x;
+  // pass m of the schedule takes entries [m waves, (m + 1) waves) of the order, forwards for even m and backwards for odd
+  // m: the wave with the most expensive tile of one pass gets the cheapest of the next
+  unsigned o_pass = 0;
+  auto order_index = [&](unsigned pass) -> unsigned {
+    const unsigned w = (pass & 1u) ? n_waves - 1u - wave_id : wave_id;
+    return pass * n_waves + w;
+  };
+  unsigned o_k = order_index(0);
   uint4 hdr_next = kNoTile;
-  uint4 hdr = kSplit ? (o_k < n_order ? fetch_order(o_k) : kNoTile) : resolve();
+  size_t ent_cur = 0, ent_next = 0;
+  uint4 hdr = kSplit ? (o_k < n_order ? fetch_order(o_k, ent_cur) : kNoTile) : resolve();
   if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
   while (hdr.x != 0xFFFFFFFFu) {
     bool next_level_issued = false;
     if (kSplit) {
-      o_k += gridDim.x;
-      hdr_next = o_k < n_order ? fetch_order(o_k) : kNoTile;
+      // (a backwards pass that runs beyond the end of the order has no tile for this wave, but the pass after it may not
+      // either: the order ends inside this pass)
+      o_k = order_index(++o_pass);
+      hdr_next = o_k < n_order ? fetch_order(o_k, ent_next) : kNoTile;
     }
     const unsigned tile = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.x);
     const unsigned h_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.y);
@@ -538,6 +559,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       ge2 = (ze > 0.0) ? scaleinv_guard2 * ze * ze : 1e300;
     }
     woff[lane] = off;
+    if (kSplit) reci_l[lane] = (unsigned)i;
     // summation order of the first lane's image, staged once (lanes of another image read it from HBM)
     const long long wave_nb0 = (long long)__builtin_amdgcn_readfirstlane((int)nb0);  // nb_off < 2^24
     if (!kSplit) {
@@ -584,8 +606,11 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       wave_lds_sync();
       if (kSplit) {
         const int k0 = min(qn, max(0, a.sp_slot_cap - t_cnt));
-        uint2 *dst = a.sp_slots + (size_t)tile * (size_t)a.sp_slot_cap + t_cnt;
-        for (int p = lane; p < k0; p += 64) dst[p] = queue2[p];
+        uint4 *dst = a.sp_slots + (size_t)tile * (size_t)a.sp_slot_cap + t_cnt;
+        for (int p = lane; p < k0; p += 64) {
+          const uint2 e = queue2[p];
+          dst[p] = uint4{e.x, reci_l[e.y], e.y, 0u};
+        }
         int done = k0;
         while (done < qn && !ch_dead) {  // beyond the slot: the tile's chain of overflow chunks
           if (ov_cur == kNoChunk || ov_fill == kChunkCap) {
@@ -599,8 +624,11 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
             ov_fill = 0;
           }
           const int k = min(qn - done, kChunkCap - ov_fill);
-          uint2 *od = a.sp_pairs + (size_t)ov_cur * kChunkCap + ov_fill;
-          for (int p = lane; p < k; p += 64) od[p] = queue2[done + p];
+          uint4 *od = a.sp_pairs + (size_t)ov_cur * kChunkCap + ov_fill;
+          for (int p = lane; p < k; p += 64) {
+            const uint2 e = queue2[done + p];
+            od[p] = uint4{e.x, reci_l[e.y], e.y, 0u};
+          }
           ov_fill += k;
           done += k;
         }
@@ -609,6 +637,8 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
         qn = 0;
         if (final && lane == 0) {
           a.sp_cnt[tile] = (unsigned)t_cnt;
+          if (a.bucket_cnt)  // word 3 of the tile's class-list entry: k_dense8 gets tile and count with one load
+            const_cast<unsigned *>(a.bucket_list)[4 * ent_cur + 3] = (unsigned)t_cnt;
           if (ov_cur != kNoChunk) a.sp_desc[ov_cur] = make_uint2((unsigned)ov_fill, kNoChunk);
         }
         wave_lds_sync();
@@ -780,6 +810,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     if (kSplit) {
       if (!next_level_issued && hdr_next.x != 0xFFFFFFFFu) load_first_level(hdr_next);
       hdr = hdr_next;
+      ent_cur = ent_next;
     } else {
       hdr = resolve();
       if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
@@ -790,19 +821,24 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   if (!kSplit && lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
 }
 
-// Dense half of the split form: one workgroup of four waves per unit of sp_t_max consecutive tiles, units claimed through
-// a counter.  Tables of per-image maxima as in the fused kernel, one per tile of the unit; the sums in image-id order.
+// Dense half of the split form: one workgroup of kWaves waves per unit of sp_t_max tiles.  Tables of per-image maxima as in
+// the fused kernel, one per tile of the unit; the sums in image-id order.  Units in the sweep's class order, most expensive
+// class first (a unit = T consecutive entries of one (queue, class) list: tile and pair count in one 16-byte load); the first
+// unit of a workgroup is static, the later ones claimed through counters.  A unit starts with one load level (pair entries +
+// per-candidate records, the header was fetched during the previous unit's sums) followed by the record gathers (both
+// records of a pair from the entry).  Three barriers per unit.
+// (Fewer tiles per unit in the expensive classes -- one from class 22 / two from class 12, from 26 / 18, from 30 / 22: no
+// gain over T everywhere.  Workgroups of two waves / one wave with their own tables: 133 / 195 us for the stage against 106.)
 template <int kWaves>
 __global__ void __launch_bounds__(64 * kWaves)
 k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of the candidate, 1 = position, 2 = spos[position]
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  unsigned *reci = reinterpret_cast<unsigned *>(smem_raw);  // [kChunkTiles * 64] record of the candidate of a table row
-  unsigned *s_next = reci + kChunkTiles * 64;               // [4]
-  unsigned *s_cnt = s_next + 4;                             // [kChunkTiles] pairs of the unit's tiles
-  unsigned *s_tile = s_cnt + kChunkTiles;                   // [kChunkTiles] the unit's tiles
-  unsigned *s_ocnt = s_tile + kChunkTiles;                  // [256] tiles of the (queue, class) lists in flat order
-  unsigned *s_ounits = s_ocnt + 256;                        // [256] units of the lists
-  unsigned *s_uincl = s_ounits + 256;                       // [64] inclusive prefix of the units, four lists per entry
+  unsigned *s_next = reinterpret_cast<unsigned *>(smem_raw);  // [4]
+  unsigned *s_cnt = s_next + 4;                               // [kChunkTiles] pairs of the unit's tiles
+  unsigned *s_tile = s_cnt + kChunkTiles;                     // [kChunkTiles] the unit's tiles
+  unsigned *s_ocnt = s_tile + kChunkTiles;                    // [256] tiles of the (queue, class) lists in flat order
+  unsigned *s_ounits = s_ocnt + 256;                          // [256] units of the lists
+  unsigned *s_uincl = s_ounits + 256;                         // [64] inclusive prefix of the units, four lists per entry
   unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_raw + kDenseHdrBytes);
   if (a.err_flag && *a.err_flag == kErrPairChunks) return;  // the overflow store was full: the run is repeated
   const long long C = a.tri_off[a.G];
@@ -811,10 +847,7 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
   constexpr int kThreads = 64 * kWaves;  // (two table rows per thread: the host limits the tiles per unit to 2 kWaves)
   const int tid = threadIdx.x;
   const int lane = lane_id();
-  // Units in the sweep's class order, most expensive class first (the workgroups claim them through a counter: the long
-  // units start first).  A unit = T consecutive entries of one (queue, class) list.  (Fewer tiles per unit in the expensive
-  // classes -- one from class 22 / two from class 12, from 26 / 18, from 30 / 22: 120 / 106 / 105 us, no gain over T everywhere.)
-  // flat order f = class rank * kTileQueues + queue as in the sweep; lane l holds the lists f = 4 l .. 4 l + 3
+  // flat order f = class rank * kTileQueues + queue as in the sweep; entry l of s_uincl covers the lists f = 4 l .. 4 l + 3
   // (the lists' counts live in LDS: ten more registers held across the rounds cost the third wave per SIMD)
   unsigned n_units = (n_tiles + (unsigned)T - 1) / (unsigned)T;
   if (a.bucket_cnt) {
@@ -824,10 +857,9 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
       for (int v = 0; v < 4; ++v) {
         const int f = 4 * lane + v;
         const unsigned c = a.bucket_cnt[((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * 32];
-        const unsigned tf = (unsigned)T;
         s_ocnt[f] = c;
-        s_ounits[f] = (c + tf - 1) / tf;
-        u_tot += (c + tf - 1) / tf;
+        s_ounits[f] = (c + (unsigned)T - 1) / (unsigned)T;
+        u_tot += (c + (unsigned)T - 1) / (unsigned)T;
       }
       unsigned u_incl = u_tot;
 #pragma unroll
@@ -842,14 +874,14 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
   }
   const int max_nb = a.max_nb;
   const int cap = a.sp_slot_cap;
-  unsigned u = blockIdx.x;
-  unsigned long long n_pairs_wg = 0;  // pair statistic, threads < T
-  while (u < n_units) {
-    LT_TRACE_MARK(3, u, 0);
-    int nt;
+  // unit -> its tiles: number and the index of its first class-list entry (natural order: its first tile)
+  auto locate = [&](unsigned uu, int &nt_o, size_t &base_o) {
+    nt_o = 0;
+    base_o = 0;
+    if (uu >= n_units) return;
     if (a.bucket_cnt) {
-      const int l = __builtin_ctzll(__ballot(s_uincl[lane] > u));
-      unsigned r = u - (l > 0 ? s_uincl[l - 1] : 0u);
+      const int l = __builtin_ctzll(__ballot(s_uincl[lane] > uu));
+      unsigned r = uu - (l > 0 ? s_uincl[l - 1] : 0u);
       int v = 0;
 #pragma unroll
       for (int w = 0; w < 3; ++w) {
@@ -857,55 +889,125 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
         if (v == w && r >= c) { r -= c; v = w + 1; }
       }
       const int f = 4 * l + v;
-      const unsigned cf = s_ocnt[f];
-      const unsigned tf = (unsigned)T;
-      const unsigned first = r * tf;
-      nt = (int)min(tf, cf - first);
-      if (tid < nt) {
-        const unsigned tile = reinterpret_cast<const uint4 *>(a.bucket_list)[
-            (size_t)((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * a.bucket_cap + first + tid].x;
-        s_tile[tid] = tile;
-        const unsigned c = a.sp_cnt[tile];
-        s_cnt[tid] = c;
-        n_pairs_wg += (unsigned long long)c;
-      }
+      const unsigned first = r * (unsigned)T;
+      nt_o = (int)min((unsigned)T, s_ocnt[f] - first);
+      base_o = (size_t)((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * a.bucket_cap + first;
     } else {
-      const unsigned t0 = u * (unsigned)T;
-      nt = (int)min((unsigned)T, n_tiles - t0);
-      if (tid < nt) {
-        s_tile[tid] = t0 + tid;
-        const unsigned c = a.sp_cnt[t0 + tid];
-        s_cnt[tid] = c;
-        n_pairs_wg += (unsigned long long)c;
+      const unsigned t0 = uu * (unsigned)T;
+      nt_o = (int)min((unsigned)T, n_tiles - t0);
+      base_o = t0;
+    }
+  };
+  auto load_hdr = [&](int who, int nt_x, size_t base_x, unsigned &tile_o, unsigned &cnt_o) {  // who < nt_x: tile and its pair count
+    tile_o = 0;
+    cnt_o = 0;
+    if (who < nt_x) {
+      if (a.bucket_cnt) {
+        const uint4 e = reinterpret_cast<const uint4 *>(a.bucket_list)[base_x + who];
+        tile_o = e.x;
+        cnt_o = e.w;
+      } else {
+        tile_o = (unsigned)base_x + (unsigned)who;
+        cnt_o = a.sp_cnt[tile_o];
       }
     }
-    __syncthreads();
-    for (int k = tid; k < nt * max_nb * 64; k += kThreads) S[k] = 0ull;
-    CandMeta mt[2];
-    long long pos[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = tid + kThreads * h;
-      pos[h] = -1;
-      mt[h] = CandMeta{0u, 0u, 0u, 0u};
-      if (r < nt * 64) {
-        const long long p = (long long)s_tile[r >> 6] * 64 + (r & 63);
-        if (p < C) {
-          pos[h] = p;
-          reci[r] = a.perm ? a.perm[p] : (unsigned)p;
-          mt[h] = a.meta[p];
-        }
+  };
+  unsigned long long n_pairs_wg = 0;  // pair statistic (lanes < T of the last wave; the first unit: of the first)
+  // Unit queues: unit u belongs to queue u % 8; a workgroup's first unit is static (its index; gridDim.x is a multiple of
+  // 8, so it is of queue index % 8), all later ones are claims on the counters: claim c of queue q is unit
+  // (gridDim.x / 8 + c) * 8 + q.  An exhausted queue sends the workgroup to the next one that still looks open (plain
+  // loads of the counters; a counter only grows).
+  // The claim is LATE (issued by the last wave before its last round of the current unit, a unit claimed early sits with a
+  // workgroup that may be in a 45 us unit while the others run dry -- the claim two units ahead that would hide every
+  // latency cost 10 us of tail); the last wave resolves it behind the barrier that ends the rounds and fetches the next
+  // unit's header while it does its share of the sums.
+  int myq = (int)(blockIdx.x & 7u);
+  auto resolve_claim = [&](unsigned c, int &q_io) -> unsigned {  // one lane
+    unsigned un = ((gridDim.x >> 3) + c) * 8u + (unsigned)q_io;
+    int tries = 0;
+    while (un >= n_units && tries < 16) {
+      ++tries;
+      int q2 = -1;
+      for (int d = 1; d < 8; ++d) {
+        const int qq = (q_io + d) & 7;
+        const unsigned seen = __hip_atomic_load(&a.sp_counters[32 * (1 + qq)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((gridDim.x >> 3) + seen) * 8u + (unsigned)qq < n_units) { q2 = qq; break; }
       }
+      if (q2 < 0) break;
+      q_io = q2;
+      const unsigned c3 = atomicAdd(&a.sp_counters[32 * (1 + q2)], 1u);
+      un = ((gridDim.x >> 3) + c3) * 8u + (unsigned)q2;
     }
-    __syncthreads();
-    LT_TRACE_MARK(3, u, 1);
+    return un;
+  };
+  const bool last_wave = tid >= kThreads - 64;
+  unsigned u_cur = blockIdx.x;
+  int nt;
+  {
+    size_t base;
+    unsigned h_tile, h_cnt;
+    locate(u_cur, nt, base);
+    load_hdr(tid, nt, base, h_tile, h_cnt);
+    if (tid < nt) {
+      s_tile[tid] = h_tile;
+      s_cnt[tid] = h_cnt;
+      n_pairs_wg += (unsigned long long)h_cnt;
+    }
+  }
+  __syncthreads();
+  while (nt > 0) {
+    LT_TRACE_MARK(3, u_cur, 0);
     // the unit's pairs as one list: slot parts first (offsets from the tiles' counts), then the overflow chains
     int off[kChunkTiles + 1];
     off[0] = 0;
 #pragma unroll
     for (int k = 0; k < kChunkTiles; ++k) off[k + 1] = off[k] + (k < nt ? min((int)s_cnt[k], cap) : 0);
-    auto eval = [&](const uint2 e, const int k) {
-      const CRec &ci = a.cand[reci[k * 64 + (int)e.y]];
+    auto entry_of = [&](int p, int &k) -> uint4 {
+      k = 0;
+#pragma unroll
+      for (int m = 1; m < kChunkTiles; ++m) k += (p >= off[m]) ? 1 : 0;
+      int o = off[0];
+#pragma unroll
+      for (int m = 1; m < kChunkTiles; ++m) o = (k >= m) ? off[m] : o;
+      return a.sp_slots[(size_t)s_tile[k] * (size_t)cap + (p - o)];
+    };
+    // first load level of the unit, all in flight together: this thread's first pair entry, its candidates' records
+    int k0 = 0;
+    uint4 e0 = uint4{0u, 0u, 0u, 0u};
+    const bool has0 = tid < off[kChunkTiles];
+    if (has0) e0 = entry_of(tid, k0);
+    CandMeta mt[2];
+    long long pos[2];
+    unsigned rrec[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = tid + kThreads * h;
+      pos[h] = -1;
+      rrec[h] = 0;
+      mt[h] = CandMeta{0u, 0u, 0u, 0u};
+      if (r < nt * 64) {
+        const long long p = (long long)s_tile[r >> 6] * 64 + (r & 63);
+        if (p < C) {
+          pos[h] = p;
+          if (score_by == 0) rrec[h] = a.perm ? a.perm[p] : (unsigned)p;
+          mt[h] = a.meta[p];
+        }
+      }
+    }
+    for (int k = tid; k < nt * max_nb * 64; k += kThreads) S[k] = 0ull;
+    __syncthreads();
+    LT_TRACE_MARK(3, u_cur, 1);
+    // iterations of the last wave over the unit's list: it claims the next unit before its last one (eight counters: one
+    // counter took 2 300 claims in 60 us and the claims came back after up to 9 us)
+    const int total = off[kChunkTiles];
+    const int n_it3 = total > kThreads - 64 ? (total - (kThreads - 64) + kThreads - 1) / kThreads : 0;
+    unsigned c2 = 0;
+    auto claim = [&]() {
+      if (tid == kThreads - 64) c2 = atomicAdd(&a.sp_counters[32 * (1 + myq)], 1u);
+    };
+    if (n_it3 <= 1) claim();
+    auto eval = [&](const uint4 e, const int k) {
+      const CRec &ci = a.cand[e.y];
       const CRec &cj = a.cand[e.x];
       const int nbs_j = cj.nb_slot;
       const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
@@ -913,16 +1015,15 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
                                    mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
                                    mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg, a.cams[(int)((unsigned)nbs_j >> 8)]);
       if (sc > 0.0)
-        atomicMax(&S[(k * max_nb + (nbs_j & 0xFF)) * 64 + (int)e.y], (unsigned long long)__double_as_longlong(sc));
+        atomicMax(&S[(k * max_nb + (nbs_j & 0xFF)) * 64 + (int)e.z], (unsigned long long)__double_as_longlong(sc));
     };
-    for (int p = tid; p < off[kChunkTiles]; p += kThreads) {
-      int k = 0;
-#pragma unroll
-      for (int m = 1; m < kChunkTiles; ++m) k += (p >= off[m]) ? 1 : 0;
-      int o = off[0];
-#pragma unroll
-      for (int m = 1; m < kChunkTiles; ++m) o = (k >= m) ? off[m] : o;
-      eval(a.sp_slots[(size_t)s_tile[k] * (size_t)cap + (p - o)], k);
+    if (has0) eval(e0, k0);
+    int it = 1;
+    for (int p = tid + kThreads; p < total; p += kThreads, ++it) {
+      if (it == n_it3 - 1) claim();
+      int k;
+      const uint4 e = entry_of(p, k);
+      eval(e, k);
     }
     for (int k = 0; k < nt; ++k) {
       if ((int)s_cnt[k] <= cap) continue;
@@ -933,11 +1034,19 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
         cc = d.y;
       }
     }
-    // the next unit is claimed here: the round trip hides behind the barrier and the sums (at the start of the unit it
-    // was a burst of one atomic per workgroup on one address when the kernel starts)
-    if (tid == 0) s_next[0] = gridDim.x + atomicAdd(&a.sp_counters[32], 1u);
     __syncthreads();
-    LT_TRACE_MARK(3, u, 2);
+    LT_TRACE_MARK(3, u_cur, 2);
+    // the last wave: the claimed unit and its header (in flight during the sums)
+    unsigned un = 0, n_tile = 0, n_cnt = 0;
+    int nt_n = 0, q_n = myq;
+    if (last_wave) {
+      if (lane == 0) un = resolve_claim(c2, q_n);
+      un = (unsigned)__builtin_amdgcn_readfirstlane((int)un);
+      q_n = __builtin_amdgcn_readfirstlane(q_n);
+      size_t base_n;
+      locate(un, nt_n, base_n);
+      load_hdr(lane, nt_n, base_n, n_tile, n_cnt);
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (pos[h] >= 0) {
@@ -947,13 +1056,33 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
         double sum = 0.0;
         for (int k = 0; k < n_nb; ++k)
           sum += __longlong_as_double((long long)S[((r >> 6) * max_nb + a.blk_order[nb0 + k]) * 64 + (r & 63)]);
-        a.score[score_by == 1 ? pos[h] : (score_by == 2 ? (long long)a.spos[pos[h]] : (long long)reci[r])] = sum;
+        a.score[score_by == 1 ? pos[h] : (score_by == 2 ? (long long)a.spos[pos[h]] : (long long)rrec[h])] = sum;
+      }
+    }
+    if (last_wave) {  // (s_tile / s_cnt of this unit were last read before the barrier that ended the rounds)
+      if (lane < nt_n) {
+        s_tile[lane] = n_tile;
+        s_cnt[lane] = n_cnt;
+        n_pairs_wg += (unsigned long long)n_cnt;
+      }
+      if (lane == 0) {
+        s_next[0] = un;
+        s_next[1] = (unsigned)q_n;
+        s_next[2] = (unsigned)nt_n;
       }
     }
     __syncthreads();
-    LT_TRACE_MARK(3, u, 3);
-    u = (unsigned)__builtin_amdgcn_readfirstlane((int)s_next[0]);
+    LT_TRACE_MARK(3, u_cur, 3);
+    u_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)s_next[0]);
+    myq = __builtin_amdgcn_readfirstlane((int)s_next[1]);
+    nt = __builtin_amdgcn_readfirstlane((int)s_next[2]);
+  }
+  if (kWaves > 1) {  // the pair statistic sits in the first wave (first unit) and in the last one: fold it into the first
     __syncthreads();
+    unsigned long long *s_stat = reinterpret_cast<unsigned long long *>(S);
+    if (last_wave) s_stat[lane] = n_pairs_wg;
+    __syncthreads();
+    if (tid < 64) n_pairs_wg += s_stat[lane];
   }
   if (a.pair_counter && tid < 64) {
     for (int d = 32; d >= 1; d >>= 1) n_pairs_wg += (unsigned long long)__shfl_xor((long long)n_pairs_wg, d);
@@ -988,7 +1117,8 @@ int score_split_t_max(int max_nb) {
   const int t = (48 * 1024) / (std::max(max_nb, 1) * 512);
   return std::max(1, std::min(t_env > 0 ? std::min(t_env, kChunkTiles) : kChunkTiles, t));
 }
-size_t score_split_chunk_bytes() { return (size_t)kChunkCap * 8; }
+size_t score_split_chunk_bytes() { return (size_t)kChunkCap * 16; }
+size_t score_split_entry_bytes() { return 16; }
 long long score_split_chunks(long long C) { return C / kChunkCap + 1024; }
 int score3_tile_buckets() { return kTileBuckets * kTileQueues; }  // counters (128 B apart) / lists: one per (queue, class)
 // (A two-kernel form -- light sweep writing per-tile pair lists, then a dense evaluation kernel -- was
@@ -1029,10 +1159,10 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.max_nb = max_nb;
   a.err_flag = err_flag;
   const bool split = sp_slots != nullptr && f32;
-  a.sp_slots = reinterpret_cast<uint2 *>(sp_slots);
+  a.sp_slots = reinterpret_cast<uint4 *>(sp_slots);
   a.sp_cnt = sp_cnt;
   a.sp_ovf = sp_ovf;
-  a.sp_pairs = reinterpret_cast<uint2 *>(sp_pairs);
+  a.sp_pairs = reinterpret_cast<uint4 *>(sp_pairs);
   a.sp_desc = reinterpret_cast<uint2 *>(sp_desc);
   a.sp_counters = draw + kTileQueues * 32;
   a.sp_chunk_cap = (unsigned)std::max<long long>(0, std::min<long long>(sp_chunks, 0x7FFFFFFFll));
@@ -1050,7 +1180,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
     a.spos = perm;
   }
   // persistent grid: as many single-wave workgroups as fit at once (LDS; registers allow LT_SCORE_RESIDENT per CU)
-  const size_t lds = split ? (size_t)kWin * 48 + 64 * 8 + (size_t)kSQCapSplit * 8 : score3_lds_bytes(max_nb, f32);
+  const size_t lds = split ? (size_t)kWin * 48 + 64 * 8 + (size_t)kSQCapSplit * 8 + 64 * 4 : score3_lds_bytes(max_nb, f32);
   const long long per_cu = std::max<long long>(1, std::min<long long>(LT_SCORE_RESIDENT, (long long)(160 * 1024 / lds)));
   const dim3 grid((unsigned)std::min<long long>(n_tiles, per_cu * n_cu)), block(64);
   if (split) {
@@ -1059,13 +1189,19 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
     const int var = perm_is_placement ? 0 : (sorted ? 1 : 2);
     if (occ_split[var] == 0) {
       int o = 0;
-      hipError_t e = var == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score3<true, false, true, true>, 64, lds)
-                   : var == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score3<true, true, false, true>, 64, lds)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score3<true, false, false, true>, 64, lds);
-      occ_split[var] = (e == hipSuccess && o > 0) ? o : 8;
+      const size_t ldsw = lds * kSweepWaves;
+      hipError_t e = var == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score3<true, false, true, true>, 64 * kSweepWaves, ldsw)
+                   : var == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score3<true, true, false, true>, 64 * kSweepWaves, ldsw)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score3<true, false, false, true>, 64 * kSweepWaves, ldsw);
+      occ_split[var] = (e == hipSuccess && o > 0) ? o : 2;
       if (const char *ev = getenv("LT_SWEEP_PER_CU")) occ_split[var] = std::max(1, atoi(ev));
     }
-    const dim3 grid((unsigned)std::min<long long>(n_tiles, (long long)occ_split[var] * n_cu));
+    a.sp_wave_lds = (int)lds;
+    const size_t lds1 = lds;
+    (void)lds1;
+    const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((n_tiles + kSweepWaves - 1) / kSweepWaves, (long long)occ_split[var] * n_cu)));
+    const dim3 block(64 * kSweepWaves);
+    const size_t lds = lds1 * kSweepWaves;
     if (perm_is_placement) hipLaunchKernelGGL((k_score3<true, false, true, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
     else if (sorted) hipLaunchKernelGGL((k_score3<true, true, false, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
     else hipLaunchKernelGGL((k_score3<true, false, false, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
@@ -1083,7 +1219,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
     }
     const long long fit = std::max<long long>(1, std::min<long long>(dense_per_cu, (long long)(160 * 1024 / lds2)));
     const int by = perm_is_placement ? 1 : (sorted && a.spos ? 2 : 0);
-    const dim3 g2((unsigned)(fit * n_cu));
+    const dim3 g2((unsigned)std::max<long long>(8, (fit * n_cu) & ~7ll));  // a multiple of 8: see the unit queues
     if (dense_waves == 4) hipLaunchKernelGGL(k_dense8<4>, g2, dim3(256), lds2, st, a, cfg, by);
     else if (dense_waves == 2) hipLaunchKernelGGL(k_dense8<2>, g2, dim3(128), lds2, st, a, cfg, by);
     else hipLaunchKernelGGL(k_dense8<1>, g2, dim3(64), lds2, st, a, cfg, by);
