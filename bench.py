@@ -134,6 +134,8 @@ def roofline_entry(name, nbytes, ms, pmc):
     k = pmc.get(name)
     if k and ms > 0:
         e["traffic"] = k.get("hbm_bytes")
+        if k.get("per_kernel"):
+            e["per_kernel_counters"] = k["per_kernel"]
         if k.get("valu_flops_f64") is not None:
             tf = k["valu_flops_f64"] / (ms * 1e-3) / 1e12
             e["valu_f64"] = {"flops_per_launch": k["valu_flops_f64"], "achieved_tflops": tf, "peak_tflops": FP64_VALU_PEAK_TF,
@@ -318,7 +320,7 @@ def main():
     if acc.get("survivors", 0.0) == 0.0:  # counted on demand when the run did not have it on the host
         acc["survivors"] = last["survivors"] * max(args.steps, 1)
     kt = {k: v / max(args.steps, 1) for k, v in acc.items()}  # average HIP-event ms per launch
-    # The timed region carries the events around the dominant kernel only (k_score3: roofline).  The generation
+    # The timed region carries the events around the dominant stage only (scoring = k_score3 + k_dense8: roofline).  The generation
     # kernels are priced in a few extra steps with their own events on (LT_FINE_TIMERS=2 costs ~5 us per step).
     if args.mode == "matched":
         prev_fine = os.environ.get("LT_FINE_TIMERS")
@@ -436,6 +438,16 @@ def main():
         # per-KERNEL durations: HIP events recorded on the launch stream right around each kernel
         # (lt_get_timers [13]-[15]); "gen" is the two-kernel stage HOT LOOP 1 for continuity with round-1 lines
         if args.mode == "matched":
+            # scoring = scoreOneNode as TWO kernels since round 4 (k_score3: the sweep, writes the pairs that pass; k_dense8:
+            # pair_score over them, maxima, sums), timed as one stage by the events around them; its counters are the sums
+            # of the two kernels' (LT_SCORE_FUSED=1: one kernel, k_score3)
+            if "k_dense8" in pmc and "k_score3" in pmc and not os.environ.get("LT_SCORE_FUSED"):
+                a_, b_ = pmc["k_score3"], pmc["k_dense8"]
+                pmc = dict(pmc)
+                pmc["k_score3"] = {k: (a_[k] + b_[k]) for k in a_ if k in b_ and isinstance(a_[k], (int, float))
+                                   and isinstance(b_[k], (int, float)) and k not in ("valu_busy_frac", "lds_active_frac")}
+                pmc["k_score3"]["per_kernel"] = {n_: {k: v for k, v in e_.items() if k != "raw"}
+                                                 for n_, e_ in (("k_score3(sweep)", a_), ("k_dense8", b_))}
             kernels = {"k_score3": (ab["score"], kt.get("k_score3", 0.0)), "k_gates": (ab["gates"], kt.get("k_gates", 0.0)),
                        "k_tri_rows": (ab["tri"], kt.get("k_tri_rows", 0.0))}
         else:
@@ -465,7 +477,9 @@ def main():
                        "valid_edges_rank0": st["valid_edges"], "tracks_rank0": st_after["tracks"]},
             "kernel_ms": kt,
             "connections_per_s": conn_total * args.steps / elapsed,
-            "roofline": dict(roof[dom], kernel=dom),
+            "roofline": dict(roof[dom], kernel=("k_score3 + k_dense8 (the scoring stage: sweep kernel + dense kernel, one pair of events)"
+                                                if dom == "k_score3" and args.mode == "matched" and not os.environ.get("LT_SCORE_FUSED")
+                                                else dom)),
             "roofline_all": roof,
             "roofline_note": pmc_note or ("traffic / valu_f64 / lds: rocprofv3 --pmc passes over this exact device code "
                                           "(profiles/r04_pmc.json, tools/prof_pmc_json.sh); FP64 VALU peak 78.6 TF"),

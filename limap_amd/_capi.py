@@ -502,7 +502,8 @@ class Context:
         return dict(zip(keys, out.tolist()))
 
     _TIMER_KEYS = ["run", "invariants", "sort", "gen", "compact", "score", "select", "gather", "upload", "download",
-                   "tail", "pairs_eval", "buffer", "k_gates", "k_tri_rows", "k_score3", "survivors", "ex_slots", "ex_cap"]
+                   "tail", "pairs_eval", "buffer", "k_gates", "k_tri_rows", "k_score3", "survivors", "ex_slots", "ex_cap",
+                   "score_fused"]
 
     def timers(self):
         out = np.zeros(24)

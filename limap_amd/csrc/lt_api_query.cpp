@@ -263,6 +263,7 @@ int lt_get_timers(lt_ctx *ctx, double out[24]) {
     }
   }
   ctx->timers[16] = (double)ctx->stat_survivors;
+  ctx->timers[19] = ctx->score_fused ? 1.0 : 0.0;  // the split scoring form's pair store overflowed once: fused from then on
   std::memcpy(out, ctx->timers, sizeof(ctx->timers));
   return LT_OK;
 }

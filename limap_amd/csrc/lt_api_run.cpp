@@ -698,7 +698,11 @@ int lt_run_device_async(lt_ctx *ctx) {
     C_run = C_bound;  // replaced by the exact count when that arrives with the error flag (finish_run)
     // split form (default for the single-precision sweep): the sweep writes pair chunks, k_dense8 evaluates them with
     // full rounds; LT_SCORE_FUSED=1 or a chunk store that overflowed once: the fused kernel
-    const bool split = score_f32 && !ctx->score_fused && !getenv("LT_SCORE_FUSED");
+    // (matched mode; the exhaustive mode's tiles carry ~25 pairs each and its units would be four tiles all the same -- the
+    // per-unit work of k_dense8 then costs what the full rounds save: 1.16 + 1.44 ms against 2.54 fused.  LT_SCORE_SPLIT=1
+    // forces the split form there and for the natural tile order, for the tests.)
+    const bool split = score_f32 && !ctx->score_fused && !getenv("LT_SCORE_FUSED") &&
+                       (tile_classes || getenv("LT_SCORE_SPLIT"));
     long long sp_chunks = 0;
     int sp_slot_cap = ctx->job_mode == 2 ? 64 : 256;  // entries per tile slot (matched: p90 of the bench scene is 182 pairs)
     if (split) {
@@ -726,9 +730,9 @@ int lt_run_device_async(lt_ctx *ctx) {
                   staged_sorted ? ctx->d_ex_rec.as<unsigned>() : nullptr,
                   staged_sorted ? ctx->d_ex_z.as<float>() : nullptr, ctx->d_err.as<int>(),
                   split ? ctx->d_sp_slots.p : nullptr, sp_slot_cap, ctx->d_sp_cnt.as<unsigned>(),
-                  ctx->d_sp_ovf.as<unsigned>(), ctx->d_sp_pairs.p, ctx->d_sp_desc.p, sp_chunks);
+                  ctx->d_sp_ovf.as<unsigned>(), ctx->d_sp_pairs.p, ctx->d_sp_desc.p, sp_chunks, ev[5]);
+    if (C_bound <= 0) HIPCHK(ctx, hipEventRecord(ev[5], st));  // nothing to score: no kernel carries the event
   }
-  HIPCHK(ctx, hipEventRecord(ev[5], st));
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));
   ENSURE(ctx, ctx->d_nvalid, 4 * (size_t)(G + 1));
   ENSURE(ctx, ctx->d_edge_off, 8 * (size_t)(G + 1));

@@ -7,6 +7,8 @@
 
 #include "lt_devfn.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 
 namespace lt {
@@ -1131,7 +1133,10 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, unsigned *bucket_cnt,
                    unsigned *bucket_list, unsigned bucket_cap, const unsigned *place, unsigned *rec, const float *st_z,
                    int *err_flag, void *sp_slots, int sp_slot_cap, unsigned *sp_cnt, unsigned *sp_ovf, void *sp_pairs,
-                   void *sp_desc, long long sp_chunks) {
+                   void *sp_desc, long long sp_chunks, hipEvent_t ev_after) {
+  // ev_before / ev_after: bound as the STOP events of k_cand_meta and of the stage's last kernel (hipExtLaunchKernelGGL:
+  // the kernel's own completion signal carries the timestamp) -- a hipEventRecord between two kernels is a barrier packet
+  // that opens a ~5.5 us gap in the stream (LT_EV_MARKERS=1: the plain records, for comparison)
   // sp_*: the pair store of the split form (sp_slots == nullptr: the fused kernel): slots of sp_slot_cap entries per tile,
   // pair counts and first overflow chunk per tile, sp_chunks overflow chunks with their (count, next) records
   // place / rec: depth-sorted sweep over STAGED records (one-pass exhaustive mode): place[natural position] = record,
@@ -1146,9 +1151,11 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   }
   // C: the candidate count or an upper bound of it (the kernels read the exact count from tri_off[G])
   const long long n_tiles = (C + 63) / 64;
-  hipLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st, G,
-                     cand_node, tri_off, node_img, nb_off, reinterpret_cast<CandMeta *>(meta), draw, bucket_cnt, bucket_list,
-                     bucket_cap);
+  static const bool ev_markers = getenv("LT_EV_MARKERS") != nullptr;
+  hipExtLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st,
+                        nullptr, ev_markers ? nullptr : ev_before, 0, G, cand_node, tri_off, node_img, nb_off,
+                        reinterpret_cast<CandMeta *>(meta), draw, bucket_cnt, bucket_list, bucket_cap);
+  hipEvent_t ev_stop = ev_markers ? nullptr : ev_after;
   Score3Args a;
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand;
   a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
@@ -1169,7 +1176,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.sp_slot_cap = sp_slot_cap;
   a.sp_t_max = score_split_t_max(max_nb);
   if (const char *e = getenv("LT_DENSE_WAVES")) a.sp_t_max = std::min(a.sp_t_max, 2 * std::max(1, atoi(e)));
-  if (ev_before) (void)hipEventRecord(ev_before, st);
+  if (ev_before && ev_markers) (void)hipEventRecord(ev_before, st);
   const bool sorted = perm != nullptr && f32 && !perm_is_placement;
   if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
     hipLaunchKernelGGL(k_depth_order, dim3(nblk2(G, 4)), dim3(256), 0, st, G, tri_off, cand,
@@ -1220,17 +1227,19 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
     const long long fit = std::max<long long>(1, std::min<long long>(dense_per_cu, (long long)(160 * 1024 / lds2)));
     const int by = perm_is_placement ? 1 : (sorted && a.spos ? 2 : 0);
     const dim3 g2((unsigned)std::max<long long>(8, (fit * n_cu) & ~7ll));  // a multiple of 8: see the unit queues
-    if (dense_waves == 4) hipLaunchKernelGGL(k_dense8<4>, g2, dim3(256), lds2, st, a, cfg, by);
-    else if (dense_waves == 2) hipLaunchKernelGGL(k_dense8<2>, g2, dim3(128), lds2, st, a, cfg, by);
-    else hipLaunchKernelGGL(k_dense8<1>, g2, dim3(64), lds2, st, a, cfg, by);
+    if (dense_waves == 4) hipExtLaunchKernelGGL(k_dense8<4>, g2, dim3(256), lds2, st, nullptr, ev_stop, 0, a, cfg, by);
+    else if (dense_waves == 2) hipExtLaunchKernelGGL(k_dense8<2>, g2, dim3(128), lds2, st, nullptr, ev_stop, 0, a, cfg, by);
+    else hipExtLaunchKernelGGL(k_dense8<1>, g2, dim3(64), lds2, st, nullptr, ev_stop, 0, a, cfg, by);
+    if (ev_after && ev_markers) (void)hipEventRecord(ev_after, st);
     return;
   }
   if (perm_is_placement) {
-    if (f32) hipLaunchKernelGGL((k_score3<true, false, true, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-    else hipLaunchKernelGGL((k_score3<false, false, true, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-  } else if (sorted) hipLaunchKernelGGL((k_score3<true, true, false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-  else if (f32) hipLaunchKernelGGL((k_score3<true, false, false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-  else hipLaunchKernelGGL((k_score3<false, false, false, false>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+    if (f32) hipExtLaunchKernelGGL((k_score3<true, false, true, false>), grid, block, lds, st, nullptr, ev_stop, 0, a, cfg, scaleinv_guard2);
+    else hipExtLaunchKernelGGL((k_score3<false, false, true, false>), grid, block, lds, st, nullptr, ev_stop, 0, a, cfg, scaleinv_guard2);
+  } else if (sorted) hipExtLaunchKernelGGL((k_score3<true, true, false, false>), grid, block, lds, st, nullptr, ev_stop, 0, a, cfg, scaleinv_guard2);
+  else if (f32) hipExtLaunchKernelGGL((k_score3<true, false, false, false>), grid, block, lds, st, nullptr, ev_stop, 0, a, cfg, scaleinv_guard2);
+  else hipExtLaunchKernelGGL((k_score3<false, false, false, false>), grid, block, lds, st, nullptr, ev_stop, 0, a, cfg, scaleinv_guard2);
+  if (ev_after && ev_markers) (void)hipEventRecord(ev_after, st);
 }
 
 }  // namespace lt

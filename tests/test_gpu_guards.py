@@ -39,7 +39,8 @@ def _same(a, b):
 def clean_env():
     keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES",
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
-            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TEST_SCORE_F64")
+            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_SCORE_SPLIT",
+            "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -443,6 +444,43 @@ def test_scoring_sweep_forms_agree(gpu_lib, clean_env, topk, n_nb):
     allp = _results(run_product(sc, cfg, topk=topk))
     _same(base, allp)
     assert allp[4]["pairs_eval"] > base[4]["pairs_eval"]
+
+
+@pytest.mark.parametrize("topk,n_nb", [(10, 6), (60, 13)])
+def test_split_and_fused_scoring_agree(gpu_lib, clean_env, topk, n_nb):
+    """The scoring stage runs as two kernels by default (sweep -> pair slots per tile -> k_dense8 over units of tiles) and
+    keeps the fused k_score3 as the fallback.  Same bits from: the fused kernel (LT_SCORE_FUSED); slots of four entries
+    (every tile with more pairs continues in a chain of overflow chunks); an overflow store of one chunk (the store
+    fills, device flag 7, the run is repeated fused and the context stays fused); the split form over the natural tile
+    order; the split form of the exhaustive mode (not its default)."""
+    sc = syn.make_scene(n_views=14, n_segs=140, n_neighbors=n_nb, seed=77, topk=topk)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    base = _results(run_product(sc, cfg, topk=topk))
+    assert base[5]["candidates"] > 1000 and base[4]["pairs_eval"] > 1000
+    os.environ["LT_SCORE_FUSED"] = "1"
+    fused = _results(run_product(sc, cfg, topk=topk))
+    _same(base, fused)
+    assert fused[4]["pairs_eval"] == base[4]["pairs_eval"]
+    del os.environ["LT_SCORE_FUSED"]
+    os.environ["LT_TEST_SPLIT_SLOT"] = "4"
+    chains = _results(run_product(sc, cfg, topk=topk))
+    _same(base, chains)
+    assert chains[4]["pairs_eval"] == base[4]["pairs_eval"]
+    os.environ["LT_TEST_SPLIT_CHUNKS"] = "1"  # slots of four entries and one overflow chunk: the store fills
+    full = _results(run_product(sc, cfg, topk=topk))
+    _same(base, full)
+    assert full[4]["score_fused"] == 1 and chains[4]["score_fused"] == 0 and base[4]["score_fused"] == 0
+    del os.environ["LT_TEST_SPLIT_SLOT"], os.environ["LT_TEST_SPLIT_CHUNKS"]
+    os.environ["LT_TEST_NO_TILE_CLASSES"] = "1"
+    os.environ["LT_SCORE_SPLIT"] = "1"
+    nat = _results(run_product(sc, cfg, topk=topk))
+    _same(base, nat)
+    del os.environ["LT_TEST_NO_TILE_CLASSES"]
+    # exhaustive mode (depth-sorted tiles): fused by default, split when asked for
+    ex_split = _results(run_product(sc, cfg, exhaustive=True))
+    del os.environ["LT_SCORE_SPLIT"]
+    ex_default = _results(run_product(sc, cfg, exhaustive=True))
+    _same(ex_default, ex_split)
 
 
 def test_second_batch_after_compute_tracks_device_and_host_tail(gpu_lib, oracle, clean_env):

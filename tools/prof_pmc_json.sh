@@ -88,7 +88,7 @@ for mode in ("matched", "exhaustive"):
     out["kernels"][mode] = kern
 json.dump(out, open("gpurun_out/r04_pmc.json", "w"), indent=1)
 for mode, kern in out["kernels"].items():
-    for n in ("k_score3", "k_gates", "k_tri_rows", "k_place", "k_gen_exhaustive"):
+    for n in ("k_score3", "k_dense8", "k_gates", "k_tri_rows", "k_place", "k_gen_exhaustive"):
         if n in kern:
             print(mode, n, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in kern[n].items() if a != "raw"})
 PY
