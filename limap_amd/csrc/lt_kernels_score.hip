@@ -831,8 +831,8 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
 // records of a pair from the entry).  Three barriers per unit.
 // (Fewer tiles per unit in the expensive classes -- one from class 22 / two from class 12, from 26 / 18, from 30 / 22: no
 // gain over T everywhere.  Workgroups of two waves / one wave with their own tables: 133 / 195 us for the stage against 106.)
-template <int kWaves>
-__global__ void __launch_bounds__(64 * kWaves)
+constexpr int kDenseWaves = 4;
+__global__ void __launch_bounds__(64 * kDenseWaves)
 k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of the candidate, 1 = position, 2 = spos[position]
   extern __shared__ __align__(16) unsigned char smem_raw[];
   unsigned *s_next = reinterpret_cast<unsigned *>(smem_raw);  // [4]
@@ -846,7 +846,9 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
   const long long C = a.tri_off[a.G];
   const unsigned n_tiles = (unsigned)((C + 63) >> 6);
   const int T = a.sp_t_max;
-  constexpr int kThreads = 64 * kWaves;  // (two table rows per thread: the host limits the tiles per unit to 2 kWaves)
+  constexpr int kWaves = kDenseWaves;
+  constexpr int kThreads = 64 * kWaves;
+  static_assert(kChunkTiles * 64 <= 2 * kThreads, "two table rows per thread");
   const int tid = threadIdx.x;
   const int lane = lane_id();
   // flat order f = class rank * kTileQueues + queue as in the sweep; entry l of s_uincl covers the lists f = 4 l .. 4 l + 3
@@ -1111,13 +1113,8 @@ size_t cand_meta_bytes() { return sizeof(CandMeta); }
 // split form: tiles per chunk for a job's widest neighbour list (k_dense8 holds one table of maxima per tile: three
 // workgroups per CU at 48 KB), bytes of chunk store per chunk, and the number of chunks for C candidates
 int score_split_t_max(int max_nb) {
-  static int t_env = -1;
-  if (t_env < 0) {
-    const char *e = getenv("LT_DENSE_TILES");
-    t_env = e ? atoi(e) : 0;
-  }
   const int t = (48 * 1024) / (std::max(max_nb, 1) * 512);
-  return std::max(1, std::min(t_env > 0 ? std::min(t_env, kChunkTiles) : kChunkTiles, t));
+  return std::max(1, std::min(kChunkTiles, t));
 }
 size_t score_split_chunk_bytes() { return (size_t)kChunkCap * 16; }
 size_t score_split_entry_bytes() { return 16; }
@@ -1175,7 +1172,6 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.sp_chunk_cap = (unsigned)std::max<long long>(0, std::min<long long>(sp_chunks, 0x7FFFFFFFll));
   a.sp_slot_cap = sp_slot_cap;
   a.sp_t_max = score_split_t_max(max_nb);
-  if (const char *e = getenv("LT_DENSE_WAVES")) a.sp_t_max = std::min(a.sp_t_max, 2 * std::max(1, atoi(e)));
   if (ev_before && ev_markers) (void)hipEventRecord(ev_before, st);
   const bool sorted = perm != nullptr && f32 && !perm_is_placement;
   if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
@@ -1200,36 +1196,21 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
       hipError_t e = var == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score3<true, false, true, true>, 64 * kSweepWaves, ldsw)
                    : var == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score3<true, true, false, true>, 64 * kSweepWaves, ldsw)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score3<true, false, false, true>, 64 * kSweepWaves, ldsw);
-      occ_split[var] = (e == hipSuccess && o > 0) ? o : 2;
-      if (const char *ev = getenv("LT_SWEEP_PER_CU")) occ_split[var] = std::max(1, atoi(ev));
+      occ_split[var] = (e == hipSuccess && o > 0) ? o : 8;
     }
     a.sp_wave_lds = (int)lds;
-    const size_t lds1 = lds;
-    (void)lds1;
-    const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((n_tiles + kSweepWaves - 1) / kSweepWaves, (long long)occ_split[var] * n_cu)));
-    const dim3 block(64 * kSweepWaves);
-    const size_t lds = lds1 * kSweepWaves;
-    if (perm_is_placement) hipLaunchKernelGGL((k_score3<true, false, true, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-    else if (sorted) hipLaunchKernelGGL((k_score3<true, true, false, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
-    else hipLaunchKernelGGL((k_score3<true, false, false, true>), grid, block, lds, st, a, cfg, scaleinv_guard2);
+    const dim3 grid1((unsigned)std::max<long long>(1, std::min<long long>((n_tiles + kSweepWaves - 1) / kSweepWaves, (long long)occ_split[var] * n_cu)));
+    const dim3 block1(64 * kSweepWaves);
+    const size_t lds1 = lds * kSweepWaves;
+    if (perm_is_placement) hipLaunchKernelGGL((k_score3<true, false, true, true>), grid1, block1, lds1, st, a, cfg, scaleinv_guard2);
+    else if (sorted) hipLaunchKernelGGL((k_score3<true, true, false, true>), grid1, block1, lds1, st, a, cfg, scaleinv_guard2);
+    else hipLaunchKernelGGL((k_score3<true, false, false, true>), grid1, block1, lds1, st, a, cfg, scaleinv_guard2);
+    // k_dense8: three workgroups of four waves per CU (registers: four waves per SIMD; LDS: one 512 B x max_nb table per tile)
     const size_t lds2 = (size_t)kDenseHdrBytes + (size_t)a.sp_t_max * (size_t)max_nb * 512;
-    static int dense_per_cu = 0;
-    if (dense_per_cu == 0) {
-      const char *e = getenv("LT_DENSE_PER_CU");
-      dense_per_cu = e ? std::max(1, atoi(e)) : 3;
-    }
-    static int dense_waves = 0;
-    if (dense_waves == 0) {
-      const char *e = getenv("LT_DENSE_WAVES");
-      dense_waves = e ? atoi(e) : 4;
-      if (dense_waves != 1 && dense_waves != 2) dense_waves = 4;
-    }
-    const long long fit = std::max<long long>(1, std::min<long long>(dense_per_cu, (long long)(160 * 1024 / lds2)));
+    const long long fit = std::max<long long>(1, std::min<long long>(3, (long long)(160 * 1024 / lds2)));
     const int by = perm_is_placement ? 1 : (sorted && a.spos ? 2 : 0);
     const dim3 g2((unsigned)std::max<long long>(8, (fit * n_cu) & ~7ll));  // a multiple of 8: see the unit queues
-    if (dense_waves == 4) hipExtLaunchKernelGGL(k_dense8<4>, g2, dim3(256), lds2, st, nullptr, ev_stop, 0, a, cfg, by);
-    else if (dense_waves == 2) hipExtLaunchKernelGGL(k_dense8<2>, g2, dim3(128), lds2, st, nullptr, ev_stop, 0, a, cfg, by);
-    else hipExtLaunchKernelGGL(k_dense8<1>, g2, dim3(64), lds2, st, nullptr, ev_stop, 0, a, cfg, by);
+    hipExtLaunchKernelGGL(k_dense8, g2, dim3(64 * kDenseWaves), lds2, st, nullptr, ev_stop, 0, a, cfg, by);
     if (ev_after && ev_markers) (void)hipEventRecord(ev_after, st);
     return;
   }
