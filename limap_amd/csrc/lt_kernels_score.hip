@@ -1,9 +1,12 @@
 // lt_kernels_score.hip -- the scoring stage (scoreOneNode, global_line_triangulator.cc:71-116): k_cand_meta (prologue
-// records, tiles by cost class), k_depth_order (exhaustive mode) and the fused scoring kernel k_score3.
-// A translation unit of its own since round 3: the stage kernels of
-// lt_kernels_v2.hip are compiled with -mllvm -disable-machine-licm (the hoisted constants cost k_tri_rows 32
-// registers and 8 % of its time), k_score3 is 2.5 % faster with the default pipeline (csrc/Makefile).
-// Compiled with -ffp-contract=off (see lt_geom.h).
+// records, tiles by cost class), k_depth_order (exhaustive mode), and scoreOneNode itself in two forms:
+//   split (matched mode, round 4): k_score3<.., kSplit = true> sweeps (conservative single-precision guards over an LDS
+//         window) and leaves the pairs that pass in per-tile slots in HBM, k_dense8 evaluates them (pair_score, per-image
+//         maxima, ordered sums) in units of tiles with workgroups of four waves;
+//   fused (exhaustive mode; the fallback when the split form's overflow store fills; LT_SCORE_FUSED=1): k_score3 does both
+//         per tile.  Same bits from both (tests/test_gpu_guards.py::test_split_and_fused_scoring_agree).
+// A translation unit of its own since round 3; compiled like lt_kernels_v2.hip with -mllvm -disable-machine-licm since round
+// 4 (k_dense8: 128 instead of 183 registers; the fused k_score3 is 2.5 % slower for it) and -ffp-contract=off (lt_geom.h).
 
 #include "lt_devfn.h"
 
@@ -71,7 +74,7 @@ k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long
   const long long C = tri_off[G];
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 2 * kTileQueues + 1) draw[i * 32] = 0;  // 128 bytes apart; the two behind the queues: chunk counters of the split form
+  if (i < 2 * kTileQueues + 1) draw[i * 32] = 0;  // 128 bytes apart; behind the draw queues: the split form's overflow-chunk counter and k_dense8's eight claim counters
   const long long C_up = (C + 63) & ~63ll;  // whole waves take part in the tile's reduction
   for (; i < C_up; i += stride) {
     unsigned n = 0, w_lo = 0, w_hi = 0;
@@ -131,7 +134,7 @@ k_cand_node(long long G, const long long *__restrict__ tri_off, unsigned *__rest
 // and are summed per lane in ascending image-id order (std::map order, :110-112).
 static __device__ __forceinline__ unsigned mt_key(long long off) { return (unsigned)off & 0xFFFFFFu; }
 constexpr int kSQCap = 512;  // the queue is drained when fewer than 256 (4 sweep iterations) slots are free
-constexpr int kSQCapSplit = 384;  // split form: 8-byte entries, emptied into the chunk store
+constexpr int kSQCapSplit = 384;  // split form: 8-byte entries, emptied into the tile's slot in HBM
 constexpr int kWin = LT_SCORE_WIN;
 
 struct Score3Args {
@@ -1110,8 +1113,8 @@ size_t score3_lds_bytes(int max_nb, bool f32) {
   return ((base + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
 }
 size_t cand_meta_bytes() { return sizeof(CandMeta); }
-// split form: tiles per chunk for a job's widest neighbour list (k_dense8 holds one table of maxima per tile: three
-// workgroups per CU at 48 KB), bytes of chunk store per chunk, and the number of chunks for C candidates
+// split form: tiles per unit of k_dense8 for a job's widest neighbour list (one table of maxima per tile: three workgroups
+// per CU at 48 KB), bytes of an overflow chunk and of a pair entry, and the number of overflow chunks for C candidates
 int score_split_t_max(int max_nb) {
   const int t = (48 * 1024) / (std::max(max_nb, 1) * 512);
   return std::max(1, std::min(kChunkTiles, t));
