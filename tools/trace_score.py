@@ -1,9 +1,10 @@
-"""Developer tool: per-wave phase timeline of k_score3 from a -DLT_TRACE build (variants/libT.so):
+"""Developer tool: per-wave phase timeline of the FUSED k_score3 from a -DLT_TRACE build (variants/libT.so):
    make -C limap_amd/csrc BUILD=build_T OUT=../variants/libT.so EXTRA=-DLT_TRACE"""
 import ctypes as C, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 os.environ.setdefault("LIMAP_AMD_LIB", os.path.join(root, "limap_amd/variants/libT.so"))
+os.environ["LT_SCORE_FUSED"] = "1"  # this tool reads the FUSED kernel's marks (the two-kernel form: tools/trace_split.py)
 import numpy as np
 from limap_amd import synthetic as syn, triangulation as tri, _capi
 
@@ -21,14 +22,6 @@ L = _capi.load_library()
 n = 4 * 4 * 65536
 buf = np.zeros(n, dtype=np.uint64)
 assert L.lt_debug_read_trace(buf.ctypes.data_as(C.c_void_p), C.c_size_t(n)) == 0
-t3 = buf.reshape(4, 65536, 4)[3].astype(np.int64)
-if (t3[:, 1] > 0).any():  # two-kernel scoring: slice 3 = k_sweep_rec (tile start, tile end)
-    m3 = t3[:, 1] > 0
-    u3 = (t3[m3] - t3[m3][:, 0].min()) / 100.0
-    d3 = u3[:, 1] - u3[:, 0]
-    print("k_sweep_rec: tiles", int(m3.sum()), "span us", u3[:, 1].max().round(1), "tile duration pct 0/10/50/90/100:",
-          np.percentile(d3, [0, 10, 50, 90, 100]).round(2), "sum ms", (d3.sum() / 1e3).round(2))
-    print("k_dense_rec (phases: table clear | dense rounds | sums):")
 t = buf.reshape(4, 65536, 4)[2].astype(np.int64)
 act = t[:, 3] > 0
 t = t[act]
