@@ -831,10 +831,13 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
 // class first (a unit = T consecutive entries of one (queue, class) list: tile and pair count in one 16-byte load); the first
 // unit of a workgroup is static, the later ones claimed through counters.  A unit starts with one load level (pair entries +
 // per-candidate records, the header was fetched during the previous unit's sums) followed by the record gathers (both
-// records of a pair from the entry).  Three barriers per unit.
+// records of a pair from the entry).  Two barriers per unit: tables clean -> rounds -> every pair in -> sums (wave w sums and
+// zeroes the table of tile w while the next unit's header and first load level are already under way).
 // (Fewer tiles per unit in the expensive classes -- one from class 22 / two from class 12, from 26 / 18, from 30 / 22: no
 // gain over T everywhere.  Workgroups of two waves / one wave with their own tables: 133 / 195 us for the stage against 106.)
 constexpr int kDenseWaves = 4;
+constexpr int kDensePerCU = 3;                  // workgroups of k_dense8 per CU
+constexpr int kDenseLdsBudget = 48 * 1024;      // LDS for a workgroup's tables of maxima
 __global__ void __launch_bounds__(64 * kDenseWaves)
 k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of the candidate, 1 = position, 2 = spos[position]
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -857,6 +860,8 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
   // flat order f = class rank * kTileQueues + queue as in the sweep; entry l of s_uincl covers the lists f = 4 l .. 4 l + 3
   // (the lists' counts live in LDS: ten more registers held across the rounds cost the third wave per SIMD)
   unsigned n_units = (n_tiles + (unsigned)T - 1) / (unsigned)T;
+  // (fewer tiles per unit in the most expensive classes -- one tile from class 30 / 28 / 24 / 20, two from 24 / 20 / 16 / 12:
+  // 65.8 / 67.1 / 68.4 / 69.3 us against 66.0 with T everywhere; four workgroups per CU with three tiles: 65.2)
   if (a.bucket_cnt) {
     if (tid < 64) {
       unsigned u_tot = 0;
@@ -865,8 +870,9 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
         const int f = 4 * lane + v;
         const unsigned c = a.bucket_cnt[((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * 32];
         s_ocnt[f] = c;
-        s_ounits[f] = (c + (unsigned)T - 1) / (unsigned)T;
-        u_tot += (c + (unsigned)T - 1) / (unsigned)T;
+        const unsigned tf = (unsigned)T;
+        s_ounits[f] = (c + tf - 1) / tf;
+        u_tot += (c + tf - 1) / tf;
       }
       unsigned u_incl = u_tot;
 #pragma unroll
@@ -896,8 +902,9 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
         if (v == w && r >= c) { r -= c; v = w + 1; }
       }
       const int f = 4 * l + v;
-      const unsigned first = r * (unsigned)T;
-      nt_o = (int)min((unsigned)T, s_ocnt[f] - first);
+      const unsigned tf = (unsigned)T;
+      const unsigned first = r * tf;
+      nt_o = (int)min(tf, s_ocnt[f] - first);
       base_o = (size_t)((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * a.bucket_cap + first;
     } else {
       const unsigned t0 = uu * (unsigned)T;
@@ -948,27 +955,27 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
     return un;
   };
   const bool last_wave = tid >= kThreads - 64;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned u_cur = blockIdx.x;
+  // the unit's header (tile and pair count of its tiles) sits in lanes < nt of EVERY wave: no LDS copy, no barrier for it
   int nt;
+  unsigned h_tile, h_cnt;
   {
     size_t base;
-    unsigned h_tile, h_cnt;
     locate(u_cur, nt, base);
-    load_hdr(tid, nt, base, h_tile, h_cnt);
-    if (tid < nt) {
-      s_tile[tid] = h_tile;
-      s_cnt[tid] = h_cnt;
-      n_pairs_wg += (unsigned long long)h_cnt;
-    }
+    load_hdr(lane, nt, base, h_tile, h_cnt);
+    if (tid < nt) n_pairs_wg += (unsigned long long)h_cnt;
   }
-  __syncthreads();
+  // the tables are zero whenever a unit starts: cleared here once, after that every wave zeroes what it sums
+  for (int k = tid; k < T * max_nb * 64; k += kThreads) S[k] = 0ull;
   while (nt > 0) {
     LT_TRACE_MARK(3, u_cur, 0);
     // the unit's pairs as one list: slot parts first (offsets from the tiles' counts), then the overflow chains
     int off[kChunkTiles + 1];
     off[0] = 0;
 #pragma unroll
-    for (int k = 0; k < kChunkTiles; ++k) off[k + 1] = off[k] + (k < nt ? min((int)s_cnt[k], cap) : 0);
+    for (int k = 0; k < kChunkTiles; ++k)
+      off[k + 1] = off[k] + (k < nt ? min((int)(unsigned)__builtin_amdgcn_readlane((int)h_cnt, k), cap) : 0);
     auto entry_of = [&](int p, int &k) -> uint4 {
       k = 0;
 #pragma unroll
@@ -976,24 +983,30 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
       int o = off[0];
 #pragma unroll
       for (int m = 1; m < kChunkTiles; ++m) o = (k >= m) ? off[m] : o;
-      return a.sp_slots[(size_t)s_tile[k] * (size_t)cap + (p - o)];
+      const unsigned tile = (unsigned)__shfl((int)h_tile, k);
+      return a.sp_slots[(size_t)tile * (size_t)cap + (p - o)];
     };
     // first load level of the unit, all in flight together: this thread's first pair entry, its candidates' records
+    const int total = off[kChunkTiles];
     int k0 = 0;
     uint4 e0 = uint4{0u, 0u, 0u, 0u};
-    const bool has0 = tid < off[kChunkTiles];
-    if (has0) e0 = entry_of(tid, k0);
+    const bool has0 = tid < total;
+    if (total > 0) {
+      int kk = 0;
+      const uint4 ee = entry_of(has0 ? tid : 0, kk);  // (every lane takes part in the shuffle; lanes without a pair read entry 0)
+      if (has0) { e0 = ee; k0 = kk; }
+    }
     CandMeta mt[2];
     long long pos[2];
     unsigned rrec[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int r = tid + kThreads * h;
+      const int ti = wave + kWaves * h;  // the tile whose candidates (table rows) this wave sums
       pos[h] = -1;
       rrec[h] = 0;
       mt[h] = CandMeta{0u, 0u, 0u, 0u};
-      if (r < nt * 64) {
-        const long long p = (long long)s_tile[r >> 6] * 64 + (r & 63);
+      if (ti < nt) {
+        const long long p = (long long)(unsigned)__builtin_amdgcn_readlane((int)h_tile, ti & (kChunkTiles - 1)) * 64 + lane;
         if (p < C) {
           pos[h] = p;
           if (score_by == 0) rrec[h] = a.perm ? a.perm[p] : (unsigned)p;
@@ -1001,12 +1014,10 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
         }
       }
     }
-    for (int k = tid; k < nt * max_nb * 64; k += kThreads) S[k] = 0ull;
-    __syncthreads();
+    __syncthreads();  // every wave has summed and zeroed its tables of the previous unit
     LT_TRACE_MARK(3, u_cur, 1);
     // iterations of the last wave over the unit's list: it claims the next unit before its last one (eight counters: one
     // counter took 2 300 claims in 60 us and the claims came back after up to 9 us)
-    const int total = off[kChunkTiles];
     const int n_it3 = total > kThreads - 64 ? (total - (kThreads - 64) + kThreads - 1) / kThreads : 0;
     unsigned c2 = 0;
     auto claim = [&]() {
@@ -1025,71 +1036,59 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
         atomicMax(&S[(k * max_nb + (nbs_j & 0xFF)) * 64 + (int)e.z], (unsigned long long)__double_as_longlong(sc));
     };
     if (has0) eval(e0, k0);
-    int it = 1;
-    for (int p = tid + kThreads; p < total; p += kThreads, ++it) {
+    const int n_it = total > (wave << 6) ? (total - (wave << 6) + kThreads - 1) / kThreads : 0;  // of this wave (wave-uniform)
+    for (int it = 1; it < n_it; ++it) {
       if (it == n_it3 - 1) claim();
+      const int p = tid + it * kThreads;
       int k;
-      const uint4 e = entry_of(p, k);
-      eval(e, k);
+      const uint4 e = entry_of(p < total ? p : 0, k);
+      if (p < total) eval(e, k);
     }
     for (int k = 0; k < nt; ++k) {
-      if ((int)s_cnt[k] <= cap) continue;
-      unsigned cc = a.sp_ovf[s_tile[k]];
+      if ((int)(unsigned)__builtin_amdgcn_readlane((int)h_cnt, k & (kChunkTiles - 1)) <= cap) continue;
+      unsigned cc = a.sp_ovf[(unsigned)__builtin_amdgcn_readlane((int)h_tile, k & (kChunkTiles - 1))];
       while (cc != kNoChunk) {
         const uint2 d = a.sp_desc[cc];
         for (int p = tid; p < (int)d.x; p += kThreads) eval(a.sp_pairs[(size_t)cc * kChunkCap + p], k);
         cc = d.y;
       }
     }
-    __syncthreads();
-    LT_TRACE_MARK(3, u_cur, 2);
-    // the last wave: the claimed unit and its header (in flight during the sums)
-    unsigned un = 0, n_tile = 0, n_cnt = 0;
-    int nt_n = 0, q_n = myq;
-    if (last_wave) {
-      if (lane == 0) un = resolve_claim(c2, q_n);
-      un = (unsigned)__builtin_amdgcn_readfirstlane((int)un);
-      q_n = __builtin_amdgcn_readfirstlane(q_n);
-      size_t base_n;
-      locate(un, nt_n, base_n);
-      load_hdr(lane, nt_n, base_n, n_tile, n_cnt);
+    if (tid == kThreads - 64) {  // the claimed unit, for everybody behind the barrier
+      int q_n = myq;
+      s_next[0] = resolve_claim(c2, q_n);
+      s_next[1] = (unsigned)q_n;
     }
+    __syncthreads();  // every pair of the unit is in the tables
+    LT_TRACE_MARK(3, u_cur, 2);
+    // the next unit's header: in flight during the sums
+    const unsigned un = (unsigned)__builtin_amdgcn_readfirstlane((int)s_next[0]);
+    myq = __builtin_amdgcn_readfirstlane((int)s_next[1]);
+    int nt_n;
+    size_t base_n;
+    unsigned n_tile, n_cnt;
+    locate(un, nt_n, base_n);
+    load_hdr(lane, nt_n, base_n, n_tile, n_cnt);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (pos[h] >= 0) {
-        const int r = tid + kThreads * h;
+        const int ti = wave + kWaves * h;
         const long long nb0 = (long long)(mt[h].nb >> 8);
         const int n_nb = (int)(mt[h].nb & 0xFFu);
         double sum = 0.0;
-        for (int k = 0; k < n_nb; ++k)
-          sum += __longlong_as_double((long long)S[((r >> 6) * max_nb + a.blk_order[nb0 + k]) * 64 + (r & 63)]);
+        for (int k = 0; k < n_nb; ++k) {
+          unsigned long long *cell = &S[(ti * max_nb + a.blk_order[nb0 + k]) * 64 + lane];
+          sum += __longlong_as_double((long long)*cell);
+          *cell = 0ull;  // (a candidate's pairs only touch the slots of its image's neighbours: the table is clean again)
+        }
         a.score[score_by == 1 ? pos[h] : (score_by == 2 ? (long long)a.spos[pos[h]] : (long long)rrec[h])] = sum;
       }
     }
-    if (last_wave) {  // (s_tile / s_cnt of this unit were last read before the barrier that ended the rounds)
-      if (lane < nt_n) {
-        s_tile[lane] = n_tile;
-        s_cnt[lane] = n_cnt;
-        n_pairs_wg += (unsigned long long)n_cnt;
-      }
-      if (lane == 0) {
-        s_next[0] = un;
-        s_next[1] = (unsigned)q_n;
-        s_next[2] = (unsigned)nt_n;
-      }
-    }
-    __syncthreads();
     LT_TRACE_MARK(3, u_cur, 3);
-    u_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)s_next[0]);
-    myq = __builtin_amdgcn_readfirstlane((int)s_next[1]);
-    nt = __builtin_amdgcn_readfirstlane((int)s_next[2]);
-  }
-  if (kWaves > 1) {  // the pair statistic sits in the first wave (first unit) and in the last one: fold it into the first
-    __syncthreads();
-    unsigned long long *s_stat = reinterpret_cast<unsigned long long *>(S);
-    if (last_wave) s_stat[lane] = n_pairs_wg;
-    __syncthreads();
-    if (tid < 64) n_pairs_wg += s_stat[lane];
+    u_cur = un;
+    nt = nt_n;
+    h_tile = n_tile;
+    h_cnt = n_cnt;
+    if (tid < nt) n_pairs_wg += (unsigned long long)h_cnt;
   }
   if (a.pair_counter && tid < 64) {
     for (int d = 32; d >= 1; d >>= 1) n_pairs_wg += (unsigned long long)__shfl_xor((long long)n_pairs_wg, d);
@@ -1116,7 +1115,7 @@ size_t cand_meta_bytes() { return sizeof(CandMeta); }
 // split form: tiles per unit of k_dense8 for a job's widest neighbour list (one table of maxima per tile: three workgroups
 // per CU at 48 KB), bytes of an overflow chunk and of a pair entry, and the number of overflow chunks for C candidates
 int score_split_t_max(int max_nb) {
-  const int t = (48 * 1024) / (std::max(max_nb, 1) * 512);
+  const int t = (kDenseLdsBudget) / (std::max(max_nb, 1) * 512);
   return std::max(1, std::min(kChunkTiles, t));
 }
 size_t score_split_chunk_bytes() { return (size_t)kChunkCap * 16; }
@@ -1210,7 +1209,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
     else hipLaunchKernelGGL((k_score3<true, false, false, true>), grid1, block1, lds1, st, a, cfg, scaleinv_guard2);
     // k_dense8: three workgroups of four waves per CU (registers: four waves per SIMD; LDS: one 512 B x max_nb table per tile)
     const size_t lds2 = (size_t)kDenseHdrBytes + (size_t)a.sp_t_max * (size_t)max_nb * 512;
-    const long long fit = std::max<long long>(1, std::min<long long>(3, (long long)(160 * 1024 / lds2)));
+    const long long fit = std::max<long long>(1, std::min<long long>(kDensePerCU, (long long)(160 * 1024 / lds2)));
     const int by = perm_is_placement ? 1 : (sorted && a.spos ? 2 : 0);
     const dim3 g2((unsigned)std::max<long long>(8, (fit * n_cu) & ~7ll));  // a multiple of 8: see the unit queues
     hipExtLaunchKernelGGL(k_dense8, g2, dim3(64 * kDenseWaves), lds2, st, nullptr, ev_stop, 0, a, cfg, by);
