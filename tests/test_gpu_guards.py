@@ -483,6 +483,20 @@ def test_split_and_fused_scoring_agree(gpu_lib, clean_env, topk, n_nb):
     _same(ex_default, ex_split)
 
 
+@pytest.mark.parametrize("n_nb", [100, 40])
+def test_split_scoring_with_wide_neighbour_lists(gpu_lib, clean_env, n_nb):
+    """k_dense8 holds one table of maxima per tile, 512 B per neighbour of the widest image: 100 neighbours leave room for
+    ONE tile per unit (40: two).  Same bits as the fused kernel."""
+    sc = syn.make_scene(n_views=110, n_segs=24, n_neighbors=n_nb, seed=5, topk=3)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    split = _results(run_product(sc, cfg, topk=3))
+    assert split[5]["candidates"] > 500 and split[4]["score_fused"] == 0
+    os.environ["LT_SCORE_FUSED"] = "1"
+    fused = _results(run_product(sc, cfg, topk=3))
+    _same(split, fused)
+    assert split[4]["pairs_eval"] == fused[4]["pairs_eval"]
+
+
 def test_second_batch_after_compute_tracks_device_and_host_tail(gpu_lib, oracle, clean_env):
     """ComputeLineTracks ends a batch.  A TriangulateImage call after it starts a NEW batch (the first one's results stay
     on the host) whether the tail ran on the device (default) or on the host (LT_TAIL_HOST); a repeated call for an image
