@@ -383,6 +383,8 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   int q = (int)(blockIdx.x & (kTileQueues - 1)), tried = 0;
   unsigned long long n_eval_total = 0;
   unsigned k_raw = 0;
+  // (the static schedule of the split form applied to the fused kernel over the exhaustive mode's natural tile order --
+  // wave w takes tiles w, w + waves, ... --: 5.65 against 3.20 ms for the stage, the tiles' costs are not spread that evenly)
   if (!kSplit && lane == 0) k_raw = atomicAdd(&a.draw[q * 32], 1u);
   // draws are mapped to tiles through the queue's cost-class lists, most expensive class first: lane b < kTileBuckets
   // holds the size of class (kTileBuckets - 1 - b) of queue q and the inclusive prefix of the sizes in that order
