@@ -268,7 +268,8 @@ int lt_get_stats(lt_ctx *ctx, int64_t out[8]);
  * in the environment at the time of the run), [15] k_score3 (default; LT_FINE_TIMERS=0 turns every per-kernel event off);
  * [16] connections that passed the stage-A gates (k_gates);
  * one-pass exhaustive mode: [17] staging slots needed (fullest region x regions), [18] staging slots provided;
- * [19] 1 when this context scores with the fused kernel because the split form's pair store overflowed once, else 0.
+ * [19] 1 when this context scores with the fused kernel because the split form's pair store overflowed once, else 0;
+ * [20] 1 when stage A of the last TriangulateImage job ran in the line-slot form (k_gates_ln: one lane per line), else 0.
  * With the scoring stage in two kernels (the default for TriangulateImage jobs) [15] spans both. */
 int lt_get_timers(lt_ctx *ctx, double out[24]);
 /* The same slots summed over every lt_run_device since the last reset ([8]-[10], [12] are not summed), and

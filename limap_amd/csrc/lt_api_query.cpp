@@ -253,7 +253,7 @@ int lt_get_timers(lt_ctx *ctx, double out[24]) {
   if (ctx->stat_survivors < 0) {
     ctx->stat_survivors = 0;
     if (ctx->ran && ctx->job_mode == 1 && ctx->n_blk > 0 && ctx->max_rows > 0 && ctx->d_surv_count.p) {
-      const size_t n = (size_t)ctx->n_blk * (size_t)gen_slots(ctx->max_rows);
+      const size_t n = (size_t)ctx->n_blk * (size_t)(ctx->rows_ln ? ctx->ln_slots : gen_slots(ctx->max_rows));
       std::vector<unsigned> sc(n);
       HIPCHK(ctx, hipSetDevice(ctx->device));
       HIPCHK(ctx, hipMemcpy(sc.data(), ctx->d_surv_count.p, 4 * n, hipMemcpyDeviceToHost));
@@ -263,6 +263,7 @@ int lt_get_timers(lt_ctx *ctx, double out[24]) {
     }
   }
   ctx->timers[16] = (double)ctx->stat_survivors;
+  ctx->timers[20] = (ctx->ran && ctx->job_mode == 1 && ctx->rows_ln) ? 1.0 : 0.0;  // stage A ran in the line-slot form
   ctx->timers[19] = ctx->score_fused ? 1.0 : 0.0;  // the split scoring form's pair store overflowed once: fused from then on
   std::memcpy(out, ctx->timers, sizeof(ctx->timers));
   return LT_OK;

@@ -182,8 +182,7 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
           ok = hipMemcpyAsync(nb.p, ctx->d_c_stream.p, sizeof(int) * from, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
                hipStreamSynchronize(ctx->stream) == hipSuccess;
         if (ok) {
-          ctx->d_c_stream.release();
-          ctx->d_c_stream = nb;
+          ctx->d_c_stream.take(nb);
         } else {
           nb.release();
           (void)hipGetLastError();
@@ -303,8 +302,7 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
         ok = hipMemcpyAsync(nbuf.p, ctx->d_c_stream.p, sizeof(int) * base, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
              hipStreamSynchronize(ctx->stream) == hipSuccess;
       if (ok) {
-        ctx->d_c_stream.release();
-        ctx->d_c_stream = nbuf;
+        ctx->d_c_stream.take(nbuf);
       } else {
         nbuf.release();
         (void)hipGetLastError();

@@ -87,8 +87,36 @@ int lt_upload(lt_ctx *ctx) {
     }
     if ((rc = upload_vec(ctx, ctx->d_ovf, ctx->h_ovf))) return rc;
     if ((rc = upload_vec(ctx, ctx->d_rowdesc, desc))) return rc;
-    launch_expand_rows(ctx->stream, ctx->n_blk, ctx->d_rowdesc.p, ctx->d_c_stream.as<unsigned>(), ctx->d_ovf.as<unsigned>(),
-                       ctx->d_m_pairs.as<unsigned>());
+    // Line-slot form (k_gates_ln): every block compressed (sorted, lines contiguous), neighbour tables within the LDS.
+    // Whether a run of equal line ids is longer than the kernel's outcome bits is only known on the device: the form is
+    // built optimistically and its flag read with the sync at the end of the upload.
+    bool try_ln = ctx->rows_sorted && ctx->n_blk > 0 && ctx->P > 0 && ctx->max_nb_segs <= 1024 && !getenv("LT_GEN_ROW_SLOTS") &&
+                  !getenv("LT_GEN_NO_LDS_TABLE");
+    for (size_t cb = 0; try_ln && cb < ctx->h_ovf_off.size(); ++cb)
+      if (ctx->h_ovf_off[cb] >= 0) try_ln = false;
+    ctx->rows_ln = false;
+    ctx->ln_slots = 0;
+    if (try_ln) {
+      ctx->ln_slots = gen_slots_ln(ctx->max_own_segs);
+      const size_t n_entries = (size_t)std::max<long long>(ctx->h_blk_line_base[ctx->n_blk], 1);
+      ENSURE(ctx, ctx->d_run_len, 4 * n_entries);
+      ENSURE(ctx, ctx->d_base_bl, 4 * n_entries);  // scratch here: the run starts (k_node_prefix rewrites it in every run)
+      ENSURE(ctx, ctx->d_slot_row0, 4 * (size_t)ctx->n_blk * (size_t)ctx->ln_slots);
+      ENSURE(ctx, ctx->d_blk_nruns, 4 * (size_t)ctx->n_blk);
+      ENSURE(ctx, ctx->d_ln_flag, 4);
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_ln_flag.p, 0, 4, ctx->stream));
+      launch_rows_ln(ctx->stream, ctx->n_blk, ctx->ln_slots, ctx->d_rowdesc.p, ctx->d_c_stream.as<unsigned>(),
+                     ctx->d_blk_line_base.as<long long>(), ctx->d_base_bl.as<unsigned>(), ctx->d_blk_nruns.as<int>(),
+                     ctx->d_run_len.as<unsigned>(), ctx->d_slot_row0.as<unsigned>(), ctx->d_m_pairs.as<unsigned short>(),
+                     ctx->d_ln_flag.as<int>());
+      int flag = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&flag, ctx->d_ln_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->rows_ln = flag == 0;
+    }
+    if (!ctx->rows_ln)
+      launch_expand_rows(ctx->stream, ctx->n_blk, ctx->d_rowdesc.p, ctx->d_c_stream.as<unsigned>(), ctx->d_ovf.as<unsigned>(),
+                         ctx->d_m_pairs.as<unsigned>());
     if ((rc = upload_vec(ctx, ctx->d_m_off, m_off))) return rc;
     // per-block records of the matched pipeline (row range, images, segment bases): a function of the job
     ENSURE(ctx, ctx->d_blkrec, blk_rec_bytes() * (size_t)std::max(ctx->n_blk, 1));
@@ -303,8 +331,10 @@ int lt_run_device_async(lt_ctx *ctx) {
   if (ctx->job_mode == 1) {
     const size_t Pn = (size_t)std::max<long long>(P, 1);
     const bool fast = ctx->rows_sorted;
-    const long long n_waves = (long long)ctx->n_blk * gen_groups(ctx->max_rows);  // candidate lists
-    const long long n_slots_all = (long long)ctx->n_blk * gen_slots(ctx->max_rows);  // survivor lists
+    const bool ln = ctx->rows_ln && fast;
+    const int ln_slots = ln ? ctx->ln_slots : 0;
+    const long long n_waves = (long long)ctx->n_blk * (ln ? gen_groups_ln(ctx->max_own_segs) : gen_groups(ctx->max_rows));  // candidate lists
+    const long long n_slots_all = (long long)ctx->n_blk * (ln ? ln_slots : gen_slots(ctx->max_rows));  // survivor lists
     const long long n_entries = ctx->h_blk_line_base[ctx->n_blk];
     // ---- generation in row order; valid candidates appended in row order to per-wave lists ----
     // VP-guided proposals: up to three candidates per match row (vp of l1, vp of l2, algebraic)
@@ -350,6 +380,10 @@ int lt_run_device_async(lt_ctx *ctx) {
     // both tables only while two workgroups still fit a CU (80 KB each): beyond that the own segments come
     // from L2 -- measured at 700 / 1000 segments per image: k_gates -16 % / -14 % against one workgroup per CU
     if (lds_segs + lds_segs1 > 1024) lds_segs1 = 0;
+    if (ln) {  // the line-slot form keeps no table of the image's own segments
+      lds_segs = std::max(ctx->max_nb_segs, 1);
+      lds_segs1 = 0;
+    }
     {
       ENSURE(ctx, ctx->d_st_row, 8 * Pn);
       ENSURE(ctx, ctx->d_surv_count, 4 * (size_t)(n_slots_all + 1));
@@ -366,7 +400,8 @@ int lt_run_device_async(lt_ctx *ctx) {
                        vp_on ? ctx->d_seg_has_vp.as<unsigned char>() : nullptr,
                        pts_on ? ctx->d_seg_pt_off.as<long long>() : nullptr, pts_on ? ctx->d_seg_pts.p : nullptr,
                        (pts_on && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr, ctx->d_err.as<int>(),
-                       many_on ? 1 : 0, one_on ? 1 : 0, group_base, phase);
+                       many_on ? 1 : 0, one_on ? 1 : 0, group_base, phase, ln_slots, ctx->d_m_pairs.as<unsigned short>(),
+                       ctx->d_run_len.as<unsigned>(), ctx->d_slot_row0.as<unsigned>());
       };
       if (!extras) {
         gen(0);
@@ -470,7 +505,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                    ctx->d_base_bl.as<unsigned>(), ctx->d_wave_count.as<unsigned>(), ctx->d_tri_off.as<long long>(),
                    ctx->d_st_c.as<CRec>(), ctx->d_st_l.as<double>(), ctx->d_st_key.as<unsigned>(),
                    ctx->d_cand.as<CRec>(), ctx->d_lite.as<double>(), ctx->d_cand_node.as<unsigned>(), group_base,
-                   perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
+                   perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr, ln_slots, ctx->d_slot_row0.as<unsigned>());
     } else {
       ENSURE(ctx, ctx->d_keys, 4 * Cn); ENSURE(ctx, ctx->d_rows, 4 * Cn);
       ENSURE(ctx, ctx->d_skeys, 4 * Cn); ENSURE(ctx, ctx->d_srows, 4 * Cn);

@@ -25,6 +25,17 @@ void dev_block_release(void *p, size_t cap);
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  // every buffer of a context returns to the block cache when the context goes (lt_destroy synchronises first): a member
+  // that is missing from a hand-kept release list can no longer leak
+  ~DevBuf() { release(); }
+  void take(DevBuf &o) {  // this buffer's block goes back to the cache, o's block moves here
+    release();
+    p = o.p; cap = o.cap;
+    o.p = nullptr; o.cap = 0;
+  }
   // NOTE: growing replaces the block (contents are NOT kept); the old block returns to the cache
   // only after the device is idle, because work of this context may still be using it.
   bool ensure(size_t bytes) {
@@ -207,6 +218,11 @@ struct lt_ctx {
   long long stat_pairs_eval = 0;
   std::vector<long long> h_blk_line_base;
   bool rows_sorted = true;   // every (image, neighbour) block lists its rows in non-decreasing line id
+  // line-slot form of the matched pipeline (k_gates_ln, lt_kernels_v2.hip): decided per upload -- every block in the
+  // compressed form, no run of equal line ids longer than gen_max_run(), neighbour tables within the LDS
+  bool rows_ln = false;
+  int ln_slots = 0;          // line slots per block (gen_slots_ln)
+  DevBuf d_run_len, d_slot_row0, d_blk_nruns, d_ln_flag;
   lt_host::HostBlock h_pinned_blk;
   long long *h_pinned = nullptr;  // pinned scratch for small device->host scalars
   DevBuf d_chunks, d_cand_meta, d_st_row, d_surv_count, d_seg_gates, d_blkrec, d_seg_vp, d_seg_has_vp;

@@ -267,7 +267,7 @@ static __device__ __forceinline__ int gate3_core(const GenCfg &cfg, double q1, d
   const double ae = fabs(__builtin_fma(n2x, re1x, __builtin_fma(n2y, re1y, n2z * re1z)));
   rej |= (as < cfg.sin_lo) | (ae < cfg.sin_lo);
   und |= !(as > cfg.sin_hi) | !(ae > cfg.sin_hi);
-  double cv[2], cerr = 0.0;
+  double cv[2], ce[2];
   bool well = q2 > 0.0;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -284,8 +284,9 @@ static __device__ __forceinline__ int gate3_core(const GenCfg &cfg, double q1, d
     well = well & (fabs(D) > 1e-4 * (fabs(t1) + fabs(t2))) & (fabs(D) > 1e-9 * na) & (n2a > 1e-30) &
            (n2a < 1e30) & (fabs(Dq) > 1e-280) & (fabs(Dq) < 1e280);
     cv[k] = numer * r;
-    cerr += (((fabs(m0) + fabs(m1)) + fabs(m2)) + fabs(m3)) * fabs(r);
+    ce[k] = (((fabs(m0) + fabs(m1)) + fabs(m2)) + fabs(m3)) * fabs(r);
   }
+  const double cerr = ce[0] + ce[1];
   // v_min/v_max drop NaN operands: harmless here, a NaN can only come from an infinite term of
   // `numer`, which makes cerr (hence the margin) infinite or NaN and the outcome "undecided"
   const double c1v = __builtin_fmin(cv[0], cv[1]), c2v = __builtin_fmax(cv[0], cv[1]);

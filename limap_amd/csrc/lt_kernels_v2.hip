@@ -113,7 +113,18 @@ struct GenArgs {
   const long long *group_base;
   int count_only;
   int many_on, one_on;    // which point-guided proposals run (seg_pts != null)
+  // Line-slot form (round 5, k_gates_ln): slot s of a block = its lines [64 s, 64 s + 64), one lane per line.
+  const unsigned short *tr;   // neighbour line of every row, per slot in (rank within the run, line) order: the rows
+                              // the lanes of a wave read in iteration j are adjacent (k_rows_transpose)
+  const unsigned *run_len;    // [(block, line)] rows of the line in the block
+  const unsigned *slot_row0;  // [n_blk * n_slots] first row of the slot (global row index); nullptr: the row-slot
+                              // form, slot s of block b starts at row rb + s * kRowsPerWave
 };
+// first row of slot s of block b (rb: the block's first row) in either slot form
+static __device__ __forceinline__ long long slot_first_row(const unsigned *__restrict__ slot_row0, int n_slots, int b, int s,
+                                                           long long rb) {
+  return slot_row0 ? (long long)slot_row0[(size_t)b * n_slots + s] : rb + (long long)s * kRowsPerWave;
+}
 
 
 // Per-block record: everything the row kernels need to know about neighbour block b in ONE scalar
@@ -366,26 +377,269 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
 #undef LT_GATES_FETCH
 }
 
+// ---------------------------------------------------------------------------------------------
+// Line-slot form of stage A (round 5).  What limap's matchers write -- every (image, neighbour) block sorted by line id,
+// the lines of the block a contiguous range, a handful of rows (top-k) per line: exactly the blocks that take the
+// compressed form of lt_rows.h -- lets ONE LANE OWN ONE LINE of the image:
+//   * everything that depends on (l1, image pair) only -- the segment's endpoints and rays, the epipolar lines of its two
+//     endpoints (gate3_epi: 2 x 15 of gate3's 178 lane instructions), its squared length -- is computed once per lane and
+//     item instead of once per row, and the table T1 of the image's own segments (40 KB of LDS, a barrier pair per image)
+//     disappears: the lane reads its own 80 bytes from the Seg array once per item;
+//   * with T1 gone the neighbour's table T2 fits twice: the NEXT block's table is copied global -> LDS by the DMA path
+//     (global_load_lds_dwordx4, no staging registers) into the other buffer while this block's rows are gated -- one
+//     barrier per block instead of two around a register-staged copy that nothing overlapped;
+//   * a row is 16 bits (the neighbour line; the line is the lane): k_rows_transpose stores the rows of a slot in
+//     (rank within the run, line) order, so the rows a wave needs in iteration j are adjacent -- 128 bytes per load.
+// Slots are line ranges here (slot s = lines [64 s, 64 s + 64) of the image), their survivor lists start at the slot's
+// first row (slot_row0) and are ordered lane-major = row order, as stage B and the placement need them.
+// Requirements (lt_upload decides; otherwise the row-slot form k_gates runs): every block compressed, no run longer than
+// kMaxRun rows (one outcome bit per row and lane), the neighbour tables within the LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxRun = 32;
+constexpr int kLnTriSlots = 2;  // stage B / placement: groups of two line slots (~1 280 rows at top-10)
+
+// Pass 1 over a compressed block: first row of every run (= line) of the block -> rstart[(block, line)], number of runs.
+__global__ void __launch_bounds__(256)
+k_rows_starts(int n_blk, const RowDesc *__restrict__ desc, const unsigned *__restrict__ stream,
+              const long long *__restrict__ blk_line_base, unsigned *__restrict__ rstart, int *__restrict__ blk_nruns,
+              int *__restrict__ ln_flag) {
+  const int b = blockIdx.x;
+  if (b >= n_blk) return;
+  const RowDesc d = desc[b];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  if (d.ooff >= 0) {  // plain form: not a line-slot job
+    if (threadIdx.x == 0) {
+      atomicOr(ln_flag, 1);
+      blk_nruns[b] = 0;
+    }
+    return;
+  }
+  const long long nbw = ((((long long)d.n + 1) / 2) + 1) & ~1ll;  // lt_rows.h: cb_nb_words
+  const unsigned long long *bits = reinterpret_cast<const unsigned long long *>(stream + d.coff + nbw);
+  const int n_words = (d.n + 63) >> 6;
+  unsigned *out = rstart + blk_line_base[b] + d.line0;
+  unsigned base = 0;  // runs that start before the current batch of words (row 0 carries no bit: run 0 starts there)
+  for (int w0 = 0; w0 < n_words; w0 += 64) {
+    const unsigned long long mine = (w0 + lane < n_words) ? bits[w0 + lane] : 0ull;
+    const unsigned cnt = (unsigned)__popcll(mine);
+    unsigned incl = cnt;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const unsigned o = __shfl_up(incl, s, 64);
+      if (lane >= s) incl += o;
+    }
+    const unsigned first = base + incl - cnt;
+    const int k_end = min(64, n_words - w0);
+    for (int k = wave; k < k_end; k += 4) {
+      const unsigned long long w = __shfl(mine, k, 64);
+      const unsigned lb = __shfl(first, k, 64);
+      const int r = ((w0 + k) << 6) + lane;
+      const bool head = r < d.n && (r == 0 || ((w >> lane) & 1ull));
+      if (head) out[lb + (unsigned)__popcll(w & ((2ull << lane) - 1ull))] = (unsigned)r;
+    }
+    base += __shfl(incl, 63, 64);
+  }
+  if (threadIdx.x == 0) blk_nruns[b] = d.n > 0 ? (int)base + 1 : 0;
+}
+
+// Pass 2: one wave per (block, line slot).  Run lengths of the slot's lines, the slot's first row, and the neighbour
+// lines of its rows in (rank within the run, line) order.
+__global__ void __launch_bounds__(256)
+k_rows_transpose(int n_blk, int n_slots, const RowDesc *__restrict__ desc, const unsigned *__restrict__ stream,
+                 const long long *__restrict__ blk_line_base, const unsigned *__restrict__ rstart,
+                 const int *__restrict__ blk_nruns, unsigned *__restrict__ run_len, unsigned *__restrict__ slot_row0,
+                 unsigned short *__restrict__ tr, int *__restrict__ ln_flag) {
+  const int b = blockIdx.y;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= n_blk || s >= n_slots) return;
+  const RowDesc d = desc[b];
+  const int lane = lane_id();
+  const size_t lin = (size_t)b * n_slots + s;
+  if (d.ooff >= 0) {
+    if (lane == 0) slot_row0[lin] = (unsigned)d.row_off;
+    return;
+  }
+  const long long lbase = blk_line_base[b];
+  const int M1 = (int)(blk_line_base[b + 1] - lbase);
+  const int nr = blk_nruns[b];
+  const int line = 64 * s + lane;
+  const int rel = line - d.line0;
+  const bool in = rel >= 0 && rel < nr;
+  const unsigned start = in ? rstart[lbase + line] : 0u;
+  const unsigned end = in ? (rel == nr - 1 ? (unsigned)d.n : rstart[lbase + line + 1]) : 0u;
+  const unsigned len = end - start;
+  if (line < M1) run_len[lbase + line] = len;
+  // the lines of a compressed block are a contiguous range and every one of them has rows: the slot's first row is the
+  // start of its first line inside the range (0 in front of the range, n behind it)
+  const int rel0 = 64 * s - d.line0;
+  const unsigned row0 = rel0 <= 0 ? 0u : (rel0 < nr ? rstart[lbase + 64 * s] : (unsigned)d.n);
+  if (lane == 0) slot_row0[lin] = (unsigned)d.row_off + row0;
+  const unsigned maxlen = wave_max_u32(len);
+  if (maxlen > (unsigned)kMaxRun && lane == 0) atomicOr(ln_flag, 2);
+  const unsigned short *nb = reinterpret_cast<const unsigned short *>(stream + d.coff);
+  unsigned short *out = tr + d.row_off;
+  unsigned base = row0;
+  for (unsigned j = 0; j < maxlen; ++j) {
+    const bool act = j < len;
+    const unsigned long long m = __ballot(act);
+    if (act) out[base + (unsigned)__popcll(m & lanemask_lt())] = nb[start + j];
+    base += (unsigned)__popcll(m);
+  }
+}
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+// kDbl: two T2 buffers (the next block's table lands while this one is in use); otherwise one buffer, refilled
+// between two barriers when the block changes (tables beyond 40 KB: two workgroups per CU still fit).
+template <bool kDbl>
+__global__ void __launch_bounds__(64 * kGateWaves) LT_GATE_OCC
+k_gates_ln(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *__restrict__ pairs_r,
+           const unsigned short *__restrict__ tr, const unsigned *__restrict__ run_len,
+           const unsigned *__restrict__ slot_row0) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  const int n_parts = a.n_slots / kGateWaves;
+  const int n_items = a.n_blk * n_parts;
+  const int per_wg = (n_items + (int)gridDim.x - 1) / (int)gridDim.x;
+  int item = (int)blockIdx.x * per_wg;
+  const int item_end = min(n_items, item + per_wg);
+  if (item >= item_end) return;
+  const unsigned tab_bytes = (unsigned)a.lds_segs * (unsigned)sizeof(SegGate);
+  // the neighbour's SegGate records, 1 KB per instruction and wave: LDS address = wave-uniform base + lane x 16
+  auto issue_table = [&](int bb, unsigned buf) {
+    const BlkRec *rp = blk_r + bb;
+    const char *src = reinterpret_cast<const char *>(a.gates + rp->g2);
+    const int bytes = rp->M2 * (int)sizeof(SegGate);
+    unsigned char *dst = smem_raw + buf * tab_bytes;
+    for (int o = wave * 1024; o < bytes; o += kGateWaves * 1024)
+      if (o + lane * 16 < bytes)
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + o + lane * 16), (lds_void_t *)(dst + o), 16, 0, 0);
+  };
+  unsigned buf = 0;
+  int tab_b = __builtin_amdgcn_readfirstlane(item / n_parts);  // block whose table is (being) loaded into `buf`
+  issue_table(tab_b, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (; item < item_end; ++item) {
+    const int b = __builtin_amdgcn_readfirstlane(item / n_parts), part = item - b * n_parts;
+    if (!kDbl && b != tab_b) {  // (uniform over the workgroup)
+      __syncthreads();  // the previous block's readers are done
+      issue_table(b, 0);
+      tab_b = b;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    int nb_blk = b;
+    if (kDbl && item + 1 < item_end) {
+      nb_blk = __builtin_amdgcn_readfirstlane((item + 1) / n_parts);
+      if (nb_blk != b) issue_table(nb_blk, buf ^ 1u);
+    }
+    const BlkRec *rec = blk_r + b;
+    const long long g1 = rec->g1, lbase = rec->lbase;
+    const int M1 = (int)(a.seg_off[rec->i1 + 1] - g1);
+    const int slot = part * kGateWaves + wave;
+    const unsigned lin = (unsigned)b * (unsigned)a.n_slots + (unsigned)slot;
+    LT_TRACE_MARK(0, lin, 0);
+    const int line = 64 * slot + lane;
+    const unsigned len = line < M1 ? run_len[lbase + line] : 0u;
+    const unsigned row0 = slot_row0[lin];
+    const unsigned maxlen = wave_max_u32(len);
+    unsigned total = 0;
+    if (maxlen > 0) {
+      // the lane's own segment: endpoints and rays (first 80 bytes of the record)
+      const double2 *p1 = reinterpret_cast<const double2 *>(a.segs + g1 + (line < M1 ? line : 0));
+      const double2 e0 = p1[0], e1 = p1[1], e2 = p1[2], e3 = p1[3], e4 = p1[4];
+      // first rows (the loads fly while the view-1 side is computed)
+      unsigned base = row0;
+      unsigned long long m_n = __ballot(0u < len);
+      unsigned nb_n = 0;
+      if (0u < len) nb_n = tr[base + (unsigned)__popcll(m_n & lanemask_lt())];
+      base += (unsigned)__popcll(m_n);
+      double F[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) F[k] = pairs_r[b].F[k];
+      const double d1x = e0.x - e1.x, d1y = e0.y - e1.y;
+      const double q1 = __builtin_fma(d1x, d1x, d1y * d1y);
+      const GateEpi ea = gate3_epi(F, e0.x, e0.y), eb = gate3_epi(F, e1.x, e1.y);
+      const unsigned char *T2 = smem_raw + (kDbl ? buf * tab_bytes : 0u);
+      unsigned pass_bits = 0, und_bits = 0;
+      for (unsigned j = 0; j < maxlen; ++j) {
+        const bool act = j < len;
+        const unsigned nbl = nb_n;
+        {  // next iteration's rows
+          const bool act_n = j + 1 < len;
+          m_n = __ballot(act_n);
+          if (act_n) nb_n = tr[base + (unsigned)__popcll(m_n & lanemask_lt())];
+          base += (unsigned)__popcll(m_n);
+        }
+        int res = 0;
+        if (act) {
+          const double2 *p2 = reinterpret_cast<const double2 *>(T2 + __umul24(nbl, (unsigned)sizeof(SegGate)));
+          const double2 h0 = p2[0], h1 = p2[1], h2 = p2[2], h3 = p2[3], h4 = p2[4];
+          res = gate3_core(cfg, q1, e2.x, e2.y, e3.x, e3.y, e4.x, e4.y, h0.x, h0.y, h1.x, h1.y, h2.x, h2.y, h3.x, h3.y,
+                           h4.x, h4.y, ea, eb);
+        }
+        pass_bits |= (res != 0 ? 1u : 0u) << j;
+        und_bits |= (res == 2 ? 1u : 0u) << j;
+      }
+      // survivor list of the slot, lane-major (= row order): offsets by a wave scan of the per-lane counts
+      const unsigned cnt = (unsigned)__popc(pass_bits);
+      unsigned incl = cnt;
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) {
+        const unsigned o = (unsigned)__shfl_up((int)incl, s, 64);
+        if (lane >= s) incl += o;
+      }
+      total = (unsigned)__shfl((int)incl, 63, 64);
+      if (total > 0) {
+        unsigned dst = row0 + incl - cnt;
+        unsigned bs = row0;
+        for (unsigned j = 0; j < maxlen; ++j) {
+          const bool act = j < len;
+          const unsigned long long m = __ballot(act);
+          if ((pass_bits >> j) & 1u) {
+            // (the row is re-read, cache-hot, rather than held in registers)
+            const unsigned v = tr[bs + (unsigned)__popcll(m & lanemask_lt())];
+            a.st_row[dst++] = make_uint2((unsigned)line | (((und_bits >> j) & 1u) ? 0x80000000u : 0u), v);
+          }
+          bs += (unsigned)__popcll(m);
+        }
+      }
+    }
+    LT_TRACE_MARK(0, lin, 2);
+    if (lane == 0) a.surv_count[lin] = total;
+    if (kDbl && nb_blk != b) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next table has landed
+      __syncthreads();                                    // ... everybody's, and nobody reads this table any more
+      buf ^= 1u;
+    }
+  }
+}
+
 // One wave per (block, group).  (A persistent-wave variant with the next item's record prefetched was
 // measured slower: the kernel is bound by gather / scatter throughput, not by latency.)
 // kExtra: additionally the optional proposals of steps 1.1 and 2 (base_line_triangulator.cc:183-281) -- per
 // connection the candidates in the reference's order many-points, one-point (one per shared point),
 // vp(l1), vp(l2), algebraic.  Which
 // of them are active is a run-time property (a.seg_pts / a.seg_vp may be null).
-template <bool kExtra>
+// kTS: slots per group (kTriSlots row slots, or kLnTriSlots line slots -- GenArgs::slot_row0)
+template <bool kExtra, int kTS>
 __global__ void __launch_bounds__(64 * kTriWaves)
 k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec *__restrict__ pairs_r,
-           const BlkRec *__restrict__ blk_r) {
+           const BlkRec *__restrict__ blk_r, const unsigned *__restrict__ slot_row0) {
   extern __shared__ __align__(16) unsigned char smem_raw[];  // per wave: 64 x (CRec | unc | key)
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
-  const int n_groups = a.n_slots / kTriSlots;
+  const int n_groups = a.n_slots / kTS;
   const int g = blockIdx.x * kTriWaves + wave;
   if (g >= n_groups) return;
   const BlkRec *rec = blk_r + b;
   const long long rb = rec->rb, re = rec->re;
-  const long long r0 = rb + (long long)g * kTriRows;
+  const long long r0 = slot_first_row(slot_row0, a.n_slots, b, g * kTS, rb);
   const unsigned lin = (unsigned)b * (unsigned)n_groups + (unsigned)g;
   LT_TRACE_MARK(1, lin, 0);
   if (r0 >= re) {
@@ -399,12 +653,12 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
   const long long out0 = (kExtra && a.group_base) ? a.group_base[lin] : r0;  // first staging slot of the group's list
   const bool wr = !(kExtra && a.count_only);
   // survivor lists of the group's slots, walked as one concatenated list
-  unsigned cs[kTriSlots + 1];
+  unsigned cs[kTS + 1];
   cs[0] = 0;
 #pragma unroll
-  for (int k = 0; k < kTriSlots; ++k)
-    cs[k + 1] = cs[k] + a.surv_count[(size_t)b * a.n_slots + (size_t)g * kTriSlots + k];
-  const unsigned n_s = cs[kTriSlots];
+  for (int k = 0; k < kTS; ++k)
+    cs[k + 1] = cs[k] + a.surv_count[(size_t)b * a.n_slots + (size_t)g * kTS + k];
+  const unsigned n_s = cs[kTS];
   unsigned wcount = 0;
   for (unsigned e0 = 0; e0 < n_s; e0 += 64) {
     const unsigned e = e0 + lane;
@@ -478,9 +732,9 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
       int k = 0;
       unsigned first = 0;
 #pragma unroll
-      for (int t = 1; t < kTriSlots; ++t)
+      for (int t = 1; t < kTS; ++t)
         if (e >= cs[t]) { k = t; first = cs[t]; }
-      const long long rs0 = r0 + (long long)k * kRowsPerWave;
+      const long long rs0 = slot_first_row(slot_row0, a.n_slots, b, g * kTS + k, rb);
       const uint2 u = a.st_row[rs0 + (e - first)];
       line = (int)(u.x & 0x7FFFFFFFu);
       ng = (int)u.y;
@@ -685,6 +939,7 @@ k_node_prefix(long long G, const int *__restrict__ node_img, const long long *__
 // One wave per slot.  Rows of a block are sorted by line id,
 // so the candidates of one (block, line) run are adjacent in the row-ordered lists; the rank is
 // found by looking back over equal keys (crossing into the previous wave's list if the run does).
+template <int kTS>
 __global__ void __launch_bounds__(256)
 k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
         const long long *__restrict__ seg_off, const long long *__restrict__ blk_line_base,
@@ -692,14 +947,16 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
         const long long *__restrict__ tri_off, const CRec *__restrict__ st_r,
         const double *__restrict__ st_unc, const unsigned *__restrict__ st_key, CRec *__restrict__ cand,
         double *__restrict__ cand_unc, unsigned *__restrict__ cand_node, int n_groups,
-        const long long *__restrict__ group_base, unsigned *__restrict__ perm) {
+        const long long *__restrict__ group_base, unsigned *__restrict__ perm,
+        const unsigned *__restrict__ slot_row0) {
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int b = blockIdx.y;
   const int g = blockIdx.x * 4 + wave;
   if (g >= n_groups) return;
+  const int n_slots = n_groups * kTS;
   const long long rb = m_off[b], re = m_off[b + 1];
-  const long long r0 = rb + (long long)g * kTriRows;
+  const long long r0 = slot_first_row(slot_row0, n_slots, b, g * kTS, rb);
   if (r0 >= re) return;
   const unsigned lin = (unsigned)b * (unsigned)n_groups + (unsigned)g;
   const unsigned count = wave_count[lin];
@@ -726,6 +983,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
     unsigned carry = 0;
     {
       long long cur_r0 = r0;
+      int cur_g = g;
       long long idx_end = (long long)e0;  // entries [0, idx_end) of the current list precede the batch
       unsigned cur_lin = lin;
       while (true) {
@@ -742,8 +1000,9 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
           idx_end -= n_valid;
         }
         if (!more) break;
-        if (cur_r0 - kTriRows < rb) break;  // first group of the block
-        cur_r0 -= kTriRows;
+        if (cur_g == 0) break;  // first group of the block
+        cur_g -= 1;
+        cur_r0 = slot_first_row(slot_row0, n_slots, b, cur_g * kTS, rb);
         cur_lin -= 1;
         // an empty list cannot tell whether the run continues further back: keep walking (bounded by the block)
         idx_end = (long long)wave_count[cur_lin];
@@ -780,7 +1039,7 @@ k_place(const long long *__restrict__ m_off, const int *__restrict__ blk_img,
 }
 
 // Generic path: pack the row-ordered wave lists into dense (key, source index) arrays for the sort
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256)  // (generic rows: always the row-slot form)
 k_pack_keys(const long long *__restrict__ m_off, const unsigned *__restrict__ wave_count,
             const long long *__restrict__ wave_pos, const unsigned *__restrict__ st_key,
             unsigned *__restrict__ keys_c, unsigned *__restrict__ src_c, int n_groups,
@@ -839,6 +1098,24 @@ int gen_slots(long long max_rows) {
 }
 // groups per block (lists of stage B / placement): wave_count[] has n_blk * gen_groups entries
 int gen_groups(long long max_rows) { return gen_slots(max_rows) / kTriSlots; }
+// the same for the line-slot form: slots of 64 lines of the image, groups of kLnTriSlots slots
+int gen_slots_ln(int max_own_segs) {
+  int n = (max_own_segs + 63) / 64;
+  return std::max((n + kGateWaves - 1) / kGateWaves * kGateWaves, kGateWaves);
+}
+int gen_groups_ln(int max_own_segs) { return gen_slots_ln(max_own_segs) / kLnTriSlots; }
+int gen_max_run() { return kMaxRun; }
+// the line-slot form of the staged rows (lt_upload): run starts, then run lengths / slot starts / transposed rows
+void launch_rows_ln(hipStream_t st, int n_blk, int n_slots, const void *desc, const unsigned *stream,
+                    const long long *blk_line_base, unsigned *rstart, int *blk_nruns, unsigned *run_len,
+                    unsigned *slot_row0, unsigned short *tr, int *ln_flag) {
+  if (n_blk <= 0) return;
+  hipLaunchKernelGGL(k_rows_starts, dim3((unsigned)n_blk), dim3(256), 0, st, n_blk, reinterpret_cast<const RowDesc *>(desc),
+                     stream, blk_line_base, rstart, blk_nruns, ln_flag);
+  hipLaunchKernelGGL(k_rows_transpose, dim3(nblk2(n_slots, 4), (unsigned)n_blk), dim3(256), 0, st, n_blk, n_slots,
+                     reinterpret_cast<const RowDesc *>(desc), stream, blk_line_base, rstart, blk_nruns, run_len, slot_row0, tr,
+                     ln_flag);
+}
 #ifdef LT_TRACE
 int score_read_trace(unsigned long long *host, size_t n);  // lt_kernels_score.hip: slices 2 and 3
 extern "C" int lt_debug_read_trace(unsigned long long *host, size_t n) {
@@ -869,7 +1146,9 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       unsigned *surv_count, long long n_segs, void *gates, void *blkrec, hipEvent_t *ev3,
                       const double *seg_vp, const unsigned char *seg_has_vp, const long long *seg_pt_off,
                       const void *seg_pts, const double *sfm_xyz, int *err_flag, int many_on, int one_on,
-                      const long long *group_base, int phase) {
+                      const long long *group_base, int phase, int ln_slots, const unsigned short *tr,
+                      const unsigned *run_len, const unsigned *slot_row0) {
+  // ln_slots > 0: the line-slot form (k_gates_ln; slots per block = ln_slots, tables tr / run_len / slot_row0)
   // phase 0: k_gates + k_tri_rows (no extra proposals).  Extra proposals: phase 1 = k_gates + the COUNTING run of
   // k_tri_rows (wave_count only), phase 2 = the storing run at group_base (the scanned counts), see GenArgs
   if (n_blk <= 0 || max_rows <= 0) return;
@@ -887,7 +1166,9 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   a.seg_off = seg_off; a.cams = cams; a.segs = segs; a.gates = reinterpret_cast<const SegGate *>(gates);
   a.pairs = pairs; a.blk_line_base = blk_line_base; a.st_row = reinterpret_cast<uint2 *>(st_row); a.surv_count = surv_count;
   a.st_r = st_r; a.st_unc = st_unc; a.st_key = st_key; a.wave_count = wave_count; a.cnt_bl = cnt_bl;
-  a.n_slots = gen_slots(max_rows); a.lds_segs = lds_segs; a.lds_segs1 = lds_segs1;
+  const bool ln = ln_slots > 0;
+  a.n_slots = ln ? ln_slots : gen_slots(max_rows); a.lds_segs = lds_segs; a.lds_segs1 = lds_segs1;
+  a.tr = ln ? tr : nullptr; a.run_len = ln ? run_len : nullptr; a.slot_row0 = ln ? slot_row0 : nullptr;
   a.seg_vp = seg_vp; a.seg_has_vp = seg_has_vp;
   a.seg_pt_off = seg_pt_off; a.seg_pts = reinterpret_cast<const SegPoint *>(seg_pts); a.sfm_xyz = sfm_xyz;
   a.err_flag = err_flag;
@@ -898,26 +1179,41 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   a.blk = reinterpret_cast<const BlkRec *>(blkrec); a.n_blk = n_blk;
   // persistent grid: as many workgroups as fit at once (registers allow 16 waves per CU)
   const long long n_items = (long long)n_blk * (a.n_slots / kGateWaves);
-  const size_t lds = (size_t)(lds_segs + lds_segs1) * sizeof(SegGate);
+  // line-slot form: T2 only, twice while two workgroups per CU still fit (2 x 2 x 40 KB)
+  const bool ln_dbl = ln && (size_t)lds_segs * sizeof(SegGate) <= 40 * 1024;
+  const size_t lds = ln ? (size_t)lds_segs * sizeof(SegGate) * (ln_dbl ? 2 : 1) : (size_t)(lds_segs + lds_segs1) * sizeof(SegGate);
   int per_cu = std::max(16 / kGateWaves, 1);
   if (lds > 0) per_cu = (int)std::max<size_t>(std::min<size_t>(160 * 1024 / lds, (size_t)per_cu), 1);
   const unsigned n_wg = (unsigned)std::min<long long>(n_items, (long long)n_cu * per_cu);
   // the tables are sized by the largest image of the job, so "fits" is a per-launch property
   const dim3 grid(n_wg), block(64 * kGateWaves);
   if (ev3) (void)hipEventRecord(ev3[0], st);
-  if (phase != 2) {
+  if (phase != 2 && ln) {
+    if (ln_dbl) hipLaunchKernelGGL((k_gates_ln<true>), grid, block, lds, st, a, cfg, a.blk, a.pairs, a.tr, a.run_len, a.slot_row0);
+    else hipLaunchKernelGGL((k_gates_ln<false>), grid, block, lds, st, a, cfg, a.blk, a.pairs, a.tr, a.run_len, a.slot_row0);
+  } else if (phase != 2) {
     if (lds_segs1 > 0 && lds_segs > 0) hipLaunchKernelGGL((k_gates<true, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
     else if (lds_segs > 0) hipLaunchKernelGGL((k_gates<false, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
     else if (lds_segs1 > 0) hipLaunchKernelGGL((k_gates<true, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
     else hipLaunchKernelGGL((k_gates<false, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
   }
   if (ev3) (void)hipEventRecord(ev3[1], st);
-  if (extra)
-    hipLaunchKernelGGL(k_tri_rows<true>, dim3(nblk2(a.n_slots / kTriSlots, kTriWaves), n_blk), dim3(64 * kTriWaves), 0, st,
-                       a, cfg, a.cams, a.pairs, a.blk);
-  else
-    hipLaunchKernelGGL(k_tri_rows<false>, dim3(nblk2(a.n_slots / kTriSlots, kTriWaves), n_blk), dim3(64 * kTriWaves),
-                       kTriWaves * (64 * 9 + 16) * sizeof(double2), st, a, cfg, a.cams, a.pairs, a.blk);
+  const size_t tri_lds = kTriWaves * (64 * 9 + 16) * sizeof(double2);
+  if (ln) {
+    const dim3 tg(nblk2(a.n_slots / kLnTriSlots, kTriWaves), n_blk);
+    if (extra)
+      hipLaunchKernelGGL((k_tri_rows<true, kLnTriSlots>), tg, dim3(64 * kTriWaves), 0, st, a, cfg, a.cams, a.pairs, a.blk, a.slot_row0);
+    else
+      hipLaunchKernelGGL((k_tri_rows<false, kLnTriSlots>), tg, dim3(64 * kTriWaves), tri_lds, st, a, cfg, a.cams, a.pairs, a.blk,
+                         a.slot_row0);
+  } else {
+    const dim3 tg(nblk2(a.n_slots / kTriSlots, kTriWaves), n_blk);
+    if (extra)
+      hipLaunchKernelGGL((k_tri_rows<true, kTriSlots>), tg, dim3(64 * kTriWaves), 0, st, a, cfg, a.cams, a.pairs, a.blk, a.slot_row0);
+    else
+      hipLaunchKernelGGL((k_tri_rows<false, kTriSlots>), tg, dim3(64 * kTriWaves), tri_lds, st, a, cfg, a.cams, a.pairs, a.blk,
+                         a.slot_row0);
+  }
   if (ev3) (void)hipEventRecord(ev3[2], st);
 }
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
@@ -931,12 +1227,19 @@ void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const CRec *st_r, const double *st_unc,
                   const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, const long long *group_base,
-                  unsigned *perm) {
+                  unsigned *perm, int ln_slots, const unsigned *slot_row0) {
   if (n_blk <= 0 || max_rows <= 0) return;
+  if (ln_slots > 0) {
+    const int n_groups = ln_slots / kLnTriSlots;
+    hipLaunchKernelGGL(k_place<kLnTriSlots>, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
+                       blk_line_base, base_bl, wave_count, tri_off, st_r, st_unc, st_key, cand, cand_unc, cand_node, n_groups,
+                       group_base, perm, slot_row0);
+    return;
+  }
   const int n_groups = gen_groups(max_rows);
-  hipLaunchKernelGGL(k_place, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
+  hipLaunchKernelGGL(k_place<kTriSlots>, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
                      blk_line_base, base_bl, wave_count, tri_off, st_r, st_unc, st_key, cand, cand_unc, cand_node, n_groups,
-                     group_base, perm);
+                     group_base, perm, (const unsigned *)nullptr);
 }
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
