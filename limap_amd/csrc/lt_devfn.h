@@ -24,6 +24,18 @@ static __device__ __forceinline__ int wave_reduce_dpp(int v, Op op) {
   v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
   return __builtin_amdgcn_readlane(v, 63);
 }
+// Inclusive prefix sum over the wave on the same path (no LDS round trips): shifts inside the rows of 16 lanes with zero
+// fill, then the last lane of row 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3.  All 64 lanes must be active.
+static __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x) {
+  int v = (int)x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2 and 3
+  return (unsigned)v;
+}
 static __device__ __forceinline__ int wave_max_i32(int v) {
   return wave_reduce_dpp(v, [](int a, int b) { return a > b ? a : b; });
 }
@@ -289,6 +301,51 @@ static __device__ __forceinline__ int gate3_core(const GenCfg &cfg, double q1, d
   const double cerr = ce[0] + ce[1];
   // v_min/v_max drop NaN operands: harmless here, a NaN can only come from an infinite term of
   // `numer`, which makes cerr (hence the margin) infinite or NaN and the outcome "undecided"
+  const double c1v = __builtin_fmin(cv[0], cv[1]), c2v = __builtin_fmax(cv[0], cv[1]);
+  const double num = __builtin_fmin(c2v, 1.0) - __builtin_fmax(c1v, 0.0);
+  const double den = __builtin_fmax(c2v, 1.0) - __builtin_fmin(c1v, 0.0);
+  const double delta = num - cfg.iou_th * den;
+  const double margin = __builtin_fma(1e-12, cerr, 1e-7 * (1.0 + fabs(c1v) + fabs(c2v)) * (1.0 + fabs(cfg.iou_th)));
+  rej |= well & (delta < -margin);
+  und |= !(well & (delta > margin));
+  if (cfg.force_undecided) return 2;  // test switch (LT_TEST_NO_FAST_GATES)
+  return rej ? 0 : (und ? 2 : 1);
+}
+
+// The same decision with fewer instructions (k_gates_ln): the numerator and its cancellation bound as FMA chains (this is
+// not reference arithmetic -- see gate3_core -- and a fused product only tightens the roundings the margin covers).
+static __device__ __forceinline__ int gate3_core_fma(const GenCfg &cfg, double q1, double rs1x, double rs1y, double rs1z,
+                                                     double re1x, double re1y, double re1z, double n2x, double n2y,
+                                                     double n2z, double lcx, double lcy, double P, double Q, double w1,
+                                                     double sv, double q2, const GateEpi &ea, const GateEpi &eb) {
+  bool rej = (q1 <= cfg.len_lo2) | (q2 <= cfg.len_lo2) | (cfg.disable_algebraic != 0);
+  bool und = !(q1 > cfg.len_hi2) | !(q2 > cfg.len_hi2);
+  const double as = fabs(__builtin_fma(n2x, rs1x, __builtin_fma(n2y, rs1y, n2z * rs1z)));
+  const double ae = fabs(__builtin_fma(n2x, re1x, __builtin_fma(n2y, re1y, n2z * re1z)));
+  rej |= (as < cfg.sin_lo) | (ae < cfg.sin_lo);
+  und |= !(as > cfg.sin_hi) | !(ae > cfg.sin_hi);
+  double cv[2], ce[2];
+  bool well = q2 > 0.0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const GateEpi &e = k == 0 ? ea : eb;
+    const double ax = e.ax, ay = e.ay, az = e.az, n2a = e.n2a, na = e.na;
+    const double t2 = lcy * ax;
+    const double D = __builtin_fma(kEps, na, __builtin_fma(lcx, ay, -t2));
+    const double tmag = __builtin_fma(fabs(lcx), fabs(ay), fabs(t2));  // |t1| + |t2|
+    const double m3 = D * sv;
+    const double numer = __builtin_fma(az, w1, __builtin_fma(ax, P, __builtin_fma(ay, Q, -m3)));
+    const double mag = __builtin_fma(fabs(az), fabs(w1), __builtin_fma(fabs(ax), fabs(P), __builtin_fma(fabs(ay), fabs(Q), fabs(m3))));
+    const double Dq = D * q2;
+    // v_rcp_f64 is good to ~2^-23; one Newton step (2^-46) is far below the 1e-7 margin of the decision
+    double r = __builtin_amdgcn_rcp(Dq);
+    r = __builtin_fma(__builtin_fma(-Dq, r, 1.0), r, r);
+    well = well & (fabs(D) > 1e-4 * tmag) & (fabs(D) > 1e-9 * na) & (n2a > 1e-30) & (n2a < 1e30) & (fabs(Dq) > 1e-280) &
+           (fabs(Dq) < 1e280);
+    cv[k] = numer * r;
+    ce[k] = mag * fabs(r);
+  }
+  const double cerr = ce[0] + ce[1];
   const double c1v = __builtin_fmin(cv[0], cv[1]), c2v = __builtin_fmax(cv[0], cv[1]);
   const double num = __builtin_fmin(c2v, 1.0) - __builtin_fmax(c1v, 0.0);
   const double den = __builtin_fmax(c2v, 1.0) - __builtin_fmin(c1v, 0.0);

@@ -135,7 +135,8 @@ struct BlkRec {
   long long lbase;    // first (block, line) counter
   int M2;             // segments of the neighbour
   int i1, i2, nbslot; // image, neighbour, position of the neighbour in the image's list
-  int pad_[2];
+  int M1;             // segments of the image
+  int pad_;
 };
 static_assert(sizeof(BlkRec) == 64, "BlkRec layout");
 
@@ -151,7 +152,8 @@ __global__ void k_build_blk(int n_blk, const long long *__restrict__ m_off, cons
   r.g1 = seg_off[r.i1]; r.g2 = seg_off[r.i2];
   r.M2 = (int)(seg_off[r.i2 + 1] - r.g2);
   r.lbase = blk_line_base[b];
-  r.pad_[0] = r.pad_[1] = 0;
+  r.M1 = (int)(seg_off[r.i1 + 1] - r.g1);
+  r.pad_ = 0;
   out[b] = r;
 }
 
@@ -488,134 +490,235 @@ k_rows_transpose(int n_blk, int n_slots, const RowDesc *__restrict__ desc, const
   }
 }
 
+// s_setprio takes an immediate
+static __device__ __forceinline__ void set_prio(int p) {  // p: wave-uniform, 0..3
+#if LT_GATE_PRIO != 0
+  if (p >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+}
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-// kDbl: two T2 buffers (the next block's table lands while this one is in use); otherwise one buffer, refilled
-// between two barriers when the block changes (tables beyond 40 KB: two workgroups per CU still fit).
-template <bool kDbl>
-__global__ void __launch_bounds__(64 * kGateWaves) LT_GATE_OCC
+// kW waves per workgroup, one table buffer per workgroup.  Workgroups of four waves while four tables fit a CU (tables up
+// to 40 KB: 512 neighbour segments), of eight beyond (two tables of up to 80 KB): 16 waves per CU either way, and as many
+// INDEPENDENT workgroups as the LDS allows -- the phases of an item in which a wave issues little (requests, survivor
+// list, barrier) then idle one wave in four on a SIMD instead of two (measured at 100 x 500: eight waves with two table
+// buffers -- the next block's table landing while this one is gated -- 65.7 us, eight waves with one buffer 65.7, four
+// waves with one buffer 63.6: what the second buffer hides is hidden by the other workgroups anyway).
+// Latency.  An item costs a wave ~2 us of arithmetic (8 us at four waves per SIMD), a global load 1-2 us, and the barrier
+// of a new block puts the waves of a workgroup in the same phase.  So no load is waited for where it is issued:
+//   * rows are fetched a GROUP of kRowAhead iterations ahead;
+//   * the per-lane inputs of item k + 1 (first row group, the lane's own segment) and the row counts / slot start of
+//     item k + 2 are requested when the gate loop of item k ends, and land while its survivors are written;
+//   * the next block's table is requested as soon as the last wave has left the gate loop of this block's last part
+//     (barrier), before the survivors are written;
+//   * the survivor list is written WITHOUT re-reading the rows: a lane keeps the neighbour lines of its last kKeep
+//     survivors in registers (a first version replayed the row positions and re-read the rows -- one dependent load per
+//     iteration, ~10 us per item).  A wave in which some lane has more survivors replays.
+// Two (or four) workgroups share a CU and the SIMD arbiter serves the OLDER waves first: without help the workgroup
+// dispatched first runs its items at full speed, the other at half, and once the first has finished the second has the
+// CU to itself at half the waves (trace, two workgroups of eight waves: items of 8 against 17 us, kernel end at 64 us for
+// 40).  Wave priority alternating in time slices between the workgroups dispatched in the first and in the second half of
+// the grid (LT_GATE_PRIO 3) evens that out; priority by the number of items done works only while a workgroup has at most
+// four items (the counts wrap), priority by position inside the item puts all waves in lockstep (slower: 72 us).
+#ifndef LT_GATE_ROW_AHEAD
+#define LT_GATE_ROW_AHEAD 4
+#endif
+constexpr int kRowAhead = LT_GATE_ROW_AHEAD;
+#ifndef LT_GATE_PRIO
+#define LT_GATE_PRIO 3
+#endif
+#ifndef LT_GATE_SLICE_BIT
+#define LT_GATE_SLICE_BIT 10  // 100 MHz clock: 10.24 us slices
+#endif
+constexpr int kKeep = 8;
+template <int kW>
+__global__ void __launch_bounds__(64 * kW) LT_GATE_OCC
 k_gates_ln(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *__restrict__ pairs_r,
            const unsigned short *__restrict__ tr, const unsigned *__restrict__ run_len,
-           const unsigned *__restrict__ slot_row0) {
+           const unsigned *__restrict__ slot_row0, uint2 *__restrict__ st_row, unsigned *__restrict__ surv_count) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
-  const int n_parts = a.n_slots / kGateWaves;
+  const int n_parts = a.n_slots / kW;
   const int n_items = a.n_blk * n_parts;
   const int per_wg = (n_items + (int)gridDim.x - 1) / (int)gridDim.x;
   int item = (int)blockIdx.x * per_wg;
+  const int wg_parity = (int)(2u * blockIdx.x >= gridDim.x);  // dispatched in the first / second round over the CUs (a guess)
+  (void)wg_parity;
   const int item_end = min(n_items, item + per_wg);
   if (item >= item_end) return;
-  const unsigned tab_bytes = (unsigned)a.lds_segs * (unsigned)sizeof(SegGate);
   // the neighbour's SegGate records, 1 KB per instruction and wave: LDS address = wave-uniform base + lane x 16
-  auto issue_table = [&](int bb, unsigned buf) {
+  auto issue_table = [&](int bb) {
     const BlkRec *rp = blk_r + bb;
     const char *src = reinterpret_cast<const char *>(a.gates + rp->g2);
     const int bytes = rp->M2 * (int)sizeof(SegGate);
-    unsigned char *dst = smem_raw + buf * tab_bytes;
-    for (int o = wave * 1024; o < bytes; o += kGateWaves * 1024)
+    for (int o = wave * 1024; o < bytes; o += kW * 1024)
       if (o + lane * 16 < bytes)
-        __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + o + lane * 16), (lds_void_t *)(dst + o), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + o + lane * 16), (lds_void_t *)(smem_raw + o), 16, 0, 0);
   };
-  unsigned buf = 0;
-  int tab_b = __builtin_amdgcn_readfirstlane(item / n_parts);  // block whose table is (being) loaded into `buf`
-  issue_table(tab_b, 0);
+  // per-lane inputs of an item: rows of the lane's line in the block and first row of the wave's slot ...
+  auto load_counts = [&](int it, unsigned &len_o, unsigned &row0_o) {
+    len_o = 0;
+    row0_o = 0;
+    if (it >= item_end) return;
+    const int bb = __builtin_amdgcn_readfirstlane(it / n_parts), pp = it - bb * n_parts;
+    const BlkRec *rp = blk_r + bb;
+    const int M1 = rp->M1;
+    const int sl = pp * kW + wave;
+    const int ln = 64 * sl + lane;
+    if (ln < M1) len_o = run_len[rp->lbase + ln];
+    row0_o = slot_row0[(size_t)bb * a.n_slots + sl];
+  };
+  // ... and the lane's own segment (endpoints and rays: the first 80 bytes of the record)
+  double2 e0, e1, e2, e3, e4;
+  auto load_seg = [&](int it) {
+    if (it >= item_end) return;
+    const int bb = __builtin_amdgcn_readfirstlane(it / n_parts), pp = it - bb * n_parts;
+    const BlkRec *rp = blk_r + bb;
+    const long long g1 = rp->g1;
+    const int M1 = rp->M1;
+    const int ln = 64 * (pp * kW + wave) + lane;
+    const double2 *p1 = reinterpret_cast<const double2 *>(a.segs + g1 + (ln < M1 ? ln : 0));
+    e0 = p1[0]; e1 = p1[1]; e2 = p1[2]; e3 = p1[3]; e4 = p1[4];
+  };
+  // rows: group g = iterations [g kRowAhead, (g + 1) kRowAhead); the rows of iteration j are adjacent in `tr`, the
+  // lane's one is the (number of lower lanes that still have a row)-th of them.  `base`: first row of iteration j0.
+  auto load_group = [&](unsigned ln_len, unsigned &base, unsigned j0, unsigned *dst) {
+#pragma unroll
+    for (int u = 0; u < kRowAhead; ++u) {
+      const bool act = j0 + (unsigned)u < ln_len;
+      const unsigned long long m = __ballot(act);
+      dst[u] = 0;
+      if (act) dst[u] = tr[base + (unsigned)__popcll(m & lanemask_lt())];
+      base += (unsigned)__popcll(m);
+    }
+  };
+  unsigned len, row0, len_n, row0_n;  // this item's / the next item's
+  unsigned nbq[kRowAhead];
+  unsigned base_first;
+  issue_table(__builtin_amdgcn_readfirstlane(item / n_parts));
+  load_counts(item, len, row0);
+  load_seg(item);
+  load_counts(item + 1, len_n, row0_n);
+  base_first = row0;
+  load_group(len, base_first, 0, nbq);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (; item < item_end; ++item) {
     const int b = __builtin_amdgcn_readfirstlane(item / n_parts), part = item - b * n_parts;
-    if (!kDbl && b != tab_b) {  // (uniform over the workgroup)
-      __syncthreads();  // the previous block's readers are done
-      issue_table(b, 0);
-      tab_b = b;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    int nb_blk = b;
-    if (kDbl && item + 1 < item_end) {
-      nb_blk = __builtin_amdgcn_readfirstlane((item + 1) / n_parts);
-      if (nb_blk != b) issue_table(nb_blk, buf ^ 1u);
-    }
-    const BlkRec *rec = blk_r + b;
-    const long long g1 = rec->g1, lbase = rec->lbase;
-    const int M1 = (int)(a.seg_off[rec->i1 + 1] - g1);
-    const int slot = part * kGateWaves + wave;
+    // (uniform over the workgroup) the block of the next item, -1: the table stays
+    const int nb_blk = (item + 1 < item_end && part == n_parts - 1) ? b + 1 : -1;
+    const int slot = part * kW + wave;
     const unsigned lin = (unsigned)b * (unsigned)a.n_slots + (unsigned)slot;
+#if LT_GATE_PRIO == 3
+    set_prio((int)(((wall_clock64() >> LT_GATE_SLICE_BIT) ^ (unsigned long long)wg_parity) & 1ull) + 1);
+#endif
     LT_TRACE_MARK(0, lin, 0);
     const int line = 64 * slot + lane;
-    const unsigned len = line < M1 ? run_len[lbase + line] : 0u;
-    const unsigned row0 = slot_row0[lin];
-    const unsigned maxlen = wave_max_u32(len);
-    unsigned total = 0;
+    const unsigned my_len = len, my_row0 = row0;
+    const unsigned maxlen = wave_max_u32(my_len);
+    unsigned pass_bits = 0, und_bits = 0;
+    unsigned k0 = 0, k1 = 0, k2 = 0, k3 = 0;  // neighbour lines of the lane's last kKeep survivors, 16 bits each
     if (maxlen > 0) {
-      // the lane's own segment: endpoints and rays (first 80 bytes of the record)
-      const double2 *p1 = reinterpret_cast<const double2 *>(a.segs + g1 + (line < M1 ? line : 0));
-      const double2 e0 = p1[0], e1 = p1[1], e2 = p1[2], e3 = p1[3], e4 = p1[4];
-      // first rows (the loads fly while the view-1 side is computed)
-      unsigned base = row0;
-      unsigned long long m_n = __ballot(0u < len);
-      unsigned nb_n = 0;
-      if (0u < len) nb_n = tr[base + (unsigned)__popcll(m_n & lanemask_lt())];
-      base += (unsigned)__popcll(m_n);
+      unsigned base = base_first;  // behind the first group (requested at the end of the previous item)
+      unsigned nbn[kRowAhead];
       double F[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) F[k] = pairs_r[b].F[k];
       const double d1x = e0.x - e1.x, d1y = e0.y - e1.y;
       const double q1 = __builtin_fma(d1x, d1x, d1y * d1y);
       const GateEpi ea = gate3_epi(F, e0.x, e0.y), eb = gate3_epi(F, e1.x, e1.y);
-      const unsigned char *T2 = smem_raw + (kDbl ? buf * tab_bytes : 0u);
-      unsigned pass_bits = 0, und_bits = 0;
-      for (unsigned j = 0; j < maxlen; ++j) {
-        const bool act = j < len;
-        const unsigned nbl = nb_n;
-        {  // next iteration's rows
-          const bool act_n = j + 1 < len;
-          m_n = __ballot(act_n);
-          if (act_n) nb_n = tr[base + (unsigned)__popcll(m_n & lanemask_lt())];
-          base += (unsigned)__popcll(m_n);
-        }
-        int res = 0;
-        if (act) {
-          const double2 *p2 = reinterpret_cast<const double2 *>(T2 + __umul24(nbl, (unsigned)sizeof(SegGate)));
-          const double2 h0 = p2[0], h1 = p2[1], h2 = p2[2], h3 = p2[3], h4 = p2[4];
-          res = gate3_core(cfg, q1, e2.x, e2.y, e3.x, e3.y, e4.x, e4.y, h0.x, h0.y, h1.x, h1.y, h2.x, h2.y, h3.x, h3.y,
-                           h4.x, h4.y, ea, eb);
-        }
-        pass_bits |= (res != 0 ? 1u : 0u) << j;
-        und_bits |= (res == 2 ? 1u : 0u) << j;
-      }
-      // survivor list of the slot, lane-major (= row order): offsets by a wave scan of the per-lane counts
-      const unsigned cnt = (unsigned)__popc(pass_bits);
-      unsigned incl = cnt;
+      for (unsigned j0 = 0; j0 < maxlen; j0 += kRowAhead) {
+#if LT_GATE_PRIO == 3
+        set_prio((int)(((wall_clock64() >> LT_GATE_SLICE_BIT) ^ (unsigned long long)wg_parity) & 1ull) + 1);
+#endif
+        if (j0 + kRowAhead < maxlen) load_group(my_len, base, j0 + kRowAhead, nbn);
 #pragma unroll
-      for (int s = 1; s < 64; s <<= 1) {
-        const unsigned o = (unsigned)__shfl_up((int)incl, s, 64);
-        if (lane >= s) incl += o;
+        for (int u = 0; u < kRowAhead; ++u) {
+          const unsigned j = j0 + (unsigned)u;
+          if (j < maxlen) {  // (uniform)
+            int res = 0;
+            if (j < my_len) {
+              const double2 *p2 = reinterpret_cast<const double2 *>(smem_raw + __umul24(nbq[u], (unsigned)sizeof(SegGate)));
+              const double2 h0 = p2[0], h1 = p2[1], h2 = p2[2], h3 = p2[3], h4 = p2[4];
+              res = gate3_core_fma(cfg, q1, e2.x, e2.y, e3.x, e3.y, e4.x, e4.y, h0.x, h0.y, h1.x, h1.y, h2.x, h2.y, h3.x,
+                                   h3.y, h4.x, h4.y, ea, eb);
+            }
+            if (res != 0) {
+              // 128-bit shift register of 16-bit entries: the newest survivor enters at the top
+              k0 = __builtin_amdgcn_alignbit(k1, k0, 16);
+              k1 = __builtin_amdgcn_alignbit(k2, k1, 16);
+              k2 = __builtin_amdgcn_alignbit(k3, k2, 16);
+              k3 = __builtin_amdgcn_alignbit(nbq[u], k3, 16);
+              pass_bits |= 1u << j;
+              und_bits |= (res == 2 ? 1u : 0u) << j;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kRowAhead; ++u) nbq[u] = nbn[u];
       }
-      total = (unsigned)__shfl((int)incl, 63, 64);
-      if (total > 0) {
-        unsigned dst = row0 + incl - cnt;
-        unsigned bs = row0;
+    }
+    LT_TRACE_MARK(0, lin, 1);
+    if (nb_blk >= 0) {
+      __syncthreads();  // nobody reads this block's table any more
+      issue_table(nb_blk);
+    }
+    // requests for the next items (see the header): first rows and segment of item + 1, counts of item + 2
+    base_first = row0_n;
+    load_group(len_n, base_first, 0, nbq);
+    load_seg(item + 1);
+    len = len_n;
+    row0 = row0_n;
+    load_counts(item + 2, len_n, row0_n);
+    // survivor list of the slot, lane-major (= row order): offsets by a wave scan of the per-lane counts
+    unsigned total = 0;
+    if (maxlen > 0) {
+      const unsigned cnt = (unsigned)__popc(pass_bits);
+      const unsigned incl = wave_incl_scan_u32(cnt);
+      total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+      const unsigned dst0 = my_row0 + incl - cnt;
+      if (__ballot(cnt > (unsigned)kKeep) == 0ull) {
+        // the register holds the survivors newest-first from the top: entry kKeep - 1 is the last one, kKeep - cnt the first
+        unsigned bits = pass_bits;
+#pragma unroll
+        for (int k = kKeep - 1; k >= 0; --k) {
+          const int back = kKeep - 1 - k;  // this entry is the (cnt - 1 - back)-th survivor
+          if ((unsigned)back < cnt) {
+            const unsigned j = 31u - (unsigned)__builtin_clz(bits);
+            bits &= ~(1u << j);
+            const unsigned w = k >= 6 ? k3 : (k >= 4 ? k2 : (k >= 2 ? k1 : k0));
+            const unsigned v = (k & 1) ? (w >> 16) : (w & 0xFFFFu);
+            st_row[dst0 + cnt - 1u - (unsigned)back] =
+                make_uint2((unsigned)line | (((und_bits >> j) & 1u) ? 0x80000000u : 0u), v);
+          }
+        }
+      } else if (total > 0) {
+        // some lane has more survivors than it keeps: replay the row positions and read the rows again
+        unsigned dst = dst0;
+        unsigned bs = my_row0;
         for (unsigned j = 0; j < maxlen; ++j) {
-          const bool act = j < len;
+          const bool act = j < my_len;
           const unsigned long long m = __ballot(act);
           if ((pass_bits >> j) & 1u) {
-            // (the row is re-read, cache-hot, rather than held in registers)
             const unsigned v = tr[bs + (unsigned)__popcll(m & lanemask_lt())];
-            a.st_row[dst++] = make_uint2((unsigned)line | (((und_bits >> j) & 1u) ? 0x80000000u : 0u), v);
+            st_row[dst++] = make_uint2((unsigned)line | (((und_bits >> j) & 1u) ? 0x80000000u : 0u), v);
           }
           bs += (unsigned)__popcll(m);
         }
       }
     }
     LT_TRACE_MARK(0, lin, 2);
-    if (lane == 0) a.surv_count[lin] = total;
-    if (kDbl && nb_blk != b) {
+    if (lane == 0) surv_count[lin] = total;
+    if (nb_blk >= 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next table has landed
-      __syncthreads();                                    // ... everybody's, and nobody reads this table any more
-      buf ^= 1u;
+      __syncthreads();                                    // ... and everybody's
     }
+    LT_TRACE_MARK(0, lin, 3);
   }
 }
 
@@ -1178,19 +1281,24 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   a.many_on = many_on; a.one_on = one_on;
   a.blk = reinterpret_cast<const BlkRec *>(blkrec); a.n_blk = n_blk;
   // persistent grid: as many workgroups as fit at once (registers allow 16 waves per CU)
-  const long long n_items = (long long)n_blk * (a.n_slots / kGateWaves);
-  // line-slot form: T2 only, twice while two workgroups per CU still fit (2 x 2 x 40 KB)
-  const bool ln_dbl = ln && (size_t)lds_segs * sizeof(SegGate) <= 40 * 1024;
-  const size_t lds = ln ? (size_t)lds_segs * sizeof(SegGate) * (ln_dbl ? 2 : 1) : (size_t)(lds_segs + lds_segs1) * sizeof(SegGate);
-  int per_cu = std::max(16 / kGateWaves, 1);
+  // line-slot form: T2 only; workgroups of four waves while four tables fit a CU, of eight beyond
+  const bool ln_w4 = ln && (size_t)lds_segs * sizeof(SegGate) <= 40 * 1024;
+  const int gate_waves = ln ? (ln_w4 ? 4 : 8) : kGateWaves;
+  const long long n_items = (long long)n_blk * (a.n_slots / gate_waves);
+  const size_t lds = ln ? (size_t)lds_segs * sizeof(SegGate) : (size_t)(lds_segs + lds_segs1) * sizeof(SegGate);
+  int per_cu = std::max(16 / gate_waves, 1);
   if (lds > 0) per_cu = (int)std::max<size_t>(std::min<size_t>(160 * 1024 / lds, (size_t)per_cu), 1);
   const unsigned n_wg = (unsigned)std::min<long long>(n_items, (long long)n_cu * per_cu);
   // the tables are sized by the largest image of the job, so "fits" is a per-launch property
-  const dim3 grid(n_wg), block(64 * kGateWaves);
+  const dim3 grid(n_wg), block(64 * gate_waves);
   if (ev3) (void)hipEventRecord(ev3[0], st);
   if (phase != 2 && ln) {
-    if (ln_dbl) hipLaunchKernelGGL((k_gates_ln<true>), grid, block, lds, st, a, cfg, a.blk, a.pairs, a.tr, a.run_len, a.slot_row0);
-    else hipLaunchKernelGGL((k_gates_ln<false>), grid, block, lds, st, a, cfg, a.blk, a.pairs, a.tr, a.run_len, a.slot_row0);
+    if (ln_w4)
+      hipLaunchKernelGGL((k_gates_ln<4>), grid, block, lds, st, a, cfg, a.blk, a.pairs, a.tr, a.run_len, a.slot_row0, a.st_row,
+                         a.surv_count);
+    else
+      hipLaunchKernelGGL((k_gates_ln<8>), grid, block, lds, st, a, cfg, a.blk, a.pairs, a.tr, a.run_len, a.slot_row0, a.st_row,
+                         a.surv_count);
   } else if (phase != 2) {
     if (lds_segs1 > 0 && lds_segs > 0) hipLaunchKernelGGL((k_gates<true, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
     else if (lds_segs > 0) hipLaunchKernelGGL((k_gates<false, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);

@@ -18,7 +18,10 @@ def child(mode, runs):
     from limap_amd import synthetic as syn, triangulation as tri
     ex = mode == "exhaustive"
     tri._pb = None  # the pybind shim links the in-tree library; everything here goes through ctypes into LIMAP_AMD_LIB
-    sc = syn.make_scene(n_views=100, n_segs=500, n_neighbors=20, seed=0)
+    if os.environ.get("AB_CONFIG3"):  # BASELINE config 3 (bench.py --config3)
+        sc = syn.make_scene(n_views=1000, n_segs=1000, n_neighbors=20, n_rooms=4, n_gt=3000, seed=1, topk=10)
+    else:
+        sc = syn.make_scene(n_views=100, n_segs=500, n_neighbors=20, seed=0)
     T = tri.GlobalLineTriangulator(syn.default_triangulation_cfg(debug_mode=True))
     T.SetRanges(sc.ranges)
     T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(j) for j in range(sc.n_images)])
