@@ -308,9 +308,17 @@ GenCfg make_gen(const lt_ctx *ctx) {
       const double sn = std::sin(ths * kPi / 180.0);
       g.sens_lo = sn * (1.0 - 1e-7);
       g.sens_hi = sn * (1.0 + 1e-7);
+      g.sens_lo2 = g.sens_lo * g.sens_lo * (1.0 - 1e-9);
+      g.sens_hi2 = g.sens_hi * g.sens_hi * (1.0 + 1e-9);
     } else {
       g.sens_lo = -1.0;   // the band covers everything: always the exact expression
       g.sens_hi = 1e300;
+      g.sens_lo2 = -1.0;
+      g.sens_hi2 = 1e300;
+    }
+    if (getenv("LT_TEST_NO_FAST_GATES")) {  // every candidate through the reference's form of the sensitivity test
+      g.sens_lo2 = -1.0;
+      g.sens_hi2 = 1e300;
     }
   }
   // `length <= min_length` skips the connection (base_line_triangulator.cc:166,177); length = sqrt(q)
@@ -558,7 +566,8 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_place_perm, &ctx->d_ex_rec, &ctx->d_ex_ent, &ctx->d_ex_z, &ctx->d_tile_list, &ctx->d_tail_keys, &ctx->d_tail_skeys, &ctx->d_tail_sims, &ctx->d_tail_mark,
                     &ctx->d_tail_pos, &ctx->d_tail_recs, &ctx->d_tail_nodes, &ctx->d_tail_tmp, &ctx->d_tail_keep,
                     &ctx->d_tail_kpos, &ctx->d_sp_slots, &ctx->d_sp_cnt, &ctx->d_sp_ovf, &ctx->d_sp_pairs, &ctx->d_sp_desc,
-                    &ctx->d_run_len, &ctx->d_slot_row0, &ctx->d_blk_nruns, &ctx->d_ln_flag};
+                    &ctx->d_run_len, &ctx->d_slot_row0, &ctx->d_blk_nruns, &ctx->d_ln_flag, &ctx->d_blk_surv, &ctx->d_blk_rnd0,
+                    &ctx->d_round_count};
   // (DevBuf releases itself when the context is deleted below; the list only makes the order explicit)
   lt_host::host_block_release(ctx->h_pinned_blk);
   lt_host::host_block_release(ctx->best_c_blk);

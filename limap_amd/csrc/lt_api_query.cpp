@@ -252,11 +252,13 @@ int lt_get_timers(lt_ctx *ctx, double out[24]) {
   ctx->timers[11] = (double)ctx->stat_pairs_eval;
   if (ctx->stat_survivors < 0) {
     ctx->stat_survivors = 0;
-    if (ctx->ran && ctx->job_mode == 1 && ctx->n_blk > 0 && ctx->max_rows > 0 && ctx->d_surv_count.p) {
-      const size_t n = (size_t)ctx->n_blk * (size_t)(ctx->rows_ln ? ctx->ln_slots : gen_slots(ctx->max_rows));
+    if (ctx->ran && ctx->job_mode == 1 && ctx->n_blk > 0 && ctx->max_rows > 0 && (ctx->d_surv_count.p || ctx->d_blk_surv.p)) {
+      // survivors per slot (row-slot form) or per block (line-slot form)
+      const bool ln = ctx->rows_ln && ctx->d_blk_surv.p;
+      const size_t n = ln ? (size_t)ctx->n_blk : (size_t)ctx->n_blk * (size_t)gen_slots(ctx->max_rows);
       std::vector<unsigned> sc(n);
       HIPCHK(ctx, hipSetDevice(ctx->device));
-      HIPCHK(ctx, hipMemcpy(sc.data(), ctx->d_surv_count.p, 4 * n, hipMemcpyDeviceToHost));
+      HIPCHK(ctx, hipMemcpy(sc.data(), ln ? ctx->d_blk_surv.p : ctx->d_surv_count.p, 4 * n, hipMemcpyDeviceToHost));
       long long tot = 0;
       for (unsigned v : sc) tot += v;
       ctx->stat_survivors = tot;

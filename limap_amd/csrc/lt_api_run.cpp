@@ -90,8 +90,11 @@ int lt_upload(lt_ctx *ctx) {
     // Line-slot form (k_gates_ln): every block compressed (sorted, lines contiguous), neighbour tables within the LDS.
     // Whether a run of equal line ids is longer than the kernel's outcome bits is only known on the device: the form is
     // built optimistically and its flag read with the sync at the end of the upload.
-    bool try_ln = ctx->rows_sorted && ctx->n_blk > 0 && ctx->P > 0 && ctx->max_nb_segs <= 1024 && !getenv("LT_GEN_ROW_SLOTS") &&
-                  !getenv("LT_GEN_NO_LDS_TABLE");
+    // (extra proposals -- VP, points -- yield a variable number of candidates per row: they keep the row-slot form)
+    const bool extras_cfg = (ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation) ||
+                            (ctx->pts_ready && (!ctx->cfg.disable_many_points_triangulation || !ctx->cfg.disable_one_point_triangulation));
+    bool try_ln = ctx->rows_sorted && ctx->n_blk > 0 && ctx->P > 0 && ctx->max_nb_segs <= 1024 && !extras_cfg &&
+                  !getenv("LT_GEN_ROW_SLOTS") && !getenv("LT_GEN_NO_LDS_TABLE");
     for (size_t cb = 0; try_ln && cb < ctx->h_ovf_off.size(); ++cb)
       if (ctx->h_ovf_off[cb] >= 0) try_ln = false;
     ctx->rows_ln = false;
@@ -109,6 +112,11 @@ int lt_upload(lt_ctx *ctx) {
                      ctx->d_blk_line_base.as<long long>(), ctx->d_base_bl.as<unsigned>(), ctx->d_blk_nruns.as<int>(),
                      ctx->d_run_len.as<unsigned>(), ctx->d_slot_row0.as<unsigned>(), ctx->d_m_pairs.as<unsigned short>(),
                      ctx->d_ln_flag.as<int>());
+      // a slot of round counts for every round a block could have
+      std::vector<unsigned> rnd0((size_t)ctx->n_blk + 1, 0u);
+      for (int bq = 0; bq < ctx->n_blk; ++bq) rnd0[(size_t)bq + 1] = rnd0[(size_t)bq] + (unsigned)((m_off[bq + 1] - m_off[bq] + 63) / 64);
+      ctx->n_round_slots = (long long)rnd0[(size_t)ctx->n_blk];
+      if ((rc = upload_vec(ctx, ctx->d_blk_rnd0, rnd0))) return rc;
       int flag = 0;
       HIPCHK(ctx, hipMemcpyAsync(&flag, ctx->d_ln_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -319,10 +327,12 @@ int lt_run_device_async(lt_ctx *ctx) {
   // + the staging counters of the one-pass exhaustive mode; all counters 128 bytes apart
   const int n_status = n_status_scan + score3_tile_buckets() * 16 + ex_regions() * 16;
   ENSURE(ctx, ctx->d_scan_status, 8 * (size_t)n_status);
+  const bool ln_job = ctx->job_mode == 1 && ctx->rows_ln && ctx->rows_sorted;
+  if (ln_job) ENSURE(ctx, ctx->d_blk_surv, 4 * (size_t)std::max(ctx->n_blk, 1));
   launch_build_pairs(st, ctx->n_blk, ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_cams.as<Cam>(),
                      ctx->d_pairs.as<PairRec>(), ctx->d_err.as<int>(),
                      ctx->d_pair_counter.as<unsigned long long>(), ctx->d_scan_status.as<unsigned long long>(),
-                     n_status);
+                     n_status, ln_job ? ctx->d_blk_surv.as<unsigned>() : nullptr);
 
   long long C_known = -1;  // candidate count once it is known on the host
   long long C_bound = 0;   // what sizes the compact arrays: the count, or an upper bound while it stays on the device
@@ -331,9 +341,21 @@ int lt_run_device_async(lt_ctx *ctx) {
   if (ctx->job_mode == 1) {
     const size_t Pn = (size_t)std::max<long long>(P, 1);
     const bool fast = ctx->rows_sorted;
+    {
+      // the line-slot form carries no extra proposals: if they were switched on after the upload, the rows go back to
+      // the row-slot form now
+      const bool vp_now = ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation;
+      const bool pts_now = ctx->pts_ready && (!ctx->cfg.disable_many_points_triangulation || !ctx->cfg.disable_one_point_triangulation);
+      if (ctx->rows_ln && (vp_now || pts_now)) {
+        launch_expand_rows(st, ctx->n_blk, ctx->d_rowdesc.p, ctx->d_c_stream.as<unsigned>(), ctx->d_ovf.as<unsigned>(),
+                           ctx->d_m_pairs.as<unsigned>());
+        ctx->rows_ln = false;
+      }
+    }
     const bool ln = ctx->rows_ln && fast;
     const int ln_slots = ln ? ctx->ln_slots : 0;
-    const long long n_waves = (long long)ctx->n_blk * (ln ? gen_groups_ln(ctx->max_own_segs) : gen_groups(ctx->max_rows));  // candidate lists
+    if (ln) ENSURE(ctx, ctx->d_round_count, 4 * (size_t)std::max<long long>(ctx->n_round_slots, 1));
+    const long long n_waves = (long long)ctx->n_blk * gen_groups(ctx->max_rows);  // candidate lists (row-slot form)
     const long long n_slots_all = (long long)ctx->n_blk * (ln ? ln_slots : gen_slots(ctx->max_rows));  // survivor lists
     const long long n_entries = ctx->h_blk_line_base[ctx->n_blk];
     // ---- generation in row order; valid candidates appended in row order to per-wave lists ----
@@ -353,7 +375,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     long long staged_total = -1;  // extras: candidates of the batch, known on the host after the counting run
     if (!extras) {
       ENSURE(ctx, ctx->d_st_c, sizeof(CRec) * Pn); ENSURE(ctx, ctx->d_st_l, sizeof(double) * Pn);
-      ENSURE(ctx, ctx->d_st_key, 4 * Pn);
+      ENSURE(ctx, ctx->d_st_key, 4 * (Pn + 64));  // (+ 64: k_place_rounds reads whole rounds)
     }
     ENSURE(ctx, ctx->d_wave_count, 4 * (size_t)(n_waves + 1));
     if (extras) ENSURE(ctx, ctx->d_wave_pos, 8 * (size_t)(n_waves + 1));
@@ -401,7 +423,8 @@ int lt_run_device_async(lt_ctx *ctx) {
                        pts_on ? ctx->d_seg_pt_off.as<long long>() : nullptr, pts_on ? ctx->d_seg_pts.p : nullptr,
                        (pts_on && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr, ctx->d_err.as<int>(),
                        many_on ? 1 : 0, one_on ? 1 : 0, group_base, phase, ln_slots, ctx->d_m_pairs.as<unsigned short>(),
-                       ctx->d_run_len.as<unsigned>(), ctx->d_slot_row0.as<unsigned>());
+                       ctx->d_run_len.as<unsigned>(), ctx->d_slot_row0.as<unsigned>(), ctx->d_blk_surv.as<unsigned>(),
+                       ctx->d_blk_rnd0.as<unsigned>(), ctx->d_round_count.as<unsigned>());
       };
       if (!extras) {
         gen(0);
@@ -505,7 +528,8 @@ int lt_run_device_async(lt_ctx *ctx) {
                    ctx->d_base_bl.as<unsigned>(), ctx->d_wave_count.as<unsigned>(), ctx->d_tri_off.as<long long>(),
                    ctx->d_st_c.as<CRec>(), ctx->d_st_l.as<double>(), ctx->d_st_key.as<unsigned>(),
                    ctx->d_cand.as<CRec>(), ctx->d_lite.as<double>(), ctx->d_cand_node.as<unsigned>(), group_base,
-                   perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr, ln_slots, ctx->d_slot_row0.as<unsigned>());
+                   perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr, ctx->d_blk_surv.as<unsigned>(),
+                   ctx->d_blk_rnd0.as<unsigned>(), ln ? ctx->d_round_count.as<unsigned>() : nullptr);
     } else {
       ENSURE(ctx, ctx->d_keys, 4 * Cn); ENSURE(ctx, ctx->d_rows, 4 * Cn);
       ENSURE(ctx, ctx->d_skeys, 4 * Cn); ENSURE(ctx, ctx->d_srows, 4 * Cn);

@@ -223,6 +223,10 @@ struct lt_ctx {
   bool rows_ln = false;
   int ln_slots = 0;          // line slots per block (gen_slots_ln)
   DevBuf d_run_len, d_slot_row0, d_blk_nruns, d_ln_flag;
+  // ... with stage B in rounds of 64 survivors of a block's dense survivor list (k_tri_rounds): survivors per block
+  // (k_gates_ln's cursors), first round slot of every block (exclusive sum of ceil(rows / 64)), candidates per round
+  DevBuf d_blk_surv, d_blk_rnd0, d_round_count;
+  long long n_round_slots = 0;
   lt_host::HostBlock h_pinned_blk;
   long long *h_pinned = nullptr;  // pinned scratch for small device->host scalars
   DevBuf d_chunks, d_cand_meta, d_st_row, d_surv_count, d_seg_gates, d_blkrec, d_seg_vp, d_seg_has_vp;

@@ -368,6 +368,27 @@ static __device__ __forceinline__ int gate3(const GenCfg &cfg, double a1x, doubl
   return gate3_core(cfg, q1, rs1x, rs1y, rs1z, re1x, re1y, re1z, n2x, n2y, n2z, lcx, lcy, P, Q, w1, sv, q2, ea, eb);
 }
 
+// Three-way form of `line.sensitivity(view) > sens_th` without a division or a square root: with b = Minv (mid, 1) the
+// reference's |dir . unit(b)| is sqrt((dir . b)^2 / |b|^2), so the cosine-domain band of sensitivity_gt becomes
+// (dir . b)^2 against sens_{lo,hi}^2 |b|^2.  The two perspective divisions of the projected endpoints use a refined
+// reciprocal (not IEEE: ~1e-16 relative, against a band of 1e-7 + 1e-9).  1: certainly greater, 0: certainly not,
+// 2: inside the band (or not finite) -- sensitivity_gt, the reference's arithmetic, decides.  The exact form costs
+// 7 IEEE divisions and a square root per view, a third of gen_finish's instructions.
+static __device__ __forceinline__ int sensitivity3(const GenCfg &cfg, const Cam &c, d3 s, d3 e, d3 dir3) {
+  d3 vs = mv(c.R, s), ve = mv(c.R, e);
+  vs.x += c.t[0]; vs.y += c.t[1]; vs.z += c.t[2];
+  ve.x += c.t[0]; ve.y += c.t[1]; ve.z += c.t[2];
+  const double rs = fast_rcp(vs.z + kEps), re = fast_rcp(ve.z + kEps);
+  const double mx = 0.5 * (__builtin_fma(c.fx, vs.x, c.cx * vs.z) * rs + __builtin_fma(c.fx, ve.x, c.cx * ve.z) * re);
+  const double my = 0.5 * (__builtin_fma(c.fy, vs.y, c.cy * vs.z) * rs + __builtin_fma(c.fy, ve.y, c.cy * ve.z) * re);
+  const d3 b = cam_backproject(c, d2{mx, my});
+  const double db = dot(dir3, b);
+  const double dd = db * db, bb = dot(b, b);
+  if (dd > cfg.sens_hi2 * bb) return 1;
+  if (dd < cfg.sens_lo2 * bb) return 0;
+  return 2;
+}
+
 // Stage B: triangulation, cheirality, sensitivity gate, uncertainty, ranges (:309-333).
 static __device__ __forceinline__ bool gen_finish(const GenCfg &cfg, const Cam &c1, const Cam &c2,
                                                   const Seg &s1, const Seg &s2, const double *Bv,
@@ -389,8 +410,18 @@ static __device__ __forceinline__ bool gen_finish(const GenCfg &cfg, const Cam &
   }
   d3 dir3 = unit(sub(pe, ps));
   // sensitivity gate (:315-317): rejected only if too sensitive in BOTH views
-  if (sensitivity_gt(cfg, c1, ps, pe, dir3) && sensitivity_gt(cfg, c2, ps, pe, dir3))
-    return false;
+  {
+    const int g1 = sensitivity3(cfg, c1, ps, pe, dir3);
+    if (g1 != 0) {
+      const int g2 = sensitivity3(cfg, c2, ps, pe, dir3);
+      if (g2 != 0) {
+        if (g1 == 1 && g2 == 1) return false;
+        // inside a band: the reference's arithmetic for whichever view could not decide
+        const bool t1 = g1 == 1 || sensitivity_gt(cfg, c1, ps, pe, dir3);
+        if (t1 && (g2 == 1 || sensitivity_gt(cfg, c2, ps, pe, dir3))) return false;
+      }
+    }
+  }
   // uncertainty (:319-321; linebase.cc:109-116; camera.cc:228-242)
   double u1 = cfg.var2d * ((z_start + z_end) / 2.0) / c1.f;
   double u2 = cfg.var2d * ((d21 + d22) / 2.0) / c2.f;

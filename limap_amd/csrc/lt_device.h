@@ -26,7 +26,7 @@ void launch_build_segs(hipStream_t st, long long n_segs, int n_img, const long l
                        const double *segs, double halfpix, const Cam *cams, Seg *out, void *gates);
 void launch_build_pairs(hipStream_t st, int n_blk, const int *blk_img, const int *blk_nb, const Cam *cams,
                         PairRec *out, int *err_flag, unsigned long long *pair_counter,
-                        unsigned long long *scan_status, int n_status);
+                        unsigned long long *scan_status, int n_status, unsigned *blk_surv);
 size_t sort_temp_bytes(long long P, int end_bit);
 int launch_sort(hipStream_t st, void *temp, size_t temp_bytes, long long P, const unsigned *keys_in,
                 unsigned *keys_out, const unsigned *vals_in, unsigned *vals_out, int end_bit);

@@ -290,6 +290,9 @@ struct GenCfg {
   // cosine-domain guards of the sensitivity gate: sensitivity > sens_th  <=>  |dir . ray| > sin(sens_th) up to
   // libm rounding; outside [sens_lo, sens_hi] the cosine decides, inside the exact expression does
   double sens_lo, sens_hi;
+  // the same band in the squared-cosine domain with a further 1e-9 on either side, for the division-free form
+  // sensitivity3 (lt_devfn.h): (dir . b)^2 against these x |b|^2
+  double sens_lo2, sens_hi2;
 };
 struct ScoreCfg {
   LinkCfg2 l2;

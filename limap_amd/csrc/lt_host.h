@@ -29,7 +29,6 @@ void launch_fn_query(hipStream_t st, const double *in30, int by_endpoints, doubl
 int gen_slots(long long max_rows);
 int gen_groups(long long max_rows);
 int gen_slots_ln(int max_own_segs);
-int gen_groups_ln(int max_own_segs);
 int gen_max_run();
 void launch_rows_ln(hipStream_t st, int n_blk, int n_slots, const void *desc, const unsigned *stream,
                     const long long *blk_line_base, unsigned *rstart, int *blk_nruns, unsigned *run_len,
@@ -47,7 +46,8 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const double *seg_vp, const unsigned char *seg_has_vp, const long long *seg_pt_off,
                       const void *seg_pts, const double *sfm_xyz, int *err_flag, int many_on, int one_on,
                       const long long *group_base, int phase, int ln_slots, const unsigned short *tr,
-                      const unsigned *run_len, const unsigned *slot_row0);
+                      const unsigned *run_len, const unsigned *slot_row0, unsigned *blk_surv, const unsigned *blk_rnd0,
+                      unsigned *round_count);
 size_t seg_point_bytes();
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
@@ -58,7 +58,7 @@ void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const CRec *st_r, const double *st_unc,
                   const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, const long long *group_base,
-                  unsigned *perm, int ln_slots, const unsigned *slot_row0);
+                  unsigned *perm, const unsigned *blk_surv, const unsigned *blk_rnd0, const unsigned *round_count);
 void launch_pack_keys(hipStream_t st, int n_blk, long long max_rows, const long long *m_off,
                       const unsigned *wave_count, const long long *wave_pos, const unsigned *st_key,
                       unsigned *keys_c, unsigned *src_c, const long long *group_base);

@@ -140,9 +140,11 @@ __global__ void k_build_pairs(int n_blk, const int *__restrict__ blk_img,
                               const int *__restrict__ blk_nb, const Cam *__restrict__ cams,
                               PairRec *__restrict__ out, int *__restrict__ err_flag,
                               unsigned long long *__restrict__ pair_counter,
-                              unsigned long long *__restrict__ scan_status, int n_status) {
+                              unsigned long long *__restrict__ scan_status, int n_status,
+                              unsigned *__restrict__ blk_surv) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   for (int k = b; k < n_status; k += gridDim.x * blockDim.x) scan_status[k] = 0ull;  // k_node_prefix's look-back
+  if (blk_surv && b < n_blk) blk_surv[b] = 0u;  // k_gates_ln's survivor cursors
   if (b == 0) {
     if (err_flag) *err_flag = 0;
     if (pair_counter) *pair_counter = 0ull;
@@ -991,9 +993,9 @@ void launch_build_scene_chunked(hipStream_t st, int n_img, long long n_segs, int
 }
 void launch_build_pairs(hipStream_t st, int n_blk, const int *blk_img, const int *blk_nb, const Cam *cams,
                         PairRec *out, int *err_flag, unsigned long long *pair_counter,
-                        unsigned long long *scan_status, int n_status) {
+                        unsigned long long *scan_status, int n_status, unsigned *blk_surv) {
   hipLaunchKernelGGL(k_build_pairs, dim3(nblk(std::max(n_blk, 1), 128)), dim3(128), 0, st, n_blk, blk_img, blk_nb, cams,
-                     out, err_flag, pair_counter, scan_status, n_status);
+                     out, err_flag, pair_counter, scan_status, n_status, blk_surv);
 }
 size_t sort_temp_bytes(long long P, int end_bit) {
   size_t bytes = 0;

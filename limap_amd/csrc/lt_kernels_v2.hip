@@ -392,13 +392,12 @@ k_gates(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *
 //     barrier per block instead of two around a register-staged copy that nothing overlapped;
 //   * a row is 16 bits (the neighbour line; the line is the lane): k_rows_transpose stores the rows of a slot in
 //     (rank within the run, line) order, so the rows a wave needs in iteration j are adjacent -- 128 bytes per load.
-// Slots are line ranges here (slot s = lines [64 s, 64 s + 64) of the image), their survivor lists start at the slot's
-// first row (slot_row0) and are ordered lane-major = row order, as stage B and the placement need them.
+// Slots are line ranges here (slot s = lines [64 s, 64 s + 64) of the image); a slot's survivors, ordered lane-major = row
+// order, are appended to the block's dense survivor list (stage B: k_tri_rounds).
 // Requirements (lt_upload decides; otherwise the row-slot form k_gates runs): every block compressed, no run longer than
 // kMaxRun rows (one outcome bit per row and lane), the neighbour tables within the LDS.
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxRun = 32;
-constexpr int kLnTriSlots = 2;  // stage B / placement: groups of two line slots (~1 280 rows at top-10)
 
 // Pass 1 over a compressed block: first row of every run (= line) of the block -> rstart[(block, line)], number of runs.
 __global__ void __launch_bounds__(256)
@@ -492,12 +491,10 @@ k_rows_transpose(int n_blk, int n_slots, const RowDesc *__restrict__ desc, const
 
 // s_setprio takes an immediate
 static __device__ __forceinline__ void set_prio(int p) {  // p: wave-uniform, 0..3
-#if LT_GATE_PRIO != 0
   if (p >= 3) __builtin_amdgcn_s_setprio(3);
   else if (p == 2) __builtin_amdgcn_s_setprio(2);
   else if (p == 1) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
-#endif
 }
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -539,7 +536,7 @@ template <int kW>
 __global__ void __launch_bounds__(64 * kW) LT_GATE_OCC
 k_gates_ln(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *__restrict__ pairs_r,
            const unsigned short *__restrict__ tr, const unsigned *__restrict__ run_len,
-           const unsigned *__restrict__ slot_row0, uint2 *__restrict__ st_row, unsigned *__restrict__ surv_count) {
+           const unsigned *__restrict__ slot_row0, uint2 *__restrict__ st_row, unsigned *__restrict__ blk_surv) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
@@ -681,7 +678,13 @@ k_gates_ln(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRe
       const unsigned cnt = (unsigned)__popc(pass_bits);
       const unsigned incl = wave_incl_scan_u32(cnt);
       total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-      const unsigned dst0 = my_row0 + incl - cnt;
+      // The block's survivors form ONE dense list from its first row on (stage B cuts it into rounds of 64): the slot's
+      // piece goes where the block's cursor stands.  The pieces of a block land in the order the waves get there --
+      // that is fine: a (block, line) run lies inside one piece, and nothing downstream depends on the order of runs.
+      unsigned off = 0;
+      if (total > 0 && lane == 0) off = atomicAdd(&blk_surv[b], total);
+      off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+      const unsigned dst0 = (unsigned)blk_r[b].rb + off + incl - cnt;
       if (__ballot(cnt > (unsigned)kKeep) == 0ull) {
         // the register holds the survivors newest-first from the top: entry kKeep - 1 is the last one, kKeep - cnt the first
         unsigned bits = pass_bits;
@@ -713,7 +716,6 @@ k_gates_ln(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRe
       }
     }
     LT_TRACE_MARK(0, lin, 2);
-    if (lane == 0) surv_count[lin] = total;
     if (nb_blk >= 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next table has landed
       __syncthreads();                                    // ... and everybody's
@@ -728,7 +730,7 @@ k_gates_ln(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRe
 // connection the candidates in the reference's order many-points, one-point (one per shared point),
 // vp(l1), vp(l2), algebraic.  Which
 // of them are active is a run-time property (a.seg_pts / a.seg_vp may be null).
-// kTS: slots per group (kTriSlots row slots, or kLnTriSlots line slots -- GenArgs::slot_row0)
+// kTS: slots per group
 template <bool kExtra, int kTS>
 __global__ void __launch_bounds__(64 * kTriWaves)
 k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec *__restrict__ pairs_r,
@@ -763,6 +765,9 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
     cs[k + 1] = cs[k] + a.surv_count[(size_t)b * a.n_slots + (size_t)g * kTS + k];
   const unsigned n_s = cs[kTS];
   unsigned wcount = 0;
+#ifdef LT_TRACE
+  if (n_s > 0) LT_TRACE_MARK(1, lin, 1);
+#endif
   for (unsigned e0 = 0; e0 < n_s; e0 += 64) {
     const unsigned e = e0 + lane;
     bool ok = false;
@@ -931,9 +936,184 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
       wave_lds_sync();
     }
     wcount += total;
+#ifdef LT_TRACE
+    if (e0 == 0) LT_TRACE_MARK(1, lin, 3);
+#endif
   }
   LT_TRACE_MARK(1, lin, 2);
   if (lane == 0) a.wave_count[lin] = wcount;
+}
+
+#ifndef LT_TRI_PRIO
+#define LT_TRI_PRIO 0
+#endif
+#ifndef LT_TRI_SLICE_BIT
+#define LT_TRI_SLICE_BIT 9
+#endif
+// Stage B of the line-slot form: the survivors of block b are ONE dense list st_row[rb ...] of blk_surv[b] entries
+// (k_gates_ln); round r = its entries [64 r, 64 r + 64), one wave per round, every round but a block's last one full
+// (groups of slots ran three rounds for ~140 survivors: 73 % of the lanes).  The valid candidates of a round go, compacted
+// and in list order, to st_*[rb + 64 r ...]; round_count[blk_rnd0[b] + r] holds their number (blk_rnd0: exclusive sum of
+// ceil(rows / 64) over the blocks -- a slot for every round a block could have).
+// Persistent workgroups (as many as are resident at once): a round is ~5 us of a wave, and one short-lived wave per round
+// -- 18 000 of them, in 8 000 workgroups -- was bound by the rate at which workgroups can be launched (trace: 2 000-2 500
+// of 4 096 wave slots occupied).  Workgroup g takes blocks g, g + gridDim.x, ...; its kTriWaves waves share the rounds
+// of a block (round r goes to wave (r - b) mod kTriWaves, so that the first rounds do not all land on wave 0) and move on
+// to the next block independently of each other.
+__global__ void __launch_bounds__(64 * kTriWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_tri_rounds(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec *__restrict__ pairs_r,
+             const BlkRec *__restrict__ blk_r, const unsigned *__restrict__ blk_surv, const unsigned *__restrict__ blk_rnd0,
+             unsigned *__restrict__ round_count) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];  // per wave: 64 x (CRec | unc | key)
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  for (int b = (int)blockIdx.x; b < a.n_blk; b += (int)gridDim.x) {
+  const int x = (wave + b) % kTriWaves;
+  const unsigned n_s = blk_surv[b];
+  const int n_rounds = (int)((n_s + 63u) >> 6);
+  if (x >= n_rounds) continue;
+  const BlkRec *rec = blk_r + b;
+  const long long rb = rec->rb;
+  const unsigned rnd0 = blk_rnd0[b];
+  const int i1 = rec->i1, i2 = rec->i2, nbslot = rec->nbslot;
+  const long long g1 = rec->g1, g2 = rec->g2;
+  const PairRec *pr = pairs_r + b;
+  const long long lbase = rec->lbase;
+  for (int r = x; r < n_rounds; r += kTriWaves) {
+    LT_TRACE_MARK(1, rnd0 + (unsigned)r, 0);
+#if LT_TRI_PRIO
+    // (as in k_gates_ln: the four workgroups of a CU take turns at being served first)
+    set_prio((int)(((wall_clock64() >> LT_TRI_SLICE_BIT) + (unsigned long long)(4u * blockIdx.x / gridDim.x)) & 3ull));
+#endif
+    const unsigned e = 64u * (unsigned)r + (unsigned)lane;
+    bool ok = false;
+    GenOut o;
+    int line = 0;
+    if (e < n_s) {
+      const uint2 u = a.st_row[rb + e];
+      line = (int)(u.x & 0x7FFFFFFFu);
+      const int ng = (int)u.y;
+#ifdef LT_TRACE
+      if (line >= 0) LT_TRACE_MARK(1, rnd0 + (unsigned)r, 1);
+#endif
+      const Seg &s1 = a.segs[g1 + line];
+      const Seg &s2 = a.segs[g2 + ng];
+      ok = true;
+      if (u.x >> 31) ok = gen_gates(cfg, s1, s2, pr->F);  // the cheap gates could not decide
+      if (ok) ok = gen_finish(cfg, cams_r[i1], cams_r[i2], s1, s2, pr->B, &o);
+      o.r.nb_slot = lite_pack(nbslot, i2);
+      o.r.ng_line = ng;
+    }
+    LT_TRACE_MARK(1, rnd0 + (unsigned)r, 3);
+    const unsigned long long m = __ballot(ok);
+    const unsigned below = (unsigned)__popcll(m & lanemask_lt());
+    const unsigned total = (unsigned)__popcll(m);
+    // The round's valid candidates go to a contiguous piece: compact them through LDS and write the piece with
+    // consecutive lanes on consecutive 16-byte units (a record-per-lane store touches 64 cache lines per instruction).
+    static_assert(sizeof(CRec) == 8 * 16, "record size in 16-byte units");
+    double2 *Lc = reinterpret_cast<double2 *>(smem_raw) + (size_t)wave * (64 * 9 + 16);
+    double *Lu = reinterpret_cast<double *>(Lc + 64 * 8);
+    unsigned *Lk = reinterpret_cast<unsigned *>(Lu + 64);
+    if (ok) {
+      const double2 *oc = reinterpret_cast<const double2 *>(&o.r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) Lc[below * 8 + k] = oc[k];
+      Lu[below] = o.unc;
+      Lk[below] = (unsigned)(g1 + line);
+      atomicAdd(&a.cnt_bl[lbase + line], 1u);  // valid candidates per (block, line): the placement's prefixes
+    }
+    wave_lds_sync();
+    const long long p0 = rb + 64ll * r;
+    double2 *dc = reinterpret_cast<double2 *>(a.st_r + p0);
+    for (unsigned u = lane; u < total * 8u; u += 64) dc[u] = Lc[u];
+    if ((unsigned)lane < total) {
+      a.st_unc[p0 + lane] = Lu[lane];
+      a.st_key[p0 + lane] = Lk[lane];
+    }
+    if (lane == 0) round_count[rnd0 + (unsigned)r] = total;
+    wave_lds_sync();
+    LT_TRACE_MARK(1, rnd0 + (unsigned)r, 2);
+  }
+  }
+}
+
+// Placement for the round lists of k_tri_rounds: as k_place, one wave per round; a (block, line) run that begins in an
+// earlier round of the block is followed back through the previous rounds' lists.
+__global__ void __launch_bounds__(256)
+k_place_rounds(const long long *__restrict__ m_off, const int *__restrict__ blk_img, const long long *__restrict__ seg_off,
+               const long long *__restrict__ blk_line_base, const unsigned *__restrict__ base_bl,
+               const long long *__restrict__ tri_off, const CRec *__restrict__ st_r, const double *__restrict__ st_unc,
+               const unsigned *__restrict__ st_key, CRec *__restrict__ cand, double *__restrict__ cand_unc,
+               unsigned *__restrict__ cand_node, unsigned *__restrict__ perm, const unsigned *__restrict__ blk_surv,
+               const unsigned *__restrict__ blk_rnd0, const unsigned *__restrict__ round_count, int n_blk) {
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  for (int b = (int)blockIdx.x; b < n_blk; b += (int)gridDim.x) {  // persistent, as k_tri_rounds
+  const int x = (wave + b) & 3;
+  const int n_rounds = (int)((blk_surv[b] + 63u) >> 6);
+  if (x >= n_rounds) continue;
+  const long long rb = m_off[b];
+  const unsigned rnd0 = blk_rnd0[b];
+  const long long g1 = seg_off[blk_img[b]];
+  const long long lbase = blk_line_base[b];
+  // (the count and the keys of the wave's next round are requested before this round's dependent loads: the kernel is a
+  // chain of small loads -- count -> keys -> offsets -- and the next round's first two links cost nothing this way; the key
+  // array has 64 entries of slack behind the last row)
+  unsigned count_n = round_count[rnd0 + (unsigned)x];
+  unsigned key_n = st_key[rb + 64ll * x + lane];
+  for (int r = x; r < n_rounds; r += 4) {
+    const unsigned count = count_n;
+    const unsigned key_raw = key_n;
+    if (r + 4 < n_rounds) {
+      count_n = round_count[rnd0 + (unsigned)(r + 4)];
+      key_n = st_key[rb + 64ll * (r + 4) + lane];
+    }
+    if (count == 0) continue;
+    const long long s0 = rb + 64ll * r;
+    const bool act = (unsigned)lane < count;
+    // rank within the (block, line) run: inside the list the distance to the run's first lane (ballot of the run heads);
+    // the run that reaches back beyond the list is followed through the earlier rounds (wave-uniform)
+    const unsigned key = act ? key_raw : 0xFFFFFFFFu;
+    const unsigned prev = (unsigned)__shfl_up((int)key, 1);
+    const bool head = act && (lane == 0 || key != prev);
+    const unsigned long long heads = __ballot(head);
+    const int my_head = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull) | 1ull);
+    const unsigned key0 = (unsigned)__builtin_amdgcn_readfirstlane((int)key);
+    unsigned carry = 0;
+    for (int pr_ = r - 1; pr_ >= 0; --pr_) {
+      const unsigned pc = round_count[rnd0 + (unsigned)pr_];
+      // an empty list cannot tell whether the run continues further back: keep walking (bounded by the block)
+      if (pc == 0) continue;
+      const long long j = (long long)pc - 64 + lane;  // the list's last 64 (all of its) entries, lane 63 = the last one
+      const bool valid = j >= 0;
+      const unsigned k = valid ? st_key[rb + 64ll * pr_ + j] : 0u;
+      const unsigned long long m = __ballot(valid && k == key0);
+      const unsigned lead = m == ~0ull ? 64u : (unsigned)__builtin_clzll(~m);
+      carry += lead;
+      if (lead < pc) break;  // a different key precedes: the run starts here
+    }
+    unsigned pos32 = 0;
+    if (act) {
+      const unsigned rank = (unsigned)(lane - my_head) + (my_head == 0 ? carry : 0u);
+      const long long pos = tri_off[key] + base_bl[lbase + (long long)(key - g1)] + rank;
+      pos32 = (unsigned)pos;  // candidate positions fit 32 bits (cand_node / tri counts are 32-bit)
+      cand_node[pos] = key;
+      if (perm) perm[pos] = (unsigned)(s0 + lane);
+    }
+    if (perm) continue;
+    // (LT_TEST_PLACE_COPY) cooperative copy in 16-byte units, see k_place
+    const double2 *src_c = reinterpret_cast<const double2 *>(st_r + s0);
+    double2 *dst_c = reinterpret_cast<double2 *>(cand);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const unsigned u = (unsigned)it * 64u + (unsigned)lane;
+      const unsigned ci = u >> 3, piece = u & 7u;
+      const unsigned p = (unsigned)__shfl((int)pos32, (int)ci);
+      if (u < count * 8u) dst_c[(size_t)p * 8u + piece] = src_c[u];
+    }
+    if (act) cand_unc[pos32] = st_unc[s0 + lane];
+  }
+  }
 }
 
 // Fast path: exclusive prefix of cnt_bl over the neighbour blocks of every node (into base_bl) and the
@@ -1201,12 +1381,11 @@ int gen_slots(long long max_rows) {
 }
 // groups per block (lists of stage B / placement): wave_count[] has n_blk * gen_groups entries
 int gen_groups(long long max_rows) { return gen_slots(max_rows) / kTriSlots; }
-// the same for the line-slot form: slots of 64 lines of the image, groups of kLnTriSlots slots
+// the line-slot form: slots of 64 lines of the image
 int gen_slots_ln(int max_own_segs) {
   int n = (max_own_segs + 63) / 64;
   return std::max((n + kGateWaves - 1) / kGateWaves * kGateWaves, kGateWaves);
 }
-int gen_groups_ln(int max_own_segs) { return gen_slots_ln(max_own_segs) / kLnTriSlots; }
 int gen_max_run() { return kMaxRun; }
 // the line-slot form of the staged rows (lt_upload): run starts, then run lengths / slot starts / transposed rows
 void launch_rows_ln(hipStream_t st, int n_blk, int n_slots, const void *desc, const unsigned *stream,
@@ -1250,8 +1429,10 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const double *seg_vp, const unsigned char *seg_has_vp, const long long *seg_pt_off,
                       const void *seg_pts, const double *sfm_xyz, int *err_flag, int many_on, int one_on,
                       const long long *group_base, int phase, int ln_slots, const unsigned short *tr,
-                      const unsigned *run_len, const unsigned *slot_row0) {
-  // ln_slots > 0: the line-slot form (k_gates_ln; slots per block = ln_slots, tables tr / run_len / slot_row0)
+                      const unsigned *run_len, const unsigned *slot_row0, unsigned *blk_surv, const unsigned *blk_rnd0,
+                      unsigned *round_count) {
+  // ln_slots > 0: the line-slot form (k_gates_ln; slots per block = ln_slots, tables tr / run_len / slot_row0) with
+  // stage B in rounds of 64 survivors (k_tri_rounds; no extra proposals in this form)
   // phase 0: k_gates + k_tri_rows (no extra proposals).  Extra proposals: phase 1 = k_gates + the COUNTING run of
   // k_tri_rows (wave_count only), phase 2 = the storing run at group_base (the scanned counts), see GenArgs
   if (n_blk <= 0 || max_rows <= 0) return;
@@ -1295,10 +1476,10 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   if (phase != 2 && ln) {
     if (ln_w4)
       hipLaunchKernelGGL((k_gates_ln<4>), grid, block, lds, st, a, cfg, a.blk, a.pairs, a.tr, a.run_len, a.slot_row0, a.st_row,
-                         a.surv_count);
+                         blk_surv);
     else
       hipLaunchKernelGGL((k_gates_ln<8>), grid, block, lds, st, a, cfg, a.blk, a.pairs, a.tr, a.run_len, a.slot_row0, a.st_row,
-                         a.surv_count);
+                         blk_surv);
   } else if (phase != 2) {
     if (lds_segs1 > 0 && lds_segs > 0) hipLaunchKernelGGL((k_gates<true, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
     else if (lds_segs > 0) hipLaunchKernelGGL((k_gates<false, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
@@ -1308,12 +1489,10 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   if (ev3) (void)hipEventRecord(ev3[1], st);
   const size_t tri_lds = kTriWaves * (64 * 9 + 16) * sizeof(double2);
   if (ln) {
-    const dim3 tg(nblk2(a.n_slots / kLnTriSlots, kTriWaves), n_blk);
-    if (extra)
-      hipLaunchKernelGGL((k_tri_rows<true, kLnTriSlots>), tg, dim3(64 * kTriWaves), 0, st, a, cfg, a.cams, a.pairs, a.blk, a.slot_row0);
-    else
-      hipLaunchKernelGGL((k_tri_rows<false, kLnTriSlots>), tg, dim3(64 * kTriWaves), tri_lds, st, a, cfg, a.cams, a.pairs, a.blk,
-                         a.slot_row0);
+    // persistent: the workgroups that are resident at once (16 waves per CU: registers and LDS)
+    const dim3 tg((unsigned)std::min<long long>(n_blk, (long long)n_cu * (16 / kTriWaves)));
+    hipLaunchKernelGGL(k_tri_rounds, tg, dim3(64 * kTriWaves), tri_lds, st, a, cfg, a.cams, a.pairs, a.blk, blk_surv, blk_rnd0,
+                       round_count);
   } else {
     const dim3 tg(nblk2(a.n_slots / kTriSlots, kTriWaves), n_blk);
     if (extra)
@@ -1335,13 +1514,19 @@ void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
                   const unsigned *wave_count, const long long *tri_off, const CRec *st_r, const double *st_unc,
                   const unsigned *st_key, CRec *cand, double *cand_unc, unsigned *cand_node, const long long *group_base,
-                  unsigned *perm, int ln_slots, const unsigned *slot_row0) {
+                  unsigned *perm, const unsigned *blk_surv, const unsigned *blk_rnd0, const unsigned *round_count) {
   if (n_blk <= 0 || max_rows <= 0) return;
-  if (ln_slots > 0) {
-    const int n_groups = ln_slots / kLnTriSlots;
-    hipLaunchKernelGGL(k_place<kLnTriSlots>, dim3(nblk2(n_groups, 4), n_blk), dim3(256), 0, st, m_off, blk_img, seg_off,
-                       blk_line_base, base_bl, wave_count, tri_off, st_r, st_unc, st_key, cand, cand_unc, cand_node, n_groups,
-                       group_base, perm, slot_row0);
+  if (round_count) {  // the line-slot form: candidate lists per round of 64 survivors
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    }
+    hipLaunchKernelGGL(k_place_rounds, dim3((unsigned)std::min<long long>(n_blk, (long long)n_cu * 8)), dim3(256), 0, st, m_off,
+                       blk_img, seg_off, blk_line_base, base_bl, tri_off, st_r, st_unc, st_key, cand, cand_unc, cand_node, perm,
+                       blk_surv, blk_rnd0, round_count, n_blk);
     return;
   }
   const int n_groups = gen_groups(max_rows);
