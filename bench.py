@@ -287,7 +287,10 @@ def main():
     def step():
         if pending[0] is not None:
             pending[0].wait()
-        ctx.refresh_scene_chunks()
+        # the invariants (camera / segment records) are rebuilt from the receive buffer when an all-gather has refilled it;
+        # a one-rank job without the collective has nothing new to rebuild them from (they were built by init_device)
+        if gather.collective:
+            ctx.refresh_scene_chunks()
         pending[0] = gather.gather_async()
         # enqueue only: the host's end-of-run bookkeeping of step k (result slots, event timings) happens
         # after step k+1 has been enqueued; the sync below completes the last one inside the timed region

@@ -100,8 +100,9 @@ int lt_init_vp(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *la
  * (structures::PL_Bipartite2d::neighbor_points).  SfM points: point3D_id -> xyz; with none given the shared
  * points are triangulated from the two views.  Enables the many-points proposal of triangulateOneNode
  * (base_line_triangulator.cc:183-236: line fit through the shared 3D points + Pluecker projection) in
- * matched and exhaustive mode, and the one-point proposal (:238-248, one candidate per shared point, at most 250 per
- * connection; see lt_fn_triangulate_line_with_one_point for the solver).  Call after lt_init. */
+ * matched and exhaustive mode, and the one-point proposal (:238-248, one candidate per shared point, any number of
+ * shared points per connection, as in the reference; see lt_fn_triangulate_line_with_one_point for the solver).
+ * Call after lt_init. */
 int lt_set_bipartites(lt_ctx *ctx, int n_img, const int32_t *img_ids, const int64_t *pt_off, const int32_t *pt_ids,
                       const double *pt_xy, const int32_t *pt_p3d, const int64_t *line_off, const int64_t *lp_off,
                       const int32_t *lp_ptids);

@@ -237,6 +237,13 @@ namespace lt_impl {
 // per-kernel HIP events cost a few microseconds of stream bubble each.  LT_FINE_TIMERS (read per run): unset / 1 =
 // the event in front of k_score3 only (timer [15]: bench.py prices the dominant kernel with it, inside its timed
 // region), 2 = also the events around k_gates and k_tri_rows (timers [13], [14]: +5 us per step), 0 = none
+const char *test_switch(const char *name) {
+  static const bool on = [] {
+    const char *e = getenv("LT_ENABLE_TEST_SWITCHES");
+    return e && e[0] == '1';
+  }();
+  return on ? getenv(name) : nullptr;
+}
 int fine_level() {
   const char *e = getenv("LT_FINE_TIMERS");
   if (!e) return 1;
@@ -286,7 +293,7 @@ GenCfg make_gen(const lt_ctx *ctx) {
   g.disable_algebraic = c.disable_algebraic_triangulation;
   // LT_TEST_NO_FAST_GATES: the cheap gates never decide, the reference's exact gates do all the work;
   // results must not change (tests/test_gpu_guards.py)
-  g.force_undecided = getenv("LT_TEST_NO_FAST_GATES") != nullptr;
+  g.force_undecided = test_switch("LT_TEST_NO_FAST_GATES") != nullptr;
   // VP-guided proposals do not depend on the algebraic gates: every row must reach the triangulation kernel
   if (c.use_vp && !c.disable_vp_triangulation) g.force_undecided = 1;
   // The gate `90 - acos(a)*180/pi < th` is equivalent to a < sin(th) up to libm rounding; outside
@@ -316,7 +323,7 @@ GenCfg make_gen(const lt_ctx *ctx) {
       g.sens_lo2 = -1.0;
       g.sens_hi2 = 1e300;
     }
-    if (getenv("LT_TEST_NO_FAST_GATES")) {  // every candidate through the reference's form of the sensitivity test
+    if (test_switch("LT_TEST_NO_FAST_GATES")) {  // every candidate through the reference's form of the sensitivity test
       g.sens_lo2 = -1.0;
       g.sens_hi2 = 1e300;
     }
@@ -347,7 +354,7 @@ ScoreCfg make_score(const lt_ctx *ctx) {
   s.cos_guard = (th < 90.0) ? std::cos(th * kPi / 180.0) : -1.0;
   // LT_TEST_NO_SCORE_GUARDS: no conservative early exit in the scoring sweep (every pair of a node is
   // evaluated densely); results must not change (tests/test_gpu_guards.py)
-  if (getenv("LT_TEST_NO_SCORE_GUARDS")) s.cos_guard = -1.0;
+  if (test_switch("LT_TEST_NO_SCORE_GUARDS")) s.cos_guard = -1.0;
   s.fullscore_th = ctx->cfg.fullscore_th;
   s.max_valid_conns = ctx->cfg.max_valid_conns;
   s.pad_ = 0;

@@ -94,7 +94,7 @@ int lt_upload(lt_ctx *ctx) {
     const bool extras_cfg = (ctx->cfg.use_vp && !ctx->cfg.disable_vp_triangulation) ||
                             (ctx->pts_ready && (!ctx->cfg.disable_many_points_triangulation || !ctx->cfg.disable_one_point_triangulation));
     bool try_ln = ctx->rows_sorted && ctx->n_blk > 0 && ctx->P > 0 && ctx->max_nb_segs <= 1024 && !extras_cfg &&
-                  !getenv("LT_GEN_ROW_SLOTS") && !getenv("LT_GEN_NO_LDS_TABLE");
+                  !test_switch("LT_GEN_ROW_SLOTS") && !test_switch("LT_GEN_NO_LDS_TABLE");
     for (size_t cb = 0; try_ln && cb < ctx->h_ovf_off.size(); ++cb)
       if (ctx->h_ovf_off[cb] >= 0) try_ln = false;
     ctx->rows_ln = false;
@@ -310,10 +310,10 @@ int lt_run_device_async(lt_ctx *ctx) {
     gcfg.force_undecided = 1;
   const ScoreCfg scfg = make_score(ctx);
   // LT_TEST_SCORE_F64: the sweep's early exit in double precision (the default is the bounded single-precision form)
-  const bool score_f32 = !getenv("LT_TEST_SCORE_F64");
+  const bool score_f32 = !test_switch("LT_TEST_SCORE_F64");
   // conservative square of the scale-invariant endpoint gate (see k_score3)
   const bool guards_on = scfg.l3.th_scaleinv > 0.0 && scfg.l3.score_th > 0.0 && scfg.l3.score_th < 1.0 &&
-                         !getenv("LT_TEST_NO_SCORE_GUARDS");
+                         !test_switch("LT_TEST_NO_SCORE_GUARDS");
   const double guard2 = guards_on ? (scfg.l3.th_scaleinv * (1.0 + 1e-6)) * (scfg.l3.th_scaleinv * (1.0 + 1e-6)) : 1e300;
   ENSURE(ctx, ctx->d_err, sizeof(int));
   ENSURE(ctx, ctx->d_pair_counter, 8);
@@ -394,7 +394,7 @@ int lt_run_device_async(lt_ctx *ctx) {
       }
       ctx->cnt_bl_clean = false;
     }
-    const bool no_lds_table = getenv("LT_GEN_NO_LDS_TABLE") != nullptr;  // developer / test switch
+    const bool no_lds_table = test_switch("LT_GEN_NO_LDS_TABLE") != nullptr;  // developer / test switch
     // LDS tables of k_gates: the neighbour's gate records (T2) and the image's own segments (T1), 80 B
     // per segment each; two workgroups per CU need both within 80 KB, one workgroup within 160 KB
     int lds_segs = (!no_lds_table && ctx->max_nb_segs <= 1024) ? ctx->max_nb_segs : 0;
@@ -474,7 +474,7 @@ int lt_run_device_async(lt_ctx *ctx) {
       const long long per_cand = (long long)(sizeof(CRec) + 8 + 8 + 4 + 4) + (long long)cand_meta_bytes();
       if (extras) {
         C_known = staged_total;  // the counting run of stage B already brought the count to the host
-      } else if (ctx->h_pinned && bound * per_cand <= kCountFreeBytes && !getenv("LT_TEST_SYNC_COUNT")) {
+      } else if (ctx->h_pinned && bound * per_cand <= kCountFreeBytes && !test_switch("LT_TEST_SYNC_COUNT")) {
         C_known = -1;
         C_bound = bound;
       } else {
@@ -496,7 +496,7 @@ int lt_run_device_async(lt_ctx *ctx) {
       C_known = *hC;
     }
     // fast path: no record is moved -- k_place writes the permutation only
-    const bool perm_mode = fast && !getenv("LT_TEST_PLACE_COPY");
+    const bool perm_mode = fast && !test_switch("LT_TEST_PLACE_COPY");
     ctx->perm_mode = perm_mode;
     ctx->compact_valid = !perm_mode;
     if (C_known < 0) {
@@ -581,15 +581,15 @@ int lt_run_device_async(lt_ctx *ctx) {
     // overflows it (device error flag 5) is repeated in the two-pass form by finish_run.  LT_TEST_EX_TWO_PASS: always
     // two passes.
     const bool plain = !pts_any && !vp_on;
-    bool staged = plain && ctx->h_pinned && !ctx->ex_two_pass && P > 0 && !getenv("LT_TEST_EX_TWO_PASS") &&
-                  !getenv("LT_TEST_EX_PASS1_BLOCK");
+    bool staged = plain && ctx->h_pinned && !ctx->ex_two_pass && P > 0 && !test_switch("LT_TEST_EX_TWO_PASS") &&
+                  !test_switch("LT_TEST_EX_PASS1_BLOCK");
     long long ex_cap = 0;
     unsigned region_cap = 0;
     unsigned long long *ex_ctr = ctx->d_scan_status.as<unsigned long long>() + n_status_scan + score3_tile_buckets() * 16;
     if (staged) {
       double frac = ctx->ex_frac > 0.0 ? ctx->ex_frac : 1.0 / 6.0;
       long long slack = 65536;
-      if (const char *f = getenv("LT_TEST_EX_CAP_FRAC")) {  // test switch: force a (too small) capacity
+      if (const char *f = test_switch("LT_TEST_EX_CAP_FRAC")) {  // test switch: force a (too small) capacity
         frac = atof(f);
         slack = 0;
       }
@@ -624,7 +624,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                                 sfm_xyz, ctx->d_err.as<int>(), many_on, one_on, ctx->d_blk_chunk_off.as<int>(),
                                 ctx->max_nb, ctx->max_chunks, ctx->d_seg_gates.p);
     } else {
-      if (plain && !getenv("LT_TEST_EX_PASS1_BLOCK"))
+      if (plain && !test_switch("LT_TEST_EX_PASS1_BLOCK"))
         launch_gates_exhaustive(st, ctx->n_blk, ctx->max_chunks, P, gcfg, ctx->d_item_off.as<long long>(),
                                 ctx->d_blk_img.as<int>(), ctx->d_blk_nb.as<int>(), ctx->d_seg_off.as<long long>(),
                                 ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
@@ -700,7 +700,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                                 seg_vp, seg_has_vp, ctx->d_seg_pt_off.as<long long>(), ctx->d_seg_pts.p, sfm_xyz,
                                 ctx->d_err.as<int>(), many_on, one_on, ctx->d_blk_chunk_off.as<int>(), ctx->max_nb,
                                 ctx->max_chunks, ctx->d_seg_gates.p);
-    else if (!vp_on && !getenv("LT_TEST_EX_PASS2_BLOCK"))
+    else if (!vp_on && !test_switch("LT_TEST_EX_PASS2_BLOCK"))
       launch_fill_exhaustive(st, ctx->n_blk, P, gcfg, ctx->d_item_off.as<long long>(), ctx->d_blk_img.as<int>(),
                              ctx->d_blk_nb.as<int>(), ctx->d_nb_off.as<long long>(), ctx->d_seg_off.as<long long>(),
                              ctx->d_cams.as<Cam>(), ctx->d_segs.as<Seg>(), ctx->d_pairs.as<PairRec>(),
@@ -743,11 +743,11 @@ int lt_run_device_async(lt_ctx *ctx) {
     // tiles listed by cost class (LT_TEST_NO_TILE_CLASSES: natural tile order)
     // (matched mode only: the wide nodes of the exhaustive mode put every tile into the top class, whose one counter
     // per queue then serialises ~4e4 appends -- k_cand_meta 0.11 -> 0.50 ms -- for an order that changes nothing)
-    const bool tile_classes = !getenv("LT_TEST_NO_TILE_CLASSES") && ctx->job_mode == 1;
+    const bool tile_classes = !test_switch("LT_TEST_NO_TILE_CLASSES") && ctx->job_mode == 1;
     const unsigned tile_cap = (unsigned)(((std::max<long long>(C_bound, 1) + 63) / 64 + 7) / 8);  // tiles of one draw queue
     if (tile_classes) ENSURE(ctx, ctx->d_tile_list, 16 * (size_t)tile_cap * (size_t)score3_tile_buckets());  // 16-byte entries
     // large nodes (exhaustive matching): depth-sorted sweep, see k_depth_order
-    const bool score_sorted = score_f32 && ctx->job_mode == 2 && !getenv("LT_TEST_SCORE_UNSORTED");
+    const bool score_sorted = score_f32 && ctx->job_mode == 2 && !test_switch("LT_TEST_SCORE_UNSORTED");
     if (score_sorted) {
       ENSURE(ctx, ctx->d_perm, 4 * (size_t)std::max<long long>(C_bound, 1));
       ENSURE(ctx, ctx->d_rng, 8 * (size_t)std::max<long long>(C_bound, 1));
@@ -760,15 +760,15 @@ int lt_run_device_async(lt_ctx *ctx) {
     // (matched mode; the exhaustive mode's tiles carry ~25 pairs each and its units would be four tiles all the same -- the
     // per-unit work of k_dense8 then costs what the full rounds save: 1.16 + 1.44 ms against 2.54 fused.  LT_SCORE_SPLIT=1
     // forces the split form there and for the natural tile order, for the tests.)
-    const bool split = score_f32 && !ctx->score_fused && !getenv("LT_SCORE_FUSED") &&
-                       (tile_classes || getenv("LT_SCORE_SPLIT"));
+    const bool split = score_f32 && !ctx->score_fused && !test_switch("LT_SCORE_FUSED") &&
+                       (tile_classes || test_switch("LT_SCORE_SPLIT"));
     long long sp_chunks = 0;
     int sp_slot_cap = ctx->job_mode == 2 ? 64 : 256;  // entries per tile slot (matched: p90 of the bench scene is 182 pairs)
     if (split) {
       const long long n_tiles_b = (std::max<long long>(C_bound, 1) + 63) / 64;
       sp_chunks = score_split_chunks(std::max<long long>(C_bound, 1));
-      if (const char *e = getenv("LT_TEST_SPLIT_CHUNKS")) sp_chunks = std::max(0, atoi(e));
-      if (const char *e = getenv("LT_TEST_SPLIT_SLOT")) sp_slot_cap = std::max(1, atoi(e));
+      if (const char *e = test_switch("LT_TEST_SPLIT_CHUNKS")) sp_chunks = std::max(0, atoi(e));
+      if (const char *e = test_switch("LT_TEST_SPLIT_SLOT")) sp_slot_cap = std::max(1, atoi(e));
       ENSURE(ctx, ctx->d_sp_slots, score_split_entry_bytes() * (size_t)sp_slot_cap * (size_t)n_tiles_b);
       ENSURE(ctx, ctx->d_sp_cnt, 4 * (size_t)n_tiles_b);
       ENSURE(ctx, ctx->d_sp_ovf, 4 * (size_t)n_tiles_b);

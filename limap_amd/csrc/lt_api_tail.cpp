@@ -14,7 +14,7 @@ extern "C" {
 // that is still resident in HBM (one batch, nothing imported, nothing read back yet) and no node filter applies
 // (min_num_outer_edges == 0, the value of cfgs/triangulation/default.yaml:81).  LT_TAIL_HOST=1 forces the host form.
 static bool tail_on_device(const lt_ctx *ctx) {
-  if (getenv("LT_TAIL_HOST") != nullptr || ctx->cfg.min_num_outer_edges > 0) return false;
+  if (test_switch("LT_TAIL_HOST") != nullptr || ctx->cfg.min_num_outer_edges > 0) return false;
   if (!ctx->inited || ctx->job_mode == 0 || ctx->downloaded || ctx->job_imgs.empty()) return false;
   if (ctx->G <= 0 || ctx->G >= (1ll << 31)) return false;
   // results that live only on the host -- an earlier batch that was read back, imported shards -- rule the device form

@@ -97,6 +97,11 @@ struct Range {
 
 namespace lt_impl {
 // lt_api.cpp
+// Test and developer switches (LT_TEST_*, LT_GEN_NO_LDS_TABLE, LT_GEN_ROW_SLOTS, LT_SCORE_FUSED, LT_SCORE_SPLIT,
+// LT_TAIL_HOST: each selects the plain / reference form of a fast path, for the tests that compare the two) are read from
+// the environment ONLY in a process that opted in with LT_ENABLE_TEST_SWITCHES=1 (tests/conftest.py, tools/ set it): a
+// production process cannot be steered into the slow forms by a stray variable.  Returns getenv(name) or nullptr.
+const char *test_switch(const char *name);
 int fine_level();  // LT_FINE_TIMERS
 bool fine_timers();
 bool fine_gen_timers();

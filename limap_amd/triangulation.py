@@ -15,10 +15,13 @@ import numpy as np
 from . import _capi
 from .base import CameraView, ImageCollection, Line2d, Line3d, LineTrack
 
+# the pybind surface of triangulation/bindings.cc:22-31,78-119 (the reference's package does `from _limap._triangulation
+# import *`, limap/triangulation/__init__.py:1-2: every free function has to be in __all__)
 __all__ = [
-    "GlobalLineTriangulator", "GlobalLineTriangulatorConfig", "get_normal_direction",
-    "compute_essential_matrix", "compute_fundamental_matrix", "compute_epipolar_IoU",
-    "triangulate_line", "triangulate_line_by_endpoints",
+    "GlobalLineTriangulator", "GlobalLineTriangulatorConfig", "get_normal_direction", "get_direction_from_VP",
+    "compute_essential_matrix", "compute_fundamental_matrix", "compute_epipolar_IoU", "triangulate_point",
+    "triangulate_line_by_endpoints", "triangulate_line", "triangulate_line_with_one_point",
+    "triangulate_line_with_direction",
 ]
 
 
@@ -239,7 +242,6 @@ def _cam11(view):
             raise ValueError("camera must be kvec4|qvec4|tvec3")
         return a
     k, q, t = _view_arrays(view)
-    n = np.linalg.norm(q)
     return np.concatenate([k, q, t])
 
 

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the library reads its test / developer switches (LT_TEST_*, LT_GEN_ROW_SLOTS, LT_SCORE_FUSED, LT_TAIL_HOST, ...) only in a
+# process that opts in: the tests that compare a fast path with its plain form need them
+os.environ["LT_ENABLE_TEST_SWITCHES"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -79,3 +79,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_python_surface_lists_every_free_function_of_the_reference_bindings():
+    """limap/triangulation/__init__.py does `from _limap._triangulation import *`: the mirror's __all__ must carry the ten
+    free functions of triangulation/bindings.cc:22-31 and the two classes (read from the reference tree where it exists)."""
+    import os
+    import re
+    from limap_amd import triangulation as tri
+    names = ["get_normal_direction", "get_direction_from_VP", "compute_essential_matrix", "compute_fundamental_matrix",
+             "compute_epipolar_IoU", "triangulate_point", "triangulate_line_by_endpoints", "triangulate_line",
+             "triangulate_line_with_one_point", "triangulate_line_with_direction"]
+    src = "/root/reference/src/limap/triangulation/bindings.cc"
+    if os.path.exists(src):
+        found = re.findall(r'm\.def\("(\w+)"', open(src).read())
+        assert sorted(found) == sorted(names)
+    for n in names + ["GlobalLineTriangulator", "GlobalLineTriangulatorConfig"]:
+        assert n in tri.__all__ and callable(getattr(tri, n)), n

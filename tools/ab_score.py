@@ -74,6 +74,7 @@ def main():
         label, lib = parts[0], parts[1]
         env = dict(os.environ)
         env["LIMAP_AMD_LIB"] = os.path.join(ROOT, lib)
+        env["LT_ENABLE_TEST_SWITCHES"] = "1"  # the developer switches of an entry (LT_GEN_ROW_SLOTS, LT_SCORE_FUSED, ...)
         env["LT_FINE_TIMERS"] = env.get("LT_FINE_TIMERS", "2")
         if len(parts) > 2 and parts[2]:
             for kv in parts[2].split(","):

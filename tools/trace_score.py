@@ -4,6 +4,7 @@ import ctypes as C, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 os.environ.setdefault("LIMAP_AMD_LIB", os.path.join(root, "limap_amd/variants/libT.so"))
+os.environ["LT_ENABLE_TEST_SWITCHES"] = "1"
 os.environ["LT_SCORE_FUSED"] = "1"  # this tool reads the FUSED kernel's marks (the two-kernel form: tools/trace_split.py)
 import numpy as np
 from limap_amd import synthetic as syn, triangulation as tri, _capi
