@@ -4,6 +4,7 @@
 #pragma once
 
 #include "lt_geom.h"
+#include "lt_svd.h"
 
 #include <omp.h>
 
@@ -31,62 +32,24 @@ inline int uf_root(int i, std::vector<int> &parent) {  // base/graph.cc:156-165 
   return r;
 }
 
-// Principal axis of a centred point set = first right-singular vector of the n x 3 point matrix, by one-sided
-// (Hestenes) Jacobi rotations of the columns: what Eigen::JacobiSVD(points, ComputeThinV).matrixV().col(0) stands
-// for in merging/aggregator.cc:76-78.  An SVD leaves the sign of a singular vector open; it decides which end of the
-// aggregated line is `start`.  The rule here -- the component of largest magnitude is positive -- is the one of the
-// CPU checker this backend is tested against and of the Eigen stand-in the reference sources are compiled with for that
-// checker; a real Eigen build may orient a track the other way round.  The rotations work on the
-// points themselves, in the same order as there, so the direction agrees to the last bit and no start / end swap is
-// left to tolerate in the comparisons.
-// `pts` is overwritten.
-inline void principal_axis(std::vector<d3> &pts, double out[3]) {
-  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+// Principal axis of a centred point set = Eigen::JacobiSVD(points, ComputeThinV).matrixV().col(0) of
+// merging/aggregator.cc:76-78, computed by Eigen 3.4's own procedure (lt_svd.h: column-pivoted Householder QR, two-sided
+// Jacobi sweeps, descending sort) so that the SIGN of the direction -- it decides which end of the aggregated line is
+// `start` -- is the one an Eigen build produces (rounds 1-4: one-sided Jacobi with a sign rule of our own).
+inline void principal_axis(const std::vector<d3> &pts, double out[3]) {
   const int n = (int)pts.size();
-  auto col = [&](int r, int c) -> double & { return c == 0 ? pts[(size_t)r].x : (c == 1 ? pts[(size_t)r].y : pts[(size_t)r].z); };
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        double alpha = 0, beta = 0, gamma = 0;
-        for (int r = 0; r < n; ++r) {
-          alpha += col(r, p) * col(r, p);
-          beta += col(r, q) * col(r, q);
-          gamma += col(r, p) * col(r, q);
-        }
-        if (gamma == 0.0) continue;
-        off = std::max(off, std::fabs(gamma) / std::sqrt(alpha * beta + 1e-300));
-        const double zeta = (beta - alpha) / (2.0 * gamma);
-        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-        const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
-        for (int r = 0; r < n; ++r) {
-          const double a = col(r, p), b = col(r, q);
-          col(r, p) = c * a - s * b;
-          col(r, q) = s * a + c * b;
-        }
-        for (int r = 0; r < 3; ++r) {
-          const double a = V[r][p], b = V[r][q];
-          V[r][p] = c * a - s * b;
-          V[r][q] = s * a + c * b;
-        }
-      }
-    if (off < 1e-15) break;
+  // (the threads of the host team aggregate thousands of tracks: storage kept per thread)
+  static thread_local lt_svd::Mat A, V;
+  static thread_local lt_svd::Scratch sc;
+  static thread_local std::vector<double> sv;
+  A.reset(n, 3);
+  for (int r = 0; r < n; ++r) {
+    A(r, 0) = pts[(size_t)r].x;
+    A(r, 1) = pts[(size_t)r].y;
+    A(r, 2) = pts[(size_t)r].z;
   }
-  int best = 0;
-  double best_n = -1;
-  for (int c = 0; c < 3; ++c) {
-    double sq = 0;
-    for (int r = 0; r < n; ++r) sq += col(r, c) * col(r, c);
-    if (sq > best_n) {
-      best_n = sq;
-      best = c;
-    }
-  }
-  const double d[3] = {V[0][best], V[1][best], V[2][best]};
-  const double ax = std::fabs(d[0]), ay = std::fabs(d[1]), az = std::fabs(d[2]);
-  const double lead = (ax >= ay && ax >= az) ? d[0] : (ay >= az ? d[1] : d[2]);
-  const double sgn = lead < 0 ? -1.0 : 1.0;
-  for (int k = 0; k < 3; ++k) out[k] = sgn * d[k];
+  lt_svd::jacobi_svd_thin_v(A, V, sv, sc);
+  out[0] = V(0, 0); out[1] = V(1, 0); out[2] = V(2, 0);
 }
 
 // Aggregator::aggregate_line3d_list, merging/aggregator.cc:53-101 (+ takebest :8-29).  Two interfaces: a list of
@@ -130,8 +93,7 @@ inline void aggregate_impl(GetLine line, const double *scores, int n, int num_ou
     pts[2 * i + 1] = sub(mk3(line(i).e[0], line(i).e[1], line(i).e[2]), center);
   }
   double dv[3];
-  sc.rot = pts;  // the rotations overwrite their matrix; the projections below use the points
-  principal_axis(sc.rot, dv);
+  principal_axis(pts, dv);
   d3 direc = mk3(dv[0], dv[1], dv[2]);
   double nn = std::sqrt(sqn(direc));
   direc = mk3(direc.x / nn, direc.y / nn, direc.z / nn);

@@ -22,6 +22,7 @@
 //
 // Build: see oracle/Makefile (g++ -O2 -fopenmp -ffp-contract=off).
 
+#include "eigen_svd_ref.h"
 #include "lt_oracle.h"
 
 #include <omp.h>
@@ -1129,60 +1130,21 @@ static std::vector<int> ComputeLineTrackLabelsAvg(const std::vector<int> &node_i
   return labels_from_parents(parent_nodes);
 }
 
-// Principal right-singular vector of an n x 3 matrix by one-sided (Hestenes) Jacobi.
-// Stands in for Eigen::JacobiSVD(ComputeThinV).matrixV().col(0) (aggregator.cc:76-78); the sign
-// of a singular vector is not defined by the SVD, so it is fixed here by a deterministic rule
-// (largest-magnitude component positive) and tests compare track lines modulo endpoint swap.
-static V3 principal_direction(std::vector<V3> rows) {
-  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+// Eigen::JacobiSVD<MatrixXd>(rows, ComputeThinV).matrixV().col(0) of an n x 3 matrix (aggregator.cc:76-78,
+// base_line_triangulator.cc:229-230) by Eigen 3.4's own procedure, sign included: oracle/eigen_svd_ref.h.
+static V3 principal_direction(const std::vector<V3> &rows) {
   const int n = int(rows.size());
-  auto col = [&](int r, int c) -> double & {
-    return c == 0 ? rows[r].x : (c == 1 ? rows[r].y : rows[r].z);
-  };
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        double alpha = 0, beta = 0, gamma = 0;
-        for (int r = 0; r < n; ++r) {
-          alpha += col(r, p) * col(r, p);
-          beta += col(r, q) * col(r, q);
-          gamma += col(r, p) * col(r, q);
-        }
-        if (gamma == 0.0) continue;
-        off = std::max(off, std::abs(gamma) / std::sqrt(alpha * beta + 1e-300));
-        double zeta = (beta - alpha) / (2.0 * gamma);
-        double t = (zeta >= 0 ? 1.0 : -1.0) / (std::abs(zeta) + std::sqrt(1.0 + zeta * zeta));
-        double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
-        for (int r = 0; r < n; ++r) {
-          double a = col(r, p), b = col(r, q);
-          col(r, p) = c * a - s * b;
-          col(r, q) = s * a + c * b;
-        }
-        for (int r = 0; r < 3; ++r) {
-          double a = V[r][p], b = V[r][q];
-          V[r][p] = c * a - s * b;
-          V[r][q] = s * a + c * b;
-        }
-      }
-    if (off < 1e-15) break;
+  ora_svd::Mat A(n, 3), V;
+  for (int r = 0; r < n; ++r) {
+    A(r, 0) = rows[size_t(r)].x;
+    A(r, 1) = rows[size_t(r)].y;
+    A(r, 2) = rows[size_t(r)].z;
   }
-  int best = 0;
-  double best_n = -1;
-  for (int c = 0; c < 3; ++c) {
-    double s = 0;
-    for (int r = 0; r < n; ++r) s += col(r, c) * col(r, c);
-    if (s > best_n) {
-      best_n = s;
-      best = c;
-    }
-  }
-  V3 d{V[0][best], V[1][best], V[2][best]};
-  double ax = std::abs(d.x), ay = std::abs(d.y), az = std::abs(d.z);
-  double lead = (ax >= ay && ax >= az) ? d.x : (ay >= az ? d.y : d.z);
-  if (lead < 0) d = -d;
-  return d;
+  std::vector<double> sv;
+  ora_svd::jacobi_svd_thin_v(A, V, sv);
+  return V3{V(0, 0), V(1, 0), V(2, 0)};
 }
+
 
 static Line3d aggregate_takebest(const std::vector<Line3d> &lines,
                                  const std::vector<double> &scores) {  // aggregator.cc:8-29

@@ -291,3 +291,75 @@ def test_save_obj_accepts_arrays_lists_and_line3d_objects(tmp_path):
     assert outs[0].count("\nl ") + outs[0].startswith("l ") == 4 and outs[0].count("v ") == 8
     lio.save_obj(str(tmp_path / "empty.obj"), [])
     assert (tmp_path / "empty.obj").read_text() == ""
+
+
+# ---- tools/diff_limap_dump.py: the offline cross-check against a dump of a real limap run -----------------------
+def _load_diff_tool():
+    spec = importlib.util.spec_from_file_location(
+        "diff_limap_dump", os.path.join(os.path.dirname(GOLD), "..", "..", "tools", "diff_limap_dump.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_diff_tool_counts_swaps_separately():
+    tool = _load_diff_tool()
+    a = _track()
+    same = _track()
+    swapped = _track()
+    swapped.image_id_list = [7, 8, 9]
+    swapped.line = base.Line3d(np.asarray(a.line.end, float), np.asarray(a.line.start, float))
+    other = _track()
+    other.image_id_list = [7, 8, 9]
+    rep = tool.compare([a, other], [same, swapped])
+    assert rep["ok"] and rep["matched"] == 1 and rep["swapped"] == 1 and rep["endpoint_mismatch"] == 0
+    moved = _track()
+    moved.line = base.Line3d(np.asarray(a.line.start, float) + 1e-3, np.asarray(a.line.end, float))
+    rep = tool.compare([a], [moved])
+    assert not rep["ok"] and rep["endpoint_mismatch"] == 1
+    lost = _track()
+    lost.line_id_list = [99] * len(lost.line_id_list)
+    rep = tool.compare([a], [lost])
+    assert not rep["ok"] and rep["missing_member_sets"] == 1 and rep["extra_member_sets"] == 1
+
+
+@pytest.mark.gpu
+def test_diff_tool_on_a_scene_folder(gpu_lib, oracle, tmp_path):
+    """The whole flow of tools/diff_limap_dump.py with the oracle standing in for the upstream run: its tracks are
+    written in limap's track format, the tool re-runs the scene folder on the GPU and must find every member set with
+    endpoints inside 1e-5 and no start / end swap (the oracle and the product share the SVD procedure)."""
+    import subprocess
+    sc = syn.make_scene(n_views=12, n_segs=90, n_neighbors=5, seed=18)
+    cfg = syn.default_triangulation_cfg()
+    ic = base.ImageCollection.from_arrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec)
+    ltio.save_imagecols(str(tmp_path / "imagecols.npy"), ic)
+    ltio.save_txt_metainfos(str(tmp_path / "metainfos.txt"), sc.neighbors, sc.ranges)
+    for n, i in enumerate(sc.img_ids):
+        ltio.save_txt_segments(str(tmp_path / "segs"), int(i), sc.segs_of(n))
+        ltio.save_matches(str(tmp_path / "matches"), int(i), sc.matches_of(int(i)))
+    from helpers import run_oracle
+    O = run_oracle(oracle, sc, cfg)
+    ot = O.ComputeLineTracks()
+    ups = []
+    for k in range(len(ot["off"]) - 1):
+        a, b = int(ot["off"][k]), int(ot["off"][k + 1])
+        tr = base.LineTrack()
+        tr.line = base.Line3d(ot["line"][k][:3], ot["line"][k][3:6])
+        tr.image_id_list = [int(x) for x in ot["image_ids"][a:b]]
+        tr.line_id_list = [int(x) for x in ot["line_ids"][a:b]]
+        tr.node_id_list = [int(x) for x in ot["node_ids"][a:b]]
+        tr.line2d_list = [base.Line2d(np.zeros(2), np.ones(2)) for _ in range(a, b)]
+        tr.line3d_list = [base.Line3d(np.zeros(3), np.ones(3)) for _ in range(a, b)]
+        tr.score_list = [0.0] * (b - a)
+        ups.append(tr)
+    assert len(ups) > 5
+    ltio.save_folder_linetracks(str(tmp_path / "upstream_tracks"), ups)
+    tool = os.path.join(os.path.dirname(GOLD), "..", "..", "tools", "diff_limap_dump.py")
+    p = subprocess.run([sys.executable, tool, "--imagecols", str(tmp_path / "imagecols.npy"), "--metainfos",
+                        str(tmp_path / "metainfos.txt"), "--segments", str(tmp_path / "segs"), "--matches",
+                        str(tmp_path / "matches"), "--tracks", str(tmp_path / "upstream_tracks")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    import json as _json
+    rep = _json.loads(p.stdout[p.stdout.index("{"):])
+    assert rep["ok"] and rep["swapped"] == 0 and rep["matched"] == len(ups)
