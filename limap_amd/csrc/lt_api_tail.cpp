@@ -170,6 +170,12 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
   static_assert(sizeof(Rec) == 128, "TailRec layout");
   const Rec *recs = (const Rec *)(base + o_recs);
   const int *nodes = (const int *)(base + o_nodes);
+  // the same records once more in graph-node order (what the union-find and the aggregation read: the G-entry tables are
+  // 100 MB at a million nodes, every access a miss)
+  const size_t n_graph = ctx->tail_gnode.size();
+  ctx->tail_nimg.resize(n_graph);
+  ctx->tail_cscore.resize(n_graph);
+  ctx->tail_ccand.resize(n_graph);
   lt_host::pool_for(Nm, 1024, [&](long long k0, long long k1) {
     for (long long k = k0; k < k1; ++k) {  // distinct nodes: no two iterations touch the same entry
       const long long g = nodes[k];
@@ -178,6 +184,12 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
       ctx->best_src2[2 * g] = ctx->img_ids[recs[k].src[0]];
       ctx->best_src2[2 * g + 1] = recs[k].src[1];
       ctx->has_best[g] = 1;
+      const int gi = ctx->tail_gmap[(size_t)g];
+      if (gi >= 0) {
+        ctx->tail_nimg[(size_t)gi] = ctx->h_node_img[g];
+        ctx->tail_cscore[(size_t)gi] = recs[k].score;
+        ctx->tail_ccand[(size_t)gi] = recs[k].c;
+      }
     }
   });
   lap("host unpack");
@@ -381,26 +393,57 @@ int lt_compute_tracks(lt_ctx *ctx) {
     }
   }
   lap("edge sort");
-  std::vector<int> parent(n_nodes, -1);
-  // images_in_track (std::set<int> per root in the reference, :52-84): only the set SIZES steer the
-  // union, so a bit set per node over the image indices is equivalent
-  const size_t W = ((size_t)ctx->n_img + 63) / 64;
-  std::vector<unsigned long long> img_bits((size_t)n_nodes * W, 0ull);
-  std::vector<int> img_cnt(n_nodes, 1);
-  for (int i = 0; i < n_nodes; ++i) {
-    const int im = ctx->h_node_img[gnode[i]];
-    img_bits[(size_t)i * W + (size_t)im / 64] |= 1ull << (im & 63);
+  // (the per-node arrays of the union-find live in the context: fresh vectors of a few MB are page faults per call)
+  std::vector<int> &parent = ctx->tail_parent;
+  parent.assign((size_t)n_nodes, -1);
+  // images_in_track (std::set<int> per root in the reference, :52-84): only the set SIZES steer the union.  A root's
+  // images as a small sorted list, made when it first absorbs another root (a singleton is its node's image): a bit set
+  // per node over the image indices -- rounds 1-4 -- is n_nodes x n_images / 8 bytes to clear per call, 13 MB and most of
+  // the 1.0-1.8 ms this loop took at 1000 images.
+  std::vector<int> &img_cnt = ctx->tail_img_cnt;
+  img_cnt.assign((size_t)n_nodes, 1);
+  std::vector<int> &nimg = ctx->tail_nimg;  // image of every graph node (tail_from_device fills it from the records)
+  if (!on_device) {
+    nimg.resize((size_t)n_nodes);
+    for (int i = 0; i < n_nodes; ++i) nimg[(size_t)i] = ctx->h_node_img[gnode[(size_t)i]];
   }
+  // the lists live in ONE arena (a vector per root cost an allocation per union: most of the 50 ns a union took): a union
+  // writes the merged list behind everything else; the dead lists are swept when the arena has grown past a few times
+  // the live ones
+  std::vector<int> &arena = ctx->tail_img_arena;
+  std::vector<long long> &set_off = ctx->tail_set_off;  // root -> first entry of its list, -1: the singleton {nimg[root]}
+  std::vector<int> &set_len = ctx->tail_set_len;
+  arena.clear();
+  set_off.assign((size_t)n_nodes, -1);
+  set_len.assign((size_t)n_nodes, 0);
+  size_t sweep_at = std::max<size_t>((size_t)1 << 16, 8 * (size_t)n_nodes);
   auto absorb = [&](int dst, int src) {  // images[dst] |= images[src]; images[src] = {}
-    int c = 0;
-    for (size_t w = 0; w < W; ++w) {
-      unsigned long long v = img_bits[(size_t)dst * W + w] | img_bits[(size_t)src * W + w];
-      img_bits[(size_t)dst * W + w] = v;
-      img_bits[(size_t)src * W + w] = 0ull;
-      c += __builtin_popcountll(v);
+    const size_t na = set_off[(size_t)dst] >= 0 ? (size_t)set_len[(size_t)dst] : 1;
+    const size_t nb = set_off[(size_t)src] >= 0 ? (size_t)set_len[(size_t)src] : 1;
+    if (arena.size() + na + nb > sweep_at) {  // sweep: the live lists move to the front of a fresh arena
+      std::vector<int> &fresh = ctx->tail_img_tmp;
+      fresh.clear();
+      for (int r = 0; r < n_nodes; ++r)
+        if (set_off[(size_t)r] >= 0 && img_cnt[(size_t)r] > 0) {
+          const long long o = set_off[(size_t)r];
+          set_off[(size_t)r] = (long long)fresh.size();
+          fresh.insert(fresh.end(), arena.begin() + o, arena.begin() + o + set_len[(size_t)r]);
+        }
+      arena.swap(fresh);
+      sweep_at = std::max(sweep_at, 4 * arena.size() + na + nb);
     }
-    img_cnt[dst] = c;
-    img_cnt[src] = 0;
+    const size_t o_new = arena.size();
+    arena.resize(o_new + na + nb);
+    const int *a = set_off[(size_t)dst] >= 0 ? arena.data() + set_off[(size_t)dst] : &nimg[(size_t)dst];
+    const int *b = set_off[(size_t)src] >= 0 ? arena.data() + set_off[(size_t)src] : &nimg[(size_t)src];
+    int *out = arena.data() + o_new;
+    const size_t n = (size_t)(std::set_union(a, a + na, b, b + nb, out) - out);
+    arena.resize(o_new + n);
+    set_off[(size_t)dst] = (long long)o_new;
+    set_len[(size_t)dst] = (int)n;
+    set_off[(size_t)src] = -1;
+    img_cnt[(size_t)dst] = (int)n;
+    img_cnt[(size_t)src] = 0;
   };
   // merging strategies (global_line_triangulator.cc:306-316): greedy unions every edge; "exhaustive" and "avg"
   // first test the two unions with LineLinker3d::check_connection in avgtest mode (line_linker.h:131-137)
@@ -470,7 +513,9 @@ int lt_compute_tracks(lt_ctx *ctx) {
   // NOTE: the reference's recursive root lookup compresses paths as a side effect and reads
   // parent_nodes[node] afterwards; labels are assigned from the parent array as it stands after
   // the union loop.  uf_root() above applies the same full path compression per lookup.
-  std::vector<int> labels(n_nodes, -1);
+  lap("  uf: unions");
+  std::vector<int> &labels = ctx->tail_labels;
+  labels.assign((size_t)n_nodes, -1);
   int n_tracks = 0;
   for (int i = 0; i < n_nodes; ++i) {
     if (parent[i] == -1) continue;
@@ -501,22 +546,28 @@ int lt_compute_tracks(lt_ctx *ctx) {
       const int tl = labels[i];
       if (tl == -1) continue;
       const long long g = gnode[i];
-      const int img = ctx->h_node_img[g];
+      const int img = nimg[(size_t)i];
       const size_t w = (size_t)wr[(size_t)tl]++;
       ts.node_ids[w] = i;
       ts.img_ids[w] = ctx->img_ids[img];
       ts.line_ids[w] = (int)(g - ctx->seg_off[img]);
-      ts.scores[w] = ctx->best_score[g];
+      ts.scores[w] = on_device ? ctx->tail_cscore[(size_t)i] : ctx->best_score[g];
       ts.gnodes[w] = g;
     }
+    lap("  tracks: members");
     // shared with the workers of the persistent team that are awake (lt_pool.h): a few thousand tracks aggregate
     // faster than a sleeping OpenMP team starts on a big host
     lt_host::pool_for((long long)nT, 16, [&](long long t0_, long long t1_) {
       static thread_local AggScratch scratch;
       for (long long t = t0_; t < t1_; ++t) {
         const size_t a = (size_t)ts.off[(size_t)t], n = (size_t)ts.off[(size_t)t + 1] - a;
-        aggregate(ctx->best_c, ts.gnodes.data() + a, ts.scores.data() + a, (int)n, ctx->cfg.num_outliers_aggregator,
-                  ts.line7.data() + 7 * (size_t)t, scratch);
+        // (device tail: the graph nodes' records in graph-node order, 2-3 MB, instead of the G-entry table)
+        if (on_device)
+          aggregate(ctx->tail_ccand.data(), ts.node_ids.data() + a, ts.scores.data() + a, (int)n, ctx->cfg.num_outliers_aggregator,
+                    ts.line7.data() + 7 * (size_t)t, scratch);
+        else
+          aggregate(ctx->best_c, ts.gnodes.data() + a, ts.scores.data() + a, (int)n, ctx->cfg.num_outliers_aggregator,
+                    ts.line7.data() + 7 * (size_t)t, scratch);
       }
     });
   }

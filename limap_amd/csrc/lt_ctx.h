@@ -310,6 +310,11 @@ struct lt_ctx {
   std::vector<int> tail_gmap;         // global node -> graph node, -1 outside a call
   std::vector<long long> tail_gnode;  // graph node -> global node
   std::vector<GEdge> tail_ge, tail_ge2;
+  std::vector<int> tail_img_tmp;
+  std::vector<int> tail_parent, tail_img_cnt, tail_labels, tail_nimg, tail_img_arena, tail_set_len;
+  std::vector<long long> tail_set_off;
+  std::vector<double> tail_cscore;   // device tail: score / record of every graph node, in graph-node order
+  std::vector<lt::Cand> tail_ccand;
   std::vector<unsigned char> valid_flags;  // valid_flags_ of run_clustering (filterNodeByNumOuterEdges), per node
   bool tracks_done = false;
   long long stat_graph_nodes = 0, stat_graph_edges = 0, stat_pairs = 0;

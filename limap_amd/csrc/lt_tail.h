@@ -116,5 +116,9 @@ inline void aggregate(const Cand *table, const long long *idx, const double *sco
                       double out7[7], AggScratch &sc) {
   aggregate_impl([&](int i) -> const Cand & { return table[idx[i]]; }, scores, n, num_outliers, out7, sc);
 }
+inline void aggregate(const Cand *table, const int *idx, const double *scores, int n, int num_outliers, double out7[7],
+                      AggScratch &sc) {
+  aggregate_impl([&](int i) -> const Cand & { return table[idx[i]]; }, scores, n, num_outliers, out7, sc);
+}
 
 }  // namespace lt
