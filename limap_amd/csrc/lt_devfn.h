@@ -365,7 +365,7 @@ static __device__ __forceinline__ int gate3(const GenCfg &cfg, double a1x, doubl
   const double d1x = a1x - b1x, d1y = a1y - b1y;
   const double q1 = __builtin_fma(d1x, d1x, d1y * d1y);
   const GateEpi ea = gate3_epi(F, a1x, a1y), eb = gate3_epi(F, b1x, b1y);
-  return gate3_core(cfg, q1, rs1x, rs1y, rs1z, re1x, re1y, re1z, n2x, n2y, n2z, lcx, lcy, P, Q, w1, sv, q2, ea, eb);
+  return gate3_core_fma(cfg, q1, rs1x, rs1y, rs1z, re1x, re1y, re1z, n2x, n2y, n2z, lcx, lcy, P, Q, w1, sv, q2, ea, eb);
 }
 
 // Three-way form of `line.sensitivity(view) > sens_th` without a division or a square root: with b = Minv (mid, 1) the

@@ -432,7 +432,7 @@ k_gates_ex(int n_blk, int max_chunks, long long n_items, GenCfg cfg, const long 
           GateEpi ea, eb;
           ea.ax = o[0]; ea.ay = o[1]; ea.az = o[2]; ea.n2a = o[3]; ea.na = o[4];
           eb.ax = o[6]; eb.ay = o[7]; eb.az = o[8]; eb.n2a = o[9]; eb.na = o[10];
-          const int res = gate3_core(cfg, o[5], s1.rs[0], s1.rs[1], s1.rs[2], s1.re[0], s1.re[1], s1.re[2], gg.n[0],
+          const int res = gate3_core_fma(cfg, o[5], s1.rs[0], s1.rs[1], s1.rs[2], s1.re[0], s1.re[1], s1.re[2], gg.n[0],
                                      gg.n[1], gg.n[2], gg.lcx, gg.lcy, gg.P, gg.Q, gg.w1, gg.sv, gg.q2, ea, eb);
           const bool t0 = in_range && res != 0;
           const unsigned long long bm = __ballot(t0);
