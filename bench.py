@@ -165,6 +165,109 @@ def feed(ctx, scene, imgs, mode, topk):
     ctx.upload()
 
 
+def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, warmup=2, n_full=3):
+    """BASELINE.json configs[2] (1000 views x 1000 segs, 4 rooms, 3000 GT segments, seed 1) as a STRONG-scaling leg of the
+    same run: the fixed job is sharded by image over the `world` ranks, one all-gather per step brings the scene to every
+    rank, each rank runs generation + scoring for its own images; `ms_per_step` = max over ranks, and
+    `step_with_merge_and_tail_ms` adds the shards' way to rank 0 and rank 0's ComputeLineTracks.  One driver run of
+    `bench.py --gpus N` thus yields north_star's config-3 curve beside the weak one."""
+    import torch
+    import torch.distributed as dist
+    from limap_amd import _capi
+    from limap_amd import dist as ltdist
+    from limap_amd import synthetic as syn
+    shape = dict(n_views=1000, n_segs=1000, n_neighbors=20, n_rooms=4, n_gt=3000, seed=1, topk=10)
+    small = os.environ.get("LT_BENCH_STRONG_SCENE")  # tests: "views,segs,neighbors" of a scene that takes a second
+    if small:
+        v, sg, nbn = (int(x) for x in small.split(","))
+        shape = dict(n_views=v, n_segs=sg, n_neighbors=nbn, seed=1, topk=10)
+    scene = syn.make_scene(**shape)
+    n_segs_img = np.diff(scene.seg_off)
+    weights = np.array([len(scene.neighbors[int(i)]) * n_segs_img[n] * 10 for n, i in enumerate(scene.img_ids)], float)
+    my_imgs = ltdist.shard_images(scene.img_ids, rank, world, weights)
+    ctx = _capi.Context(cfg_dict=cfg, device=local_rank)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.set_ranges(*scene.ranges)
+    gather = ltdist.SceneGather(scene.img_ids, scene.seg_off, rank, world, dev, weights=weights, force_collective=use_dist)
+    gather.load_local(scene.kvec, scene.qvec, scene.tvec, scene.segs)
+    d_k, d_q, d_t, d_s = gather.all_gather()
+    ctx.init_device(scene.img_ids, d_k.data_ptr(), d_q.data_ptr(), d_t.data_ptr(), scene.seg_off, d_s.data_ptr())
+    feed(ctx, scene, my_imgs, "matched", 10)
+    ctx.set_scene_chunks(*gather.chunk_pointers())
+    pending = [gather.gather_async()]
+
+    def step():
+        if pending[0] is not None:
+            pending[0].wait()
+        if gather.collective:
+            ctx.refresh_scene_chunks()
+        pending[0] = gather.gather_async()
+        ctx.run_device(wait=False)
+
+    def sync():
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def rmax(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize(dev)
+    local = time.perf_counter() - t0
+    sync()
+    elapsed = rmax(time.perf_counter() - t0)
+    my_idx = np.searchsorted(scene.img_ids, my_imgs)
+    node_range = (int(scene.seg_off[my_idx[0]]), int(scene.seg_off[my_idx[-1] + 1])) if len(my_idx) else (0, 0)
+    note = None
+    tf0 = time.perf_counter()
+    try:
+        for _ in range(n_full):
+            step()
+            ctx.sync()
+            if world > 1:
+                ltdist.merge_shards_device(ctx, node_range, rank, world, dev)
+            if rank == 0:
+                ctx.compute_tracks()
+        sync()
+    except Exception as e:
+        note = f"{type(e).__name__}: {e}"
+    full = rmax(time.perf_counter() - tf0)
+    if pending[0] is not None:
+        pending[0].wait()
+        torch.cuda.synchronize(dev)
+    st = ctx.stats()
+    cand = float(st["candidates"])
+    per_rank = [1e3 * local / steps]
+    if use_dist:
+        tot = torch.tensor([cand], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        cand = float(tot.item())
+        allr = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, torch.tensor([per_rank[0]], dtype=torch.float64, device=dev))
+        per_rank = allr.cpu().tolist()
+    res = {"workload": (f"synthetic {shape['n_views']} views x {shape['n_segs']} segs/view in total, {shape['n_neighbors']} neighbours, "
+                        "matched topk=10" + ("" if small else ", 4 rooms (BASELINE configs[2])")),
+           "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
+           "value": cand * steps / elapsed, "unit": "candidates/s",
+           "step_with_merge_and_tail_ms": None if note else 1e3 * full / n_full, "note": note,
+           "ms_per_step_per_rank": per_rank, "tracks_rank0": st["tracks"] if rank == 0 else None, "candidates": cand}
+    del ctx
+    return res
+
+
 _REAL_STDOUT = None
 
 
@@ -213,6 +316,12 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extras (batches in flight, exhaustive leg): profiling runs want the main kernels only")
+    ap.add_argument("--strong-leg", default="auto", choices=["auto", "on", "off"],
+                    help="BASELINE config 3 as a strong-scaling leg of the same run (`strong_config3` in the line); auto = "
+                         "with the default workload")
+    ap.add_argument("--sustain-s", type=float, default=2.0,
+                    help="after the timed region: the same step looped for about this long (sustained_ms_per_step; an "
+                         "outside observer -- rocm-smi -- sees the device busy); 0 = off")
     args = ap.parse_args()
     if args.config3:
         args.scaling, args.views, args.segs, args.rooms, args.gt, args.seed = "strong", 1000, 1000, 4, 3000, 1
@@ -497,6 +606,43 @@ def main():
                       "images_per_rank": per_rank_imgs, "allgather_alone_us": allgather_us},
             "device_source_hash": device_source_hash(),
         }
+
+    # ---- the same step, sustained: the timed region above is a few milliseconds of a process that runs for tens of
+    # seconds; this loop keeps the device on the step for --sustain-s so that an observer outside the process (the driver's
+    # SMI sampler) sees it busy, and reports what the step costs when it is not a burst ----
+    sustained = None
+    if args.sustain_s > 0 and not args.no_extras:
+        n_s = max(args.steps, int(args.sustain_s * 1e3 / max(ms_per_step, 1e-3)))
+        if use_dist:
+            t_n = torch.tensor([n_s], dtype=torch.int64, device=dev)
+            dist.broadcast(t_n, 0)
+            n_s = int(t_n.item())
+        sync()
+        ts0 = time.perf_counter()
+        for _ in range(n_s):
+            step()
+        sync()
+        el_s = time.perf_counter() - ts0
+        if use_dist:
+            t_s = torch.tensor([el_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_s, op=dist.ReduceOp.MAX)
+            el_s = float(t_s.item())
+        sustained = {"steps": n_s, "seconds": el_s, "sustained_ms_per_step": 1e3 * el_s / n_s}
+        if pending[0] is not None:
+            pending[0].wait()
+            torch.cuda.synchronize(dev)
+    if out is not None and sustained is not None:
+        out["sustained_ms_per_step"] = sustained["sustained_ms_per_step"]
+        out["sustained"] = sustained
+
+    # ---- the strong-scaling leg: BASELINE config 3 over the same ranks (every rank takes part) ----
+    if args.mode == "matched" and (args.strong_leg == "on" or (args.strong_leg == "auto" and default_wl and not args.no_extras)):
+        try:
+            sc3 = strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist)
+        except Exception as e:  # an extra: never lose the main line over it
+            sc3 = {"error": f"{type(e).__name__}: {e}"}
+        if out is not None:
+            out["strong_config3"] = sc3
 
     # ---- extra (not `value`): independent batches in flight, N = 1 ----
     # A service that triangulates independent scenes keeps more than one batch in flight; two contexts (each

@@ -13,11 +13,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_has_the_contract_fields(gpu_lib):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                          "--views", "12", "--segs", "60", "--neighbors", "5"],
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
+                          "--views", "12", "--segs", "60", "--neighbors", "5", "--strong-leg", "on", "--sustain-s", "0.2"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT,
+                         env=dict(os.environ, LT_BENCH_STRONG_SCENE="30,80,6"))
     assert res.returncode == 0, res.stderr[-2000:]
     line = res.stdout.strip().splitlines()[-1]
     d = json.loads(line)
+    # one run prints the weak figure and the strong-scaling leg (BASELINE config 3; a small scene here), and a sustained one
+    sc3 = d["strong_config3"]
+    assert "error" not in sc3, sc3
+    assert sc3["scaling"] == "strong" and sc3["n_gpus"] == 1 and sc3["ms_per_step"] > 0 and sc3["value"] > 0
+    assert sc3["step_with_merge_and_tail_ms"] > sc3["ms_per_step"] and len(sc3["ms_per_step_per_rank"]) == 1
+    assert sc3["tracks_rank0"] > 0
+    assert d["sustained_ms_per_step"] > 0 and d["sustained"]["seconds"] >= 0.15
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -44,9 +52,12 @@ def test_bench_collective_path_one_rank(gpu_lib):
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
                           "--gpus", "1", "--steps", "3", "--warmup", "1", "--views", "12", "--segs", "60",
-                          "--neighbors", "5", "--no-cpu-baseline"],
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT, env=env)
+                          "--neighbors", "5", "--no-cpu-baseline", "--strong-leg", "on", "--sustain-s", "0.2"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT,
+                         env=dict(env, LT_BENCH_STRONG_SCENE="30,80,6"))
     assert res.returncode == 0, res.stderr[-2000:]
     d = json.loads(res.stdout.strip().splitlines()[-1])
+    assert "error" not in d["strong_config3"] and d["strong_config3"]["ms_per_step"] > 0
+    assert d["sustained_ms_per_step"] > 0
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["counts"]["candidates"] > 0 and d["tracks_whole_scene"] > 0
