@@ -248,6 +248,32 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
     except Exception as e:
         note = f"{type(e).__name__}: {e}"
     full = rmax(time.perf_counter() - tf0)
+    # ... and PIPELINED: rank 0 enqueues the device half of step k's tail, then step k + 1, and does the host half of
+    # step k's tail (graph, union-find, aggregation) while the device works on step k + 1 (lt_compute_tracks_begin / _end)
+    over, over_note = None, None
+    if note is None:
+        try:
+            def merge_and_begin():
+                ctx.sync()
+                if world > 1:
+                    ltdist.merge_shards_device(ctx, node_range, rank, world, dev)
+                if rank == 0:
+                    ctx.compute_tracks_begin()
+            sync()
+            step()
+            merge_and_begin()
+            to0 = time.perf_counter()
+            for _ in range(n_full):
+                step()
+                if rank == 0:
+                    ctx.compute_tracks_end()
+                merge_and_begin()
+            if rank == 0:
+                ctx.compute_tracks_end()
+            sync()
+            over = rmax(time.perf_counter() - to0)
+        except Exception as e:
+            over_note = f"{type(e).__name__}: {e}"
     if pending[0] is not None:
         pending[0].wait()
         torch.cuda.synchronize(dev)
@@ -266,6 +292,8 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
            "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
            "value": cand * steps / elapsed, "unit": "candidates/s",
            "step_with_merge_and_tail_ms": None if note else 1e3 * full / n_full, "note": note,
+           "step_with_merge_and_tail_overlapped_ms": None if over is None else 1e3 * over / n_full,
+           "overlapped_note": over_note or "the host half of step k's tail (rank 0) runs while the device works on step k + 1",
            "ms_per_step_per_rank": per_rank, "tracks_rank0": st["tracks"] if rank == 0 else None, "candidates": cand}
     del ctx
     return res

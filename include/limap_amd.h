@@ -167,6 +167,14 @@ int lt_flush(lt_ctx *ctx);
 
 /* ComputeLineTracks() -- global_line_triangulator.cc:353-359 */
 int lt_compute_tracks(lt_ctx *ctx);
+/* The same in two halves, for a caller that streams steps (rank 0 of a multi-GPU job; no reference counterpart):
+ * _begin enqueues the device half of the tail behind the resident run -- valid-edge keys, sort, similarities, the graph
+ * nodes' records into page-locked memory -- and returns; the caller may then enqueue the NEXT run (lt_run_device_async);
+ * _end waits for the tail's own event, not for that run, and does the host half (graph, union-find, aggregation:
+ * global_line_triangulator.cc:234-351) while the device works on the next step.  Needs the device form of the tail
+ * (results resident, min_num_outer_edges == 0); lt_compute_tracks() == _begin + _end. */
+int lt_compute_tracks_begin(lt_ctx *ctx);
+int lt_compute_tracks_end(lt_ctx *ctx);
 
 /* CountImages / CountLines -- base_line_triangulator.h:84-87 */
 int64_t lt_count_images(lt_ctx *ctx);

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "lt_unset_ranges", "lt_init", "lt_init_vp", "lt_set_bipartites", "lt_set_sfm_points", "lt_init_device", "lt_refresh_scene_device", "lt_set_scene_chunks",
     "lt_refresh_scene_chunks", "lt_triangulate_image", "lt_triangulate_image_rows", "lt_triangulate_all_rows",
     "lt_triangulate_image_exhaustive", "lt_upload", "lt_run_device", "lt_download", "lt_flush",
-    "lt_compute_tracks", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
+    "lt_compute_tracks", "lt_compute_tracks_begin", "lt_compute_tracks_end", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
     "lt_get_num_tris", "lt_get_valid_flags", "lt_num_valid_edges", "lt_get_valid_edges", "lt_num_all_tris", "lt_get_all_tris",
     "lt_num_tracks", "lt_num_track_members", "lt_get_tracks", "lt_image_results_size",
     "lt_export_image_results", "lt_import_image_results", "lt_shard_node_bytes", "lt_shard_count", "lt_shard_build", "lt_shard_export", "lt_shard_import", "lt_ts_from_ctx", "lt_ts_create", "lt_ts_destroy",
@@ -136,7 +136,8 @@ def load_library():
     L.lt_triangulate_image_rows.argtypes = [vp, C.c_int, C.c_int, i32p, C.POINTER(C.c_void_p), i64p]
     L.lt_triangulate_all_rows.argtypes = [vp, C.c_int, i32p, i64p, i32p, C.POINTER(C.c_void_p), i64p]
     L.lt_triangulate_image_exhaustive.argtypes = [vp, C.c_int, C.c_int, i32p]
-    for n in ("lt_upload", "lt_run_device", "lt_run_device_async", "lt_sync", "lt_download", "lt_flush", "lt_compute_tracks"):
+    for n in ("lt_upload", "lt_run_device", "lt_run_device_async", "lt_sync", "lt_download", "lt_flush", "lt_compute_tracks",
+              "lt_compute_tracks_begin", "lt_compute_tracks_end"):
         getattr(L, n).argtypes = [vp]
     for n in ("lt_count_images", "lt_num_nodes", "lt_num_valid_edges", "lt_num_all_tris", "lt_num_tracks",
               "lt_num_track_members"):
@@ -390,6 +391,14 @@ class Context:
 
     def compute_tracks(self):
         self.chk(self.L.lt_compute_tracks(self.h))
+
+    def compute_tracks_begin(self):
+        """Device half of ComputeLineTracks enqueued behind the resident run; the next run may be enqueued before
+        compute_tracks_end() does the host half (include/limap_amd.h: lt_compute_tracks_begin)."""
+        self.chk(self.L.lt_compute_tracks_begin(self.h))
+
+    def compute_tracks_end(self):
+        self.chk(self.L.lt_compute_tracks_end(self.h))
 
     # --- getters ---
     def num_nodes(self):

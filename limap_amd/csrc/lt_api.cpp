@@ -577,6 +577,8 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_round_count};
   // (DevBuf releases itself when the context is deleted below; the list only makes the order explicit)
   lt_host::host_block_release(ctx->h_pinned_blk);
+  if (ctx->tail_pend.active) lt_host::host_block_release(ctx->tail_pend.hb);  // a tail begun and never collected
+  if (ctx->ev_tail) (void)hipEventDestroy(ctx->ev_tail);
   lt_host::host_block_release(ctx->best_c_blk);
   lt_host::host_block_release(ctx->init_blk);
   for (DevBuf *b : bufs) b->release();

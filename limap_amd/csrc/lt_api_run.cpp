@@ -470,8 +470,15 @@ int lt_run_device_async(lt_ctx *ctx) {
       // whole run is enqueued without a host round trip (the count then arrives with the error flag);
       // otherwise (or with LT_TEST_SYNC_COUNT) one 8-byte copy + stream sync fetches the exact count.
       const long long bound = P;
-      constexpr long long kCountFreeBytes = 8ll << 30;
-      const long long per_cand = (long long)(sizeof(CRec) + 8 + 8 + 4 + 4) + (long long)cand_meta_bytes();
+      // (288 GB of HBM: a sixth of it may go to bound-sized arrays before a run pays a host round trip for its count --
+      // at 2e8 match rows the bound costs 20 GB, and the round trip kept lt_run_device_async from returning before the
+      // generation stage had finished, i.e. from being asynchronous at all)
+      constexpr long long kCountFreeBytes = 48ll << 30;
+      // per candidate of the bound: permutation or moved record (LT_TEST_PLACE_COPY), score, flag, node, scoring prologue
+      // record, and the pair slots of the split scoring form (256 entries of 16 bytes per tile of 64)
+      const bool perm_bound = !test_switch("LT_TEST_PLACE_COPY");
+      const long long per_cand = (perm_bound ? 4 : (long long)(sizeof(CRec) + 8)) + 8 + 4 + 4 + (long long)cand_meta_bytes() +
+                                 (long long)score_split_entry_bytes() * 256 / 64;
       if (extras) {
         C_known = staged_total;  // the counting run of stage B already brought the count to the host
       } else if (ctx->h_pinned && bound * per_cand <= kCountFreeBytes && !test_switch("LT_TEST_SYNC_COUNT")) {

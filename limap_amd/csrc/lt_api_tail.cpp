@@ -59,9 +59,14 @@ static void tail_build_keys(lt_ctx *ctx, int kb) {
 // sorted unique undirected edges + their similarities; the graph nodes' best candidates land in ctx->best_c etc.
 // Two host synchronisations: one for the number of valid edges (it sizes the sort), one at the end; the graph
 // nodes' records are written by the gather kernel straight into page-locked host memory.
+// Two halves since round 5: tail_device_enqueue leaves the device half of the tail in the stream behind the run it
+// belongs to (one host synchronisation inside, for the number of valid edges that sizes the sort) and records an event;
+// tail_device_collect waits for THAT EVENT only -- a later run may already be enqueued behind it -- and builds the graph
+// from the page-locked results.  lt_compute_tracks calls both; lt_compute_tracks_begin / _end let a caller that streams
+// steps put the next step's kernels between them, so that the host half of step k's tail runs while the device is busy
+// with step k + 1.
 extern "C++" {
-template <class AddEdge>
-static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
+static int tail_device_enqueue(lt_ctx *ctx) {
   LT_FINISH(ctx);
   static const bool trace = getenv("LT_TAIL_TRACE") != nullptr;
   double tp = now_ms();
@@ -92,6 +97,10 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
   lap("scan + sync (E)");
   ctx->E = E;
   ctx->C = ctx->C_last;
+  lt_ctx::TailPending &tp_ = ctx->tail_pend;
+  tp_ = lt_ctx::TailPending();
+  tp_.active = true;
+  tp_.E = E;
   if (E <= 0) return LT_OK;
   const size_t En = (size_t)E;
   if (!merged) ENSURE(ctx, ctx->d_tail_keys, 8 * En);
@@ -107,15 +116,15 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
   const size_t max_nodes = (size_t)std::min<long long>(G, 2 * E);
   const size_t o_pairs = 64, o_recs = o_pairs + 16 * En, o_nodes = o_recs + tail_rec_bytes() * max_nodes;
   lt_host::HostBlock hb = lt_host::host_block_acquire(o_nodes + 4 * max_nodes);
-  if (!hb.p) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the edge list");
-  struct Rel {
-    lt_host::HostBlock b;
-    ~Rel() { lt_host::host_block_release(b); }
-  } rel{hb};
+  if (!hb.p) {
+    tp_.active = false;
+    return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the edge list");
+  }
+  tp_.hb = hb;  // released by tail_device_collect
+  tp_.max_nodes = max_nodes; tp_.o_pairs = o_pairs; tp_.o_recs = o_recs; tp_.o_nodes = o_nodes; tp_.kb = kb;
   char *base = (char *)hb.p;
   long long *hn = (long long *)base;  // [0] graph nodes, [1] graph edges
   hn[0] = hn[1] = 0;
-  const unsigned long long *hpairs = (const unsigned long long *)(base + o_pairs);
   if (!merged) tail_build_keys(ctx, kb);
   if (launch_tail_sort(st, ctx->d_tail_tmp.p, sort_tmp, E, ctx->d_tail_keys.as<unsigned long long>(),
                        ctx->d_tail_skeys.as<unsigned long long>(), end_bit) != 0)
@@ -149,8 +158,39 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
     HIPCHK(ctx, hipMemcpyAsync(base + o_nodes, ctx->d_tail_nodes.p, 4 * max_nodes, hipMemcpyDeviceToHost, st));
   }
   HIPCHK(ctx, hipGetLastError());
+  if (!ctx->ev_tail) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventRecord(ctx->ev_tail, st));
   lap("enqueue");
-  HIPCHK(ctx, hipStreamSynchronize(st));
+  return LT_OK;
+}
+
+template <class AddEdge>
+static int tail_device_collect(lt_ctx *ctx, AddEdge &&add_edge) {
+  static const bool trace = getenv("LT_TAIL_TRACE") != nullptr;
+  double tp = now_ms();
+  auto lap = [&](const char *what) {
+    if (!trace) return;
+    double t = now_ms();
+    fprintf(stderr, "[tail]   %-16s %.3f ms\n", what, t - tp);
+    tp = t;
+  };
+  lt_ctx::TailPending &tp_ = ctx->tail_pend;
+  if (!tp_.active) return fail(ctx, LT_ERR_STATE, "internal: no device tail in flight");
+  tp_.active = false;
+  const long long E = tp_.E;
+  if (E <= 0) return LT_OK;
+  struct Rel {
+    lt_host::HostBlock b;
+    ~Rel() { lt_host::host_block_release(b); }
+  } rel{tp_.hb};
+  tp_.hb = lt_host::HostBlock();
+  const size_t max_nodes = tp_.max_nodes, o_pairs = tp_.o_pairs, o_recs = tp_.o_recs, o_nodes = tp_.o_nodes;
+  const int kb = tp_.kb;
+  char *base = (char *)rel.b.p;
+  long long *hn = (long long *)base;
+  const unsigned long long *hpairs = (const unsigned long long *)(base + o_pairs);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipEventSynchronize(ctx->ev_tail));
   lap("sync");
   const long long Nm = hn[0], Ne = hn[1];
   if (Nm < 0 || (size_t)Nm > max_nodes || Ne < 0 || Ne > E)
@@ -197,11 +237,32 @@ static int tail_from_device(lt_ctx *ctx, AddEdge &&add_edge) {
 }
 }  // extern "C++"
 
+int lt_compute_tracks_begin(lt_ctx *ctx) {
+  LT_RANGE("lt_compute_tracks_begin (device half of the tail enqueued)");
+  if (ctx->cfg.merging_strategy < 0 || ctx->cfg.merging_strategy > 2)  // global_line_triangulator.cc:314-316
+    return fail(ctx, LT_ERR_RUNTIME, "Error!The given merging strategy is not implemented");
+  if (ctx->tail_pend.active) return fail(ctx, LT_ERR_STATE, "lt_compute_tracks_begin: a tail is already in flight");
+  if (!tail_on_device(ctx))
+    return fail(ctx, LT_ERR_STATE, "lt_compute_tracks_begin needs the device form of the tail (results resident, "
+                                   "min_num_outer_edges == 0): call lt_compute_tracks instead");
+  lt_host::SpinPool::get(lt_host::row_workers()).wake();
+  int rc;
+  if (!ctx->uploaded && (rc = lt_upload(ctx))) return rc;
+  if (!ctx->ran && (rc = lt_run_device(ctx))) return rc;
+  ctx->valid_flags.assign((size_t)ctx->G, 1);
+  return tail_device_enqueue(ctx);
+}
+int lt_compute_tracks_end(lt_ctx *ctx) {
+  if (!ctx->tail_pend.active) return fail(ctx, LT_ERR_STATE, "lt_compute_tracks_end without lt_compute_tracks_begin");
+  return lt_compute_tracks(ctx);
+}
+
 int lt_compute_tracks(lt_ctx *ctx) {
   LT_RANGE("lt_compute_tracks (tail: edge set, similarities, union-find, aggregation)");
   if (ctx->cfg.merging_strategy < 0 || ctx->cfg.merging_strategy > 2)  // global_line_triangulator.cc:314-316
     return fail(ctx, LT_ERR_RUNTIME, "Error!The given merging strategy is not implemented");
-  const bool on_device = tail_on_device(ctx);
+  const bool in_flight = ctx->tail_pend.active;  // lt_compute_tracks_begin ran: the device half is (being) done
+  const bool on_device = in_flight || tail_on_device(ctx);
   if (ctx->shard_keys >= 0 && !on_device) {
     ctx->shard_keys = -1;
     return fail(ctx, LT_ERR_STATE, "shards were imported on the device (lt_shard_import), but the device form of the tail "
@@ -209,7 +270,9 @@ int lt_compute_tracks(lt_ctx *ctx) {
   }
   lt_host::SpinPool::get(lt_host::row_workers()).wake();  // the host half of the tail shares its loops with the team
   int rc;
-  if (on_device) {
+  if (in_flight) {
+    // (a later run may be enqueued behind the tail: nothing is flushed or waited for here)
+  } else if (on_device) {
     if (!ctx->uploaded && (rc = lt_upload(ctx))) return rc;
     if (!ctx->ran && (rc = lt_run_device(ctx))) return rc;
   } else {
@@ -249,8 +312,11 @@ int lt_compute_tracks(lt_ctx *ctx) {
   std::vector<unsigned long long> edges;
   std::vector<double> sims;
   if (on_device) {
-    ctx->valid_flags.assign((size_t)G, 1);
-    if ((rc = tail_from_device(ctx, add_edge))) return rc;
+    if (!in_flight) {
+      ctx->valid_flags.assign((size_t)G, 1);
+      if ((rc = tail_device_enqueue(ctx))) return rc;
+    }
+    if ((rc = tail_device_collect(ctx, add_edge))) return rc;
     lap("device edges+sims");
   } else {
   const int min_outer = ctx->cfg.min_num_outer_edges;

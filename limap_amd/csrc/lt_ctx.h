@@ -307,6 +307,15 @@ struct lt_ctx {
     double sim;
     int n1, n2;
   };
+  // device half of a tail that is enqueued but not collected yet (lt_compute_tracks_begin .. _end)
+  struct TailPending {
+    bool active = false;
+    long long E = 0;
+    lt_host::HostBlock hb;
+    size_t max_nodes = 0, o_pairs = 0, o_recs = 0, o_nodes = 0;
+    int kb = 0;
+  } tail_pend;
+  hipEvent_t ev_tail = nullptr;
   std::vector<int> tail_gmap;         // global node -> graph node, -1 outside a call
   std::vector<long long> tail_gnode;  // graph node -> global node
   std::vector<GEdge> tail_ge, tail_ge2;

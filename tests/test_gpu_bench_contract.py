@@ -25,6 +25,7 @@ def test_bench_line_has_the_contract_fields(gpu_lib):
     assert sc3["scaling"] == "strong" and sc3["n_gpus"] == 1 and sc3["ms_per_step"] > 0 and sc3["value"] > 0
     assert sc3["step_with_merge_and_tail_ms"] > sc3["ms_per_step"] and len(sc3["ms_per_step_per_rank"]) == 1
     assert sc3["tracks_rank0"] > 0
+    assert sc3["step_with_merge_and_tail_overlapped_ms"] > 0, sc3
     assert d["sustained_ms_per_step"] > 0 and d["sustained"]["seconds"] >= 0.15
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
