@@ -191,12 +191,21 @@ def gather_packed_to_rank0(ints, flts, rank, world, device):
     return [(gi[r][:int(all_sizes[r, 0])].cpu().numpy(), gf[r][:int(all_sizes[r, 1])].cpu().numpy()) for r in range(world)]
 
 
-def merge_shards_device(ctx, node_range, rank, world, device=None):
-    """Round 4: the shards' way to rank 0 WITHOUT the host -- every rank builds the undirected valid-edge keys of its
-    own nodes on its device, the per-node results are slices [g_lo, g_hi) of the arrays the device tail reads (images are
-    sharded in id order), and both travel as two flat buffers through ONE tensor `gather` each (sizes first, one small
-    all-gather); rank 0 copies them into place on its device (`lt_shard_import`) and its `compute_tracks()` then runs
-    the device form of the tail over the whole scene.  No per-image export, no numpy packing, no host tail.
+def merge_shards_device(ctx, node_range, rank, world, device=None, all_ranges=None, key_cap=None):
+    """The shards' way to rank 0 WITHOUT the host -- every rank builds the undirected valid-edge keys of its own nodes on
+    its device, the per-node results are slices [g_lo, g_hi) of the arrays the device tail reads (images are sharded in
+    id order); rank 0 copies what arrives into place on its device (`lt_shard_import`) and its `compute_tracks()` then
+    runs the device form of the tail over the whole scene.  No per-image export, no numpy packing, no host tail.
+
+    Since round 5 everything a rank sends is ONE blob -- a 64-byte header (key count, node range, truncation flag), the
+    node slices, the keys -- through ONE tensor `gather`:
+      * default: a small all-gather of (key count, node range) first, so that the blobs are padded to the largest shard
+        exactly: 2 collectives per merge (round 4: 3, the node slices and the keys as separate gathers);
+      * `all_ranges` (every rank's (g_lo, g_hi): the sharding is deterministic, every rank can compute it) together with
+        `key_cap` (keys per rank the blob has room for, the same number on every rank): no size exchange, the header
+        carries what rank 0 needs -- 1 collective.  A rank with more keys than `key_cap` cannot send them: it and rank 0
+        both raise after the gather (nobody hangs, the merge fails loudly); choose the capacity from a bound the job
+        knows (valid edges per node x nodes of the largest shard).
     node_range = (g_lo, g_hi): this rank's node range.  Under a gloo group the buffers are host tensors (the copies in
     `lt_shard_export` / `_import` take either).  Returns the number of keys merged on rank 0 (0 elsewhere)."""
     if world == 1:
@@ -208,30 +217,51 @@ def merge_shards_device(ctx, node_range, rank, world, device=None):
         device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     g_lo, g_hi = int(node_range[0]), int(node_range[1])
     n_keys = ctx.shard_count()
-    mine = torch.tensor([n_keys, g_lo, g_hi], dtype=torch.int64, device=device)
-    allv = torch.zeros(3 * world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(allv, mine)
-    allv = allv.cpu().numpy().reshape(world, 3)
-    total = int(allv[:, 0].sum())
-    ctx.shard_build(total if rank == 0 else n_keys)
+    one_collective = all_ranges is not None and key_cap is not None
+    if one_collective:
+        ranges = np.asarray(all_ranges, np.int64).reshape(world, 2)
+        max_keys = max(int(key_cap), 1)
+        counts = None
+    else:
+        mine = torch.tensor([n_keys, g_lo, g_hi], dtype=torch.int64, device=device)
+        allv = torch.zeros(3 * world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(allv, mine)
+        allv = allv.cpu().numpy().reshape(world, 3)
+        ranges, counts = allv[:, 1:3], allv[:, 0]
+        max_keys = max(int(counts.max()), 1)
     nb = ctx.shard_node_bytes()
-    max_nodes = max(int((allv[:, 2] - allv[:, 1]).max()), 1)
-    max_keys = max(int(allv[:, 0].max()), 1)
-    # rank 0 sends nothing: its own slices are already in place
-    t_nodes = torch.empty(max_nodes * nb, dtype=torch.uint8, device=device)
-    t_keys = torch.empty(max_keys * 8, dtype=torch.uint8, device=device)
-    if rank != 0:
-        ctx.shard_export(g_lo, g_hi, t_nodes.data_ptr(), t_keys.data_ptr())
-    g_nodes = [torch.empty_like(t_nodes) for _ in range(world)] if rank == 0 else None
-    g_keys = [torch.empty_like(t_keys) for _ in range(world)] if rank == 0 else None
-    dist.gather(t_nodes, g_nodes, dst=0)
-    dist.gather(t_keys, g_keys, dst=0)
+    max_nodes = max(int((ranges[:, 1] - ranges[:, 0]).max()), 1)
+    truncated = rank != 0 and n_keys > max_keys  # (rank 0 sends no keys: its own are already in place)
+    o_nodes, o_keys = 64, 64 + ((max_nodes * nb + 63) // 64) * 64
+    blob = torch.empty(o_keys + max_keys * 8, dtype=torch.uint8, device=device)
+    hdr = torch.tensor([n_keys, g_lo, g_hi, int(truncated), 0, 0, 0, 0], dtype=torch.int64)
+    blob[:64].copy_(hdr.view(torch.uint8))
+    if counts is not None:
+        ctx.shard_build(int(counts.sum()) if rank == 0 else n_keys)
+    elif rank != 0:
+        ctx.shard_build(n_keys)
+    if rank != 0 and not truncated:  # rank 0 sends nothing but its header: its own slices are already in place
+        ctx.shard_export(g_lo, g_hi, blob.data_ptr() + o_nodes, blob.data_ptr() + o_keys)
+    got = [torch.empty_like(blob) for _ in range(world)] if rank == 0 else None
+    dist.gather(blob, got, dst=0)
+    if truncated:
+        raise RuntimeError(f"merge_shards_device: rank {rank} has {n_keys} valid-edge keys, the blob has room for {max_keys} "
+                           "(key_cap): raise the capacity or let the merge exchange the sizes (key_cap=None)")
     if rank != 0:
         return 0
     if device.type == "cuda":
-        torch.cuda.synchronize(device)  # the gathered buffers are read on the context's own stream
+        torch.cuda.synchronize(device)  # the gathered blobs are read on the context's own stream
+    if counts is None:  # one collective: the headers carry the counts
+        heads = torch.stack([g[:64] for g in got]).cpu().numpy().view(np.int64).reshape(world, 8)
+        if heads[:, 3].any():
+            bad = [int(r) for r in np.nonzero(heads[:, 3])[0]]
+            raise RuntimeError(f"merge_shards_device: ranks {bad} could not send their keys (key_cap = {max_keys} too small)")
+        counts = heads[:, 0]
+        ctx.shard_build(int(counts.sum()))
+    total = int(counts.sum())
     for r in range(1, world):
-        ctx.shard_import(int(allv[r, 1]), int(allv[r, 2]), g_nodes[r].data_ptr(), int(allv[r, 0]), g_keys[r].data_ptr())
+        ctx.shard_import(int(ranges[r, 0]), int(ranges[r, 1]), got[r].data_ptr() + o_nodes, int(counts[r]),
+                         got[r].data_ptr() + o_keys)
     return total
 
 

@@ -69,11 +69,22 @@ def _worker(rank, world, port, q, backend="nccl", merge="host"):
             ctx.refresh_scene_chunks()   # the per-step path: invariants rebuilt straight from the receive buffer
         ctx.run_device()
         res = None
-        if merge == "device":
+        if merge in ("device", "device1", "device1_small"):
             # round 4: nothing is read back -- keys and node slices travel device to device (host tensors under gloo),
-            # rank 0's device tail runs over the whole scene
-            n_keys = ltdist.merge_shards_device(ctx, (int(sc.seg_off[a]), int(sc.seg_off[b])), rank, world,
-                                                dev if backend == "nccl" else None)
+            # rank 0's device tail runs over the whole scene.  "device1": the one-collective form (round 5: static node
+            # ranges + a key capacity, the counts ride in the blob's header); "device1_small": a capacity that does not
+            # hold -- the rank that cannot send and rank 0 both raise, nobody hangs
+            kw = {}
+            if merge != "device":
+                kw["all_ranges"] = [(int(sc.seg_off[g.bounds[r]]), int(sc.seg_off[g.bounds[r + 1]])) for r in range(world)]
+                kw["key_cap"] = 1 if merge == "device1_small" else 64 * 1024
+            try:
+                n_keys = ltdist.merge_shards_device(ctx, (int(sc.seg_off[a]), int(sc.seg_off[b])), rank, world,
+                                                    dev if backend == "nccl" else None, **kw)
+            except RuntimeError as e:
+                q.put((rank, ok, dict(error=str(e))))
+                dist.barrier()
+                return
             if rank == 0:
                 ctx.compute_tracks()
                 t = ctx.get_tracks()
@@ -151,3 +162,17 @@ def test_two_ranks_device_merge_on_one_gpu_gloo(gpu_lib, oracle):
     _check(out, 2, oracle)
     assert out[0][2]["n_keys"] > 0
 
+
+
+def test_two_ranks_one_collective_merge_on_one_gpu_gloo(gpu_lib, oracle):
+    """The merge as ONE gather (round 5): every rank knows every node range (the sharding is deterministic), the key
+    counts ride in the 64-byte header of the blob -- no size exchange.  Same tracks as the oracle's single-process run."""
+    out = _run(2, "gloo", merge="device1")
+    _check(out, 2, oracle)
+    assert out[0][2]["n_keys"] > 0
+
+
+def test_one_collective_merge_fails_loudly_when_the_keys_do_not_fit(gpu_lib):
+    out = _run(2, "gloo", merge="device1_small")
+    assert all("error" in r[2] for r in out), out
+    assert "key_cap" in out[1][2]["error"] and "could not send" in out[0][2]["error"]
