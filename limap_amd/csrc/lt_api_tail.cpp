@@ -12,9 +12,12 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------
 // Device half of the tail (lt_kernels_tail.hip): possible when the results of the whole scene are those of the run
 // that is still resident in HBM (one batch, nothing imported, nothing read back yet) and no node filter applies
-// (min_num_outer_edges == 0, the value of cfgs/triangulation/default.yaml:81).  LT_TAIL_HOST=1 forces the host form.
+// The node filter (min_num_outer_edges > 0, global_line_triangulator.cc:168-232) runs on the device too since round 5
+// (k_outer_filter) -- except over imported shards: it needs the DIRECTED valid edges of every node, and a shard brings
+// undirected keys.  LT_TAIL_HOST=1 forces the host form.
 static bool tail_on_device(const lt_ctx *ctx) {
-  if (test_switch("LT_TAIL_HOST") != nullptr || ctx->cfg.min_num_outer_edges > 0) return false;
+  if (test_switch("LT_TAIL_HOST") != nullptr) return false;
+  if (ctx->cfg.min_num_outer_edges > 0 && ctx->shard_keys >= 0) return false;
   if (!ctx->inited || ctx->job_mode == 0 || ctx->downloaded || ctx->job_imgs.empty()) return false;
   if (ctx->G <= 0 || ctx->G >= (1ll << 31)) return false;
   // results that live only on the host -- an earlier batch that was read back, imported shards -- rule the device form
@@ -101,7 +104,11 @@ static int tail_device_enqueue(lt_ctx *ctx) {
   tp_ = lt_ctx::TailPending();
   tp_.active = true;
   tp_.E = E;
-  if (E <= 0) return LT_OK;
+  if (E <= 0) {
+    // no valid edge anywhere: with a node filter every node falls short of min_num_outer_edges
+    if (ctx->cfg.min_num_outer_edges > 0 && !merged) ctx->valid_flags.assign((size_t)G, 0);
+    return LT_OK;
+  }
   const size_t En = (size_t)E;
   if (!merged) ENSURE(ctx, ctx->d_tail_keys, 8 * En);
   ENSURE(ctx, ctx->d_tail_skeys, 8 * En); ENSURE(ctx, ctx->d_tail_sims, 8 * En);
@@ -129,10 +136,33 @@ static int tail_device_enqueue(lt_ctx *ctx) {
   if (launch_tail_sort(st, ctx->d_tail_tmp.p, sort_tmp, E, ctx->d_tail_keys.as<unsigned long long>(),
                        ctx->d_tail_skeys.as<unsigned long long>(), end_bit) != 0)
     return fail(ctx, LT_ERR_HIP, "rocprim radix sort failed");
+  // filterNodeByNumOuterEdges (:168-232) on the resident run: passes of k_outer_filter until one changes nothing (the
+  // flag comes back every four passes; a scene needs a handful)
+  const unsigned char *d_flags = nullptr;
+  if (ctx->cfg.min_num_outer_edges > 0 && !merged) {
+    ENSURE(ctx, ctx->d_outer_flags, (size_t)G + 64);
+    unsigned char *fl = ctx->d_outer_flags.as<unsigned char>();
+    int *d_changed = reinterpret_cast<int *>(fl + (((size_t)G + 15) / 16) * 16);
+    HIPCHK(ctx, hipMemsetAsync(fl, 1, (size_t)G, st));
+    for (int round = 0; round < (1 << 20); ++round) {
+      HIPCHK(ctx, hipMemsetAsync(d_changed, 0, 4, st));
+      for (int k = 0; k < 4; ++k)
+        launch_outer_filter(st, G, ctx->d_tri_off.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
+                            ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(), ctx->d_seg_off.as<long long>(),
+                            ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr, ctx->cfg.min_num_outer_edges, fl,
+                            d_changed);
+      int changed = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      if (!changed) break;
+    }
+    d_flags = fl;
+    tp_.filtered = true;
+  }
   LinkCfg3 l3 = make_l3(ctx->cfg);
   l3.use_angle = 1; l3.use_overlap = 1; l3.use_perp = 0; l3.use_innerseg = 1; l3.use_scaleinv = 0;  // line_linker.h:123-129
   launch_tail_sims(st, E, ctx->d_tail_skeys.as<unsigned long long>(), ctx->d_ntris.as<int>(), ctx->d_best_c.as<Cand>(), l3,
-                   kb, ctx->d_tail_sims.as<double>(), ctx->d_tail_mark.as<unsigned>(), ctx->d_tail_keep.as<unsigned>());
+                   kb, ctx->d_tail_sims.as<double>(), ctx->d_tail_mark.as<unsigned>(), ctx->d_tail_keep.as<unsigned>(), d_flags);
   if (launch_scan_u32_to_i64(st, ctx->d_tail_tmp.p, scan_tmp2, E + 1, ctx->d_tail_keep.as<unsigned>(),
                              ctx->d_tail_kpos.as<long long>()) != 0 ||
       launch_scan_u32_to_i64(st, ctx->d_scan_tmp.p, scan_tmp, G + 1, ctx->d_tail_mark.as<unsigned>(),
@@ -191,6 +221,8 @@ static int tail_device_collect(lt_ctx *ctx, AddEdge &&add_edge) {
   const unsigned long long *hpairs = (const unsigned long long *)(base + o_pairs);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipEventSynchronize(ctx->ev_tail));
+  if (tp_.filtered)  // valid_flags_ of the reference (GetAllValidBestTris ... read them)
+    HIPCHK(ctx, hipMemcpy(ctx->valid_flags.data(), ctx->d_outer_flags.p, (size_t)ctx->G, hipMemcpyDeviceToHost));
   lap("sync");
   const long long Nm = hn[0], Ne = hn[1];
   if (Nm < 0 || (size_t)Nm > max_nodes || Ne < 0 || Ne > E)

@@ -314,7 +314,9 @@ struct lt_ctx {
     lt_host::HostBlock hb;
     size_t max_nodes = 0, o_pairs = 0, o_recs = 0, o_nodes = 0;
     int kb = 0;
+    bool filtered = false;  // the node filter ran on the device: valid_flags come from d_outer_flags
   } tail_pend;
+  DevBuf d_outer_flags;     // k_outer_filter: one byte per node (+ the "changed" word behind them)
   hipEvent_t ev_tail = nullptr;
   std::vector<int> tail_gmap;         // global node -> graph node, -1 outside a call
   std::vector<long long> tail_gnode;  // graph node -> global node

@@ -92,7 +92,9 @@ void launch_tail_keys(hipStream_t st, long long G, const long long *tri_off, con
 int launch_tail_sort(hipStream_t st, void *temp, size_t temp_bytes, long long E, const unsigned long long *keys_in,
                      unsigned long long *keys_out, int end_bit);
 void launch_tail_sims(hipStream_t st, long long E, const unsigned long long *skeys, const int *n_tris, const Cand *best_c,
-                      const LinkCfg3 &cfg, int kb, double *sims, unsigned *mark, unsigned *keep);
+                      const LinkCfg3 &cfg, int kb, double *sims, unsigned *mark, unsigned *keep, const unsigned char *flags);
+void launch_outer_filter(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag, const CRec *cand,
+                         const long long *seg_off, const unsigned *perm, int min_outer, unsigned char *flags, int *changed);
 void launch_tail_compact(hipStream_t st, long long E, const unsigned long long *skeys, const double *sims,
                          const unsigned *keep, const long long *kpos, void *out_pairs, long long *n_out);
 void launch_tail_gather(hipStream_t st, long long G, const unsigned *mark, const long long *pos, const Cand *best_c,

@@ -42,12 +42,43 @@ k_tail_keys(long long G, const long long *__restrict__ tri_off, const unsigned *
   }
 }
 
+// filterNodeByNumOuterEdges (global_line_triangulator.cc:168-232): a node stays valid while at least min_outer of its valid
+// edges lead to valid nodes.  The reference removes nodes through a queue; the result is the greatest fixed point of
+// "every kept node keeps min_outer outgoing edges into the kept set", which any monotone removal order reaches: here every
+// pass clears the nodes that fall short against the current flags (in place), until a pass changes nothing.
+__global__ void __launch_bounds__(256)
+k_outer_filter(long long G, const long long *__restrict__ tri_off, const unsigned *__restrict__ edge_flag,
+               const CRec *__restrict__ cand, const long long *__restrict__ seg_off, const unsigned *__restrict__ perm,
+               int min_outer, unsigned char *flags, int *__restrict__ changed) {
+  const long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (g >= G) return;
+  if (!flags[g]) return;
+  const int lane = lane_id();
+  const long long off = tri_off[g];
+  const int n = (int)(tri_off[g + 1] - off);
+  int cnt = 0;
+  for (int i0 = 0; i0 < n && cnt < min_outer; i0 += 64) {
+    const int i = i0 + lane;
+    bool f = (i < n) && edge_flag[off + i];
+    if (f) {
+      const int2 l = *reinterpret_cast<const int2 *>(&cand[perm ? (long long)perm[off + i] : off + i].nb_slot);
+      const long long h = seg_off[(int)((unsigned)l.x >> 8)] + (long long)l.y;
+      f = flags[h] != 0;
+    }
+    cnt += (int)__popcll(__ballot(f));
+  }
+  if (cnt < min_outer && lane == 0) {
+    flags[g] = 0;
+    *changed = 1;
+  }
+}
+
 // similarity of every distinct key (the first of a run of equal keys; the others get -1), and the nodes that enter
 // the graph (score != 0, global_line_triangulator.cc:284-285)
 __global__ void __launch_bounds__(256)
 k_tail_sims(long long E, const unsigned long long *__restrict__ skeys, const int *__restrict__ n_tris,
             const Cand *__restrict__ best_c, LinkCfg3 cfg, int kb, double *__restrict__ sims,
-            unsigned *__restrict__ mark, unsigned *__restrict__ keep) {
+            unsigned *__restrict__ mark, unsigned *__restrict__ keep, const unsigned char *__restrict__ flags) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i == E) keep[E] = 0u;  // the scan of the flags runs over E + 1 entries
   if (i >= E) return;
@@ -59,8 +90,9 @@ k_tail_sims(long long E, const unsigned long long *__restrict__ skeys, const int
   }
   const long long a = (long long)(key >> kb), b = (long long)(key & ((1ull << kb) - 1ull));
   double s = 0.0;
-  // a node without any candidate holds a value-initialised TriTuple in the reference: its zero line scores 0
-  if (n_tris[a] > 0 && n_tris[b] > 0) {
+  // a node without any candidate holds a value-initialised TriTuple in the reference: its zero line scores 0; an edge
+  // with a filtered endpoint (flags: k_outer_filter) is not in the reference's edge set at all (:243-261)
+  if (n_tris[a] > 0 && n_tris[b] > 0 && (!flags || (flags[a] && flags[b]))) {
     const Cand ca = best_c[a];
     const Cand cb = best_c[b];
     L3 la{mk3(ca.s[0], ca.s[1], ca.s[2]), mk3(ca.e[0], ca.e[1], ca.e[2])};
@@ -145,10 +177,16 @@ int launch_tail_sort(hipStream_t st, void *temp, size_t temp_bytes, long long E,
 }
 
 void launch_tail_sims(hipStream_t st, long long E, const unsigned long long *skeys, const int *n_tris, const Cand *best_c,
-                      const LinkCfg3 &cfg, int kb, double *sims, unsigned *mark, unsigned *keep) {
+                      const LinkCfg3 &cfg, int kb, double *sims, unsigned *mark, unsigned *keep, const unsigned char *flags) {
   if (E > 0)
     hipLaunchKernelGGL(k_tail_sims, dim3((unsigned)((E + 1 + 255) / 256)), dim3(256), 0, st, E, skeys, n_tris, best_c,
-                       cfg, kb, sims, mark, keep);
+                       cfg, kb, sims, mark, keep, flags);
+}
+void launch_outer_filter(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag, const CRec *cand,
+                         const long long *seg_off, const unsigned *perm, int min_outer, unsigned char *flags, int *changed) {
+  if (G > 0)
+    hipLaunchKernelGGL(k_outer_filter, dim3((unsigned)((G * 64 + 255) / 256)), dim3(256), 0, st, G, tri_off, edge_flag, cand,
+                       seg_off, perm, min_outer, flags, changed);
 }
 void launch_tail_compact(hipStream_t st, long long E, const unsigned long long *skeys, const double *sims,
                          const unsigned *keep, const long long *kpos, void *out_pairs, long long *n_out) {

@@ -210,6 +210,10 @@ def merge_shards_device(ctx, node_range, rank, world, device=None, all_ranges=No
     `lt_shard_export` / `_import` take either).  Returns the number of keys merged on rank 0 (0 elsewhere)."""
     if world == 1:
         return 0
+    # (checked before any collective, on a value every rank shares: nobody is left waiting in a gather)
+    if int(getattr(ctx.cfg, "min_num_outer_edges", 0)) > 0:
+        raise ValueError("merge_shards_device: the node filter (min_num_outer_edges > 0) needs the directed valid edges of "
+                         "every node, a shard brings undirected keys: use merge_shards_on_rank0 for this configuration")
     import torch
     import torch.distributed as dist
     if device is None:

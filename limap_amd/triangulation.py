@@ -160,6 +160,10 @@ except Exception:  # pragma: no cover
     _limap_base = None
 
 
+# (the shim links liblimap_amd.so, which needs a HIP runtime: torch's bundled copy has to be in the process FIRST, or a
+# later `import torch` loads a second runtime that finds no GPU -- _capi._preload_torch_hip_runtime; round 5: the preload
+# only ran in load_library(), i.e. after this import, and `limap_amd` before `torch` broke torch.cuda)
+_capi._preload_torch_hip_runtime()
 try:  # the pybind11 shim over the C ABI (limap_amd/csrc/lt_pybind.cpp): the per-image calls and ComputeLineTracks
     from . import _lt_pybind as _pb
 except ImportError:  # pragma: no cover

@@ -63,10 +63,44 @@ def test_two_half_tail_protocol_errors(gpu_lib):
     with pytest.raises(RuntimeError, match="already in flight"):
         ctx.compute_tracks_begin()
     ctx.compute_tracks_end()
-    # the host form of the tail (a node filter is configured) has no two-half form
+    # the host form of the tail (forced by the developer switch) has no two-half form
+    import os
+    os.environ["LT_TAIL_HOST"] = "1"
+    try:
+        c2 = _ctx(sc, syn.default_triangulation_cfg())
+        with pytest.raises(RuntimeError, match="device form of the tail"):
+            c2.compute_tracks_begin()
+        c2.compute_tracks()
+    finally:
+        del os.environ["LT_TAIL_HOST"]
+
+
+@pytest.mark.parametrize("min_outer", [1, 2, 3])
+def test_node_filter_on_the_device(gpu_lib, oracle, min_outer):
+    """filterNodeByNumOuterEdges (global_line_triangulator.cc:168-232) in the device form of the tail (k_outer_filter,
+    round 5): valid flags, tracks and their lines equal the oracle's and the host form's -- one-call and two-half tail."""
+    import os
+    from helpers import compare_tracks, run_oracle
+    sc = syn.make_scene(n_views=16, n_segs=120, n_neighbors=7, seed=33)
     cfg = syn.default_triangulation_cfg()
-    cfg["min_num_outer_edges"] = 1
-    c2 = _ctx(sc, cfg)
-    with pytest.raises(RuntimeError, match="device form of the tail"):
-        c2.compute_tracks_begin()
-    c2.compute_tracks()
+    cfg["min_num_outer_edges"] = min_outer
+    cfg["max_valid_conns"] = 4
+    O = run_oracle(oracle, sc, cfg)
+    ot = O.ComputeLineTracks()
+    dev = _ctx(sc, cfg)
+    dev.run_device(wait=False)
+    dev.compute_tracks_begin()
+    dev.run_device(wait=False)
+    dev.compute_tracks_end()
+    got = dev.get_tracks()
+    compare_tracks(got, ot)
+    flags_dev = np.asarray(dev.get_valid_flags())
+    assert 0 < int(flags_dev.sum()) < len(flags_dev), "the filter should remove some nodes and keep some"
+    os.environ["LT_TAIL_HOST"] = "1"
+    try:
+        host = _ctx(sc, cfg)
+        host.compute_tracks()
+        _same(host.get_tracks(), got)
+        assert np.array_equal(np.asarray(host.get_valid_flags()), flags_dev)
+    finally:
+        del os.environ["LT_TAIL_HOST"]
