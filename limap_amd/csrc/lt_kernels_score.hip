@@ -1037,13 +1037,14 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
       if (sc > 0.0)
         atomicMax(&S[(k * max_nb + (nbs_j & 0xFF)) * 64 + (int)e.z], (unsigned long long)__double_as_longlong(sc));
     };
-    if (has0) eval(e0, k0);
+    // (ONE inlined instance of pair_score for the unit's list: the first entry was fetched with the unit's first load level)
     const int n_it = total > (wave << 6) ? (total - (wave << 6) + kThreads - 1) / kThreads : 0;  // of this wave (wave-uniform)
-    for (int it = 1; it < n_it; ++it) {
-      if (it == n_it3 - 1) claim();
+    for (int it = 0; it < n_it; ++it) {
+      if (it > 0 && it == n_it3 - 1) claim();
       const int p = tid + it * kThreads;
-      int k;
-      const uint4 e = entry_of(p < total ? p : 0, k);
+      int k = k0;
+      uint4 e = e0;
+      if (it > 0) e = entry_of(p < total ? p : 0, k);
       if (p < total) eval(e, k);
     }
     for (int k = 0; k < nt; ++k) {

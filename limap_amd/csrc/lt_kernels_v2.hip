@@ -1037,6 +1037,9 @@ k_tri_rounds(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRe
   }
 }
 
+#ifndef LT_PLACE_WG_PER_CU
+#define LT_PLACE_WG_PER_CU 8
+#endif
 // Placement for the round lists of k_tri_rounds: as k_place, one wave per round; a (block, line) run that begins in an
 // earlier round of the block is followed back through the previous rounds' lists.
 __global__ void __launch_bounds__(256)
@@ -1524,7 +1527,7 @@ void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long
           hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
         n_cu = 256;
     }
-    hipLaunchKernelGGL(k_place_rounds, dim3((unsigned)std::min<long long>(n_blk, (long long)n_cu * 8)), dim3(256), 0, st, m_off,
+    hipLaunchKernelGGL(k_place_rounds, dim3((unsigned)std::min<long long>(n_blk, (long long)n_cu * LT_PLACE_WG_PER_CU)), dim3(256), 0, st, m_off,
                        blk_img, seg_off, blk_line_base, base_bl, tri_off, st_r, st_unc, st_key, cand, cand_unc, cand_node, perm,
                        blk_surv, blk_rnd0, round_count, n_blk);
     return;
