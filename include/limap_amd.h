@@ -159,7 +159,10 @@ int lt_run_device(lt_ctx *ctx); /* kernels only, inputs resident in HBM; repeata
  * completed AFTER the new run has been enqueued, and ITS status is the return value (a streaming caller keeps
  * the device busy across the host's end-of-run bookkeeping); lt_sync completes the run in flight and returns
  * its status.  Every other entry point that touches results or inputs completes it first.  No reference
- * counterpart (the reference's TriangulateImage is synchronous host code). */
+ * counterpart (the reference's TriangulateImage is synchronous host code).
+ * Two configurations make the call SYNCHRONOUS in part: with extra proposals (VP, points) stage B runs twice and the host
+ * waits for the candidate count between the two runs (it sizes the staging exactly; this also drains a run that was still
+ * in flight); and when the bound-sized arrays of a batch would exceed 48 GB the exact count is fetched before placement. */
 int lt_run_device_async(lt_ctx *ctx);
 int lt_sync(lt_ctx *ctx);
 int lt_download(lt_ctx *ctx);   /* per-node results -> host */

@@ -36,12 +36,20 @@ struct RowJob {
       J.line0[b] = B.n > 0 ? (int)B.src[0] : 0;
       J.ovf_off[b] = -1;
       if (rs.irregular && !err) {  // not the matchers' shape: the plain form, line | neighbour line << 16
-        static thread_local std::vector<unsigned> tmp;
-        tmp.resize((size_t)B.n);
-        (void)lt::pack_rows(B.src, B.n, tmp.data());
-        std::lock_guard<std::mutex> lk(*J.ovf_mu);
-        J.ovf_off[b] = (long long)J.ovf->size();
-        J.ovf->insert(J.ovf->end(), tmp.begin(), tmp.end());
+        // (the only allocations of the pass: out of memory becomes the block's error code 4 -- on a pool worker an
+        // exception would be swallowed and the chunk never counted as done; on the caller it would cross extern "C")
+        try {
+          static thread_local std::vector<unsigned> tmp;
+          tmp.resize((size_t)B.n);
+          (void)lt::pack_rows(B.src, B.n, tmp.data());
+          std::lock_guard<std::mutex> lk(*J.ovf_mu);
+          J.ovf_off[b] = (long long)J.ovf->size();
+          J.ovf->insert(J.ovf->end(), tmp.begin(), tmp.end());
+        } catch (const std::exception &) {
+          err = 4;
+          J.bad[b] = err;
+          J.ovf_off[b] = -1;
+        }
       }
       uns_t |= rs.unsorted;
       if (err) J.bad_any.store(1, std::memory_order_relaxed);
@@ -157,6 +165,7 @@ int lt_triangulate_image_rows(lt_ctx *ctx, int img_id, int n_nb, const int32_t *
     if (!bad[k]) continue;
     ctx->h_m_pairs.grow_to(base);
     ctx->h_ovf.resize(ovf_base);
+    if (bad[k] & 4) return fail(ctx, LT_ERR_RUNTIME, "out of host memory while buffering the match rows");
     if (bad[k] & 1)  // base_line_triangulator.cc:87-94
       return fail(ctx, LT_ERR_RUNTIME,
                   "IndexError! Out-of-index matches exist between image (img_id = " + std::to_string(img_id) +
@@ -383,6 +392,7 @@ int lt_triangulate_all_rows(lt_ctx *ctx, int n_images, const int32_t *img_ids, c
     ctx->h_m_pairs.grow_to(base);
     ctx->h_ovf.resize(ovf_base);
     const RowBlk &B = blks[(size_t)b];
+    if (bad[(size_t)b] & 4) return fail(ctx, LT_ERR_RUNTIME, "out of host memory while buffering the match rows");
     if (bad[(size_t)b] & 1)  // base_line_triangulator.cc:87-94
       return fail(ctx, LT_ERR_RUNTIME,
                   "IndexError! Out-of-index matches exist between image (img_id = " + std::to_string(B.img_id) +

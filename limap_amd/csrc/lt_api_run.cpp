@@ -289,6 +289,18 @@ int lt_run_device_async(lt_ctx *ctx) {
   if (!ctx->uploaded) return fail(ctx, LT_ERR_STATE, "lt_run_device before lt_upload");
   if (!ctx->h_pinned) LT_FINISH(ctx);  // no pinned result slots: nothing may stay in flight
   ctx->shard_keys = ctx->shard_own_keys = -1;  // a new run: nothing of an earlier merge is pending
+  // host copies of the job's images from an earlier read-back are superseded by this run: forget them, so that a query
+  // after the device form of the tail (which refreshes the graph's nodes only) cannot see what an earlier configuration
+  // left behind
+  if (ctx->inited && !ctx->best_c_set.empty())
+    for (int idx : ctx->job_imgs)
+      if (ctx->best_c_set[(size_t)idx] == 1) {
+        ctx->best_c_set[(size_t)idx] = 0;
+        for (long long g = ctx->seg_off[idx]; g < ctx->seg_off[idx + 1]; ++g) {
+          if ((size_t)g < ctx->has_best.size()) ctx->has_best[(size_t)g] = 0;
+          if ((size_t)g < ctx->valid_edges.cnt.size()) ctx->valid_edges.cnt[(size_t)g] = 0;
+        }
+      }
   const int set = ctx->run_pending ? (ctx->pend_set ^ 1) : 0;
   if (ctx->h_pinned) std::memset(ctx->h_pinned + 8 * set, 0, 32);  // this set's result slots (its previous run is finished)
   if (set == 1 && !ctx->ev_b[0])

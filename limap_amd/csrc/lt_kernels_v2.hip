@@ -2,9 +2,15 @@
 // stage (see DESIGN.md section 3 for the map; lt_kernels.hip keeps the invariant builders, the
 // generic radix-sort grouping, the exhaustive generation and the selection kernels).
 //
+//   k_rows_starts + k_rows_transpose (upload) -> k_gates_ln + k_tri_rounds -> k_node_prefix + k_place_rounds
+//       HOT LOOP 1 in the LINE-SLOT form (round 5; the default for what limap's matchers write: sorted blocks with
+//       contiguous lines and at most 32 rows per line).  k_gates_ln: one lane per line of the image, the view-1 side of
+//       the gates once per lane, rows as 16-bit neighbour lines in (rank, line) order, the neighbour's gate table in
+//       LDS by DMA -> the block's dense survivor list.  k_tri_rounds: rounds of 64 survivors, persistent workgroups ->
+//       valid candidates per round.  k_place_rounds: the permutation into the reference's candidate order.
 //   k_gates + k_tri_rows
-//       HOT LOOP 1 in row (block) order.  k_gates: coalesced match rows, the neighbour's gate table
-//       staged in LDS, cheap three-way gates on every row -> ordered survivor lists.  k_tri_rows:
+//       HOT LOOP 1 in the ROW-SLOT form (blocks in any other shape; extra proposals).  k_gates: coalesced match rows, the
+//       neighbour's gate table staged in LDS, cheap three-way gates on every row -> ordered survivor lists.  k_tri_rows:
 //       triangulation etc. for the survivors on dense wave64s -> valid candidates appended in row
 //       order to per-slot lists.
 //   k_node_prefix + k_place (rows of every block sorted by line id -- what limap's matchers write)
@@ -944,12 +950,6 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
   if (lane == 0) a.wave_count[lin] = wcount;
 }
 
-#ifndef LT_TRI_PRIO
-#define LT_TRI_PRIO 0
-#endif
-#ifndef LT_TRI_SLICE_BIT
-#define LT_TRI_SLICE_BIT 9
-#endif
 // Stage B of the line-slot form: the survivors of block b are ONE dense list st_row[rb ...] of blk_surv[b] entries
 // (k_gates_ln); round r = its entries [64 r, 64 r + 64), one wave per round, every round but a block's last one full
 // (groups of slots ran three rounds for ~140 survivors: 73 % of the lanes).  The valid candidates of a round go, compacted
@@ -959,7 +959,9 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
 // -- 18 000 of them, in 8 000 workgroups -- was bound by the rate at which workgroups can be launched (trace: 2 000-2 500
 // of 4 096 wave slots occupied).  Workgroup g takes blocks g, g + gridDim.x, ...; its kTriWaves waves share the rounds
 // of a block (round r goes to wave (r - b) mod kTriWaves, so that the first rounds do not all land on wave 0) and move on
-// to the next block independently of each other.
+// to the next block independently of each other.  (Time-sliced wave priorities between the workgroups of a CU, which
+// help k_gates_ln, cost this kernel 10 us; a staggered start of the four workgroups of a CU 2 us: not kept.  Forcing
+// four waves per SIMD -- 127 registers with six spilled, against 131 and three waves -- is worth 10 us.)
 __global__ void __launch_bounds__(64 * kTriWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_tri_rounds(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec *__restrict__ pairs_r,
              const BlkRec *__restrict__ blk_r, const unsigned *__restrict__ blk_surv, const unsigned *__restrict__ blk_rnd0,
@@ -981,10 +983,6 @@ k_tri_rounds(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRe
   const long long lbase = rec->lbase;
   for (int r = x; r < n_rounds; r += kTriWaves) {
     LT_TRACE_MARK(1, rnd0 + (unsigned)r, 0);
-#if LT_TRI_PRIO
-    // (as in k_gates_ln: the four workgroups of a CU take turns at being served first)
-    set_prio((int)(((wall_clock64() >> LT_TRI_SLICE_BIT) + (unsigned long long)(4u * blockIdx.x / gridDim.x)) & 3ull));
-#endif
     const unsigned e = 64u * (unsigned)r + (unsigned)lane;
     bool ok = false;
     GenOut o;
@@ -1475,7 +1473,9 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   const unsigned n_wg = (unsigned)std::min<long long>(n_items, (long long)n_cu * per_cu);
   // the tables are sized by the largest image of the job, so "fits" is a per-launch property
   const dim3 grid(n_wg), block(64 * gate_waves);
-  if (ev3) (void)hipEventRecord(ev3[0], st);
+  // (extra proposals run this in two phases: the k_gates events belong to phase 1, the one behind stage B to phase 2 --
+  // the k_tri_rows figure then spans the counting run, the scan of the counts and the storing run)
+  if (ev3 && phase != 2) (void)hipEventRecord(ev3[0], st);
   if (phase != 2 && ln) {
     if (ln_w4)
       hipLaunchKernelGGL((k_gates_ln<4>), grid, block, lds, st, a, cfg, a.blk, a.pairs, a.tr, a.run_len, a.slot_row0, a.st_row,
@@ -1489,7 +1489,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
     else if (lds_segs1 > 0) hipLaunchKernelGGL((k_gates<true, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
     else hipLaunchKernelGGL((k_gates<false, false>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
   }
-  if (ev3) (void)hipEventRecord(ev3[1], st);
+  if (ev3 && phase != 2) (void)hipEventRecord(ev3[1], st);
   const size_t tri_lds = kTriWaves * (64 * 9 + 16) * sizeof(double2);
   if (ln) {
     // persistent: the workgroups that are resident at once (16 waves per CU: registers and LDS)
@@ -1504,7 +1504,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
       hipLaunchKernelGGL((k_tri_rows<false, kTriSlots>), tg, dim3(64 * kTriWaves), tri_lds, st, a, cfg, a.cams, a.pairs, a.blk,
                          a.slot_row0);
   }
-  if (ev3) (void)hipEventRecord(ev3[2], st);
+  if (ev3 && phase != 1) (void)hipEventRecord(ev3[2], st);
 }
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
