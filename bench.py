@@ -52,7 +52,7 @@ def device_source_hash():
     return h.hexdigest()[:16]
 
 
-def algorithmic_bytes(stats, n_img_active, nn, survivors, mode):
+def algorithmic_bytes(stats, n_img_active, nn, survivors, mode, line_slots=False):
     """SURVEY.md 8(d): bytes_score = 136 C + 104 nodes + 4 E ;
     bytes_gen = 8 P + 32 (nodes + N nn M) + 88 N (1 + nn) + 96 C, with NO 8 P term in exhaustive mode (the
     connections are implicit there).  The rows reach the device packed to one 32-bit word each since round 3, so the
@@ -62,7 +62,9 @@ def algorithmic_bytes(stats, n_img_active, nn, survivors, mode):
                    rows that pass the gates (8 S, S = stage-A survivors; an entry carries the row)
       k_tri_rows : the survivor list (8 S) and the candidate records it emits (96 C)."""
     C, E, P, G = stats["candidates"], stats["valid_edges"], stats["connections"], stats["active_nodes"]
-    rows = 4 * P if mode == "matched" else 0  # one packed word per match row (line | neighbour line << 16)
+    # one packed word per match row (line | neighbour line << 16) in the row-slot form; 16 bits (the neighbour line: the
+    # line is the lane) + 4 bytes of run length per (block, line) in the line-slot form of round 5
+    rows = ((2 * P + 4 * nn * G) if line_slots else 4 * P) if mode == "matched" else 0
     score = 136 * C + 104 * G + 4 * E
     gen = rows + 32 * (G + nn * G) + 88 * n_img_active * (1 + nn) + 96 * C
     gates = rows + 32 * (G + nn * G) + 88 * n_img_active * (1 + nn) + 8 * survivors
@@ -118,12 +120,12 @@ def load_pmc(world, default_wl):
     """Counter-derived per-launch numbers (HBM bytes, FP64 VALU flops, LDS bytes) from the rocprofv3 --pmc passes
     committed under profiles/ -- valid for the default 1-GPU workload and ONLY for the device code they were
     collected on (source hash recorded in the file); anything else reports null."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r05_pmc.json")
     if not (default_wl and world == 1 and os.path.exists(path)):
         return {}, None
     d = json.load(open(path))
     if d.get("device_source_hash") != device_source_hash():
-        return {}, "profiles/r04_pmc.json was collected on different device code: counter-derived fields are null"
+        return {}, "profiles/r05_pmc.json was collected on different device code: counter-derived fields are null"
     return d.get("kernels", {}), None
 
 
@@ -576,7 +578,8 @@ def main():
                  (100, 500, 20, 10, "weak", 0, 0, 0)
     pmc_all, pmc_note = load_pmc(world, default_wl)
     if rank == 0:
-        ab = algorithmic_bytes(st, len(my_imgs), args.neighbors, kt.get("survivors", 0.0), args.mode)
+        ab = algorithmic_bytes(st, len(my_imgs), args.neighbors, kt.get("survivors", 0.0), args.mode,
+                               line_slots=bool(last.get("line_slots", 0.0)))
         pmc = pmc_all.get(args.mode, {})
         # per-KERNEL durations: HIP events recorded on the launch stream right around each kernel
         # (lt_get_timers [13]-[15]); "gen" is the two-kernel stage HOT LOOP 1 for continuity with round-1 lines
@@ -597,6 +600,10 @@ def main():
             kernels = {"k_score3": (ab["score"], kt.get("k_score3", 0.0)), "k_gen_exhaustive": (ab["gen"], kt.get("gen", 0.0))}
         dom = max(kernels, key=lambda k: kernels[k][1])
         roof = {name: roofline_entry(name, nbytes, ms, pmc) for name, (nbytes, ms) in kernels.items()}
+        kt["line_slots"] = last.get("line_slots", 0.0)
+        if args.mode == "matched" and last.get("line_slots", 0.0):  # the stage names stay, the kernels are round 5's
+            roof["k_gates"]["kernel"] = "k_gates_ln (stage A, line-slot form: one lane per line)"
+            roof["k_tri_rows"]["kernel"] = "k_tri_rounds (stage B in rounds of 64 survivors)"
         if args.mode == "matched" and kt.get("gen", 0.0) > 0:
             roof["stage_gen(k_gates+k_tri_rows)"] = roofline_entry("stage_gen", ab["gen"], kt["gen"], {})
         wl = (f"synthetic {args.views} views x {args.segs} segs/view " + ("in total" if strong else "per GPU")
@@ -625,7 +632,7 @@ def main():
                                                 else dom)),
             "roofline_all": roof,
             "roofline_note": pmc_note or ("traffic / valu_f64 / lds: rocprofv3 --pmc passes over this exact device code "
-                                          "(profiles/r04_pmc.json, tools/prof_pmc_json.sh); FP64 VALU peak 78.6 TF"),
+                                          "(profiles/r05_pmc.json, tools/prof_pmc_json.sh); FP64 VALU peak 78.6 TF"),
             "host_ms": {"upload_matches": 1e3 * t_upload, "tail_compute_tracks": 1e3 * t_tail,
                         "merge_shards_device": None if t_merge is None else 1e3 * t_merge},
             "tracks_whole_scene": st_after["tracks"], "merge_note": merge_note,
