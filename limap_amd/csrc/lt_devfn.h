@@ -848,12 +848,8 @@ static __device__ __forceinline__ bool vp_candidate(const GenCfg &cfg, const Cam
   return dir_candidate(cfg, c1, c2, s1, s2, Bv, unit(mv(c1.Minv, mk3(vp[0], vp[1], vp[2]))), out);
 }
 
-static __device__ __forceinline__ bool gen_one(const GenCfg &cfg, const Cam &c1, const Cam &c2,
-                                               const Seg &s1, const Seg &s2, const PairRec &pr,
-                                               GenOut *out) {
-  if (!gen_gates(cfg, s1, s2, pr.F)) return false;
-  return gen_finish(cfg, c1, c2, s1, s2, pr.B, out);
-}
+// (Callers run gen_gates where the cheap gates left a pair undecided and then gen_finish for EVERY lane from one call
+// site: `undecided ? gates-then-finish : finish` as two inlined copies made a wave with mixed lanes run gen_finish twice.)
 
 // Dense evaluation of one (i, j) pair (global_line_triangulator.cc:97-104): LineLinker3d score in
 // shared-parent mode (3D angle + one-way scale-invariant endpoint distance with l_i's depths,

@@ -49,7 +49,7 @@ void launch_gates_exhaustive(hipStream_t st, int n_blk, int max_chunks, long lon
                              const Cam *cams, const Seg *segs, const PairRec *pairs, unsigned long long *masks,
                              const int *blk_chunk_off, const void *gates, unsigned long long *ent_out,
                              unsigned long long *ctr, unsigned region_cap, int *err_flag);
-void launch_tri_exhaustive(hipStream_t st, const unsigned long long *ent, const unsigned long long *ctr,
+void launch_tri_exhaustive(hipStream_t st, unsigned long long *ent, const unsigned long long *ctr,
                            unsigned region_cap, const GenCfg &cfg, long long n_items, const long long *item_off,
                            const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
                            const Cam *cams, const Seg *segs, const PairRec *pairs, const int *blk_chunk_off,

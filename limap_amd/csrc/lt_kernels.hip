@@ -299,9 +299,11 @@ k_gen_ex_block(long long n_items, GenCfg cfg, const long long *__restrict__ item
         GenOut o;
         bool ok;
         if (kind == 0) {
-          if (kFill) ok = gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o);   // pass 1 proved the gates
-          else if ((ent >> 11) & 1u) ok = gen_one(cfg, cams[i1], cams[i2], s1, s2, pr, &o);
-          else ok = gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o);
+          // ONE inlined gen_finish for both kinds of entry (pass 1 proved the gates / the cheap gates could not decide):
+          // as two call sites a wave with mixed lanes ran the function twice
+          bool pass = true;
+          if (!kFill && ((ent >> 11) & 1u)) pass = gen_gates(cfg, s1, s2, pr.F);
+          ok = pass && gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o);
         } else {
           ok = vp_candidate(cfg, cams[i1], cams[i2], s1, s2, pr.B, seg_vp + 3 * (kind == 1 ? g : g2base + ng), &o);
         }
@@ -467,8 +469,9 @@ k_gates_ex(int n_blk, int max_chunks, long long n_items, GenCfg cfg, const long 
             const Seg &s1 = segs[g1base + nd];
             const Seg &s2 = segs[g2base + (c << 6) + ln];
             GenOut o;
-            const bool ok = (ent & 64u) ? gen_one(cfg, cams[i1], cams[i2], s1, s2, pr, &o)
-                                        : gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o);
+            bool pass = true;  // one inlined gen_finish, see k_gen_list
+            if (ent & 64u) pass = gen_gates(cfg, s1, s2, pr.F);
+            const bool ok = pass && gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o);
             if (ok) atomicOr(&lmask[nd - seg0], 1ull << ln);
           }
           n_ent = base;
@@ -491,21 +494,32 @@ k_gates_ex(int n_blk, int max_chunks, long long n_items, GenCfg cfg, const long 
 }
 
 // One-pass exhaustive mode, dense evaluation: one wave per block of 64 listed connections (all of one image pair).
-// Exact gates where the cheap ones could not decide, triangulation; a survivor is written to the staging slot with
-// the index of its entry (the other slots are holes: node = ~0) and sets its bit in the ballot word of its work
-// item (masks zeroed beforehand) -- from there on the counts, offsets and the permutation are those of the two-pass
-// form.
+// Exact gates where the cheap ones could not decide, triangulation.  The survivors of a block (27 % of its 64
+// entries on the bench scene) are COMPACTED to the front of the block's 64 staging slots, in lane order: record,
+// uncertainty, depth key, node and -- in place -- the 8-byte entry k_place_ex decodes; the slots behind them are holes
+// (node = ~0).  Round 5: the kernel used to store the whole 8 KB record row of every block that had a survivor, holes
+// included -- 4.75 GB of writes per launch against 1.1 GB of records (1.82 -> 1.58 ms).  Measured and not kept: the
+// staging arrays dense across blocks -- one cursor per region serialises its 3e4 atomics at ~100 ns each (+1.3 ms),
+// 64 cursors per region: +0.1 ms against this form; the kernel persistent with the next block's entries and image
+// ids loaded ahead: 187 registers (+0.1 ms), capped at 128: 45 spills (+0.26 ms); entry and uncertainty compacted by
+// shuffles instead of LDS (32 KB: five workgroups to a CU instead of four): +0.15 ms.  A survivor also sets its bit in
+// the ballot word of its work item (masks zeroed beforehand) -- from there on the counts, offsets and the
+// permutation are those of the two-pass form.
 __global__ void __launch_bounds__(256)
-k_tri_ex(const unsigned long long *__restrict__ ent, const unsigned long long *__restrict__ ctr, unsigned region_cap,
+k_tri_ex(unsigned long long *__restrict__ ent, const unsigned long long *__restrict__ ctr, unsigned region_cap,
          GenCfg cfg, long long n_items, const long long *__restrict__ item_off, const int *__restrict__ blk_img,
          const int *__restrict__ blk_nb, const long long *__restrict__ nb_off, const long long *__restrict__ seg_off,
          const Cam *__restrict__ cams, const Seg *__restrict__ segs, const PairRec *__restrict__ pairs,
          const int *__restrict__ blk_chunk_off, unsigned long long *__restrict__ masks, CRec *__restrict__ st_r,
          double *__restrict__ st_unc, unsigned *__restrict__ st_node, float *__restrict__ st_z) {
-  // The 64 staging slots of a block are contiguous: the records go through LDS and leave as full 1 KB rows (a lane
+  // The records go through LDS and leave as full 128-byte lines, 64 lanes on consecutive 16-byte pieces (a lane
   // storing its own 128-byte record writes 16-byte pieces 128 bytes apart -- every store instruction then touches 64
-  // cache lines, and the kernel was bound by that, not by its arithmetic).  Holes carry stale bytes, nobody reads them.
+  // cache lines).
   __shared__ double2 s_out[4][64 * 8];
+  __shared__ unsigned long long s_ent[4][64];
+  __shared__ double s_unc[4][64];
+  __shared__ unsigned s_node[4][64];
+  __shared__ float s_z[4][64];
   const int region = blockIdx.y;
   const unsigned long long n = ctr[region * 16];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -520,38 +534,53 @@ k_tri_ex(const unsigned long long *__restrict__ ent, const unsigned long long *_
   const long long b = (long long)(e_hi0 >> 1);
   const int i1 = blk_img[b], i2 = blk_nb[b];
   bool ok = false;
-  unsigned node = 0xFFFFFFFFu;
-  double o_depth0 = 0.0;
+  GenOut o;
+  long long g = 0;
+  int ng = 0;
   if (e != ~0ull) {
-    const int ng = (int)(e & 0xFFFFu), nd = (int)((e >> 16) & 0xFFFFu);
-    const long long g = seg_off[i1] + nd;
+    ng = (int)(e & 0xFFFFu);
+    const int nd = (int)((e >> 16) & 0xFFFFu);
+    g = seg_off[i1] + nd;
     const Seg &s1 = segs[g];
     const Seg &s2 = segs[seg_off[i2] + ng];
     const PairRec &pr = pairs[b];
-    GenOut o;
-    ok = ((e >> 32) & 1ull) ? gen_one(cfg, cams[i1], cams[i2], s1, s2, pr, &o)
-                            : gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o);
-    if (ok) {
-      o.r.nb_slot = lite_pack((int)(b - nb_off[i1]), i2);
-      o.r.ng_line = ng;
-      *reinterpret_cast<CRec *>(&s_out[wv][8 * lane]) = o.r;
-      st_unc[slot] = o.unc;
-      node = (unsigned)g;
-      o_depth0 = o.r.depth[0];
-      const long long item = item_off[g] + blk_chunk_off[b] + (ng >> 6);
-      if (item < n_items) atomicOr(&masks[item], 1ull << (ng & 63));
-    }
+    // the exact gates only where the cheap ones could not decide, then ONE inlined gen_finish for every lane (as
+    // two call sites a wave with mixed lanes ran gen_finish twice)
+    bool pass = true;
+    if ((e >> 32) & 1ull) pass = gen_gates(cfg, s1, s2, pr.F);
+    ok = pass && gen_finish(cfg, cams[i1], cams[i2], s1, s2, pr.B, &o);
   }
-  st_node[slot] = node;
-  // the depth-order keys of the scoring stage (single-precision start depth), 4 bytes per slot: k_depth_order then
-  // gathers from a 0.1 GB array that stays in the last-level cache instead of one 112-byte record per key
-  st_z[slot] = ok ? (float)o_depth0 : 0.0f;
-  if (__ballot(ok)) {
-    wave_lds_sync();
-    double2 *dc = reinterpret_cast<double2 *>(st_r + slot0);
+  const unsigned long long okm = __ballot(ok);
+  const int cnt = __popcll(okm);
+  if (ok) {
+    const int rank = __popcll(okm & lanemask_lt());
+    o.r.nb_slot = lite_pack((int)(b - nb_off[i1]), i2);
+    o.r.ng_line = ng;
+    *reinterpret_cast<CRec *>(&s_out[wv][8 * rank]) = o.r;
+    s_ent[wv][rank] = e;
+    s_unc[wv][rank] = o.unc;
+    s_node[wv][rank] = (unsigned)g;
+    // the depth-order keys of the scoring stage (single-precision start depth), 4 bytes per slot: k_depth_order then
+    // gathers from a 0.1 GB array that stays in the last-level cache instead of one 112-byte record per key
+    s_z[wv][rank] = (float)o.r.depth[0];
+    const long long item = item_off[g] + blk_chunk_off[b] + (ng >> 6);
+    if (item < n_items) atomicOr(&masks[item], 1ull << (ng & 63));
+  }
+  if (cnt == 0) {
+    st_node[slot] = 0xFFFFFFFFu;
+    return;
+  }
+  wave_lds_sync();
+  st_node[slot] = lane < cnt ? s_node[wv][lane] : 0xFFFFFFFFu;
+  if (lane < cnt) {
+    ent[slot] = s_ent[wv][lane];
+    st_unc[slot] = s_unc[wv][lane];
+    st_z[slot] = s_z[wv][lane];
+  }
+  double2 *dc = reinterpret_cast<double2 *>(st_r + slot0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) dc[k * 64 + lane] = s_out[wv][k * 64 + lane];
-  }
+  for (int k = 0; k < 8; ++k)
+    if (k * 64 + lane < cnt * 8) dc[k * 64 + lane] = s_out[wv][k * 64 + lane];
 }
 
 // Pass 2 of the plain exhaustive mode: one wave per (image pair, eighth of the image's nodes).  The survivors of
@@ -757,8 +786,9 @@ k_gen_exhaustive_pts(long long n_items, GenCfg cfg, const long long *__restrict_
       const int res = gate3(cfg, s1.x1, s1.y1, s1.x2, s1.y2, s1.rs[0], s1.rs[1], s1.rs[2], s1.re[0], s1.re[1], s1.re[2],
                             gg.n[0], gg.n[1], gg.n[2], gg.lcx, gg.lcy, gg.P, gg.Q, gg.w1, gg.sv, gg.q2, pairs[b].F);
       bool ok = false;
-      if (res == 1) ok = gen_finish(cfg, cams[i1], cams[i2], s1, s2, pairs[b].B, &o);
-      else if (res == 2) ok = gen_one(cfg, cams[i1], cams[i2], s1, s2, pairs[b], &o);
+      bool pass = res != 0;  // one inlined gen_finish for decided (1) and undecided (2) pairs
+      if (res == 2) pass = gen_gates(cfg, s1, s2, pairs[b].F);
+      if (pass) ok = gen_finish(cfg, cams[i1], cams[i2], s1, s2, pairs[b].B, &o);
       if (ok) emit(o);
     }
   }
@@ -1086,7 +1116,7 @@ void launch_gates_exhaustive(hipStream_t st, int n_blk, int max_chunks, long lon
                        seg_off, cams, segs, pairs, masks, blk_chunk_off, gates, ent_out, ctr, region_cap, err_flag);
 }
 // one-pass form: dense evaluation of the entry blocks (masks zeroed beforehand)
-void launch_tri_exhaustive(hipStream_t st, const unsigned long long *ent, const unsigned long long *ctr,
+void launch_tri_exhaustive(hipStream_t st, unsigned long long *ent, const unsigned long long *ctr,
                            unsigned region_cap, const GenCfg &cfg, long long n_items, const long long *item_off,
                            const int *blk_img, const int *blk_nb, const long long *nb_off, const long long *seg_off,
                            const Cam *cams, const Seg *segs, const PairRec *pairs, const int *blk_chunk_off,
