@@ -584,6 +584,8 @@ void lt_destroy(lt_ctx *ctx) {
   for (DevBuf *b : bufs) b->release();
   for (auto &e : ctx->ev_b)
     if (e) (void)hipEventDestroy(e);
+  for (auto &e : ctx->ev_end)
+    if (e) (void)hipEventDestroy(e);
   // a context that still owns its stream hands stream + events to the next context
   if (ctx->pool_stream) (void)hipStreamSynchronize(ctx->pool_stream);
   if (!(ctx->pool_stream && lt_host::stream_set_release(ctx->device, ctx->pool_stream, ctx->ev))) {

@@ -184,7 +184,7 @@ int finish_run(lt_ctx *ctx) {
   long long *hp = ctx->h_pinned ? ctx->h_pinned + 8 * ctx->pend_set : nullptr;
   int derr = 0;
   if (hp) {
-    HIPCHK(ctx, hipEventSynchronize(ev[12]));
+    HIPCHK(ctx, hipEventSynchronize(ctx->pend_ev_end));
     derr = (int)hp[1];
     ctx->stat_pairs_eval = hp[2];
     ctx->C_last = ctx->pend_count_on_device ? hp[0] : ctx->pend_C;
@@ -255,13 +255,17 @@ int finish_run(lt_ctx *ctx) {
   float ms;
   ctx->timers[1] = ctx->timers[2] = ctx->timers[7] = 0.0;
   const int eg = ctx->pend_ev_gen_end, ep = ctx->pend_ev_place_end;
-  const int ee = hp ? 12 : 7;  // end of the run: the end marker behind the result copies, if there are result slots
-  const int kA[4] = {0, eg, ep, 5}, kB[4] = {eg, ep, 5, ee}, kT[4] = {3, 4, 5, 6};
+  // start of the run: its own event, or the end marker of the run it was enqueued behind (lt_run_device_async); end of
+  // the run: the end marker behind the result record, if there are result slots
+  const hipEvent_t e_start = ctx->pend_ev_start ? ctx->pend_ev_start : ev[0];
+  const hipEvent_t e_end = hp ? ctx->pend_ev_end : ev[7];
+  const hipEvent_t kA[4] = {e_start, ev[eg], ev[ep], ev[5]}, kB[4] = {ev[eg], ev[ep], ev[5], e_end};
+  const int kT[4] = {3, 4, 5, 6};
   for (int k = 0; k < 4; ++k) {
-    HIPCHK(ctx, hipEventElapsedTime(&ms, ev[kA[k]], ev[kB[k]]));
+    HIPCHK(ctx, hipEventElapsedTime(&ms, kA[k], kB[k]));
     ctx->timers[kT[k]] = ms;
   }
-  HIPCHK(ctx, hipEventElapsedTime(&ms, ev[0], ev[ee]));
+  HIPCHK(ctx, hipEventElapsedTime(&ms, e_start, e_end));
   ctx->timers[0] = ms;
   // single-kernel durations of the matched pipeline: [13] k_gates, [14] k_tri_rows, [15] k_score3
   ctx->timers[13] = ctx->timers[14] = ctx->timers[15] = 0.0;
@@ -332,7 +336,11 @@ int lt_run_device_async(lt_ctx *ctx) {
   ENSURE(ctx, ctx->d_result3, 32);
   ENSURE(ctx, ctx->d_pairs, sizeof(PairRec) * (size_t)std::max(ctx->n_blk, 1));
   ENSURE(ctx, ctx->d_tri_off, sizeof(long long) * (size_t)(G + 1));
-  HIPCHK(ctx, hipEventRecord(ev[0], st));
+  // Enqueued behind a run still in flight: that run's end marker is this run's start event.  (Every other entry point
+  // that puts work on the stream completes the pending run first -- LT_FINISH --, so nothing sits between the two.)
+  hipEvent_t ev_start = ev[0];
+  if (ctx->run_pending && hp && ctx->pend_ev_end && !test_switch("LT_TEST_OWN_START_EVENT")) ev_start = ctx->pend_ev_end;
+  else HIPCHK(ctx, hipEventRecord(ev[0], st));
   // also zeroes the error flag, the pair statistic and the look-back state of k_node_prefix's scan
   // (+ the tile cost-class counters of k_cand_meta / k_score3 behind the scan's words: zeroed by the same kernel)
   const int n_status_scan = (int)((G + 1 + 255) / 256) + 1;
@@ -832,12 +840,16 @@ int lt_run_device_async(lt_ctx *ctx) {
   HIPCHK(ctx, hipGetLastError());
   // the device error flag, the candidate count and the pair statistic ride on the stream into this set's
   // pinned slots; finish_run reads them behind the end marker
+  hipEvent_t ev_end = nullptr;
   if (hp) {
     // hp[0] candidate count, hp[1] error flag, hp[2] pair statistic: one record, WRITTEN BY k_select straight into this
     // set's page-locked slots (round 4: the 32-byte device-to-host copy was a 4 us blit kernel in every step); hp[3]: fullest
     // staging region of the one-pass exhaustive mode (k_place_ex).  The slots were zeroed when the run was enqueued (no
     // nodes: k_select does not run).
-    HIPCHK(ctx, hipEventRecord(ev[12], st));
+    if (!ctx->ev_end[0])
+      for (auto &e : ctx->ev_end) HIPCHK(ctx, hipEventCreate(&e));
+    ev_end = ctx->ev_end[ctx->run_seq++ % 3u];
+    HIPCHK(ctx, hipEventRecord(ev_end, st));
   }
   int rc_prev = LT_OK;
   if (ctx->run_pending) {  // the previous run (the other set)
@@ -846,6 +858,8 @@ int lt_run_device_async(lt_ctx *ctx) {
     ctx->in_run_async = false;
   }
   ctx->run_pending = true;
+  ctx->pend_ev_start = ev_start;
+  ctx->pend_ev_end = ev_end;
   ctx->pend_set = set;
   ctx->pend_count_on_device = C_known < 0;
   ctx->pend_fine_gen = fine_gen;

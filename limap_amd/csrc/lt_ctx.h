@@ -335,6 +335,12 @@ struct lt_ctx {
   long long stat_survivors = 0;  // connections that passed stage A (k_gates) in the last run
   hipEvent_t ev[14] = {nullptr};  // [0..11] timing, [12] end-of-run marker
   hipEvent_t ev_b[14] = {nullptr};  // second set, created when a run is enqueued behind one still in flight
+  // end-of-run markers of pipelined runs: a ring of three, so that run k+1 can use run k's marker as its START event
+  // (two events recorded back to back at the boundary of two runs cost two ~5 us bubbles in the stream, one is enough)
+  // and still read it when it is finished -- during the enqueue of run k+2, which records the third one
+  hipEvent_t ev_end[3] = {nullptr};
+  unsigned run_seq = 0;
+  hipEvent_t pend_ev_start = nullptr, pend_ev_end = nullptr;  // of the run in flight
   bool run_pending = false;         // lt_run_device_async left a run in flight (finish_run completes it)
   int pend_set = 0;                 // its event / pinned-slot set
   bool pend_count_on_device = false;
