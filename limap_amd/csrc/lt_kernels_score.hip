@@ -838,8 +838,17 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
 // (Fewer tiles per unit in the expensive classes -- one from class 22 / two from class 12, from 26 / 18, from 30 / 22: no
 // gain over T everywhere.  Workgroups of two waves / one wave with their own tables: 133 / 195 us for the stage against 106.)
 constexpr int kDenseWaves = 4;
-constexpr int kDensePerCU = 3;                  // workgroups of k_dense8 per CU
-constexpr int kDenseLdsBudget = 48 * 1024;      // LDS for a workgroup's tables of maxima
+// (round 5, k_dense8 at 113 registers: four workgroups per CU with units of three tiles -- 36 KB of tables at 20
+// neighbours -- 107.5 us for the stage against 108.9 with three workgroups and units of four tiles (48 KB); three
+// workgroups with units of three: 110.6)
+#ifndef LT_DENSE_PER_CU
+#define LT_DENSE_PER_CU 4
+#endif
+#ifndef LT_DENSE_LDS_KB
+#define LT_DENSE_LDS_KB 36
+#endif
+constexpr int kDensePerCU = LT_DENSE_PER_CU;                  // workgroups of k_dense8 per CU
+constexpr int kDenseLdsBudget = LT_DENSE_LDS_KB * 1024;      // LDS for a workgroup's tables of maxima
 __global__ void __launch_bounds__(64 * kDenseWaves)
 k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of the candidate, 1 = position, 2 = spos[position]
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -1210,7 +1219,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
     if (perm_is_placement) hipLaunchKernelGGL((k_score3<true, false, true, true>), grid1, block1, lds1, st, a, cfg, scaleinv_guard2);
     else if (sorted) hipLaunchKernelGGL((k_score3<true, true, false, true>), grid1, block1, lds1, st, a, cfg, scaleinv_guard2);
     else hipLaunchKernelGGL((k_score3<true, false, false, true>), grid1, block1, lds1, st, a, cfg, scaleinv_guard2);
-    // k_dense8: three workgroups of four waves per CU (registers: four waves per SIMD; LDS: one 512 B x max_nb table per tile)
+    // k_dense8: kDensePerCU workgroups of four waves per CU (registers: four waves per SIMD; LDS: one 512 B x max_nb table per tile)
     const size_t lds2 = (size_t)kDenseHdrBytes + (size_t)a.sp_t_max * (size_t)max_nb * 512;
     const long long fit = std::max<long long>(1, std::min<long long>(kDensePerCU, (long long)(160 * 1024 / lds2)));
     const int by = perm_is_placement ? 1 : (sorted && a.spos ? 2 : 0);
