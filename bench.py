@@ -445,6 +445,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # The library SAMPLES the events around the stages of pipelined runs (each one is a ~5 us bubble in the stream): every
+    # LT_TIMER_SAMPLE-th run carries them (default 8).  The roofline's kernel duration is the mean over the sampled steps of
+    # the timed region -- at least four of them.
+    if "LT_TIMER_SAMPLE" not in os.environ:
+        os.environ["LT_TIMER_SAMPLE"] = str(max(1, min(8, args.steps // 4)))
+    event_sampling = int(os.environ["LT_TIMER_SAMPLE"])
     for _ in range(args.warmup):
         step()
     sync()
@@ -470,6 +476,7 @@ def main():
     if args.mode == "matched":
         prev_fine = os.environ.get("LT_FINE_TIMERS")
         os.environ["LT_FINE_TIMERS"] = "2"
+        os.environ["LT_TIMER_SAMPLE"] = "1"
         ctx.timer_sums(reset=True)
         for _ in range(5):
             step()
@@ -479,6 +486,7 @@ def main():
             os.environ.pop("LT_FINE_TIMERS", None)
         else:
             os.environ["LT_FINE_TIMERS"] = prev_fine
+        os.environ["LT_TIMER_SAMPLE"] = str(event_sampling)
         # (generation and placement stages too: the timed region records no event between them)
         for k in ("k_gates", "k_tri_rows", "gen", "compact"):
             kt[k] = acc2[k] / max(n2, 1)
@@ -629,7 +637,9 @@ def main():
             "connections_per_s": conn_total * args.steps / elapsed,
             "roofline": dict(roof[dom], kernel=("k_score3 + k_dense8 (the scoring stage: sweep kernel + dense kernel, one pair of events)"
                                                 if dom == "k_score3" and args.mode == "matched" and not os.environ.get("LT_SCORE_FUSED")
-                                                else dom)),
+                                                else dom),
+                             event_sampling=f"HIP events around the stage on every {event_sampling}. step of the timed region "
+                                            "(LT_TIMER_SAMPLE; each event is a ~5 us bubble in the stream)"),
             "roofline_all": roof,
             "roofline_note": pmc_note or ("traffic / valu_f64 / lds: rocprofv3 --pmc passes over this exact device code "
                                           "(profiles/r05_pmc.json, tools/prof_pmc_json.sh); FP64 VALU peak 78.6 TF"),

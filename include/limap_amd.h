@@ -282,12 +282,17 @@ int lt_get_stats(lt_ctx *ctx, int64_t out[8]);
  * one-pass exhaustive mode: [17] staging slots needed (fullest region x regions), [18] staging slots provided;
  * [19] 1 when this context scores with the fused kernel because the split form's pair store overflowed once, else 0;
  * [20] 1 when stage A of the last TriangulateImage job ran in the line-slot form (k_gates_ln: one lane per line), else 0.
- * With the scoring stage in two kernels (the default for TriangulateImage jobs) [15] spans both. */
+ * With the scoring stage in two kernels (the default for TriangulateImage jobs) [15] spans both.
+ * SAMPLING: an event between two kernels costs a ~5 us bubble in the stream, so a run enqueued BEHIND one still in flight
+ * (lt_run_device_async back to back) carries the stage events -- [3]-[6], [13]-[15] -- only every LT_TIMER_SAMPLE-th time
+ * (environment, read per run; default 8, 1 = every run); in between those slots keep the values of the last run that
+ * did.  A run that starts on an idle context always carries them; [0] is measured for every run. */
 int lt_get_timers(lt_ctx *ctx, double out[24]);
 /* The same slots summed over every lt_run_device since the last reset ([8]-[10], [12] are not summed), and
  * the number of runs ([16] is not summed either: lt_get_timers counts it on demand with a device readback,
  * which is why a caller that times many runs should read the sums once instead of lt_get_timers per run).
- * reset != 0 clears the sums after reading. */
+ * reset != 0 clears the sums after reading.  The sampled stage slots (above) are summed over the sampled runs and
+ * scaled to the number of runs. */
 int lt_get_timer_sums(lt_ctx *ctx, double out[24], int64_t *n_runs, int reset);
 
 /* The library keeps released device blocks and page-locked staging blocks in a process-wide cache

@@ -274,10 +274,16 @@ int lt_get_timers(lt_ctx *ctx, double out[24]) {
 int lt_get_timer_sums(lt_ctx *ctx, double out[24], int64_t *n_runs, int reset) {
   LT_FINISH(ctx);
   std::memcpy(out, ctx->timer_sums, sizeof(ctx->timer_sums));
+  // the stage timers are sampled in pipelined runs (lt_ctx.h): their sums are scaled to the number of runs
+  if (ctx->timer_stage_runs > 0 && ctx->timer_stage_runs < ctx->timer_runs) {
+    const double f = (double)ctx->timer_runs / (double)ctx->timer_stage_runs;
+    for (int k : {3, 4, 5, 6, 13, 14, 15}) out[k] *= f;
+  }
   if (n_runs) *n_runs = ctx->timer_runs;
   if (reset) {
     std::memset(ctx->timer_sums, 0, sizeof(ctx->timer_sums));
     ctx->timer_runs = 0;
+    ctx->timer_stage_runs = 0;
   }
   return LT_OK;
 }

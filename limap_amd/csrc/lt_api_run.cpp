@@ -259,14 +259,17 @@ int finish_run(lt_ctx *ctx) {
   // the run: the end marker behind the result record, if there are result slots
   const hipEvent_t e_start = ctx->pend_ev_start ? ctx->pend_ev_start : ev[0];
   const hipEvent_t e_end = hp ? ctx->pend_ev_end : ev[7];
+  HIPCHK(ctx, hipEventElapsedTime(&ms, e_start, e_end));
+  ctx->timers[0] = ms;
+  const bool sampled = ctx->pend_sampled;  // this run carried the stage events (lt_ctx.h); otherwise [3]-[6], [13]-[15] keep
+                                           // the values of the last run that did
+  if (sampled) {
   const hipEvent_t kA[4] = {e_start, ev[eg], ev[ep], ev[5]}, kB[4] = {ev[eg], ev[ep], ev[5], e_end};
   const int kT[4] = {3, 4, 5, 6};
   for (int k = 0; k < 4; ++k) {
     HIPCHK(ctx, hipEventElapsedTime(&ms, kA[k], kB[k]));
     ctx->timers[kT[k]] = ms;
   }
-  HIPCHK(ctx, hipEventElapsedTime(&ms, e_start, e_end));
-  ctx->timers[0] = ms;
   // single-kernel durations of the matched pipeline: [13] k_gates, [14] k_tri_rows, [15] k_score3
   ctx->timers[13] = ctx->timers[14] = ctx->timers[15] = 0.0;
   if (ctx->pend_fine_gen && ctx->job_mode == 1 && ctx->n_blk > 0 && ctx->max_rows > 0) {
@@ -275,9 +278,13 @@ int finish_run(lt_ctx *ctx) {
   }
   if (ctx->pend_fine_score && ctx->C_last > 0 && hipEventElapsedTime(&ms, ev[11], ev[5]) == hipSuccess) ctx->timers[15] = ms;
   (void)hipGetLastError();
+  ++ctx->timer_stage_runs;
+  }
   ctx->timers[11] = (double)ctx->stat_pairs_eval;
-  for (int k = 0; k < 24; ++k)  // [16] (survivors) is counted on demand by lt_get_timers, not per run
-    if (k != 8 && k != 9 && k != 10 && k != 12 && k != 16) ctx->timer_sums[k] += ctx->timers[k];
+  for (int k = 0; k < 24; ++k) {  // [16] (survivors) is counted on demand by lt_get_timers, not per run
+    const bool stage = (k >= 3 && k <= 6) || (k >= 13 && k <= 15);
+    if (k != 8 && k != 9 && k != 10 && k != 12 && k != 16 && (sampled || !stage)) ctx->timer_sums[k] += ctx->timers[k];
+  }
   ++ctx->timer_runs;
   return LT_OK;
 }
@@ -312,7 +319,13 @@ int lt_run_device_async(lt_ctx *ctx) {
   hipEvent_t *ev = set ? ctx->ev_b : ctx->ev;
   long long *hp = ctx->h_pinned ? ctx->h_pinned + 8 * set : nullptr;
   ctx->ex_staged_set[set] = false;
-  const bool fine_gen = fine_gen_timers(), fine_score = fine_timers();
+  // stage events: every run that starts on an idle context, every LT_TIMER_SAMPLE-th of the runs enqueued behind one in
+  // flight (lt_ctx.h)
+  int sample_n = 8;
+  if (const char *e = getenv("LT_TIMER_SAMPLE")) sample_n = std::max(1, atoi(e));
+  if (!(ctx->run_pending && hp)) ctx->async_seq = 0;
+  const bool sampled = (ctx->async_seq++ % (unsigned)sample_n) == 0u;
+  const bool fine_gen = sampled && fine_gen_timers(), fine_score = sampled && fine_timers();
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const long long G = ctx->G, P = ctx->P;
@@ -578,7 +591,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     }
     // ... and the one in front of k_score3 ends the placement stage (it then includes k_cand_meta)
     if (fine_score && C_bound > 0) ev_place_end = 11;
-    else HIPCHK(ctx, hipEventRecord(ev[4], st));
+    else if (sampled) HIPCHK(ctx, hipEventRecord(ev[4], st));
     if (gen_event_pending) ev_gen_end = ev_place_end;
   } else if (ctx->job_mode == 2) {
     ctx->perm_mode = false;
@@ -694,7 +707,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     if (staged) {
       launch_tri_offsets_ex(st, G, ctx->d_item_off.as<long long>(), ctx->d_mask_pos.as<long long>(), P, -1, ex_cap,
                             ctx->d_tri_off.as<long long>(), ctx->d_err.as<int>());
-      HIPCHK(ctx, hipEventRecord(ev[3], st));
+      if (sampled) HIPCHK(ctx, hipEventRecord(ev[3], st));
       launch_place_exhaustive(st, ex_ctr, region_cap, ctx->d_ex_ent.as<unsigned long long>(),
                               ctx->d_st_key.as<unsigned>(), ctx->d_item_off.as<long long>(),
                               ctx->d_blk_chunk_off.as<int>(), ctx->d_masks.as<unsigned long long>(),
@@ -707,13 +720,13 @@ int lt_run_device_async(lt_ctx *ctx) {
       ctx->cand_cap = ex_cap;
       C_known = -1;
       C_bound = ex_cap;
-      HIPCHK(ctx, hipEventRecord(ev[4], st));
+      if (sampled) HIPCHK(ctx, hipEventRecord(ev[4], st));
     } else {
     // the candidate count sizes the compacted arrays: one small host round trip
     long long total = 0;
     HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_mask_pos.as<long long>() + P, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    HIPCHK(ctx, hipEventRecord(ev[3], st));
+    if (sampled) HIPCHK(ctx, hipEventRecord(ev[3], st));
     const size_t Cn = (size_t)std::max<long long>(total, 1);
     ENSURE(ctx, ctx->d_cand, sizeof(CRec) * Cn); ENSURE(ctx, ctx->d_lite, sizeof(double) * Cn);
     ENSURE(ctx, ctx->d_score, 8 * Cn); ENSURE(ctx, ctx->d_edge_flag, 4 * Cn);
@@ -746,7 +759,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     launch_cand_node(st, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>());
     C_known = total;
     C_bound = total;
-    HIPCHK(ctx, hipEventRecord(ev[4], st));
+    if (sampled) HIPCHK(ctx, hipEventRecord(ev[4], st));
     }
   } else {
     ctx->perm_mode = false;
@@ -756,7 +769,8 @@ int lt_run_device_async(lt_ctx *ctx) {
     ENSURE(ctx, ctx->d_score, 8); ENSURE(ctx, ctx->d_edge_flag, 4); ENSURE(ctx, ctx->d_cand_node, 4);
     C_known = 0;
     C_bound = 0;
-    for (int k = 3; k <= 4; ++k) HIPCHK(ctx, hipEventRecord(ev[k], st));
+    for (int k = 3; k <= 4; ++k)
+      if (sampled) HIPCHK(ctx, hipEventRecord(ev[k], st));
   }
 
   // ---- scoring ----
@@ -816,8 +830,8 @@ int lt_run_device_async(lt_ctx *ctx) {
                   staged_sorted ? ctx->d_ex_rec.as<unsigned>() : nullptr,
                   staged_sorted ? ctx->d_ex_z.as<float>() : nullptr, ctx->d_err.as<int>(),
                   split ? ctx->d_sp_slots.p : nullptr, sp_slot_cap, ctx->d_sp_cnt.as<unsigned>(),
-                  ctx->d_sp_ovf.as<unsigned>(), ctx->d_sp_pairs.p, ctx->d_sp_desc.p, sp_chunks, ev[5]);
-    if (C_bound <= 0) HIPCHK(ctx, hipEventRecord(ev[5], st));  // nothing to score: no kernel carries the event
+                  ctx->d_sp_ovf.as<unsigned>(), ctx->d_sp_pairs.p, ctx->d_sp_desc.p, sp_chunks, sampled ? ev[5] : nullptr);
+    if (C_bound <= 0 && sampled) HIPCHK(ctx, hipEventRecord(ev[5], st));  // nothing to score: no kernel carries the event
   }
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));
   ENSURE(ctx, ctx->d_nvalid, 4 * (size_t)(G + 1));
@@ -859,6 +873,7 @@ int lt_run_device_async(lt_ctx *ctx) {
   }
   ctx->run_pending = true;
   ctx->pend_ev_start = ev_start;
+  ctx->pend_sampled = sampled;
   ctx->pend_ev_end = ev_end;
   ctx->pend_set = set;
   ctx->pend_count_on_device = C_known < 0;

@@ -341,6 +341,12 @@ struct lt_ctx {
   hipEvent_t ev_end[3] = {nullptr};
   unsigned run_seq = 0;
   hipEvent_t pend_ev_start = nullptr, pend_ev_end = nullptr;  // of the run in flight
+  // Stage events of pipelined runs are SAMPLED (every event between two kernels is a ~5 us bubble in the stream): a run
+  // enqueued behind one in flight carries them only every LT_TIMER_SAMPLE-th time (default 8); a run that starts on an
+  // idle context always does.  The stage timers keep the last sampled values in between; the sums count sampled runs.
+  unsigned async_seq = 0;
+  bool pend_sampled = true;
+  long long timer_stage_runs = 0;
   bool run_pending = false;         // lt_run_device_async left a run in flight (finish_run completes it)
   int pend_set = 0;                 // its event / pinned-slot set
   bool pend_count_on_device = false;

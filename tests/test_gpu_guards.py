@@ -39,7 +39,7 @@ def _same(a, b):
 def clean_env():
     keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES",
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
-            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_SCORE_SPLIT",
+            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TIMER_SAMPLE", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_SCORE_SPLIT",
             "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
@@ -245,6 +245,22 @@ def test_async_runs_pipeline(gpu_lib, clean_env):
     ctx.run_device(wait=False)
     ctx.sync()
     assert ctx.timer_sums()[1] == 6
+    # the stage events of pipelined runs are sampled (LT_TIMER_SAMPLE, include/limap_amd.h: lt_get_timers): the sums are
+    # scaled to the number of runs, the whole-run timer is measured for every run, the results do not depend on it
+    per_run = {}
+    for sample in ("1", "4"):
+        os.environ["LT_TIMER_SAMPLE"] = sample
+        ctx.sync()
+        ctx.timer_sums(reset=True)
+        for _ in range(12):
+            ctx.run_device(wait=False)
+        sums, n = ctx.timer_sums(reset=True)
+        assert n == 12 and sums["run"] > 0 and sums["score"] > 0 and sums["gen"] > 0
+        per_run[sample] = {k: sums[k] / n for k in ("run", "score", "gen")}
+        _same(base, _results(T))
+    os.environ.pop("LT_TIMER_SAMPLE", None)
+    for k in ("score", "gen"):
+        assert 0.5 < per_run["4"][k] / per_run["1"][k] < 2.0, (k, per_run)
     # a failing run (a shared point3D id without an SfM point is detected on the device)
     from limap_amd import triangulation as tri
     bpts, sfm = syn.make_bipartites(sc, seed=3)
