@@ -570,7 +570,7 @@ void lt_destroy(lt_ctx *ctx) {
                     &ctx->d_best_src, &ctx->d_ntris, &ctx->d_err, &ctx->d_blk_line_base, &ctx->d_cnt_bl,
                     &ctx->d_st_key, &ctx->d_wave_count, &ctx->d_wave_pos, &ctx->d_ntris_u, &ctx->d_cand_node,
                     &ctx->d_pair_counter, &ctx->d_result3, &ctx->d_tile_order, &ctx->d_scan_status, &ctx->d_perm, &ctx->d_rng, &ctx->d_chunks, &ctx->d_cand_meta, &ctx->d_st_row, &ctx->d_surv_count, &ctx->d_seg_gates, &ctx->d_blkrec, &ctx->d_seg_vp, &ctx->d_seg_has_vp, &ctx->d_base_bl, &ctx->d_blk_chunk_off, &ctx->d_needed, &ctx->d_seg_pts, &ctx->d_seg_pt_off, &ctx->d_sfm_xyz,
-                    &ctx->d_place_perm, &ctx->d_ex_rec, &ctx->d_ex_ent, &ctx->d_ex_z, &ctx->d_tile_list, &ctx->d_tail_keys, &ctx->d_tail_skeys, &ctx->d_tail_sims, &ctx->d_tail_mark,
+                    &ctx->d_place_perm, &ctx->d_ex_rec, &ctx->d_ex_ent, &ctx->d_node_rec, &ctx->d_ex_z, &ctx->d_tile_list, &ctx->d_tail_keys, &ctx->d_tail_skeys, &ctx->d_tail_sims, &ctx->d_tail_mark,
                     &ctx->d_tail_pos, &ctx->d_tail_recs, &ctx->d_tail_nodes, &ctx->d_tail_tmp, &ctx->d_tail_keep,
                     &ctx->d_tail_kpos, &ctx->d_sp_slots, &ctx->d_sp_cnt, &ctx->d_sp_ovf, &ctx->d_sp_pairs, &ctx->d_sp_desc,
                     &ctx->d_run_len, &ctx->d_slot_row0, &ctx->d_blk_nruns, &ctx->d_ln_flag, &ctx->d_blk_surv, &ctx->d_blk_rnd0,

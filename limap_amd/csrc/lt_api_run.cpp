@@ -367,6 +367,7 @@ int lt_run_device_async(lt_ctx *ctx) {
                      ctx->d_pair_counter.as<unsigned long long>(), ctx->d_scan_status.as<unsigned long long>(),
                      n_status, ln_job ? ctx->d_blk_surv.as<unsigned>() : nullptr);
 
+  bool node_rec_valid = false;  // k_node_prefix of this run wrote the per-node scoring records (d_node_rec)
   long long C_known = -1;  // candidate count once it is known on the host
   long long C_bound = 0;   // what sizes the compact arrays: the count, or an upper bound while it stays on the device
   int ev_gen_end = 3, ev_place_end = 4;  // events that close the generation / placement stage (see finish_run)
@@ -491,11 +492,13 @@ int lt_run_device_async(lt_ctx *ctx) {
     if (!hC) hC = &hC_fallback;
     if (fast) {
       // rows of every block are sorted by line id: sort-free placement
+      ENSURE(ctx, ctx->d_node_rec, 16 * (size_t)std::max<long long>(G, 1));
       launch_node_prefix(st, G, ctx->d_node_img.as<int>(), ctx->d_seg_off.as<long long>(),
                          ctx->d_nb_off.as<long long>(), ctx->d_blk_line_base.as<long long>(),
                          ctx->d_cnt_bl.as<unsigned>(), ctx->d_base_bl.as<unsigned>(), ctx->d_ntris_u.as<unsigned>(),
                          ctx->d_tri_off.as<long long>(), ctx->d_scan_status.as<unsigned long long>(),
-                         ctx->d_err.as<int>());  // tri_off = exclusive scan of the counts, in the same kernel
+                         ctx->d_err.as<int>(), ctx->d_node_rec.p);  // tri_off = exclusive scan of the counts, in the same kernel
+      node_rec_valid = true;
       ctx->cnt_bl_clean = true;
       // Nothing below needs the candidate count on the host (the kernels read tri_off[G]; the grids of
       // k_place / k_score3 do not depend on it) except the SIZE of the compact arrays.  While the trivial
@@ -830,7 +833,8 @@ int lt_run_device_async(lt_ctx *ctx) {
                   staged_sorted ? ctx->d_ex_rec.as<unsigned>() : nullptr,
                   staged_sorted ? ctx->d_ex_z.as<float>() : nullptr, ctx->d_err.as<int>(),
                   split ? ctx->d_sp_slots.p : nullptr, sp_slot_cap, ctx->d_sp_cnt.as<unsigned>(),
-                  ctx->d_sp_ovf.as<unsigned>(), ctx->d_sp_pairs.p, ctx->d_sp_desc.p, sp_chunks, sampled ? ev[5] : nullptr);
+                  ctx->d_sp_ovf.as<unsigned>(), ctx->d_sp_pairs.p, ctx->d_sp_desc.p, sp_chunks, sampled ? ev[5] : nullptr,
+                  node_rec_valid ? ctx->d_node_rec.p : nullptr);
     if (C_bound <= 0 && sampled) HIPCHK(ctx, hipEventRecord(ev[5], st));  // nothing to score: no kernel carries the event
   }
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));

@@ -251,6 +251,7 @@ struct lt_ctx {
   // one-pass exhaustive mode (k_gates_ex<true>): staging capacity as a fraction of the connections (0 = not measured
   // yet), adapted to the last run's yield; ex_two_pass: the next run uses the two-pass form (after an overflow)
   DevBuf d_ex_rec;             // record of every depth-sorted position (k_depth_order over staged records)
+  DevBuf d_node_rec;           // per node: the scoring prologue record of its candidates (k_node_prefix -> k_cand_meta)
   DevBuf d_ex_ent;             // entry blocks of k_gates_ex<true> (8 B per staging slot)
   DevBuf d_ex_z;               // single-precision start depth of every staging slot (keys of k_depth_order)
   long long ex_region_cap = 0; // of the run in flight

@@ -52,7 +52,7 @@ size_t seg_point_bytes();
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
                         unsigned *base_bl, unsigned *n_tris, long long *tri_off, unsigned long long *status,
-                        int *err_flag);
+                        int *err_flag, void *node_rec);
 void launch_expand_rows(hipStream_t st, int n_blk, const void *desc, const unsigned *stream, const unsigned *ovf, unsigned *rows);
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
@@ -76,7 +76,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, unsigned *bucket_cnt,
                    unsigned *bucket_list, unsigned bucket_cap, const unsigned *place, unsigned *rec, const float *st_z,
                    int *err_flag, void *sp_slots, int sp_slot_cap, unsigned *sp_cnt, unsigned *sp_ovf, void *sp_pairs,
-                   void *sp_desc, long long sp_chunks, hipEvent_t ev_after);
+                   void *sp_desc, long long sp_chunks, hipEvent_t ev_after, const void *node_rec);
 size_t score_split_chunk_bytes();
 size_t score_split_entry_bytes();
 long long score_split_chunks(long long C);

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256)
 k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long *__restrict__ tri_off,
             const int *__restrict__ node_img, const long long *__restrict__ nb_off, CandMeta *__restrict__ meta,
             unsigned *__restrict__ draw, unsigned *__restrict__ bucket_cnt, unsigned *__restrict__ bucket_list,
-            unsigned bucket_cap) {
+            unsigned bucket_cap, const uint4 *__restrict__ node_rec) {
   // grid-stride over the exact candidate count tri_off[G]; the host may only know an upper bound
   const long long C = tri_off[G];
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -80,14 +80,19 @@ k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long
     unsigned n = 0, w_lo = 0, w_hi = 0;
     if (i < C) {
       const unsigned g = cand_node[i];
-      const long long off = tri_off[g];
-      const int img = node_img[g];
-      const long long nb0 = nb_off[img];
       CandMeta m;
-      m.off_lo = (unsigned)(off & 0xFFFFFFFFll);
-      m.off_hi = (unsigned)(off >> 32);
-      m.n = (unsigned)(tri_off[g + 1] - off);
-      m.nb = ((unsigned)nb0 << 8) | (unsigned)(nb_off[img + 1] - nb0);
+      if (node_rec) {  // the node's record as k_node_prefix wrote it: one 16-byte gather
+        const uint4 r = node_rec[g];
+        m.off_lo = r.x; m.off_hi = r.y; m.n = r.z; m.nb = r.w;
+      } else {
+        const long long off = tri_off[g];
+        const int img = node_img[g];
+        const long long nb0 = nb_off[img];
+        m.off_lo = (unsigned)(off & 0xFFFFFFFFll);
+        m.off_hi = (unsigned)(off >> 32);
+        m.n = (unsigned)(tri_off[g + 1] - off);
+        m.nb = ((unsigned)nb0 << 8) | (unsigned)(nb_off[img + 1] - nb0);
+      }
       meta[i] = m;
       n = m.n;
       w_lo = m.off_lo; w_hi = m.off_lo + m.n;
@@ -1144,7 +1149,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, unsigned *bucket_cnt,
                    unsigned *bucket_list, unsigned bucket_cap, const unsigned *place, unsigned *rec, const float *st_z,
                    int *err_flag, void *sp_slots, int sp_slot_cap, unsigned *sp_cnt, unsigned *sp_ovf, void *sp_pairs,
-                   void *sp_desc, long long sp_chunks, hipEvent_t ev_after) {
+                   void *sp_desc, long long sp_chunks, hipEvent_t ev_after, const void *node_rec) {
   // ev_before / ev_after: bound as the STOP events of k_cand_meta and of the stage's last kernel (hipExtLaunchKernelGGL:
   // the kernel's own completion signal carries the timestamp) -- a hipEventRecord between two kernels is a barrier packet
   // that opens a ~5.5 us gap in the stream (LT_EV_MARKERS=1: the plain records, for comparison)
@@ -1165,7 +1170,8 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   static const bool ev_markers = getenv("LT_EV_MARKERS") != nullptr;
   hipExtLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st,
                         nullptr, ev_markers ? nullptr : ev_before, 0, G, cand_node, tri_off, node_img, nb_off,
-                        reinterpret_cast<CandMeta *>(meta), draw, bucket_cnt, bucket_list, bucket_cap);
+                        reinterpret_cast<CandMeta *>(meta), draw, bucket_cnt, bucket_list, bucket_cap,
+                        reinterpret_cast<const uint4 *>(node_rec));
   hipEvent_t ev_stop = ev_markers ? nullptr : ev_after;
   Score3Args a;
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand;

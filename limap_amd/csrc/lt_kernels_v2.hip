@@ -1130,7 +1130,8 @@ __global__ void __launch_bounds__(256)
 k_node_prefix(long long G, const int *__restrict__ node_img, const long long *__restrict__ seg_off,
               const long long *__restrict__ nb_off, const long long *__restrict__ blk_line_base,
               unsigned *__restrict__ cnt_bl, unsigned *__restrict__ base_bl, unsigned *__restrict__ n_tris,
-              long long *__restrict__ tri_off, unsigned long long *__restrict__ status, int *__restrict__ err_flag) {
+              long long *__restrict__ tri_off, unsigned long long *__restrict__ status, int *__restrict__ err_flag,
+              uint4 *__restrict__ node_rec) {
   __shared__ unsigned s_tile;
   __shared__ long long s_wave[4];
   __shared__ long long s_prefix;
@@ -1140,12 +1141,14 @@ k_node_prefix(long long G, const int *__restrict__ node_img, const long long *__
   const long long g = tile * 256 + threadIdx.x;
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   unsigned run = 0;
+  unsigned nbv = 0;  // (nb_off[img] << 8) | neighbours of the node's image: CandMeta::nb
   if (g < G) {
     int img = node_img[g];
     int line = (int)(g - seg_off[img]);
     // all loads of a chunk of 16 blocks first, then the stores: interleaved, every load would have to wait for
     // the store before it (same array as far as the compiler can tell) -- 20 serial round trips per thread
     const long long b0 = nb_off[img], b1 = nb_off[img + 1];
+    nbv = ((unsigned)b0 << 8) | (unsigned)(b1 - b0);
     for (long long bb = b0; bb < b1; bb += 16) {
       long long e[16];
       unsigned c[16];
@@ -1212,10 +1215,14 @@ k_node_prefix(long long G, const int *__restrict__ node_img, const long long *__
     }
   }
   __syncthreads();
+  const long long off = s_prefix + wbase + incl - (long long)run;
   if (g <= G) {
-    tri_off[g] = s_prefix + wbase + incl - (long long)run;
+    tri_off[g] = off;
     n_tris[g] = run;
   }
+  // the scoring prologue record of the node's candidates (CandMeta, lt_kernels_score.hip), 16 bytes per node: k_cand_meta
+  // then copies it with one gather per candidate instead of five (tri_off twice, node_img, nb_off twice)
+  if (node_rec && g < G) node_rec[g] = uint4{(unsigned)(off & 0xFFFFFFFFll), (unsigned)(off >> 32), run, nbv};
 }
 
 // Fast path: move every staged candidate to its final, reference-ordered position
@@ -1509,9 +1516,9 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,
                         unsigned *base_bl, unsigned *n_tris, long long *tri_off, unsigned long long *status,
-                        int *err_flag) {
+                        int *err_flag, void *node_rec) {
   hipLaunchKernelGGL(k_node_prefix, dim3(nblk2(G + 1, 256)), dim3(256), 0, st, G, node_img, seg_off, nb_off,
-                     blk_line_base, cnt_bl, base_bl, n_tris, tri_off, status, err_flag);
+                     blk_line_base, cnt_bl, base_bl, n_tris, tri_off, status, err_flag, reinterpret_cast<uint4 *>(node_rec));
 }
 void launch_place(hipStream_t st, int n_blk, long long max_rows, const long long *m_off, const int *blk_img,
                   const long long *seg_off, const long long *blk_line_base, const unsigned *base_bl,
