@@ -494,17 +494,18 @@ k_gates_ex(int n_blk, int max_chunks, long long n_items, GenCfg cfg, const long 
 }
 
 // One-pass exhaustive mode, dense evaluation: one wave per block of 64 listed connections (all of one image pair).
-// Exact gates where the cheap ones could not decide, triangulation.  The survivors of a block (27 % of its 64
-// entries on the bench scene) are COMPACTED to the front of the block's 64 staging slots, in lane order: record,
+// Exact gates where the cheap ones could not decide, triangulation.  The survivors of a block (78 % of its entries on
+// the bench scene: 2.2e7 of 2.85e7) are COMPACTED to the front of the block's 64 staging slots, in lane order: record,
 // uncertainty, depth key, node and -- in place -- the 8-byte entry k_place_ex decodes; the slots behind them are holes
 // (node = ~0).  Round 5: the kernel used to store the whole 8 KB record row of every block that had a survivor, holes
-// included -- 4.75 GB of writes per launch against 1.1 GB of records (1.82 -> 1.58 ms).  Measured and not kept: the
-// staging arrays dense across blocks -- one cursor per region serialises its 3e4 atomics at ~100 ns each (+1.3 ms),
-// 64 cursors per region: +0.1 ms against this form; the kernel persistent with the next block's entries and image
-// ids loaded ahead: 187 registers (+0.1 ms), capped at 128: 45 spills (+0.26 ms); entry and uncertainty compacted by
-// shuffles instead of LDS (32 KB: five workgroups to a CU instead of four): +0.15 ms.  A survivor also sets its bit in
-// the ballot word of its work item (masks zeroed beforehand) -- from there on the counts, offsets and the
-// permutation are those of the two-pass form.
+// included: 4.75 -> 4.0 GB of writes per launch, 1.82 -> 1.58 ms.  The kernel is bound by those stores (2.2e7 records
+// of 128 bytes + 20 bytes of keys each; 3.2 TB/s of mixed traffic, VALU issue 0.28; without its stores: 0.8 ms).
+// Measured and not kept: the staging arrays dense across blocks -- one cursor per region serialises its 3e4 atomics at
+// ~100 ns each (+1.3 ms), 64 cursors per region: +0.1 ms against this form; the kernel persistent (grid = resident
+// set): no change; persistent with the next block's entries and image ids loaded ahead: 187 registers (+0.1 ms),
+// capped at 128: 45 spills (+0.26 ms); entry and uncertainty compacted by shuffles instead of LDS (32 KB: five
+// workgroups to a CU instead of four): +0.15 ms.  A survivor also sets its bit in the ballot word of its work item
+// (masks zeroed beforehand) -- from there on the counts, offsets and the permutation are those of the two-pass form.
 __global__ void __launch_bounds__(256)
 k_tri_ex(unsigned long long *__restrict__ ent, const unsigned long long *__restrict__ ctr, unsigned region_cap,
          GenCfg cfg, long long n_items, const long long *__restrict__ item_off, const int *__restrict__ blk_img,

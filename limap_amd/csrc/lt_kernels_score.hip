@@ -1129,8 +1129,8 @@ size_t score3_lds_bytes(int max_nb, bool f32) {
   return ((base + (size_t)max_nb * 4 + 15) & ~(size_t)15) + (size_t)max_nb * 64 * 8;
 }
 size_t cand_meta_bytes() { return sizeof(CandMeta); }
-// split form: tiles per unit of k_dense8 for a job's widest neighbour list (one table of maxima per tile: three workgroups
-// per CU at 48 KB), bytes of an overflow chunk and of a pair entry, and the number of overflow chunks for C candidates
+// split form: tiles per unit of k_dense8 for a job's widest neighbour list (one table of maxima per tile: kDensePerCU
+// workgroups per CU within kDenseLdsBudget each), bytes of an overflow chunk and of a pair entry, and the number of overflow chunks for C candidates
 int score_split_t_max(int max_nb) {
   const int t = (kDenseLdsBudget) / (std::max(max_nb, 1) * 512);
   return std::max(1, std::min(kChunkTiles, t));
