@@ -167,6 +167,19 @@ def feed(ctx, scene, imgs, mode, topk):
     ctx.upload()
 
 
+def shard_node_ranges(scene, world, weights):
+    """every rank's node range [g_lo, g_hi) under ltdist.shard_images (deterministic: each rank computes all of them) and a
+    key capacity for the one-collective form of merge_shards_device: 8 valid edges per node of the largest shard (the
+    bench scenes have 0.3-2; a rank that exceeds it fails loudly)"""
+    from limap_amd import dist as ltdist
+    ranges = []
+    for r in range(world):
+        imgs = ltdist.shard_images(scene.img_ids, r, world, weights)
+        idx = np.searchsorted(scene.img_ids, imgs)
+        ranges.append((int(scene.seg_off[idx[0]]), int(scene.seg_off[idx[-1] + 1])) if len(idx) else (0, 0))
+    return ranges, 8 * max(max(b - a for a, b in ranges), 1)
+
+
 def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, warmup=2, n_full=3):
     """BASELINE.json configs[2] (1000 views x 1000 segs, 4 rooms, 3000 GT segments, seed 1) as a STRONG-scaling leg of the
     same run: the fixed job is sharded by image over the `world` ranks, one all-gather per step brings the scene to every
@@ -190,18 +203,22 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
     ctx = _capi.Context(cfg_dict=cfg, device=local_rank)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     ctx.set_ranges(*scene.ranges)
-    gather = ltdist.SceneGather(scene.img_ids, scene.seg_off, rank, world, dev, weights=weights, force_collective=use_dist)
+    gather = ltdist.SceneGather(scene.img_ids, scene.seg_off, rank, world, _comm_dev(dev), weights=weights, force_collective=use_dist)
     gather.load_local(scene.kvec, scene.qvec, scene.tvec, scene.segs)
     d_k, d_q, d_t, d_s = gather.all_gather()
+    if ONE_GPU:
+        d_k, d_q, d_t, d_s = d_k.to(dev), d_q.to(dev), d_t.to(dev), d_s.to(dev)
     ctx.init_device(scene.img_ids, d_k.data_ptr(), d_q.data_ptr(), d_t.data_ptr(), scene.seg_off, d_s.data_ptr())
     feed(ctx, scene, my_imgs, "matched", 10)
-    ctx.set_scene_chunks(*gather.chunk_pointers())
+    if not ONE_GPU:
+        ctx.set_scene_chunks(*gather.chunk_pointers())
     pending = [gather.gather_async()]
+    merge_dev = None if ONE_GPU else dev
 
     def step():
         if pending[0] is not None:
             pending[0].wait()
-        if gather.collective:
+        if gather.collective and not ONE_GPU:
             ctx.refresh_scene_chunks()
         pending[0] = gather.gather_async()
         ctx.run_device(wait=False)
@@ -216,7 +233,7 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
     def rmax(x):
         if not use_dist:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=_comm_dev(dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -233,6 +250,7 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
     elapsed = rmax(time.perf_counter() - t0)
     my_idx = np.searchsorted(scene.img_ids, my_imgs)
     node_range = (int(scene.seg_off[my_idx[0]]), int(scene.seg_off[my_idx[-1] + 1])) if len(my_idx) else (0, 0)
+    all_ranges, key_cap = shard_node_ranges(scene, world, weights)  # -> ONE collective per merge
     note = None
     tf0 = time.perf_counter()
     try:
@@ -243,7 +261,7 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
             step()
             ctx.sync()
             if world > 1:
-                ltdist.merge_shards_device(ctx, node_range, rank, world, dev)
+                ltdist.merge_shards_device(ctx, node_range, rank, world, merge_dev, all_ranges=all_ranges, key_cap=key_cap)
             if rank == 0:
                 ctx.compute_tracks()
         sync()
@@ -258,7 +276,7 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
             def merge_and_begin():
                 ctx.sync()
                 if world > 1:
-                    ltdist.merge_shards_device(ctx, node_range, rank, world, dev)
+                    ltdist.merge_shards_device(ctx, node_range, rank, world, merge_dev, all_ranges=all_ranges, key_cap=key_cap)
                 if rank == 0:
                     ctx.compute_tracks_begin()
             sync()
@@ -283,11 +301,11 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
     cand = float(st["candidates"])
     per_rank = [1e3 * local / steps]
     if use_dist:
-        tot = torch.tensor([cand], dtype=torch.float64, device=dev)
+        tot = torch.tensor([cand], dtype=torch.float64, device=_comm_dev(dev))
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         cand = float(tot.item())
-        allr = torch.zeros(world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allr, torch.tensor([per_rank[0]], dtype=torch.float64, device=dev))
+        allr = torch.zeros(world, dtype=torch.float64, device=_comm_dev(dev))
+        dist.all_gather_into_tensor(allr, torch.tensor([per_rank[0]], dtype=torch.float64, device=_comm_dev(dev)))
         per_rank = allr.cpu().tolist()
     res = {"workload": (f"synthetic {shape['n_views']} views x {shape['n_segs']} segs/view in total, {shape['n_neighbors']} neighbours, "
                         "matched topk=10" + ("" if small else ", 4 rooms (BASELINE configs[2])")),
@@ -302,6 +320,16 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
 
 
 _REAL_STDOUT = None
+# LT_BENCH_ONE_GPU=1 (tests): an N-rank job whose ranks all use cuda:0 -- backend gloo (RCCL wants a device per rank), the
+# scene gathered through host tensors and copied to the device, no per-step refresh from the receive buffer.  It exists to run
+# the N > 1 control flow of this file (sharding, merges, reductions, the strong leg) on a one-GPU box.
+ONE_GPU = os.environ.get("LT_BENCH_ONE_GPU") == "1"
+
+
+def _comm_dev(dev):
+    """device of the small tensors that go through collectives"""
+    import torch
+    return torch.device("cpu") if ONE_GPU else dev
 
 
 def _quiet_stdout():
@@ -369,6 +397,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if ONE_GPU:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # LT_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, all-gather, barrier, reductions)
@@ -378,7 +408,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if ONE_GPU:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from limap_amd import _capi
     from limap_amd import synthetic as syn
@@ -407,9 +440,11 @@ def main():
     ctx.set_ranges(*scene.ranges)
 
     # ---- scene payload: this rank uploads only its own images, the rest arrives by all-gather ----
-    gather = ltdist.SceneGather(scene.img_ids, scene.seg_off, rank, world, dev, weights=weights, force_collective=use_dist)
+    gather = ltdist.SceneGather(scene.img_ids, scene.seg_off, rank, world, _comm_dev(dev), weights=weights, force_collective=use_dist)
     gather.load_local(scene.kvec, scene.qvec, scene.tvec, scene.segs)
     d_k, d_q, d_t, d_s = gather.all_gather()
+    if ONE_GPU:
+        d_k, d_q, d_t, d_s = d_k.to(dev), d_q.to(dev), d_t.to(dev), d_s.to(dev)
     ctx.init_device(scene.img_ids, d_k.data_ptr(), d_q.data_ptr(), d_t.data_ptr(), scene.seg_off, d_s.data_ptr())
 
     # ---- this rank's images: buffer + upload the match lists (resident before the timed region) ----
@@ -418,7 +453,9 @@ def main():
     t_upload = time.perf_counter() - t_up0
 
     # per-step path: the invariants are rebuilt straight from the all-gather's receive buffer
-    ctx.set_scene_chunks(*gather.chunk_pointers())
+    if not ONE_GPU:
+        ctx.set_scene_chunks(*gather.chunk_pointers())
+    merge_dev = None if ONE_GPU else dev
 
     # One step = the scene of one batch arrives by all-gather, the invariants are rebuilt from the receive
     # buffer, the hot path runs.  The collective for the NEXT step is launched as soon as this step's
@@ -431,7 +468,7 @@ def main():
             pending[0].wait()
         # the invariants (camera / segment records) are rebuilt from the receive buffer when an all-gather has refilled it;
         # a one-rank job without the collective has nothing new to rebuild them from (they were built by init_device)
-        if gather.collective:
+        if gather.collective and not ONE_GPU:
             ctx.refresh_scene_chunks()
         pending[0] = gather.gather_async()
         # enqueue only: the host's end-of-run bookkeeping of step k (result slots, event timings) happens
@@ -511,11 +548,12 @@ def main():
     # global node index (images are sharded in id order).
     my_idx = np.searchsorted(scene.img_ids, my_imgs)
     node_range = (int(scene.seg_off[my_idx[0]]), int(scene.seg_off[my_idx[-1] + 1])) if len(my_idx) else (0, 0)
+    all_ranges, key_cap = shard_node_ranges(scene, world, weights)  # -> ONE collective per merge
     merge_note, t_merge = None, None
     if world > 1:
         try:
             tm0 = time.perf_counter()
-            ltdist.merge_shards_device(ctx, node_range, rank, world, dev)
+            ltdist.merge_shards_device(ctx, node_range, rank, world, merge_dev, all_ranges=all_ranges, key_cap=key_cap)
             t_merge = time.perf_counter() - tm0
         except Exception as e:  # never lose the throughput line over the (untimed) merge
             merge_note = f"merge failed: {type(e).__name__}: {e}"
@@ -538,7 +576,7 @@ def main():
             step()
             ctx.sync()
             if world > 1:  # (nothing is downloaded: the tail works from device-resident results, merged on the device)
-                ltdist.merge_shards_device(ctx, node_range, rank, world, dev)
+                ltdist.merge_shards_device(ctx, node_range, rank, world, merge_dev, all_ranges=all_ranges, key_cap=key_cap)
             if rank == 0 or world == 1:
                 ctx.compute_tracks()
         sync()
@@ -549,7 +587,7 @@ def main():
         pending[0].wait()
         torch.cuda.synchronize(dev)
     if use_dist:
-        t_f = torch.tensor([full_elapsed], dtype=torch.float64, device=dev)
+        t_f = torch.tensor([full_elapsed], dtype=torch.float64, device=_comm_dev(dev))
         dist.all_reduce(t_f, op=dist.ReduceOp.MAX)
         full_elapsed = float(t_f.item())
     step_full_ms = None if full_note else 1e3 * full_elapsed / n_full
@@ -561,14 +599,14 @@ def main():
 
     per_rank_ms = [1e3 * elapsed_local / max(args.steps, 1)]
     if use_dist:
-        t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t_el = torch.tensor([elapsed], dtype=torch.float64, device=_comm_dev(dev))
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         elapsed = float(t_el.item())
-        tot = torch.tensor([st["candidates"], st["connections"], st["pairs"]], dtype=torch.float64, device=dev)
+        tot = torch.tensor([st["candidates"], st["connections"], st["pairs"]], dtype=torch.float64, device=_comm_dev(dev))
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         cand_total, conn_total, pairs_total = [float(x) for x in tot.tolist()]
-        loc = torch.tensor([per_rank_ms[0], float(st["candidates"]), float(len(my_imgs))], dtype=torch.float64, device=dev)
-        allr = torch.zeros(3 * world, dtype=torch.float64, device=dev)
+        loc = torch.tensor([per_rank_ms[0], float(st["candidates"]), float(len(my_imgs))], dtype=torch.float64, device=_comm_dev(dev))
+        allr = torch.zeros(3 * world, dtype=torch.float64, device=_comm_dev(dev))
         dist.all_gather_into_tensor(allr, loc)
         allr = allr.cpu().numpy().reshape(world, 3)
         per_rank_ms = allr[:, 0].tolist()
@@ -649,7 +687,7 @@ def main():
             "track_report": track_report_gpu,
             "ranks": {"world_size": dist.get_world_size() if use_dist else 1,
                       "n_ranks_rccl": dist.get_world_size() if (use_dist and dist.get_backend() == "nccl") else 0,
-                      "backend": (dist.get_backend() + " (RCCL)") if use_dist else None,
+                      "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if use_dist else None,
                       "ms_per_step_per_rank": per_rank_ms, "candidates_per_rank": per_rank_cand,
                       "images_per_rank": per_rank_imgs, "allgather_alone_us": allgather_us},
             "device_source_hash": device_source_hash(),
@@ -662,7 +700,7 @@ def main():
     if args.sustain_s > 0 and not args.no_extras:
         n_s = max(args.steps, int(args.sustain_s * 1e3 / max(ms_per_step, 1e-3)))
         if use_dist:
-            t_n = torch.tensor([n_s], dtype=torch.int64, device=dev)
+            t_n = torch.tensor([n_s], dtype=torch.int64, device=_comm_dev(dev))
             dist.broadcast(t_n, 0)
             n_s = int(t_n.item())
         sync()
@@ -672,7 +710,7 @@ def main():
         sync()
         el_s = time.perf_counter() - ts0
         if use_dist:
-            t_s = torch.tensor([el_s], dtype=torch.float64, device=dev)
+            t_s = torch.tensor([el_s], dtype=torch.float64, device=_comm_dev(dev))
             dist.all_reduce(t_s, op=dist.ReduceOp.MAX)
             el_s = float(t_s.item())
         sustained = {"steps": n_s, "seconds": el_s, "sustained_ms_per_step": 1e3 * el_s / n_s}

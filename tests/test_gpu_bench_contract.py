@@ -62,3 +62,34 @@ def test_bench_collective_path_one_rank(gpu_lib):
     assert d["sustained_ms_per_step"] > 0
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["counts"]["candidates"] > 0 and d["tracks_whole_scene"] > 0
+
+
+def test_bench_two_ranks_on_one_gpu(gpu_lib):
+    """bench.py as the driver launches it for N = 2 -- torch.distributed.run, two ranks -- on the ONE GPU a test box has
+    (LT_BENCH_ONE_GPU=1: both ranks on cuda:0, gloo instead of RCCL, the scene gathered through host tensors): the N > 1
+    control flow of the file -- connection-weighted shards, the merge of the shards on rank 0 in its one-collective form,
+    the reductions over ranks, the strong-scaling leg with its sequential and its overlapped tail -- runs to the JSON
+    line, and the whole-scene track count is that of a one-rank run of the same scene."""
+    common = ["--steps", "3", "--warmup", "1", "--views", "12", "--segs", "60", "--neighbors", "5", "--no-cpu-baseline",
+              "--no-extras", "--strong-leg", "on", "--sustain-s", "0.2", "--scaling", "strong"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LT_BENCH_STRONG_SCENE="30,80,6")
+    res2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(ROOT, "bench.py"),
+                           "--gpus", "2"] + common,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT,
+                          env=dict(env, LT_BENCH_ONE_GPU="1"))
+    assert res2.returncode == 0, res2.stderr[-3000:]
+    d2 = json.loads(res2.stdout.strip().splitlines()[-1])
+    res1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res1.returncode == 0, res1.stderr[-3000:]
+    d1 = json.loads(res1.stdout.strip().splitlines()[-1])
+    assert d2["n_gpus"] == 2 and d2["ranks"]["world_size"] == 2 and d2["ranks"]["backend"] == "gloo"
+    assert d2["merge_note"] is None, d2["merge_note"]
+    assert d2["counts"]["candidates"] == d1["counts"]["candidates"] > 0
+    assert d2["tracks_whole_scene"] == d1["tracks_whole_scene"] > 0
+    s2, s1 = d2["strong_config3"], d1["strong_config3"]
+    assert "error" not in s2 and s2["note"] is None and s2["overlapped_note"].startswith("the host half"), s2
+    assert s2["n_gpus"] == 2 and len(s2["ms_per_step_per_rank"]) == 2
+    assert s2["candidates"] == s1["candidates"] > 0 and s2["tracks_rank0"] == s1["tracks_rank0"] > 0
+    assert s2["step_with_merge_and_tail_ms"] > 0 and s2["step_with_merge_and_tail_overlapped_ms"] > 0
