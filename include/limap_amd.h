@@ -233,7 +233,8 @@ int lt_import_image_results(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb
  * device copies; the pointers may be device or host memory.  Order of calls: every rank lt_shard_count; lt_shard_build
  * (total_keys = the sum over the ranks on the rank that merges, the own count elsewhere); the other ranks lt_shard_export;
  * the merging rank lt_shard_import once per other rank, then lt_compute_tracks (which needs the device form of the
- * tail: min_num_outer_edges == 0). */
+ * tail; with imported shards: min_num_outer_edges == 0).  lt_shard_import checks on the device that every imported key
+ * names two nodes of this scene as (min << kb | max) -- LT_ERR_ARGUMENT otherwise; the node blobs are taken as they are. */
 int lt_shard_node_bytes(void);
 int lt_shard_count(lt_ctx *ctx, int64_t *n_keys);
 int lt_shard_build(lt_ctx *ctx, int64_t total_keys);

@@ -756,10 +756,19 @@ int lt_shard_import(lt_ctx *ctx, int64_t g_lo, int64_t g_hi, const void *nodes_b
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_best_src.as<int>() + 2 * g_lo, in + (sizeof(Cand) + 8) * n, 8 * n, hipMemcpyDefault, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_ntris.as<int>() + g_lo, in + (sizeof(Cand) + 16) * n, 4 * n, hipMemcpyDefault, st));
   }
-  if (n_keys > 0)
+  int bad = 0;
+  if (n_keys > 0) {
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_tail_keys.as<unsigned long long>() + ctx->shard_keys, keys_blob, 8 * (size_t)n_keys,
                                hipMemcpyDefault, st));
+    // the keys index the per-node arrays in the similarity kernel: both ids must be nodes of this scene
+    ENSURE(ctx, ctx->d_err, sizeof(int));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_err.p, 0, sizeof(int), st));
+    launch_check_keys(st, n_keys, ctx->d_tail_keys.as<unsigned long long>() + ctx->shard_keys, bits_for(ctx->G + 1), ctx->G,
+                      ctx->d_err.as<int>());
+    HIPCHK(ctx, hipMemcpyAsync(&bad, ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  }
   HIPCHK(ctx, hipStreamSynchronize(st));  // the source buffers belong to the caller
+  if (bad) return fail(ctx, LT_ERR_ARGUMENT, "lt_shard_import: a key names a node outside this scene (or is not min << kb | max)");
   ctx->shard_keys += n_keys;
   ctx->tracks_done = false;
   return LT_OK;

@@ -182,6 +182,19 @@ void launch_tail_sims(hipStream_t st, long long E, const unsigned long long *ske
     hipLaunchKernelGGL(k_tail_sims, dim3((unsigned)((E + 1 + 255) / 256)), dim3(256), 0, st, E, skeys, n_tris, best_c,
                        cfg, kb, sims, mark, keep, flags);
 }
+// keys that arrive from another rank (lt_shard_import): both node ids must be nodes of this scene and min < max as
+// lt_shard_export writes them -- the similarity kernel indexes the per-node arrays with them
+__global__ void k_check_keys(long long n, const unsigned long long *__restrict__ keys, int kb, long long G,
+                             int *__restrict__ bad) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = keys[i];
+  const unsigned long long a = k >> kb, b = k & ((1ull << kb) - 1ull);
+  if (a >= (unsigned long long)G || b >= (unsigned long long)G || a >= b) *bad = 1;
+}
+void launch_check_keys(hipStream_t st, long long n, const unsigned long long *keys, int kb, long long G, int *bad) {
+  if (n > 0) hipLaunchKernelGGL(k_check_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, keys, kb, G, bad);
+}
 void launch_outer_filter(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag, const CRec *cand,
                          const long long *seg_off, const unsigned *perm, int min_outer, unsigned char *flags, int *changed) {
   if (G > 0)

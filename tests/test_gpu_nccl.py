@@ -176,3 +176,38 @@ def test_one_collective_merge_fails_loudly_when_the_keys_do_not_fit(gpu_lib):
     out = _run(2, "gloo", merge="device1_small")
     assert all("error" in r[2] for r in out), out
     assert "key_cap" in out[1][2]["error"] and "could not send" in out[0][2]["error"]
+
+
+def test_shard_import_rejects_keys_outside_the_scene(gpu_lib):
+    """lt_shard_import range-checks the keys it is handed (they index the per-node arrays in the similarity kernel): a
+    key that names a node >= G, or is not (min << kb | max), is an argument error -- and a clean re-import still works."""
+    from limap_amd import _capi, synthetic as syn, triangulation as tri
+    sc = syn.make_scene(n_views=10, n_segs=80, n_neighbors=5, seed=77)
+    T = tri.GlobalLineTriangulator(syn.default_triangulation_cfg())
+    T.SetRanges(sc.ranges)
+    T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, [sc.segs_of(j) for j in range(sc.n_images)])
+    T.TriangulateAll({int(i): sc.matches_of(int(i)) for i in sc.img_ids})
+    ctx = T.context()
+    ctx.upload()
+    ctx.run_device()
+    n = ctx.shard_count()
+    assert n > 0
+    G = int(sc.seg_off[-1])
+    nodes = np.zeros(ctx.shard_node_bytes() * G, np.uint8)
+    keys = np.zeros(n, np.uint64)
+    ctx.shard_build(n)                           # as a sending rank: its own keys only
+    ctx.shard_export(0, G, nodes.ctypes.data, keys.ctypes.data)
+    assert ctx.shard_count() == n
+    ctx.shard_build(2 * n)                       # as the merging rank: room for one other rank with as many keys
+    kb = max(1, int(G).bit_length())             # bits_for(G + 1): the smallest kb with 2^kb >= G + 1
+    assert int(keys.max() & np.uint64((1 << kb) - 1)) < G and int(keys.max() >> np.uint64(kb)) < G
+    bad = keys.copy()
+    bad[n // 2] = np.uint64(((G + 5) << kb) | (G + 9))   # both ids beyond the scene
+    with pytest.raises(ValueError, match="outside this scene"):
+        ctx.shard_import(0, G, nodes.ctypes.data, n, bad.ctypes.data)
+    swapped = keys.copy()
+    a, b = int(keys[0] >> np.uint64(kb)), int(keys[0] & np.uint64((1 << kb) - 1))
+    swapped[0] = np.uint64((b << kb) | a)               # max << kb | min
+    with pytest.raises(ValueError, match="outside this scene"):
+        ctx.shard_import(0, G, nodes.ctypes.data, n, swapped.ctypes.data)
+    ctx.shard_import(0, G, nodes.ctypes.data, n, keys.ctypes.data)   # the same shard again, untouched: accepted
