@@ -81,6 +81,10 @@ def _preload_torch_hip_runtime():
     this extension's NEEDED libamdhip64.so.7 resolve to it, whatever the import order.  No torch, no-op."""
     if "torch" in sys.modules:
         return
+    # LIMAP_AMD_SYSTEM_HIP=1: a process that will never import torch and uses /opt/rocm's stack throughout (e.g. one that
+    # loads liblimap_amd_rccl.so, which links the system's librccl) keeps the system runtime
+    if os.environ.get("LIMAP_AMD_SYSTEM_HIP") == "1":
+        return
     try:
         import importlib.util
         spec = importlib.util.find_spec("torch")
