@@ -360,8 +360,11 @@ def main():
     _quiet_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: a timed region of ~50 ms (200 steps of 0.25 ms) -- with 20 steps the 5 ms region carried ~4 % of fixed cost
+    # (the first step's enqueue latency, the final synchronisation's wake-up) and was too short for an outside observer
+    # of the GPU to see
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--views", type=int, default=100, help="views per GPU (weak scaling) / in total (strong scaling)")
     ap.add_argument("--segs", type=int, default=500)
     ap.add_argument("--neighbors", type=int, default=20)
