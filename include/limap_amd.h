@@ -175,7 +175,8 @@ int lt_compute_tracks(lt_ctx *ctx);
  * nodes' records into page-locked memory -- and returns; the caller may then enqueue the NEXT run (lt_run_device_async);
  * _end waits for the tail's own event, not for that run, and does the host half (graph, union-find, aggregation:
  * global_line_triangulator.cc:234-351) while the device works on the next step.  Needs the device form of the tail
- * (results resident, min_num_outer_edges == 0); lt_compute_tracks() == _begin + _end. */
+ * (results of the run resident on the device; min_num_outer_edges > 0 is fine for a single context -- the node filter
+ * runs on the device -- but not over imported shards); lt_compute_tracks() == _begin + _end. */
 int lt_compute_tracks_begin(lt_ctx *ctx);
 int lt_compute_tracks_end(lt_ctx *ctx);
 

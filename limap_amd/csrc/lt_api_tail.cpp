@@ -102,13 +102,25 @@ static int tail_device_enqueue(lt_ctx *ctx) {
   ctx->C = ctx->C_last;
   lt_ctx::TailPending &tp_ = ctx->tail_pend;
   tp_ = lt_ctx::TailPending();
-  tp_.active = true;
   tp_.E = E;
   if (E <= 0) {
     // no valid edge anywhere: with a node filter every node falls short of min_num_outer_edges
     if (ctx->cfg.min_num_outer_edges > 0 && !merged) ctx->valid_flags.assign((size_t)G, 0);
+    tp_.active = true;
     return LT_OK;
   }
+  // the tail counts as "in flight" only once its event is recorded.  Every error return before that point
+  // releases the page-locked block and leaves tail_pend cleared, so a retry starts from scratch instead of collecting
+  // from a block that was never filled.
+  struct PendGuard {
+    lt_ctx *c;
+    bool armed = true;
+    ~PendGuard() {
+      if (!armed) return;
+      if (c->tail_pend.hb.p) lt_host::host_block_release(c->tail_pend.hb);
+      c->tail_pend = lt_ctx::TailPending();
+    }
+  } guard{ctx};
   const size_t En = (size_t)E;
   if (!merged) ENSURE(ctx, ctx->d_tail_keys, 8 * En);
   ENSURE(ctx, ctx->d_tail_skeys, 8 * En); ENSURE(ctx, ctx->d_tail_sims, 8 * En);
@@ -122,13 +134,15 @@ static int tail_device_enqueue(lt_ctx *ctx) {
   // block; at most E distinct edges and min(G, 2 E) nodes enter the graph
   const size_t max_nodes = (size_t)std::min<long long>(G, 2 * E);
   const size_t o_pairs = 64, o_recs = o_pairs + 16 * En, o_nodes = o_recs + tail_rec_bytes() * max_nodes;
-  lt_host::HostBlock hb = lt_host::host_block_acquire(o_nodes + 4 * max_nodes);
-  if (!hb.p) {
-    tp_.active = false;
-    return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the edge list");
-  }
-  tp_.hb = hb;  // released by tail_device_collect
+  // with the node filter the per-node flags travel in the same block (copied on the context stream in front of the
+  // event: tail_device_collect needs no device copy of its own and cannot wait on a run enqueued behind the tail)
+  const bool with_filter = ctx->cfg.min_num_outer_edges > 0 && !merged;
+  const size_t o_flags = (o_nodes + 4 * max_nodes + 63) / 64 * 64;
+  lt_host::HostBlock hb = lt_host::host_block_acquire(o_flags + (with_filter ? (size_t)G : 0));
+  if (!hb.p) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the edge list");
+  tp_.hb = hb;  // released by tail_device_collect (or by the guard above on an error return)
   tp_.max_nodes = max_nodes; tp_.o_pairs = o_pairs; tp_.o_recs = o_recs; tp_.o_nodes = o_nodes; tp_.kb = kb;
+  tp_.o_flags = o_flags;
   char *base = (char *)hb.p;
   long long *hn = (long long *)base;  // [0] graph nodes, [1] graph edges
   hn[0] = hn[1] = 0;
@@ -139,7 +153,7 @@ static int tail_device_enqueue(lt_ctx *ctx) {
   // filterNodeByNumOuterEdges (:168-232) on the resident run: passes of k_outer_filter until one changes nothing (the
   // flag comes back every four passes; a scene needs a handful)
   const unsigned char *d_flags = nullptr;
-  if (ctx->cfg.min_num_outer_edges > 0 && !merged) {
+  if (with_filter) {
     ENSURE(ctx, ctx->d_outer_flags, (size_t)G + 64);
     unsigned char *fl = ctx->d_outer_flags.as<unsigned char>();
     int *d_changed = reinterpret_cast<int *>(fl + (((size_t)G + 15) / 16) * 16);
@@ -158,6 +172,7 @@ static int tail_device_enqueue(lt_ctx *ctx) {
     }
     d_flags = fl;
     tp_.filtered = true;
+    HIPCHK(ctx, hipMemcpyAsync(base + o_flags, fl, (size_t)G, hipMemcpyDeviceToHost, st));
   }
   LinkCfg3 l3 = make_l3(ctx->cfg);
   l3.use_angle = 1; l3.use_overlap = 1; l3.use_perp = 0; l3.use_innerseg = 1; l3.use_scaleinv = 0;  // line_linker.h:123-129
@@ -190,6 +205,8 @@ static int tail_device_enqueue(lt_ctx *ctx) {
   HIPCHK(ctx, hipGetLastError());
   if (!ctx->ev_tail) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
   HIPCHK(ctx, hipEventRecord(ctx->ev_tail, st));
+  tp_.active = true;
+  guard.armed = false;
   lap("enqueue");
   return LT_OK;
 }
@@ -209,6 +226,7 @@ static int tail_device_collect(lt_ctx *ctx, AddEdge &&add_edge) {
   tp_.active = false;
   const long long E = tp_.E;
   if (E <= 0) return LT_OK;
+  if (!tp_.hb.p) return fail(ctx, LT_ERR_STATE, "internal: device tail in flight without its host block");
   struct Rel {
     lt_host::HostBlock b;
     ~Rel() { lt_host::host_block_release(b); }
@@ -221,8 +239,8 @@ static int tail_device_collect(lt_ctx *ctx, AddEdge &&add_edge) {
   const unsigned long long *hpairs = (const unsigned long long *)(base + o_pairs);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipEventSynchronize(ctx->ev_tail));
-  if (tp_.filtered)  // valid_flags_ of the reference (GetAllValidBestTris ... read them)
-    HIPCHK(ctx, hipMemcpy(ctx->valid_flags.data(), ctx->d_outer_flags.p, (size_t)ctx->G, hipMemcpyDeviceToHost));
+  if (tp_.filtered)  // valid_flags_ of the reference (GetAllValidBestTris ... read them): copied in front of the event
+    std::memcpy(ctx->valid_flags.data(), base + tp_.o_flags, (size_t)ctx->G);
   lap("sync");
   const long long Nm = hn[0], Ne = hn[1];
   if (Nm < 0 || (size_t)Nm > max_nodes || Ne < 0 || Ne > E)
@@ -275,8 +293,9 @@ int lt_compute_tracks_begin(lt_ctx *ctx) {
     return fail(ctx, LT_ERR_RUNTIME, "Error!The given merging strategy is not implemented");
   if (ctx->tail_pend.active) return fail(ctx, LT_ERR_STATE, "lt_compute_tracks_begin: a tail is already in flight");
   if (!tail_on_device(ctx))
-    return fail(ctx, LT_ERR_STATE, "lt_compute_tracks_begin needs the device form of the tail (results resident, "
-                                   "min_num_outer_edges == 0): call lt_compute_tracks instead");
+    return fail(ctx, LT_ERR_STATE, "lt_compute_tracks_begin needs the device form of the tail (results of the run "
+                                   "resident on the device; with imported shards min_num_outer_edges == 0): call "
+                                   "lt_compute_tracks instead");
   lt_host::SpinPool::get(lt_host::row_workers()).wake();
   int rc;
   if (!ctx->uploaded && (rc = lt_upload(ctx))) return rc;

@@ -313,7 +313,7 @@ struct lt_ctx {
     bool active = false;
     long long E = 0;
     lt_host::HostBlock hb;
-    size_t max_nodes = 0, o_pairs = 0, o_recs = 0, o_nodes = 0;
+    size_t max_nodes = 0, o_pairs = 0, o_recs = 0, o_nodes = 0, o_flags = 0;
     int kb = 0;
     bool filtered = false;  // the node filter ran on the device: valid_flags come from d_outer_flags
   } tail_pend;

@@ -29,6 +29,7 @@ struct lt_dist {
   void *d_blob = nullptr, *d_got = nullptr;  // merge: this rank's blob | rank 0: world blobs
   size_t blob_cap = 0, got_cap = 0;
   long long *d_cnt = nullptr;  // 3 x world int64 (size exchange of the two-collective merge)
+  long long h_hdr[8] = {0}, h_mine[3] = {0};  // sources of asynchronous copies: must outlive an early error return
   std::string err;
 };
 
@@ -207,8 +208,9 @@ int lt_dist_merge_shards(lt_dist *d, int64_t key_cap, int64_t *n_keys_merged) {
   std::vector<long long> counts;  // known up front only in the two-collective form
   int64_t max_keys = key_cap;
   if (key_cap <= 0) {
-    long long mine[3] = {(long long)n_keys, (long long)lo[rank], (long long)hi[rank]};
-    DHIP(d, hipMemcpyAsync(d->d_cnt + 3 * rank, mine, sizeof(mine), hipMemcpyHostToDevice, d->st));
+    long long *mine = d->h_mine;
+    mine[0] = (long long)n_keys; mine[1] = (long long)lo[rank]; mine[2] = (long long)hi[rank];
+    DHIP(d, hipMemcpyAsync(d->d_cnt + 3 * rank, mine, sizeof(d->h_mine), hipMemcpyHostToDevice, d->st));
     DNCCL(d, ncclAllGather(d->d_cnt + 3 * rank, d->d_cnt, 3, ncclInt64, d->comm, d->st));
     std::vector<long long> all((size_t)3 * world);
     DHIP(d, hipMemcpyAsync(all.data(), d->d_cnt, 8 * all.size(), hipMemcpyDeviceToHost, d->st));
@@ -217,6 +219,13 @@ int lt_dist_merge_shards(lt_dist *d, int64_t key_cap, int64_t *n_keys_merged) {
     max_keys = 1;
     for (int r = 0; r < world; ++r) {
       counts[r] = all[(size_t)3 * r];
+      // a peer that sharded differently (other weights, another seg_off) would be imported into the wrong node range
+      if (counts[r] < 0 || all[(size_t)3 * r + 1] != lo[r] || all[(size_t)3 * r + 2] != hi[r]) {
+        char msg[200];
+        std::snprintf(msg, sizeof(msg), "lt_dist_merge_shards: rank %d reports node range [%lld, %lld), expected [%lld, %lld)", r,
+                      all[(size_t)3 * r + 1], all[(size_t)3 * r + 2], (long long)lo[r], (long long)hi[r]);
+        return fail(d, LT_ERR_ARGUMENT, msg);
+      }
       max_keys = std::max<int64_t>(max_keys, counts[r]);
     }
   }
@@ -227,8 +236,10 @@ int lt_dist_merge_shards(lt_dist *d, int64_t key_cap, int64_t *n_keys_merged) {
   const size_t blob_bytes = o_keys + (size_t)max_keys * 8;
   int rc = ensure(d, &d->d_blob, &d->blob_cap, blob_bytes);
   if (rc) return rc;
-  const long long hdr[8] = {(long long)n_keys, (long long)lo[rank], (long long)hi[rank], truncated ? 1 : 0, 0, 0, 0, 0};
-  DHIP(d, hipMemcpyAsync(d->d_blob, hdr, sizeof(hdr), hipMemcpyHostToDevice, d->st));
+  long long *hdr = d->h_hdr;
+  hdr[0] = (long long)n_keys; hdr[1] = (long long)lo[rank]; hdr[2] = (long long)hi[rank]; hdr[3] = truncated ? 1 : 0;
+  hdr[4] = hdr[5] = hdr[6] = hdr[7] = 0;
+  DHIP(d, hipMemcpyAsync(d->d_blob, hdr, sizeof(d->h_hdr), hipMemcpyHostToDevice, d->st));
   if (!counts.empty()) {
     long long total = 0;
     for (long long c : counts) total += c;
@@ -269,6 +280,14 @@ int lt_dist_merge_shards(lt_dist *d, int64_t key_cap, int64_t *n_keys_merged) {
         char msg[200];
         std::snprintf(msg, sizeof(msg), "lt_dist_merge_shards: rank %d could not send its keys (key_cap = %lld too small)", r,
                       (long long)max_keys);
+        return fail(d, LT_ERR_ARGUMENT, msg);
+      }
+      // the header is a peer's word: a count beyond the blob's key room would make lt_shard_import read past it, a
+      // different node range would import the slices into the wrong place
+      if (h[0] < 0 || h[0] > (long long)max_keys || h[1] != (long long)lo[r] || h[2] != (long long)hi[r]) {
+        char msg[256];
+        std::snprintf(msg, sizeof(msg), "lt_dist_merge_shards: rank %d's header says %lld keys for nodes [%lld, %lld); expected "
+                      "at most %lld keys for [%lld, %lld)", r, h[0], h[1], h[2], (long long)max_keys, (long long)lo[r], (long long)hi[r]);
         return fail(d, LT_ERR_ARGUMENT, msg);
       }
       counts[r] = h[0];

@@ -260,7 +260,15 @@ def merge_shards_device(ctx, node_range, rank, world, device=None, all_ranges=No
         if heads[:, 3].any():
             bad = [int(r) for r in np.nonzero(heads[:, 3])[0]]
             raise RuntimeError(f"merge_shards_device: ranks {bad} could not send their keys (key_cap = {max_keys} too small)")
-        counts = heads[:, 0]
+        counts = heads[:, 0].copy()
+        counts[0] = n_keys  # rank 0's own keys are already in place
+        # the headers are the peers' word: a count beyond the blob's key room would make lt_shard_import read past it,
+        # another node range would put the slices in the wrong place (a peer that sharded with different weights)
+        for r in range(1, world):
+            if not (0 <= counts[r] <= max_keys) or heads[r, 1] != ranges[r, 0] or heads[r, 2] != ranges[r, 1]:
+                raise RuntimeError(f"merge_shards_device: rank {r}'s header says {int(counts[r])} keys for nodes "
+                                   f"[{int(heads[r, 1])}, {int(heads[r, 2])}); expected at most {max_keys} keys for "
+                                   f"[{int(ranges[r, 0])}, {int(ranges[r, 1])})")
         ctx.shard_build(int(counts.sum()))
     total = int(counts.sum())
     for r in range(1, world):

@@ -40,6 +40,35 @@ def available():
     return os.path.exists(LIB_PATH) or os.path.isdir(REFERENCE_SRC)
 
 
+def tree_source_hash():
+    """SHA-256 (16 hex digits) over the tree files oracle/_ref is compiled against besides the reference's own sources:
+    every stand-in header under ref_shim/, eigen_svd_ref.h, lt_oracle.h, ref_driver.cpp -- in sorted relative-path order,
+    each as `path NUL bytes NUL`.  oracle/Makefile bakes it into the library (`ref_source_hash()`)."""
+    import hashlib
+    files = [os.path.join(_HERE, f) for f in ("eigen_svd_ref.h", "lt_oracle.h", "ref_driver.cpp")]
+    for root, _, names in os.walk(os.path.join(_HERE, "ref_shim")):
+        files += [os.path.join(root, n) for n in names]
+    h = hashlib.sha256()
+    for f in sorted(files, key=lambda f: os.path.relpath(f, _HERE)):
+        h.update(os.path.relpath(f, _HERE).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def library_source_hash():
+    """The hash baked into the built oracle/_ref library, or None when it is absent / predates the hash."""
+    if not os.path.exists(LIB_PATH):
+        return None
+    dll = C.PyDLL(LIB_PATH)
+    try:
+        fn = dll.ref_source_hash
+    except AttributeError:
+        return None
+    fn.restype = C.c_char_p
+    return fn().decode()
+
+
 class _Renamed:
     """ora_* names resolved as ref_* in the reference-backed library."""
 
@@ -144,3 +173,9 @@ def imagecols_from_dict(d):
     if n < 0:
         raise RuntimeError("ImageCollection(dict) failed (%d)" % n)
     return ids[:n], k[:n], q[:n], t[:n]
+
+
+if __name__ == "__main__":
+    import sys
+    if "--hash" in sys.argv:
+        print(tree_source_hash())

@@ -689,4 +689,12 @@ int ref_imagecols_from_dict(PyObject *dict, int cap, int32_t *img_ids, double *k
   }
 }
 
+// Hash of the tree files this library was compiled against (stand-in headers, eigen_svd_ref.h, lt_oracle.h, this file):
+// oracle/Makefile passes it (oracle/ref.py --hash), tests/test_oracle_vs_ref.py compares it with the tree's, so a prebuilt
+// _ref that is older than the headers it embeds cannot pass for current.
+#ifndef REF_SOURCE_HASH
+#define REF_SOURCE_HASH "unknown"
+#endif
+const char *ref_source_hash() { return REF_SOURCE_HASH; }
+
 }  // extern "C"
