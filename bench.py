@@ -319,6 +319,124 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
     return res
 
 
+def streamed_config5_leg(cfg, rank, world, local_rank, dev, use_dist, pmc_path=None):
+    """BASELINE.json configs[4] ("Rome16K / large COLMAP model (>= 5k images) streamed triangulation, 8 GPUs, HBM GB/s
+    roofline report"; reference caller runners/rome16k/triangulation.py:15-45, cfgs/triangulation/rome16k.yaml) on its
+    synthetic stand-in: 5000 views x 600 segs over 50 rooms, 20 neighbours, matched top-10, add_halfpix --
+    STREAMED through limap_amd.stream: chunks of 250 consecutive images, each on a worker context that holds only the chunk's
+    neighbour closure, chunk k on rank k % world, no collective while the chunks run, every rank's per-image results to rank 0
+    through one gather, ONE ComputeLineTracks there.  A chunk's working set (30 M match rows, ~1.7 M candidate records,
+    pair store) is ~0.45 GB: past the 256 MB Infinity Cache, so the per-kernel bytes / time here are HBM numbers."""
+    import torch
+    import torch.distributed as dist
+    from limap_amd import stream as ltstream
+    from limap_amd import synthetic as syn
+    shape = dict(n_views=5000, n_segs=600, n_neighbors=20, n_rooms=50, seed=2)
+    chunk = 250
+    small = os.environ.get("LT_BENCH_STREAM_SCENE")  # tests: "views,segs,neighbors,chunk" of a scene that takes a second
+    if small:
+        v, sg, nbn, chunk = (int(x) for x in small.split(","))
+        shape = dict(n_views=v, n_segs=sg, n_neighbors=nbn, seed=2)
+    t0 = time.perf_counter()
+    scene = syn.make_scene(**shape)
+    t_scene = time.perf_counter() - t0
+    cfg5 = dict(cfg)
+    cfg5["add_halfpix"] = True  # cfgs/triangulation/rome16k.yaml
+    st = ltstream.StreamedTriangulation(cfg5, scene.img_ids, scene.kvec, scene.qvec, scene.tvec, scene.seg_off, scene.segs,
+                                        scene.neighbors, scene.ranges, chunk_images=chunk, rank=rank, world=world,
+                                        device=local_rank, comm_device=_comm_dev(dev))
+
+    def rmax(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=_comm_dev(dev))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def rsum(xs):
+        if not use_dist:
+            return list(xs)
+        t = torch.tensor(list(xs), dtype=torch.float64, device=_comm_dev(dev))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().tolist()
+
+    if use_dist:
+        dist.barrier()
+    tw0 = time.perf_counter()
+    for ch in st.my_chunks():
+        st.run_chunk(ch, scene.matches_of, fine_timers=True)
+    torch.cuda.synchronize(dev)
+    t_matches = 1e-3 * sum(r["matches_ms"] for r in st.per_chunk)  # the synthetic generator is not part of the pipeline
+    wall_chunks = rmax(time.perf_counter() - tw0 - t_matches)
+    tf0 = time.perf_counter()
+    note = None
+    A = None
+    try:
+        A = st.finish()
+    except Exception as e:
+        note = f"{type(e).__name__}: {e}"
+    t_finish = rmax(time.perf_counter() - tf0)
+    nn = shape["n_neighbors"]
+    # per kernel: algorithmic bytes (SURVEY 8d, the same formulas as the main line) and event time summed over this rank's
+    # chunks, then over the ranks -- bytes / time = the rate one GPU sustains on a chunk
+    keys = ("gates", "tri", "score")
+    tkey = {"gates": "k_gates", "tri": "k_tri_rows", "score": "k_score3"}
+    by, ms = {k: 0.0 for k in keys}, {k: 0.0 for k in keys}
+    ws = []
+    for r in st.per_chunk:
+        G_act = int(r["images"]) * shape["n_segs"]
+        ab = algorithmic_bytes(dict(candidates=r["candidates"], valid_edges=r["valid_edges"], connections=r["connections"],
+                                    active_nodes=G_act), r["images"], nn, r.get("survivors", 0.0), "matched",
+                               line_slots=bool(r.get("line_slots", 0.0)))
+        for k in keys:
+            by[k] += ab[k]
+            ms[k] += r.get(tkey[k], 0.0)
+        # what a chunk keeps resident in HBM while it runs: 16-bit transposed rows + run lengths, the derived per-segment
+        # tables of the closure (128 + 80 B), candidate records (128 B) + meta / score / perm (32 B), the pair store of the
+        # split scoring form (256 entries of 16 B per 64 candidates)
+        ws.append(2 * r["connections"] + 4 * nn * G_act + 208 * r["closure_segments"] + 160 * r["candidates"] + 64 * r["candidates"])
+    tot = rsum([by[k] for k in keys] + [ms[k] for k in keys] +
+               [sum(r["device_ms"] for r in st.per_chunk), sum(r["candidates"] for r in st.per_chunk),
+                sum(r["connections"] for r in st.per_chunk), float(len(st.per_chunk)),
+                sum(r["init_ms"] for r in st.per_chunk), sum(r["buffer_ms"] for r in st.per_chunk),
+                sum(r["upload_ms"] for r in st.per_chunk), sum(r["export_ms"] for r in st.per_chunk), float(sum(ws))])
+    B = dict(zip(keys, tot[0:3]))
+    T = dict(zip(keys, tot[3:6]))
+    dev_ms, cands, conns, n_chunks, init_ms, buf_ms, up_ms, exp_ms, ws_sum = tot[6:15]
+    pmc = {}
+    if pmc_path and os.path.exists(pmc_path) and not small:
+        d = json.load(open(pmc_path))
+        if d.get("device_source_hash") == device_source_hash():
+            pmc = d.get("kernels", {})
+    names = {"gates": "k_gates_ln (stage A)", "tri": "k_tri_rounds (stage B)", "score": "scoring stage (k_score3 sweep + k_dense8)"}
+    roof = {}
+    for k in keys:
+        gbs = B[k] / (T[k] * 1e-3) / 1e9 if T[k] > 0 else 0.0
+        roof[tkey[k]] = {"kernel": names[k], "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_chunk": B[k] / max(n_chunks, 1),
+                         "kernel_ms_per_chunk": T[k] / max(n_chunks, 1),
+                         "traffic": (pmc.get(tkey[k], {}).get("hbm_bytes_per_chunk") if pmc else None)}
+    res = {"workload": (f"synthetic {shape['n_views']} views x {shape['n_segs']} segs, {nn} neighbours, matched topk=10, add_halfpix"
+                        + ("" if small else " (stand-in for BASELINE configs[4], rome16k.yaml)")
+                        + f", streamed in chunks of {chunk} images with their neighbour closure, chunk k on rank k % {world}"),
+           "n_gpus": world, "chunks": int(n_chunks), "chunk_images": chunk,
+           "closure_images_max": int(rmax(float(max((r["closure_images"] for r in st.per_chunk), default=0)))),
+           "connections": int(conns), "candidates": int(cands),
+           "device_ms_per_chunk": dev_ms / max(n_chunks, 1),
+           "host_ms_per_chunk": {"init_closure": init_ms / max(n_chunks, 1), "buffer_rows": buf_ms / max(n_chunks, 1),
+                                 "upload": up_ms / max(n_chunks, 1), "download_export_import": exp_ms / max(n_chunks, 1)},
+           "hbm_working_set_bytes_per_chunk": ws_sum / max(n_chunks, 1),
+           "chunks_wall_s": wall_chunks, "images_per_s": shape["n_views"] / wall_chunks if wall_chunks > 0 else None,
+           "candidates_per_s": cands / wall_chunks if wall_chunks > 0 else None,
+           "candidates_per_s_device": cands / (dev_ms * 1e-3) * world if dev_ms > 0 else None,
+           "gather_import_tail_s": t_finish, "tracks": (A.stats()["tracks"] if A is not None else None), "note": note,
+           "roofline": roof, "scene_generation_s": t_scene,
+           "timing_note": "chunks_wall_s = max over ranks of (wall of its chunks - time inside the synthetic match generator); "
+                          "per-kernel times are HIP events of every chunk run (LT_FINE_TIMERS=2), bytes the SURVEY 8(d) formulas"}
+    del st
+    return res
+
+
 _REAL_STDOUT = None
 # LT_BENCH_ONE_GPU=1 (tests): an N-rank job whose ranks all use cuda:0 -- backend gloo (RCCL wants a device per rank), the
 # scene gathered through host tensors and copied to the device, no per-step refresh from the receive buffer.  It exists to run
@@ -383,6 +501,11 @@ def main():
     ap.add_argument("--strong-leg", default="auto", choices=["auto", "on", "off"],
                     help="BASELINE config 3 as a strong-scaling leg of the same run (`strong_config3` in the line); auto = "
                          "with the default workload")
+    ap.add_argument("--stream-leg", default="auto", choices=["auto", "on", "off"],
+                    help="BASELINE config 5's stand-in (5000 x 600, streamed in chunks with neighbour closure, chunks round-robin "
+                         "over the ranks) as a leg of the same run (`streamed_config5` in the line); auto = with the default workload")
+    ap.add_argument("--stream", action="store_true",
+                    help="the streamed leg only: the line's value is the streamed job's candidates/s (5000 x 600)")
     ap.add_argument("--sustain-s", type=float, default=2.0,
                     help="after the timed region: the same step looped for about this long (sustained_ms_per_step; an "
                          "outside observer -- rocm-smi -- sees the device busy); 0 = off")
@@ -419,6 +542,26 @@ def main():
     from limap_amd import _capi
     from limap_amd import synthetic as syn
     from limap_amd import dist as ltdist
+
+    stream_pmc = os.path.join(ROOT, "profiles", "r06_stream_pmc.json")
+    if args.stream:
+        # the streamed job as its own line: one "step" = the whole model once through the chunks
+        cfg = syn.default_triangulation_cfg()
+        leg = streamed_config5_leg(cfg, rank, world, local_rank, dev, use_dist, pmc_path=stream_pmc)
+        if rank == 0:
+            sc = leg["roofline"]["k_score3"]
+            _emit(json.dumps({
+                "metric": "3D line candidates scored/sec, large model streamed in chunks (BASELINE configs[4] stand-in)",
+                "value": leg["candidates_per_s"], "unit": "candidates/s", "n_gpus": world, "steps": 1, "warmup": 0,
+                "ms_per_step": 1e3 * leg["chunks_wall_s"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic", "config": {"workload": leg["workload"]},
+                "roofline": {"bound": "hbm", "achieved": sc["achieved"], "peak": sc["peak"], "unit": "GB/s", "frac": sc["frac"],
+                             "traffic": sc["traffic"], "kernel": sc["kernel"]},
+                "cpu_baseline": None, "streamed_config5": leg, "device_source_hash": device_source_hash()}))
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     strong = args.scaling == "strong"
     n_total = args.views if strong else args.views * world
@@ -732,6 +875,15 @@ def main():
             sc3 = {"error": f"{type(e).__name__}: {e}"}
         if out is not None:
             out["strong_config3"] = sc3
+
+    # ---- the streamed leg: BASELINE config 5's stand-in over the same ranks (every rank takes part) ----
+    if args.mode == "matched" and (args.stream_leg == "on" or (args.stream_leg == "auto" and default_wl and not args.no_extras)):
+        try:
+            s5 = streamed_config5_leg(cfg, rank, world, local_rank, dev, use_dist, pmc_path=stream_pmc)
+        except Exception as e:  # an extra: never lose the main line over it
+            s5 = {"error": f"{type(e).__name__}: {e}"}
+        if out is not None:
+            out["streamed_config5"] = s5
 
     # ---- extra (not `value`): independent batches in flight, N = 1 ----
     # A service that triangulates independent scenes keeps more than one batch in flight; two contexts (each

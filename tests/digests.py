@@ -45,4 +45,8 @@ CASES = {
     # BASELINE configs[2]: 1000 views x 1000 segs over 4 rooms, matched top-10, EVERY image (1e8 connections)
     "config3_matched_all": dict(scene=dict(n_views=1000, n_segs=1000, n_neighbors=20, n_rooms=4, n_gt=3000, seed=1),
                                 exhaustive=False),
+    # a fifth of BASELINE configs[4]'s stand-in (5000 x 600 streamed): 1000 views x 600 segs over 10 rooms, matched top-10,
+    # rome16k.yaml's add_halfpix -- what tests/test_gpu_stream.py streams in chunks through limap_amd.stream
+    "stream_1000x600": dict(scene=dict(n_views=1000, n_segs=600, n_neighbors=20, n_rooms=10, seed=2), exhaustive=False,
+                            cfg=dict(add_halfpix=True)),
 }

@@ -23,6 +23,7 @@ for name in (sys.argv[1:] or list(CASES)):
     t0 = time.time()
     sc = syn.make_scene(**case["scene"])
     cfg = syn.default_triangulation_cfg()
+    cfg.update(case.get("cfg", {}))
     O = ora.OracleTriangulator(cfg, faithful=False)
     O.SetRanges(sc.ranges)
     O.Init(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, sc.seg_off, sc.segs)

@@ -174,3 +174,64 @@ def test_config3_shaped_sharding_world8_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(r, True) for r in range(8)]
+
+
+def _stream_worker(rank, world, port, q):
+    """The streamed job's control flow on CPU (limap_amd/stream.py; the device part is tests/test_gpu_stream.py): every
+    rank plans the same chunks, takes chunk k iff k % world == rank, builds the closure sub-scene, and its per-image results
+    reach rank 0 through the ONE gather -- every image exactly once, from the rank its chunk belongs to."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from limap_amd import stream as ltstream, synthetic as syn
+        sc = syn.make_scene(n_views=23, n_segs=20, n_neighbors=4, seed=4)
+        plan = ltstream.plan_chunks(sc.img_ids, sc.neighbors, 5, world)
+        ok = [c.rank for c in plan] == [k % world for k in range(len(plan))] and len(plan) == 5
+        ok = ok and sorted(int(i) for c in plan for i in c.images) == sc.img_ids.tolist()
+        mine = [c for c in plan if c.rank == rank]
+        results = []
+        for c in mine:
+            need = set(int(i) for i in c.images) | {int(n) for i in c.images for n in sc.neighbors[int(i)]}
+            ok = ok and set(c.closure.tolist()) == need and bool(np.all(np.diff(c.closure) > 0))
+            ids, k, qv, t, off, sg = ltstream.closure_arrays(c, sc.img_ids, sc.kvec, sc.qvec, sc.tvec, sc.seg_off, sc.segs)
+            for j, i in enumerate(ids):  # the sub-scene's rows are the model's rows of the same image
+                n = sc.img_ids.tolist().index(int(i))
+                ok = ok and np.array_equal(sg[off[j]:off[j + 1]], sc.segs[sc.seg_off[n]:sc.seg_off[n + 1]])
+                ok = ok and np.array_equal(k[j], sc.kvec[n]) and np.array_equal(qv[j], sc.qvec[n]) and np.array_equal(t[j], sc.tvec[n])
+            for i in c.images:  # stand-in for lt_export_image_results: tagged with the chunk and the rank
+                n = sc.img_ids.tolist().index(int(i))
+                m = int(sc.seg_off[n + 1] - sc.seg_off[n])
+                eoff = np.arange(m + 1, dtype=np.int64)
+                results.append(dict(img_id=int(i), nb_ids=np.asarray(sc.neighbors[int(i)], np.int32),
+                                    line=np.full((m, 10), float(c.index)), score=np.full(m, float(rank)),
+                                    src=np.zeros((m, 2), np.int32), n_tris=np.full(m, c.index, np.int32), edge_off=eoff,
+                                    edges=np.zeros((m, 2), np.int32)))
+        others = ltstream.gather_results(results, rank, world, torch.device("cpu"))
+        if rank == 0:
+            got = sorted([r["img_id"] for r in results] + [r["img_id"] for r in others])
+            ok = ok and got == sc.img_ids.tolist()
+            by_img = {int(i): c for c in plan for i in c.images}
+            for r in others:
+                c = by_img[r["img_id"]]
+                ok = ok and c.rank != 0 and float(r["score"][0]) == float(c.rank) and int(r["n_tris"][0]) == c.index
+        else:
+            ok = ok and others is None
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_streamed_chunks_round_robin_and_one_gather(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + world + (os.getpid() % 500)
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    assert res == [(r, True) for r in range(world)], res

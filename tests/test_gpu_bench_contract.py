@@ -13,12 +13,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_has_the_contract_fields(gpu_lib):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                          "--views", "12", "--segs", "60", "--neighbors", "5", "--strong-leg", "on", "--sustain-s", "0.2"],
+                          "--views", "12", "--segs", "60", "--neighbors", "5", "--strong-leg", "on", "--sustain-s", "0.2",
+                          "--stream-leg", "on"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT,
-                         env=dict(os.environ, LT_BENCH_STRONG_SCENE="30,80,6"))
+                         env=dict(os.environ, LT_BENCH_STRONG_SCENE="30,80,6", LT_BENCH_STREAM_SCENE="40,60,6,9"))
     assert res.returncode == 0, res.stderr[-2000:]
     line = res.stdout.strip().splitlines()[-1]
     d = json.loads(line)
+    # ... and the streamed leg (BASELINE config 5's stand-in; a small scene here): chunks with their neighbour closure
+    s5 = d["streamed_config5"]
+    assert "error" not in s5 and s5["note"] is None, s5
+    assert s5["chunks"] == 5 and s5["chunk_images"] == 9 and 9 < s5["closure_images_max"] < 40 and s5["tracks"] > 0
+    assert s5["candidates"] > 0 and s5["images_per_s"] > 0 and s5["device_ms_per_chunk"] > 0
+    for k in ("k_gates", "k_tri_rows", "k_score3"):
+        r5 = s5["roofline"][k]
+        assert r5["bound"] == "hbm" and r5["achieved"] > 0 and abs(r5["frac"] - r5["achieved"] / r5["peak"]) < 1e-12
     # one run prints the weak figure and the strong-scaling leg (BASELINE config 3; a small scene here), and a sustained one
     sc3 = d["strong_config3"]
     assert "error" not in sc3, sc3
@@ -71,8 +80,8 @@ def test_bench_two_ranks_on_one_gpu(gpu_lib):
     the reductions over ranks, the strong-scaling leg with its sequential and its overlapped tail -- runs to the JSON
     line, and the whole-scene track count is that of a one-rank run of the same scene."""
     common = ["--steps", "3", "--warmup", "1", "--views", "12", "--segs", "60", "--neighbors", "5", "--no-cpu-baseline",
-              "--no-extras", "--strong-leg", "on", "--sustain-s", "0.2", "--scaling", "strong"]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LT_BENCH_STRONG_SCENE="30,80,6")
+              "--no-extras", "--strong-leg", "on", "--sustain-s", "0.2", "--scaling", "strong", "--stream-leg", "on"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LT_BENCH_STRONG_SCENE="30,80,6", LT_BENCH_STREAM_SCENE="40,60,6,9")
     res2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                            "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(ROOT, "bench.py"),
                            "--gpus", "2"] + common,
@@ -93,3 +102,8 @@ def test_bench_two_ranks_on_one_gpu(gpu_lib):
     assert s2["n_gpus"] == 2 and len(s2["ms_per_step_per_rank"]) == 2
     assert s2["candidates"] == s1["candidates"] > 0 and s2["tracks_rank0"] == s1["tracks_rank0"] > 0
     assert s2["step_with_merge_and_tail_ms"] > 0 and s2["step_with_merge_and_tail_overlapped_ms"] > 0
+    # the streamed leg: chunks dealt round-robin to the two ranks, one gather to rank 0, the same model as one rank's
+    t2, t1 = d2["streamed_config5"], d1["streamed_config5"]
+    assert "error" not in t2 and t2["note"] is None and "error" not in t1 and t1["note"] is None, (t2, t1)
+    assert t2["n_gpus"] == 2 and t2["chunks"] == t1["chunks"] == 5
+    assert t2["candidates"] == t1["candidates"] > 0 and t2["connections"] == t1["connections"] and t2["tracks"] == t1["tracks"] > 0

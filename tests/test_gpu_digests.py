@@ -22,6 +22,7 @@ def test_whole_scene_digests_equal_the_oracles(gpu_lib, name):
     case = CASES[name]
     sc = syn.make_scene(**case["scene"])
     cfg = syn.default_triangulation_cfg()
+    cfg.update(case.get("cfg", {}))
     T = run_product(sc, cfg, exhaustive=case["exhaustive"])
     T.ComputeLineTracks()
     ctx = T.context()
