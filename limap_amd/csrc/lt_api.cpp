@@ -357,7 +357,22 @@ ScoreCfg make_score(const lt_ctx *ctx) {
   if (test_switch("LT_TEST_NO_SCORE_GUARDS")) s.cos_guard = -1.0;
   s.fullscore_th = ctx->cfg.fullscore_th;
   s.max_valid_conns = ctx->cfg.max_valid_conns;
-  s.pad_ = 0;
+  // single-exp form of pair_score: gate bands around q_th = sqrt(-2 ln score_th) (+-1e-9 relative: at score_th in
+  // [1e-3, 0.999] the exponential at the band's edges differs from score_th by >= 2e-12 relative, four orders above the
+  // error of exp and of q * q).  Outside that range, or with the 2D inner-segment term on, the term-by-term form runs.
+  auto band = [](double th, double *lo, double *hi) -> bool {
+    if (!(th >= 1e-3 && th <= 0.999)) {
+      *lo = -1.0;
+      *hi = 1e300;
+      return false;
+    }
+    const double q = std::sqrt(-2.0 * std::log(th));
+    *lo = q * (1.0 - 1e-9);
+    *hi = q * (1.0 + 1e-9);
+    return true;
+  };
+  const bool b3 = band(s.l3.score_th, &s.q3_lo, &s.q3_hi), b2 = band(s.l2.score_th, &s.q2_lo, &s.q2_hi);
+  s.fast = (b3 && b2 && !s.l2.use_innerseg && !test_switch("LT_TEST_PAIR_SCORE_TERMS")) ? 1 : 0;
   return s;
 }
 

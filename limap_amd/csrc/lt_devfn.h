@@ -857,7 +857,7 @@ static __device__ __forceinline__ bool vp_candidate(const GenCfg &cfg, const Cam
 // projected into the view of j against the 2D segment that generated j.  The unit directions are
 // the ones stored with the candidates: Line3d::direction() is a pure function of the endpoints, so
 // the stored value is bit-identical to the reference's recomputation.
-static __device__ __forceinline__ double pair_score(const ScoreCfg &cfg, d3 si, d3 ei, d3 diri, double dep0,
+static __device__ __forceinline__ double pair_score_terms(const ScoreCfg &cfg, d3 si, d3 ei, d3 diri, double dep0,
                                                     double dep1, d3 sj, d3 ej, d3 dirj, const double *segj,
                                                     const Cam &camj) {
   const LinkCfg3 &c3 = cfg.l3;
@@ -879,6 +879,106 @@ static __device__ __forceinline__ double pair_score(const ScoreCfg &cfg, d3 si, 
   double s2 = score2d(cfg.l2, pi, sg);
   if (s2 == 0) return 0.0;
   return dmin(s3, s2);
+}
+
+
+// The same function with every shared sub-expression evaluated ONCE and ONE exponential (round 6).  pair_score_terms is the
+// reference's text term by term: dir(l) and len(l) of the two 2D lines are recomputed by angle_between, both overlap_oneway
+// and both perp_oneway (the compiler does not merge them across the early returns: 30 IEEE divisions, 14 square roots and
+// five exp per pair), although they are the same expressions on the same inputs --
+//   * len(l) = sqrt(sqn(l.s - l.e)) and the norm inside dir(l) = unit(l.e - l.s) are the same double: (a - b) = -(b - a)
+//     exactly, squares and their sum agree bit for bit;
+//   * overlap_oneway's numerators dot(l1.s - l2.s, dir(l2)), dot(l1.e - l2.s, dir(l2)) are perp_oneway's pa, pb.
+// 22 divisions, 8 square roots (+ the two inside acos), same bits.
+// One exp: every term's score is exp(-(q * q) / 2) with its own q = value / sigma, gated `< score_th -> 0`; the result is 0 if
+// a gate fails, else the minimum = the exponential of the LARGEST q (the exponential's argument -(q * q) / 2 is monotone in
+// q, rounding included).  Whether a gate fails is decided on q against sqrt(-2 ln score_th) with a +-1e-9 band inside which the
+// exponential itself is evaluated (ScoreCfg::q*_lo / q*_hi, lt_api.cpp: make_score).  NaN terms take no part in dmin(score,
+// NaN) = score of the term-by-term form; here `q > qmax` and the band tests are false for them: the same.
+// tests/test_gpu_guards.py::test_pair_score_fused_equals_term_by_term holds both forms to the same bits
+// (LT_TEST_PAIR_SCORE_TERMS=1 runs the reference's text).
+static __device__ __forceinline__ bool term_fails(double q, double q_lo, double q_hi, double score_th) {
+  if (q >= q_hi) return true;
+  if (q > q_lo) return exp(-(q * q) / 2.0) < score_th;  // inside the band: the reference's own comparison
+  return false;
+}
+static __device__ __forceinline__ double pair_score(const ScoreCfg &cfg, d3 si, d3 ei, d3 diri, double dep0,
+                                                    double dep1, d3 sj, d3 ej, d3 dirj, const double *segj,
+                                                    const Cam &camj) {
+  if (!cfg.fast) return pair_score_terms(cfg, si, ei, diri, dep0, dep1, sj, ej, dirj, segj, camj);
+  const LinkCfg3 &c3 = cfg.l3;
+  const LinkCfg2 &c2 = cfg.l2;
+  double qmax = 0.0;  // exp(-0) = 1: the score every linker starts from
+  {  // LineLinker3d, shared-parent mode: score_angle (line_linker.cc:185-192)
+    const double ang = angle_deg_from_cos(fabs(dot(diri, dirj)));
+    const double q = ang / (c3.th_angle * c3.mult);
+    if (term_fails(q, cfg.q3_lo, cfg.q3_hi, c3.score_th)) return 0.0;
+    qmax = q > qmax ? q : qmax;
+  }
+  {  // score_scaleinv (line_linker.cc:269-277, line_dists.cc:55-60)
+    const double ds = sqrt(sqn(sub(si, sj)));
+    const double de = sqrt(sqn(sub(ei, ej)));
+    const double d = dmax(ds / (dep0 + kEps), de / (dep1 + kEps));
+    const double q = d / (c3.th_scaleinv * c3.mult);
+    if (term_fails(q, cfg.q3_lo, cfg.q3_hi, c3.score_th)) return 0.0;
+    qmax = q > qmax ? q : qmax;
+  }
+  // LineLinker2d::compute_score (line_linker.cc:139-160) of l_i projected into the view of j against j's 2D segment
+  const d2 ps = cam_project(camj, si), pe = cam_project(camj, ei);
+  const d2 gs = mk2(segj[0], segj[1]), ge = mk2(segj[2], segj[3]);
+  // dir / len of both lines, once
+  const d2 v1 = sub(pe, ps), v2 = sub(ge, gs);
+  const double z1 = sqn(v1), z2 = sqn(v2);
+  const double n1 = sqrt(z1), n2 = sqrt(z2);  // = len(l1), len(l2)
+  const d2 u1 = z1 > 0.0 ? d2{v1.x / n1, v1.y / n1} : v1;
+  const d2 u2 = z2 > 0.0 ? d2{v2.x / n2, v2.y / n2} : v2;
+  double ang2 = 0.0;
+  const bool need_ang = c2.use_angle || (c2.use_overlap && c2.use_smartangle);
+  if (need_ang) ang2 = angle_deg_from_cos(fabs(dot(u1, u2)));
+  if (c2.use_angle) {
+    const double q = ang2 / (c2.th_angle * c2.mult);
+    if (term_fails(q, cfg.q2_lo, cfg.q2_hi, c2.score_th)) return 0.0;
+    qmax = q > qmax ? q : qmax;
+  }
+  // offsets of either line's endpoints from the other line's start, along and across the other line
+  const d2 a = sub(ps, gs), b = sub(pe, gs);    // l1 against l2
+  const double pa = dot(a, u2), pb = dot(b, u2);
+  const d2 a2 = sub(gs, ps), b2 = sub(ge, ps);  // l2 against l1
+  const double pa2 = dot(a2, u1), pb2 = dot(b2, u1);
+  if (c2.use_overlap) {  // bioverlap (line_dists.h:189-208)
+    double p1 = pa / n2, p2 = pb / n2;
+    if (p1 > p2) { const double t = p1; p1 = p2; p2 = t; }
+    const double o1 = dmin(p2, 1.0) - dmax(p1, 0.0);
+    double r1 = pa2 / n1, r2 = pb2 / n1;
+    if (r1 > r2) { const double t = r1; r1 = r2; r2 = t; }
+    const double o2 = dmin(r2, 1.0) - dmax(r1, 0.0);
+    const double ov = dmax(o1, o2);
+    if (!(ov > c2.th_overlap)) return 0.0;
+    if (c2.use_angle && c2.use_smartangle) {  // line_linker.cc:49-65
+      double th = c2.th_angle;
+      if (ov < c2.th_smartoverlap) {
+        double ratio = (c2.th_smartoverlap - ov) / (c2.th_smartoverlap - c2.th_overlap);
+        ratio = dmin(ratio, 1.0);
+        th = c2.th_angle - ratio * (c2.th_angle - c2.th_smartangle);
+      }
+      const double q = ang2 / (th * c2.mult);
+      if (term_fails(q, cfg.q2_lo, cfg.q2_hi, c2.score_th)) return 0.0;
+      qmax = q > qmax ? q : qmax;
+    }
+  }
+  if (c2.use_perp) {  // perp_dist (line_dists.h:98-133): max of the four endpoint distances
+    double m = sqrt(dmax(sqn(a) - pa * pa, 0.0));
+    const double de = sqrt(dmax(sqn(b) - pb * pb, 0.0));
+    const double dc = sqrt(dmax(sqn(a2) - pa2 * pa2, 0.0));
+    const double dd = sqrt(dmax(sqn(b2) - pb2 * pb2, 0.0));
+    if (m < de) m = de;
+    if (m < dc) m = dc;
+    if (m < dd) m = dd;
+    const double q = m / (c2.th_perp * c2.mult);
+    if (term_fails(q, cfg.q2_lo, cfg.q2_hi, c2.score_th)) return 0.0;
+    qmax = q > qmax ? q : qmax;
+  }
+  return exp(-(qmax * qmax) / 2.0);
 }
 
 }  // namespace lt

@@ -299,7 +299,12 @@ struct ScoreCfg {
   LinkCfg3 l3;       // already switched to shared-parent scoring
   double cos_guard;  // |cos| below this can never pass the 3D angle gate
   double fullscore_th;
-  int max_valid_conns, pad_;
+  // pair_score's single-exp form (lt_devfn.h): a term exp(-q^2 / 2) passes its gate `>= score_th` iff q <= sqrt(-2 ln score_th)
+  // up to rounding -- below q*_lo it certainly passes, from q*_hi on it certainly fails, in between the exponential itself
+  // decides (q3: 3D linker's score_th, q2: 2D linker's)
+  double q3_lo, q3_hi, q2_lo, q2_hi;
+  int max_valid_conns;
+  int fast;  // 1: pair_score_fused may be used (thresholds in the range the bands are proven for, no 2D inner-segment term)
 };
 
 LT_HD double expscore(double val, double sigma) {  // line_linker.cc:15-17 (pow(x,2) == x*x)

@@ -40,7 +40,7 @@ def clean_env():
     keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES",
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
             "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TIMER_SAMPLE", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_SCORE_SPLIT",
-            "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS")
+            "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS", "LT_TEST_PAIR_SCORE_TERMS")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -497,6 +497,39 @@ def test_split_and_fused_scoring_agree(gpu_lib, clean_env, topk, n_nb):
     del os.environ["LT_SCORE_SPLIT"]
     ex_default = _results(run_product(sc, cfg, exhaustive=True))
     _same(ex_default, ex_split)
+
+
+@pytest.mark.parametrize("variant", ["default", "no_smartangle", "no_overlap", "angle_only", "other_thresholds"])
+def test_pair_score_fused_equals_term_by_term(gpu_lib, clean_env, variant):
+    """pair_score evaluates the shared sub-expressions of the 2D linker once and ONE exponential (of the largest q) instead
+    of the reference's five gated ones (lt_devfn.h); LT_TEST_PAIR_SCORE_TERMS=1 runs the reference's text term by term.
+    Same bits -- every candidate's support score, hence every discrete result -- in both scoring forms and both modes."""
+    sc = syn.make_scene(n_views=16, n_segs=150, n_neighbors=7, seed=123)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    l2 = dict(cfg["linker2d_config"]) if "linker2d_config" in cfg else None
+    key2, key3 = ("linker2d_config", "linker3d_config")
+    if variant != "default":
+        assert key2 in cfg and key3 in cfg, sorted(cfg)
+    if variant == "no_smartangle":
+        cfg[key2] = dict(l2, use_smartangle=False)
+    elif variant == "no_overlap":
+        cfg[key2] = dict(l2, use_overlap=False)
+    elif variant == "angle_only":
+        cfg[key2] = dict(l2, use_overlap=False, use_smartangle=False, use_perp=False)
+    elif variant == "other_thresholds":
+        cfg[key2] = dict(l2, score_th=0.3, th_angle=9.0, th_perp=4.0, th_overlap=0.02, th_smartoverlap=0.2)
+        cfg[key3] = dict(cfg[key3], score_th=0.7, th_angle=12.0, th_scaleinv=0.03)
+    for exhaustive in (False, True):
+        fused = _results(run_product(sc, cfg, exhaustive=exhaustive))
+        assert fused[5]["candidates"] > 1000 and fused[4]["pairs_eval"] > 500
+        os.environ["LT_TEST_PAIR_SCORE_TERMS"] = "1"
+        terms = _results(run_product(sc, cfg, exhaustive=exhaustive))
+        del os.environ["LT_TEST_PAIR_SCORE_TERMS"]
+        _same(terms, fused)
+    os.environ["LT_SCORE_FUSED"] = "1"
+    one_kernel = _results(run_product(sc, cfg))
+    os.environ["LT_TEST_PAIR_SCORE_TERMS"] = "1"
+    _same(_results(run_product(sc, cfg)), one_kernel)
 
 
 @pytest.mark.parametrize("n_nb", [100, 40])
