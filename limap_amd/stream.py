@@ -18,7 +18,7 @@ per-node results (global_line_triangulator.cc:138-151).  So a large model need n
 
 Results do not depend on the chunking: the closure holds everything `TriangulateImage` reads, image and neighbour
 ids ascend in the sub-scene as in the model, valid edges name (neighbour slot, line) against the image's own neighbour
-list.  tests/test_gpu_stream.py holds a 1000 x 600 scene in 4+ chunks to the oracle's whole-scene digests.
+list.  tests/test_gpu_stream.py holds a 1000 x 600 scene in 4+ chunks to committed whole-scene digests of the CPU checker.
 """
 import time
 
