@@ -819,6 +819,13 @@ int lt_run_device_async(lt_ctx *ctx) {
       ENSURE(ctx, ctx->d_sp_pairs, score_split_chunk_bytes() * (size_t)std::max<long long>(sp_chunks, 1));
       ENSURE(ctx, ctx->d_sp_desc, 8 * (size_t)std::max<long long>(sp_chunks, 1));
     }
+    // the sweep lists its finished tiles by their true pair count for k_dense8 (LT_TEST_NO_PAIR_CLASSES: units in the order
+    // of k_cand_meta's cost classes, as in round 5)
+    const bool pair_classes = split && tile_classes && !test_switch("LT_TEST_NO_PAIR_CLASSES");
+    if (pair_classes) {
+      ENSURE(ctx, ctx->d_pc_cnt, 128 * (size_t)score3_tile_buckets());
+      ENSURE(ctx, ctx->d_pc_list, 8 * (size_t)tile_cap * (size_t)score3_tile_buckets());
+    }
     launch_score3(st, C_bound, G, ctx->d_tri_off.as<long long>(), ctx->d_cand_node.as<unsigned>(), ctx->d_cand_meta.p,
                   ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(), ctx->d_node_img.as<int>(),
                   ctx->d_nb_off.as<long long>(), ctx->d_blk_order.as<int>(), ctx->d_cams.as<Cam>(),
@@ -834,7 +841,8 @@ int lt_run_device_async(lt_ctx *ctx) {
                   staged_sorted ? ctx->d_ex_z.as<float>() : nullptr, ctx->d_err.as<int>(),
                   split ? ctx->d_sp_slots.p : nullptr, sp_slot_cap, ctx->d_sp_cnt.as<unsigned>(),
                   ctx->d_sp_ovf.as<unsigned>(), ctx->d_sp_pairs.p, ctx->d_sp_desc.p, sp_chunks, sampled ? ev[5] : nullptr,
-                  node_rec_valid ? ctx->d_node_rec.p : nullptr);
+                  node_rec_valid ? ctx->d_node_rec.p : nullptr, pair_classes ? ctx->d_pc_cnt.as<unsigned>() : nullptr,
+                  pair_classes ? ctx->d_pc_list.p : nullptr, tile_cap);
     if (C_bound <= 0 && sampled) HIPCHK(ctx, hipEventRecord(ev[5], st));  // nothing to score: no kernel carries the event
   }
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));

@@ -902,10 +902,9 @@ static __device__ __forceinline__ bool term_fails(double q, double q_lo, double 
   if (q > q_lo) return exp(-(q * q) / 2.0) < score_th;  // inside the band: the reference's own comparison
   return false;
 }
-static __device__ __forceinline__ double pair_score(const ScoreCfg &cfg, d3 si, d3 ei, d3 diri, double dep0,
-                                                    double dep1, d3 sj, d3 ej, d3 dirj, const double *segj,
-                                                    const Cam &camj) {
-  if (!cfg.fast) return pair_score_terms(cfg, si, ei, diri, dep0, dep1, sj, ej, dirj, segj, camj);
+static __device__ __forceinline__ double pair_score_fused(const ScoreCfg &cfg, d3 si, d3 ei, d3 diri, double dep0,
+                                                          double dep1, d3 sj, d3 ej, d3 dirj, const double *segj,
+                                                          const Cam &camj) {
   const LinkCfg3 &c3 = cfg.l3;
   const LinkCfg2 &c2 = cfg.l2;
   double qmax = 0.0;  // exp(-0) = 1: the score every linker starts from
@@ -979,6 +978,14 @@ static __device__ __forceinline__ double pair_score(const ScoreCfg &cfg, d3 si, 
     qmax = q > qmax ? q : qmax;
   }
   return exp(-(qmax * qmax) / 2.0);
+}
+// run-time choice (the fused k_score3; k_dense8 is compiled once per form: both bodies in one kernel cost it 34 registers
+// and the fourth wave per SIMD)
+static __device__ __forceinline__ double pair_score(const ScoreCfg &cfg, d3 si, d3 ei, d3 diri, double dep0,
+                                                    double dep1, d3 sj, d3 ej, d3 dirj, const double *segj,
+                                                    const Cam &camj) {
+  if (!cfg.fast) return pair_score_terms(cfg, si, ei, diri, dep0, dep1, sj, ej, dirj, segj, camj);
+  return pair_score_fused(cfg, si, ei, diri, dep0, dep1, sj, ej, dirj, segj, camj);
 }
 
 }  // namespace lt

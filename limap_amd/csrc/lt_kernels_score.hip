@@ -69,11 +69,12 @@ __global__ void __launch_bounds__(256)
 k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long *__restrict__ tri_off,
             const int *__restrict__ node_img, const long long *__restrict__ nb_off, CandMeta *__restrict__ meta,
             unsigned *__restrict__ draw, unsigned *__restrict__ bucket_cnt, unsigned *__restrict__ bucket_list,
-            unsigned bucket_cap, const uint4 *__restrict__ node_rec) {
+            unsigned bucket_cap, const uint4 *__restrict__ node_rec, unsigned *__restrict__ pc_cnt) {
   // grid-stride over the exact candidate count tri_off[G]; the host may only know an upper bound
   const long long C = tri_off[G];
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pc_cnt && i < kTileQueues * kTileBuckets) pc_cnt[i * 32] = 0;  // the sweep's pair-count lists
   if (i < 2 * kTileQueues + 1) draw[i * 32] = 0;  // 128 bytes apart; behind the draw queues: the split form's overflow-chunk counter and k_dense8's eight claim counters
   const long long C_up = (C + 63) & ~63ll;  // whole waves take part in the tile's reduction
   for (; i < C_up; i += stride) {
@@ -171,7 +172,16 @@ struct Score3Args {
   int sp_slot_cap;
   int sp_t_max;           // tiles per unit of k_dense8 (one table of maxima per tile in its LDS)
   int sp_wave_lds;        // LDS bytes of one wave of the sweep kernel
+  // round 6: the sweep lists every finished tile by its TRUE pair count (class = pairs / 16, one list per (queue, class) as
+  // for the cost classes); k_dense8 takes its units from these lists, heaviest first
+  unsigned *pc_cnt;       // kTileQueues * kTileBuckets counters, 128 bytes apart (zeroed by k_cand_meta)
+  uint2 *pc_list;         // lists of pc_cap entries: x = tile, y = its pair count
+  unsigned pc_cap;
 };
+__device__ __forceinline__ int pair_bucket(unsigned pairs) {
+  const unsigned b = pairs >> 4;
+  return (int)(b < (unsigned)(kTileBuckets - 1) ? b : (unsigned)(kTileBuckets - 1));
+}
 
 // Split form of the scoring stage (round 4).  The sweep kernel writes the pairs that pass its guards to the SLOT of their
 // tile in HBM (sp_slot_cap entries of 16 bytes; what does not fit goes to a chain of overflow chunks handed out through a
@@ -525,6 +535,17 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   size_t ent_cur = 0, ent_next = 0;
   uint4 hdr = kSplit ? (o_k < n_order ? fetch_order(o_k, ent_cur) : kNoTile) : resolve();
   if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
+  // kSplit: a finished tile is appended to the list of its pair-count class (a.pc_*).  The append's atomic is issued at the
+  // tile's end and its result used -- the entry stored -- only after the NEXT tile's first window is staged, so that the wave
+  // does not sit on the round trip
+  bool pc_pending = false;
+  unsigned pc_idx = 0, pc_qb = 0;
+  uint2 pc_ent = make_uint2(0u, 0u);
+  auto pc_flush = [&]() {
+    if (!pc_pending) return;
+    if (lane == 0 && pc_idx < a.pc_cap) a.pc_list[(size_t)pc_qb * a.pc_cap + pc_idx] = pc_ent;
+    pc_pending = false;
+  };
   while (hdr.x != 0xFFFFFFFFu) {
     bool next_level_issued = false;
     if (kSplit) {
@@ -653,6 +674,13 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
             const_cast<unsigned *>(a.bucket_list)[4 * ent_cur + 3] = (unsigned)t_cnt;
           if (ov_cur != kNoChunk) a.sp_desc[ov_cur] = make_uint2((unsigned)ov_fill, kNoChunk);
         }
+        if (final && a.pc_cnt) {
+          pc_flush();  // (still pending only if this tile had no window to stage)
+          pc_qb = (tile & (unsigned)(kTileQueues - 1)) * (unsigned)kTileBuckets + (unsigned)pair_bucket((unsigned)t_cnt);
+          pc_ent = make_uint2(tile, (unsigned)t_cnt);
+          if (lane == 0) pc_idx = atomicAdd(&a.pc_cnt[pc_qb * 32], 1u);
+          pc_pending = true;
+        }
         wave_lds_sync();
         return;
       }
@@ -719,6 +747,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       if (kSplit && !next_level_issued) {  // the registers of this tile's first level are free now
         next_level_issued = true;
         if (hdr_next.x != 0xFFFFFFFFu) load_first_level(hdr_next);
+        pc_flush();  // the previous tile's list entry
       }
       // this lane's sub-range of the window
       long long jlo = (off + r_lo) > wb ? (off + r_lo) : wb;
@@ -828,6 +857,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       if (hdr.x != 0xFFFFFFFFu) load_first_level(hdr);
     }
   }
+  if (kSplit) pc_flush();
   // (kSplit: the pair statistic is summed by k_dense8 from the tiles' counts -- here every wave ends at about the same time,
   // and three thousand atomics on one address in a burst held up the loads of the waves that still had a tile: 20-40 us)
   if (!kSplit && lane == 0 && a.pair_counter && n_eval_total) atomicAdd(a.pair_counter, n_eval_total);
@@ -852,8 +882,17 @@ constexpr int kDenseWaves = 4;
 #ifndef LT_DENSE_LDS_KB
 #define LT_DENSE_LDS_KB 36
 #endif
+#ifndef LT_DENSE_SUM_CHUNK
+#define LT_DENSE_SUM_CHUNK 4
+#endif
+constexpr int kSumChunk = LT_DENSE_SUM_CHUNK;
 constexpr int kDensePerCU = LT_DENSE_PER_CU;                  // workgroups of k_dense8 per CU
 constexpr int kDenseLdsBudget = LT_DENSE_LDS_KB * 1024;      // LDS for a workgroup's tables of maxima
+// (round 6, measured and not kept: a STATIC schedule -- workgroup b takes units b, 2 G - 1 - b, 2 G + b, ... of the pair-count
+// order, no claims, so that the header of unit j + 2 and every thread's first entry of unit j + 1 can be fetched a unit ahead,
+// behind the rounds' own gathers -- 98.3 us for the stage against 95.5 with the claims below: what the prefetch saves per unit
+// the fixed assignment loses in balance, 286 of 1 024 workgroups still busy at 40 us of 49.)
+template <bool kFast>  // kFast: pair_score_fused / pair_score_terms (ScoreCfg::fast)
 __global__ void __launch_bounds__(64 * kDenseWaves)
 k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of the candidate, 1 = position, 2 = spos[position]
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -878,15 +917,24 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
   unsigned n_units = (n_tiles + (unsigned)T - 1) / (unsigned)T;
   // (fewer tiles per unit in the most expensive classes -- one tile from class 30 / 28 / 24 / 20, two from 24 / 20 / 16 / 12:
   // 65.8 / 67.1 / 68.4 / 69.3 us against 66.0 with T everywhere; four workgroups per CU with three tiles: 65.2)
-  if (a.bucket_cnt) {
+  // round 6: the lists are the sweep's PAIR-COUNT classes when it wrote them (a.pc_cnt) -- a unit's time is its pairs, and the
+  // cost classes of k_cand_meta (sum of node sizes) predict them with a correlation of 0.6: heavy units started late, 17 us
+  // of the kernel's 61 were its tail (trace in profiles/r06_score_experiments.txt)
+  const bool use_pc = a.pc_cnt != nullptr;
+  // (heavy tiles as units of their own -- one tile per unit from 192 pairs, two from 96: 115 us for the stage against 107 with T
+  // everywhere, 3 878 units instead of 3 091 and half-empty second rounds; from 256 / 128: 110)
+  auto tiles_per_unit = [&](int) -> int { return T; };
+  const unsigned *list_cnt = use_pc ? a.pc_cnt : a.bucket_cnt;
+  const unsigned list_cap = use_pc ? a.pc_cap : a.bucket_cap;
+  if (list_cnt) {
     if (tid < 64) {
       unsigned u_tot = 0;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int f = 4 * lane + v;
-        const unsigned c = a.bucket_cnt[((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * 32];
+        const unsigned c = list_cnt[((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * 32];
         s_ocnt[f] = c;
-        const unsigned tf = (unsigned)T;
+        const unsigned tf = (unsigned)tiles_per_unit(f);
         s_ounits[f] = (c + tf - 1) / tf;
         u_tot += (c + tf - 1) / tf;
       }
@@ -908,7 +956,7 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
     nt_o = 0;
     base_o = 0;
     if (uu >= n_units) return;
-    if (a.bucket_cnt) {
+    if (list_cnt) {
       const int l = __builtin_ctzll(__ballot(s_uincl[lane] > uu));
       unsigned r = uu - (l > 0 ? s_uincl[l - 1] : 0u);
       int v = 0;
@@ -918,10 +966,10 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
         if (v == w && r >= c) { r -= c; v = w + 1; }
       }
       const int f = 4 * l + v;
-      const unsigned tf = (unsigned)T;
+      const unsigned tf = (unsigned)tiles_per_unit(f);
       const unsigned first = r * tf;
       nt_o = (int)min(tf, s_ocnt[f] - first);
-      base_o = (size_t)((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * a.bucket_cap + first;
+      base_o = (size_t)((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * list_cap + first;
     } else {
       const unsigned t0 = uu * (unsigned)T;
       nt_o = (int)min((unsigned)T, n_tiles - t0);
@@ -932,7 +980,11 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
     tile_o = 0;
     cnt_o = 0;
     if (who < nt_x) {
-      if (a.bucket_cnt) {
+      if (use_pc) {
+        const uint2 e = a.pc_list[base_x + who];
+        tile_o = e.x;
+        cnt_o = e.y;
+      } else if (a.bucket_cnt) {
         const uint4 e = reinterpret_cast<const uint4 *>(a.bucket_list)[base_x + who];
         tile_o = e.x;
         cnt_o = e.w;
@@ -972,6 +1024,7 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
   };
   const bool last_wave = tid >= kThreads - 64;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  (void)last_wave;
   unsigned u_cur = blockIdx.x;
   // the unit's header (tile and pair count of its tiles) sits in lanes < nt of EVERY wave: no LDS copy, no barrier for it
   int nt;
@@ -1032,6 +1085,26 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
     }
     __syncthreads();  // every wave has summed and zeroed its tables of the previous unit
     LT_TRACE_MARK(3, u_cur, 1);
+    // summation order (image-id order of the neighbour slots) of the image of each of this wave's tiles, one entry per lane:
+    // the sums then take it by readlane instead of one global load per neighbour and lane (round 6: the sums were 23 % of a
+    // unit's time, twenty dependent L1 round trips).  Lanes of another image (a tile that straddles two) read it from memory.
+    // (the lanes' own neighbour-table base and count are taken out of the prologue records HERE: a first use after the next
+    // unit's header loads were issued made the sums wait for those loads -- the memory counter is in order)
+    int ordv[2] = {0, 0};
+    long long wnb0[2] = {-1, -1};
+    unsigned nb0_l[2] = {0u, 0u};
+    int nn_l[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (wave + kWaves * h < nt) {  // (wave-uniform; lane 0 of a listed tile is a candidate)
+        nb0_l[h] = mt[h].nb >> 8;
+        nn_l[h] = pos[h] >= 0 ? (int)(mt[h].nb & 0xFFu) : 0;
+        wnb0[h] = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)nb0_l[h]);
+        const int n0 = __builtin_amdgcn_readfirstlane(nn_l[h]);
+        if (lane < n0) ordv[h] = a.blk_order[wnb0[h] + lane];
+        if (n0 > 64) wnb0[h] = -1;  // more neighbours than lanes: every lane reads its order from memory
+      }
+    }
     // iterations of the last wave over the unit's list: it claims the next unit before its last one (eight counters: one
     // counter took 2 300 claims in 60 us and the claims came back after up to 9 us)
     const int n_it3 = total > kThreads - 64 ? (total - (kThreads - 64) + kThreads - 1) / kThreads : 0;
@@ -1044,10 +1117,18 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
       const CRec &ci = a.cand[e.y];
       const CRec &cj = a.cand[e.x];
       const int nbs_j = cj.nb_slot;
-      const double sc = pair_score(cfg, mk3(ci.s[0], ci.s[1], ci.s[2]), mk3(ci.e[0], ci.e[1], ci.e[2]),
-                                   mk3(ci.dir[0], ci.dir[1], ci.dir[2]), ci.depth[0], ci.depth[1],
-                                   mk3(cj.s[0], cj.s[1], cj.s[2]), mk3(cj.e[0], cj.e[1], cj.e[2]),
-                                   mk3(cj.dir[0], cj.dir[1], cj.dir[2]), cj.seg, a.cams[(int)((unsigned)nbs_j >> 8)]);
+#if defined(LT_ABL_DENSE) && LT_ABL_DENSE == 1  // developer ablation: the loads without the arithmetic
+      const double sc = 0.75 + 1e-300 * (ci.s[0] + cj.seg[3] + ci.depth[1] + cj.dir[2]);
+#elif defined(LT_ABL_DENSE) && LT_ABL_DENSE == 2  // neither the record gathers nor the arithmetic
+      const double sc = 0.75;
+#else
+      const d3 si_ = mk3(ci.s[0], ci.s[1], ci.s[2]), ei_ = mk3(ci.e[0], ci.e[1], ci.e[2]), di_ = mk3(ci.dir[0], ci.dir[1], ci.dir[2]);
+      const d3 sj_ = mk3(cj.s[0], cj.s[1], cj.s[2]), ej_ = mk3(cj.e[0], cj.e[1], cj.e[2]), dj_ = mk3(cj.dir[0], cj.dir[1], cj.dir[2]);
+      const Cam &camj = a.cams[(int)((unsigned)nbs_j >> 8)];
+      double sc;
+      if constexpr (kFast) sc = pair_score_fused(cfg, si_, ei_, di_, ci.depth[0], ci.depth[1], sj_, ej_, dj_, cj.seg, camj);
+      else sc = pair_score_terms(cfg, si_, ei_, di_, ci.depth[0], ci.depth[1], sj_, ej_, dj_, cj.seg, camj);
+#endif
       if (sc > 0.0)
         atomicMax(&S[(k * max_nb + (nbs_j & 0xFF)) * 64 + (int)e.z], (unsigned long long)__double_as_longlong(sc));
     };
@@ -1077,7 +1158,10 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
     }
     __syncthreads();  // every pair of the unit is in the tables
     LT_TRACE_MARK(3, u_cur, 2);
-    // the next unit's header: in flight during the sums
+    // the next unit's header: in flight during the sums.  (The order vectors were loaded before the rounds and are first read
+    // in the sums: without this use in front of the header loads the compiler waits for THEM there -- vmcnt(0), the counter
+    // is in order -- and the sums started with the header's round trip, 2 us per unit.)
+    asm volatile("" : "+v"(ordv[0]), "+v"(ordv[1]));
     const unsigned un = (unsigned)__builtin_amdgcn_readfirstlane((int)s_next[0]);
     myq = __builtin_amdgcn_readfirstlane((int)s_next[1]);
     int nt_n;
@@ -1087,18 +1171,45 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
     load_hdr(lane, nt_n, base_n, n_tile, n_cnt);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (pos[h] >= 0) {
-        const int ti = wave + kWaves * h;
-        const long long nb0 = (long long)(mt[h].nb >> 8);
-        const int n_nb = (int)(mt[h].nb & 0xFFu);
-        double sum = 0.0;
+      const int ti = wave + kWaves * h;
+      if (ti >= nt) continue;  // wave-uniform
+      const bool act = pos[h] >= 0;
+      const long long nb0 = (long long)nb0_l[h];
+      const int n_nb = nn_l[h];
+      const bool own = nb0 == wnb0[h];
+      const int n_max = wave_max_i32(n_nb);  // the loop is wave-uniform: readlane takes the order whatever the lanes' state
+      // kSumChunk cells at a time: the reads first (independent of each other), then the ordered additions, then the zeroes -- as
+      // one read / add / write per neighbour the compiler kept every read behind the previous write (LDS, may alias): twenty
+      // LDS round trips in a row, 2.4 us per unit.  Cells beyond the lane's own neighbours add +0.0 (exact).
+      double sum = 0.0;
+      // (two copies of the loop: the common one -- every lane of the tile belongs to the image whose order the wave holds --
+      // contains no global load, so nothing in it waits on the memory counter, on which the NEXT unit's header loads issued
+      // just above are still outstanding: with the order read from memory inside the loop the sums began with a wait for
+      // that header, 2 us per unit)
+      if (!__any(act && !own)) {
+        for (int k0 = 0; k0 < n_max; k0 += kSumChunk) {
+          unsigned long long v[kSumChunk];
+          int sl[kSumChunk];
+#pragma unroll
+          for (int u = 0; u < kSumChunk; ++u) {
+            const int k = k0 + u;
+            sl[u] = __builtin_amdgcn_readlane(ordv[h], k & 63);
+            v[u] = k < n_nb ? S[(ti * max_nb + sl[u]) * 64 + lane] : 0ull;
+          }
+#pragma unroll
+          for (int u = 0; u < kSumChunk; ++u) sum += __longlong_as_double((long long)v[u]);
+#pragma unroll
+          for (int u = 0; u < kSumChunk; ++u)  // (a candidate's pairs only touch the slots of its image's neighbours: the table is clean again)
+            if (k0 + u < n_nb) S[(ti * max_nb + sl[u]) * 64 + lane] = 0ull;
+        }
+      } else {
         for (int k = 0; k < n_nb; ++k) {
           unsigned long long *cell = &S[(ti * max_nb + a.blk_order[nb0 + k]) * 64 + lane];
           sum += __longlong_as_double((long long)*cell);
-          *cell = 0ull;  // (a candidate's pairs only touch the slots of its image's neighbours: the table is clean again)
+          *cell = 0ull;
         }
-        a.score[score_by == 1 ? pos[h] : (score_by == 2 ? (long long)a.spos[pos[h]] : (long long)rrec[h])] = sum;
       }
+      if (act) a.score[score_by == 1 ? pos[h] : (score_by == 2 ? (long long)a.spos[pos[h]] : (long long)rrec[h])] = sum;
     }
     LT_TRACE_MARK(3, u_cur, 3);
     u_cur = un;
@@ -1149,7 +1260,8 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    bool f32, unsigned *perm, void *rng, bool perm_is_placement, unsigned *bucket_cnt,
                    unsigned *bucket_list, unsigned bucket_cap, const unsigned *place, unsigned *rec, const float *st_z,
                    int *err_flag, void *sp_slots, int sp_slot_cap, unsigned *sp_cnt, unsigned *sp_ovf, void *sp_pairs,
-                   void *sp_desc, long long sp_chunks, hipEvent_t ev_after, const void *node_rec) {
+                   void *sp_desc, long long sp_chunks, hipEvent_t ev_after, const void *node_rec, unsigned *pc_cnt,
+                   void *pc_list, unsigned pc_cap) {
   // ev_before / ev_after: bound as the STOP events of k_cand_meta and of the stage's last kernel (hipExtLaunchKernelGGL:
   // the kernel's own completion signal carries the timestamp) -- a hipEventRecord between two kernels is a barrier packet
   // that opens a ~5.5 us gap in the stream (LT_EV_MARKERS=1: the plain records, for comparison)
@@ -1171,7 +1283,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   hipExtLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st,
                         nullptr, ev_markers ? nullptr : ev_before, 0, G, cand_node, tri_off, node_img, nb_off,
                         reinterpret_cast<CandMeta *>(meta), draw, bucket_cnt, bucket_list, bucket_cap,
-                        reinterpret_cast<const uint4 *>(node_rec));
+                        reinterpret_cast<const uint4 *>(node_rec), pc_cnt);
   hipEvent_t ev_stop = ev_markers ? nullptr : ev_after;
   Score3Args a;
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand;
@@ -1192,6 +1304,11 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.sp_chunk_cap = (unsigned)std::max<long long>(0, std::min<long long>(sp_chunks, 0x7FFFFFFFll));
   a.sp_slot_cap = sp_slot_cap;
   a.sp_t_max = score_split_t_max(max_nb);
+  // pair-count lists: only with the split form over the cost-class schedule (the natural-order / fused forms do not use them)
+  const bool use_pc = split && bucket_cnt != nullptr && pc_cnt != nullptr && pc_list != nullptr;
+  a.pc_cnt = use_pc ? pc_cnt : nullptr;
+  a.pc_list = reinterpret_cast<uint2 *>(pc_list);
+  a.pc_cap = pc_cap;
   if (ev_before && ev_markers) (void)hipEventRecord(ev_before, st);
   const bool sorted = perm != nullptr && f32 && !perm_is_placement;
   if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
@@ -1230,7 +1347,8 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
     const long long fit = std::max<long long>(1, std::min<long long>(kDensePerCU, (long long)(160 * 1024 / lds2)));
     const int by = perm_is_placement ? 1 : (sorted && a.spos ? 2 : 0);
     const dim3 g2((unsigned)std::max<long long>(8, (fit * n_cu) & ~7ll));  // a multiple of 8: see the unit queues
-    hipExtLaunchKernelGGL(k_dense8, g2, dim3(64 * kDenseWaves), lds2, st, nullptr, ev_stop, 0, a, cfg, by);
+    if (cfg.fast) hipExtLaunchKernelGGL(k_dense8<true>, g2, dim3(64 * kDenseWaves), lds2, st, nullptr, ev_stop, 0, a, cfg, by);
+    else hipExtLaunchKernelGGL(k_dense8<false>, g2, dim3(64 * kDenseWaves), lds2, st, nullptr, ev_stop, 0, a, cfg, by);
     if (ev_after && ev_markers) (void)hipEventRecord(ev_after, st);
     return;
   }

@@ -40,7 +40,7 @@ def clean_env():
     keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES",
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
             "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TIMER_SAMPLE", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_SCORE_SPLIT",
-            "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS", "LT_TEST_PAIR_SCORE_TERMS")
+            "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS", "LT_TEST_PAIR_SCORE_TERMS", "LT_TEST_NO_PAIR_CLASSES")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -487,6 +487,14 @@ def test_split_and_fused_scoring_agree(gpu_lib, clean_env, topk, n_nb):
     _same(base, full)
     assert full[4]["score_fused"] == 1 and chains[4]["score_fused"] == 0 and base[4]["score_fused"] == 0
     del os.environ["LT_TEST_SPLIT_SLOT"], os.environ["LT_TEST_SPLIT_CHUNKS"]
+    # k_dense8's units in the order of k_cand_meta's cost classes instead of the sweep's pair-count lists (round 6)
+    os.environ["LT_TEST_NO_PAIR_CLASSES"] = "1"
+    _same(base, _results(run_product(sc, cfg, topk=topk)))
+    del os.environ["LT_TEST_NO_PAIR_CLASSES"]
+    os.environ["LT_TEST_SPLIT_SLOT"] = "4"   # ... and the pair-count lists with overflow chains everywhere
+    os.environ["LT_TEST_NO_PAIR_CLASSES"] = "1"
+    _same(base, _results(run_product(sc, cfg, topk=topk)))
+    del os.environ["LT_TEST_SPLIT_SLOT"], os.environ["LT_TEST_NO_PAIR_CLASSES"]
     os.environ["LT_TEST_NO_TILE_CLASSES"] = "1"
     os.environ["LT_SCORE_SPLIT"] = "1"
     nat = _results(run_product(sc, cfg, topk=topk))

@@ -207,6 +207,53 @@ def test_aggregator_matches_the_oracle_bit_for_bit_including_orientation():
         assert np.array_equal(out, np.asarray(want).ravel()[:7]), (trial, n, out, want)
 
 
+def test_principal_axis_against_an_independent_svd_and_how_stable_its_sign_is():
+    """The one third-party assumption nothing in this container can compile away: Eigen's JacobiSVD decides which end of an
+    aggregated track is `start` (merging/aggregator.cc:76-78: `matrixV().col(0)`), and lt_svd.h / oracle/eigen_svd_ref.h are
+    restatements of Eigen 3.4's procedure, not Eigen.  Two properties that do not depend on either restatement:
+      (a) the AXIS equals numpy's (LAPACK) first right singular vector of the centred endpoint matrix up to sign;
+      (b) the SIGN is stable: perturbing the endpoints by 1e-9 relative -- far more than any reduction-order or FMA
+          difference between a real Eigen build and the restatement could -- flips it for (almost) no track.  The measured
+          rate is the size of what remains assumed ("Eigen behaviours assumed")."""
+    import ctypes as C
+    from limap_amd import _capi
+    L = _capi.load_library()
+    rng = np.random.default_rng(17)
+    dp = C.POINTER(C.c_double)
+
+    def agg(lines, scores):
+        out = np.zeros(7)
+        assert L.lt_fn_aggregate_line3d_list(len(lines), lines.ctypes.data_as(dp), scores.ctypes.data_as(dp), 0, out.ctypes.data_as(dp)) == 0
+        return out
+
+    n_tracks, n_flips, worst_axis = 1500, 0, 0.0
+    for _ in range(n_tracks):
+        n = int(rng.integers(4, 30))
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        c0 = rng.normal(size=3) * 5
+        noise = 10.0 ** rng.uniform(-4, -1)
+        lines = np.zeros((n, 10))
+        for i in range(n):
+            a, b = np.sort(rng.uniform(-3, 3, 2))
+            s, e = c0 + a * d + rng.normal(size=3) * noise, c0 + b * d + rng.normal(size=3) * noise
+            lines[i, :3], lines[i, 3:6] = (e, s) if rng.random() < 0.5 else (s, e)
+            lines[i, 6:8] = rng.uniform(1, 9, 2); lines[i, 8] = 0.05; lines[i, 9] = 1.0
+        scores = rng.uniform(0, 10, n)
+        out = agg(lines, scores)
+        axis = out[3:6] - out[:3]
+        axis /= np.linalg.norm(axis)
+        pts = np.concatenate([lines[:, :3], lines[:, 3:6]], 0)
+        v = np.linalg.svd(pts - pts.mean(0), full_matrices=False)[2][0]
+        worst_axis = max(worst_axis, 1.0 - abs(float(axis @ v)))
+        pert = lines.copy()
+        pert[:, :6] *= 1.0 + 1e-9 * rng.uniform(-1, 1, (n, 6))
+        out2 = agg(pert, scores)
+        n_flips += int(float((out2[3:6] - out2[:3]) @ axis) < 0)
+    assert worst_axis < 1e-9, worst_axis
+    print(f"principal-axis sign flips under a 1e-9 perturbation: {n_flips} of {n_tracks}")
+    assert n_flips <= n_tracks // 200, n_flips
+
+
 def test_match_row_pass_vector_paths_equal_plain_numpy():
     """The host pass over a block of match rows (lt_rows.h: staged word line | neighbour line << 16, column maxima as
     unsigned, sortedness) -- scalar, AVX2 and AVX-512 forms against numpy, on ragged lengths around the vector widths,
