@@ -133,3 +133,63 @@ def test_one_rank_rccl_gather_init_refresh_and_tracks(gpu_lib):
     if "skip" in d:
         pytest.skip(d["skip"])
     assert d["tracks"] > 0 and d["candidates"] > 0
+
+
+# ---- the plain-C host (examples/rccl_host.c -> limap_amd/rccl_host): the C-ABI boundary carries the multi-GPU path ----
+HOST = os.path.join(ROOT, "limap_amd", "rccl_host")
+
+
+def test_plain_c_host_is_built_against_the_two_headers_only():
+    if not os.path.exists(LIB):
+        pytest.skip("liblimap_amd_rccl.so is not built on this box (no RCCL): no C host either")
+    assert os.path.exists(HOST), "limap_amd/rccl_host is not built (make -C limap_amd/csrc rccl)"
+    src = open(os.path.join(ROOT, "examples", "rccl_host.c")).read()
+    ours = [h for h in re.findall(r'#include "([^"]+)"', src)]
+    assert sorted(ours) == ["limap_amd.h", "limap_amd_rccl.h"], ours  # nothing of the product's internals, no C++
+
+
+def _run_c_host(tmp_path, world, n_gpus_needed):
+    import torch
+    if torch.cuda.device_count() < n_gpus_needed:
+        pytest.skip(f"needs {n_gpus_needed} GPUs (RCCL refuses one device twice), this box has {torch.cuda.device_count()}")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from write_scene_bin import fnv_members, write_scene_bin
+    from limap_amd import synthetic as syn
+    from helpers import run_product
+    sc = syn.make_scene(n_views=24, n_segs=90, n_neighbors=6, seed=41)
+    scene_bin, idf = str(tmp_path / "scene.bin"), str(tmp_path / "nccl_id")
+    write_scene_bin(scene_bin, sc)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = [str(tmp_path / f"out{r}.txt") for r in range(world)]
+    procs = [subprocess.Popen([HOST, str(r), str(world), scene_bin, idf, outs[r]], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    res = [p.communicate(timeout=600) for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, (r, res[r][1][-2000:])
+    line = open(outs[0]).read().split()
+    got = dict(zip(line[0::2], line[1::2]))
+    # the one-process result through the Python mirror (itself held to the oracle by the parity tests)
+    T = run_product(sc, syn.default_triangulation_cfg())
+    T.ComputeLineTracks()
+    tr = T.context().get_tracks()
+    assert int(got["tracks"]) == len(tr["off"]) - 1 > 0 and int(got["members"]) == len(tr["image_ids"])
+    assert int(got["fnv"], 16) == fnv_members(tr["off"], tr["image_ids"], tr["line_ids"])
+    return got
+
+
+@pytest.mark.gpu
+def test_plain_c_host_one_rank(gpu_lib, tmp_path):
+    """the whole sequence of examples/rccl_host.c with a one-rank communicator (what a one-GPU box can run)"""
+    if not os.path.exists(HOST):
+        pytest.skip("limap_amd/rccl_host is not built")
+    _run_c_host(tmp_path, 1, 1)
+
+
+@pytest.mark.gpu
+def test_plain_c_host_two_ranks(gpu_lib, tmp_path):
+    """two processes, two GPUs, ncclCommInitRank over a file-shared unique id: all-gather, sharded run, one-collective
+    merge, ComputeLineTracks on rank 0 -- the tracks of the one-process run"""
+    if not os.path.exists(HOST):
+        pytest.skip("limap_amd/rccl_host is not built")
+    got = _run_c_host(tmp_path, 2, 2)
+    assert int(got["keys"]) > 0
