@@ -149,9 +149,12 @@ def test_plain_c_host_is_built_against_the_two_headers_only():
 
 
 def _run_c_host(tmp_path, world, n_gpus_needed):
-    import torch
-    if torch.cuda.device_count() < n_gpus_needed:
-        pytest.skip(f"needs {n_gpus_needed} GPUs (RCCL refuses one device twice), this box has {torch.cuda.device_count()}")
+    # (device count from a child process: importing torch HERE, after liblimap_amd_rccl.so has pulled in the system's librccl,
+    # would leave this process with torch bound to a foreign RCCL -- it aborts at exit)
+    n_dev = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                               stdout=subprocess.PIPE, text=True, timeout=300).stdout.strip().splitlines()[-1])
+    if n_dev < n_gpus_needed:
+        pytest.skip(f"needs {n_gpus_needed} GPUs (RCCL refuses one device twice), this box has {n_dev}")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from write_scene_bin import fnv_members, write_scene_bin
     from limap_amd import synthetic as syn
@@ -169,7 +172,7 @@ def _run_c_host(tmp_path, world, n_gpus_needed):
     line = open(outs[0]).read().split()
     got = dict(zip(line[0::2], line[1::2]))
     # the one-process result through the Python mirror (itself held to the oracle by the parity tests)
-    T = run_product(sc, syn.default_triangulation_cfg())
+    T = run_product(sc, {})  # the C host runs lt_config_default: the reference's class defaults, no yaml on top
     T.ComputeLineTracks()
     tr = T.context().get_tracks()
     assert int(got["tracks"]) == len(tr["off"]) - 1 > 0 and int(got["members"]) == len(tr["image_ids"])
