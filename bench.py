@@ -314,7 +314,9 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
            "step_with_merge_and_tail_ms": None if note else 1e3 * full / n_full, "note": note,
            "step_with_merge_and_tail_overlapped_ms": None if over is None else 1e3 * over / n_full,
            "overlapped_note": over_note or "the host half of step k's tail (rank 0) runs while the device works on step k + 1",
-           "ms_per_step_per_rank": per_rank, "tracks_rank0": st["tracks"] if rank == 0 else None, "candidates": cand}
+           "ms_per_step_per_rank": per_rank, "load_imbalance_max_over_mean": max(per_rank) / (sum(per_rank) / len(per_rank)),
+           "n_ranks_rccl": dist.get_world_size() if (use_dist and dist.get_backend() == "nccl") else 0,
+           "tracks_rank0": st["tracks"] if rank == 0 else None, "candidates": cand}
     del ctx
     return res
 
@@ -835,6 +837,7 @@ def main():
                       "n_ranks_rccl": dist.get_world_size() if (use_dist and dist.get_backend() == "nccl") else 0,
                       "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if use_dist else None,
                       "ms_per_step_per_rank": per_rank_ms, "candidates_per_rank": per_rank_cand,
+                      "load_imbalance_max_over_mean": (max(per_rank_ms) / (sum(per_rank_ms) / len(per_rank_ms))) if per_rank_ms else None,
                       "images_per_rank": per_rank_imgs, "allgather_alone_us": allgather_us},
             "device_source_hash": device_source_hash(),
         }

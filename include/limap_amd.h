@@ -225,6 +225,15 @@ int lt_export_image_results(lt_ctx *ctx, int img_id, int32_t *out_nb_ids /*[255]
 int lt_import_image_results(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb_ids, const double *line10,
                             const double *score, const int32_t *src2, const int32_t *n_tris,
                             const int64_t *edge_off, const int32_t *edges2);
+/* The same for n images in ONE call and two flat blobs -- what a streamed job moves per chunk (limap_amd/stream.py:
+ * BASELINE configs[4], runners/rome16k/triangulation.py:15-45) and what the ranks of a multi-GPU job gather to rank 0.
+ * ints: n, then per image  img_id, n_nb, m (lines), ne (valid edges), nb_ids[n_nb], src[m][2], n_tris[m], edge_cnt[m],
+ * edges[ne][2];  dbls: per image  line10[m][10], score[m]  (the layout of limap_amd.dist.pack_image_results, so blobs packed
+ * either way are interchangeable).  lt_export_images_size returns the two lengths; lt_import_images_packed checks the
+ * blob against n_ints / n_dbls and every id and count in it before it touches the context (LT_ERR_ARGUMENT otherwise). */
+int lt_export_images_size(lt_ctx *ctx, int n, const int32_t *img_ids, int64_t *n_ints, int64_t *n_dbls);
+int lt_export_images_packed(lt_ctx *ctx, int n, const int32_t *img_ids, int32_t *ints, double *dbls);
+int lt_import_images_packed(lt_ctx *ctx, const int32_t *ints, int64_t n_ints, const double *dbls, int64_t n_dbls);
 
 /* ---- shards of a multi-GPU run, device to device (no reference counterpart: the reference is one process).
  * Images are sharded over the ranks in id order, so a rank's nodes are one range [g_lo, g_hi) of the global node index

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "lt_compute_tracks", "lt_compute_tracks_begin", "lt_compute_tracks_end", "lt_count_images", "lt_count_lines", "lt_num_nodes", "lt_get_best",
     "lt_get_num_tris", "lt_get_valid_flags", "lt_num_valid_edges", "lt_get_valid_edges", "lt_num_all_tris", "lt_get_all_tris",
     "lt_num_tracks", "lt_num_track_members", "lt_get_tracks", "lt_image_results_size",
-    "lt_export_image_results", "lt_import_image_results", "lt_shard_node_bytes", "lt_shard_count", "lt_shard_build", "lt_shard_export", "lt_shard_import", "lt_ts_from_ctx", "lt_ts_create", "lt_ts_destroy",
+    "lt_export_image_results", "lt_import_image_results", "lt_export_images_size", "lt_export_images_packed", "lt_import_images_packed", "lt_shard_node_bytes", "lt_shard_count", "lt_shard_build", "lt_shard_export", "lt_shard_import", "lt_ts_from_ctx", "lt_ts_create", "lt_ts_destroy",
     "lt_ts_num_tracks", "lt_ts_num_members", "lt_ts_get", "lt_ts_filter_by_reprojection",
     "lt_ts_filter_by_sensitivity", "lt_ts_filter_by_overlap", "lt_ts_remerge_once", "lt_get_stats", "lt_get_timers", "lt_get_timer_sums", "lt_run_device_async", "lt_sync",
     "lt_release_cached_memory", "lt_reserve_host",
@@ -159,6 +159,9 @@ def load_library():
     L.lt_image_results_size.restype = C.c_int64
     L.lt_export_image_results.argtypes = [vp, C.c_int, i32p, i32p, dp, dp, i32p, i32p, i64p, i32p]
     L.lt_import_image_results.argtypes = [vp, C.c_int, C.c_int, i32p, dp, dp, i32p, i32p, i64p, i32p]
+    L.lt_export_images_size.argtypes = [vp, C.c_int, i32p, i64p, i64p]
+    L.lt_export_images_packed.argtypes = [vp, C.c_int, i32p, i32p, dp]
+    L.lt_import_images_packed.argtypes = [vp, i32p, C.c_int64, dp, C.c_int64]
     L.lt_shard_node_bytes.argtypes = []
     L.lt_shard_count.argtypes = [vp, i64p]
     L.lt_shard_build.argtypes = [vp, C.c_int64]
@@ -488,6 +491,20 @@ class Context:
         self.chk(self.L.lt_import_image_results(self.h, int(r["img_id"]), len(nb), ptr(nb, C.c_int32), ptr(line, C.c_double),
                                                 ptr(score, C.c_double), ptr(src, C.c_int32), ptr(nt, C.c_int32),
                                                 ptr(eoff, C.c_int64), ptr(edges, C.c_int32)))
+
+    def export_images_packed(self, img_ids):
+        """Per-node results of the given images as (int32 blob, float64 blob) -- dist.pack_image_results' layout."""
+        ids = i32(img_ids)
+        ni, nd = C.c_int64(0), C.c_int64(0)
+        self.chk(self.L.lt_export_images_size(self.h, len(ids), ptr(ids, C.c_int32), C.byref(ni), C.byref(nd)))
+        ints, dbls = np.empty(ni.value, np.int32), np.empty(max(nd.value, 1), np.float64)
+        self.chk(self.L.lt_export_images_packed(self.h, len(ids), ptr(ids, C.c_int32), ptr(ints, C.c_int32), ptr(dbls, C.c_double)))
+        return ints, dbls[:nd.value]
+
+    def import_images_packed(self, ints, dbls):
+        ints, dbls = i32(ints), f64(dbls)
+        d = dbls if dbls.size else np.zeros(1)
+        self.chk(self.L.lt_import_images_packed(self.h, ptr(ints, C.c_int32), len(ints), ptr(d, C.c_double), len(dbls)))
 
     # --- shards of a multi-GPU run, device to device (include/limap_amd.h: lt_shard_*) ---
     def shard_node_bytes(self):

@@ -236,6 +236,136 @@ int lt_import_image_results(lt_ctx *ctx, int img_id, int n_nb, const int32_t *nb
   return LT_OK;
 }
 
+// ---- bulk form (include/limap_amd.h: the layout of limap_amd.dist.pack_image_results) ----
+int lt_export_images_size(lt_ctx *ctx, int n, const int32_t *img_ids, int64_t *n_ints, int64_t *n_dbls) {
+  int rc = lt_flush(ctx);
+  if (rc) return rc;
+  long long ni = 1, nd = 0;
+  for (int k = 0; k < n; ++k) {
+    auto it = ctx->id2idx.find(img_ids[k]);
+    if (it == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "unknown image id " + std::to_string(img_ids[k]));
+    const int idx = it->second;
+    if (!ctx->triangulated[idx]) return fail(ctx, LT_ERR_STATE, "image was not triangulated on this context");
+    const long long m = ctx->seg_off[idx + 1] - ctx->seg_off[idx];
+    long long ne = 0;
+    for (long long g = ctx->seg_off[idx]; g < ctx->seg_off[idx + 1]; ++g) ne += (long long)ctx->valid_edges[g].size() / 2;
+    ni += 4 + (long long)ctx->neighbors[idx].size() + 4 * m + 2 * ne;
+    nd += 11 * m;
+  }
+  *n_ints = ni;
+  *n_dbls = nd;
+  return LT_OK;
+}
+
+int lt_export_images_packed(lt_ctx *ctx, int n, const int32_t *img_ids, int32_t *ints, double *dbls) {
+  int rc = lt_flush(ctx);
+  if (rc) return rc;
+  int32_t *ip = ints;
+  double *dp = dbls;
+  *ip++ = n;
+  for (int k = 0; k < n; ++k) {
+    auto it = ctx->id2idx.find(img_ids[k]);
+    if (it == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "unknown image id " + std::to_string(img_ids[k]));
+    const int idx = it->second;
+    if (!ctx->triangulated[idx]) return fail(ctx, LT_ERR_STATE, "image was not triangulated on this context");
+    const auto &nb = ctx->neighbors[idx];
+    const long long g0 = ctx->seg_off[idx], m = ctx->seg_off[idx + 1] - g0;
+    int32_t *head = ip;
+    ip += 4;
+    for (size_t j = 0; j < nb.size(); ++j) *ip++ = ctx->img_ids[nb[j]];
+    int32_t *src = ip, *nt = src + 2 * m, *cnt = nt + m, *edges = cnt + m;
+    double *line = dp, *score = dp + 10 * m;
+    long long ne = 0;
+    for (long long l = 0; l < m; ++l) {
+      const long long g = g0 + l;
+      const Cand &c = ctx->best_c[g];
+      double *o = line + 10 * l;
+      for (int q = 0; q < 3; ++q) { o[q] = c.s[q]; o[3 + q] = c.e[q]; }
+      o[6] = c.depth[0]; o[7] = c.depth[1]; o[8] = c.unc; o[9] = c.score3;
+      score[l] = ctx->best_score[g];
+      src[2 * l] = ctx->best_src2[2 * g];
+      src[2 * l + 1] = ctx->best_src2[2 * g + 1];
+      nt[l] = ctx->n_tris[g];
+      const auto v = ctx->valid_edges[g];
+      if (!v.empty()) std::memcpy(edges + 2 * ne, v.data(), 4 * v.size());
+      cnt[l] = (int32_t)(v.size() / 2);
+      ne += (long long)v.size() / 2;
+    }
+    head[0] = img_ids[k]; head[1] = (int32_t)nb.size(); head[2] = (int32_t)m; head[3] = (int32_t)ne;
+    ip = edges + 2 * ne;
+    dp += 11 * m;
+  }
+  return LT_OK;
+}
+
+int lt_import_images_packed(lt_ctx *ctx, const int32_t *ints, int64_t n_ints, const double *dbls, int64_t n_dbls) {
+  if (!ctx->inited) return fail(ctx, LT_ERR_STATE, "import before Init");
+  if (n_ints < 1 || ints[0] < 0) return fail(ctx, LT_ERR_ARGUMENT, "lt_import_images_packed: malformed blob");
+  const int n = ints[0];
+  // first pass: everything in the blob is checked before the context changes
+  {
+    long long ip = 1, dp = 0;
+    for (int k = 0; k < n; ++k) {
+      if (ip + 4 > n_ints) return fail(ctx, LT_ERR_ARGUMENT, "lt_import_images_packed: blob ends inside an image header");
+      const long long n_nb = ints[ip + 1], m = ints[ip + 2], ne = ints[ip + 3];
+      auto it = ctx->id2idx.find(ints[ip]);
+      if (it == ctx->id2idx.end()) return fail(ctx, LT_ERR_ARGUMENT, "unknown image id " + std::to_string(ints[ip]));
+      if (n_nb < 0 || n_nb > 255 || ne < 0 || m != ctx->seg_off[it->second + 1] - ctx->seg_off[it->second])
+        return fail(ctx, LT_ERR_ARGUMENT, "lt_import_images_packed: image " + std::to_string(ints[ip]) +
+                                              " has other line / neighbour counts than the blob says");
+      const long long body = n_nb + 4 * m + 2 * ne;
+      if (ip + 4 + body > n_ints || dp + 11 * m > n_dbls)
+        return fail(ctx, LT_ERR_ARGUMENT, "lt_import_images_packed: blob shorter than its headers say");
+      const int32_t *nbp = ints + ip + 4, *cnt = nbp + n_nb + 3 * m;
+      for (long long j = 0; j < n_nb; ++j)
+        if (ctx->id2idx.find(nbp[j]) == ctx->id2idx.end())
+          return fail(ctx, LT_ERR_ARGUMENT, "unknown neighbour image id " + std::to_string(nbp[j]));
+      long long sum = 0;
+      for (long long l = 0; l < m; ++l) {
+        if (cnt[l] < 0) return fail(ctx, LT_ERR_ARGUMENT, "lt_import_images_packed: negative edge count");
+        sum += cnt[l];
+      }
+      if (sum != ne) return fail(ctx, LT_ERR_ARGUMENT, "lt_import_images_packed: edge counts do not add up");
+      ip += 4 + body;
+      dp += 11 * m;
+    }
+  }
+  long long ip = 1, dp = 0;
+  for (int k = 0; k < n; ++k) {
+    const int idx = ctx->id2idx.find(ints[ip])->second;
+    const long long n_nb = ints[ip + 1], m = ints[ip + 2], ne = ints[ip + 3];
+    const int32_t *nbp = ints + ip + 4, *src = nbp + n_nb, *nt = src + 2 * m, *cnt = nt + m, *edges = cnt + m;
+    const double *line = dbls + dp, *score = line + 10 * m;
+    std::vector<int> nb((size_t)n_nb);
+    for (long long j = 0; j < n_nb; ++j) nb[(size_t)j] = ctx->id2idx.find(nbp[j])->second;
+    ctx->neighbors[idx] = nb;
+    ctx->triangulated[idx] = 1;
+    const long long g0 = ctx->seg_off[idx];
+    long long e = 0;
+    for (long long l = 0; l < m; ++l) {
+      const long long g = g0 + l;
+      Cand &c = ctx->best_c[g];
+      c = Cand{};
+      const double *o = line + 10 * l;
+      for (int q = 0; q < 3; ++q) { c.s[q] = o[q]; c.e[q] = o[3 + q]; }
+      c.depth[0] = o[6]; c.depth[1] = o[7]; c.unc = o[8]; c.score3 = o[9];
+      ctx->best_score[g] = score[l];
+      ctx->best_src2[2 * g] = src[2 * l];
+      ctx->best_src2[2 * g + 1] = src[2 * l + 1];
+      ctx->n_tris[g] = nt[l];
+      ctx->has_best[g] = nt[l] > 0 ? 1 : 0;
+      ctx->valid_edges.set(g, edges + 2 * e, edges + 2 * (e + cnt[l]));
+      e += cnt[l];
+    }
+    ctx->best_c_set[(size_t)idx] = 1;
+    ip += 4 + n_nb + 4 * m + 2 * ne;
+    dp += 11 * m;
+  }
+  define_best_of_other_images(ctx);
+  ctx->tracks_done = false;
+  return LT_OK;
+}
+
 int lt_get_stats(lt_ctx *ctx, int64_t out[8]) {
   LT_FINISH(ctx);
   if (ctx->inited && ctx->ran && !ctx->downloaded) {  // the pair statistic is summed from the per-node counts

@@ -75,23 +75,30 @@ def closure_arrays(chunk, img_ids, kvec, qvec, tvec, seg_off, segs):
             np.ascontiguousarray(np.asarray(tvec)[idx]), off, np.ascontiguousarray(np.asarray(segs)[rows]))
 
 
-def gather_results(results, rank, world, device=None):
-    """The streamed job's ONE collective: every rank's exported per-image results to rank 0 (`gather` of two packed
-    tensors, dist.gather_packed_to_rank0).  Returns the other ranks' results as one list on rank 0, None elsewhere."""
+def merge_blobs(blobs):
+    """Several packed result blobs (int32, float64) -> one: the counts add up, the bodies follow each other."""
+    if not blobs:
+        return np.zeros(1, np.int32), np.zeros(0, np.float64)
+    n = sum(int(b[0][0]) for b in blobs)
+    return (np.concatenate([np.array([n], np.int32)] + [np.asarray(b[0], np.int32)[1:] for b in blobs]),
+            np.concatenate([np.asarray(b[1], np.float64) for b in blobs]))
+
+
+def gather_results(blobs, rank, world, device=None):
+    """The streamed job's ONE collective: every rank's packed per-image results (a list of blobs, one per chunk) to rank 0
+    (`gather` of two tensors, dist.gather_packed_to_rank0).  Returns the other ranks' blobs -- one (ints, dbls) pair per
+    rank, ready for `import_images_packed` -- on rank 0, None elsewhere."""
     from . import dist as ltdist
     import torch
     import torch.distributed as dist
     if device is None:
         backend = dist.get_backend()
         device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    ints, flts = ltdist.pack_image_results(results if rank != 0 else [])
+    ints, flts = merge_blobs(blobs if rank != 0 else [])
     parts = ltdist.gather_packed_to_rank0(ints, flts, rank, world, device)
     if rank != 0:
         return None
-    out = []
-    for r in range(1, world):
-        out += ltdist.unpack_image_results(*parts[r])
-    return out
+    return [parts[r] for r in range(1, world)]
 
 
 class StreamedTriangulation:
@@ -125,7 +132,7 @@ class StreamedTriangulation:
             self.worker.set_ranges(*ranges)
         self.acc = None
         self.accumulate = accumulate
-        self.results = []      # this rank's exported per-image results (rank 0 imports its own as it goes)
+        self.results = []      # this rank's packed results, one blob per chunk (rank 0 imports its own as it goes)
         self.per_chunk = []
         self.n_imported = 0
 
@@ -151,19 +158,19 @@ class StreamedTriangulation:
         W.init(ids, k, q, tv, off, sg)
         rec["closure_segments"] = int(off[-1])
         rec["init_ms"] = 1e3 * (time.perf_counter() - t)
-        t_m = 0.0
+        # the chunk's match rows in ONE call (lt_triangulate_all_rows: one pass of the host team over all blocks; the per-image
+        # form cost 66 us of Python and ctypes per image, 25x the chunk's device time)
         t = time.perf_counter()
-        for i in chunk.images:
-            tm = time.perf_counter()
-            m = matches_of(int(i))  # stands in for reading matches_{id}.npy (line_triangulation.py:160-165)
-            t_m += time.perf_counter() - tm
-            nb = list(m.keys())
-            moff = np.zeros(len(nb) + 1, np.int64)
-            moff[1:] = np.cumsum([len(m[x]) for x in nb])
-            pairs = np.concatenate([m[x] for x in nb], 0) if nb else np.zeros((0, 2), np.int32)
-            W.triangulate_image(int(i), nb, moff, pairs)
-        rec["matches_ms"] = 1e3 * t_m
-        rec["buffer_ms"] = 1e3 * (time.perf_counter() - t) - rec["matches_ms"]
+        ms = [matches_of(int(i)) for i in chunk.images]  # stands in for reading matches_{id}.npy (line_triangulation.py:160-165)
+        rec["matches_ms"] = 1e3 * (time.perf_counter() - t)
+        t = time.perf_counter()
+        nbs, arrs = [], []
+        for m in ms:
+            nbs.append([int(x) for x in m.keys()])
+            arrs.append([a if (a.dtype == np.int32 and a.flags.c_contiguous and a.ndim == 2) else
+                         np.ascontiguousarray(np.asarray(a).reshape(-1, 2), np.int32) for a in m.values()])
+        W.triangulate_all_rows(chunk.images, nbs, arrs)
+        rec["buffer_ms"] = 1e3 * (time.perf_counter() - t)
         t = time.perf_counter()
         W.upload()
         rec["upload_ms"] = 1e3 * (time.perf_counter() - t)
@@ -190,14 +197,12 @@ class StreamedTriangulation:
         rec["valid_edges"] = int(st["valid_edges"])
         t = time.perf_counter()
         W.download()
-        out = [W.export_image_results(int(i)) for i in chunk.images]
+        blob = W.export_images_packed(chunk.images)  # one call, two flat arrays (lt_export_images_packed)
         if self.rank == 0 and self.accumulate:
-            A = self._accumulator()
-            for r in out:
-                A.import_image_results(r)
-            self.n_imported += len(out)
+            self._accumulator().import_images_packed(*blob)
+            self.n_imported += len(chunk.images)
         else:
-            self.results += out
+            self.results.append(blob)
         rec["export_ms"] = 1e3 * (time.perf_counter() - t)
         self.per_chunk.append(rec)
         return rec
@@ -209,9 +214,9 @@ class StreamedTriangulation:
             others = gather_results(self.results, self.rank, self.world, self.comm_device)
             if self.rank == 0:
                 A = self._accumulator()
-                for res in others:
-                    A.import_image_results(res)
-                    self.n_imported += 1
+                for ints, dbls in others:
+                    A.import_images_packed(ints, dbls)
+                    self.n_imported += int(ints[0])
         if self.rank != 0:
             return None
         A = self._accumulator()

@@ -208,12 +208,19 @@ def _stream_worker(rank, world, port, q):
                                     line=np.full((m, 10), float(c.index)), score=np.full(m, float(rank)),
                                     src=np.zeros((m, 2), np.int32), n_tris=np.full(m, c.index, np.int32), edge_off=eoff,
                                     edges=np.zeros((m, 2), np.int32)))
-        others = ltstream.gather_results(results, rank, world, torch.device("cpu"))
+        from limap_amd import dist as ltdist
+        # one blob per chunk, as StreamedTriangulation keeps them
+        blobs, k0 = [], 0
+        for c in mine:
+            blobs.append(ltdist.pack_image_results(results[k0:k0 + len(c.images)]))
+            k0 += len(c.images)
+        others = ltstream.gather_results(blobs, rank, world, torch.device("cpu"))
         if rank == 0:
-            got = sorted([r["img_id"] for r in results] + [r["img_id"] for r in others])
-            ok = ok and got == sc.img_ids.tolist()
+            got_other = [r for part in others for r in ltdist.unpack_image_results(*part)]
+            got = sorted([r["img_id"] for r in results] + [r["img_id"] for r in got_other])
+            ok = ok and got == sc.img_ids.tolist() and len(others) == world - 1
             by_img = {int(i): c for c in plan for i in c.images}
-            for r in others:
+            for r in got_other:
                 c = by_img[r["img_id"]]
                 ok = ok and c.rank != 0 and float(r["score"][0]) == float(c.rank) and int(r["n_tris"][0]) == c.index
         else:

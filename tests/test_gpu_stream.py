@@ -31,9 +31,12 @@ def _stream(sc, cfg, chunk_images, world=1, fine=False):
     root = jobs[0]
     root.all_chunks = [rec for st in jobs for rec in st.per_chunk]
     for st in jobs[1:]:
-        for res in ltdist.unpack_image_results(*ltdist.pack_image_results(st.results)):
-            root._accumulator().import_image_results(res)
-            root.n_imported += 1
+        ints, dbls = ltstream.merge_blobs(st.results)
+        # (through the Python packer as well: the two layouts are one)
+        back = ltdist.pack_image_results(ltdist.unpack_image_results(ints, dbls))
+        assert np.array_equal(back[0], ints) and np.array_equal(back[1], dbls)
+        root._accumulator().import_images_packed(ints, dbls)
+        root.n_imported += int(ints[0])
     root.world = 1  # (the exchange was done by hand)
     return root, root.finish()
 
