@@ -892,6 +892,11 @@ constexpr int kDenseLdsBudget = LT_DENSE_LDS_KB * 1024;      // LDS for a workgr
 // order, no claims, so that the header of unit j + 2 and every thread's first entry of unit j + 1 can be fetched a unit ahead,
 // behind the rounds' own gathers -- 98.3 us for the stage against 95.5 with the claims below: what the prefetch saves per unit
 // the fixed assignment loses in balance, 286 of 1 024 workgroups still busy at 40 us of 49.)
+// (... and claims ONE UNIT AHEAD -- second unit static as well, the claim for unit j + 2 issued at the start of unit j, the
+// header of unit j + 2 fetched during unit j's sums and every thread's first entry of unit j + 1 at the end of unit j's
+// rounds --: 100.0 against 96.2 us, same bits.  The kernel without its arithmetic and without its record gathers
+// (LT_ABL_DENSE=2) still takes 32 of its 48 us, but not as a chain of exposed round trips at the start of a unit: taking
+// those away does not shorten it.)
 template <bool kFast>  // kFast: pair_score_fused / pair_score_terms (ScoreCfg::fast)
 __global__ void __launch_bounds__(64 * kDenseWaves)
 k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of the candidate, 1 = position, 2 = spos[position]
