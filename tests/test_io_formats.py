@@ -323,6 +323,65 @@ def test_diff_tool_counts_swaps_separately():
     assert not rep["ok"] and rep["missing_member_sets"] == 1 and rep["extra_member_sets"] == 1
 
 
+def _load_tool(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(GOLD), "..", "..", "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_upstream_kit_folders_are_deterministic_and_self_consistent(tmp_path):
+    """tools/export_scene_for_limap.py (the scenes of this repository as limap output folders, for a machine WITH limap):
+    the small cases regenerate to the committed digests (tests/golden/export_digests.json), read back through this
+    package's readers as the scene they came from, and `diff_limap_dump.py --ours-folder` (the no-GPU form: upstream's
+    tracks against the folder of expected tracks) accepts the expected tracks against themselves."""
+    import json as _json
+    import subprocess
+    kit = _load_tool("export_scene_for_limap")
+    gold = _json.load(open(os.path.join(os.path.dirname(GOLD), "export_digests.json")))
+    for name in ("matched_s11", "exhaustive_s12", "matched_outer2_halfpix_s13"):
+        sc, cfg, d = kit.export_case(str(tmp_path), name)
+        assert kit.folder_digest(d) == gold[name]["sha256_inputs"], name
+        ic = ltio.read_imagecols(os.path.join(d, "imagecols.npy"))
+        assert ic.get_img_ids() == [int(i) for i in sc.img_ids]
+        nb, rg = ltio.read_txt_metainfos(os.path.join(d, "metainfos.txt"))
+        assert nb == {int(i): [int(x) for x in sc.neighbors[int(i)]] for i in sc.img_ids} and np.array_equal(rg[0], sc.ranges[0])
+        assert np.array_equal(ltio.read_txt_segments(os.path.join(d, "segments"), int(sc.img_ids[3])), sc.segs_of(3))
+        if name.startswith("matched"):
+            m = ltio.read_matches(os.path.join(d, "matches"), int(sc.img_ids[2]))
+            want = sc.matches_of(int(sc.img_ids[2]), kit.CASES[name][5])
+            assert sorted(m) == sorted(want) and all(np.array_equal(m[k], want[k]) for k in want)
+    kit.CASES_TOPK[0] = kit.CASES["matched_s11"][5]
+    sc, cfg, d = kit.export_case(str(tmp_path), "matched_s11")
+    assert kit.write_expected(sc, cfg, d, False) == gold["matched_s11"]["expected_tracks"] > 0
+    tool = os.path.join(os.path.dirname(GOLD), "..", "..", "tools", "diff_limap_dump.py")
+    p = subprocess.run([sys.executable, tool, "--ours-folder", os.path.join(d, "expected"), "--tracks", os.path.join(d, "expected")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    rep = _json.loads(p.stdout[p.stdout.index("{"):])
+    assert rep["ok"] and rep["matched"] == gold["matched_s11"]["expected_tracks"] and rep["swapped"] == 0
+
+
+@pytest.mark.gpu
+def test_upstream_kit_expected_tracks_are_what_this_backend_computes(gpu_lib, tmp_path):
+    """the kit's folder through the GPU path of the diff tool, the kit's expected/ folder standing in for upstream's"""
+    import json as _json
+    import subprocess
+    kit = _load_tool("export_scene_for_limap")
+    for name in ("matched_s11", "exhaustive_s12"):
+        kit.CASES_TOPK[0] = kit.CASES[name][5] or None
+        sc, cfg, d = kit.export_case(str(tmp_path), name)
+        n = kit.write_expected(sc, cfg, d, name.startswith("exhaustive"))
+        tool = os.path.join(os.path.dirname(GOLD), "..", "..", "tools", "diff_limap_dump.py")
+        cmd = [sys.executable, tool, "--imagecols", os.path.join(d, "imagecols.npy"), "--metainfos", os.path.join(d, "metainfos.txt"),
+               "--segments", os.path.join(d, "segments"), "--tracks", os.path.join(d, "expected"), "--cfg", os.path.join(d, "cfg.json")]
+        cmd += ["--exhaustive"] if name.startswith("exhaustive") else ["--matches", os.path.join(d, "matches")]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        assert p.returncode == 0, p.stdout + p.stderr
+        rep = _json.loads(p.stdout[p.stdout.index("{"):])
+        assert rep["ok"] and rep["matched"] == n > 0 and rep["swapped"] == 0
+
+
 @pytest.mark.gpu
 def test_diff_tool_on_a_scene_folder(gpu_lib, oracle, tmp_path):
     """The whole flow of tools/diff_limap_dump.py with the oracle standing in for the upstream run: its tracks are

@@ -79,9 +79,12 @@ def compare(ours, theirs, rtol=1e-5):
 
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--imagecols", required=True)
-    ap.add_argument("--metainfos", required=True)
-    ap.add_argument("--segments", required=True)
+    ap.add_argument("--ours-folder", default=None,
+                    help="compare --tracks with THIS folder of track_*.txt instead of running the scene here (no GPU needed: "
+                         "e.g. the expected/ folder tools/export_scene_for_limap.py --expected wrote)")
+    ap.add_argument("--imagecols", default=None)
+    ap.add_argument("--metainfos", default=None)
+    ap.add_argument("--segments", default=None)
     ap.add_argument("--matches", default=None, help="folder of matches_<img_id>.npy (not needed with --exhaustive)")
     ap.add_argument("--tracks", required=True, help="folder of track_*.txt written by upstream (limapio.save_folder_linetracks)")
     ap.add_argument("--cfg", default=None, help="yaml / json with the `triangulation` section upstream ran with (default: limap's defaults)")
@@ -100,6 +103,12 @@ def main():
             user = json.load(open(args.cfg))
         cfg.update(user.get("triangulation", user))
     theirs = ltio.read_folder_linetracks(args.tracks)
+    if args.ours_folder:
+        rep = compare(ltio.read_folder_linetracks(args.ours_folder), theirs, args.rtol)
+        print(json.dumps(rep, indent=1))
+        return 0 if rep["ok"] else 1
+    if not (args.imagecols and args.metainfos and args.segments):
+        ap.error("--imagecols, --metainfos and --segments are needed unless --ours-folder is given")
     _, ours = ltio.triangulate_scene_folder(args.imagecols, args.metainfos, args.segments, args.matches, cfg,
                                             exhaustive=args.exhaustive)
     rep = compare(ours, theirs, args.rtol)
