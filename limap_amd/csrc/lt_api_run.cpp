@@ -16,6 +16,7 @@ int lt_upload(lt_ctx *ctx) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   double t0 = now_ms();
   build_job_tables(ctx);
+  ctx->blk_vorder_ok = false;
   int rc;
   {
     // images referenced by the job (lt_refresh_scene_chunks rebuilds only their segment records)
@@ -127,6 +128,16 @@ int lt_upload(lt_ctx *ctx) {
                          ctx->d_m_pairs.as<unsigned>());
     if ((rc = upload_vec(ctx, ctx->d_m_off, m_off))) return rc;
     // per-block records of the matched pipeline (row range, images, segment bases): a function of the job
+    {  // k_gates_ln takes the blocks in (neighbour, image) order: see the kernel
+      std::vector<int> vo((size_t)std::max(ctx->n_blk, 1), 0);
+      for (int b = 0; b < ctx->n_blk; ++b) vo[(size_t)b] = b;
+      std::stable_sort(vo.begin(), vo.begin() + ctx->n_blk, [&](int x, int y) {
+        return ctx->h_blk_nb[(size_t)x] != ctx->h_blk_nb[(size_t)y] ? ctx->h_blk_nb[(size_t)x] < ctx->h_blk_nb[(size_t)y]
+                                                                    : ctx->h_blk_img[(size_t)x] < ctx->h_blk_img[(size_t)y];
+      });
+      if ((rc = upload_vec(ctx, ctx->d_blk_vorder, vo))) return rc;
+      ctx->blk_vorder_ok = true;
+    }
     ENSURE(ctx, ctx->d_blkrec, blk_rec_bytes() * (size_t)std::max(ctx->n_blk, 1));
     launch_build_blk(ctx->stream, ctx->n_blk, ctx->d_m_off.as<long long>(), ctx->d_blk_img.as<int>(),
                      ctx->d_blk_nb.as<int>(), ctx->d_blk_slot.as<int>(), ctx->d_seg_off.as<long long>(),
@@ -458,7 +469,8 @@ int lt_run_device_async(lt_ctx *ctx) {
                        (pts_on && ctx->sfm_given) ? ctx->d_sfm_xyz.as<double>() : nullptr, ctx->d_err.as<int>(),
                        many_on ? 1 : 0, one_on ? 1 : 0, group_base, phase, ln_slots, ctx->d_m_pairs.as<unsigned short>(),
                        ctx->d_run_len.as<unsigned>(), ctx->d_slot_row0.as<unsigned>(), ctx->d_blk_surv.as<unsigned>(),
-                       ctx->d_blk_rnd0.as<unsigned>(), ctx->d_round_count.as<unsigned>());
+                       ctx->d_blk_rnd0.as<unsigned>(), ctx->d_round_count.as<unsigned>(),
+                       (ctx->blk_vorder_ok && !test_switch("LT_TEST_GATES_IMAGE_MAJOR")) ? ctx->d_blk_vorder.as<int>() : nullptr);
       };
       if (!extras) {
         gen(0);

@@ -240,6 +240,8 @@ struct lt_ctx {
   DevBuf d_scan_status;      // k_node_prefix: ticket counter + per-tile look-back state
   DevBuf d_tile_order;       // k_score3: tile draw counters
   DevBuf d_tile_list;        // k_score3: tiles by cost class (kTileBuckets lists of cand_cap / 64 entries)
+  DevBuf d_blk_vorder;       // k_gates_ln: the blocks in (neighbour, image) order
+  bool blk_vorder_ok = false;
   DevBuf d_pc_cnt, d_pc_list;  // split scoring: the sweep's lists of tiles by pair count (counters 128 B apart | 8-byte entries)
   DevBuf d_sp_slots, d_sp_cnt, d_sp_ovf, d_sp_pairs, d_sp_desc;  // split scoring: per-tile slots of the pairs that pass the sweep, counts, overflow chunks
   bool score_fused = false;      // the chunk store overflowed once (device flag 7): this context scores with the fused kernel

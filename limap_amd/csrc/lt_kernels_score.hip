@@ -638,6 +638,13 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
     auto drain = [&](bool final) {
       wave_lds_sync();
       if (kSplit) {
+        if (final && a.pc_cnt) {  // the list append's atomic first: its round trip runs under the stores below
+          pc_flush();  // (still pending only if this tile had no window to stage)
+          pc_qb = (tile & (unsigned)(kTileQueues - 1)) * (unsigned)kTileBuckets + (unsigned)pair_bucket((unsigned)(t_cnt + qn));
+          pc_ent = make_uint2(tile, (unsigned)(t_cnt + qn));
+          if (lane == 0) pc_idx = atomicAdd(&a.pc_cnt[pc_qb * 32], 1u);
+          pc_pending = true;
+        }
         const int k0 = min(qn, max(0, a.sp_slot_cap - t_cnt));
         uint4 *dst = a.sp_slots + (size_t)tile * (size_t)a.sp_slot_cap + t_cnt;
         for (int p = lane; p < k0; p += 64) {
@@ -673,13 +680,6 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
           if (a.bucket_cnt)  // word 3 of the tile's class-list entry: k_dense8 gets tile and count with one load
             const_cast<unsigned *>(a.bucket_list)[4 * ent_cur + 3] = (unsigned)t_cnt;
           if (ov_cur != kNoChunk) a.sp_desc[ov_cur] = make_uint2((unsigned)ov_fill, kNoChunk);
-        }
-        if (final && a.pc_cnt) {
-          pc_flush();  // (still pending only if this tile had no window to stage)
-          pc_qb = (tile & (unsigned)(kTileQueues - 1)) * (unsigned)kTileBuckets + (unsigned)pair_bucket((unsigned)t_cnt);
-          pc_ent = make_uint2(tile, (unsigned)t_cnt);
-          if (lane == 0) pc_idx = atomicAdd(&a.pc_cnt[pc_qb * 32], 1u);
-          pc_pending = true;
         }
         wave_lds_sync();
         return;

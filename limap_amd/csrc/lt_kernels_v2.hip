@@ -542,14 +542,28 @@ template <int kW>
 __global__ void __launch_bounds__(64 * kW) LT_GATE_OCC
 k_gates_ln(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRec *__restrict__ pairs_r,
            const unsigned short *__restrict__ tr, const unsigned *__restrict__ run_len,
-           const unsigned *__restrict__ slot_row0, uint2 *__restrict__ st_row, unsigned *__restrict__ blk_surv) {
+           const unsigned *__restrict__ slot_row0, uint2 *__restrict__ st_row, unsigned *__restrict__ blk_surv,
+           const int *__restrict__ vorder) {
+  // vorder (round 6): the blocks in the order (neighbour image, image) -- virtual block v is block vorder[v] -- and the
+  // workgroups of one XCD (dispatched round-robin: blockIdx % 8) take one CONTIGUOUS eighth of that order.  A neighbour's
+  // gate table (80 B x its segments) is what every block reads whole; in image-major order the ~20 blocks that share a
+  // table were spread over the grid, every XCD's L2 saw every table and the kernel's traffic was 2.8 x its algorithmic
+  // bytes.  Now the blocks of a neighbour run on one XCD (its table misses that L2 once), and a workgroup whose next
+  // block has the same neighbour keeps the table in its LDS.  Results do not depend on the order: every block writes its
+  // own survivor list.  nullptr: image-major as in round 5 (LT_TEST_GATES_IMAGE_MAJOR).
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   const int n_parts = a.n_slots / kW;
   const int n_items = a.n_blk * n_parts;
   const int per_wg = (n_items + (int)gridDim.x - 1) / (int)gridDim.x;
-  int item = (int)blockIdx.x * per_wg;
+  unsigned wq = blockIdx.x;
+  if (vorder && (gridDim.x & 7u) == 0u) wq = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  auto blk_of = [&](int it) -> int {  // (uniform) the block of an item
+    const int v = __builtin_amdgcn_readfirstlane(it / n_parts);
+    return vorder ? __builtin_amdgcn_readfirstlane(vorder[v]) : v;
+  };
+  int item = (int)wq * per_wg;
   const int wg_parity = (int)(2u * blockIdx.x >= gridDim.x);  // dispatched in the first / second round over the CUs (a guess)
   (void)wg_parity;
   const int item_end = min(n_items, item + per_wg);
@@ -568,7 +582,7 @@ k_gates_ln(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRe
     len_o = 0;
     row0_o = 0;
     if (it >= item_end) return;
-    const int bb = __builtin_amdgcn_readfirstlane(it / n_parts), pp = it - bb * n_parts;
+    const int bb = blk_of(it), pp = it % n_parts;
     const BlkRec *rp = blk_r + bb;
     const int M1 = rp->M1;
     const int sl = pp * kW + wave;
@@ -580,7 +594,7 @@ k_gates_ln(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRe
   double2 e0, e1, e2, e3, e4;
   auto load_seg = [&](int it) {
     if (it >= item_end) return;
-    const int bb = __builtin_amdgcn_readfirstlane(it / n_parts), pp = it - bb * n_parts;
+    const int bb = blk_of(it), pp = it % n_parts;
     const BlkRec *rp = blk_r + bb;
     const long long g1 = rp->g1;
     const int M1 = rp->M1;
@@ -603,7 +617,7 @@ k_gates_ln(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRe
   unsigned len, row0, len_n, row0_n;  // this item's / the next item's
   unsigned nbq[kRowAhead];
   unsigned base_first;
-  issue_table(__builtin_amdgcn_readfirstlane(item / n_parts));
+  issue_table(blk_of(item));
   load_counts(item, len, row0);
   load_seg(item);
   load_counts(item + 1, len_n, row0_n);
@@ -612,9 +626,11 @@ k_gates_ln(GenArgs a, GenCfg cfg, const BlkRec *__restrict__ blk_r, const PairRe
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (; item < item_end; ++item) {
-    const int b = __builtin_amdgcn_readfirstlane(item / n_parts), part = item - b * n_parts;
-    // (uniform over the workgroup) the block of the next item, -1: the table stays
-    const int nb_blk = (item + 1 < item_end && part == n_parts - 1) ? b + 1 : -1;
+    const int b = blk_of(item), part = item % n_parts;
+    // (uniform over the workgroup) the block of the next item, -1: the table stays -- the same block's next part, or a
+    // block with the same neighbour (the order groups them)
+    int nb_blk = (item + 1 < item_end && part == n_parts - 1) ? blk_of(item + 1) : -1;
+    if (nb_blk >= 0 && blk_r[nb_blk].g2 == blk_r[b].g2 && blk_r[nb_blk].M2 == blk_r[b].M2) nb_blk = -1;
     const int slot = part * kW + wave;
     const unsigned lin = (unsigned)b * (unsigned)a.n_slots + (unsigned)slot;
 #if LT_GATE_PRIO == 3
@@ -1438,7 +1454,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const void *seg_pts, const double *sfm_xyz, int *err_flag, int many_on, int one_on,
                       const long long *group_base, int phase, int ln_slots, const unsigned short *tr,
                       const unsigned *run_len, const unsigned *slot_row0, unsigned *blk_surv, const unsigned *blk_rnd0,
-                      unsigned *round_count) {
+                      unsigned *round_count, const int *blk_vorder) {
   // ln_slots > 0: the line-slot form (k_gates_ln; slots per block = ln_slots, tables tr / run_len / slot_row0) with
   // stage B in rounds of 64 survivors (k_tri_rounds; no extra proposals in this form)
   // phase 0: k_gates + k_tri_rows (no extra proposals).  Extra proposals: phase 1 = k_gates + the COUNTING run of
@@ -1486,10 +1502,10 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
   if (phase != 2 && ln) {
     if (ln_w4)
       hipLaunchKernelGGL((k_gates_ln<4>), grid, block, lds, st, a, cfg, a.blk, a.pairs, a.tr, a.run_len, a.slot_row0, a.st_row,
-                         blk_surv);
+                         blk_surv, blk_vorder);
     else
       hipLaunchKernelGGL((k_gates_ln<8>), grid, block, lds, st, a, cfg, a.blk, a.pairs, a.tr, a.run_len, a.slot_row0, a.st_row,
-                         blk_surv);
+                         blk_surv, blk_vorder);
   } else if (phase != 2) {
     if (lds_segs1 > 0 && lds_segs > 0) hipLaunchKernelGGL((k_gates<true, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);
     else if (lds_segs > 0) hipLaunchKernelGGL((k_gates<false, true>), grid, block, lds, st, a, cfg, a.blk, a.pairs);

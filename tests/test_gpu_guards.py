@@ -40,7 +40,7 @@ def clean_env():
     keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES",
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
             "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TIMER_SAMPLE", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_SCORE_SPLIT",
-            "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS", "LT_TEST_PAIR_SCORE_TERMS", "LT_TEST_NO_PAIR_CLASSES")
+            "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS", "LT_TEST_PAIR_SCORE_TERMS", "LT_TEST_NO_PAIR_CLASSES", "LT_TEST_GATES_IMAGE_MAJOR")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -505,6 +505,22 @@ def test_split_and_fused_scoring_agree(gpu_lib, clean_env, topk, n_nb):
     del os.environ["LT_SCORE_SPLIT"]
     ex_default = _results(run_product(sc, cfg, exhaustive=True))
     _same(ex_default, ex_split)
+
+
+@pytest.mark.parametrize("shape", [(24, 160, 8, 10), (40, 30, 12, 4), (9, 700, 5, 3)])
+def test_stage_a_block_order_does_not_matter(gpu_lib, clean_env, shape):
+    """k_gates_ln takes the blocks in (neighbour, image) order, one contiguous eighth of it per XCD, and keeps a neighbour's
+    gate table in LDS across blocks that share it (round 6); LT_TEST_GATES_IMAGE_MAJOR=1 runs them image-major with a table
+    load per block as in round 5.  Same bits: scenes with one block per workgroup, with many (more blocks than workgroup
+    slots), and with tables of more than 512 segments (workgroups of eight waves)."""
+    n_views, n_segs, nn, topk = shape
+    sc = syn.make_scene(n_views=n_views, n_segs=n_segs, n_neighbors=nn, seed=91, topk=topk)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    new = _results(run_product(sc, cfg, topk=topk))
+    assert new[5]["candidates"] > 300 and new[4]["line_slots"] == 1
+    os.environ["LT_TEST_GATES_IMAGE_MAJOR"] = "1"
+    old = _results(run_product(sc, cfg, topk=topk))
+    _same(old, new)
 
 
 @pytest.mark.parametrize("variant", ["default", "no_smartangle", "no_overlap", "angle_only", "other_thresholds"])
