@@ -120,12 +120,12 @@ def load_pmc(world, default_wl):
     """Counter-derived per-launch numbers (HBM bytes, FP64 VALU flops, LDS bytes) from the rocprofv3 --pmc passes
     committed under profiles/ -- valid for the default 1-GPU workload and ONLY for the device code they were
     collected on (source hash recorded in the file); anything else reports null."""
-    path = os.path.join(ROOT, "profiles", "r05_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r06_pmc.json")
     if not (default_wl and world == 1 and os.path.exists(path)):
         return {}, None
     d = json.load(open(path))
     if d.get("device_source_hash") != device_source_hash():
-        return {}, "profiles/r05_pmc.json was collected on different device code: counter-derived fields are null"
+        return {}, "profiles/r06_pmc.json was collected on different device code: counter-derived fields are null"
     return d.get("kernels", {}), None
 
 
@@ -828,7 +828,7 @@ def main():
                                             "(LT_TIMER_SAMPLE; each event is a ~5 us bubble in the stream)"),
             "roofline_all": roof,
             "roofline_note": pmc_note or ("traffic / valu_f64 / lds: rocprofv3 --pmc passes over this exact device code "
-                                          "(profiles/r05_pmc.json, tools/prof_pmc_json.sh); FP64 VALU peak 78.6 TF"),
+                                          "(profiles/r06_pmc.json, tools/prof_pmc_json.sh); FP64 VALU peak 78.6 TF"),
             "host_ms": {"upload_matches": 1e3 * t_upload, "tail_compute_tracks": 1e3 * t_tail,
                         "merge_shards_device": None if t_merge is None else 1e3 * t_merge},
             "tracks_whole_scene": st_after["tracks"], "merge_note": merge_note,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Counter-derived per-launch numbers for bench.py's roofline block -> gpurun_out/r05_pmc.json (copy to profiles/).
+# Counter-derived per-launch numbers for bench.py's roofline block -> gpurun_out/${TAG:-r06}_pmc.json (copy to profiles/).
 #   HBM bytes     : reads  = 32 x TCC_EA0_RDREQ_32B + 64 x TCC_EA0_RDREQ_64B + 128 x TCC_EA0_RDREQ_128B (the L2's memory-side
 #                   requests by size; calibrated on known byte counts in this code's access patterns --
 #                   profiles/r03_traffic_calib.txt: every pattern, streams and record gathers alike, is served by 128-byte
@@ -49,7 +49,7 @@ out = {"device_source_hash": bench.device_source_hash(),
                  "valu_insts": "SQ_INSTS_VALU (wave-level; x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time) = share of the VALU issue slots)",
                  "lds_active_frac": "SQ_ACTIVE_INST_LDS / SQ_BUSY_CU_CYCLES"},
        "kernels": {}}
-# (round 5: the line-slot form's kernels are what runs on the bench scene; bench.py asks for the stage names)
+# (since round 5: the line-slot form's kernels are what runs on the bench scene; bench.py asks for the stage names)
 alias = {"k_gen_ex_block": "k_gen_exhaustive", "k_gates_ln": "k_gates", "k_tri_rounds": "k_tri_rows", "k_place_rounds": "k_place"}
 for mode in ("matched", "exhaustive"):
     vals = {}
@@ -87,7 +87,8 @@ for mode in ("matched", "exhaustive"):
         a, b = kern["k_gates_ex"], kern["k_tri_ex"]
         kern["k_gen_exhaustive"] = {f: a[f] + b[f] for f in ("hbm_bytes", "valu_flops_f64", "valu_insts") if f in a and f in b}
     out["kernels"][mode] = kern
-json.dump(out, open("gpurun_out/r05_pmc.json", "w"), indent=1)
+import os
+json.dump(out, open("gpurun_out/%s_pmc.json" % os.environ.get("TAG", "r06"), "w"), indent=1)
 for mode, kern in out["kernels"].items():
     for n in ("k_score3", "k_dense8", "k_gates", "k_tri_rows", "k_place", "k_gen_exhaustive"):
         if n in kern:
