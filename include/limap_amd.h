@@ -175,8 +175,8 @@ int lt_compute_tracks(lt_ctx *ctx);
  * nodes' records into page-locked memory -- and returns; the caller may then enqueue the NEXT run (lt_run_device_async);
  * _end waits for the tail's own event, not for that run, and does the host half (graph, union-find, aggregation:
  * global_line_triangulator.cc:234-351) while the device works on the next step.  Needs the device form of the tail
- * (results of the run resident on the device; min_num_outer_edges > 0 is fine for a single context -- the node filter
- * runs on the device -- but not over imported shards); lt_compute_tracks() == _begin + _end. */
+ * (results of the run resident on the device; the node filter of min_num_outer_edges > 0 runs on the device too, over a
+ * single context's run as over imported shards); lt_compute_tracks() == _begin + _end. */
 int lt_compute_tracks_begin(lt_ctx *ctx);
 int lt_compute_tracks_end(lt_ctx *ctx);
 
@@ -243,7 +243,9 @@ int lt_import_images_packed(lt_ctx *ctx, const int32_t *ints, int64_t n_ints, co
  * device copies; the pointers may be device or host memory.  Order of calls: every rank lt_shard_count; lt_shard_build
  * (total_keys = the sum over the ranks on the rank that merges, the own count elsewhere); the other ranks lt_shard_export;
  * the merging rank lt_shard_import once per other rank, then lt_compute_tracks (which needs the device form of the
- * tail; with imported shards: min_num_outer_edges == 0).  lt_shard_import checks on the device that every imported key
+ * tail).  With min_num_outer_edges > 0 the keys of a shard are DIRECTED (source node << kb | target node): the merging rank
+ * runs filterNodeByNumOuterEdges (global_line_triangulator.cc:168-232) over the merged list before it sorts the undirected
+ * form.  lt_shard_import checks on the device that every imported key
  * names two nodes of this scene as (min << kb | max) -- LT_ERR_ARGUMENT otherwise; the node blobs are taken as they are. */
 int lt_shard_node_bytes(void);
 int lt_shard_count(lt_ctx *ctx, int64_t *n_keys);

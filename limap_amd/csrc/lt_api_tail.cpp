@@ -13,11 +13,10 @@ extern "C" {
 // Device half of the tail (lt_kernels_tail.hip): possible when the results of the whole scene are those of the run
 // that is still resident in HBM (one batch, nothing imported, nothing read back yet) and no node filter applies
 // The node filter (min_num_outer_edges > 0, global_line_triangulator.cc:168-232) runs on the device too since round 5
-// (k_outer_filter) -- except over imported shards: it needs the DIRECTED valid edges of every node, and a shard brings
-// undirected keys.  LT_TAIL_HOST=1 forces the host form.
+// (k_outer_filter) -- since round 6 also over imported shards: with the filter on a shard ships DIRECTED keys
+// (source << kb | target) and the filter runs over the merged key list (k_outer_*_keys).  LT_TAIL_HOST=1 forces the host form.
 static bool tail_on_device(const lt_ctx *ctx) {
   if (test_switch("LT_TAIL_HOST") != nullptr) return false;
-  if (ctx->cfg.min_num_outer_edges > 0 && ctx->shard_keys >= 0) return false;
   if (!ctx->inited || ctx->job_mode == 0 || ctx->downloaded || ctx->job_imgs.empty()) return false;
   if (ctx->G <= 0 || ctx->G >= (1ll << 31)) return false;
   // results that live only on the host -- an earlier batch that was read back, imported shards -- rule the device form
@@ -51,13 +50,16 @@ static int tail_count_keys(lt_ctx *ctx, long long *E_out) {
   *E_out = hp[0];
   return LT_OK;
 }
-// keys (min node << kb | max node) of the resident run's valid edges -> d_tail_keys[0 .. E), in node / candidate order
-static void tail_build_keys(lt_ctx *ctx, int kb) {
+// keys (min node << kb | max node; directed: source << kb | target) of the resident run's valid edges -> d_tail_keys[0 .. E),
+// in node / candidate order
+static void tail_build_keys(lt_ctx *ctx, int kb, bool directed = false) {
   launch_tail_keys(ctx->stream, ctx->G, ctx->d_tri_off.as<long long>(), ctx->d_edge_flag.as<unsigned>(),
                    ctx->d_edge_off.as<long long>(), ctx->perm_mode ? ctx->d_st_c.as<CRec>() : ctx->d_cand.as<CRec>(),
                    ctx->d_seg_off.as<long long>(), kb, ctx->d_tail_keys.as<unsigned long long>(),
-                   ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr);
+                   ctx->perm_mode ? ctx->d_place_perm.as<unsigned>() : nullptr, directed ? 1 : 0);
 }
+// a shard's keys are directed iff the node filter is on (every rank of a job has the same configuration)
+static bool shard_keys_directed(const lt_ctx *ctx) { return ctx->cfg.min_num_outer_edges > 0; }
 
 // sorted unique undirected edges + their similarities; the graph nodes' best candidates land in ctx->best_c etc.
 // Two host synchronisations: one for the number of valid edges (it sizes the sort), one at the end; the graph
@@ -105,7 +107,7 @@ static int tail_device_enqueue(lt_ctx *ctx) {
   tp_.E = E;
   if (E <= 0) {
     // no valid edge anywhere: with a node filter every node falls short of min_num_outer_edges
-    if (ctx->cfg.min_num_outer_edges > 0 && !merged) ctx->valid_flags.assign((size_t)G, 0);
+    if (ctx->cfg.min_num_outer_edges > 0) ctx->valid_flags.assign((size_t)G, 0);
     tp_.active = true;
     return LT_OK;
   }
@@ -136,7 +138,7 @@ static int tail_device_enqueue(lt_ctx *ctx) {
   const size_t o_pairs = 64, o_recs = o_pairs + 16 * En, o_nodes = o_recs + tail_rec_bytes() * max_nodes;
   // with the node filter the per-node flags travel in the same block (copied on the context stream in front of the
   // event: tail_device_collect needs no device copy of its own and cannot wait on a run enqueued behind the tail)
-  const bool with_filter = ctx->cfg.min_num_outer_edges > 0 && !merged;
+  const bool with_filter = ctx->cfg.min_num_outer_edges > 0;
   const size_t o_flags = (o_nodes + 4 * max_nodes + 63) / 64 * 64;
   lt_host::HostBlock hb = lt_host::host_block_acquire(o_flags + (with_filter ? (size_t)G : 0));
   if (!hb.p) return fail(ctx, LT_ERR_RUNTIME, "out of host memory for the edge list");
@@ -147,13 +149,38 @@ static int tail_device_enqueue(lt_ctx *ctx) {
   long long *hn = (long long *)base;  // [0] graph nodes, [1] graph edges
   hn[0] = hn[1] = 0;
   if (!merged) tail_build_keys(ctx, kb);
+  // filterNodeByNumOuterEdges over a MERGED key list (the shards shipped directed keys): passes of count / apply until one
+  // changes nothing, then the keys take their undirected form for the sort
+  const unsigned char *d_flags = nullptr;
+  if (with_filter && merged) {
+    ENSURE(ctx, ctx->d_outer_flags, (size_t)G + 64);
+    ENSURE(ctx, ctx->d_tail_pos, 8 * (size_t)(G + 1));  // (free until the scan below: the per-node counters live here)
+    unsigned char *fl = ctx->d_outer_flags.as<unsigned char>();
+    int *d_changed = reinterpret_cast<int *>(fl + (((size_t)G + 15) / 16) * 16);
+    unsigned *counts = ctx->d_tail_pos.as<unsigned>();
+    HIPCHK(ctx, hipMemsetAsync(fl, 1, (size_t)G, st));
+    HIPCHK(ctx, hipMemsetAsync(counts, 0, 4 * (size_t)G, st));
+    for (int round = 0; round < (1 << 20); ++round) {
+      HIPCHK(ctx, hipMemsetAsync(d_changed, 0, 4, st));
+      for (int k = 0; k < 4; ++k)
+        launch_outer_pass_keys(st, E, ctx->d_tail_keys.as<unsigned long long>(), kb, G, counts, ctx->cfg.min_num_outer_edges,
+                               fl, d_changed);
+      int changed = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      if (!changed) break;
+    }
+    launch_keys_undirect(st, E, ctx->d_tail_keys.as<unsigned long long>(), kb);
+    d_flags = fl;
+    tp_.filtered = true;
+    HIPCHK(ctx, hipMemcpyAsync(base + o_flags, fl, (size_t)G, hipMemcpyDeviceToHost, st));
+  }
   if (launch_tail_sort(st, ctx->d_tail_tmp.p, sort_tmp, E, ctx->d_tail_keys.as<unsigned long long>(),
                        ctx->d_tail_skeys.as<unsigned long long>(), end_bit) != 0)
     return fail(ctx, LT_ERR_HIP, "rocprim radix sort failed");
   // filterNodeByNumOuterEdges (:168-232) on the resident run: passes of k_outer_filter until one changes nothing (the
   // flag comes back every four passes; a scene needs a handful)
-  const unsigned char *d_flags = nullptr;
-  if (with_filter) {
+  if (with_filter && !merged) {
     ENSURE(ctx, ctx->d_outer_flags, (size_t)G + 64);
     unsigned char *fl = ctx->d_outer_flags.as<unsigned char>();
     int *d_changed = reinterpret_cast<int *>(fl + (((size_t)G + 15) / 16) * 16);
@@ -317,7 +344,7 @@ int lt_compute_tracks(lt_ctx *ctx) {
   if (ctx->shard_keys >= 0 && !on_device) {
     ctx->shard_keys = -1;
     return fail(ctx, LT_ERR_STATE, "shards were imported on the device (lt_shard_import), but the device form of the tail "
-                                   "is not available (min_num_outer_edges > 0, LT_TAIL_HOST, or results already read back)");
+                                   "is not available (LT_TAIL_HOST, or results already read back)");
   }
   lt_host::SpinPool::get(lt_host::row_workers()).wake();  // the host half of the tail shares its loops with the team
   int rc;
@@ -701,7 +728,9 @@ int lt_compute_tracks(lt_ctx *ctx) {
 // rank's nodes are ONE range [g_lo, g_hi) of the global node index and its per-node results are slices of the arrays the
 // device tail reads.  What rank 0 needs of another rank is therefore
 //   nodes blob  [n x 112 B best candidate | n x 8 B score | n x 8 B source (image index, line) | n x 4 B candidate count]
-//   keys blob   the rank's undirected valid-edge keys (min node << kb | max node: G is global, so is kb), 8 B each,
+//   keys blob   the rank's valid-edge keys, 8 B each: undirected (min node << kb | max node: G is global, so is kb), or --
+//               with the node filter on (min_num_outer_edges > 0) -- directed (source << kb | target), from which rank 0
+//               runs the filter over the whole scene before it brings them to the undirected form,
 // both produced and consumed by copies / kernels on the devices -- no per-image export, no Python loop, no host tail.
 // Protocol: every rank lt_shard_count -> (the counts travel) -> lt_shard_build(total on rank 0) -> the others
 // lt_shard_export into the collective's send buffers -> gather -> rank 0 lt_shard_import per rank -> lt_compute_tracks.
@@ -726,7 +755,7 @@ int lt_shard_build(lt_ctx *ctx, int64_t total_keys) {
   if (total_keys < ctx->shard_own_keys) return fail(ctx, LT_ERR_ARGUMENT, "lt_shard_build: fewer keys than this rank's own");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ENSURE(ctx, ctx->d_tail_keys, 8 * (size_t)std::max<long long>(total_keys, 1));
-  if (ctx->shard_own_keys > 0) tail_build_keys(ctx, bits_for(ctx->G + 1));
+  if (ctx->shard_own_keys > 0) tail_build_keys(ctx, bits_for(ctx->G + 1), shard_keys_directed(ctx));
   HIPCHK(ctx, hipGetLastError());
   ctx->shard_keys = ctx->shard_own_keys;  // imports append behind them
   ctx->shard_keys_cap = total_keys;
@@ -783,7 +812,7 @@ int lt_shard_import(lt_ctx *ctx, int64_t g_lo, int64_t g_hi, const void *nodes_b
     ENSURE(ctx, ctx->d_err, sizeof(int));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_err.p, 0, sizeof(int), st));
     launch_check_keys(st, n_keys, ctx->d_tail_keys.as<unsigned long long>() + ctx->shard_keys, bits_for(ctx->G + 1), ctx->G,
-                      ctx->d_err.as<int>());
+                      ctx->d_err.as<int>(), shard_keys_directed(ctx) ? 1 : 0);
     HIPCHK(ctx, hipMemcpyAsync(&bad, ctx->d_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
   }
   HIPCHK(ctx, hipStreamSynchronize(st));  // the source buffers belong to the caller

@@ -88,12 +88,15 @@ size_t tail_rec_bytes();
 size_t tail_sort_temp_bytes(long long E, int end_bit);
 void launch_tail_keys(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
                       const long long *edge_off, const CRec *cand, const long long *seg_off, int kb,
-                      unsigned long long *keys, const unsigned *perm);
+                      unsigned long long *keys, const unsigned *perm, int directed);
 int launch_tail_sort(hipStream_t st, void *temp, size_t temp_bytes, long long E, const unsigned long long *keys_in,
                      unsigned long long *keys_out, int end_bit);
 void launch_tail_sims(hipStream_t st, long long E, const unsigned long long *skeys, const int *n_tris, const Cand *best_c,
                       const LinkCfg3 &cfg, int kb, double *sims, unsigned *mark, unsigned *keep, const unsigned char *flags);
-void launch_check_keys(hipStream_t st, long long n, const unsigned long long *keys, int kb, long long G, int *bad);
+void launch_check_keys(hipStream_t st, long long n, const unsigned long long *keys, int kb, long long G, int *bad, int directed);
+void launch_outer_pass_keys(hipStream_t st, long long E, const unsigned long long *keys, int kb, long long G, unsigned *counts,
+                            int min_outer, unsigned char *flags, int *changed);
+void launch_keys_undirect(hipStream_t st, long long E, unsigned long long *keys, int kb);
 void launch_outer_filter(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag, const CRec *cand,
                          const long long *seg_off, const unsigned *perm, int min_outer, unsigned char *flags, int *changed);
 void launch_tail_compact(hipStream_t st, long long E, const unsigned long long *skeys, const double *sims,

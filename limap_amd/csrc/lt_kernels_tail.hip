@@ -19,7 +19,9 @@ __global__ void __launch_bounds__(256)
 k_tail_keys(long long G, const long long *__restrict__ tri_off, const unsigned *__restrict__ edge_flag,
             const long long *__restrict__ edge_off, const CRec *__restrict__ cand,
             const long long *__restrict__ seg_off, int kb, unsigned long long *__restrict__ keys,
-            const unsigned *__restrict__ perm) {
+            const unsigned *__restrict__ perm, int directed) {
+  // directed: (source node << kb | target node) -- what a shard ships when the node filter is on (k_outer_*_keys below
+  // count a node's edges into the kept set from them; k_keys_undirect then brings them to the form above)
   const long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (g >= G) return;
   const int lane = lane_id();
@@ -36,7 +38,8 @@ k_tail_keys(long long G, const long long *__restrict__ tri_off, const unsigned *
       const unsigned long long h = (unsigned long long)(seg_off[(int)((unsigned)l.x >> 8)] + (long long)l.y);
       const unsigned long long a = (unsigned long long)g < h ? (unsigned long long)g : h;
       const unsigned long long b = (unsigned long long)g < h ? h : (unsigned long long)g;
-      keys[base + __popcll(m & lanemask_lt())] = (a << kb) | b;  // kb = bits of a node index: fewer sort passes
+      keys[base + __popcll(m & lanemask_lt())] =
+          directed ? (((unsigned long long)g << kb) | h) : ((a << kb) | b);  // kb = bits of a node index: fewer sort passes
     }
     base += __popcll(m);
   }
@@ -71,6 +74,40 @@ k_outer_filter(long long G, const long long *__restrict__ tri_off, const unsigne
     flags[g] = 0;
     *changed = 1;
   }
+}
+
+// The same filter over a list of DIRECTED keys (source << kb | target) -- the merged tail of a multi-GPU job, where the valid
+// edges of the other ranks' nodes exist on this device only as the keys their shards brought (round 6).  One pass = count,
+// for every kept source, its edges into the kept set; then clear the nodes that fall short (and the counters, for the next
+// pass).  Same greatest fixed point as k_outer_filter; a node without any key has no valid edge and falls at once.
+__global__ void __launch_bounds__(256)
+k_outer_count_keys(long long E, const unsigned long long *__restrict__ keys, int kb, const unsigned char *__restrict__ flags,
+                   unsigned *__restrict__ counts) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E) return;
+  const unsigned long long k = keys[i];
+  const unsigned long long a = k >> kb, b = k & ((1ull << kb) - 1ull);
+  if (flags[a] && flags[b]) atomicAdd(&counts[a], 1u);
+}
+__global__ void __launch_bounds__(256)
+k_outer_apply_keys(long long G, unsigned *__restrict__ counts, int min_outer, unsigned char *__restrict__ flags,
+                   int *__restrict__ changed) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const unsigned c = counts[g];
+  counts[g] = 0u;
+  if (flags[g] && c < (unsigned)min_outer) {
+    flags[g] = 0;
+    *changed = 1;
+  }
+}
+__global__ void __launch_bounds__(256)
+k_keys_undirect(long long E, unsigned long long *__restrict__ keys, int kb) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E) return;
+  const unsigned long long k = keys[i];
+  const unsigned long long a = k >> kb, b = k & ((1ull << kb) - 1ull);
+  keys[i] = a < b ? k : ((b << kb) | a);
 }
 
 // similarity of every distinct key (the first of a run of equal keys; the others get -1), and the nodes that enter
@@ -164,10 +201,20 @@ size_t tail_sort_temp_bytes(long long E, int end_bit) {
 
 void launch_tail_keys(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag,
                       const long long *edge_off, const CRec *cand, const long long *seg_off, int kb,
-                      unsigned long long *keys, const unsigned *perm) {
+                      unsigned long long *keys, const unsigned *perm, int directed) {
   if (G > 0)
     hipLaunchKernelGGL(k_tail_keys, dim3((unsigned)((G * 64 + 255) / 256)), dim3(256), 0, st, G, tri_off, edge_flag,
-                       edge_off, cand, seg_off, kb, keys, perm);
+                       edge_off, cand, seg_off, kb, keys, perm, directed);
+}
+void launch_outer_pass_keys(hipStream_t st, long long E, const unsigned long long *keys, int kb, long long G, unsigned *counts,
+                            int min_outer, unsigned char *flags, int *changed) {
+  if (E > 0)
+    hipLaunchKernelGGL(k_outer_count_keys, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, E, keys, kb, flags, counts);
+  if (G > 0)
+    hipLaunchKernelGGL(k_outer_apply_keys, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, G, counts, min_outer, flags, changed);
+}
+void launch_keys_undirect(hipStream_t st, long long E, unsigned long long *keys, int kb) {
+  if (E > 0) hipLaunchKernelGGL(k_keys_undirect, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, E, keys, kb);
 }
 
 int launch_tail_sort(hipStream_t st, void *temp, size_t temp_bytes, long long E, const unsigned long long *keys_in,
@@ -183,17 +230,18 @@ void launch_tail_sims(hipStream_t st, long long E, const unsigned long long *ske
                        cfg, kb, sims, mark, keep, flags);
 }
 // keys that arrive from another rank (lt_shard_import): both node ids must be nodes of this scene and min < max as
-// lt_shard_export writes them -- the similarity kernel indexes the per-node arrays with them
+// lt_shard_export writes them (directed keys -- node filter on -- are source << kb | target: any order, not equal) -- the
+// similarity kernel indexes the per-node arrays with them
 __global__ void k_check_keys(long long n, const unsigned long long *__restrict__ keys, int kb, long long G,
-                             int *__restrict__ bad) {
+                             int *__restrict__ bad, int directed) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned long long k = keys[i];
   const unsigned long long a = k >> kb, b = k & ((1ull << kb) - 1ull);
-  if (a >= (unsigned long long)G || b >= (unsigned long long)G || a >= b) *bad = 1;
+  if (a >= (unsigned long long)G || b >= (unsigned long long)G || (directed ? a == b : a >= b)) *bad = 1;
 }
-void launch_check_keys(hipStream_t st, long long n, const unsigned long long *keys, int kb, long long G, int *bad) {
-  if (n > 0) hipLaunchKernelGGL(k_check_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, keys, kb, G, bad);
+void launch_check_keys(hipStream_t st, long long n, const unsigned long long *keys, int kb, long long G, int *bad, int directed) {
+  if (n > 0) hipLaunchKernelGGL(k_check_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, keys, kb, G, bad, directed);
 }
 void launch_outer_filter(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag, const CRec *cand,
                          const long long *seg_off, const unsigned *perm, int min_outer, unsigned char *flags, int *changed) {

@@ -206,14 +206,12 @@ def merge_shards_device(ctx, node_range, rank, world, device=None, all_ranges=No
         carries what rank 0 needs -- 1 collective.  A rank with more keys than `key_cap` cannot send them: it and rank 0
         both raise after the gather (nobody hangs, the merge fails loudly); choose the capacity from a bound the job
         knows (valid edges per node x nodes of the largest shard).
+    With the node filter on (`min_num_outer_edges > 0`) the keys travel DIRECTED (source, target) and rank 0 runs
+    `filterNodeByNumOuterEdges` over the merged list on its device (round 6; refused before).
     node_range = (g_lo, g_hi): this rank's node range.  Under a gloo group the buffers are host tensors (the copies in
     `lt_shard_export` / `_import` take either).  Returns the number of keys merged on rank 0 (0 elsewhere)."""
     if world == 1:
         return 0
-    # (checked before any collective, on a value every rank shares: nobody is left waiting in a gather)
-    if int(getattr(ctx.cfg, "min_num_outer_edges", 0)) > 0:
-        raise ValueError("merge_shards_device: the node filter (min_num_outer_edges > 0) needs the directed valid edges of "
-                         "every node, a shard brings undirected keys: use merge_shards_on_rank0 for this configuration")
     import torch
     import torch.distributed as dist
     if device is None:

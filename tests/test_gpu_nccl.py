@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q, backend="nccl", merge="host"):
+def _worker(rank, world, port, q, backend="nccl", merge="host", min_outer=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -36,7 +36,7 @@ def _worker(rank, world, port, q, backend="nccl", merge="host"):
     try:
         from limap_amd import _capi, dist as ltdist, synthetic as syn
         sc = syn.make_scene(n_views=14, n_segs=90, n_neighbors=6, seed=21)
-        cfg = syn.default_triangulation_cfg()
+        cfg = syn.default_triangulation_cfg(min_num_outer_edges=min_outer)
         weights = np.array([len(sc.neighbors[int(i)]) for i in sc.img_ids], float)
         mine = ltdist.shard_images(sc.img_ids, rank, world, weights)
         g = ltdist.SceneGather(sc.img_ids, sc.seg_off, rank, world, cdev, weights=weights, force_collective=True)
@@ -89,7 +89,7 @@ def _worker(rank, world, port, q, backend="nccl", merge="host"):
                 ctx.compute_tracks()
                 t = ctx.get_tracks()
                 res = dict(tracks={k: np.asarray(v) for k, v in t.items()}, best=None, imported=sc.n_images - len(mine),
-                           mine=len(mine), n_keys=n_keys)
+                           mine=len(mine), n_keys=n_keys, valid_flags=np.asarray(ctx.get_valid_flags()))
         else:
             ctx.download()
             # device None: merge_shards_on_rank0 picks it from the process group's backend (host tensors under gloo)
@@ -106,13 +106,13 @@ def _worker(rank, world, port, q, backend="nccl", merge="host"):
         dist.destroy_process_group()
 
 
-def _run(world, backend="nccl", merge="host"):
+def _run(world, backend="nccl", merge="host", min_outer=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, merge)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, merge, min_outer)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=300) for _ in procs]
@@ -122,14 +122,14 @@ def _run(world, backend="nccl", merge="host"):
     return sorted(out, key=lambda x: x[0])
 
 
-def _check(out, world, oracle):
+def _check(out, world, oracle, min_outer=0):
     from limap_amd import synthetic as syn
     from helpers import compare_best, compare_tracks, run_oracle
     assert all(ok for _, ok, _ in out)
     res = out[0][2]
     sc = syn.make_scene(n_views=14, n_segs=90, n_neighbors=6, seed=21)
     assert res["imported"] + res["mine"] == sc.n_images
-    O = run_oracle(oracle, sc, syn.default_triangulation_cfg())
+    O = run_oracle(oracle, sc, syn.default_triangulation_cfg(min_num_outer_edges=min_outer))
     if res["best"] is not None:  # (the device merge leaves the other shards' per-node results on the device)
         compare_best(res["best"], O.get_best())
     compare_tracks(res["tracks"], O.ComputeLineTracks())
@@ -162,6 +162,23 @@ def test_two_ranks_device_merge_on_one_gpu_gloo(gpu_lib, oracle):
     _check(out, 2, oracle)
     assert out[0][2]["n_keys"] > 0
 
+
+
+@pytest.mark.parametrize("min_outer", [1, 2])
+def test_two_ranks_device_merge_with_the_node_filter(gpu_lib, oracle, min_outer):
+    """min_num_outer_edges > 0 over imported shards (round 6; refused before): with the filter on a shard ships DIRECTED keys,
+    rank 0 runs filterNodeByNumOuterEdges (global_line_triangulator.cc:168-232) over the merged list on its device, then the
+    tail as usual -- tracks and the per-node valid flags of the oracle's single-process run."""
+    from helpers import run_oracle
+    from limap_amd import synthetic as syn
+    out = _run(2, "gloo", merge="device1", min_outer=min_outer)
+    _check(out, 2, oracle, min_outer)
+    sc = syn.make_scene(n_views=14, n_segs=90, n_neighbors=6, seed=21)
+    n_with = len(run_oracle(oracle, sc, syn.default_triangulation_cfg(min_num_outer_edges=min_outer)).ComputeLineTracks()["off"]) - 1
+    n_without = len(run_oracle(oracle, sc, syn.default_triangulation_cfg()).ComputeLineTracks()["off"]) - 1
+    assert 0 < n_with < n_without  # the filter really removes nodes, and tracks remain
+    flags = out[0][2]["valid_flags"].astype(bool)
+    assert 0 < flags.sum() < len(flags)
 
 
 def test_two_ranks_one_collective_merge_on_one_gpu_gloo(gpu_lib, oracle):
