@@ -212,14 +212,16 @@ static int tail_device_enqueue(lt_ctx *ctx) {
     return fail(ctx, LT_ERR_HIP, "rocprim scan failed");
   if (hb.pinned) {  // the kernels write across PCIe: the host needs no size before the copies
     launch_tail_compact(st, E, ctx->d_tail_skeys.as<unsigned long long>(), ctx->d_tail_sims.as<double>(),
-                        ctx->d_tail_keep.as<unsigned>(), ctx->d_tail_kpos.as<long long>(), base + o_pairs, hn + 1);
+                        ctx->d_tail_keep.as<unsigned>(), ctx->d_tail_kpos.as<long long>(), base + o_pairs, hn + 1,
+                        ctx->d_tail_pos.as<long long>(), kb);
     launch_tail_gather(st, G, ctx->d_tail_mark.as<unsigned>(), ctx->d_tail_pos.as<long long>(), ctx->d_best_c.as<Cand>(),
                        ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(), base + o_recs, (int *)(base + o_nodes), hn);
   } else {  // no page-locked memory: pack on the device, copy the bounds
     ENSURE(ctx, ctx->d_tail_recs, 16 * En + tail_rec_bytes() * max_nodes + 64); ENSURE(ctx, ctx->d_tail_nodes, 4 * max_nodes);
     char *dp = (char *)ctx->d_tail_recs.p;
     launch_tail_compact(st, E, ctx->d_tail_skeys.as<unsigned long long>(), ctx->d_tail_sims.as<double>(),
-                        ctx->d_tail_keep.as<unsigned>(), ctx->d_tail_kpos.as<long long>(), dp, (long long *)ctx->d_tail_keys.p);
+                        ctx->d_tail_keep.as<unsigned>(), ctx->d_tail_kpos.as<long long>(), dp, (long long *)ctx->d_tail_keys.p,
+                        ctx->d_tail_pos.as<long long>(), kb);
     launch_tail_gather(st, G, ctx->d_tail_mark.as<unsigned>(), ctx->d_tail_pos.as<long long>(), ctx->d_best_c.as<Cand>(),
                        ctx->d_best_score.as<double>(), ctx->d_best_src.as<int>(), dp + 16 * En, ctx->d_tail_nodes.as<int>(),
                        nullptr);
@@ -260,7 +262,7 @@ static int tail_device_collect(lt_ctx *ctx, AddEdge &&add_edge) {
   } rel{tp_.hb};
   tp_.hb = lt_host::HostBlock();
   const size_t max_nodes = tp_.max_nodes, o_pairs = tp_.o_pairs, o_recs = tp_.o_recs, o_nodes = tp_.o_nodes;
-  const int kb = tp_.kb;
+  (void)tp_.kb;
   char *base = (char *)rel.b.p;
   long long *hn = (long long *)base;
   const unsigned long long *hpairs = (const unsigned long long *)(base + o_pairs);
@@ -272,11 +274,18 @@ static int tail_device_collect(lt_ctx *ctx, AddEdge &&add_edge) {
   const long long Nm = hn[0], Ne = hn[1];
   if (Nm < 0 || (size_t)Nm > max_nodes || Ne < 0 || Ne > E)
     return fail(ctx, LT_ERR_RUNTIME, "internal: graph size out of range");
-  const unsigned long long mask = (1ull << kb) - 1ull;
+  // graph nodes in edge order (base/graph.cc:57-87): the edges name their endpoints by RANK among the graph's nodes (the
+  // order of `nodes` / `recs` below), so the node map has one entry per graph node, not per node of the scene
+  const int *nodes = (const int *)(base + o_nodes);
+  std::vector<int> &kmap = ctx->tail_kmap;  // rank -> graph node
+  kmap.assign((size_t)Nm, -1);
   for (long long i = 0; i < Ne; ++i) {  // distinct keys with score != 0 (:284-285), in std::set order
     double sim;
     std::memcpy(&sim, &hpairs[2 * i + 1], 8);
-    add_edge((long long)(hpairs[2 * i] >> kb), (long long)(hpairs[2 * i] & mask), sim);
+    const unsigned long long ka = hpairs[2 * i] >> 32, kb2 = hpairs[2 * i] & 0xFFFFFFFFull;
+    if (ka >= (unsigned long long)Nm || kb2 >= (unsigned long long)Nm)
+      return fail(ctx, LT_ERR_RUNTIME, "internal: graph edge names a node outside the graph");
+    add_edge(kmap[(size_t)ka], (long long)nodes[ka], kmap[(size_t)kb2], (long long)nodes[kb2], sim);
   }
   lap("graph");
   struct Rec {
@@ -286,7 +295,6 @@ static int tail_device_collect(lt_ctx *ctx, AddEdge &&add_edge) {
   };
   static_assert(sizeof(Rec) == 128, "TailRec layout");
   const Rec *recs = (const Rec *)(base + o_recs);
-  const int *nodes = (const int *)(base + o_nodes);
   // the same records once more in graph-node order (what the union-find and the aggregation read: the G-entry tables are
   // 100 MB at a million nodes, every access a miss)
   const size_t n_graph = ctx->tail_gnode.size();
@@ -301,7 +309,7 @@ static int tail_device_collect(lt_ctx *ctx, AddEdge &&add_edge) {
       ctx->best_src2[2 * g] = ctx->img_ids[recs[k].src[0]];
       ctx->best_src2[2 * g + 1] = recs[k].src[1];
       ctx->has_best[g] = 1;
-      const int gi = ctx->tail_gmap[(size_t)g];
+      const int gi = kmap[(size_t)k];
       if (gi >= 0) {
         ctx->tail_nimg[(size_t)gi] = ctx->h_node_img[g];
         ctx->tail_cscore[(size_t)gi] = recs[k].score;
@@ -372,7 +380,8 @@ int lt_compute_tracks(lt_ctx *ctx) {
   std::vector<int> &gmap = ctx->tail_gmap;            // global node -> graph node
   std::vector<long long> &gnode = ctx->tail_gnode;    // graph node -> global node
   std::vector<GEdge> &ge = ctx->tail_ge;
-  if ((long long)gmap.size() != G) gmap.assign((size_t)G, -1);
+  // (the device form names the graph's nodes by rank: it needs no map over the scene's nodes)
+  if (!on_device && (long long)gmap.size() != G) gmap.assign((size_t)G, -1);
   gnode.clear();
   ge.clear();
   auto find_or_create = [&](long long g) {
@@ -394,7 +403,18 @@ int lt_compute_tracks(lt_ctx *ctx) {
       ctx->valid_flags.assign((size_t)G, 1);
       if ((rc = tail_device_enqueue(ctx))) return rc;
     }
-    if ((rc = tail_device_collect(ctx, add_edge))) return rc;
+    auto add_edge_ranked = [&](int &ma, long long ga, int &mb, long long gb, double sim) {
+      if (ma < 0) {
+        ma = (int)gnode.size();
+        gnode.push_back(ga);
+      }
+      if (mb < 0) {
+        mb = (int)gnode.size();
+        gnode.push_back(gb);
+      }
+      ge.push_back(GEdge{sim, ma, mb});
+    };
+    if ((rc = tail_device_collect(ctx, add_edge_ranked))) return rc;
     lap("device edges+sims");
   } else {
   const int min_outer = ctx->cfg.min_num_outer_edges;
@@ -715,7 +735,8 @@ int lt_compute_tracks(lt_ctx *ctx) {
       }
     });
   }
-  for (long long g : gnode) gmap[(size_t)g] = -1;  // leave the scratch map clean
+  if (!on_device)
+    for (long long g : gnode) gmap[(size_t)g] = -1;  // leave the scratch map clean
   lap("tracks+aggregate");
   ctx->tracks_done = true;
   ctx->timers[10] = now_ms() - t0;

@@ -322,7 +322,8 @@ struct lt_ctx {
   } tail_pend;
   DevBuf d_outer_flags;     // k_outer_filter: one byte per node (+ the "changed" word behind them)
   hipEvent_t ev_tail = nullptr;
-  std::vector<int> tail_gmap;         // global node -> graph node, -1 outside a call
+  std::vector<int> tail_gmap;         // global node -> graph node, -1 outside a call (host form of the tail)
+  std::vector<int> tail_kmap;         // device form: rank among the graph's nodes -> graph node
   std::vector<long long> tail_gnode;  // graph node -> global node
   std::vector<GEdge> tail_ge, tail_ge2;
   std::vector<int> tail_img_tmp;

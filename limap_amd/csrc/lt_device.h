@@ -100,7 +100,8 @@ void launch_keys_undirect(hipStream_t st, long long E, unsigned long long *keys,
 void launch_outer_filter(hipStream_t st, long long G, const long long *tri_off, const unsigned *edge_flag, const CRec *cand,
                          const long long *seg_off, const unsigned *perm, int min_outer, unsigned char *flags, int *changed);
 void launch_tail_compact(hipStream_t st, long long E, const unsigned long long *skeys, const double *sims,
-                         const unsigned *keep, const long long *kpos, void *out_pairs, long long *n_out);
+                         const unsigned *keep, const long long *kpos, void *out_pairs, long long *n_out, const long long *npos,
+                         int kb);
 void launch_tail_gather(hipStream_t st, long long G, const unsigned *mark, const long long *pos, const Cand *best_c,
                         const double *best_score, const int *best_src2, void *recs, int *nodes, long long *n_out);
 

@@ -144,16 +144,21 @@ k_tail_sims(long long E, const unsigned long long *__restrict__ skeys, const int
   }
 }
 
-// the graph's edges (distinct keys with a non-zero similarity), in key order, packed into (key, sim) pairs -- the
-// destination may be page-locked host memory
+// the graph's edges (distinct keys with a non-zero similarity), in key order, packed into (pair, sim) entries -- the
+// destination may be page-locked host memory.  pair = (rank of node a among the graph's nodes) << 32 | (rank of node b):
+// the positions k_tail_gather writes the two nodes' records to (npos: the scan of `mark`).  The host then builds the graph
+// over tables of the graph's size (round 6; with global node ids its node map had one entry per node of the SCENE and every
+// lookup missed the cache: 0.43 ms of config 3's tail).
 __global__ void __launch_bounds__(256)
 k_tail_compact(long long E, const unsigned long long *__restrict__ skeys, const double *__restrict__ sims,
                const unsigned *__restrict__ keep, const long long *__restrict__ kpos, double2 *__restrict__ out,
-               long long *__restrict__ n_out) {
+               long long *__restrict__ n_out, const long long *__restrict__ npos, int kb) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) *n_out = kpos[E];
   if (i >= E || !keep[i]) return;
-  out[kpos[i]] = double2{__longlong_as_double((long long)skeys[i]), sims[i]};
+  const unsigned long long key = skeys[i];
+  const unsigned long long a = (unsigned long long)npos[key >> kb], b = (unsigned long long)npos[key & ((1ull << kb) - 1ull)];
+  out[kpos[i]] = double2{__longlong_as_double((long long)((a << 32) | b)), sims[i]};
 }
 
 // the graph nodes' results, packed in ascending node order: 128-byte records (best candidate 112 B, support score,
@@ -250,10 +255,11 @@ void launch_outer_filter(hipStream_t st, long long G, const long long *tri_off, 
                        seg_off, perm, min_outer, flags, changed);
 }
 void launch_tail_compact(hipStream_t st, long long E, const unsigned long long *skeys, const double *sims,
-                         const unsigned *keep, const long long *kpos, void *out_pairs, long long *n_out) {
+                         const unsigned *keep, const long long *kpos, void *out_pairs, long long *n_out, const long long *npos,
+                         int kb) {
   if (E > 0)
     hipLaunchKernelGGL(k_tail_compact, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, E, skeys, sims, keep, kpos,
-                       reinterpret_cast<double2 *>(out_pairs), n_out);
+                       reinterpret_cast<double2 *>(out_pairs), n_out, npos, kb);
 }
 
 void launch_tail_gather(hipStream_t st, long long G, const unsigned *mark, const long long *pos, const Cand *best_c,
