@@ -28,6 +28,20 @@ for k in range(n):
     cfg["fullscore_th"] = float(rng.choice([1.0, 2.0]))
     cfg["max_valid_conns"] = int(rng.choice([1000, 4]))
     cfg["add_halfpix"] = bool(rng.integers(0, 2))
+    # round 6: the 2D linker's terms and thresholds (pair_score_fused: which q binds, the gate bands), the node filter
+    rng2 = np.random.default_rng([seed0 + k, 6])
+    l2 = cfg["linker2d_config"]
+    l2["th_angle"] = float(rng2.choice([3.0, 5.0, 8.0]))
+    l2["th_perp"] = float(rng2.choice([1.0, 2.0, 4.0]))
+    l2["th_overlap"] = float(rng2.choice([0.02, 0.05, 0.2]))
+    l2["score_th"] = float(rng2.choice([0.3, 0.5, 0.7]))
+    if rng2.integers(0, 4) == 0:
+        l2["use_smartangle"] = False
+    if rng2.integers(0, 6) == 0:
+        l2["use_perp"] = False
+    cfg["linker3d_config"]["score_th"] = float(rng2.choice([0.4, 0.5, 0.6]))
+    if rng2.integers(0, 5) == 0:
+        cfg["min_num_outer_edges"] = int(rng2.integers(1, 3))
     ex = bool(k % 3 == 2)
     try:
         T = run_product(sc, cfg, exhaustive=ex)
