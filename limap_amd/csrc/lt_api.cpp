@@ -372,7 +372,10 @@ ScoreCfg make_score(const lt_ctx *ctx) {
     return true;
   };
   const bool b3 = band(s.l3.score_th, &s.q3_lo, &s.q3_hi), b2 = band(s.l2.score_th, &s.q2_lo, &s.q2_hi);
-  s.fast = (b3 && b2 && !s.l2.use_innerseg && !test_switch("LT_TEST_PAIR_SCORE_TERMS")) ? 1 : 0;
+  // (positive thresholds: every q = value / (threshold x multiplier) is then >= 0 or NaN, which is what the bands assume)
+  const bool pos = s.l3.th_angle > 0.0 && s.l3.th_scaleinv > 0.0 && s.l2.th_angle > 0.0 && s.l2.th_perp > 0.0 &&
+                   s.l2.th_smartangle > 0.0 && s.l2.th_smartangle <= s.l2.th_angle && s.l2.th_smartoverlap > s.l2.th_overlap;
+  s.fast = (b3 && b2 && pos && !s.l2.use_innerseg && !test_switch("LT_TEST_PAIR_SCORE_TERMS")) ? 1 : 0;
   return s;
 }
 
