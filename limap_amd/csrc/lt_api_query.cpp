@@ -397,6 +397,7 @@ int lt_get_timers(lt_ctx *ctx, double out[24]) {
   ctx->timers[16] = (double)ctx->stat_survivors;
   ctx->timers[20] = (ctx->ran && ctx->job_mode == 1 && ctx->rows_ln) ? 1.0 : 0.0;  // stage A ran in the line-slot form
   ctx->timers[19] = ctx->score_fused ? 1.0 : 0.0;  // the split scoring form's pair store overflowed once: fused from then on
+  ctx->timers[21] = ctx->score_two_kernels ? 1.0 : 0.0;  // k_score_q raised device flag 8 once: sweep + k_dense8 from then on
   std::memcpy(out, ctx->timers, sizeof(ctx->timers));
   return LT_OK;
 }

@@ -226,6 +226,20 @@ int finish_run(lt_ctx *ctx) {
     ctx->ex_retry_depth = 0;
     return rc2;
   }
+  if (derr == 8) {
+    // k_score_q found workgroups of one queue on different XCDs, or a wait for a swept tile timed out (the GPU shared with
+    // another persistent kernel): this context scores in the two-kernel form from now on, the run is repeated
+    if (ctx->score_two_kernels)
+      return fail(ctx, LT_ERR_RUNTIME, "internal: device flag 8 outside the one-kernel scoring form");
+    ctx->score_two_kernels = true;
+    if (ctx->in_run_async) return LT_OK;
+    const int depth = ctx->ex_retry_depth;
+    ctx->ex_retry_depth = depth + 1;
+    int rc2 = lt_run_device_async(ctx);
+    if (!rc2) rc2 = finish_run(ctx);
+    ctx->ex_retry_depth = depth;
+    return rc2;
+  }
   if (derr == 7) {
     // the chunk store of the split scoring form did not hold the pairs that passed the sweep: this context scores with the
     // fused kernel from now on (no store), the run is repeated
@@ -854,7 +868,9 @@ int lt_run_device_async(lt_ctx *ctx) {
                   split ? ctx->d_sp_slots.p : nullptr, sp_slot_cap, ctx->d_sp_cnt.as<unsigned>(),
                   ctx->d_sp_ovf.as<unsigned>(), ctx->d_sp_pairs.p, ctx->d_sp_desc.p, sp_chunks, sampled ? ev[5] : nullptr,
                   node_rec_valid ? ctx->d_node_rec.p : nullptr, pair_classes ? ctx->d_pc_cnt.as<unsigned>() : nullptr,
-                  pair_classes ? ctx->d_pc_list.p : nullptr, tile_cap);
+                  pair_classes ? ctx->d_pc_list.p : nullptr, tile_cap,
+                  /*one_kernel=*/test_switch("LT_SCORE_ONE_KERNEL") && !ctx->score_two_kernels &&
+                      ctx->n_img < (1 << 18) /* k_score_q's pair entries carry the neighbour word in 26 bits */);
     if (C_bound <= 0 && sampled) HIPCHK(ctx, hipEventRecord(ev[5], st));  // nothing to score: no kernel carries the event
   }
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));

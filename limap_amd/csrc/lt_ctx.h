@@ -244,6 +244,7 @@ struct lt_ctx {
   bool blk_vorder_ok = false;
   DevBuf d_pc_cnt, d_pc_list;  // split scoring: the sweep's lists of tiles by pair count (counters 128 B apart | 8-byte entries)
   DevBuf d_sp_slots, d_sp_cnt, d_sp_ovf, d_sp_pairs, d_sp_desc;  // split scoring: per-tile slots of the pairs that pass the sweep, counts, overflow chunks
+  bool score_two_kernels = false;  // k_score_q raised device flag 8 once: this context scores with k_score3<split> + k_dense8
   bool score_fused = false;      // the chunk store overflowed once (device flag 7): this context scores with the fused kernel
   DevBuf d_base_bl;          // exclusive prefix of cnt_bl over the neighbour blocks of a node
   // matched fast path: the candidate records stay in the staging lists of stage B; k_place writes only

@@ -69,13 +69,23 @@ __global__ void __launch_bounds__(256)
 k_cand_meta(long long G, const unsigned *__restrict__ cand_node, const long long *__restrict__ tri_off,
             const int *__restrict__ node_img, const long long *__restrict__ nb_off, CandMeta *__restrict__ meta,
             unsigned *__restrict__ draw, unsigned *__restrict__ bucket_cnt, unsigned *__restrict__ bucket_list,
-            unsigned bucket_cap, const uint4 *__restrict__ node_rec, unsigned *__restrict__ pc_cnt) {
+            unsigned bucket_cap, const uint4 *__restrict__ node_rec, unsigned *__restrict__ pc_cnt,
+            uint2 *__restrict__ fifo, unsigned fifo_cap) {
   // grid-stride over the exact candidate count tri_off[G]; the host may only know an upper bound
   const long long C = tri_off[G];
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (pc_cnt && i < kTileQueues * kTileBuckets) pc_cnt[i * 32] = 0;  // the sweep's pair-count lists
   if (i < 2 * kTileQueues + 1) draw[i * 32] = 0;  // 128 bytes apart; behind the draw queues: the split form's overflow-chunk counter and k_dense8's eight claim counters
+  if (fifo) {
+    // k_score_q: behind those the XCD seen by each queue's first workgroup (none yet) and the queues' sweep-claim counters;
+    // the FIFOs of finished tiles (queue q: fifo[q * fifo_cap ...], one entry per tile of the queue) start empty
+    if (i >= 2 * kTileQueues + 1 && i < 3 * kTileQueues + 1) draw[i * 32] = 0xFFFFFFFFu;
+    if (i >= 3 * kTileQueues + 1 && i < 4 * kTileQueues + 1) draw[i * 32] = 0;
+    const long long per = ((C + 63) / 64 + kTileQueues - 1) / kTileQueues;
+    for (long long j = i; j < per * kTileQueues; j += stride)
+      fifo[(size_t)(j / per) * fifo_cap + (size_t)(j % per)] = make_uint2(0xFFFFFFFFu, 0u);
+  }
   const long long C_up = (C + 63) & ~63ll;  // whole waves take part in the tile's reduction
   for (; i < C_up; i += stride) {
     unsigned n = 0, w_lo = 0, w_hi = 0;
@@ -1229,6 +1239,599 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 6, second half: the scoring stage as ONE persistent kernel -- k_score_q.
+// ---------------------------------------------------------------------------------------------
+// The two kernels above run one after the other: 41 us in which every wave of the chip waits on window gathers (VALU issue
+// 0.44) followed by 53 us in which every wave runs pair_score rounds behind LDS maxima and barriers (0.45), and k_dense8
+// fetches the records of every pair a second time from another XCD's side of the chip.  Here a workgroup of four waves
+// ALTERNATES between the two roles:
+//   sweep role   -- its four waves sweep one tile each (the code of k_score3<split>: window in LDS in single precision, two
+//                   guards, the passing pairs to the tile's slot) and PUBLISH the finished tile as (tile, pair count) in the
+//                   FIFO of their XCD;
+//   dense role   -- the four waves together take a unit of T consecutive FIFO entries (the code of k_dense8: one list of
+//                   pairs over the unit's tiles, pair_score one pair per lane, per-image maxima in LDS, ordered sums).
+// A workgroup consumes about as many tiles as it has produced (4 per pass against T per unit), so the FIFO stays a few
+// entries deep: the pair entries and both records of a pair are still in the XCD's L2 when the dense role asks for them,
+// and the four workgroups of a CU are in different roles at any time -- the gathers of one hide behind the arithmetic of
+// another.  After its last pass a workgroup drains the FIFO until every unit of its XCD is claimed.
+//   Producer and consumer of a tile are ALWAYS on the same XCD (queue x = blockIdx.x % 8, the dispatch order of the
+// hardware; checked against the XCC_ID register, device flag 8 sends the context back to the two-kernel form): the pair
+// entries travel through that XCD's L2 with plain stores and loads, only the 8-byte FIFO entry is a device-scope store /
+// load.  Nothing waits on a consumer: the slots of all tiles exist up front, a producer never blocks, so a consumer's
+// wait for a FIFO entry is bounded by the sweep of that tile (and by kQSpinMax, against a hang if the assumption about the
+// dispatch order ever failed).  Same bits as the two-kernel form and as the fused kernel (tests/test_gpu_guards.py).
+//   MEASURED (profiles/r06_score_experiments.txt, items 8-10): 94.7-96.6 us for the stage against 94.1-95.6 in the two-kernel
+// form at 100 x 500, 0.664 against 0.649 ms at config 3; L2 memory-side traffic 172 against 169 MB (a pass of one XCD's 512
+// waves stages 6 MB of records, more than its 4 MB of L2: the records are gone again when the dense role asks for them);
+// VALU instructions + 8 %.  The workgroups stay in step -- all sweep, then all evaluate -- because they start together and
+// a pass takes about as long everywhere.  NOT THE DEFAULT: LT_SCORE_ONE_KERNEL=1 (a test switch) selects it.
+constexpr int kErrXcdMap = 8;   // device error flag: workgroups of one queue ran on different XCDs, or a FIFO wait timed out
+constexpr int kQHdrBytes = 64 + 2 * kTileBuckets * 4;  // [0] the claimed unit, [1] abort, [2], [3] the next pass's first entry; from [16]: class sizes and their inclusive prefix
+constexpr int kQCap = 352;       // the sweep role's pair queue (entries of 8 bytes; emptied into the tile's slot from kQCap - 256 on)
+constexpr int kQSweepWaveBytes = kWin * 48 + kQCap * 8 + 64 * 4;
+constexpr int kQPreBytes = 16 + 64 * 4 + 128 * 4;  // per wave, behind the role area: the NEXT tile's list entry, record index per lane, first window chunk's record indices
+constexpr unsigned kFifoEmpty = 0xFFFFFFFFu;
+constexpr int kQSpinMax = 1 << 20;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+static __device__ __forceinline__ uint2 fifo_load(const uint2 *p) {
+  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+  return make_uint2((unsigned)v, (unsigned)(v >> 32));
+}
+static __device__ __forceinline__ void fifo_store(uint2 *p, unsigned tile, unsigned cnt) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)tile | ((unsigned long long)cnt << 32),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static __device__ __forceinline__ unsigned &q_word3(uint4 *e) { return reinterpret_cast<unsigned *>(e)[3]; }
+// first load level of a tile: prologue record, record index, the record indices of the first window chunk -- loaded while
+// the dense role's sums of the unit before it run (k_score_q), or at the start of the tile
+struct QFirst {
+  uint4 hdr;  // the tile's class-list entry: tile, first and end position of its window
+  CandMeta mt;
+  unsigned p_i, w0, w1;
+};
+template <bool kPerm>
+static __device__ __forceinline__ QFirst q_first_level(const Score3Args &a, const uint4 hdr, const long long C, const int lane) {
+  QFirst f;
+  f.hdr = hdr;
+  f.mt = CandMeta{0u, 0u, 0u, 0u};
+  f.p_i = 0; f.w0 = 0; f.w1 = 0;
+  const long long tpos = (long long)hdr.x * 64 + lane;
+  if (tpos < C) {
+    f.mt = a.meta[tpos];
+    f.p_i = kPerm ? a.perm[tpos] : (unsigned)tpos;
+  }
+  if (kPerm && hdr.z > hdr.y) {
+    const unsigned w = (hdr.z - hdr.y) < (unsigned)kWin ? (hdr.z - hdr.y) : (unsigned)kWin;
+    if ((unsigned)lane < w) f.w0 = a.perm[(size_t)hdr.y + lane];
+    if ((unsigned)lane + 64u < w) f.w1 = a.perm[(size_t)hdr.y + 64 + lane];
+  }
+  return f;
+}
+// sweep role: one wave, one tile (k_score3<true, false, kPerm, true> without the schedule around it)
+template <bool kPerm>
+static __device__ __forceinline__ void q_sweep_tile(const Score3Args &a, const ScoreCfg &cfg, const double scaleinv_guard2,
+                                                    unsigned char *smem_raw, const QFirst &fl, const long long C,
+                                                    const int lane, uint2 *fifo, unsigned *q_alloc, bool &ch_dead) {
+  const uint4 hdr = fl.hdr;
+  float4 *W4 = reinterpret_cast<float4 *>(smem_raw);
+  uint2 *queue2 = reinterpret_cast<uint2 *>(smem_raw + (size_t)kWin * 48);
+  unsigned *reci_l = reinterpret_cast<unsigned *>(smem_raw + (size_t)kWin * 48 + (size_t)kQCap * 8);
+  const unsigned tile = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.x);
+  const unsigned h_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.y);
+  const unsigned h_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.z);
+  const bool h_bounds = h_hi > h_lo;
+  const long long i0 = (long long)tile * 64;
+  const long long tpos = i0 + lane;
+  const bool active = tpos < C;
+  LT_TRACE_MARK(2, tile, 0);
+  const CandMeta p_mt = fl.mt;
+  const unsigned p_i = fl.p_i, w0src = fl.w0, w1src = fl.w1;
+  const long long i = active ? (long long)p_i : 0;
+  long long off = 0;
+  int n = 0, sloti = -1;
+  double six = 0, siy = 0, siz = 0, eix = 0, eiy = 0, eiz = 0, gs2 = 0, ge2 = 0;
+  float dixf = 0, diyf = 0, dizf = 0;
+  if (active) {
+    off = ((long long)p_mt.off_hi << 32) | (long long)p_mt.off_lo;
+    n = (int)p_mt.n;
+    const CRec &ci = a.cand[i];
+    dixf = (float)ci.dir[0]; diyf = (float)ci.dir[1]; dizf = (float)ci.dir[2];
+    sloti = ci.nb_slot;  // (the whole word: candidates of one node share the image, so equal slots = equal words)
+    six = ci.s[0]; siy = ci.s[1]; siz = ci.s[2];
+    eix = ci.e[0]; eiy = ci.e[1]; eiz = ci.e[2];
+    const double zs = ci.depth[0] + kEps, ze = ci.depth[1] + kEps;
+    gs2 = (zs > 0.0) ? scaleinv_guard2 * zs * zs : 1e300;
+    ge2 = (ze > 0.0) ? scaleinv_guard2 * ze * ze : 1e300;
+  }
+  reci_l[lane] = (unsigned)i;
+  const double ox = readlane_f64(six, 0), oy = readlane_f64(siy, 0), oz = readlane_f64(siz, 0);
+  const float sixf = (float)(six - ox), siyf = (float)(siy - oy), sizf = (float)(siz - oz);
+  const float eixf = (float)(eix - ox), eiyf = (float)(eiy - oy), eizf = (float)(eiz - oz);
+  float ri = fmaxf(fmaxf(fmaxf(fabsf(sixf), fabsf(siyf)), fabsf(sizf)), fmaxf(fmaxf(fabsf(eixf), fabsf(eiyf)), fabsf(eizf)));
+  if (!active) ri = 0.0f;
+  const double gs = sqrt(gs2), ge = sqrt(ge2);
+  const float cosf_guard = cfg.cos_guard > -1.0 ? (float)(cfg.cos_guard - 2e-6) : -2.0f;
+  long long lo, hi;
+  if (h_bounds) {
+    lo = (long long)h_lo; hi = (long long)h_hi;
+  } else {
+    const int last = (int)((C - i0) < 64 ? (C - i0) : 64) - 1;
+    lo = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)off);
+    hi = (long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(off + n), last);
+  }
+  int qn = 0, t_cnt = 0, ov_fill = 0;
+  unsigned ov_cur = kNoChunk;
+  unsigned f_idx = 0;  // lane 0: this tile's place in the FIFO
+  auto ch_alloc = [&]() -> unsigned {
+    unsigned id = 0;
+    if (lane == 0) id = atomicAdd(&a.sp_counters[0], 1u);
+    id = (unsigned)__builtin_amdgcn_readfirstlane((int)id);
+    if (id >= a.sp_chunk_cap) {
+      ch_dead = true;
+      if (lane == 0 && a.err_flag) atomicCAS(a.err_flag, 0, kErrPairChunks);
+      return kNoChunk;
+    }
+    return id;
+  };
+  auto drain = [&](const bool final) {
+    wave_lds_sync();
+    if (final && lane == 0) f_idx = atomicAdd(q_alloc, 1u);  // its round trip runs under the stores below
+    const int k0 = min(qn, max(0, a.sp_slot_cap - t_cnt));
+    uint4 *dst = a.sp_slots + (size_t)tile * (size_t)a.sp_slot_cap + t_cnt;
+    for (int p = lane; p < k0; p += 64) {
+      const uint2 e = queue2[p];
+      dst[p] = uint4{e.x, reci_l[e.y & 63u], e.y, 0u};
+    }
+    int done = k0;
+    while (done < qn && !ch_dead) {
+      if (ov_cur == kNoChunk || ov_fill == kChunkCap) {
+        const unsigned nxt = ch_alloc();
+        if (ch_dead) break;
+        if (lane == 0) {
+          // the chain is kept IN BAND (word 3 of an entry is free): first chunk in entry 0 of the tile's slot, next chunk and
+          // fill in entries 0 and 1 of a chunk.  sp_ovf / sp_desc pack many tiles / chunks into a cache line that a consumer's
+          // CU may hold from an earlier read -- these lines belong to one tile and are read after it is published, once.
+          if (ov_cur == kNoChunk) q_word3(a.sp_slots + (size_t)tile * (size_t)a.sp_slot_cap) = nxt;
+          else {
+            q_word3(a.sp_pairs + (size_t)ov_cur * kChunkCap) = nxt;
+            q_word3(a.sp_pairs + (size_t)ov_cur * kChunkCap + 1) = (unsigned)ov_fill;
+          }
+        }
+        ov_cur = nxt;
+        ov_fill = 0;
+      }
+      const int k = min(qn - done, kChunkCap - ov_fill);
+      uint4 *od = a.sp_pairs + (size_t)ov_cur * kChunkCap + ov_fill;
+      for (int p = lane; p < k; p += 64) {
+        const uint2 e = queue2[done + p];
+        od[p] = uint4{e.x, reci_l[e.y & 63u], e.y, 0u};
+      }
+      ov_fill += k;
+      done += k;
+    }
+    t_cnt += qn;
+    qn = 0;
+    if (final) {
+      if (lane == 0) {
+        a.sp_cnt[tile] = (unsigned)t_cnt;
+        if (ov_cur != kNoChunk) {
+          q_word3(a.sp_pairs + (size_t)ov_cur * kChunkCap) = kNoChunk;
+          q_word3(a.sp_pairs + (size_t)ov_cur * kChunkCap + 1) = (unsigned)ov_fill;
+        }
+      }
+      // the tile's entries (and chain) have reached the L2 before the FIFO entry can be seen.  A tile whose chain could
+      // not even be started (the overflow store is full: the run is repeated) is published with what its slot holds.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned pub = (ch_dead && ov_cur == kNoChunk) ? (unsigned)min(t_cnt, a.sp_slot_cap) : (unsigned)t_cnt;
+      if (lane == 0) fifo_store(&fifo[f_idx], tile, pub);
+    }
+    wave_lds_sync();
+  };
+  for (long long wb = lo; wb < hi; wb += kWin) {
+    wave_lds_sync();
+    const int wn = (int)((hi - wb) < kWin ? (hi - wb) : kWin);
+    float rw = ri;
+    for (int e = lane; e < wn; e += 64) {
+      const long long src = !kPerm ? wb + e
+                            : ((h_bounds && wb == lo && e < 128) ? (long long)(e < 64 ? w0src : w1src) : (long long)a.perm[wb + e]);
+      const CRec &c = a.cand[src];
+      const float sx = (float)(c.s[0] - ox), sy = (float)(c.s[1] - oy), sz = (float)(c.s[2] - oz);
+      const float ex = (float)(c.e[0] - ox), ey = (float)(c.e[1] - oy), ez = (float)(c.e[2] - oz);
+      W4[3 * e + 0] = float4{(float)c.dir[0], (float)c.dir[1], (float)c.dir[2], __int_as_float(c.nb_slot)};
+      W4[3 * e + 1] = float4{sx, ex, sy, ey};
+      W4[3 * e + 2] = float4{sz, ez, __uint_as_float((unsigned)src), 0.0f};
+      rw = fmaxf(rw, fmaxf(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)), fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez))));
+    }
+    rw = wave_max_f32_nan(rw);
+    const double delta = 1e-6 * (double)rw;
+    const float gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
+    const float gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
+    wave_lds_sync();
+    if (wb == lo) { LT_TRACE_MARK(2, tile, 1); }
+    long long jlo = off > wb ? off : wb;
+    long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
+    const int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
+    const int cmax = wave_max_i32(cnt);
+    const int w0 = (int)(jlo - wb);
+    const int self_t = (int)(tpos - jlo);
+    const int wlast = cnt > 0 ? w0 + cnt - 1 : 0;
+    const int wbase = cnt > 0 ? w0 : 0;
+    for (int t = 0; t < cmax; t += 4) {
+      float4 A[4], B[4];
+      float2 E[4];
+      unsigned Jr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int w = min(wbase + t + u, wlast);
+        A[u] = W4[3 * w + 0];
+        B[u] = W4[3 * w + 1];
+        const float4 e4 = W4[3 * w + 2];
+        E[u] = make_float2(e4.x, e4.y);
+        Jr[u] = __float_as_uint(e4.z);
+      }
+      bool pass[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float c = fabsf(__builtin_fmaf(dizf, A[u].z, __builtin_fmaf(diyf, A[u].y, dixf * A[u].x)));
+        const float ax = sixf - B[u].x, bx = eixf - B[u].y;
+        const float ay = siyf - B[u].z, by = eiyf - B[u].w;
+        const float az = sizf - E[u].x, bz = eizf - E[u].y;
+        const float ds2 = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));
+        const float de2 = __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));
+        pass[u] = (t + u < cnt) & (t + u != self_t) & (__float_as_int(A[u].w) != sloti) & !(c < cosf_guard) &
+                  !(ds2 > gsf) & !(de2 > gef);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned long long m = __ballot(pass[u]);
+        if (m) {
+          // (the neighbour word of j rides in the entry: the dense role fetches j's camera together with the records)
+          if (pass[u]) queue2[qn + __popcll(m & lanemask_lt())] = make_uint2(Jr[u], (unsigned)lane | ((unsigned)__float_as_int(A[u].w) << 6));
+          qn += __popcll(m);
+        }
+      }
+      if (qn > kQCap - 256) drain(false);
+    }
+  }
+  LT_TRACE_MARK(2, tile, 2);
+  drain(true);
+  LT_TRACE_MARK(2, tile, 3);
+}
+
+#ifndef LT_Q_WAVES_PER_EU
+#define LT_Q_WAVES_PER_EU 4
+#endif
+#ifndef LT_Q_PREFETCH
+#define LT_Q_PREFETCH 1
+#endif
+template <bool kFast, bool kPerm>
+__global__ void __launch_bounds__(64 * kDenseWaves) __attribute__((amdgpu_waves_per_eu(LT_Q_WAVES_PER_EU, LT_Q_WAVES_PER_EU)))
+k_score_q(Score3Args a, ScoreCfg cfg, double scaleinv_guard2, int score_by) {
+  extern __shared__ __align__(16) unsigned char smem_all[];
+  unsigned *s_hdr = reinterpret_cast<unsigned *>(smem_all);
+  unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_all + kQHdrBytes);
+  constexpr int kWaves = kDenseWaves;
+  constexpr int kThreads = 64 * kWaves;
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = (int)(blockIdx.x & (unsigned)(kTileQueues - 1));
+  const long long C = a.tri_off[a.G];
+  const int T = a.sp_t_max;
+  const int max_nb = a.max_nb;
+  const int cap = a.sp_slot_cap;
+  uint2 *fifo = a.pc_list + (size_t)x * a.pc_cap;
+  unsigned *q_alloc = a.draw + x * 32;
+  unsigned *q_claim = a.sp_counters + 32 * (1 + x);
+  unsigned *q_sweep = a.draw + (3 * kTileQueues + 1 + x) * 32;
+  // tiles are CLAIMED, four consecutive entries of the queue's order per pass (no static share: a workgroup that is not
+  // resident yet owes nothing; nobody ever waits for a tile that is not already being swept)
+  unsigned k_raw = 0;
+  if (tid == 0) k_raw = atomicAdd(q_sweep, (unsigned)kDenseWaves);
+  unsigned char *smem_wave = smem_all + kQHdrBytes + (size_t)wave * kQSweepWaveBytes;
+  // the queue's tiles in class order, most expensive class first: entry l < kTileBuckets of the two LDS vectors is class
+  // kTileBuckets - 1 - l (every wave writes the same values: no barrier needed for its own reads)
+  unsigned *s_cls_cnt = s_hdr + 16, *s_cls_incl = s_hdr + 16 + kTileBuckets;
+  unsigned n_x;
+  {
+    const unsigned cls_cnt = lane < kTileBuckets ? a.bucket_cnt[(x * kTileBuckets + (kTileBuckets - 1 - lane)) * 32] : 0u;
+    const unsigned cls_incl = wave_incl_scan_u32(cls_cnt);
+    n_x = (unsigned)__builtin_amdgcn_readlane((int)cls_incl, 63);
+    if (lane < kTileBuckets) { s_cls_cnt[lane] = cls_cnt; s_cls_incl[lane] = cls_incl; }
+    wave_lds_sync();
+  }
+  auto fetch_x_ptr = [&](const unsigned k) -> const uint4 * {  // k < n_x, wave-uniform
+    const unsigned incl = lane < kTileBuckets ? s_cls_incl[lane] : 0xFFFFFFFFu;
+    const int l = __builtin_ctzll(__ballot(incl > k));
+    const unsigned base = s_cls_incl[l] - s_cls_cnt[l];
+    return reinterpret_cast<const uint4 *>(a.bucket_list) + ((size_t)(x * kTileBuckets + (kTileBuckets - 1 - l)) * a.bucket_cap + (k - base));
+  };
+  auto fetch_x = [&](const unsigned k) -> uint4 { return *fetch_x_ptr(k); };
+  // per wave, behind both roles' areas: where the next tile's first loads land
+  unsigned *pre_hdr = reinterpret_cast<unsigned *>(smem_all + a.sp_wave_lds + (size_t)wave * kQPreBytes);
+  unsigned *pre_pi = pre_hdr + 4, *pre_w = pre_hdr + 4 + 64;
+  if (tid == 0) s_hdr[1] = 0u;
+  unsigned produced = 0, consumed = 0;
+  unsigned c_raw = 0;  // thread kThreads - 64: the unit it has claimed
+  bool prev_sweep = true, ch_dead = false;
+  unsigned n_pairs_wg = 0;  // pair statistic of this workgroup (lanes < T of the first wave)
+  if (tid == 0) s_hdr[2] = k_raw;
+  __syncthreads();
+  // a claim is a GROUP of four consecutive entries of the queue's order (group g = entries 4 g .. 4 g + 3).  (Measured and
+  // dropped: the first claims alternating between the expensive and the cheap end of the order, so that half of the
+  // workgroups come back early and the roles interleave from the start -- 97.6 against 95.1 us.)
+  const unsigned n_grp = (n_x + (unsigned)kWaves - 1u) / (unsigned)kWaves;
+  auto group_of = [&](const unsigned g) -> unsigned { return g; };
+  unsigned gi = (unsigned)__builtin_amdgcn_readfirstlane((int)s_hdr[2]) / (unsigned)kWaves;
+  int par = 1;  // s_hdr[2 + par]: the next pass's claim (two cells in turn: a slow wave still reads the last one)
+  int pre_stage = 0;  // the next tile's prefetch: 1 = its list entry is on the way to LDS, 2 = its first load level too
+  while (gi < n_grp) {
+    // ---- sweep role: the four entries of group group_of(gi), one tile per wave
+    const unsigned k_base = group_of(gi) * (unsigned)kWaves;
+    produced += min((unsigned)kWaves, n_x - k_base);
+    if (tid == 0) k_raw = atomicAdd(q_sweep, (unsigned)kWaves);  // the next pass's tiles
+    bool want = produced / (unsigned)T > consumed;
+    if (want && tid == kThreads - 64) c_raw = atomicAdd(q_claim, 1u);
+    if (k_base + (unsigned)wave < n_x) {
+      QFirst fl;
+      if (pre_stage == 0) {
+        fl = q_first_level<kPerm>(a, fetch_x(k_base + (unsigned)wave), C, lane);
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA loads of this tile's entry (and first level)
+        const uint4 hdr = uint4{pre_hdr[0], pre_hdr[1], pre_hdr[2], 0u};
+        if (pre_stage == 1) {
+          fl = q_first_level<kPerm>(a, hdr, C, lane);
+        } else {
+          fl.hdr = hdr;
+          fl.mt = CandMeta{0u, 0u, 0u, 0u};
+          const long long tp = (long long)hdr.x * 64 + lane;
+          if (tp < C) fl.mt = a.meta[tp];
+          fl.p_i = pre_pi[lane]; fl.w0 = pre_w[lane]; fl.w1 = pre_w[64 + lane];
+        }
+      }
+      q_sweep_tile<kPerm>(a, cfg, scaleinv_guard2, smem_wave, fl, C, lane, fifo, q_alloc, ch_dead);
+    }
+    pre_stage = 0;
+    if (tid == 0) s_hdr[2 + par] = k_raw;
+    if (want && tid == kThreads - 64) s_hdr[0] = c_raw;
+    __syncthreads();
+    prev_sweep = true;
+    gi = (unsigned)__builtin_amdgcn_readfirstlane((int)s_hdr[2 + par]) / (unsigned)kWaves;
+    par ^= 1;
+    const bool draining = gi >= n_grp;  // no tile left to sweep: this workgroup helps to empty the FIFO
+    const unsigned k_next = draining ? n_x : group_of(gi) * (unsigned)kWaves + (unsigned)wave;  // this wave's next entry
+#if LT_Q_PREFETCH
+    if (k_next < n_x) {
+      const uint4 *ent = fetch_x_ptr(k_next);
+      if (lane == 0) __builtin_amdgcn_global_load_lds((gbl_void_t *)ent, (lds_void_t *)pre_hdr, 16, 0, 0);
+      pre_stage = 1;
+    }
+#endif
+    if (draining && !want) {
+      if (tid == kThreads - 64) s_hdr[0] = atomicAdd(q_claim, 1u);
+      __syncthreads();
+      want = true;
+    }
+    // ---- dense role: units of T consecutive FIFO entries
+    bool any_dense = false;
+    while (want) {
+      const unsigned u_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)s_hdr[0]);
+      const unsigned long long e0 = (unsigned long long)u_cur * (unsigned)T;
+      if (e0 >= n_x) {
+        if (draining) goto done;  // every unit of this queue is claimed
+        break;
+      }
+      ++consumed;
+      any_dense = true;
+      const bool more = draining || produced / (unsigned)T > consumed;
+      const int nt = (int)min((unsigned long long)T, (unsigned long long)n_x - e0);
+      LT_TRACE_MARK(3, u_cur * 8u + (unsigned)x, 0);
+      // the unit's header (tile and pair count of its tiles) in lanes < nt of EVERY wave: wait for the producers
+      unsigned h_tile = 0, h_cnt = 0;
+      {
+        bool timed_out = false;
+        if (lane < nt) {
+          int spins = 0;
+          for (;;) {
+            const uint2 e = fifo_load(&fifo[e0 + (unsigned)lane]);
+            if (e.x != kFifoEmpty) { h_tile = e.x; h_cnt = e.y; break; }
+            if (++spins > kQSpinMax) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+          }
+        }
+        if (__any(timed_out)) {
+          h_tile = 0; h_cnt = 0;
+          if (lane == 0) {
+            s_hdr[1] = 1u;
+            if (a.err_flag) atomicCAS(a.err_flag, 0, kErrXcdMap);
+          }
+        }
+      }
+      if (tid < nt) n_pairs_wg += h_cnt;
+      if (prev_sweep) {  // the sweep's windows lay over the tables
+        for (int k = tid; k < T * max_nb * 64; k += kThreads) S[k] = 0ull;
+        prev_sweep = false;
+      }
+      int off[kChunkTiles + 1];
+      off[0] = 0;
+#pragma unroll
+      for (int k = 0; k < kChunkTiles; ++k)
+        off[k + 1] = off[k] + (k < nt ? min((int)(unsigned)__builtin_amdgcn_readlane((int)h_cnt, k), cap) : 0);
+      auto entry_of = [&](int p, int &k) -> uint4 {
+        k = 0;
+#pragma unroll
+        for (int m = 1; m < kChunkTiles; ++m) k += (p >= off[m]) ? 1 : 0;
+        int o = off[0];
+#pragma unroll
+        for (int m = 1; m < kChunkTiles; ++m) o = (k >= m) ? off[m] : o;
+        const unsigned tile = (unsigned)__shfl((int)h_tile, k);
+        return a.sp_slots[(size_t)tile * (size_t)cap + (p - o)];
+      };
+      const int total = off[kChunkTiles];
+      int k0e = 0;
+      uint4 e0v = uint4{0u, 0u, 0u, 0u};
+      const bool has0 = tid < total;
+      if (total > 0) {
+        int kk = 0;
+        const uint4 ee = entry_of(has0 ? tid : 0, kk);
+        if (has0) { e0v = ee; k0e = kk; }
+      }
+      CandMeta mt[2];
+      long long pos[2];
+      unsigned rrec[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ti = wave + kWaves * h;
+        pos[h] = -1;
+        rrec[h] = 0;
+        mt[h] = CandMeta{0u, 0u, 0u, 0u};
+        if (ti < nt) {
+          const long long p = (long long)(unsigned)__builtin_amdgcn_readlane((int)h_tile, ti & (kChunkTiles - 1)) * 64 + lane;
+          if (p < C) {
+            pos[h] = p;
+            if (score_by == 0) rrec[h] = a.perm ? a.perm[p] : (unsigned)p;
+            mt[h] = a.meta[p];
+          }
+        }
+      }
+      __syncthreads();  // the tables are clean (zeroed above, or summed and zeroed by the previous unit)
+      if (s_hdr[1]) return;  // a wait timed out: the run is repeated in the two-kernel form
+      LT_TRACE_MARK(3, u_cur * 8u + (unsigned)x, 1);
+      int ordv[2] = {0, 0};
+      long long wnb0[2] = {-1, -1};
+      unsigned nb0_l[2] = {0u, 0u};
+      int nn_l[2] = {0, 0};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (wave + kWaves * h < nt) {
+          nb0_l[h] = mt[h].nb >> 8;
+          nn_l[h] = pos[h] >= 0 ? (int)(mt[h].nb & 0xFFu) : 0;
+          wnb0[h] = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)nb0_l[h]);
+          const int n0 = __builtin_amdgcn_readfirstlane(nn_l[h]);
+          if (lane < n0) ordv[h] = a.blk_order[wnb0[h] + lane];
+          if (n0 > 64) wnb0[h] = -1;
+        }
+      }
+      const int n_it3 = total > kThreads - 64 ? (total - (kThreads - 64) + kThreads - 1) / kThreads : 0;
+      auto claim = [&]() {
+        if (more && tid == kThreads - 64) c_raw = atomicAdd(q_claim, 1u);
+      };
+      if (n_it3 <= 1) claim();
+      auto eval = [&](const uint4 e, const int k) {
+        const CRec &ci = a.cand[e.y];
+        const CRec &cj = a.cand[e.x];
+        const int nbs_j = (int)(e.z >> 6);  // = cj.nb_slot
+        const d3 si_ = mk3(ci.s[0], ci.s[1], ci.s[2]), ei_ = mk3(ci.e[0], ci.e[1], ci.e[2]), di_ = mk3(ci.dir[0], ci.dir[1], ci.dir[2]);
+        const d3 sj_ = mk3(cj.s[0], cj.s[1], cj.s[2]), ej_ = mk3(cj.e[0], cj.e[1], cj.e[2]), dj_ = mk3(cj.dir[0], cj.dir[1], cj.dir[2]);
+        const Cam &camj = a.cams[(int)((unsigned)nbs_j >> 8)];
+        double sc;
+        if constexpr (kFast) sc = pair_score_fused(cfg, si_, ei_, di_, ci.depth[0], ci.depth[1], sj_, ej_, dj_, cj.seg, camj);
+        else sc = pair_score_terms(cfg, si_, ei_, di_, ci.depth[0], ci.depth[1], sj_, ej_, dj_, cj.seg, camj);
+        if (sc > 0.0)
+          atomicMax(&S[(k * max_nb + (nbs_j & 0xFF)) * 64 + (int)(e.z & 63u)], (unsigned long long)__double_as_longlong(sc));
+      };
+      const int n_it = total > (wave << 6) ? (total - (wave << 6) + kThreads - 1) / kThreads : 0;
+      for (int it = 0; it < n_it; ++it) {
+        if (it > 0 && it == n_it3 - 1) claim();
+        const int p = tid + it * kThreads;
+        int k = k0e;
+        uint4 e = e0v;
+        if (it > 0) e = entry_of(p < total ? p : 0, k);
+        if (p < total) eval(e, k);
+      }
+      for (int k = 0; k < nt; ++k) {
+        if ((int)(unsigned)__builtin_amdgcn_readlane((int)h_cnt, k & (kChunkTiles - 1)) <= cap) continue;
+        unsigned cc = q_word3(a.sp_slots + (size_t)(unsigned)__builtin_amdgcn_readlane((int)h_tile, k & (kChunkTiles - 1)) * (size_t)cap);
+        while (cc != kNoChunk) {
+          const unsigned nxt = q_word3(a.sp_pairs + (size_t)cc * kChunkCap);
+          const unsigned fill = q_word3(a.sp_pairs + (size_t)cc * kChunkCap + 1);
+          for (int p = tid; p < (int)fill; p += kThreads) eval(a.sp_pairs[(size_t)cc * kChunkCap + p], k);
+          cc = nxt;
+        }
+      }
+      if (more && tid == kThreads - 64) s_hdr[0] = c_raw;
+      __syncthreads();  // every pair of the unit is in the tables
+      LT_TRACE_MARK(3, u_cur * 8u + (unsigned)x, 2);
+      asm volatile("" : "+v"(ordv[0]), "+v"(ordv[1]));
+#if LT_Q_PREFETCH
+      if (pre_stage == 1) {
+        // the next tile's list entry has landed (the rounds' loads came back behind it): its record index per lane and the
+        // record indices of its first window chunk, global -> LDS by the DMA path, no register holds them across the sums
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned n_tile = pre_hdr[0], n_lo = pre_hdr[1], n_hi = pre_hdr[2];
+        const long long tp = (long long)n_tile * 64 + lane;
+        if (tp < C) __builtin_amdgcn_global_load_lds((gbl_void_t *)(a.perm + tp), (lds_void_t *)pre_pi, 4, 0, 0);
+        if (n_hi > n_lo) {
+          const unsigned w = (n_hi - n_lo) < (unsigned)kWin ? (n_hi - n_lo) : (unsigned)kWin;
+          if ((unsigned)lane < w) __builtin_amdgcn_global_load_lds((gbl_void_t *)(a.perm + (size_t)n_lo + lane), (lds_void_t *)pre_w, 4, 0, 0);
+          if ((unsigned)lane + 64u < w)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(a.perm + (size_t)n_lo + 64 + lane), (lds_void_t *)(pre_w + 64), 4, 0, 0);
+        }
+        pre_stage = 2;
+      }
+#endif
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ti = wave + kWaves * h;
+        if (ti >= nt) continue;
+        const bool act = pos[h] >= 0;
+        const long long nb0 = (long long)nb0_l[h];
+        const int n_nb = nn_l[h];
+        const bool own = nb0 == wnb0[h];
+        const int n_max = wave_max_i32(n_nb);
+        double sum = 0.0;
+        if (!__any(act && !own)) {
+          for (int kk0 = 0; kk0 < n_max; kk0 += kSumChunk) {
+            unsigned long long v[kSumChunk];
+            int sl[kSumChunk];
+#pragma unroll
+            for (int u = 0; u < kSumChunk; ++u) {
+              const int k = kk0 + u;
+              sl[u] = __builtin_amdgcn_readlane(ordv[h], k & 63);
+              v[u] = k < n_nb ? S[(ti * max_nb + sl[u]) * 64 + lane] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < kSumChunk; ++u) sum += __longlong_as_double((long long)v[u]);
+#pragma unroll
+            for (int u = 0; u < kSumChunk; ++u)
+              if (kk0 + u < n_nb) S[(ti * max_nb + sl[u]) * 64 + lane] = 0ull;
+          }
+        } else {
+          for (int k = 0; k < n_nb; ++k) {
+            unsigned long long *cell = &S[(ti * max_nb + a.blk_order[nb0 + k]) * 64 + lane];
+            sum += __longlong_as_double((long long)*cell);
+            *cell = 0ull;
+          }
+        }
+        if (act) a.score[score_by == 1 ? pos[h] : (score_by == 2 ? (long long)a.spos[pos[h]] : (long long)rrec[h])] = sum;
+      }
+      LT_TRACE_MARK(3, u_cur * 8u + (unsigned)x, 3);
+      want = more;
+    }
+    if (any_dense && !draining) __syncthreads();  // the sums are done before the next pass's windows overwrite the tables
+  }
+done:
+  if (tid < 64) {
+    unsigned long long np = (unsigned long long)n_pairs_wg;
+    for (int d = 32; d >= 1; d >>= 1) np += (unsigned long long)__shfl_xor((long long)np, d);
+    if (tid == 0) {
+      if (a.pair_counter && np) atomicAdd(a.pair_counter, np);
+      // every workgroup of this queue on one XCD?  (looked at by the host with the run's error flag: nothing in the kernel
+      // has to hold the answer)
+      unsigned xcc = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      xcc &= 0xFu;
+      const unsigned seen = atomicCAS(&a.draw[(2 * kTileQueues + 1 + x) * 32], kFifoEmpty, xcc);
+      if (seen != kFifoEmpty && seen != xcc && a.err_flag) atomicCAS(a.err_flag, 0, kErrXcdMap);
+    }
+  }
+}
+
 #ifdef LT_TRACE
 int score_read_trace(unsigned long long *host, size_t n) {  // slices 2 and 3 of the trace array
   if (n < 4 * 4 * 65536) return -1;
@@ -1266,7 +1869,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    unsigned *bucket_list, unsigned bucket_cap, const unsigned *place, unsigned *rec, const float *st_z,
                    int *err_flag, void *sp_slots, int sp_slot_cap, unsigned *sp_cnt, unsigned *sp_ovf, void *sp_pairs,
                    void *sp_desc, long long sp_chunks, hipEvent_t ev_after, const void *node_rec, unsigned *pc_cnt,
-                   void *pc_list, unsigned pc_cap) {
+                   void *pc_list, unsigned pc_cap, bool one_kernel) {
   // ev_before / ev_after: bound as the STOP events of k_cand_meta and of the stage's last kernel (hipExtLaunchKernelGGL:
   // the kernel's own completion signal carries the timestamp) -- a hipEventRecord between two kernels is a barrier packet
   // that opens a ~5.5 us gap in the stream (LT_EV_MARKERS=1: the plain records, for comparison)
@@ -1275,6 +1878,10 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   // place / rec: depth-sorted sweep over STAGED records (one-pass exhaustive mode): place[natural position] = record,
   // rec (scratch, one word per candidate) receives the record of every sorted position
   if (C <= 0) return;
+  // one_kernel: the split form as ONE persistent kernel (k_score_q) where it applies: single-precision sweep over the
+  // placement permutation (matched mode), cost-class lists and the pair store present
+  const bool q_form = one_kernel && sp_slots != nullptr && f32 && perm != nullptr && perm_is_placement && rng == nullptr &&
+                      bucket_cnt != nullptr && pc_list != nullptr;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -1288,7 +1895,8 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   hipExtLaunchKernelGGL(k_cand_meta, dim3((unsigned)std::min<long long>(nblk2(C, 256), 16ll * n_cu)), dim3(256), 0, st,
                         nullptr, ev_markers ? nullptr : ev_before, 0, G, cand_node, tri_off, node_img, nb_off,
                         reinterpret_cast<CandMeta *>(meta), draw, bucket_cnt, bucket_list, bucket_cap,
-                        reinterpret_cast<const uint4 *>(node_rec), pc_cnt);
+                        reinterpret_cast<const uint4 *>(node_rec), pc_cnt,
+                        q_form ? reinterpret_cast<uint2 *>(pc_list) : nullptr, pc_cap);
   hipEvent_t ev_stop = ev_markers ? nullptr : ev_after;
   Score3Args a;
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand;
@@ -1328,6 +1936,31 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   const size_t lds = split ? (size_t)kWin * 48 + 64 * 8 + (size_t)kSQCapSplit * 8 + 64 * 4 : score3_lds_bytes(max_nb, f32);
   const long long per_cu = std::max<long long>(1, std::min<long long>(LT_SCORE_RESIDENT, (long long)(160 * 1024 / lds)));
   const dim3 grid((unsigned)std::min<long long>(n_tiles, per_cu * n_cu)), block(64);
+  if (split && q_form) {
+    a.pc_cnt = nullptr;  // (the FIFOs live in pc_list; no pair-count classes)
+    // LDS: header | the roles' area (four sweep windows + queues, or the unit's tables of maxima) | four prefetch areas
+    const size_t lds_roles = (size_t)kQHdrBytes + std::max((size_t)kDenseWaves * (size_t)kQSweepWaveBytes, (size_t)a.sp_t_max * (size_t)max_nb * 512);
+    a.sp_wave_lds = (int)lds_roles;  // (here: where the prefetch areas start)
+    const size_t ldsq = lds_roles + (size_t)kDenseWaves * (size_t)kQPreBytes;
+    static int occ_q[2] = {0, 0};
+    static size_t occ_q_lds[2] = {0, 0};
+    const int v = cfg.fast ? 1 : 0;
+    if (occ_q[v] == 0 || occ_q_lds[v] != ldsq) {
+      int o = 0;
+      hipError_t e = v ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score_q<true, true>, 64 * kDenseWaves, ldsq)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_score_q<false, true>, 64 * kDenseWaves, ldsq);
+      occ_q[v] = (e == hipSuccess && o > 0) ? o : 1;
+      occ_q_lds[v] = ldsq;
+    }
+    // every workgroup that can be resident, a multiple of 8 (queue = workgroup % 8 = XCD); at most one per four tiles
+    long long wgs = std::min<long long>((long long)occ_q[v] * n_cu, (n_tiles + kDenseWaves - 1) / kDenseWaves + 7);
+    wgs = std::max<long long>(8, wgs & ~7ll);
+    const dim3 gq((unsigned)wgs);
+    if (cfg.fast) hipExtLaunchKernelGGL((k_score_q<true, true>), gq, dim3(64 * kDenseWaves), ldsq, st, nullptr, ev_stop, 0, a, cfg, scaleinv_guard2, 1);
+    else hipExtLaunchKernelGGL((k_score_q<false, true>), gq, dim3(64 * kDenseWaves), ldsq, st, nullptr, ev_stop, 0, a, cfg, scaleinv_guard2, 1);
+    if (ev_after && ev_markers) (void)hipEventRecord(ev_after, st);
+    return;
+  }
   if (split) {
     // static schedule: exactly the workgroups that are resident at once
     static int occ_split[3] = {0, 0, 0};

@@ -40,7 +40,8 @@ def clean_env():
     keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES",
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
             "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TIMER_SAMPLE", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_SCORE_SPLIT",
-            "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS", "LT_TEST_PAIR_SCORE_TERMS", "LT_TEST_NO_PAIR_CLASSES", "LT_TEST_GATES_IMAGE_MAJOR")
+            "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS", "LT_TEST_PAIR_SCORE_TERMS", "LT_TEST_NO_PAIR_CLASSES", "LT_TEST_GATES_IMAGE_MAJOR",
+            "LT_SCORE_ONE_KERNEL")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -465,7 +466,9 @@ def test_scoring_sweep_forms_agree(gpu_lib, clean_env, topk, n_nb):
 @pytest.mark.parametrize("topk,n_nb", [(10, 6), (60, 13)])
 def test_split_and_fused_scoring_agree(gpu_lib, clean_env, topk, n_nb):
     """The scoring stage runs as two kernels by default (sweep -> pair slots per tile -> k_dense8 over units of tiles) and
-    keeps the fused k_score3 as the fallback.  Same bits from: the fused kernel (LT_SCORE_FUSED); slots of four entries
+    keeps the fused k_score3 as the fallback.  Same bits from: the ONE-kernel form of round 6 (k_score_q, LT_SCORE_ONE_KERNEL:
+    workgroups alternate between sweeping tiles and evaluating units of finished tiles from their XCD's FIFO; measured, not
+    the default), also with overflow chains everywhere; the fused kernel (LT_SCORE_FUSED); slots of four entries
     (every tile with more pairs continues in a chain of overflow chunks); an overflow store of one chunk (the store
     fills, device flag 7, the run is repeated fused and the context stays fused); the split form over the natural tile
     order; the split form of the exhaustive mode (not its default)."""
@@ -473,6 +476,13 @@ def test_split_and_fused_scoring_agree(gpu_lib, clean_env, topk, n_nb):
     cfg = syn.default_triangulation_cfg(debug_mode=True)
     base = _results(run_product(sc, cfg, topk=topk))
     assert base[5]["candidates"] > 1000 and base[4]["pairs_eval"] > 1000
+    os.environ["LT_SCORE_ONE_KERNEL"] = "1"
+    one = _results(run_product(sc, cfg, topk=topk))
+    _same(base, one)
+    assert one[4]["pairs_eval"] == base[4]["pairs_eval"] and one[4]["score_two_kernels"] == 0
+    os.environ["LT_TEST_SPLIT_SLOT"] = "4"
+    _same(base, _results(run_product(sc, cfg, topk=topk)))
+    del os.environ["LT_SCORE_ONE_KERNEL"], os.environ["LT_TEST_SPLIT_SLOT"]
     os.environ["LT_SCORE_FUSED"] = "1"
     fused = _results(run_product(sc, cfg, topk=topk))
     _same(base, fused)
