@@ -202,7 +202,7 @@ constexpr int kChunkCap = 512;
 constexpr int kChunkTiles = 8;
 constexpr unsigned kNoChunk = 0xFFFFFFFFu;
 constexpr int kErrPairChunks = 7;  // device error flag: the overflow store is full (finish_run repeats the run fused)
-constexpr int kDenseHdrBytes = 16 + kChunkTiles * 8 + 256 * 8 + 64 * 4;  // k_dense8's LDS in front of the tables
+constexpr int kDenseHdrBytes = 16 + kChunkTiles * 8 + 256 * 4 + 64 * 4;  // k_dense8's LDS in front of the tables
 
 // Depth order of a node's candidates (large nodes: exhaustive matching gives ~450 candidates per node and
 // 1.6e10 ordered pairs per scene, of which the sweep passes 0.05 %).  All candidates of a node are seen from
@@ -907,16 +907,20 @@ constexpr int kDenseLdsBudget = LT_DENSE_LDS_KB * 1024;      // LDS for a workgr
 // rounds --: 100.0 against 96.2 us, same bits.  The kernel without its arithmetic and without its record gathers
 // (LT_ABL_DENSE=2) still takes 32 of its 48 us, but not as a chain of exposed round trips at the start of a unit: taking
 // those away does not shorten it.)
+#ifdef LT_DENSE_WPE
+#define LT_DENSE_OCC __attribute__((amdgpu_waves_per_eu(LT_DENSE_WPE, LT_DENSE_WPE)))
+#else
+#define LT_DENSE_OCC
+#endif
 template <bool kFast>  // kFast: pair_score_fused / pair_score_terms (ScoreCfg::fast)
-__global__ void __launch_bounds__(64 * kDenseWaves)
+__global__ void __launch_bounds__(64 * kDenseWaves) LT_DENSE_OCC
 k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of the candidate, 1 = position, 2 = spos[position]
   extern __shared__ __align__(16) unsigned char smem_raw[];
   unsigned *s_next = reinterpret_cast<unsigned *>(smem_raw);  // [4]
   unsigned *s_cnt = s_next + 4;                               // [kChunkTiles] pairs of the unit's tiles
   unsigned *s_tile = s_cnt + kChunkTiles;                     // [kChunkTiles] the unit's tiles
   unsigned *s_ocnt = s_tile + kChunkTiles;                    // [256] tiles of the (queue, class) lists in flat order
-  unsigned *s_ounits = s_ocnt + 256;                          // [256] units of the lists
-  unsigned *s_uincl = s_ounits + 256;                         // [64] inclusive prefix of the units, four lists per entry
+  unsigned *s_uincl = s_ocnt + 256;                           // [64] inclusive prefix of the lists' units, four lists per entry
   unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_raw + kDenseHdrBytes);
   if (a.err_flag && *a.err_flag == kErrPairChunks) return;  // the overflow store was full: the run is repeated
   const long long C = a.tri_off[a.G];
@@ -950,7 +954,6 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
         const unsigned c = list_cnt[((f & (kTileQueues - 1)) * kTileBuckets + (kTileBuckets - 1 - (f >> 3))) * 32];
         s_ocnt[f] = c;
         const unsigned tf = (unsigned)tiles_per_unit(f);
-        s_ounits[f] = (c + tf - 1) / tf;
         u_tot += (c + tf - 1) / tf;
       }
       unsigned u_incl = u_tot;
@@ -977,7 +980,7 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
       int v = 0;
 #pragma unroll
       for (int w = 0; w < 3; ++w) {
-        const unsigned c = s_ounits[4 * l + w];
+        const unsigned c = (s_ocnt[4 * l + w] + (unsigned)tiles_per_unit(4 * l + w) - 1u) / (unsigned)tiles_per_unit(4 * l + w);  // units of the list
         if (v == w && r >= c) { r -= c; v = w + 1; }
       }
       const int f = 4 * l + v;
