@@ -476,6 +476,61 @@ def _emit(line):
         data = data[os.write(fd, data):]
 
 
+def e2e_child(views, segs, neighbors, seed, topk):
+    """`bench.py --e2e-child ...`: the reference's call sequence in a process WITHOUT torch -- what a caller of the library
+    that does not import torch sees.  torch's wheel ships its own libamdhip64.so.7 / libhsa-runtime64 (ROCm 7.0); a process
+    that imports torch first makes every later library with that soname -- liblimap_amd.so included -- run on THOSE instead
+    of the system's ROCm 7.2 runtime it was built against, and the host path of this library (a few hundred short HIP calls
+    per scene) is 0.6 ms slower there (tools/profile_e2e_variants.py: 2.98 -> 3.61 ms).  Prints one E2E_CHILD json line."""
+    import gc
+    from limap_amd import merging, synthetic as syn, triangulation as tri
+    sc = syn.make_scene(n_views=views, n_segs=segs, n_neighbors=neighbors, seed=seed)
+    cfg = syn.default_triangulation_cfg()
+    matches = {int(i): sc.matches_of(int(i), topk) for i in sc.img_ids}
+    segs_list = [sc.segs_of(j) for j in range(sc.n_images)]
+    n_rep = 6
+    per_image, batched, with_post, parts = [], [], [], []
+    n_tracks = n_post = 0
+    for form in ("per_image", "batched"):
+        for rep in range(n_rep):
+            gc.collect()
+            gc.disable()
+            t0 = time.perf_counter()
+            T = tri.GlobalLineTriangulator(cfg)
+            T.SetRanges(sc.ranges)
+            T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, segs_list)
+            t1 = time.perf_counter()
+            if form == "per_image":
+                for i in sc.img_ids:
+                    T.TriangulateImage(int(i), matches[int(i)])
+            else:
+                T.TriangulateAll(matches)
+            t2 = time.perf_counter()
+            tracks = T.ComputeLineTracks()
+            t3 = time.perf_counter()
+            n_tracks = len(tracks)
+            if form == "per_image":
+                per_image.append(1e3 * (t3 - t0))
+                parts.append({"ctor_init": round(1e3 * (t1 - t0), 2), "buffer": round(1e3 * (t2 - t1), 2),
+                              "compute_tracks": round(1e3 * (t3 - t2), 2)})
+                ts = merging.TrackSet.from_triangulator(T)
+                ts.filter_by_reprojection(8.0, 5.0).remerge(REMERGE_LINKER).filter_by_reprojection(8.0, 5.0)
+                ts.filter_by_sensitivity(75.0, 3).filter_by_overlap(0.5, 3)
+                with_post.append(1e3 * (time.perf_counter() - t0))
+                n_post = len(ts)
+                del ts
+            else:
+                batched.append(1e3 * (t3 - t0))
+            gc.enable()
+            del T, tracks
+    med = lambda v: float(np.median(v[1:]))  # repetition 0 is the cold one
+    print("E2E_CHILD " + json.dumps({
+        "e2e_wall_ms": med(per_image), "e2e_with_postprocess_ms": med(with_post), "e2e_batched_ms": med(batched),
+        "e2e_reps_ms": [round(x, 3) for x in per_image], "e2e_with_postprocess_reps_ms": [round(x, 3) for x in with_post],
+        "e2e_batched_reps_ms": [round(x, 3) for x in batched], "e2e_reps_parts": parts, "tracks": n_tracks,
+        "tracks_after_postprocess": n_post, "torch_in_process": "torch" in sys.modules}), flush=True)
+
+
 def main():
     _quiet_stdout()
     ap = argparse.ArgumentParser()
@@ -511,7 +566,11 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=2.0,
                     help="after the timed region: the same step looped for about this long (sustained_ms_per_step; an "
                          "outside observer -- rocm-smi -- sees the device busy); 0 = off")
+    ap.add_argument("--e2e-child", nargs=5, type=int, metavar=("VIEWS", "SEGS", "NEIGHBORS", "SEED", "TOPK"),
+                    help="internal: the end-to-end call sequence in this (torch-free) process, see e2e_child")
     args = ap.parse_args()
+    if args.e2e_child:
+        return e2e_child(*args.e2e_child)
     if args.config3:
         args.scaling, args.views, args.segs, args.rooms, args.gt, args.seed = "strong", 1000, 1000, 4, 3000, 1
 
@@ -1072,6 +1131,26 @@ def main():
                     out["e2e_after_warmup_ms"] = {"error": pr.stderr[-300:]}
             except Exception as e:  # an extra: never lose the main line over it
                 out["e2e_after_warmup_ms"] = {"error": f"{type(e).__name__}: {e}"}
+        # the same call sequences in a process that has NOT imported torch (see e2e_child: torch's bundled HIP / HSA runtime
+        # takes over every library loaded after it); the in-process figures above stay the headline e2e_* fields
+        if args.mode == "matched" and default_wl and not args.no_extras:
+            try:
+                import subprocess
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-child", str(args.views), str(args.segs),
+                                     str(args.neighbors), str(args.seed), str(args.topk)], capture_output=True, text=True,
+                                    timeout=180)
+                line = [l for l in pr.stdout.splitlines() if l.startswith("E2E_CHILD ")]
+                if line:
+                    ch = json.loads(line[-1][10:])
+                    assert ch["tracks"] == len(tracks_py) and not ch["torch_in_process"]
+                    ch["note"] = ("fresh process without torch: liblimap_amd.so on the system ROCm runtime it links; in this "
+                                  "process torch was imported first and its bundled libamdhip64.so.7 / libhsa-runtime64 serve "
+                                  "every HIP call of the library (e2e_wall_ms above)")
+                    out["e2e_clean_process"] = ch
+                else:
+                    out["e2e_clean_process"] = {"error": pr.stderr[-300:]}
+            except Exception as e:  # an extra: never lose the main line over it
+                out["e2e_clean_process"] = {"error": f"{type(e).__name__}: {e}"}
         out["postprocess"] = {"ms": post_ms, "reps_ms": [round(x, 3) for x in post_all], "tracks_after": post_tracks,
                               "steps": "filter_by_reprojection, remerge (to fixed point), filter_by_reprojection, "
                                        "filter_by_sensitivity, filter_by_overlap (cfgs/triangulation/default.yaml:102-115)"}

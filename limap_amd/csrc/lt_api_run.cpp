@@ -809,7 +809,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     if (ctx->h_nb_off[ctx->n_img] >= (1ll << 24))
       return fail(ctx, LT_ERR_ARGUMENT, "too many (image, neighbour) blocks in one batch (>= 2^24)");
     ENSURE(ctx, ctx->d_cand_meta, cand_meta_bytes() * (size_t)std::max<long long>(C_bound, 1));
-    ENSURE(ctx, ctx->d_tile_order, 64 * 128);  // the tile draw counters of k_score3 (8 x 128 B)
+    ENSURE(ctx, ctx->d_tile_order, 64 * 128);  // counters of the scoring stage, 128 B apart: draw queues of the fused kernel, overflow chunks, unit claims, k_score_q's XCD cells
     // tiles listed by cost class (LT_TEST_NO_TILE_CLASSES: natural tile order)
     // (matched mode only: the wide nodes of the exhaustive mode put every tile into the top class, whose one counter
     // per queue then serialises ~4e4 appends -- k_cand_meta 0.11 -> 0.50 ms -- for an order that changes nothing)
@@ -869,8 +869,10 @@ int lt_run_device_async(lt_ctx *ctx) {
                   ctx->d_sp_ovf.as<unsigned>(), ctx->d_sp_pairs.p, ctx->d_sp_desc.p, sp_chunks, sampled ? ev[5] : nullptr,
                   node_rec_valid ? ctx->d_node_rec.p : nullptr, pair_classes ? ctx->d_pc_cnt.as<unsigned>() : nullptr,
                   pair_classes ? ctx->d_pc_list.p : nullptr, tile_cap,
-                  /*one_kernel=*/test_switch("LT_SCORE_ONE_KERNEL") && !ctx->score_two_kernels &&
-                      ctx->n_img < (1 << 18) /* k_score_q's pair entries carry the neighbour word in 26 bits */);
+                  // the one-kernel form k_score_q (default; LT_SCORE_TWO_KERNELS=1 or device flag 8 once: sweep kernel + k_dense8;
+                  // its pair entries carry the neighbour word in 26 bits; 2 = LT_TEST_Q_LOSE_TILE, a tile is never published)
+                  (ctx->score_two_kernels || test_switch("LT_SCORE_TWO_KERNELS") || ctx->n_img >= (1 << 18))
+                      ? 0 : (test_switch("LT_TEST_Q_LOSE_TILE") ? 2 : 1));
     if (C_bound <= 0 && sampled) HIPCHK(ctx, hipEventRecord(ev[5], st));  // nothing to score: no kernel carries the event
   }
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));

@@ -77,7 +77,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    unsigned *bucket_list, unsigned bucket_cap, const unsigned *place, unsigned *rec, const float *st_z,
                    int *err_flag, void *sp_slots, int sp_slot_cap, unsigned *sp_cnt, unsigned *sp_ovf, void *sp_pairs,
                    void *sp_desc, long long sp_chunks, hipEvent_t ev_after, const void *node_rec, unsigned *pc_cnt,
-                   void *pc_list, unsigned pc_cap, bool one_kernel);
+                   void *pc_list, unsigned pc_cap, int one_kernel);
 size_t score_split_chunk_bytes();
 size_t score_split_entry_bytes();
 long long score_split_chunks(long long C);

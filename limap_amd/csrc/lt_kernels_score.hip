@@ -1243,39 +1243,39 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
 }
 
 // ---------------------------------------------------------------------------------------------
-// Round 6, second half: the scoring stage as ONE persistent kernel -- k_score_q.
+// Round 6, second half: the scoring stage as ONE kernel -- k_score_q.  The default of the matched mode.
 // ---------------------------------------------------------------------------------------------
 // The two kernels above run one after the other: 41 us in which every wave of the chip waits on window gathers (VALU issue
-// 0.44) followed by 53 us in which every wave runs pair_score rounds behind LDS maxima and barriers (0.45), and k_dense8
-// fetches the records of every pair a second time from another XCD's side of the chip.  Here a workgroup of four waves
-// ALTERNATES between the two roles:
-//   sweep role   -- its four waves sweep one tile each (the code of k_score3<split>: window in LDS in single precision, two
-//                   guards, the passing pairs to the tile's slot) and PUBLISH the finished tile as (tile, pair count) in the
-//                   FIFO of their XCD;
-//   dense role   -- the four waves together take a unit of T consecutive FIFO entries (the code of k_dense8: one list of
-//                   pairs over the unit's tiles, pair_score one pair per lane, per-image maxima in LDS, ordered sums).
-// A workgroup consumes about as many tiles as it has produced (4 per pass against T per unit), so the FIFO stays a few
-// entries deep: the pair entries and both records of a pair are still in the XCD's L2 when the dense role asks for them,
-// and the four workgroups of a CU are in different roles at any time -- the gathers of one hide behind the arithmetic of
-// another.  After its last pass a workgroup drains the FIFO until every unit of its XCD is claimed.
+// 0.44), the last 15 of them with a growing part of the chip idle (a wave has two or three tiles), then k_dense8's start
+// and 50 us of pair_score rounds behind LDS maxima and barriers (0.45).  Here ONE grid of workgroups of four waves does both:
+//   sweep role   -- a workgroup sweeps its share of the queue's tiles (the code of k_score3<split>: window in LDS in single
+//                   precision, two guards, the passing pairs to the tile's slot), one tile per wave at a time, and PUBLISHES
+//                   every finished tile as (tile, pair count) in the FIFO of its XCD, at the tile's place in the queue's
+//                   cost-class order;
+//   dense role   -- when its share is swept the same workgroup turns to units of T consecutive FIFO entries (the code of
+//                   k_dense8: one list of pairs over the unit's tiles, pair_score one pair per lane, per-image maxima in LDS,
+//                   ordered sums), claimed through the queue's counter, most expensive tiles first, and waits -- bounded --
+//                   for a unit's tiles where they are not published yet.
+// The workgroups finish their shares between 25 and 40 us; the dense role starts in every slot the moment it is free, on
+// tiles other workgroups published long before, and the sweep's tail and the dense kernel's start disappear.
 //   Producer and consumer of a tile are ALWAYS on the same XCD (queue x = blockIdx.x % 8, the dispatch order of the
 // hardware; checked against the XCC_ID register, device flag 8 sends the context back to the two-kernel form): the pair
 // entries travel through that XCD's L2 with plain stores and loads, only the 8-byte FIFO entry is a device-scope store /
-// load.  Nothing waits on a consumer: the slots of all tiles exist up front, a producer never blocks, so a consumer's
-// wait for a FIFO entry is bounded by the sweep of that tile (and by kQSpinMax, against a hang if the assumption about the
-// dispatch order ever failed).  Same bits as the two-kernel form and as the fused kernel (tests/test_gpu_guards.py).
-//   MEASURED (profiles/r06_score_experiments.txt, items 8-10): 94.7-96.6 us for the stage against 94.1-95.6 in the two-kernel
-// form at 100 x 500, 0.664 against 0.649 ms at config 3; L2 memory-side traffic 172 against 169 MB (a pass of one XCD's 512
-// waves stages 6 MB of records, more than its 4 MB of L2: the records are gone again when the dense role asks for them);
-// VALU instructions + 8 %.  The workgroups stay in step -- all sweep, then all evaluate -- because they start together and
-// a pass takes about as long everywhere.  NOT THE DEFAULT: LT_SCORE_ONE_KERNEL=1 (a test switch) selects it.
+// load, and the overflow chains are kept in band (word 3 of an entry) because sp_ovf / sp_desc pack many tiles into cache
+// lines a consumer's CU may already hold.  Nothing waits on a consumer: the slots of all tiles exist up front.  Same bits as
+// the two-kernel form and as the fused kernel (tests/test_gpu_guards.py).
+//   MEASURED (profiles/r06_score_experiments.txt, items 8-14): 86.0 us for the stage against 95.4 in the two-kernel form at
+// 100 x 500, 0.593 against 0.659 ms at config 3.  What did NOT work on the way: workgroups ALTERNATING between the roles
+// pass by pass (equal to the two kernels: they stay in step, all sweep, then all evaluate), tiles drawn from device
+// counters (the draws' round trips at the start), FIFO places in the order the tiles finish (the heaviest tiles finish
+// last: their units were claimed second and ended the kernel), part of the slots dense from the start.
+// ---------------------------------------------------------------------------------------------
 constexpr int kErrXcdMap = 8;   // device error flag: workgroups of one queue ran on different XCDs, or a FIFO wait timed out
-constexpr int kQHdrBytes = 64 + 2 * kTileBuckets * 4;  // [0] the claimed unit, [1] abort, [2], [3] the next pass's first entry; from [16]: class sizes and their inclusive prefix
+constexpr int kQHdrBytes = 64 + 2 * kTileBuckets * 4;  // [0] the claimed unit, [1] abort; from [16]: class sizes and their inclusive prefix
 constexpr int kQCap = 352;       // the sweep role's pair queue (entries of 8 bytes; emptied into the tile's slot from kQCap - 256 on)
 constexpr int kQSweepWaveBytes = kWin * 48 + kQCap * 8 + 64 * 4;
-constexpr int kQPreBytes = 16 + 64 * 4 + 128 * 4;  // per wave, behind the role area: the NEXT tile's list entry, record index per lane, first window chunk's record indices
 constexpr unsigned kFifoEmpty = 0xFFFFFFFFu;
-constexpr int kQSpinMax = 1 << 20;
+constexpr int kQSpinMax = 1 << 11;  // ~2 ms of waiting for one FIFO entry (a tile takes ~10 us): see the sweep role
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -1316,10 +1316,15 @@ static __device__ __forceinline__ QFirst q_first_level(const Score3Args &a, cons
   return f;
 }
 // sweep role: one wave, one tile (k_score3<true, false, kPerm, true> without the schedule around it)
-template <bool kPerm>
+template <bool kPerm, class Pre>
 static __device__ __forceinline__ void q_sweep_tile(const Score3Args &a, const ScoreCfg &cfg, const double scaleinv_guard2,
                                                     unsigned char *smem_raw, const QFirst &fl, const long long C,
-                                                    const int lane, uint2 *fifo, unsigned *q_alloc, bool &ch_dead) {
+                                                    const int lane, uint2 *fifo, const unsigned f_idx, bool &ch_dead,
+                                                    Pre &&prefetch_next) {  // called once, when the first window is staged
+  // f_idx: the tile's place in the FIFO = its place in the queue's cost-class order (units are then runs of the ORDER, the
+  // most expensive tiles first, whatever the order the tiles finish in: with places handed out at a tile's end the heaviest
+  // tiles of the first pass -- the last to finish -- formed the units that were claimed second, at 45-50 us, and the longest
+  // of them (40 us) ended the kernel at 88)
   const uint4 hdr = fl.hdr;
   float4 *W4 = reinterpret_cast<float4 *>(smem_raw);
   uint2 *queue2 = reinterpret_cast<uint2 *>(smem_raw + (size_t)kWin * 48);
@@ -1369,7 +1374,7 @@ static __device__ __forceinline__ void q_sweep_tile(const Score3Args &a, const S
   }
   int qn = 0, t_cnt = 0, ov_fill = 0;
   unsigned ov_cur = kNoChunk;
-  unsigned f_idx = 0;  // lane 0: this tile's place in the FIFO
+  bool prefetched = false;
   auto ch_alloc = [&]() -> unsigned {
     unsigned id = 0;
     if (lane == 0) id = atomicAdd(&a.sp_counters[0], 1u);
@@ -1383,7 +1388,6 @@ static __device__ __forceinline__ void q_sweep_tile(const Score3Args &a, const S
   };
   auto drain = [&](const bool final) {
     wave_lds_sync();
-    if (final && lane == 0) f_idx = atomicAdd(q_alloc, 1u);  // its round trip runs under the stores below
     const int k0 = min(qn, max(0, a.sp_slot_cap - t_cnt));
     uint4 *dst = a.sp_slots + (size_t)tile * (size_t)a.sp_slot_cap + t_cnt;
     for (int p = lane; p < k0; p += 64) {
@@ -1455,7 +1459,11 @@ static __device__ __forceinline__ void q_sweep_tile(const Score3Args &a, const S
     const float gsf = (float)((gs + delta) * (gs + delta) * (1.0 + 2e-6));
     const float gef = (float)((ge + delta) * (ge + delta) * (1.0 + 2e-6));
     wave_lds_sync();
-    if (wb == lo) { LT_TRACE_MARK(2, tile, 1); }
+    if (wb == lo) {
+      LT_TRACE_MARK(2, tile, 1);
+      prefetch_next();  // (the registers of this tile's first load level are free now)
+      prefetched = true;
+    }
     long long jlo = off > wb ? off : wb;
     long long jhi = (off + n) < (wb + wn) ? (off + n) : (wb + wn);
     const int cnt = (active && jhi > jlo) ? (int)(jhi - jlo) : 0;
@@ -1502,6 +1510,7 @@ static __device__ __forceinline__ void q_sweep_tile(const Score3Args &a, const S
     }
   }
   LT_TRACE_MARK(2, tile, 2);
+  if (!prefetched) prefetch_next();
   drain(true);
   LT_TRACE_MARK(2, tile, 3);
 }
@@ -1509,12 +1518,9 @@ static __device__ __forceinline__ void q_sweep_tile(const Score3Args &a, const S
 #ifndef LT_Q_WAVES_PER_EU
 #define LT_Q_WAVES_PER_EU 4
 #endif
-#ifndef LT_Q_PREFETCH
-#define LT_Q_PREFETCH 1
-#endif
 template <bool kFast, bool kPerm>
 __global__ void __launch_bounds__(64 * kDenseWaves) __attribute__((amdgpu_waves_per_eu(LT_Q_WAVES_PER_EU, LT_Q_WAVES_PER_EU)))
-k_score_q(Score3Args a, ScoreCfg cfg, double scaleinv_guard2, int score_by) {
+k_score_q(Score3Args a, ScoreCfg cfg, double scaleinv_guard2, int score_by, unsigned n_sweep_wgs, int test_lose_tile) {
   extern __shared__ __align__(16) unsigned char smem_all[];
   unsigned *s_hdr = reinterpret_cast<unsigned *>(smem_all);
   unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_all + kQHdrBytes);
@@ -1523,20 +1529,13 @@ k_score_q(Score3Args a, ScoreCfg cfg, double scaleinv_guard2, int score_by) {
   const int tid = threadIdx.x;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int x = (int)(blockIdx.x & (unsigned)(kTileQueues - 1));
+  const int x = (int)(blockIdx.x & (unsigned)(kTileQueues - 1));  // n_sweep_wgs is a multiple of 8: the same rule in both roles
   const long long C = a.tri_off[a.G];
   const int T = a.sp_t_max;
   const int max_nb = a.max_nb;
   const int cap = a.sp_slot_cap;
   uint2 *fifo = a.pc_list + (size_t)x * a.pc_cap;
-  unsigned *q_alloc = a.draw + x * 32;
   unsigned *q_claim = a.sp_counters + 32 * (1 + x);
-  unsigned *q_sweep = a.draw + (3 * kTileQueues + 1 + x) * 32;
-  // tiles are CLAIMED, four consecutive entries of the queue's order per pass (no static share: a workgroup that is not
-  // resident yet owes nothing; nobody ever waits for a tile that is not already being swept)
-  unsigned k_raw = 0;
-  if (tid == 0) k_raw = atomicAdd(q_sweep, (unsigned)kDenseWaves);
-  unsigned char *smem_wave = smem_all + kQHdrBytes + (size_t)wave * kQSweepWaveBytes;
   // the queue's tiles in class order, most expensive class first: entry l < kTileBuckets of the two LDS vectors is class
   // kTileBuckets - 1 - l (every wave writes the same values: no barrier needed for its own reads)
   unsigned *s_cls_cnt = s_hdr + 16, *s_cls_incl = s_hdr + 16 + kTileBuckets;
@@ -1548,90 +1547,80 @@ k_score_q(Score3Args a, ScoreCfg cfg, double scaleinv_guard2, int score_by) {
     if (lane < kTileBuckets) { s_cls_cnt[lane] = cls_cnt; s_cls_incl[lane] = cls_incl; }
     wave_lds_sync();
   }
-  auto fetch_x_ptr = [&](const unsigned k) -> const uint4 * {  // k < n_x, wave-uniform
+  auto fetch_x = [&](const unsigned k) -> uint4 {  // k < n_x, wave-uniform
     const unsigned incl = lane < kTileBuckets ? s_cls_incl[lane] : 0xFFFFFFFFu;
     const int l = __builtin_ctzll(__ballot(incl > k));
     const unsigned base = s_cls_incl[l] - s_cls_cnt[l];
-    return reinterpret_cast<const uint4 *>(a.bucket_list) + ((size_t)(x * kTileBuckets + (kTileBuckets - 1 - l)) * a.bucket_cap + (k - base));
+    return reinterpret_cast<const uint4 *>(a.bucket_list)[(size_t)(x * kTileBuckets + (kTileBuckets - 1 - l)) * a.bucket_cap + (k - base)];
   };
-  auto fetch_x = [&](const unsigned k) -> uint4 { return *fetch_x_ptr(k); };
-  // per wave, behind both roles' areas: where the next tile's first loads land
-  unsigned *pre_hdr = reinterpret_cast<unsigned *>(smem_all + a.sp_wave_lds + (size_t)wave * kQPreBytes);
-  unsigned *pre_pi = pre_hdr + 4, *pre_w = pre_hdr + 4 + 64;
-  if (tid == 0) s_hdr[1] = 0u;
-  unsigned produced = 0, consumed = 0;
-  unsigned c_raw = 0;  // thread kThreads - 64: the unit it has claimed
-  bool prev_sweep = true, ch_dead = false;
-  unsigned n_pairs_wg = 0;  // pair statistic of this workgroup (lanes < T of the first wave)
-  if (tid == 0) s_hdr[2] = k_raw;
-  __syncthreads();
-  // a claim is a GROUP of four consecutive entries of the queue's order (group g = entries 4 g .. 4 g + 3).  (Measured and
-  // dropped: the first claims alternating between the expensive and the cheap end of the order, so that half of the
-  // workgroups come back early and the roles interleave from the start -- 97.6 against 95.1 us.)
-  const unsigned n_grp = (n_x + (unsigned)kWaves - 1u) / (unsigned)kWaves;
-  auto group_of = [&](const unsigned g) -> unsigned { return g; };
-  unsigned gi = (unsigned)__builtin_amdgcn_readfirstlane((int)s_hdr[2]) / (unsigned)kWaves;
-  int par = 1;  // s_hdr[2 + par]: the next pass's claim (two cells in turn: a slow wave still reads the last one)
-  int pre_stage = 0;  // the next tile's prefetch: 1 = its list entry is on the way to LDS, 2 = its first load level too
-  while (gi < n_grp) {
-    // ---- sweep role: the four entries of group group_of(gi), one tile per wave
-    const unsigned k_base = group_of(gi) * (unsigned)kWaves;
-    produced += min((unsigned)kWaves, n_x - k_base);
-    if (tid == 0) k_raw = atomicAdd(q_sweep, (unsigned)kWaves);  // the next pass's tiles
-    bool want = produced / (unsigned)T > consumed;
-    if (want && tid == kThreads - 64) c_raw = atomicAdd(q_claim, 1u);
-    if (k_base + (unsigned)wave < n_x) {
-      QFirst fl;
-      if (pre_stage == 0) {
-        fl = q_first_level<kPerm>(a, fetch_x(k_base + (unsigned)wave), C, lane);
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA loads of this tile's entry (and first level)
-        const uint4 hdr = uint4{pre_hdr[0], pre_hdr[1], pre_hdr[2], 0u};
-        if (pre_stage == 1) {
-          fl = q_first_level<kPerm>(a, hdr, C, lane);
-        } else {
-          fl.hdr = hdr;
-          fl.mt = CandMeta{0u, 0u, 0u, 0u};
-          const long long tp = (long long)hdr.x * 64 + lane;
-          if (tp < C) fl.mt = a.meta[tp];
-          fl.p_i = pre_pi[lane]; fl.w0 = pre_w[lane]; fl.w1 = pre_w[64 + lane];
-        }
-      }
-      q_sweep_tile<kPerm>(a, cfg, scaleinv_guard2, smem_wave, fl, C, lane, fifo, q_alloc, ch_dead);
-    }
-    pre_stage = 0;
-    if (tid == 0) s_hdr[2 + par] = k_raw;
-    if (want && tid == kThreads - 64) s_hdr[0] = c_raw;
+  unsigned n_pairs_wg = 0;  // pair statistic of this workgroup (dense role: lanes < T of the first wave)
+  if (blockIdx.x < n_sweep_wgs) {
+    // ---- sweep role.  The workgroup's SHARE of the queue's order is static as in k_score3<split> -- pass m takes entries
+    // [m W, (m + 1) W) of the order (W = sweep waves of this queue), forwards for even m and backwards for odd m, this
+    // workgroup the four entries of its four ranks -- and its four waves draw from that share through a counter in LDS (the
+    // workgroup turns to the dense role when its last wave is through).  The next tile is drawn at the start of the current
+    // one, its list entry fetched then and its first load level once the current window is staged.
+    // (Measured and dropped: every wave drawing its tiles from per-queue device counters, 16 first-draw counters per queue
+    // against the burst at the start -- no share is owed by a workgroup that is not resident, so nothing could ever wait on
+    // one --: 98-100 us against 86, the draws' round trips at the start of 4 096 waves cost what the form gains.  With static
+    // shares a grid that is not fully resident -- another kernel on the GPU -- can leave a unit waiting for a tile nobody
+    // sweeps yet: the wait is bounded (kQSpinMax, ~2 ms), raises device flag 8 and the run is repeated in the two-kernel form.)
+    const unsigned W_x = (n_sweep_wgs >> 3) * (unsigned)kWaves;
+    const unsigned r0 = (blockIdx.x >> 3) * (unsigned)kWaves;
+    unsigned char *smem_wave = smem_all + kQHdrBytes + (size_t)wave * kQSweepWaveBytes;
+    if (tid == 0) s_hdr[2] = 0u;
     __syncthreads();
-    prev_sweep = true;
-    gi = (unsigned)__builtin_amdgcn_readfirstlane((int)s_hdr[2 + par]) / (unsigned)kWaves;
-    par ^= 1;
-    const bool draining = gi >= n_grp;  // no tile left to sweep: this workgroup helps to empty the FIFO
-    const unsigned k_next = draining ? n_x : group_of(gi) * (unsigned)kWaves + (unsigned)wave;  // this wave's next entry
-#if LT_Q_PREFETCH
-    if (k_next < n_x) {
-      const uint4 *ent = fetch_x_ptr(k_next);
-      if (lane == 0) __builtin_amdgcn_global_load_lds((gbl_void_t *)ent, (lds_void_t *)pre_hdr, 16, 0, 0);
-      pre_stage = 1;
-    }
-#endif
-    if (draining && !want) {
-      if (tid == kThreads - 64) s_hdr[0] = atomicAdd(q_claim, 1u);
-      __syncthreads();
-      want = true;
-    }
-    // ---- dense role: units of T consecutive FIFO entries
-    bool any_dense = false;
-    while (want) {
-      const unsigned u_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)s_hdr[0]);
-      const unsigned long long e0 = (unsigned long long)u_cur * (unsigned)T;
-      if (e0 >= n_x) {
-        if (draining) goto done;  // every unit of this queue is claimed
-        break;
+    bool ch_dead = false;
+    auto draw = [&]() -> unsigned {  // -> this wave's next entry of the order, n_x when the share is used up
+      for (;;) {
+        unsigned idx = 0;
+        if (lane == 0) idx = atomicAdd(&s_hdr[2], 1u);
+        idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+        const unsigned pass = idx >> 2, rr = r0 + (idx & 3u);
+        if ((unsigned long long)pass * W_x >= n_x) return n_x;
+        const unsigned kk = pass * W_x + ((pass & 1u) ? W_x - 1u - rr : rr);
+        if (kk < n_x) return kk;  // (a rank without an entry in the last pass: draw on)
       }
-      ++consumed;
-      any_dense = true;
-      const bool more = draining || produced / (unsigned)T > consumed;
+    };
+    unsigned k = draw();
+    QFirst fl;
+    if (k < n_x) fl = q_first_level<kPerm>(a, fetch_x(k), C, lane);
+    while (k < n_x) {
+      const unsigned k_n = draw();
+      uint4 hdr_n = uint4{0u, 0u, 0u, 0u};
+      if (k_n < n_x) hdr_n = fetch_x(k_n);
+      QFirst fl_n;
+      fl_n.hdr = hdr_n; fl_n.mt = CandMeta{0u, 0u, 0u, 0u}; fl_n.p_i = 0; fl_n.w0 = 0; fl_n.w1 = 0;
+      // (LT_TEST_Q_LOSE_TILE: the first tile of queue 0 is never swept -- its unit's wait runs into the bound, device flag 8)
+      if (test_lose_tile && x == 0 && k == 0) {
+        if (k_n < n_x) fl_n = q_first_level<kPerm>(a, hdr_n, C, lane);
+      } else {
+        q_sweep_tile<kPerm>(a, cfg, scaleinv_guard2, smem_wave, fl, C, lane, fifo, k, ch_dead,
+                     [&]() { if (k_n < n_x) fl_n = q_first_level<kPerm>(a, hdr_n, C, lane); });
+      }
+      fl = fl_n;
+      k = k_n;
+    }
+    __syncthreads();  // the four windows are done with: the tables of the dense role lie over them
+  }
+  {
+    // ---- dense role (a sweep workgroup goes on here when its share is swept -- no new workgroup has to be dispatched into
+    // its slot and set up --, a workgroup behind the sweep workgroups starts here): units of T consecutive FIFO entries, every one of them CLAIMED (claim c = unit c; the later claims are
+    // issued before the last round of the unit before).  No static first unit: dense workgroups arrive as the sweep
+    // workgroups end, over 15 us, and the front of the FIFO holds the most expensive tiles -- with unit = rank the heaviest
+    // units waited for the workgroups that arrive last (the longest unit, 40 us, then started at 40 us).
+    const unsigned n_units = (n_x + (unsigned)T - 1u) / (unsigned)T;
+    const unsigned d_wgs = 0u;
+    unsigned c_raw = 0;  // thread kThreads - 64: its claim
+    if (tid == kThreads - 64) {
+      s_hdr[1] = 0u;
+      s_hdr[0] = atomicAdd(q_claim, 1u);
+    }
+    for (int k = tid; k < T * max_nb * 64; k += kThreads) S[k] = 0ull;
+    __syncthreads();
+    unsigned u_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)s_hdr[0]);
+    while (u_cur < n_units) {
+      const unsigned long long e0 = (unsigned long long)u_cur * (unsigned)T;
       const int nt = (int)min((unsigned long long)T, (unsigned long long)n_x - e0);
       LT_TRACE_MARK(3, u_cur * 8u + (unsigned)x, 0);
       // the unit's header (tile and pair count of its tiles) in lanes < nt of EVERY wave: wait for the producers
@@ -1656,10 +1645,6 @@ k_score_q(Score3Args a, ScoreCfg cfg, double scaleinv_guard2, int score_by) {
         }
       }
       if (tid < nt) n_pairs_wg += h_cnt;
-      if (prev_sweep) {  // the sweep's windows lay over the tables
-        for (int k = tid; k < T * max_nb * 64; k += kThreads) S[k] = 0ull;
-        prev_sweep = false;
-      }
       int off[kChunkTiles + 1];
       off[0] = 0;
 #pragma unroll
@@ -1722,7 +1707,7 @@ k_score_q(Score3Args a, ScoreCfg cfg, double scaleinv_guard2, int score_by) {
       }
       const int n_it3 = total > kThreads - 64 ? (total - (kThreads - 64) + kThreads - 1) / kThreads : 0;
       auto claim = [&]() {
-        if (more && tid == kThreads - 64) c_raw = atomicAdd(q_claim, 1u);
+        if (tid == kThreads - 64) c_raw = atomicAdd(q_claim, 1u);
       };
       if (n_it3 <= 1) claim();
       auto eval = [&](const uint4 e, const int k) {
@@ -1757,27 +1742,10 @@ k_score_q(Score3Args a, ScoreCfg cfg, double scaleinv_guard2, int score_by) {
           cc = nxt;
         }
       }
-      if (more && tid == kThreads - 64) s_hdr[0] = c_raw;
+      if (tid == kThreads - 64) s_hdr[0] = d_wgs + c_raw;  // claim c of this queue is unit d_wgs + c
       __syncthreads();  // every pair of the unit is in the tables
       LT_TRACE_MARK(3, u_cur * 8u + (unsigned)x, 2);
       asm volatile("" : "+v"(ordv[0]), "+v"(ordv[1]));
-#if LT_Q_PREFETCH
-      if (pre_stage == 1) {
-        // the next tile's list entry has landed (the rounds' loads came back behind it): its record index per lane and the
-        // record indices of its first window chunk, global -> LDS by the DMA path, no register holds them across the sums
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned n_tile = pre_hdr[0], n_lo = pre_hdr[1], n_hi = pre_hdr[2];
-        const long long tp = (long long)n_tile * 64 + lane;
-        if (tp < C) __builtin_amdgcn_global_load_lds((gbl_void_t *)(a.perm + tp), (lds_void_t *)pre_pi, 4, 0, 0);
-        if (n_hi > n_lo) {
-          const unsigned w = (n_hi - n_lo) < (unsigned)kWin ? (n_hi - n_lo) : (unsigned)kWin;
-          if ((unsigned)lane < w) __builtin_amdgcn_global_load_lds((gbl_void_t *)(a.perm + (size_t)n_lo + lane), (lds_void_t *)pre_w, 4, 0, 0);
-          if ((unsigned)lane + 64u < w)
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(a.perm + (size_t)n_lo + 64 + lane), (lds_void_t *)(pre_w + 64), 4, 0, 0);
-        }
-        pre_stage = 2;
-      }
-#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int ti = wave + kWaves * h;
@@ -1814,11 +1782,9 @@ k_score_q(Score3Args a, ScoreCfg cfg, double scaleinv_guard2, int score_by) {
         if (act) a.score[score_by == 1 ? pos[h] : (score_by == 2 ? (long long)a.spos[pos[h]] : (long long)rrec[h])] = sum;
       }
       LT_TRACE_MARK(3, u_cur * 8u + (unsigned)x, 3);
-      want = more;
+      u_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)s_hdr[0]);  // (written in front of the rounds' barrier)
     }
-    if (any_dense && !draining) __syncthreads();  // the sums are done before the next pass's windows overwrite the tables
   }
-done:
   if (tid < 64) {
     unsigned long long np = (unsigned long long)n_pairs_wg;
     for (int d = 32; d >= 1; d >>= 1) np += (unsigned long long)__shfl_xor((long long)np, d);
@@ -1872,7 +1838,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
                    unsigned *bucket_list, unsigned bucket_cap, const unsigned *place, unsigned *rec, const float *st_z,
                    int *err_flag, void *sp_slots, int sp_slot_cap, unsigned *sp_cnt, unsigned *sp_ovf, void *sp_pairs,
                    void *sp_desc, long long sp_chunks, hipEvent_t ev_after, const void *node_rec, unsigned *pc_cnt,
-                   void *pc_list, unsigned pc_cap, bool one_kernel) {
+                   void *pc_list, unsigned pc_cap, int one_kernel) {
   // ev_before / ev_after: bound as the STOP events of k_cand_meta and of the stage's last kernel (hipExtLaunchKernelGGL:
   // the kernel's own completion signal carries the timestamp) -- a hipEventRecord between two kernels is a barrier packet
   // that opens a ~5.5 us gap in the stream (LT_EV_MARKERS=1: the plain records, for comparison)
@@ -1883,7 +1849,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   if (C <= 0) return;
   // one_kernel: the split form as ONE persistent kernel (k_score_q) where it applies: single-precision sweep over the
   // placement permutation (matched mode), cost-class lists and the pair store present
-  const bool q_form = one_kernel && sp_slots != nullptr && f32 && perm != nullptr && perm_is_placement && rng == nullptr &&
+  const bool q_form = one_kernel != 0 && sp_slots != nullptr && f32 && perm != nullptr && perm_is_placement && rng == nullptr &&
                       bucket_cnt != nullptr && pc_list != nullptr;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -1941,10 +1907,8 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   const dim3 grid((unsigned)std::min<long long>(n_tiles, per_cu * n_cu)), block(64);
   if (split && q_form) {
     a.pc_cnt = nullptr;  // (the FIFOs live in pc_list; no pair-count classes)
-    // LDS: header | the roles' area (four sweep windows + queues, or the unit's tables of maxima) | four prefetch areas
-    const size_t lds_roles = (size_t)kQHdrBytes + std::max((size_t)kDenseWaves * (size_t)kQSweepWaveBytes, (size_t)a.sp_t_max * (size_t)max_nb * 512);
-    a.sp_wave_lds = (int)lds_roles;  // (here: where the prefetch areas start)
-    const size_t ldsq = lds_roles + (size_t)kDenseWaves * (size_t)kQPreBytes;
+    // LDS: header | the role's area (four sweep windows + queues, or the unit's tables of maxima)
+    const size_t ldsq = (size_t)kQHdrBytes + std::max((size_t)kDenseWaves * (size_t)kQSweepWaveBytes, (size_t)a.sp_t_max * (size_t)max_nb * 512);
     static int occ_q[2] = {0, 0};
     static size_t occ_q_lds[2] = {0, 0};
     const int v = cfg.fast ? 1 : 0;
@@ -1955,12 +1919,17 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
       occ_q[v] = (e == hipSuccess && o > 0) ? o : 1;
       occ_q_lds[v] = ldsq;
     }
-    // every workgroup that can be resident, a multiple of 8 (queue = workgroup % 8 = XCD); at most one per four tiles
-    long long wgs = std::min<long long>((long long)occ_q[v] * n_cu, (n_tiles + kDenseWaves - 1) / kDenseWaves + 7);
-    wgs = std::max<long long>(8, wgs & ~7ll);
-    const dim3 gq((unsigned)wgs);
-    if (cfg.fast) hipExtLaunchKernelGGL((k_score_q<true, true>), gq, dim3(64 * kDenseWaves), ldsq, st, nullptr, ev_stop, 0, a, cfg, scaleinv_guard2, 1);
-    else hipExtLaunchKernelGGL((k_score_q<false, true>), gq, dim3(64 * kDenseWaves), ldsq, st, nullptr, ev_stop, 0, a, cfg, scaleinv_guard2, 1);
+    // sweep workgroups first (four waves, one tile each at a time; they go on as dense workgroups when their share is swept),
+    // dense-only workgroups in the slots a small job leaves: both counts multiples of 8 (queue = workgroup % 8 = XCD in
+    // either role).  (Measured: 7 / 6 / 4 eighths of the slots starting in the sweep role and the rest as dense workgroups
+    // from the start -- 88.5 / 89.1 / 88.9 us against 86.2 with all of them sweeping first.)
+    const long long slots = std::max<long long>(8, ((long long)occ_q[v] * n_cu) & ~7ll);
+    const long long n_sw = std::max<long long>(8, std::min<long long>(slots, ((n_tiles + kDenseWaves - 1) / kDenseWaves + 7) & ~7ll));
+    const long long n_units_b = (n_tiles + a.sp_t_max - 1) / a.sp_t_max;
+    const long long n_de = std::max<long long>(0, std::min<long long>(slots - n_sw, (n_units_b + 7) & ~7ll));
+    const dim3 gq((unsigned)(n_sw + n_de));
+    if (cfg.fast) hipExtLaunchKernelGGL((k_score_q<true, true>), gq, dim3(64 * kDenseWaves), ldsq, st, nullptr, ev_stop, 0, a, cfg, scaleinv_guard2, 1, (unsigned)n_sw, one_kernel == 2 ? 1 : 0);
+    else hipExtLaunchKernelGGL((k_score_q<false, true>), gq, dim3(64 * kDenseWaves), ldsq, st, nullptr, ev_stop, 0, a, cfg, scaleinv_guard2, 1, (unsigned)n_sw, one_kernel == 2 ? 1 : 0);
     if (ev_after && ev_markers) (void)hipEventRecord(ev_after, st);
     return;
   }

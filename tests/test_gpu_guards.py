@@ -41,7 +41,7 @@ def clean_env():
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
             "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TIMER_SAMPLE", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_SCORE_SPLIT",
             "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS", "LT_TEST_PAIR_SCORE_TERMS", "LT_TEST_NO_PAIR_CLASSES", "LT_TEST_GATES_IMAGE_MAJOR",
-            "LT_SCORE_ONE_KERNEL")
+            "LT_SCORE_TWO_KERNELS", "LT_TEST_Q_LOSE_TILE")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -465,6 +465,37 @@ def test_scoring_sweep_forms_agree(gpu_lib, clean_env, topk, n_nb):
 
 @pytest.mark.parametrize("topk,n_nb", [(10, 6), (60, 13)])
 def test_split_and_fused_scoring_agree(gpu_lib, clean_env, topk, n_nb):
+    """The scoring stage runs as ONE kernel by default (k_score_q, round 6: workgroups sweep their share of the tiles and
+    publish each finished tile in their XCD's FIFO, then turn to evaluating units of finished tiles), keeps the two-kernel
+    form of rounds 4-6 (sweep kernel -> k_dense8; LT_SCORE_TWO_KERNELS, and the fallback behind device flag 8) and the fused
+    k_score3 as the last fallback.  Same bits from: the two-kernel form, also with overflow chains everywhere; a run in which
+    a tile is never published (LT_TEST_Q_LOSE_TILE: a unit's wait runs into its bound, flag 8, the run is repeated in the
+    two-kernel form and the context stays there); the fused kernel (LT_SCORE_FUSED); slots of four entries
+    (every tile with more pairs continues in a chain of overflow chunks); an overflow store of one chunk (the store
+    fills, device flag 7, the run is repeated fused and the context stays fused); the split form over the natural tile
+    order; the split form of the exhaustive mode (not its default)."""
+    sc = syn.make_scene(n_views=14, n_segs=140, n_neighbors=n_nb, seed=77, topk=topk)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    base = _results(run_product(sc, cfg, topk=topk))
+    assert base[5]["candidates"] > 1000
+    if topk > 10:
+        assert np.diff(base[0]["off"]).max() > 100, "the scene is meant to have windows beyond one chunk"
+    os.environ["LT_TEST_SCORE_F64"] = "1"
+    f64 = _results(run_product(sc, cfg, topk=topk))
+    _same(base, f64)
+    del os.environ["LT_TEST_SCORE_F64"]
+    os.environ["LT_TEST_NO_TILE_CLASSES"] = "1"
+    nat = _results(run_product(sc, cfg, topk=topk))
+    _same(base, nat)
+    del os.environ["LT_TEST_NO_TILE_CLASSES"]
+    os.environ["LT_TEST_NO_SCORE_GUARDS"] = "1"
+    allp = _results(run_product(sc, cfg, topk=topk))
+    _same(base, allp)
+    assert allp[4]["pairs_eval"] > base[4]["pairs_eval"]
+
+
+@pytest.mark.parametrize("topk,n_nb", [(10, 6), (60, 13)])
+def test_split_and_fused_scoring_agree(gpu_lib, clean_env, topk, n_nb):
     """The scoring stage runs as two kernels by default (sweep -> pair slots per tile -> k_dense8 over units of tiles) and
     keeps the fused k_score3 as the fallback.  Same bits from: the ONE-kernel form of round 6 (k_score_q, LT_SCORE_ONE_KERNEL:
     workgroups alternate between sweeping tiles and evaluating units of finished tiles from their XCD's FIFO; measured, not
@@ -475,14 +506,19 @@ def test_split_and_fused_scoring_agree(gpu_lib, clean_env, topk, n_nb):
     sc = syn.make_scene(n_views=14, n_segs=140, n_neighbors=n_nb, seed=77, topk=topk)
     cfg = syn.default_triangulation_cfg(debug_mode=True)
     base = _results(run_product(sc, cfg, topk=topk))
-    assert base[5]["candidates"] > 1000 and base[4]["pairs_eval"] > 1000
-    os.environ["LT_SCORE_ONE_KERNEL"] = "1"
-    one = _results(run_product(sc, cfg, topk=topk))
-    _same(base, one)
-    assert one[4]["pairs_eval"] == base[4]["pairs_eval"] and one[4]["score_two_kernels"] == 0
+    assert base[5]["candidates"] > 1000 and base[4]["pairs_eval"] > 1000 and base[4]["score_two_kernels"] == 0
+    os.environ["LT_SCORE_TWO_KERNELS"] = "1"
+    two = _results(run_product(sc, cfg, topk=topk))
+    _same(base, two)
+    assert two[4]["pairs_eval"] == base[4]["pairs_eval"]
     os.environ["LT_TEST_SPLIT_SLOT"] = "4"
     _same(base, _results(run_product(sc, cfg, topk=topk)))
-    del os.environ["LT_SCORE_ONE_KERNEL"], os.environ["LT_TEST_SPLIT_SLOT"]
+    del os.environ["LT_SCORE_TWO_KERNELS"], os.environ["LT_TEST_SPLIT_SLOT"]
+    os.environ["LT_TEST_Q_LOSE_TILE"] = "1"
+    lost = _results(run_product(sc, cfg, topk=topk))
+    _same(base, lost)
+    assert lost[4]["score_two_kernels"] == 1
+    del os.environ["LT_TEST_Q_LOSE_TILE"]
     os.environ["LT_SCORE_FUSED"] = "1"
     fused = _results(run_product(sc, cfg, topk=topk))
     _same(base, fused)

@@ -1,0 +1,44 @@
+"""Developer tool: the end-to-end call sequence under the conditions bench.py measures it in (torch imported and initialised,
+the Python track list built, a post-processing chain between repetitions), one factor at a time.
+   python tools/profile_e2e_variants.py [torch] [tracks] [post] [ranks]"""
+import gc, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+flags = set(sys.argv[1:])
+if "torch" in flags:
+    import torch
+    torch.cuda.init()
+    x = torch.zeros(1 << 20, device="cuda:0")
+    torch.cuda.synchronize()
+import numpy as np
+from limap_amd import synthetic as syn, triangulation as tri, merging
+sc = syn.make_scene(n_views=100, n_segs=500, n_neighbors=20, seed=0)
+cfg = syn.default_triangulation_cfg()
+matches = {int(i): sc.matches_of(int(i)) for i in sc.img_ids}
+segs_list = [sc.segs_of(j) for j in range(sc.n_images)]
+res = []
+for rep in range(7):
+    gc.collect(); gc.disable()
+    t0 = time.perf_counter()
+    T = tri.GlobalLineTriangulator(cfg)
+    T.SetRanges(sc.ranges)
+    T.InitArrays(sc.img_ids, sc.kvec, sc.qvec, sc.tvec, segs_list)
+    t1 = time.perf_counter()
+    for i in sc.img_ids:
+        T.TriangulateImage(int(i), matches[int(i)])
+    t2 = time.perf_counter()
+    if "tracks" in flags:
+        tr = T.ComputeLineTracks()
+    else:
+        T.context().compute_tracks()
+    t3 = time.perf_counter()
+    if "post" in flags:
+        ts = merging.TrackSet.from_triangulator(T)
+        ts.filter_by_reprojection(8.0, 5.0).remerge(dict(linker2d={}, linker3d={})) if False else ts.filter_by_reprojection(8.0, 5.0)
+        ts.filter_by_sensitivity(75.0, 3).filter_by_overlap(0.5, 3)
+        del ts
+    gc.enable()
+    tm = T.timers()
+    res.append((t1 - t0, t2 - t1, t3 - t2, t3 - t0))
+    del T
+r = 1e3 * np.median(np.array(res[2:]), axis=0)
+print(sorted(flags), "ctor_init %.2f buffer %.2f compute_tracks %.2f total %.2f" % tuple(r), "[upload %.2f run %.2f tail %.2f]" % (tm["upload"], tm["run"], tm["tail"]))

@@ -64,4 +64,14 @@ for lo_, hi_ in ((0, 16), (16, 24), (24, 32), (32, 48), (48, 64), (64, 400)):
 report(t2, ["prologue+window", "sweep (+mid stores)", "final stores"], "sweep kernel (tiles)", int(os.environ.get("SLOTS1", 3072)))
 if (t3[:, 3] > 0).any():
     report(t3, ["clear+loads", "rounds", "sums"], "k_dense8 (units)", int(os.environ.get("SLOTS2", 768)))
+    a2, a3 = t2[t2[:, 3] > 0], t3[t3[:, 3] > 0]
+    o = a2[:, 0].min()
+    print("common clock (us from the first tile's start): tiles end", (a2[:, 3].max() - o) / 100.0, "| first unit starts", (a3[:, 0].min() - o) / 100.0,
+          "| unit starts pct 10/50/90", np.percentile((a3[:, 0] - o) / 100.0, [10, 50, 90]).round(1), "| last unit ends", (a3[:, 3].max() - o) / 100.0)
+    # busy workgroup-time of the dense role against the slots' time from the first unit's start to the last unit's end
+    st_, en_ = (a3[:, 0] - o) / 100.0, (a3[:, 3] - o) / 100.0
+    for lo_, hi_ in ((0, 20), (20, 30), (30, 40), (40, 50), (50, 60), (60, 70), (70, 80), (80, 90), (90, 120)):
+        busy = np.clip(np.minimum(en_, hi_) - np.maximum(st_, lo_), 0, None).sum() / (hi_ - lo_)
+        til = np.clip(np.minimum((a2[:, 3] - o) / 100.0, hi_) - np.maximum((a2[:, 0] - o) / 100.0, lo_), 0, None).sum() / (hi_ - lo_)
+        print(f"  [{lo_},{hi_}) us: units busy on average {busy:.0f} workgroups, tiles busy {til:.0f} waves")
 print("timers", {k: round(v, 4) for k, v in ctx.timers().items() if k in ("k_score3", "run")})
