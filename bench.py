@@ -410,7 +410,7 @@ def streamed_config5_leg(cfg, rank, world, local_rank, dev, use_dist, pmc_path=N
         d = json.load(open(pmc_path))
         if d.get("device_source_hash") == device_source_hash():
             pmc = d.get("kernels", {})
-    names = {"gates": "k_gates_ln (stage A)", "tri": "k_tri_rounds (stage B)", "score": "scoring stage (k_score3 sweep + k_dense8)"}
+    names = {"gates": "k_gates_ln (stage A)", "tri": "k_tri_rounds (stage B)", "score": "scoring stage (k_score_q)"}
     roof = {}
     for k in keys:
         gbs = B[k] / (T[k] * 1e-3) / 1e9 if T[k] > 0 else 0.0
@@ -524,11 +524,11 @@ def e2e_child(views, segs, neighbors, seed, topk):
             gc.enable()
             del T, tracks
     med = lambda v: float(np.median(v[1:]))  # repetition 0 is the cold one
-    print("E2E_CHILD " + json.dumps({
+    _emit("E2E_CHILD " + json.dumps({
         "e2e_wall_ms": med(per_image), "e2e_with_postprocess_ms": med(with_post), "e2e_batched_ms": med(batched),
         "e2e_reps_ms": [round(x, 3) for x in per_image], "e2e_with_postprocess_reps_ms": [round(x, 3) for x in with_post],
         "e2e_batched_reps_ms": [round(x, 3) for x in batched], "e2e_reps_parts": parts, "tracks": n_tracks,
-        "tracks_after_postprocess": n_post, "torch_in_process": "torch" in sys.modules}), flush=True)
+        "tracks_after_postprocess": n_post, "torch_in_process": "torch" in sys.modules}))
 
 
 def main():
@@ -715,7 +715,7 @@ def main():
     if acc.get("survivors", 0.0) == 0.0:  # counted on demand when the run did not have it on the host
         acc["survivors"] = last["survivors"] * max(args.steps, 1)
     kt = {k: v / max(args.steps, 1) for k, v in acc.items()}  # average HIP-event ms per launch
-    # The timed region carries the events around the dominant stage only (scoring = k_score3 + k_dense8: roofline).  The generation
+    # The timed region carries the events around the dominant stage only (scoring = k_score_q: roofline).  The generation
     # kernels are priced in a few extra steps with their own events on (LT_FINE_TIMERS=2 costs ~5 us per step).
     if args.mode == "matched":
         prev_fine = os.environ.get("LT_FINE_TIMERS")
@@ -840,7 +840,12 @@ def main():
             # scoring = scoreOneNode as TWO kernels since round 4 (k_score3: the sweep, writes the pairs that pass; k_dense8:
             # pair_score over them, maxima, sums), timed as one stage by the events around them; its counters are the sums
             # of the two kernels' (LT_SCORE_FUSED=1: one kernel, k_score3)
-            if "k_dense8" in pmc and "k_score3" in pmc and not os.environ.get("LT_SCORE_FUSED"):
+            # Round 6: ONE kernel again, k_score_q (sweep role, then dense role, per workgroup) -- its counters are the stage's
+            two_kernels = bool(last.get("score_two_kernels", 0.0)) or bool(os.environ.get("LT_SCORE_TWO_KERNELS"))
+            if "k_score_q" in pmc and not two_kernels and not os.environ.get("LT_SCORE_FUSED"):
+                pmc = dict(pmc)
+                pmc["k_score3"] = dict(pmc["k_score_q"])
+            elif "k_dense8" in pmc and "k_score3" in pmc and not os.environ.get("LT_SCORE_FUSED"):
                 a_, b_ = pmc["k_score3"], pmc["k_dense8"]
                 pmc = dict(pmc)
                 pmc["k_score3"] = {k: (a_[k] + b_[k]) for k in a_ if k in b_ and isinstance(a_[k], (int, float))
@@ -880,9 +885,11 @@ def main():
                        "valid_edges_rank0": st["valid_edges"], "tracks_rank0": st_after["tracks"]},
             "kernel_ms": kt,
             "connections_per_s": conn_total * args.steps / elapsed,
-            "roofline": dict(roof[dom], kernel=("k_score3 + k_dense8 (the scoring stage: sweep kernel + dense kernel, one pair of events)"
-                                                if dom == "k_score3" and args.mode == "matched" and not os.environ.get("LT_SCORE_FUSED")
-                                                else dom),
+            "roofline": dict(roof[dom], kernel=(dom if not (dom == "k_score3" and args.mode == "matched" and not os.environ.get("LT_SCORE_FUSED"))
+                                                else ("k_score3 + k_dense8 (the scoring stage in its two-kernel form: sweep kernel + dense kernel, one pair of events)"
+                                                      if (kt.get("score_two_kernels") or os.environ.get("LT_SCORE_TWO_KERNELS"))
+                                                      else "k_score_q (the scoring stage, scoreOneNode, as one kernel: every workgroup sweeps its share "
+                                                           "of the tiles, then evaluates units of finished tiles)")),
                              event_sampling=f"HIP events around the stage on every {event_sampling}. step of the timed region "
                                             "(LT_TIMER_SAMPLE; each event is a ~5 us bubble in the stream)"),
             "roofline_all": roof,

@@ -90,7 +90,7 @@ for mode in ("matched", "exhaustive"):
 import os
 json.dump(out, open("gpurun_out/%s_pmc.json" % os.environ.get("TAG", "r06"), "w"), indent=1)
 for mode, kern in out["kernels"].items():
-    for n in ("k_score3", "k_dense8", "k_gates", "k_tri_rows", "k_place", "k_gen_exhaustive"):
+    for n in ("k_score_q", "k_score3", "k_dense8", "k_gates", "k_tri_rows", "k_place", "k_gen_exhaustive"):
         if n in kern:
             print(mode, n, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in kern[n].items() if a != "raw"})
 PY

@@ -33,7 +33,7 @@ def hbm(v):
 out = {"device_source_hash": bench.device_source_hash(),
        "workload": "bench.py --stream on 1000 x 600 in four chunks of 250 images (LT_BENCH_STREAM_SCENE=1000,600,20,250): per-launch = per-chunk averages",
        "how": "tools/prof_stream_pmc.sh; units as in r06_pmc.json", "kernels": {}, "raw": vals}
-names = {"k_gates": ["k_gates_ln"], "k_tri_rows": ["k_tri_rounds"], "k_score3": ["k_score3", "k_dense8"]}
+names = {"k_gates": ["k_gates_ln"], "k_tri_rows": ["k_tri_rounds"], "k_score3": ["k_score3", "k_dense8", "k_score_q"]}
 for key, ks in names.items():
     tot = [0.0, 0.0, 0.0]
     for k in ks:
