@@ -478,10 +478,11 @@ def _emit(line):
 
 def e2e_child(views, segs, neighbors, seed, topk):
     """`bench.py --e2e-child ...`: the reference's call sequence in a process WITHOUT torch -- what a caller of the library
-    that does not import torch sees.  torch's wheel ships its own libamdhip64.so.7 / libhsa-runtime64 (ROCm 7.0); a process
-    that imports torch first makes every later library with that soname -- liblimap_amd.so included -- run on THOSE instead
-    of the system's ROCm 7.2 runtime it was built against, and the host path of this library (a few hundred short HIP calls
-    per scene) is 0.6 ms slower there (tools/profile_e2e_variants.py: 2.98 -> 3.61 ms).  Prints one E2E_CHILD json line."""
+    that does not import torch sees.  `import torch` alone (no CUDA initialisation needed) makes the host path of this
+    library 0.4-0.6 ms slower in the same process (tools/profile_e2e_variants.py: 2.9-3.2 -> 3.4-3.8 ms; constructor + Init
+    0.43 -> 0.7-0.8, the 100 TriangulateImage calls 1.2 -> 1.5); which HIP runtime serves the calls (torch's bundled one or
+    the system's), OpenMP / MKL thread counts and wait policy, NUMA confinement and malloc tunables do not account for it --
+    the cause was not found.  Prints one E2E_CHILD json line."""
     import gc
     from limap_amd import merging, synthetic as syn, triangulation as tri
     sc = syn.make_scene(n_views=views, n_segs=segs, n_neighbors=neighbors, seed=seed)
@@ -1138,8 +1139,8 @@ def main():
                     out["e2e_after_warmup_ms"] = {"error": pr.stderr[-300:]}
             except Exception as e:  # an extra: never lose the main line over it
                 out["e2e_after_warmup_ms"] = {"error": f"{type(e).__name__}: {e}"}
-        # the same call sequences in a process that has NOT imported torch (see e2e_child: torch's bundled HIP / HSA runtime
-        # takes over every library loaded after it); the in-process figures above stay the headline e2e_* fields
+        # the same call sequences in a process that has NOT imported torch (see e2e_child); the in-process figures above stay
+        # the headline e2e_* fields
         if args.mode == "matched" and default_wl and not args.no_extras:
             try:
                 import subprocess
@@ -1150,9 +1151,9 @@ def main():
                 if line:
                     ch = json.loads(line[-1][10:])
                     assert ch["tracks"] == len(tracks_py) and not ch["torch_in_process"]
-                    ch["note"] = ("fresh process without torch: liblimap_amd.so on the system ROCm runtime it links; in this "
-                                  "process torch was imported first and its bundled libamdhip64.so.7 / libhsa-runtime64 serve "
-                                  "every HIP call of the library (e2e_wall_ms above)")
+                    ch["note"] = ("the same call sequences in a fresh child process that does not import torch; `import torch` alone "
+                                  "adds 0.4-0.6 ms to the host path in the same process (cause not found: DESIGN.md section 4) -- "
+                                  "e2e_wall_ms above is measured in this process, which needs torch for the driver's contract")
                     out["e2e_clean_process"] = ch
                 else:
                     out["e2e_clean_process"] = {"error": pr.stderr[-300:]}

@@ -4,11 +4,27 @@ the Python track list built, a post-processing chain between repetitions), one f
 import gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 flags = set(sys.argv[1:])
-if "torch" in flags:
+if "torch" in flags or "torch_import" in flags or "torch_init" in flags:
     import torch
-    torch.cuda.init()
-    x = torch.zeros(1 << 20, device="cuda:0")
-    torch.cuda.synchronize()
+    if "torch_import" not in flags:
+        torch.cuda.init()
+    if "torch" in flags:
+        x = torch.zeros(1 << 20, device="cuda:0")
+        torch.cuda.synchronize()
+if "pin" in flags or "pin_other" in flags:  # confine the process to one NUMA node (the one the main thread is on, or the other one)
+    cpu = int(open("/proc/self/stat").read().split()[38])
+    nodes = {}
+    for d in os.listdir("/sys/devices/system/node"):
+        if d.startswith("node") and d[4:].isdigit():
+            cl = open(f"/sys/devices/system/node/{d}/cpulist").read().strip()
+            cpus = set()
+            for part in cl.split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+            nodes[int(d[4:])] = cpus
+    mine = [n for n, c in nodes.items() if cpu in c][0]
+    pick = mine if "pin" in flags else [n for n in nodes if n != mine][0]
+    os.sched_setaffinity(0, nodes[pick])
 import numpy as np
 from limap_amd import synthetic as syn, triangulation as tri, merging
 sc = syn.make_scene(n_views=100, n_segs=500, n_neighbors=20, seed=0)
