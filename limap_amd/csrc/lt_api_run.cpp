@@ -383,7 +383,7 @@ int lt_run_device_async(lt_ctx *ctx) {
   // (+ the tile cost-class counters of k_cand_meta / k_score3 behind the scan's words: zeroed by the same kernel)
   const int n_status_scan = (int)((G + 1 + 255) / 256) + 1;
   // + the staging counters of the one-pass exhaustive mode; all counters 128 bytes apart
-  const int n_status = n_status_scan + score3_tile_buckets() * 16 + ex_regions() * 16;
+  const int n_status = n_status_scan + score3_tile_buckets() * 16 + ex_regions() * 16 + 8 * 16;  // ... + k_tri_rounds' unit counters
   ENSURE(ctx, ctx->d_scan_status, 8 * (size_t)n_status);
   const bool ln_job = ctx->job_mode == 1 && ctx->rows_ln && ctx->rows_sorted;
   if (ln_job) ENSURE(ctx, ctx->d_blk_surv, 4 * (size_t)std::max(ctx->n_blk, 1));
@@ -484,7 +484,9 @@ int lt_run_device_async(lt_ctx *ctx) {
                        many_on ? 1 : 0, one_on ? 1 : 0, group_base, phase, ln_slots, ctx->d_m_pairs.as<unsigned short>(),
                        ctx->d_run_len.as<unsigned>(), ctx->d_slot_row0.as<unsigned>(), ctx->d_blk_surv.as<unsigned>(),
                        ctx->d_blk_rnd0.as<unsigned>(), ctx->d_round_count.as<unsigned>(),
-                       (ctx->blk_vorder_ok && !test_switch("LT_TEST_GATES_IMAGE_MAJOR")) ? ctx->d_blk_vorder.as<int>() : nullptr);
+                       (ctx->blk_vorder_ok && !test_switch("LT_TEST_GATES_IMAGE_MAJOR")) ? ctx->d_blk_vorder.as<int>() : nullptr,
+                       test_switch("LT_TEST_TRI_STATIC") ? nullptr
+                           : (unsigned *)(ctx->d_scan_status.as<unsigned long long>() + n_status_scan + score3_tile_buckets() * 16 + ex_regions() * 16));
       };
       if (!extras) {
         gen(0);

@@ -47,7 +47,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const void *seg_pts, const double *sfm_xyz, int *err_flag, int many_on, int one_on,
                       const long long *group_base, int phase, int ln_slots, const unsigned short *tr,
                       const unsigned *run_len, const unsigned *slot_row0, unsigned *blk_surv, const unsigned *blk_rnd0,
-                      unsigned *round_count, const int *blk_vorder);
+                      unsigned *round_count, const int *blk_vorder, unsigned *tri_unit_ctr);
 size_t seg_point_bytes();
 void launch_node_prefix(hipStream_t st, long long G, const int *node_img, const long long *seg_off,
                         const long long *nb_off, const long long *blk_line_base, unsigned *cnt_bl,

@@ -981,7 +981,7 @@ k_tri_rows(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec 
 __global__ void __launch_bounds__(64 * kTriWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_tri_rounds(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRec *__restrict__ pairs_r,
              const BlkRec *__restrict__ blk_r, const unsigned *__restrict__ blk_surv, const unsigned *__restrict__ blk_rnd0,
-             unsigned *__restrict__ round_count, const int *__restrict__ vorder) {
+             unsigned *__restrict__ round_count, const int *__restrict__ vorder, unsigned *__restrict__ unit_ctr) {
   extern __shared__ __align__(16) unsigned char smem_raw[];  // per wave: 64 x (CRec | unc | key)
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
@@ -995,9 +995,38 @@ k_tri_rounds(GenArgs a, GenCfg cfg, const Cam *__restrict__ cams_r, const PairRe
   const int v_begin = xcd_major ? (int)(blockIdx.x & 7u) * n8 : 0;
   const int v_end = xcd_major ? min(a.n_blk, v_begin + n8) : a.n_blk;
   const int v_step = xcd_major ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-  for (int v = v_begin + (xcd_major ? (int)(blockIdx.x >> 3) : (int)blockIdx.x); v < v_end; v += v_step) {
+  // UNITS (round 6, second half): a unit = the rounds x, x + 4, ... of one block = what one wave does in a block.  A wave's
+  // FIRST unit is static as before (its workgroup's first block, rounds (wave + block) % 4), every later one is CLAIMED from
+  // its XCD's counter over the queue's remaining units (unit u = block u / 4 of the XCD's eighth, rounds u % 4), the claim
+  // issued at the start of the unit before.  With blocks dealt g, g + G, ... the waves had 2 blocks each whatever the blocks
+  // held (a block has 200 to 1 200 survivors): trace at 100 x 500 -- 1 700 waves in rounds at 20 us, 857 at 30 us, 78 at 40 us
+  // of 47.  Measured: BASELINE config 3 (20 000 blocks, 19 per workgroup) 0.855 -> 0.778 ms; at 100 x 500 (2 000 blocks, 2 per
+  // workgroup) 50.5 -> 56 us -- the four units of a block then run on four CUs and each fetches the block's cameras, pair
+  // record and neighbour segments for itself, which costs more than two blocks per workgroup can be out of balance.  So:
+  // claims from four blocks per workgroup on; unit_ctr == nullptr (or a grid that is not a multiple of 8): the static deal.
+  const bool claims = xcd_major && unit_ctr != nullptr && (long long)a.n_blk >= 4ll * (long long)gridDim.x;
+  unsigned *ctr = claims ? unit_ctr + 32u * (blockIdx.x & 7u) : nullptr;
+  const unsigned n_static = claims ? (gridDim.x >> 3) * (unsigned)kTriWaves : 0u;  // units dealt statically per queue
+  unsigned c_raw = 0;
+  bool first = true;
+  int v = v_begin + (xcd_major ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+  int x_dyn = -1;
+  for (;;) {
+  if (claims) {
+    if (!first) {
+      const unsigned u = n_static + (unsigned)__builtin_amdgcn_readfirstlane((int)c_raw);
+      v = v_begin + (int)(u / (unsigned)kTriWaves);
+      x_dyn = (int)(u % (unsigned)kTriWaves);
+    }
+    if (v >= v_end) break;
+    if (lane == 0) c_raw = atomicAdd(ctr, 1u);  // the unit after this one (read when this one is done)
+  } else {
+    if (!first) v += v_step;
+    if (v >= v_end) break;
+  }
+  first = false;
   const int b = vorder ? vorder[v] : v;
-  const int x = (wave + b) % kTriWaves;
+  const int x = x_dyn >= 0 ? x_dyn : (wave + b) % kTriWaves;
   const unsigned n_s = blk_surv[b];
   const int n_rounds = (int)((n_s + 63u) >> 6);
   if (x >= n_rounds) continue;
@@ -1465,7 +1494,8 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
                       const void *seg_pts, const double *sfm_xyz, int *err_flag, int many_on, int one_on,
                       const long long *group_base, int phase, int ln_slots, const unsigned short *tr,
                       const unsigned *run_len, const unsigned *slot_row0, unsigned *blk_surv, const unsigned *blk_rnd0,
-                      unsigned *round_count, const int *blk_vorder) {
+                      unsigned *round_count, const int *blk_vorder, unsigned *tri_unit_ctr) {
+  // tri_unit_ctr: eight counters, 128 B apart, zero at the start of the run: k_tri_rounds' unit claims (nullptr: static deal)
   // ln_slots > 0: the line-slot form (k_gates_ln; slots per block = ln_slots, tables tr / run_len / slot_row0) with
   // stage B in rounds of 64 survivors (k_tri_rounds; no extra proposals in this form)
   // phase 0: k_gates + k_tri_rows (no extra proposals).  Extra proposals: phase 1 = k_gates + the COUNTING run of
@@ -1529,7 +1559,7 @@ void launch_gen_split(hipStream_t st, int n_blk, long long max_rows, const GenCf
     // persistent: the workgroups that are resident at once (16 waves per CU: registers and LDS)
     const dim3 tg((unsigned)std::min<long long>(n_blk, (long long)n_cu * (16 / kTriWaves)));
     hipLaunchKernelGGL(k_tri_rounds, tg, dim3(64 * kTriWaves), tri_lds, st, a, cfg, a.cams, a.pairs, a.blk, blk_surv, blk_rnd0,
-                       round_count, blk_vorder);
+                       round_count, blk_vorder, tri_unit_ctr);
   } else {
     const dim3 tg(nblk2(a.n_slots / kTriSlots, kTriWaves), n_blk);
     if (extra)

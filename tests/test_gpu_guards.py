@@ -41,7 +41,7 @@ def clean_env():
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
             "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TIMER_SAMPLE", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_SCORE_SPLIT",
             "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS", "LT_TEST_PAIR_SCORE_TERMS", "LT_TEST_NO_PAIR_CLASSES", "LT_TEST_GATES_IMAGE_MAJOR",
-            "LT_SCORE_TWO_KERNELS", "LT_TEST_Q_LOSE_TILE")
+            "LT_SCORE_TWO_KERNELS", "LT_TEST_Q_LOSE_TILE", "LT_TEST_TRI_STATIC")
     saved = {k: os.environ.pop(k, None) for k in keys}
     yield
     for k in keys:
@@ -566,6 +566,19 @@ def test_stage_a_block_order_does_not_matter(gpu_lib, clean_env, shape):
     assert new[5]["candidates"] > 300 and new[4]["line_slots"] == 1
     os.environ["LT_TEST_GATES_IMAGE_MAJOR"] = "1"
     old = _results(run_product(sc, cfg, topk=topk))
+    _same(old, new)
+
+
+def test_stage_b_unit_claims_equal_the_static_deal(gpu_lib, clean_env):
+    """k_tri_rounds claims its units (the rounds x, x + 4, ... of a block) from per-XCD counters once a workgroup has four
+    blocks or more (round 6: BASELINE config 3 0.855 -> 0.778 ms); LT_TEST_TRI_STATIC=1 deals the blocks g, g + G, ... as
+    before.  Same bits on a scene with 4 400 blocks (220 views x 20 neighbours)."""
+    sc = syn.make_scene(n_views=220, n_segs=40, n_neighbors=20, seed=31, topk=4)
+    cfg = syn.default_triangulation_cfg(debug_mode=True)
+    new = _results(run_product(sc, cfg, topk=4))
+    assert new[5]["candidates"] > 2000 and new[4]["line_slots"] == 1
+    os.environ["LT_TEST_TRI_STATIC"] = "1"
+    old = _results(run_product(sc, cfg, topk=4))
     _same(old, new)
 
 
