@@ -464,7 +464,9 @@ int build_invariants(lt_ctx *ctx, const double *hk = nullptr, const double *hq =
       std::memcpy(k.data(), hk, 32 * (size_t)n);
       std::memcpy(q.data(), hq, 32 * (size_t)n);
       std::memcpy(t.data(), ht, 24 * (size_t)n);
-      ctx->h_segs.assign(hs, hs + 4 * (size_t)ctx->G);
+      std::vector<double>().swap(ctx->h_segs);
+      ctx->h_segs_ptr = hs;  // (the context's own scene block: lives until the next Init)
+      ctx->h_segs_add = ctx->cfg.add_halfpix ? 0.5 : 0.0;
     } else {
       ctx->h_segs.assign(4 * (size_t)ctx->G, 0.0);
       if (n > 0) {
@@ -475,8 +477,12 @@ int build_invariants(lt_ctx *ctx, const double *hk = nullptr, const double *hq =
       if (ctx->G > 0)
         HIPCHK(ctx, hipMemcpy(ctx->h_segs.data(), ctx->d_segs_raw.p, 32 * (size_t)ctx->G, hipMemcpyDeviceToHost));
     }
-    if (ctx->cfg.add_halfpix)
-      for (double &v : ctx->h_segs) v = v + 0.5;
+    if (!(hk && hq && ht && hs)) {
+      if (ctx->cfg.add_halfpix)
+        for (double &v : ctx->h_segs) v = v + 0.5;
+      ctx->h_segs_ptr = ctx->h_segs.data();
+      ctx->h_segs_add = 0.0;
+    }
     ctx->h_cams.resize(n);
     for (int i = 0; i < n; ++i) cam_build(&k[4 * i], &q[4 * i], &t[3 * i], &ctx->h_cams[i]);
   }

@@ -104,6 +104,34 @@ struct RawInts {
   }
 };
 
+// A per-node host array that starts as zeros WITHOUT being written: calloc of a large block is fresh zero pages from the
+// kernel, touched only where somebody writes or reads.  Init of a context used to assign ~45 bytes of zeros per node to the
+// per-node result arrays below -- 8 ms at 10^6 nodes -- although a job whose tail runs on the device never downloads them.
+template <class T>
+struct ZeroVec {
+  T *p = nullptr;
+  size_t n = 0;
+  ZeroVec() = default;
+  ZeroVec(const ZeroVec &) = delete;
+  ZeroVec &operator=(const ZeroVec &) = delete;
+  ~ZeroVec() { std::free(p); }
+  void assign(size_t count, T zero) {  // (only zeros)
+    (void)zero;
+    std::free(p);
+    p = count ? static_cast<T *>(std::calloc(count, sizeof(T))) : nullptr;
+    n = p ? count : 0;
+    if (count && !p) throw std::bad_alloc();
+  }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T *data() { return p; }
+  const T *data() const { return p; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+  const T *begin() const { return p; }
+  const T *end() const { return p + n; }
+};
+
 // Valid edges of every node, flat (slot, ng_line) pairs: one pool + per-node (offset, count), so that a
 // download is one bulk append instead of one allocation per node.  Nodes of later batches append.
 struct EdgeStore {
@@ -115,8 +143,8 @@ struct EdgeStore {
     const int *data() const { return p; }
     int operator[](size_t i) const { return p[i]; }
   };
-  std::vector<long long> off;
-  std::vector<int> cnt;   // ints (2 per edge)
+  ZeroVec<long long> off;
+  ZeroVec<int> cnt;   // ints (2 per edge)
   std::vector<int> pool;
   void reset(long long G) { off.assign((size_t)G, 0); cnt.assign((size_t)G, 0); pool.clear(); }
   View operator[](long long g) const { return View{pool.data() + off[(size_t)g], (size_t)cnt[(size_t)g]}; }
@@ -167,7 +195,9 @@ struct lt_ctx {
   long long G = 0;
   std::vector<int> h_node_img;  // node -> image index
   std::vector<lt::Cam> h_cams;     // host copy of the camera table (post-triangulation filters)
-  std::vector<double> h_segs;     // host copy of the 2D segments, x1 y1 x2 y2 (after add_halfpix)
+  std::vector<double> h_segs;     // host copy of the 2D segments, x1 y1 x2 y2 (after add_halfpix) -- only where Init got device buffers
+  const double *h_segs_ptr = nullptr;  // the 2D segments on the host: h_segs, or the scene block of lt_init (init_blk: no 32 B per
+  double h_segs_add = 0.0;             // segment copied at Init -- 3 ms at 10^6 segments); a reader adds h_segs_add (add_halfpix)
   DevBuf d_kvec, d_qvec, d_tvec, d_segs_raw, d_cams, d_segs, d_seg_off, d_node_img;
 
   // ---- buffered job ----
@@ -292,9 +322,9 @@ struct lt_ctx {
   lt_host::HostBlock init_blk;  // page-locked copy of the scene lt_init uploads from (copies may still be in flight)
   Cand *best_c = nullptr;
   std::vector<char> best_c_set;
-  std::vector<double> best_score;
-  std::vector<int> best_src2, n_tris;
-  std::vector<unsigned char> has_best;
+  lt_host::ZeroVec<double> best_score;
+  lt_host::ZeroVec<int> best_src2, n_tris;
+  lt_host::ZeroVec<unsigned char> has_best;
   lt_host::EdgeStore valid_edges;  // per node: flat (slot, ng_line) pairs
   // debug_mode: tris_ of EVERY batch (the reference keeps tris_ for all images, global_line_triangulator.cc:156-159);
   // records appended at download time, per node a range of the pool
@@ -303,8 +333,8 @@ struct lt_ctx {
     int src2[2];
   };
   std::vector<DebugTri> dbg_pool;
-  std::vector<long long> dbg_off;
-  std::vector<int> dbg_cnt;
+  lt_host::ZeroVec<long long> dbg_off;
+  lt_host::ZeroVec<int> dbg_cnt;
   // ---- tail ----
   TrackStore tracks;
   // scratch of the tail, kept between calls (a fresh 200 KB vector costs more in page faults than the graph build)

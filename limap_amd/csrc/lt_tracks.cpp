@@ -90,7 +90,7 @@ lt_trackset *lt_ts_from_ctx(lt_ctx *ctx) {
       mm.img_id = src.img_ids[a + k]; mm.line_id = src.line_ids[a + k]; mm.node_id = src.node_ids[a + k];
       mm.score = src.scores[a + k];
       long long g = src.gnodes[a + k];
-      std::memcpy(mm.l2d, &ctx->h_segs[4 * g], 32);
+      for (int c = 0; c < 4; ++c) mm.l2d[c] = ctx->h_segs_ptr[4 * g + c] + ctx->h_segs_add;  // (v + 0.5 as at Init before round 6)
       mm.l3d = ctx->best_c[g];
     }
   }
