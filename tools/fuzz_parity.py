@@ -1,5 +1,6 @@
 """Developer tool: randomised differential run, product (HIP) against the CPU oracle (test infrastructure) on
-random small scenes / modes / a few configuration knobs.  usage (GPU box): python tools/fuzz_parity.py [n] [seed0] [big]"""
+random small scenes / modes / a few configuration knobs.  usage (GPU box): python tools/fuzz_parity.py [n] [seed0] [big|wide]
+("wide": 205-260 views with 20 neighbours each -- more than 4 096 (image, neighbour) blocks, the regime in which stage B claims its units)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,11 +13,14 @@ from helpers import compare_best, compare_candidates, compare_tracks, compare_va
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 big = len(sys.argv) > 3 and sys.argv[3] == "big"  # larger scenes: tracks exist, the tail is exercised
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
 ora.build()
 bad = 0
 for k in range(n):
     rng = np.random.default_rng(seed0 + k)
-    if big:
+    if wide:
+        nv, ns, nn = int(rng.integers(205, 261)), int(rng.integers(20, 61)), 20
+    elif big:
         nv, ns, nn = int(rng.integers(16, 31)), int(rng.integers(100, 260)), int(rng.integers(6, 11))
     else:
         nv, ns, nn = int(rng.integers(5, 15)), int(rng.integers(20, 160)), int(rng.integers(2, 8))
@@ -42,7 +46,7 @@ for k in range(n):
     cfg["linker3d_config"]["score_th"] = float(rng2.choice([0.4, 0.5, 0.6]))
     if rng2.integers(0, 5) == 0:
         cfg["min_num_outer_edges"] = int(rng2.integers(1, 3))
-    ex = bool(k % 3 == 2)
+    ex = bool(k % 3 == 2) and not wide  # (wide: the matched mode is what the block count matters for)
     try:
         T = run_product(sc, cfg, exhaustive=ex)
         O = run_oracle(ora, sc, cfg, exhaustive=ex)
