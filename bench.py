@@ -268,6 +268,11 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
     except Exception as e:
         note = f"{type(e).__name__}: {e}"
     full = rmax(time.perf_counter() - tf0)
+    tail_ms = None
+    if rank == 0 and note is None:  # rank 0's last ComputeLineTracks by stage (lt_get_timers slots 10, 22, 23)
+        tmt = ctx.timers()
+        tail_ms = {"total": tmt["tail"], "device_half_and_graph": tmt["tail_device"], "edge_order_and_union_find": tmt["tail_unionfind"],
+                   "members_and_aggregation": tmt["tail"] - tmt["tail_device"] - tmt["tail_unionfind"]}
     # ... and PIPELINED: rank 0 enqueues the device half of step k's tail, then step k + 1, and does the host half of
     # step k's tail (graph, union-find, aggregation) while the device works on step k + 1 (lt_compute_tracks_begin / _end)
     over, over_note = None, None
@@ -311,7 +316,7 @@ def strong_config3_leg(cfg, rank, world, local_rank, dev, use_dist, steps=5, war
                         "matched topk=10" + ("" if small else ", 4 rooms (BASELINE configs[2])")),
            "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
            "value": cand * steps / elapsed, "unit": "candidates/s",
-           "step_with_merge_and_tail_ms": None if note else 1e3 * full / n_full, "note": note,
+           "step_with_merge_and_tail_ms": None if note else 1e3 * full / n_full, "note": note, "tail_ms": tail_ms,
            "step_with_merge_and_tail_overlapped_ms": None if over is None else 1e3 * over / n_full,
            "overlapped_note": over_note or "the host half of step k's tail (rank 0) runs while the device works on step k + 1",
            "ms_per_step_per_rank": per_rank, "load_imbalance_max_over_mean": max(per_rank) / (sum(per_rank) / len(per_rank)),

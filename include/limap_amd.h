@@ -294,8 +294,11 @@ int lt_get_stats(lt_ctx *ctx, int64_t out[8]);
  * [16] connections that passed the stage-A gates (k_gates);
  * one-pass exhaustive mode: [17] staging slots needed (fullest region x regions), [18] staging slots provided;
  * [19] 1 when this context scores with the fused kernel because the split form's pair store overflowed once, else 0;
- * [20] 1 when stage A of the last TriangulateImage job ran in the line-slot form (k_gates_ln: one lane per line), else 0.
- * With the scoring stage in two kernels (the default for TriangulateImage jobs) [15] spans both.
+ * [20] 1 when stage A of the last TriangulateImage job ran in the line-slot form (k_gates_ln: one lane per line), else 0;
+ * [21] 1 when this context scores in the two-kernel form because the one-kernel form (k_score_q) raised its flag once, else 0;
+ * [22], [23] of the last lt_compute_tracks ([10]): its device half + graph, its edge order + union-find (the rest of [10] is
+ * the track members and their aggregation).
+ * [15] spans the whole scoring stage (one kernel, k_score_q, by default for TriangulateImage jobs; two in the fallback form).
  * SAMPLING: an event between two kernels costs a ~5 us bubble in the stream, so a run enqueued BEHIND one still in flight
  * (lt_run_device_async back to back) carries the stage events -- [3]-[6], [13]-[15] -- only every LT_TIMER_SAMPLE-th time
  * (environment, read per run; default 8, 1 = every run); in between those slots keep the values of the last run that

@@ -533,7 +533,7 @@ class Context:
 
     _TIMER_KEYS = ["run", "invariants", "sort", "gen", "compact", "score", "select", "gather", "upload", "download",
                    "tail", "pairs_eval", "buffer", "k_gates", "k_tri_rows", "k_score3", "survivors", "ex_slots", "ex_cap",
-                   "score_fused", "line_slots", "score_two_kernels"]
+                   "score_fused", "line_slots", "score_two_kernels", "tail_device", "tail_unionfind"]
 
     def timers(self):
         out = np.zeros(24)

@@ -368,11 +368,16 @@ int lt_compute_tracks(lt_ctx *ctx) {
   double t0 = now_ms();
   static const bool tail_trace = getenv("LT_TAIL_TRACE") != nullptr;  // developer: stage times to stderr
   double tprev = t0;
+  // the stages' times also go to the context (lt_get_timers slots 22 / 23: device half + graph, edge order + union-find; the
+  // rest of slot 10 is members + aggregation)
+  double acc_dev = 0.0, acc_uf = 0.0;
   auto lap = [&](const char *what) {
-    if (!tail_trace) return;
     double t = now_ms();
-    fprintf(stderr, "[tail] %-18s %.3f ms\n", what, t - tprev);
+    const double d = t - tprev;
     tprev = t;
+    if (!std::strncmp(what, "device", 6) || !std::strncmp(what, "graph", 5) || !std::strncmp(what, "edge sims", 9)) acc_dev += d;
+    else if (!std::strncmp(what, "edge sort", 9) || !std::strncmp(what, "union", 5) || !std::strncmp(what, "  uf", 4)) acc_uf += d;
+    if (tail_trace) fprintf(stderr, "[tail] %-18s %.3f ms\n", what, d);
   };
   const long long G = ctx->G;
   // graph in edge order (base/graph.cc:57-87); scratch kept in the context
@@ -740,6 +745,8 @@ int lt_compute_tracks(lt_ctx *ctx) {
   lap("tracks+aggregate");
   ctx->tracks_done = true;
   ctx->timers[10] = now_ms() - t0;
+  ctx->timers[22] = acc_dev;
+  ctx->timers[23] = acc_uf;
   return LT_OK;
 }
 
