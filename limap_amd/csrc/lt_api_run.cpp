@@ -822,7 +822,7 @@ int lt_run_device_async(lt_ctx *ctx) {
     const bool score_sorted = score_f32 && ctx->job_mode == 2 && !test_switch("LT_TEST_SCORE_UNSORTED");
     if (score_sorted) {
       ENSURE(ctx, ctx->d_perm, 4 * (size_t)std::max<long long>(C_bound, 1));
-      ENSURE(ctx, ctx->d_rng, 8 * (size_t)std::max<long long>(C_bound, 1));
+      ENSURE(ctx, ctx->d_rng, 4 * (size_t)std::max<long long>(C_bound, 1));
     }
     // depth-sorted sweep over the staged records of the one-pass exhaustive mode: see k_depth_order
     const bool staged_sorted = score_sorted && ctx->perm_mode && ctx->job_mode == 2;

@@ -165,7 +165,7 @@ struct Score3Args {
   unsigned *draw;                    // kTileQueues draw counters, 128 bytes apart: queue q = tiles q, q + 8, ...
   const unsigned *perm;              // kSorted: candidate record at depth-sorted position t (k_depth_order)
   const unsigned *spos;              // kSorted over staged records: natural position (score index) of sorted position t
-  const uint2 *rng;                  // kSorted: node-relative range of sorted positions lane t has to sweep
+  const unsigned *rng;               // kSorted: node-relative range of sorted positions lane t has to sweep (lo | hi << 16; ~0: all)
   const unsigned *bucket_cnt;        // tiles by cost class (k_cand_meta): counts, lists of bucket_cap entries each
   const unsigned *bucket_list;       // entries of four words: tile, first and end position of its window, 0
   unsigned bucket_cap;
@@ -210,58 +210,139 @@ constexpr int kDenseHdrBytes = 16 + kChunkTiles * 8 + 256 * 4 + 64 * 4;  // k_de
 // gradient (third row of R) of the point: |z_i - z_j| <= |start_i - start_j|.  A pair whose depths differ by
 // more than the scale-invariant guard radius of i can therefore not pass the sweep's distance guard -- in
 // depth-sorted order candidate i only has to sweep a contiguous range of positions.  One wave per node:
-// bitonic sort of (float depth, index) in LDS, then the range of every position by binary search.  The float
+// bitonic sort of (float depth, index) in registers, then a range for every four positions by bisection.  The float
 // keys only steer the pruning (radius widened by their rounding); nodes above kSortMax candidates or with a
 // non-finite depth keep the identity order and the full range.  Which pairs reach the dense evaluation is
 // unchanged, so is every result (LT_TEST_SCORE_UNSORTED: the plain sweep).
 constexpr int kSortMax = 2048;  // the index takes the 11 low bits of the sort word
 
-// Bitonic sort of R * 64 packed 32-bit words (21 key bits | 11 index bits) held R per lane (element e = r * 64 + lane): a
-// compare-exchange distance >= 64 pairs two registers of the same lane, a smaller one the same register of
-// two lanes (one shuffle).  No LDS traffic, every loop unrolled.  (A first version that kept the arrays in
-// LDS and synchronised per stage took 5 ms for the 50 000 nodes of the exhaustive benchmark; this one 0.5.)
-template <int R>
-static __device__ __forceinline__ void wave_bitonic(unsigned (&v)[R], int lane) {
-  constexpr int N = R * 64;
-#pragma unroll
-  for (int k = 2; k <= N; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      if (j >= 64) {
-        const int rj = j >> 6;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          if ((r & rj) == 0) {
-            const bool up = (((r * 64) & k) == 0);  // bit k of e = r * 64 + lane lies above the lane bits
-            const unsigned x = v[r], y = v[r | rj];
-            const unsigned mn = min(x, y), mx = max(x, y);
-            v[r] = up ? mn : mx;
-            v[r | rj] = up ? mx : mn;
-          }
-        }
-      } else {
-        const bool lower = (lane & j) == 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int e = r * 64 + lane;
-          const bool up = (e & k) == 0;
-          const unsigned o = (unsigned)__shfl_xor((int)v[r], j);
-          v[r] = (up == lower) ? min(v[r], o) : max(v[r], o);
-        }
-      }
-    }
+// Value of lane (lane ^ kX) for the lane distances a blocked bitonic network takes.  Within a row of 16 lanes a DPP move (no
+// trip through the LDS pipe, which ds_bpermute is); across rows gfx950's row / half swaps; the two mirrored distances that
+// cross rows (31, 63: once per sort each) stay with ds_bpermute.
+template <int kX>
+static __device__ __forceinline__ unsigned lane_xor(unsigned x, int lane) {
+  if constexpr (kX == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);         // quad_perm [1,0,3,2]
+  else if constexpr (kX == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  else if constexpr (kX == 3) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x1B, 0xF, 0xF, true);    // quad_perm [3,2,1,0]
+  else if constexpr (kX == 7) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  else if constexpr (kX == 4) return lane_xor<3>(lane_xor<7>(x, lane), lane);
+  else if constexpr (kX == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, true);   // row_ror:8
+  else if constexpr (kX == 15) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);  // row_mirror
+  else if constexpr (kX == 16) {
+    const auto p = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // [0] = rows 0,0,2,2 of x; [1] = rows 1,1,3,3
+    return (lane & 16) ? p[0] : p[1];
+  } else if constexpr (kX == 32) {
+    const auto p = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // [0] = lower half twice; [1] = upper half twice
+    return (lane & 32) ? p[0] : p[1];
+  } else {
+    return (unsigned)__shfl_xor((int)x, kX);
   }
 }
 
-// sorts the node's (depth, index) words and leaves the sorted float keys in LDS (key[0..n)) and perm in HBM
+// Bitonic sort of R * 64 packed 32-bit words (21 key bits | 11 index bits) held R per lane, BLOCKED: element e = lane * R + r.
+// A compare-exchange distance below R pairs two registers of the same lane with the direction known at compile time (two
+// instructions per pair); a larger one the same register of two lanes.  Every merge opens with the mirrored exchange
+// (e against e ^ (k - 1)), so that all comparators point upwards and no lane-dependent direction is left.  No LDS traffic,
+// every loop unrolled.  (Round 5's form held element r * 64 + lane in register r: 39 of the 45 steps of 512 elements went
+// between lanes, through ds_bpermute; here 21 do, 15 of them as DPP moves.  0.18 ms of k_depth_order then.)
+template <int R, int kStep, bool kMirror>
+static __device__ __forceinline__ void bitonic_lanes(unsigned (&v)[R], int lane) {
+  // exchange with lane ^ kStep; kMirror (the opening exchange of a merge; kStep = 2^m - 1): with its mirrored register.
+  // (min / max with the DPP operand folded in by inline assembly -- three instructions per element instead of the
+  // compiler's four -- was measured: no difference, the kernel is not bound by its instruction count.)
+  const bool lower = (lane & (kMirror ? (kStep + 1) >> 1 : kStep)) == 0;
+  unsigned mn[R], mx[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if constexpr (!kMirror && (kStep == 16 || kStep == 32)) {
+      // rows 0,0,2,2 / 1,1,3,3 (halves 0,0 / 1,1) of the word: the two partners, in both their lanes
+      const auto p = kStep == 16 ? __builtin_amdgcn_permlane16_swap(v[r], v[r], false, false)
+                                 : __builtin_amdgcn_permlane32_swap(v[r], v[r], false, false);
+      mn[r] = min(p[0], p[1]); mx[r] = max(p[0], p[1]);
+    } else {
+      const unsigned o = lane_xor<kStep>(v[kMirror ? R - 1 - r : r], lane);
+      mn[r] = min(v[r], o); mx[r] = max(v[r], o);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = lower ? mn[r] : mx[r];
+}
+template <int R, int K>
+static __device__ __forceinline__ void bitonic_merge(unsigned (&v)[R], int lane) {
+  // merge of sorted runs of K / 2 into runs of K
+  if constexpr (K <= R) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if ((r & (K >> 1)) == 0) {
+        const unsigned x = v[r], y = v[r ^ (K - 1)];
+        v[r] = min(x, y);
+        v[r ^ (K - 1)] = max(x, y);
+      }
+  } else {
+    bitonic_lanes<R, K / R - 1, true>(v, lane);
+  }
+  if constexpr (K >= 4) {
+    // the remaining distances K / 4 ... 1, all upwards
+    if constexpr (K / 4 >= 32 * R) bitonic_lanes<R, 32, false>(v, lane);
+    if constexpr (K / 4 >= 16 * R) bitonic_lanes<R, 16, false>(v, lane);
+    if constexpr (K / 4 >= 8 * R) bitonic_lanes<R, 8, false>(v, lane);
+    if constexpr (K / 4 >= 4 * R) bitonic_lanes<R, 4, false>(v, lane);
+    if constexpr (K / 4 >= 2 * R) bitonic_lanes<R, 2, false>(v, lane);
+    if constexpr (K / 4 >= R) bitonic_lanes<R, 1, false>(v, lane);
+#pragma unroll
+    for (int j = (K / 4 < R ? K / 4 : R / 2); j > 0; j >>= 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if ((r & j) == 0) {
+          const unsigned x = v[r], y = v[r | j];
+          v[r] = min(x, y);
+          v[r | j] = max(x, y);
+        }
+    }
+  }
+}
+template <int R, int K>
+static __device__ __forceinline__ void bitonic_from(unsigned (&v)[R], int lane) {
+  bitonic_merge<R, K>(v, lane);
+  if constexpr (K < R * 64) bitonic_from<R, 2 * K>(v, lane);
+}
+template <int R>
+static __device__ __forceinline__ void wave_bitonic(unsigned (&v)[R], int lane) {
+  bitonic_from<R, 2>(v, lane);
+}
+
+constexpr unsigned kDepthKeyMask = 0xFFFFF800u;
+#ifndef LT_DEPTH_GROUP
+#define LT_DEPTH_GROUP 4
+#endif
+constexpr int kDepthGroup = LT_DEPTH_GROUP;  // sorted positions that share a sweep range (power of two)
+static __device__ __forceinline__ float depth_key(unsigned w) { return __uint_as_float(w & kDepthKeyMask); }
+// first position of the sorted words kw[a0 .. n) whose key is >= t (kStrict: > t)
+template <bool kStrict>
+static __device__ __forceinline__ int depth_bound(const unsigned *kw, int a, int b, float t) {
+  while (a < b) {
+    const int m = (a + b) >> 1;
+    const float k = depth_key(kw[m]);
+    if (kStrict ? (k <= t) : (k < t)) a = m + 1; else b = m;
+  }
+  return a;
+}
+// Sorts the node's (depth, index) words, then gives every sorted position its record and its sweep range.  Lane l ends
+// up with the sorted positions l * R .. l * R + R - 1 in its registers; the words also go to LDS (kw), where the lanes
+// look up each other's keys.  A range is found once per kDepthGroup consecutive positions (from the smallest lower and the
+// largest upper threshold among them: a superset of each one's own range, which is all the sweep needs) and written for
+// all of them, packed into one word, in a coalesced pass.  (Round 5 bisected twice for every position -- 0.32 ms of the
+// kernel's 0.68 -- and wrote two words.)
 template <int R>
 static __device__ __forceinline__ bool depth_sort_node(const CRec *__restrict__ cand, long long off, int n, int lane,
-                                                       float *key, unsigned *__restrict__ perm,
+                                                       unsigned *kw, unsigned *__restrict__ perm,
                                                        const unsigned *__restrict__ place, unsigned *__restrict__ rec,
-                                                       const float *__restrict__ st_z) {
+                                                       const float *__restrict__ st_z, double guard,
+                                                       unsigned *__restrict__ rng) {
   // word = the float key with its 11 low mantissa bits replaced by the index (n <= 2048): half the compare-exchange
-  // and shuffle work of a (key, index) pair of words; the keys only steer the pruning, k_depth_order widens the
-  // radius by the 2^-12 the truncation can cost
+  // and shuffle work of a (key, index) pair of words; the keys only steer the pruning, the radius below is widened
+  // by the 2^-12 the truncation can cost.  (Loaded striped -- coalesced -- and sorted as if blocked: the network does
+  // not care where a word starts.)
   unsigned v[R];
   bool bad = false;
 #pragma unroll
@@ -270,83 +351,100 @@ static __device__ __forceinline__ bool depth_sort_node(const CRec *__restrict__ 
     v[r] = ~0u;  // padding sorts to the end
     if (e < n) {
       // st_z: the same key, already rounded to single precision, from the compact per-slot array of k_tri_ex
+      // (k_place_ex scattering the keys to the candidates' positions next to the slot numbers, for a streamed read here:
+      // 54 us less here, 88 more there)
       const double z = st_z ? (double)st_z[place[off + e]] : cand[place ? (long long)place[off + e] : off + e].depth[0];
       const float kf = (float)z;
       bad = bad || !(z > 0.0 && z < 1e30);  // non-positive / NaN / inf / absurd depth: no pruning for this node
-      v[r] = (__float_as_uint(kf) & 0xFFFFF800u) | (unsigned)e;  // positive floats order like their bits
+      v[r] = (__float_as_uint(kf) & kDepthKeyMask) | (unsigned)e;  // positive floats order like their bits
     }
   }
   if (__ballot(bad)) return false;
   wave_bitonic<R>(v, lane);
+  const int base = lane * R;
+#pragma unroll
+  for (int r = 0; r < R; ++r) kw[base + r] = v[r];
+  wave_lds_sync();
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int e = r * 64 + lane;
     if (e < n) {
-      key[e] = __uint_as_float(v[r] & 0xFFFFF800u);
-      const long long nat = off + (long long)(v[r] & 0x7FFu);
+      const long long nat = off + (long long)(kw[e] & 0x7FFu);
       perm[off + e] = (unsigned)nat;
       if (place) rec[off + e] = place[nat];
     }
   }
+  constexpr int S = R < kDepthGroup ? R : kDepthGroup;
+  unsigned res[R / S];
+#pragma unroll
+  for (int q = 0; q < R / S; ++q) {
+    float lo_v = __builtin_inff(), hi_v = -__builtin_inff();
+    bool full = false;
+#pragma unroll
+    for (int r = q * S; r < q * S + S; ++r) {
+      if (base + r < n) {
+        const float z = depth_key(v[r]);
+        const double zz = (double)z + kEps;
+        // radius of the sweep's distance guard for this candidate, widened by what the keys lost: a key is the depth
+        // truncated to 13 mantissa bits, k <= z < k (1 + 2^-12), so |k_i - k_j| <= (rad(z_i) + 2.5e-4 k_i)(1 + 2.6e-4)
+        const double rad = guard * zz * 1.001 + 3e-4 * (double)z + 1e-30;
+        full = full || !(rad < 1e299);
+        lo_v = fminf(lo_v, (float)((double)z - rad));
+        hi_v = fmaxf(hi_v, (float)((double)z + rad));
+      }
+    }
+    res[q] = 0xFFFFFFFFu;
+    if (base + q * S < n && !full) {
+      const int a = depth_bound<false>(kw, 0, n, lo_v);  // first position with key >= lo_v
+      const int b = depth_bound<true>(kw, a, n, hi_v);   // first position with key > hi_v
+      // (float)(z -+ rad) rounds either way: one more position on each side
+      res[q] = (unsigned)max(a - 1, 0) | ((unsigned)min(b + 1, n) << 16);
+    }
+  }
+  wave_lds_sync();  // every lane is done with the keys
+#pragma unroll
+  for (int q = 0; q < R / S; ++q) kw[lane * (R / S) + q] = res[q];
+  wave_lds_sync();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = r * 64 + lane;
+    if (e < n) rng[off + e] = kw[e / S];
+  }
   return true;
 }
 
-__global__ void __launch_bounds__(256)
+// One wave per node and per workgroup (four nodes to a workgroup held the LDS of a finished node until the largest of the four
+// was done: 428 against 318 us).  Two launches: nodes up to kSortSmall candidates with a quarter of the LDS and half the
+// registers of the network for 2 048 -- twice the waves in flight for the bulk of the nodes -- and the rest.
+constexpr int kSortSmall = 512;
+template <bool kBig>
+__global__ void __launch_bounds__(64)
 k_depth_order(long long G, const long long *__restrict__ tri_off, const CRec *__restrict__ cand, double guard,
-              unsigned *__restrict__ perm, uint2 *__restrict__ rng, const unsigned *__restrict__ place,
+              unsigned *__restrict__ perm, unsigned *__restrict__ rng, const unsigned *__restrict__ place,
               unsigned *__restrict__ rec, const float *__restrict__ st_z) {
   // place != nullptr: the records are staged (one-pass exhaustive mode), the candidate at natural position p is record
   // place[p]; perm then holds the natural position and rec the record of every depth-sorted position
-  __shared__ float s_key[4][kSortMax];
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  __shared__ unsigned kw[kBig ? kSortMax : kSortSmall];
   const int lane = lane_id();
-  const long long g = (long long)blockIdx.x * 4 + wv;
-  if (g >= G) return;
+  const long long g = (long long)blockIdx.x;
   const long long off = tri_off[g];
   const int n = (int)(tri_off[g + 1] - off);
-  if (n <= 0) return;
-  float *key = s_key[wv];
+  if (n <= 0 || (n > kSortSmall) != kBig) return;
   bool sorted = false;
-  if (n <= 64) sorted = depth_sort_node<1>(cand, off, n, lane, key, perm, place, rec, st_z);
-  else if (n <= 128) sorted = depth_sort_node<2>(cand, off, n, lane, key, perm, place, rec, st_z);
-  else if (n <= 256) sorted = depth_sort_node<4>(cand, off, n, lane, key, perm, place, rec, st_z);
-  else if (n <= 512) sorted = depth_sort_node<8>(cand, off, n, lane, key, perm, place, rec, st_z);
-  else if (n <= 1024) sorted = depth_sort_node<16>(cand, off, n, lane, key, perm, place, rec, st_z);
-  else if (n <= 2048) sorted = depth_sort_node<32>(cand, off, n, lane, key, perm, place, rec, st_z);
-  if (sorted) {
-    wave_lds_sync();
-    for (int r = lane; r < n; r += 64) {
-      const float z = key[r];
-      const double zz = (double)z + kEps;
-      // radius of the sweep's distance guard for this candidate, widened by what the keys lost: a key is the depth
-      // truncated to 13 mantissa bits, k <= z < k (1 + 2^-12), so |k_i - k_j| <= (rad(z_i) + 2.5e-4 k_i)(1 + 2.6e-4)
-      const double rad = guard * zz * 1.001 + 3e-4 * (double)z + 1e-30;
-      int lo = 0, hi = n;
-      if (rad < 1e299) {
-        const float lo_v = (float)((double)z - rad), hi_v = (float)((double)z + rad);
-        int a = 0, b = n;  // first position with key >= lo_v
-        while (a < b) {
-          const int m = (a + b) >> 1;
-          if (key[m] < lo_v) a = m + 1; else b = m;
-        }
-        lo = a;
-        b = n;             // first position with key > hi_v
-        while (a < b) {
-          const int m = (a + b) >> 1;
-          if (key[m] <= hi_v) a = m + 1; else b = m;
-        }
-        hi = a;
-        // (float)(z -+ rad) rounds either way: one more position on each side
-        lo = max(lo - 1, 0);
-        hi = min(hi + 1, n);
-      }
-      rng[off + r] = make_uint2((unsigned)lo, (unsigned)hi);
-    }
+  if constexpr (!kBig) {
+    if (n <= 64) sorted = depth_sort_node<1>(cand, off, n, lane, kw, perm, place, rec, st_z, guard, rng);
+    else if (n <= 128) sorted = depth_sort_node<2>(cand, off, n, lane, kw, perm, place, rec, st_z, guard, rng);
+    else if (n <= 256) sorted = depth_sort_node<4>(cand, off, n, lane, kw, perm, place, rec, st_z, guard, rng);
+    else sorted = depth_sort_node<8>(cand, off, n, lane, kw, perm, place, rec, st_z, guard, rng);
   } else {
+    if (n <= 1024) sorted = depth_sort_node<16>(cand, off, n, lane, kw, perm, place, rec, st_z, guard, rng);
+    else if (n <= 2048) sorted = depth_sort_node<32>(cand, off, n, lane, kw, perm, place, rec, st_z, guard, rng);
+  }
+  if (!sorted) {
     for (int r = lane; r < n; r += 64) {
       perm[off + r] = (unsigned)(off + r);
       if (place) rec[off + r] = place[off + r];
-      rng[off + r] = make_uint2(0u, (unsigned)n);
+      rng[off + r] = 0xFFFFFFFFu;  // the whole node
     }
   }
 }
@@ -466,7 +564,7 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
   // while they run, was measured twice -- rounds 2 and 3: 133 against 122 us; the dense rounds' own loads queue behind
   // it on the in-order vmcnt.)
   CandMeta p_mt = {0u, 0u, 0u, 0u};
-  uint2 p_rg = make_uint2(0u, 0u);
+  unsigned p_rg = 0u;
   unsigned p_i = 0, p_w0 = 0, p_w1 = 0;
   static_assert(kWin <= 128, "the first window chunk's record indices are two per lane");
   auto load_first_level = [&](const uint4 h) {
@@ -586,8 +684,8 @@ k_score3(Score3Args a, ScoreCfg cfg, double scaleinv_guard2) {
       n = (int)mt.n;
       r_lo = 0; r_hi = n;
       if (kSorted) {
-        const uint2 rg = p_rg;
-        r_lo = (int)rg.x; r_hi = (int)rg.y;
+        const unsigned rg = p_rg;
+        if (rg != 0xFFFFFFFFu) { r_lo = (int)(rg & 0xFFFFu); r_hi = (int)(rg >> 16); }
       }
       nb0 = (long long)(mt.nb >> 8);
       n_nb = (int)(mt.nb & 0xFFu);
@@ -1871,7 +1969,7 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.G = G; a.tri_off = tri_off; a.meta = reinterpret_cast<const CandMeta *>(meta); a.cand = cand;
   a.blk_order = blk_order; a.cams = cams; a.score = score; a.pair_counter = pair_counter;
   a.draw = draw;
-  a.perm = perm; a.rng = reinterpret_cast<const uint2 *>(rng);
+  a.perm = perm; a.rng = reinterpret_cast<const unsigned *>(rng);
   a.spos = nullptr;
   a.bucket_cnt = bucket_cnt; a.bucket_list = bucket_list; a.bucket_cap = bucket_cap;
   a.max_nb = max_nb;
@@ -1893,10 +1991,13 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   a.pc_cap = pc_cap;
   if (ev_before && ev_markers) (void)hipEventRecord(ev_before, st);
   const bool sorted = perm != nullptr && f32 && !perm_is_placement;
-  if (sorted)  // depth order + sweep ranges per node (large nodes: exhaustive matching)
-    hipLaunchKernelGGL(k_depth_order, dim3(nblk2(G, 4)), dim3(256), 0, st, G, tri_off, cand,
-                       scaleinv_guard2 < 1e299 ? std::sqrt(scaleinv_guard2) : 1e300, perm, reinterpret_cast<uint2 *>(rng),
-                       place, rec, place ? st_z : nullptr);
+  if (sorted && G > 0) {  // depth order + sweep ranges per node (large nodes: exhaustive matching)
+    const double guard = scaleinv_guard2 < 1e299 ? std::sqrt(scaleinv_guard2) : 1e300;
+    hipLaunchKernelGGL(k_depth_order<true>, dim3((unsigned)G), dim3(64), 0, st, G, tri_off, cand, guard, perm,
+                       reinterpret_cast<unsigned *>(rng), place, rec, place ? st_z : nullptr);
+    hipLaunchKernelGGL(k_depth_order<false>, dim3((unsigned)G), dim3(64), 0, st, G, tri_off, cand, guard, perm,
+                       reinterpret_cast<unsigned *>(rng), place, rec, place ? st_z : nullptr);
+  }
   if (sorted && place) {
     a.perm = rec;
     a.spos = perm;
