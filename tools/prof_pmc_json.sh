@@ -63,7 +63,9 @@ for mode in ("matched", "exhaustive"):
         m = re.search(r"(k_[a-z_0-9]+)", row[0])
         if not m:
             continue
-        vals.setdefault(m.group(1), {})[row[1]] = float(row[3])
+        # (instantiations of one template -- k_depth_order<big> / <small> -- run once each per step: their counters add up)
+        d = vals.setdefault(m.group(1), {})
+        d[row[1]] = d.get(row[1], 0.0) + float(row[3])
     kern = {}
     for name, v in vals.items():
         k = {"raw": v}

@@ -1,9 +1,16 @@
 """Developer tool: the end-to-end call sequence under the conditions bench.py measures it in (torch imported and initialised,
 the Python track list built, a post-processing chain between repetitions), one factor at a time.
-   python tools/profile_e2e_variants.py [torch] [tracks] [post] [ranks]"""
+   python tools/profile_e2e_variants.py [torch] [torch_import] [gomp] [sysgomp] [tracks] [post]"""
 import gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 flags = set(sys.argv[1:])
+if "gomp" in flags:  # torch's bundled libgomp (an older build with the system one's soname) without torch: whoever loads first wins
+    import ctypes, importlib.util
+    _t = os.path.dirname(importlib.util.find_spec("torch").origin)
+    ctypes.CDLL(os.path.join(_t, "lib", "libgomp.so"), mode=ctypes.RTLD_GLOBAL)
+if "sysgomp" in flags:  # the system's libgomp first, then torch: torch runs on the system's
+    import ctypes
+    ctypes.CDLL("libgomp.so.1", mode=ctypes.RTLD_GLOBAL)
 if "torch" in flags or "torch_import" in flags or "torch_init" in flags:
     import torch
     if "torch_import" not in flags:
