@@ -829,11 +829,12 @@ int lt_run_device_async(lt_ctx *ctx) {
     C_run = C_bound;  // replaced by the exact count when that arrives with the error flag (finish_run)
     // split form (default for the single-precision sweep): the sweep writes pair chunks, k_dense8 evaluates them with
     // full rounds; LT_SCORE_FUSED=1 or a chunk store that overflowed once: the fused kernel
-    // (matched mode; the exhaustive mode's tiles carry ~25 pairs each and its units would be four tiles all the same -- the
-    // per-unit work of k_dense8 then costs what the full rounds save: 1.16 + 1.44 ms against 2.54 fused.  LT_SCORE_SPLIT=1
-    // forces the split form there and for the natural tile order, for the tests.)
+    // (the exhaustive mode's depth-sorted tiles carry ~25 pairs each and k_dense8's units there are a few tiles whatever they
+    // hold: 1.16 + 1.44 ms against 2.54 fused in round 5, 1.15 + 1.13 against 2.36 since round 6 -- the fused kernel keeps its
+    // 10 KB table of maxima per wave through the sweep, six waves to a CU.  LT_SCORE_SPLIT=1 forces the split form for
+    // the natural tile order too, for the tests.)
     const bool split = score_f32 && !ctx->score_fused && !test_switch("LT_SCORE_FUSED") &&
-                       (tile_classes || test_switch("LT_SCORE_SPLIT"));
+                       (tile_classes || staged_sorted || test_switch("LT_SCORE_SPLIT"));
     long long sp_chunks = 0;
     int sp_slot_cap = ctx->job_mode == 2 ? 64 : 256;  // entries per tile slot (matched: p90 of the bench scene is 182 pairs)
     if (split) {

@@ -546,11 +546,17 @@ def test_split_and_fused_scoring_agree(gpu_lib, clean_env, topk, n_nb):
     nat = _results(run_product(sc, cfg, topk=topk))
     _same(base, nat)
     del os.environ["LT_TEST_NO_TILE_CLASSES"]
-    # exhaustive mode (depth-sorted tiles): fused by default, split when asked for
-    ex_split = _results(run_product(sc, cfg, exhaustive=True))
     del os.environ["LT_SCORE_SPLIT"]
+    # exhaustive mode (depth-sorted tiles): split by default since round 6, fused when asked for
     ex_default = _results(run_product(sc, cfg, exhaustive=True))
-    _same(ex_default, ex_split)
+    os.environ["LT_SCORE_FUSED"] = "1"
+    ex_fused = _results(run_product(sc, cfg, exhaustive=True))
+    _same(ex_default, ex_fused)
+    assert ex_default[4]["score_fused"] == 0 and ex_fused[4]["pairs_eval"] == ex_default[4]["pairs_eval"]
+    del os.environ["LT_SCORE_FUSED"]
+    os.environ["LT_TEST_SPLIT_SLOT"] = "4"  # ... and its overflow chains
+    _same(ex_default, _results(run_product(sc, cfg, exhaustive=True)))
+    del os.environ["LT_TEST_SPLIT_SLOT"]
 
 
 @pytest.mark.parametrize("shape", [(24, 160, 8, 10), (40, 30, 12, 4), (9, 700, 5, 3)])
