@@ -129,6 +129,20 @@ def load_pmc(world, default_wl):
     return d.get("kernels", {}), None
 
 
+def exhaustive_stage_pmc(pmc):
+    """Counters of the exhaustive mode's scoring stage: since round 6 it runs in the split form -- k_depth_order (two size
+    classes, summed by tools/prof_pmc_json.sh), the sweep kernel k_score3<sorted, split> and k_dense8 -- and one pair of events
+    times the three; LT_SCORE_FUSED=1: k_depth_order + the fused k_score3."""
+    parts = [n for n in ("k_depth_order", "k_score3", "k_dense8") if n in pmc]
+    if os.environ.get("LT_SCORE_FUSED") or "k_dense8" not in pmc or "k_score3" not in pmc:
+        return pmc
+    out = dict(pmc)
+    keys = set.intersection(*[set(k for k, v in pmc[n].items() if isinstance(v, (int, float))) for n in parts])
+    out["k_score3"] = {k: sum(pmc[n][k] for n in parts) for k in keys if k not in ("valu_busy_frac", "lds_active_frac")}
+    out["k_score3"]["per_kernel"] = {n: {k: v for k, v in pmc[n].items() if k != "raw"} for n in parts}
+    return out
+
+
 def roofline_entry(name, nbytes, ms, pmc):
     gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     e = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -882,6 +896,7 @@ def main():
             kernels = {"k_score3": (ab["score"], kt.get("k_score3", 0.0)), "k_gates": (ab["gates"], kt.get("k_gates", 0.0)),
                        "k_tri_rows": (ab["tri"], kt.get("k_tri_rows", 0.0))}
         else:
+            pmc = exhaustive_stage_pmc(pmc)
             kernels = {"k_score3": (ab["score"], kt.get("k_score3", 0.0)), "k_gen_exhaustive": (ab["gen"], kt.get("gen", 0.0))}
         dom = max(kernels, key=lambda k: kernels[k][1])
         roof = {name: roofline_entry(name, nbytes, ms, pmc) for name, (nbytes, ms) in kernels.items()}
@@ -1046,7 +1061,7 @@ def main():
             sx = cx.stats()
             sx["active_nodes"] = st["active_nodes"]
             abx = algorithmic_bytes(sx, len(my_imgs), args.neighbors, 0.0, "exhaustive")
-            pmx = pmc_all.get("exhaustive", {})
+            pmx = exhaustive_stage_pmc(pmc_all.get("exhaustive", {}))
             rx = {"k_score3": roofline_entry("k_score3", abx["score"], ktx.get("k_score3", 0.0), pmx),
                   "k_gen_exhaustive": roofline_entry("k_gen_exhaustive", abx["gen"], ktx.get("gen", 0.0), pmx)}
             out["exhaustive"] = {"ms_per_step": 1e3 * el / n_x, "value": sx["candidates"] * n_x / el, "unit": "candidates/s",
