@@ -497,11 +497,13 @@ def _emit(line):
 
 def e2e_child(views, segs, neighbors, seed, topk):
     """`bench.py --e2e-child ...`: the reference's call sequence in a process WITHOUT torch -- what a caller of the library
-    that does not import torch sees.  `import torch` alone (no CUDA initialisation needed) makes the host path of this
-    library 0.4-0.6 ms slower in the same process (tools/profile_e2e_variants.py: 2.9-3.2 -> 3.4-3.8 ms; constructor + Init
-    0.43 -> 0.7-0.8, the 100 TriangulateImage calls 1.2 -> 1.5); which HIP runtime serves the calls (torch's bundled one or
-    the system's), OpenMP / MKL thread counts and wait policy, NUMA confinement and malloc tunables do not account for it --
-    the cause was not found.  Prints one E2E_CHILD json line."""
+    that does not import torch sees.  In a process that has imported torch the same repetitions measured 0.4-0.6 ms more
+    (tools/profile_e2e_variants.py: 2.9-3.2 -> 3.4-3.8 ms; constructor + Init 0.43 -> 0.7-0.8).  Found at the end of round 6:
+    the harness's own gc.collect() in front of every repetition walks the ~1e6 objects `import torch` leaves behind and the
+    repetition starts with cold caches (gc.freeze() once, or no collection: constructor + Init back at 0.3-0.4); loading
+    torch's libraries without the Python import, which HIP runtime serves the calls, OpenMP / MKL settings, NUMA confinement
+    and malloc tunables change nothing.  The legs below freeze the collector's generations before their repetitions; this
+    child stays as the figure of a torch-free caller.  Prints one E2E_CHILD json line."""
     import gc
     from limap_amd import merging, synthetic as syn, triangulation as tri
     sc = syn.make_scene(n_views=views, n_segs=segs, n_neighbors=neighbors, seed=seed)
@@ -511,6 +513,7 @@ def e2e_child(views, segs, neighbors, seed, topk):
     n_rep = 6
     per_image, batched, with_post, parts = [], [], [], []
     n_tracks = n_post = 0
+    gc.collect(); gc.freeze()
     for form in ("per_image", "batched"):
         for rep in range(n_rep):
             gc.collect()
@@ -1083,10 +1086,16 @@ def main():
         from limap_amd import merging
         import gc
         n_rep = 5
+        # Everything alive now (torch's ~1e6 objects, the scene) leaves the collector's generations: the collection in front of
+        # each repetition then walks only what the previous repetition left, instead of evicting the library's and the HIP
+        # runtime's working set from the caches right before the clock starts (that was the "0.4-0.6 ms that come with
+        # `import torch`" of the round's first lines: constructor + Init 0.6-0.7 ms against 0.3-0.4)
+        gc.collect()
+        gc.freeze()
         for rep in range(n_rep):
             torch.cuda.synchronize(dev)
-            gc.collect()   # a generation-2 pass over the synthetic scene's objects (tens of ms) must not
-            gc.disable()   # land inside one of the three timed repetitions
+            gc.collect()   # a generation-2 pass over the previous repetition's objects must not
+            gc.disable()   # land inside one of the timed repetitions
             t0 = time.perf_counter()
             T = tri.GlobalLineTriangulator(cfg, device=local_rank)
             T.SetRanges(scene.ranges)
@@ -1197,9 +1206,10 @@ def main():
                 if line:
                     ch = json.loads(line[-1][10:])
                     assert ch["tracks"] == len(tracks_py) and not ch["torch_in_process"]
-                    ch["note"] = ("the same call sequences in a fresh child process that does not import torch; `import torch` alone "
-                                  "adds 0.4-0.6 ms to the host path in the same process (cause not found: DESIGN.md section 4) -- "
-                                  "e2e_wall_ms above is measured in this process, which needs torch for the driver's contract")
+                    ch["note"] = ("the same call sequences in a fresh child process that does not import torch (e2e_wall_ms above is "
+                                  "measured in this process, which needs torch for the driver's contract; until the end of round 6 it "
+                                  "read 0.4-0.6 ms more than this child: the harness's gc.collect() before each repetition walked "
+                                  "torch's objects and the repetition started with cold caches -- gc.freeze() now, DESIGN.md section 4)")
                     out["e2e_clean_process"] = ch
                 else:
                     out["e2e_clean_process"] = {"error": pr.stderr[-300:]}

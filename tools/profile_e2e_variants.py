@@ -8,6 +8,14 @@ if "gomp" in flags:  # torch's bundled libgomp (an older build with the system o
     import ctypes, importlib.util
     _t = os.path.dirname(importlib.util.find_spec("torch").origin)
     ctypes.CDLL(os.path.join(_t, "lib", "libgomp.so"), mode=ctypes.RTLD_GLOBAL)
+for _f, _libs in (("roctracer", ("libroctracer64.so", "librocprofiler-register.so")), ("rocblas", ("librocblas.so", "libMIOpen.so", "libhipblaslt.so")),
+                  ("c10", ("libc10.so",)), ("torch_cpu", ("libtorch_cpu.so",)), ("torch_hip", ("libtorch_hip.so",))):
+    if _f in flags:  # parts of what `import torch` loads, without torch: which one slows the HIP calls of this library down?
+        import ctypes, importlib.util
+        _t = os.path.dirname(importlib.util.find_spec("torch").origin)
+        ctypes.CDLL(os.path.join(_t, "lib", "libamdhip64.so"), mode=ctypes.RTLD_GLOBAL)
+        for _l in _libs:
+            ctypes.CDLL(os.path.join(_t, "lib", _l), mode=ctypes.RTLD_GLOBAL)
 if "sysgomp" in flags:  # the system's libgomp first, then torch: torch runs on the system's
     import ctypes
     ctypes.CDLL("libgomp.so.1", mode=ctypes.RTLD_GLOBAL)
@@ -39,8 +47,12 @@ cfg = syn.default_triangulation_cfg()
 matches = {int(i): sc.matches_of(int(i)) for i in sc.img_ids}
 segs_list = [sc.segs_of(j) for j in range(sc.n_images)]
 res = []
+if "freeze" in flags:  # what was imported so far leaves the collector's generations: a collection no longer walks torch's objects
+    gc.collect(); gc.freeze()
 for rep in range(7):
-    gc.collect(); gc.disable()
+    if "nogc" not in flags:
+        gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     T = tri.GlobalLineTriangulator(cfg)
     T.SetRanges(sc.ranges)
