@@ -874,8 +874,11 @@ int lt_run_device_async(lt_ctx *ctx) {
                   pair_classes ? ctx->d_pc_list.p : nullptr, tile_cap,
                   // the one-kernel form k_score_q (default; LT_SCORE_TWO_KERNELS=1 or device flag 8 once: sweep kernel + k_dense8;
                   // its pair entries carry the neighbour word in 26 bits; 2 = LT_TEST_Q_LOSE_TILE, a tile is never published)
-                  (ctx->score_two_kernels || test_switch("LT_SCORE_TWO_KERNELS") || ctx->n_img >= (1 << 18))
-                      ? 0 : (test_switch("LT_TEST_Q_LOSE_TILE") ? 2 : 1));
+                  // (+ 4 = LT_TEST_DENSE_TABLES: k_dense8's per-tile tables in the exhaustive mode too, instead of k_dense_rows;
+                  //  + 8 = LT_TEST_DENSE_FEW_ROWS: k_dense_rows with a table of 64 rows)
+                  (((ctx->score_two_kernels || test_switch("LT_SCORE_TWO_KERNELS") || ctx->n_img >= (1 << 18))
+                        ? 0 : (test_switch("LT_TEST_Q_LOSE_TILE") ? 2 : 1)) |
+                   (test_switch("LT_TEST_DENSE_TABLES") ? 4 : 0) | (test_switch("LT_TEST_DENSE_FEW_ROWS") ? 8 : 0)));
     if (C_bound <= 0 && sampled) HIPCHK(ctx, hipEventRecord(ev[5], st));  // nothing to score: no kernel carries the event
   }
   ENSURE(ctx, ctx->d_best_idx, 8 * (size_t)std::max<long long>(G, 1));

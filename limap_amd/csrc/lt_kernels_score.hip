@@ -1340,6 +1340,265 @@ k_dense8(Score3Args a, ScoreCfg cfg, int score_by) {  // score_by: 0 = record of
   }
 }
 
+// k_dense8 for the depth-sorted tiles of the exhaustive mode (round 6, last part).  A tile there carries ~25 pairs on ~20 of
+// its 64 candidates; with one 64 x max_nb table of maxima per tile (10 KB) a unit was three tiles -- 75 pairs for four waves, and
+// 1.1e5 units each paying its header, entries and sums (1.13 ms, 128 ns per 1 000 pairs against 67 in matched mode).  Here a
+// unit is kChunkTiles consecutive tiles and the table has a ROW only for a candidate that has a pair: a first pass over the
+// unit's entries sets the tiles' 64-bit masks, row = (rows of the tiles before) + (mask bits below the lane); the rows of a
+// unit (~160) fit the same 36 KB.  A unit whose rows do not fit is worked off in groups of tiles that do.  Units in natural
+// order (the exhaustive mode has no cost-class lists), claimed as in k_dense8.  Same arithmetic, same order of the sums.
+constexpr int kRowsHdrBytes = 16 + kChunkTiles * 8 + (kChunkTiles + 8) * 4;
+template <bool kFast>
+__global__ void __launch_bounds__(64 * kDenseWaves) LT_DENSE_OCC
+k_dense_rows(Score3Args a, ScoreCfg cfg, int score_by, int rows_cap) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  unsigned *s_next = reinterpret_cast<unsigned *>(smem_raw);                              // [4]
+  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(smem_raw + 16);     // [kChunkTiles] candidates with a pair
+  unsigned long long *S = reinterpret_cast<unsigned long long *>(smem_raw + ((kRowsHdrBytes + 15) & ~15));
+  if (a.err_flag && *a.err_flag == kErrPairChunks) return;  // the overflow store was full: the run is repeated
+  const long long C = a.tri_off[a.G];
+  const unsigned n_tiles = (unsigned)((C + 63) >> 6);
+  constexpr int T = kChunkTiles;
+  constexpr int kWaves = kDenseWaves;
+  constexpr int kThreads = 64 * kWaves;
+  static_assert(kChunkTiles * 64 <= 2 * kThreads, "two tiles per wave in the sums");
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const unsigned n_units = (n_tiles + (unsigned)T - 1) / (unsigned)T;
+  const int max_nb = a.max_nb;
+  const int cap = a.sp_slot_cap;
+  unsigned long long n_pairs_wg = 0;
+  int myq = (int)(blockIdx.x & 7u);
+  auto resolve_claim = [&](unsigned c, int &q_io) -> unsigned {  // one lane; as in k_dense8
+    unsigned un = ((gridDim.x >> 3) + c) * 8u + (unsigned)q_io;
+    int tries = 0;
+    while (un >= n_units && tries < 16) {
+      ++tries;
+      int q2 = -1;
+      for (int d = 1; d < 8; ++d) {
+        const int qq = (q_io + d) & 7;
+        const unsigned seen = __hip_atomic_load(&a.sp_counters[32 * (1 + qq)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((gridDim.x >> 3) + seen) * 8u + (unsigned)qq < n_units) { q2 = qq; break; }
+      }
+      if (q2 < 0) break;
+      q_io = q2;
+      const unsigned c3 = atomicAdd(&a.sp_counters[32 * (1 + q2)], 1u);
+      un = ((gridDim.x >> 3) + c3) * 8u + (unsigned)q2;
+    }
+    return un;
+  };
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto header = [&](unsigned uu, int &nt_o, unsigned &tile_o, unsigned &cnt_o) {  // lanes < nt of every wave: tile and pair count
+    nt_o = 0; tile_o = 0; cnt_o = 0;
+    if (uu >= n_units) return;
+    const unsigned t0 = uu * (unsigned)T;
+    nt_o = (int)min((unsigned)T, n_tiles - t0);
+    if (lane < nt_o) {
+      tile_o = t0 + (unsigned)lane;
+      cnt_o = a.sp_cnt[tile_o];
+    }
+  };
+  unsigned u_cur = blockIdx.x;
+  int nt;
+  unsigned h_tile, h_cnt;
+  header(u_cur, nt, h_tile, h_cnt);
+  if (tid < nt) n_pairs_wg += (unsigned long long)h_cnt;
+  for (int k = tid; k < rows_cap * max_nb; k += kThreads) S[k] = 0ull;
+  while (nt > 0) {
+    int off[kChunkTiles + 1];
+    off[0] = 0;
+#pragma unroll
+    for (int k = 0; k < kChunkTiles; ++k)
+      off[k + 1] = off[k] + (k < nt ? min((int)(unsigned)__builtin_amdgcn_readlane((int)h_cnt, k), cap) : 0);
+    auto entry_of = [&](int p, int &k) -> uint4 {
+      k = 0;
+#pragma unroll
+      for (int m = 1; m < kChunkTiles; ++m) k += (p >= off[m]) ? 1 : 0;
+      int o = off[0];
+#pragma unroll
+      for (int m = 1; m < kChunkTiles; ++m) o = (k >= m) ? off[m] : o;
+      return a.sp_slots[(size_t)(u_cur * (unsigned)T + (unsigned)k) * (size_t)cap + (p - o)];  // (tiles of a unit are consecutive)
+    };
+    const int total = off[kChunkTiles];
+    if (tid < kChunkTiles) s_mask[tid] = 0ull;
+    // the candidates (table rows) this wave sums: tiles wave and wave + kWaves of the unit
+    CandMeta mt[2];
+    long long pos[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ti = wave + kWaves * h;
+      pos[h] = -1;
+      mt[h] = CandMeta{0u, 0u, 0u, 0u};
+      if (ti < nt) {
+        const long long p = (long long)(unsigned)__builtin_amdgcn_readlane((int)h_tile, ti & (kChunkTiles - 1)) * 64 + lane;
+        if (p < C) {
+          pos[h] = p;
+          mt[h] = a.meta[p];
+        }
+      }
+    }
+    __syncthreads();  // masks cleared; every wave has summed and zeroed its rows of the previous unit
+    // ---- pass 1: which candidates have a pair (the entries are read again in pass 2: L2) ----
+    for (int p = tid; p < total; p += kThreads) {
+      int k;
+      const uint4 e = entry_of(p, k);
+      atomicOr(&s_mask[k], 1ull << (e.z & 63u));
+    }  // (entry_of holds no cross-lane operation: the loop may diverge)
+    for (int k = 0; k < nt; ++k) {
+      if ((int)(unsigned)__builtin_amdgcn_readlane((int)h_cnt, k & (kChunkTiles - 1)) <= cap) continue;
+      unsigned cc = a.sp_ovf[(unsigned)__builtin_amdgcn_readlane((int)h_tile, k & (kChunkTiles - 1))];
+      while (cc != kNoChunk) {
+        const uint2 d = a.sp_desc[cc];
+        for (int p = tid; p < (int)d.x; p += kThreads) atomicOr(&s_mask[k], 1ull << (a.sp_pairs[(size_t)cc * kChunkCap + p].z & 63u));
+        cc = d.y;
+      }
+    }
+    int ordv[2] = {0, 0};
+    long long wnb0[2] = {-1, -1};
+    unsigned nb0_l[2] = {0u, 0u};
+    int nn_l[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (wave + kWaves * h < nt) {
+        nb0_l[h] = mt[h].nb >> 8;
+        nn_l[h] = pos[h] >= 0 ? (int)(mt[h].nb & 0xFFu) : 0;
+        wnb0[h] = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)nb0_l[h]);
+        const int n0 = __builtin_amdgcn_readfirstlane(nn_l[h]);
+        if (lane < n0) ordv[h] = a.blk_order[wnb0[h] + lane];
+        if (n0 > 64) wnb0[h] = -1;
+      }
+    }
+    __syncthreads();  // the masks are complete
+    unsigned long long mk[kChunkTiles];
+    int rb[kChunkTiles + 1];  // rows of the unit's tiles before tile k
+    rb[0] = 0;
+#pragma unroll
+    for (int k = 0; k < kChunkTiles; ++k) {
+      mk[k] = k < nt ? s_mask[k] : 0ull;
+      rb[k + 1] = rb[k] + __popcll(mk[k]);
+    }
+    unsigned c2 = 0;
+    bool claimed = false;
+    auto eval = [&](const uint4 e, const int k, const int row0) {
+      const CRec &ci = a.cand[e.y];
+      const CRec &cj = a.cand[e.x];
+      const int nbs_j = cj.nb_slot;
+      const d3 si_ = mk3(ci.s[0], ci.s[1], ci.s[2]), ei_ = mk3(ci.e[0], ci.e[1], ci.e[2]), di_ = mk3(ci.dir[0], ci.dir[1], ci.dir[2]);
+      const d3 sj_ = mk3(cj.s[0], cj.s[1], cj.s[2]), ej_ = mk3(cj.e[0], cj.e[1], cj.e[2]), dj_ = mk3(cj.dir[0], cj.dir[1], cj.dir[2]);
+      const Cam &camj = a.cams[(int)((unsigned)nbs_j >> 8)];
+      double sc;
+      if constexpr (kFast) sc = pair_score_fused(cfg, si_, ei_, di_, ci.depth[0], ci.depth[1], sj_, ej_, dj_, cj.seg, camj);
+      else sc = pair_score_terms(cfg, si_, ei_, di_, ci.depth[0], ci.depth[1], sj_, ej_, dj_, cj.seg, camj);
+      if (sc > 0.0) {
+        unsigned long long m = 0ull;
+        int r0 = 0;
+#pragma unroll
+        for (int q = 0; q < kChunkTiles; ++q) {
+          m = (k == q) ? mk[q] : m;
+          r0 = (k == q) ? rb[q] : r0;
+        }
+        const int row = r0 - row0 + __popcll(m & ((1ull << (e.z & 63u)) - 1ull));
+        atomicMax(&S[row * max_nb + (nbs_j & 0xFF)], (unsigned long long)__double_as_longlong(sc));
+      }
+    };
+    // groups of consecutive tiles whose rows fit the table (nearly always the whole unit)
+    int ka = 0;
+    while (ka < nt) {
+      int kb = ka + 1;
+#pragma unroll
+      for (int q = 1; q <= kChunkTiles; ++q)
+        if (q > ka && q <= nt && rb[q] - rb[ka] <= rows_cap) kb = q;  // (the largest prefix that fits; one tile always does)
+      int p_lo = 0, p_hi = 0, row0 = 0;
+#pragma unroll
+      for (int q = 0; q <= kChunkTiles; ++q) {
+        p_lo = (q == ka) ? off[q] : p_lo;
+        p_hi = (q == kb) ? off[q] : p_hi;
+        row0 = (q == ka) ? rb[q] : row0;
+      }
+      if (kb >= nt && !claimed) {  // the last group: claim the next unit under its rounds
+        claimed = true;
+        if (tid == kThreads - 64) c2 = atomicAdd(&a.sp_counters[32 * (1 + myq)], 1u);
+      }
+      for (int p = p_lo + tid; p < p_hi; p += kThreads) {
+        int k;
+        const uint4 e = entry_of(p, k);
+        eval(e, k, row0);
+      }
+      for (int k = ka; k < kb; ++k) {
+        if ((int)(unsigned)__builtin_amdgcn_readlane((int)h_cnt, k & (kChunkTiles - 1)) <= cap) continue;
+        unsigned cc = a.sp_ovf[(unsigned)__builtin_amdgcn_readlane((int)h_tile, k & (kChunkTiles - 1))];
+        while (cc != kNoChunk) {
+          const uint2 d = a.sp_desc[cc];
+          for (int p = tid; p < (int)d.x; p += kThreads) eval(a.sp_pairs[(size_t)cc * kChunkCap + p], k, row0);
+          cc = d.y;
+        }
+      }
+      if (kb >= nt && tid == kThreads - 64) {
+        int q_n = myq;
+        s_next[0] = resolve_claim(c2, q_n);
+        s_next[1] = (unsigned)q_n;
+      }
+      __syncthreads();  // every pair of the group is in the table
+      // ---- the sums of the group's tiles: a lane with a row reads it in its image's order and leaves it zero ----
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ti = wave + kWaves * h;
+        if (ti >= nt || ti < ka || ti >= kb) continue;  // wave-uniform
+        const bool act = pos[h] >= 0;
+        unsigned long long m = 0ull;
+        int r0 = 0;
+#pragma unroll
+        for (int q = 0; q < kChunkTiles; ++q) {
+          m = (ti == q) ? mk[q] : m;
+          r0 = (ti == q) ? rb[q] : r0;
+        }
+        const bool has = ((m >> lane) & 1ull) != 0ull;
+        const int row = r0 - row0 + __popcll(m & ((1ull << lane) - 1ull));
+        const long long nb0 = (long long)nb0_l[h];
+        const int n_nb = has ? nn_l[h] : 0;
+        const bool own = nb0 == wnb0[h];
+        const int n_max = wave_max_i32(n_nb);
+        double sum = 0.0;
+        if (!__any(has && !own)) {
+          for (int k0 = 0; k0 < n_max; k0 += kSumChunk) {
+            unsigned long long v[kSumChunk];
+            int sl[kSumChunk];
+#pragma unroll
+            for (int u = 0; u < kSumChunk; ++u) {
+              const int k = k0 + u;
+              sl[u] = __builtin_amdgcn_readlane(ordv[h], k & 63);
+              v[u] = k < n_nb ? S[row * max_nb + sl[u]] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < kSumChunk; ++u) sum += __longlong_as_double((long long)v[u]);
+#pragma unroll
+            for (int u = 0; u < kSumChunk; ++u)
+              if (k0 + u < n_nb) S[row * max_nb + sl[u]] = 0ull;
+          }
+        } else {
+          for (int k = 0; k < n_nb; ++k) {
+            unsigned long long *cell = &S[row * max_nb + a.blk_order[nb0 + k]];
+            sum += __longlong_as_double((long long)*cell);
+            *cell = 0ull;
+          }
+        }
+        if (act) a.score[score_by == 1 ? pos[h] : (score_by == 2 ? (long long)a.spos[pos[h]] : (long long)(a.perm ? a.perm[pos[h]] : (unsigned)pos[h]))] = sum;
+      }
+      ka = kb;
+      if (ka < nt) __syncthreads();  // the next group's rows start from a clean table
+    }
+    const unsigned un = (unsigned)__builtin_amdgcn_readfirstlane((int)s_next[0]);
+    myq = __builtin_amdgcn_readfirstlane((int)s_next[1]);
+    u_cur = un;
+    header(u_cur, nt, h_tile, h_cnt);
+    if (tid < nt) n_pairs_wg += (unsigned long long)h_cnt;
+  }
+  if (a.pair_counter && tid < 64) {
+    for (int d = 32; d >= 1; d >>= 1) n_pairs_wg += (unsigned long long)__shfl_xor((long long)n_pairs_wg, d);
+    if (tid == 0 && n_pairs_wg) atomicAdd(a.pair_counter, n_pairs_wg);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Round 6, second half: the scoring stage as ONE kernel -- k_score_q.  The default of the matched mode.
 // ---------------------------------------------------------------------------------------------
@@ -1947,6 +2206,9 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
   if (C <= 0) return;
   // one_kernel: the split form as ONE persistent kernel (k_score_q) where it applies: single-precision sweep over the
   // placement permutation (matched mode), cost-class lists and the pair store present
+  const bool dense_tables = (one_kernel & 4) != 0;  // LT_TEST_DENSE_TABLES: k_dense8 instead of k_dense_rows (exhaustive mode)
+  const bool few_rows = (one_kernel & 8) != 0;      // LT_TEST_DENSE_FEW_ROWS: a table of 64 rows (units worked off in groups of tiles)
+  one_kernel &= 3;
   const bool q_form = one_kernel != 0 && sp_slots != nullptr && f32 && perm != nullptr && perm_is_placement && rng == nullptr &&
                       bucket_cnt != nullptr && pc_list != nullptr;
   static int n_cu = 0;
@@ -2057,6 +2319,17 @@ void launch_score3(hipStream_t st, long long C, long long G, const long long *tr
     const size_t lds2 = (size_t)kDenseHdrBytes + (size_t)a.sp_t_max * (size_t)max_nb * 512;
     const long long fit = std::max<long long>(1, std::min<long long>(kDensePerCU, (long long)(160 * 1024 / lds2)));
     const int by = perm_is_placement ? 1 : (sorted && a.spos ? 2 : 0);
+    // depth-sorted tiles without class lists (the exhaustive mode): units of kChunkTiles tiles over row-compacted tables
+    const int rows_cap = few_rows ? 64 : kDenseLdsBudget / (std::max(max_nb, 1) * 8);
+    if (sorted && !use_pc && bucket_cnt == nullptr && rows_cap >= 64 && !dense_tables) {
+      const size_t lds3 = (size_t)((kRowsHdrBytes + 15) & ~15) + (size_t)rows_cap * (size_t)max_nb * 8;
+      const long long fit3 = std::max<long long>(1, std::min<long long>(kDensePerCU, (long long)(160 * 1024 / lds3)));
+      const dim3 g3((unsigned)std::max<long long>(8, (fit3 * n_cu) & ~7ll));
+      if (cfg.fast) hipExtLaunchKernelGGL(k_dense_rows<true>, g3, dim3(64 * kDenseWaves), lds3, st, nullptr, ev_stop, 0, a, cfg, by, rows_cap);
+      else hipExtLaunchKernelGGL(k_dense_rows<false>, g3, dim3(64 * kDenseWaves), lds3, st, nullptr, ev_stop, 0, a, cfg, by, rows_cap);
+      if (ev_after && ev_markers) (void)hipEventRecord(ev_after, st);
+      return;
+    }
     const dim3 g2((unsigned)std::max<long long>(8, (fit * n_cu) & ~7ll));  // a multiple of 8: see the unit queues
     if (cfg.fast) hipExtLaunchKernelGGL(k_dense8<true>, g2, dim3(64 * kDenseWaves), lds2, st, nullptr, ev_stop, 0, a, cfg, by);
     else hipExtLaunchKernelGGL(k_dense8<false>, g2, dim3(64 * kDenseWaves), lds2, st, nullptr, ev_stop, 0, a, cfg, by);

@@ -39,7 +39,7 @@ def _same(a, b):
 def clean_env():
     keys = ("LT_TEST_NO_FAST_GATES", "LT_TEST_NO_SCORE_GUARDS", "LT_TEST_PLACE_COPY", "LT_TEST_NO_TILE_CLASSES",
             "LT_TEST_EX_TWO_PASS", "LT_TEST_EX_PASS1_BLOCK", "LT_TEST_EX_PASS2_BLOCK", "LT_TEST_EX_CAP_FRAC",
-            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TIMER_SAMPLE", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_SCORE_SPLIT",
+            "LT_TEST_SCORE_UNSORTED", "LT_FINE_TIMERS", "LT_TIMER_SAMPLE", "LT_TEST_SCORE_F64", "LT_SCORE_FUSED", "LT_SCORE_SPLIT", "LT_TEST_DENSE_TABLES", "LT_TEST_DENSE_FEW_ROWS",
             "LT_TEST_SPLIT_SLOT", "LT_TEST_SPLIT_CHUNKS", "LT_TEST_PAIR_SCORE_TERMS", "LT_TEST_NO_PAIR_CLASSES", "LT_TEST_GATES_IMAGE_MAJOR",
             "LT_SCORE_TWO_KERNELS", "LT_TEST_Q_LOSE_TILE", "LT_TEST_TRI_STATIC")
     saved = {k: os.environ.pop(k, None) for k in keys}
@@ -557,6 +557,15 @@ def test_split_and_fused_scoring_agree(gpu_lib, clean_env, topk, n_nb):
     os.environ["LT_TEST_SPLIT_SLOT"] = "4"  # ... and its overflow chains
     _same(ex_default, _results(run_product(sc, cfg, exhaustive=True)))
     del os.environ["LT_TEST_SPLIT_SLOT"]
+    # the dense kernel of the exhaustive mode: units of eight tiles over a row-compacted table (k_dense_rows) by default;
+    # with a table of 64 rows (units worked off in groups of tiles), also over overflow chains; k_dense8's per-tile tables
+    for env in ({"LT_TEST_DENSE_FEW_ROWS": "1"}, {"LT_TEST_DENSE_FEW_ROWS": "1", "LT_TEST_SPLIT_SLOT": "4"}, {"LT_TEST_DENSE_TABLES": "1"}):
+        os.environ.update(env)
+        r = _results(run_product(sc, cfg, exhaustive=True))
+        _same(ex_default, r)
+        assert r[4]["pairs_eval"] == ex_default[4]["pairs_eval"]
+        for k in env:
+            del os.environ[k]
 
 
 @pytest.mark.parametrize("shape", [(24, 160, 8, 10), (40, 30, 12, 4), (9, 700, 5, 3)])
