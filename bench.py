@@ -132,9 +132,10 @@ def load_pmc(world, default_wl):
 def exhaustive_stage_pmc(pmc):
     """Counters of the exhaustive mode's scoring stage: since round 6 it runs in the split form -- k_depth_order (two size
     classes, summed by tools/prof_pmc_json.sh), the sweep kernel k_score3<sorted, split> and k_dense8 -- and one pair of events
-    times the three; LT_SCORE_FUSED=1: k_depth_order + the fused k_score3."""
-    parts = [n for n in ("k_depth_order", "k_score3", "k_dense8") if n in pmc]
-    if os.environ.get("LT_SCORE_FUSED") or "k_dense8" not in pmc or "k_score3" not in pmc:
+    times the three (the dense kernel there is k_dense_rows since the last part of the round); LT_SCORE_FUSED=1: k_depth_order + the
+    fused k_score3."""
+    parts = [n for n in ("k_depth_order", "k_score3", "k_dense8", "k_dense_rows") if n in pmc]
+    if os.environ.get("LT_SCORE_FUSED") or not ("k_dense8" in pmc or "k_dense_rows" in pmc) or "k_score3" not in pmc:
         return pmc
     out = dict(pmc)
     keys = set.intersection(*[set(k for k, v in pmc[n].items() if isinstance(v, (int, float))) for n in parts])
