@@ -148,6 +148,70 @@ class _LazyLineTrack(LineTrack):
         return (_track_from_state, (self.materialise().__dict__,))
 
 
+class _LazyTrackList(list):
+    """The list ComputeLineTracks / GetTracks hand back: a `list` of LineTrack whose elements are built when they are first
+    looked at (1 367 track objects of the bench scene cost 0.3 ms to create -- a tenth of the whole call sequence -- and a caller
+    that goes on with the array form, merging.TrackSet, never touches them).  Unbuilt slots hold None internally; every way
+    into the list that could see one goes through `_at` or builds everything first."""
+
+    def __init__(self, t, segs, _raw=None):
+        list.__init__(self, [None] * (len(t["off"]) - 1) if _raw is None else _raw)
+        self._t, self._segs = t, segs
+
+    def _at(self, i):
+        v = list.__getitem__(self, i)
+        if v is None:
+            v = _LazyLineTrack(self._t, i, self._segs)
+            list.__setitem__(self, i, v)
+        return v
+
+    def _all(self):
+        # (elements appended / inserted by a caller are real objects; a slot is unbuilt only while it is None AND still at
+        # its original index, which holds as long as nobody reorders the list before this runs -- every reordering method
+        # below runs it first)
+        for i in range(list.__len__(self)):
+            if list.__getitem__(self, i) is None:
+                list.__setitem__(self, i, _LazyLineTrack(self._t, i, self._segs))
+        return self
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._at(k) for k in range(*i.indices(list.__len__(self)))]
+        n = list.__len__(self)
+        k = i + n if i < 0 else i
+        if not 0 <= k < n:
+            raise IndexError("list index out of range")
+        return self._at(k)
+
+    def __iter__(self):
+        for i in range(list.__len__(self)):
+            yield self._at(i)
+
+    def __reversed__(self):
+        for i in range(list.__len__(self) - 1, -1, -1):
+            yield self._at(i)
+
+    def copy(self):  # another lazy list over the same arrays, sharing what is built (a shallow copy, as list.copy is)
+        return _LazyTrackList(self._t, self._segs, _raw=list(list.__iter__(self)))
+
+    __copy__ = copy
+
+    def __reduce__(self):
+        return (list, (list(self),))
+
+    def _plain(name):  # the rest of list's interface: build everything, then list's own method
+        def f(self, *a, **k):
+            return getattr(list, name)(self._all(), *a, **k)
+        f.__name__ = name
+        return f
+
+    for _n in ("__contains__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__", "__add__", "__mul__", "__rmul__", "__iadd__",
+               "__imul__", "__repr__", "__delitem__", "__setitem__", "index", "count", "sort", "reverse", "pop", "remove", "insert"):
+        locals()[_n] = _plain(_n)
+    del _n, _plain
+    __hash__ = None
+
+
 def _track_from_state(state):
     out = LineTrack()
     out.__dict__.update(state)
@@ -424,7 +488,7 @@ class GlobalLineTriangulator:
         return self.GetTracks()
 
     def GetTracks(self):
-        return list(self._tracks)
+        return self._tracks.copy() if isinstance(self._tracks, _LazyTrackList) else list(self._tracks)
 
     def CountImages(self):
         return self._ctx.count_images()
@@ -554,13 +618,12 @@ class GlobalLineTriangulator:
         # The reference hands back pybind wrappers of C++ LineTracks (no per-member Python objects until they are
         # looked at); building ~35 000 Line2d / Line3d objects eagerly here cost 20x the whole triangulation.
         segs = self._seg_store  # (not the triangulator: see _SegStore)
-        tracks = [_LazyLineTrack(t, n, segs) for n in range(len(t["off"]) - 1)]
         if _limap_base is not None:  # limap's LineTrack when limap is installed (linetrack.cc:50-74 dict ctor)
             try:
-                return [_limap_base.LineTrack(tr.as_dict()) for tr in tracks]
+                return [_limap_base.LineTrack(_LazyLineTrack(t, n, segs).as_dict()) for n in range(len(t["off"]) - 1)]
             except Exception:
                 pass
-        return tracks
+        return _LazyTrackList(t, segs)
 
 
 # ---- free functions (bindings.cc:22-31; doc wrappers triangulation.py:1-138 of the reference) ----
